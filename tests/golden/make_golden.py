@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the upstream reference (build container only).
+
+Run from the repo root:  ``python tests/golden/make_golden.py``
+
+The reference lives at /root/reference and never travels: this script imports
+its classes in-process (the unused ``torch_geometric`` imports are stubbed in
+``sys.modules``), feeds them seeded inputs, and stores *data only* — inputs,
+every ``state_dict`` tensor, fp32 outputs, fp64 outputs
+(``torch.set_default_dtype(float64)``) and the
+gradients of ``out.pow(2).sum()`` — as compressed ``.npz`` files next to this
+script.  ``tests/test_oracle_golden.py`` replays them against ``oracle/``.
+
+Weights are re-drawn at O(1) scale before capture: the reference's own
+``xavier_normal_(gain=0.01)`` init (GNAN.py:49-53) yields outputs ~1e-14 for
+which a relative comparison is meaningless.
+"""
+import ast
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------ import the reference
+def _stub_pyg():
+    import scipy.sparse
+
+    def to_scipy_sparse_matrix(edge_index, edge_attr=None, num_nodes=None):
+        ei = edge_index.cpu().numpy()
+        n = int(ei.max()) + 1 if num_nodes is None else num_nodes
+        return scipy.sparse.coo_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(n, n))
+
+    pyg = types.ModuleType("torch_geometric")
+    nn_ = types.ModuleType("torch_geometric.nn")
+    utils = types.ModuleType("torch_geometric.utils")
+    for name in ["GraphConv", "GINConv", "GATv2Conv", "GraphSAGE", "TransformerConv", "global_mean_pool"]:
+        setattr(nn_, name, object)
+    utils.to_scipy_sparse_matrix = to_scipy_sparse_matrix
+    pyg.nn, pyg.utils = nn_, utils
+    sys.modules.update({"torch_geometric": pyg, "torch_geometric.nn": nn_, "torch_geometric.utils": utils})
+
+
+_stub_pyg()
+sys.path.insert(0, REF)
+import GNAN as ref_gnan            # noqa: E402
+import models as ref_models        # noqa: E402
+import pre_process_datasets as ref_pre  # noqa: E402
+
+
+def _batched_class():
+    """batched_pyg_main.py trains at import; pull out only its model class (lines 98-184)."""
+    src = open(os.path.join(REF, "batched_pyg_main.py")).read()
+    tree = ast.parse(src)
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TensorGNAN"][0]
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "batched_pyg_main.py", "exec"), ns)
+    return ns["TensorGNAN"]
+
+
+RefBatched = _batched_class()
+
+
+class Bag:
+    """Duck-typed stand-in for a PyG ``Data`` object (fields read at GNAN.py:56,66,147,161)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+# ------------------------------------------------------------------ inputs
+def random_graph(rng, n, directed, n_isolated, avg_deg=2.2):
+    """Sparse random graph with >=2 components and isolated nodes so that nd==0 occurs."""
+    live = n - n_isolated
+    half = max(2, live // 2)
+    edges = []
+    for lo, hi in [(0, half), (half, live)]:          # two components, never bridged
+        size = hi - lo
+        if size < 2:
+            continue
+        m = max(1, int(avg_deg * size / (1 if directed else 2)))
+        src = rng.integers(lo, hi, m)
+        dst = rng.integers(lo, hi, m)
+        keep = src != dst
+        edges.append(np.stack([src[keep], dst[keep]]))
+    ei = np.concatenate(edges, axis=1)
+    ei = np.unique(ei, axis=1)                        # no duplicate edges (they would become weight-2)
+    if not directed:
+        ei = np.unique(np.concatenate([ei, ei[::-1]], axis=1), axis=1)
+    return ei.astype(np.int64)
+
+
+def run_pre_process(ei, n, f_raw, rng, graph_task):
+    x = torch.from_numpy(rng.random((n, f_raw), dtype=np.float32))
+    data = Bag(x=x, edge_index=torch.from_numpy(ei))
+    tmp = tempfile.mkdtemp()
+    if graph_task:
+        ref_pre.pre_process([data], True, "golden", processed_data_dir=tmp)
+    else:
+        ref_pre.pre_process(data, False, "golden", processed_data_dir=tmp)
+    return data
+
+
+def redraw(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 2:
+                fan_in, fan_out = p.shape[1], p.shape[0]
+                p.copy_(torch.randn(p.shape, generator=g) * (2.0 / (fan_in + fan_out)) ** 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+
+
+def capture(build, call, data32, seed):
+    """Run the reference in fp32 and fp64 with identical weights; return arrays to store."""
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(seed)
+    m32 = build().eval()
+    redraw(m32, seed)
+    out32 = call(m32, data32)
+    m32.zero_grad()
+    out32.pow(2).sum().backward()
+    sd = {k: v.detach().clone() for k, v in m32.state_dict().items()}
+    g32 = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+           for k, p in m32.named_parameters()}
+
+    torch.set_default_dtype(torch.float64)
+    try:
+        m64 = build().eval()
+        m64.load_state_dict({k: v.double() for k, v in sd.items()})
+        data64 = Bag(**{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
+                        for k, v in data32.__dict__.items()})
+        out64 = call(m64, data64)
+        m64.zero_grad()
+        out64.pow(2).sum().backward()
+        g64 = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+               for k, p in m64.named_parameters()}
+    finally:
+        torch.set_default_dtype(torch.float32)
+    arrays = {"out32": out32.detach().numpy(), "out64": out64.detach().numpy()}
+    for k, v in sd.items():
+        arrays["sd/" + k] = v.numpy()
+    for k, v in g32.items():
+        arrays["g32/" + k] = v.numpy()
+    for k, v in g64.items():
+        arrays["g64/" + k] = v.numpy()
+    return arrays
+
+
+def save(name, meta, data, arrays):
+    for k in ["x", "edge_index", "node_distances", "normalization_matrix"]:
+        if hasattr(data, k):
+            arrays["in/" + k] = getattr(data, k).numpy()
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    return os.path.getsize(path)
+
+
+# ------------------------------------------------------------------ case matrix
+def model_cases():
+    cases = []
+    cid = 0
+
+    def add(variant, **kw):
+        nonlocal cid
+        base = dict(variant=variant, seed=cid % 3, n=40, f_raw=3, H=8, C=3, L=3, bias=True,
+                    normalize_rho=True, directed=False, n_isolated=2)
+        base.update(kw)
+        base["id"] = cid
+        cases.append(base)
+        cid += 1
+
+    # A.1 / A.2  stand-alone TensorGNAN (GNAN.py:9-79)
+    for L in (1, 2, 3):
+        add("standalone_tensor_node", L=L, n=40, C=3)
+    add("standalone_tensor_node", normalize_rho=False, C=5, H=32, f_raw=8)
+    add("standalone_tensor_node", bias=False, C=1, n=7, n_isolated=1)
+    add("standalone_tensor_node", directed=True, n=300, C=3, H=32, f_raw=8, n_isolated=5)
+    add("standalone_tensor_graph", C=1, n=40)
+    add("standalone_tensor_graph", C=3, n=7, n_isolated=1, L=2)
+    add("standalone_tensor_graph", C=1, n=40, normalize_rho=False, directed=True)
+    # A.3  models.TensorGNAN (models.py:303-384)
+    add("models_tensor_node", rho_per_feature=False, C=3)
+    add("models_tensor_node", rho_per_feature=True, C=3)
+    add("models_tensor_node", rho_per_feature=True, C=5, n=300, H=32, f_raw=8, n_isolated=5)
+    add("models_tensor_node", rho_per_feature=False, C=1, normalize_rho=False, L=2)
+    add("models_tensor_node", rho_per_feature=False, C=3, L=1, directed=True)
+    add("models_tensor_graph", rho_per_feature=False, C=1, readout_n_layers=0)
+    add("models_tensor_graph", rho_per_feature=True, C=3, readout_n_layers=0, n=7, n_isolated=1)
+    add("models_tensor_graph", rho_per_feature=False, C=1, readout_n_layers=2)
+    add("models_tensor_graph", rho_per_feature=True, C=3, readout_n_layers=2, directed=True)
+    add("models_tensor_graph", rho_per_feature=False, C=1, readout_n_layers=1, normalize_rho=False)
+    add("models_tensor_graph", rho_per_feature=False, C=1, readout_n_layers=0, bias=False, n=300,
+        H=32, f_raw=8, n_isolated=5)
+    # A.5  GNAN per-node loop (GNAN.py:82-172, models.py:387-477)
+    add("standalone_gnan", rho_per_feature=False, C=3)
+    add("standalone_gnan", rho_per_feature=True, C=3, node_ids=[1, 5, 7])
+    add("standalone_gnan", rho_per_feature=False, C=1, normalize_rho=False, L=2)
+    add("models_gnan", rho_per_feature=False, C=3, node_ids=[1, 5, 7])
+    add("models_gnan", rho_per_feature=True, C=5, H=32, f_raw=8)
+    add("models_gnan", rho_per_feature=False, C=3, L=1, n=7, n_isolated=1)
+    add("models_gnan", rho_per_feature=False, C=1, n=300, H=32, f_raw=8, n_isolated=5, directed=True)
+    # NAM (models.py:259-300)
+    add("models_nam", C=3, L=3)
+    add("models_nam", C=1, L=2, bias=False)
+    return cases
+
+
+def build_and_call(c, F):
+    v = c["variant"]
+    kw = dict(in_channels=F, out_channels=c["C"], hidden_channels=c["H"], bias=c["bias"], dropout=0.0,
+              device="cpu")
+    if v.startswith("standalone_tensor"):
+        graph = v.endswith("graph")
+        return (lambda: ref_gnan.TensorGNAN(n_layers=c["L"], normalize_rho=c["normalize_rho"],
+                                            is_graph_task=graph, **kw),
+                lambda m, d: m.forward(d))
+    if v.startswith("models_tensor"):
+        graph = v.endswith("graph")
+        return (lambda: ref_models.TensorGNAN(n_layers=c["L"], normalize_rho=c["normalize_rho"],
+                                              is_graph_task=graph, rho_per_feature=c["rho_per_feature"],
+                                              readout_n_layers=c.get("readout_n_layers", 0), **kw),
+                lambda m, d: m.forward(d))
+    if v == "standalone_gnan":
+        return (lambda: ref_gnan.GNAN(n_layers=c["L"], normalize_rho=c["normalize_rho"],
+                                      rho_per_feature=c["rho_per_feature"], **kw),
+                lambda m, d: m.forward(d, c.get("node_ids")))
+    if v == "models_gnan":
+        return (lambda: ref_models.GNAN(num_layers=c["L"], normalize_rho=c["normalize_rho"],
+                                        rho_per_feature=c["rho_per_feature"], **kw),
+                lambda m, d: m.forward(d, c.get("node_ids")))
+    if v == "models_nam":
+        return (lambda: ref_models.NAM(num_layers=c["L"], **kw), lambda m, d: m.forward(d.x))
+    raise ValueError(v)
+
+
+def main():
+    total = 0
+    manifest = []
+    for c in model_cases():
+        rng = np.random.default_rng(1000 + c["id"])
+        graph_task = c["variant"].endswith("graph")
+        ei = random_graph(rng, c["n"], c["directed"], c["n_isolated"])
+        if not graph_task:
+            # node-task preprocessing infers N from the largest edge endpoint (pre_process_datasets.py:128):
+            # keep the isolated nodes in the middle of the id range, not at the end.
+            n = c["n"]
+            perm = np.arange(n)
+            top = int(ei.max())
+            perm[[top, n - 1]] = perm[[n - 1, top]]
+            ei = perm[ei]
+        data = run_pre_process(ei, c["n"], c["f_raw"], rng, graph_task)
+        F = data.x.shape[1]
+        build, call = build_and_call(c, F)
+        arrays = capture(build, call, data, c["seed"])
+        name = f"case_{c['id']:03d}_{c['variant']}"
+        size = save(name, c, data, arrays)
+        total += size
+        manifest.append(name)
+        print(f"{name}: out {arrays['out32'].shape} {size / 1024:.1f} KiB")
+
+    # f-2: batched block-diagonal variant (batched_pyg_main.py:98-184)
+    for bid, (C, graph) in enumerate([(2, True), (3, False)]):
+        rng = np.random.default_rng(5000 + bid)
+        sizes = [5, 9, 4, 12]
+        xs, blocks = [], []
+        for s in sizes:
+            ei = random_graph(rng, s, False, 1 if s > 4 else 0)
+            d = run_pre_process(ei, s, 3, rng, True)
+            hop = torch.round(1.0 / d.node_distances.clamp_min(1e-9)) - 1.0
+            hop[d.node_distances == 0] = -1.0        # unreachable marked like cross-graph pairs
+            xs.append(d.x)
+            blocks.append(hop)
+        n = sum(sizes)
+        dist = torch.full((n, n), -1.0)
+        o = 0
+        for s, b in zip(sizes, blocks):
+            dist[o:o + s, o:o + s] = b
+            o += s
+        batch = torch.cat([torch.full((s,), i, dtype=torch.long) for i, s in enumerate(sizes)])
+        data = Bag(x=torch.cat(xs), dist=dist, batch=batch)
+        F = data.x.shape[1]
+        c = dict(variant="batched_tensor", id=100 + bid, seed=bid, C=C, H=8, F=F, graph=graph)
+        arrays = capture(lambda: RefBatched(F, C, 2, hidden_channels=8, is_graph_task=graph),
+                         lambda m, d: m.forward(d.x, d.dist, d.batch), data, bid)
+        arrays["in/x"], arrays["in/dist"], arrays["in/batch"] = data.x.numpy(), dist.numpy(), batch.numpy()
+        name = f"case_{100 + bid:03d}_batched_tensor"
+        total += save(name, c, Bag(), arrays)
+        manifest.append(name)
+        print(name)
+
+    # f-1: preprocessing in -> out pairs (pre_process_datasets.py:104-142)
+    for pid, (n, directed, iso) in enumerate([(7, False, 1), (12, True, 2), (60, False, 4), (25, True, 0)]):
+        rng = np.random.default_rng(7000 + pid)
+        ei = random_graph(rng, n, directed, iso)
+        d = run_pre_process(ei, n, 2, rng, True)
+        c = dict(variant="pre_process", id=200 + pid, n=n, directed=directed)
+        name = f"case_{200 + pid:03d}_pre_process"
+        total += save(name, c, d, {})
+        manifest.append(name)
+        print(name)
+
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print(f"{len(manifest)} cases, {total / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
