@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the GNAN aggregation hot path on MI355X — prints ONE JSON line (rank 0).
+
+Metric (BASELINE.json): edges aggregated / second for the TensorGNAN forward, next to the achieved HBM
+bandwidth of the rho-weighted CSR SpMM.  Workload: Graph500 R-MAT scale 24 trimmed
+to 10M nodes / 100M edges (+ one self pair per node), K = 1 hop codes, 64 feature columns, H = 64, L = 3,
+one output channel, evaluated in the reference's order (aggregate all 64 per-feature columns, then sum
+over features: models.py:373-376), fp32, synthetic data, random O(1) weights.
+
+A "step" is one full forward over the whole graph:  shape functions -> (all-gather) -> aggregation ->
+feature sum.  With N > 1 ranks the node range is vertex-partitioned (strong scaling: the graph is fixed).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--edges", type=int, default=100_000_000)
+    ap.add_argument("--scale", type=int, default=24)
+    ap.add_argument("--feat", type=int, default=64)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--out", type=int, default=1)
+    ap.add_argument("--order", default="reference", choices=["reference", "sum_first"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nodes", type=int, default=500_000, help="nodes of the CPU shape-function sample")
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
+    return ap.parse_args()
+
+
+def spmm_algorithmic_bytes(g, W):
+    """nnz*(4 col + 1 code + W*4 gathered row) + rows*(rowptr + W*4 output + 12 count table)."""
+    rp = 8 if g.rowptr.dtype == torch.int64 else 4
+    return g.nnz * (4 + 1 + W * 4) + g.n_rows * (rp + W * 4 + 4 * g.n_codes)
+
+
+def fmlp_flops(n, F, H, L, C):
+    return 2.0 * n * F * (H + max(L - 2, 0) * H * H + H * C) if L >= 2 else 2.0 * n * F * C
+
+
+def cpu_baseline(args, model, g, x, operand_full):
+    """Time the oracle (PyTorch-CPU restatement of the reference path) on a bounded sample, all host cores."""
+    from oracle import gnan_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    n_f = min(args.cpu_nodes, x.shape[0])
+    xs = x[:n_f].cpu()
+    t0 = time.perf_counter()
+    fx = O.feature_mlps(xs, sd)                                   # Python loop over features, GNAN.py:58-62
+    t_f = time.perf_counter() - t0
+    del fx
+    n_r = min(args.cpu_rows, g.n_rows)
+    rowptr = g.rowptr[: n_r + 1].cpu().long().numpy()
+    nnz_s = int(rowptr[-1])
+    col = g.col[:nnz_s].cpu().numpy()
+    code = g.code[:nnz_s].cpu().numpy()
+    cnt = g.cnt[:n_r].cpu().long().numpy()
+    S = operand_full.cpu()
+    lut = O.rho_lut(sd, g.n_codes)
+    t0 = time.perf_counter()
+    y = O.spmm_csr_sparse(rowptr, col, code, S, lut, cnt)
+    y = y.sum(dim=1)
+    t_s = time.perf_counter() - t0
+    n_tot, nnz_tot = args.nodes, args.edges + args.nodes
+    est = t_f * n_tot / n_f + t_s * nnz_tot / nnz_s
+    return {
+        "value": args.edges / est, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle/gnan_oracle.py on host: shape functions on the first {n_f} nodes ({t_f:.2f} s) + "
+                   f"torch.sparse_csr aggregation of the first {n_r} rows / {nnz_s} pairs against the full "
+                   f"{S.shape[0]}x{S.shape[1]} operand ({t_s:.2f} s); scaled to the full graph"),
+        "fmlp_nodes_per_s": n_f / t_f, "spmm_pairs_per_s": nnz_s / t_s,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gnan_amd  # noqa: F401
+    from gnan_amd import synthetic as syn
+    from gnan_amd.distributed import VertexPartition, partitioned_forward
+    from gnan_amd.functional import stack_mlps
+    from gnan_amd.graph import hop_inputs
+    from gnan_amd.models import TensorGNAN
+
+    N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
+    part = VertexPartition(N, world, rank)
+    t_setup = time.perf_counter()
+    src, dst = syn.rmat_edges(args.scale, N, E, seed=0, device=dev)
+    g = syn.hop1_csr(src, dst, N, part.lo, part.hi)
+    del src, dst
+    g.long_row_plan()
+    x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
+    torch.manual_seed(0)
+    model = TensorGNAN(F, C, L, hidden_channels=H, normalize_rho=True, rho_per_feature=False, device="cuda")
+    with torch.no_grad():                                    # O(1)-scale weights (the upstream init gives ~1e-14 outputs)
+        for p in model.parameters():
+            if p.dim() == 2:
+                torch.nn.init.xavier_normal_(p, gain=1.0)
+            else:
+                p.normal_(0.0, 0.5)
+    model = model.to(dev).eval()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    with torch.no_grad():
+        stacked = stack_mlps(model.fs)
+        lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
+    stage_names = ["fmlp", "gather", "spmm", "readout"]
+    events = []
+
+    def step(record):
+        marks = {}
+        if record:
+            def mark(name):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks[name] = ev
+        else:
+            mark = None
+        with torch.no_grad():
+            out = partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C, marks=mark)
+        if record:
+            events.append(marks)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    stages = {n: 0.0 for n in stage_names}
+    for m in events:
+        prev = m["start"]
+        for n in stage_names:
+            stages[n] += prev.elapsed_time(m[n])
+            prev = m[n]
+    stages = {n: v / max(1, len(events)) for n, v in stages.items()}
+
+    W = F * C if args.order == "reference" else C
+    b_alg = spmm_algorithmic_bytes(g, W)
+    spmm_s = stages["spmm"] / 1e3
+    achieved = b_alg / spmm_s / 1e9 if spmm_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    workload = f"rmat_s{args.scale}_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_{args.order}_K1"
+    if os.path.exists(tpath):
+        rec = json.load(open(tpath))
+        if rec.get("workload") == workload and rec.get("n_gpus") == world:
+            traffic = rec.get("bytes_per_launch")
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "edges aggregated/sec, TensorGNAN forward", "value": E / (elapsed / args.steps),
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "nodes": N, "edges": E, "stored_pairs_rank0": g.nnz,
+                       "operand_width": W, "partition": f"vertex-block x{world}", "exchange":
+                       "all_gather(operand)" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},
+            "stages_ms": stages,
+            "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
+            "fmlp_tflops": fmlp_flops(part.hi - part.lo, F, H, L, C) / (stages["fmlp"] / 1e3) / 1e12
+            if stages["fmlp"] > 0 else None,
+            "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            "setup_s": t_setup, "checksum": float(out.double().sum()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            with torch.no_grad():
+                from gnan_amd.functional import feature_mlps
+                operand = feature_mlps(x, stacked, args.order == "sum_first")
+            result["cpu_baseline"] = cpu_baseline(args, model, g, x, operand)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

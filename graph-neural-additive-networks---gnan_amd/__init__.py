@@ -1,0 +1,14 @@
+"""gnan_amd — MI355X-native implementation of GNAN's distance-weighted additive aggregation path.
+
+Drop-in for the reference's ``TensorGNAN`` / ``GNAN`` / ``NAM`` modules
+(``from gnan_amd.models import *`` instead of ``from models import *``;
+``from gnan_amd.GNAN import TensorGNAN, GNAN`` instead of ``from GNAN import …``).
+The arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI in
+``include/gnan_hip.h``; see DESIGN.md and INTEGRATION.md.
+"""
+from . import GNAN, models  # noqa: F401  (mirror modules)
+from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps  # noqa: F401
+from .graph import HopGraph, hop_inputs, shell_counts_csr  # noqa: F401
+
+__all__ = ["GNAN", "models", "HopGraph", "StackedMLP", "feature_mlps", "rho_aggregate", "stack_mlps",
+           "hop_inputs", "shell_counts_csr"]

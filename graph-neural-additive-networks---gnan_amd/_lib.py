@@ -1,0 +1,105 @@
+"""ctypes binding of ``libgnan_hip.so`` (the C ABI declared in ``include/gnan_hip.h``).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or a call fails, the error is raised to the caller.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
+ABI_VERSION = 1
+
+GNAN_F32, GNAN_BF16 = 0, 1
+MAX_CODES = 256
+
+
+class GnanHipError(RuntimeError):
+    pass
+
+
+class FmlpArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("n", C.c_int64), ("x_stride", C.c_int64),
+        ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32),
+        ("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
+        ("w_last", C.c_void_p), ("b_last", C.c_void_p),
+        ("sum_features", C.c_int32),
+        ("out", C.c_void_p), ("out_stride", C.c_int64),
+    ]
+
+
+class SpmmArgs(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64), ("n_cols", C.c_int64),
+        ("rowptr", C.c_void_p), ("rowptr_is64", C.c_int32),
+        ("col", C.c_void_p), ("code", C.c_void_p), ("row_ids", C.c_void_p),
+        ("S", C.c_void_p), ("s_dtype", C.c_int32), ("W", C.c_int32), ("s_stride", C.c_int64),
+        ("lut", C.c_void_p), ("lut_row_stride", C.c_int64), ("D", C.c_int32), ("Cw", C.c_int32),
+        ("cnt", C.c_void_p), ("cnt_stride", C.c_int64),
+        ("s_total", C.c_void_p), ("weight_by_col", C.c_int32), ("minus_rest", C.c_int32),
+        ("Y", C.c_void_p), ("y_stride", C.c_int64),
+        ("long_threshold", C.c_int64), ("long_rows", C.c_void_p), ("long_slice_ptr", C.c_void_p),
+        ("n_long", C.c_int32), ("n_slices", C.c_int32), ("slice_edges", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/gnan_hip.h declares: (name, restype, argtypes)
+SYMBOLS = {
+    "gnan_abi_version": (C.c_int, []),
+    "gnan_last_error": (C.c_char_p, []),
+    "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
+    "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
+    "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
+    "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
+    "gnan_dense_to_code": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises ``GnanHipError`` if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GnanHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.gnan_abi_version() != ABI_VERSION:
+            raise GnanHipError(f"ABI mismatch: library {handle.gnan_abi_version()} vs binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gnan_last_error()
+        raise GnanHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_device(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GnanHipError(
+                "gnan_amd runs on the MI355X only: got a CPU tensor. Move the module and its inputs to the GPU "
+                "(`model.to('cuda')`, `data.to('cuda')`); there is deliberately no CPU fallback.")

@@ -1,0 +1,599 @@
+// rho(distance)-weighted neighbourhood sum over a hop-coded adjacency (gfx950).
+//
+// Replaces GNAN.py:65-73 / models.py:368-376 (rho on N^2 pairs, normalisation, bmm, feature sum)
+// and the per-node loop GNAN.py:159-170.  See include/gnan_hip.h for the contract.
+//
+// Mapping (wave64):  an operand row of W floats is covered by LPR lanes x VEC floats
+// (16 lanes x float4 for W = 64: one 256-B row = one fully used 16-B/lane request).  A wave
+// therefore holds G = 64/LPR independent lane groups:
+//   * row blocks  : one group per output row, edges walked sequentially, index pairs fetched
+//                   LPR at a time with one coalesced load and broadcast inside the group by
+//                   ds_bpermute; no cross-lane reduction, the group stores its own row;
+//   * slice blocks: hub rows (degree > long_threshold) are cut into slices; a 256-thread
+//                   workgroup owns a slice, every wave streams 64 index pairs per load, its G
+//                   groups stride over them, partial rows meet in LDS, and a fix-up kernel adds
+//                   the slices in a fixed order (bit-reproducible, no float atomics).
+// HBM-bound: per edge 4 B col + 1 B code + W*4 B gathered row; per row rowptr + W*4 B store.
+#include "common.hpp"
+
+namespace {
+
+using gnan::kWave;
+
+struct Params {
+  int64_t n_rows, n_cols;
+  const void* rowptr;
+  int rowptr_is64;
+  const int32_t* col;
+  const uint8_t* code;
+  const int32_t* row_ids;
+  const float* S;
+  int W;
+  int64_t s_stride;
+  const float* lut;
+  int64_t lut_row_stride;
+  int D, Cw;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const float* s_total;
+  int weight_by_col, minus_rest;
+  float* Y;
+  int64_t y_stride;
+  int64_t long_threshold;
+  const int32_t* long_rows;
+  const int32_t* long_slice_ptr;
+  int n_long, n_slices, slice_edges;
+  float* partial;  // [n_slices, 2, W]
+};
+
+__device__ __forceinline__ int64_t load_rowptr(const Params& p, int64_t i) {
+  return p.rowptr_is64 ? static_cast<const int64_t*>(p.rowptr)[i]
+                       : static_cast<int64_t>(static_cast<const int32_t*>(p.rowptr)[i]);
+}
+
+template <int VEC>
+struct Vec {
+  float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> load_vec(const float* ptr) {
+  Vec<VEC> r;
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(ptr);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(ptr);
+    r.v[0] = t.x; r.v[1] = t.y;
+  } else {
+    r.v[0] = *ptr;
+  }
+  return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* ptr, const Vec<VEC>& r) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(ptr) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(ptr) = make_float2(r.v[0], r.v[1]);
+  } else {
+    *ptr = r.v[0];
+  }
+}
+
+// Weights of adjacency row i for hop code d, for the VEC columns starting at column w0.
+//   wt = lut[i*lrs + d*Cw + (w % Cw)] / max(cnt[i, d], 1)          (IEEE division, as torch.div)
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> row_weights(const Params& p, int64_t i, int d, int w0) {
+  Vec<VEC> w;
+  const float* l = p.lut + i * p.lut_row_stride + static_cast<int64_t>(d) * p.Cw;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) w.v[v] = l[p.Cw == 1 ? 0 : (w0 + v) % p.Cw];
+  if (p.cnt) {
+    const int c = p.cnt[i * p.cnt_stride + d];
+    const float r = static_cast<float>(c > 1 ? c : 1);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) w.v[v] = w.v[v] / r;
+  }
+  return w;
+}
+
+// Weight of one listed pair.  Forward: the table row is the output row i.  Transposed use
+// (backward w.r.t. S): the table row is the neighbour c (weight_by_col) and the rest-bucket weight
+// is subtracted (minus_rest), because d/dS_j of  wt_rest * (total - sum_listed S)  is  -wt_rest.
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> edge_weights(const Params& p, int64_t i, int c, int d, int w0) {
+  const int64_t r = p.weight_by_col ? static_cast<int64_t>(c) : i;
+  Vec<VEC> w = row_weights<VEC>(p, r, d, w0);
+  if (p.minus_rest) {
+    const Vec<VEC> wr = row_weights<VEC>(p, r, p.D - 1, w0);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) w.v[v] -= wr.v[v];
+  }
+  return w;
+}
+
+// Per-row weight cache for the common truncated case (Cw == 1, D <= 4): four registers.
+struct SmallW {
+  float w[4];
+  __device__ __forceinline__ float pick(int d) const {
+    float r = w[0];
+    r = d == 1 ? w[1] : r;
+    r = d == 2 ? w[2] : r;
+    r = d >= 3 ? w[3] : r;
+    return r;
+  }
+};
+
+__device__ __forceinline__ SmallW small_weights(const Params& p, int64_t i) {
+  SmallW s;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float v = 0.f;
+    if (d < p.D) {
+      v = p.lut[i * p.lut_row_stride + d];
+      if (p.cnt) {
+        const int c = p.cnt[i * p.cnt_stride + d];
+        v = v / static_cast<float>(c > 1 ? c : 1);
+      }
+    }
+    s.w[d] = v;
+  }
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows kernel: one LPR-lane group per output row
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPR, bool DENSE, bool SMALLD>
+__device__ __forceinline__ void rows_body(const Params& p, const int64_t block_id) {
+  constexpr int G = kWave / LPR;     // groups (rows) per wave
+  constexpr int TILE = LPR * VEC;    // operand columns one pass covers
+  constexpr int UNROLL = 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int sub = lane % LPR;
+  const int slot = lane / LPR;
+  const int64_t q = (block_id * (blockDim.x / kWave) + wave) * G + slot;
+  if (q >= p.n_rows) return;
+  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  int64_t lo, hi, code_base;
+  if constexpr (DENSE) {
+    lo = 0;
+    hi = p.n_cols;
+    code_base = i * p.n_cols;
+  } else {
+    lo = load_rowptr(p, i);
+    hi = load_rowptr(p, i + 1);
+    code_base = 0;
+    if (hi - lo > p.long_threshold) return;  // hub row: long kernel
+  }
+  const int rest = p.D - 1;
+  SmallW sw;
+  if constexpr (SMALLD) sw = small_weights(p, i);
+
+  for (int w0 = 0; w0 < p.W; w0 += TILE) {
+    const int cw = w0 + sub * VEC;
+    const bool col_ok = cw < p.W;
+    Vec<VEC> acc, all;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc.v[v] = all.v[v] = 0.f;
+
+    for (int64_t base = lo; base < hi; base += LPR) {
+      const int64_t e = base + sub;
+      int colv = 0, codev = 0;
+      if (e < hi) {
+        if constexpr (!DENSE) colv = p.col[e];
+        codev = p.code[code_base + e];
+      }
+      const int m = static_cast<int>(hi - base < LPR ? hi - base : LPR);
+      for (int j0 = 0; j0 < m; j0 += UNROLL) {
+        Vec<VEC> s[UNROLL];
+        int d[UNROLL], c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          const int j = j0 + u;
+          if constexpr (DENSE) {
+            c[u] = static_cast<int>(base) + j;
+          } else {
+            c[u] = __shfl(colv, j, LPR);
+          }
+          d[u] = __shfl(codev, j, LPR);
+          d[u] = d[u] < rest ? d[u] : rest;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) s[u].v[v] = 0.f;
+          if (j < m && col_ok) s[u] = load_vec<VEC>(p.S + static_cast<int64_t>(c[u]) * p.s_stride + cw);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          if (j0 + u < m) {
+            if constexpr (SMALLD) {
+              const float w = sw.pick(d[u]);
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w, s[u].v[v], acc.v[v]);
+            } else {
+              const Vec<VEC> w = edge_weights<VEC>(p, i, c[u], d[u], cw);
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w.v[v], s[u].v[v], acc.v[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) all.v[v] += s[u].v[v];
+          }
+        }
+      }
+    }
+    if (col_ok) {
+      if (p.s_total) {
+        Vec<VEC> wr;
+        if constexpr (SMALLD) {
+          const float w = sw.pick(rest);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) wr.v[v] = w;
+        } else {
+          wr = row_weights<VEC>(p, i, rest, cw);
+        }
+        const Vec<VEC> tot = load_vec<VEC>(p.s_total + cw);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(wr.v[v], tot.v[v] - all.v[v], acc.v[v]);
+      }
+      store_vec<VEC>(p.Y + q * p.y_stride + cw, acc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// long kernel: one 256-thread workgroup per slice of a hub row
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPR, bool SMALLD>
+__device__ __forceinline__ void slice_body(const Params& p, const int s) {
+  constexpr int G = kWave / LPR;
+  constexpr int TILE = LPR * VEC;
+  constexpr int NW = 4;  // waves per workgroup
+  __shared__ float red[NW][2][TILE];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int sub = lane % LPR;
+  const int slot = lane / LPR;
+  // which hub row owns slice s: last r with long_slice_ptr[r] <= s
+  int a = 0, b = p.n_long;
+  while (b - a > 1) {
+    const int mid = (a + b) >> 1;
+    if (p.long_slice_ptr[mid] <= s) a = mid; else b = mid;
+  }
+  const int64_t q = p.long_rows[a];
+  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int64_t row_lo = load_rowptr(p, i), row_hi = load_rowptr(p, i + 1);
+  const int64_t lo = row_lo + static_cast<int64_t>(s - p.long_slice_ptr[a]) * p.slice_edges;
+  const int64_t hi = lo + p.slice_edges < row_hi ? lo + p.slice_edges : row_hi;
+  const int rest = p.D - 1;
+  SmallW sw;
+  if constexpr (SMALLD) sw = small_weights(p, i);
+
+  for (int w0 = 0; w0 < p.W; w0 += TILE) {
+    const int cw = w0 + sub * VEC;
+    const bool col_ok = cw < p.W;
+    Vec<VEC> acc, all;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc.v[v] = all.v[v] = 0.f;
+    // wave `wave` takes 64-edge chunks wave, wave+NW, ...
+    for (int64_t base = lo + static_cast<int64_t>(wave) * kWave; base < hi; base += NW * kWave) {
+      const int64_t e = base + lane;
+      int colv = 0, codev = 0;
+      if (e < hi) {
+        colv = p.col[e];
+        codev = p.code[e];
+      }
+      const int m = static_cast<int>(hi - base < kWave ? hi - base : kWave);
+#pragma unroll 4
+      for (int t = 0; t < LPR; ++t) {
+        const int j = slot + t * G;
+        const int c = __shfl(colv, j);
+        int d = __shfl(codev, j);
+        d = d < rest ? d : rest;
+        if (j < m && col_ok) {
+          const Vec<VEC> sv = load_vec<VEC>(p.S + static_cast<int64_t>(c) * p.s_stride + cw);
+          if constexpr (SMALLD) {
+            const float w = sw.pick(d);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w, sv.v[v], acc.v[v]);
+          } else {
+            const Vec<VEC> w = edge_weights<VEC>(p, i, c, d, cw);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w.v[v], sv.v[v], acc.v[v]);
+          }
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) all.v[v] += sv.v[v];
+        }
+      }
+    }
+    // groups of one wave -> group 0 (fixed butterfly order), then waves -> LDS -> wave 0
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        acc.v[v] += __shfl_xor(acc.v[v], off);
+        all.v[v] += __shfl_xor(all.v[v], off);
+      }
+    }
+    __syncthreads();
+    if (slot == 0) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        red[wave][0][sub * VEC + v] = acc.v[v];
+        red[wave][1][sub * VEC + v] = all.v[v];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && slot == 0 && col_ok) {
+      float* out = p.partial + static_cast<int64_t>(s) * 2 * p.W;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float x = 0.f, y = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          x += red[w][0][sub * VEC + v];
+          y += red[w][1][sub * VEC + v];
+        }
+        out[cw + v] = x;
+        out[p.W + cw + v] = y;
+      }
+    }
+  }
+}
+
+// One launch covers everything: workgroups [0, n_slices) take the hub-row slices (they start first,
+// so the long-latency slices overlap the bulk), the rest take 4*G ordinary rows each.
+template <int VEC, int LPR, bool DENSE, bool SMALLD>
+__global__ __launch_bounds__(256) void spmm_kernel(const Params p) {
+  if constexpr (!DENSE) {
+    if (static_cast<int>(blockIdx.x) < p.n_slices) {
+      slice_body<VEC, LPR, SMALLD>(p, static_cast<int>(blockIdx.x));
+      return;
+    }
+    rows_body<VEC, LPR, false, SMALLD>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
+  } else {
+    rows_body<VEC, LPR, true, SMALLD>(p, static_cast<int64_t>(blockIdx.x));
+  }
+}
+
+// fix-up: add a hub row's slices in slice order, apply the rest-bucket term, store the row.
+__global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
+  const int r = blockIdx.x;
+  const int64_t q = p.long_rows[r];
+  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
+  for (int w = threadIdx.x; w < p.W; w += blockDim.x) {
+    float acc = 0.f, all = 0.f;
+    for (int s = s0; s < s1; ++s) {
+      acc += p.partial[static_cast<int64_t>(s) * 2 * p.W + w];
+      all += p.partial[static_cast<int64_t>(s) * 2 * p.W + p.W + w];
+    }
+    if (p.s_total) {
+      const Vec<1> wr = row_weights<1>(p, i, p.D - 1, w);
+      acc = fmaf(wr.v[0], p.s_total[w] - all, acc);
+    }
+    p.Y[q * p.y_stride + w] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shell sums:  T[q, d, :] = sum_{e in row, code_e == d} S[col_e, :]   (and the rest bucket)
+// Needed only by the backward pass (gradient w.r.t. the weight table):  dwt[q, d, c] =
+// sum_{w = c mod Cw} dY[q, w] * T[q, d, w].  Same traversal as the rows kernel; a lane owns its
+// columns of T[q, :, :], so plain read-modify-write on global memory is race-free.
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPR, bool DENSE>
+__global__ __launch_bounds__(256) void spmm_shell_sums_kernel(const Params p) {
+  constexpr int G = kWave / LPR;
+  constexpr int TILE = LPR * VEC;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int sub = lane % LPR;
+  const int slot = lane / LPR;
+  const int64_t q = (static_cast<int64_t>(blockIdx.x) * (blockDim.x / kWave) + wave) * G + slot;
+  if (q >= p.n_rows) return;
+  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  int64_t lo, hi, code_base;
+  if constexpr (DENSE) {
+    lo = 0; hi = p.n_cols; code_base = i * p.n_cols;
+  } else {
+    lo = load_rowptr(p, i); hi = load_rowptr(p, i + 1); code_base = 0;
+  }
+  const int rest = p.D - 1;
+  float* T = p.Y + q * static_cast<int64_t>(p.D) * p.W;
+  for (int w0 = 0; w0 < p.W; w0 += TILE) {
+    const int cw = w0 + sub * VEC;
+    const bool col_ok = cw < p.W;
+    Vec<VEC> all;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) all.v[v] = 0.f;
+    for (int64_t base = lo; base < hi; base += LPR) {
+      const int64_t e = base + sub;
+      int colv = 0, codev = 0;
+      if (e < hi) {
+        if constexpr (!DENSE) colv = p.col[e];
+        codev = p.code[code_base + e];
+      }
+      const int m = static_cast<int>(hi - base < LPR ? hi - base : LPR);
+      for (int j = 0; j < m; ++j) {
+        int c;
+        if constexpr (DENSE) c = static_cast<int>(base) + j; else c = __shfl(colv, j, LPR);
+        int d = __shfl(codev, j, LPR);
+        d = d < rest ? d : rest;
+        if (col_ok) {
+          const Vec<VEC> sv = load_vec<VEC>(p.S + static_cast<int64_t>(c) * p.s_stride + cw);
+          float* t = T + static_cast<int64_t>(d) * p.W + cw;
+          Vec<VEC> cur = load_vec<VEC>(t);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { cur.v[v] += sv.v[v]; all.v[v] += sv.v[v]; }
+          store_vec<VEC>(t, cur);
+        }
+      }
+    }
+    if (col_ok && p.s_total) {
+      const Vec<VEC> tot = load_vec<VEC>(p.s_total + cw);
+      Vec<VEC> r;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) r.v[v] = tot.v[v] - all.v[v];
+      store_vec<VEC>(T + static_cast<int64_t>(rest) * p.W + cw, r);
+    }
+  }
+}
+
+template <int VEC, int LPR>
+int launch_shell(const Params& p, bool dense, hipStream_t st) {
+  constexpr int G = kWave / LPR;
+  const int rows_per_block = 4 * G;
+  const int64_t blocks = (p.n_rows + rows_per_block - 1) / rows_per_block;
+  if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "shell_sums: too many rows for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (dense) {
+    hipLaunchKernelGGL((spmm_shell_sums_kernel<VEC, LPR, true>), grid, block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((spmm_shell_sums_kernel<VEC, LPR, false>), grid, block, 0, st, p);
+  }
+  return gnan::check_launch("spmm_shell_sums_kernel");
+}
+
+template <int VEC>
+int launch_shell_lpr(const Params& p, int lpr, bool dense, hipStream_t st) {
+  switch (lpr) {
+    case 1: return launch_shell<VEC, 1>(p, dense, st);
+    case 2: return launch_shell<VEC, 2>(p, dense, st);
+    case 4: return launch_shell<VEC, 4>(p, dense, st);
+    case 8: return launch_shell<VEC, 8>(p, dense, st);
+    case 16: return launch_shell<VEC, 16>(p, dense, st);
+    case 32: return launch_shell<VEC, 32>(p, dense, st);
+    default: return launch_shell<VEC, 64>(p, dense, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPR>
+int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
+  constexpr int G = kWave / LPR;
+  const int rows_per_block = 4 * G;
+  const int n_slices = dense ? 0 : p.n_slices;
+  const int64_t blocks = (p.n_rows + rows_per_block - 1) / rows_per_block + n_slices;
+  if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: too many rows for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (dense) {
+    hipLaunchKernelGGL((spmm_kernel<VEC, LPR, true, false>), grid, block, 0, st, p);
+  } else if (smalld) {
+    hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true>), grid, block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, false>), grid, block, 0, st, p);
+  }
+  if (int rc = gnan::check_launch("spmm_kernel")) return rc;
+  if (n_slices > 0) {
+    hipLaunchKernelGGL(spmm_long_fixup_kernel, dim3(static_cast<unsigned>(p.n_long)), dim3(256), 0, st, p);
+    if (int rc = gnan::check_launch("spmm_long_fixup_kernel")) return rc;
+  }
+  return GNAN_OK;
+}
+
+template <int VEC>
+int launch_lpr(const Params& p, int lpr, bool dense, bool smalld, hipStream_t st) {
+  switch (lpr) {
+    case 1: return launch<VEC, 1>(p, dense, smalld, st);
+    case 2: return launch<VEC, 2>(p, dense, smalld, st);
+    case 4: return launch<VEC, 4>(p, dense, smalld, st);
+    case 8: return launch<VEC, 8>(p, dense, smalld, st);
+    case 16: return launch<VEC, 16>(p, dense, smalld, st);
+    case 32: return launch<VEC, 32>(p, dense, smalld, st);
+    default: return launch<VEC, 64>(p, dense, smalld, st);
+  }
+}
+
+int validate(const gnan_spmm_args* a) {
+  GNAN_REQUIRE(a != nullptr, "spmm: null args");
+  GNAN_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0, "spmm: negative size");
+  GNAN_REQUIRE(a->W >= 1, "spmm: W must be >= 1 (got %d)", a->W);
+  GNAN_REQUIRE(a->D >= 1 && a->D <= GNAN_MAX_CODES, "spmm: D must be in [1, %d] (got %d)", GNAN_MAX_CODES, a->D);
+  GNAN_REQUIRE(a->Cw >= 1, "spmm: Cw must be >= 1");
+  GNAN_REQUIRE(a->n_cols <= 0x7fffffffLL, "spmm: n_cols exceeds int32 column ids");
+  if (a->n_rows == 0) return GNAN_OK;
+  GNAN_REQUIRE(a->S && a->lut && a->Y && a->code, "spmm: null S / lut / Y / code");
+  GNAN_REQUIRE((a->rowptr == nullptr) == (a->col == nullptr), "spmm: rowptr and col must both be set (CSR) or both NULL (dense)");
+  GNAN_REQUIRE(a->s_stride >= a->W && a->y_stride >= a->W, "spmm: row stride smaller than W");
+  if (a->s_dtype != GNAN_F32) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: only fp32 operand rows are implemented");
+  GNAN_REQUIRE(!(a->weight_by_col && a->s_total), "spmm: weight_by_col excludes the rest-bucket term (add it outside)");
+  if (a->n_long > 0) {
+    GNAN_REQUIRE(a->rowptr != nullptr, "spmm: long-row plan needs the CSR layout");
+    GNAN_REQUIRE(a->long_rows && a->long_slice_ptr && a->slice_edges > 0 && a->n_slices > 0,
+                 "spmm: incomplete long-row plan");
+  }
+  return GNAN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a) {
+  if (!a || a->n_long <= 0) return 0;
+  return static_cast<size_t>(a->n_slices) * 2 * static_cast<size_t>(a->W) * sizeof(float);
+}
+
+namespace {
+
+Params make_params(const gnan_spmm_args* a) {
+  Params p;
+  p.n_rows = a->n_rows; p.n_cols = a->n_cols;
+  p.rowptr = a->rowptr; p.rowptr_is64 = a->rowptr_is64;
+  p.col = a->col; p.code = a->code; p.row_ids = a->row_ids;
+  p.S = static_cast<const float*>(a->S); p.W = a->W; p.s_stride = a->s_stride;
+  p.lut = a->lut; p.lut_row_stride = a->lut_row_stride; p.D = a->D; p.Cw = a->Cw;
+  p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total;
+  p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest;
+  p.Y = a->Y; p.y_stride = a->y_stride;
+  p.long_threshold = a->n_long > 0 ? a->long_threshold : INT64_MAX;
+  p.long_rows = a->long_rows; p.long_slice_ptr = a->long_slice_ptr;
+  p.n_long = a->n_long > 0 ? a->n_long : 0;
+  p.n_slices = a->n_long > 0 ? a->n_slices : 0;
+  p.slice_edges = a->slice_edges;
+  p.partial = static_cast<float*>(a->workspace);
+  return p;
+}
+
+// operand rows are read 16 B per lane when shape and alignment allow it, else 4 B per lane
+void pick_tiling(const gnan_spmm_args* a, const float* out, int64_t out_stride, int* vec, int* lpr) {
+  auto aligned = [](const void* ptr, size_t n) { return (reinterpret_cast<uintptr_t>(ptr) % n) == 0; };
+  *vec = 1;
+  if (a->W % 4 == 0 && a->s_stride % 4 == 0 && out_stride % 4 == 0 && aligned(a->S, 16) && aligned(out, 16) &&
+      (!a->s_total || aligned(a->s_total, 16)))
+    *vec = 4;
+  *lpr = 1;
+  while (*lpr * *vec < a->W && *lpr < kWave) *lpr <<= 1;
+}
+
+}  // namespace
+
+extern "C" int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream) {
+  if (int rc = validate(a)) return rc;
+  if (a->n_rows == 0) return GNAN_OK;
+  GNAN_REQUIRE(!a->weight_by_col, "shell_sums: weight_by_col has no meaning here");
+  const Params p = make_params(a);
+  int vec, lpr;
+  pick_tiling(a, a->Y, a->W, &vec, &lpr);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool dense = a->rowptr == nullptr;
+  return vec == 4 ? launch_shell_lpr<4>(p, lpr, dense, st) : launch_shell_lpr<1>(p, lpr, dense, st);
+}
+
+extern "C" int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream) {
+  if (int rc = validate(a)) return rc;
+  if (a->n_rows == 0) return GNAN_OK;
+  const size_t need = gnan_spmm_fwd_workspace_bytes(a);
+  if (need > 0 && (a->workspace == nullptr || a->workspace_bytes < need))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "spmm: workspace %zu B < required %zu B", a->workspace_bytes, need);
+  const Params p = make_params(a);
+
+  const bool dense = a->rowptr == nullptr;
+  const bool smalld = !dense && a->Cw == 1 && a->D <= 4 && !a->weight_by_col && !a->minus_rest;
+  int vec, lpr;
+  pick_tiling(a, a->Y, a->y_stride, &vec, &lpr);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return vec == 4 ? launch_lpr<4>(p, lpr, dense, smalld, st) : launch_lpr<1>(p, lpr, dense, smalld, st);
+}

@@ -1,0 +1,299 @@
+"""Autograd-aware host wrappers around the HIP kernels (``libgnan_hip.so``).
+
+Two operators make up the path:
+
+* :func:`feature_mlps` — all per-feature shape functions in one launch
+  (replaces the Python loop GNAN.py:57-62);
+* :func:`rho_aggregate` — the rho(distance)-weighted neighbourhood sum over a
+  :class:`~.graph.HopGraph` (replaces GNAN.py:65-73 / models.py:368-376 and the
+  per-node loop GNAN.py:159-170).
+
+Everything here needs device tensors; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .graph import HopGraph
+
+
+# =============================================================================
+# stacked per-feature MLP parameters
+# =============================================================================
+class StackedMLP(NamedTuple):
+    """The reference's F separate ``nn.Sequential`` MLPs (GNAN.py:24-34) stacked over the feature axis."""
+    w_first: Optional[torch.Tensor]   # [F, H]
+    b_first: Optional[torch.Tensor]   # [F, H]
+    w_mid: Optional[torch.Tensor]     # [L-2, F, H, H]
+    b_mid: Optional[torch.Tensor]     # [L-2, F, H]
+    w_last: torch.Tensor              # [F, C, H]  ([F, C] when L == 1)
+    b_last: Optional[torch.Tensor]    # [F, C]
+    L: int
+    H: int
+    C: int
+    F: int
+
+
+def stack_mlps(mlps: Sequence[torch.nn.Sequential]) -> StackedMLP:
+    """Stack the Linear layers of F structurally identical MLPs (autograd flows back through the stack)."""
+    lin = [[m for m in seq if isinstance(m, torch.nn.Linear)] for seq in mlps]
+    F, L = len(lin), len(lin[0])
+    has_bias = lin[0][0].bias is not None
+    C = lin[0][-1].out_features
+
+    def st(idx, attr, squeeze=False):
+        ts = [getattr(layers[idx], attr) for layers in lin]
+        out = torch.stack(ts, 0)
+        return out[..., 0] if squeeze else out
+
+    if L == 1:
+        return StackedMLP(None, None, None, None, st(0, "weight", True), st(0, "bias") if has_bias else None,
+                          1, 0, C, F)
+    H = lin[0][0].out_features
+    w_mid = b_mid = None
+    if L > 2:
+        w_mid = torch.stack([st(l, "weight") for l in range(1, L - 1)], 0)
+        b_mid = torch.stack([st(l, "bias") for l in range(1, L - 1)], 0) if has_bias else None
+    return StackedMLP(st(0, "weight", True), st(0, "bias") if has_bias else None, w_mid, b_mid,
+                      st(L - 1, "weight"), st(L - 1, "bias") if has_bias else None, L, H, C, F)
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
+    x = x.detach().float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    n = x.shape[0]
+    width = p.C if sum_features else p.F * p.C
+    out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+    keep = [_c(t) for t in (p.w_first, p.b_first, p.w_mid, p.b_mid, p.w_last, p.b_last)]
+    a = _lib.FmlpArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=p.F, L=p.L, H=p.H, C=p.C,
+                      w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]), w_mid=_lib.ptr(keep[2]),
+                      b_mid=_lib.ptr(keep[3]), w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]),
+                      sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0))
+    _lib.check(_lib.lib().gnan_fmlp_fwd(a, _lib.stream_of(x)), "gnan_fmlp_fwd")
+    return out
+
+
+def _fmlp_eager(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
+    """Batched-GEMM restatement on the device, used ONLY to obtain parameter gradients in backward
+    (recompute + torch autograd) until the HIP weight-gradient kernel lands.  Never used for forward."""
+    xt = x.t().unsqueeze(-1)                                            # [F, n, 1]
+    if p.L == 1:
+        h = xt * p.w_last.unsqueeze(1)                                  # [F, n, C]
+        if p.b_last is not None:
+            h = h + p.b_last.unsqueeze(1)
+    else:
+        h = xt * p.w_first.unsqueeze(1)
+        if p.b_first is not None:
+            h = h + p.b_first.unsqueeze(1)
+        h = torch.relu(h)                                               # [F, n, H]
+        for l in range(p.L - 2):
+            h = torch.bmm(h, p.w_mid[l].transpose(1, 2))
+            if p.b_mid is not None:
+                h = h + p.b_mid[l].unsqueeze(1)
+            h = torch.relu(h)
+        h = torch.bmm(h, p.w_last.transpose(1, 2))                      # [F, n, C]
+        if p.b_last is not None:
+            h = h + p.b_last.unsqueeze(1)
+    if sum_features:
+        return h.sum(0)                                                 # [n, C]
+    return h.permute(1, 0, 2).reshape(x.shape[0], -1)                   # [n, F*C]
+
+
+_BWD_CHUNK_ELEMS = 1 << 28   # activation floats per recompute chunk (1 GiB)
+
+
+class _FeatureMLPs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sum_features, L, H, C, F, *params):
+        p = StackedMLP(*params, L, H, C, F)
+        ctx.meta = (sum_features, L, H, C, F)
+        ctx.save_for_backward(x, *[t for t in params if t is not None])
+        ctx.present = [t is not None for t in params]
+        return _fmlp_launch(x, p, sum_features)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        sum_features, L, H, C, F = ctx.meta
+        saved = list(ctx.saved_tensors)
+        x = saved.pop(0)
+        params = [saved.pop(0) if present else None for present in ctx.present]
+        leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
+        p = StackedMLP(*leaves, L, H, C, F)
+        live = [t for t in leaves if t is not None]
+        grads = [torch.zeros_like(t) for t in live]
+        n = x.shape[0]
+        chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))
+        xd = x.detach().float()
+        gx = torch.zeros_like(xd) if ctx.needs_input_grad[0] else None
+        for lo in range(0, n, chunk):
+            xs = xd[lo:lo + chunk]
+            if gx is not None:
+                xs = xs.clone().requires_grad_(True)
+            with torch.enable_grad():
+                out = _fmlp_eager(xs, p, sum_features)
+            got = torch.autograd.grad(out, live + ([xs] if gx is not None else []), grad_out[lo:lo + chunk])
+            for g, d in zip(grads, got):
+                g += d
+            if gx is not None:
+                gx[lo:lo + chunk] = got[-1]
+        it = iter(grads)
+        pg = [next(it) if present else None for present in ctx.present]
+        return (gx, None, None, None, None, None, *pg)
+
+
+def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
+    """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157."""
+    _lib.require_device(x, p.w_last)
+    if x.shape[1] != p.F:
+        raise ValueError(f"x has {x.shape[1]} feature columns, the model was built for {p.F}")
+    return _FeatureMLPs.apply(x, sum_features, p.L, p.H, p.C, p.F,
+                              p.w_first, p.b_first, p.w_mid, p.b_mid, p.w_last, p.b_last)
+
+
+# =============================================================================
+# rho-weighted aggregation
+# =============================================================================
+def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut, weight_by_col=False,
+               minus_rest=False, plan=None, workspace=None) -> _lib.SpmmArgs:
+    D, Cw = lut.shape[-2], lut.shape[-1]
+    a = _lib.SpmmArgs(
+        n_rows=out.shape[0], n_cols=g.n_cols,
+        rowptr=_lib.ptr(g.rowptr), rowptr_is64=int(g.rowptr is not None and g.rowptr.dtype == torch.int64),
+        col=_lib.ptr(g.col), code=_lib.ptr(g.code), row_ids=_lib.ptr(row_ids),
+        S=_lib.ptr(S), s_dtype=_lib.GNAN_F32, W=S.shape[1], s_stride=S.stride(0),
+        lut=_lib.ptr(lut), lut_row_stride=(D * Cw if per_row_lut else 0), D=D, Cw=Cw,
+        cnt=_lib.ptr(g.cnt) if use_cnt else None, cnt_stride=g.cnt.stride(0),
+        s_total=_lib.ptr(s_total), weight_by_col=int(weight_by_col), minus_rest=int(minus_rest),
+        Y=_lib.ptr(out), y_stride=out.stride(0),
+        long_threshold=(plan.threshold if plan is not None else 0),
+        long_rows=_lib.ptr(plan.rows) if plan is not None else None,
+        long_slice_ptr=_lib.ptr(plan.slice_ptr) if plan is not None else None,
+        n_long=(plan.n_long if plan is not None else 0), n_slices=(plan.n_slices if plan is not None else 0),
+        slice_edges=(plan.slice_edges if plan is not None else 0),
+        workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0))
+    return a
+
+
+def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
+                row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
+                minus_rest: bool = False, s_total: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``."""
+    _lib.require_device(S, lut, g.code)
+    S = S.detach().float()
+    if S.stride(1) != 1:
+        S = S.contiguous()
+    lut = lut.detach().float().contiguous()
+    per_row = lut.dim() == 3
+    if lut.shape[-2] != g.n_codes:
+        raise ValueError(f"weight table has {lut.shape[-2]} codes, graph has {g.n_codes}")
+    if S.shape[0] != g.n_cols:
+        raise ValueError(f"operand has {S.shape[0]} rows, graph has {g.n_cols} neighbour nodes")
+    if S.shape[1] % lut.shape[-1] != 0:
+        raise ValueError("operand width must be a multiple of the weight-channel count")
+    n_out = g.n_rows if row_ids is None else int(row_ids.numel())
+    out = torch.empty((n_out, S.shape[1]), dtype=torch.float32, device=S.device)
+    if with_rest and s_total is None:
+        s_total = S.sum(dim=0, dtype=torch.float64).float()
+    if not with_rest:
+        s_total = None
+    plan = None if g.is_dense else g.long_row_plan(row_ids)
+    a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan)
+    need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
+    ws = None
+    if need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=S.device)
+        a.workspace, a.workspace_bytes = _lib.ptr(ws), need
+    _lib.check(_lib.lib().gnan_spmm_fwd(a, _lib.stream_of(S)), "gnan_spmm_fwd")
+    return out
+
+
+def shell_sums_launch(g: HopGraph, S: torch.Tensor, lut_like: torch.Tensor, with_rest: bool,
+                      row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``T[q, d, w]`` = sum of operand rows per hop shell (``gnan_spmm_shell_sums``)."""
+    S = S.detach().float()
+    if S.stride(1) != 1:
+        S = S.contiguous()
+    n_out = g.n_rows if row_ids is None else int(row_ids.numel())
+    D = g.n_codes
+    T = torch.zeros((n_out, D, S.shape[1]), dtype=torch.float32, device=S.device)
+    s_total = S.sum(dim=0, dtype=torch.float64).float() if with_rest else None
+    lut = lut_like.detach().float().contiguous()
+    a = _spmm_args(g, S, lut, False, s_total, T.view(n_out, -1), row_ids, lut.dim() == 3)
+    _lib.check(_lib.lib().gnan_spmm_shell_sums(a, _lib.stream_of(S)), "gnan_spmm_shell_sums")
+    return T
+
+
+class _RhoAggregate(torch.autograd.Function):
+    """Y = A_w(lut, cnt) @ S  with the rest-bucket term; gradients for S and the weight table."""
+
+    @staticmethod
+    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids):
+        ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids = g, use_cnt, with_rest, row_ids
+        ctx.save_for_backward(S, lut)
+        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids)
+
+    @staticmethod
+    def backward(ctx, dY):
+        S, lut = ctx.saved_tensors
+        g, use_cnt, with_rest, row_ids = ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids
+        dY = dY.contiguous().float()
+        W = S.shape[1]
+        D, Cw = lut.shape[-2], lut.shape[-1]
+        per_row = lut.dim() == 3
+        rows = None if row_ids is None else row_ids.long()
+        cnt = g.cnt if rows is None else g.cnt[rows]
+        inv = (1.0 / cnt.clamp_min(1).float()) if use_cnt else None            # [n_out, D]
+        dS = dlut = None
+
+        if ctx.needs_input_grad[0]:
+            dY_full = dY
+            if rows is not None:
+                dY_full = torch.zeros((g.n_rows, W), dtype=torch.float32, device=dY.device)
+                dY_full.index_add_(0, rows, dY)
+            dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
+                             weight_by_col=True, minus_rest=with_rest)
+            if with_rest:
+                # d/dS_j of  wt(i, rest) * total  : the same vector for every j
+                l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
+                w_rest = l_rest * inv[:, D - 1:D] if inv is not None else l_rest   # [n_out or 1, Cw]
+                w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
+                dS = dS + (w_rest * dY).sum(0, keepdim=True)
+
+        if ctx.needs_input_grad[1]:
+            T = shell_sums_launch(g, S, lut, with_rest, row_ids)                  # [n_out, D, W]
+            dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
+            if inv is not None:
+                dwt = dwt * inv.unsqueeze(-1)                                     # [n_out, D, Cw]
+            if per_row:
+                if rows is None:
+                    dlut = dwt
+                else:
+                    dlut = torch.zeros_like(lut)
+                    dlut.index_add_(0, rows, dwt)
+            else:
+                dlut = dwt.sum(0)
+        return dS, dlut, None, None, None, None
+
+
+def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
+                  with_rest: Optional[bool] = None, row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``Y[q] = sum_j wt(i_q, hop(i_q, j)) * S[j]`` over the hop-coded adjacency ``g``.
+
+    ``lut [D, Cw]`` (post-rho / un-normalised: ``rho`` at the D distinct distances) or
+    ``lut [N, D, Cw]`` (pre-rho: ``rho(u_d / cnt[i, d])``); ``use_cnt`` divides by the shell size
+    (models.py:369-370).  ``with_rest`` defaults to True for CSR graphs (unlisted pairs get the
+    ``rho(0)`` weight) and False for dense ones (every pair is listed).
+    """
+    if with_rest is None:
+        with_rest = not g.is_dense
+    if row_ids is not None:
+        row_ids = row_ids.to(device=g.device, dtype=torch.int32).contiguous()
+    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids)

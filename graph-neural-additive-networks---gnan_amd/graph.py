@@ -1,0 +1,194 @@
+"""Hop-coded adjacency resident in HBM — the data structure the aggregation kernels read.
+
+The reference ships two dense fp32 ``N x N`` matrices per graph
+(``node_distances`` and ``normalization_matrix``, pre_process_datasets.py:104-142).
+Both are piecewise constant over hop shells, so one byte per listed pair (the hop
+index) plus a per-row table of shell sizes carries the same information:
+
+* dense layout — ``code [N, N] uint8``; every pair is listed, ``code == D-1`` marks
+  unreachable pairs.  Produced on the GPU from the reference's dense inputs.
+* CSR layout   — ``rowptr``/``col``/``code``; only pairs within ``K`` hops are listed,
+  everything else falls into the rest bucket ``D-1``.  The only way
+  the large configurations can exist at all.
+
+``cnt [N, D] int32`` holds the shell sizes ``|{j : hop(i, j) == d}|`` (last column:
+size of the rest bucket), i.e. the distinct values of ``normalization_matrix`` row i.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+LONG_ROW_THRESHOLD = 512   # rows with more listed pairs than this go through the slice kernel
+SLICE_EDGES = 2048         # pairs per slice of a hub row
+
+
+@dataclass
+class LongRowPlan:
+    """Hub rows of a CSR graph, cut into fixed-size slices (deterministic reduction order)."""
+    rows: Optional[torch.Tensor]        # int32 [n_long] output-row indices
+    slice_ptr: Optional[torch.Tensor]   # int32 [n_long + 1]
+    n_long: int = 0
+    n_slices: int = 0
+    threshold: int = LONG_ROW_THRESHOLD
+    slice_edges: int = SLICE_EDGES
+
+
+@dataclass
+class HopGraph:
+    n_rows: int
+    n_cols: int
+    n_codes: int                         # D: hop shells 0..D-2 plus the rest bucket D-1
+    code: torch.Tensor                   # uint8: [nnz] (CSR) or [n_rows, n_cols] (dense)
+    cnt: torch.Tensor                    # int32 [n_rows, D]
+    rowptr: Optional[torch.Tensor] = None   # int32/int64 [n_rows + 1]; None => dense layout
+    col: Optional[torch.Tensor] = None      # int32 [nnz]
+    _plan: Optional[LongRowPlan] = field(default=None, repr=False)
+    _transposed: Optional["HopGraph"] = field(default=None, repr=False)
+
+    @property
+    def is_dense(self) -> bool:
+        return self.rowptr is None
+
+    @property
+    def nnz(self) -> int:
+        return self.n_rows * self.n_cols if self.is_dense else int(self.col.numel())
+
+    @property
+    def device(self) -> torch.device:
+        return self.code.device
+
+    # ------------------------------------------------------------------ builders
+    @staticmethod
+    def from_dense(node_distances: torch.Tensor, normalization_matrix: Optional[torch.Tensor] = None) -> "HopGraph":
+        """Re-derive hop codes and shell counts from the reference's dense inputs, on the GPU.
+
+        Raises if ``node_distances`` is not of the form ``float32(1/(1+hop))`` / 0
+        (pre_process_datasets.py:112-114) or if ``normalization_matrix`` is not the
+        per-row count of equal entries (pre_process_datasets.py:117-121): the shell
+        kernels are only equivalent to the reference under those two properties.
+        """
+        nd = node_distances
+        _lib.require_device(nd, normalization_matrix)
+        if nd.dim() != 2:
+            raise ValueError(f"node_distances must be 2-D, got {tuple(nd.shape)}")
+        nd = nd.float()
+        if nd.stride(1) != 1:
+            nd = nd.contiguous()
+        norm = normalization_matrix
+        if norm is not None:
+            if norm.shape != nd.shape:
+                raise ValueError("normalization_matrix and node_distances differ in shape")
+            norm = norm.float()
+            if norm.stride() != nd.stride():
+                nd, norm = nd.contiguous(), norm.contiguous()
+        n_rows, n_cols = nd.shape
+        code = torch.empty((n_rows, n_cols), dtype=torch.uint8, device=nd.device)
+        cnt256 = torch.empty((n_rows, _lib.MAX_CODES), dtype=torch.int32, device=nd.device)
+        status = torch.zeros(2, dtype=torch.int32, device=nd.device)
+        _lib.check(_lib.lib().gnan_dense_to_code(_lib.ptr(nd), _lib.ptr(norm), n_rows, n_cols, nd.stride(0),
+                                                 _lib.ptr(code), _lib.ptr(cnt256), _lib.ptr(status),
+                                                 _lib.stream_of(nd)), "gnan_dense_to_code")
+        flags, max_hop = (int(v) for v in status.tolist())   # one small D2H read per graph
+        if flags & 1:
+            raise _lib.GnanHipError(
+                "node_distances holds values that are not float32(1/(1+hop)) with hop <= 254 (or 0 for "
+                "unreachable pairs); the shell kernels cannot represent it")
+        if flags & 2:
+            raise _lib.GnanHipError(
+                "normalization_matrix is not the per-row count of equal node_distances entries "
+                "(pre_process_datasets.py:117-121); the shell kernels cannot represent it")
+        D = max_hop + 2
+        cnt = torch.cat([cnt256[:, : D - 1], cnt256[:, _lib.MAX_CODES - 1:]], dim=1).contiguous()
+        return HopGraph(n_rows=n_rows, n_cols=n_cols, n_codes=D, code=code, cnt=cnt)
+
+    @staticmethod
+    def from_csr(rowptr: torch.Tensor, col: torch.Tensor, code: torch.Tensor, n_cols: int, n_codes: int,
+                 cnt: Optional[torch.Tensor] = None) -> "HopGraph":
+        """Wrap a caller-built hop-coded CSR.  ``code`` values must be < n_codes-1.  Pure index work:
+        runs wherever the tensors live (the kernels later insist on device memory)."""
+        if rowptr.dtype not in (torch.int32, torch.int64):
+            raise TypeError("rowptr must be int32 or int64")
+        n_rows = rowptr.numel() - 1
+        col = col.to(torch.int32).contiguous()
+        code = code.to(torch.uint8).contiguous()
+        if not 2 <= n_codes <= _lib.MAX_CODES:
+            raise ValueError(f"n_codes must be in [2, {_lib.MAX_CODES}]")
+        if cnt is None:
+            cnt = shell_counts_csr(rowptr, code, n_cols, n_codes)
+        cnt = cnt.to(torch.int32).contiguous()
+        if cnt.shape != (n_rows, n_codes):
+            raise ValueError(f"cnt must be [{n_rows}, {n_codes}], got {tuple(cnt.shape)}")
+        return HopGraph(n_rows=n_rows, n_cols=n_cols, n_codes=n_codes, code=code, cnt=cnt,
+                        rowptr=rowptr.contiguous(), col=col)
+
+    # ------------------------------------------------------------------ derived structures
+    def long_row_plan(self, row_ids: Optional[torch.Tensor] = None) -> LongRowPlan:
+        """Hub rows and their slices; cached for the identity row order."""
+        if self.is_dense:
+            return LongRowPlan(None, None)
+        if row_ids is None and self._plan is not None:
+            return self._plan
+        deg = (self.rowptr[1:] - self.rowptr[:-1])
+        if row_ids is not None:
+            deg = deg[row_ids.long()]
+        long_rows = torch.nonzero(deg > LONG_ROW_THRESHOLD).flatten()
+        n_long = int(long_rows.numel())
+        if n_long == 0:
+            plan = LongRowPlan(None, None)
+        else:
+            n_sl = (deg[long_rows] + SLICE_EDGES - 1) // SLICE_EDGES
+            ptr = torch.zeros(n_long + 1, dtype=torch.int64, device=self.device)
+            ptr[1:] = torch.cumsum(n_sl, 0)
+            plan = LongRowPlan(long_rows.to(torch.int32), ptr.to(torch.int32), n_long, int(ptr[-1]))
+        if row_ids is None:
+            self._plan = plan
+        return plan
+
+    def transposed(self) -> "HopGraph":
+        """Adjacency with the roles of row and neighbour swapped (used for the gradient w.r.t. S).
+
+        ``cnt`` of the transposed graph is the *forward* graph's table: the kernels index it by
+        the neighbour (``weight_by_col``), which is the forward pass's output row.
+        """
+        if self._transposed is not None:
+            return self._transposed
+        if self.is_dense:
+            t = HopGraph(n_rows=self.n_cols, n_cols=self.n_rows, n_codes=self.n_codes,
+                         code=self.code.t().contiguous(), cnt=self.cnt)
+        else:
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            row_of_edge = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), deg)
+            order = torch.argsort(self.col.long(), stable=True)
+            counts = torch.bincount(self.col.long(), minlength=self.n_cols)
+            rowptr_t = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=self.device)
+            rowptr_t[1:] = torch.cumsum(counts, 0)
+            t = HopGraph(n_rows=self.n_cols, n_cols=self.n_rows, n_codes=self.n_codes,
+                         code=self.code[order].contiguous(), cnt=self.cnt,
+                         rowptr=rowptr_t.to(self.rowptr.dtype), col=row_of_edge[order].to(torch.int32).contiguous())
+        self._transposed = t
+        return t
+
+
+def shell_counts_csr(rowptr: torch.Tensor, code: torch.Tensor, n_cols: int, n_codes: int) -> torch.Tensor:
+    """``cnt[i, d]`` for a hop-coded CSR: listed pairs per code, rest bucket = ``n_cols - listed``
+    (the reference's counting rule, pre_process_datasets.py:136-140, per shell)."""
+    n_rows = rowptr.numel() - 1
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    row_of_edge = torch.repeat_interleave(torch.arange(n_rows, device=rowptr.device), deg)
+    flat = torch.bincount(row_of_edge * n_codes + code.long(), minlength=n_rows * n_codes)
+    cnt = flat.view(n_rows, n_codes)
+    cnt[:, n_codes - 1] = n_cols - deg
+    return cnt.to(torch.int32)
+
+
+def hop_inputs(n_codes: int, device) -> torch.Tensor:
+    """The distinct values ``node_distances`` takes: ``float32(1/(1+d))`` for ``d < D-1``, then 0
+    (pre_process_datasets.py:112-114) — the only points rho is ever evaluated at."""
+    u = torch.zeros(n_codes, dtype=torch.float32)          # D host divisions: bit-identical to the
+    u[: n_codes - 1] = 1.0 / (torch.arange(n_codes - 1, dtype=torch.float32) + 1.0)   # reference's CPU values
+    return u.to(device)

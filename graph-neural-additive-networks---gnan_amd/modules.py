@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's model interface for the aggregation path.
+
+Same class names, constructor signatures, ``forward`` signatures, parameter
+registration order (hence the same RNG stream at construction) and
+``state_dict`` keys as the reference:
+
+* :class:`StandaloneTensorGNAN`, :class:`StandaloneGNAN` — the stand-alone model file
+  (GNAN.py:9-79, GNAN.py:82-176); exported as ``gnan_amd.GNAN.TensorGNAN`` / ``.GNAN``;
+* :class:`NAM`, :class:`TensorGNAN`, :class:`GNAN` — the copy ``main.py`` imports
+  (models.py:259-300, 303-384, 387-481); exported from ``gnan_amd.models``.
+
+``forward`` never evaluates rho per pair and never loops over features or nodes in
+Python: it stacks the per-feature weights, launches the fused shape-function kernel,
+evaluates rho on the handful of distinct distances, and launches the hop-coded
+aggregation kernel (``functional.py`` -> ``libgnan_hip.so``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps
+from .graph import HopGraph, hop_inputs
+
+
+# =============================================================================
+# construction helpers (layouts fixed by the reference's state_dict keys)
+# =============================================================================
+def _shape_mlp(n_layers: int, hidden: Optional[int], out: int, bias: bool, dropout: Optional[float]) -> nn.Sequential:
+    """``R -> R^out`` MLP.  With ``dropout`` given: Linear/ReLU/Dropout triples (keys 0,3,6,… —
+    GNAN.py:24-34); with ``dropout=None``: Linear/ReLU pairs (keys 0,2,4,… — GNAN.py:38-47)."""
+    if n_layers == 1:
+        return nn.Sequential(nn.Linear(1, out, bias=bias))
+    mods, width_in = [], 1
+    for _ in range(n_layers - 1):
+        mods += [nn.Linear(width_in, hidden, bias=bias), nn.ReLU()]
+        if dropout is not None:
+            mods.append(nn.Dropout(p=dropout))
+        width_in = hidden
+    mods.append(nn.Linear(hidden, out, bias=bias))
+    return nn.Sequential(*mods)
+
+
+def _tiny_init(module: nn.Module) -> None:
+    """The TensorGNAN re-initialisation: xavier-normal with gain 0.01, zero biases (GNAN.py:49-53)."""
+    for name, p in module.named_parameters():
+        if "weight" in name:
+            nn.init.xavier_normal_(p, gain=0.01)
+        elif "bias" in name:
+            nn.init.constant_(p, 0)
+
+
+class _PathBase(nn.Module):
+    """Shared plumbing: stacked-weight cache, hop-graph lookup, rho look-up tables."""
+
+    def _init_caches(self):
+        self._stack_cache = {}
+        self._graph_cache = None
+
+    # ---- parameters -> stacked device tensors --------------------------------------------
+    def _stacked(self, name: str, mlps) -> StackedMLP:
+        params = [p for seq in mlps for p in seq.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return stack_mlps(mlps)                       # autograd flows back through torch.stack
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._stack_cache.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, stack_mlps(mlps))
+            self._stack_cache[name] = hit
+        return hit[1]
+
+    def _check_dropout(self):
+        if self.training and self.dropout and self.dropout > 0:
+            raise NotImplementedError(
+                "training-mode Dropout inside the fused shape-function kernel is not implemented; call "
+                ".eval() (the reference itself leaves eval mode on after its first evaluation, trainer.py:97) "
+                "or construct the model with dropout=0.0")
+
+    # ---- inputs -> hop-coded adjacency -----------------------------------------------------
+    def _graph(self, inputs, want_norm: bool) -> HopGraph:
+        g = getattr(inputs, "gnan_graph", None)
+        if g is not None:
+            return g
+        if hasattr(inputs, "gnan_rowptr"):
+            key = ("csr", inputs.gnan_rowptr.data_ptr(), inputs.gnan_col.data_ptr(), inputs.gnan_code.data_ptr())
+            if self._graph_cache is None or self._graph_cache[0] != key:
+                g = HopGraph.from_csr(inputs.gnan_rowptr, inputs.gnan_col, inputs.gnan_code,
+                                      n_cols=inputs.x.shape[0], n_codes=int(inputs.gnan_n_codes),
+                                      cnt=getattr(inputs, "gnan_cnt", None))
+                self._graph_cache = (key, g)
+            return self._graph_cache[1]
+        nd = inputs.node_distances
+        norm = inputs.normalization_matrix if want_norm else getattr(inputs, "normalization_matrix", None)
+        key = ("dense", nd.data_ptr(), nd._version, tuple(nd.shape),
+               None if norm is None else (norm.data_ptr(), norm._version))
+        if self._graph_cache is None or self._graph_cache[0] != key:
+            self._graph_cache = (key, HopGraph.from_dense(nd, norm))
+        return self._graph_cache[1]
+
+    # ---- rho on the distinct distances -------------------------------------------------------
+    def _lut_global(self, g: HopGraph) -> torch.Tensor:
+        """``lut[d] = rho(float32(1/(1+d)))``, ``lut[D-1] = rho(0)`` — D rows instead of N^2 (models.py:368)."""
+        return self.rho(hop_inputs(g.n_codes, g.device).view(-1, 1))
+
+    def _lut_pre_rho(self, g: HopGraph) -> torch.Tensor:
+        """``lut[i, d] = rho(u_d / cnt[i, d])`` — the pre-rho normalisation of GNAN.py:65-67, per shell."""
+        arg = hop_inputs(g.n_codes, g.device).unsqueeze(0) / g.cnt.clamp_min(1).float()
+        return self.rho(arg.view(-1, 1)).view(g.n_rows, g.n_codes, -1)
+
+
+# =============================================================================
+# the stand-alone model file (GNAN.py)
+# =============================================================================
+class StandaloneTensorGNAN(_PathBase):
+    """``TensorGNAN`` of the stand-alone model file — constructor GNAN.py:10-53, forward GNAN.py:55-79.
+
+    Pre-rho normalisation; rho always has ``out_channels`` outputs; ``rho_per_feature`` and
+    ``readout_n_layers`` are accepted and ignored, as upstream.
+    """
+
+    def __init__(self, in_channels, out_channels, n_layers, hidden_channels=None, bias=True, dropout=0.0,
+                 device='cpu', rho_per_feature=False, normalize_rho=True, is_graph_task=False, readout_n_layers=1):
+        super().__init__()
+        self.device = device
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.n_layers = n_layers
+        self.bias = bias
+        self.dropout = dropout
+        self.rho_per_feature = rho_per_feature
+        self.normalize_rho = normalize_rho
+        self.is_graph_task = is_graph_task
+        self.fs = nn.ModuleList(_shape_mlp(n_layers, hidden_channels, out_channels, bias, dropout)
+                                for _ in range(in_channels))
+        self.rho = _shape_mlp(n_layers, hidden_channels, out_channels, not is_graph_task, None)
+        _tiny_init(self)
+        self._init_caches()
+
+    def forward(self, inputs):
+        self._check_dropout()
+        x = inputs.x
+        _lib.require_device(x)
+        g = self._graph(inputs, want_norm=bool(self.normalize_rho))
+        S = feature_mlps(x, self._stacked("fs", self.fs), sum_features=True)          # [N, C]
+        lut = self._lut_pre_rho(g) if self.normalize_rho else self._lut_global(g)
+        Y = rho_aggregate(g, S, lut, use_cnt=False)                                   # [N, C]
+        if not self.is_graph_task:
+            return Y                                                                  # GNAN.py:72-73,79
+        return Y.sum(dim=0).view(-1, 1)                                               # [C, 1]  GNAN.py:75-79
+
+
+class _GNANCore(_PathBase):
+    """``GNAN`` — constructor GNAN.py:83-137 / models.py:388-442, forward GNAN.py:146-172."""
+
+    def _build(self, in_channels, out_channels, n_layers, hidden_channels, bias, dropout, device,
+               normalize_rho, rho_per_feature):
+        self.device = device
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.num_layers = n_layers
+        self.bias = bias
+        self.dropout = dropout
+        self.rho_per_feature = rho_per_feature
+        self.normalize_rho = normalize_rho
+        self.fs = nn.ModuleList(_shape_mlp(n_layers, hidden_channels, out_channels, bias, dropout)
+                                for _ in range(in_channels))
+        # rho has one output unless rho_per_feature (then one per output channel, GNAN.py:118-121);
+        # a single-layer rho is always out_channels wide (GNAN.py:125-126).
+        width = out_channels if (rho_per_feature or n_layers == 1) else 1
+        if rho_per_feature:
+            # upstream builds F copies and keeps using the LAST one under the name `rho`
+            # (GNAN.py:108-123,137): `rho` shares its Linear modules with `rhos[F-1]`.
+            self.rhos = nn.ModuleList(_shape_mlp(n_layers, hidden_channels, width, bias, None)
+                                      for _ in range(in_channels))
+            self.rho = nn.Sequential(*list(self.rhos[-1]))
+        else:
+            self.rho = _shape_mlp(n_layers, hidden_channels, width, bias, None)
+        self._init_caches()
+
+    def forward(self, inputs, node_ids=None):
+        self._check_dropout()
+        x = inputs.x
+        _lib.require_device(x)
+        g = self._graph(inputs, want_norm=True)            # GNAN.py:161 reads it unconditionally
+        S = feature_mlps(x, self._stacked("fs", self.fs), sum_features=True)          # f_sums, GNAN.py:157
+        rows = None
+        if node_ids is not None:
+            rows = torch.as_tensor(list(node_ids) if not torch.is_tensor(node_ids) else node_ids,
+                                   dtype=torch.int32, device=x.device)
+        return rho_aggregate(g, S, self._lut_global(g), use_cnt=bool(self.normalize_rho), row_ids=rows)
+
+    def print_rho_params(self):
+        for name, param in self.rho.named_parameters():
+            print(name, param)
+
+
+class StandaloneGNAN(_GNANCore):
+    def __init__(self, in_channels, out_channels, n_layers, hidden_channels=None, bias=True, dropout=0.0,
+                 device='cpu', normalize_rho=True, rho_per_feature=False):
+        super().__init__()
+        self._build(in_channels, out_channels, n_layers, hidden_channels, bias, dropout, device,
+                    normalize_rho, rho_per_feature)
+
+
+# =============================================================================
+# the copy main.py imports (models.py)
+# =============================================================================
+class NAM(_PathBase):
+    """``NAM`` — models.py:259-300: ``sum_k f_k(x[:, k])``."""
+
+    def __init__(self, in_channels, out_channels, num_layers, hidden_channels=None, bias=True, dropout=0.0,
+                 device='cpu'):
+        super().__init__()
+        self.device = device
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.bias = bias
+        self.dropout = dropout
+        self.fs = nn.ModuleList(_shape_mlp(num_layers, hidden_channels, out_channels, bias, dropout)
+                                for _ in range(in_channels))
+        self._init_caches()
+
+    def forward(self, x):
+        self._check_dropout()
+        return feature_mlps(x, self._stacked("fs", self.fs), sum_features=True)
+
+
+class TensorGNAN(_PathBase):
+    """``TensorGNAN`` as ``main.py`` uses it — constructor models.py:304-356, forward models.py:358-384.
+
+    Post-rho normalisation; rho is one-wide unless ``rho_per_feature``; graph tasks may end in a
+    ``NAM`` read-out over the per-feature aggregates.
+    """
+
+    def __init__(self, in_channels, out_channels, n_layers, hidden_channels=None, bias=True, dropout=0.0,
+                 device='cpu', rho_per_feature=False, normalize_rho=True, is_graph_task=False, readout_n_layers=1):
+        super().__init__()
+        self.device = device
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.n_layers = n_layers
+        self.bias = bias
+        self.dropout = dropout
+        self.rho_per_feature = rho_per_feature
+        self.normalize_rho = normalize_rho
+        self.is_graph_task = is_graph_task
+        self.readout_n_layers = readout_n_layers
+        self.aggregation_order = "sum_first"          # or "reference" (models.py:373-376 evaluation order)
+        with_readout = bool(is_graph_task and readout_n_layers > 0)
+        self.actual_output_dim_f = 1 if with_readout else out_channels                       # models.py:320
+        self.actual_output_dim_rho = 1 if (not rho_per_feature or with_readout) else out_channels  # :321
+        self.fs = nn.ModuleList(_shape_mlp(n_layers, hidden_channels, self.actual_output_dim_f, bias, dropout)
+                                for _ in range(in_channels))
+        self.rho = _shape_mlp(n_layers, hidden_channels, self.actual_output_dim_rho, not is_graph_task, None)
+        if with_readout:
+            self.readout_nam = NAM(in_channels, out_channels, readout_n_layers, hidden_channels, bias, dropout,
+                                   device)
+        _tiny_init(self)
+        self._init_caches()
+
+    def forward(self, inputs):
+        self._check_dropout()
+        x = inputs.x
+        _lib.require_device(x)
+        g = self._graph(inputs, want_norm=bool(self.normalize_rho))
+        lut = self._lut_global(g)
+        use_cnt = bool(self.normalize_rho)
+        with_readout = self.is_graph_task and self.readout_n_layers > 0
+        fs = self._stacked("fs", self.fs)
+        if with_readout:
+            fx = feature_mlps(x, fs, sum_features=False)                              # [N, F]   (f is 1-wide)
+            hidden = rho_aggregate(g, fx, lut, use_cnt).sum(dim=0).view(1, -1)        # [1, F]   models.py:379
+            return self.readout_nam(hidden).T                                         # [C, 1]   models.py:380-384
+        if self.aggregation_order == "reference":
+            # the upstream evaluation order (models.py:373-376): aggregate every feature column, then sum
+            # over features.  Same function, F times the aggregation traffic; kept because the intermediate
+            # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
+            # in this order.
+            Y = self.feature_contributions(inputs, _g=g, _lut=lut).sum(dim=1)         # [N, C]
+        else:
+            S = feature_mlps(x, fs, sum_features=True)                                # [N, C]  sum-first
+            Y = rho_aggregate(g, S, lut, use_cnt)                                     # [N, C]
+        if not self.is_graph_task:
+            return Y                                                                  # models.py:375-376,384
+        return Y.sum(dim=0).view(-1, 1)                                               # [C, 1]  models.py:383-384
+
+    def feature_contributions(self, inputs, _g=None, _lut=None):
+        """``mf[i, k, c] = sum_j m_ij[c] * f_k(x[j, k])[c]`` — the per-feature aggregate of models.py:373,
+        returned as ``[N, F, C]`` (the reference holds it as ``[C, N, F]``)."""
+        x = inputs.x
+        g = self._graph(inputs, want_norm=bool(self.normalize_rho)) if _g is None else _g
+        lut = self._lut_global(g) if _lut is None else _lut
+        fx = feature_mlps(x, self._stacked("fs", self.fs), sum_features=False)        # [N, F*C]
+        Y = rho_aggregate(g, fx, lut, bool(self.normalize_rho))                       # [N, F*C]
+        return Y.view(x.shape[0], -1, self.actual_output_dim_f)
+
+
+class GNAN(_GNANCore):
+    """``models.GNAN``: identical to the stand-alone one except that the depth argument is spelled
+    ``num_layers`` (models.py:388; ``main.py:79-83`` passes it by keyword).  Both spellings work."""
+
+    def __init__(self, in_channels, out_channels, num_layers=None, hidden_channels=None, bias=True, dropout=0.0,
+                 device='cpu', normalize_rho=True, rho_per_feature=False, n_layers=None):
+        super().__init__()
+        depth = num_layers if num_layers is not None else n_layers
+        if depth is None:
+            raise TypeError("GNAN() missing the depth argument (num_layers / n_layers)")
+        self._build(in_channels, out_channels, depth, hidden_channels, bias, dropout, device,
+                    normalize_rho, rho_per_feature)

@@ -1,0 +1,181 @@
+/*
+ * gnan_hip.h — C ABI of libgnan_hip.so: the MI355X (gfx950) kernels behind GNAN's
+ * distance-weighted additive aggregation (TensorGNAN.forward / GNAN.forward).
+ *
+ * The reference has no FFI layer for this path (it is stock ATen ops issued from Python);
+ * each entry point below names the reference lines whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned memory (row-major, contiguous rows);
+ *    the library never allocates or frees caller-visible memory; scratch is passed in;
+ *  - every call enqueues work on `stream` and returns immediately (no device sync);
+ *  - return value: 0 on success, negative gnan_status on failure; the message of the last
+ *    failure on the calling thread is available through gnan_last_error();
+ *  - no C++ exception crosses the boundary; no mutable global state.
+ */
+#ifndef GNAN_HIP_H
+#define GNAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNAN_ABI_VERSION 1
+
+typedef void* gnan_stream_t; /* hipStream_t */
+
+enum gnan_status {
+  GNAN_OK = 0,
+  GNAN_ERR_BAD_ARG = -1,     /* null pointer, negative size, misaligned stride ... */
+  GNAN_ERR_UNSUPPORTED = -2, /* shape outside what the kernels cover */
+  GNAN_ERR_HIP = -3,         /* a HIP runtime call failed */
+  GNAN_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+enum gnan_dtype { GNAN_F32 = 0, GNAN_BF16 = 1 };
+
+/* Largest number of hop codes (shells incl. the rest bucket) a uint8 code can address. */
+#define GNAN_MAX_CODES 256
+
+int gnan_abi_version(void);
+const char* gnan_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-feature shape functions  fx[n, k, :] = f_k(x[n, k])
+ * replaces the Python feature loop GNAN.py:57-62 (= GNAN.py:150-155, models.py:360-365,
+ * models.py:292-297), i.e. F x (L addmm + (L-1) relu + strided copy_).
+ *
+ * Weights are the reference's per-feature nn.Linear tensors stacked over the feature axis:
+ *   L == 1 : w_last [F, C] (Linear(1, C).weight[:, 0]), b_last [F, C]
+ *   L >= 2 : w_first [F, H], b_first [F, H]                       Linear(1, H)
+ *            w_mid [L-2, F, H, H] (out, in), b_mid [L-2, F, H]    Linear(H, H)
+ *            w_last [F, C, H], b_last [F, C]                      Linear(H, C)
+ * Bias pointers may be NULL (bias=False).  ReLU after every layer but the last; Dropout is the
+ * caller's business (eval mode / p = 0 only).
+ *
+ * sum_features == 0 : out[n, k*C + c]               ("reference order", fx of GNAN.py:57)
+ * sum_features == 1 : out[n, c] = sum_k fx[n, k, c]  (f_sums of GNAN.py:157)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gnan_fmlp_args {
+  const float* x;        /* [n, F], row stride x_stride floats */
+  int64_t n;
+  int64_t x_stride;
+  int32_t F, L, H, C;
+  const float* w_first;
+  const float* b_first;
+  const float* w_mid;
+  const float* b_mid;
+  const float* w_last;
+  const float* b_last;
+  int32_t sum_features;
+  float* out;            /* [n, out_stride] */
+  int64_t out_stride;
+} gnan_fmlp_args;
+
+int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rho(distance)-weighted neighbourhood sum over a hop-coded adjacency
+ *
+ *   Y[i, w] = sum_{e in row i} wt(i, code_e, w) * S[col_e, w]
+ *           + wt(i, D-1, w) * ( s_total[w] - sum_{e in row i} S[col_e, w] )      (if s_total)
+ *   wt(i, d, w) = lut[i*lut_row_stride + d*Cw + (w % Cw)] / max(cnt[i*cnt_stride + d], 1)
+ *
+ * replaces rho on all N^2 pairs + normalisation + bmm + feature sum:
+ *   GNAN.py:65-73 / models.py:368-376 (TensorGNAN) and the per-node loop GNAN.py:159-170 /
+ *   models.py:464-475 (GNAN).  It relies on node_distances being piecewise constant over
+ *   hop shells (pre_process_datasets.py:112-121): rho is evaluated once per shell by the
+ *   caller (`lut`), never per pair.
+ *
+ * Adjacency, two layouts:
+ *   CSR   : rowptr (int32 or int64, n_rows+1), col int32, code uint8 (hop index < D-1)
+ *   dense : rowptr == col == NULL; code is [n_rows, n_cols] row-major, neighbour j of row i
+ *           is column j; code D-1 marks "unreachable" pairs (they still count as listed).
+ * row_ids (optional) selects / reorders output rows: output row q aggregates adjacency row
+ * row_ids[q] (GNAN.forward(node_ids), GNAN.py:159).  The adjacency row index is also the
+ * index into cnt / a per-row lut.
+ *
+ * Normalisation orders:
+ *   post-rho (models.py:369-370)  : global lut (lut_row_stride = 0) + cnt
+ *   none                          : global lut, cnt = NULL
+ *   pre-rho  (GNAN.py:65-67)      : per-row lut (lut_row_stride = D*Cw), cnt = NULL
+ *
+ * Transposed use (gradient w.r.t. S, i.e. autograd through GNAN.py:70): run the same kernel on the
+ * transposed adjacency with weight_by_col = 1 (the weight table is indexed by the neighbour, which
+ * is the forward pass's output row) and minus_rest = 1; s_total must be NULL.
+ *
+ * Rows longer than `long_threshold` edges are not touched by the main kernel; the caller lists
+ * them in long_rows and the library splits each into slices of `slice_edges` edges reduced in a
+ * fixed order (deterministic), using `workspace`.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gnan_spmm_args {
+  int64_t n_rows;            /* output rows */
+  int64_t n_cols;            /* rows of S (nodes that can be neighbours) */
+  const void* rowptr;        /* NULL => dense layout */
+  int32_t rowptr_is64;
+  const int32_t* col;
+  const uint8_t* code;
+  const int32_t* row_ids;    /* optional [n_rows] */
+  const void* S;             /* [n_cols, W] operand rows */
+  int32_t s_dtype;           /* gnan_dtype */
+  int32_t W;
+  int64_t s_stride;          /* elements between operand rows */
+  const float* lut;          /* [D, Cw] or [n_adj_rows, D, Cw] */
+  int64_t lut_row_stride;    /* 0 => global table */
+  int32_t D;                 /* number of codes incl. the rest bucket (index D-1) */
+  int32_t Cw;                /* 1 or a divisor pattern of W: weight channel = w % Cw */
+  const int32_t* cnt;        /* optional [n_adj_rows, cnt_stride] shell counts */
+  int64_t cnt_stride;
+  const float* s_total;      /* optional [W]: column sums of S; enables the rest-bucket term */
+  int32_t weight_by_col;     /* transposed use: table row = neighbour col_e instead of output row */
+  int32_t minus_rest;        /* transposed use: wt(., d) - wt(., D-1) per listed pair */
+  float* Y;                  /* [n_rows, W] fp32 */
+  int64_t y_stride;
+  /* long-row plan (CSR only; n_long == 0 => every row goes through the main kernel) */
+  int64_t long_threshold;
+  const int32_t* long_rows;      /* [n_long] output-row indices q of the long rows */
+  const int32_t* long_slice_ptr; /* [n_long+1] prefix sum of slices per long row */
+  int32_t n_long;
+  int32_t n_slices;
+  int32_t slice_edges;
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_spmm_args;
+
+size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
+int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream);
+
+/* Shell sums for the backward pass (autograd through GNAN.py:67-70 w.r.t. rho's parameters):
+ *   T[q, d, w] = sum_{e in row, code_e == d} S[col_e, w]            d < D-1
+ *   T[q, D-1, w] (+)= s_total[w] - sum_{e in row} S[col_e, w]       (if s_total; dense layout
+ *                                                                    accumulates rest-coded pairs)
+ * Same arguments as gnan_spmm_fwd; `Y` is T [n_rows, D, W] fp32, ZEROED by the caller; lut, cnt,
+ * y_stride and the long-row plan are ignored.  The gradient of the weight table is then
+ *   dwt[q, d, c] = sum_{w % Cw == c} dY[q, w] * T[q, d, w]. */
+int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense inputs -> hop codes + shell counts
+ * replaces nothing in the model file: it re-derives, on the GPU, the shell structure that
+ * pre_process_datasets.py:112-121 baked into the two dense matrices, and checks it.
+ *
+ *   code[i, j] = round(1 / nd[i, j]) - 1        (exact for nd = float32(1/(1+hop)))
+ *              = 255                            for nd == 0 (unreachable)
+ *   cnt[i, d]  = #{ j : code[i, j] == d },  d < 255;   cnt[i, 255] = #{ j : nd[i, j] == 0 }
+ *
+ * status[0] |= 1 if some nd is not of the form float32(1/(1+hop)) with hop <= 254
+ * status[0] |= 2 if norm != NULL and norm[i, j] != cnt[i, code[i, j]] somewhere
+ * status[1]  = max hop seen (atomicMax).          status must be zeroed by the caller.
+ * ------------------------------------------------------------------------------------------- */
+int gnan_dense_to_code(const float* nd, const float* norm, int64_t n_rows, int64_t n_cols,
+                       int64_t in_stride, uint8_t* code, int32_t* cnt /* [n_rows, 256] */,
+                       int32_t* status /* [2] */, gnan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNAN_HIP_H */

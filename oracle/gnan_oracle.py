@@ -329,3 +329,28 @@ def rel_err(y: Tensor, truth: Tensor) -> float:
     t = truth.double()
     den = float(t.abs().max())
     return float((y.double() - t).abs().max()) / (den if den > 0 else 1.0)
+
+
+def spmm_csr_sparse(rowptr: np.ndarray, col: np.ndarray, code: np.ndarray, S: Tensor, lut: Tensor,
+                    cnt: Optional[np.ndarray]) -> Tensor:
+    """:func:`spmm_csr` for one weight channel, vectorised through ``torch.sparse_csr`` (MKL, all host cores).
+
+    This is the CPU comparator for graphs the dense reference cannot hold: edge values
+    ``lut[code] / cnt[row, code]`` from the same table as the kernels use, with the rest-bucket term
+    folded in as ``(w_e - w_rest[row]) * S[col]  +  w_rest[row] * total``.
+    """
+    n = len(rowptr) - 1
+    rp = torch.from_numpy(np.asarray(rowptr, dtype=np.int64))
+    deg = rp[1:] - rp[:-1]
+    row_of_edge = torch.repeat_interleave(torch.arange(n), deg)
+    codet = torch.from_numpy(np.asarray(code, dtype=np.int64))
+    l = lut.reshape(-1).to(S.dtype)
+    if cnt is None:
+        w_e, w_rest = l[codet], l[-1].expand(n)
+    else:
+        c = torch.from_numpy(np.maximum(cnt, 1)).to(S.dtype)
+        w_e = l[codet] / c[row_of_edge, codet]
+        w_rest = l[-1] / c[:, -1]
+    A = torch.sparse_csr_tensor(rp, torch.from_numpy(np.asarray(col, dtype=np.int64)), w_e - w_rest[row_of_edge],
+                                size=(n, S.shape[0]))
+    return A @ S + w_rest.unsqueeze(1) * S.sum(dim=0, keepdim=True)

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports what the header declares."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import gnan_amd
+from gnan_amd import _lib
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gnan_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gnan_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 6
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/gnan_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "ctypes binding and header disagree"
+
+
+def test_abi_version_and_error_channel():
+    lib = _lib.lib()
+    assert lib.gnan_abi_version() == _lib.ABI_VERSION
+    # argument validation happens on the host before any HIP call: usable without a GPU
+    a = _lib.SpmmArgs(n_rows=4, n_cols=4, W=0, D=2, Cw=1)
+    rc = lib.gnan_spmm_fwd(a, None)
+    assert rc == -1 and b"W must be" in lib.gnan_last_error()
+    f = _lib.FmlpArgs(n=-1, F=1, L=1, C=1)
+    assert lib.gnan_fmlp_fwd(f, None) == -1
+
+
+def test_struct_layout_matches_header():
+    """Field order of the ctypes structs == field order of the C structs (names must line up)."""
+    text = open(os.path.join(ROOT, "include", "gnan_hip.h")).read()
+    for struct, cls in (("gnan_fmlp_args", _lib.FmlpArgs), ("gnan_spmm_args", _lib.SpmmArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+            for n in names.split(","):
+                fields.append(n.strip().lstrip("*").strip())
+        assert fields == [f[0] for f in cls._fields_], struct
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from gnan_amd.models import TensorGNAN
+
+    class Bag:
+        pass
+
+    d = Bag()
+    d.x = torch.rand(5, 3)
+    d.edge_index = torch.zeros(2, 0, dtype=torch.long)
+    d.node_distances = torch.eye(5)
+    d.normalization_matrix = torch.ones(5, 5)
+    m = TensorGNAN(3, 2, 3, hidden_channels=8).eval()
+    with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
+        m.forward(d)

@@ -1,0 +1,189 @@
+"""Kernel-level GPU tests: each C-ABI entry point against the oracle on seeded inputs, incl. edge cases
+(empty rows, hub rows, ragged widths, row subsets) and size-independent properties (linearity)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+
+
+def _mlp_state(F, L, H, C, bias, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k in range(F):
+        dims = [1] + [H] * (L - 1) + [C]
+        for li in range(L):
+            sd[f"fs.{k}.{3 * li}.weight"] = torch.randn(dims[li + 1], dims[li], generator=g) * (2.0 / (dims[li] + dims[li + 1])) ** 0.5
+            if bias:
+                sd[f"fs.{k}.{3 * li}.bias"] = torch.randn(dims[li + 1], generator=g) * 0.5
+    return sd
+
+
+def _stack(sd, F, L, H, C, bias):
+    from gnan_amd.functional import StackedMLP
+
+    def cat(li, what):
+        return torch.stack([sd[f"fs.{k}.{3 * li}.{what}"] for k in range(F)], 0).to(DEV)
+
+    if L == 1:
+        return StackedMLP(None, None, None, None, cat(0, "weight")[..., 0], cat(0, "bias") if bias else None, 1, 0, C, F)
+    w_mid = b_mid = None
+    if L > 2:
+        w_mid = torch.stack([cat(li, "weight") for li in range(1, L - 1)], 0)
+        b_mid = torch.stack([cat(li, "bias") for li in range(1, L - 1)], 0) if bias else None
+    return StackedMLP(cat(0, "weight")[..., 0], cat(0, "bias") if bias else None, w_mid, b_mid,
+                      cat(L - 1, "weight"), cat(L - 1, "bias") if bias else None, L, H, C, F)
+
+
+@pytest.mark.parametrize("F,L,H,C,bias", [
+    (3, 1, 0, 2, True), (4, 2, 8, 3, True), (5, 3, 8, 1, True), (9, 3, 32, 5, False),
+    (15, 3, 64, 1, True), (7, 4, 16, 7, True), (3, 3, 20, 40, True), (64, 3, 64, 1, True),
+])
+@pytest.mark.parametrize("sum_features", [True, False])
+def test_feature_mlps_vs_oracle(F, L, H, C, bias, sum_features):
+    from gnan_amd.functional import feature_mlps
+    n = 203
+    sd = _mlp_state(F, L, max(H, 1), C, bias, seed=F * 100 + L)
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(1))
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()})
+    ref32 = O.feature_mlps(x, sd)
+    if sum_features:
+        truth, ref32 = truth.sum(1), ref32.sum(1)
+    else:
+        truth, ref32 = truth.reshape(n, -1), ref32.reshape(n, -1)
+    with torch.no_grad():
+        y = feature_mlps(x.to(DEV), _stack(sd, F, L, H, C, bias), sum_features).cpu()
+    assert y.shape == truth.shape
+    e_build, e_ref = O.rel_err(y, truth), O.rel_err(ref32, truth)
+    assert e_build <= max(1e-5, e_ref), (e_build, e_ref)
+
+
+def _random_csr(n_rows, n_cols, K, rng, hubs=()):
+    deg = rng.poisson(6, n_rows)
+    deg[rng.random(n_rows) < 0.1] = 0                    # empty rows
+    for r, d in hubs:
+        deg[r] = d
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, n_cols, nnz).astype(np.int32)
+    code = rng.integers(0, K + 1, nnz).astype(np.uint8)
+    return rowptr, col, code
+
+
+def _graph(rowptr, col, code, n_cols, D, idx_dtype=torch.int64):
+    from gnan_amd import HopGraph
+    return HopGraph.from_csr(torch.from_numpy(rowptr).to(idx_dtype).to(DEV), torch.from_numpy(col).to(DEV),
+                             torch.from_numpy(code).to(DEV), n_cols=n_cols, n_codes=D)
+
+
+def _cnt_np(rowptr, code, n_cols, D):
+    n = len(rowptr) - 1
+    cnt = np.zeros((n, D), dtype=np.int64)
+    for i in range(n):
+        seg = code[rowptr[i]:rowptr[i + 1]]
+        cnt[i, :D - 1] = np.bincount(seg, minlength=D - 1)[:D - 1]
+        cnt[i, D - 1] = n_cols - len(seg)
+    return cnt
+
+
+@pytest.mark.parametrize("W,Cw", [(1, 1), (3, 1), (3, 3), (7, 7), (8, 1), (40, 40), (40, 8), (64, 1), (100, 1), (300, 1)])
+@pytest.mark.parametrize("K,use_cnt,per_row", [(1, True, False), (2, False, False), (5, True, False), (1, False, True)])
+def test_spmm_csr_vs_oracle(W, Cw, K, use_cnt, per_row):
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(W * 10 + K)
+    n_rows, n_cols, D = 301, 257, K + 2
+    rowptr, col, code = _random_csr(n_rows, n_cols, K, rng, hubs=[(5, 700), (17, 2500)])
+    cnt = _cnt_np(rowptr, code, n_cols, D)
+    S = torch.from_numpy(rng.standard_normal((n_cols, W)).astype(np.float32))
+    lut = torch.from_numpy(rng.standard_normal((n_rows, D, Cw) if per_row else (D, Cw)).astype(np.float32))
+    wt64 = (lut.double() if per_row else O.weight_table(lut.double(), cnt if use_cnt else None)
+            .expand(n_rows, -1, -1))
+    truth = O.spmm_csr(rowptr, col, code, S.double(), wt64)
+    g = _graph(rowptr, col, code, n_cols, D, torch.int32 if W % 2 else torch.int64)
+    assert np.array_equal(g.cnt.cpu().numpy(), cnt)
+    y = spmm_launch(g, S.to(DEV), lut.to(DEV), use_cnt, with_rest=True).cpu()
+    assert O.rel_err(y, truth) <= 1e-5, O.rel_err(y, truth)
+
+
+def test_spmm_row_subset_and_dense_equals_csr():
+    from gnan_amd import HopGraph
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(7)
+    n, D, W = 90, 6, 5
+    hops = rng.integers(-1, D - 1, (n, n)).astype(np.int32)          # -1 = unreachable
+    nd = torch.zeros(n, n)
+    nd[torch.from_numpy(hops >= 0)] = 1.0 / (torch.from_numpy(hops[hops >= 0]).float() + 1.0)
+    dense = HopGraph.from_dense(nd.to(DEV))
+    rowptr, col, code = O.csr_from_hops(hops, D - 2)
+    csr = _graph(rowptr, col, code, n, dense.n_codes)
+    assert np.array_equal(csr.cnt.cpu().numpy(), dense.cnt.cpu().numpy())
+    S = torch.randn(n, W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    lut = torch.randn(dense.n_codes, 1, generator=torch.Generator().manual_seed(4)).to(DEV)
+    y_dense = spmm_launch(dense, S, lut, True, with_rest=False)
+    y_csr = spmm_launch(csr, S, lut, True, with_rest=True)
+    assert O.rel_err(y_csr.cpu(), y_dense.cpu().double()) <= 2e-6
+    ids = torch.tensor([4, 0, 77, 4], dtype=torch.int32, device=DEV)
+    y_sub = spmm_launch(dense, S, lut, True, with_rest=False, row_ids=ids)
+    assert torch.equal(y_sub, y_dense[ids.long()])                       # same arithmetic, bit-identical
+    y_sub = spmm_launch(csr, S, lut, True, with_rest=True, row_ids=ids)
+    assert torch.equal(y_sub, y_csr[ids.long()])
+
+
+def test_spmm_is_linear_in_the_operand_at_scale():
+    """Size-independent property at a size the oracle cannot reach: A(aS1 + S2) == a A S1 + A S2."""
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(11)
+    n, K, W = 200_000, 1, 64
+    deg = np.minimum(rng.zipf(1.8, n), 50_000)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    g = _graph(rowptr, rng.integers(0, n, nnz).astype(np.int32), rng.integers(0, K + 1, nnz).astype(np.uint8), n, K + 2)
+    S1 = torch.randn(n, W, device=DEV)
+    S2 = torch.randn(n, W, device=DEV)
+    lut = torch.tensor([[1.0], [0.5], [0.01]], device=DEV)
+    y = spmm_launch(g, 2.0 * S1 + S2, lut, True, True)
+    y12 = 2.0 * spmm_launch(g, S1, lut, True, True) + spmm_launch(g, S2, lut, True, True)
+    scale = float(y12.abs().max())
+    assert float((y - y12).abs().max()) <= 2e-5 * scale
+    # deterministic: the hub-row slices are reduced in a fixed order
+    assert torch.equal(y, spmm_launch(g, 2.0 * S1 + S2, lut, True, True))
+
+
+def test_empty_inputs():
+    from gnan_amd.functional import spmm_launch
+    g = _graph(np.zeros(1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0, np.uint8), 5, 3)
+    y = spmm_launch(g, torch.randn(5, 4, device=DEV), torch.randn(3, 1, device=DEV), True, True)
+    assert y.shape == (0, 4)
+
+
+@pytest.mark.parametrize("per_row,use_cnt,Cw", [(False, True, 1), (False, False, 3), (True, False, 3)])
+def test_rho_aggregate_gradients_vs_autograd_oracle(per_row, use_cnt, Cw):
+    """Backward kernels (transposed SpMM + shell sums) vs torch autograd through the oracle, in float64."""
+    from gnan_amd.functional import rho_aggregate
+    rng = np.random.default_rng(5)
+    n, K, W = 120, 2, 6
+    D = K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(3, 900)])
+    cnt = _cnt_np(rowptr, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n, W)))
+    lut = torch.from_numpy(rng.standard_normal((n, D, Cw) if per_row else (D, Cw)))
+    S64, lut64 = S.clone().requires_grad_(True), lut.clone().requires_grad_(True)
+    wt = lut64 if per_row else O.weight_table(lut64, cnt if use_cnt else None).expand(n, -1, -1)
+    O.spmm_csr(rowptr, col, code, S64, wt).pow(2).sum().backward()
+    g = _graph(rowptr, col, code, n, D)
+    Sd = S.float().to(DEV).requires_grad_(True)
+    lutd = lut.float().to(DEV).requires_grad_(True)
+    rho_aggregate(g, Sd, lutd, use_cnt).pow(2).sum().backward()
+    assert O.rel_err(Sd.grad.cpu(), S64.grad) <= 2e-5
+    assert O.rel_err(lutd.grad.cpu(), lut64.grad) <= 2e-5
