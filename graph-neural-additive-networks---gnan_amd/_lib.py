@@ -13,9 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GNAN_F32, GNAN_BF16 = 0, 1
+FMLP_AUTO, FMLP_LANE, FMLP_MFMA = 0, 1, 2
 MAX_CODES = 256
 
 
@@ -31,6 +32,7 @@ class FmlpArgs(C.Structure):
         ("w_last", C.c_void_p), ("b_last", C.c_void_p),
         ("sum_features", C.c_int32),
         ("out", C.c_void_p), ("out_stride", C.c_int64),
+        ("algo", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -56,6 +58,7 @@ _lib: Optional[C.CDLL] = None
 SYMBOLS = {
     "gnan_abi_version": (C.c_int, []),
     "gnan_last_error": (C.c_char_p, []),
+    "gnan_fmlp_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpArgs)]),
     "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),

@@ -65,6 +65,9 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.detach().float().contiguous()
 
 
+FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to compare the lane kernel with the matrix-core kernel
+
+
 def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
     x = x.detach().float()
     if x.stride(1) != 1:
@@ -76,7 +79,11 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Te
     a = _lib.FmlpArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=p.F, L=p.L, H=p.H, C=p.C,
                       w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]), w_mid=_lib.ptr(keep[2]),
                       b_mid=_lib.ptr(keep[3]), w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]),
-                      sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0))
+                      sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0), algo=FMLP_ALGO)
+    need = _lib.lib().gnan_fmlp_fwd_workspace_bytes(a)
+    if need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)   # packed weights (caching allocator)
+        a.workspace, a.workspace_bytes = _lib.ptr(ws), need
     _lib.check(_lib.lib().gnan_fmlp_fwd(a, _lib.stream_of(x)), "gnan_fmlp_fwd")
     return out
 

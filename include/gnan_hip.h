@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 1
+#define GNAN_ABI_VERSION 2
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -74,8 +74,14 @@ typedef struct gnan_fmlp_args {
   int32_t sum_features;
   float* out;            /* [n, out_stride] */
   int64_t out_stride;
+  int32_t algo;          /* gnan_fmlp_algo; AUTO picks the matrix-core kernel when the shape allows */
+  void* workspace;       /* packed weights for the matrix-core kernel, 16-byte aligned */
+  size_t workspace_bytes;
 } gnan_fmlp_args;
 
+enum gnan_fmlp_algo { GNAN_FMLP_AUTO = 0, GNAN_FMLP_LANE = 1, GNAN_FMLP_MFMA = 2 };
+
+size_t gnan_fmlp_fwd_workspace_bytes(const gnan_fmlp_args* a);
 int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

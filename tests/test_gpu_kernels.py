@@ -47,10 +47,15 @@ def _stack(sd, F, L, H, C, bias):
 @pytest.mark.parametrize("F,L,H,C,bias", [
     (3, 1, 0, 2, True), (4, 2, 8, 3, True), (5, 3, 8, 1, True), (9, 3, 32, 5, False),
     (15, 3, 64, 1, True), (7, 4, 16, 7, True), (3, 3, 20, 40, True), (64, 3, 64, 1, True),
+    (6, 3, 33, 2, True), (5, 4, 64, 8, False), (2, 5, 16, 3, True), (3, 3, 96, 2, True), (1, 3, 64, 4, True),
 ])
 @pytest.mark.parametrize("sum_features", [True, False])
-def test_feature_mlps_vs_oracle(F, L, H, C, bias, sum_features):
+@pytest.mark.parametrize("algo", ["lane", "auto"])
+def test_feature_mlps_vs_oracle(F, L, H, C, bias, sum_features, algo, monkeypatch):
+    """Both kernels (lane-per-node fallback and the matrix-core kernel AUTO picks for 3<=L<=4, H<=64, C<=8)."""
+    from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_LANE if algo == "lane" else _lib.FMLP_AUTO)
     n = 203
     sd = _mlp_state(F, L, max(H, 1), C, bias, seed=F * 100 + L)
     x = torch.rand(n, F, generator=torch.Generator().manual_seed(1))
@@ -187,3 +192,32 @@ def test_rho_aggregate_gradients_vs_autograd_oracle(per_row, use_cnt, Cw):
     rho_aggregate(g, Sd, lutd, use_cnt).pow(2).sum().backward()
     assert O.rel_err(Sd.grad.cpu(), S64.grad) <= 2e-5
     assert O.rel_err(lutd.grad.cpu(), lut64.grad) <= 2e-5
+
+
+def test_matrix_core_kernel_is_the_one_auto_picks_and_rejects_foreign_shapes(monkeypatch):
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)
+    sd = _mlp_state(2, 3, 96, 1, True, seed=0)                  # H = 96 > 64: outside the MFMA kernel
+    x = torch.rand(10, 2, device=DEV)
+    with pytest.raises(_lib.GnanHipError, match="MFMA path covers"):
+        feature_mlps(x, _stack(sd, 2, 3, 96, 1, True), True)
+    sd = _mlp_state(2, 3, 64, 1, True, seed=0)
+    y_mfma = feature_mlps(x, _stack(sd, 2, 3, 64, 1, True), True)
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_LANE)
+    y_lane = feature_mlps(x, _stack(sd, 2, 3, 64, 1, True), True)
+    assert O.rel_err(y_mfma.cpu(), y_lane.cpu().double()) <= 2e-6
+
+
+def test_feature_mlps_large_ragged_batch():
+    """Property check at a size the oracle would take minutes for: two disjoint halves == the whole."""
+    from gnan_amd.functional import feature_mlps
+    F, L, H, C = 64, 3, 64, 1
+    sd = _mlp_state(F, L, H, C, True, seed=9)
+    st = _stack(sd, F, L, H, C, True)
+    x = torch.rand(100_003, F, device=DEV)
+    whole = feature_mlps(x, st, False)
+    assert torch.equal(whole[:50_001], feature_mlps(x[:50_001], st, False))
+    assert torch.equal(whole[50_001:], feature_mlps(x[50_001:], st, False))
+    sub = O.feature_mlps(x[:97].cpu().double(), {k: v.double() for k, v in sd.items()}).reshape(97, -1)
+    assert O.rel_err(whole[:97].cpu(), sub) <= 1e-5
