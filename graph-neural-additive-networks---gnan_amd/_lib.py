@@ -13,10 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GNAN_F32, GNAN_BF16 = 0, 1
-FMLP_AUTO, FMLP_LANE, FMLP_MFMA = 0, 1, 2
+FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
 MAX_CODES = 256
 
 
@@ -33,6 +33,15 @@ class FmlpArgs(C.Structure):
         ("sum_features", C.c_int32),
         ("out", C.c_void_p), ("out_stride", C.c_int64),
         ("algo", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class FpwlArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("n", C.c_int64), ("x_stride", C.c_int64), ("F", C.c_int32), ("C", C.c_int32),
+        ("off", C.c_void_p), ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p),
+        ("max_pieces", C.c_int32), ("features_per_group", C.c_int32), ("max_group_pieces", C.c_int32),
+        ("sum_features", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64),
     ]
 
 
@@ -60,6 +69,7 @@ SYMBOLS = {
     "gnan_last_error": (C.c_char_p, []),
     "gnan_fmlp_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpArgs)]),
     "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
+    "gnan_fpwl_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),

@@ -65,10 +65,41 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.detach().float().contiguous()
 
 
-FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to compare the lane kernel with the matrix-core kernel
+FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to pin one of the three evaluation strategies
+PWL_MIN_WORK = 1 << 24       # AUTO tabulates the shape functions once n*F look-ups outweigh the table build
 
 
-def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
+def _fpwl_launch(x: torch.Tensor, t, sum_features: bool) -> torch.Tensor:
+    """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``."""
+    x = x.detach().float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    n, F = x.shape
+    C = t.val.shape[1]
+    out = torch.empty((n, C if sum_features else F * C), dtype=torch.float32, device=x.device)
+    a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
+                      anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
+                      max_pieces=t.max_pieces, features_per_group=t.features_per_group,
+                      max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
+                      out=_lib.ptr(out), out_stride=out.stride(0))
+    _lib.check(_lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)), "gnan_fpwl_fwd")
+    return out
+
+
+def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool) -> torch.Tensor:
+    """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise."""
+    algo = FMLP_ALGO
+    if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= PWL_MIN_WORK):
+        from .pwl import build_tables
+        tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
+        if tables is not None:
+            return _fpwl_launch(x, tables, sum_features)
+        if algo == _lib.FMLP_PWL:
+            raise _lib.GnanHipError("shape functions need more pieces than the look-up kernel supports")
+    return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo)
+
+
+def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int = 0) -> torch.Tensor:
     x = x.detach().float()
     if x.stride(1) != 1:
         x = x.contiguous()
@@ -79,7 +110,7 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Te
     a = _lib.FmlpArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=p.F, L=p.L, H=p.H, C=p.C,
                       w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]), w_mid=_lib.ptr(keep[2]),
                       b_mid=_lib.ptr(keep[3]), w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]),
-                      sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0), algo=FMLP_ALGO)
+                      sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0), algo=algo)
     need = _lib.lib().gnan_fmlp_fwd_workspace_bytes(a)
     if need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)   # packed weights (caching allocator)
@@ -124,7 +155,7 @@ class _FeatureMLPs(torch.autograd.Function):
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
-        return _fmlp_launch(x, p, sum_features)
+        return _fmlp_forward(x, p, sum_features)
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -1,0 +1,187 @@
+"""Exact piecewise-linear tables of the per-feature shape functions.
+
+Each ``f_k : R -> R^C`` is a ReLU MLP of a SCALAR input (GNAN.py:24-34), hence exactly piecewise linear in
+``x``: its kinks are the points where some hidden unit's pre-activation crosses zero.  For the reference's
+default depth the count is small (H kinks from the first layer plus a handful per later unit — ~130 for
+H = 64, L = 3), so ``f_k`` can be tabulated *exactly*, once per forward, from the current weights:
+
+    f_k(x) = val[i] + slope[i] * (x - anchor[i]),      i = #{ breakpoints of f_k <= x }
+
+and evaluating N x F shape functions becomes N x F table look-ups (``gnan_fpwl_fwd``) instead of
+2·N·F·H² flops.  This is the same idea the aggregation uses for rho (evaluate the network only where its
+argument can actually change behaviour), applied to ``f``.
+
+The tables are built here with a few batched float64 torch ops on the device (O(F · P · H²) flops, P ~ 10²);
+kink positions are found layer by layer from sign changes of the pre-activations between consecutive
+breakpoints (each pre-activation is affine there), and the table values are the network itself evaluated in
+float64 at the float32-rounded breakpoints — so the tabulated function agrees with the float64 reference to
+float32 round-off, independent of N.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+
+
+MAX_PIECES = 4096          # per feature; beyond this the tabulation is refused (use the matrix-core kernel)
+
+
+LDS_PREFERRED = 48 * 1024  # table bytes per feature group that still leaves >= 3 workgroups per CU
+LDS_LIMIT = 150 * 1024
+
+
+class PwlTables(NamedTuple):
+    off: torch.Tensor      # int32 [F + 1]   piece offsets; feature k owns pieces off[k] .. off[k+1]-1
+    anchor: torch.Tensor   # fp32  [T]       anchor[off[k] + i] = left breakpoint of piece i (piece 0: the first breakpoint)
+    val: torch.Tensor      # fp32  [T, C]    f_k(anchor)
+    slope: torch.Tensor    # fp32  [T, C]
+    max_pieces: int
+    features_per_group: int   # consecutive features sharing one LDS image in gnan_fpwl_fwd
+    max_group_pieces: int
+
+
+def _plan_groups(off, C):
+    """Largest power-of-two group (<= 16 features) whose tables fit the preferred LDS budget."""
+    F = len(off) - 1
+    best = None
+    for fg in (16, 8, 4, 2, 1):
+        mg = max(off[min(F, k + fg)] - off[k] for k in range(0, F, fg))
+        nbytes = mg * (1 + 2 * C) * 4
+        if nbytes <= LDS_PREFERRED:
+            return fg, mg
+        if nbytes <= LDS_LIMIT and best is None:
+            best = (fg, mg)
+    return best
+
+
+def _prefix(x: torch.Tensor, p, depth: int, w, b):
+    """Pre-activations of hidden layer ``depth`` (0-based) at points ``x [F, M]`` -> ``[F, M, H]`` (float64)."""
+    z = x.unsqueeze(-1) * w[0].unsqueeze(1)
+    if b[0] is not None:
+        z = z + b[0].unsqueeze(1)
+    for l in range(1, depth + 1):
+        z = torch.bmm(torch.relu(z), w[l].transpose(1, 2))
+        if b[l] is not None:
+            z = z + b[l].unsqueeze(1)
+    return z
+
+
+def _network(x: torch.Tensor, p, w, b, w_last, b_last):
+    """Full ``f_k`` at ``x [F, M]`` -> ``[F, M, C]`` in float64."""
+    if p.L == 1:
+        y = x.unsqueeze(-1) * w_last.unsqueeze(1)
+    else:
+        h = torch.relu(_prefix(x, p, p.L - 2, w, b))
+        y = torch.bmm(h, w_last.transpose(1, 2))
+    if b_last is not None:
+        y = y + b_last.unsqueeze(1)
+    return y
+
+
+@torch.no_grad()
+def build_tables(p) -> Optional[PwlTables]:
+    """Tabulate all F shape functions; returns None if some feature needs more than MAX_PIECES pieces."""
+    dev = p.w_last.device
+    f64 = torch.float64
+    F = p.F
+    INF = float("inf")
+    if p.L >= 2:
+        w = [p.w_first.to(f64)] + [p.w_mid[l].to(f64) for l in range(p.L - 2)]
+        b = [None if p.b_first is None else p.b_first.to(f64)] + \
+            [None if p.b_mid is None else p.b_mid[l].to(f64) for l in range(p.L - 2)]
+    else:
+        w, b = [], []
+    w_last = p.w_last.to(f64)
+    b_last = None if p.b_last is None else p.b_last.to(f64)
+
+    bp = torch.full((F, 0), INF, dtype=f64, device=dev)             # sorted breakpoints, +inf padded
+    for depth in range(p.L - 1):                                     # every hidden layer adds its units' zero crossings
+        if depth == 0:
+            b0 = b[0] if b[0] is not None else torch.zeros_like(w[0])
+            new = torch.where(w[0] != 0, -b0 / w[0], torch.full_like(w[0], INF))       # [F, H]
+        else:
+            finite = torch.isfinite(bp)
+            any_f = finite.any(dim=1, keepdim=True)
+            t_first = torch.where(any_f, bp[:, :1], torch.zeros_like(bp[:, :1]))
+            t_last = torch.where(any_f, torch.where(finite, bp, torch.full_like(bp, -INF)).amax(dim=1, keepdim=True),
+                                 torch.zeros_like(bp[:, :1]))
+            pad = torch.where(finite, bp, t_last.expand_as(bp))
+            nodes = torch.cat([t_first - 2, t_first - 1, pad, t_last + 1, t_last + 2], dim=1)     # [F, P + 4]
+            z = _prefix(nodes, p, depth, w, b)                                                    # [F, P + 4, H]
+            e0, e1 = nodes[:, :-1].unsqueeze(-1), nodes[:, 1:].unsqueeze(-1)
+            z0, z1 = z[:, :-1], z[:, 1:]
+            inside = (z0 * z1) < 0                                   # sign change strictly inside (e0, e1)
+            root = e0 + (e1 - e0) * (z0 / (z0 - z1))
+            new_in = torch.where(inside, root, torch.full_like(root, INF))
+            # rays: extrapolate the affine piece beyond the outermost sample points
+            dl = z[:, 1] - z[:, 0]
+            rl = nodes[:, :1] - z[:, 0] / dl * (nodes[:, 1:2] - nodes[:, :1])
+            ok_l = (dl != 0) & (z[:, 0] / dl > 0)
+            dr = z[:, -1] - z[:, -2]
+            rr = nodes[:, -1:] - z[:, -1] / dr * (nodes[:, -1:] - nodes[:, -2:-1])
+            ok_r = (dr != 0) & (z[:, -1] / dr < 0)
+            new = torch.cat([new_in.reshape(F, -1), torch.where(ok_l, rl, torch.full_like(rl, INF)),
+                             torch.where(ok_r, rr, torch.full_like(rr, INF))], dim=1)
+        new = torch.where(torch.isfinite(new), new, torch.full_like(new, INF))       # NaN / -inf -> dropped
+        bp, _ = torch.sort(torch.cat([bp, new], dim=1), dim=1)
+        keep = max(1, int(torch.isfinite(bp).sum(dim=1).max()))
+        if keep > MAX_PIECES - 1:
+            return None
+        bp = bp[:, :keep]
+    if bp.shape[1] == 0:                                             # L == 1: affine, no kinks
+        bp = torch.full((F, 1), INF, dtype=f64, device=dev)
+
+    # float32 anchors (what the kernel compares x against), network values there in float64
+    bp32 = torch.where(torch.isfinite(bp), bp.clamp(-3.0e38, 3.0e38), bp).float()
+    finite = torch.isfinite(bp32)
+    n_bp = finite.sum(dim=1)                                          # [F]
+    P = bp32.shape[1]
+    t = bp32.to(f64)
+    any_f = (n_bp > 0).unsqueeze(1)
+    t_first = torch.where(any_f, t[:, :1], torch.zeros((F, 1), dtype=f64, device=dev))
+    t_last = torch.where(any_f, torch.where(finite, t, torch.full_like(t, -INF)).amax(dim=1, keepdim=True),
+                         torch.zeros_like(t_first))
+    tp = torch.where(finite, t, t_last.expand_as(t))
+    nodes = torch.cat([t_first - 1, tp, t_last + 1], dim=1)          # [F, P + 2]
+    v = _network(nodes, p, w, b, w_last, b_last)                     # [F, P + 2, C]
+    width = (nodes[:, 1:] - nodes[:, :-1]).unsqueeze(-1)             # [F, P + 1, 1]
+    sl = torch.where(width > 0, (v[:, 1:] - v[:, :-1]) / width, torch.zeros_like(v[:, 1:]))   # slope of piece i
+    # piece i (0..P): anchor = its left breakpoint, except piece 0 which is anchored at the first breakpoint
+    anchor = torch.cat([nodes[:, 1:2], nodes[:, 1:-1]], dim=1)       # [F, P + 1]
+    val = torch.cat([v[:, 1:2], v[:, 1:-1]], dim=1)                  # [F, P + 1, C]
+    # features with fewer breakpoints: their trailing pieces are zero-width copies; keep only n_bp + 1 pieces
+    pieces = n_bp + 1
+    # the right ray's slope lives at index n_bp of `sl` only when n_bp == P; gather it per feature
+    idx = torch.arange(P + 1, device=dev).unsqueeze(0)
+    ray = sl[:, -1:].expand(-1, P + 1, -1)
+    sl = torch.where((idx == n_bp.unsqueeze(1)).unsqueeze(-1), ray, sl)
+    keep = idx < pieces.unsqueeze(1)
+    off = torch.zeros(F + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(pieces, 0)
+    C = val.shape[-1]
+    off_host = off.tolist()                                          # one small D2H copy: sizes the LDS images
+    plan = _plan_groups(off_host, C)
+    if plan is None:
+        return None
+    return PwlTables(off.to(torch.int32), anchor[keep].float().contiguous(), val[keep].float().reshape(-1, C).contiguous(),
+                     sl[keep].float().reshape(-1, C).contiguous(), max(b - a for a, b in zip(off_host, off_host[1:])),
+                     plan[0], plan[1])
+
+
+def evaluate_reference(x: torch.Tensor, t: PwlTables, sum_features: bool) -> torch.Tensor:
+    """Plain-torch evaluation of the tables (used by the CPU tests of the table builder; the product path
+    evaluates them with ``gnan_fpwl_fwd``)."""
+    n, F = x.shape
+    C = t.val.shape[1]
+    out = x.new_zeros((n, C) if sum_features else (n, F * C))
+    off = t.off.tolist()
+    for k in range(F):
+        a = t.anchor[off[k]:off[k + 1]]
+        i = torch.searchsorted(a[1:].contiguous(), x[:, k].contiguous(), right=True)
+        y = t.val[off[k]:off[k + 1]][i] + t.slope[off[k]:off[k + 1]][i] * (x[:, k] - a[i]).unsqueeze(1)
+        if sum_features:
+            out += y
+        else:
+            out[:, k * C:(k + 1) * C] = y
+    return out

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 2
+#define GNAN_ABI_VERSION 3
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -83,6 +83,37 @@ enum gnan_fmlp_algo { GNAN_FMLP_AUTO = 0, GNAN_FMLP_LANE = 1, GNAN_FMLP_MFMA = 2
 
 size_t gnan_fmlp_fwd_workspace_bytes(const gnan_fmlp_args* a);
 int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Shape functions by exact piecewise-linear table look-up — same outputs as gnan_fmlp_fwd.
+ * Each f_k (a ReLU MLP of a scalar, GNAN.py:24-34) is exactly piecewise linear; the caller tabulates it
+ * from the current weights (gnan_amd/pwl.py) and this kernel evaluates
+ *     f_k(x)[c] = val[i, c] + slope[i, c] * (x - anchor[i]),   i = off[k] + #{ j in 1..P_k : anchor[off[k]+j] <= x }
+ * for every (node, feature): replaces GNAN.py:57-62 by N*F binary searches in LDS.
+ *   off [F+1] int32 piece offsets (feature k has P_k + 1 = off[k+1]-off[k] pieces, P_k breakpoints
+ *   anchor[off[k]+1 .. off[k]+P_k], ascending); anchor [T]; val, slope [T, C].
+ *   max_pieces       = max_k (off[k+1]-off[k])
+ *   features_per_group in {1,2,4,8,16}: consecutive features whose tables share one LDS image;
+ *   max_group_pieces = max over groups of the pieces in the group (sizes the LDS image).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gnan_fpwl_args {
+  const float* x;          /* [n, F] */
+  int64_t n;
+  int64_t x_stride;
+  int32_t F, C;
+  const int32_t* off;
+  const float* anchor;
+  const float* val;
+  const float* slope;
+  int32_t max_pieces;
+  int32_t features_per_group;
+  int32_t max_group_pieces;
+  int32_t sum_features;    /* as gnan_fmlp_args */
+  float* out;
+  int64_t out_stride;
+} gnan_fpwl_args;
+
+int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rho(distance)-weighted neighbourhood sum over a hop-coded adjacency

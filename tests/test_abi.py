@@ -40,7 +40,8 @@ def test_abi_version_and_error_channel():
 def test_struct_layout_matches_header():
     """Field order of the ctypes structs == field order of the C structs (names must line up)."""
     text = open(os.path.join(ROOT, "include", "gnan_hip.h")).read()
-    for struct, cls in (("gnan_fmlp_args", _lib.FmlpArgs), ("gnan_spmm_args", _lib.SpmmArgs)):
+    for struct, cls in (("gnan_fmlp_args", _lib.FmlpArgs), ("gnan_spmm_args", _lib.SpmmArgs),
+                        ("gnan_fpwl_args", _lib.FpwlArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

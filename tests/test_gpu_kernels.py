@@ -50,12 +50,14 @@ def _stack(sd, F, L, H, C, bias):
     (6, 3, 33, 2, True), (5, 4, 64, 8, False), (2, 5, 16, 3, True), (3, 3, 96, 2, True), (1, 3, 64, 4, True),
 ])
 @pytest.mark.parametrize("sum_features", [True, False])
-@pytest.mark.parametrize("algo", ["lane", "auto"])
+@pytest.mark.parametrize("algo", ["lane", "auto", "pwl"])
 def test_feature_mlps_vs_oracle(F, L, H, C, bias, sum_features, algo, monkeypatch):
-    """Both kernels (lane-per-node fallback and the matrix-core kernel AUTO picks for 3<=L<=4, H<=64, C<=8)."""
+    """All three strategies: lane-per-node kernel, the matrix-core kernel AUTO picks for 3<=L<=4, H<=64,
+    C<=8 at this size, and the exact piecewise-linear table look-up AUTO picks for large batches."""
     from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
-    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_LANE if algo == "lane" else _lib.FMLP_AUTO)
+    monkeypatch.setattr(functional, "FMLP_ALGO",
+                        {"lane": _lib.FMLP_LANE, "auto": _lib.FMLP_AUTO, "pwl": _lib.FMLP_PWL}[algo])
     n = 203
     sd = _mlp_state(F, L, max(H, 1), C, bias, seed=F * 100 + L)
     x = torch.rand(n, F, generator=torch.Generator().manual_seed(1))
@@ -209,9 +211,12 @@ def test_matrix_core_kernel_is_the_one_auto_picks_and_rejects_foreign_shapes(mon
     assert O.rel_err(y_mfma.cpu(), y_lane.cpu().double()) <= 2e-6
 
 
-def test_feature_mlps_large_ragged_batch():
+@pytest.mark.parametrize("algo", ["mfma", "pwl"])
+def test_feature_mlps_large_ragged_batch(algo, monkeypatch):
     """Property check at a size the oracle would take minutes for: two disjoint halves == the whole."""
+    from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA if algo == "mfma" else _lib.FMLP_PWL)
     F, L, H, C = 64, 3, 64, 1
     sd = _mlp_state(F, L, H, C, True, seed=9)
     st = _stack(sd, F, L, H, C, True)
@@ -221,3 +226,22 @@ def test_feature_mlps_large_ragged_batch():
     assert torch.equal(whole[50_001:], feature_mlps(x[50_001:], st, False))
     sub = O.feature_mlps(x[:97].cpu().double(), {k: v.double() for k, v in sd.items()}).reshape(97, -1)
     assert O.rel_err(whole[:97].cpu(), sub) <= 1e-5
+
+
+def test_table_lookup_matches_matrix_core_kernel_at_scale(monkeypatch):
+    """1M nodes x 64 features: the two independent evaluation strategies agree to fp32 round-off."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    F, L, H, C = 64, 3, 64, 1
+    sd = _mlp_state(F, L, H, C, True, seed=4)
+    st = _stack(sd, F, L, H, C, True)
+    x = torch.rand(1_000_000, F, device=DEV) * 3 - 1
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)
+    a = feature_mlps(x, st, False)
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    b = feature_mlps(x, st, False)
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    sa, sb = feature_mlps(x, st, True), None
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)
+    sb = feature_mlps(x, st, True)
+    assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())

@@ -1,0 +1,90 @@
+"""CPU tests of the piecewise-linear tabulation of the shape functions (gnan_amd/pwl.py) against the oracle.
+
+The table *builder* is plain torch and runs anywhere; the product evaluates the tables with the HIP kernel
+gnan_fpwl_fwd (covered by the GPU tests).  Here the tables are evaluated by pwl.evaluate_reference."""
+import pytest
+import torch
+
+import gnan_amd  # noqa: F401
+from gnan_amd import pwl
+from gnan_amd.functional import StackedMLP
+from oracle import gnan_oracle as O
+
+
+def mlp_state(F, L, H, C, bias, seed, w_scale=1.0, b_scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k in range(F):
+        dims = [1] + [H] * (L - 1) + [C]
+        for li in range(L):
+            sd[f"fs.{k}.{3 * li}.weight"] = torch.randn(dims[li + 1], dims[li], generator=g) * w_scale * (2.0 / (dims[li] + dims[li + 1])) ** 0.5
+            if bias:
+                sd[f"fs.{k}.{3 * li}.bias"] = torch.randn(dims[li + 1], generator=g) * b_scale
+    return sd
+
+
+def stack(sd, F, L, H, C, bias):
+    def cat(li, what):
+        return torch.stack([sd[f"fs.{k}.{3 * li}.{what}"] for k in range(F)], 0)
+    if L == 1:
+        return StackedMLP(None, None, None, None, cat(0, "weight")[..., 0], cat(0, "bias") if bias else None, 1, 0, C, F)
+    w_mid = b_mid = None
+    if L > 2:
+        w_mid = torch.stack([cat(li, "weight") for li in range(1, L - 1)], 0)
+        b_mid = torch.stack([cat(li, "bias") for li in range(1, L - 1)], 0) if bias else None
+    return StackedMLP(cat(0, "weight")[..., 0], cat(0, "bias") if bias else None, w_mid, b_mid,
+                      cat(L - 1, "weight"), cat(L - 1, "bias") if bias else None, L, H, C, F)
+
+
+def probe_points(n, F, seed):
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(seed)) * 4 - 2
+    x[:8, :] = torch.tensor([0.0, 1.0, -1.0, 0.5, 100.0, -100.0, 1e-8, -0.0]).unsqueeze(1)
+    return x
+
+
+@pytest.mark.parametrize("F,L,H,C,bias", [
+    (3, 1, 0, 2, True), (4, 2, 8, 3, True), (5, 3, 8, 1, True), (9, 3, 32, 5, False), (15, 3, 64, 1, True),
+    (7, 4, 16, 7, True), (3, 3, 20, 40, True), (2, 5, 16, 3, True), (6, 3, 33, 2, False),
+])
+def test_tables_reproduce_the_mlp(F, L, H, C, bias):
+    sd = mlp_state(F, L, max(H, 1), C, bias, seed=F * 100 + L)
+    t = pwl.build_tables(stack(sd, F, L, H, C, bias))
+    assert t is not None
+    n = 4000
+    x = probe_points(n, F, 1)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(n, -1)
+    ref32 = O.feature_mlps(x, sd).reshape(n, -1)
+    y = pwl.evaluate_reference(x, t, False)
+    assert O.rel_err(y, truth) <= max(1e-5, O.rel_err(ref32, truth))
+    ys = pwl.evaluate_reference(x, t, True)
+    assert O.rel_err(ys, truth.reshape(n, F, C).sum(1)) <= 1e-5
+
+
+def test_degenerate_kinks_and_dead_units():
+    """Zero biases put every first-layer kink at x = 0; zero first-layer weights create units without a kink."""
+    F, L, H, C = 4, 3, 16, 2
+    sd = mlp_state(F, L, H, C, True, seed=3, b_scale=0.0)
+    sd["fs.1.0.weight"][::2] = 0.0                         # dead / constant units
+    sd["fs.2.0.bias"] += 0.3
+    t = pwl.build_tables(stack(sd, F, L, H, C, True))
+    x = probe_points(2000, F, 2)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(2000, -1)
+    assert torch.isfinite(t.slope).all() and torch.isfinite(t.val).all()
+    assert O.rel_err(pwl.evaluate_reference(x, t, False), truth) <= 1e-5
+
+
+def test_reference_initialisation_scale():
+    """The upstream init (xavier gain 0.01, zero bias: GNAN.py:49-53) gives ~1e-6-scale outputs; still exact."""
+    F, L, H, C = 6, 3, 64, 1
+    sd = mlp_state(F, L, H, C, True, seed=5, w_scale=0.01, b_scale=0.0)
+    t = pwl.build_tables(stack(sd, F, L, H, C, True))
+    x = torch.rand(3000, F)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(3000, -1)
+    assert O.rel_err(pwl.evaluate_reference(x, t, False), truth) <= 1e-5
+
+
+def test_piece_count_is_small_for_default_shapes():
+    F, L, H, C = 64, 3, 64, 1
+    t = pwl.build_tables(stack(mlp_state(F, L, H, C, True, seed=0), F, L, H, C, True))
+    assert t.max_pieces <= 4 * H                           # ~2H in practice: H first-layer kinks + ~1 per second-layer unit
+    assert t.features_per_group == 16 and t.max_group_pieces * 12 <= pwl.LDS_PREFERRED
