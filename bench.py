@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--out", type=int, default=1)
     ap.add_argument("--order", default="reference", choices=["reference", "sum_first"])
+    ap.add_argument("--fmlp-algo", default="auto", choices=["auto", "lane", "mfma", "pwl"],
+                    help="shape-function strategy: auto = exact table look-up at this size; mfma = fp32 matrix cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="nodes of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
@@ -108,8 +110,11 @@ def main():
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
     from gnan_amd.distributed import VertexPartition, partitioned_forward
+    from gnan_amd import _lib, functional
     from gnan_amd.functional import stack_mlps
     from gnan_amd.graph import hop_inputs
+    functional.FMLP_ALGO = {"auto": _lib.FMLP_AUTO, "lane": _lib.FMLP_LANE, "mfma": _lib.FMLP_MFMA,
+                            "pwl": _lib.FMLP_PWL}[args.fmlp_algo]
     from gnan_amd.models import TensorGNAN
 
     N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
@@ -135,7 +140,7 @@ def main():
     with torch.no_grad():
         stacked = stack_mlps(model.fs)
         lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
-    stage_names = ["fmlp", "gather", "spmm", "readout"]
+    stage_names = ["fmlp", "gather", "total", "spmm", "readout"]
     events = []
 
     def step(record):
@@ -210,7 +215,7 @@ def main():
             "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
             "fmlp_tflops": fmlp_flops(part.hi - part.lo, F, H, L, C) / (stages["fmlp"] / 1e3) / 1e12
             if stages["fmlp"] > 0 else None,
-            "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "fmlp_algo": args.fmlp_algo,
             "setup_s": t_setup, "checksum": float(out.double().sum()),
         }
         if world == 1 and not args.no_cpu_baseline:

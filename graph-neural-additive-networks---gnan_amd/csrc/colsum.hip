@@ -1,0 +1,88 @@
+// Column sums of the operand, total[w] = sum_j S[j, w] — the "everything" term of the rest bucket
+// (pairs not listed in the CSR get weight rho(0)/cnt_rest).  One streaming pass over S,
+// fp32 per-thread partials, float64 across threads and workgroups, fixed reduction order (deterministic).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlocks = 1024;
+
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ S, int64_t n, int W, int64_t stride,
+                                                             double* __restrict__ partial) {
+  // thread (cx, ry): column chunk cx of VEC floats, rows ry, ry + RY, ... inside this workgroup's row range
+  const int chunks = (W + VEC - 1) / VEC;
+  const int cpb = chunks < 256 ? chunks : 256;     // column chunks handled per pass
+  const int RY = 256 / cpb;
+  const int cx = threadIdx.x % cpb, ry = threadIdx.x / cpb;
+  __shared__ double red[256 * VEC];
+  const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  for (int c0 = 0; c0 < chunks; c0 += cpb) {
+    const int c = c0 + cx;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    if (c < chunks && ry < RY) {
+      for (int64_t r = r0 + ry; r < r1; r += RY) {
+        const float* ptr = S + r * stride + static_cast<int64_t>(c) * VEC;
+        if constexpr (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(ptr);
+          acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+        } else {
+          acc[0] += ptr[0];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) red[threadIdx.x * VEC + v] = acc[v];
+    __syncthreads();
+    if (ry == 0 && c < chunks) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        double s = 0.0;
+        for (int y = 0; y < RY; ++y) s += red[(y * cpb + cx) * VEC + v];
+        if (c * VEC + v < W) partial[static_cast<int64_t>(blockIdx.x) * W + c * VEC + v] = s;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int blocks, int W,
+                                                           float* __restrict__ total) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < W; w += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += partial[static_cast<int64_t>(b) * W + w];
+    total[w] = static_cast<float>(s);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t gnan_colsum_workspace_bytes(int32_t W) { return static_cast<size_t>(kBlocks) * W * sizeof(double); }
+
+extern "C" int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
+                           size_t workspace_bytes, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && W >= 1, "colsum: bad sizes");
+  GNAN_REQUIRE(S && total && workspace, "colsum: null pointer");
+  GNAN_REQUIRE(stride >= W, "colsum: row stride smaller than W");
+  if (workspace_bytes < gnan_colsum_workspace_bytes(W))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "colsum: workspace %zu B < required %zu B", workspace_bytes,
+                      gnan_colsum_workspace_bytes(W));
+  GNAN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 8 == 0, "colsum: workspace must be 8-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int blocks = static_cast<int>(n / 256 + 1);
+  blocks = blocks > kBlocks ? kBlocks : blocks;
+  double* partial = static_cast<double*>(workspace);
+  const bool vec = W % 4 == 0 && stride % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0;
+  if (vec) {
+    hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(blocks), dim3(256), 0, st, S, n, W, stride, partial);
+  } else {
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(blocks), dim3(256), 0, st, S, n, W, stride, partial);
+  }
+  if (int rc = gnan::check_launch("colsum_partial_kernel")) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((W + 255) / 256), dim3(256), 0, st, partial, blocks, W, total);
+  return gnan::check_launch("colsum_final_kernel");
+}

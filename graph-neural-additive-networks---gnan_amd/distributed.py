@@ -41,8 +41,8 @@ class VertexPartition:
 
 
 def _hip_compute() -> Dict[str, Callable]:
-    from .functional import feature_mlps, rho_aggregate
-    return {"feature_mlps": feature_mlps, "aggregate": rho_aggregate}
+    from .functional import column_sums, feature_mlps, rho_aggregate
+    return {"feature_mlps": feature_mlps, "column_sums": column_sums, "aggregate": rho_aggregate}
 
 
 def gather_operand(local: torch.Tensor, part: VertexPartition, group=None) -> torch.Tensor:
@@ -77,7 +77,9 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
     mark("gather")
-    Y = ops["aggregate"](graph_local, operand, lut, use_cnt)
+    total = ops["column_sums"](operand)          # rest-bucket operand; every rank derives it from the gathered rows
+    mark("total")
+    Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total)
     mark("spmm")
     if order == "reference":
         Y = Y.view(Y.shape[0], -1, out_channels).sum(dim=1)

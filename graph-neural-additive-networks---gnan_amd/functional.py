@@ -220,6 +220,21 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
     return a
 
 
+def column_sums(S: torch.Tensor) -> torch.Tensor:
+    """``total[w] = sum_j S[j, w]`` (``gnan_colsum``): the rest-bucket operand of the aggregation."""
+    _lib.require_device(S)
+    S = S.detach().float()
+    if S.stride(1) != 1:
+        S = S.contiguous()
+    n, W = S.shape
+    total = torch.empty(W, dtype=torch.float32, device=S.device)
+    need = _lib.lib().gnan_colsum_workspace_bytes(W)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=S.device)
+    _lib.check(_lib.lib().gnan_colsum(_lib.ptr(S), n, W, S.stride(0), _lib.ptr(total), _lib.ptr(ws), need,
+                                      _lib.stream_of(S)), "gnan_colsum")
+    return total
+
+
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
                 row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
                 minus_rest: bool = False, s_total: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -239,7 +254,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
     out = torch.empty((n_out, S.shape[1]), dtype=torch.float32, device=S.device)
     if with_rest and s_total is None:
-        s_total = S.sum(dim=0, dtype=torch.float64).float()
+        s_total = column_sums(S)
     if not with_rest:
         s_total = None
     plan = None if g.is_dense else g.long_row_plan(row_ids)
@@ -262,7 +277,7 @@ def shell_sums_launch(g: HopGraph, S: torch.Tensor, lut_like: torch.Tensor, with
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
     D = g.n_codes
     T = torch.zeros((n_out, D, S.shape[1]), dtype=torch.float32, device=S.device)
-    s_total = S.sum(dim=0, dtype=torch.float64).float() if with_rest else None
+    s_total = column_sums(S) if with_rest else None
     lut = lut_like.detach().float().contiguous()
     a = _spmm_args(g, S, lut, False, s_total, T.view(n_out, -1), row_ids, lut.dim() == 3)
     _lib.check(_lib.lib().gnan_spmm_shell_sums(a, _lib.stream_of(S)), "gnan_spmm_shell_sums")
@@ -273,10 +288,10 @@ class _RhoAggregate(torch.autograd.Function):
     """Y = A_w(lut, cnt) @ S  with the rest-bucket term; gradients for S and the weight table."""
 
     @staticmethod
-    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids):
+    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids, s_total=None):
         ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids = g, use_cnt, with_rest, row_ids
         ctx.save_for_backward(S, lut)
-        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids)
+        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total)
 
     @staticmethod
     def backward(ctx, dY):
@@ -318,11 +333,12 @@ class _RhoAggregate(torch.autograd.Function):
                     dlut.index_add_(0, rows, dwt)
             else:
                 dlut = dwt.sum(0)
-        return dS, dlut, None, None, None, None
+        return dS, dlut, None, None, None, None, None
 
 
 def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
-                  with_rest: Optional[bool] = None, row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  with_rest: Optional[bool] = None, row_ids: Optional[torch.Tensor] = None,
+                  s_total: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``Y[q] = sum_j wt(i_q, hop(i_q, j)) * S[j]`` over the hop-coded adjacency ``g``.
 
     ``lut [D, Cw]`` (post-rho / un-normalised: ``rho`` at the D distinct distances) or
@@ -334,4 +350,4 @@ def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
         with_rest = not g.is_dense
     if row_ids is not None:
         row_ids = row_ids.to(device=g.device, dtype=torch.int32).contiguous()
-    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids)
+    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total)

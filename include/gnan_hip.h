@@ -195,6 +195,12 @@ int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream);
  *   dwt[q, d, c] = sum_{w % Cw == c} dY[q, w] * T[q, d, w]. */
 int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream);
 
+/* Column sums total[w] = sum_j S[j, w] of the operand (the `s_total` argument of gnan_spmm_fwd):
+ * one streaming pass, float64 across threads, fixed order.  Workspace: gnan_colsum_workspace_bytes(W). */
+size_t gnan_colsum_workspace_bytes(int32_t W);
+int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
+                size_t workspace_bytes, gnan_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense inputs -> hop codes + shell counts
  * replaces nothing in the model file: it re-derives, on the GPU, the shell structure that

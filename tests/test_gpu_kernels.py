@@ -245,3 +245,13 @@ def test_table_lookup_matches_matrix_core_kernel_at_scale(monkeypatch):
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)
     sb = feature_mlps(x, st, True)
     assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())
+
+
+@pytest.mark.parametrize("n,W", [(1, 1), (1000, 7), (4097, 64), (300_000, 64), (50_000, 3)])
+def test_column_sums(n, W):
+    from gnan_amd.functional import column_sums
+    S = torch.randn(n, W, generator=torch.Generator().manual_seed(n)).to(DEV)
+    got = column_sums(S).cpu().double()
+    want = S.cpu().double().sum(0)
+    assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(S.abs().sum(0).max()))
+    assert torch.equal(column_sums(S), column_sums(S))          # fixed reduction order
