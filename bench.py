@@ -50,10 +50,11 @@ def parse():
     return ap.parse_args()
 
 
-def spmm_algorithmic_bytes(g, W):
-    """nnz*(4 col + 1 code + W*4 gathered row) + rows*(rowptr + W*4 output + 12 count table)."""
+def spmm_algorithmic_bytes(g, W, W_out):
+    """SURVEY.md §8d: nnz*(4 col + 1 code + W*4 gathered row) + rows*(rowptr + W_out*4 output + 12 count table);
+    W_out = C when the feature sum is fused into the epilogue (reference order), else W."""
     rp = 8 if g.rowptr.dtype == torch.int64 else 4
-    return g.nnz * (4 + 1 + W * 4) + g.n_rows * (rp + W * 4 + 4 * g.n_codes)
+    return g.nnz * (4 + 1 + W * 4) + g.n_rows * (rp + W_out * 4 + 4 * g.n_codes)
 
 
 def fmlp_flops(n, F, H, L, C):
@@ -140,7 +141,7 @@ def main():
     with torch.no_grad():
         stacked = stack_mlps(model.fs)
         lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
-    stage_names = ["fmlp", "gather", "total", "spmm", "readout"]
+    stage_names = ["fmlp", "gather", "total", "spmm"]
     events = []
 
     def step(record):
@@ -186,7 +187,7 @@ def main():
     stages = {n: v / max(1, len(events)) for n, v in stages.items()}
 
     W = F * C if args.order == "reference" else C
-    b_alg = spmm_algorithmic_bytes(g, W)
+    b_alg = spmm_algorithmic_bytes(g, W, C)
     spmm_s = stages["spmm"] / 1e3
     achieved = b_alg / spmm_s / 1e9 if spmm_s > 0 else 0.0
     traffic = None

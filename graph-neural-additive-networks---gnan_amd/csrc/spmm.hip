@@ -37,6 +37,7 @@ struct Params {
   int64_t cnt_stride;
   const float* s_total;
   int weight_by_col, minus_rest;
+  int reduce_cr;  // > 0: store only the per-channel sums over columns w = c (mod reduce_cr)
   float* Y;
   int64_t y_stride;
   int64_t long_threshold;
@@ -172,6 +173,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
   const int rest = p.D - 1;
   SmallW sw;
   if constexpr (SMALLD) sw = small_weights(p, i);
+  float red[4] = {0.f, 0.f, 0.f, 0.f};  // fused feature sum (reduce_cr in {1, 2, 4}): channel partials of this lane
 
   for (int w0 = 0; w0 < p.W; w0 += TILE) {
     const int cw = w0 + sub * VEC;
@@ -237,8 +239,27 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(wr.v[v], tot.v[v] - all.v[v], acc.v[v]);
       }
-      store_vec<VEC>(p.Y + q * p.y_stride + cw, acc);
+      if (p.reduce_cr == 0) {
+        store_vec<VEC>(p.Y + q * p.y_stride + cw, acc);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int ch = (cw + v) & (p.reduce_cr - 1);  // reduce_cr is a power of two
+#pragma unroll
+          for (int c = 0; c < 4; ++c) red[c] += ch == c ? acc.v[v] : 0.f;
+        }
+      }
     }
+  }
+  if (p.reduce_cr) {
+    // read-out fused into the epilogue (GNAN.py:72-73): add the channel partials of the group's lanes
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red[c] += __shfl_xor(red[c], off);
+    }
+    if (sub == 0)
+      for (int c = 0; c < p.reduce_cr; ++c) p.Y[q * p.y_stride + c] = red[c];
   }
 }
 
@@ -363,18 +384,34 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
   const int64_t q = p.long_rows[r];
   const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
   const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
-  for (int w = threadIdx.x; w < p.W; w += blockDim.x) {
+  __shared__ float tile[256];
+  float chan = 0.f;  // thread c < reduce_cr accumulates channel c over the column tiles
+  for (int w0 = 0; w0 < p.W; w0 += 256) {
+    const int w = w0 + threadIdx.x;
     float acc = 0.f, all = 0.f;
-    for (int s = s0; s < s1; ++s) {
-      acc += p.partial[static_cast<int64_t>(s) * 2 * p.W + w];
-      all += p.partial[static_cast<int64_t>(s) * 2 * p.W + p.W + w];
+    if (w < p.W) {
+      for (int s = s0; s < s1; ++s) {
+        acc += p.partial[static_cast<int64_t>(s) * 2 * p.W + w];
+        all += p.partial[static_cast<int64_t>(s) * 2 * p.W + p.W + w];
+      }
+      if (p.s_total) {
+        const Vec<1> wr = row_weights<1>(p, i, p.D - 1, w);
+        acc = fmaf(wr.v[0], p.s_total[w] - all, acc);
+      }
+      if (p.reduce_cr == 0) p.Y[q * p.y_stride + w] = acc;
     }
-    if (p.s_total) {
-      const Vec<1> wr = row_weights<1>(p, i, p.D - 1, w);
-      acc = fmaf(wr.v[0], p.s_total[w] - all, acc);
+    if (p.reduce_cr) {  // fixed-order tree: strides stay multiples of reduce_cr, so channels never mix
+      __syncthreads();
+      tile[threadIdx.x] = acc;
+      __syncthreads();
+      for (int st = 128; st >= p.reduce_cr; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) tile[threadIdx.x] += tile[threadIdx.x + st];
+        __syncthreads();
+      }
+      if (static_cast<int>(threadIdx.x) < p.reduce_cr) chan += tile[threadIdx.x];
     }
-    p.Y[q * p.y_stride + w] = acc;
   }
+  if (p.reduce_cr && static_cast<int>(threadIdx.x) < p.reduce_cr) p.Y[q * p.y_stride + threadIdx.x] = chan;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,9 +555,16 @@ int validate(const gnan_spmm_args* a) {
   if (a->n_rows == 0) return GNAN_OK;
   GNAN_REQUIRE(a->S && a->lut && a->Y && a->code, "spmm: null S / lut / Y / code");
   GNAN_REQUIRE((a->rowptr == nullptr) == (a->col == nullptr), "spmm: rowptr and col must both be set (CSR) or both NULL (dense)");
-  GNAN_REQUIRE(a->s_stride >= a->W && a->y_stride >= a->W, "spmm: row stride smaller than W");
+  GNAN_REQUIRE(a->s_stride >= a->W && (a->reduce_cr != 0 || a->y_stride >= a->W), "spmm: row stride smaller than W");
   if (a->s_dtype != GNAN_F32) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: only fp32 operand rows are implemented");
   GNAN_REQUIRE(!(a->weight_by_col && a->s_total), "spmm: weight_by_col excludes the rest-bucket term (add it outside)");
+  if (a->reduce_cr != 0) {
+    const int cr = a->reduce_cr;
+    if (!(cr == 1 || cr == 2 || cr == 4) || a->W % cr != 0)
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: fused read-out needs reduce_cr in {1, 2, 4} dividing W (got %d, W=%d)",
+                        cr, a->W);
+    GNAN_REQUIRE(a->y_stride >= cr, "spmm: y_stride smaller than reduce_cr");
+  }
   if (a->n_long > 0) {
     GNAN_REQUIRE(a->rowptr != nullptr, "spmm: long-row plan needs the CSR layout");
     GNAN_REQUIRE(a->long_rows && a->long_slice_ptr && a->slice_edges > 0 && a->n_slices > 0,
@@ -546,7 +590,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.S = static_cast<const float*>(a->S); p.W = a->W; p.s_stride = a->s_stride;
   p.lut = a->lut; p.lut_row_stride = a->lut_row_stride; p.D = a->D; p.Cw = a->Cw;
   p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total;
-  p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest;
+  p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest; p.reduce_cr = a->reduce_cr;
   p.Y = a->Y; p.y_stride = a->y_stride;
   p.long_threshold = a->n_long > 0 ? a->long_threshold : INT64_MAX;
   p.long_rows = a->long_rows; p.long_slice_ptr = a->long_slice_ptr;
@@ -593,7 +637,11 @@ extern "C" int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream) {
   const bool dense = a->rowptr == nullptr;
   const bool smalld = !dense && a->Cw == 1 && a->D <= 4 && !a->weight_by_col && !a->minus_rest;
   int vec, lpr;
-  pick_tiling(a, a->Y, a->y_stride, &vec, &lpr);
+  if (a->reduce_cr) {
+    pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);  // narrow output: scalar stores
+  } else {
+    pick_tiling(a, a->Y, a->y_stride, &vec, &lpr);
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   return vec == 4 ? launch_lpr<4>(p, lpr, dense, smalld, st) : launch_lpr<1>(p, lpr, dense, smalld, st);
 }

@@ -79,9 +79,8 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     mark("gather")
     total = ops["column_sums"](operand)          # rest-bucket operand; every rank derives it from the gathered rows
     mark("total")
-    Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total)
+    # reference order: the feature sum of models.py:375-376 rides in the aggregation kernel's epilogue
+    Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total,
+                         reduce_channels=out_channels if order == "reference" else 0)
     mark("spmm")
-    if order == "reference":
-        Y = Y.view(Y.shape[0], -1, out_channels).sum(dim=1)
-    mark("readout")
     return Y

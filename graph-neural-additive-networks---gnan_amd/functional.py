@@ -200,7 +200,7 @@ def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Te
 # rho-weighted aggregation
 # =============================================================================
 def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut, weight_by_col=False,
-               minus_rest=False, plan=None, workspace=None) -> _lib.SpmmArgs:
+               minus_rest=False, plan=None, workspace=None, reduce_cr=0) -> _lib.SpmmArgs:
     D, Cw = lut.shape[-2], lut.shape[-1]
     a = _lib.SpmmArgs(
         n_rows=out.shape[0], n_cols=g.n_cols,
@@ -210,7 +210,7 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         lut=_lib.ptr(lut), lut_row_stride=(D * Cw if per_row_lut else 0), D=D, Cw=Cw,
         cnt=_lib.ptr(g.cnt) if use_cnt else None, cnt_stride=g.cnt.stride(0),
         s_total=_lib.ptr(s_total), weight_by_col=int(weight_by_col), minus_rest=int(minus_rest),
-        Y=_lib.ptr(out), y_stride=out.stride(0),
+        reduce_cr=int(reduce_cr), Y=_lib.ptr(out), y_stride=out.stride(0),
         long_threshold=(plan.threshold if plan is not None else 0),
         long_rows=_lib.ptr(plan.rows) if plan is not None else None,
         long_slice_ptr=_lib.ptr(plan.slice_ptr) if plan is not None else None,
@@ -235,10 +235,14 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
     return total
 
 
+FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum over features in its epilogue
+
+
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
                 row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
-                minus_rest: bool = False, s_total: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``."""
+                minus_rest: bool = False, s_total: Optional[torch.Tensor] = None, reduce_cr: int = 0) -> torch.Tensor:
+    """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``.
+    ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns."""
     _lib.require_device(S, lut, g.code)
     S = S.detach().float()
     if S.stride(1) != 1:
@@ -252,13 +256,14 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     if S.shape[1] % lut.shape[-1] != 0:
         raise ValueError("operand width must be a multiple of the weight-channel count")
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
-    out = torch.empty((n_out, S.shape[1]), dtype=torch.float32, device=S.device)
+    out = torch.empty((n_out, reduce_cr if reduce_cr else S.shape[1]), dtype=torch.float32, device=S.device)
     if with_rest and s_total is None:
         s_total = column_sums(S)
     if not with_rest:
         s_total = None
     plan = None if g.is_dense else g.long_row_plan(row_ids)
-    a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan)
+    a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
+                   reduce_cr=reduce_cr)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
     ws = None
     if need:
@@ -288,10 +293,10 @@ class _RhoAggregate(torch.autograd.Function):
     """Y = A_w(lut, cnt) @ S  with the rest-bucket term; gradients for S and the weight table."""
 
     @staticmethod
-    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids, s_total=None):
-        ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids = g, use_cnt, with_rest, row_ids
+    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids, s_total=None, reduce_cr=0):
+        ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids, ctx.reduce_cr = g, use_cnt, with_rest, row_ids, reduce_cr
         ctx.save_for_backward(S, lut)
-        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total)
+        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr)
 
     @staticmethod
     def backward(ctx, dY):
@@ -299,6 +304,8 @@ class _RhoAggregate(torch.autograd.Function):
         g, use_cnt, with_rest, row_ids = ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids
         dY = dY.contiguous().float()
         W = S.shape[1]
+        if ctx.reduce_cr:                     # the fused feature sum broadcasts its gradient over the features
+            dY = dY.repeat(1, W // ctx.reduce_cr)
         D, Cw = lut.shape[-2], lut.shape[-1]
         per_row = lut.dim() == 3
         rows = None if row_ids is None else row_ids.long()
@@ -333,12 +340,12 @@ class _RhoAggregate(torch.autograd.Function):
                     dlut.index_add_(0, rows, dwt)
             else:
                 dlut = dwt.sum(0)
-        return dS, dlut, None, None, None, None, None
+        return dS, dlut, None, None, None, None, None, None
 
 
 def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
                   with_rest: Optional[bool] = None, row_ids: Optional[torch.Tensor] = None,
-                  s_total: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  s_total: Optional[torch.Tensor] = None, reduce_channels: int = 0) -> torch.Tensor:
     """``Y[q] = sum_j wt(i_q, hop(i_q, j)) * S[j]`` over the hop-coded adjacency ``g``.
 
     ``lut [D, Cw]`` (post-rho / un-normalised: ``rho`` at the D distinct distances) or
@@ -350,4 +357,7 @@ def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
         with_rest = not g.is_dense
     if row_ids is not None:
         row_ids = row_ids.to(device=g.device, dtype=torch.int32).contiguous()
-    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total)
+    if reduce_channels and reduce_channels not in FUSABLE_READOUT:
+        Y = _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, 0)
+        return Y.view(Y.shape[0], -1, reduce_channels).sum(dim=1)
+    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, reduce_channels)

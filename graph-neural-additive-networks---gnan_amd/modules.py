@@ -281,7 +281,8 @@ class TensorGNAN(_PathBase):
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate
             # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
             # in this order.
-            Y = self.feature_contributions(inputs, _g=g, _lut=lut).sum(dim=1)         # [N, C]
+            fx = feature_mlps(x, fs, sum_features=False)                              # [N, F*C]
+            Y = rho_aggregate(g, fx, lut, use_cnt, reduce_channels=self.actual_output_dim_f)   # [N, C]
         else:
             S = feature_mlps(x, fs, sum_features=True)                                # [N, C]  sum-first
             Y = rho_aggregate(g, S, lut, use_cnt)                                     # [N, C]

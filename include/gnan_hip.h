@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 3
+#define GNAN_ABI_VERSION 4
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -170,7 +170,9 @@ typedef struct gnan_spmm_args {
   const float* s_total;      /* optional [W]: column sums of S; enables the rest-bucket term */
   int32_t weight_by_col;     /* transposed use: table row = neighbour col_e instead of output row */
   int32_t minus_rest;        /* transposed use: wt(., d) - wt(., D-1) per listed pair */
-  float* Y;                  /* [n_rows, W] fp32 */
+  int32_t reduce_cr;         /* fused read-out: 0 = store all W columns; c in {1,2,4} = store only
+                                Y[q, c'] = sum over columns w = c' (mod c)  (the feature sum of GNAN.py:72-73) */
+  float* Y;                  /* [n_rows, W] fp32  ([n_rows, reduce_cr] with the fused read-out) */
   int64_t y_stride;
   /* long-row plan (CSR only; n_long == 0 => every row goes through the main kernel) */
   int64_t long_threshold;

@@ -255,3 +255,50 @@ def test_column_sums(n, W):
     want = S.cpu().double().sum(0)
     assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(S.abs().sum(0).max()))
     assert torch.equal(column_sums(S), column_sums(S))          # fixed reduction order
+
+
+@pytest.mark.parametrize("W,cr", [(64, 1), (64, 4), (8, 2), (6, 2), (6, 1), (300, 4), (3, 1), (1, 1)])
+def test_fused_feature_sum_equals_unfused(W, cr):
+    """reduce_cr: per-channel sums over the operand columns in the kernel epilogue (rows, hub slices, dense)."""
+    from gnan_amd import HopGraph
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(W * 7 + cr)
+    n, K = 400, 2
+    D = K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(9, 800), (100, 3000)])
+    g = _graph(rowptr, col, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut = torch.from_numpy(rng.standard_normal((D, cr)).astype(np.float32)).to(DEV)
+    full = spmm_launch(g, S, lut, True, True)
+    want = full.double().view(n, W // cr, cr).sum(1)
+    got = spmm_launch(g, S, lut, True, True, reduce_cr=cr)
+    assert got.shape == (n, cr)
+    assert O.rel_err(got.cpu(), want.cpu()) <= 2e-6
+    nd = torch.zeros(n, n)
+    hops = rng.integers(-1, 3, (n, n))
+    nd[torch.from_numpy(hops >= 0)] = 1.0 / (torch.from_numpy(hops[hops >= 0]).float() + 1.0)
+    dense = HopGraph.from_dense(nd.to(DEV))
+    lut_d = torch.from_numpy(rng.standard_normal((dense.n_codes, cr)).astype(np.float32)).to(DEV)
+    full = spmm_launch(dense, S, lut_d, True, False)
+    got = spmm_launch(dense, S, lut_d, True, False, reduce_cr=cr)
+    assert O.rel_err(got.cpu(), full.double().view(n, W // cr, cr).sum(1).cpu()) <= 2e-6
+
+
+def test_fused_feature_sum_gradients():
+    from gnan_amd.functional import rho_aggregate
+    rng = np.random.default_rng(3)
+    n, K, F, C = 150, 1, 5, 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(2, 700)])
+    g = _graph(rowptr, col, code, n, K + 2)
+    S0 = torch.from_numpy(rng.standard_normal((n, F * C)).astype(np.float32)).to(DEV)
+    l0 = torch.from_numpy(rng.standard_normal((K + 2, C)).astype(np.float32)).to(DEV)
+    grads = []
+    for fused in (C, 0):
+        S, lut = S0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+        Y = rho_aggregate(g, S, lut, True, reduce_channels=fused)
+        if not fused:
+            Y = Y.view(n, F, C).sum(1)
+        Y.pow(2).sum().backward()
+        grads.append((S.grad.clone(), lut.grad.clone()))
+    assert O.rel_err(grads[0][0].cpu(), grads[1][0].cpu().double()) <= 1e-5
+    assert O.rel_err(grads[0][1].cpu(), grads[1][1].cpu().double()) <= 1e-5

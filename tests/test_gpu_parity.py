@@ -104,3 +104,28 @@ def test_dense_to_code_rejects_foreign_inputs(gpu):
     nd = torch.tensor([[1.0, 0.5], [0.5, 1.0]], device=gpu.DEV)
     with pytest.raises(GnanHipError, match="normalization_matrix"):
         HopGraph.from_dense(nd, torch.full((2, 2), 2.0, device=gpu.DEV))
+
+
+@pytest.mark.parametrize("name", golden_names("models_tensor_node"))
+def test_reference_order_and_feature_contributions(gpu, name):
+    """aggregation_order='reference' (models.py:373-376: aggregate F*C columns, then sum over features) and the
+    per-feature contribution tensor mf give the same outputs as the sum-first default."""
+    g = Golden(name)
+    mod = gpu.build_module(g)
+    data = gpu.device_inputs(g)
+    mod.aggregation_order = "reference"
+    with torch.no_grad():
+        y = mod.forward(data).cpu()
+        mf = mod.feature_contributions(data).cpu()               # [N, F, C]
+    ok, e_build, e_ref = tolerance_ok(y, g.out32, g.out64, floor=1e-5)
+    assert ok, f"reference order: build err {e_build:.3e} vs fp32-reference err {e_ref:.3e}"
+    ok, e_build, e_ref = tolerance_ok(mf.sum(1), g.out32, g.out64, floor=1e-5)
+    assert ok, f"feature_contributions: build err {e_build:.3e}"
+    # truth for the contribution tensor itself: the reference's mf = m @ fx, from the oracle pieces in float64
+    i64, p64 = inputs_from(g, torch.float64), params_from(g, torch.float64)
+    fx = O.feature_mlps(i64["x"], p64)
+    m = O._rho_dense(i64["node_distances"], p64)
+    if g.meta["normalize_rho"]:
+        m = m / i64["normalization_matrix"].unsqueeze(-1)
+    mf64 = torch.matmul(m.permute(2, 0, 1), fx.permute(2, 0, 1)).permute(1, 2, 0)   # [N, F, C]
+    assert O.rel_err(mf, mf64) <= 1e-5
