@@ -1,0 +1,94 @@
+"""World-size-2 (and 3, ragged) CPU tests of the vertex-partitioned forward over gloo.
+
+The collective plumbing (partition arithmetic, padding of the last shard, all-gather of the operand, local
+rest-bucket totals, global column ids) is exactly what runs over RCCL on the GPUs; the two local compute
+steps are substituted by the oracle here (tests may use it, the product never does)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gnan_amd  # noqa: F401
+from gnan_amd import synthetic as syn
+from gnan_amd.distributed import VertexPartition, partitioned_forward
+from oracle import gnan_oracle as O
+from test_pwl_tables import mlp_state, stack
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_compute(sd, C):
+    def feature_mlps(x, stacked, sum_features):
+        fx = O.feature_mlps(x, sd)
+        return fx.sum(1) if sum_features else fx.reshape(x.shape[0], -1)
+
+    def column_sums(S):
+        return S.sum(0)
+
+    def aggregate(g, S, lut, use_cnt, s_total=None, reduce_channels=0):
+        rowptr, col, code = g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy()
+        cnt = g.cnt.long().numpy() if use_cnt else None
+        wt = O.weight_table(lut, cnt).expand(g.n_rows, -1, -1)
+        assert torch.allclose(s_total, S.sum(0))
+        Y = O.spmm_csr(rowptr, col, code, S, wt)
+        return Y.view(Y.shape[0], -1, reduce_channels).sum(1) if reduce_channels else Y
+    return {"feature_mlps": feature_mlps, "column_sums": column_sums, "aggregate": aggregate}
+
+
+def _problem(n, F, C):
+    src, dst = syn.rmat_edges(9, n, 6 * n, seed=0, device="cpu", chunk=1 << 12)
+    x = syn.block_features(n, F, 0, n, seed=1, device="cpu", block=64)
+    sd = mlp_state(F, 3, 8, C, True, seed=2)
+    sd.update({"rho.0.weight": torch.randn(8, 1, generator=torch.Generator().manual_seed(3)),
+               "rho.0.bias": torch.randn(8, generator=torch.Generator().manual_seed(4)),
+               "rho.2.weight": torch.randn(1, 8, generator=torch.Generator().manual_seed(5)),
+               "rho.2.bias": torch.randn(1, generator=torch.Generator().manual_seed(6))})
+    return src, dst, x, sd
+
+
+def _worker(rank, world, port, n, F, C, order, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src, dst, x, sd = _problem(n, F, C)
+        part = VertexPartition(n, world, rank)
+        g = syn.hop1_csr(src, dst, n, part.lo, part.hi)
+        lut = O.rho_lut(sd, 3)
+        y = partitioned_forward(x[part.lo:part.hi], g, stack(sd, F, 3, 8, C, True), lut, True, part, order=order,
+                                out_channels=C, compute=_oracle_compute(sd, C))
+        np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
+        np.save(os.path.join(out_dir, f"x{rank}.npy"), x[part.lo:part.hi].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,order", [(2, 300, "sum_first"), (2, 300, "reference"), (3, 301, "reference")])
+def test_partitioned_forward_equals_single_process(world, n, order, tmp_path):
+    F, C = 5, 1
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, F, C, order, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    src, dst, x, sd = _problem(n, F, C)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)]), x.numpy())
+    g = syn.hop1_csr(src, dst, n)
+    S = O.feature_mlps(x, sd).sum(1)
+    wt = O.weight_table(O.rho_lut(sd, 3), g.cnt.long().numpy()).expand(n, -1, -1)
+    want = O.spmm_csr(g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy(), S, wt)
+    assert got.shape == (n, C)
+    assert O.rel_err(torch.from_numpy(got), want.double()) <= 1e-5
+
+
+def test_partition_arithmetic():
+    for n, world in [(10, 3), (7, 8), (16, 4), (1, 2)]:
+        parts = [VertexPartition(n, world, r) for r in range(world)]
+        assert parts[0].lo == 0 and parts[-1].hi == n
+        assert all(a.hi == b.lo for a, b in zip(parts, parts[1:]))
+        assert all(p.hi - p.lo <= p.block for p in parts)
