@@ -128,6 +128,103 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward: per-piece moments of the upstream gradient
+//   M[t, 0, c] = sum_{(n,k) in piece t} g[n,k,c]            M[t, 1, c] = sum g[n,k,c] * (x[n,k] - anchor[t])
+// On a piece f_k is affine in x AND so is d f_k(x) / d theta (fixed activation pattern), hence the parameter
+// gradient  sum_n g_n * df_k(x_n)/dtheta  depends on the nodes of a piece only through these two moments;
+// gnan_amd/pwl.py turns them into exact parameter gradients by back-propagating through the tiny MLP at
+// two points per piece.  Same traversal as the forward; bins live in LDS (ds_add_f32) and are flushed with
+// one global atomic per bin per workgroup.
+// ---------------------------------------------------------------------------------------------
+struct MomentParams {
+  Params f;            // x, tables, grouping as in the forward (val / slope / out unused)
+  const float* g;      // upstream gradient: [n, F*C] (per feature) or [n, C] (sum_features)
+  int64_t g_stride;
+  float* M;            // [T, 2, C], zeroed by the caller
+};
+
+template <int FG>
+__global__ __launch_bounds__(256) void fpwl_moments_kernel(const MomentParams mp) {
+  const Params& p = mp.f;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_off[FG + 1];
+  const int tid = threadIdx.x;
+  const int C = p.C;
+  const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
+  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
+  const int g_idx = blockIdx.y;
+  const int k0 = g_idx * FG;
+  const int nf = p.F - k0 < FG ? p.F - k0 : FG;
+  const int base = p.off[k0];
+  const int tot = p.off[k0 + nf] - base;
+  float* anchor_l = smem;
+  float* bins = smem + tot;                        // [tot][2][C]
+  for (int i = tid; i < tot; i += 256) anchor_l[i] = p.anchor[base + i];
+  for (int i = tid; i < tot * 2 * C; i += 256) bins[i] = 0.f;
+  if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
+  __syncthreads();
+  int po[FG], pn[FG];
+#pragma unroll
+  for (int f = 0; f < FG; ++f) {
+    po[f] = f < nf ? s_off[f] : 0;
+    pn[f] = f < nf ? s_off[f + 1] - s_off[f] - 1 : 0;
+  }
+  for (int64_t n = n_lo + tid; n < n_hi; n += 256) {
+    float xv[FG];
+    const float* xr = p.x + n * p.x_stride + k0;
+#pragma unroll
+    for (int f = 0; f < FG; ++f) xv[f] = f < nf ? xr[f] : 0.f;
+    int idx[FG];
+#pragma unroll
+    for (int f = 0; f < FG; ++f) idx[f] = 0;
+    for (int step = p.step0; step > 0; step >>= 1) {
+#pragma unroll
+      for (int f = 0; f < FG; ++f) {
+        const int j = idx[f] + step;
+        const int jj = j <= pn[f] ? j : 0;
+        const float a = anchor_l[po[f] + jj];
+        idx[f] = (j <= pn[f] && a <= xv[f]) ? j : idx[f];
+      }
+    }
+    const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0) * C);
+#pragma unroll
+    for (int f = 0; f < FG; ++f) {
+      if (f < nf) {
+        const int piece = po[f] + idx[f];
+        const float d = xv[f] - anchor_l[piece];
+        float* b = bins + static_cast<int64_t>(piece) * 2 * C;
+        for (int c = 0; c < C; ++c) {
+          const float gv = gr[p.sum_features ? c : f * C + c];
+          atomicAdd(b + c, gv);
+          atomicAdd(b + C + c, gv * d);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* out = mp.M + static_cast<int64_t>(base) * 2 * C;
+  for (int i = tid; i < tot * 2 * C; i += 256) {
+    const float v = bins[i];
+    if (v != 0.f) atomicAdd(out + i, v);
+  }
+}
+
+template <int FG>
+int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fpwl_moments_kernel<FG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const Params& p = mp.f;
+  const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+  if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
+  hipLaunchKernelGGL(fpwl_moments_kernel<FG>, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(p.n_groups)),
+                     dim3(256), lds, st, mp);
+  return gnan::check_launch("fpwl_moments_kernel");
+}
+
 template <int FG>
 int launch(const Params& p, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
@@ -144,35 +241,73 @@ int launch(const Params& p, size_t lds, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
+namespace {
+int common_checks(const gnan_fpwl_args* a) {
   GNAN_REQUIRE(a != nullptr, "fpwl: null args");
   GNAN_REQUIRE(a->n >= 0 && a->F >= 1 && a->C >= 1, "fpwl: bad sizes");
   if (a->n == 0) return GNAN_OK;
-  GNAN_REQUIRE(a->x && a->out && a->off && a->anchor && a->val && a->slope, "fpwl: null pointer");
+  GNAN_REQUIRE(a->x && a->off && a->anchor, "fpwl: null pointer");
   GNAN_REQUIRE(a->x_stride >= a->F, "fpwl: x row stride smaller than F");
   GNAN_REQUIRE(a->max_pieces >= 1 && a->max_group_pieces >= 1, "fpwl: max_pieces / max_group_pieces must be >= 1");
   const int fg = a->features_per_group;
   GNAN_REQUIRE(fg == 1 || fg == 2 || fg == 4 || fg == 8 || fg == 16, "fpwl: features_per_group must be 1, 2, 4, 8 or 16");
-  const int64_t ow = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
-  GNAN_REQUIRE(a->out_stride >= ow, "fpwl: out row stride smaller than the output width");
   const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
   if (lds > 150 * 1024)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: %zu B of tables per feature group exceed LDS; use fewer features per group",
                       lds);
+  return GNAN_OK;
+}
+
+Params base_params(const gnan_fpwl_args* a) {
   Params p;
   p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F; p.C = a->C;
   p.off = a->off; p.anchor = a->anchor; p.val = a->val; p.slope = a->slope;
   int step0 = 0;
   while ((step0 ? step0 * 2 : 1) <= a->max_pieces - 1) step0 = step0 ? step0 * 2 : 1;
   p.step0 = step0;
-  p.n_groups = (a->F + fg - 1) / fg;
+  p.n_groups = (a->F + a->features_per_group - 1) / a->features_per_group;
   int64_t npb = (a->n / 1024 + 255) / 256 * 256;           // aim at ~1024 workgroups along the node axis
   p.nodes_per_block = static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
   p.sum_features = a->sum_features;
+  p.vec_x = p.vec_out = 0;
+  p.out = a->out; p.out_stride = a->out_stride;
+  return p;
+}
+}  // namespace
+
+extern "C" int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, float* moments,
+                                 gnan_stream_t stream) {
+  if (int rc = common_checks(a)) return rc;
+  if (a->n == 0) return GNAN_OK;
+  GNAN_REQUIRE(grad && moments, "fpwl_moments: null grad / moments");
+  const int64_t gw = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
+  GNAN_REQUIRE(grad_stride >= gw, "fpwl_moments: grad row stride smaller than its width");
+  MomentParams mp;
+  mp.f = base_params(a);
+  mp.g = grad; mp.g_stride = grad_stride; mp.M = moments;
+  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a->features_per_group) {
+    case 1: return launch_moments<1>(mp, lds, st);
+    case 2: return launch_moments<2>(mp, lds, st);
+    case 4: return launch_moments<4>(mp, lds, st);
+    case 8: return launch_moments<8>(mp, lds, st);
+    default: return launch_moments<16>(mp, lds, st);
+  }
+}
+
+extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
+  if (int rc = common_checks(a)) return rc;
+  if (a->n == 0) return GNAN_OK;
+  GNAN_REQUIRE(a->out && a->val && a->slope, "fpwl: null pointer");
+  const int fg = a->features_per_group;
+  const int64_t ow = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
+  GNAN_REQUIRE(a->out_stride >= ow, "fpwl: out row stride smaller than the output width");
+  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
+  Params p = base_params(a);
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
   p.vec_x = fg % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 && aligned(a->x);
   p.vec_out = fg % 4 == 0 && a->F % 4 == 0 && a->out_stride % 4 == 0 && aligned(a->out);
-  p.out = a->out; p.out_stride = a->out_stride;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (fg) {
     case 1: return launch<1>(p, lds, st);

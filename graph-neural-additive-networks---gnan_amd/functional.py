@@ -86,17 +86,38 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool) -> torch.Tensor:
     return out
 
 
-def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool) -> torch.Tensor:
-    """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise."""
+def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) -> torch.Tensor:
+    """Per-piece moments of the upstream gradient (``gnan_fpwl_moments``) -> ``[T, 2, C]``."""
+    x = x.detach().float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    grad = grad.detach().float()
+    if grad.stride(1) != 1:
+        grad = grad.contiguous()
+    n, F = x.shape
+    C = t.val.shape[1]
+    M = torch.zeros((t.anchor.numel(), 2, C), dtype=torch.float32, device=x.device)
+    a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
+                      anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
+                      max_pieces=t.max_pieces, features_per_group=t.features_per_group,
+                      max_group_pieces=t.max_group_pieces, sum_features=int(sum_features), out=None, out_stride=0)
+    _lib.check(_lib.lib().gnan_fpwl_moments(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(M), _lib.stream_of(x)),
+               "gnan_fpwl_moments")
+    return M
+
+
+def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool):
+    """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
+    Returns ``(out, tables or None)``."""
     algo = FMLP_ALGO
     if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= PWL_MIN_WORK):
         from .pwl import build_tables
         tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
         if tables is not None:
-            return _fpwl_launch(x, tables, sum_features)
+            return _fpwl_launch(x, tables, sum_features), tables
         if algo == _lib.FMLP_PWL:
             raise _lib.GnanHipError("shape functions need more pieces than the look-up kernel supports")
-    return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo)
+    return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo), None
 
 
 def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int = 0) -> torch.Tensor:
@@ -155,7 +176,8 @@ class _FeatureMLPs(torch.autograd.Function):
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
-        return _fmlp_forward(x, p, sum_features)
+        out, ctx.tables = _fmlp_forward(x, p, sum_features)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -166,6 +188,18 @@ class _FeatureMLPs(torch.autograd.Function):
         leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
         p = StackedMLP(*leaves, L, H, C, F)
         live = [t for t in leaves if t is not None]
+        if ctx.tables is not None and not ctx.needs_input_grad[0]:
+            # table path: one streaming pass bins the upstream gradient per piece (HIP), then the exact
+            # parameter gradients follow from 2 probe points per piece through the tiny batched MLP
+            from .pwl import parameter_grads_from_moments
+            M = _fpwl_moments(x, ctx.tables, grad_out, sum_features)
+            got = parameter_grads_from_moments(
+                p, ctx.tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()
+                                                                          for t in q[:6]], *q[6:]), False))
+            it = iter(got)
+            pg = [None if not present else next(it) for present in ctx.present]
+            pg = [None if g is None else g.to(torch.float32) for g in pg]
+            return (None, None, None, None, None, None, *pg)
         grads = [torch.zeros_like(t) for t in live]
         n = x.shape[0]
         chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))

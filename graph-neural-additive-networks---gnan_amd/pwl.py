@@ -185,3 +185,72 @@ def evaluate_reference(x: torch.Tensor, t: PwlTables, sum_features: bool) -> tor
         else:
             out[:, k * C:(k + 1) * C] = y
     return out
+
+
+# =============================================================================
+# backward: per-piece moments -> exact parameter gradients
+# =============================================================================
+def piece_probe_points(t: PwlTables):
+    """Two points strictly inside every piece, ``u1 = a + h`` and ``u2 = a + 2h`` (``h`` = a third of the piece
+    width; ``-1`` / ``+1`` on the two unbounded pieces), and ``h`` itself.  All ``[T]`` float64."""
+    off = t.off.long()
+    T = t.anchor.numel()
+    a = t.anchor.double()
+    first = torch.zeros(T, dtype=torch.bool, device=a.device)
+    last = torch.zeros(T, dtype=torch.bool, device=a.device)
+    first[off[:-1]] = True
+    last[off[1:] - 1] = True
+    nxt = torch.cat([a[1:], a[-1:]])
+    w = nxt - a
+    h = torch.where(w > 0, w / 3.0, torch.ones_like(w))
+    h = torch.where(first, -torch.ones_like(h), h)
+    h = torch.where(last, torch.ones_like(h), h)          # a single-piece (affine) feature is both: +1 wins
+    return a + h, a + 2.0 * h, h
+
+
+def moments_reference(x: torch.Tensor, g: torch.Tensor, t: PwlTables, sum_features: bool) -> torch.Tensor:
+    """Plain-torch restatement of ``gnan_fpwl_moments`` (CPU tests): ``M [T, 2, C]``."""
+    n, F = x.shape
+    C = t.val.shape[1]
+    M = torch.zeros(t.anchor.numel(), 2, C, dtype=torch.float64)
+    off = t.off.tolist()
+    for k in range(F):
+        a = t.anchor[off[k]:off[k + 1]]
+        i = torch.searchsorted(a[1:].contiguous(), x[:, k].contiguous(), right=True)
+        gk = (g if sum_features else g[:, k * C:(k + 1) * C]).double()
+        d = (x[:, k] - a[i]).double().unsqueeze(1)
+        M[off[k]:off[k + 1], 0].index_add_(0, i, gk)
+        M[off[k]:off[k + 1], 1].index_add_(0, i, gk * d)
+    return M
+
+
+def parameter_grads_from_moments(p, t: PwlTables, M: torch.Tensor, evaluate):
+    """Exact gradients of ``sum_n <g_n, f(x_n)>`` w.r.t. the stacked parameters, from the per-piece moments.
+
+    On piece ``t`` (anchor ``a``) ``f(x) = val + slope (x - a)`` with ``val``, ``slope`` functions of the
+    parameters, so the objective is ``<val, M0> + <slope, M1>``.  With two probe points inside the piece,
+    ``val = 2 f(u1) - f(u2)`` and ``slope = (f(u2) - f(u1)) / h``, i.e. the objective equals
+    ``<f(u1), 2 M0 - M1/h> + <f(u2), -M0 + M1/h>``: a weighted sum of network outputs at 2T points, which is
+    back-propagated through the (tiny) batched MLP ``evaluate(U, p)`` in float64.
+    ``p``: StackedMLP of leaf tensors with ``requires_grad``; returns gradients in the order of its non-None tensors.
+    """
+    u1, u2, h = piece_probe_points(t)
+    M = M.double()
+    c2 = -M[:, 0] + M[:, 1] / h.unsqueeze(1)                  # [T, C]
+    c1 = M[:, 0] - c2                                         # = 2 M0 - M1/h
+    off = t.off.long()
+    F = off.numel() - 1
+    C = M.shape[2]
+    pieces = off[1:] - off[:-1]
+    feat = torch.repeat_interleave(torch.arange(F, device=M.device), pieces)      # feature of every piece
+    local = torch.arange(M.shape[0], device=M.device) - off[:-1][feat]
+    rows = 2 * int(pieces.max())
+    U = torch.zeros(rows, F, dtype=torch.float64, device=M.device)
+    W = torch.zeros(rows, F, C, dtype=torch.float64, device=M.device)
+    U[2 * local, feat], U[2 * local + 1, feat] = u1, u2
+    W[2 * local, feat], W[2 * local + 1, feat] = c1, c2
+    live = [q for q in p[:6] if q is not None]
+    with torch.enable_grad():
+        y = evaluate(U, p).view(rows, F, C)                   # float64 through the casts inside `evaluate`
+        obj = (y * W).sum()
+    return torch.autograd.grad(obj, live, allow_unused=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 4
+#define GNAN_ABI_VERSION 5
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -114,6 +114,16 @@ typedef struct gnan_fpwl_args {
 } gnan_fpwl_args;
 
 int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
+
+/* Backward of the table look-up (autograd through GNAN.py:57-62 w.r.t. the f_k parameters): per-piece
+ * moments of the upstream gradient `grad` ([n, F*C], or [n, C] when sum_features),
+ *   moments[t, 0, c] = sum_{(n,k) in piece t} grad[n,k,c]
+ *   moments[t, 1, c] = sum_{(n,k) in piece t} grad[n,k,c] * (x[n,k] - anchor[t])
+ * accumulated with atomics into `moments` [T, 2, C] (ZEROED by the caller).  On a piece both f_k and
+ * d f_k / d theta are affine in x, so these moments determine the parameter gradient exactly
+ * (gnan_amd/pwl.py finishes it on two points per piece).  `val`, `slope`, `out` of the args are unused. */
+int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, float* moments,
+                      gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rho(distance)-weighted neighbourhood sum over a hop-coded adjacency

@@ -302,3 +302,21 @@ def test_fused_feature_sum_gradients():
         grads.append((S.grad.clone(), lut.grad.clone()))
     assert O.rel_err(grads[0][0].cpu(), grads[1][0].cpu().double()) <= 1e-5
     assert O.rel_err(grads[0][1].cpu(), grads[1][1].cpu().double()) <= 1e-5
+
+
+@pytest.mark.parametrize("F,L,H,C,sum_features", [(5, 3, 8, 1, True), (20, 3, 16, 2, False), (64, 3, 64, 1, False),
+                                                   (3, 3, 16, 40, True)])
+def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features):
+    from gnan_amd import pwl
+    from gnan_amd.functional import _fpwl_moments
+    sd = _mlp_state(F, L, H, C, True, seed=F)
+    st = _stack(sd, F, L, H, C, True)
+    t = pwl.build_tables(st)
+    n = 20_000
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(1)) * 4 - 2
+    g = torch.randn(n, C if sum_features else F * C, generator=torch.Generator().manual_seed(2))
+    tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t])
+    want = pwl.moments_reference(x, g, tc, sum_features)
+    got = _fpwl_moments(x.to(DEV), t, g.to(DEV), sum_features).cpu().double()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale

@@ -25,8 +25,17 @@ def gpu():
     return gpu_util
 
 
+@pytest.fixture(params=["auto", "pwl"])
+def strategy(request, monkeypatch):
+    """Shape-function strategy: what AUTO picks at these sizes (matrix-core / lane kernel) and the forced
+    piecewise-linear table path (what AUTO picks for large graphs)."""
+    from gnan_amd import _lib, functional
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_AUTO if request.param == "auto" else _lib.FMLP_PWL)
+    return request.param
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_forward_matches_golden(gpu, name):
+def test_forward_matches_golden(gpu, name, strategy):
     g = Golden(name)
     mod = gpu.build_module(g)
     with torch.no_grad():
@@ -37,7 +46,7 @@ def test_forward_matches_golden(gpu, name):
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_backward_matches_golden(gpu, name):
+def test_backward_matches_golden(gpu, name, strategy):
     g = Golden(name)
     mod = gpu.build_module(g)
     y = gpu.call(mod, g, gpu.device_inputs(g))

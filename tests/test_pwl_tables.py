@@ -88,3 +88,31 @@ def test_piece_count_is_small_for_default_shapes():
     t = pwl.build_tables(stack(mlp_state(F, L, H, C, True, seed=0), F, L, H, C, True))
     assert t.max_pieces <= 4 * H                           # ~2H in practice: H first-layer kinks + ~1 per second-layer unit
     assert t.features_per_group == 16 and t.max_group_pieces * 12 <= pwl.LDS_PREFERRED
+
+
+@pytest.mark.parametrize("F,L,H,C,bias,sum_features", [
+    (4, 2, 8, 3, True, False), (5, 3, 8, 1, True, True), (6, 3, 16, 2, False, False), (3, 4, 8, 2, True, True),
+    (2, 1, 0, 2, True, False),
+])
+def test_moment_backward_equals_autograd(F, L, H, C, bias, sum_features):
+    """Per-piece moments + 2 probe points per piece reproduce the exact parameter gradients."""
+    from gnan_amd.functional import _fmlp_eager
+    sd = mlp_state(F, L, max(H, 1), C, bias, seed=F + 10 * L)
+    st = stack(sd, F, L, H, C, bias)
+    t = pwl.build_tables(st)
+    n = 3000
+    x = probe_points(n, F, 4)
+    g = torch.randn(n, C if sum_features else F * C, generator=torch.Generator().manual_seed(5))
+    # truth: autograd through the batched float64 restatement
+    leaves = [None if q is None else q.double().requires_grad_(True) for q in st[:6]]
+    p64 = StackedMLP(*leaves, *st[6:])
+    y = _fmlp_eager(x.double(), p64, sum_features)
+    want = torch.autograd.grad((y * g.double()).sum(), [q for q in leaves if q is not None])
+    M = pwl.moments_reference(x, g, t, sum_features)
+    leaves32 = [None if q is None else q.clone().requires_grad_(True) for q in st[:6]]
+    got = pwl.parameter_grads_from_moments(
+        StackedMLP(*leaves32, *st[6:]), t, M,
+        lambda U, q: _fmlp_eager(U, StackedMLP(*[None if a is None else a.double() for a in q[:6]], *q[6:]), False))
+    scale = max(float(w.abs().max()) for w in want)
+    for a, b in zip(got, want):
+        assert float((a.double() - b).abs().max()) <= 2e-5 * scale
