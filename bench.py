@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--order", default="reference", choices=["reference", "sum_first"])
     ap.add_argument("--fmlp-algo", default="auto", choices=["auto", "lane", "mfma", "pwl"],
                     help="shape-function strategy: auto = exact table look-up at this size; mfma = fp32 matrix cores")
+    ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature"],
+                    help="multi-GPU decomposition: vertex blocks + all-gather of the operand, or feature columns + "
+                         "all-reduce of the [N, C] partial outputs; auto = fewer bytes over xGMI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="nodes of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
@@ -110,7 +113,8 @@ def main():
 
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
-    from gnan_amd.distributed import VertexPartition, partitioned_forward
+    from gnan_amd.distributed import (FeaturePartition, VertexPartition, choose_partition,
+                                      feature_parallel_forward, partitioned_forward, slice_features)
     from gnan_amd import _lib, functional
     from gnan_amd.functional import stack_mlps
     from gnan_amd.graph import hop_inputs
@@ -119,13 +123,21 @@ def main():
     from gnan_amd.models import TensorGNAN
 
     N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
+    partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, world, args.order)
+    if partition == "feature" and args.order != "reference":
+        raise SystemExit("--partition feature needs --order reference (sum-first exchanges the narrow operand)")
     part = VertexPartition(N, world, rank)
+    fpart = FeaturePartition(F, world, rank)
     t_setup = time.perf_counter()
     src, dst = syn.rmat_edges(args.scale, N, E, seed=0, device=dev)
-    g = syn.hop1_csr(src, dst, N, part.lo, part.hi)
+    if partition == "vertex":
+        g = syn.hop1_csr(src, dst, N, part.lo, part.hi)
+        x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
+    else:                                        # whole graph, this rank's feature columns
+        g = syn.hop1_csr(src, dst, N)
+        x = syn.block_features(N, F, 0, N, seed=1, device=dev)[:, fpart.lo:fpart.hi].contiguous()
     del src, dst
     g.long_row_plan()
-    x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
     torch.manual_seed(0)
     model = TensorGNAN(F, C, L, hidden_channels=H, normalize_rho=True, rho_per_feature=False, device="cuda")
     with torch.no_grad():                                    # O(1)-scale weights (the upstream init gives ~1e-14 outputs)
@@ -141,7 +153,8 @@ def main():
     with torch.no_grad():
         stacked = stack_mlps(model.fs)
         lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
-    stage_names = ["fmlp", "gather", "total", "spmm"]
+    stage_names = ["fmlp", "gather", "total", "spmm"] + (["reduce"] if partition == "feature" else [])
+    stacked_local = slice_features(stacked, fpart.lo, fpart.hi) if partition == "feature" else None
     events = []
 
     def step(record):
@@ -154,7 +167,11 @@ def main():
         else:
             mark = None
         with torch.no_grad():
-            out = partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C, marks=mark)
+            if partition == "vertex":
+                out = partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
+                                          marks=mark)
+            else:
+                out = feature_parallel_forward(x, g, stacked_local, lut, True, fpart, out_channels=C, marks=mark)
         if record:
             events.append(marks)
         return out
@@ -186,7 +203,10 @@ def main():
             prev = m[n]
     stages = {n: v / max(1, len(events)) for n, v in stages.items()}
 
-    W = F * C if args.order == "reference" else C
+    if partition == "feature":
+        W = (fpart.hi - fpart.lo) * C
+    else:
+        W = F * C if args.order == "reference" else C
     b_alg = spmm_algorithmic_bytes(g, W, C)
     spmm_s = stages["spmm"] / 1e3
     achieved = b_alg / spmm_s / 1e9 if spmm_s > 0 else 0.0
@@ -207,17 +227,19 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "nodes": N, "edges": E, "stored_pairs_rank0": g.nnz,
-                       "operand_width": W, "partition": f"vertex-block x{world}", "exchange":
-                       "all_gather(operand)" if world > 1 else "none"},
+                       "operand_width": W, "partition": f"{partition} x{world}", "exchange":
+                       "none" if world == 1 else ("all_gather(operand [N,W])" if partition == "vertex"
+                                                  else "all_reduce(out [N,C])")},
             "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},
             "stages_ms": stages,
             "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
-            "fmlp_tflops": fmlp_flops(part.hi - part.lo, F, H, L, C) / (stages["fmlp"] / 1e3) / 1e12
+            "fmlp_tflops": fmlp_flops(x.shape[0], x.shape[1], H, L, C) / (stages["fmlp"] / 1e3) / 1e12
             if stages["fmlp"] > 0 else None,
             "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "fmlp_algo": args.fmlp_algo,
-            "setup_s": t_setup, "checksum": float(out.double().sum()),
+            "setup_s": t_setup, "checksum": float(out.double().sum()) if partition == "vertex" or world == 1 else
+            float(out.double().sum()),
         }
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():

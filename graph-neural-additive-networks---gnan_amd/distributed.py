@@ -11,6 +11,13 @@ and its rows of the output.
 
 The rest-bucket term needs the column sums of the full operand; every rank computes them from the
 gathered operand, so no second collective is needed.  Parameters are replicated.
+
+Feature partition (the cheaper exchange when the aggregation runs in the reference's order, W = F*C):
+the operand COLUMNS are sharded instead — rank ``p`` owns features ``[k_lo, k_hi)`` for ALL nodes, computes its
+slice of ``fx`` from its columns of ``x`` (no operand exchange at all), aggregates it over the whole graph
+with the feature sum fused, and the ranks add their ``[N, C]`` partial outputs with one all-reduce.
+xGMI is point-to-point (7 links per GPU): an all-gather of ``N*F*C`` floats is link-bound and costs more than
+all the compute it feeds, while the all-reduce moves ``N*C`` floats — :func:`choose_partition` picks by bytes.
 """
 from __future__ import annotations
 
@@ -83,4 +90,75 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total,
                          reduce_channels=out_channels if order == "reference" else 0)
     mark("spmm")
+    return Y
+
+
+# =============================================================================
+# feature partition
+# =============================================================================
+@dataclass
+class FeaturePartition:
+    n_features: int
+    world: int
+    rank: int
+
+    @property
+    def block(self) -> int:
+        return -(-self.n_features // self.world)
+
+    @property
+    def lo(self) -> int:
+        return min(self.rank * self.block, self.n_features)
+
+    @property
+    def hi(self) -> int:
+        return min(self.lo + self.block, self.n_features)
+
+
+def slice_features(stacked, lo: int, hi: int):
+    """Rows ``[lo, hi)`` of every stacked per-feature tensor (the feature axis is dim 0, or dim 1 of ``*_mid``)."""
+    def cut(t, axis):
+        return None if t is None else t.narrow(axis, lo, hi - lo).contiguous()
+    return type(stacked)(cut(stacked.w_first, 0), cut(stacked.b_first, 0), cut(stacked.w_mid, 1),
+                         cut(stacked.b_mid, 1), cut(stacked.w_last, 0), cut(stacked.b_last, 0),
+                         stacked.L, stacked.H, stacked.C, hi - lo)
+
+
+def choose_partition(n_nodes: int, n_features: int, out_channels: int, world: int, order: str) -> str:
+    """'vertex' or 'feature', by the bytes each rank receives over xGMI per forward."""
+    if world == 1 or order == "sum_first":
+        return "vertex"
+    gather_bytes = n_nodes * n_features * out_channels * 4 * (world - 1) / world
+    allreduce_bytes = 2 * n_nodes * out_channels * 4 * (world - 1) / world
+    return "feature" if allreduce_bytes < gather_bytes else "vertex"
+
+
+def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lut: torch.Tensor, use_cnt: bool,
+                             part: FeaturePartition, out_channels: int = 1, group=None,
+                             compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None):
+    """Reference-order forward with the feature axis sharded; returns the full ``[N, out_channels]`` output
+    (identical on every rank after the all-reduce).
+
+    ``x_cols [N, k_hi-k_lo]`` are this rank's columns of ``x``; ``stacked_local`` the matching slice of the
+    stacked shape-function weights (:func:`slice_features`); ``graph_full`` the whole hop-coded adjacency.
+    """
+    ops = compute or _hip_compute()
+    mark = marks or (lambda name: None)
+    mark("start")
+    n = graph_full.n_rows
+    if part.hi > part.lo:
+        operand = ops["feature_mlps"](x_cols, stacked_local, False)            # [N, Fp*C]
+        mark("fmlp")
+        mark("gather")                                                         # nothing to exchange here
+        total = ops["column_sums"](operand)
+        mark("total")
+        Y = ops["aggregate"](graph_full, operand, lut, use_cnt, s_total=total, reduce_channels=out_channels)
+    else:                                                                      # more ranks than features
+        for name in ("fmlp", "gather", "total"):
+            mark(name)
+        Y = x_cols.new_zeros((n, out_channels))
+    mark("spmm")
+    if part.world > 1:
+        dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=group)
+    mark("reduce")
     return Y

@@ -96,6 +96,8 @@ def build_tables(p) -> Optional[PwlTables]:
     b_last = None if p.b_last is None else p.b_last.to(f64)
 
     bp = torch.full((F, 0), INF, dtype=f64, device=dev)             # sorted breakpoints, +inf padded
+    cap_per_layer = max(64, 4 * max(p.H, 1))                        # ~2H kinks per layer in practice (see module doc)
+    overflow = torch.zeros((), dtype=torch.bool, device=dev)
     for depth in range(p.L - 1):                                     # every hidden layer adds its units' zero crossings
         if depth == 0:
             b0 = b[0] if b[0] is not None else torch.zeros_like(w[0])
@@ -125,10 +127,11 @@ def build_tables(p) -> Optional[PwlTables]:
                              torch.where(ok_r, rr, torch.full_like(rr, INF))], dim=1)
         new = torch.where(torch.isfinite(new), new, torch.full_like(new, INF))       # NaN / -inf -> dropped
         bp, _ = torch.sort(torch.cat([bp, new], dim=1), dim=1)
-        keep = max(1, int(torch.isfinite(bp).sum(dim=1).max()))
-        if keep > MAX_PIECES - 1:
-            return None
-        bp = bp[:, :keep]
+        # keep a fixed number of columns per layer (no host round trip); an overflow is detected at the end
+        cap = min(bp.shape[1], cap_per_layer * (depth + 1))
+        if bp.shape[1] > cap:
+            overflow = overflow | torch.isfinite(bp[:, cap]).any()
+            bp = bp[:, :cap]
     if bp.shape[1] == 0:                                             # L == 1: affine, no kinks
         bp = torch.full((F, 1), INF, dtype=f64, device=dev)
 
@@ -160,7 +163,10 @@ def build_tables(p) -> Optional[PwlTables]:
     off = torch.zeros(F + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(pieces, 0)
     C = val.shape[-1]
-    off_host = off.tolist()                                          # one small D2H copy: sizes the LDS images
+    host = torch.cat([off, overflow.to(torch.int64).view(1)]).tolist()   # the ONE device->host copy of the build
+    off_host, overflowed = host[:-1], bool(host[-1])
+    if overflowed or max(b - a for a, b in zip(off_host, off_host[1:])) > MAX_PIECES:
+        return None
     plan = _plan_groups(off_host, C)
     if plan is None:
         return None

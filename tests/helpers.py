@@ -42,7 +42,9 @@ def oracle_forward(golden, dtype, params=None):
 
 def tolerance_ok(y, ref32, truth64, floor=1e-5):
     """SURVEY §8c rule: error vs the fp64 reference must not exceed max(floor, the fp32 reference's own)."""
-    t = torch.as_tensor(np.array(truth64), dtype=torch.float64)
-    e_build = O.rel_err(torch.as_tensor(np.array(y)), t)
-    e_ref = O.rel_err(torch.as_tensor(np.array(ref32)), t)
+    def as_t(v):
+        return v.detach().cpu() if torch.is_tensor(v) else torch.from_numpy(np.asarray(v))
+    t = as_t(truth64).double()
+    e_build = O.rel_err(as_t(y), t)
+    e_ref = O.rel_err(as_t(ref32), t)
     return e_build <= max(floor, e_ref), e_build, e_ref

@@ -86,6 +86,52 @@ def test_partitioned_forward_equals_single_process(world, n, order, tmp_path):
     assert O.rel_err(torch.from_numpy(got), want.double()) <= 1e-5
 
 
+def _feature_worker(rank, world, port, n, F, C, out_dir):
+    from gnan_amd.distributed import FeaturePartition, feature_parallel_forward, slice_features
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src, dst, x, sd = _problem(n, F, C)
+        part = FeaturePartition(F, world, rank)
+        g = syn.hop1_csr(src, dst, n)
+        lut = O.rho_lut(sd, 3)
+        sd_local = {}
+        for k in range(part.lo, part.hi):                       # the oracle sees only this rank's shape functions
+            for key, v in sd.items():
+                if key.startswith(f"fs.{k}."):
+                    sd_local[f"fs.{k - part.lo}." + key.split(".", 2)[2]] = v
+        st = slice_features(stack(sd, F, 3, 8, C, True), part.lo, part.hi)
+        assert st.F == part.hi - part.lo
+        y = feature_parallel_forward(x[:, part.lo:part.hi].contiguous(), g, st, lut, True, part, out_channels=C,
+                                     compute=_oracle_compute(sd_local, C))
+        np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F", [(2, 5), (3, 4), (4, 3)])
+def test_feature_parallel_forward_equals_single_process(world, F, tmp_path):
+    n, C = 200, 1
+    port = _free_port()
+    mp.spawn(_feature_worker, args=(world, port, n, F, C, str(tmp_path)), nprocs=world, join=True)
+    src, dst, x, sd = _problem(n, F, C)
+    g = syn.hop1_csr(src, dst, n)
+    S = O.feature_mlps(x, sd).sum(1)
+    wt = O.weight_table(O.rho_lut(sd, 3), g.cnt.long().numpy()).expand(n, -1, -1)
+    want = O.spmm_csr(g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy(), S, wt)
+    for r in range(world):                                       # every rank holds the full, identical output
+        got = np.load(tmp_path / f"y{r}.npy")
+        assert O.rel_err(torch.from_numpy(got), want.double()) <= 1e-5
+
+
+def test_choose_partition_by_exchanged_bytes():
+    from gnan_amd.distributed import choose_partition
+    assert choose_partition(10_000_000, 64, 1, 8, "reference") == "feature"     # 2.2 GB gather vs 70 MB reduce
+    assert choose_partition(10_000_000, 64, 1, 8, "sum_first") == "vertex"      # narrow operand: gather it
+    assert choose_partition(10_000_000, 2, 1, 8, "reference") == "vertex"
+    assert choose_partition(10_000_000, 64, 1, 1, "reference") == "vertex"
+
+
 def test_partition_arithmetic():
     for n, world in [(10, 3), (7, 8), (16, 4), (1, 2)]:
         parts = [VertexPartition(n, world, r) for r in range(world)]

@@ -116,3 +116,12 @@ def test_moment_backward_equals_autograd(F, L, H, C, bias, sum_features):
     scale = max(float(w.abs().max()) for w in want)
     for a, b in zip(got, want):
         assert float((a.double() - b).abs().max()) <= 2e-5 * scale
+
+
+def test_builder_refuses_when_pieces_overflow(monkeypatch):
+    """More kinks than the per-layer column budget or MAX_PIECES -> None (callers fall back to the MLP kernels)."""
+    F, L, H, C = 3, 3, 16, 1
+    st = stack(mlp_state(F, L, H, C, True, seed=1), F, L, H, C, True)
+    assert pwl.build_tables(st) is not None
+    monkeypatch.setattr(pwl, "MAX_PIECES", 8)
+    assert pwl.build_tables(st) is None
