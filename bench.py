@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature"],
                     help="multi-GPU decomposition: vertex blocks + all-gather of the operand, or feature columns + "
                          "all-reduce of the [N, C] partial outputs; auto = fewer bytes over xGMI")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="development aid on a 1-GPU box: run rank 0's share of a P-rank job WITHOUT the collectives "
+                         "(stage times only; the printed value is not a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="nodes of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
@@ -123,11 +126,17 @@ def main():
     from gnan_amd.models import TensorGNAN
 
     N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
-    partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, world, args.order)
+    emulated = args.emulate_world > 1 and world == 1
+    pworld = args.emulate_world if emulated else world       # how many shares the work is cut into
+    partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, pworld, args.order)
     if partition == "feature" and args.order != "reference":
         raise SystemExit("--partition feature needs --order reference (sum-first exchanges the narrow operand)")
-    part = VertexPartition(N, world, rank)
-    fpart = FeaturePartition(F, world, rank)
+    part = VertexPartition(N, pworld, rank)
+    fpart = FeaturePartition(F, pworld, rank)
+    if emulated:                                             # same shares, no process group: collectives are skipped
+        part.world = fpart.world = 1
+        part.__class__ = type("EmuV", (VertexPartition,), {"block": property(lambda self: -(-N // pworld))})
+        fpart.__class__ = type("EmuF", (FeaturePartition,), {"block": property(lambda self: -(-F // pworld))})
     t_setup = time.perf_counter()
     src, dst = syn.rmat_edges(args.scale, N, E, seed=0, device=dev)
     if partition == "vertex":
@@ -238,7 +247,7 @@ def main():
             "fmlp_tflops": fmlp_flops(x.shape[0], x.shape[1], H, L, C) / (stages["fmlp"] / 1e3) / 1e12
             if stages["fmlp"] > 0 else None,
             "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "fmlp_algo": args.fmlp_algo,
-            "setup_s": t_setup, "checksum": float(out.double().sum()) if partition == "vertex" or world == 1 else
+            "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": float(out.double().sum()) if partition == "vertex" or world == 1 else
             float(out.double().sum()),
         }
         if world == 1 and not args.no_cpu_baseline:
