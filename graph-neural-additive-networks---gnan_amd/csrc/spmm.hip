@@ -152,6 +152,8 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
   constexpr int UNROLL = 4;
+  constexpr int IW = LPR > 16 ? LPR : 16;  // index pairs fetched per round by one group
+  constexpr int IPL = IW / LPR;            // ... per lane
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   const int sub = lane % LPR;
@@ -182,26 +184,34 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc.v[v] = all.v[v] = 0.f;
 
-    for (int64_t base = lo; base < hi; base += LPR) {
-      const int64_t e = base + sub;
-      int colv = 0, codev = 0;
-      if (e < hi) {
-        if constexpr (!DENSE) colv = p.col[e];
-        codev = p.code[code_base + e];
+    // The group fetches IW = max(LPR, 16) index pairs per round — IPL per lane — so that narrow operand
+    // rows (few lanes per group) still see 16 gathers between two dependent index loads.
+    for (int64_t base = lo; base < hi; base += IW) {
+      int colv[IPL], codev[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const int64_t e = base + sub * IPL + r;
+        colv[r] = codev[r] = 0;
+        if (e < hi) {
+          if constexpr (!DENSE) colv[r] = p.col[e];
+          codev[r] = p.code[code_base + e];
+        }
       }
-      const int m = static_cast<int>(hi - base < LPR ? hi - base : LPR);
-      for (int j0 = 0; j0 < m; j0 += UNROLL) {
+      const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
+#pragma unroll
+      for (int j0 = 0; j0 < IW; j0 += UNROLL) {
+        if (j0 >= m) break;
         Vec<VEC> s[UNROLL];
         int d[UNROLL], c[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-          const int j = j0 + u;
+          const int j = j0 + u;              // compile-time after unrolling: lane j / IPL holds it in register j % IPL
           if constexpr (DENSE) {
             c[u] = static_cast<int>(base) + j;
           } else {
-            c[u] = __shfl(colv, j, LPR);
+            c[u] = __shfl(colv[j % IPL], j / IPL, LPR);
           }
-          d[u] = __shfl(codev, j, LPR);
+          d[u] = __shfl(codev[j % IPL], j / IPL, LPR);
           d[u] = d[u] < rest ? d[u] : rest;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) s[u].v[v] = 0.f;
