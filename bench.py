@@ -51,7 +51,7 @@ def parse():
                     help="development aid on a 1-GPU box: run rank 0's share of a P-rank job WITHOUT the collectives "
                          "(stage times only; the printed value is not a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-nodes", type=int, default=500_000, help="nodes of the CPU shape-function sample")
+    ap.add_argument("--cpu-nodes", type=int, default=500_000, help="upper bound of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
     return ap.parse_args()
 
@@ -68,16 +68,31 @@ def fmlp_flops(n, F, H, L, C):
 
 
 def cpu_baseline(args, model, g, x, operand_full):
-    """Time the oracle (PyTorch-CPU restatement of the reference path) on a bounded sample, all host cores."""
+    """Time the oracle (PyTorch-CPU restatement of the reference path) on a bounded sample of the same workload.
+
+    Shape functions: the reference's own per-feature Python loop of nn.Linear calls (GNAN.py:58-62); the thread
+    count is calibrated (all cores is not the fastest for F small GEMMs) and reported.  Aggregation:
+    torch.sparse_csr (MKL) with the same weight table, all cores.  Each leg is sized to ~10 s and scaled to
+    the full graph."""
     from oracle import gnan_oracle as O
-    torch.set_num_threads(os.cpu_count())
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    n_f = min(args.cpu_nodes, x.shape[0])
-    xs = x[:n_f].cpu()
+    ncpu = os.cpu_count()
+    x_host = x[: min(args.cpu_nodes, x.shape[0])].cpu()
+    rates = {}
+    for th in sorted({ncpu, min(ncpu, 64), min(ncpu, 16)}):
+        torch.set_num_threads(th)
+        O.feature_mlps(x_host[:2000], sd)                          # warm-up (MKL thread pool, allocator)
+        t0 = time.perf_counter()
+        O.feature_mlps(x_host[:10000], sd)
+        rates[th] = 10000 / (time.perf_counter() - t0)
+    th_f = max(rates, key=rates.get)
+    torch.set_num_threads(th_f)
+    n_f = int(min(x_host.shape[0], max(10000, rates[th_f] * 10)))
     t0 = time.perf_counter()
-    fx = O.feature_mlps(xs, sd)                                   # Python loop over features, GNAN.py:58-62
+    O.feature_mlps(x_host[:n_f], sd)                               # Python loop over features, GNAN.py:58-62
     t_f = time.perf_counter() - t0
-    del fx
+
+    torch.set_num_threads(ncpu)
     n_r = min(args.cpu_rows, g.n_rows)
     rowptr = g.rowptr[: n_r + 1].cpu().long().numpy()
     nnz_s = int(rowptr[-1])
@@ -86,6 +101,7 @@ def cpu_baseline(args, model, g, x, operand_full):
     cnt = g.cnt[:n_r].cpu().long().numpy()
     S = operand_full.cpu()
     lut = O.rho_lut(sd, g.n_codes)
+    O.spmm_csr_sparse(rowptr[:1001], col[: rowptr[1000]], code[: rowptr[1000]], S, lut, cnt[:1000])   # warm-up
     t0 = time.perf_counter()
     y = O.spmm_csr_sparse(rowptr, col, code, S, lut, cnt)
     y = y.sum(dim=1)
@@ -93,11 +109,13 @@ def cpu_baseline(args, model, g, x, operand_full):
     n_tot, nnz_tot = args.nodes, args.edges + args.nodes
     est = t_f * n_tot / n_f + t_s * nnz_tot / nnz_s
     return {
-        "value": args.edges / est, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"oracle/gnan_oracle.py on host: shape functions on the first {n_f} nodes ({t_f:.2f} s) + "
-                   f"torch.sparse_csr aggregation of the first {n_r} rows / {nnz_s} pairs against the full "
-                   f"{S.shape[0]}x{S.shape[1]} operand ({t_s:.2f} s); scaled to the full graph"),
-        "fmlp_nodes_per_s": n_f / t_f, "spmm_pairs_per_s": nnz_s / t_s,
+        "value": args.edges / est, "unit": "edges/s", "cores": th_f, "kind": "port",
+        "sample": (f"oracle/gnan_oracle.py on the host ({ncpu} hardware threads): shape functions on the first {n_f} "
+                   f"nodes with {th_f} threads ({t_f:.2f} s; calibrated nodes/s by threads: "
+                   f"{ {k: round(v) for k, v in rates.items()} }) + torch.sparse_csr aggregation of the first {n_r} "
+                   f"rows / {nnz_s} pairs against the full {S.shape[0]}x{S.shape[1]} operand with {ncpu} threads "
+                   f"({t_s:.2f} s); both legs scaled to the full graph"),
+        "fmlp_nodes_per_s": n_f / t_f, "spmm_pairs_per_s": nnz_s / t_s, "spmm_cores": ncpu,
     }
 
 

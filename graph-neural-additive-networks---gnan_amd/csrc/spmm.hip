@@ -152,7 +152,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
   constexpr int UNROLL = 4;
-  constexpr int IW = LPR > 16 ? LPR : 16;  // index pairs fetched per round by one group
+  constexpr int IW = LPR >= 8 ? LPR : 16;  // index pairs fetched per round by one group (narrow rows: 16)
   constexpr int IPL = IW / LPR;            // ... per lane
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -198,9 +198,10 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
         }
       }
       const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
-#pragma unroll
-      for (int j0 = 0; j0 < IW; j0 += UNROLL) {
-        if (j0 >= m) break;
+      // IPL > 1: fully unrolled so that the register index j % IPL is static; IPL == 1: plain runtime loop
+#pragma unroll(IPL > 1 ? IW / UNROLL : 1)
+      for (int j0 = 0; j0 < (IPL > 1 ? IW : m); j0 += UNROLL) {
+        if (IPL > 1 && j0 >= m) break;
         Vec<VEC> s[UNROLL];
         int d[UNROLL], c[UNROLL];
 #pragma unroll
