@@ -7,9 +7,9 @@
 // searches in LDS.  HBM-bound (x in, fx out), no matrix work at all.
 //
 // Mapping: a workgroup owns a contiguous block of nodes and a group of <= FG consecutive features whose
-// tables it copies to LDS once (amortised over the node block).  Thread = node: it loads the node's FG x
-// values (one 64-B sector for FG = 16), runs the FG searches in lock-step (FG independent LDS reads per
-// step hide the LDS latency; all lanes of a wave search the same table), and stores FG*C results.
+// tables it copies to LDS once (amortised over the node block).  Thread = (node, 4 features): one 16-B load,
+// 4 searches in lock-step (independent LDS reads per step hide the LDS latency), one 16-B store; the 4 threads
+// of a node cover one 64-B sector of x and of fx.
 #include "common.hpp"
 
 namespace {
@@ -31,11 +31,44 @@ struct Params {
   int64_t out_stride;
 };
 
+// Thread = (node, feature quad): FPT = min(FG, 4) features per thread, TPN = FG / FPT threads per node, so a
+// node's FG x values are one contiguous 16-B load per thread (a 64-B sector per node for FG = 16), the
+// per-thread state is a handful of registers (8 waves/SIMD), and every thread runs FPT independent searches.
+template <int FG>
+struct Map {
+  static constexpr int FPT = FG < 4 ? FG : 4;
+  static constexpr int TPN = FG / FPT;
+  static constexpr int NODES = 256 / TPN;  // nodes per workgroup pass
+};
+
+// Piece of feature f (group-relative, LDS tables): i = #{ j in 1..pn : anchor[po + j] <= x }, searched for
+// the thread's FPT features in lock-step (FPT independent LDS reads per step).
+template <int FPT>
+__device__ __forceinline__ void search(const float* anchor_l, const int (&po)[FPT], const int (&pn)[FPT],
+                                       const float (&xv)[FPT], int step0, int (&idx)[FPT]) {
+#pragma unroll
+  for (int f = 0; f < FPT; ++f) idx[f] = 0;
+  for (int step = step0; step > 0; step >>= 1) {
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const int j = idx[f] + step;
+      const int jj = j <= pn[f] ? j : 0;  // out of range -> harmless in-range read
+      const float a = anchor_l[po[f] + jj];
+      idx[f] = (j <= pn[f] && a <= xv[f]) ? j : idx[f];
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < FPT; ++f) idx[f] += po[f];
+}
+
 template <int FG>
 __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
+  constexpr int FPT = Map<FG>::FPT, TPN = Map<FG>::TPN, NODES = Map<FG>::NODES;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_off[FG + 1];
   const int tid = threadIdx.x;
+  const int q = tid % TPN;            // which feature quad of the group
+  const int nl = tid / TPN;           // node slot inside a pass
   const int C = p.C;
   const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
@@ -58,69 +91,57 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
     }
     if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
     __syncthreads();
-    int po[FG], pn[FG];  // piece offset / number of breakpoints of each feature of the group (uniform)
+    int po[FPT], pn[FPT];
+    bool live[FPT];
 #pragma unroll
-    for (int f = 0; f < FG; ++f) {
-      po[f] = f < nf ? s_off[f] : 0;
-      pn[f] = f < nf ? s_off[f + 1] - s_off[f] - 1 : 0;
+    for (int f = 0; f < FPT; ++f) {
+      const int fg = q * FPT + f;
+      live[f] = fg < nf;
+      po[f] = live[f] ? s_off[fg] : 0;
+      pn[f] = live[f] ? s_off[fg + 1] - s_off[fg] - 1 : 0;
     }
 
-    for (int64_t n = n_lo + tid; n < n_hi; n += 256) {
-      float xv[FG];
-      const float* xr = p.x + n * p.x_stride + k0;
-      if (p.vec_x && nf == FG) {
-#pragma unroll
-        for (int q = 0; q < FG / 4; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(xr + 4 * q);
-          xv[4 * q + 0] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w;
-        }
+    for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
+      float xv[FPT];
+      const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
+      if (FPT == 4 && p.vec_x && nf == FG) {
+        const float4 t = *reinterpret_cast<const float4*>(xr);
+        xv[0] = t.x; xv[1 % FPT] = t.y; xv[2 % FPT] = t.z; xv[3 % FPT] = t.w;
       } else {
 #pragma unroll
-        for (int f = 0; f < FG; ++f) xv[f] = f < nf ? xr[f] : 0.f;
+        for (int f = 0; f < FPT; ++f) xv[f] = live[f] ? xr[f] : 0.f;
       }
-      int idx[FG];
+      int idx[FPT];
+      search<FPT>(anchor_l, po, pn, xv, p.step0, idx);
+      float d[FPT];
 #pragma unroll
-      for (int f = 0; f < FG; ++f) idx[f] = 0;
-      for (int step = p.step0; step > 0; step >>= 1) {
-#pragma unroll
-        for (int f = 0; f < FG; ++f) {
-          const int j = idx[f] + step;
-          const int jj = j <= pn[f] ? j : 0;                     // out of range -> harmless in-range read
-          const float a = anchor_l[po[f] + jj];
-          idx[f] = (j <= pn[f] && a <= xv[f]) ? j : idx[f];
-        }
-      }
-      float d[FG];
-#pragma unroll
-      for (int f = 0; f < FG; ++f) {
-        idx[f] += po[f];
-        d[f] = xv[f] - anchor_l[idx[f]];
-      }
+      for (int f = 0; f < FPT; ++f) d[f] = xv[f] - anchor_l[idx[f]];
+
       if (p.sum_features) {
         float* o = p.out + n * p.out_stride;
         for (int c = 0; c < C; ++c) {
           float a = 0.f;
 #pragma unroll
-          for (int f = 0; f < FG; ++f)
-            if (f < nf) a += fmaf(slope_l[idx[f] * C + c], d[f], val_l[idx[f] * C + c]);
-          o[c] = g == 0 ? a : o[c] + a;   // groups run one after the other inside the workgroup: no race
+          for (int f = 0; f < FPT; ++f)
+            if (live[f]) a += fmaf(slope_l[idx[f] * C + c], d[f], val_l[idx[f] * C + c]);
+#pragma unroll
+          for (int off = 1; off < TPN; off <<= 1) a += __shfl_xor(a, off);   // the node's TPN threads
+          // groups run one after the other inside the workgroup and a node keeps its thread: no race
+          if (q == 0) o[c] = g == 0 ? a : o[c] + a;
         }
       } else {
-        float* o = p.out + n * p.out_stride + static_cast<int64_t>(k0) * C;
-        if (C == 1 && p.vec_out && nf == FG) {
-#pragma unroll
-          for (int q = 0; q < FG / 4; ++q) {
-            float4 t;
-            t.x = fmaf(slope_l[idx[4 * q + 0]], d[4 * q + 0], val_l[idx[4 * q + 0]]);
-            t.y = fmaf(slope_l[idx[4 * q + 1]], d[4 * q + 1], val_l[idx[4 * q + 1]]);
-            t.z = fmaf(slope_l[idx[4 * q + 2]], d[4 * q + 2], val_l[idx[4 * q + 2]]);
-            t.w = fmaf(slope_l[idx[4 * q + 3]], d[4 * q + 3], val_l[idx[4 * q + 3]]);
-            *reinterpret_cast<float4*>(o + 4 * q) = t;
-          }
+        float* o = p.out + n * p.out_stride + static_cast<int64_t>(k0 + q * FPT) * C;
+        if (FPT == 4 && C == 1 && p.vec_out && nf == FG) {
+          float4 t;
+          t.x = fmaf(slope_l[idx[0]], d[0], val_l[idx[0]]);
+          t.y = fmaf(slope_l[idx[1 % FPT]], d[1 % FPT], val_l[idx[1 % FPT]]);
+          t.z = fmaf(slope_l[idx[2 % FPT]], d[2 % FPT], val_l[idx[2 % FPT]]);
+          t.w = fmaf(slope_l[idx[3 % FPT]], d[3 % FPT], val_l[idx[3 % FPT]]);
+          *reinterpret_cast<float4*>(o) = t;
         } else {
 #pragma unroll
-          for (int f = 0; f < FG; ++f)
-            if (f < nf)
+          for (int f = 0; f < FPT; ++f)
+            if (live[f])
               for (int c = 0; c < C; ++c) o[f * C + c] = fmaf(slope_l[idx[f] * C + c], d[f], val_l[idx[f] * C + c]);
         }
       }
@@ -146,15 +167,16 @@ struct MomentParams {
 
 template <int FG>
 __global__ __launch_bounds__(256) void fpwl_moments_kernel(const MomentParams mp) {
+  constexpr int FPT = Map<FG>::FPT, TPN = Map<FG>::TPN, NODES = Map<FG>::NODES;
   const Params& p = mp.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_off[FG + 1];
   const int tid = threadIdx.x;
+  const int q = tid % TPN, nl = tid / TPN;
   const int C = p.C;
   const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
-  const int g_idx = blockIdx.y;
-  const int k0 = g_idx * FG;
+  const int k0 = blockIdx.y * FG;
   const int nf = p.F - k0 < FG ? p.F - k0 : FG;
   const int base = p.off[k0];
   const int tot = p.off[k0 + nf] - base;
@@ -164,36 +186,28 @@ __global__ __launch_bounds__(256) void fpwl_moments_kernel(const MomentParams mp
   for (int i = tid; i < tot * 2 * C; i += 256) bins[i] = 0.f;
   if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
   __syncthreads();
-  int po[FG], pn[FG];
+  int po[FPT], pn[FPT];
+  bool live[FPT];
 #pragma unroll
-  for (int f = 0; f < FG; ++f) {
-    po[f] = f < nf ? s_off[f] : 0;
-    pn[f] = f < nf ? s_off[f + 1] - s_off[f] - 1 : 0;
+  for (int f = 0; f < FPT; ++f) {
+    const int fg = q * FPT + f;
+    live[f] = fg < nf;
+    po[f] = live[f] ? s_off[fg] : 0;
+    pn[f] = live[f] ? s_off[fg + 1] - s_off[fg] - 1 : 0;
   }
-  for (int64_t n = n_lo + tid; n < n_hi; n += 256) {
-    float xv[FG];
-    const float* xr = p.x + n * p.x_stride + k0;
+  for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
+    float xv[FPT];
+    const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
 #pragma unroll
-    for (int f = 0; f < FG; ++f) xv[f] = f < nf ? xr[f] : 0.f;
-    int idx[FG];
+    for (int f = 0; f < FPT; ++f) xv[f] = live[f] ? xr[f] : 0.f;
+    int idx[FPT];
+    search<FPT>(anchor_l, po, pn, xv, p.step0, idx);
+    const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0 + q * FPT) * C);
 #pragma unroll
-    for (int f = 0; f < FG; ++f) idx[f] = 0;
-    for (int step = p.step0; step > 0; step >>= 1) {
-#pragma unroll
-      for (int f = 0; f < FG; ++f) {
-        const int j = idx[f] + step;
-        const int jj = j <= pn[f] ? j : 0;
-        const float a = anchor_l[po[f] + jj];
-        idx[f] = (j <= pn[f] && a <= xv[f]) ? j : idx[f];
-      }
-    }
-    const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0) * C);
-#pragma unroll
-    for (int f = 0; f < FG; ++f) {
-      if (f < nf) {
-        const int piece = po[f] + idx[f];
-        const float d = xv[f] - anchor_l[piece];
-        float* b = bins + static_cast<int64_t>(piece) * 2 * C;
+    for (int f = 0; f < FPT; ++f) {
+      if (live[f]) {
+        const float d = xv[f] - anchor_l[idx[f]];
+        float* b = bins + static_cast<int64_t>(idx[f]) * 2 * C;
         for (int c = 0; c < C; ++c) {
           const float gv = gr[p.sum_features ? c : f * C + c];
           atomicAdd(b + c, gv);
