@@ -61,7 +61,8 @@ __device__ __forceinline__ void search(const float* anchor_l, const int (&po)[FP
   for (int f = 0; f < FPT; ++f) idx[f] += po[f];
 }
 
-template <int FG>
+// SUM: out[n, c] = sum over features (f_sums, GNAN.py:157); FAST: C == 1, full groups, 16-B aligned rows.
+template <int FG, bool SUM, bool FAST>
 __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   constexpr int FPT = Map<FG>::FPT, TPN = Map<FG>::TPN, NODES = Map<FG>::NODES;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,12 +73,12 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   const int C = p.C;
   const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
-  const int g_lo = p.sum_features ? 0 : blockIdx.y;
-  const int g_hi = p.sum_features ? p.n_groups : g_lo + 1;
+  const int g_lo = SUM ? 0 : blockIdx.y;
+  const int g_hi = SUM ? p.n_groups : g_lo + 1;
 
   for (int g = g_lo; g < g_hi; ++g) {
     const int k0 = g * FG;
-    const int nf = p.F - k0 < FG ? p.F - k0 : FG;
+    const int nf = FAST ? FG : (p.F - k0 < FG ? p.F - k0 : FG);
     const int base = p.off[k0];
     const int tot = p.off[k0 + nf] - base;
     float* anchor_l = smem;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
     for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
       float xv[FPT];
       const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
-      if (FPT == 4 && p.vec_x && nf == FG) {
+      if constexpr (FAST && FPT == 4) {
         const float4 t = *reinterpret_cast<const float4*>(xr);
         xv[0] = t.x; xv[1 % FPT] = t.y; xv[2 % FPT] = t.z; xv[3 % FPT] = t.w;
       } else {
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
 #pragma unroll
       for (int f = 0; f < FPT; ++f) d[f] = xv[f] - anchor_l[idx[f]];
 
-      if (p.sum_features) {
+      if constexpr (SUM) {
         float* o = p.out + n * p.out_stride;
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < (FAST ? 1 : C); ++c) {
           float a = 0.f;
 #pragma unroll
           for (int f = 0; f < FPT; ++f)
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
         }
       } else {
         float* o = p.out + n * p.out_stride + static_cast<int64_t>(k0 + q * FPT) * C;
-        if (FPT == 4 && C == 1 && p.vec_out && nf == FG) {
+        if constexpr (FAST && FPT == 4) {
           float4 t;
           t.x = fmaf(slope_l[idx[0]], d[0], val_l[idx[0]]);
           t.y = fmaf(slope_l[idx[1 % FPT]], d[1 % FPT], val_l[idx[1 % FPT]]);
@@ -241,16 +242,22 @@ int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
 
 template <int FG>
 int launch(const Params& p, size_t lds, hipStream_t st) {
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fpwl_kernel<FG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  }
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
   if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
   const dim3 grid(static_cast<unsigned>(bx), p.sum_features ? 1u : static_cast<unsigned>(p.n_groups));
-  hipLaunchKernelGGL(fpwl_kernel<FG>, grid, dim3(256), lds, st, p);
-  return gnan::check_launch("fpwl_kernel");
+  // FAST: one output channel, whole groups only, 16-B aligned x (and fx) rows
+  const bool fast = FG % 4 == 0 && p.C == 1 && p.F % FG == 0 && p.vec_x && (p.sum_features || p.vec_out);
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, p);
+    return gnan::check_launch("fpwl_kernel");
+  };
+  if (p.sum_features) return fast ? go(fpwl_kernel<FG, true, true>) : go(fpwl_kernel<FG, true, false>);
+  return fast ? go(fpwl_kernel<FG, false, true>) : go(fpwl_kernel<FG, false, false>);
 }
 
 }  // namespace

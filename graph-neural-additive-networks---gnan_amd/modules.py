@@ -58,14 +58,25 @@ class _PathBase(nn.Module):
 
     def _init_caches(self):
         self._stack_cache = {}
+        self._flat_params = {}
         self._graph_cache = None
+
+    def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): storage moves, caches are stale
+        out = super()._apply(fn, *args, **kwargs)
+        self._stack_cache, self._flat_params = {}, {}
+        return out
 
     # ---- parameters -> stacked device tensors --------------------------------------------
     def _stacked(self, name: str, mlps) -> StackedMLP:
-        params = [p for seq in mlps for p in seq.parameters()]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        """Stacked weights of F per-feature MLPs.  With autograd on, ``torch.stack`` is part of the graph; without
+        it the stack is cached and keyed on the parameters' version counters (in-place updates — optimizer steps,
+        ``load_state_dict`` — bump them), so an evaluation loop pays for the F x L small copies once."""
+        params = self._flat_params.get(name)
+        if params is None:                               # walking 10^3 nn.Sequential objects costs ~20 ms: do it once
+            params = self._flat_params[name] = [p for seq in mlps for p in seq.parameters()]
+        if torch.is_grad_enabled() and params[0].requires_grad:
             return stack_mlps(mlps)                       # autograd flows back through torch.stack
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple([p._version for p in params])
         hit = self._stack_cache.get(name)
         if hit is None or hit[0] != key:
             with torch.no_grad():
