@@ -29,6 +29,7 @@ struct Params {
   int vec_x, vec_out;
   float* out;
   int64_t out_stride;
+  double* col_partial;   // optional [gridDim.x, F]: per-workgroup column sums of the output (FAST, per-feature mode)
 };
 
 // Thread = (node, feature quad): FPT = min(FG, 4) features per thread, TPN = FG / FPT threads per node, so a
@@ -102,6 +103,9 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
       pn[f] = live[f] ? s_off[fg + 1] - s_off[fg] - 1 : 0;
     }
 
+    float ps[FPT];  // this thread's share of the column sums of fx (rest-bucket total of the aggregation)
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) ps[f] = 0.f;
     for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
       float xv[FPT];
       const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
           t.z = fmaf(slope_l[idx[2 % FPT]], d[2 % FPT], val_l[idx[2 % FPT]]);
           t.w = fmaf(slope_l[idx[3 % FPT]], d[3 % FPT], val_l[idx[3 % FPT]]);
           *reinterpret_cast<float4*>(o) = t;
+          ps[0] += t.x; ps[1 % FPT] += t.y; ps[2 % FPT] += t.z; ps[3 % FPT] += t.w;
         } else {
 #pragma unroll
           for (int f = 0; f < FPT; ++f)
@@ -147,7 +152,31 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
         }
       }
     }
+    if constexpr (FAST && !SUM && FPT == 4) {
+      if (p.col_partial) {   // fixed-order workgroup reduction: 64 node slots per feature, float64
+        float* red = smem + tot * 3;               // FAST: C == 1, tables take 3 floats per piece
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) red[tid * FPT + f] = ps[f];
+        __syncthreads();
+        if (tid < FG) {
+          const int qq = tid / FPT, ff = tid % FPT;
+          double acc = 0.0;
+          for (int s2 = 0; s2 < NODES; ++s2) acc += red[(s2 * TPN + qq) * FPT + ff];
+          p.col_partial[static_cast<int64_t>(blockIdx.x) * p.F + k0 + tid] = acc;
+        }
+      }
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void fpwl_total_kernel(const double* __restrict__ partial, int blocks, int W,
+                                                         float* __restrict__ total) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += partial[static_cast<int64_t>(b) * W + w];
+  total[w] = static_cast<float>(s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -241,12 +270,17 @@ int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
 }
 
 template <int FG>
-int launch(const Params& p, size_t lds, hipStream_t st) {
+int launch(const Params& p, size_t lds, hipStream_t st, float* total_out) {
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
   if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
   const dim3 grid(static_cast<unsigned>(bx), p.sum_features ? 1u : static_cast<unsigned>(p.n_groups));
   // FAST: one output channel, whole groups only, 16-B aligned x (and fx) rows
   const bool fast = FG % 4 == 0 && p.C == 1 && p.F % FG == 0 && p.vec_x && (p.sum_features || p.vec_out);
+  if (p.col_partial) {
+    if (!fast || p.sum_features)
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: fused column sums need C == 1, F %% %d == 0, 16-B aligned rows, per-feature output", FG);
+    lds += 256 * 4 * sizeof(float);
+  }
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -257,7 +291,13 @@ int launch(const Params& p, size_t lds, hipStream_t st) {
     return gnan::check_launch("fpwl_kernel");
   };
   if (p.sum_features) return fast ? go(fpwl_kernel<FG, true, true>) : go(fpwl_kernel<FG, true, false>);
-  return fast ? go(fpwl_kernel<FG, false, true>) : go(fpwl_kernel<FG, false, false>);
+  if (int rc = fast ? go(fpwl_kernel<FG, false, true>) : go(fpwl_kernel<FG, false, false>)) return rc;
+  if (p.col_partial) {
+    hipLaunchKernelGGL(fpwl_total_kernel, dim3((p.F + 255) / 256), dim3(256), 0, st, p.col_partial,
+                       static_cast<int>(bx), p.F, total_out);
+    return gnan::check_launch("fpwl_total_kernel");
+  }
+  return GNAN_OK;
 }
 
 }  // namespace
@@ -292,6 +332,7 @@ Params base_params(const gnan_fpwl_args* a) {
   p.sum_features = a->sum_features;
   p.vec_x = p.vec_out = 0;
   p.out = a->out; p.out_stride = a->out_stride;
+  p.col_partial = nullptr;
   return p;
 }
 }  // namespace
@@ -329,12 +370,26 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
   p.vec_x = fg % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 && aligned(a->x);
   p.vec_out = fg % 4 == 0 && a->F % 4 == 0 && a->out_stride % 4 == 0 && aligned(a->out);
+  if (a->total) {
+    const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+    const size_t need = static_cast<size_t>(bx) * a->F * sizeof(double);
+    if (a->total_workspace == nullptr || a->total_workspace_bytes < need)
+      return gnan::fail(GNAN_ERR_WORKSPACE, "fpwl: total workspace %zu B < required %zu B", a->total_workspace_bytes, need);
+    p.col_partial = static_cast<double*>(a->total_workspace);
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (fg) {
-    case 1: return launch<1>(p, lds, st);
-    case 2: return launch<2>(p, lds, st);
-    case 4: return launch<4>(p, lds, st);
-    case 8: return launch<8>(p, lds, st);
-    default: return launch<16>(p, lds, st);
+    case 1: return launch<1>(p, lds, st, a->total);
+    case 2: return launch<2>(p, lds, st, a->total);
+    case 4: return launch<4>(p, lds, st, a->total);
+    case 8: return launch<8>(p, lds, st, a->total);
+    default: return launch<16>(p, lds, st, a->total);
   }
+}
+
+extern "C" size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a) {
+  if (!a || a->n <= 0) return 0;
+  const Params p = base_params(a);
+  const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+  return static_cast<size_t>(bx) * a->F * sizeof(double);
 }

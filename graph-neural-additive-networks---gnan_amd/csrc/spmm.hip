@@ -16,6 +16,8 @@
 // HBM-bound: per edge 4 B col + 1 B code + W*4 B gathered row; per row rowptr + W*4 B store.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 using gnan::kWave;
@@ -147,11 +149,12 @@ __device__ __forceinline__ SmallW small_weights(const Params& p, int64_t i) {
 // ---------------------------------------------------------------------------------------------
 // rows kernel: one LPR-lane group per output row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool DENSE, bool SMALLD>
+template <int VEC, int LPR, bool DENSE, bool SMALLD, int TUNE = 0>
 __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_id) {
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
-  constexpr int UNROLL = 4;
+  constexpr int UNROLL = (TUNE & 1) ? 8 : 4;
+  constexpr bool NT_IDX = (TUNE & 2) != 0;
   constexpr int IW = LPR >= 8 ? LPR : 16;  // index pairs fetched per round by one group (narrow rows: 16)
   constexpr int IPL = IW / LPR;            // ... per lane
   const int lane = threadIdx.x & (kWave - 1);
@@ -193,8 +196,13 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
         const int64_t e = base + sub * IPL + r;
         colv[r] = codev[r] = 0;
         if (e < hi) {
-          if constexpr (!DENSE) colv[r] = p.col[e];
-          codev[r] = p.code[code_base + e];
+          if constexpr (NT_IDX) {   // index streams are read once: keep them out of the way of the gathered rows
+            if constexpr (!DENSE) colv[r] = __builtin_nontemporal_load(p.col + e);
+            codev[r] = __builtin_nontemporal_load(p.code + code_base + e);
+          } else {
+            if constexpr (!DENSE) colv[r] = p.col[e];
+            codev[r] = p.code[code_base + e];
+          }
         }
       }
       const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
@@ -376,16 +384,16 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
 
 // One launch covers everything: workgroups [0, n_slices) take the hub-row slices (they start first,
 // so the long-latency slices overlap the bulk), the rest take 4*G ordinary rows each.
-template <int VEC, int LPR, bool DENSE, bool SMALLD>
+template <int VEC, int LPR, bool DENSE, bool SMALLD, int TUNE = 0>
 __global__ __launch_bounds__(256) void spmm_kernel(const Params p) {
   if constexpr (!DENSE) {
     if (static_cast<int>(blockIdx.x) < p.n_slices) {
       slice_body<VEC, LPR, SMALLD>(p, static_cast<int>(blockIdx.x));
       return;
     }
-    rows_body<VEC, LPR, false, SMALLD>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
+    rows_body<VEC, LPR, false, SMALLD, TUNE>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
   } else {
-    rows_body<VEC, LPR, true, SMALLD>(p, static_cast<int64_t>(blockIdx.x));
+    rows_body<VEC, LPR, true, SMALLD, TUNE>(p, static_cast<int64_t>(blockIdx.x));
   }
 }
 
@@ -531,6 +539,14 @@ int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
   if (dense) {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, true, false>), grid, block, 0, st, p);
   } else if (smalld) {
+    static const int tune = getenv("GNAN_SPMM_TUNE") ? atoi(getenv("GNAN_SPMM_TUNE")) : 0;   // development knob
+    if (VEC == 4 && LPR == 16 && tune == 1) {
+      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, 1>), grid, block, 0, st, p);
+    } else if (VEC == 4 && LPR == 16 && tune == 2) {
+      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, 2>), grid, block, 0, st, p);
+    } else if (VEC == 4 && LPR == 16 && tune == 3) {
+      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, 3>), grid, block, 0, st, p);
+    } else
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true>), grid, block, 0, st, p);
   } else {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, false>), grid, block, 0, st, p);

@@ -80,11 +80,14 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     ops = compute or _hip_compute()
     mark = marks or (lambda name: None)
     mark("start")
-    operand_local = ops["feature_mlps"](x_local, stacked, order == "sum_first")
+    # the column sums of the operand (rest-bucket total) come out of the shape-function pass; the ranks add
+    # their W-float partials instead of re-reading the gathered operand
+    operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True)
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
     mark("gather")
-    total = ops["column_sums"](operand)          # rest-bucket operand; every rank derives it from the gathered rows
+    if part.world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     mark("total")
     # reference order: the feature sum of models.py:375-376 rides in the aggregation kernel's epilogue
     Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total,
@@ -147,10 +150,9 @@ def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lu
     mark("start")
     n = graph_full.n_rows
     if part.hi > part.lo:
-        operand = ops["feature_mlps"](x_cols, stacked_local, False)            # [N, Fp*C]
+        operand, total = ops["feature_mlps"](x_cols, stacked_local, False, return_total=True)   # [N, Fp*C], [Fp*C]
         mark("fmlp")
         mark("gather")                                                         # nothing to exchange here
-        total = ops["column_sums"](operand)
         mark("total")
         Y = ops["aggregate"](graph_full, operand, lut, use_cnt, s_total=total, reduce_channels=out_channels)
     else:                                                                      # more ranks than features

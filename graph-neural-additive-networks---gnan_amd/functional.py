@@ -69,8 +69,10 @@ FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to pin one of the three evaluatio
 PWL_MIN_WORK = 1 << 24       # AUTO tabulates the shape functions once n*F look-ups outweigh the table build
 
 
-def _fpwl_launch(x: torch.Tensor, t, sum_features: bool) -> torch.Tensor:
-    """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``."""
+def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False):
+    """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``.
+    With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
+    when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
     x = x.detach().float()
     if x.stride(1) != 1:
         x = x.contiguous()
@@ -82,8 +84,16 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool) -> torch.Tensor:
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
                       out=_lib.ptr(out), out_stride=out.stride(0))
+    total = None
+    fpg = t.features_per_group
+    if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and n > 0):
+        total = torch.empty(F, dtype=torch.float32, device=x.device)
+        need = _lib.lib().gnan_fpwl_total_workspace_bytes(a)
+        ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
+        a.total, a.total_workspace, a.total_workspace_bytes = _lib.ptr(total), _lib.ptr(ws), need
     _lib.check(_lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)), "gnan_fpwl_fwd")
-    return out
+    return (out, total) if want_total else out
 
 
 def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) -> torch.Tensor:
@@ -106,18 +116,20 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) ->
     return M
 
 
-def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool):
+def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False):
     """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
-    Returns ``(out, tables or None)``."""
+    Returns ``(out, tables or None, total or None)``."""
     algo = FMLP_ALGO
     if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= PWL_MIN_WORK):
         from .pwl import build_tables
         tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
         if tables is not None:
-            return _fpwl_launch(x, tables, sum_features), tables
+            out, total = _fpwl_launch(x, tables, sum_features, want_total=True) if want_total else \
+                (_fpwl_launch(x, tables, sum_features), None)
+            return out, tables, total
         if algo == _lib.FMLP_PWL:
             raise _lib.GnanHipError("shape functions need more pieces than the look-up kernel supports")
-    return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo), None
+    return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo), None, None
 
 
 def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int = 0) -> torch.Tensor:
@@ -171,16 +183,21 @@ _BWD_CHUNK_ELEMS = 1 << 28   # activation floats per recompute chunk (1 GiB)
 
 class _FeatureMLPs(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, sum_features, L, H, C, F, *params):
+    def forward(ctx, x, sum_features, want_total, L, H, C, F, *params):
         p = StackedMLP(*params, L, H, C, F)
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
-        out, ctx.tables = _fmlp_forward(x, p, sum_features)
-        return out
+        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, want_total)
+        if not want_total:
+            return out
+        if total is None:
+            total = column_sums(out)
+        ctx.mark_non_differentiable(total)     # d total / d out is accounted for inside the aggregation's backward
+        return out, total
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *unused):
         sum_features, L, H, C, F = ctx.meta
         saved = list(ctx.saved_tensors)
         x = saved.pop(0)
@@ -199,7 +216,7 @@ class _FeatureMLPs(torch.autograd.Function):
             it = iter(got)
             pg = [None if not present else next(it) for present in ctx.present]
             pg = [None if g is None else g.to(torch.float32) for g in pg]
-            return (None, None, None, None, None, None, *pg)
+            return (None, None, None, None, None, None, None, *pg)
         grads = [torch.zeros_like(t) for t in live]
         n = x.shape[0]
         chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))
@@ -218,15 +235,17 @@ class _FeatureMLPs(torch.autograd.Function):
                 gx[lo:lo + chunk] = got[-1]
         it = iter(grads)
         pg = [next(it) if present else None for present in ctx.present]
-        return (gx, None, None, None, None, None, *pg)
+        return (gx, None, None, None, None, None, None, *pg)
 
 
-def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
-    """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157."""
+def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False):
+    """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157.
+    ``return_total`` additionally returns the column sums of the result (the aggregation's rest-bucket operand),
+    fused into the look-up kernel where possible."""
     _lib.require_device(x, p.w_last)
     if x.shape[1] != p.F:
         raise ValueError(f"x has {x.shape[1]} feature columns, the model was built for {p.F}")
-    return _FeatureMLPs.apply(x, sum_features, p.L, p.H, p.C, p.F,
+    return _FeatureMLPs.apply(x, sum_features, return_total, p.L, p.H, p.C, p.F,
                               p.w_first, p.b_first, p.w_mid, p.b_mid, p.w_last, p.b_last)
 
 

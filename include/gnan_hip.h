@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 5
+#define GNAN_ABI_VERSION 6
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -111,8 +111,13 @@ typedef struct gnan_fpwl_args {
   int32_t sum_features;    /* as gnan_fmlp_args */
   float* out;
   int64_t out_stride;
+  float* total;            /* optional [F]: column sums of the per-feature output (the aggregation's s_total),
+                              produced in the same pass; needs C == 1, whole groups, 16-B aligned rows */
+  void* total_workspace;   /* gnan_fpwl_total_workspace_bytes() */
+  size_t total_workspace_bytes;
 } gnan_fpwl_args;
 
+size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);
 int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
 
 /* Backward of the table look-up (autograd through GNAN.py:57-62 w.r.t. the f_k parameters): per-piece

@@ -320,3 +320,21 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features):
     got = _fpwl_moments(x.to(DEV), t, g.to(DEV), sum_features).cpu().double()
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("n,F", [(70_000, 64), (300_000, 16), (5000, 32)])
+def test_fused_column_sums_of_table_lookup(n, F, monkeypatch):
+    """feature_mlps(return_total=True): the look-up kernel's fused column sums == a separate pass over its output."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import column_sums, feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    sd = _mlp_state(F, 3, 16, 1, True, seed=F)
+    st = _stack(sd, F, 3, 16, 1, True)
+    x = torch.rand(n, F, device=DEV) * 2 - 1
+    out, total = feature_mlps(x, st, False, return_total=True)
+    want = out.double().sum(0)
+    assert float((total.double() - want).abs().max()) <= 1e-6 * float(out.abs().sum(0).max())
+    assert torch.equal(total, feature_mlps(x, st, False, return_total=True)[1])       # fixed reduction order
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)                     # other strategies: separate pass
+    out2, total2 = feature_mlps(x, st, False, return_total=True)
+    assert torch.equal(total2, column_sums(out2))
