@@ -170,13 +170,20 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   }
 }
 
+// One workgroup per column: 256 threads stride over the per-workgroup partials, then a fixed-order tree.
 __global__ __launch_bounds__(256) void fpwl_total_kernel(const double* __restrict__ partial, int blocks, int W,
                                                          float* __restrict__ total) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= W) return;
+  __shared__ double red[256];
+  const int w = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[static_cast<int64_t>(b) * W + w];
-  total[w] = static_cast<float>(s);
+  for (int b = threadIdx.x; b < blocks; b += 256) s += partial[static_cast<int64_t>(b) * W + w];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[w] = static_cast<float>(red[0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,8 +300,8 @@ int launch(const Params& p, size_t lds, hipStream_t st, float* total_out) {
   if (p.sum_features) return fast ? go(fpwl_kernel<FG, true, true>) : go(fpwl_kernel<FG, true, false>);
   if (int rc = fast ? go(fpwl_kernel<FG, false, true>) : go(fpwl_kernel<FG, false, false>)) return rc;
   if (p.col_partial) {
-    hipLaunchKernelGGL(fpwl_total_kernel, dim3((p.F + 255) / 256), dim3(256), 0, st, p.col_partial,
-                       static_cast<int>(bx), p.F, total_out);
+    hipLaunchKernelGGL(fpwl_total_kernel, dim3(p.F), dim3(256), 0, st, p.col_partial, static_cast<int>(bx), p.F,
+                       total_out);
     return gnan::check_launch("fpwl_total_kernel");
   }
   return GNAN_OK;
