@@ -6,9 +6,9 @@ Drop-in for the reference's ``TensorGNAN`` / ``GNAN`` / ``NAM`` modules
 The arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI in
 ``include/gnan_hip.h``; see DESIGN.md and INTEGRATION.md.
 """
-from . import GNAN, models  # noqa: F401  (mirror modules)
+from . import GNAN, batched, models  # noqa: F401  (mirror modules)
 from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps  # noqa: F401
 from .graph import HopGraph, hop_inputs, shell_counts_csr  # noqa: F401
 
-__all__ = ["GNAN", "models", "HopGraph", "StackedMLP", "feature_mlps", "rho_aggregate", "stack_mlps",
+__all__ = ["GNAN", "models", "batched", "HopGraph", "StackedMLP", "feature_mlps", "rho_aggregate", "stack_mlps",
            "hop_inputs", "shell_counts_csr"]

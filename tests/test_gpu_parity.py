@@ -138,3 +138,29 @@ def test_reference_order_and_feature_contributions(gpu, name):
         m = m / i64["normalization_matrix"].unsqueeze(-1)
     mf64 = torch.matmul(m.permute(2, 0, 1), fx.permute(2, 0, 1)).permute(1, 2, 0)   # [N, F, C]
     assert O.rel_err(mf, mf64) <= 1e-5
+
+
+@pytest.mark.parametrize("name", golden_names("batched"))
+def test_batched_variant_matches_golden(gpu, name):
+    """f-2: the block-diagonal batched TensorGNAN (batched_pyg_main.py:98-184), forward and gradients."""
+    from gnan_amd.batched import TensorGNAN
+    g = Golden(name)
+    m = g.meta
+    mod = TensorGNAN(m["F"], m["C"], 2, hidden_channels=m["H"], is_graph_task=m["graph"], device=gpu.DEV)
+    mod.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in g.sd.items()}, strict=True)
+    mod = mod.to(gpu.DEV).eval()
+    x = torch.from_numpy(np.array(g.inputs["x"])).to(gpu.DEV)
+    dist = torch.from_numpy(np.array(g.inputs["dist"])).to(gpu.DEV)
+    batch = torch.from_numpy(np.array(g.inputs["batch"])).to(gpu.DEV)
+    y = mod.forward(x, dist, batch)
+    assert tuple(y.shape) == g.out32.shape
+    ok, e_build, e_ref = tolerance_ok(y.detach().cpu(), g.out32, g.out64, floor=1e-5)
+    assert ok, f"build err {e_build:.3e} vs fp32-reference err {e_ref:.3e}"
+    y.pow(2).sum().backward()
+    gscale = max(float(np.abs(v).max()) for v in g.g64.values())
+    for k, ref64 in g.g64.items():
+        p = dict(mod.named_parameters())[k]
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu().double().numpy()
+        e_build = np.abs(got - ref64).max() / gscale
+        e_ref = np.abs(g.g32[k].astype(np.float64) - ref64).max() / gscale
+        assert e_build <= max(2e-5, 2 * e_ref), f"{k}: build {e_build:.3e} vs fp32-reference {e_ref:.3e}"
