@@ -126,6 +126,54 @@ class HopGraph:
         return HopGraph(n_rows=n_rows, n_cols=n_cols, n_codes=n_codes, code=code, cnt=cnt,
                         rowptr=rowptr.contiguous(), col=col)
 
+    @staticmethod
+    def from_edge_index(edge_index: torch.Tensor, num_nodes: int, max_hops: Optional[int] = None) -> "HopGraph":
+        """Preprocessing on the GPU: hop codes and shell counts straight from ``edge_index``.
+
+        * ``max_hops is None`` or ``>= 2``: all-pairs BFS (``gnan_bfs_dense``) -> dense layout, what
+          ``pre_process`` (pre_process_datasets.py:104-142) encodes in its two N x N matrices; needs N^2 bytes.
+        * ``max_hops == 1``: the K = 1 hop-coded CSR (self pair + direct neighbours), any size.
+        Edges are directed as given; duplicate edges count once (the reference's COO->LIL conversion would turn
+        them into weight-2 edges, SURVEY.md A.7 — coalesce upstream if that quirk matters).
+        """
+        _lib.require_device(edge_index)
+        ei = edge_index.long()
+        n = int(num_nodes)
+        dev = ei.device
+        keep = ei[0] != ei[1] if max_hops == 1 else torch.ones(ei.shape[1], dtype=torch.bool, device=dev)
+        key = torch.unique(ei[0, keep] * n + ei[1, keep])             # coalesced, sorted by (src, dst)
+        src, dst = key // n, key % n
+        if max_hops == 1:
+            rows = torch.cat([torch.arange(n, device=dev), src])
+            cols = torch.cat([torch.arange(n, device=dev), dst])
+            code = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev),
+                              torch.ones(src.numel(), dtype=torch.uint8, device=dev)])
+            order = torch.argsort(rows * n + cols)
+            rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+            if int(rowptr[-1]) < 2 ** 31:
+                rowptr = rowptr.to(torch.int32)
+            return HopGraph.from_csr(rowptr, cols[order].to(torch.int32), code[order], n_cols=n, n_codes=3)
+        if n * n > (1 << 33):
+            raise _lib.GnanHipError(f"all-pairs hop codes of {n} nodes need {n * n / 2**30:.0f} GiB; use max_hops=1")
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+        rowptr, col = rowptr.to(torch.int32), dst.to(torch.int32).contiguous()
+        code = torch.empty((n, n), dtype=torch.uint8, device=dev)
+        cnt256 = torch.empty((n, _lib.MAX_CODES), dtype=torch.int32, device=dev)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        need = _lib.lib().gnan_bfs_dense_workspace_bytes(n)
+        ws = torch.empty(max(1, need // 4), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().gnan_bfs_dense(_lib.ptr(rowptr), _lib.ptr(col), n, 254 if max_hops is None else max_hops,
+                                             _lib.ptr(code), _lib.ptr(cnt256), _lib.ptr(status), _lib.ptr(ws), need,
+                                             _lib.stream_of(code)), "gnan_bfs_dense")
+        flags, max_hop = (int(v) for v in status.tolist())
+        if flags & 1:
+            raise _lib.GnanHipError("a shortest path longer than 254 hops cannot be coded in one byte")
+        D = max_hop + 2
+        cnt = torch.cat([cnt256[:, : D - 1], cnt256[:, _lib.MAX_CODES - 1:]], dim=1).contiguous()
+        return HopGraph(n_rows=n, n_cols=n, n_codes=D, code=code, cnt=cnt)
+
     # ------------------------------------------------------------------ derived structures
     def long_row_plan(self, row_ids: Optional[torch.Tensor] = None) -> LongRowPlan:
         """Hub rows and their slices; cached for the identity row order."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 6
+#define GNAN_ABI_VERSION 7
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -234,6 +234,19 @@ int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* tot
 int gnan_dense_to_code(const float* nd, const float* norm, int64_t n_rows, int64_t n_cols,
                        int64_t in_stride, uint8_t* code, int32_t* cnt /* [n_rows, 256] */,
                        int32_t* status /* [2] */, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * All-pairs hop distances on the GPU (graphs small enough for N x N bytes)
+ * replaces the host preprocessing pre_process_datasets.py:104-142 (scipy Dijkstra over the directed
+ * unit-weight adjacency + N^2 Python lambda calls counting equal entries):
+ *   code[i, j] = hop(i -> j), 255 if unreachable or beyond max_hops;   cnt[i, d] = #{ j : code[i, j] == d }
+ * Adjacency: CSR of the directed edge list (rowptr int32 [n+1], col int32), duplicates harmless.
+ * status[0] |= 1 if a hop distance >= 255 occurred; status[1] = max hop seen.  status zeroed by the caller.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnan_bfs_dense_workspace_bytes(int32_t n);
+int gnan_bfs_dense(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t max_hops, uint8_t* code,
+                   int32_t* cnt /* [n, 256] */, int32_t* status /* [2] */, void* workspace, size_t workspace_bytes,
+                   gnan_stream_t stream);
 
 #ifdef __cplusplus
 }

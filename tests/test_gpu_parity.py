@@ -164,3 +164,32 @@ def test_batched_variant_matches_golden(gpu, name):
         e_build = np.abs(got - ref64).max() / gscale
         e_ref = np.abs(g.g32[k].astype(np.float64) - ref64).max() / gscale
         assert e_build <= max(2e-5, 2 * e_ref), f"{k}: build {e_build:.3e} vs fp32-reference {e_ref:.3e}"
+
+
+@pytest.mark.parametrize("name", golden_names("pre_process") + [MODEL_CASES[5], MODEL_CASES[11], MODEL_CASES[0]])
+@pytest.mark.parametrize("max_hops", [None, 2, 1])
+def test_gpu_preprocessing_bit_exact(gpu, name, max_hops):
+    """f-1: hop codes / shell counts from edge_index on the GPU == what the reference's pre_process encodes."""
+    from gnan_amd import HopGraph
+    g = Golden(name)
+    n = g.inputs["node_distances"].shape[0]
+    ei = torch.from_numpy(np.array(g.inputs["edge_index"])).to(gpu.DEV)
+    hops = O.hop_codes_from_dense(torch.from_numpy(np.array(g.inputs["node_distances"])))
+    graph = HopGraph.from_edge_index(ei, n, max_hops)
+    if max_hops == 1:
+        rowptr, col, code = O.csr_from_hops(hops, 1)
+        assert np.array_equal(graph.rowptr.cpu().numpy(), rowptr)
+        assert np.array_equal(graph.col.cpu().numpy(), col)
+        assert np.array_equal(graph.code.cpu().numpy(), code)
+        assert np.array_equal(graph.cnt.cpu().numpy(), O.shell_counts(np.where(hops > 1, -1, hops), 3))
+        return
+    if max_hops is not None:
+        hops = np.where(hops > max_hops, -1, hops)
+    D = int(hops.max()) + 2
+    assert graph.n_codes == D
+    assert np.array_equal(graph.code.cpu().numpy(), np.where(hops < 0, 255, hops).astype(np.uint8))
+    assert np.array_equal(graph.cnt.cpu().numpy(), O.shell_counts(hops, D))
+    if max_hops is None:                                      # and it is interchangeable with the dense-input route
+        dense = HopGraph.from_dense(torch.from_numpy(np.array(g.inputs["node_distances"])).to(gpu.DEV),
+                                    torch.from_numpy(np.array(g.inputs["normalization_matrix"])).to(gpu.DEV))
+        assert torch.equal(dense.code, graph.code) and torch.equal(dense.cnt, graph.cnt)
