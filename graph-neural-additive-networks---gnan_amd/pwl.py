@@ -79,9 +79,10 @@ def _network(x: torch.Tensor, p, w, b, w_last, b_last):
     return y
 
 
-@torch.no_grad()
-def build_tables(p) -> Optional[PwlTables]:
-    """Tabulate all F shape functions; returns None if some feature needs more than MAX_PIECES pieces."""
+def _build_padded(p):
+    """Device part of the build — static shapes only, no host round trip (so it can live in a hipGraph):
+    returns ``(off [F+1] int64, overflow [] bool, anchor [F, P+1], val [F, P+1, C], slope [F, P+1, C], keep [F, P+1])``
+    where ``keep`` marks the first ``pieces_k`` slots of every feature."""
     dev = p.w_last.device
     f64 = torch.float64
     F = p.F
@@ -162,16 +163,71 @@ def build_tables(p) -> Optional[PwlTables]:
     keep = idx < pieces.unsqueeze(1)
     off = torch.zeros(F + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(pieces, 0)
+    return torch.cat([off, overflow.to(torch.int64).view(1)]), anchor.float(), val.float(), sl.float(), keep
+
+
+class _GraphedBuild:
+    """The ~60 tiny launches of ``_build_padded`` captured once per model shape into a hipGraph and replayed.
+
+    Per forward: one fused copy of the current weights into the graph's static inputs, one graph launch.
+    Falls back to eager execution if capture is not possible (CPU tensors, capture already in progress, ...)."""
+
+    _cache = {}
+
+    def __init__(self, p):
+        live = [t for t in p[:6] if t is not None]
+        self.static_in = [torch.empty_like(t) for t in live]
+        self.present = [t is not None for t in p[:6]]
+        torch._foreach_copy_(self.static_in, live)
+        it = iter(self.static_in)
+        sp = type(p)(*[next(it) if pr else None for pr in self.present], *p[6:])
+        side = torch.cuda.Stream(device=p.w_last.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # warm-up outside capture (lazy inits, allocator)
+                _build_padded(sp)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = _build_padded(sp)
+
+    def __call__(self, p):
+        torch._foreach_copy_(self.static_in, [t for t in p[:6] if t is not None])
+        self.graph.replay()
+        return self.static_out
+
+    @classmethod
+    def run(cls, p):
+        dev = p.w_last.device
+        if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return _build_padded(p)
+        key = (dev, p.F, p.L, p.H, p.C, tuple(t is not None for t in p[:6]))
+        g = cls._cache.get(key)
+        if g is None:
+            try:
+                g = cls(p)
+            except Exception:                        # capture unsupported here: remember and run eagerly
+                g = False
+            cls._cache[key] = g
+        return g(p) if g else _build_padded(p)
+
+
+@torch.no_grad()
+def build_tables(p, use_graph: bool = True) -> Optional[PwlTables]:
+    """Tabulate all F shape functions; returns None if some feature needs more than MAX_PIECES pieces."""
+    packed, anchor, val, sl, keep = _GraphedBuild.run(p) if use_graph else _build_padded(p)
     C = val.shape[-1]
-    host = torch.cat([off, overflow.to(torch.int64).view(1)]).tolist()   # the ONE device->host copy of the build
+    host = packed.tolist()                                          # the ONE device->host copy of the build
     off_host, overflowed = host[:-1], bool(host[-1])
     if overflowed or max(b - a for a, b in zip(off_host, off_host[1:])) > MAX_PIECES:
         return None
     plan = _plan_groups(off_host, C)
     if plan is None:
         return None
-    return PwlTables(off.to(torch.int32), anchor[keep].float().contiguous(), val[keep].float().reshape(-1, C).contiguous(),
-                     sl[keep].float().reshape(-1, C).contiguous(), max(b - a for a, b in zip(off_host, off_host[1:])),
+    sel = keep.reshape(-1).nonzero().squeeze(1)                     # slots that hold a real piece, feature-major
+    off = torch.tensor(off_host, dtype=torch.int32).to(anchor.device, non_blocking=True)
+    return PwlTables(off, anchor.reshape(-1)[sel].contiguous(), val.reshape(-1, C)[sel].contiguous(),
+                     sl.reshape(-1, C)[sel].contiguous(), max(b - a for a, b in zip(off_host, off_host[1:])),
                      plan[0], plan[1])
 
 
