@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .functional import feature_mlps, rho_aggregate
+from .functional import rho_aggregate
 from .graph import HopGraph
 from .modules import _PathBase
 
@@ -69,7 +69,7 @@ class TensorGNAN(_PathBase):
         if self._graph_cache is None or self._graph_cache[0] != key:
             self._graph_cache = (key, hop_graph_from_counts(dist_batch))
         g = self._graph_cache[1]
-        S = feature_mlps(x_batch, self._stacked("fs", self.fs), sum_features=True)          # [N, C]
+        S = self._features(x_batch, "fs", self.fs, True)                                    # [N, C]
         hops = torch.arange(g.n_codes - 1, dtype=torch.float32, device=x_batch.device).view(-1, 1)
         lut = torch.cat([self.rho(hops), torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)
         Y = rho_aggregate(g, S, lut, use_cnt=False, with_rest=False)                        # [N, C]

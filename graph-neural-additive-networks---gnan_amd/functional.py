@@ -152,9 +152,12 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
     return out
 
 
-def _fmlp_eager(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Tensor:
-    """Batched-GEMM restatement on the device, used ONLY to obtain parameter gradients in backward
-    (recompute + torch autograd) until the HIP weight-gradient kernel lands.  Never used for forward."""
+def _fmlp_eager(x: torch.Tensor, p: StackedMLP, sum_features: bool, dropout: float = 0.0) -> torch.Tensor:
+    """Batched-GEMM restatement on the device.  Used (a) inside backward passes to obtain parameter gradients
+    (recompute + torch autograd on small batches; two probe points per piece on the table path) and (b) as the
+    forward while training-mode Dropout is active (``dropout > 0``: ``F.dropout`` after every hidden ReLU,
+    GNAN.py:28,32).  The eval-mode forward never comes here."""
+    drop = (lambda h: torch.nn.functional.dropout(h, dropout, training=True)) if dropout > 0 else (lambda h: h)
     xt = x.t().unsqueeze(-1)                                            # [F, n, 1]
     if p.L == 1:
         h = xt * p.w_last.unsqueeze(1)                                  # [F, n, C]
@@ -164,12 +167,12 @@ def _fmlp_eager(x: torch.Tensor, p: StackedMLP, sum_features: bool) -> torch.Ten
         h = xt * p.w_first.unsqueeze(1)
         if p.b_first is not None:
             h = h + p.b_first.unsqueeze(1)
-        h = torch.relu(h)                                               # [F, n, H]
+        h = drop(torch.relu(h))                                         # [F, n, H]
         for l in range(p.L - 2):
             h = torch.bmm(h, p.w_mid[l].transpose(1, 2))
             if p.b_mid is not None:
                 h = h + p.b_mid[l].unsqueeze(1)
-            h = torch.relu(h)
+            h = drop(torch.relu(h))
         h = torch.bmm(h, p.w_last.transpose(1, 2))                      # [F, n, C]
         if p.b_last is not None:
             h = h + p.b_last.unsqueeze(1)

@@ -85,11 +85,26 @@ class _PathBase(nn.Module):
         return hit[1]
 
     def _check_dropout(self):
-        if self.training and self.dropout and self.dropout > 0:
-            raise NotImplementedError(
-                "training-mode Dropout inside the fused shape-function kernel is not implemented; call "
-                ".eval() (the reference itself leaves eval mode on after its first evaluation, trainer.py:97) "
-                "or construct the model with dropout=0.0")
+        """Training-mode Dropout (GNAN.py:28,32) is stochastic and tied to torch's RNG stream, which a fused kernel
+        cannot reproduce; while it is active the shape functions run as batched torch GEMMs with ``F.dropout`` on
+        the device (:meth:`_features`).  The reference only ever trains with Dropout in its first epoch — it never
+        leaves eval mode again after ``trainer.py:97`` — so this is the cold path; a one-time note says so."""
+        if self._dropout_active() and not getattr(self, "_dropout_noted", False):
+            import warnings
+            warnings.warn("gnan_amd: training-mode Dropout (p=%g) is active: shape functions run as batched torch "
+                          "GEMMs on the GPU instead of the fused HIP kernels until .eval() is called" % self.dropout)
+            self._dropout_noted = True
+
+    def _dropout_active(self) -> bool:
+        return bool(self.training and self.dropout and self.dropout > 0)
+
+    def _features(self, x, name, mlps, sum_features: bool):
+        """Shape functions of all features: fused HIP kernels, or the Dropout cold path described above."""
+        if self._dropout_active():
+            from .functional import _fmlp_eager
+            _lib.require_device(x)
+            return _fmlp_eager(x.float(), stack_mlps(mlps), sum_features, dropout=float(self.dropout))
+        return feature_mlps(x, self._stacked(name, mlps), sum_features=sum_features)
 
     # ---- inputs -> hop-coded adjacency -----------------------------------------------------
     def _graph(self, inputs, want_norm: bool) -> HopGraph:
@@ -156,7 +171,7 @@ class StandaloneTensorGNAN(_PathBase):
         x = inputs.x
         _lib.require_device(x)
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
-        S = feature_mlps(x, self._stacked("fs", self.fs), sum_features=True)          # [N, C]
+        S = self._features(x, "fs", self.fs, True)                                    # [N, C]
         lut = self._lut_pre_rho(g) if self.normalize_rho else self._lut_global(g)
         Y = rho_aggregate(g, S, lut, use_cnt=False)                                   # [N, C]
         if not self.is_graph_task:
@@ -197,7 +212,7 @@ class _GNANCore(_PathBase):
         x = inputs.x
         _lib.require_device(x)
         g = self._graph(inputs, want_norm=True)            # GNAN.py:161 reads it unconditionally
-        S = feature_mlps(x, self._stacked("fs", self.fs), sum_features=True)          # f_sums, GNAN.py:157
+        S = self._features(x, "fs", self.fs, True)                                    # f_sums, GNAN.py:157
         rows = None
         if node_ids is not None:
             rows = torch.as_tensor(list(node_ids) if not torch.is_tensor(node_ids) else node_ids,
@@ -238,7 +253,7 @@ class NAM(_PathBase):
 
     def forward(self, x):
         self._check_dropout()
-        return feature_mlps(x, self._stacked("fs", self.fs), sum_features=True)
+        return self._features(x, "fs", self.fs, True)
 
 
 class TensorGNAN(_PathBase):
@@ -282,9 +297,8 @@ class TensorGNAN(_PathBase):
         lut = self._lut_global(g)
         use_cnt = bool(self.normalize_rho)
         with_readout = self.is_graph_task and self.readout_n_layers > 0
-        fs = self._stacked("fs", self.fs)
         if with_readout:
-            fx = feature_mlps(x, fs, sum_features=False)                              # [N, F]   (f is 1-wide)
+            fx = self._features(x, "fs", self.fs, False)                              # [N, F]   (f is 1-wide)
             hidden = rho_aggregate(g, fx, lut, use_cnt).sum(dim=0).view(1, -1)        # [1, F]   models.py:379
             return self.readout_nam(hidden).T                                         # [C, 1]   models.py:380-384
         if self.aggregation_order == "reference":
@@ -292,10 +306,10 @@ class TensorGNAN(_PathBase):
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate
             # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
             # in this order.
-            fx = feature_mlps(x, fs, sum_features=False)                              # [N, F*C]
+            fx = self._features(x, "fs", self.fs, False)                              # [N, F*C]
             Y = rho_aggregate(g, fx, lut, use_cnt, reduce_channels=self.actual_output_dim_f)   # [N, C]
         else:
-            S = feature_mlps(x, fs, sum_features=True)                                # [N, C]  sum-first
+            S = self._features(x, "fs", self.fs, True)                                # [N, C]  sum-first
             Y = rho_aggregate(g, S, lut, use_cnt)                                     # [N, C]
         if not self.is_graph_task:
             return Y                                                                  # models.py:375-376,384
@@ -307,7 +321,7 @@ class TensorGNAN(_PathBase):
         x = inputs.x
         g = self._graph(inputs, want_norm=bool(self.normalize_rho)) if _g is None else _g
         lut = self._lut_global(g) if _lut is None else _lut
-        fx = feature_mlps(x, self._stacked("fs", self.fs), sum_features=False)        # [N, F*C]
+        fx = self._features(x, "fs", self.fs, False)                                  # [N, F*C]
         Y = rho_aggregate(g, fx, lut, bool(self.normalize_rho))                       # [N, F*C]
         return Y.view(x.shape[0], -1, self.actual_output_dim_f)
 

@@ -193,3 +193,33 @@ def test_gpu_preprocessing_bit_exact(gpu, name, max_hops):
         dense = HopGraph.from_dense(torch.from_numpy(np.array(g.inputs["node_distances"])).to(gpu.DEV),
                                     torch.from_numpy(np.array(g.inputs["normalization_matrix"])).to(gpu.DEV))
         assert torch.equal(dense.code, graph.code) and torch.equal(dense.cnt, graph.cnt)
+
+
+def test_training_mode_dropout_is_supported(gpu):
+    """run.sh trains with dropout 0.6 and the module starts in train mode: the first epoch must work.
+    Dropout is stochastic, so the check is determinism under a seed, finiteness, and that eval() is unaffected."""
+    import warnings
+    g = Golden(MODEL_CASES[9])                                  # models.TensorGNAN, node task
+    mod = gpu.build_module(g)
+    data = gpu.device_inputs(g)
+    with torch.no_grad():
+        y_eval = mod.forward(data)
+    mod.dropout = 0.3
+    for f in mod.fs:
+        for layer in f:
+            if isinstance(layer, torch.nn.Dropout):
+                layer.p = 0.3
+    mod.train()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        torch.manual_seed(7)
+        y1 = mod.forward(data)
+        torch.manual_seed(7)
+        y2 = mod.forward(data)
+    assert any("Dropout" in str(m.message) for m in w)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y_eval)
+    y1.pow(2).sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)
+    mod.eval()
+    with torch.no_grad():
+        assert torch.equal(mod.forward(data), y_eval)
