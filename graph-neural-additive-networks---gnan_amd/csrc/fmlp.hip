@@ -38,6 +38,10 @@ struct Params {
   int sum_features;
   float* out;
   int64_t out_stride;
+  // matrix-core kernel only: features are cut into gridDim.y chunks so that graphs with few nodes but many
+  // features (Cora: 2.7k x 1434) still fill the chip; with sum_features the chunks meet in `sum_partial`
+  int feat_chunk;
+  float* sum_partial;  // [chunks, n, C] or nullptr (single chunk)
 };
 
 constexpr int JB = 8;
@@ -207,9 +211,11 @@ __global__ __launch_bounds__(256, 2) void fmlp_mfma_kernel(const Params p, const
   for (int nt = 0; nt < NT; ++nt) {
     node[nt] = (tile0 + nt) * 32 + nl;
     valid[nt] = node[nt] < p.n;
-    xcur[nt] = valid[nt] ? p.x[node[nt] * p.x_stride] : 0.f;
+    xcur[nt] = valid[nt] ? p.x[node[nt] * p.x_stride + blockIdx.y * p.feat_chunk] : 0.f;
   }
-  stage_feature<NCH>(packed, smem, lane, wave);
+  const int k_lo = blockIdx.y * p.feat_chunk;
+  const int k_hi = k_lo + p.feat_chunk < p.F ? k_lo + p.feat_chunk : p.F;
+  stage_feature<NCH>(packed + static_cast<int64_t>(k_lo) * FS, smem, lane, wave);
   __syncthreads();
 
   float sum[NT][CT];
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void fmlp_mfma_kernel(const Params p, const
     const float* vec = buf + MIDF;
     // prefetch the next feature's packed weights and x column into registers (the last iteration
     // harmlessly re-fetches its own feature: keeps the staging registers unconditional)
-    const int kn = k + 1 < p.F ? k + 1 : k;
+    const int kn = k + 1 < k_hi ? k + 1 : k;
     float xnext[NT];
     stage_feature<NCH>(packed + static_cast<int64_t>(kn) * FS, nbuf, lane, wave);
 #pragma unroll
@@ -314,9 +320,9 @@ __global__ __launch_bounds__(256, 2) void fmlp_mfma_kernel(const Params p, const
     for (int nt = 0; nt < NT; ++nt) xcur[nt] = xnext[nt];
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the next feature's buffer
   };
-  for (int k = 0; k < p.F; k += 2) {
+  for (int k = k_lo; k < k_hi; k += 2) {
     feature_step(k, smem, smem + FS);
-    if (k + 1 < p.F) feature_step(k + 1, smem + FS, smem);
+    if (k + 1 < k_hi) feature_step(k + 1, smem + FS, smem);
   }
   if constexpr (SUM) {
 #pragma unroll
@@ -324,10 +330,25 @@ __global__ __launch_bounds__(256, 2) void fmlp_mfma_kernel(const Params p, const
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const float v = sum[nt][c] + __shfl_xor(sum[nt][c], 32) + blsum[c];
-        if (half == 0 && valid[nt] && c < p.C) p.out[node[nt] * p.out_stride + c] = v;
+        if (half == 0 && valid[nt] && c < p.C) {
+          if (p.sum_partial) {
+            p.sum_partial[(static_cast<int64_t>(blockIdx.y) * p.n + node[nt]) * p.C + c] = v;
+          } else {
+            p.out[node[nt] * p.out_stride + c] = v;
+          }
+        }
       }
     }
   }
+}
+
+// out[n, c] = sum over feature chunks of sum_partial[chunk, n, c], in chunk order (deterministic).
+__global__ __launch_bounds__(256) void fmlp_chunk_sum_kernel(const Params p, int chunks) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= p.n * p.C) return;
+  float a = 0.f;
+  for (int ch = 0; ch < chunks; ++ch) a += p.sum_partial[static_cast<int64_t>(ch) * p.n * p.C + i];
+  p.out[(i / p.C) * p.out_stride + i % p.C] = a;
 }
 
 constexpr int kNT = 2;  // 32-node tiles per wave
@@ -344,22 +365,41 @@ bool mfma_shape(const Params& p, MfmaShape* s) {
   return true;
 }
 
+// Feature chunks (gridDim.y): enough workgroups for ~4 per CU when the node axis alone is too short.
+int feature_chunks(int64_t n, int F) {
+  const int64_t node_blocks = (n + 4 * kNT * 32 - 1) / (4 * kNT * 32);
+  int64_t chunks = (1024 + node_blocks - 1) / node_blocks;
+  const int64_t max_chunks = (F + 1) / 2;          // at least two features per chunk (double-buffered pairs)
+  chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);
+  return static_cast<int>(chunks);
+}
+
 template <int HT, int NMID, int CT>
 int launch_mfma(const Params& p, const float* packed, hipStream_t st) {
   constexpr size_t lds = 2 * static_cast<size_t>(feature_floats(HT, NMID, CT)) * sizeof(float);
   const int64_t nodes_per_block = 4 * kNT * 32;
   const int64_t blocks = (p.n + nodes_per_block - 1) / nodes_per_block;
   if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fmlp: too many nodes for one launch");
+  const int chunks = (p.F + p.feat_chunk - 1) / p.feat_chunk;
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
       if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fmlp: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, p, packed);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(chunks)), dim3(256), lds, st,
+                       p, packed);
     return gnan::check_launch("fmlp_mfma_kernel");
   };
-  return p.sum_features ? go(fmlp_mfma_kernel<HT, NMID, CT, true, kNT>) : go(fmlp_mfma_kernel<HT, NMID, CT, false, kNT>);
+  if (!p.sum_features) return go(fmlp_mfma_kernel<HT, NMID, CT, false, kNT>);
+  if (int rc = go(fmlp_mfma_kernel<HT, NMID, CT, true, kNT>)) return rc;
+  if (p.sum_partial) {
+    const int64_t total = p.n * p.C;
+    hipLaunchKernelGGL(fmlp_chunk_sum_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, p,
+                       chunks);
+    return gnan::check_launch("fmlp_chunk_sum_kernel");
+  }
+  return GNAN_OK;
 }
 
 template <int HT, int NMID>
@@ -372,7 +412,18 @@ int launch_mfma_ct(const Params& p, int CT, const float* packed, hipStream_t st)
   }
 }
 
-int run_mfma(const Params& p, const MfmaShape& s, float* packed, hipStream_t st) {
+size_t packed_bytes(const Params& p, const MfmaShape& s) {
+  return static_cast<size_t>(p.F) * feature_floats(s.HT, s.NMID, s.CT) * sizeof(float);
+}
+
+int run_mfma(Params p, const MfmaShape& s, float* packed, hipStream_t st) {
+  const int chunks = feature_chunks(p.n, p.F);
+  p.feat_chunk = (p.F + chunks - 1) / chunks;
+  p.feat_chunk += p.feat_chunk & 1;                  // even: chunks start on a double-buffer pair boundary
+  const int real_chunks = (p.F + p.feat_chunk - 1) / p.feat_chunk;
+  p.sum_partial = (p.sum_features && real_chunks > 1)
+                      ? reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + packed_bytes(p, s))
+                      : nullptr;
   hipLaunchKernelGGL(fmlp_pack_kernel, dim3(p.F), dim3(256), 0, st, p, packed, s.HT, s.NMID, s.CT);
   if (int rc = gnan::check_launch("fmlp_pack_kernel")) return rc;
   if (s.HT == 1) return s.NMID == 1 ? launch_mfma_ct<1, 1>(p, s.CT, packed, st) : launch_mfma_ct<1, 2>(p, s.CT, packed, st);
@@ -386,6 +437,7 @@ Params make_params(const gnan_fmlp_args* a) {
   p.w_first = a->w_first; p.b_first = a->b_first; p.w_mid = a->w_mid; p.b_mid = a->b_mid;
   p.w_last = a->w_last; p.b_last = a->b_last;
   p.sum_features = a->sum_features; p.out = a->out; p.out_stride = a->out_stride;
+  p.feat_chunk = a->F; p.sum_partial = nullptr;
   return p;
 }
 
@@ -396,7 +448,12 @@ extern "C" size_t gnan_fmlp_fwd_workspace_bytes(const gnan_fmlp_args* a) {
   const Params p = make_params(a);
   MfmaShape s;
   if (!mfma_shape(p, &s)) return 0;
-  return static_cast<size_t>(p.F) * feature_floats(s.HT, s.NMID, s.CT) * sizeof(float);
+  size_t bytes = packed_bytes(p, s);
+  if (p.sum_features) {                               // room for the per-chunk partial sums (upper bound)
+    const int chunks = feature_chunks(p.n, p.F);
+    if (chunks > 1) bytes += static_cast<size_t>(chunks) * p.n * p.C * sizeof(float);
+  }
+  return bytes;
 }
 
 extern "C" int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream) {
