@@ -67,6 +67,7 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to pin one of the three evaluation strategies
 PWL_MIN_WORK = 1 << 24       # AUTO tabulates the shape functions once n*F look-ups outweigh the table build
+PWL_MIN_WORK_GRAD = 1 << 18  # ... much earlier when a backward pass follows: the moment kernel replaces a full recompute
 
 
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False):
@@ -116,11 +117,13 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) ->
     return M
 
 
-def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False):
+def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False,
+                  needs_grad: bool = False):
     """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
     Returns ``(out, tables or None, total or None)``."""
     algo = FMLP_ALGO
-    if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= PWL_MIN_WORK):
+    threshold = PWL_MIN_WORK_GRAD if needs_grad else PWL_MIN_WORK
+    if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= threshold):
         from .pwl import build_tables
         tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
         if tables is not None:
@@ -191,7 +194,8 @@ class _FeatureMLPs(torch.autograd.Function):
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
-        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, want_total)
+        needs_grad = any(ctx.needs_input_grad[7:]) and not ctx.needs_input_grad[0]
+        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, want_total, needs_grad)
         if not want_total:
             return out
         if total is None:
