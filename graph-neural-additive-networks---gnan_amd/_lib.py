@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -46,6 +46,16 @@ class FpwlArgs(C.Structure):
     ]
 
 
+class PwlBuildArgs(C.Structure):
+    _fields_ = [
+        ("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
+        ("w_last", C.c_void_p), ("b_last", C.c_void_p),
+        ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32),
+        ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p), ("pieces", C.c_void_p),
+        ("overflow", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+    ]
+
+
 class SpmmArgs(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_cols", C.c_int64),
@@ -70,6 +80,8 @@ SYMBOLS = {
     "gnan_last_error": (C.c_char_p, []),
     "gnan_fmlp_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpArgs)]),
     "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
+    "gnan_pwl_build_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "gnan_pwl_build": (C.c_int, [C.POINTER(PwlBuildArgs), C.c_void_p]),
     "gnan_fpwl_total_workspace_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),
     "gnan_fpwl_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p]),
     "gnan_fpwl_moments": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

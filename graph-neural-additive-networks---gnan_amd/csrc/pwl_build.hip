@@ -1,0 +1,273 @@
+// Exact piecewise-linear tabulation of the shape functions, on the device (gfx950).
+//
+// f_k is a ReLU MLP of a scalar (GNAN.py:24-34), hence piecewise linear; this kernel finds its kinks and
+// tabulates it for gnan_fpwl_fwd, once per forward, from the current weights.  One workgroup per feature,
+// everything in LDS, float64 arithmetic:
+//   1. kinks of the first layer  t_j = -b1_j / w1_j, bitonic-sorted;
+//   2. (L = 3) between consecutive kinks every second-layer pre-activation z_j(x) is affine: threads walk the
+//      sample points, detect sign changes, append the roots, sort again;
+//   3. the network itself is evaluated at the float32-rounded kinks (+ one point beyond each end) and turned
+//      into (anchor, value, slope) per piece.
+// It replaces ~150 tiny framework launches of the torch restatement of the same procedure
+// (gnan_amd/pwl.py:_build_padded, which remains the reference implementation and the L >= 4 path).
+#include "common.hpp"
+
+#include <cmath>
+
+namespace {
+
+constexpr int kCap = 1024;        // breakpoints per feature this kernel can hold
+
+struct BuildParams {
+  const float* w_first;  // [F, H]
+  const float* b_first;  // [F, H] or null
+  const float* w_mid;    // [F, H, H] (L == 3) or null
+  const float* b_mid;    // [F, H] or null
+  const float* w_last;   // [F, C, H]
+  const float* b_last;   // [F, C] or null
+  int F, L, H, C;
+  int cap;               // pieces - 1 allowed per feature (<= kCap)
+  float* anchor;         // [F, cap + 1]
+  float* val;            // [F, cap + 1, C]
+  float* slope;          // [F, cap + 1, C]
+  int32_t* pieces;       // [F]
+  int32_t* overflow;     // [1]
+  double* scratch;       // [F, cap + 2, C] network values at the table nodes
+};
+
+__device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n_pow2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double x = a[i], y = a[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { a[i] = y; a[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// pre-activation of second-layer unit j at x (L == 3)
+__device__ __forceinline__ double z2(const float* w1, const float* b1, const float* W2row, float b2, int H, double x) {
+  double z = b2;
+  for (int k = 0; k < H; ++k) {
+    const double h = fma(static_cast<double>(w1[k]), x, static_cast<double>(b1[k]));
+    z = fma(static_cast<double>(W2row[k]), h > 0.0 ? h : 0.0, z);
+  }
+  return z;
+}
+
+__global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* bp = reinterpret_cast<double*>(smem_raw);        // [kCap]
+  double* cand = bp + kCap;                                 // [kCap]
+  float* w1 = reinterpret_cast<float*>(cand + kCap);        // [H]
+  float* b1 = w1 + p.H;                                     // [H]
+  float* b2 = b1 + p.H;                                     // [H]
+  float* W2 = b2 + p.H;                                     // [H*H] (L == 3)
+  __shared__ int n_cand, n_bp, over;
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x;
+  const int H = p.H, C = p.C;
+  const double INF = INFINITY;
+
+  for (int i = tid; i < H; i += 256) {
+    w1[i] = p.w_first[k * H + i];
+    b1[i] = p.b_first ? p.b_first[k * H + i] : 0.f;
+    b2[i] = (p.L == 3 && p.b_mid) ? p.b_mid[k * H + i] : 0.f;
+  }
+  if (p.L == 3)
+    for (int i = tid; i < H * H; i += 256) W2[i] = p.w_mid[static_cast<int64_t>(k) * H * H + i];
+  for (int i = tid; i < kCap; i += 256) bp[i] = INF;
+  if (tid == 0) { n_cand = 0; over = 0; }
+  __syncthreads();
+
+  // ---- 1. first-layer kinks -------------------------------------------------------------------
+  for (int j = tid; j < H; j += 256) {
+    const double t = w1[j] != 0.f ? -static_cast<double>(b1[j]) / static_cast<double>(w1[j]) : INF;
+    bp[j] = isfinite(t) ? t : INF;
+  }
+  __syncthreads();
+  int pow2 = 1;
+  while (pow2 < H) pow2 <<= 1;
+  bitonic_sort(bp, pow2, tid);
+  if (tid == 0) {
+    int c = 0;
+    while (c < H && isfinite(bp[c])) ++c;
+    n_bp = c;
+  }
+  __syncthreads();
+
+  // ---- 2. second-layer kinks ------------------------------------------------------------------
+  if (p.L == 3) {
+    const int P = n_bp;
+    const double t_first = P ? bp[0] : 0.0, t_last = P ? bp[P - 1] : 0.0;
+    const int n_nodes = P + 4;
+    auto node = [&](int i) -> double {
+      if (i == 0) return t_first - 2.0;
+      if (i == 1) return t_first - 1.0;
+      if (i < P + 2) return bp[i - 2];
+      return i == P + 2 ? t_last + 1.0 : t_last + 2.0;
+    };
+    // thread = (unit j, segment s): walks its share of the node sequence, one node of overlap
+    const int segs = 256 / H > 0 ? 256 / H : 1;
+    for (int j = tid / segs; j < H; j += 256 / segs) {
+      const int s = tid % segs;
+      const int per = (n_nodes - 1 + segs - 1) / segs;     // intervals per segment
+      const int i0 = s * per, i1 = i0 + per < n_nodes - 1 ? i0 + per : n_nodes - 1;
+      if (i0 < i1 || (s == 0)) {
+        const float* row = W2 + j * H;
+        double e_prev = node(i0), z_prev = z2(w1, b1, row, b2[j], H, e_prev);
+        double e_first = e_prev, z_first = z_prev, e_second = 0, z_second = 0;
+        for (int i = i0 + 1; i <= i1; ++i) {
+          const double e = node(i), z = z2(w1, b1, row, b2[j], H, e);
+          if (i == 1) { e_second = e; z_second = z; }
+          if (z_prev * z < 0.0) {
+            const double r = e_prev + (e - e_prev) * (z_prev / (z_prev - z));
+            if (isfinite(r)) {
+              const int at = atomicAdd(&n_cand, 1);
+              if (at < kCap) cand[at] = r; else over = 1;
+            }
+          }
+          if (i == n_nodes - 1) {                           // right ray: extrapolate the outermost affine piece
+            const double dr = z - z_prev;
+            if (dr != 0.0 && z / dr < 0.0) {
+              const double r = e - z / dr * (e - e_prev);
+              if (isfinite(r)) {
+                const int at = atomicAdd(&n_cand, 1);
+                if (at < kCap) cand[at] = r; else over = 1;
+              }
+            }
+          }
+          e_prev = e; z_prev = z;
+        }
+        if (s == 0 && n_nodes >= 2) {                       // left ray
+          const double dl = z_second - z_first;
+          if (dl != 0.0 && z_first / dl > 0.0) {
+            const double r = e_first - z_first / dl * (e_second - e_first);
+            if (isfinite(r)) {
+              const int at = atomicAdd(&n_cand, 1);
+              if (at < kCap) cand[at] = r; else over = 1;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int nc = n_cand < kCap ? n_cand : kCap;
+    if (P + nc > p.cap) { if (tid == 0) over = 1; }
+    const int total = P + nc < kCap ? P + nc : kCap;
+    for (int i = tid; i < nc; i += 256)
+      if (P + i < kCap) bp[P + i] = cand[i];
+    __syncthreads();
+    pow2 = 1;
+    while (pow2 < total) pow2 <<= 1;
+    bitonic_sort(bp, pow2 > 1 ? pow2 : 2, tid);
+    if (tid == 0) n_bp = total < p.cap ? total : p.cap;
+    __syncthreads();
+  }
+
+  // ---- 3. table: float32 anchors, float64 network values ----------------------------------------------
+  const int P = n_bp;
+  for (int i = tid; i < P; i += 256) {
+    double t = bp[i];
+    t = t > 3.0e38 ? 3.0e38 : (t < -3.0e38 ? -3.0e38 : t);
+    bp[i] = static_cast<double>(static_cast<float>(t));
+  }
+  __syncthreads();
+  const double t_first = P ? bp[0] : 0.0, t_last = P ? bp[P - 1] : 0.0;
+  auto tnode = [&](int i) -> double {                       // P + 2 nodes (P == 0: -1, 0, +1 with a virtual kink at 0)
+    if (i == 0) return t_first - 1.0;
+    if (i <= (P ? P : 1)) return P ? bp[i - 1] : 0.0;
+    return t_last + 1.0;
+  };
+  const int Pn = P ? P : 1;                                 // table nodes between the two outer ones
+  double* V = p.scratch + static_cast<int64_t>(k) * (p.cap + 2) * C;
+  const float* Wl = p.w_last + static_cast<int64_t>(k) * C * H;
+  for (int i = tid; i < Pn + 2; i += 256) {
+    const double x = tnode(i);
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      double acc[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = (p.b_last && c0 + t < C) ? p.b_last[k * C + c0 + t] : 0.0;
+      for (int j = 0; j < H; ++j) {
+        double h;
+        if (p.L == 3) {
+          h = z2(w1, b1, W2 + j * H, b2[j], H, x);
+        } else {
+          h = fma(static_cast<double>(w1[j]), x, static_cast<double>(b1[j]));
+        }
+        h = h > 0.0 ? h : 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (c0 + t < C) acc[t] = fma(static_cast<double>(Wl[(c0 + t) * H + j]), h, acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (c0 + t < C) V[static_cast<int64_t>(i) * C + c0 + t] = acc[t];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int pieces = P + 1;
+  float* A = p.anchor + static_cast<int64_t>(k) * (p.cap + 1);
+  float* VL = p.val + static_cast<int64_t>(k) * (p.cap + 1) * C;
+  float* SL = p.slope + static_cast<int64_t>(k) * (p.cap + 1) * C;
+  for (int i = tid; i < pieces; i += 256) {
+    // piece i lies between table nodes i and i+1; it is anchored at its left kink, piece 0 at the first kink
+    const int an = i == 0 ? 1 : i;
+    A[i] = static_cast<float>(tnode(an));
+    const double width = tnode(i + 1) - tnode(i);
+    for (int c = 0; c < C; ++c) {
+      VL[i * C + c] = static_cast<float>(V[static_cast<int64_t>(an) * C + c]);
+      double s;
+      if (P == 0) {
+        s = V[2 * C + c] - V[1 * C + c];                    // affine: f(1) - f(0)
+      } else {
+        s = width > 0.0 ? (V[static_cast<int64_t>(i + 1) * C + c] - V[static_cast<int64_t>(i) * C + c]) / width : 0.0;
+      }
+      SL[i * C + c] = static_cast<float>(s);
+    }
+  }
+  if (tid == 0) {
+    p.pieces[k] = pieces;
+    if (over) atomicOr(p.overflow, 1);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t gnan_pwl_build_scratch_bytes(int32_t F, int32_t C, int32_t cap) {
+  return static_cast<size_t>(F) * (cap + 2) * C * sizeof(double);
+}
+
+extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "pwl_build: null args");
+  GNAN_REQUIRE(a->F >= 1 && a->C >= 1 && a->H >= 1, "pwl_build: bad sizes");
+  if (a->L != 2 && a->L != 3) return gnan::fail(GNAN_ERR_UNSUPPORTED, "pwl_build: kernel covers L in {2, 3} (got %d)", a->L);
+  if (a->H > 128) return gnan::fail(GNAN_ERR_UNSUPPORTED, "pwl_build: hidden width %d > 128", a->H);
+  GNAN_REQUIRE(a->cap >= 1 && a->cap <= kCap, "pwl_build: cap must be in [1, %d]", kCap);
+  GNAN_REQUIRE(a->w_first && a->w_last && a->anchor && a->val && a->slope && a->pieces && a->overflow && a->scratch,
+               "pwl_build: null pointer");
+  if (a->L == 3) GNAN_REQUIRE(a->w_mid != nullptr, "pwl_build: L == 3 needs w_mid");
+  if (a->scratch_bytes < gnan_pwl_build_scratch_bytes(a->F, a->C, a->cap))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "pwl_build: scratch too small");
+  BuildParams p;
+  p.w_first = a->w_first; p.b_first = a->b_first; p.w_mid = a->w_mid; p.b_mid = a->b_mid;
+  p.w_last = a->w_last; p.b_last = a->b_last;
+  p.F = a->F; p.L = a->L; p.H = a->H; p.C = a->C; p.cap = a->cap;
+  p.anchor = a->anchor; p.val = a->val; p.slope = a->slope; p.pieces = a->pieces; p.overflow = a->overflow;
+  p.scratch = static_cast<double*>(a->scratch);
+  const size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwl_build_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "pwl_build: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(pwl_build_kernel, dim3(a->F), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return gnan::check_launch("pwl_build_kernel");
+}

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 7
+#define GNAN_ABI_VERSION 8
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -129,6 +129,31 @@ int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
  * (gnan_amd/pwl.py finishes it on two points per piece).  `val`, `slope`, `out` of the args are unused. */
 int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, float* moments,
                       gnan_stream_t stream);
+
+/* Build the look-up tables on the device: one workgroup per feature finds the kinks of f_k (zero crossings
+ * of its hidden pre-activations, float64) and tabulates the network at them.  Covers L in {2, 3}, H <= 128.
+ * Outputs are padded per feature to cap+1 pieces; pieces[k] says how many are real; *overflow is set if a
+ * feature has more than `cap` kinks (the caller then falls back).  Weight layout as gnan_fmlp_args. */
+typedef struct gnan_pwl_build_args {
+  const float* w_first;   /* [F, H] */
+  const float* b_first;   /* [F, H] or NULL */
+  const float* w_mid;     /* [F, H, H] when L == 3 */
+  const float* b_mid;     /* [F, H] or NULL */
+  const float* w_last;    /* [F, C, H] */
+  const float* b_last;    /* [F, C] or NULL */
+  int32_t F, L, H, C;
+  int32_t cap;            /* <= 1024 */
+  float* anchor;          /* [F, cap+1] */
+  float* val;             /* [F, cap+1, C] */
+  float* slope;           /* [F, cap+1, C] */
+  int32_t* pieces;        /* [F] */
+  int32_t* overflow;      /* [1], zeroed by the caller */
+  void* scratch;          /* gnan_pwl_build_scratch_bytes(F, C, cap) */
+  size_t scratch_bytes;
+} gnan_pwl_build_args;
+
+size_t gnan_pwl_build_scratch_bytes(int32_t F, int32_t C, int32_t cap);
+int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rho(distance)-weighted neighbourhood sum over a hop-coded adjacency

@@ -338,3 +338,42 @@ def test_fused_column_sums_of_table_lookup(n, F, monkeypatch):
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)                     # other strategies: separate pass
     out2, total2 = feature_mlps(x, st, False, return_total=True)
     assert torch.equal(total2, column_sums(out2))
+
+
+@pytest.mark.parametrize("F,L,H,C,bias", [(5, 3, 8, 1, True), (9, 3, 32, 5, False), (64, 3, 64, 1, True), (6, 3, 33, 2, True),
+                                           (4, 2, 8, 3, True), (3, 3, 20, 40, True), (2, 3, 128, 2, True)])
+def test_table_build_kernel_matches_torch_builder(F, L, H, C, bias, monkeypatch):
+    """gnan_pwl_build (one workgroup per feature) vs the torch restatement of the same procedure, and vs the oracle."""
+    from gnan_amd import pwl
+    sd = _mlp_state(F, L, H, C, bias, seed=F * 7 + H)
+    st = _stack(sd, F, L, H, C, bias)
+    monkeypatch.setattr(pwl, "BUILD_BACKEND", "torch")
+    t_ref = pwl.build_tables(st)
+    monkeypatch.setattr(pwl, "BUILD_BACKEND", "auto")
+    t_hip = pwl.build_tables(st)
+    assert torch.equal(t_ref.off, t_hip.off), "same number of pieces per feature"
+    assert float((t_ref.anchor - t_hip.anchor).abs().max()) <= 1e-6 * max(1.0, float(t_ref.anchor.abs().max()))
+    x = (torch.rand(5000, F, generator=torch.Generator().manual_seed(2)) * 6 - 3)
+    x[:4] = torch.tensor([0.0, 1.0, -50.0, 50.0]).unsqueeze(1)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(5000, -1)
+    tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t_hip])
+    assert O.rel_err(pwl.evaluate_reference(x, tc, False), truth) <= 1e-5
+
+
+def test_table_build_kernel_degenerate_weights():
+    """Zero biases (all first-layer kinks coincide at 0), dead units (w1 = 0) and an all-zero feature."""
+    from gnan_amd import pwl
+    F, L, H, C = 4, 3, 16, 2
+    sd = _mlp_state(F, L, H, C, True, seed=3)
+    for k in range(F):
+        sd[f"fs.{k}.0.bias"].zero_()
+    sd["fs.1.0.weight"][::2] = 0.0
+    sd["fs.2.0.weight"].zero_()
+    sd["fs.2.0.bias"].fill_(0.25)
+    st = _stack(sd, F, L, H, C, True)
+    t = pwl.build_tables(st)
+    assert torch.isfinite(t.val).all() and torch.isfinite(t.slope).all() and torch.isfinite(t.anchor).all()
+    x = torch.rand(3000, F) * 4 - 2
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(3000, -1)
+    tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t])
+    assert O.rel_err(pwl.evaluate_reference(x, tc, False), truth) <= 1e-5
