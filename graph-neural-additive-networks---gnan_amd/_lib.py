@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -51,7 +51,7 @@ class PwlBuildArgs(C.Structure):
         ("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
         ("w_last", C.c_void_p), ("b_last", C.c_void_p),
         ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32),
-        ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p), ("pieces", C.c_void_p),
+        ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p), ("off", C.c_void_p),
         ("overflow", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
     ]
 

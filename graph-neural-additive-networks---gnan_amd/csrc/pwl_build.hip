@@ -239,10 +239,54 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
   }
 }
 
+// Pack the per-feature padded tables back to back: off[k] = pieces[0] + ... + pieces[k-1].
+struct CompactParams {
+  const float* anchor_p;   // padded [F, cap+1]
+  const float* val_p;      // padded [F, cap+1, C]
+  const float* slope_p;
+  const int32_t* pieces;
+  int F, C, cap;
+  int32_t* off;            // [F+1]
+  float* anchor;           // compact [T], capacity F*(cap+1)
+  float* val;
+  float* slope;
+};
+
+__global__ __launch_bounds__(256) void pwl_compact_kernel(const CompactParams p) {
+  __shared__ int red[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  int s = 0;
+  for (int j = tid; j < k; j += 256) s += p.pieces[j];
+  red[tid] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  const int base = red[0];
+  const int n = p.pieces[k];
+  if (tid == 0) {
+    p.off[k] = base;
+    if (k == p.F - 1) p.off[p.F] = base + n;
+  }
+  const float* a = p.anchor_p + static_cast<int64_t>(k) * (p.cap + 1);
+  const float* v = p.val_p + static_cast<int64_t>(k) * (p.cap + 1) * p.C;
+  const float* sl = p.slope_p + static_cast<int64_t>(k) * (p.cap + 1) * p.C;
+  for (int i = tid; i < n; i += 256) p.anchor[base + i] = a[i];
+  for (int i = tid; i < n * p.C; i += 256) {
+    p.val[static_cast<int64_t>(base) * p.C + i] = v[i];
+    p.slope[static_cast<int64_t>(base) * p.C + i] = sl[i];
+  }
+}
+
+size_t padded_floats(int F, int C, int cap) { return static_cast<size_t>(F) * (cap + 1) * (1 + 2 * static_cast<size_t>(C)); }
+
 }  // namespace
 
 extern "C" size_t gnan_pwl_build_scratch_bytes(int32_t F, int32_t C, int32_t cap) {
-  return static_cast<size_t>(F) * (cap + 2) * C * sizeof(double);
+  // float64 network values at the table nodes | padded per-feature tables | pieces per feature
+  return static_cast<size_t>(F) * (cap + 2) * C * sizeof(double) + padded_floats(F, C, cap) * sizeof(float) +
+         static_cast<size_t>(F) * sizeof(int32_t);
 }
 
 extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream) {
@@ -251,7 +295,7 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   if (a->L != 2 && a->L != 3) return gnan::fail(GNAN_ERR_UNSUPPORTED, "pwl_build: kernel covers L in {2, 3} (got %d)", a->L);
   if (a->H > 128) return gnan::fail(GNAN_ERR_UNSUPPORTED, "pwl_build: hidden width %d > 128", a->H);
   GNAN_REQUIRE(a->cap >= 1 && a->cap <= kCap, "pwl_build: cap must be in [1, %d]", kCap);
-  GNAN_REQUIRE(a->w_first && a->w_last && a->anchor && a->val && a->slope && a->pieces && a->overflow && a->scratch,
+  GNAN_REQUIRE(a->w_first && a->w_last && a->anchor && a->val && a->slope && a->off && a->overflow && a->scratch,
                "pwl_build: null pointer");
   if (a->L == 3) GNAN_REQUIRE(a->w_mid != nullptr, "pwl_build: L == 3 needs w_mid");
   if (a->scratch_bytes < gnan_pwl_build_scratch_bytes(a->F, a->C, a->cap))
@@ -260,14 +304,26 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   p.w_first = a->w_first; p.b_first = a->b_first; p.w_mid = a->w_mid; p.b_mid = a->b_mid;
   p.w_last = a->w_last; p.b_last = a->b_last;
   p.F = a->F; p.L = a->L; p.H = a->H; p.C = a->C; p.cap = a->cap;
-  p.anchor = a->anchor; p.val = a->val; p.slope = a->slope; p.pieces = a->pieces; p.overflow = a->overflow;
+  p.overflow = a->overflow;
   p.scratch = static_cast<double*>(a->scratch);
+  float* padded = reinterpret_cast<float*>(p.scratch + static_cast<size_t>(a->F) * (a->cap + 2) * a->C);
+  p.anchor = padded;
+  p.val = p.anchor + static_cast<size_t>(a->F) * (a->cap + 1);
+  p.slope = p.val + static_cast<size_t>(a->F) * (a->cap + 1) * a->C;
+  p.pieces = reinterpret_cast<int32_t*>(p.slope + static_cast<size_t>(a->F) * (a->cap + 1) * a->C);
   const size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwl_build_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "pwl_build: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(pwl_build_kernel, dim3(a->F), dim3(256), lds, static_cast<hipStream_t>(stream), p);
-  return gnan::check_launch("pwl_build_kernel");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pwl_build_kernel, dim3(a->F), dim3(256), lds, st, p);
+  if (int rc = gnan::check_launch("pwl_build_kernel")) return rc;
+  CompactParams c;
+  c.anchor_p = p.anchor; c.val_p = p.val; c.slope_p = p.slope; c.pieces = p.pieces;
+  c.F = a->F; c.C = a->C; c.cap = a->cap;
+  c.off = a->off; c.anchor = a->anchor; c.val = a->val; c.slope = a->slope;
+  hipLaunchKernelGGL(pwl_compact_kernel, dim3(a->F), dim3(256), 0, st, c);
+  return gnan::check_launch("pwl_compact_kernel");
 }

@@ -212,33 +212,40 @@ class _GraphedBuild:
         return g(p) if g else _build_padded(p)
 
 
-def _build_padded_hip(p):
-    """Same contract as :func:`_build_padded`, computed by ONE kernel (``gnan_pwl_build``: a workgroup per
-    feature, float64, LDS-resident) instead of ~150 framework launches.  Covers L in {2, 3}, H <= 128."""
+def _build_tables_hip(p) -> Optional[PwlTables]:
+    """Tables by TWO kernel launches (``gnan_pwl_build``: a workgroup per feature finds the kinks and tabulates the
+    network in float64, LDS-resident; a second tiny kernel packs the features back to back) and one
+    device->host copy of the F+1 offsets.  Covers L in {2, 3}, H <= 128; same result as :func:`_build_padded`."""
     from . import _lib
     dev = p.w_last.device
     F, C = p.F, p.C
     cap = min(1024, max(64, 4 * p.H) * (p.L - 1))
-    anchor = torch.empty((F, cap + 1), dtype=torch.float32, device=dev)
-    val = torch.empty((F, cap + 1, C), dtype=torch.float32, device=dev)
-    slope = torch.empty((F, cap + 1, C), dtype=torch.float32, device=dev)
-    meta = torch.zeros(F + 1, dtype=torch.int32, device=dev)          # pieces[F] | overflow
+    T = F * (cap + 1)
+    anchor = torch.empty(T, dtype=torch.float32, device=dev)
+    val = torch.empty((T, C), dtype=torch.float32, device=dev)
+    slope = torch.empty((T, C), dtype=torch.float32, device=dev)
+    meta = torch.zeros(F + 2, dtype=torch.int32, device=dev)          # off[F+1] | overflow
     need = _lib.lib().gnan_pwl_build_scratch_bytes(F, C, cap)
-    scratch = torch.empty(need // 8, dtype=torch.float64, device=dev)
+    scratch = torch.empty(need // 8 + 1, dtype=torch.float64, device=dev)
     keepalive = [t if t is None else t.detach().float().contiguous() for t in p[:6]]
     w_mid = keepalive[2][0] if keepalive[2] is not None else None      # [1, F, H, H] -> [F, H, H]
     b_mid = keepalive[3][0] if keepalive[3] is not None else None
     a = _lib.PwlBuildArgs(w_first=_lib.ptr(keepalive[0]), b_first=_lib.ptr(keepalive[1]), w_mid=_lib.ptr(w_mid),
                           b_mid=_lib.ptr(b_mid), w_last=_lib.ptr(keepalive[4]), b_last=_lib.ptr(keepalive[5]),
                           F=F, L=p.L, H=p.H, C=C, cap=cap, anchor=_lib.ptr(anchor), val=_lib.ptr(val),
-                          slope=_lib.ptr(slope), pieces=_lib.ptr(meta), overflow=meta[F:].data_ptr(),
-                          scratch=_lib.ptr(scratch), scratch_bytes=need)
+                          slope=_lib.ptr(slope), off=_lib.ptr(meta), overflow=meta[F + 1:].data_ptr(),
+                          scratch=_lib.ptr(scratch), scratch_bytes=scratch.numel() * 8)
     _lib.check(_lib.lib().gnan_pwl_build(a, _lib.stream_of(anchor)), "gnan_pwl_build")
-    pieces = meta[:F].long()
-    off = torch.zeros(F + 1, dtype=torch.int64, device=dev)
-    off[1:] = torch.cumsum(pieces, 0)
-    keep = torch.arange(cap + 1, device=dev).unsqueeze(0) < pieces.unsqueeze(1)
-    return torch.cat([off, meta[F:].long()]), anchor, val, slope, keep
+    host = meta.tolist()                                            # the ONE device->host copy of the build
+    off_host, overflowed = host[:-1], bool(host[-1])
+    biggest = max(b - a_ for a_, b in zip(off_host, off_host[1:]))
+    if overflowed or biggest > MAX_PIECES:
+        return None
+    plan = _plan_groups(off_host, C)
+    if plan is None:
+        return None
+    n = off_host[-1]
+    return PwlTables(meta[: F + 1], anchor[:n], val[:n], slope[:n], biggest, plan[0], plan[1])
 
 
 BUILD_BACKEND = "auto"       # "auto": HIP kernel where it applies, else the (graph-replayed) torch restatement; "torch"
@@ -248,9 +255,8 @@ BUILD_BACKEND = "auto"       # "auto": HIP kernel where it applies, else the (gr
 def build_tables(p, use_graph: bool = True) -> Optional[PwlTables]:
     """Tabulate all F shape functions; returns None if some feature needs more than MAX_PIECES pieces."""
     if BUILD_BACKEND == "auto" and p.w_last.is_cuda and p.L in (2, 3) and 1 <= p.H <= 128:
-        packed, anchor, val, sl, keep = _build_padded_hip(p)
-    else:
-        packed, anchor, val, sl, keep = _GraphedBuild.run(p) if use_graph else _build_padded(p)
+        return _build_tables_hip(p)
+    packed, anchor, val, sl, keep = _GraphedBuild.run(p) if use_graph else _build_padded(p)
     C = val.shape[-1]
     host = packed.tolist()                                          # the ONE device->host copy of the build
     off_host, overflowed = host[:-1], bool(host[-1])

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 8
+#define GNAN_ABI_VERSION 9
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -132,8 +132,9 @@ int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_s
 
 /* Build the look-up tables on the device: one workgroup per feature finds the kinks of f_k (zero crossings
  * of its hidden pre-activations, float64) and tabulates the network at them.  Covers L in {2, 3}, H <= 128.
- * Outputs are padded per feature to cap+1 pieces; pieces[k] says how many are real; *overflow is set if a
- * feature has more than `cap` kinks (the caller then falls back).  Weight layout as gnan_fmlp_args. */
+ * Outputs are the compact tables gnan_fpwl_fwd reads (features back to back, off[k] = first piece of feature
+ * k, capacity F*(cap+1) pieces); *overflow is set if a feature has more than `cap` kinks (the caller then
+ * falls back).  Weight layout as gnan_fmlp_args. */
 typedef struct gnan_pwl_build_args {
   const float* w_first;   /* [F, H] */
   const float* b_first;   /* [F, H] or NULL */
@@ -143,10 +144,10 @@ typedef struct gnan_pwl_build_args {
   const float* b_last;    /* [F, C] or NULL */
   int32_t F, L, H, C;
   int32_t cap;            /* <= 1024 */
-  float* anchor;          /* [F, cap+1] */
-  float* val;             /* [F, cap+1, C] */
-  float* slope;           /* [F, cap+1, C] */
-  int32_t* pieces;        /* [F] */
+  float* anchor;          /* [F*(cap+1)]      compact */
+  float* val;             /* [F*(cap+1), C] */
+  float* slope;           /* [F*(cap+1), C] */
+  int32_t* off;           /* [F+1] */
   int32_t* overflow;      /* [1], zeroed by the caller */
   void* scratch;          /* gnan_pwl_build_scratch_bytes(F, C, cap) */
   size_t scratch_bytes;
