@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int kCap = 1024;        // breakpoints per feature this kernel can hold
+constexpr int kNodeChunk = 32;    // table nodes evaluated per pass
 
 struct BuildParams {
   const float* w_first;  // [F, H]
@@ -33,6 +34,7 @@ struct BuildParams {
   int32_t* pieces;       // [F]
   int32_t* overflow;     // [1]
   double* scratch;       // [F, cap + 2, C] network values at the table nodes
+  int hid_offset;        // byte offset of the hidden-activation tile in dynamic LDS (8-byte aligned)
 };
 
 __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
   float* b1 = w1 + p.H;                                     // [H]
   float* b2 = b1 + p.H;                                     // [H]
   float* W2 = b2 + p.H;                                     // [H*H] (L == 3)
+  double* hid = reinterpret_cast<double*>(smem_raw + p.hid_offset);   // [kNodeChunk, H]
   __shared__ int n_cand, n_bp, over;
   const int tid = threadIdx.x;
   const int k = blockIdx.x;
@@ -188,28 +191,25 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
   const int Pn = P ? P : 1;                                 // table nodes between the two outer ones
   double* V = p.scratch + static_cast<int64_t>(k) * (p.cap + 2) * C;
   const float* Wl = p.w_last + static_cast<int64_t>(k) * C * H;
-  for (int i = tid; i < Pn + 2; i += 256) {
-    const double x = tnode(i);
-    for (int c0 = 0; c0 < C; c0 += 8) {
-      double acc[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = (p.b_last && c0 + t < C) ? p.b_last[k * C + c0 + t] : 0.0;
-      for (int j = 0; j < H; ++j) {
-        double h;
-        if (p.L == 3) {
-          h = z2(w1, b1, W2 + j * H, b2[j], H, x);
-        } else {
-          h = fma(static_cast<double>(w1[j]), x, static_cast<double>(b1[j]));
-        }
-        h = h > 0.0 ? h : 0.0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (c0 + t < C) acc[t] = fma(static_cast<double>(Wl[(c0 + t) * H + j]), h, acc[t]);
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (c0 + t < C) V[static_cast<int64_t>(i) * C + c0 + t] = acc[t];
+  // the network at the table nodes, kNodeChunk nodes at a time: (node, hidden unit) pairs fill the last hidden
+  // layer in LDS, then (node, channel) pairs take the output dot products
+  for (int n0 = 0; n0 < Pn + 2; n0 += kNodeChunk) {
+    const int nn = Pn + 2 - n0 < kNodeChunk ? Pn + 2 - n0 : kNodeChunk;
+    for (int it = tid; it < nn * H; it += 256) {
+      const int ni = it / H, j = it % H;
+      const double x = tnode(n0 + ni);
+      double h = p.L == 3 ? z2(w1, b1, W2 + j * H, b2[j], H, x)
+                          : fma(static_cast<double>(w1[j]), x, static_cast<double>(b1[j]));
+      hid[ni * H + j] = h > 0.0 ? h : 0.0;
     }
+    __syncthreads();
+    for (int it = tid; it < nn * C; it += 256) {
+      const int ni = it / C, c = it % C;
+      double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
+      for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
+      V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
+    }
+    __syncthreads();
   }
   __threadfence_block();
   __syncthreads();
@@ -311,7 +311,10 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   p.val = p.anchor + static_cast<size_t>(a->F) * (a->cap + 1);
   p.slope = p.val + static_cast<size_t>(a->F) * (a->cap + 1) * a->C;
   p.pieces = reinterpret_cast<int32_t*>(p.slope + static_cast<size_t>(a->F) * (a->cap + 1) * a->C);
-  const size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
+  size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
+  lds = (lds + 7) & ~static_cast<size_t>(7);
+  p.hid_offset = static_cast<int>(lds);
+  lds += static_cast<size_t>(kNodeChunk) * a->H * sizeof(double);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwl_build_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -18,7 +18,7 @@ import re
 import sys
 
 src, prefix = sys.argv[1], sys.argv[2]
-ours = ("spmm", "fmlp", "dense_to_code", "colsum")
+ours = ("spmm", "fmlp", "fpwl", "pwl_", "dense_to_code", "colsum", "bfs_")
 
 rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "*_kernel_stats.csv"))[0])))
 with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
