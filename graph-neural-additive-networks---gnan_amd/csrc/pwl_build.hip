@@ -53,12 +53,13 @@ __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
   }
 }
 
-// pre-activation of second-layer unit j at x (L == 3)
-__device__ __forceinline__ double z2(const float* w1, const float* b1, const float* W2row, float b2, int H, double x) {
+// pre-activation of second-layer unit j at x (L == 3).  W2 sits TRANSPOSED in LDS (W2t[k*H + j]) so that lanes
+// holding consecutive units read consecutive banks (row-major would be a 32-way bank conflict on every read).
+__device__ __forceinline__ double z2(const float* w1, const float* b1, const float* W2t_col, float b2, int H, double x) {
   double z = b2;
   for (int k = 0; k < H; ++k) {
     const double h = fma(static_cast<double>(w1[k]), x, static_cast<double>(b1[k]));
-    z = fma(static_cast<double>(W2row[k]), h > 0.0 ? h : 0.0, z);
+    z = fma(static_cast<double>(W2t_col[k * H]), h > 0.0 ? h : 0.0, z);
   }
   return z;
 }
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
     b2[i] = (p.L == 3 && p.b_mid) ? p.b_mid[k * H + i] : 0.f;
   }
   if (p.L == 3)
-    for (int i = tid; i < H * H; i += 256) W2[i] = p.w_mid[static_cast<int64_t>(k) * H * H + i];
+    for (int i = tid; i < H * H; i += 256)       // coalesced read of W[j][kk], transposed write
+      W2[(i % H) * H + i / H] = p.w_mid[static_cast<int64_t>(k) * H * H + i];
   for (int i = tid; i < kCap; i += 256) bp[i] = INF;
   if (tid == 0) { n_cand = 0; over = 0; }
   __syncthreads();
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
       const int per = (n_nodes - 1 + segs - 1) / segs;     // intervals per segment
       const int i0 = s * per, i1 = i0 + per < n_nodes - 1 ? i0 + per : n_nodes - 1;
       if (i0 < i1 || (s == 0)) {
-        const float* row = W2 + j * H;
+        const float* row = W2 + j;
         double e_prev = node(i0), z_prev = z2(w1, b1, row, b2[j], H, e_prev);
         double e_first = e_prev, z_first = z_prev, e_second = 0, z_second = 0;
         for (int i = i0 + 1; i <= i1; ++i) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
     for (int it = tid; it < nn * H; it += 256) {
       const int ni = it / H, j = it % H;
       const double x = tnode(n0 + ni);
-      double h = p.L == 3 ? z2(w1, b1, W2 + j * H, b2[j], H, x)
+      double h = p.L == 3 ? z2(w1, b1, W2 + j, b2[j], H, x)
                           : fma(static_cast<double>(w1[j]), x, static_cast<double>(b1[j]));
       hid[ni * H + j] = h > 0.0 ? h : 0.0;
     }
