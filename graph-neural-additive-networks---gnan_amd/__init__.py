@@ -6,7 +6,7 @@ Drop-in for the reference's ``TensorGNAN`` / ``GNAN`` / ``NAM`` modules
 The arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI in
 ``include/gnan_hip.h``; see DESIGN.md and INTEGRATION.md.
 """
-from . import GNAN, batched, models  # noqa: F401  (mirror modules)
+from . import GNAN, batched, harness, interpret, models  # noqa: F401  (mirror modules + f-3 / f-4)
 from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps  # noqa: F401
 from .graph import HopGraph, hop_inputs, shell_counts_csr  # noqa: F401
 

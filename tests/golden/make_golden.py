@@ -309,6 +309,65 @@ def main():
         manifest.append(name)
         print(name)
 
+    # f-3: the reference's epoch loops on a plain torch model (trainer.py:23-154)
+    import trainer as ref_trainer                     # noqa: E402  (sklearn only; importable here)
+
+    class Probe(torch.nn.Module):                     # forward(data) -> logits, like the GNAN classes
+        def __init__(self, f, c):
+            super().__init__()
+            self.lin = torch.nn.Linear(f, c)
+
+        def forward(self, data):
+            return self.lin(data.x)
+
+    class ToyData(Bag):
+        def to(self, device):
+            return self
+
+    for tid, (c, graph_task, loss_name) in enumerate([(1, False, "BCEWithLogitsLoss"), (3, False, "CrossEntropyLoss"),
+                                                      (1, True, "MSELoss"), (1, True, "BCEWithLogitsLoss")]):
+        torch.manual_seed(40 + tid)
+        rng = np.random.default_rng(9000 + tid)
+        batches = []
+        for b in range(3):
+            n = 12 if not graph_task else 1
+            x = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+            if loss_name == "CrossEntropyLoss":
+                y = torch.from_numpy(rng.integers(0, c, n))
+            elif loss_name == "MSELoss":
+                y = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+            else:
+                y = torch.from_numpy(rng.choice([-1.0, 1.0], n).astype(np.float32))   # {-1,+1}: remapped to {0,1}
+            masks = {m: torch.from_numpy(rng.random(n) < 0.6) for m in ("train_mask", "val_mask", "test_mask")}
+            for m in masks.values():
+                m[0] = True
+            batches.append(ToyData(x=x, y=y, **masks))
+        model = Probe(4, c)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        loss_fn = getattr(torch.nn, loss_name)()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        classify = loss_name != "MSELoss"
+        tr = ref_trainer.train_epoch(model, batches, loss_fn, opt, "cpu", classify=classify, compute_auc=False,
+                                     is_graph_task=graph_task)
+        sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+        te = ref_trainer.test_epoch(model, batches, loss_fn, "cpu", classify=classify,
+                                    compute_auc=(loss_name == "BCEWithLogitsLoss" and not graph_task),
+                                    val_mask=True, is_graph_task=graph_task)
+        arrays = {"train_ret": np.array(tr, dtype=np.float64), "test_ret": np.array(te, dtype=np.float64)}
+        for k, v in sd0.items():
+            arrays["sd0/" + k] = v.numpy()
+        for k, v in sd1.items():
+            arrays["sd1/" + k] = v.numpy()
+        for b, d in enumerate(batches):
+            for k, v in d.__dict__.items():
+                arrays[f"b{b}/{k}"] = v.numpy()
+        meta = dict(variant="trainer", id=300 + tid, C=c, graph=graph_task, loss=loss_name, classify=classify)
+        name = f"case_{300 + tid:03d}_trainer"
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        manifest.append(name)
+        print(name, tr, te)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print(f"{len(manifest)} cases, {total / 1024:.0f} KiB")
