@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -65,7 +65,7 @@ class SpmmArgs(C.Structure):
         ("lut", C.c_void_p), ("lut_row_stride", C.c_int64), ("D", C.c_int32), ("Cw", C.c_int32),
         ("cnt", C.c_void_p), ("cnt_stride", C.c_int64),
         ("s_total", C.c_void_p), ("weight_by_col", C.c_int32), ("minus_rest", C.c_int32),
-        ("reduce_cr", C.c_int32), ("Y", C.c_void_p), ("y_stride", C.c_int64),
+        ("reduce_cr", C.c_int32), ("scatter_out", C.c_int32), ("Y", C.c_void_p), ("y_stride", C.c_int64),
         ("long_threshold", C.c_int64), ("long_rows", C.c_void_p), ("long_slice_ptr", C.c_void_p),
         ("n_long", C.c_int32), ("n_slices", C.c_int32), ("slice_edges", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),

@@ -40,6 +40,7 @@ struct Params {
   const float* s_total;
   int weight_by_col, minus_rest;
   int reduce_cr;  // > 0: store only the per-channel sums over columns w = c (mod reduce_cr)
+  int scatter_out;  // output row q is stored at Y[row_ids[q]] (rows are PROCESSED in row_ids order, e.g. by degree)
   float* Y;
   int64_t y_stride;
   int64_t long_threshold;
@@ -259,7 +260,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
         for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(wr.v[v], tot.v[v] - all.v[v], acc.v[v]);
       }
       if (p.reduce_cr == 0) {
-        store_vec<VEC>(p.Y + q * p.y_stride + cw, acc);
+        store_vec<VEC>(p.Y + (p.scatter_out ? i : q) * p.y_stride + cw, acc);
       } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -278,7 +279,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
       for (int c = 0; c < 4; ++c) red[c] += __shfl_xor(red[c], off);
     }
     if (sub == 0)
-      for (int c = 0; c < p.reduce_cr; ++c) p.Y[q * p.y_stride + c] = red[c];
+      for (int c = 0; c < p.reduce_cr; ++c) p.Y[(p.scatter_out ? i : q) * p.y_stride + c] = red[c];
   }
 }
 
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
         const Vec<1> wr = row_weights<1>(p, i, p.D - 1, w);
         acc = fmaf(wr.v[0], p.s_total[w] - all, acc);
       }
-      if (p.reduce_cr == 0) p.Y[q * p.y_stride + w] = acc;
+      if (p.reduce_cr == 0) p.Y[(p.scatter_out ? i : q) * p.y_stride + w] = acc;
     }
     if (p.reduce_cr) {  // fixed-order tree: strides stay multiples of reduce_cr, so channels never mix
       __syncthreads();
@@ -430,7 +431,8 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
       if (static_cast<int>(threadIdx.x) < p.reduce_cr) chan += tile[threadIdx.x];
     }
   }
-  if (p.reduce_cr && static_cast<int>(threadIdx.x) < p.reduce_cr) p.Y[q * p.y_stride + threadIdx.x] = chan;
+  if (p.reduce_cr && static_cast<int>(threadIdx.x) < p.reduce_cr)
+    p.Y[(p.scatter_out ? i : q) * p.y_stride + threadIdx.x] = chan;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -585,6 +587,7 @@ int validate(const gnan_spmm_args* a) {
   GNAN_REQUIRE(a->s_stride >= a->W && (a->reduce_cr != 0 || a->y_stride >= a->W), "spmm: row stride smaller than W");
   if (a->s_dtype != GNAN_F32) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: only fp32 operand rows are implemented");
   GNAN_REQUIRE(!(a->weight_by_col && a->s_total), "spmm: weight_by_col excludes the rest-bucket term (add it outside)");
+  GNAN_REQUIRE(!a->scatter_out || a->row_ids, "spmm: scatter_out needs row_ids");
   if (a->reduce_cr != 0) {
     const int cr = a->reduce_cr;
     if (!(cr == 1 || cr == 2 || cr == 4) || a->W % cr != 0)
@@ -618,6 +621,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.lut = a->lut; p.lut_row_stride = a->lut_row_stride; p.D = a->D; p.Cw = a->Cw;
   p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total;
   p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest; p.reduce_cr = a->reduce_cr;
+  p.scatter_out = a->scatter_out;
   p.Y = a->Y; p.y_stride = a->y_stride;
   p.long_threshold = a->n_long > 0 ? a->long_threshold : INT64_MAX;
   p.long_rows = a->long_rows; p.long_slice_ptr = a->long_slice_ptr;

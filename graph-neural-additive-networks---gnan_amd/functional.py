@@ -262,7 +262,7 @@ def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_tota
 # rho-weighted aggregation
 # =============================================================================
 def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut, weight_by_col=False,
-               minus_rest=False, plan=None, workspace=None, reduce_cr=0) -> _lib.SpmmArgs:
+               minus_rest=False, plan=None, workspace=None, reduce_cr=0, scatter_out=False) -> _lib.SpmmArgs:
     D, Cw = lut.shape[-2], lut.shape[-1]
     a = _lib.SpmmArgs(
         n_rows=out.shape[0], n_cols=g.n_cols,
@@ -272,7 +272,7 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         lut=_lib.ptr(lut), lut_row_stride=(D * Cw if per_row_lut else 0), D=D, Cw=Cw,
         cnt=_lib.ptr(g.cnt) if use_cnt else None, cnt_stride=g.cnt.stride(0),
         s_total=_lib.ptr(s_total), weight_by_col=int(weight_by_col), minus_rest=int(minus_rest),
-        reduce_cr=int(reduce_cr), Y=_lib.ptr(out), y_stride=out.stride(0),
+        reduce_cr=int(reduce_cr), scatter_out=int(scatter_out), Y=_lib.ptr(out), y_stride=out.stride(0),
         long_threshold=(plan.threshold if plan is not None else 0),
         long_rows=_lib.ptr(plan.rows) if plan is not None else None,
         long_slice_ptr=_lib.ptr(plan.slice_ptr) if plan is not None else None,
@@ -298,6 +298,7 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
 
 
 FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum over features in its epilogue
+DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
 
 
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
@@ -323,9 +324,16 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
         s_total = column_sums(S)
     if not with_rest:
         s_total = None
-    plan = None if g.is_dense else g.long_row_plan(row_ids)
+    scatter = False
+    if g.is_dense:
+        plan = None
+    elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
+        row_ids, plan = g.degree_schedule()      # process rows by degree, store them in place
+        scatter = True
+    else:
+        plan = g.long_row_plan(row_ids)
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
-                   reduce_cr=reduce_cr)
+                   reduce_cr=reduce_cr, scatter_out=scatter)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
     ws = None
     if need:

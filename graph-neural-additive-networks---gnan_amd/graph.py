@@ -49,6 +49,8 @@ class HopGraph:
     col: Optional[torch.Tensor] = None      # int32 [nnz]
     _plan: Optional[LongRowPlan] = field(default=None, repr=False)
     _transposed: Optional["HopGraph"] = field(default=None, repr=False)
+    _degree_order: Optional[torch.Tensor] = field(default=None, repr=False)
+    _degree_plan: Optional[LongRowPlan] = field(default=None, repr=False)
 
     @property
     def is_dense(self) -> bool:
@@ -196,6 +198,16 @@ class HopGraph:
         if row_ids is None:
             self._plan = plan
         return plan
+
+    def degree_schedule(self):
+        """Rows sorted by number of listed pairs (stable) and the hub-row plan in that order — the processing
+        schedule of the aggregation kernel: the 4..32 rows that share a wavefront then have (almost) equal
+        lengths, so no lane group idles while a neighbour finishes a longer row.  Cached per graph."""
+        if self._degree_order is None:
+            deg = (self.rowptr[1:] - self.rowptr[:-1])
+            self._degree_order = torch.argsort(deg, stable=True).to(torch.int32)
+            self._degree_plan = self.long_row_plan(self._degree_order)
+        return self._degree_order, self._degree_plan
 
     def transposed(self) -> "HopGraph":
         """Adjacency with the roles of row and neighbour swapped (used for the gradient w.r.t. S).

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 9
+#define GNAN_ABI_VERSION 10
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -213,6 +213,9 @@ typedef struct gnan_spmm_args {
   int32_t minus_rest;        /* transposed use: wt(., d) - wt(., D-1) per listed pair */
   int32_t reduce_cr;         /* fused read-out: 0 = store all W columns; c in {1,2,4} = store only
                                 Y[q, c'] = sum over columns w = c' (mod c)  (the feature sum of GNAN.py:72-73) */
+  int32_t scatter_out;       /* 1: rows are PROCESSED in row_ids order (a schedule, e.g. by degree, so that the
+                                rows sharing a wavefront have similar lengths) but STORED at Y[row_ids[q]] —
+                                row_ids must then be a permutation of the adjacency rows */
   float* Y;                  /* [n_rows, W] fp32  ([n_rows, reduce_cr] with the fused read-out) */
   int64_t y_stride;
   /* long-row plan (CSR only; n_long == 0 => every row goes through the main kernel) */

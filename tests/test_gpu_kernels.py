@@ -377,3 +377,20 @@ def test_table_build_kernel_degenerate_weights():
     truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(3000, -1)
     tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t])
     assert O.rel_err(pwl.evaluate_reference(x, tc, False), truth) <= 1e-5
+
+
+def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
+    """Rows processed in degree order and stored in place == rows processed in natural order (same arithmetic per row)."""
+    from gnan_amd import functional
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(21)
+    n, K, W = 5000, 1, 16
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(3, 900), (4000, 4000)])
+    g = _graph(rowptr, col, code, n, K + 2)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut = torch.tensor([[1.0], [0.5], [0.01]], device=DEV)
+    y_sched = spmm_launch(g, S, lut, True, True)
+    r_sched = spmm_launch(g, S, lut, True, True, reduce_cr=1)
+    monkeypatch.setattr(functional, "DEGREE_SCHEDULE_MIN_WIDTH", 1 << 30)
+    assert torch.equal(y_sched, spmm_launch(g, S, lut, True, True))
+    assert torch.equal(r_sched, spmm_launch(g, S, lut, True, True, reduce_cr=1))
