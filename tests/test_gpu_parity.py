@@ -14,7 +14,7 @@ from oracle import gnan_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODEL_CASES = [n for n in golden_names() if "pre_process" not in n and "batched" not in n]
+MODEL_CASES = [n for n in golden_names() if not any(t in n for t in ("pre_process", "batched", "trainer"))]
 
 
 @pytest.fixture(scope="module")
