@@ -171,81 +171,6 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
 }
 
 // One workgroup per column: 256 threads stride over the per-workgroup partials, then a fixed-order tree.
-// Whole-row variant (C == 1, F a power-of-two multiple of 4 up to 256, all tables <= 128 KiB of LDS): one 1024-thread
-// workgroup per CU holds the tables of ALL features, thread = (node, 4 features), so a wavefront reads and writes whole
-// consecutive rows of x / fx — the access pattern of a plain copy (the grouped kernel touches one 64-B sector per
-// node per workgroup and runs at half the copy rate).
-template <bool SUM>
-__global__ __launch_bounds__(1024) void fpwl_rows_kernel(const Params p, const int total_pieces) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* anchor_l = smem;
-  float* val_l = smem + total_pieces;
-  float* slope_l = val_l + total_pieces;
-  int* off_l = reinterpret_cast<int*>(slope_l + total_pieces);            // [F + 1]
-  float* red = reinterpret_cast<float*>(off_l + p.F + 1);                 // [1024 * 4] (column sums only)
-  const int tid = threadIdx.x;
-  const int TPN = p.F / 4, NODES = 1024 / TPN;
-  const int q = tid % TPN, nl = tid / TPN;
-  for (int i = tid; i < total_pieces; i += 1024) {
-    anchor_l[i] = p.anchor[i];
-    val_l[i] = p.val[i];
-    slope_l[i] = p.slope[i];
-  }
-  for (int i = tid; i <= p.F; i += 1024) off_l[i] = p.off[i];
-  __syncthreads();
-  int po[4], pn[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    po[f] = off_l[4 * q + f];
-    pn[f] = off_l[4 * q + f + 1] - po[f] - 1;
-  }
-  const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
-  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
-  float ps[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
-    const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + 4 * q);
-    const float xv[4] = {t.x, t.y, t.z, t.w};
-    int idx[4];
-    search<4>(anchor_l, po, pn, xv, p.step0, idx);
-    float y[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) y[f] = fmaf(slope_l[idx[f]], xv[f] - anchor_l[idx[f]], val_l[idx[f]]);
-    if constexpr (SUM) {
-      float a = (y[0] + y[1]) + (y[2] + y[3]);
-      for (int off = 1; off < TPN; off <<= 1) a += __shfl_xor(a, off);      // TPN <= 64: the node's threads share a wave
-      if (q == 0) p.out[n * p.out_stride] = a;
-    } else {
-      *reinterpret_cast<float4*>(p.out + n * p.out_stride + 4 * q) = make_float4(y[0], y[1], y[2], y[3]);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) ps[f] += y[f];
-    }
-  }
-  if constexpr (!SUM) {
-    if (p.col_partial) {
-      __syncthreads();
-#pragma unroll
-      for (int f = 0; f < 4; ++f) red[tid * 4 + f] = ps[f];
-      __syncthreads();
-      if (tid < p.F) {
-        const int qq = tid / 4, ff = tid % 4;
-        double acc = 0.0;
-        for (int s2 = 0; s2 < NODES; ++s2) acc += red[(s2 * TPN + qq) * 4 + ff];
-        p.col_partial[static_cast<int64_t>(blockIdx.x) * p.F + tid] = acc;
-      }
-    }
-  }
-}
-
-constexpr int kRowsNodesPerBlock = 8192;
-
-bool rows_mode(const gnan_fpwl_args* a) {
-  const int tpn = a->F / 4;
-  auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
-  return a->C == 1 && a->F % 4 == 0 && tpn >= 1 && tpn <= 64 && (tpn & (tpn - 1)) == 0 && a->total_pieces > 0 &&
-         static_cast<size_t>(a->total_pieces) * 12 <= 128 * 1024 && a->x_stride % 4 == 0 && aligned(a->x) &&
-         (a->sum_features || (a->out_stride % 4 == 0 && aligned(a->out))) && a->n >= 4 * kRowsNodesPerBlock;
-}
-
 __global__ __launch_bounds__(256) void fpwl_total_kernel(const double* __restrict__ partial, int blocks, int W,
                                                          float* __restrict__ total) {
   __shared__ double red[256];
@@ -449,32 +374,6 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a->out_stride >= ow, "fpwl: out row stride smaller than the output width");
   const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
   Params p = base_params(a);
-  hipStream_t st0 = static_cast<hipStream_t>(stream);
-  if (rows_mode(a)) {
-    p.nodes_per_block = kRowsNodesPerBlock;
-    const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
-    if (a->total) {
-      const size_t need = static_cast<size_t>(bx) * a->F * sizeof(double);
-      if (a->total_workspace == nullptr || a->total_workspace_bytes < need)
-        return gnan::fail(GNAN_ERR_WORKSPACE, "fpwl: total workspace %zu B < required %zu B", a->total_workspace_bytes, need);
-      p.col_partial = static_cast<double*>(a->total_workspace);
-    }
-    const size_t lds_rows = static_cast<size_t>(a->total_pieces) * 12 + (a->F + 1) * sizeof(int) + 1024 * 4 * sizeof(float);
-    auto go = [&](auto kernel) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_rows));
-      if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(bx)), dim3(1024), lds_rows, st0, p, a->total_pieces);
-      return gnan::check_launch("fpwl_rows_kernel");
-    };
-    if (int rc = a->sum_features ? go(fpwl_rows_kernel<true>) : go(fpwl_rows_kernel<false>)) return rc;
-    if (p.col_partial) {
-      hipLaunchKernelGGL(fpwl_total_kernel, dim3(p.F), dim3(256), 0, st0, p.col_partial, static_cast<int>(bx), p.F,
-                         a->total);
-      return gnan::check_launch("fpwl_total_kernel");
-    }
-    return GNAN_OK;
-  }
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
   p.vec_x = fg % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 && aligned(a->x);
   p.vec_out = fg % 4 == 0 && a->F % 4 == 0 && a->out_stride % 4 == 0 && aligned(a->out);

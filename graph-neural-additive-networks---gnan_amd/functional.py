@@ -84,8 +84,8 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
-                      max_group_pieces=t.max_group_pieces, total_pieces=int(t.anchor.numel()),
-                      sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0))
+                      max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
+                      out=_lib.ptr(out), out_stride=out.stride(0))
     total = None
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 11
+#define GNAN_ABI_VERSION 10
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -108,7 +108,6 @@ typedef struct gnan_fpwl_args {
   int32_t max_pieces;
   int32_t features_per_group;
   int32_t max_group_pieces;
-  int32_t total_pieces;    /* off[F] if known (enables the whole-row kernel when all tables fit LDS), else 0 */
   int32_t sum_features;    /* as gnan_fmlp_args */
   float* out;
   int64_t out_stride;
