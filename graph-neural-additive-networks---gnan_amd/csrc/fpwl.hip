@@ -30,6 +30,8 @@ struct Params {
   float* out;
   int64_t out_stride;
   double* col_partial;   // optional [gridDim.x, F]: per-workgroup column sums of the output (FAST, per-feature mode)
+  int acc_offset;        // > 0 (sum over features, C > 1): float offset in dynamic LDS of the [C][NODES] accumulators;
+                         // the workgroup then owns ONE pass of nodes and walks all feature groups for them
 };
 
 // Thread = (node, feature quad): FPT = min(FG, 4) features per thread, TPN = FG / FPT threads per node, so a
@@ -76,6 +78,10 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
   const int g_lo = SUM ? 0 : blockIdx.y;
   const int g_hi = SUM ? p.n_groups : g_lo + 1;
+  float* acc_l = smem + p.acc_offset;
+  if (SUM && p.acc_offset) {
+    for (int i = tid; i < C * NODES; i += 256) acc_l[i] = 0.f;
+  }
 
   for (int g = g_lo; g < g_hi; ++g) {
     const int k0 = g * FG;
@@ -132,7 +138,10 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
 #pragma unroll
           for (int off = 1; off < TPN; off <<= 1) a += __shfl_xor(a, off);   // the node's TPN threads
           // groups run one after the other inside the workgroup and a node keeps its thread: no race
-          if (q == 0) o[c] = g == 0 ? a : o[c] + a;
+          if (q == 0) {
+            if (p.acc_offset) acc_l[c * NODES + nl] += a;      // many channels: accumulate on chip, store once
+            else o[c] = g == 0 ? a : o[c] + a;
+          }
         }
       } else {
         float* o = p.out + n * p.out_stride + static_cast<int64_t>(k0 + q * FPT) * C;
@@ -167,6 +176,12 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
         }
       }
     }
+  }
+  if (SUM && p.acc_offset) {
+    __syncthreads();
+    const int64_t n = n_lo + nl;
+    if (n < n_hi)
+      for (int c = q; c < C; c += TPN) p.out[n * p.out_stride + c] = acc_l[c * NODES + nl];
   }
 }
 
@@ -277,10 +292,17 @@ int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
 }
 
 template <int FG>
-int launch(const Params& p, size_t lds, hipStream_t st, float* total_out) {
+int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
+  if (p.sum_features && p.C > 1) {        // accumulate the feature sum in LDS: one pass of nodes per workgroup
+    if (lds + static_cast<size_t>(p.C) * Map<FG>::NODES * sizeof(float) <= 150 * 1024) {
+      p.acc_offset = static_cast<int>(lds / sizeof(float));
+      p.nodes_per_block = Map<FG>::NODES;
+    }
+  }
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
   if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
   const dim3 grid(static_cast<unsigned>(bx), p.sum_features ? 1u : static_cast<unsigned>(p.n_groups));
+  if (p.acc_offset) lds += static_cast<size_t>(p.C) * Map<FG>::NODES * sizeof(float);
   // FAST: one output channel, whole groups only, 16-B aligned x (and fx) rows
   const bool fast = FG % 4 == 0 && p.C == 1 && p.F % FG == 0 && p.vec_x && (p.sum_features || p.vec_out);
   if (p.col_partial) {
@@ -340,6 +362,7 @@ Params base_params(const gnan_fpwl_args* a) {
   p.vec_x = p.vec_out = 0;
   p.out = a->out; p.out_stride = a->out_stride;
   p.col_partial = nullptr;
+  p.acc_offset = 0;
   return p;
 }
 }  // namespace
