@@ -50,13 +50,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
+// One workgroup per column: 256 threads stride over the per-workgroup partials, then a fixed-order tree.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int blocks, int W,
                                                            float* __restrict__ total) {
-  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < W; w += gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partial[static_cast<int64_t>(b) * W + w];
-    total[w] = static_cast<float>(s);
+  __shared__ double red[256];
+  const int w = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 256) s += partial[static_cast<int64_t>(b) * W + w];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) total[w] = static_cast<float>(red[0]);
 }
 
 }  // namespace
@@ -83,6 +90,6 @@ extern "C" int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride,
     hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(blocks), dim3(256), 0, st, S, n, W, stride, partial);
   }
   if (int rc = gnan::check_launch("colsum_partial_kernel")) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((W + 255) / 256), dim3(256), 0, st, partial, blocks, W, total);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(W), dim3(256), 0, st, partial, blocks, W, total);
   return gnan::check_launch("colsum_final_kernel");
 }

@@ -53,36 +53,123 @@ def _tiny_init(module: nn.Module) -> None:
             nn.init.constant_(p, 0)
 
 
+class FlatMLPStore:
+    """The F x L per-feature ``nn.Linear`` parameters of a ``ModuleList`` of identical MLPs, re-homed into six
+    contiguous buffers (first / middle / last layer, weights and biases) of which every Parameter is a view.
+
+    The Parameters keep their identity, names and shapes (``state_dict`` keys, optimizers, ``fs[k](x)`` all work as
+    before), but the kernels read the stacked buffers directly: no ``torch.stack`` of 10^2..10^4 small tensors per
+    forward, no un-stacking in backward.  Gradients reach the Parameters through six proxy leaves: a hook adds the
+    stacked gradient into a flat gradient buffer of which every ``Parameter.grad`` is a view (re-linked only after
+    ``zero_grad(set_to_none=True)`` dropped the views).  In-place updates (optimizer steps, ``load_state_dict``)
+    keep the sharing; ``.to()`` / ``.float()`` re-home (:meth:`rebuild`)."""
+
+    def __init__(self, mlps):
+        self.mlps = mlps
+        self.rebuild()
+
+    def rebuild(self) -> None:
+        lin = [[m for m in seq if isinstance(m, nn.Linear)] for seq in self.mlps]
+        self.lin, self.F, self.L = lin, len(lin), len(lin[0])
+        self.has_bias = lin[0][0].bias is not None
+        L = self.L
+        self.C = lin[0][-1].out_features
+        self.H = lin[0][0].out_features if L >= 2 else 0
+
+        def home(layers, attr):                       # stack [len(layers), F, ...] and turn the Parameters into views
+            with torch.no_grad():
+                buf = torch.stack([torch.stack([getattr(lin[k][l], attr).data for k in range(self.F)], 0)
+                                   for l in layers], 0).contiguous()
+                for i, l in enumerate(layers):
+                    for k in range(self.F):
+                        getattr(lin[k][l], attr).data = buf[i, k]
+            return buf
+        first, mid, last = ([0], list(range(1, L - 1)), [L - 1]) if L >= 2 else ([], [], [0])
+        self.slots = {"first": first, "mid": mid, "last": last}
+        self.buf = {}
+        for part, layers in self.slots.items():
+            if layers:
+                self.buf[part + "_w"] = home(layers, "weight")
+                if self.has_bias:
+                    self.buf[part + "_b"] = home(layers, "bias")
+        self.grad = {}
+
+    def consistent(self) -> bool:
+        """Cheap guard: the first and the last Parameter still live inside the buffers."""
+        a, b = self.lin[0][-1].weight, self.lin[-1][-1].weight
+        w = self.buf["last_w"]
+        return a.data_ptr() == w[0, 0].data_ptr() and b.data_ptr() == w[0, self.F - 1].data_ptr() and a.device == w.device
+
+    def _kernel_view(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        if name in ("first_w",):
+            return t[0, ..., 0]                       # [1, F, H, 1] -> [F, H]
+        if name in ("first_b", "last_b"):
+            return t[0]
+        if name == "last_w":
+            return t[0, ..., 0] if self.L == 1 else t[0]     # L == 1: Linear(1, C) -> [F, C]
+        return t                                      # mid_w [L-2, F, H, H], mid_b [L-2, F, H]
+
+    def _link_grads(self, name: str) -> None:
+        part, attr = name.split("_")
+        g = self.grad[name]
+        for i, l in enumerate(self.slots[part]):
+            for k in range(self.F):
+                getattr(self.lin[k][l], "weight" if attr == "w" else "bias").grad = g[i, k]
+
+    def _linked(self, name: str) -> bool:
+        g = self.grad.get(name)
+        if g is None:
+            return False
+        part, attr = name.split("_")
+        p0 = getattr(self.lin[0][self.slots[part][0]], "weight" if attr == "w" else "bias")
+        p1 = getattr(self.lin[-1][self.slots[part][-1]], "weight" if attr == "w" else "bias")
+        return (p0.grad is not None and p1.grad is not None and p0.grad.data_ptr() == g[0, 0].data_ptr()
+                and p1.grad.data_ptr() == g[-1, -1].data_ptr())
+
+    def _on_grad(self, name: str, g: torch.Tensor) -> None:
+        full = self.buf[name]
+        g = g.reshape(full.shape).to(full.dtype)
+        if self._linked(name):
+            self.grad[name].add_(g)                   # ordinary autograd accumulation, on the flat buffer
+        else:
+            self.grad[name] = g.clone()
+            self._link_grads(name)
+
+    def stacked(self, track_grad: bool) -> StackedMLP:
+        out = {}
+        for name, t in self.buf.items():
+            v = self._kernel_view(name, t)
+            if track_grad:
+                v = v.detach().requires_grad_(True)
+                v.register_hook(lambda g, name=name: self._on_grad(name, g))
+            out[name] = v
+        return StackedMLP(out.get("first_w"), out.get("first_b"), out.get("mid_w"), out.get("mid_b"),
+                          out["last_w"], out.get("last_b"), self.L, self.H, self.C, self.F)
+
+
 class _PathBase(nn.Module):
-    """Shared plumbing: stacked-weight cache, hop-graph lookup, rho look-up tables."""
+    """Shared plumbing: flat parameter stores, hop-graph lookup, rho look-up tables."""
 
     def _init_caches(self):
-        self._stack_cache = {}
-        self._flat_params = {}
+        self._stores = {}
         self._graph_cache = None
 
-    def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): storage moves, caches are stale
+    def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): every Parameter moved on its own
         out = super()._apply(fn, *args, **kwargs)
-        self._stack_cache, self._flat_params = {}, {}
+        for store in getattr(self, "_stores", {}).values():
+            store.rebuild()                              # re-home them into contiguous buffers on the new device
         return out
 
     # ---- parameters -> stacked device tensors --------------------------------------------
     def _stacked(self, name: str, mlps) -> StackedMLP:
-        """Stacked weights of F per-feature MLPs.  With autograd on, ``torch.stack`` is part of the graph; without
-        it the stack is cached and keyed on the parameters' version counters (in-place updates — optimizer steps,
-        ``load_state_dict`` — bump them), so an evaluation loop pays for the F x L small copies once."""
-        params = self._flat_params.get(name)
-        if params is None:                               # walking 10^3 nn.Sequential objects costs ~20 ms: do it once
-            params = self._flat_params[name] = [p for seq in mlps for p in seq.parameters()]
-        if torch.is_grad_enabled() and params[0].requires_grad:
-            return stack_mlps(mlps)                       # autograd flows back through torch.stack
-        key = tuple([p._version for p in params])
-        hit = self._stack_cache.get(name)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = (key, stack_mlps(mlps))
-            self._stack_cache[name] = hit
-        return hit[1]
+        """Stacked weights of the F per-feature MLPs — views of the :class:`FlatMLPStore`, no copies.  With autograd on,
+        proxy leaves carry the stacked gradients back to the individual Parameters."""
+        store = self._stores.get(name)
+        if store is None:
+            store = self._stores[name] = FlatMLPStore(mlps)
+        elif not store.consistent():
+            store.rebuild()
+        return store.stacked(torch.is_grad_enabled() and store.lin[0][0].weight.requires_grad)
 
     def _check_dropout(self):
         """Training-mode Dropout (GNAN.py:28,32) is stochastic and tied to torch's RNG stream, which a fused kernel

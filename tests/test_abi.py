@@ -69,3 +69,43 @@ def test_cpu_tensors_are_rejected_loudly():
     m = TensorGNAN(3, 2, 3, hidden_channels=8).eval()
     with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
         m.forward(d)
+
+
+def test_flat_parameter_store_keeps_the_module_contract():
+    """Parameters become views of six contiguous buffers: names, values, optimizer steps, load_state_dict and
+    gradient accumulation behave exactly as with independent Parameters."""
+    from gnan_amd.functional import _fmlp_eager, stack_mlps
+    from gnan_amd.models import TensorGNAN
+    torch.manual_seed(0)
+    m = TensorGNAN(5, 2, 3, hidden_channels=8)
+    keys = list(m.state_dict().keys())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    st = m._stacked("fs", m.fs)
+    assert list(m.state_dict().keys()) == keys
+    assert all(torch.equal(m.state_dict()[k], before[k]) for k in keys)
+    for a, b in zip(st[:6], stack_mlps(m.fs)[:6]):
+        assert torch.equal(a.detach(), b.detach())
+    x = torch.rand(7, 5)
+    _fmlp_eager(x, st, True).pow(2).sum().backward()
+    got = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    _fmlp_eager(x, stack_mlps(m.fs), True).pow(2).sum().backward()
+    for n, p in m.named_parameters():
+        if n.startswith("fs."):
+            assert torch.allclose(p.grad, got[n], atol=1e-6), n
+    m.zero_grad(set_to_none=False)                          # grads stay linked to the flat buffer: accumulate twice
+    for _ in range(2):
+        _fmlp_eager(x, m._stacked("fs", m.fs), True).pow(2).sum().backward()
+    for n, p in m.named_parameters():
+        if n.startswith("fs."):
+            assert torch.allclose(p.grad, 2 * got[n], atol=1e-5), n
+    torch.optim.SGD(m.parameters(), lr=0.1).step()           # in-place update is visible through the buffers
+    assert torch.equal(m._stacked("fs", m.fs).w_last.detach(), stack_mlps(m.fs).w_last.detach())
+    m.load_state_dict(before)
+    assert torch.equal(m._stacked("fs", m.fs).w_mid.detach(), stack_mlps(m.fs).w_mid.detach())
+    import copy
+    m2 = copy.deepcopy(m)                                     # copies lose the sharing; the guard re-homes them
+    with torch.no_grad():
+        m2.fs[1][3].weight.add_(1.0)
+    assert torch.equal(m2._stacked("fs", m2.fs).w_mid.detach(), stack_mlps(m2.fs).w_mid.detach())
+    assert m.double()._stacked("fs", m.fs).w_last.dtype == torch.float64
