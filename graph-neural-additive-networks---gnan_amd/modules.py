@@ -81,8 +81,8 @@ class FlatMLPStore:
                 buf = torch.stack([torch.stack([getattr(lin[k][l], attr).data for k in range(self.F)], 0)
                                    for l in layers], 0).contiguous()
                 for i, l in enumerate(layers):
-                    for k in range(self.F):
-                        getattr(lin[k][l], attr).data = buf[i, k]
+                    for k, view in enumerate(buf[i].unbind(0)):      # one C++ call for the F views
+                        getattr(lin[k][l], attr).data = view
             return buf
         first, mid, last = ([0], list(range(1, L - 1)), [L - 1]) if L >= 2 else ([], [], [0])
         self.slots = {"first": first, "mid": mid, "last": last}
@@ -112,9 +112,10 @@ class FlatMLPStore:
     def _link_grads(self, name: str) -> None:
         part, attr = name.split("_")
         g = self.grad[name]
+        which = "weight" if attr == "w" else "bias"
         for i, l in enumerate(self.slots[part]):
-            for k in range(self.F):
-                getattr(self.lin[k][l], "weight" if attr == "w" else "bias").grad = g[i, k]
+            for k, view in enumerate(g[i].unbind(0)):                # one C++ call for the F views
+                getattr(self.lin[k][l], which).grad = view
 
     def _linked(self, name: str) -> bool:
         g = self.grad.get(name)
