@@ -68,7 +68,7 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to pin one of the three evaluation strategies
 PWL_MIN_WORK = 1 << 24       # AUTO tabulates the shape functions once n*F look-ups outweigh the table build
 PWL_MIN_WORK_GRAD = 1 << 18  # ... much earlier when a backward pass follows: the moment kernel replaces a full recompute
-PWL_MIN_NODES = 1 << 14      # the table build costs ~cap*passes node-equivalents per feature: pointless for small graphs
+PWL_MIN_NODES = 1 << 14      # inference on small graphs: the matrix-core kernel beats table build + look-up
 
 
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False):
@@ -125,7 +125,7 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
     algo = FMLP_ALGO
     threshold = PWL_MIN_WORK_GRAD if needs_grad else PWL_MIN_WORK
     if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= threshold
-                                 and x.shape[0] >= PWL_MIN_NODES):
+                                 and (needs_grad or x.shape[0] >= PWL_MIN_NODES)):
         from .pwl import build_tables
         tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
         if tables is not None:
