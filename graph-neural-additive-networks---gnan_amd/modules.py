@@ -92,7 +92,7 @@ class FlatMLPStore:
                 self.buf[part + "_w"] = home(layers, "weight")
                 if self.has_bias:
                     self.buf[part + "_b"] = home(layers, "bias")
-        self.grad = {}
+        self.grad, self.grad_views = {}, {}
 
     def consistent(self) -> bool:
         """Cheap guard: the first and the last Parameter still live inside the buffers."""
@@ -110,12 +110,18 @@ class FlatMLPStore:
         return t                                      # mid_w [L-2, F, H, H], mid_b [L-2, F, H]
 
     def _link_grads(self, name: str) -> None:
-        part, attr = name.split("_")
-        g = self.grad[name]
-        which = "weight" if attr == "w" else "bias"
-        for i, l in enumerate(self.slots[part]):
-            for k, view in enumerate(g[i].unbind(0)):                # one C++ call for the F views
-                getattr(self.lin[k][l], which).grad = view
+        """Point every Parameter's ``.grad`` at its slice of the flat gradient buffer (the (param, view) pairs are
+        built once per buffer; after ``zero_grad(set_to_none=True)`` only the F x L assignments are repeated)."""
+        pairs = self.grad_views.get(name)
+        if pairs is None:
+            part, attr = name.split("_")
+            g = self.grad[name]
+            which = "weight" if attr == "w" else "bias"
+            pairs = [(getattr(self.lin[k][l], which), view)
+                     for i, l in enumerate(self.slots[part]) for k, view in enumerate(g[i].unbind(0))]
+            self.grad_views[name] = pairs
+        for param, view in pairs:
+            param.grad = view
 
     def _linked(self, name: str) -> bool:
         g = self.grad.get(name)
@@ -133,7 +139,9 @@ class FlatMLPStore:
         if self._linked(name):
             self.grad[name].add_(g)                   # ordinary autograd accumulation, on the flat buffer
         else:
-            self.grad[name] = g.clone()
+            if name not in self.grad:
+                self.grad[name] = torch.empty_like(full)
+            self.grad[name].copy_(g)                  # the buffer (and the views cut from it) persists across steps
             self._link_grads(name)
 
     def stacked(self, track_grad: bool) -> StackedMLP:
