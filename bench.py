@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--order", default="reference", choices=["reference", "sum_first"])
     ap.add_argument("--fmlp-algo", default="auto", choices=["auto", "lane", "mfma", "pwl"],
                     help="shape-function strategy: auto = exact table look-up at this size; mfma = fp32 matrix cores")
+    ap.add_argument("--operand", default="f32", choices=["f32", "bf16"],
+                    help="storage format of the aggregated operand rows (bf16: storage only, fp32 accumulation; the "
+                         "papers100M-shaped configuration of BASELINE.json; not comparable with the fp32 reference at 1e-5)")
     ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature"],
                     help="multi-GPU decomposition: vertex blocks + all-gather of the operand, or feature columns + "
                          "all-reduce of the [N, C] partial outputs; auto = fewer bytes over xGMI")
@@ -56,11 +59,11 @@ def parse():
     return ap.parse_args()
 
 
-def spmm_algorithmic_bytes(g, W, W_out):
+def spmm_algorithmic_bytes(g, W, W_out, elem=4):
     """SURVEY.md §8d: nnz*(4 col + 1 code + W*4 gathered row) + rows*(rowptr + W_out*4 output + 12 count table);
     W_out = C when the feature sum is fused into the epilogue (reference order), else W."""
     rp = 8 if g.rowptr.dtype == torch.int64 else 4
-    return g.nnz * (4 + 1 + W * 4) + g.n_rows * (rp + W_out * 4 + 4 * g.n_codes)
+    return g.nnz * (4 + 1 + W * elem) + g.n_rows * (rp + W_out * 4 + 4 * g.n_codes)
 
 
 def fmlp_flops(n, F, H, L, C):
@@ -180,6 +183,7 @@ def main():
     with torch.no_grad():
         stacked = stack_mlps(model.fs)
         lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
+    op_dtype = torch.bfloat16 if args.operand == "bf16" else torch.float32
     stage_names = ["fmlp", "gather", "total", "spmm"] + (["reduce"] if partition == "feature" else [])
     stacked_local = slice_features(stacked, fpart.lo, fpart.hi) if partition == "feature" else None
     events = []
@@ -196,9 +200,10 @@ def main():
         with torch.no_grad():
             if partition == "vertex":
                 out = partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
-                                          marks=mark)
+                                          marks=mark, operand_dtype=op_dtype)
             else:
-                out = feature_parallel_forward(x, g, stacked_local, lut, True, fpart, out_channels=C, marks=mark)
+                out = feature_parallel_forward(x, g, stacked_local, lut, True, fpart, out_channels=C, marks=mark,
+                                               operand_dtype=op_dtype)
         if record:
             events.append(marks)
         return out
@@ -234,12 +239,12 @@ def main():
         W = (fpart.hi - fpart.lo) * C
     else:
         W = F * C if args.order == "reference" else C
-    b_alg = spmm_algorithmic_bytes(g, W, C)
+    b_alg = spmm_algorithmic_bytes(g, W, C, 2 if args.operand == "bf16" else 4)
     spmm_s = stages["spmm"] / 1e3
     achieved = b_alg / spmm_s / 1e9 if spmm_s > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    workload = f"rmat_s{args.scale}_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_{args.order}_K1"
+    workload = f"rmat_s{args.scale}_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_{args.order}_K1" + ("" if args.operand == "f32" else "_bf16")
     if os.path.exists(tpath):
         rec = json.load(open(tpath))
         if rec.get("workload") == workload and rec.get("n_gpus") == world:
@@ -251,7 +256,8 @@ def main():
         result = {
             "metric": "edges aggregated/sec, TensorGNAN forward", "value": E / (elapsed / args.steps),
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.operand == "f32" else "bf16 operand storage, f32 accumulate",
             "data": "synthetic",
             "config": {"workload": workload, "nodes": N, "edges": E, "stored_pairs_rank0": g.nnz,
                        "operand_width": W, "partition": f"{partition} x{world}", "exchange":

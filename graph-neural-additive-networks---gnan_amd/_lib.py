@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -42,7 +42,7 @@ class FpwlArgs(C.Structure):
         ("off", C.c_void_p), ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p),
         ("max_pieces", C.c_int32), ("features_per_group", C.c_int32), ("max_group_pieces", C.c_int32),
         ("sum_features", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64),
-        ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
+        ("out_dtype", C.c_int32), ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
     ]
 
 
@@ -94,6 +94,8 @@ SYMBOLS = {
     "gnan_bfs_dense_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_bfs_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnan_colsum_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
     "gnan_dense_to_code": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -7,7 +7,8 @@ namespace {
 
 constexpr int kBlocks = 1024;
 
-template <int VEC>
+// BF16: S holds bf16 rows (VEC must be 4: 8-B loads), widened to fp32 before summing.
+template <int VEC, bool BF16 = false>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ S, int64_t n, int W, int64_t stride,
                                                              double* __restrict__ partial) {
   // thread (cx, ry): column chunk cx of VEC floats, rows ry, ry + RY, ... inside this workgroup's row range
@@ -27,7 +28,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (c < chunks && ry < RY) {
       for (int64_t r = r0 + ry; r < r1; r += RY) {
         const float* ptr = S + r * stride + static_cast<int64_t>(c) * VEC;
-        if constexpr (VEC == 4) {
+        if constexpr (BF16) {
+          const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(S) + r * stride +
+                                                          static_cast<int64_t>(c) * 4);
+          acc[0] += __uint_as_float(t.x << 16); acc[1] += __uint_as_float(t.x & 0xffff0000u);
+          acc[2] += __uint_as_float(t.y << 16); acc[3] += __uint_as_float(t.y & 0xffff0000u);
+        } else if constexpr (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4*>(ptr);
           acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
         } else {
@@ -69,6 +75,25 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
 }  // namespace
 
 extern "C" size_t gnan_colsum_workspace_bytes(int32_t W) { return static_cast<size_t>(kBlocks) * W * sizeof(double); }
+
+extern "C" int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
+                                size_t workspace_bytes, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && W >= 1, "colsum: bad sizes");
+  GNAN_REQUIRE(S && total && workspace, "colsum: null pointer");
+  GNAN_REQUIRE(stride >= W && W % 4 == 0 && stride % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 8 == 0,
+               "colsum_bf16: needs W %% 4 == 0 and 8-B aligned rows");
+  if (workspace_bytes < gnan_colsum_workspace_bytes(W))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "colsum: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int blocks = static_cast<int>(n / 256 + 1);
+  blocks = blocks > kBlocks ? kBlocks : blocks;
+  double* partial = static_cast<double*>(workspace);
+  hipLaunchKernelGGL((colsum_partial_kernel<4, true>), dim3(blocks), dim3(256), 0, st, static_cast<const float*>(S), n, W,
+                     stride, partial);
+  if (int rc = gnan::check_launch("colsum_partial_kernel")) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(W), dim3(256), 0, st, partial, blocks, W, total);
+  return gnan::check_launch("colsum_final_kernel");
+}
 
 extern "C" int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                            size_t workspace_bytes, gnan_stream_t stream) {

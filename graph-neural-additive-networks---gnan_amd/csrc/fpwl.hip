@@ -30,6 +30,7 @@ struct Params {
   float* out;
   int64_t out_stride;
   double* col_partial;   // optional [gridDim.x, F]: per-workgroup column sums of the output (FAST, per-feature mode)
+  int out_bf16;          // per-feature output stored as bf16 rows (FAST path only)
   int acc_offset;        // > 0 (sum over features, C > 1): float offset in dynamic LDS of the [C][NODES] accumulators;
                          // the workgroup then owns ONE pass of nodes and walks all feature groups for them
 };
@@ -64,8 +65,14 @@ __device__ __forceinline__ void search(const float* anchor_l, const int (&po)[FP
   for (int f = 0; f < FPT; ++f) idx[f] += po[f];
 }
 
-// SUM: out[n, c] = sum over features (f_sums, GNAN.py:157); FAST: C == 1, full groups, 16-B aligned rows.
-template <int FG, bool SUM, bool FAST>
+__device__ __forceinline__ unsigned bf16_bits(float f) {      // round-to-nearest-even, as torch.bfloat16
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// SUM: out[n, c] = sum over features (f_sums, GNAN.py:157); FAST: C == 1, full groups, 16-B aligned rows;
+// OUT16 (FAST, per-feature output only): store bf16 rows — the operand format of the bf16-storage aggregation.
+template <int FG, bool SUM, bool FAST, bool OUT16 = false>
 __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   constexpr int FPT = Map<FG>::FPT, TPN = Map<FG>::TPN, NODES = Map<FG>::NODES;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -151,7 +158,16 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
           t.y = fmaf(slope_l[idx[1 % FPT]], d[1 % FPT], val_l[idx[1 % FPT]]);
           t.z = fmaf(slope_l[idx[2 % FPT]], d[2 % FPT], val_l[idx[2 % FPT]]);
           t.w = fmaf(slope_l[idx[3 % FPT]], d[3 % FPT], val_l[idx[3 % FPT]]);
-          *reinterpret_cast<float4*>(o) = t;
+          if constexpr (OUT16) {
+            const unsigned b0 = bf16_bits(t.x), b1 = bf16_bits(t.y), b2 = bf16_bits(t.z), b3 = bf16_bits(t.w);
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(p.out) + n * p.out_stride + (k0 + q * FPT);
+            *reinterpret_cast<uint2*>(o16) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+            // the column sums must describe the operand the aggregation will actually read: the rounded values
+            t = make_float4(__uint_as_float(b0 << 16), __uint_as_float(b1 << 16), __uint_as_float(b2 << 16),
+                            __uint_as_float(b3 << 16));
+          } else {
+            *reinterpret_cast<float4*>(o) = t;
+          }
           ps[0] += t.x; ps[1 % FPT] += t.y; ps[2 % FPT] += t.z; ps[3 % FPT] += t.w;
         } else {
 #pragma unroll
@@ -319,8 +335,18 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, p);
     return gnan::check_launch("fpwl_kernel");
   };
-  if (p.sum_features) return fast ? go(fpwl_kernel<FG, true, true>) : go(fpwl_kernel<FG, true, false>);
-  if (int rc = fast ? go(fpwl_kernel<FG, false, true>) : go(fpwl_kernel<FG, false, false>)) return rc;
+  if (p.out_bf16) {
+    if constexpr (FG % 4 == 0) {
+      if (!fast || p.sum_features)
+        return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: bf16 output needs C == 1, whole feature groups, aligned rows, per-feature mode");
+      if (int rc = go(fpwl_kernel<FG, false, true, true>)) return rc;
+    } else {
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: bf16 output needs feature groups of >= 4");
+    }
+  } else {
+    if (p.sum_features) return fast ? go(fpwl_kernel<FG, true, true>) : go(fpwl_kernel<FG, true, false>);
+    if (int rc = fast ? go(fpwl_kernel<FG, false, true>) : go(fpwl_kernel<FG, false, false>)) return rc;
+  }
   if (p.col_partial) {
     hipLaunchKernelGGL(fpwl_total_kernel, dim3(p.F), dim3(256), 0, st, p.col_partial, static_cast<int>(bx), p.F,
                        total_out);
@@ -360,9 +386,10 @@ Params base_params(const gnan_fpwl_args* a) {
   p.nodes_per_block = static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
   p.sum_features = a->sum_features;
   p.vec_x = p.vec_out = 0;
-  p.out = a->out; p.out_stride = a->out_stride;
+  p.out = static_cast<float*>(a->out); p.out_stride = a->out_stride;
   p.col_partial = nullptr;
   p.acc_offset = 0;
+  p.out_bf16 = a->out_dtype == GNAN_BF16;
   return p;
 }
 }  // namespace
@@ -400,6 +427,7 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
   p.vec_x = fg % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 && aligned(a->x);
   p.vec_out = fg % 4 == 0 && a->F % 4 == 0 && a->out_stride % 4 == 0 && aligned(a->out);
+  GNAN_REQUIRE(a->out_dtype == GNAN_F32 || a->out_dtype == GNAN_BF16, "fpwl: unknown out_dtype");
   if (a->total) {
     const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
     const size_t need = static_cast<size_t>(bx) * a->F * sizeof(double);

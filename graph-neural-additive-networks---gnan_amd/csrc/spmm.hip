@@ -29,7 +29,7 @@ struct Params {
   const int32_t* col;
   const uint8_t* code;
   const int32_t* row_ids;
-  const float* S;
+  const void* S;   // fp32 rows, or bf16 rows when the kernels are instantiated with VEC == 8
   int W;
   int64_t s_stride;
   const float* lut;
@@ -63,7 +63,10 @@ struct Vec {
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> load_vec(const float* ptr) {
   Vec<VEC> r;
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 8) {
+    const float4 a = *reinterpret_cast<const float4*>(ptr), b = *reinterpret_cast<const float4*>(ptr + 4);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  } else if constexpr (VEC == 4) {
     const float4 t = *reinterpret_cast<const float4*>(ptr);
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
   } else if constexpr (VEC == 2) {
@@ -75,8 +78,32 @@ __device__ __forceinline__ Vec<VEC> load_vec(const float* ptr) {
   return r;
 }
 
+// Operand rows: fp32 for VEC in {1, 4}; VEC == 8 is the bf16-storage mode (8 bf16 = one 16-B request per lane,
+// widened to fp32 in registers; accumulation and output stay fp32).
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> load_operand(const void* S, int64_t row, int64_t stride, int col) {
+  if constexpr (VEC == 8) {
+    const uint4 t = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(S) + row * stride + col);
+    Vec<VEC> r;
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r.v[2 * i] = __uint_as_float(w[i] << 16);
+      r.v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+    return r;
+  } else {
+    return load_vec<VEC>(static_cast<const float*>(S) + row * stride + col);
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* ptr, const Vec<VEC>& r) {
+  if constexpr (VEC == 8) {
+    *reinterpret_cast<float4*>(ptr) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    *reinterpret_cast<float4*>(ptr + 4) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    return;
+  }
   if constexpr (VEC == 4) {
     *reinterpret_cast<float4*>(ptr) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
   } else if constexpr (VEC == 2) {
@@ -225,7 +252,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           d[u] = d[u] < rest ? d[u] : rest;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) s[u].v[v] = 0.f;
-          if (j < m && col_ok) s[u] = load_vec<VEC>(p.S + static_cast<int64_t>(c[u]) * p.s_stride + cw);
+          if (j < m && col_ok) s[u] = load_operand<VEC>(p.S, c[u], p.s_stride, cw);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -333,7 +360,7 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
         int d = __shfl(codev, j);
         d = d < rest ? d : rest;
         if (j < m && col_ok) {
-          const Vec<VEC> sv = load_vec<VEC>(p.S + static_cast<int64_t>(c) * p.s_stride + cw);
+          const Vec<VEC> sv = load_operand<VEC>(p.S, c, p.s_stride, cw);
           if constexpr (SMALLD) {
             const float w = sw.pick(d);
 #pragma unroll
@@ -480,7 +507,7 @@ __global__ __launch_bounds__(256) void spmm_shell_sums_kernel(const Params p) {
         int d = __shfl(codev, j, LPR);
         d = d < rest ? d : rest;
         if (col_ok) {
-          const Vec<VEC> sv = load_vec<VEC>(p.S + static_cast<int64_t>(c) * p.s_stride + cw);
+          const Vec<VEC> sv = load_operand<VEC>(p.S, c, p.s_stride, cw);
           float* t = T + static_cast<int64_t>(d) * p.W + cw;
           Vec<VEC> cur = load_vec<VEC>(t);
 #pragma unroll
@@ -541,14 +568,6 @@ int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
   if (dense) {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, true, false>), grid, block, 0, st, p);
   } else if (smalld) {
-    static const int tune = getenv("GNAN_SPMM_TUNE") ? atoi(getenv("GNAN_SPMM_TUNE")) : 0;   // development knob
-    if (VEC == 4 && LPR == 16 && tune == 1) {
-      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, 1>), grid, block, 0, st, p);
-    } else if (VEC == 4 && LPR == 16 && tune == 2) {
-      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, 2>), grid, block, 0, st, p);
-    } else if (VEC == 4 && LPR == 16 && tune == 3) {
-      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, 3>), grid, block, 0, st, p);
-    } else
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true>), grid, block, 0, st, p);
   } else {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, false>), grid, block, 0, st, p);
@@ -585,7 +604,15 @@ int validate(const gnan_spmm_args* a) {
   GNAN_REQUIRE(a->S && a->lut && a->Y && a->code, "spmm: null S / lut / Y / code");
   GNAN_REQUIRE((a->rowptr == nullptr) == (a->col == nullptr), "spmm: rowptr and col must both be set (CSR) or both NULL (dense)");
   GNAN_REQUIRE(a->s_stride >= a->W && (a->reduce_cr != 0 || a->y_stride >= a->W), "spmm: row stride smaller than W");
-  if (a->s_dtype != GNAN_F32) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: only fp32 operand rows are implemented");
+  if (a->s_dtype != GNAN_F32 && a->s_dtype != GNAN_BF16) return gnan::fail(GNAN_ERR_BAD_ARG, "spmm: unknown operand dtype %d", a->s_dtype);
+  if (a->s_dtype == GNAN_BF16) {
+    if (a->W % 8 != 0 || a->s_stride % 8 != 0 || reinterpret_cast<uintptr_t>(a->S) % 16 != 0 || a->rowptr == nullptr)
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: bf16 operand rows need the CSR layout, W %% 8 == 0 and 16-B aligned rows");
+    if (a->reduce_cr == 0 && (a->y_stride % 4 != 0 || reinterpret_cast<uintptr_t>(a->Y) % 16 != 0))
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: bf16 operand rows need a 16-B aligned fp32 output");
+    if (a->s_total && reinterpret_cast<uintptr_t>(a->s_total) % 16 != 0)
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: s_total must be 16-B aligned");
+  }
   GNAN_REQUIRE(!(a->weight_by_col && a->s_total), "spmm: weight_by_col excludes the rest-bucket term (add it outside)");
   GNAN_REQUIRE(!a->scatter_out || a->row_ids, "spmm: scatter_out needs row_ids");
   if (a->reduce_cr != 0) {
@@ -617,7 +644,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.n_rows = a->n_rows; p.n_cols = a->n_cols;
   p.rowptr = a->rowptr; p.rowptr_is64 = a->rowptr_is64;
   p.col = a->col; p.code = a->code; p.row_ids = a->row_ids;
-  p.S = static_cast<const float*>(a->S); p.W = a->W; p.s_stride = a->s_stride;
+  p.S = a->S; p.W = a->W; p.s_stride = a->s_stride;
   p.lut = a->lut; p.lut_row_stride = a->lut_row_stride; p.D = a->D; p.Cw = a->Cw;
   p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total;
   p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest; p.reduce_cr = a->reduce_cr;
@@ -649,6 +676,7 @@ extern "C" int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t strea
   if (int rc = validate(a)) return rc;
   if (a->n_rows == 0) return GNAN_OK;
   GNAN_REQUIRE(!a->weight_by_col, "shell_sums: weight_by_col has no meaning here");
+  if (a->s_dtype != GNAN_F32) return gnan::fail(GNAN_ERR_UNSUPPORTED, "shell_sums: fp32 operand rows only (no backward for bf16 storage)");
   const Params p = make_params(a);
   int vec, lpr;
   pick_tiling(a, a->Y, a->W, &vec, &lpr);
@@ -674,5 +702,10 @@ extern "C" int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream) {
     pick_tiling(a, a->Y, a->y_stride, &vec, &lpr);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->s_dtype == GNAN_BF16) {
+    lpr = 1;
+    while (lpr * 8 < a->W && lpr < kWave) lpr <<= 1;
+    return launch_lpr<8>(p, lpr, false, smalld, st);
+  }
   return vec == 4 ? launch_lpr<4>(p, lpr, dense, smalld, st) : launch_lpr<1>(p, lpr, dense, smalld, st);
 }

@@ -68,7 +68,8 @@ def gather_operand(local: torch.Tensor, part: VertexPartition, group=None) -> to
 
 def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.Tensor, use_cnt: bool,
                         part: VertexPartition, order: str = "sum_first", out_channels: int = 1, group=None,
-                        compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None):
+                        compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
+                        operand_dtype=torch.float32):
     """Forward of the node-level path on this rank's block; returns ``out[lo:hi, :out_channels]``.
 
     ``order='sum_first'`` exchanges the narrow ``[N, C]`` operand (what the drop-in modules do);
@@ -82,7 +83,8 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     mark("start")
     # the column sums of the operand (rest-bucket total) come out of the shape-function pass; the ranks add
     # their W-float partials instead of re-reading the gathered operand
-    operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True)
+    kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
+    operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True, **kw)
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
     mark("gather")
@@ -138,7 +140,8 @@ def choose_partition(n_nodes: int, n_features: int, out_channels: int, world: in
 
 def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lut: torch.Tensor, use_cnt: bool,
                              part: FeaturePartition, out_channels: int = 1, group=None,
-                             compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None):
+                             compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
+                             operand_dtype=torch.float32):
     """Reference-order forward with the feature axis sharded; returns the full ``[N, out_channels]`` output
     (identical on every rank after the all-reduce).
 
@@ -150,7 +153,8 @@ def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lu
     mark("start")
     n = graph_full.n_rows
     if part.hi > part.lo:
-        operand, total = ops["feature_mlps"](x_cols, stacked_local, False, return_total=True)   # [N, Fp*C], [Fp*C]
+        kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
+        operand, total = ops["feature_mlps"](x_cols, stacked_local, False, return_total=True, **kw)   # [N, Fp*C], [Fp*C]
         mark("fmlp")
         mark("gather")                                                         # nothing to exchange here
         mark("total")

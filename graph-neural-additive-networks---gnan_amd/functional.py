@@ -71,7 +71,7 @@ PWL_MIN_WORK_GRAD = 1 << 18  # ... much earlier when a backward pass follows: th
 PWL_MIN_NODES = 1 << 14      # inference on small graphs: the matrix-core kernel beats table build + look-up
 
 
-def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False):
+def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32):
     """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``.
     With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
     when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
@@ -80,12 +80,13 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         x = x.contiguous()
     n, F = x.shape
     C = t.val.shape[1]
-    out = torch.empty((n, C if sum_features else F * C), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, C if sum_features else F * C), dtype=out_dtype, device=x.device)
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
-                      out=_lib.ptr(out), out_stride=out.stride(0))
+                      out=_lib.ptr(out), out_stride=out.stride(0),
+                      out_dtype=_lib.GNAN_BF16 if out_dtype == torch.bfloat16 else _lib.GNAN_F32)
     total = None
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
@@ -119,18 +120,20 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) ->
 
 
 def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False,
-                  needs_grad: bool = False):
+                  needs_grad: bool = False, out_dtype=torch.float32):
     """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
     Returns ``(out, tables or None, total or None)``."""
     algo = FMLP_ALGO
+    if out_dtype != torch.float32:                      # bf16 operand rows exist only on the table path
+        algo = _lib.FMLP_PWL
     threshold = PWL_MIN_WORK_GRAD if needs_grad else PWL_MIN_WORK
     if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= threshold
                                  and (needs_grad or x.shape[0] >= PWL_MIN_NODES)):
         from .pwl import build_tables
         tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
         if tables is not None:
-            out, total = _fpwl_launch(x, tables, sum_features, want_total=True) if want_total else \
-                (_fpwl_launch(x, tables, sum_features), None)
+            out, total = _fpwl_launch(x, tables, sum_features, want_total=True, out_dtype=out_dtype) if want_total \
+                else (_fpwl_launch(x, tables, sum_features, out_dtype=out_dtype), None)
             return out, tables, total
         if algo == _lib.FMLP_PWL:
             raise _lib.GnanHipError("shape functions need more pieces than the look-up kernel supports")
@@ -191,13 +194,15 @@ _BWD_CHUNK_ELEMS = 1 << 28   # activation floats per recompute chunk (1 GiB)
 
 class _FeatureMLPs(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, sum_features, want_total, L, H, C, F, *params):
+    def forward(ctx, x, sum_features, want_total, out_dtype, L, H, C, F, *params):
         p = StackedMLP(*params, L, H, C, F)
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
-        needs_grad = any(ctx.needs_input_grad[7:]) and not ctx.needs_input_grad[0]
-        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, want_total, needs_grad)
+        needs_grad = any(ctx.needs_input_grad[8:]) and not ctx.needs_input_grad[0]
+        if needs_grad and out_dtype != torch.float32:
+            raise _lib.GnanHipError("bf16 operand storage is an inference format: no backward pass")
+        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, want_total, needs_grad, out_dtype)
         if not want_total:
             return out
         if total is None:
@@ -225,7 +230,7 @@ class _FeatureMLPs(torch.autograd.Function):
             it = iter(got)
             pg = [None if not present else next(it) for present in ctx.present]
             pg = [None if g is None else g.to(torch.float32) for g in pg]
-            return (None, None, None, None, None, None, None, *pg)
+            return (None, None, None, None, None, None, None, None, *pg)
         grads = [torch.zeros_like(t) for t in live]
         n = x.shape[0]
         chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))
@@ -244,17 +249,19 @@ class _FeatureMLPs(torch.autograd.Function):
                 gx[lo:lo + chunk] = got[-1]
         it = iter(grads)
         pg = [next(it) if present else None for present in ctx.present]
-        return (gx, None, None, None, None, None, None, *pg)
+        return (gx, None, None, None, None, None, None, None, *pg)
 
 
-def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False):
+def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False,
+                 out_dtype=torch.float32):
     """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157.
     ``return_total`` additionally returns the column sums of the result (the aggregation's rest-bucket operand),
-    fused into the look-up kernel where possible."""
+    fused into the look-up kernel where possible.  ``out_dtype=torch.bfloat16`` stores the per-feature rows in bf16
+    (inference only; one output channel), the operand format of the bf16-storage aggregation."""
     _lib.require_device(x, p.w_last)
     if x.shape[1] != p.F:
         raise ValueError(f"x has {x.shape[1]} feature columns, the model was built for {p.F}")
-    return _FeatureMLPs.apply(x, sum_features, return_total, p.L, p.H, p.C, p.F,
+    return _FeatureMLPs.apply(x, sum_features, return_total, out_dtype, p.L, p.H, p.C, p.F,
                               p.w_first, p.b_first, p.w_mid, p.b_mid, p.w_last, p.b_last)
 
 
@@ -268,7 +275,8 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         n_rows=out.shape[0], n_cols=g.n_cols,
         rowptr=_lib.ptr(g.rowptr), rowptr_is64=int(g.rowptr is not None and g.rowptr.dtype == torch.int64),
         col=_lib.ptr(g.col), code=_lib.ptr(g.code), row_ids=_lib.ptr(row_ids),
-        S=_lib.ptr(S), s_dtype=_lib.GNAN_F32, W=S.shape[1], s_stride=S.stride(0),
+        S=_lib.ptr(S), s_dtype=_lib.GNAN_BF16 if S.dtype == torch.bfloat16 else _lib.GNAN_F32, W=S.shape[1],
+        s_stride=S.stride(0),
         lut=_lib.ptr(lut), lut_row_stride=(D * Cw if per_row_lut else 0), D=D, Cw=Cw,
         cnt=_lib.ptr(g.cnt) if use_cnt else None, cnt_stride=g.cnt.stride(0),
         s_total=_lib.ptr(s_total), weight_by_col=int(weight_by_col), minus_rest=int(minus_rest),
@@ -285,15 +293,19 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
 def column_sums(S: torch.Tensor) -> torch.Tensor:
     """``total[w] = sum_j S[j, w]`` (``gnan_colsum``): the rest-bucket operand of the aggregation."""
     _lib.require_device(S)
-    S = S.detach().float()
+    S = S.detach()
+    bf16 = S.dtype == torch.bfloat16
+    if not bf16:
+        S = S.float()
     if S.stride(1) != 1:
         S = S.contiguous()
     n, W = S.shape
     total = torch.empty(W, dtype=torch.float32, device=S.device)
     need = _lib.lib().gnan_colsum_workspace_bytes(W)
     ws = torch.empty(need // 8, dtype=torch.float64, device=S.device)
-    _lib.check(_lib.lib().gnan_colsum(_lib.ptr(S), n, W, S.stride(0), _lib.ptr(total), _lib.ptr(ws), need,
-                                      _lib.stream_of(S)), "gnan_colsum")
+    fn = _lib.lib().gnan_colsum_bf16 if bf16 else _lib.lib().gnan_colsum
+    _lib.check(fn(_lib.ptr(S), n, W, S.stride(0), _lib.ptr(total), _lib.ptr(ws), need, _lib.stream_of(S)),
+               "gnan_colsum")
     return total
 
 
@@ -307,7 +319,9 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``.
     ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns."""
     _lib.require_device(S, lut, g.code)
-    S = S.detach().float()
+    S = S.detach()
+    if S.dtype != torch.bfloat16:                        # bf16 rows: storage format only, accumulation stays fp32
+        S = S.float()
     if S.stride(1) != 1:
         S = S.contiguous()
     lut = lut.detach().float().contiguous()
@@ -425,6 +439,8 @@ def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
     """
     if with_rest is None:
         with_rest = not g.is_dense
+    if S.dtype == torch.bfloat16 and (S.requires_grad or (torch.is_grad_enabled() and lut.requires_grad)):
+        raise _lib.GnanHipError("bf16 operand storage is an inference format: run under torch.no_grad()")
     if row_ids is not None:
         row_ids = row_ids.to(device=g.device, dtype=torch.int32).contiguous()
     if reduce_channels and reduce_channels not in FUSABLE_READOUT:

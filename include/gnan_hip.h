@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 10
+#define GNAN_ABI_VERSION 11
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -109,8 +109,10 @@ typedef struct gnan_fpwl_args {
   int32_t features_per_group;
   int32_t max_group_pieces;
   int32_t sum_features;    /* as gnan_fmlp_args */
-  float* out;
-  int64_t out_stride;
+  void* out;
+  int64_t out_stride;      /* in elements */
+  int32_t out_dtype;       /* gnan_dtype of `out`: GNAN_BF16 stores bf16 rows (per-feature mode, C == 1, whole groups) —
+                              the operand format of the bf16-storage aggregation; `total` then sums the rounded values */
   float* total;            /* optional [F]: column sums of the per-feature output (the aggregation's s_total),
                               produced in the same pass; needs C == 1, whole groups, 16-B aligned rows */
   void* total_workspace;   /* gnan_fpwl_total_workspace_bytes() */
@@ -246,6 +248,9 @@ int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream);
 size_t gnan_colsum_workspace_bytes(int32_t W);
 int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                 size_t workspace_bytes, gnan_stream_t stream);
+/* same for bf16 operand rows (stride in elements, W % 4 == 0, 8-B aligned rows) */
+int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
+                     size_t workspace_bytes, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense inputs -> hop codes + shell counts

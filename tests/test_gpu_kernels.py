@@ -394,3 +394,45 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     monkeypatch.setattr(functional, "DEGREE_SCHEDULE_MIN_WIDTH", 1 << 30)
     assert torch.equal(y_sched, spmm_launch(g, S, lut, True, True))
     assert torch.equal(r_sched, spmm_launch(g, S, lut, True, True, reduce_cr=1))
+
+
+@pytest.mark.parametrize("W,reduce_cr", [(64, 1), (64, 0), (8, 1), (16, 0), (128, 4)])
+def test_bf16_operand_storage(W, reduce_cr):
+    """bf16 rows, fp32 accumulate: exact w.r.t. the oracle evaluated on the bf16-rounded operand."""
+    from gnan_amd.functional import column_sums, spmm_launch
+    rng = np.random.default_rng(W + reduce_cr)
+    n, K = 3000, 1
+    D = K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 900), (1500, 2600)])
+    cnt = _cnt_np(rowptr, code, n, D)
+    g = _graph(rowptr, col, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32))
+    S16 = S.to(torch.bfloat16)
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32))
+    truth = O.spmm_csr(rowptr, col, code, S16.double(), O.weight_table(lut.double(), cnt).expand(n, -1, -1))
+    if reduce_cr:
+        truth = truth.view(n, W // reduce_cr, reduce_cr).sum(1)
+    tot = column_sums(S16.to(DEV))
+    assert float((tot.cpu().double() - S16.double().sum(0)).abs().max()) <= 1e-5 * float(S16.double().abs().sum(0).max())
+    y = spmm_launch(g, S16.to(DEV), lut.to(DEV), True, True, reduce_cr=reduce_cr).cpu()
+    assert y.shape == truth.shape
+    assert O.rel_err(y, truth) <= 1e-5, O.rel_err(y, truth)
+
+
+def test_bf16_rows_from_the_table_lookup(monkeypatch):
+    """feature_mlps(out_dtype=bf16): the stored rows are the correctly rounded fp32 results and the fused totals
+    describe the rounded operand."""
+    from gnan_amd.functional import feature_mlps
+    F, L, H, C = 32, 3, 16, 1
+    sd = _mlp_state(F, L, H, C, True, seed=1)
+    st = _stack(sd, F, L, H, C, True)
+    x = torch.rand(40_000, F, device=DEV) * 2 - 1
+    with torch.no_grad():
+        y32 = feature_mlps(x, st, False, out_dtype=torch.float32)
+        y16, tot = feature_mlps(x, st, False, return_total=True, out_dtype=torch.bfloat16)
+    assert y16.dtype == torch.bfloat16
+    exact = (y16.float() == y32.to(torch.bfloat16).float()).float().mean()
+    assert float(exact) >= 0.999                       # fp32 inputs of the rounding differ in the last ulp at most
+    assert float((y16.float() - y32).abs().max()) <= 2 ** -7 * float(y32.abs().max())
+    want = y16.double().sum(0)
+    assert float((tot.double() - want).abs().max()) <= 1e-5 * float(y16.double().abs().sum(0).max())
