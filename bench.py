@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature"],
                     help="multi-GPU decomposition: vertex blocks + all-gather of the operand, or feature columns + "
                          "all-reduce of the [N, C] partial outputs; auto = fewer bytes over xGMI")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL on ROCm); gloo + --same-device is a dry run of the "
+                         "multi-rank code path on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="development aid: every rank uses cuda:0")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on a 1-GPU box: run rank 0's share of a P-rank job WITHOUT the collectives "
                          "(stage times only; the printed value is not a result)")
@@ -130,10 +134,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
