@@ -88,10 +88,10 @@ def cpu_baseline(args, model, g, x, operand_full):
     rates = {}
     for th in sorted({ncpu, min(ncpu, 64), min(ncpu, 16)}):
         torch.set_num_threads(th)
-        O.feature_mlps(x_host[:2000], sd)                          # warm-up (MKL thread pool, allocator)
+        O.feature_mlps(x_host[:256], sd)                           # warm-up (MKL thread pool, allocator)
         t0 = time.perf_counter()
-        O.feature_mlps(x_host[:10000], sd)
-        rates[th] = 10000 / (time.perf_counter() - t0)
+        O.feature_mlps(x_host[:1500], sd)
+        rates[th] = 1500 / (time.perf_counter() - t0)
     th_f = max(rates, key=rates.get)
     torch.set_num_threads(th_f)
     n_f = int(min(x_host.shape[0], max(10000, rates[th_f] * 10)))
