@@ -81,9 +81,20 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
   const int q = tid % TPN;            // which feature quad of the group
   const int nl = tid / TPN;           // node slot inside a pass
   const int C = p.C;
-  const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
+  // Per-feature mode: the n_groups workgroups that share a node block read different 64-B sectors of the same x rows.
+  // Linear workgroup ids go round-robin over the 8 XCDs, so (id % 8) picks the XCD and, inside it, the groups of one
+  // node block are adjacent in time: the rows' 128-B lines are fetched into that XCD's L2 once.
+  int64_t nb = blockIdx.x;
+  int g_first = 0;
+  if (!SUM) {
+    const int64_t id = blockIdx.x;
+    g_first = static_cast<int>((id >> 3) % p.n_groups);
+    nb = ((id >> 3) / p.n_groups) * 8 + (id & 7);
+  }
+  const int64_t n_lo = nb * p.nodes_per_block;
+  if (n_lo >= p.n) return;
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
-  const int g_lo = SUM ? 0 : blockIdx.y;
+  const int g_lo = SUM ? 0 : g_first;
   const int g_hi = SUM ? p.n_groups : g_lo + 1;
   float* acc_l = smem + p.acc_offset;
   if (SUM && p.acc_offset) {
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void fpwl_kernel(const Params p) {
           const int qq = tid / FPT, ff = tid % FPT;
           double acc = 0.0;
           for (int s2 = 0; s2 < NODES; ++s2) acc += red[(s2 * TPN + qq) * FPT + ff];
-          p.col_partial[static_cast<int64_t>(blockIdx.x) * p.F + k0 + tid] = acc;
+          p.col_partial[nb * p.F + k0 + tid] = acc;
         }
       }
     }
@@ -316,8 +327,9 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
     }
   }
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
-  if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
-  const dim3 grid(static_cast<unsigned>(bx), p.sum_features ? 1u : static_cast<unsigned>(p.n_groups));
+  const int64_t wgs = p.sum_features ? bx : (bx + 7) / 8 * 8 * p.n_groups;     // see the id -> (node block, group) map
+  if (wgs > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
+  const dim3 grid(static_cast<unsigned>(wgs));
   if (p.acc_offset) lds += static_cast<size_t>(p.C) * Map<FG>::NODES * sizeof(float);
   // FAST: one output channel, whole groups only, 16-B aligned x (and fx) rows
   const bool fast = FG % 4 == 0 && p.C == 1 && p.F % FG == 0 && p.vec_x && (p.sum_features || p.vec_out);
