@@ -97,6 +97,40 @@ __device__ __forceinline__ Vec<VEC> load_operand(const void* S, int64_t row, int
   }
 }
 
+// A gathered operand chunk as it sits in registers while the load is in flight: bf16 rows stay packed (4 VGPRs for
+// 8 values) until they are consumed, so the in-flight window of the bf16 mode costs no more registers than fp32.
+template <int VEC>
+struct Raw {
+  Vec<VEC> f;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f.v[v] = 0.f;
+  }
+  __device__ __forceinline__ void load(const void* S, int64_t row, int64_t stride, int col) {
+    f = load_vec<VEC>(static_cast<const float*>(S) + row * stride + col);
+  }
+  __device__ __forceinline__ Vec<VEC> widen() const { return f; }
+};
+
+template <>
+struct Raw<8> {
+  uint4 t;
+  __device__ __forceinline__ void zero() { t = make_uint4(0u, 0u, 0u, 0u); }
+  __device__ __forceinline__ void load(const void* S, int64_t row, int64_t stride, int col) {
+    t = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(S) + row * stride + col);
+  }
+  __device__ __forceinline__ Vec<8> widen() const {
+    Vec<8> r;
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r.v[2 * i] = __uint_as_float(w[i] << 16);
+      r.v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+    return r;
+  }
+};
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* ptr, const Vec<VEC>& r) {
   if constexpr (VEC == 8) {
@@ -204,8 +238,18 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
     if (hi - lo > p.long_threshold) return;  // hub row: long kernel
   }
   const int rest = p.D - 1;
+  // SMALLD folds the rest bucket into the listed weights:  sum_d w_d s + w_rest (total - sum s)
+  //   = sum_d (w_d - w_rest) s + w_rest total,  so no second accumulator for the listed operand rows is needed.
   SmallW sw;
-  if constexpr (SMALLD) sw = small_weights(p, i);
+  float w_rest = 0.f;
+  if constexpr (SMALLD) {
+    sw = small_weights(p, i);
+    if (p.s_total) {
+      w_rest = sw.pick(rest);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) sw.w[d] = d < rest ? sw.w[d] - w_rest : 0.f;
+    }
+  }
   float red[4] = {0.f, 0.f, 0.f, 0.f};  // fused feature sum (reduce_cr in {1, 2, 4}): channel partials of this lane
 
   for (int w0 = 0; w0 < p.W; w0 += TILE) {
@@ -238,7 +282,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 #pragma unroll(IPL > 1 ? IW / UNROLL : 1)
       for (int j0 = 0; j0 < (IPL > 1 ? IW : m); j0 += UNROLL) {
         if (IPL > 1 && j0 >= m) break;
-        Vec<VEC> s[UNROLL];
+        Raw<VEC> s[UNROLL];
         int d[UNROLL], c[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -250,41 +294,40 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           }
           d[u] = __shfl(codev[j % IPL], j / IPL, LPR);
           d[u] = d[u] < rest ? d[u] : rest;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) s[u].v[v] = 0.f;
-          if (j < m && col_ok) s[u] = load_operand<VEC>(p.S, c[u], p.s_stride, cw);
+          s[u].zero();
+          if (j < m && col_ok) s[u].load(p.S, c[u], p.s_stride, cw);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           if (j0 + u < m) {
+            const Vec<VEC> sv = s[u].widen();
             if constexpr (SMALLD) {
               const float w = sw.pick(d[u]);
 #pragma unroll
-              for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w, s[u].v[v], acc.v[v]);
+              for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w, sv.v[v], acc.v[v]);
             } else {
               const Vec<VEC> w = edge_weights<VEC>(p, i, c[u], d[u], cw);
 #pragma unroll
-              for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w.v[v], s[u].v[v], acc.v[v]);
+              for (int v = 0; v < VEC; ++v) {
+                acc.v[v] = fmaf(w.v[v], sv.v[v], acc.v[v]);
+                all.v[v] += sv.v[v];
+              }
             }
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) all.v[v] += s[u].v[v];
           }
         }
       }
     }
     if (col_ok) {
       if (p.s_total) {
-        Vec<VEC> wr;
-        if constexpr (SMALLD) {
-          const float w = sw.pick(rest);
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) wr.v[v] = w;
-        } else {
-          wr = row_weights<VEC>(p, i, rest, cw);
-        }
         const Vec<VEC> tot = load_vec<VEC>(p.s_total + cw);
+        if constexpr (SMALLD) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(wr.v[v], tot.v[v] - all.v[v], acc.v[v]);
+          for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w_rest, tot.v[v], acc.v[v]);
+        } else {
+          const Vec<VEC> wr = row_weights<VEC>(p, i, rest, cw);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(wr.v[v], tot.v[v] - all.v[v], acc.v[v]);
+        }
       }
       if (p.reduce_cr == 0) {
         store_vec<VEC>(p.Y + (p.scatter_out ? i : q) * p.y_stride + cw, acc);
