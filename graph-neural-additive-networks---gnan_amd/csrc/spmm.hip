@@ -456,7 +456,8 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
 // One launch covers everything: workgroups [0, n_slices) take the hub-row slices (they start first,
 // so the long-latency slices overlap the bulk), the rest take 4*G ordinary rows each.
 template <int VEC, int LPR, bool DENSE, bool SMALLD, int TUNE = 0>
-__global__ __launch_bounds__(256) void spmm_kernel(const Params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SMALLD && LPR >= 8) ? 8 : 1)))
+void spmm_kernel(const Params p) {
   if constexpr (!DENSE) {
     if (static_cast<int>(blockIdx.x) < p.n_slices) {
       slice_body<VEC, LPR, SMALLD>(p, static_cast<int>(blockIdx.x));
