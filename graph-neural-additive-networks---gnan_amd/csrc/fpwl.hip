@@ -246,9 +246,9 @@ struct MomentParams {
   float* M;            // [T, 2, C], zeroed by the caller
 };
 
-template <int FG>
-__global__ __launch_bounds__(256) void fpwl_moments_kernel(const MomentParams mp) {
-  constexpr int FPT = Map<FG>::FPT, TPN = Map<FG>::TPN, NODES = Map<FG>::NODES;
+template <int FG, int BS>
+__global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp) {
+  constexpr int FPT = Map<FG, BS>::FPT, TPN = Map<FG, BS>::TPN, NODES = Map<FG, BS>::NODES;
   const Params& p = mp.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_off[FG + 1];
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void fpwl_moments_kernel(const MomentParams mp
   const int tot = p.off[k0 + nf] - base;
   float* anchor_l = smem;
   float* bins = smem + tot;                        // [tot][2][C]
-  for (int i = tid; i < tot; i += 256) anchor_l[i] = p.anchor[base + i];
-  for (int i = tid; i < tot * 2 * C; i += 256) bins[i] = 0.f;
+  for (int i = tid; i < tot; i += BS) anchor_l[i] = p.anchor[base + i];
+  for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = 0.f;
   if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
   __syncthreads();
   int po[FPT], pn[FPT];
@@ -299,24 +299,24 @@ __global__ __launch_bounds__(256) void fpwl_moments_kernel(const MomentParams mp
   }
   __syncthreads();
   float* out = mp.M + static_cast<int64_t>(base) * 2 * C;
-  for (int i = tid; i < tot * 2 * C; i += 256) {
+  for (int i = tid; i < tot * 2 * C; i += BS) {
     const float v = bins[i];
     if (v != 0.f) atomicAdd(out + i, v);
   }
 }
 
-template <int FG>
+template <int FG, int BS>
 int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fpwl_moments_kernel<FG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fpwl_moments_kernel<FG, BS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const Params& p = mp.f;
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
   if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
-  hipLaunchKernelGGL(fpwl_moments_kernel<FG>, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(p.n_groups)),
-                     dim3(256), lds, st, mp);
+  hipLaunchKernelGGL((fpwl_moments_kernel<FG, BS>), dim3(static_cast<unsigned>(bx), static_cast<unsigned>(p.n_groups)),
+                     dim3(BS), lds, st, mp);
   return gnan::check_launch("fpwl_moments_kernel");
 }
 
@@ -421,11 +421,11 @@ extern "C" int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int
   const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a->features_per_group) {
-    case 1: return launch_moments<1>(mp, lds, st);
-    case 2: return launch_moments<2>(mp, lds, st);
-    case 4: return launch_moments<4>(mp, lds, st);
-    case 8: return launch_moments<8>(mp, lds, st);
-    default: return launch_moments<16>(mp, lds, st);
+    case 1: return launch_moments<1, 256>(mp, lds, st);
+    case 2: return launch_moments<2, 256>(mp, lds, st);
+    case 4: return launch_moments<4, 256>(mp, lds, st);
+    case 8: return launch_moments<8, 512>(mp, lds, st);
+    default: return launch_moments<16, 512>(mp, lds, st);
   }
 }
 
