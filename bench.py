@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--operand", default="f32", choices=["f32", "bf16"],
                     help="storage format of the aggregated operand rows (bf16: storage only, fp32 accumulation; the "
                          "papers100M-shaped configuration of BASELINE.json; not comparable with the fp32 reference at 1e-5)")
-    ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature"],
+    ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature", "halo"],
                     help="multi-GPU decomposition: vertex blocks + all-gather of the operand, or feature columns + "
                          "all-reduce of the [N, C] partial outputs; auto = fewer bytes over xGMI")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -146,8 +146,9 @@ def main():
 
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
-    from gnan_amd.distributed import (FeaturePartition, VertexPartition, choose_partition,
-                                      feature_parallel_forward, partitioned_forward, slice_features)
+    from gnan_amd.distributed import (FeaturePartition, VertexPartition, build_halo_plan, choose_partition,
+                                      feature_parallel_forward, halo_recompute_forward, partitioned_forward,
+                                      slice_features)
     from gnan_amd import _lib, functional
     from gnan_amd.functional import stack_mlps
     from gnan_amd.graph import hop_inputs
@@ -169,7 +170,12 @@ def main():
         fpart.__class__ = type("EmuF", (FeaturePartition,), {"block": property(lambda self: -(-F // pworld))})
     t_setup = time.perf_counter()
     src, dst = syn.rmat_edges(args.scale, N, E, seed=0, device=dev)
-    if partition == "vertex":
+    plan = None
+    if partition == "halo":                      # owned rows; x rows of the owned nodes AND of the remote nodes they list
+        plan = build_halo_plan(syn.hop1_csr(src, dst, N, part.lo, part.hi), part)
+        g = plan.graph
+        x = syn.block_features(N, F, 0, N, seed=1, device=dev)[plan.node_ids()].contiguous()
+    elif partition == "vertex":
         g = syn.hop1_csr(src, dst, N, part.lo, part.hi)
         x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
     else:                                        # whole graph, this rank's feature columns
@@ -207,7 +213,10 @@ def main():
         else:
             mark = None
         with torch.no_grad():
-            if partition == "vertex":
+            if partition == "halo":
+                out = halo_recompute_forward(x, plan, stacked, lut, True, order=args.order, out_channels=C,
+                                             marks=mark, operand_dtype=op_dtype)
+            elif partition == "vertex":
                 out = partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
                                           marks=mark, operand_dtype=op_dtype)
             else:
@@ -270,7 +279,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "nodes": N, "edges": E, "stored_pairs_rank0": g.nnz,
                        "operand_width": W, "partition": f"{partition} x{world}", "exchange":
-                       "none" if world == 1 else ("all_gather(operand [N,W])" if partition == "vertex"
+                       "none" if world == 1 else ("all_reduce(column sums [W])" if partition == "halo" else
+                                                  "all_gather(operand [N,W])" if partition == "vertex"
                                                   else "all_reduce(out [N,C])")},
             "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -280,8 +290,8 @@ def main():
             "fmlp_effective_tflops": fmlp_flops(x.shape[0], x.shape[1], H, L, C) / (stages["fmlp"] / 1e3) / 1e12
             if stages["fmlp"] > 0 else None,
             "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "fmlp_algo": args.fmlp_algo,
-            "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": float(out.double().sum()) if partition == "vertex" or world == 1 else
-            float(out.double().sum()),
+            "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": float(out.double().sum()),
+            "operand_rows_rank0": int(x.shape[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():

@@ -18,6 +18,8 @@ namespace {
 
 constexpr int kCap = 1024;        // breakpoints per feature this kernel can hold
 constexpr int kNodeChunk = 32;    // table nodes evaluated per pass
+constexpr int kBT = 1024;         // threads of the build workgroup: one workgroup per feature means one wave per SIMD at
+                                  // 256 threads, and every LDS round trip of the dot products is exposed; 16 waves hide it
 
 struct BuildParams {
   const float* w_first;  // [F, H]
@@ -40,7 +42,7 @@ struct BuildParams {
 __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
   for (int k = 2; k <= n_pow2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n_pow2; i += 256) {
+      for (int i = tid; i < n_pow2; i += kBT) {
         const int l = i ^ j;
         if (l > i) {
           const double x = a[i], y = a[l];
@@ -57,14 +59,15 @@ __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
 // holding consecutive units read consecutive banks (row-major would be a 32-way bank conflict on every read).
 __device__ __forceinline__ double z2(const float* w1, const float* b1, const float* W2t_col, float b2, int H, double x) {
   double z = b2;
-  for (int k = 0; k < H; ++k) {
+#pragma unroll 8
+  for (int k = 0; k < H; ++k) {     // unrolled: the LDS reads of 8 terms are in flight together, the fma chain stays in order
     const double h = fma(static_cast<double>(w1[k]), x, static_cast<double>(b1[k]));
     z = fma(static_cast<double>(W2t_col[k * H]), h > 0.0 ? h : 0.0, z);
   }
   return z;
 }
 
-__global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
+__global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* bp = reinterpret_cast<double*>(smem_raw);        // [kCap]
   double* cand = bp + kCap;                                 // [kCap]
@@ -79,20 +82,20 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
   const int H = p.H, C = p.C;
   const double INF = INFINITY;
 
-  for (int i = tid; i < H; i += 256) {
+  for (int i = tid; i < H; i += kBT) {
     w1[i] = p.w_first[k * H + i];
     b1[i] = p.b_first ? p.b_first[k * H + i] : 0.f;
     b2[i] = (p.L == 3 && p.b_mid) ? p.b_mid[k * H + i] : 0.f;
   }
   if (p.L == 3)
-    for (int i = tid; i < H * H; i += 256)       // coalesced read of W[j][kk], transposed write
+    for (int i = tid; i < H * H; i += kBT)       // coalesced read of W[j][kk], transposed write
       W2[(i % H) * H + i / H] = p.w_mid[static_cast<int64_t>(k) * H * H + i];
-  for (int i = tid; i < kCap; i += 256) bp[i] = INF;
+  for (int i = tid; i < kCap; i += kBT) bp[i] = INF;
   if (tid == 0) { n_cand = 0; over = 0; }
   __syncthreads();
 
   // ---- 1. first-layer kinks -------------------------------------------------------------------
-  for (int j = tid; j < H; j += 256) {
+  for (int j = tid; j < H; j += kBT) {
     const double t = w1[j] != 0.f ? -static_cast<double>(b1[j]) / static_cast<double>(w1[j]) : INF;
     bp[j] = isfinite(t) ? t : INF;
   }
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
       return i == P + 2 ? t_last + 1.0 : t_last + 2.0;
     };
     // thread = (unit j, segment s): walks its share of the node sequence, one node of overlap
-    const int segs = 256 / H > 0 ? 256 / H : 1;
-    for (int j = tid / segs; j < H; j += 256 / segs) {
+    const int segs = kBT / H > 0 ? kBT / H : 1;
+    for (int j = tid / segs; j < H; j += kBT / segs) {
       const int s = tid % segs;
       const int per = (n_nodes - 1 + segs - 1) / segs;     // intervals per segment
       const int i0 = s * per, i1 = i0 + per < n_nodes - 1 ? i0 + per : n_nodes - 1;
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
     const int nc = n_cand < kCap ? n_cand : kCap;
     if (P + nc > p.cap) { if (tid == 0) over = 1; }
     const int total = P + nc < kCap ? P + nc : kCap;
-    for (int i = tid; i < nc; i += 256)
+    for (int i = tid; i < nc; i += kBT)
       if (P + i < kCap) bp[P + i] = cand[i];
     __syncthreads();
     pow2 = 1;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
 
   // ---- 3. table: float32 anchors, float64 network values ----------------------------------------------
   const int P = n_bp;
-  for (int i = tid; i < P; i += 256) {
+  for (int i = tid; i < P; i += kBT) {
     double t = bp[i];
     t = t > 3.0e38 ? 3.0e38 : (t < -3.0e38 ? -3.0e38 : t);
     bp[i] = static_cast<double>(static_cast<float>(t));
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
   // layer in LDS, then (node, channel) pairs take the output dot products
   for (int n0 = 0; n0 < Pn + 2; n0 += kNodeChunk) {
     const int nn = Pn + 2 - n0 < kNodeChunk ? Pn + 2 - n0 : kNodeChunk;
-    for (int it = tid; it < nn * H; it += 256) {
+    for (int it = tid; it < nn * H; it += kBT) {
       const int ni = it / H, j = it % H;
       const double x = tnode(n0 + ni);
       double h = p.L == 3 ? z2(w1, b1, W2 + j, b2[j], H, x)
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
       hid[ni * H + j] = h > 0.0 ? h : 0.0;
     }
     __syncthreads();
-    for (int it = tid; it < nn * C; it += 256) {
+    for (int it = tid; it < nn * C; it += kBT) {
       const int ni = it / C, c = it % C;
       double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
       for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void pwl_build_kernel(const BuildParams p) {
   float* A = p.anchor + static_cast<int64_t>(k) * (p.cap + 1);
   float* VL = p.val + static_cast<int64_t>(k) * (p.cap + 1) * C;
   float* SL = p.slope + static_cast<int64_t>(k) * (p.cap + 1) * C;
-  for (int i = tid; i < pieces; i += 256) {
+  for (int i = tid; i < pieces; i += kBT) {
     // piece i lies between table nodes i and i+1; it is anchored at its left kink, piece 0 at the first kink
     const int an = i == 0 ? 1 : i;
     A[i] = static_cast<float>(tnode(an));
@@ -323,7 +326,7 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
     if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "pwl_build: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(pwl_build_kernel, dim3(a->F), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(pwl_build_kernel, dim3(a->F), dim3(kBT), lds, st, p);
   if (int rc = gnan::check_launch("pwl_build_kernel")) return rc;
   CompactParams c;
   c.anchor_p = p.anchor; c.val_p = p.val; c.slope_p = p.slope; c.pieces = p.pieces;

@@ -18,6 +18,15 @@ slice of ``fx`` from its columns of ``x`` (no operand exchange at all), aggregat
 with the feature sum fused, and the ranks add their ``[N, C]`` partial outputs with one all-reduce.
 xGMI is point-to-point (7 links per GPU): an all-gather of ``N*F*C`` floats is link-bound and costs more than
 all the compute it feeds, while the all-reduce moves ``N*C`` floats — :func:`choose_partition` picks by bytes.
+
+Halo recompute (what the bench uses for the reference order on more than one GPU): ``x`` is an input that does not
+change between forwards, so rank ``p`` keeps, next to its own rows, a copy of the ``x`` rows of every remote node one
+of its rows lists (its halo, found once per graph) and evaluates the shape functions for them itself.  Nothing of
+size ``N`` crosses xGMI any more — the only collective is an all-reduce of the ``W`` column sums for the rest bucket
+— at the price of ``n_halo * F`` redundant table look-ups per rank (1.4 ms per 10M x 64 on an MI355X, against
+2-4 ms for the 320 MB shard every link would have to carry in the all-gather) and of HBM capacity, which is what a
+288 GB device has to spare.  Backward needs no exchange either: the loss of the owned rows depends on the
+parameters through locally computed values only, so the ranks just add their parameter gradients.
 """
 from __future__ import annotations
 
@@ -129,10 +138,17 @@ def slice_features(stacked, lo: int, hi: int):
                          stacked.L, stacked.H, stacked.C, hi - lo)
 
 
-def choose_partition(n_nodes: int, n_features: int, out_channels: int, world: int, order: str) -> str:
-    """'vertex' or 'feature', by the bytes each rank receives over xGMI per forward."""
+def choose_partition(n_nodes: int, n_features: int, out_channels: int, world: int, order: str,
+                     replicated_inputs: bool = True) -> str:
+    """'vertex', 'feature' or 'halo', by the bytes each rank receives over xGMI per forward.
+
+    Sum-first exchanges the narrow ``[N, C]`` operand: vertex partition with one all-gather.  The reference order
+    (``[N, F*C]`` operand) exchanges nothing if every rank may hold the ``x`` rows of its halo (halo recompute);
+    if the inputs must stay sharded it is the feature partition unless the operand is narrower than two outputs."""
     if world == 1 or order == "sum_first":
         return "vertex"
+    if replicated_inputs:
+        return "halo"
     gather_bytes = n_nodes * n_features * out_channels * 4 * (world - 1) / world
     allreduce_bytes = 2 * n_nodes * out_channels * 4 * (world - 1) / world
     return "feature" if allreduce_bytes < gather_bytes else "vertex"
@@ -167,4 +183,72 @@ def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lu
     if part.world > 1:
         dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=group)
     mark("reduce")
+    return Y
+
+
+# =============================================================================
+# halo recompute: vertex partition without an operand exchange
+# =============================================================================
+@dataclass
+class HaloPlan:
+    """Static per graph and rank: which operand rows the owned rows read and where they sit in the compact operand."""
+    part: VertexPartition
+    n_own: int
+    halo: torch.Tensor            # int64 [n_halo]: global ids of the remote nodes listed by owned rows, ascending
+    graph: object                 # HopGraph of the owned rows; column ids index the compact operand
+                                  # (own node i -> i - lo, halo node -> n_own + its position in ``halo``)
+
+    @property
+    def n_needed(self) -> int:
+        return self.n_own + int(self.halo.numel())
+
+    def node_ids(self) -> torch.Tensor:
+        """Global node id of every compact operand row (``x_compact = x[node_ids()]``)."""
+        own = torch.arange(self.part.lo, self.part.hi, device=self.halo.device)
+        return torch.cat([own, self.halo])
+
+
+def build_halo_plan(graph_local, part: VertexPartition) -> HaloPlan:
+    """``graph_local``: hop-coded CSR of the owned rows with GLOBAL column ids (e.g. ``synthetic.hop1_csr(..., lo, hi)``).
+    Index work only (bit-exact, runs wherever the tensors live); the shell counts keep referring to the whole graph."""
+    from .graph import HopGraph
+    lo, hi = part.lo, part.hi
+    n_own = hi - lo
+    col = graph_local.col.long()
+    own = (col >= lo) & (col < hi)
+    halo = torch.unique(col[~own])                                   # sorted
+    pos = torch.searchsorted(halo, col) if halo.numel() else torch.zeros_like(col)
+    compact = torch.where(own, col - lo, n_own + pos)
+    g = HopGraph.from_csr(graph_local.rowptr, compact.to(torch.int32), graph_local.code,
+                          n_cols=n_own + int(halo.numel()), n_codes=graph_local.n_codes, cnt=graph_local.cnt)
+    return HaloPlan(part, n_own, halo, g)
+
+
+def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut: torch.Tensor, use_cnt: bool,
+                           order: str = "reference", out_channels: int = 1, group=None,
+                           compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
+                           operand_dtype=torch.float32):
+    """Forward on the owned rows from ``x_compact = x[plan.node_ids()]``; returns ``out[lo:hi, :out_channels]``.
+    Same stages and ``marks`` as :func:`partitioned_forward`; the "gather" stage is empty by construction."""
+    ops = compute or _hip_compute()
+    mark = marks or (lambda name: None)
+    part = plan.part
+    mark("start")
+    kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
+    sum_first = order == "sum_first"
+    if plan.halo.numel() == 0:                    # nothing remote: the column sums ride in the shape-function pass
+        operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, **kw)
+    else:
+        operand = ops["feature_mlps"](x_compact, stacked, sum_first, **kw)
+        total = None
+    mark("fmlp")
+    mark("gather")
+    if total is None:
+        total = ops["column_sums"](operand[: plan.n_own])          # owned rows partition the nodes: no double counting
+    if part.world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    mark("total")
+    Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total,
+                         reduce_channels=out_channels if order == "reference" else 0)
+    mark("spmm")
     return Y

@@ -125,11 +125,62 @@ def test_feature_parallel_forward_equals_single_process(world, F, tmp_path):
         assert O.rel_err(torch.from_numpy(got), want.double()) <= 1e-5
 
 
+def _halo_compute(sd, C):
+    base = _oracle_compute(sd, C)
+
+    def aggregate(g, S, lut, use_cnt, s_total=None, reduce_channels=0):
+        rowptr, col, code = g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy()
+        wt = O.weight_table(lut, g.cnt.long().numpy() if use_cnt else None).expand(g.n_rows, -1, -1)
+        # the oracle forms the rest bucket from the operand it is given; the compact operand is not the whole graph
+        Y = O.spmm_csr(rowptr, col, code, S, wt) + wt[:, -1] * (s_total - S.sum(0)).unsqueeze(0)
+        return Y.view(Y.shape[0], -1, reduce_channels).sum(1) if reduce_channels else Y
+    return {**base, "aggregate": aggregate}
+
+
+def _halo_worker(rank, world, port, n, F, C, order, out_dir):
+    from gnan_amd.distributed import build_halo_plan, halo_recompute_forward
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src, dst, x, sd = _problem(n, F, C)
+        part = VertexPartition(n, world, rank)
+        g = syn.hop1_csr(src, dst, n, part.lo, part.hi)
+        plan = build_halo_plan(g, part)
+        ids = plan.node_ids()
+        # index work is bit-exact: compact ids point at the same global nodes, own rows first, halo ascending
+        assert torch.equal(ids[plan.graph.col.long()], g.col.long())
+        assert torch.equal(ids[: plan.n_own], torch.arange(part.lo, part.hi))
+        halo = ids[plan.n_own:]
+        assert bool((halo[1:] > halo[:-1]).all()) and not bool(((halo >= part.lo) & (halo < part.hi)).any())
+        assert set(halo.tolist()) == set(g.col.long().tolist()) - set(range(part.lo, part.hi))
+        y = halo_recompute_forward(x[ids], plan, stack(sd, F, 3, 8, C, True), O.rho_lut(sd, 3), True, order=order,
+                                   out_channels=C, compute=_halo_compute(sd, C))
+        np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,order", [(2, 300, "reference"), (3, 301, "reference"), (2, 300, "sum_first")])
+def test_halo_recompute_forward_equals_single_process(world, n, order, tmp_path):
+    F, C = 5, 1
+    port = _free_port()
+    mp.spawn(_halo_worker, args=(world, port, n, F, C, order, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    src, dst, x, sd = _problem(n, F, C)
+    g = syn.hop1_csr(src, dst, n)
+    S = O.feature_mlps(x, sd).sum(1)
+    wt = O.weight_table(O.rho_lut(sd, 3), g.cnt.long().numpy()).expand(n, -1, -1)
+    want = O.spmm_csr(g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy(), S, wt)
+    assert got.shape == (n, C)
+    assert O.rel_err(torch.from_numpy(got), want.double()) <= 1e-5
+
+
 def test_choose_partition_by_exchanged_bytes():
     from gnan_amd.distributed import choose_partition
-    assert choose_partition(10_000_000, 64, 1, 8, "reference") == "feature"     # 2.2 GB gather vs 70 MB reduce
+    assert choose_partition(10_000_000, 64, 1, 8, "reference") == "halo"        # inputs replicated: no exchange
+    assert choose_partition(10_000_000, 64, 1, 8, "reference", replicated_inputs=False) == "feature"  # 2.2 GB vs 70 MB
     assert choose_partition(10_000_000, 64, 1, 8, "sum_first") == "vertex"      # narrow operand: gather it
-    assert choose_partition(10_000_000, 2, 1, 8, "reference") == "vertex"
+    assert choose_partition(10_000_000, 2, 1, 8, "reference", replicated_inputs=False) == "vertex"
     assert choose_partition(10_000_000, 64, 1, 1, "reference") == "vertex"
 
 
