@@ -245,6 +245,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
+    checksum = out.double().sum().reshape(1)
+    if world > 1 and partition != "feature":      # row-partitioned output: add the ranks' shares (feature: already whole)
+        dist.all_reduce(checksum, op=dist.ReduceOp.SUM)
+    checksum = float(checksum)
+
     stages = {n: 0.0 for n in stage_names}
     for m in events:
         prev = m["start"]
@@ -290,7 +295,7 @@ def main():
             "fmlp_effective_tflops": fmlp_flops(x.shape[0], x.shape[1], H, L, C) / (stages["fmlp"] / 1e3) / 1e12
             if stages["fmlp"] > 0 else None,
             "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "fmlp_algo": args.fmlp_algo,
-            "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": float(out.double().sum()),
+            "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": checksum,
             "operand_rows_rank0": int(x.shape[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
