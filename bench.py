@@ -7,8 +7,11 @@ to 10M nodes / 100M edges (+ one self pair per node), K = 1 hop codes, 64 featur
 one output channel, evaluated in the reference's order (aggregate all 64 per-feature columns, then sum
 over features: models.py:373-376), fp32, synthetic data, random O(1) weights.
 
-A "step" is one full forward over the whole graph:  shape functions -> (all-gather) -> aggregation ->
-feature sum.  With N > 1 ranks the node range is vertex-partitioned (strong scaling: the graph is fixed).
+A "step" is one full forward over the whole graph:  table build -> shape functions -> aggregation -> feature sum.
+With N > 1 ranks the node range is vertex-partitioned (strong scaling: the graph is fixed) and, in the reference
+order, every rank also holds the x rows of its halo and evaluates their shape functions itself, so the only
+collective is an all-reduce of the 64 column sums (gnan_amd/distributed.py: halo recompute; --partition picks the
+all-gather or the feature-sharded variants instead).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
