@@ -17,7 +17,7 @@ size of the rest bucket), i.e. the distinct values of ``normalization_matrix`` r
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -129,22 +129,34 @@ class HopGraph:
                         rowptr=rowptr.contiguous(), col=col)
 
     @staticmethod
-    def from_edge_index(edge_index: torch.Tensor, num_nodes: int, max_hops: Optional[int] = None) -> "HopGraph":
+    def from_edge_index(edge_index: torch.Tensor, num_nodes: int, max_hops: Optional[int] = None,
+                        layout: str = "auto", rows: Optional[Tuple[int, int]] = None) -> "HopGraph":
         """Preprocessing on the GPU: hop codes and shell counts straight from ``edge_index``.
 
-        * ``max_hops is None`` or ``>= 2``: all-pairs BFS (``gnan_bfs_dense``) -> dense layout, what
-          ``pre_process`` (pre_process_datasets.py:104-142) encodes in its two N x N matrices; needs N^2 bytes.
+        * ``max_hops is None``: all-pairs BFS (``gnan_bfs_dense``) -> dense layout, what ``pre_process``
+          (pre_process_datasets.py:104-142) encodes in its two N x N matrices; needs N^2 bytes.
         * ``max_hops == 1``: the K = 1 hop-coded CSR (self pair + direct neighbours), any size.
+        * ``max_hops = K >= 2``: dense while N^2 bytes fit (``layout='auto'``), else — or with ``layout='csr'`` —
+          the K-hop truncated hop-coded CSR (``gnan_bfs_khop``: every node within K directed hops is listed with
+          its hop count, everything farther joins the rest bucket); ``rows=(lo, hi)`` builds only that row block
+          (vertex partition, global column ids).  Listed nodes are ordered by (hop, node id) inside a row.
         Edges are directed as given; duplicate edges count once (the reference's COO->LIL conversion would turn
         them into weight-2 edges, SURVEY.md A.7 — coalesce upstream if that quirk matters).
         """
         _lib.require_device(edge_index)
+        if layout not in ("auto", "dense", "csr"):
+            raise ValueError("layout must be 'auto', 'dense' or 'csr'")
         ei = edge_index.long()
         n = int(num_nodes)
         dev = ei.device
         keep = ei[0] != ei[1] if max_hops == 1 else torch.ones(ei.shape[1], dtype=torch.bool, device=dev)
         key = torch.unique(ei[0, keep] * n + ei[1, keep])             # coalesced, sorted by (src, dst)
         src, dst = key // n, key % n
+        khop_csr = max_hops is not None and max_hops >= 2 and (layout == "csr" or (layout == "auto" and n * n > (1 << 33)))
+        if khop_csr:
+            return _khop_csr(src, dst, n, int(max_hops), rows)
+        if rows is not None:
+            raise ValueError("rows=(lo, hi) is supported by the K-hop CSR layout only (max_hops >= 2, layout='csr')")
         if max_hops == 1:
             rows = torch.cat([torch.arange(n, device=dev), src])
             cols = torch.cat([torch.arange(n, device=dev), dst])
@@ -232,6 +244,61 @@ class HopGraph:
                          rowptr=rowptr_t.to(self.rowptr.dtype), col=row_of_edge[order].to(torch.int32).contiguous())
         self._transposed = t
         return t
+
+
+KHOP_WORKGROUPS = 1024       # persistent workgroups of gnan_bfs_khop (each owns an N-bit bitmap and one queue)
+KHOP_MAX_PAIRS = 1 << 33     # refuse K-hop lists beyond this many pairs (5 B each)
+KHOP_QUEUE_START = 1 << 16   # first guess of the largest K-hop ball; grows x8 while some row overflows
+
+
+def _khop_csr(src: torch.Tensor, dst: torch.Tensor, n: int, K: int, rows: Optional[Tuple[int, int]]) -> "HopGraph":
+    """K-hop truncated hop-coded CSR from the coalesced, (src, dst)-sorted edge list (``gnan_bfs_khop``)."""
+    dev = src.device
+    lo, hi = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    if not 0 <= lo <= hi <= n:
+        raise ValueError(f"rows={rows} outside [0, {n}]")
+    if not 2 <= K <= _lib.MAX_CODES - 2:
+        raise ValueError(f"max_hops must be in [2, {_lib.MAX_CODES - 2}]")
+    n_rows = hi - lo
+    adj_ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    adj_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+    adj_col = dst.to(torch.int32).contiguous()
+    wgs = max(1, min(KHOP_WORKGROUPS, n_rows))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    level_cnt = torch.zeros((n_rows, K + 1), dtype=torch.int32, device=dev)
+    cap = min(n, KHOP_QUEUE_START)
+    while True:                                   # count pass; the queue capacity grows until every ball fits
+        need = _lib.lib().gnan_bfs_khop_workspace_bytes(n, cap, wgs)
+        ws = torch.empty(need // 4 + 1, dtype=torch.int32, device=dev)
+        args = (_lib.ptr(adj_ptr), 1, _lib.ptr(adj_col), n, K, lo, hi)
+        tail = (cap, wgs, _lib.ptr(status), _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(ws))
+        _lib.check(_lib.lib().gnan_bfs_khop(*args, _lib.ptr(level_cnt), None, None, None, *tail), "gnan_bfs_khop")
+        if not int(status.item()) & 1:
+            break
+        if cap >= n:
+            raise _lib.GnanHipError("gnan_bfs_khop: queue overflow at full capacity")   # cannot happen: a ball has <= n nodes
+        cap = min(n, cap * 8)
+        status.zero_()
+    per_row = level_cnt.sum(1, dtype=torch.int64)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(per_row, 0)
+    nnz = int(rowptr[-1])
+    if nnz > KHOP_MAX_PAIRS:
+        raise _lib.GnanHipError(f"{K}-hop lists of this graph hold {nnz:.3g} pairs (> {KHOP_MAX_PAIRS:.3g}); lower max_hops")
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    code = torch.empty(nnz, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().gnan_bfs_khop(*args, None, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(code), *tail),
+               "gnan_bfs_khop")
+    # hop levels are contiguous inside a row but the order inside a level depends on scheduling: fix it by node id,
+    # so that the same graph always gives the same lists (and the same floating-point summation order downstream)
+    seg = torch.repeat_interleave(torch.arange(n_rows, device=dev), per_row) * (K + 1) + code.long()
+    by_col = torch.sort(col.long(), stable=True).indices
+    order = by_col[torch.sort(seg[by_col], stable=True).indices]
+    col = col[order].contiguous()                 # `code` is unchanged by the permutation (constant per segment)
+    cnt = torch.cat([level_cnt, (n - per_row).to(torch.int32).unsqueeze(1)], dim=1)
+    if nnz < 2 ** 31:
+        rowptr = rowptr.to(torch.int32)
+    return HopGraph.from_csr(rowptr, col, code, n_cols=n, n_codes=K + 2, cnt=cnt)
 
 
 def shell_counts_csr(rowptr: torch.Tensor, code: torch.Tensor, n_cols: int, n_codes: int) -> torch.Tensor:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 11
+#define GNAN_ABI_VERSION 12
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -281,6 +281,25 @@ size_t gnan_bfs_dense_workspace_bytes(int32_t n);
 int gnan_bfs_dense(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t max_hops, uint8_t* code,
                    int32_t* cnt /* [n, 256] */, int32_t* status /* [2] */, void* workspace, size_t workspace_bytes,
                    gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K-hop truncated hop-coded CSR, for graphs too large for N x N bytes (pre_process_datasets.py:104-142 truncated at
+ * max_hops: pairs farther apart join the rest bucket, i.e. the dense matrices with every entry beyond max_hops zeroed).
+ * For each source row r in [row_lo, row_hi): all nodes within max_hops directed hops and their hop counts.
+ * Call twice with the same graph arguments:
+ *   count pass (out_rowptr == NULL): level_cnt[r - row_lo, d] = #{nodes at hop d}, d = 0..max_hops (d = 0: r itself)
+ *   fill pass  (out_rowptr = exclusive prefix sum of the row totals, int64): out_col / out_code hold row r's nodes
+ *              at out_rowptr[r - row_lo] in BFS order (hop 0 first); the order inside one hop level is unspecified.
+ * Adjacency: CSR of the directed edge list, duplicates and self loops harmless.  queue_cap bounds the nodes one row
+ * may list; status[0] |= 1 if a row exceeded it (outputs invalid: retry with a larger queue_cap).  status zeroed by
+ * the caller.  workspace: gnan_bfs_khop_workspace_bytes(n, queue_cap, n_workgroups).
+ * ------------------------------------------------------------------------------------------- */
+size_t gnan_bfs_khop_workspace_bytes(int64_t n, int32_t queue_cap, int32_t n_workgroups);
+int gnan_bfs_khop(const void* rowptr, int32_t rowptr_is64, const int32_t* col, int64_t n, int32_t max_hops,
+                  int64_t row_lo, int64_t row_hi, int32_t* level_cnt /* [rows, max_hops+1] */,
+                  const int64_t* out_rowptr, int32_t* out_col, uint8_t* out_code, int32_t queue_cap,
+                  int32_t n_workgroups, int32_t* status /* [1] */, void* workspace, size_t workspace_bytes,
+                  gnan_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,65 @@ def test_gpu_preprocessing_bit_exact(gpu, name, max_hops):
         assert torch.equal(dense.code, graph.code) and torch.equal(dense.cnt, graph.cnt)
 
 
+def _khop_expected(hops, K, lo, hi):
+    """(rowptr, col, code) with rows [lo, hi) ordered by (hop, node id) — the order gnan_amd documents."""
+    cols, codes, ptr = [], [], [0]
+    for i in range(lo, hi):
+        j = np.nonzero((hops[i] >= 0) & (hops[i] <= K))[0]
+        order = np.lexsort((j, hops[i, j]))
+        cols.append(j[order])
+        codes.append(hops[i, j[order]])
+        ptr.append(ptr[-1] + len(j))
+    return np.array(ptr), np.concatenate(cols).astype(np.int32), np.concatenate(codes).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", golden_names("pre_process") + [MODEL_CASES[5], MODEL_CASES[11]])
+@pytest.mark.parametrize("K", [2, 3, 6])
+def test_gpu_khop_csr_preprocessing_bit_exact(gpu, name, K, monkeypatch):
+    """f-1 for graphs too large for N^2 bytes: K-hop truncated hop-coded CSR straight from edge_index
+    (gnan_bfs_khop) == the reference's pre_process matrices with everything beyond K hops zeroed."""
+    from gnan_amd import HopGraph, graph as graph_mod
+    g = Golden(name)
+    n = g.inputs["node_distances"].shape[0]
+    ei = torch.from_numpy(np.array(g.inputs["edge_index"])).to(gpu.DEV)
+    hops = O.hop_codes_from_dense(torch.from_numpy(np.array(g.inputs["node_distances"])))
+    monkeypatch.setattr(graph_mod, "KHOP_QUEUE_START", 2)          # also walks the queue-growth path
+    got = HopGraph.from_edge_index(ei, n, K, layout="csr")
+    rowptr, col, code = _khop_expected(hops, K, 0, n)
+    assert got.n_codes == K + 2 and got.n_cols == n
+    assert np.array_equal(got.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(got.col.cpu().numpy(), col)
+    assert np.array_equal(got.code.cpu().numpy(), code)
+    assert np.array_equal(got.cnt.cpu().numpy(), O.shell_counts(np.where(hops > K, -1, hops), K + 2))
+    lo, hi = n // 3, n - 1                                         # a row block keeps global column ids
+    blk = HopGraph.from_edge_index(ei, n, K, layout="csr", rows=(lo, hi))
+    rp, cb, cd = _khop_expected(hops, K, lo, hi)
+    assert np.array_equal(blk.rowptr.cpu().numpy(), rp) and np.array_equal(blk.col.cpu().numpy(), cb)
+    assert np.array_equal(blk.code.cpu().numpy(), cd)
+    assert torch.equal(blk.cnt, got.cnt[lo:hi])
+
+
+@pytest.mark.parametrize("name", [MODEL_CASES[9], MODEL_CASES[11]])
+def test_khop_csr_forward_matches_truncated_dense_reference(gpu, name):
+    """Module forward on the K = 2 CSR built on the device == oracle on the dense inputs truncated at 2 hops."""
+    from gnan_amd import HopGraph
+    g = Golden(name)
+    if g.meta.get("node_ids") or not g.meta["variant"].startswith("models_tensor_node"):
+        pytest.skip("node-level models.TensorGNAN fixtures only")
+    i64 = inputs_from(g, torch.float64)
+    p64 = params_from(g, torch.float64)
+    nd_k, norm_k = O.truncate_dense(i64["node_distances"], 2)
+    truth = O.tensor_gnan_forward_models(i64["x"], nd_k, norm_k, p64, g.meta["normalize_rho"], False)
+    mod = gpu.build_module(g)
+    data = gpu.device_inputs(g)
+    n = data.x.shape[0]
+    data.gnan_graph = HopGraph.from_edge_index(torch.from_numpy(np.array(g.inputs["edge_index"])).to(gpu.DEV), n, 2,
+                                               layout="csr")
+    with torch.no_grad():
+        y = mod.forward(data)
+    assert O.rel_err(y.cpu().double(), truth) <= 1e-5
+
+
 def test_training_mode_dropout_is_supported(gpu):
     """run.sh trains with dropout 0.6 and the module starts in train mode: the first epoch must work.
     Dropout is stochastic, so the check is determinism under a seed, finiteness, and that eval() is unaffected."""

@@ -152,7 +152,36 @@ def arxiv_shaped():
     print(json.dumps(out))
 
 
+def arxiv_khop():
+    """f-1 at a size the dense matrices cannot reach (2 x 115 GB): K-hop hop-coded CSR built on the device."""
+    import time
+    from gnan_amd import HopGraph
+    N, E, F = 169_343, 1_166_243, 129
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    src = torch.randint(0, N, (E,), generator=gen, device=DEV)
+    dst = (torch.rand(E, generator=gen, device=DEV) ** 3 * N).long().clamp_(0, N - 1)
+    ei = torch.stack([src, dst])
+    x = syn.block_features(N, F, 0, N, 1, DEV)
+    m = TensorGNAN(F, 1, 3, hidden_channels=64, device=DEV)
+    redraw(m)
+    m = m.to(DEV).eval()
+    out = {"what": "arxiv_shaped_khop_preprocessing"}
+    for K in (1, 2, 3):
+        HopGraph.from_edge_index(ei, N, K, layout="csr" if K > 1 else "auto")          # warm-up (allocator, lazy inits)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = HopGraph.from_edge_index(ei, N, K, layout="csr" if K > 1 else "auto")
+        torch.cuda.synchronize()
+        out[f"K{K}_build_ms"] = (time.perf_counter() - t0) * 1e3
+        out[f"K{K}_pairs"] = g.nnz
+        d = Bag(x=x, edge_index=None, gnan_graph=g)
+        with torch.no_grad():
+            out[f"K{K}_fwd_ms"] = timeit(lambda: m.forward(d), reps=5, warm=2)
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pwl", "cora", "muta", "arxiv"]
+    which = sys.argv[1:] or ["pwl", "cora", "muta", "arxiv", "khop"]
     for w in which:
-        {"pwl": pwl_split, "cora": cora_shaped, "muta": mutagenicity_shaped, "arxiv": arxiv_shaped}[w]()
+        {"pwl": pwl_split, "cora": cora_shaped, "muta": mutagenicity_shaped, "arxiv": arxiv_shaped,
+         "khop": arxiv_khop}[w]()
