@@ -163,6 +163,8 @@ def main():
     emulated = args.emulate_world > 1 and world == 1
     pworld = args.emulate_world if emulated else world       # how many shares the work is cut into
     partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, pworld, args.order)
+    if emulated and partition == "vertex":
+        raise SystemExit("--emulate-world covers the halo and feature partitions (a vertex share needs the other ranks' operand)")
     if partition == "feature" and args.order != "reference":
         raise SystemExit("--partition feature needs --order reference (sum-first exchanges the narrow operand)")
     part = VertexPartition(N, pworld, rank)

@@ -211,12 +211,11 @@ __device__ __forceinline__ SmallW small_weights(const Params& p, int64_t i) {
 // ---------------------------------------------------------------------------------------------
 // rows kernel: one LPR-lane group per output row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool DENSE, bool SMALLD, int TUNE = 0>
+template <int VEC, int LPR, bool DENSE, bool SMALLD>
 __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_id) {
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
-  constexpr int UNROLL = (TUNE & 1) ? 8 : 4;
-  constexpr bool NT_IDX = (TUNE & 2) != 0;
+  constexpr int UNROLL = 4;          // gathers in flight per lane (8 costs registers, hence waves: slower)
   constexpr int IW = LPR >= 8 ? LPR : 16;  // index pairs fetched per round by one group (narrow rows: 16)
   constexpr int IPL = IW / LPR;            // ... per lane
   const int lane = threadIdx.x & (kWave - 1);
@@ -268,13 +267,8 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
         const int64_t e = base + sub * IPL + r;
         colv[r] = codev[r] = 0;
         if (e < hi) {
-          if constexpr (NT_IDX) {   // index streams are read once: keep them out of the way of the gathered rows
-            if constexpr (!DENSE) colv[r] = __builtin_nontemporal_load(p.col + e);
-            codev[r] = __builtin_nontemporal_load(p.code + code_base + e);
-          } else {
-            if constexpr (!DENSE) colv[r] = p.col[e];
-            codev[r] = p.code[code_base + e];
-          }
+          if constexpr (!DENSE) colv[r] = p.col[e];
+          codev[r] = p.code[code_base + e];
         }
       }
       const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
@@ -455,7 +449,7 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
 
 // One launch covers everything: workgroups [0, n_slices) take the hub-row slices (they start first,
 // so the long-latency slices overlap the bulk), the rest take 4*G ordinary rows each.
-template <int VEC, int LPR, bool DENSE, bool SMALLD, int TUNE = 0>
+template <int VEC, int LPR, bool DENSE, bool SMALLD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SMALLD && LPR >= 8) ? 8 : 1)))
 void spmm_kernel(const Params p) {
   if constexpr (!DENSE) {
@@ -463,9 +457,9 @@ void spmm_kernel(const Params p) {
       slice_body<VEC, LPR, SMALLD>(p, static_cast<int>(blockIdx.x));
       return;
     }
-    rows_body<VEC, LPR, false, SMALLD, TUNE>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
+    rows_body<VEC, LPR, false, SMALLD>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
   } else {
-    rows_body<VEC, LPR, true, SMALLD, TUNE>(p, static_cast<int64_t>(blockIdx.x));
+    rows_body<VEC, LPR, true, SMALLD>(p, static_cast<int64_t>(blockIdx.x));
   }
 }
 
