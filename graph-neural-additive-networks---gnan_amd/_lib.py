@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -43,6 +43,7 @@ class FpwlArgs(C.Structure):
         ("max_pieces", C.c_int32), ("features_per_group", C.c_int32), ("max_group_pieces", C.c_int32),
         ("sum_features", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64),
         ("out_dtype", C.c_int32), ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
+        ("total_rows", C.c_int64),
     ]
 
 

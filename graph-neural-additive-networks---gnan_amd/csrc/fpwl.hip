@@ -31,6 +31,7 @@ struct Params {
   int64_t out_stride;
   double* col_partial;   // optional [gridDim.x, F]: per-workgroup column sums of the output (FAST, per-feature mode)
   int out_bf16;          // per-feature output stored as bf16 rows (FAST path only)
+  int64_t total_rows;    // column sums cover nodes [0, total_rows) only
   int acc_offset;        // > 0 (sum over features, C > 1): float offset in dynamic LDS of the [C][NODES] accumulators;
                          // the workgroup then owns ONE pass of nodes and walks all feature groups for them
 };
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(BS) void fpwl_kernel(const Params p) {
           } else {
             *reinterpret_cast<float4*>(o) = t;
           }
-          ps[0] += t.x; ps[1 % FPT] += t.y; ps[2 % FPT] += t.z; ps[3 % FPT] += t.w;
+          if (n < p.total_rows) { ps[0] += t.x; ps[1 % FPT] += t.y; ps[2 % FPT] += t.z; ps[3 % FPT] += t.w; }
         } else {
 #pragma unroll
           for (int f = 0; f < FPT; ++f)
@@ -402,6 +403,7 @@ Params base_params(const gnan_fpwl_args* a) {
   p.vec_x = p.vec_out = 0;
   p.out = static_cast<float*>(a->out); p.out_stride = a->out_stride;
   p.col_partial = nullptr;
+  p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
   p.acc_offset = 0;
   p.out_bf16 = a->out_dtype == GNAN_BF16;
   return p;

@@ -236,15 +236,11 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     mark("start")
     kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
     sum_first = order == "sum_first"
-    if plan.halo.numel() == 0:                    # nothing remote: the column sums ride in the shape-function pass
-        operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, **kw)
-    else:
-        operand = ops["feature_mlps"](x_compact, stacked, sum_first, **kw)
-        total = None
+    # the column sums ride in the shape-function pass, restricted to the owned rows: they partition the nodes, so the
+    # ranks' sums add up to the whole graph's without double counting
+    operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, total_rows=plan.n_own, **kw)
     mark("fmlp")
     mark("gather")
-    if total is None:
-        total = ops["column_sums"](operand[: plan.n_own])          # owned rows partition the nodes: no double counting
     if part.world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     mark("total")

@@ -71,7 +71,8 @@ PWL_MIN_WORK_GRAD = 1 << 18  # ... much earlier when a backward pass follows: th
 PWL_MIN_NODES = 1 << 14      # inference on small graphs: the matrix-core kernel beats table build + look-up
 
 
-def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32):
+def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32,
+                 total_rows: Optional[int] = None):
     """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``.
     With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
     when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
@@ -95,6 +96,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         need = _lib.lib().gnan_fpwl_total_workspace_bytes(a)
         ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
         a.total, a.total_workspace, a.total_workspace_bytes = _lib.ptr(total), _lib.ptr(ws), need
+        a.total_rows = n if total_rows is None else int(total_rows)
     _lib.check(_lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)), "gnan_fpwl_fwd")
     return (out, total) if want_total else out
 
@@ -120,7 +122,7 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) ->
 
 
 def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False,
-                  needs_grad: bool = False, out_dtype=torch.float32):
+                  needs_grad: bool = False, out_dtype=torch.float32, total_rows: Optional[int] = None):
     """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
     Returns ``(out, tables or None, total or None)``."""
     algo = FMLP_ALGO
@@ -132,7 +134,8 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
         from .pwl import build_tables
         tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
         if tables is not None:
-            out, total = _fpwl_launch(x, tables, sum_features, want_total=True, out_dtype=out_dtype) if want_total \
+            out, total = _fpwl_launch(x, tables, sum_features, want_total=True, out_dtype=out_dtype,
+                                      total_rows=total_rows) if want_total \
                 else (_fpwl_launch(x, tables, sum_features, out_dtype=out_dtype), None)
             return out, tables, total
         if algo == _lib.FMLP_PWL:
@@ -194,19 +197,24 @@ _BWD_CHUNK_ELEMS = 1 << 28   # activation floats per recompute chunk (1 GiB)
 
 class _FeatureMLPs(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, sum_features, want_total, out_dtype, L, H, C, F, *params):
+    def forward(ctx, x, sum_features, want_total, out_dtype, total_rows, L, H, C, F, *params):
         p = StackedMLP(*params, L, H, C, F)
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
-        needs_grad = any(ctx.needs_input_grad[8:]) and not ctx.needs_input_grad[0]
+        needs_grad = any(ctx.needs_input_grad[9:]) and not ctx.needs_input_grad[0]
         if needs_grad and out_dtype != torch.float32:
             raise _lib.GnanHipError("bf16 operand storage is an inference format: no backward pass")
-        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, want_total, needs_grad, out_dtype)
+        if total_rows is not None and not 0 <= total_rows <= x.shape[0]:
+            raise ValueError(f"total_rows={total_rows} outside [0, {x.shape[0]}]")
+        fused_total = want_total and total_rows != 0           # 0 rows: the kernel reads that as "all", sum nothing instead
+        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, fused_total, needs_grad, out_dtype, total_rows)
         if not want_total:
             return out
+        if total_rows == 0:
+            total = out.new_zeros(out.shape[1], dtype=torch.float32)
         if total is None:
-            total = column_sums(out)
+            total = column_sums(out if total_rows is None else out[:total_rows])
         ctx.mark_non_differentiable(total)     # d total / d out is accounted for inside the aggregation's backward
         return out, total
 
@@ -230,7 +238,7 @@ class _FeatureMLPs(torch.autograd.Function):
             it = iter(got)
             pg = [None if not present else next(it) for present in ctx.present]
             pg = [None if g is None else g.to(torch.float32) for g in pg]
-            return (None, None, None, None, None, None, None, None, *pg)
+            return (None, None, None, None, None, None, None, None, None, *pg)
         grads = [torch.zeros_like(t) for t in live]
         n = x.shape[0]
         chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))
@@ -249,19 +257,20 @@ class _FeatureMLPs(torch.autograd.Function):
                 gx[lo:lo + chunk] = got[-1]
         it = iter(grads)
         pg = [next(it) if present else None for present in ctx.present]
-        return (gx, None, None, None, None, None, None, None, *pg)
+        return (gx, None, None, None, None, None, None, None, None, *pg)
 
 
 def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False,
-                 out_dtype=torch.float32):
+                 out_dtype=torch.float32, total_rows: Optional[int] = None):
     """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157.
     ``return_total`` additionally returns the column sums of the result (the aggregation's rest-bucket operand),
     fused into the look-up kernel where possible.  ``out_dtype=torch.bfloat16`` stores the per-feature rows in bf16
-    (inference only; one output channel), the operand format of the bf16-storage aggregation."""
+    (inference only; one output channel), the operand format of the bf16-storage aggregation.  ``total_rows`` limits
+    the column sums to the first rows (a rank's owned rows ahead of its halo rows, ``distributed.halo_recompute_forward``)."""
     _lib.require_device(x, p.w_last)
     if x.shape[1] != p.F:
         raise ValueError(f"x has {x.shape[1]} feature columns, the model was built for {p.F}")
-    return _FeatureMLPs.apply(x, sum_features, return_total, out_dtype, p.L, p.H, p.C, p.F,
+    return _FeatureMLPs.apply(x, sum_features, return_total, out_dtype, total_rows, p.L, p.H, p.C, p.F,
                               p.w_first, p.b_first, p.w_mid, p.b_mid, p.w_last, p.b_last)
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 12
+#define GNAN_ABI_VERSION 13
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -117,6 +117,8 @@ typedef struct gnan_fpwl_args {
                               produced in the same pass; needs C == 1, whole groups, 16-B aligned rows */
   void* total_workspace;   /* gnan_fpwl_total_workspace_bytes() */
   size_t total_workspace_bytes;
+  int64_t total_rows;      /* `total` covers rows [0, total_rows) only (a rank's owned rows ahead of its halo rows);
+                              <= 0 or >= n: all rows */
 } gnan_fpwl_args;
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);

@@ -26,10 +26,10 @@ def _free_port():
 
 
 def _oracle_compute(sd, C):
-    def feature_mlps(x, stacked, sum_features, return_total=False):
+    def feature_mlps(x, stacked, sum_features, return_total=False, total_rows=None):
         fx = O.feature_mlps(x, sd)
         out = fx.sum(1) if sum_features else fx.reshape(x.shape[0], -1)
-        return (out, out.sum(0)) if return_total else out
+        return (out, out[:total_rows].sum(0)) if return_total else out
 
     def column_sums(S):
         return S.sum(0)

@@ -335,9 +335,15 @@ def test_fused_column_sums_of_table_lookup(n, F, monkeypatch):
     want = out.double().sum(0)
     assert float((total.double() - want).abs().max()) <= 1e-6 * float(out.abs().sum(0).max())
     assert torch.equal(total, feature_mlps(x, st, False, return_total=True)[1])       # fixed reduction order
+    for rows in (0, 1, 777, n // 2 + 3, n):                                          # a rank's owned rows ahead of its halo
+        out_r, total_r = feature_mlps(x, st, False, return_total=True, total_rows=rows)
+        assert torch.equal(out_r, out)
+        want_r = out[:rows].double().sum(0)
+        assert float((total_r.double() - want_r).abs().max()) <= 1e-6 * max(1e-30, float(out.abs().sum(0).max()))
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_MFMA)                     # other strategies: separate pass
     out2, total2 = feature_mlps(x, st, False, return_total=True)
     assert torch.equal(total2, column_sums(out2))
+    assert torch.equal(feature_mlps(x, st, False, return_total=True, total_rows=777)[1], column_sums(out2[:777]))
 
 
 @pytest.mark.parametrize("F,L,H,C,bias", [(5, 3, 8, 1, True), (9, 3, 32, 5, False), (64, 3, 64, 1, True), (6, 3, 33, 2, True),
