@@ -12,6 +12,8 @@
 // of a node cover one 64-B sector of x and of fx.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace {
 
 struct Params {
@@ -32,6 +34,8 @@ struct Params {
   double* col_partial;   // optional [gridDim.x, F]: per-workgroup column sums of the output (FAST, per-feature mode)
   int out_bf16;          // per-feature output stored as bf16 rows (FAST path only)
   int64_t total_rows;    // column sums cover nodes [0, total_rows) only
+  int max_pieces;        // largest piece count of one feature
+  int soff_offset;       // fpwl_fast_kernel: float offset of its group-offset array in dynamic LDS
   int acc_offset;        // > 0 (sum over features, C > 1): float offset in dynamic LDS of the [C][NODES] accumulators;
                          // the workgroup then owns ONE pass of nodes and walks all feature groups for them
 };
@@ -215,6 +219,140 @@ __global__ __launch_bounds__(BS) void fpwl_kernel(const Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The C == 1 work-horse: the look-up is VALU-bound (68 vector instructions per look-up in the kernel above, counted
+// with SQ_INSTS_VALU; its LDS and HBM sides have slack), so this variant strips the search to 3 instructions per step:
+//   * every feature's anchors sit in LDS padded with +inf to P2 = 2^NSTEP entries -> no bounds test in the loop;
+//   * the loop is fully unrolled and `pos` is kept as an LDS *byte address*, so probe j = pos + step is the
+//     immediate offset of the ds_read:   a = lds[pos + 4*step];  pos += a <= x ? 4*step : 0;
+//   * entry 0 of a feature is the anchor of piece 0 (never probed), so lds[pos] after the loop is the piece's
+//     anchor and (val, slope) is one 8-byte read at 2*pos + delta.
+// Same arithmetic per look-up as fpwl_kernel (val + slope * (x - anchor)), hence bit-identical results.
+// ---------------------------------------------------------------------------------------------
+// reads at raw LDS byte addresses (see fpwl_fast_kernel)
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x2_t lds_cfloat2;
+__device__ __forceinline__ float lds_f32(int addr) { return *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(static_cast<unsigned>(addr))); }
+__device__ __forceinline__ float2 lds_f32x2(int addr) {
+  const f32x2_t v = *reinterpret_cast<lds_cfloat2*>(static_cast<uintptr_t>(static_cast<unsigned>(addr)));
+  return make_float2(v.x, v.y);
+}
+
+template <int FG, bool SUM, bool OUT16, int NSTEP, int BS>
+__global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
+  static_assert(FG % 4 == 0, "feature quads");
+  constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
+  // `pos` is a raw LDS byte address (LDS base folded in once per group): addressing through the `smem` symbol costs
+  // a fourth instruction per step, because its base is only resolved at link time
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;       // [FG + 1], behind tables and reduction scratch
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float*)smem));
+  const int tid = threadIdx.x;
+  const int q = tid % TPN;
+  const int nl = tid / TPN;
+  int64_t nb = blockIdx.x;
+  int g_first = 0;
+  if (!SUM) {                                       // (id % 8) = XCD, groups of a node block adjacent inside it
+    const int64_t id = blockIdx.x;
+    g_first = static_cast<int>((id >> 3) % p.n_groups);
+    nb = ((id >> 3) / p.n_groups) * 8 + (id & 7);
+  }
+  const int64_t n_lo = nb * p.nodes_per_block;
+  if (n_lo >= p.n) return;
+  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
+  const int g_lo = SUM ? 0 : g_first;
+  const int g_hi = SUM ? p.n_groups : g_lo + 1;
+  constexpr int kVsBytes = FG * P2 * 4;             // (val, slope) pairs start behind the padded anchors
+
+  for (int g = g_lo; g < g_hi; ++g) {
+    const int k0 = g * FG;
+    const int base = p.off[k0];
+    const int tot = p.off[k0 + FG] - base;
+    __syncthreads();                                // previous group's look-ups are done with the LDS tables
+    if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
+    __syncthreads();
+    for (int i = tid; i < FG * P2; i += BS) {
+      const int f = i >> NSTEP, j = i & (P2 - 1);
+      smem[i] = j < s_off[f + 1] - s_off[f] ? p.anchor[base + s_off[f] + j] : INFINITY;
+    }
+    float2* vs_l = reinterpret_cast<float2*>(smem + FG * P2);
+    for (int i = tid; i < tot; i += BS) vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
+    __syncthreads();
+    int pos0[FPT], delta[FPT];
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const int fg = q * FPT + f;
+      pos0[f] = static_cast<int>(lds_base) + (fg << NSTEP) * 4;
+      delta[f] = static_cast<int>(lds_base) + kVsBytes + s_off[fg] * 8 - 2 * pos0[f];
+    }
+
+    float ps[FPT] = {0.f, 0.f, 0.f, 0.f};           // column sums of the output (per-feature mode)
+    for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
+      const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
+      const float xv[FPT] = {t.x, t.y, t.z, t.w};
+      int pos[FPT];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) pos[f] = pos0[f];
+#pragma unroll
+      for (int step = P2 / 2; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+          const float a = lds_f32(pos[f] + 4 * step);
+          pos[f] += a <= xv[f] ? 4 * step : 0;
+        }
+      }
+      float y[FPT];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const float an = lds_f32(pos[f]);
+        const float2 vs = lds_f32x2(2 * pos[f] + delta[f]);
+        y[f] = fmaf(vs.y, xv[f] - an, vs.x);
+      }
+      if constexpr (SUM) {
+        float a = 0.f;
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) a += y[f];
+#pragma unroll
+        for (int off = 1; off < TPN; off <<= 1) a += __shfl_xor(a, off);   // the node's TPN threads
+        if (q == 0) {                               // groups run one after the other and a node keeps its thread
+          float* o = p.out + n * p.out_stride;
+          o[0] = g == 0 ? a : o[0] + a;
+        }
+      } else {
+        float4 r = make_float4(y[0], y[1], y[2], y[3]);
+        if constexpr (OUT16) {
+          const unsigned b0 = bf16_bits(r.x), b1 = bf16_bits(r.y), b2 = bf16_bits(r.z), b3 = bf16_bits(r.w);
+          uint16_t* o16 = reinterpret_cast<uint16_t*>(p.out) + n * p.out_stride + (k0 + q * FPT);
+          *reinterpret_cast<uint2*>(o16) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+          // the column sums must describe the operand the aggregation will actually read: the rounded values
+          r = make_float4(__uint_as_float(b0 << 16), __uint_as_float(b1 << 16), __uint_as_float(b2 << 16),
+                          __uint_as_float(b3 << 16));
+        } else {
+          *reinterpret_cast<float4*>(p.out + n * p.out_stride + k0 + q * FPT) = r;
+        }
+        if (n < p.total_rows) { ps[0] += r.x; ps[1] += r.y; ps[2] += r.z; ps[3] += r.w; }
+      }
+    }
+    if constexpr (!SUM) {
+      if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64
+        float* red = smem + FG * P2 + 2 * tot;
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) red[tid * FPT + f] = ps[f];
+        __syncthreads();
+        if (tid < FG) {
+          const int qq = tid / FPT, ff = tid % FPT;
+          double acc = 0.0;
+          for (int s2 = 0; s2 < NODES; ++s2) acc += red[(s2 * TPN + qq) * FPT + ff];
+          p.col_partial[nb * p.F + k0 + tid] = acc;
+        }
+      }
+    }
+  }
+}
+
 // One workgroup per column: 256 threads stride over the per-workgroup partials, then a fixed-order tree.
 __global__ __launch_bounds__(256) void fpwl_total_kernel(const double* __restrict__ partial, int blocks, int W,
                                                          float* __restrict__ total) {
@@ -323,6 +461,7 @@ int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
 
 template <int FG, int BS>
 int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
+  const size_t table_lds = lds;            // (1 + 2C) floats per piece of the largest group
   if (p.sum_features && p.C > 1) {        // accumulate the feature sum in LDS: one pass of nodes per workgroup
     if (lds + static_cast<size_t>(p.C) * Map<FG, BS>::NODES * sizeof(float) <= 150 * 1024) {
       p.acc_offset = static_cast<int>(lds / sizeof(float));
@@ -340,6 +479,47 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
     if (!fast || p.sum_features)
       return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: fused column sums need C == 1, F %% %d == 0, 16-B aligned rows, per-feature output", FG);
     lds += BS * 4 * sizeof(float);
+  }
+  if constexpr (FG % 4 == 0) {
+    int nstep = 6;
+    while ((1 << nstep) < p.max_pieces) ++nstep;
+    size_t lds_fast = (static_cast<size_t>(FG) << nstep) * sizeof(float) + table_lds / 3 * 2 +
+                      (p.col_partial ? BS * 4 * sizeof(float) : 0);            // C == 1: 2 of the 3 floats per piece
+    p.soff_offset = static_cast<int>(lds_fast / sizeof(float));
+    lds_fast += (FG + 1) * sizeof(int);
+    if (fast && nstep <= 10 && lds_fast <= 150 * 1024) {
+      auto fgo = [&](auto kernel) {
+        if (lds_fast > 64 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_fast));
+          if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(BS), lds_fast, st, p);
+        return gnan::check_launch("fpwl_fast_kernel");
+      };
+      auto by_mode = [&](auto ns) {
+        constexpr int NS = decltype(ns)::value;
+        if (p.out_bf16) return p.sum_features ? gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: bf16 output is per-feature only")
+                                              : fgo(fpwl_fast_kernel<FG, false, true, NS, BS>);
+        return p.sum_features ? fgo(fpwl_fast_kernel<FG, true, false, NS, BS>)
+                              : fgo(fpwl_fast_kernel<FG, false, false, NS, BS>);
+      };
+      int rc;
+      switch (nstep) {
+        case 6: rc = by_mode(std::integral_constant<int, 6>{}); break;
+        case 7: rc = by_mode(std::integral_constant<int, 7>{}); break;
+        case 8: rc = by_mode(std::integral_constant<int, 8>{}); break;
+        case 9: rc = by_mode(std::integral_constant<int, 9>{}); break;
+        default: rc = by_mode(std::integral_constant<int, 10>{}); break;
+      }
+      if (rc) return rc;
+      if (p.col_partial) {
+        hipLaunchKernelGGL(fpwl_total_kernel, dim3(p.F), dim3(256), 0, st, p.col_partial, static_cast<int>(bx), p.F,
+                           total_out);
+        return gnan::check_launch("fpwl_total_kernel");
+      }
+      return GNAN_OK;
+    }
   }
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) {
@@ -403,6 +583,8 @@ Params base_params(const gnan_fpwl_args* a) {
   p.vec_x = p.vec_out = 0;
   p.out = static_cast<float*>(a->out); p.out_stride = a->out_stride;
   p.col_partial = nullptr;
+  p.max_pieces = a->max_pieces;
+  p.soff_offset = 0;
   p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
   p.acc_offset = 0;
   p.out_bf16 = a->out_dtype == GNAN_BF16;
