@@ -710,6 +710,358 @@ void pick_tiling(const gnan_spmm_args* a, const float* out, int64_t out_stride, 
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Gradient w.r.t. the weight table without materialising the per-shell sums (truncated-hop case: D <= 4, Cw == 1).
+//   dwt[q, d] = inv(q, d) * sum_w dY[q, w] * T[q, d, w],   T[q, d, :] = sum of the operand rows of q's hop-d pairs,
+//   T[q, rest, :] = total - sum_{d < rest} T[q, d, :]  (or the listed rest pairs when there is no rest bucket).
+// Same traversal as the forward kernel (gather the operand rows once), four accumulators per lane instead of one,
+// contracted with the row's dY in the epilogue; spmm_shell_sums_kernel + torch needed a [n, D, W] tensor and one
+// global read-modify-write per listed pair for this.  Rows / hub slices / fix-up as in the forward.  With
+// `reduce_rows` the rows' contributions meet in fixed-order float64 partials (workgroup, then grid): dlut[d].
+// ---------------------------------------------------------------------------------------------
+struct GradParams {
+  const float* dY;       // [n_rows, dy_channels]; column w of the operand pairs with dY[q, w % dy_channels]
+  int64_t dy_stride;
+  int dy_channels;
+  float* dwt;            // per-row mode: [n_rows, D]
+  double* blk;           // reduce mode: [n_row_blocks + n_long, 4]
+  float* slice_T;        // [n_slices, 4, W]
+  int reduce_rows;
+  int64_t n_row_blocks;
+};
+
+template <int VEC>
+__device__ __forceinline__ void grad_finish(const Params& p, const GradParams& gp, int64_t i, int64_t oq, int cw,
+                                            bool col_ok, Vec<VEC> (&t)[4], float (&pd)[4]) {
+  // contract this lane's columns of T with dY and fold the rest bucket
+  const int rest = p.D - 1;
+  if (col_ok) {
+    Vec<VEC> dy;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) dy.v[v] = gp.dY[oq * gp.dy_stride + (cw + v) % gp.dy_channels];
+    if (p.s_total) {
+      const Vec<VEC> tot = load_vec<VEC>(p.s_total + cw);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float lower = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) lower += d < rest ? t[d].v[v] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) t[d].v[v] = d == rest ? tot.v[v] - lower : t[d].v[v];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) pd[d] = fmaf(dy.v[v], t[d].v[v], pd[d]);
+  }
+}
+
+__device__ __forceinline__ float grad_inv(const Params& p, int64_t i, int d) {
+  if (!p.cnt || d >= p.D) return d < p.D ? 1.f : 0.f;
+  const int c = p.cnt[i * p.cnt_stride + d];
+  return 1.f / static_cast<float>(c > 1 ? c : 1);
+}
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, const GradParams gp) {
+  constexpr int G = kWave / LPR;
+  constexpr int TILE = LPR * VEC;
+  constexpr int NW = 4;
+  __shared__ float red[NW][4][TILE];            // slice blocks: waves -> wave 0
+  __shared__ float rowsum[NW * G][4];           // row blocks: the groups' dwt for the workgroup partial
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int sub = lane % LPR;
+  const int slot = lane / LPR;
+  const int rest = p.D - 1;
+
+  if (static_cast<int>(blockIdx.x) < p.n_slices) {
+    // ---- hub-row slice: per-shell sums of this slice -> slice_T[s] ------------------------------
+    const int s = blockIdx.x;
+    int a = 0, b = p.n_long;
+    while (b - a > 1) {
+      const int mid = (a + b) >> 1;
+      if (p.long_slice_ptr[mid] <= s) a = mid; else b = mid;
+    }
+    const int64_t q = p.long_rows[a];
+    const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+    const int64_t row_lo = load_rowptr(p, i), row_hi = load_rowptr(p, i + 1);
+    const int64_t lo = row_lo + static_cast<int64_t>(s - p.long_slice_ptr[a]) * p.slice_edges;
+    const int64_t hi = lo + p.slice_edges < row_hi ? lo + p.slice_edges : row_hi;
+    for (int w0 = 0; w0 < p.W; w0 += TILE) {
+      const int cw = w0 + sub * VEC;
+      const bool col_ok = cw < p.W;
+      Vec<VEC> t[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t[d].v[v] = 0.f;
+      for (int64_t base = lo + static_cast<int64_t>(wave) * kWave; base < hi; base += NW * kWave) {
+        const int64_t e = base + lane;
+        int colv = 0, codev = 0;
+        if (e < hi) { colv = p.col[e]; codev = p.code[e]; }
+        const int m = static_cast<int>(hi - base < kWave ? hi - base : kWave);
+#pragma unroll 4
+        for (int tt = 0; tt < LPR; ++tt) {
+          const int j = slot + tt * G;
+          const int c = __shfl(colv, j);
+          int d = __shfl(codev, j);
+          d = d < rest ? d : rest;
+          if (j < m && col_ok) {
+            const Vec<VEC> sv = load_operand<VEC>(p.S, c, p.s_stride, cw);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) t[dd].v[v] += d == dd ? sv.v[v] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int off = LPR; off < kWave; off <<= 1)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) t[d].v[v] += __shfl_xor(t[d].v[v], off);
+      __syncthreads();
+      if (slot == 0)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) red[wave][d][sub * VEC + v] = t[d].v[v];
+      __syncthreads();
+      if (wave == 0 && slot == 0 && col_ok) {
+        float* out = gp.slice_T + static_cast<int64_t>(s) * 4 * p.W;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            float x = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x += red[w][d][sub * VEC + v];
+            out[d * p.W + cw + v] = x;
+          }
+      }
+    }
+    return;
+  }
+
+  // ---- row block: one LPR-lane group per output row ------------------------------------------------
+  const int64_t block_id = static_cast<int64_t>(blockIdx.x) - p.n_slices;
+  const int64_t q = (block_id * NW + wave) * G + slot;
+  float pd[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t i = 0, oq = 0;
+  bool live = q < p.n_rows;
+  if (live) {
+    i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+    oq = p.scatter_out ? i : q;
+    const int64_t lo = load_rowptr(p, i), hi = load_rowptr(p, i + 1);
+    live = hi - lo <= p.long_threshold;                 // hub rows: slices + fix-up
+    if (live) {
+      for (int w0 = 0; w0 < p.W; w0 += TILE) {
+        const int cw = w0 + sub * VEC;
+        const bool col_ok = cw < p.W;
+        Vec<VEC> t[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) t[d].v[v] = 0.f;
+        for (int64_t base = lo; base < hi; base += LPR) {
+          const int64_t e = base + sub;
+          int colv = 0, codev = 0;
+          if (e < hi) { colv = p.col[e]; codev = p.code[e]; }
+          const int m = static_cast<int>(hi - base < LPR ? hi - base : LPR);
+          for (int j0 = 0; j0 < m; j0 += 4) {
+            Vec<VEC> sv[4];
+            int d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + u;
+              const int c = __shfl(colv, j, LPR);
+              d[u] = __shfl(codev, j, LPR);
+              d[u] = d[u] < rest ? d[u] : rest;
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) sv[u].v[v] = 0.f;
+              if (j < m && col_ok) sv[u] = load_operand<VEC>(p.S, c, p.s_stride, cw);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (j0 + u < m)
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+                  for (int v = 0; v < VEC; ++v) t[dd].v[v] += d[u] == dd ? sv[u].v[v] : 0.f;
+          }
+        }
+        grad_finish<VEC>(p, gp, i, oq, cw, col_ok, t, pd);
+      }
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) pd[d] += __shfl_xor(pd[d], off);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) pd[d] *= grad_inv(p, i, d);
+      if (!gp.reduce_rows && sub == 0)
+        for (int d = 0; d < p.D; ++d) gp.dwt[oq * p.D + d] = pd[d];
+    }
+  }
+  if (gp.reduce_rows) {
+    if (sub == 0)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) rowsum[wave * G + slot][d] = live ? pd[d] : 0.f;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double acc = 0.0;
+      for (int r = 0; r < NW * G; ++r) acc += rowsum[r][threadIdx.x];
+      gp.blk[block_id * 4 + threadIdx.x] = acc;
+    }
+  }
+}
+
+// hub rows: add the slices in order, contract with dY, scale; one workgroup per hub row
+__global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p, const GradParams gp) {
+  const int r = blockIdx.x;
+  const int64_t q = p.long_rows[r];
+  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int64_t oq = p.scatter_out ? i : q;
+  const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
+  const int rest = p.D - 1;
+  __shared__ double tile[4][256];
+  double pd[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int w = threadIdx.x; w < p.W; w += 256) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; ++s)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) t[d] += gp.slice_T[(static_cast<int64_t>(s) * 4 + d) * p.W + w];
+    if (p.s_total) {
+      float lower = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) lower += d < rest ? t[d] : 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) t[d] = d == rest ? p.s_total[w] - lower : t[d];
+    }
+    const float dy = gp.dY[oq * gp.dy_stride + w % gp.dy_channels];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) pd[d] += static_cast<double>(dy) * t[d];
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) tile[d][threadIdx.x] = pd[d];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) tile[d][threadIdx.x] += tile[d][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) {
+    const int d = threadIdx.x;
+    const double v = tile[d][0] * grad_inv(p, i, d);
+    if (gp.reduce_rows) gp.blk[(gp.n_row_blocks + r) * 4 + d] = v;
+    else if (d < p.D) gp.dwt[oq * p.D + d] = static_cast<float>(v);
+  }
+}
+
+// dlut[d] = sum over the workgroup / hub-row partials, fixed order
+__global__ __launch_bounds__(256) void spmm_lut_grad_final_kernel(const double* __restrict__ blk, int64_t n, int D,
+                                                                  float* __restrict__ out) {
+  __shared__ double red[256];
+  const int d = blockIdx.x;
+  double s = 0.0;
+  for (int64_t b = threadIdx.x; b < n; b += 256) s += blk[b * 4 + d];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && d < D) out[d] = static_cast<float>(red[0]);
+}
+
+template <int VEC, int LPR>
+int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut) {
+  constexpr int G = kWave / LPR;
+  const int64_t row_blocks = (p.n_rows + 4 * G - 1) / (4 * G);
+  gp.n_row_blocks = row_blocks;
+  const int64_t blocks = row_blocks + p.n_slices;
+  if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "lut_grad: too many rows for one launch");
+  hipLaunchKernelGGL((spmm_lut_grad_kernel<VEC, LPR>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p, gp);
+  if (int rc = gnan::check_launch("spmm_lut_grad_kernel")) return rc;
+  if (p.n_slices > 0) {
+    hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel, dim3(static_cast<unsigned>(p.n_long)), dim3(256), 0, st, p, gp);
+    if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
+  }
+  if (gp.reduce_rows) {
+    hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(4), dim3(256), 0, st, gp.blk, row_blocks + p.n_long, p.D, dlut);
+    return gnan::check_launch("spmm_lut_grad_final_kernel");
+  }
+  return GNAN_OK;
+}
+
+template <int VEC>
+int launch_lut_grad_lpr(const Params& p, const GradParams& gp, int lpr, hipStream_t st, float* dlut) {
+  switch (lpr) {
+    case 1: return launch_lut_grad<VEC, 1>(p, gp, st, dlut);
+    case 2: return launch_lut_grad<VEC, 2>(p, gp, st, dlut);
+    case 4: return launch_lut_grad<VEC, 4>(p, gp, st, dlut);
+    case 8: return launch_lut_grad<VEC, 8>(p, gp, st, dlut);
+    case 16: return launch_lut_grad<VEC, 16>(p, gp, st, dlut);
+    case 32: return launch_lut_grad<VEC, 32>(p, gp, st, dlut);
+    default: return launch_lut_grad<VEC, 64>(p, gp, st, dlut);
+  }
+}
+
+size_t lut_grad_blk_entries(const gnan_spmm_args* a, int vec, int lpr) {
+  const int G = kWave / lpr;
+  return static_cast<size_t>((a->n_rows + 4 * G - 1) / (4 * G)) + static_cast<size_t>(a->n_long > 0 ? a->n_long : 0);
+}
+
+}  // namespace
+
+extern "C" size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduce_rows) {
+  if (!a || a->n_rows <= 0) return 0;
+  int vec, lpr;
+  pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
+  size_t bytes = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
+  bytes = (bytes + 7) / 8 * 8;
+  if (reduce_rows) bytes += lut_grad_blk_entries(a, vec, lpr) * 4 * sizeof(double);
+  return bytes;
+}
+
+extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stride, int32_t dy_channels,
+                                  float* dwt, int32_t reduce_rows, void* workspace, size_t workspace_bytes,
+                                  gnan_stream_t stream) {
+  if (int rc = validate(a)) return rc;
+  GNAN_REQUIRE(dwt != nullptr, "lut_grad: null output");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->n_rows == 0) {
+    if (reduce_rows) {
+      hipError_t e = hipMemsetAsync(dwt, 0, static_cast<size_t>(a->D) * sizeof(float), st);
+      if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "lut_grad: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    return GNAN_OK;
+  }
+  GNAN_REQUIRE(dY != nullptr && dy_channels >= 1 && dy_stride >= dy_channels, "lut_grad: bad dY");
+  if (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->s_dtype != GNAN_F32 || a->weight_by_col)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "lut_grad: needs the CSR layout, D <= 4, one weight channel, fp32 operand rows");
+  GNAN_REQUIRE(a->W % dy_channels == 0, "lut_grad: dy_channels must divide W");
+  const size_t need = gnan_spmm_lut_grad_workspace_bytes(a, reduce_rows);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "lut_grad: workspace %zu B < required %zu B", workspace_bytes, need);
+  const Params p = make_params(a);
+  int vec, lpr;
+  pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
+  GradParams gp;
+  gp.dY = dY; gp.dy_stride = dy_stride; gp.dy_channels = dy_channels; gp.dwt = dwt; gp.reduce_rows = reduce_rows;
+  gp.slice_T = static_cast<float*>(workspace);
+  size_t off = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
+  off = (off + 7) / 8 * 8;
+  gp.blk = reinterpret_cast<double*>(static_cast<char*>(workspace) + off);
+  gp.n_row_blocks = 0;
+  return vec == 4 ? launch_lut_grad_lpr<4>(p, gp, lpr, st, dwt) : launch_lut_grad_lpr<1>(p, gp, lpr, st, dwt);
+}
+
 extern "C" int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream) {
   if (int rc = validate(a)) return rc;
   if (a->n_rows == 0) return GNAN_OK;

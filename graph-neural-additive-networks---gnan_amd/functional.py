@@ -382,12 +382,43 @@ def shell_sums_launch(g: HopGraph, S: torch.Tensor, lut_like: torch.Tensor, with
     return T
 
 
+def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_cnt: bool, with_rest: bool,
+                    row_ids: Optional[torch.Tensor], s_total: Optional[torch.Tensor], reduce_rows: bool) -> torch.Tensor:
+    """``gnan_spmm_lut_grad``: ``dwt[q, d] = inv(q, d) * sum_w dY[q, w % dY.shape[1]] * T[q, d, w]`` without the
+    ``[n, D, W]`` shell sums; ``reduce_rows`` sums over the rows -> ``[D, 1]``, else ``[n_out, D, 1]``."""
+    S = S.detach().float()
+    if S.stride(1) != 1:
+        S = S.contiguous()
+    dY = dY.detach().float().contiguous()
+    n_out = g.n_rows if row_ids is None else int(row_ids.numel())
+    if with_rest and s_total is None:
+        s_total = column_sums(S)
+    if not with_rest:
+        s_total = None
+    scatter = False
+    if row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
+        row_ids, plan = g.degree_schedule()
+        scatter = True
+    else:
+        plan = g.long_row_plan(row_ids)
+    out = torch.zeros((D,) if reduce_rows else (n_out, D), dtype=torch.float32, device=S.device)
+    lut_like = torch.empty((D, 1), dtype=torch.float32, device=S.device)       # only its shape is read
+    a = _spmm_args(g, S, lut_like, use_cnt, s_total, out.view(-1, 1), row_ids, False, plan=plan, scatter_out=scatter)
+    a.n_rows, a.y_stride = n_out, S.shape[1]                                   # Y is not written by this entry point
+    need = _lib.lib().gnan_spmm_lut_grad_workspace_bytes(a, int(reduce_rows))
+    ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=S.device)
+    _lib.check(_lib.lib().gnan_spmm_lut_grad(a, _lib.ptr(dY), dY.stride(0), dY.shape[1], _lib.ptr(out), int(reduce_rows),
+                                             _lib.ptr(ws), ws.numel() * 8, _lib.stream_of(S)), "gnan_spmm_lut_grad")
+    return out.unsqueeze(-1)
+
+
 class _RhoAggregate(torch.autograd.Function):
     """Y = A_w(lut, cnt) @ S  with the rest-bucket term; gradients for S and the weight table."""
 
     @staticmethod
     def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids, s_total=None, reduce_cr=0):
         ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids, ctx.reduce_cr = g, use_cnt, with_rest, row_ids, reduce_cr
+        ctx.s_total = None if s_total is None else s_total.detach()
         ctx.save_for_backward(S, lut)
         return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr)
 
@@ -396,11 +427,15 @@ class _RhoAggregate(torch.autograd.Function):
         S, lut = ctx.saved_tensors
         g, use_cnt, with_rest, row_ids = ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids
         dY = dY.contiguous().float()
+        dY_out = dY                           # as the forward returned it: [n_out, W] or, with the fused sum, [n_out, cr]
         W = S.shape[1]
-        if ctx.reduce_cr:                     # the fused feature sum broadcasts its gradient over the features
-            dY = dY.repeat(1, W // ctx.reduce_cr)
         D, Cw = lut.shape[-2], lut.shape[-1]
         per_row = lut.dim() == 3
+        # truncated-hop graphs: the table gradient comes out of one pass over the listed pairs (gnan_spmm_lut_grad)
+        fused_lut_grad = (ctx.needs_input_grad[1] and not g.is_dense and D <= 4 and Cw == 1
+                          and S.dtype == torch.float32)
+        if ctx.reduce_cr and (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not fused_lut_grad)):
+            dY = dY.repeat(1, W // ctx.reduce_cr)   # the fused feature sum broadcasts its gradient over the features
         rows = None if row_ids is None else row_ids.long()
         cnt = g.cnt if rows is None else g.cnt[rows]
         inv = (1.0 / cnt.clamp_min(1).float()) if use_cnt else None            # [n_out, D]
@@ -420,11 +455,16 @@ class _RhoAggregate(torch.autograd.Function):
                 w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
                 dS = dS + (w_rest * dY).sum(0, keepdim=True)
 
-        if ctx.needs_input_grad[1]:
-            T = shell_sums_launch(g, S, lut, with_rest, row_ids)                  # [n_out, D, W]
-            dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
-            if inv is not None:
-                dwt = dwt * inv.unsqueeze(-1)                                     # [n_out, D, Cw]
+        if ctx.needs_input_grad[1] and fused_lut_grad and not per_row:
+            dlut = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, True)       # [D, 1]
+        elif ctx.needs_input_grad[1]:
+            if fused_lut_grad:
+                dwt = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, False)   # [n_out, D, 1]
+            else:
+                T = shell_sums_launch(g, S, lut, with_rest, row_ids)              # [n_out, D, W]
+                dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
+                if inv is not None:
+                    dwt = dwt * inv.unsqueeze(-1)                                 # [n_out, D, Cw]
             if per_row:
                 if rows is None:
                     dlut = dwt

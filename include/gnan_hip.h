@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 13
+#define GNAN_ABI_VERSION 14
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -270,6 +270,22 @@ int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float*
 int gnan_dense_to_code(const float* nd, const float* norm, int64_t n_rows, int64_t n_cols,
                        int64_t in_stride, uint8_t* code, int32_t* cnt /* [n_rows, 256] */,
                        int32_t* status /* [2] */, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gradient of gnan_spmm_fwd w.r.t. its weight table, fused (the truncated-hop case: CSR layout, D <= 4, Cw == 1,
+ * fp32 operand rows; anything else returns GNAN_ERR_UNSUPPORTED — use gnan_spmm_shell_sums then).
+ *   dwt[q, d] = inv(q, d) * sum_w dY[q, w % dy_channels] * T[q, d, w]
+ * with T the per-shell sums of the operand over row q's listed pairs (rest bucket: s_total - lower shells when
+ * a->s_total is set) and inv = 1 / max(cnt, 1) when a->cnt is set.  dy_channels == W, or the fused read-out's
+ * reduce_cr (its gradient is broadcast over the feature columns).  Rows are addressed as in the forward
+ * (row_ids / scatter_out / hub-row plan); a->lut is only consulted for D and Cw, a->Y is ignored.
+ * reduce_rows == 0: dwt is [n_rows, D];  != 0: dwt is [D] = the sum over rows (fixed-order float64 partials).
+ * This is the backward of models.py:368-371 w.r.t. rho's outputs at the D distinct distances.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduce_rows);
+int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stride, int32_t dy_channels,
+                       float* dwt, int32_t reduce_rows, void* workspace, size_t workspace_bytes,
+                       gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs hop distances on the GPU (graphs small enough for N x N bytes)

@@ -385,6 +385,38 @@ def test_table_build_kernel_degenerate_weights():
     assert O.rel_err(pwl.evaluate_reference(x, tc, False), truth) <= 1e-5
 
 
+@pytest.mark.parametrize("W,dyc,use_cnt,with_rest", [(64, 64, True, True), (64, 1, True, True), (1, 1, True, True),
+                                                      (8, 2, False, True), (6, 6, True, False), (16, 16, False, False),
+                                                      (300, 4, True, True)])
+def test_fused_table_gradient_equals_shell_sums_route(W, dyc, use_cnt, with_rest):
+    """gnan_spmm_lut_grad (one pass, no [n, D, W] tensor) == shell sums contracted with dY in float64, for rows, hub
+    rows, row subsets, the broadcast gradient of the fused read-out (dy_channels < W) and both reduction modes."""
+    from gnan_amd.functional import lut_grad_launch, shell_sums_launch
+    rng = np.random.default_rng(W * 3 + dyc)
+    n, K = 3000, 2
+    D = K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 5000), (2999, 2100)])
+    g = _graph(rowptr, col, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    dummy = torch.zeros((D, 1), device=DEV)
+    for ids in (None, torch.from_numpy(rng.integers(0, n, 500).astype(np.int32)).to(DEV)):
+        n_out = n if ids is None else 500
+        dY = torch.from_numpy(rng.standard_normal((n_out, dyc)).astype(np.float32)).to(DEV)
+        T = shell_sums_launch(g, S, dummy, with_rest, ids).double()                       # [n_out, D, W]
+        want = (T * dY.double().repeat(1, W // dyc).unsqueeze(1)).sum(2)                  # [n_out, D]
+        if use_cnt:
+            cnt = g.cnt if ids is None else g.cnt[ids.long()]
+            want = want / cnt.clamp_min(1).double()
+        rows = lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, False)
+        assert rows.shape == (n_out, D, 1)
+        scale = float(want.abs().max())
+        assert float((rows[..., 0].double() - want).abs().max()) <= 2e-5 * scale
+        total = lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, True)
+        assert total.shape == (D, 1)
+        assert float((total[:, 0].double() - want.sum(0)).abs().max()) <= 2e-5 * float(want.abs().sum(0).max())
+        assert torch.equal(total, lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, True))   # fixed order
+
+
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order and stored in place == rows processed in natural order (same arithmetic per row)."""
     from gnan_amd import functional

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Forward+backward of models.TensorGNAN on the C4-shaped graph (R-MAT 10M / 100M, F = 64): where a training step's time goes.
+    python tools/train_step_c4.py [nodes edges scale]        (under rocprofv3 --kernel-trace --stats for the kernel split)"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import gnan_amd  # noqa: E402,F401
+from gnan_amd import synthetic as syn  # noqa: E402
+from gnan_amd.models import TensorGNAN  # noqa: E402
+
+DEV = "cuda"
+N, E, SCALE = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (10_000_000, 100_000_000, 24)))
+F = 64
+
+
+class Bag:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def main():
+    torch.manual_seed(0)
+    src, dst = syn.rmat_edges(SCALE, N, E, seed=0, device=DEV)
+    g = syn.hop1_csr(src, dst, N)
+    del src, dst
+    x = syn.block_features(N, F, 0, N, seed=1, device=DEV)
+    y = torch.randn(N, 1, device=DEV)
+    m = TensorGNAN(F, 1, 3, hidden_channels=64, device=DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            torch.nn.init.xavier_normal_(p, gain=1.0) if p.dim() == 2 else p.normal_(0.0, 0.5)
+    m = m.to(DEV).eval()                       # eval: the reference trains without Dropout after its first epoch
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    d = Bag(x=x, edge_index=None, gnan_graph=g)
+    out = {"what": f"train_step_rmat_{N}n_{E}e_F{F}"}
+
+    def fwd():
+        with torch.no_grad():
+            return m.forward(d)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m.forward(d), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for name, fn, reps in (("fwd_ms", fwd, 5), ("fwd_bwd_adam_ms", step, 5)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / reps * 1e3
+    out["loss"] = float(step())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
