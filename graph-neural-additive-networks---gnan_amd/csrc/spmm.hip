@@ -41,6 +41,7 @@ struct Params {
   int weight_by_col, minus_rest;
   int reduce_cr;  // > 0: store only the per-channel sums over columns w = c (mod reduce_cr)
   int scatter_out;  // output row q is stored at Y[row_ids[q]] (rows are PROCESSED in row_ids order, e.g. by degree)
+  int s_by_code;    // the operand row of pair (i, c, d) is S[c * D + d]: one pre-weighted row per (node, hop code)
   float* Y;
   int64_t y_stride;
   int64_t long_threshold;
@@ -289,7 +290,8 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           d[u] = __shfl(codev[j % IPL], j / IPL, LPR);
           d[u] = d[u] < rest ? d[u] : rest;
           s[u].zero();
-          if (j < m && col_ok) s[u].load(p.S, c[u], p.s_stride, cw);
+          if (j < m && col_ok)
+            s[u].load(p.S, p.s_by_code ? static_cast<int64_t>(c[u]) * p.D + d[u] : static_cast<int64_t>(c[u]), p.s_stride, cw);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -397,7 +399,7 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
         int d = __shfl(codev, j);
         d = d < rest ? d : rest;
         if (j < m && col_ok) {
-          const Vec<VEC> sv = load_operand<VEC>(p.S, c, p.s_stride, cw);
+          const Vec<VEC> sv = load_operand<VEC>(p.S, p.s_by_code ? static_cast<int64_t>(c) * p.D + d : static_cast<int64_t>(c), p.s_stride, cw);
           if constexpr (SMALLD) {
             const float w = sw.pick(d);
 #pragma unroll
@@ -652,6 +654,8 @@ int validate(const gnan_spmm_args* a) {
       return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: s_total must be 16-B aligned");
   }
   GNAN_REQUIRE(!(a->weight_by_col && a->s_total), "spmm: weight_by_col excludes the rest-bucket term (add it outside)");
+  GNAN_REQUIRE(!a->s_by_code || (a->rowptr != nullptr && a->s_total == nullptr && a->s_dtype == GNAN_F32),
+               "spmm: s_by_code needs the CSR layout, fp32 rows and no rest-bucket term");
   GNAN_REQUIRE(!a->scatter_out || a->row_ids, "spmm: scatter_out needs row_ids");
   if (a->reduce_cr != 0) {
     const int cr = a->reduce_cr;
@@ -687,6 +691,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total;
   p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest; p.reduce_cr = a->reduce_cr;
   p.scatter_out = a->scatter_out;
+  p.s_by_code = a->s_by_code;
   p.Y = a->Y; p.y_stride = a->y_stride;
   p.long_threshold = a->n_long > 0 ? a->long_threshold : INT64_MAX;
   p.long_rows = a->long_rows; p.long_slice_ptr = a->long_slice_ptr;

@@ -69,6 +69,7 @@ FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to pin one of the three evaluatio
 PWL_MIN_WORK = 1 << 24       # AUTO tabulates the shape functions once n*F look-ups outweigh the table build
 PWL_MIN_WORK_GRAD = 1 << 18  # ... much earlier when a backward pass follows: the moment kernel replaces a full recompute
 PWL_MIN_NODES = 1 << 14      # inference on small graphs: the matrix-core kernel beats table build + look-up
+NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) operand while its rows stay <= 128 B
 
 
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32,
@@ -278,7 +279,8 @@ def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_tota
 # rho-weighted aggregation
 # =============================================================================
 def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut, weight_by_col=False,
-               minus_rest=False, plan=None, workspace=None, reduce_cr=0, scatter_out=False) -> _lib.SpmmArgs:
+               minus_rest=False, plan=None, workspace=None, reduce_cr=0, scatter_out=False,
+               s_by_code=False) -> _lib.SpmmArgs:
     D, Cw = lut.shape[-2], lut.shape[-1]
     a = _lib.SpmmArgs(
         n_rows=out.shape[0], n_cols=g.n_cols,
@@ -295,7 +297,8 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         long_slice_ptr=_lib.ptr(plan.slice_ptr) if plan is not None else None,
         n_long=(plan.n_long if plan is not None else 0), n_slices=(plan.n_slices if plan is not None else 0),
         slice_edges=(plan.slice_edges if plan is not None else 0),
-        workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0))
+        workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0),
+        s_by_code=int(s_by_code))
     return a
 
 
@@ -324,9 +327,11 @@ DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row
 
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
                 row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
-                minus_rest: bool = False, s_total: Optional[torch.Tensor] = None, reduce_cr: int = 0) -> torch.Tensor:
+                minus_rest: bool = False, s_total: Optional[torch.Tensor] = None, reduce_cr: int = 0,
+                s_by_code: bool = False) -> torch.Tensor:
     """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``.
-    ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns."""
+    ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns.
+    ``s_by_code``: ``S`` is ``[n_cols * D, W]`` and the pair with neighbour ``c`` and hop code ``d`` reads row ``c*D + d``."""
     _lib.require_device(S, lut, g.code)
     S = S.detach()
     if S.dtype != torch.bfloat16:                        # bf16 rows: storage format only, accumulation stays fp32
@@ -337,7 +342,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     per_row = lut.dim() == 3
     if lut.shape[-2] != g.n_codes:
         raise ValueError(f"weight table has {lut.shape[-2]} codes, graph has {g.n_codes}")
-    if S.shape[0] != g.n_cols:
+    if S.shape[0] != g.n_cols * (g.n_codes if s_by_code else 1):
         raise ValueError(f"operand has {S.shape[0]} rows, graph has {g.n_cols} neighbour nodes")
     if S.shape[1] % lut.shape[-1] != 0:
         raise ValueError("operand width must be a multiple of the weight-channel count")
@@ -356,7 +361,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     else:
         plan = g.long_row_plan(row_ids)
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
-                   reduce_cr=reduce_cr, scatter_out=scatter)
+                   reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
     ws = None
     if need:
@@ -446,8 +451,21 @@ class _RhoAggregate(torch.autograd.Function):
             if rows is not None:
                 dY_full = torch.zeros((g.n_rows, W), dtype=torch.float32, device=dY.device)
                 dY_full.index_add_(0, rows, dY)
-            dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
-                             weight_by_col=True, minus_rest=with_rest)
+            if not g.is_dense and Cw == 1 and W * D <= NARROW_DS_MAX_WIDTH:
+                # narrow operand: fold the per-pair weight into a pre-weighted operand with one row per (node, hop code),
+                # Z[i, d] = (wt(i, d) - wt(i, rest)) dY[i], and gather it over the transposed adjacency with unit weights —
+                # one random request per listed pair instead of the operand row plus the neighbour's table row
+                wt = (lut[..., 0] if per_row else lut[:, 0].unsqueeze(0)).float()                 # [N or 1, D]
+                if use_cnt:
+                    wt = wt / g.cnt.clamp_min(1).float()
+                if with_rest:
+                    wt = wt - wt[:, D - 1:D]
+                Z = (wt.unsqueeze(-1) * dY_full.unsqueeze(1)).reshape(g.n_rows * D, W)
+                dS = spmm_launch(g.transposed(), Z, torch.ones((D, 1), device=Z.device), False, False, None,
+                                 s_by_code=True)
+            else:
+                dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
+                                 weight_by_col=True, minus_rest=with_rest)
             if with_rest:
                 # d/dS_j of  wt(i, rest) * total  : the same vector for every j
                 l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 14
+#define GNAN_ABI_VERSION 15
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -231,6 +231,9 @@ typedef struct gnan_spmm_args {
   int32_t slice_edges;
   void* workspace;
   size_t workspace_bytes;
+  int32_t s_by_code;             /* gnan_spmm_fwd only: S has n_cols * D rows and pair (i, c, d) reads S[c * D + d] — the
+                                    backward w.r.t. a narrow S folds the per-pair weight into a pre-weighted operand
+                                    Z[i, d, :] = (wt(i, d) - wt(i, D-1)) * dY[i, :] and gathers it with unit weights */
 } gnan_spmm_args;
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
