@@ -383,10 +383,16 @@ struct MomentParams {
   const float* g;      // upstream gradient: [n, F*C] (per feature) or [n, C] (sum_features)
   int64_t g_stride;
   float* M;            // [T, 2, C], zeroed by the caller
+  // fixed-point mode (FIXED): LDS float atomics run at ~200 G/s on gfx950 (a compare-and-swap loop), integer ones at
+  // ~2500 G/s (tools/lds_atomic_rate.hip), so the bins hold round(v * 2^e) in 64-bit integers: 12x cheaper to update,
+  // and — integer addition being associative — bit-reproducible.  scales = {2^e0, 2^e1} for M0 / M1 terms.
+  const double* scales;
+  unsigned long long* Mi;   // [T, 2, C] two's-complement sums, zeroed by the caller
 };
 
-template <int FG, int BS>
+template <int FG, int BS, bool FIXED>
 __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp) {
+  using bin_t = std::conditional_t<FIXED, unsigned long long, float>;
   constexpr int FPT = Map<FG, BS>::FPT, TPN = Map<FG, BS>::TPN, NODES = Map<FG, BS>::NODES;
   const Params& p = mp.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -401,9 +407,11 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
   const int base = p.off[k0];
   const int tot = p.off[k0 + nf] - base;
   float* anchor_l = smem;
-  float* bins = smem + tot;                        // [tot][2][C]
+  bin_t* bins = reinterpret_cast<bin_t*>(smem + (tot + 1) / 2 * 2);   // [tot][2][C], 8-byte aligned
   for (int i = tid; i < tot; i += BS) anchor_l[i] = p.anchor[base + i];
-  for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = 0.f;
+  for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = bin_t(0);
+  double s0 = 1.0, s1 = 1.0;
+  if constexpr (FIXED) { s0 = mp.scales[0]; s1 = mp.scales[1]; }
   if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
   __syncthreads();
   int po[FPT], pn[FPT];
@@ -427,35 +435,54 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
     for (int f = 0; f < FPT; ++f) {
       if (live[f]) {
         const float d = xv[f] - anchor_l[idx[f]];
-        float* b = bins + static_cast<int64_t>(idx[f]) * 2 * C;
+        bin_t* b = bins + static_cast<int64_t>(idx[f]) * 2 * C;
         for (int c = 0; c < C; ++c) {
           const float gv = gr[p.sum_features ? c : f * C + c];
-          atomicAdd(b + c, gv);
-          atomicAdd(b + C + c, gv * d);
+          if constexpr (FIXED) {
+            atomicAdd(b + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv) * s0)));
+            atomicAdd(b + C + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv * d) * s1)));
+          } else {
+            atomicAdd(b + c, gv);
+            atomicAdd(b + C + c, gv * d);
+          }
         }
       }
     }
   }
   __syncthreads();
-  float* out = mp.M + static_cast<int64_t>(base) * 2 * C;
-  for (int i = tid; i < tot * 2 * C; i += BS) {
-    const float v = bins[i];
-    if (v != 0.f) atomicAdd(out + i, v);
+  if constexpr (FIXED) {
+    unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2 * C;
+    for (int i = tid; i < tot * 2 * C; i += BS) {
+      const unsigned long long v = bins[i];
+      if (v != 0ull) atomicAdd(out + i, v);
+    }
+  } else {
+    float* out = mp.M + static_cast<int64_t>(base) * 2 * C;
+    for (int i = tid; i < tot * 2 * C; i += BS) {
+      const float v = bins[i];
+      if (v != 0.f) atomicAdd(out + i, v);
+    }
   }
 }
 
 template <int FG, int BS>
 int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
+  const bool fixed = mp.Mi != nullptr;
+  const void* fn = fixed ? reinterpret_cast<const void*>(&fpwl_moments_kernel<FG, BS, true>)
+                         : reinterpret_cast<const void*>(&fpwl_moments_kernel<FG, BS, false>);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fpwl_moments_kernel<FG, BS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const Params& p = mp.f;
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
   if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
-  hipLaunchKernelGGL((fpwl_moments_kernel<FG, BS>), dim3(static_cast<unsigned>(bx), static_cast<unsigned>(p.n_groups)),
-                     dim3(BS), lds, st, mp);
+  const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(p.n_groups));
+  if (fixed) {
+    hipLaunchKernelGGL((fpwl_moments_kernel<FG, BS, true>), grid, dim3(BS), lds, st, mp);
+  } else {
+    hipLaunchKernelGGL((fpwl_moments_kernel<FG, BS, false>), grid, dim3(BS), lds, st, mp);
+  }
   return gnan::check_launch("fpwl_moments_kernel");
 }
 
@@ -592,17 +619,22 @@ Params base_params(const gnan_fpwl_args* a) {
 }
 }  // namespace
 
-extern "C" int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, float* moments,
-                                 gnan_stream_t stream) {
+namespace {
+int moments_common(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, float* moments,
+                   const double* scales, int64_t* moments_fixed, gnan_stream_t stream) {
   if (int rc = common_checks(a)) return rc;
   if (a->n == 0) return GNAN_OK;
-  GNAN_REQUIRE(grad && moments, "fpwl_moments: null grad / moments");
   const int64_t gw = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(grad_stride >= gw, "fpwl_moments: grad row stride smaller than its width");
   MomentParams mp;
   mp.f = base_params(a);
   mp.g = grad; mp.g_stride = grad_stride; mp.M = moments;
-  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
+  mp.scales = scales; mp.Mi = reinterpret_cast<unsigned long long*>(moments_fixed);
+  const size_t bin = moments_fixed ? sizeof(unsigned long long) : sizeof(float);
+  const size_t pieces = static_cast<size_t>(a->max_group_pieces);
+  const size_t lds = (pieces + 1) / 2 * 2 * sizeof(float) + pieces * 2 * static_cast<size_t>(a->C) * bin;
+  if (lds > 150 * 1024)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_moments: %zu B of bins per feature group exceed LDS", lds);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a->features_per_group) {
     case 1: return launch_moments<1, 256>(mp, lds, st);
@@ -611,6 +643,19 @@ extern "C" int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int
     case 8: return launch_moments<8, 512>(mp, lds, st);
     default: return launch_moments<16, 512>(mp, lds, st);
   }
+}
+}  // namespace
+
+extern "C" int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, float* moments,
+                                 gnan_stream_t stream) {
+  GNAN_REQUIRE(a == nullptr || a->n == 0 || (grad && moments), "fpwl_moments: null grad / moments");
+  return moments_common(a, grad, grad_stride, moments, nullptr, nullptr, stream);
+}
+
+extern "C" int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride,
+                                       const double* scales, int64_t* moments, gnan_stream_t stream) {
+  GNAN_REQUIRE(a == nullptr || a->n == 0 || (grad && moments && scales), "fpwl_moments_fixed: null grad / scales / moments");
+  return moments_common(a, grad, grad_stride, nullptr, scales, moments, stream);
 }
 
 extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {

@@ -102,8 +102,27 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     return (out, total) if want_total else out
 
 
+MOMENTS_FIXED_POINT = True    # accumulate the per-piece moments in 64-bit fixed point (integer LDS atomics, reproducible)
+_ABS_MAX_CACHE = {}           # (data_ptr, version, shape) -> device scalar: max |x| of the (static) feature matrix
+
+
+def _abs_max_cached(x: torch.Tensor) -> torch.Tensor:
+    key = (x.data_ptr(), x._version, tuple(x.shape), x.device)
+    hit = _ABS_MAX_CACHE.get(key)
+    if hit is None:
+        if len(_ABS_MAX_CACHE) > 16:
+            _ABS_MAX_CACHE.clear()
+        hit = _ABS_MAX_CACHE[key] = x.abs().max().double()
+    return hit
+
+
 def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) -> torch.Tensor:
-    """Per-piece moments of the upstream gradient (``gnan_fpwl_moments``) -> ``[T, 2, C]``."""
+    """Per-piece moments of the upstream gradient (``gnan_fpwl_moments[_fixed]``) -> ``[T, 2, C]`` float32.
+
+    Fixed-point route (default where the 64-bit bins fit LDS): every term is added as ``round(v * 2^e)`` with ``e``
+    chosen on the device from ``max |grad|`` and ``max |x - anchor|`` such that n terms cannot overflow 62 bits —
+    per-term resolution 2^-(61 - log2 n) of the largest term, i.e. far below fp32 — and the sums do not depend on
+    the order of the atomics."""
     x = x.detach().float()
     if x.stride(1) != 1:
         x = x.contiguous()
@@ -112,11 +131,24 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) ->
         grad = grad.contiguous()
     n, F = x.shape
     C = t.val.shape[1]
-    M = torch.zeros((t.anchor.numel(), 2, C), dtype=torch.float32, device=x.device)
+    T = t.anchor.numel()
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features), out=None, out_stride=0)
+    mgp = t.max_group_pieces
+    if MOMENTS_FIXED_POINT and n > 0 and (mgp + 1) // 2 * 8 + mgp * 2 * C * 8 <= 150 * 1024:
+        bits = 61 - max(1, (max(n, 2) - 1).bit_length())            # a bin receives at most n terms
+        tiny = torch.finfo(torch.float64).tiny
+        g_max = grad.abs().max().double().clamp_min(tiny)
+        d_max = (_abs_max_cached(x) + t.anchor.abs().max().double()).clamp_min(tiny)
+        e = torch.stack([torch.floor(bits - torch.log2(g_max)), torch.floor(bits - torch.log2(g_max * d_max))])
+        scales = torch.exp2(e.clamp(-1000.0, 1000.0))
+        Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
+        _lib.check(_lib.lib().gnan_fpwl_moments_fixed(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(scales), _lib.ptr(Mi),
+                                                      _lib.stream_of(x)), "gnan_fpwl_moments_fixed")
+        return (Mi.double() / scales.view(1, 2, 1)).float()
+    M = torch.zeros((T, 2, C), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().gnan_fpwl_moments(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(M), _lib.stream_of(x)),
                "gnan_fpwl_moments")
     return M

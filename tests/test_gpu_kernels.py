@@ -306,9 +306,11 @@ def test_fused_feature_sum_gradients():
 
 @pytest.mark.parametrize("F,L,H,C,sum_features", [(5, 3, 8, 1, True), (20, 3, 16, 2, False), (64, 3, 64, 1, False),
                                                    (3, 3, 16, 40, True)])
-def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features):
-    from gnan_amd import pwl
+@pytest.mark.parametrize("fixed", [True, False])
+def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkeypatch):
+    from gnan_amd import functional, pwl
     from gnan_amd.functional import _fpwl_moments
+    monkeypatch.setattr(functional, "MOMENTS_FIXED_POINT", fixed)
     sd = _mlp_state(F, L, H, C, True, seed=F)
     st = _stack(sd, F, L, H, C, True)
     t = pwl.build_tables(st)
@@ -317,9 +319,16 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features):
     g = torch.randn(n, C if sum_features else F * C, generator=torch.Generator().manual_seed(2))
     tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t])
     want = pwl.moments_reference(x, g, tc, sum_features)
-    got = _fpwl_moments(x.to(DEV), t, g.to(DEV), sum_features).cpu().double()
+    xd, gd = x.to(DEV), g.to(DEV)
+    got = _fpwl_moments(xd, t, gd, sum_features).cpu().double()
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-5 * scale
+    if fixed:                                   # integer accumulation: bit-reproducible, and exact to ~2^-40 of the largest term
+        assert torch.equal(_fpwl_moments(xd, t, gd, sum_features), _fpwl_moments(xd, t, gd, sum_features))
+        assert float((got - want).abs().max()) <= 1e-6 * scale
+        tiny = _fpwl_moments(xd, t, gd * 1e-30, sum_features).cpu().double()          # the scale follows the gradient's size
+        assert float((tiny - want * 1e-30).abs().max()) <= 2e-6 * scale * 1e-30
+        assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("n,F", [(70_000, 64), (300_000, 16), (5000, 32)])
