@@ -873,19 +873,29 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
         for (int d = 0; d < 4; ++d)
 #pragma unroll
           for (int v = 0; v < VEC; ++v) t[d].v[v] = 0.f;
-        for (int64_t base = lo; base < hi; base += LPR) {
-          const int64_t e = base + sub;
-          int colv = 0, codev = 0;
-          if (e < hi) { colv = p.col[e]; codev = p.code[e]; }
-          const int m = static_cast<int>(hi - base < LPR ? hi - base : LPR);
-          for (int j0 = 0; j0 < m; j0 += 4) {
+        // as in the forward: IW index pairs per round (IPL per lane), so narrow rows still see 16 gathers between
+        // two dependent index loads
+        constexpr int IW = LPR >= 8 ? LPR : 16;
+        constexpr int IPL = IW / LPR;
+        for (int64_t base = lo; base < hi; base += IW) {
+          int colv[IPL], codev[IPL];
+#pragma unroll
+          for (int r = 0; r < IPL; ++r) {
+            const int64_t e = base + sub * IPL + r;
+            colv[r] = codev[r] = 0;
+            if (e < hi) { colv[r] = p.col[e]; codev[r] = p.code[e]; }
+          }
+          const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
+#pragma unroll(IPL > 1 ? IW / 4 : 1)
+          for (int j0 = 0; j0 < (IPL > 1 ? IW : m); j0 += 4) {
+            if (IPL > 1 && j0 >= m) break;
             Vec<VEC> sv[4];
             int d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int j = j0 + u;
-              const int c = __shfl(colv, j, LPR);
-              d[u] = __shfl(codev, j, LPR);
+              const int c = __shfl(colv[j % IPL], j / IPL, LPR);
+              d[u] = __shfl(codev[j % IPL], j / IPL, LPR);
               d[u] = d[u] < rest ? d[u] : rest;
 #pragma unroll
               for (int v = 0; v < VEC; ++v) sv[u].v[v] = 0.f;

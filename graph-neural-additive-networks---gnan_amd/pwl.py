@@ -347,7 +347,7 @@ def parameter_grads_from_moments(p, t: PwlTables, M: torch.Tensor, evaluate):
     pieces = off[1:] - off[:-1]
     feat = torch.repeat_interleave(torch.arange(F, device=M.device), pieces)      # feature of every piece
     local = torch.arange(M.shape[0], device=M.device) - off[:-1][feat]
-    rows = 2 * int(pieces.max())
+    rows = 2 * t.max_pieces                                   # host-known: no device->host copy in the backward
     U = torch.zeros(rows, F, dtype=torch.float64, device=M.device)
     W = torch.zeros(rows, F, C, dtype=torch.float64, device=M.device)
     U[2 * local, feat], U[2 * local + 1, feat] = u1, u2
