@@ -352,7 +352,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 // ---------------------------------------------------------------------------------------------
 // long kernel: one 256-thread workgroup per slice of a hub row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool SMALLD>
+template <int VEC, int LPR, bool SMALLD, bool DENSE = false>
 __device__ __forceinline__ void slice_body(const Params& p, const int s) {
   constexpr int G = kWave / LPR;
   constexpr int TILE = LPR * VEC;
@@ -370,7 +370,9 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
   }
   const int64_t q = p.long_rows[a];
   const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
-  const int64_t row_lo = load_rowptr(p, i), row_hi = load_rowptr(p, i + 1);
+  // dense layout: the "pairs" of row i are all n_cols neighbours, the column is the position, codes sit at i*n_cols
+  const int64_t row_lo = DENSE ? 0 : load_rowptr(p, i), row_hi = DENSE ? p.n_cols : load_rowptr(p, i + 1);
+  const int64_t code_base = DENSE ? i * p.n_cols : 0;
   const int64_t lo = row_lo + static_cast<int64_t>(s - p.long_slice_ptr[a]) * p.slice_edges;
   const int64_t hi = lo + p.slice_edges < row_hi ? lo + p.slice_edges : row_hi;
   const int rest = p.D - 1;
@@ -388,8 +390,8 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
       const int64_t e = base + lane;
       int colv = 0, codev = 0;
       if (e < hi) {
-        colv = p.col[e];
-        codev = p.code[e];
+        colv = DENSE ? static_cast<int>(e) : p.col[e];
+        codev = p.code[code_base + e];
       }
       const int m = static_cast<int>(hi - base < kWave ? hi - base : kWave);
 #pragma unroll 4
@@ -461,6 +463,10 @@ void spmm_kernel(const Params p) {
     }
     rows_body<VEC, LPR, false, SMALLD>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
   } else {
+    if (p.n_slices > 0) {      // few rows, many neighbours: every row is cut into slices, there are no row blocks
+      slice_body<VEC, LPR, SMALLD, true>(p, static_cast<int>(blockIdx.x));
+      return;
+    }
     rows_body<VEC, LPR, true, SMALLD>(p, static_cast<int64_t>(blockIdx.x));
   }
 }
@@ -601,8 +607,8 @@ template <int VEC, int LPR>
 int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
   constexpr int G = kWave / LPR;
   const int rows_per_block = 4 * G;
-  const int n_slices = dense ? 0 : p.n_slices;
-  const int64_t blocks = (p.n_rows + rows_per_block - 1) / rows_per_block + n_slices;
+  const int n_slices = p.n_slices;
+  const int64_t blocks = dense && n_slices > 0 ? n_slices : (p.n_rows + rows_per_block - 1) / rows_per_block + n_slices;
   if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: too many rows for one launch");
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
   if (dense) {
@@ -665,7 +671,8 @@ int validate(const gnan_spmm_args* a) {
     GNAN_REQUIRE(a->y_stride >= cr, "spmm: y_stride smaller than reduce_cr");
   }
   if (a->n_long > 0) {
-    GNAN_REQUIRE(a->rowptr != nullptr, "spmm: long-row plan needs the CSR layout");
+    GNAN_REQUIRE(a->rowptr != nullptr || (a->n_long == a->n_rows && a->long_threshold == 0),
+                 "spmm: a row plan for the dense layout must slice every row (n_long == n_rows, long_threshold == 0)");
     GNAN_REQUIRE(a->long_rows && a->long_slice_ptr && a->slice_edges > 0 && a->n_slices > 0,
                  "spmm: incomplete long-row plan");
   }

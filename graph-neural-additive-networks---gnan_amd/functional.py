@@ -69,6 +69,9 @@ FMLP_ALGO = _lib.FMLP_AUTO   # tests flip this to pin one of the three evaluatio
 PWL_MIN_WORK = 1 << 24       # AUTO tabulates the shape functions once n*F look-ups outweigh the table build
 PWL_MIN_WORK_GRAD = 1 << 18  # ... much earlier when a backward pass follows: the moment kernel replaces a full recompute
 PWL_MIN_NODES = 1 << 14      # inference on small graphs: the matrix-core kernel beats table build + look-up
+SUM_VIA_FEATURES_MAX_NODES = 32768   # table look-up with a feature sum and C > 1 on small graphs: per-feature pass + sum
+DENSE_SLICE_MAX_ROWS = 16384  # dense layout: slice every row over workgroups while row blocks alone would not fill the GPU
+DENSE_SLICE_MIN_COLS = 512
 NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) operand while its rows stay <= 128 B
 
 
@@ -82,6 +85,14 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         x = x.contiguous()
     n, F = x.shape
     C = t.val.shape[1]
+    if (sum_features and C > 1 and F >= 16 and n < SUM_VIA_FEATURES_MAX_NODES and n * F * C * 4 <= (1 << 30)
+            and out_dtype == torch.float32):
+        # few nodes, many features, several channels (Cora: 2708 x 1434 x 7): the summing kernel walks all feature groups
+        # inside one workgroup per 64-128 nodes — a few dozen workgroups.  (node block, feature group) workgroups fill
+        # the GPU instead; the feature sum over the [n, F, C] result is a 100-MB reduction
+        per = _fpwl_launch(x, t, False)
+        out = per.view(n, F, C).sum(dim=1)
+        return (out, None) if want_total else out
     out = torch.empty((n, C if sum_features else F * C), dtype=out_dtype, device=x.device)
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
@@ -386,7 +397,8 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
         s_total = None
     scatter = False
     if g.is_dense:
-        plan = None
+        # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
+        plan = g.dense_slice_plan(n_out) if (n_out < DENSE_SLICE_MAX_ROWS and g.n_cols >= DENSE_SLICE_MIN_COLS) else None
     elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
         row_ids, plan = g.degree_schedule()      # process rows by degree, store them in place
         scatter = True

@@ -51,6 +51,7 @@ class HopGraph:
     _transposed: Optional["HopGraph"] = field(default=None, repr=False)
     _degree_order: Optional[torch.Tensor] = field(default=None, repr=False)
     _degree_plan: Optional[LongRowPlan] = field(default=None, repr=False)
+    _dense_plans: dict = field(default_factory=dict, repr=False)
 
     @property
     def is_dense(self) -> bool:
@@ -210,6 +211,20 @@ class HopGraph:
         if row_ids is None:
             self._plan = plan
         return plan
+
+    def dense_slice_plan(self, n_out: int) -> LongRowPlan:
+        """Dense layout with few output rows: cut EVERY row into column slices, one workgroup each (a dense row has
+        n_cols pairs; one lane group per row would leave most of the 256 CUs idle on a Cora-sized graph)."""
+        key = int(n_out)
+        hit = self._dense_plans.get(key)
+        if hit is None:
+            if len(self._dense_plans) > 8:
+                self._dense_plans.clear()
+            spr = (self.n_cols + SLICE_EDGES - 1) // SLICE_EDGES
+            rows = torch.arange(n_out, dtype=torch.int32, device=self.device)
+            ptr = torch.arange(n_out + 1, dtype=torch.int32, device=self.device) * spr
+            hit = self._dense_plans[key] = LongRowPlan(rows, ptr, n_out, n_out * spr, threshold=0)
+        return hit
 
     def degree_schedule(self):
         """Rows sorted by number of listed pairs (stable) and the hub-row plan in that order — the processing
