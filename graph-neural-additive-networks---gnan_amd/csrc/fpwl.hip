@@ -35,6 +35,7 @@ struct Params {
   int out_bf16;          // per-feature output stored as bf16 rows (FAST path only)
   int64_t total_rows;    // column sums cover nodes [0, total_rows) only
   int max_pieces;        // largest piece count of one feature
+  int max_group_pieces;  // largest piece count of one feature group
   int soff_offset;       // fpwl_fast_kernel: float offset of its group-offset array in dynamic LDS
   int acc_offset;        // > 0 (sum over features, C > 1): float offset in dynamic LDS of the [C][NODES] accumulators;
                          // the workgroup then owns ONE pass of nodes and walks all feature groups for them
@@ -465,9 +466,122 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
   }
 }
 
+// Fixed-point moments with the 3-instruction search of fpwl_fast_kernel (whole feature groups, <= 1023 pieces per feature):
+// LDS = padded anchors [FG][2^NSTEP] | 64-bit bins [tot][2][C] | group offsets.
+template <int FG, int NSTEP, int BS>
+__global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParams mp) {
+  static_assert(FG % 4 == 0, "feature quads");
+  constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
+  const Params& p = mp.f;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int q = tid % TPN, nl = tid / TPN;
+  const int C = p.C;
+  const int64_t n_lo = static_cast<int64_t>(blockIdx.x) * p.nodes_per_block;
+  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
+  const int k0 = blockIdx.y * FG;
+  const int base = p.off[k0];
+  const int tot = p.off[k0 + FG] - base;
+  unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + FG * P2);   // 8-byte aligned: FG * P2 is even
+  int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float*)smem));
+  if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
+  for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = 0ull;
+  __syncthreads();
+  for (int i = tid; i < FG * P2; i += BS) {
+    const int f = i >> NSTEP, j = i & (P2 - 1);
+    smem[i] = j < s_off[f + 1] - s_off[f] ? p.anchor[base + s_off[f] + j] : INFINITY;
+  }
+  __syncthreads();
+  int pos0[FPT], binoff[FPT];
+#pragma unroll
+  for (int f = 0; f < FPT; ++f) {
+    const int fg = q * FPT + f;
+    pos0[f] = static_cast<int>(lds_base) + (fg << NSTEP) * 4;
+    binoff[f] = s_off[fg];
+  }
+  const double s0 = mp.scales[0], s1 = mp.scales[1];
+  for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
+    const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
+    float xv[FPT];
+    if (p.vec_x) {
+      const float4 t = *reinterpret_cast<const float4*>(xr);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+    } else {
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) xv[f] = xr[f];
+    }
+    int pos[FPT];
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) pos[f] = pos0[f];
+#pragma unroll
+    for (int step = P2 / 2; step >= 1; step >>= 1) {
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const float a = lds_f32(pos[f] + 4 * step);
+        pos[f] += a <= xv[f] ? 4 * step : 0;
+      }
+    }
+    const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0 + q * FPT) * C);
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const float d = xv[f] - lds_f32(pos[f]);
+      unsigned long long* b = bins + static_cast<int64_t>(binoff[f] + ((pos[f] - pos0[f]) >> 2)) * 2 * C;
+      for (int c = 0; c < C; ++c) {
+        const float gv = gr[p.sum_features ? c : f * C + c];
+        atomicAdd(b + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv) * s0)));
+        atomicAdd(b + C + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv * d) * s1)));
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2 * C;
+  for (int i = tid; i < tot * 2 * C; i += BS) {
+    const unsigned long long v = bins[i];
+    if (v != 0ull) atomicAdd(out + i, v);
+  }
+}
+
+template <int FG, int NSTEP, int BS>
+int launch_moments_fast(MomentParams mp, hipStream_t st) {
+  Params& p = mp.f;
+  const size_t pieces = static_cast<size_t>(p.max_group_pieces);
+  size_t lds = (static_cast<size_t>(FG) << NSTEP) * sizeof(float) + pieces * 2 * static_cast<size_t>(p.C) * sizeof(unsigned long long);
+  p.soff_offset = static_cast<int>(lds / sizeof(float));
+  lds += (FG + 1) * sizeof(int);
+  if (lds > 150 * 1024) return -1;                       // caller falls back to the plain kernel
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fpwl_moments_fast_kernel<FG, NSTEP, BS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+  if (bx > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
+  hipLaunchKernelGGL((fpwl_moments_fast_kernel<FG, NSTEP, BS>), dim3(static_cast<unsigned>(bx), static_cast<unsigned>(p.n_groups)),
+                     dim3(BS), lds, st, mp);
+  return gnan::check_launch("fpwl_moments_fast_kernel");
+}
+
 template <int FG, int BS>
 int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
   const bool fixed = mp.Mi != nullptr;
+  if constexpr (FG % 4 == 0) {
+    if (fixed && mp.f.F % FG == 0) {
+      int nstep = 6;
+      while ((1 << nstep) < mp.f.max_pieces) ++nstep;
+      int rc = -1;
+      switch (nstep) {
+        case 6: rc = launch_moments_fast<FG, 6, BS>(mp, st); break;
+        case 7: rc = launch_moments_fast<FG, 7, BS>(mp, st); break;
+        case 8: rc = launch_moments_fast<FG, 8, BS>(mp, st); break;
+        case 9: rc = launch_moments_fast<FG, 9, BS>(mp, st); break;
+        case 10: rc = launch_moments_fast<FG, 10, BS>(mp, st); break;
+        default: break;
+      }
+      if (rc != -1) return rc;
+    }
+  }
   const void* fn = fixed ? reinterpret_cast<const void*>(&fpwl_moments_kernel<FG, BS, true>)
                          : reinterpret_cast<const void*>(&fpwl_moments_kernel<FG, BS, false>);
   if (lds > 64 * 1024) {
@@ -611,6 +725,7 @@ Params base_params(const gnan_fpwl_args* a) {
   p.out = static_cast<float*>(a->out); p.out_stride = a->out_stride;
   p.col_partial = nullptr;
   p.max_pieces = a->max_pieces;
+  p.max_group_pieces = a->max_group_pieces;
   p.soff_offset = 0;
   p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
   p.acc_offset = 0;
@@ -630,6 +745,8 @@ int moments_common(const gnan_fpwl_args* a, const float* grad, int64_t grad_stri
   mp.f = base_params(a);
   mp.g = grad; mp.g_stride = grad_stride; mp.M = moments;
   mp.scales = scales; mp.Mi = reinterpret_cast<unsigned long long*>(moments_fixed);
+  mp.f.vec_x = a->features_per_group % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 &&
+               reinterpret_cast<uintptr_t>(a->x) % 16 == 0;
   const size_t bin = moments_fixed ? sizeof(unsigned long long) : sizeof(float);
   const size_t pieces = static_cast<size_t>(a->max_group_pieces);
   const size_t lds = (pieces + 1) / 2 * 2 * sizeof(float) + pieces * 2 * static_cast<size_t>(a->C) * bin;
