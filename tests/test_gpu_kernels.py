@@ -146,6 +146,46 @@ def test_spmm_row_subset_and_dense_equals_csr():
     assert torch.equal(y_sub, y_csr[ids.long()])
 
 
+@pytest.mark.parametrize("n,W,reduce_cr,Cw", [(700, 7, 0, 1), (2500, 64, 1, 1), (1030, 6, 2, 2), (600, 3, 0, 3)])
+def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
+    """Cora-sized dense inputs: every row cut into column slices (dense_slice_plan) == one lane group per row (the
+    arithmetic differs only in summation order) == the oracle; row subsets, transposed use and gradients included."""
+    from gnan_amd import HopGraph, functional
+    from gnan_amd.functional import rho_aggregate, spmm_launch
+    rng = np.random.default_rng(n + W)
+    D = 7
+    hops = rng.integers(-1, D - 1, (n, n)).astype(np.int32)
+    nd = torch.zeros(n, n)
+    nd[torch.from_numpy(hops >= 0)] = 1.0 / (torch.from_numpy(hops[hops >= 0]).float() + 1.0)
+    g = HopGraph.from_dense(nd.to(DEV))
+    S = torch.randn(n, W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    lut = torch.randn(g.n_codes, Cw, generator=torch.Generator().manual_seed(4)).to(DEV)
+    ids = torch.from_numpy(rng.integers(0, n, 97).astype(np.int32)).to(DEV)
+    sliced = spmm_launch(g, S, lut, True, with_rest=False, reduce_cr=reduce_cr)
+    sliced_sub = spmm_launch(g, S, lut, True, with_rest=False, row_ids=ids, reduce_cr=reduce_cr)
+    sliced_t = spmm_launch(g.transposed(), S, lut, True, False, None, weight_by_col=True)
+    monkeypatch.setattr(functional, "DENSE_SLICE_MAX_ROWS", 0)             # row blocks only
+    plain = spmm_launch(g, S, lut, True, with_rest=False, reduce_cr=reduce_cr)
+    plain_t = spmm_launch(g.transposed(), S, lut, True, False, None, weight_by_col=True)
+    assert float((sliced - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
+    assert float((sliced_t - plain_t).abs().max()) <= 2e-5 * float(plain_t.abs().max())
+    assert torch.equal(sliced_sub, sliced[ids.long()])
+    rowptr, col, code = O.csr_from_hops(hops, D - 2)
+    wt = O.weight_table(lut.cpu().double(), g.cnt.cpu().numpy())
+    truth = O.spmm_csr(rowptr, col, code, S.cpu().double(), wt)           # rest bucket: unreachable pairs, weight lut[D-1]
+    if reduce_cr:
+        truth = truth.view(n, -1, reduce_cr).sum(1)
+    assert O.rel_err(sliced.cpu(), truth) <= 1e-5
+    monkeypatch.undo()
+    Sg, lg = S.clone().requires_grad_(True), lut.clone().requires_grad_(True)
+    rho_aggregate(g, Sg, lg, True).pow(2).sum().backward()
+    monkeypatch.setattr(functional, "DENSE_SLICE_MAX_ROWS", 0)
+    Sp, lp = S.clone().requires_grad_(True), lut.clone().requires_grad_(True)
+    rho_aggregate(g, Sp, lp, True).pow(2).sum().backward()
+    assert float((Sg.grad - Sp.grad).abs().max()) <= 2e-5 * float(Sp.grad.abs().max())
+    assert float((lg.grad - lp.grad).abs().max()) <= 2e-5 * float(lp.grad.abs().max())
+
+
 def test_spmm_is_linear_in_the_operand_at_scale():
     """Size-independent property at a size the oracle cannot reach: A(aS1 + S2) == a A S1 + A S2."""
     from gnan_amd.functional import spmm_launch
