@@ -797,6 +797,22 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   // wide groups: 512-thread workgroups share one LDS image of the tables (A/B on C4: 1.92 -> 1.42 ms; 1024: 1.50 ms)
+  // feature sum with many channels: the tables of a group are reloaded per pass of nodes, so the widest workgroup whose
+  // [C][nodes] accumulators still fit LDS wins (arxiv-shaped, C = 40: one feature per group, 46 KB of tables per pass)
+  if (a->sum_features && a->C > 1 && fg <= 4) {
+    const int tpn = fg < 4 ? 1 : fg / 4;
+    auto fits = [&](int bs) { return lds + static_cast<size_t>(a->C) * (bs / tpn) * sizeof(float) <= 150 * 1024; };
+    const int bs = fits(1024) ? 1024 : fits(512) ? 512 : 256;
+    switch (fg * 10000 + bs) {
+      case 11024: return launch<1, 1024>(p, lds, st, a->total);
+      case 10512: return launch<1, 512>(p, lds, st, a->total);
+      case 21024: return launch<2, 1024>(p, lds, st, a->total);
+      case 20512: return launch<2, 512>(p, lds, st, a->total);
+      case 41024: return launch<4, 1024>(p, lds, st, a->total);
+      case 40512: return launch<4, 512>(p, lds, st, a->total);
+      default: break;
+    }
+  }
   switch (fg) {
     case 1: return launch<1, 256>(p, lds, st, a->total);
     case 2: return launch<2, 256>(p, lds, st, a->total);
