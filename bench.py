@@ -73,6 +73,15 @@ def spmm_algorithmic_bytes(g, W, W_out, elem=4):
     return g.nnz * (4 + 1 + W * elem) + g.n_rows * (rp + W_out * 4 + 4 * g.n_codes)
 
 
+def git_sha():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def fmlp_flops(n, F, H, L, C):
     return 2.0 * n * F * (H + max(L - 2, 0) * H * H + H * C) if L >= 2 else 2.0 * n * F * C
 
@@ -256,12 +265,15 @@ def main():
     checksum = float(checksum)
 
     stages = {n: 0.0 for n in stage_names}
+    per_step = []                                    # device time of every timed step (HIP events on the compute stream)
     for m in events:
         prev = m["start"]
         for n in stage_names:
             stages[n] += prev.elapsed_time(m[n])
             prev = m[n]
+        per_step.append(m["start"].elapsed_time(m[stage_names[-1]]))
     stages = {n: v / max(1, len(events)) for n, v in stages.items()}
+    per_step.sort()
 
     if partition == "feature":
         W = (fpart.hi - fpart.lo) * C
@@ -296,6 +308,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},
             "stages_ms": stages,
+            "step_ms_device": {"min": per_step[0], "median": per_step[len(per_step) // 2]} if per_step else None,
+            "seeds": {"graph": 0, "features": 1, "weights": 0}, "git_sha": git_sha(),
             "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
             "fmlp_effective_tflops": fmlp_flops(x.shape[0], x.shape[1], H, L, C) / (stages["fmlp"] / 1e3) / 1e12
             if stages["fmlp"] > 0 else None,
