@@ -753,10 +753,13 @@ int moments_common(const gnan_fpwl_args* a, const float* grad, int64_t grad_stri
   if (lds > 150 * 1024)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_moments: %zu B of bins per feature group exceed LDS", lds);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // few features per group means many channels: tens of KB of bins per workgroup, so only a wide workgroup puts enough
+  // waves on a CU (arxiv-shaped, C = 40: 91 KB of bins per feature -> one workgroup per CU)
+  const bool wide = lds > 40 * 1024;
   switch (a->features_per_group) {
-    case 1: return launch_moments<1, 256>(mp, lds, st);
-    case 2: return launch_moments<2, 256>(mp, lds, st);
-    case 4: return launch_moments<4, 256>(mp, lds, st);
+    case 1: return wide ? launch_moments<1, 1024>(mp, lds, st) : launch_moments<1, 256>(mp, lds, st);
+    case 2: return wide ? launch_moments<2, 1024>(mp, lds, st) : launch_moments<2, 256>(mp, lds, st);
+    case 4: return wide ? launch_moments<4, 1024>(mp, lds, st) : launch_moments<4, 256>(mp, lds, st);
     case 8: return launch_moments<8, 512>(mp, lds, st);
     default: return launch_moments<16, 512>(mp, lds, st);
   }
