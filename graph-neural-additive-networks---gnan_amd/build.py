@@ -1,34 +1,59 @@
-"""Build ``libgnan_hip.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build ``libgnan_hip.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every ``csrc/*.hip`` file becomes its own object under ``build/`` (compiled in parallel, re-compiled only when it or a
+header changed); the objects are linked into the one shared library the C ABI lives in.
+"""
 import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "libgnan_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
 
 
+def headers():
+    return glob.glob(os.path.join(HERE, "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+
+
+def _stale(target: str, deps) -> bool:
+    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    deps = sources() + glob.glob(os.path.join(HERE, "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+    return _stale(OUT, sources() + headers())
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return OUT
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"), *sources(), "-o", OUT]
+def _compile(src: str, force: bool, verbose: bool) -> str:
+    obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+    if force or _stale(obj, [src] + headers()):
+        cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True, out: str = OUT) -> str:
+    if not force and out == OUT and not needs_build():
+        return out
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(lambda s: _compile(s, force, verbose), sources()))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
