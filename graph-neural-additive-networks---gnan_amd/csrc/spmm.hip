@@ -180,13 +180,17 @@ __device__ __forceinline__ Vec<VEC> edge_weights(const Params& p, int64_t i, int
   return w;
 }
 
-// Per-row weight cache for the common truncated case (Cw == 1, D <= 4): four registers.
+// Per-row weight cache for the common truncated case (Cw == 1, D <= 4): four registers.  The empty asm statements
+// keep the select chain a chain: left alone, the optimiser rewrites it as an indexed load from a 4-float stack array,
+// which the backend then places in LDS (8 KB per workgroup and a ds_read + wait per listed pair).
 struct SmallW {
   float w[4];
   __device__ __forceinline__ float pick(int d) const {
     float r = w[0];
     r = d == 1 ? w[1] : r;
+    asm volatile("" : "+v"(r));
     r = d == 2 ? w[2] : r;
+    asm volatile("" : "+v"(r));
     r = d >= 3 ? w[3] : r;
     return r;
   }
@@ -212,7 +216,7 @@ __device__ __forceinline__ SmallW small_weights(const Params& p, int64_t i) {
 // ---------------------------------------------------------------------------------------------
 // rows kernel: one LPR-lane group per output row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool DENSE, bool SMALLD>
+template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE>
 __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_id) {
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
@@ -291,7 +295,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           d[u] = d[u] < rest ? d[u] : rest;
           s[u].zero();
           if (j < m && col_ok)
-            s[u].load(p.S, p.s_by_code ? static_cast<int64_t>(c[u]) * p.D + d[u] : static_cast<int64_t>(c[u]), p.s_stride, cw);
+            s[u].load(p.S, BYCODE ? static_cast<int64_t>(c[u]) * p.D + d[u] : static_cast<int64_t>(c[u]), p.s_stride, cw);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -352,7 +356,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 // ---------------------------------------------------------------------------------------------
 // long kernel: one 256-thread workgroup per slice of a hub row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool SMALLD, bool DENSE = false>
+template <int VEC, int LPR, bool SMALLD, bool DENSE, bool BYCODE>
 __device__ __forceinline__ void slice_body(const Params& p, const int s) {
   constexpr int G = kWave / LPR;
   constexpr int TILE = LPR * VEC;
@@ -401,7 +405,7 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
         int d = __shfl(codev, j);
         d = d < rest ? d : rest;
         if (j < m && col_ok) {
-          const Vec<VEC> sv = load_operand<VEC>(p.S, p.s_by_code ? static_cast<int64_t>(c) * p.D + d : static_cast<int64_t>(c), p.s_stride, cw);
+          const Vec<VEC> sv = load_operand<VEC>(p.S, BYCODE ? static_cast<int64_t>(c) * p.D + d : static_cast<int64_t>(c), p.s_stride, cw);
           if constexpr (SMALLD) {
             const float w = sw.pick(d);
 #pragma unroll
@@ -453,21 +457,23 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
 
 // One launch covers everything: workgroups [0, n_slices) take the hub-row slices (they start first,
 // so the long-latency slices overlap the bulk), the rest take 4*G ordinary rows each.
-template <int VEC, int LPR, bool DENSE, bool SMALLD>
+// BYCODE (operand row = (neighbour, hop code), the narrow-operand backward) is a template parameter: as a run-time
+// flag its address arithmetic cost the W = 64 kernels 4 VGPRs and the bf16 variant 20 B of scratch (bf16 rows 2.85 -> 3.35 ms).
+template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SMALLD && LPR >= 8) ? 8 : 1)))
 void spmm_kernel(const Params p) {
   if constexpr (!DENSE) {
     if (static_cast<int>(blockIdx.x) < p.n_slices) {
-      slice_body<VEC, LPR, SMALLD>(p, static_cast<int>(blockIdx.x));
+      slice_body<VEC, LPR, SMALLD, false, BYCODE>(p, static_cast<int>(blockIdx.x));
       return;
     }
-    rows_body<VEC, LPR, false, SMALLD>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
+    rows_body<VEC, LPR, false, SMALLD, BYCODE>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
   } else {
     if (p.n_slices > 0) {      // few rows, many neighbours: every row is cut into slices, there are no row blocks
-      slice_body<VEC, LPR, SMALLD, true>(p, static_cast<int>(blockIdx.x));
+      slice_body<VEC, LPR, SMALLD, true, false>(p, static_cast<int>(blockIdx.x));
       return;
     }
-    rows_body<VEC, LPR, true, SMALLD>(p, static_cast<int64_t>(blockIdx.x));
+    rows_body<VEC, LPR, true, SMALLD, false>(p, static_cast<int64_t>(blockIdx.x));
   }
 }
 
@@ -611,7 +617,17 @@ int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
   const int64_t blocks = dense && n_slices > 0 ? n_slices : (p.n_rows + rows_per_block - 1) / rows_per_block + n_slices;
   if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: too many rows for one launch");
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-  if (dense) {
+  if (p.s_by_code) {
+    if constexpr (VEC <= 4 && VEC * LPR <= 32) {  // validate(): fp32 rows of at most 32 columns, CSR layout
+      if (smalld) {
+        hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, true>), grid, block, 0, st, p);
+      } else {
+        hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, false, true>), grid, block, 0, st, p);
+      }
+    } else {
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: s_by_code covers operand rows of at most 32 columns");
+    }
+  } else if (dense) {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, true, false>), grid, block, 0, st, p);
   } else if (smalld) {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true>), grid, block, 0, st, p);
@@ -662,6 +678,8 @@ int validate(const gnan_spmm_args* a) {
   GNAN_REQUIRE(!(a->weight_by_col && a->s_total), "spmm: weight_by_col excludes the rest-bucket term (add it outside)");
   GNAN_REQUIRE(!a->s_by_code || (a->rowptr != nullptr && a->s_total == nullptr && a->s_dtype == GNAN_F32),
                "spmm: s_by_code needs the CSR layout, fp32 rows and no rest-bucket term");
+  if (a->s_by_code && a->W > 32)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: s_by_code covers operand rows of at most 32 columns (got W=%d)", a->W);
   GNAN_REQUIRE(!a->scatter_out || a->row_ids, "spmm: scatter_out needs row_ids");
   if (a->reduce_cr != 0) {
     const int cr = a->reduce_cr;
