@@ -221,14 +221,19 @@ __global__ __launch_bounds__(BS) void fpwl_kernel(const Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The C == 1 work-horse: the look-up is VALU-bound (68 vector instructions per look-up in the kernel above, counted
-// with SQ_INSTS_VALU; its LDS and HBM sides have slack), so this variant strips the search to 3 instructions per step:
-//   * every feature's anchors sit in LDS padded with +inf to P2 = 2^NSTEP entries -> no bounds test in the loop;
-//   * the loop is fully unrolled and `pos` is kept as an LDS *byte address*, so probe j = pos + step is the
-//     immediate offset of the ds_read:   a = lds[pos + 4*step];  pos += a <= x ? 4*step : 0;
-//   * entry 0 of a feature is the anchor of piece 0 (never probed), so lds[pos] after the loop is the piece's
-//     anchor and (val, slope) is one 8-byte read at 2*pos + delta.
-// Same arithmetic per look-up as fpwl_kernel (val + slope * (x - anchor)), hence bit-identical results.
+// The C == 1 work-horse.  Two things bound the plain kernel above: vector instructions (68 per look-up, counted with
+// SQ_INSTS_VALU) and LDS bank conflicts of the binary search (level s of a search over a sorted array probes 2^s
+// addresses that are 2^(NSTEP-s) words apart: with 32 banks for ds_read_b32 that is one or two banks for every level
+// but the last two, i.e. up to 8-way conflicts).  This variant
+//   * keeps every feature's anchors in LDS as a complete search TREE in breadth-first (Eytzinger) order, padded with
+//     +inf to P2 = 2^NSTEP - 1 nodes: the 2^s nodes of level s are 2^s consecutive words, i.e. 2^s distinct banks
+//     up to level 5 and at most 2^(s-5) addresses per bank below, and there is no bounds test in the loop;
+//   * unrolls the loop completely and carries the node as an LDS *byte address* a = Q + 4k (Q: tree of the thread's
+//     first feature; the other three trees are reached through the immediate offset of the ds_read), so a step is
+//       t = lds[a];  a = 2a + (t <= x ? 4 - Q : -Q)            (compare, select, shift-add: 3 vector instructions)
+//   * after NSTEP steps k - P2 is the piece: its anchor sits in a compact array at a + dA[f] and (val, slope) is one
+//     8-byte read at 2 (a + dA[f]) + const.
+// Same piece and same arithmetic per look-up as fpwl_kernel (val + slope * (x - anchor)), hence bit-identical results.
 // ---------------------------------------------------------------------------------------------
 // reads at raw LDS byte addresses (see fpwl_fast_kernel)
 typedef __attribute__((address_space(3))) const float lds_cfloat;
@@ -240,14 +245,44 @@ __device__ __forceinline__ float2 lds_f32x2(int addr) {
   return make_float2(v.x, v.y);
 }
 
+// Sorted index of node k (1 <= k < 2^NSTEP) of the complete breadth-first tree over the sorted entries 1 .. 2^NSTEP - 1.
+template <int NSTEP>
+__device__ __forceinline__ int tree_sorted_index(int k) {
+  const int l = 31 - __clz(k);                       // level of the node, root = 0
+  return (2 * (k - (1 << l)) + 1) << (NSTEP - 1 - l);
+}
+
+// LDS image of one feature group: [FG][P2] tree words, [tot] (val, slope) pairs, [tot] anchors in piece order.
+template <int FG, int NSTEP, int BS>
+__device__ __forceinline__ void load_tree_tables(const Params& p, float* smem, const int* s_off, int base, int tot,
+                                                 bool with_vs) {
+  constexpr int P2 = 1 << NSTEP;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < FG * P2; i += BS) {
+    const int f = i >> NSTEP, k = i & (P2 - 1);
+    float v = INFINITY;
+    if (k) {
+      const int j = tree_sorted_index<NSTEP>(k);
+      if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
+    }
+    smem[i] = v;
+  }
+  float2* vs_l = reinterpret_cast<float2*>(smem + FG * P2);
+  float* an_l = smem + FG * P2 + 2 * tot;
+  for (int i = tid; i < tot; i += BS) {
+    if (with_vs) vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
+    an_l[i] = p.anchor[base + i];
+  }
+}
+
 template <int FG, bool SUM, bool OUT16, int NSTEP, int BS>
 __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
   static_assert(FG % 4 == 0, "feature quads");
   constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
-  // `pos` is a raw LDS byte address (LDS base folded in once per group): addressing through the `smem` symbol costs
-  // a fourth instruction per step, because its base is only resolved at link time
+  // addresses are raw LDS byte addresses (LDS base folded in once per group): addressing through the `smem` symbol
+  // costs a fourth instruction per step, because its base is only resolved at link time
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;       // [FG + 1], behind tables and reduction scratch
+  int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;       // [FG + 1], behind the tables
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
   const int tid = threadIdx.x;
@@ -265,7 +300,7 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
   const int g_lo = SUM ? 0 : g_first;
   const int g_hi = SUM ? p.n_groups : g_lo + 1;
-  constexpr int kVsBytes = FG * P2 * 4;             // (val, slope) pairs start behind the padded anchors
+  constexpr int kTreeBytes = FG * P2 * 4;           // (val, slope) pairs start behind the trees, the anchors behind them
 
   for (int g = g_lo; g < g_hi; ++g) {
     const int k0 = g * FG;
@@ -274,52 +309,49 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
     __syncthreads();                                // previous group's look-ups are done with the LDS tables
     if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
     __syncthreads();
-    for (int i = tid; i < FG * P2; i += BS) {
-      const int f = i >> NSTEP, j = i & (P2 - 1);
-      smem[i] = j < s_off[f + 1] - s_off[f] ? p.anchor[base + s_off[f] + j] : INFINITY;
-    }
-    float2* vs_l = reinterpret_cast<float2*>(smem + FG * P2);
-    for (int i = tid; i < tot; i += BS) vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
+    load_tree_tables<FG, NSTEP, BS>(p, smem, s_off, base, tot, true);
     __syncthreads();
-    int pos0[FPT], delta[FPT];
+    const int Q = static_cast<int>(lds_base) + q * (FPT * P2 * 4);     // tree of the thread's first feature
+    int nQ = -Q, nQ4 = 4 - Q;
+    asm volatile("" : "+v"(nQ), "+v"(nQ4));         // two opaque registers: keeps the step at compare, select, shift-add
+    const int vs_minus_2an = static_cast<int>(lds_base) + kTreeBytes - 2 * (static_cast<int>(lds_base) + kTreeBytes + 8 * tot);
+    int dA[FPT];
 #pragma unroll
-    for (int f = 0; f < FPT; ++f) {
-      const int fg = q * FPT + f;
-      pos0[f] = static_cast<int>(lds_base) + (fg << NSTEP) * 4;
-      delta[f] = static_cast<int>(lds_base) + kVsBytes + s_off[fg] * 8 - 2 * pos0[f];
-    }
+    for (int f = 0; f < FPT; ++f)
+      dA[f] = static_cast<int>(lds_base) + kTreeBytes + 8 * tot + 4 * s_off[q * FPT + f] - 4 * P2 - Q;
 
     float ps[FPT] = {0.f, 0.f, 0.f, 0.f};           // column sums of the output (per-feature mode)
     for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
       const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
       const float xv[FPT] = {t.x, t.y, t.z, t.w};
-      int pos[FPT];
+      int a[FPT];
 #pragma unroll
-      for (int f = 0; f < FPT; ++f) pos[f] = pos0[f];
+      for (int f = 0; f < FPT; ++f) a[f] = Q + 4;   // node 1 = root
 #pragma unroll
-      for (int step = P2 / 2; step >= 1; step >>= 1) {
+      for (int step = 0; step < NSTEP; ++step) {
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
-          const float a = lds_f32(pos[f] + 4 * step);
-          pos[f] += a <= xv[f] ? 4 * step : 0;
+          const float e = lds_f32(a[f] + f * (P2 * 4));
+          a[f] = (a[f] << 1) + (e <= xv[f] ? nQ4 : nQ);
         }
       }
       float y[FPT];
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const float an = lds_f32(pos[f]);
-        const float2 vs = lds_f32x2(2 * pos[f] + delta[f]);
+        const int pa = a[f] + dA[f];
+        const float an = lds_f32(pa);
+        const float2 vs = lds_f32x2(2 * pa + vs_minus_2an);
         y[f] = fmaf(vs.y, xv[f] - an, vs.x);
       }
       if constexpr (SUM) {
-        float a = 0.f;
+        float acc = 0.f;
 #pragma unroll
-        for (int f = 0; f < FPT; ++f) a += y[f];
+        for (int f = 0; f < FPT; ++f) acc += y[f];
 #pragma unroll
-        for (int off = 1; off < TPN; off <<= 1) a += __shfl_xor(a, off);   // the node's TPN threads
+        for (int off = 1; off < TPN; off <<= 1) acc += __shfl_xor(acc, off);   // the node's TPN threads
         if (q == 0) {                               // groups run one after the other and a node keeps its thread
           float* o = p.out + n * p.out_stride;
-          o[0] = g == 0 ? a : o[0] + a;
+          o[0] = g == 0 ? acc : o[0] + acc;
         }
       } else {
         float4 r = make_float4(y[0], y[1], y[2], y[3]);
@@ -338,7 +370,7 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
     }
     if constexpr (!SUM) {
       if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64
-        float* red = smem + FG * P2 + 2 * tot;
+        float* red = smem;   // the tables are dead by now: the scratch takes their place (the host sizes LDS for both)
         __syncthreads();
 #pragma unroll
         for (int f = 0; f < FPT; ++f) red[tid * FPT + f] = ps[f];
@@ -466,7 +498,8 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
   }
 }
 
-// Fixed-point moments with the 3-instruction search of fpwl_fast_kernel (whole feature groups, <= 1023 pieces per feature):
+// Fixed-point moments with a 3-instruction search over padded SORTED anchors (the layout fpwl_fast_kernel had before its
+// search trees; this kernel is bound by its LDS atomics, not by the probes) (whole feature groups, <= 1023 pieces per feature):
 // LDS = padded anchors [FG][2^NSTEP] | 64-bit bins [tot][2][C] | group offsets.
 template <int FG, int NSTEP, int BS>
 __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParams mp) {
@@ -624,8 +657,9 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
   if constexpr (FG % 4 == 0) {
     int nstep = 6;
     while ((1 << nstep) < p.max_pieces) ++nstep;
-    size_t lds_fast = (static_cast<size_t>(FG) << nstep) * sizeof(float) + table_lds / 3 * 2 +
-                      (p.col_partial ? BS * 4 * sizeof(float) : 0);            // C == 1: 2 of the 3 floats per piece
+    // trees + (val, slope) pairs + anchors in piece order (C == 1: 3 floats per piece); the column-sum scratch re-uses it
+    size_t lds_fast = (static_cast<size_t>(FG) << nstep) * sizeof(float) + table_lds;
+    if (p.col_partial && lds_fast < BS * 4 * sizeof(float)) lds_fast = BS * 4 * sizeof(float);
     p.soff_offset = static_cast<int>(lds_fast / sizeof(float));
     lds_fast += (FG + 1) * sizeof(int);
     if (fast && nstep <= 10 && lds_fast <= 150 * 1024) {
