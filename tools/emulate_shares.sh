@@ -1,0 +1,6 @@
+# Per-rank stage times of a P-rank halo-recompute job, measured on ONE GPU (collectives excluded): P = 1, 2, 4, 8
+for P in 1 2 4 8; do
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --emulate-world $P --partition halo "$@" 2>/dev/null | python -c "
+import sys, json
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print($P, 'wall', round(d['ms_per_step'],3), 'device', d['step_ms_device'], {k: round(v, 3) for k, v in d['stages_ms'].items()}, d['operand_rows_rank0'], d['config']['stored_pairs_rank0'])"
+done
