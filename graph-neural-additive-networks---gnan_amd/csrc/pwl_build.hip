@@ -17,7 +17,8 @@
 namespace {
 
 constexpr int kCap = 1024;        // breakpoints per feature this kernel can hold
-constexpr int kNodeChunk = 32;    // table nodes evaluated per pass
+constexpr int kNodeChunk = 31;    // intervals per pass of the root search = 32 nodes (one node of overlap): 32 x 64 (node, unit)
+                                  // pairs are exactly two passes of the 1024 threads
 constexpr int kBT = 1024;         // threads of the build workgroup: one workgroup per feature means one wave per SIMD at
                                   // 256 threads, and every LDS round trip of the dot products is exposed; 16 waves hide it
 
@@ -36,7 +37,7 @@ struct BuildParams {
   int32_t* pieces;       // [F]
   int32_t* overflow;     // [1]
   double* scratch;       // [F, cap + 2, C] network values at the table nodes
-  int hid_offset;        // byte offset of the hidden-activation tile in dynamic LDS (8-byte aligned)
+  int hid_offset;        // byte offset of the two [kNodeChunk + 1, H] float64 tiles in dynamic LDS (8-byte aligned)
 };
 
 __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
@@ -55,16 +56,34 @@ __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
   }
 }
 
-// pre-activation of second-layer unit j at x (L == 3).  W2 sits TRANSPOSED in LDS (W2t[k*H + j]) so that lanes
-// holding consecutive units read consecutive banks (row-major would be a 32-way bank conflict on every read).
-__device__ __forceinline__ double z2(const float* w1, const float* b1, const float* W2t_col, float b2, int H, double x) {
-  double z = b2;
-#pragma unroll 8
-  for (int k = 0; k < H; ++k) {     // unrolled: the LDS reads of 8 terms are in flight together, the fma chain stays in order
-    const double h = fma(static_cast<double>(w1[k]), x, static_cast<double>(b1[k]));
-    z = fma(static_cast<double>(W2t_col[k * H]), h > 0.0 ? h : 0.0, z);
+// Second-layer pre-activations of a run of nodes (L == 3):  zt[ni, j] = b2_j + sum_k W2[j, k] relu(w1_k x_ni + b1_k).
+// The first-layer activations of a node are the same for all H units, so they are computed ONCE per node into h1
+// (float64, LDS) and every unit's dot product reads them back: one fma and two LDS reads per term instead of two
+// fmas, three float->double conversions and a select (the kernel is bound by float64 issue: 25 + 45 us of its 87 us
+// were these dot products).  Same operations in the same order per value as evaluating each unit on its own.
+// W2 sits TRANSPOSED in LDS (W2t[k*H + j]): lanes holding consecutive units read consecutive banks, the h1 reads
+// are broadcasts.  Ends with a barrier; h1 holds relu(layer 1) and zt the pre-activations of layer 2.
+template <typename NodeFn>
+__device__ __forceinline__ void eval_nodes(NodeFn node, int n0, int nn, int H, bool three, const float* w1, const float* b1,
+                                           const float* b2, const float* W2t, double* h1, double* zt, int tid) {
+  for (int it = tid; it < nn * H; it += kBT) {
+    const int ni = it / H, kk = it % H;
+    const double h = fma(static_cast<double>(w1[kk]), node(n0 + ni), static_cast<double>(b1[kk]));
+    h1[it] = h > 0.0 ? h : 0.0;
   }
-  return z;
+  __syncthreads();
+  if (three) {
+    for (int it = tid; it < nn * H; it += kBT) {
+      const int ni = it / H, j = it % H;
+      const double* hrow = h1 + ni * H;
+      const float* wcol = W2t + j;
+      double z = b2[j];
+#pragma unroll 8
+      for (int kk = 0; kk < H; ++kk) z = fma(static_cast<double>(wcol[kk * H]), hrow[kk], z);
+      zt[it] = z;
+    }
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
@@ -75,7 +94,8 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   float* b1 = w1 + p.H;                                     // [H]
   float* b2 = b1 + p.H;                                     // [H]
   float* W2 = b2 + p.H;                                     // [H*H] (L == 3)
-  double* hid = reinterpret_cast<double*>(smem_raw + p.hid_offset);   // [kNodeChunk, H]
+  double* h1 = reinterpret_cast<double*>(smem_raw + p.hid_offset);    // [kNodeChunk + 1, H] relu(layer 1)
+  double* zt = h1 + (kNodeChunk + 1) * p.H;                            // [kNodeChunk + 1, H] layer-2 pre-activations
   __shared__ int n_cand, n_bp, over;
   const int tid = threadIdx.x;
   const int k = blockIdx.x;
@@ -103,11 +123,9 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   int pow2 = 1;
   while (pow2 < H) pow2 <<= 1;
   bitonic_sort(bp, pow2, tid);
-  if (tid == 0) {
-    int c = 0;
-    while (c < H && isfinite(bp[c])) ++c;
-    n_bp = c;
-  }
+  if (tid == 0) n_bp = 0;
+  __syncthreads();
+  if (tid < H && isfinite(bp[tid]) && (tid == H - 1 || !isfinite(bp[tid + 1]))) n_bp = tid + 1;   // sorted: infinities last
   __syncthreads();
 
   // ---- 2. second-layer kinks ------------------------------------------------------------------
@@ -121,49 +139,31 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
       if (i < P + 2) return bp[i - 2];
       return i == P + 2 ? t_last + 1.0 : t_last + 2.0;
     };
-    // thread = (unit j, segment s): walks its share of the node sequence, one node of overlap
-    const int segs = kBT / H > 0 ? kBT / H : 1;
-    for (int j = tid / segs; j < H; j += kBT / segs) {
-      const int s = tid % segs;
-      const int per = (n_nodes - 1 + segs - 1) / segs;     // intervals per segment
-      const int i0 = s * per, i1 = i0 + per < n_nodes - 1 ? i0 + per : n_nodes - 1;
-      if (i0 < i1 || (s == 0)) {
-        const float* row = W2 + j;
-        double e_prev = node(i0), z_prev = z2(w1, b1, row, b2[j], H, e_prev);
-        double e_first = e_prev, z_first = z_prev, e_second = 0, z_second = 0;
-        for (int i = i0 + 1; i <= i1; ++i) {
-          const double e = node(i), z = z2(w1, b1, row, b2[j], H, e);
-          if (i == 1) { e_second = e; z_second = z; }
-          if (z_prev * z < 0.0) {
-            const double r = e_prev + (e - e_prev) * (z_prev / (z_prev - z));
-            if (isfinite(r)) {
-              const int at = atomicAdd(&n_cand, 1);
-              if (at < kCap) cand[at] = r; else over = 1;
-            }
-          }
-          if (i == n_nodes - 1) {                           // right ray: extrapolate the outermost affine piece
-            const double dr = z - z_prev;
-            if (dr != 0.0 && z / dr < 0.0) {
-              const double r = e - z / dr * (e - e_prev);
-              if (isfinite(r)) {
-                const int at = atomicAdd(&n_cand, 1);
-                if (at < kCap) cand[at] = r; else over = 1;
-              }
-            }
-          }
-          e_prev = e; z_prev = z;
+    // chunks of kNodeChunk intervals (kNodeChunk + 1 nodes, one node of overlap); thread = (interval, unit)
+    auto push = [&](double r) {
+      if (isfinite(r)) {
+        const int at = atomicAdd(&n_cand, 1);
+        if (at < kCap) cand[at] = r; else over = 1;
+      }
+    };
+    for (int c0 = 0; c0 < n_nodes - 1; c0 += kNodeChunk) {
+      const int nn = n_nodes - c0 < kNodeChunk + 1 ? n_nodes - c0 : kNodeChunk + 1;     // nodes of this chunk
+      eval_nodes(node, c0, nn, H, true, w1, b1, b2, W2, h1, zt, tid);
+      for (int it = tid; it < (nn - 1) * H; it += kBT) {
+        const int li = it / H + 1, j = it % H, i = c0 + li;                              // interval (i - 1, i)
+        const double e_prev = node(i - 1), e = node(i);
+        const double z_prev = zt[(li - 1) * H + j], z = zt[li * H + j];
+        if (z_prev * z < 0.0) push(e_prev + (e - e_prev) * (z_prev / (z_prev - z)));
+        if (i == n_nodes - 1) {                             // right ray: extrapolate the outermost affine piece
+          const double dr = z - z_prev;
+          if (dr != 0.0 && z / dr < 0.0) push(e - z / dr * (e - e_prev));
         }
-        if (s == 0 && n_nodes >= 2) {                       // left ray
-          const double dl = z_second - z_first;
-          if (dl != 0.0 && z_first / dl > 0.0) {
-            const double r = e_first - z_first / dl * (e_second - e_first);
-            if (isfinite(r)) {
-              const int at = atomicAdd(&n_cand, 1);
-              if (at < kCap) cand[at] = r; else over = 1;
-            }
-          }
+        if (i == 1) {                                       // left ray
+          const double dl = z - z_prev;
+          if (dl != 0.0 && z_prev / dl > 0.0) push(e_prev - z_prev / dl * (e - e_prev));
         }
       }
+      __syncthreads();                                      // the tiles are rewritten by the next chunk
     }
     __syncthreads();
     const int nc = n_cand < kCap ? n_cand : kCap;
@@ -196,21 +196,21 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   const int Pn = P ? P : 1;                                 // table nodes between the two outer ones
   double* V = p.scratch + static_cast<int64_t>(k) * (p.cap + 2) * C;
   const float* Wl = p.w_last + static_cast<int64_t>(k) * C * H;
-  // the network at the table nodes, kNodeChunk nodes at a time: (node, hidden unit) pairs fill the last hidden
-  // layer in LDS, then (node, channel) pairs take the output dot products
-  for (int n0 = 0; n0 < Pn + 2; n0 += kNodeChunk) {
-    const int nn = Pn + 2 - n0 < kNodeChunk ? Pn + 2 - n0 : kNodeChunk;
-    for (int it = tid; it < nn * H; it += kBT) {
-      const int ni = it / H, j = it % H;
-      const double x = tnode(n0 + ni);
-      double h = p.L == 3 ? z2(w1, b1, W2 + j, b2[j], H, x)
-                          : fma(static_cast<double>(w1[j]), x, static_cast<double>(b1[j]));
-      hid[ni * H + j] = h > 0.0 ? h : 0.0;
+  // the network at the table nodes, kNodeChunk + 1 nodes at a time: the last hidden layer into LDS (eval_nodes), then
+  // (node, channel) pairs take the output dot products
+  for (int n0 = 0; n0 < Pn + 2; n0 += kNodeChunk + 1) {
+    const int nn = Pn + 2 - n0 < kNodeChunk + 1 ? Pn + 2 - n0 : kNodeChunk + 1;
+    eval_nodes(tnode, n0, nn, H, p.L == 3, w1, b1, b2, W2, h1, zt, tid);
+    const double* hid = h1;                                 // L == 2: relu(layer 1) is the last hidden layer
+    if (p.L == 3) {
+      for (int it = tid; it < nn * H; it += kBT) zt[it] = zt[it] > 0.0 ? zt[it] : 0.0;
+      __syncthreads();
+      hid = zt;
     }
-    __syncthreads();
     for (int it = tid; it < nn * C; it += kBT) {
       const int ni = it / C, c = it % C;
       double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
+#pragma unroll 8
       for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
       V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
     }
@@ -319,7 +319,7 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
   lds = (lds + 7) & ~static_cast<size_t>(7);
   p.hid_offset = static_cast<int>(lds);
-  lds += static_cast<size_t>(kNodeChunk) * a->H * sizeof(double);
+  lds += 2 * static_cast<size_t>(kNodeChunk + 1) * a->H * sizeof(double);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwl_build_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -477,41 +477,68 @@ void spmm_kernel(const Params p) {
   }
 }
 
-// fix-up: add a hub row's slices in slice order, apply the rest-bucket term, store the row.
+// fix-up: add a hub row's slices in a fixed order, apply the rest-bucket term, store the row.
+// One WAVE per hub row, four rows per workgroup, no barriers: a power-law graph has tens of thousands of hub rows with
+// one or two slices each (R-MAT 10M/100M: 33 068 rows, 45 284 slices, at most 114 per row), so a workgroup per row was
+// bound by the workgroup launch rate (0.10 ms).  Lane = column (64 columns per pass); narrower operands put
+// K = 64 / W' lanes on a column (W' = W rounded up to a power of two), lane k takes slices k, k + K, ...; loads are
+// issued eight at a time; the K partial sums are added in lane order.  One fixed order per row: bit-reproducible.
 __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
-  const int r = blockIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  if (r >= p.n_long) return;
   const int64_t q = p.long_rows[r];
   const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
   const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
-  __shared__ float tile[256];
-  float chan = 0.f;  // thread c < reduce_cr accumulates channel c over the column tiles
-  for (int w0 = 0; w0 < p.W; w0 += 256) {
-    const int w = w0 + threadIdx.x;
+  int wp = 1;
+  while (wp < p.W && wp < kWave) wp <<= 1;
+  const int K = kWave / wp;              // slice lanes per column
+  const int k = lane / wp;
+  float chan = 0.f;                      // lane c < reduce_cr accumulates channel c over the column passes
+  for (int w0 = 0; w0 < p.W; w0 += kWave) {
+    const int w = w0 + lane % wp;
     float acc = 0.f, all = 0.f;
     if (w < p.W) {
-      for (int s = s0; s < s1; ++s) {
-        acc += p.partial[static_cast<int64_t>(s) * 2 * p.W + w];
-        all += p.partial[static_cast<int64_t>(s) * 2 * p.W + p.W + w];
+      const float* src = p.partial + w;
+      const int64_t row = 2 * static_cast<int64_t>(p.W);
+      int s = s0 + k;
+      for (; s + 7 * K < s1; s += 8 * K) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a[u] = src[(s + u * K) * row];
+          b[u] = src[(s + u * K) * row + p.W];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc += a[u];
+          all += b[u];
+        }
       }
+      for (; s < s1; s += K) {
+        acc += src[s * row];
+        all += src[s * row + p.W];
+      }
+    }
+    for (int kk = 1; kk < K; ++kk) {     // slice lanes -> lane 0 of the column, in lane order
+      const float a2 = __shfl(acc, lane % wp + kk * wp), b2 = __shfl(all, lane % wp + kk * wp);
+      if (k == 0) { acc += a2; all += b2; }
+    }
+    const bool owner = k == 0 && w < p.W;
+    if (owner) {
       if (p.s_total) {
         const Vec<1> wr = row_weights<1>(p, i, p.D - 1, w);
         acc = fmaf(wr.v[0], p.s_total[w] - all, acc);
       }
       if (p.reduce_cr == 0) p.Y[(p.scatter_out ? i : q) * p.y_stride + w] = acc;
     }
-    if (p.reduce_cr) {  // fixed-order tree: strides stay multiples of reduce_cr, so channels never mix
-      __syncthreads();
-      tile[threadIdx.x] = acc;
-      __syncthreads();
-      for (int st = 128; st >= p.reduce_cr; st >>= 1) {
-        if (static_cast<int>(threadIdx.x) < st) tile[threadIdx.x] += tile[threadIdx.x + st];
-        __syncthreads();
-      }
-      if (static_cast<int>(threadIdx.x) < p.reduce_cr) chan += tile[threadIdx.x];
+    if (p.reduce_cr) {  // fixed butterfly: offsets stay multiples of reduce_cr, so channels never mix
+      float v = owner ? acc : 0.f;
+      for (int off = kWave / 2; off >= p.reduce_cr; off >>= 1) v += __shfl_xor(v, off);
+      chan += v;
     }
   }
-  if (p.reduce_cr && static_cast<int>(threadIdx.x) < p.reduce_cr)
-    p.Y[(p.scatter_out ? i : q) * p.y_stride + threadIdx.x] = chan;
+  if (p.reduce_cr && lane < p.reduce_cr) p.Y[(p.scatter_out ? i : q) * p.y_stride + lane] = chan;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -636,7 +663,7 @@ int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
   }
   if (int rc = gnan::check_launch("spmm_kernel")) return rc;
   if (n_slices > 0) {
-    hipLaunchKernelGGL(spmm_long_fixup_kernel, dim3(static_cast<unsigned>(p.n_long)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(spmm_long_fixup_kernel, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p);
     if (int rc = gnan::check_launch("spmm_long_fixup_kernel")) return rc;
   }
   return GNAN_OK;
