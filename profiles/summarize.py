@@ -24,8 +24,9 @@ rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "*_kernel_s
 with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys())
     w.writeheader()
-    for r in rows[:25]:
-        w.writerow(r)
+    for n, r in enumerate(rows):                      # top 25 of the process + every kernel of this library
+        if n < 25 or any(o in r["Name"] for o in ours):
+            w.writerow(r)
 
 acc = collections.defaultdict(list)
 for d in ("fetch", "write", "tcc"):
