@@ -17,8 +17,8 @@
 namespace {
 
 constexpr int kCap = 1024;        // breakpoints per feature this kernel can hold
-constexpr int kNodeChunk = 31;    // intervals per pass of the root search = 32 nodes (one node of overlap): 32 x 64 (node, unit)
-                                  // pairs are exactly two passes of the 1024 threads
+// nodes evaluated per pass (p.chunk): 64 while two [chunk, H] float64 tiles fit next to W2 (H <= 64: 64 x 64 / 4 = one
+// (two nodes, two units) item per thread), else 32; the root search overlaps consecutive passes by one node
 constexpr int kBT = 1024;         // threads of the build workgroup: one workgroup per feature means one wave per SIMD at
                                   // 256 threads, and every LDS round trip of the dot products is exposed; 16 waves hide it
 
@@ -37,7 +37,8 @@ struct BuildParams {
   int32_t* pieces;       // [F]
   int32_t* overflow;     // [1]
   double* scratch;       // [F, cap + 2, C] network values at the table nodes
-  int hid_offset;        // byte offset of the two [kNodeChunk + 1, H] float64 tiles in dynamic LDS (8-byte aligned)
+  int hid_offset;        // byte offset of the two [chunk, H] float64 tiles in dynamic LDS (8-byte aligned)
+  int chunk;             // nodes per pass
 };
 
 __device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
@@ -72,7 +73,36 @@ __device__ __forceinline__ void eval_nodes(NodeFn node, int n0, int nn, int H, b
     h1[it] = h > 0.0 ? h : 0.0;
   }
   __syncthreads();
-  if (three) {
+  if (three && H % 2 == 0) {
+    // thread = (two nodes, two units): one 8-byte read of W2t and two broadcast reads of h1 feed four fma chains —
+    // 3 LDS instructions per 4 terms instead of 8 (the dot products are bound by the LDS issue rate), and the four
+    // independent chains hide the float64 latency.  Each value still sees the same operations in the same order.
+    const int H2 = H / 2, nn2 = (nn + 1) / 2;
+    for (int it = tid; it < nn2 * H2; it += kBT) {
+      const int np = it / H2, jp = it % H2;
+      const int na = 2 * np, nb = 2 * np + 1 < nn ? 2 * np + 1 : na;
+      const double* ha = h1 + na * H;
+      const double* hb = h1 + nb * H;
+      const float2* wc = reinterpret_cast<const float2*>(W2t + 2 * jp);   // 8-byte aligned: H is even
+      double z00 = b2[2 * jp], z01 = b2[2 * jp + 1], z10 = z00, z11 = z01;
+#pragma unroll 8
+      for (int kk = 0; kk < H; ++kk) {
+        const float2 w = wc[kk * H2];
+        const double a = ha[kk], b = hb[kk];
+        z00 = fma(static_cast<double>(w.x), a, z00);
+        z01 = fma(static_cast<double>(w.y), a, z01);
+        z10 = fma(static_cast<double>(w.x), b, z10);
+        z11 = fma(static_cast<double>(w.y), b, z11);
+      }
+      zt[na * H + 2 * jp] = z00;
+      zt[na * H + 2 * jp + 1] = z01;
+      if (nb != na) {
+        zt[nb * H + 2 * jp] = z10;
+        zt[nb * H + 2 * jp + 1] = z11;
+      }
+    }
+    __syncthreads();
+  } else if (three) {
     for (int it = tid; it < nn * H; it += kBT) {
       const int ni = it / H, j = it % H;
       const double* hrow = h1 + ni * H;
@@ -94,8 +124,8 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   float* b1 = w1 + p.H;                                     // [H]
   float* b2 = b1 + p.H;                                     // [H]
   float* W2 = b2 + p.H;                                     // [H*H] (L == 3)
-  double* h1 = reinterpret_cast<double*>(smem_raw + p.hid_offset);    // [kNodeChunk + 1, H] relu(layer 1)
-  double* zt = h1 + (kNodeChunk + 1) * p.H;                            // [kNodeChunk + 1, H] layer-2 pre-activations
+  double* h1 = reinterpret_cast<double*>(smem_raw + p.hid_offset);    // [chunk, H] relu(layer 1)
+  double* zt = h1 + p.chunk * p.H;                                     // [chunk, H] layer-2 pre-activations
   __shared__ int n_cand, n_bp, over;
   const int tid = threadIdx.x;
   const int k = blockIdx.x;
@@ -139,15 +169,15 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
       if (i < P + 2) return bp[i - 2];
       return i == P + 2 ? t_last + 1.0 : t_last + 2.0;
     };
-    // chunks of kNodeChunk intervals (kNodeChunk + 1 nodes, one node of overlap); thread = (interval, unit)
+    // passes of chunk - 1 intervals (chunk nodes, one node of overlap); thread = (interval, unit)
     auto push = [&](double r) {
       if (isfinite(r)) {
         const int at = atomicAdd(&n_cand, 1);
         if (at < kCap) cand[at] = r; else over = 1;
       }
     };
-    for (int c0 = 0; c0 < n_nodes - 1; c0 += kNodeChunk) {
-      const int nn = n_nodes - c0 < kNodeChunk + 1 ? n_nodes - c0 : kNodeChunk + 1;     // nodes of this chunk
+    for (int c0 = 0; c0 < n_nodes - 1; c0 += p.chunk - 1) {
+      const int nn = n_nodes - c0 < p.chunk ? n_nodes - c0 : p.chunk;                    // nodes of this pass
       eval_nodes(node, c0, nn, H, true, w1, b1, b2, W2, h1, zt, tid);
       for (int it = tid; it < (nn - 1) * H; it += kBT) {
         const int li = it / H + 1, j = it % H, i = c0 + li;                              // interval (i - 1, i)
@@ -196,10 +226,10 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   const int Pn = P ? P : 1;                                 // table nodes between the two outer ones
   double* V = p.scratch + static_cast<int64_t>(k) * (p.cap + 2) * C;
   const float* Wl = p.w_last + static_cast<int64_t>(k) * C * H;
-  // the network at the table nodes, kNodeChunk + 1 nodes at a time: the last hidden layer into LDS (eval_nodes), then
+  // the network at the table nodes, p.chunk nodes at a time: the last hidden layer into LDS (eval_nodes), then
   // (node, channel) pairs take the output dot products
-  for (int n0 = 0; n0 < Pn + 2; n0 += kNodeChunk + 1) {
-    const int nn = Pn + 2 - n0 < kNodeChunk + 1 ? Pn + 2 - n0 : kNodeChunk + 1;
+  for (int n0 = 0; n0 < Pn + 2; n0 += p.chunk) {
+    const int nn = Pn + 2 - n0 < p.chunk ? Pn + 2 - n0 : p.chunk;
     eval_nodes(tnode, n0, nn, H, p.L == 3, w1, b1, b2, W2, h1, zt, tid);
     const double* hid = h1;                                 // L == 2: relu(layer 1) is the last hidden layer
     if (p.L == 3) {
@@ -319,7 +349,8 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
   lds = (lds + 7) & ~static_cast<size_t>(7);
   p.hid_offset = static_cast<int>(lds);
-  lds += 2 * static_cast<size_t>(kNodeChunk + 1) * a->H * sizeof(double);
+  p.chunk = a->H <= 64 ? 64 : 32;
+  lds += 2 * static_cast<size_t>(p.chunk) * a->H * sizeof(double);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwl_build_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
