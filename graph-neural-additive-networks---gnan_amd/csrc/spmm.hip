@@ -989,42 +989,71 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
 
 // hub rows: add the slices in order, contract with dY, scale; one workgroup per hub row
 __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p, const GradParams gp) {
-  const int r = blockIdx.x;
+  // one wave per hub row (four rows per workgroup, no barriers), as in spmm_long_fixup_kernel: lane = column, operands
+  // narrower than a wave put K = 64 / W' lanes on a column, lane k takes slices k, k + K, ...
+  const int lane = threadIdx.x & (kWave - 1);
+  const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  if (r >= p.n_long) return;
   const int64_t q = p.long_rows[r];
   const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
   const int64_t oq = p.scatter_out ? i : q;
   const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
   const int rest = p.D - 1;
-  __shared__ double tile[4][256];
+  int wp = 1;
+  while (wp < p.W && wp < kWave) wp <<= 1;
+  const int K = kWave / wp;
+  const int k = lane / wp;
   double pd[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int w = threadIdx.x; w < p.W; w += 256) {
+  for (int w0 = 0; w0 < p.W; w0 += kWave) {
+    const int w = w0 + lane % wp;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = s0; s < s1; ++s)
+    if (w < p.W) {
+      int s = s0 + k;
+      for (; s + K < s1; s += 2 * K) {     // two slices = eight independent loads at a time
+        float a[4], b[4];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) t[d] += gp.slice_T[(static_cast<int64_t>(s) * 4 + d) * p.W + w];
-    if (p.s_total) {
-      float lower = 0.f;
+        for (int d = 0; d < 4; ++d) {
+          a[d] = gp.slice_T[(static_cast<int64_t>(s) * 4 + d) * p.W + w];
+          b[d] = gp.slice_T[(static_cast<int64_t>(s + K) * 4 + d) * p.W + w];
+        }
 #pragma unroll
-      for (int d = 0; d < 4; ++d) lower += d < rest ? t[d] : 0.f;
+        for (int d = 0; d < 4; ++d) t[d] = (t[d] + a[d]) + b[d];
+      }
+      for (; s < s1; s += K)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) t[d] = d == rest ? p.s_total[w] - lower : t[d];
+        for (int d = 0; d < 4; ++d) t[d] += gp.slice_T[(static_cast<int64_t>(s) * 4 + d) * p.W + w];
     }
-    const float dy = gp.dY[oq * gp.dy_stride + w % gp.dy_channels];
+    for (int kk = 1; kk < K; ++kk) {       // slice lanes -> lane 0 of the column, in lane order
 #pragma unroll
-    for (int d = 0; d < 4; ++d) pd[d] += static_cast<double>(dy) * t[d];
+      for (int d = 0; d < 4; ++d) {
+        const float v = __shfl(t[d], lane % wp + kk * wp);
+        if (k == 0) t[d] += v;
+      }
+    }
+    if (k == 0 && w < p.W) {
+      if (p.s_total) {
+        float lower = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) lower += d < rest ? t[d] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) t[d] = d == rest ? p.s_total[w] - lower : t[d];
+      }
+      const float dy = gp.dY[oq * gp.dy_stride + w % gp.dy_channels];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) pd[d] += static_cast<double>(dy) * t[d];
+    }
   }
 #pragma unroll
-  for (int d = 0; d < 4; ++d) tile[d][threadIdx.x] = pd[d];
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (static_cast<int>(threadIdx.x) < st)
+  for (int off = kWave / 2; off > 0; off >>= 1)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) tile[d][threadIdx.x] += tile[d][threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x < 4) {
-    const int d = threadIdx.x;
-    const double v = tile[d][0] * grad_inv(p, i, d);
+    for (int d = 0; d < 4; ++d) pd[d] += __shfl_xor(pd[d], off);
+  if (lane < 4) {
+    const int d = lane;
+    double mine = pd[0];
+    mine = d == 1 ? pd[1] : mine;
+    mine = d == 2 ? pd[2] : mine;
+    mine = d == 3 ? pd[3] : mine;
+    const double v = mine * grad_inv(p, i, d);
     if (gp.reduce_rows) gp.blk[(gp.n_row_blocks + r) * 4 + d] = v;
     else if (d < p.D) gp.dwt[oq * p.D + d] = static_cast<float>(v);
   }
@@ -1056,7 +1085,7 @@ int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut)
   hipLaunchKernelGGL((spmm_lut_grad_kernel<VEC, LPR>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p, gp);
   if (int rc = gnan::check_launch("spmm_lut_grad_kernel")) return rc;
   if (p.n_slices > 0) {
-    hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel, dim3(static_cast<unsigned>(p.n_long)), dim3(256), 0, st, p, gp);
+    hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p, gp);
     if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
   }
   if (gp.reduce_rows) {

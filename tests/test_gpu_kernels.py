@@ -297,6 +297,29 @@ def test_column_sums(n, W):
     assert torch.equal(column_sums(S), column_sums(S))          # fixed reduction order
 
 
+@pytest.mark.parametrize("W,cr", [(1, 0), (1, 1), (8, 0), (8, 2), (24, 0), (24, 4), (64, 0), (64, 1), (320, 0), (320, 4)])
+def test_hub_rows_with_many_slices(W, cr):
+    """Hub rows of 20 and 41 slices: the fix-up kernel's eight-loads-at-a-time loop, its slice lanes for operands narrower
+    than a wave (W = 1, 8, 24) and its column passes for wider ones (W = 320), with and without the fused feature sum."""
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(1000 + W * 3 + cr)
+    n_rows, n_cols, K = 64, 5000, 1
+    D = K + 2
+    rowptr, col, code = _random_csr(n_rows, n_cols, K, rng, hubs=[(3, 40000), (40, 83001), (41, 513)])
+    cnt = _cnt_np(rowptr, code, n_cols, D)
+    S = torch.from_numpy(rng.standard_normal((n_cols, W)).astype(np.float32))
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32))
+    wt64 = O.weight_table(lut.double(), cnt).expand(n_rows, -1, -1)
+    truth = O.spmm_csr(rowptr, col, code, S.double(), wt64)
+    g = _graph(rowptr, col, code, n_cols, D)
+    y = spmm_launch(g, S.to(DEV), lut.to(DEV), True, with_rest=True, reduce_cr=cr).cpu()
+    if cr:
+        truth = truth.view(n_rows, W // cr, cr).sum(1)
+    assert O.rel_err(y, truth) <= 1e-5, O.rel_err(y, truth)
+    again = spmm_launch(g, S.to(DEV), lut.to(DEV), True, with_rest=True, reduce_cr=cr).cpu()
+    assert torch.equal(y, again)                                     # fixed reduction order
+
+
 @pytest.mark.parametrize("W,cr", [(64, 1), (64, 4), (8, 2), (6, 2), (6, 1), (300, 4), (3, 1), (1, 1)])
 def test_fused_feature_sum_equals_unfused(W, cr):
     """reduce_cr: per-channel sums over the operand columns in the kernel epilogue (rows, hub slices, dense)."""
