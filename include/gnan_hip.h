@@ -239,7 +239,8 @@ typedef struct gnan_spmm_args {
   size_t workspace_bytes;
   int32_t s_by_code;             /* gnan_spmm_fwd only: S has n_cols * D rows and pair (i, c, d) reads S[c * D + d] — the
                                     backward w.r.t. a narrow S folds the per-pair weight into a pre-weighted operand
-                                    Z[i, d, :] = (wt(i, d) - wt(i, D-1)) * dY[i, :] and gathers it with unit weights */
+                                    Z[i, d, :] = (wt(i, d) - wt(i, D-1)) * dY[i, :] and gathers it with unit weights.
+                                    CSR layout, fp32 rows, no s_total, W <= 32 (GNAN_ERR_UNSUPPORTED beyond) */
 } gnan_spmm_args;
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
