@@ -56,6 +56,18 @@ __device__ __forceinline__ int64_t load_rowptr(const Params& p, int64_t i) {
                        : static_cast<int64_t>(static_cast<const int32_t*>(p.rowptr)[i]);
 }
 
+// Processing slot q -> adjacency row (index into rowptr / cnt / a per-row weight table) and output row.
+//   no row_ids        : both q                         row_ids, scatter_out 0 : row_ids[q] -> q   (row subset)
+//   scatter_out 1     : row_ids[q] -> row_ids[q]       (rows PROCESSED in row_ids order, e.g. by degree, stored in place)
+//   scatter_out 2     : q -> row_ids[q]                (the adjacency itself is stored in processing order — a degree-sorted
+//                       copy of the CSR — so that rowptr, cnt and the index pairs of neighbouring lane groups are adjacent)
+__device__ __forceinline__ int64_t adj_row(const Params& p, int64_t q) {
+  return (p.row_ids && p.scatter_out != 2) ? static_cast<int64_t>(p.row_ids[q]) : q;
+}
+__device__ __forceinline__ int64_t out_row(const Params& p, int64_t q, int64_t i) {
+  return p.scatter_out == 2 ? static_cast<int64_t>(p.row_ids[q]) : (p.scatter_out ? i : q);
+}
+
 template <int VEC>
 struct Vec {
   float v[VEC];
@@ -220,7 +232,10 @@ template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE>
 __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_id) {
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
-  constexpr int UNROLL = 4;          // gathers in flight per lane (8 costs registers, hence waves: slower)
+  // gathers in flight per lane.  fp32 rows: 1, 2, 3 and 4 measure the same (4.68-4.76 ms on C4: at 8 waves/SIMD the
+  // kernel sits on the L2 request rate, not on latency), 8 costs registers, hence waves.  bf16 rows: 2 fits
+  // the 64-VGPR budget of 8 waves/SIMD without scratch: 2.93 -> 2.71 ms (1: 2.77, 3: 2.70, 4: 2.93).
+  constexpr int UNROLL = VEC == 8 ? 2 : 4;
   constexpr int IW = LPR >= 8 ? LPR : 16;  // index pairs fetched per round by one group (narrow rows: 16)
   constexpr int IPL = IW / LPR;            // ... per lane
   const int lane = threadIdx.x & (kWave - 1);
@@ -229,7 +244,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
   const int slot = lane / LPR;
   const int64_t q = (block_id * (blockDim.x / kWave) + wave) * G + slot;
   if (q >= p.n_rows) return;
-  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int64_t i = adj_row(p, q);
   int64_t lo, hi, code_base;
   if constexpr (DENSE) {
     lo = 0;
@@ -330,7 +345,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
         }
       }
       if (p.reduce_cr == 0) {
-        store_vec<VEC>(p.Y + (p.scatter_out ? i : q) * p.y_stride + cw, acc);
+        store_vec<VEC>(p.Y + out_row(p, q, i) * p.y_stride + cw, acc);
       } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -349,7 +364,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
       for (int c = 0; c < 4; ++c) red[c] += __shfl_xor(red[c], off);
     }
     if (sub == 0)
-      for (int c = 0; c < p.reduce_cr; ++c) p.Y[(p.scatter_out ? i : q) * p.y_stride + c] = red[c];
+      for (int c = 0; c < p.reduce_cr; ++c) p.Y[out_row(p, q, i) * p.y_stride + c] = red[c];
   }
 }
 
@@ -373,7 +388,7 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
     if (p.long_slice_ptr[mid] <= s) a = mid; else b = mid;
   }
   const int64_t q = p.long_rows[a];
-  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int64_t i = adj_row(p, q);
   // dense layout: the "pairs" of row i are all n_cols neighbours, the column is the position, codes sit at i*n_cols
   const int64_t row_lo = DENSE ? 0 : load_rowptr(p, i), row_hi = DENSE ? p.n_cols : load_rowptr(p, i + 1);
   const int64_t code_base = DENSE ? i * p.n_cols : 0;
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
   const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   if (r >= p.n_long) return;
   const int64_t q = p.long_rows[r];
-  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int64_t i = adj_row(p, q);
   const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
   int wp = 1;
   while (wp < p.W && wp < kWave) wp <<= 1;
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
         const Vec<1> wr = row_weights<1>(p, i, p.D - 1, w);
         acc = fmaf(wr.v[0], p.s_total[w] - all, acc);
       }
-      if (p.reduce_cr == 0) p.Y[(p.scatter_out ? i : q) * p.y_stride + w] = acc;
+      if (p.reduce_cr == 0) p.Y[out_row(p, q, i) * p.y_stride + w] = acc;
     }
     if (p.reduce_cr) {  // fixed butterfly: offsets stay multiples of reduce_cr, so channels never mix
       float v = owner ? acc : 0.f;
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
       chan += v;
     }
   }
-  if (p.reduce_cr && lane < p.reduce_cr) p.Y[(p.scatter_out ? i : q) * p.y_stride + lane] = chan;
+  if (p.reduce_cr && lane < p.reduce_cr) p.Y[out_row(p, q, i) * p.y_stride + lane] = chan;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(256) void spmm_shell_sums_kernel(const Params p) {
   const int slot = lane / LPR;
   const int64_t q = (static_cast<int64_t>(blockIdx.x) * (blockDim.x / kWave) + wave) * G + slot;
   if (q >= p.n_rows) return;
-  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+  const int64_t i = adj_row(p, q);
   int64_t lo, hi, code_base;
   if constexpr (DENSE) {
     lo = 0; hi = p.n_cols; code_base = i * p.n_cols;
@@ -844,7 +859,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
       if (p.long_slice_ptr[mid] <= s) a = mid; else b = mid;
     }
     const int64_t q = p.long_rows[a];
-    const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
+    const int64_t i = adj_row(p, q);
     const int64_t row_lo = load_rowptr(p, i), row_hi = load_rowptr(p, i + 1);
     const int64_t lo = row_lo + static_cast<int64_t>(s - p.long_slice_ptr[a]) * p.slice_edges;
     const int64_t hi = lo + p.slice_edges < row_hi ? lo + p.slice_edges : row_hi;
@@ -912,8 +927,8 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
   int64_t i = 0, oq = 0;
   bool live = q < p.n_rows;
   if (live) {
-    i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
-    oq = p.scatter_out ? i : q;
+    i = adj_row(p, q);
+    oq = out_row(p, q, i);
     const int64_t lo = load_rowptr(p, i), hi = load_rowptr(p, i + 1);
     live = hi - lo <= p.long_threshold;                 // hub rows: slices + fix-up
     if (live) {
@@ -995,8 +1010,8 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
   const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   if (r >= p.n_long) return;
   const int64_t q = p.long_rows[r];
-  const int64_t i = p.row_ids ? static_cast<int64_t>(p.row_ids[q]) : q;
-  const int64_t oq = p.scatter_out ? i : q;
+  const int64_t i = adj_row(p, q);
+  const int64_t oq = out_row(p, q, i);
   const int s0 = p.long_slice_ptr[r], s1 = p.long_slice_ptr[r + 1];
   const int rest = p.D - 1;
   int wp = 1;

@@ -52,6 +52,7 @@ class HopGraph:
     _degree_order: Optional[torch.Tensor] = field(default=None, repr=False)
     _degree_plan: Optional[LongRowPlan] = field(default=None, repr=False)
     _dense_plans: dict = field(default_factory=dict, repr=False)
+    _sorted_copy: Optional["HopGraph"] = field(default=None, repr=False)
 
     @property
     def is_dense(self) -> bool:
@@ -225,6 +226,46 @@ class HopGraph:
             ptr = torch.arange(n_out + 1, dtype=torch.int32, device=self.device) * spr
             hit = self._dense_plans[key] = LongRowPlan(rows, ptr, n_out, n_out * spr, threshold=0)
         return hit
+
+    def degree_sorted_copy(self):
+        """``(copy, order, plan)``: the CSR stored in the processing order of :meth:`degree_schedule` — row ``q`` of the
+        copy is row ``order[q]`` of this graph (its pairs in their original order), ``cnt`` permuted alike, ``plan`` the
+        hub-row plan of the copy.  The aggregation kernel walks the copy front to back and stores row ``q`` at
+        ``Y[order[q]]`` (``scatter_out = 2``): same arithmetic per row, hence bit-identical output, but ``rowptr``, ``cnt``
+        and the index pairs of the lane groups sharing a wavefront are adjacent in memory instead of scattered — fewer L2
+        requests, which is what bounds the kernel.  Costs a second copy of (col, code) in HBM; cached per graph."""
+        if self._sorted_copy is None:
+            order, _ = self.degree_schedule()
+            o = order.long()
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            deg_s = deg[o]
+            rowptr_s = torch.zeros(self.n_rows + 1, dtype=torch.int64, device=self.device)
+            rowptr_s[1:] = torch.cumsum(deg_s, 0)
+            nnz = int(self.col.numel())
+            col_s = torch.empty_like(self.col)
+            code_s = torch.empty_like(self.code)
+            chunk = 1 << 27                                   # pairs per pass: bounds the int64 temporaries
+            bounds = torch.searchsorted(rowptr_s, torch.arange(0, nnz + chunk, chunk, device=self.device).clamp_(max=nnz))
+            bounds[-1] = self.n_rows
+            src_start = self.rowptr.long()[:-1][o]
+            for b in range(bounds.numel() - 1):
+                r0, r1 = int(bounds[b]), int(bounds[b + 1])
+                if r1 <= r0:
+                    continue
+                e0, e1 = int(rowptr_s[r0]), int(rowptr_s[r1])
+                if e1 <= e0:
+                    continue
+                d = deg_s[r0:r1]
+                src = torch.arange(e0, e1, device=self.device) + torch.repeat_interleave(src_start[r0:r1] - rowptr_s[r0:r1], d)
+                col_s[e0:e1] = self.col[src]
+                code_s[e0:e1] = self.code[src]
+                del src
+            rp = rowptr_s if self.rowptr.dtype == torch.int64 else rowptr_s.to(torch.int32)
+            g = HopGraph(n_rows=self.n_rows, n_cols=self.n_cols, n_codes=self.n_codes, code=code_s,
+                         cnt=self.cnt[o].contiguous(), rowptr=rp, col=col_s)
+            g.long_row_plan()
+            self._sorted_copy = g
+        return self._sorted_copy, self._degree_order, self._sorted_copy._plan
 
     def degree_schedule(self):
         """Rows sorted by number of listed pairs (stable) and the hub-row plan in that order — the processing

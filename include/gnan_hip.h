@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 16
+#define GNAN_ABI_VERSION 17
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -225,7 +225,10 @@ typedef struct gnan_spmm_args {
                                 Y[q, c'] = sum over columns w = c' (mod c)  (the feature sum of GNAN.py:72-73) */
   int32_t scatter_out;       /* 1: rows are PROCESSED in row_ids order (a schedule, e.g. by degree, so that the
                                 rows sharing a wavefront have similar lengths) but STORED at Y[row_ids[q]] —
-                                row_ids must then be a permutation of the adjacency rows */
+                                row_ids must then be a permutation of the adjacency rows.
+                                2: the adjacency (rowptr / col / code / cnt) is ITSELF stored in processing order (e.g. a
+                                degree-sorted copy of the CSR): slot q reads adjacency row q and stores at Y[row_ids[q]].
+                                Same result as 1 on the un-permuted adjacency, fewer scattered index requests */
   float* Y;                  /* [n_rows, W] fp32  ([n_rows, reduce_cr] with the fused read-out) */
   int64_t y_stride;
   /* long-row plan (CSR only; n_long == 0 => every row goes through the main kernel) */

@@ -490,7 +490,8 @@ def test_fused_table_gradient_equals_shell_sums_route(W, dyc, use_cnt, with_rest
 
 
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
-    """Rows processed in degree order and stored in place == rows processed in natural order (same arithmetic per row)."""
+    """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
+    place == rows processed in natural order (same arithmetic per row)."""
     from gnan_amd import functional
     from gnan_amd.functional import spmm_launch
     rng = np.random.default_rng(21)
@@ -499,11 +500,24 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     g = _graph(rowptr, col, code, n, K + 2)
     S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     lut = torch.tensor([[1.0], [0.5], [0.01]], device=DEV)
-    y_sched = spmm_launch(g, S, lut, True, True)
-    r_sched = spmm_launch(g, S, lut, True, True, reduce_cr=1)
-    monkeypatch.setattr(functional, "DEGREE_SCHEDULE_MIN_WIDTH", 1 << 30)
-    assert torch.equal(y_sched, spmm_launch(g, S, lut, True, True))
-    assert torch.equal(r_sched, spmm_launch(g, S, lut, True, True, reduce_cr=1))
+    assert functional.DEGREE_SORTED_COPY
+    y_copy = spmm_launch(g, S, lut, True, True)                  # degree-sorted copy of the CSR (scatter_out = 2)
+    r_copy = spmm_launch(g, S, lut, True, True, reduce_cr=1)
+    gs, order, _ = g.degree_sorted_copy()
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).cpu().numpy()
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(n)) and np.all(np.diff(deg[o]) >= 0)
+    rp_s, col_s, code_s = gs.rowptr.cpu().numpy(), gs.col.cpu().numpy(), gs.code.cpu().numpy()
+    for q in (0, 1, n // 2, n - 2, n - 1):                        # row q of the copy = row order[q], pairs in their order
+        a, b = rowptr[o[q]], rowptr[o[q] + 1]
+        assert np.array_equal(col_s[rp_s[q]:rp_s[q + 1]], col[a:b]) and np.array_equal(code_s[rp_s[q]:rp_s[q + 1]], code[a:b])
+    assert torch.equal(gs.cnt, g.cnt[order.long()])
+    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY", False)  # degree order through an index (scatter_out = 1)
+    assert torch.equal(y_copy, spmm_launch(g, S, lut, True, True))
+    assert torch.equal(r_copy, spmm_launch(g, S, lut, True, True, reduce_cr=1))
+    monkeypatch.setattr(functional, "DEGREE_SCHEDULE_MIN_WIDTH", 1 << 30)   # natural order
+    assert torch.equal(y_copy, spmm_launch(g, S, lut, True, True))
+    assert torch.equal(r_copy, spmm_launch(g, S, lut, True, True, reduce_cr=1))
 
 
 @pytest.mark.parametrize("W,reduce_cr", [(64, 1), (64, 0), (8, 1), (16, 0), (128, 4)])
