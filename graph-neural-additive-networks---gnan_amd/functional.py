@@ -368,6 +368,7 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
 
 FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum over features in its epilogue
 DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
+DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
 
 
@@ -403,7 +404,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
         # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
         plan = g.dense_slice_plan(n_out) if (n_out < DENSE_SLICE_MAX_ROWS and g.n_cols >= DENSE_SLICE_MIN_COLS) else None
     elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
-        if DEGREE_SORTED_COPY and not per_row and not weight_by_col:
+        if DEGREE_SORTED_COPY and not per_row and not weight_by_col and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
             g, row_ids, plan = g.degree_sorted_copy()   # walk a degree-sorted copy of the CSR, store rows at their own index
             scatter = 2
         else:

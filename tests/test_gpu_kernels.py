@@ -501,6 +501,7 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     lut = torch.tensor([[1.0], [0.5], [0.01]], device=DEV)
     assert functional.DEGREE_SORTED_COPY
+    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 2)
     y_copy = spmm_launch(g, S, lut, True, True)                  # degree-sorted copy of the CSR (scatter_out = 2)
     r_copy = spmm_launch(g, S, lut, True, True, reduce_cr=1)
     gs, order, _ = g.degree_sorted_copy()
