@@ -57,8 +57,9 @@ class VertexPartition:
 
 
 def _hip_compute() -> Dict[str, Callable]:
-    from .functional import column_sums, feature_mlps, rho_aggregate
-    return {"feature_mlps": feature_mlps, "column_sums": column_sums, "aggregate": rho_aggregate}
+    from .functional import column_sums, feature_mlps, rest_total_term, rho_aggregate
+    return {"feature_mlps": feature_mlps, "column_sums": column_sums, "aggregate": rho_aggregate,
+            "rest_total_term": rest_total_term}
 
 
 def gather_operand(local: torch.Tensor, part: VertexPartition, group=None) -> torch.Tensor:
@@ -241,10 +242,21 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, total_rows=plan.n_own, **kw)
     mark("fmlp")
     mark("gather")
+    rc = out_channels if order == "reference" else 0
+    if part.world > 1 and not torch.is_grad_enabled() and "rest_total_term" in ops:
+        # inference: the aggregation does not wait for the all-reduce of the 256-byte column sums (tens of microseconds of
+        # collective latency against ~0.6 ms of kernel on a 1/8 share) — it runs against zero sums, i.e. computes
+        # sum_d (wt_d - wt_rest) * S, and the wt_rest * total term is added once the collective has landed
+        work = dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        mark("total")
+        Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=torch.zeros_like(total), reduce_channels=rc)
+        work.wait()
+        Y = Y + ops["rest_total_term"](plan.graph, lut, use_cnt, total, rc)
+        mark("spmm")
+        return Y
     if part.world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     mark("total")
-    Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total,
-                         reduce_channels=out_channels if order == "reference" else 0)
+    Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total, reduce_channels=rc)
     mark("spmm")
     return Y

@@ -546,6 +546,35 @@ class _RhoAggregate(torch.autograd.Function):
         return dS, dlut, None, None, None, None, None, None
 
 
+def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor, reduce_channels: int = 0,
+                    row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The part of the aggregation that depends on the operand only through its column sums:
+    ``R[q, w] = wt(i_q, D-1, w) * total[w]`` (summed per channel ``w mod reduce_channels`` with the fused read-out).
+
+    ``rho_aggregate(..., s_total=total) == rho_aggregate(..., s_total=zeros) + rest_total_term(..., total)`` up to
+    rounding: a multi-rank forward can run the aggregation while the all-reduce of ``total`` is still in flight and add
+    this term afterwards (inference only: no autograd through it)."""
+    D, Cw = lut.shape[-2], lut.shape[-1]
+    W = int(total.numel())
+    rows = None if row_ids is None else row_ids.long()
+    with torch.no_grad():
+        if lut.dim() == 3:
+            w_rest = (lut[:, D - 1, :] if rows is None else lut[rows, D - 1, :]).float()          # [n, Cw]
+        else:
+            w_rest = lut[D - 1].float().unsqueeze(0)                                              # [1, Cw]
+        if use_cnt:
+            c = g.cnt[:, D - 1:D] if rows is None else g.cnt[rows, D - 1:D]
+            w_rest = w_rest / c.clamp_min(1).float()
+        n = g.n_rows if rows is None else int(rows.numel())
+        w_rest = w_rest.expand(n, Cw)
+        idx = torch.arange(W, device=total.device)
+        if reduce_channels:
+            A = torch.zeros((Cw, reduce_channels), dtype=torch.float32, device=total.device)
+            A.index_put_((idx % Cw, idx % reduce_channels), total.float(), accumulate=True)
+            return w_rest @ A
+        return w_rest[:, idx % Cw] * total.float().unsqueeze(0)
+
+
 def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
                   with_rest: Optional[bool] = None, row_ids: Optional[torch.Tensor] = None,
                   s_total: Optional[torch.Tensor] = None, reduce_channels: int = 0) -> torch.Tensor:

@@ -137,7 +137,7 @@ def _halo_compute(sd, C):
     return {**base, "aggregate": aggregate}
 
 
-def _halo_worker(rank, world, port, n, F, C, order, out_dir):
+def _halo_worker(rank, world, port, n, F, C, order, out_dir, overlap=False):
     from gnan_amd.distributed import build_halo_plan, halo_recompute_forward
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -153,18 +153,25 @@ def _halo_worker(rank, world, port, n, F, C, order, out_dir):
         halo = ids[plan.n_own:]
         assert bool((halo[1:] > halo[:-1]).all()) and not bool(((halo >= part.lo) & (halo < part.hi)).any())
         assert set(halo.tolist()) == set(g.col.long().tolist()) - set(range(part.lo, part.hi))
-        y = halo_recompute_forward(x[ids], plan, stack(sd, F, 3, 8, C, True), O.rho_lut(sd, 3), True, order=order,
-                                   out_channels=C, compute=_halo_compute(sd, C))
+        compute = _halo_compute(sd, C)
+        if overlap:   # inference path: aggregate against zero column sums while their all-reduce is in flight, add the rest after
+            from gnan_amd.functional import rest_total_term
+            compute["rest_total_term"] = rest_total_term
+        with torch.no_grad() if overlap else torch.enable_grad():
+            y = halo_recompute_forward(x[ids], plan, stack(sd, F, 3, 8, C, True), O.rho_lut(sd, 3), True, order=order,
+                                       out_channels=C, compute=compute)
         np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,order", [(2, 300, "reference"), (3, 301, "reference"), (2, 300, "sum_first")])
-def test_halo_recompute_forward_equals_single_process(world, n, order, tmp_path):
+@pytest.mark.parametrize("world,n,order,overlap", [(2, 300, "reference", False), (3, 301, "reference", False),
+                                                   (2, 300, "sum_first", False), (2, 300, "reference", True),
+                                                   (3, 301, "sum_first", True)])
+def test_halo_recompute_forward_equals_single_process(world, n, order, overlap, tmp_path):
     F, C = 5, 1
     port = _free_port()
-    mp.spawn(_halo_worker, args=(world, port, n, F, C, order, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_halo_worker, args=(world, port, n, F, C, order, str(tmp_path), overlap), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
     src, dst, x, sd = _problem(n, F, C)
     g = syn.hop1_csr(src, dst, n)

@@ -320,6 +320,27 @@ def test_hub_rows_with_many_slices(W, cr):
     assert torch.equal(y, again)                                     # fixed reduction order
 
 
+@pytest.mark.parametrize("W,Cw,cr,per_row,use_cnt", [(64, 1, 1, False, True), (64, 1, 0, False, True), (8, 4, 4, False, True),
+                                                      (12, 4, 2, False, False), (6, 3, 0, True, False), (64, 1, 4, False, True)])
+def test_rest_bucket_total_can_be_added_afterwards(W, Cw, cr, per_row, use_cnt):
+    """aggregate(total) == aggregate(zero sums) + rest_total_term(total): what lets a multi-rank forward overlap the
+    all-reduce of the column sums with the aggregation (rows, hub slices, fused read-out, per-row tables)."""
+    from gnan_amd.functional import rest_total_term, spmm_launch
+    rng = np.random.default_rng(500 + W + Cw + cr)
+    n, K = 700, 1
+    D = K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(11, 900), (300, 5000)])
+    g = _graph(rowptr, col, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut = torch.from_numpy(rng.standard_normal((n, D, Cw) if per_row else (D, Cw)).astype(np.float32)).to(DEV)
+    total = torch.from_numpy(rng.standard_normal(W).astype(np.float32)).to(DEV) * 50       # NOT the sums of S: any vector
+    fused = spmm_launch(g, S, lut, use_cnt, True, s_total=total, reduce_cr=cr)
+    split = spmm_launch(g, S, lut, use_cnt, True, s_total=torch.zeros_like(total), reduce_cr=cr)
+    split = split + rest_total_term(g, lut, use_cnt, total, cr)
+    assert split.shape == fused.shape
+    assert O.rel_err(split.cpu(), fused.double().cpu()) <= 2e-6
+
+
 @pytest.mark.parametrize("W,cr", [(64, 1), (64, 4), (8, 2), (6, 2), (6, 1), (300, 4), (3, 1), (1, 1)])
 def test_fused_feature_sum_equals_unfused(W, cr):
     """reduce_cr: per-channel sums over the operand columns in the kernel epilogue (rows, hub slices, dense)."""
