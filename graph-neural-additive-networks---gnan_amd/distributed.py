@@ -251,7 +251,7 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
         mark("total")
         Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=torch.zeros_like(total), reduce_channels=rc)
         work.wait()
-        Y = Y + ops["rest_total_term"](plan.graph, lut, use_cnt, total, rc)
+        Y += ops["rest_total_term"](plan.graph, lut, use_cnt, total, rc)
         mark("spmm")
         return Y
     if part.world > 1:

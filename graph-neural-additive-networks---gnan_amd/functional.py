@@ -558,6 +558,11 @@ def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.
     W = int(total.numel())
     rows = None if row_ids is None else row_ids.long()
     with torch.no_grad():
+        if lut.dim() == 2 and Cw == 1 and rows is None and (reduce_channels or W == 1):
+            # the common case in three small launches: per-channel sums of total, times rho(0), times the cached 1/|rest shell|
+            t = total.float().view(-1, max(reduce_channels, 1)).sum(0) * lut[D - 1, 0].float()
+            inv = g.inv_rest_count() if use_cnt else torch.ones((g.n_rows, 1), dtype=torch.float32, device=total.device)
+            return inv * t.unsqueeze(0)
         if lut.dim() == 3:
             w_rest = (lut[:, D - 1, :] if rows is None else lut[rows, D - 1, :]).float()          # [n, Cw]
         else:

@@ -53,6 +53,7 @@ class HopGraph:
     _degree_plan: Optional[LongRowPlan] = field(default=None, repr=False)
     _dense_plans: dict = field(default_factory=dict, repr=False)
     _sorted_copy: Optional["HopGraph"] = field(default=None, repr=False)
+    _inv_rest: Optional[torch.Tensor] = field(default=None, repr=False)
 
     @property
     def is_dense(self) -> bool:
@@ -226,6 +227,12 @@ class HopGraph:
             ptr = torch.arange(n_out + 1, dtype=torch.int32, device=self.device) * spr
             hit = self._dense_plans[key] = LongRowPlan(rows, ptr, n_out, n_out * spr, threshold=0)
         return hit
+
+    def inv_rest_count(self) -> torch.Tensor:
+        """``1 / max(cnt[:, D-1], 1)`` as float32 ``[n_rows, 1]`` (graph data, cached): the normalisation of the rest bucket."""
+        if self._inv_rest is None:
+            self._inv_rest = 1.0 / self.cnt[:, self.n_codes - 1:self.n_codes].clamp_min(1).float()
+        return self._inv_rest
 
     def degree_sorted_copy(self):
         """``(copy, order, plan)``: the CSR stored in the processing order of :meth:`degree_schedule` — row ``q`` of the
