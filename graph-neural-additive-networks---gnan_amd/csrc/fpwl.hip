@@ -252,7 +252,14 @@ __device__ __forceinline__ int tree_sorted_index(int k) {
   return (2 * (k - (1 << l)) + 1) << (NSTEP - 1 - l);
 }
 
-// LDS image of one feature group: [FG][P2] tree words, [tot] (val, slope) pairs, [tot] anchors in piece order.
+// Words of skew between the trees of consecutive feature QUADS.  One ds_read of the search serves the four quads of a
+// wave (lane = (node, quad)), i.e. four different trees; were the trees aligned alike, their level-s nodes would share
+// banks and every level would be a 4-way conflict (SQ_LDS_BANK_CONFLICT: 68 % of the kernel's LDS cycles).  With 8 words
+// of skew the nodes of levels 0-3 of the four trees fall on 32 distinct banks and level 4 on each bank twice.
+constexpr int kTreeSkew = 8;
+
+// LDS image of one feature group: [FG][P2] tree words (+ kTreeSkew words per quad), [tot] (val, slope) pairs, [tot] anchors
+// in piece order.
 template <int FG, int NSTEP, int BS>
 __device__ __forceinline__ void load_tree_tables(const Params& p, float* smem, const int* s_off, int base, int tot,
                                                  bool with_vs) {
@@ -265,10 +272,11 @@ __device__ __forceinline__ void load_tree_tables(const Params& p, float* smem, c
       const int j = tree_sorted_index<NSTEP>(k);
       if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
     }
-    smem[i] = v;
+    smem[i + (f / 4) * kTreeSkew] = v;
   }
-  float2* vs_l = reinterpret_cast<float2*>(smem + FG * P2);
-  float* an_l = smem + FG * P2 + 2 * tot;
+  constexpr int kTreeWords = FG * P2 + (FG / 4) * kTreeSkew;
+  float2* vs_l = reinterpret_cast<float2*>(smem + kTreeWords);
+  float* an_l = smem + kTreeWords + 2 * tot;
   for (int i = tid; i < tot; i += BS) {
     if (with_vs) vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
     an_l[i] = p.anchor[base + i];
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
   const int g_lo = SUM ? 0 : g_first;
   const int g_hi = SUM ? p.n_groups : g_lo + 1;
-  constexpr int kTreeBytes = FG * P2 * 4;           // (val, slope) pairs start behind the trees, the anchors behind them
+  constexpr int kTreeBytes = (FG * P2 + TPN * kTreeSkew) * 4;   // (val, slope) pairs start behind the trees, the anchors behind them
 
   for (int g = g_lo; g < g_hi; ++g) {
     const int k0 = g * FG;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
     __syncthreads();
     load_tree_tables<FG, NSTEP, BS>(p, smem, s_off, base, tot, true);
     __syncthreads();
-    const int Q = static_cast<int>(lds_base) + q * (FPT * P2 * 4);     // tree of the thread's first feature
+    const int Q = static_cast<int>(lds_base) + q * ((FPT * P2 + kTreeSkew) * 4);   // tree of the thread's first feature
     int nQ = -Q, nQ4 = 4 - Q;
     asm volatile("" : "+v"(nQ), "+v"(nQ4));         // two opaque registers: keeps the step at compare, select, shift-add
     const int vs_minus_2an = static_cast<int>(lds_base) + kTreeBytes - 2 * (static_cast<int>(lds_base) + kTreeBytes + 8 * tot);
@@ -658,7 +666,7 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
     int nstep = 6;
     while ((1 << nstep) < p.max_pieces) ++nstep;
     // trees + (val, slope) pairs + anchors in piece order (C == 1: 3 floats per piece); the column-sum scratch re-uses it
-    size_t lds_fast = (static_cast<size_t>(FG) << nstep) * sizeof(float) + table_lds;
+    size_t lds_fast = ((static_cast<size_t>(FG) << nstep) + (FG / 4) * kTreeSkew) * sizeof(float) + table_lds;
     if (p.col_partial && lds_fast < BS * 4 * sizeof(float)) lds_fast = BS * 4 * sizeof(float);
     p.soff_offset = static_cast<int>(lds_fast / sizeof(float));
     lds_fast += (FG + 1) * sizeof(int);
