@@ -506,13 +506,15 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
   }
 }
 
-// Fixed-point moments with a 3-instruction search over padded SORTED anchors (the layout fpwl_fast_kernel had before its
-// search trees; this kernel is bound by its LDS atomics, not by the probes) (whole feature groups, <= 1023 pieces per feature):
-// LDS = padded anchors [FG][2^NSTEP] | 64-bit bins [tot][2][C] | group offsets.
+// Fixed-point moments with the search of fpwl_fast_kernel (skewed breadth-first trees, 3 instructions per step; whole feature
+// groups, <= 1023 pieces per feature).  With padded SORTED anchors, aligned alike for the four quads of a wave, 75 % of this
+// kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT 7.9e8 of SQ_LDS_IDX_ACTIVE 1.06e9 on C4).
+// LDS = trees [FG][2^NSTEP] (+ skew) | 64-bit bins [tot][2][C] | anchors in piece order [tot] | group offsets.
 template <int FG, int NSTEP, int BS>
 __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParams mp) {
   static_assert(FG % 4 == 0, "feature quads");
   constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
+  constexpr int kTreeWords = FG * P2 + TPN * kTreeSkew;                 // even: the bins behind it are 8-byte aligned
   const Params& p = mp.f;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -523,25 +525,31 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
   const int k0 = blockIdx.y * FG;
   const int base = p.off[k0];
   const int tot = p.off[k0 + FG] - base;
-  unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + FG * P2);   // 8-byte aligned: FG * P2 is even
+  unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + kTreeWords);
+  float* an_l = reinterpret_cast<float*>(bins + static_cast<int64_t>(tot) * 2 * C);
   int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
   if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
   for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = 0ull;
+  for (int i = tid; i < tot; i += BS) an_l[i] = p.anchor[base + i];
   __syncthreads();
   for (int i = tid; i < FG * P2; i += BS) {
-    const int f = i >> NSTEP, j = i & (P2 - 1);
-    smem[i] = j < s_off[f + 1] - s_off[f] ? p.anchor[base + s_off[f] + j] : INFINITY;
+    const int f = i >> NSTEP, k = i & (P2 - 1);
+    float v = INFINITY;
+    if (k) {
+      const int j = tree_sorted_index<NSTEP>(k);
+      if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
+    }
+    smem[i + (f / FPT) * kTreeSkew] = v;
   }
   __syncthreads();
-  int pos0[FPT], binoff[FPT];
+  const int Q = static_cast<int>(lds_base) + q * ((FPT * P2 + kTreeSkew) * 4);   // tree of the thread's first feature
+  int nQ = -Q, nQ4 = 4 - Q;
+  asm volatile("" : "+v"(nQ), "+v"(nQ4));           // two opaque registers: compare, select, shift-add per step
+  int binoff[FPT];
 #pragma unroll
-  for (int f = 0; f < FPT; ++f) {
-    const int fg = q * FPT + f;
-    pos0[f] = static_cast<int>(lds_base) + (fg << NSTEP) * 4;
-    binoff[f] = s_off[fg];
-  }
+  for (int f = 0; f < FPT; ++f) binoff[f] = s_off[q * FPT + f];
   const double s0 = mp.scales[0], s1 = mp.scales[1];
   for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
     const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
@@ -553,22 +561,23 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
 #pragma unroll
       for (int f = 0; f < FPT; ++f) xv[f] = xr[f];
     }
-    int pos[FPT];
+    int a[FPT];
 #pragma unroll
-    for (int f = 0; f < FPT; ++f) pos[f] = pos0[f];
+    for (int f = 0; f < FPT; ++f) a[f] = Q + 4;     // node 1 = root
 #pragma unroll
-    for (int step = P2 / 2; step >= 1; step >>= 1) {
+    for (int step = 0; step < NSTEP; ++step) {
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const float a = lds_f32(pos[f] + 4 * step);
-        pos[f] += a <= xv[f] ? 4 * step : 0;
+        const float e = lds_f32(a[f] + f * (P2 * 4));
+        a[f] = (a[f] << 1) + (e <= xv[f] ? nQ4 : nQ);
       }
     }
     const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0 + q * FPT) * C);
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {
-      const float d = xv[f] - lds_f32(pos[f]);
-      unsigned long long* b = bins + static_cast<int64_t>(binoff[f] + ((pos[f] - pos0[f]) >> 2)) * 2 * C;
+      const int piece = binoff[f] + (((a[f] - Q) >> 2) - P2);
+      const float d = xv[f] - an_l[piece];
+      unsigned long long* b = bins + static_cast<int64_t>(piece) * 2 * C;
       for (int c = 0; c < C; ++c) {
         const float gv = gr[p.sum_features ? c : f * C + c];
         atomicAdd(b + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv) * s0)));
@@ -588,7 +597,8 @@ template <int FG, int NSTEP, int BS>
 int launch_moments_fast(MomentParams mp, hipStream_t st) {
   Params& p = mp.f;
   const size_t pieces = static_cast<size_t>(p.max_group_pieces);
-  size_t lds = (static_cast<size_t>(FG) << NSTEP) * sizeof(float) + pieces * 2 * static_cast<size_t>(p.C) * sizeof(unsigned long long);
+  size_t lds = ((static_cast<size_t>(FG) << NSTEP) + (FG / 4) * kTreeSkew) * sizeof(float) +
+               pieces * 2 * static_cast<size_t>(p.C) * sizeof(unsigned long long) + pieces * sizeof(float);
   p.soff_offset = static_cast<int>(lds / sizeof(float));
   lds += (FG + 1) * sizeof(int);
   if (lds > 150 * 1024) return -1;                       // caller falls back to the plain kernel
