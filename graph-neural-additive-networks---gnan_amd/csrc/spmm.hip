@@ -497,7 +497,7 @@ void spmm_kernel(const Params p) {
 // one or two slices each (R-MAT 10M/100M: 33 068 rows, 45 284 slices, at most 114 per row), so a workgroup per row was
 // bound by the workgroup launch rate (0.10 ms).  Lane = column (64 columns per pass); narrower operands put
 // K = 64 / W' lanes on a column (W' = W rounded up to a power of two), lane k takes slices k, k + K, ...; loads are
-// issued eight at a time; the K partial sums are added in lane order.  One fixed order per row: bit-reproducible.
+// issued eight at a time; the K partial sums meet in a fixed butterfly.  One fixed order per row: bit-reproducible.
 __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
   const int lane = threadIdx.x & (kWave - 1);
   const int r = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
@@ -535,9 +535,9 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
         all += src[s * row + p.W];
       }
     }
-    for (int kk = 1; kk < K; ++kk) {     // slice lanes -> lane 0 of the column, in lane order
-      const float a2 = __shfl(acc, lane % wp + kk * wp), b2 = __shfl(all, lane % wp + kk * wp);
-      if (k == 0) { acc += a2; all += b2; }
+    for (int off = wp; off < kWave; off <<= 1) {   // slice lanes of a column: fixed butterfly, every lane ends with the sum
+      acc += __shfl_xor(acc, off);
+      all += __shfl_xor(all, off);
     }
     const bool owner = k == 0 && w < p.W;
     if (owner) {
@@ -1038,13 +1038,9 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
 #pragma unroll
         for (int d = 0; d < 4; ++d) t[d] += gp.slice_T[(static_cast<int64_t>(s) * 4 + d) * p.W + w];
     }
-    for (int kk = 1; kk < K; ++kk) {       // slice lanes -> lane 0 of the column, in lane order
+    for (int off = wp; off < kWave; off <<= 1)   // slice lanes of a column: fixed butterfly, every lane ends with the sum
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const float v = __shfl(t[d], lane % wp + kk * wp);
-        if (k == 0) t[d] += v;
-      }
-    }
+      for (int d = 0; d < 4; ++d) t[d] += __shfl_xor(t[d], off);
     if (k == 0 && w < p.W) {
       if (p.s_total) {
         float lower = 0.f;
@@ -1075,19 +1071,40 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
 }
 
 // dlut[d] = sum over the workgroup / hub-row partials, fixed order
-__global__ __launch_bounds__(256) void spmm_lut_grad_final_kernel(const double* __restrict__ blk, int64_t n, int D,
-                                                                  float* __restrict__ out) {
-  __shared__ double red[256];
-  const int d = blockIdx.x;
-  double s = 0.0;
-  for (int64_t b = threadIdx.x; b < n; b += 256) s += blk[b * 4 + d];
-  red[threadIdx.x] = s;
+__global__ __launch_bounds__(1024) void spmm_lut_grad_final_kernel(const double* __restrict__ blk, int64_t n, int D,
+                                                                   float* __restrict__ out) {
+  // one 1024-thread workgroup: a thread adds whole [4] records (32 contiguous bytes), eight loads in flight; the partials
+  // meet in a fixed tree.  (Four 256-thread workgroups walking 72k records of a 10M-node graph one by one took 95 us.)
+  __shared__ double red[4][1024];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const double2* rec = reinterpret_cast<const double2*>(blk);
+  int64_t b = threadIdx.x;
+  for (; b + 7 * 1024 < n; b += 8 * 1024) {
+    double2 lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      lo[u] = rec[(b + u * 1024) * 2];
+      hi[u] = rec[(b + u * 1024) * 2 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s[0] += lo[u].x; s[1] += lo[u].y; s[2] += hi[u].x; s[3] += hi[u].y;
+    }
+  }
+  for (; b < n; b += 1024) {
+    const double2 lo = rec[b * 2], hi = rec[b * 2 + 1];
+    s[0] += lo.x; s[1] += lo.y; s[2] += hi.x; s[3] += hi.y;
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) red[d][threadIdx.x] = s[d];
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+  for (int st = 512; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) red[d][threadIdx.x] += red[d][threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && d < D) out[d] = static_cast<float>(red[0]);
+  if (static_cast<int>(threadIdx.x) < D && threadIdx.x < 4) out[threadIdx.x] = static_cast<float>(red[threadIdx.x][0]);
 }
 
 template <int VEC, int LPR>
@@ -1104,7 +1121,7 @@ int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut)
     if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
   }
   if (gp.reduce_rows) {
-    hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(4), dim3(256), 0, st, gp.blk, row_blocks + p.n_long, p.D, dlut);
+    hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(1), dim3(1024), 0, st, gp.blk, row_blocks + p.n_long, p.D, dlut);
     return gnan::check_launch("spmm_lut_grad_final_kernel");
   }
   return GNAN_OK;
@@ -1135,7 +1152,7 @@ extern "C" size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, in
   int vec, lpr;
   pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
   size_t bytes = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
-  bytes = (bytes + 7) / 8 * 8;
+  bytes = (bytes + 15) / 16 * 16;
   if (reduce_rows) bytes += lut_grad_blk_entries(a, vec, lpr) * 4 * sizeof(double);
   return bytes;
 }
@@ -1167,7 +1184,7 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
   gp.dY = dY; gp.dy_stride = dy_stride; gp.dy_channels = dy_channels; gp.dwt = dwt; gp.reduce_rows = reduce_rows;
   gp.slice_T = static_cast<float*>(workspace);
   size_t off = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
-  off = (off + 7) / 8 * 8;
+  off = (off + 15) / 16 * 16;   // the final reduction reads 16-byte halves of the [4] records
   gp.blk = reinterpret_cast<double*>(static_cast<char*>(workspace) + off);
   gp.n_row_blocks = 0;
   return vec == 4 ? launch_lut_grad_lpr<4>(p, gp, lpr, st, dwt) : launch_lut_grad_lpr<1>(p, gp, lpr, st, dwt);
