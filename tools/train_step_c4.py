@@ -61,6 +61,15 @@ def main():
         out[name] = (time.perf_counter() - t0) / reps * 1e3
     out["loss"] = float(step())
     print(json.dumps(out))
+    if os.environ.get("GNAN_STEP_PROFILE"):        # kernel split of the steady-state step (torch.profiler, 3 steps)
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:28]
+        for e in rows:
+            print(f"{e.device_time_total / 3e3:9.3f} ms/step  x{e.count / 3:6.1f}  {e.key[:110]}")
 
 
 if __name__ == "__main__":
