@@ -268,9 +268,10 @@ def main():
     per_step = []                                    # device time of every timed step (HIP events on the compute stream)
     for m in events:
         prev = m["start"]
-        for n in stage_names:
-            stages[n] += prev.elapsed_time(m[n])
-            prev = m[n]
+        for n in stage_names:                        # stages that are empty by construction record no event (0 ms)
+            if n in m:
+                stages[n] += prev.elapsed_time(m[n])
+                prev = m[n]
         per_step.append(m["start"].elapsed_time(m[stage_names[-1]]))
     stages = {n: v / max(1, len(events)) for n, v in stages.items()}
     per_step.sort()

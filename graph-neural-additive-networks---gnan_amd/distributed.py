@@ -97,10 +97,10 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True, **kw)
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
-    mark("gather")
-    if part.world > 1:
+    if part.world > 1:                       # one rank: no exchange, no event (every recorded event is a barrier packet)
+        mark("gather")
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    mark("total")
+        mark("total")
     # reference order: the feature sum of models.py:375-376 rides in the aggregation kernel's epilogue
     Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total,
                          reduce_channels=out_channels if order == "reference" else 0)
@@ -172,13 +172,10 @@ def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lu
     if part.hi > part.lo:
         kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
         operand, total = ops["feature_mlps"](x_cols, stacked_local, False, return_total=True, **kw)   # [N, Fp*C], [Fp*C]
-        mark("fmlp")
-        mark("gather")                                                         # nothing to exchange here
-        mark("total")
+        mark("fmlp")                                                           # no "gather" / "total" stage here
         Y = ops["aggregate"](graph_full, operand, lut, use_cnt, s_total=total, reduce_channels=out_channels)
     else:                                                                      # more ranks than features
-        for name in ("fmlp", "gather", "total"):
-            mark(name)
+        mark("fmlp")
         Y = x_cols.new_zeros((n, out_channels))
     mark("spmm")
     if part.world > 1:
@@ -230,7 +227,7 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
                            compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
                            operand_dtype=torch.float32):
     """Forward on the owned rows from ``x_compact = x[plan.node_ids()]``; returns ``out[lo:hi, :out_channels]``.
-    Same stages and ``marks`` as :func:`partitioned_forward`; the "gather" stage is empty by construction."""
+    Same stages and ``marks`` as :func:`partitioned_forward`; there is no "gather" stage, and "total" only with > 1 rank."""
     ops = compute or _hip_compute()
     mark = marks or (lambda name: None)
     part = plan.part
@@ -241,7 +238,6 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     # ranks' sums add up to the whole graph's without double counting
     operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, total_rows=plan.n_own, **kw)
     mark("fmlp")
-    mark("gather")
     rc = out_channels if order == "reference" else 0
     if part.world > 1 and not torch.is_grad_enabled() and "rest_total_term" in ops:
         # inference: the aggregation does not wait for the all-reduce of the 256-byte column sums (tens of microseconds of
@@ -256,7 +252,7 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
         return Y
     if part.world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    mark("total")
+        mark("total")
     Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total, reduce_channels=rc)
     mark("spmm")
     return Y

@@ -212,6 +212,17 @@ class _GraphedBuild:
         return g(p) if g else _build_padded(p)
 
 
+_PINNED_META = {}
+
+
+def _pinned_meta(dev, n: int) -> torch.Tensor:
+    key = (dev, n)
+    buf = _PINNED_META.get(key)
+    if buf is None:
+        buf = _PINNED_META[key] = torch.empty(n, dtype=torch.int32, pin_memory=True)
+    return buf
+
+
 def _build_tables_hip(p) -> Optional[PwlTables]:
     """Tables by TWO kernel launches (``gnan_pwl_build``: a workgroup per feature finds the kinks and tabulates the
     network in float64, LDS-resident; a second tiny kernel packs the features back to back) and one
@@ -236,7 +247,12 @@ def _build_tables_hip(p) -> Optional[PwlTables]:
                           slope=_lib.ptr(slope), off=_lib.ptr(meta), overflow=meta[F + 1:].data_ptr(),
                           scratch=_lib.ptr(scratch), scratch_bytes=scratch.numel() * 8)
     _lib.check(_lib.lib().gnan_pwl_build(a, _lib.stream_of(anchor)), "gnan_pwl_build")
-    host = meta.tolist()                                            # the ONE device->host copy of the build
+    # the ONE device->host copy of the build: into a cached pinned buffer, asynchronously, then wait for the stream —
+    # a pageable .tolist() goes through a staging copy and costs tens of microseconds during which the GPU idles
+    pinned = _pinned_meta(dev, F + 2)
+    pinned.copy_(meta, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    host = pinned.tolist()
     off_host, overflowed = host[:-1], bool(host[-1])
     biggest = max(b - a_ for a_, b in zip(off_host, off_host[1:]))
     if overflowed or biggest > MAX_PIECES:
