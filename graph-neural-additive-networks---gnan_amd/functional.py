@@ -115,6 +115,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     return (out, total) if want_total else out
 
 
+SPECULATIVE_LOOKUP = os.environ.get("GNAN_SPECULATIVE_LOOKUP", "1") != "0"   # queue the look-up before the piece counts are read back
 MOMENTS_FIXED_POINT = True    # accumulate the per-piece moments in 64-bit fixed point (integer LDS atomics, reproducible)
 _ABS_MAX_CACHE = {}           # (data_ptr, version, shape) -> device scalar: max |x| of the (static) feature matrix
 
@@ -177,13 +178,36 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
     threshold = PWL_MIN_WORK_GRAD if needs_grad else PWL_MIN_WORK
     if algo == _lib.FMLP_PWL or (algo == _lib.FMLP_AUTO and x.shape[0] * p.F >= threshold
                                  and (needs_grad or x.shape[0] >= PWL_MIN_NODES)):
-        from .pwl import build_tables
-        tables = build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
-        if tables is not None:
-            out, total = _fpwl_launch(x, tables, sum_features, want_total=True, out_dtype=out_dtype,
-                                      total_rows=total_rows) if want_total \
-                else (_fpwl_launch(x, tables, sum_features, out_dtype=out_dtype), None)
-            return out, tables, total
+        from .pwl import build_tables, build_tables_lazy, covers, hip_build_applies
+        stacked = StackedMLP(*[_c(t) for t in p[:6]], *p[6:])
+
+        def look_up(t):
+            return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows) \
+                if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype), None)
+
+        if SPECULATIVE_LOOKUP and hip_build_applies(stacked) and not torch.cuda.is_current_stream_capturing():
+            # Sizing the look-up needs the tables' piece counts, i.e. a device->host copy between the table build and the
+            # look-up during which the GPU idles (60-70 us: 1 % of the C4 forward, 6 % of a 1/8 share).  The look-up is
+            # queued right behind the build with the sizes of the LAST forward plus some room; the counts are read
+            # afterwards (they arrived long before) and the look-up is queued again in the rare case they outgrew the guess.
+            pending = build_tables_lazy(stacked)
+            guess = pending.speculative()
+            res = None
+            if guess is not None:
+                try:
+                    res = look_up(guess)
+                except _lib.GnanHipError:          # a guess the kernel refuses is just a wrong guess
+                    res = None
+            tables = pending.resolve()
+            if tables is not None:
+                if res is None or not covers(guess, tables):
+                    res = look_up(tables)
+                return res[0], tables, res[1]
+        else:
+            tables = build_tables(stacked)
+            if tables is not None:
+                out, total = look_up(tables)
+                return out, tables, total
         if algo == _lib.FMLP_PWL:
             raise _lib.GnanHipError("shape functions need more pieces than the look-up kernel supports")
     return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo), None, None

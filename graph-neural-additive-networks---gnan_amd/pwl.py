@@ -223,7 +223,7 @@ def _pinned_meta(dev, n: int) -> torch.Tensor:
     return buf
 
 
-def _build_tables_hip(p) -> Optional[PwlTables]:
+def _build_tables_hip(p, lazy: bool = False):
     """Tables by TWO kernel launches (``gnan_pwl_build``: a workgroup per feature finds the kinks and tabulates the
     network in float64, LDS-resident; a second tiny kernel packs the features back to back) and one
     device->host copy of the F+1 offsets.  Covers L in {2, 3}, H <= 128; same result as :func:`_build_padded`."""
@@ -247,30 +247,87 @@ def _build_tables_hip(p) -> Optional[PwlTables]:
                           slope=_lib.ptr(slope), off=_lib.ptr(meta), overflow=meta[F + 1:].data_ptr(),
                           scratch=_lib.ptr(scratch), scratch_bytes=scratch.numel() * 8)
     _lib.check(_lib.lib().gnan_pwl_build(a, _lib.stream_of(anchor)), "gnan_pwl_build")
-    # the ONE device->host copy of the build: into a cached pinned buffer, asynchronously, then wait for the stream —
-    # a pageable .tolist() goes through a staging copy and costs tens of microseconds during which the GPU idles
+    # the ONE device->host copy of the build: into a cached pinned buffer, asynchronously; an event marks its arrival
     pinned = _pinned_meta(dev, F + 2)
     pinned.copy_(meta, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()
-    host = pinned.tolist()
-    off_host, overflowed = host[:-1], bool(host[-1])
-    biggest = max(b - a_ for a_, b in zip(off_host, off_host[1:]))
-    if overflowed or biggest > MAX_PIECES:
-        return None
-    plan = _plan_groups(off_host, C)
-    if plan is None:
-        return None
-    n = off_host[-1]
-    return PwlTables(meta[: F + 1], anchor[:n], val[:n], slope[:n], biggest, plan[0], plan[1])
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(dev))
+    pending = _PendingTables(meta, pinned, done, anchor, val, slope, F, C, (dev, F, p.L, p.H, C), keepalive + [scratch])
+    return pending if lazy else pending.resolve()
+
+
+_LAST_PLAN = {}     # (device, F, L, H, C) -> (max pieces, features per group, max group pieces) of the last exact tables
+
+
+class _PendingTables:
+    """Tables whose kernels are queued but whose piece counts have not been read back yet."""
+
+    def __init__(self, meta, pinned, done, anchor, val, slope, F, C, key, keepalive):
+        self.meta, self.pinned, self.done = meta, pinned, done
+        self.anchor, self.val, self.slope = anchor, val, slope
+        self.F, self.C, self.key, self.keepalive = F, C, key, keepalive
+
+    def speculative(self) -> Optional[PwlTables]:
+        """Tables sized from the LAST forward's piece counts (same power-of-two search depth, 1/8 more room per feature
+        group), usable to queue the look-up before this build's counts are known; None on the first call.  The caller
+        must check :meth:`PwlTables` from :meth:`resolve` against them (:func:`covers`) and re-launch if they fall short."""
+        last = _LAST_PLAN.get(self.key)
+        if last is None:
+            return None
+        biggest, fg, mg = last
+        p2 = 1
+        while p2 < biggest:
+            p2 <<= 1
+        room = min(mg + mg // 8 + 8, LDS_LIMIT // ((1 + 2 * self.C) * 4))     # never ask for more LDS than the kernel accepts
+        if room < mg:
+            return None
+        return PwlTables(self.meta[: self.F + 1], self.anchor, self.val, self.slope, max(p2, 64), fg, room)
+
+    def resolve(self) -> Optional[PwlTables]:
+        self.done.synchronize()
+        host = self.pinned.tolist()
+        off_host, overflowed = host[:-1], bool(host[-1])
+        biggest = max(b - a_ for a_, b in zip(off_host, off_host[1:]))
+        if overflowed or biggest > MAX_PIECES:
+            _LAST_PLAN.pop(self.key, None)
+            return None
+        plan = _plan_groups(off_host, self.C)
+        if plan is None:
+            _LAST_PLAN.pop(self.key, None)
+            return None
+        _LAST_PLAN[self.key] = (biggest, plan[0], plan[1])
+        n = off_host[-1]
+        return PwlTables(self.meta[: self.F + 1], self.anchor[:n], self.val[:n], self.slope[:n], biggest, plan[0], plan[1])
+
+
+def covers(spec: PwlTables, exact: PwlTables) -> bool:
+    """Did a look-up launched with the speculative sizes ``spec`` see every piece of the ``exact`` tables?  It did iff the
+    search depth reaches the largest feature and the LDS image holds the largest group of ``spec``'s grouping."""
+    if exact.max_pieces > spec.max_pieces:
+        return False
+    if exact.features_per_group == spec.features_per_group:
+        return exact.max_group_pieces <= spec.max_group_pieces
+    # different grouping: a group of fg features holds at most fg * max_pieces pieces
+    return spec.features_per_group * exact.max_pieces <= spec.max_group_pieces
 
 
 BUILD_BACKEND = "auto"       # "auto": HIP kernel where it applies, else the (graph-replayed) torch restatement; "torch"
 
 
+def hip_build_applies(p) -> bool:
+    return BUILD_BACKEND == "auto" and p.w_last.is_cuda and p.L in (2, 3) and 1 <= p.H <= 128
+
+
+@torch.no_grad()
+def build_tables_lazy(p):
+    """Queue the table build and return a :class:`_PendingTables` (kernel route only; check :func:`hip_build_applies`)."""
+    return _build_tables_hip(p, lazy=True)
+
+
 @torch.no_grad()
 def build_tables(p, use_graph: bool = True) -> Optional[PwlTables]:
     """Tabulate all F shape functions; returns None if some feature needs more than MAX_PIECES pieces."""
-    if BUILD_BACKEND == "auto" and p.w_last.is_cuda and p.L in (2, 3) and 1 <= p.H <= 128:
+    if hip_build_applies(p):
         return _build_tables_hip(p)
     packed, anchor, val, sl, keep = _GraphedBuild.run(p) if use_graph else _build_padded(p)
     C = val.shape[-1]

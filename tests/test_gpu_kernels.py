@@ -415,6 +415,35 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
 
 
+def test_speculative_lookup_survives_a_wrong_guess(monkeypatch):
+    """The look-up is queued with the LAST forward's table sizes before this forward's are known: same output when the
+    guess was right, when there was none, and when it was far too small (the look-up is then queued again)."""
+    from gnan_amd import _lib, functional, pwl
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    F, L, H, C, n = 32, 3, 32, 1, 70000
+    sd = _mlp_state(F, L, H, C, True, seed=77)
+    st = _stack(sd, F, L, H, C, True)
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(5)).to(DEV)
+    monkeypatch.setattr(functional, "SPECULATIVE_LOOKUP", False)
+    with torch.no_grad():
+        want, want_tot = feature_mlps(x, st, False, return_total=True)
+    monkeypatch.setattr(functional, "SPECULATIVE_LOOKUP", True)
+    pwl._LAST_PLAN.clear()
+    with torch.no_grad():
+        first, first_tot = feature_mlps(x, st, False, return_total=True)          # no guess yet
+        assert len(pwl._LAST_PLAN) == 1
+        second, second_tot = feature_mlps(x, st, False, return_total=True)        # right guess
+        key = next(iter(pwl._LAST_PLAN))
+        pwl._LAST_PLAN[key] = (5, 16, 40)                                         # far too small: depth 3 bits, 40 pieces per group
+        third, third_tot = feature_mlps(x, st, False, return_total=True)
+        pwl._LAST_PLAN[key] = (5, 4, 4000)                                        # another grouping, too shallow a search
+        fourth = feature_mlps(x, st, True)
+    for got, tot in ((first, first_tot), (second, second_tot), (third, third_tot)):
+        assert torch.equal(got, want) and torch.equal(tot, want_tot)
+    assert O.rel_err(fourth.cpu(), want.double().sum(1, keepdim=True).cpu()) <= 1e-6
+
+
 @pytest.mark.parametrize("n,F", [(70_000, 64), (300_000, 16), (5000, 32)])
 def test_fused_column_sums_of_table_lookup(n, F, monkeypatch):
     """feature_mlps(return_total=True): the look-up kernel's fused column sums == a separate pass over its output."""
