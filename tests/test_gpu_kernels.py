@@ -415,13 +415,14 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
 
 
-def test_speculative_lookup_survives_a_wrong_guess(monkeypatch):
+@pytest.mark.parametrize("C", [1, 3])
+def test_speculative_lookup_survives_a_wrong_guess(C, monkeypatch):
     """The look-up is queued with the LAST forward's table sizes before this forward's are known: same output when the
     guess was right, when there was none, and when it was far too small (the look-up is then queued again)."""
     from gnan_amd import _lib, functional, pwl
     from gnan_amd.functional import feature_mlps
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
-    F, L, H, C, n = 32, 3, 32, 1, 70000
+    F, L, H, n = 32, 3, 32, 70000
     sd = _mlp_state(F, L, H, C, True, seed=77)
     st = _stack(sd, F, L, H, C, True)
     x = torch.rand(n, F, generator=torch.Generator().manual_seed(5)).to(DEV)
@@ -441,7 +442,7 @@ def test_speculative_lookup_survives_a_wrong_guess(monkeypatch):
         fourth = feature_mlps(x, st, True)
     for got, tot in ((first, first_tot), (second, second_tot), (third, third_tot)):
         assert torch.equal(got, want) and torch.equal(tot, want_tot)
-    assert O.rel_err(fourth.cpu(), want.double().sum(1, keepdim=True).cpu()) <= 1e-6
+    assert O.rel_err(fourth.cpu(), want.double().view(n, F, C).sum(1).cpu()) <= 1e-6
 
 
 @pytest.mark.parametrize("n,F", [(70_000, 64), (300_000, 16), (5000, 32)])
