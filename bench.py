@@ -74,11 +74,20 @@ def spmm_algorithmic_bytes(g, W, W_out, elem=4):
 
 
 def git_sha():
+    """Commit of the sources: from git where the checkout has a .git, else the stamp build.py left next to the library
+    (the GPU boxes receive a snapshot without .git)."""
     try:
         import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                             timeout=5).stdout.strip()
+        if sha:
+            return sha
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "graph-neural-additive-networks---gnan_amd", "libgnan_hip.sha")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 

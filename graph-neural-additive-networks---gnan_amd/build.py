@@ -53,7 +53,22 @@ def build(force: bool = False, verbose: bool = True, out: str = OUT) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    _stamp(out)
     return out
+
+
+def _stamp(out: str) -> None:
+    """Record the commit the library was built from next to it (bench.py reports it where there is no .git)."""
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                             timeout=5).stdout.strip()
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                               text=True, timeout=10).stdout.strip()
+        if sha:
+            with open(os.path.splitext(out)[0] + ".sha", "w") as f:
+                f.write(sha + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":
