@@ -45,6 +45,7 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
 
 def build(force: bool = False, verbose: bool = True, out: str = OUT) -> str:
     if not force and out == OUT and not needs_build():
+        _stamp(out)
         return out
     os.makedirs(OBJ_DIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
