@@ -94,6 +94,8 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     # the column sums of the operand (rest-bucket total) come out of the shape-function pass; the ranks add
     # their W-float partials instead of re-reading the gathered operand
     kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
+    if compute is None and out_channels == 1:
+        kw["pad_ok"] = True        # a ragged feature count may come back padded with zero columns: the read-out sums them away
     operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True, **kw)
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
@@ -233,6 +235,8 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     part = plan.part
     mark("start")
     kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
+    if compute is None and out_channels == 1:
+        kw["pad_ok"] = True        # a ragged feature count may come back padded with zero columns: the read-out sums them away
     sum_first = order == "sum_first"
     # the column sums ride in the shape-function pass, restricted to the owned rows: they partition the nodes, so the
     # ranks' sums add up to the whole graph's without double counting

@@ -194,13 +194,14 @@ class _PathBase(nn.Module):
     def _dropout_active(self) -> bool:
         return bool(self.training and self.dropout and self.dropout > 0)
 
-    def _features(self, x, name, mlps, sum_features: bool):
-        """Shape functions of all features: fused HIP kernels, or the Dropout cold path described above."""
+    def _features(self, x, name, mlps, sum_features: bool, pad_ok: bool = False):
+        """Shape functions of all features: fused HIP kernels, or the Dropout cold path described above.
+        ``pad_ok``: the per-feature result may carry extra all-zero columns (``functional.feature_mlps``)."""
         if self._dropout_active():
             from .functional import _fmlp_eager
             _lib.require_device(x)
             return _fmlp_eager(x.float(), stack_mlps(mlps), sum_features, dropout=float(self.dropout))
-        return feature_mlps(x, self._stacked(name, mlps), sum_features=sum_features)
+        return feature_mlps(x, self._stacked(name, mlps), sum_features=sum_features, pad_ok=pad_ok)
 
     # ---- inputs -> hop-coded adjacency -----------------------------------------------------
     def _graph(self, inputs, want_norm: bool) -> HopGraph:
@@ -394,15 +395,15 @@ class TensorGNAN(_PathBase):
         use_cnt = bool(self.normalize_rho)
         with_readout = self.is_graph_task and self.readout_n_layers > 0
         if with_readout:
-            fx = self._features(x, "fs", self.fs, False)                              # [N, F]   (f is 1-wide)
-            hidden = rho_aggregate(g, fx, lut, use_cnt).sum(dim=0).view(1, -1)        # [1, F]   models.py:379
+            fx = self._features(x, "fs", self.fs, False, pad_ok=True)                 # [N, F]   (f is 1-wide; + zero columns)
+            hidden = rho_aggregate(g, fx, lut, use_cnt).sum(dim=0).view(1, -1)[:, :x.shape[1]]   # [1, F]   models.py:379
             return self.readout_nam(hidden).T                                         # [C, 1]   models.py:380-384
         if self.aggregation_order == "reference":
             # the upstream evaluation order (models.py:373-376): aggregate every feature column, then sum
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate
             # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
             # in this order.
-            fx = self._features(x, "fs", self.fs, False)                              # [N, F*C]
+            fx = self._features(x, "fs", self.fs, False, pad_ok=True)                 # [N, F*C] (+ zero columns when C == 1)
             Y = rho_aggregate(g, fx, lut, use_cnt, reduce_channels=self.actual_output_dim_f)   # [N, C]
         else:
             S = self._features(x, "fs", self.fs, True)                                # [N, C]  sum-first
@@ -417,9 +418,9 @@ class TensorGNAN(_PathBase):
         x = inputs.x
         g = self._graph(inputs, want_norm=bool(self.normalize_rho)) if _g is None else _g
         lut = self._lut_global(g) if _lut is None else _lut
-        fx = self._features(x, "fs", self.fs, False)                                  # [N, F*C]
+        fx = self._features(x, "fs", self.fs, False, pad_ok=True)                     # [N, F*C] (+ zero columns when C == 1)
         Y = rho_aggregate(g, fx, lut, bool(self.normalize_rho))                       # [N, F*C]
-        return Y.view(x.shape[0], -1, self.actual_output_dim_f)
+        return Y.view(x.shape[0], -1, self.actual_output_dim_f)[:, :x.shape[1]]
 
 
 class GNAN(_GNANCore):

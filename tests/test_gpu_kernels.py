@@ -415,6 +415,47 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("F,L,bias", [(21, 3, True), (33, 2, False), (5, 3, True)])
+def test_ragged_feature_counts_are_padded(F, L, bias, monkeypatch):
+    """F = raw features + the ones column is rarely a multiple of 16: large inputs are evaluated with all-zero shape
+    functions appended (whole 16-feature groups, aligned rows).  Same values and gradients as the unpadded evaluation,
+    in both result layouts, with the fused column sums, and bf16 rows become available."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    H, C, n = 16, 1, 40000
+    sd = _mlp_state(F, L, H, C, bias, seed=F + L)
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(9)).to(DEV)
+    gsum = torch.randn(n, C, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gper = torch.randn(n, F, generator=torch.Generator().manual_seed(2)).to(DEV)
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    results = {}
+    for tag, pad in (("plain", 0), ("padded", 16)):
+        monkeypatch.setattr(functional, "PAD_FEATURES", pad)
+        monkeypatch.setattr(functional, "PAD_MIN_WORK", 1)
+        st = _stack(sd, F, L, H, C, bias)
+        leaves = [t for t in st[:6] if t is not None]
+        for t in leaves:
+            t.requires_grad_(True)
+        s_out = feature_mlps(x, st, True)
+        g_sum = torch.autograd.grad(s_out, leaves, gsum)
+        p_out, tot = feature_mlps(x, st, False, return_total=True)
+        assert p_out.shape == (n, F) and tot.shape == (F,)
+        g_per = torch.autograd.grad(p_out, leaves, gper)
+        wide = feature_mlps(x, st, False, pad_ok=True)
+        results[tag] = (s_out.detach(), p_out.detach(), tot, g_sum, g_per, wide.detach())
+    a, b = results["plain"], results["padded"]
+    assert b[5].shape == (n, (F + 15) // 16 * 16) and float(b[5][:, F:].abs().max()) == 0.0 and torch.equal(b[5][:, :F], b[1])
+    assert a[5].shape == (n, F)
+    assert O.rel_err(b[0].cpu(), a[0].double().cpu()) <= 2e-6 and O.rel_err(b[1].cpu(), a[1].double().cpu()) <= 2e-6
+    assert O.rel_err(b[2].cpu(), a[2].double().cpu()) <= 2e-6
+    for ga, gb in zip(a[3] + a[4], b[3] + b[4]):
+        assert ga.shape == gb.shape and O.rel_err(gb.cpu(), ga.double().cpu()) <= 1e-5
+    monkeypatch.setattr(functional, "PAD_FEATURES", 16)
+    with torch.no_grad():
+        rows16 = feature_mlps(x, _stack(sd, F, L, H, C, bias), False, out_dtype=torch.bfloat16, pad_ok=True)
+    assert rows16.dtype == torch.bfloat16 and torch.equal(rows16[:, :F], a[1].to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("C", [1, 3])
 def test_speculative_lookup_survives_a_wrong_guess(C, monkeypatch):
     """The look-up is queued with the LAST forward's table sizes before this forward's are known: same output when the
