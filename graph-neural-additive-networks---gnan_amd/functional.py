@@ -331,7 +331,8 @@ class _FeatureMLPs(torch.autograd.Function):
 
 
 PAD_FEATURES = 16            # the fast look-up / moment kernels and the 16-byte operand gathers want whole 16-feature groups
-PAD_MIN_WORK = 1 << 22       # n * F from which a ragged feature count is padded (below it nothing is bound by those kernels)
+PAD_MIN_WORK = 1 << 26       # n * F from which a ragged feature count is padded: the arxiv-shaped graph (n * F = 2^24.4) is
+                             # bound by the host, the six concatenations (and their backward) cost it 0.1 / 1.5 ms
 _X_PAD_CACHE = {}            # (data_ptr, version, shape, ...) -> zero-padded copy of a (static) feature matrix
 
 
