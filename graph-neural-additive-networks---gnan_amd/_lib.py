@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -58,6 +58,18 @@ class PwlBuildArgs(C.Structure):
     ]
 
 
+class FmlpBwdArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("n", C.c_int64), ("x_stride", C.c_int64),
+        ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32),
+        ("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
+        ("w_last", C.c_void_p), ("b_last", C.c_void_p),
+        ("sum_features", C.c_int32), ("grad", C.c_void_p), ("grad_stride", C.c_int64),
+        ("d_w_first", C.c_void_p), ("d_b_first", C.c_void_p), ("d_w_mid", C.c_void_p), ("d_b_mid", C.c_void_p),
+        ("d_w_last", C.c_void_p), ("d_b_last", C.c_void_p),
+    ]
+
+
 class SpmmArgs(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_cols", C.c_int64),
@@ -83,6 +95,7 @@ SYMBOLS = {
     "gnan_last_error": (C.c_char_p, []),
     "gnan_fmlp_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpArgs)]),
     "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
+    "gnan_fmlp_bwd": (C.c_int, [C.POINTER(FmlpBwdArgs), C.c_void_p]),
     "gnan_pwl_build_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_pwl_build": (C.c_int, [C.POINTER(PwlBuildArgs), C.c_void_p]),
     "gnan_fpwl_total_workspace_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),

@@ -1,0 +1,195 @@
+// Parameter gradients of the shape functions for SMALL batches (gfx950): what autograd computes behind
+// GNAN.py:57-62 when trainer.py:66 calls backward() on graphs of a few thousand nodes (Cora, Mutagenicity), where the
+// forward evaluates the MLPs directly (gnan_fmlp_fwd) and the table route's moments do not pay.
+//
+//   f_k(x) = W3 relu(W2 relu(w1 x + b1) + b2) + b3          (L == 3, H <= 64, C <= 8)
+//   given g[n, c] = dLoss / d f_k(x[n, k])[c]:   d{w1, b1, W2, b2, W3, b3} of every feature k, summed over the nodes.
+//
+// One 256-thread workgroup per feature, nothing crosses workgroups (no atomics: the result does not depend on the
+// schedule).  A wave owns a node at a time; lane j is hidden unit j of both hidden layers.  The lane keeps row j and
+// column j of W2 and row j of dW2 in registers (192 VGPRs: one wave per SIMD), and the activations and deltas of the
+// other units reach it through v_readlane with constant lane numbers — scalar operands of the fmas, no LDS in the node
+// loop.  Per node and wave: 3 H^2 fmas (z2, dW2 += dz2 x h1, dh1 = W2^T dz2).  The four waves' partial sums meet in LDS
+// in wave order at the end.
+#include "common.hpp"
+
+namespace {
+
+using gnan::kWave;
+
+struct BwdParams {
+  const float* x;
+  int64_t n, x_stride;
+  int F, H, C;
+  const float *w_first, *b_first, *w_mid, *b_mid, *w_last, *b_last;
+  int sum_features;
+  const float* grad;
+  int64_t grad_stride;
+  float *d_w_first, *d_b_first, *d_w_mid, *d_b_mid, *d_w_last, *d_b_last;
+};
+
+constexpr int kH = 64;      // lanes = hidden units (H <= 64: the rest idle with zero weights)
+constexpr int kCmax = 8;
+constexpr int kWaves = 4;
+
+__device__ __forceinline__ float lane_value(float v, int lane) {      // lane must be a compile-time constant
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int C>
+__global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParams p) {
+  const int k = blockIdx.x;                       // feature
+  const int j = threadIdx.x & (kWave - 1);        // hidden unit
+  const int wv = threadIdx.x / kWave;             // node slot
+  const int H = p.H;
+  const bool unit = j < H;
+  __shared__ float red[kWaves][kH][17];           // chunked reduction of the waves' partial sums (16 values + pad)
+
+  // this unit's weights
+  const float w1 = unit ? p.w_first[static_cast<int64_t>(k) * H + j] : 0.f;
+  const float b1 = unit && p.b_first ? p.b_first[static_cast<int64_t>(k) * H + j] : 0.f;
+  const float b2 = unit && p.b_mid ? p.b_mid[static_cast<int64_t>(k) * H + j] : 0.f;
+  const float* W2 = p.w_mid + static_cast<int64_t>(k) * H * H;
+  float w2row[kH], w2col[kH], dw2[kH];
+#pragma unroll
+  for (int t = 0; t < kH; ++t) {
+    w2row[t] = unit && t < H ? W2[j * H + t] : 0.f;       // W2[j, t]
+    w2col[t] = unit && t < H ? W2[t * H + j] : 0.f;       // W2[t, j]
+    dw2[t] = 0.f;
+  }
+  float w3[C], dw3[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    w3[c] = unit ? p.w_last[(static_cast<int64_t>(k) * C + c) * H + j] : 0.f;
+    dw3[c] = 0.f;
+  }
+  float dw1 = 0.f, db1 = 0.f, db2 = 0.f;
+  float db3[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) db3[c] = 0.f;
+
+  for (int64_t node = wv; node < p.n; node += kWaves) {
+    const float x = p.x[node * p.x_stride + k];
+    const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
+    float gv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gv[c] = g[c];
+    // forward
+    const float a1 = fmaf(w1, x, b1);
+    const float h1 = unit && a1 > 0.f ? a1 : 0.f;
+    float z2 = b2;
+#pragma unroll
+    for (int t = 0; t < kH; ++t) z2 = fmaf(w2row[t], lane_value(h1, t), z2);
+    const float h2 = unit && z2 > 0.f ? z2 : 0.f;
+    // backward through the output layer
+    float dh2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      dh2 = fmaf(gv[c], w3[c], dh2);
+      dw3[c] = fmaf(gv[c], h2, dw3[c]);
+      db3[c] += gv[c];
+    }
+    const float dz2 = unit && z2 > 0.f ? dh2 : 0.f;
+    db2 += dz2;
+    // dW2[j, t] += dz2_j h1_t;   dh1_j = sum_t W2[t, j] dz2_t
+    float dh1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < kH; ++t) {
+      dw2[t] = fmaf(dz2, lane_value(h1, t), dw2[t]);
+      dh1 = fmaf(w2col[t], lane_value(dz2, t), dh1);
+    }
+    const float dz1 = unit && a1 > 0.f ? dh1 : 0.f;
+    dw1 = fmaf(dz1, x, dw1);
+    db1 += dz1;
+  }
+
+  // waves -> wave 0, in wave order: dW2 sixteen columns at a time, then the vectors
+  float* dW2 = p.d_w_mid + static_cast<int64_t>(k) * H * H;
+  for (int t0 = 0; t0 < kH; t0 += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) red[wv][j][t] = dw2[t0 + t];
+    __syncthreads();
+    if (wv == 0 && unit) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t0 + t < H) {
+          float s = red[0][j][t];
+          for (int w = 1; w < kWaves; ++w) s += red[w][j][t];
+          dW2[j * H + t0 + t] = s;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  red[wv][j][0] = dw1; red[wv][j][1] = db1; red[wv][j][2] = db2;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { red[wv][j][3 + c] = dw3[c]; }
+  __syncthreads();
+  if (wv == 0 && unit) {
+    float s[3 + C];
+#pragma unroll
+    for (int t = 0; t < 3 + C; ++t) {
+      s[t] = red[0][j][t];
+      for (int w = 1; w < kWaves; ++w) s[t] += red[w][j][t];
+    }
+    p.d_w_first[static_cast<int64_t>(k) * H + j] = s[0];
+    if (p.d_b_first) p.d_b_first[static_cast<int64_t>(k) * H + j] = s[1];
+    if (p.d_b_mid) p.d_b_mid[static_cast<int64_t>(k) * H + j] = s[2];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p.d_w_last[(static_cast<int64_t>(k) * C + c) * H + j] = s[3 + c];
+  }
+  if (p.d_b_last) {       // db3 is the same in every lane of a wave: lane 0 of each wave, then wave order
+    __syncthreads();
+    if (j == 0)
+#pragma unroll
+      for (int c = 0; c < C; ++c) red[wv][0][c] = db3[c];
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float s = red[0][0][threadIdx.x];
+      for (int w = 1; w < kWaves; ++w) s += red[w][0][threadIdx.x];
+      p.d_b_last[static_cast<int64_t>(k) * C + threadIdx.x] = s;
+    }
+  }
+}
+
+template <int C>
+int launch_bwd(const BwdParams& p, hipStream_t st) {
+  hipLaunchKernelGGL((fmlp_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F)), dim3(kWaves * kWave), 0, st, p);
+  return gnan::check_launch("fmlp_bwd_kernel");
+}
+
+}  // namespace
+
+extern "C" int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "fmlp_bwd: null args");
+  GNAN_REQUIRE(a->n >= 0 && a->F >= 1, "fmlp_bwd: bad sizes");
+  if (a->L != 3 || a->H < 1 || a->H > kH || a->C < 1 || a->C > kCmax)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fmlp_bwd: covers L == 3, H <= %d, C <= %d (got L=%d H=%d C=%d)", kH, kCmax,
+                      a->L, a->H, a->C);
+  GNAN_REQUIRE(a->w_first && a->w_mid && a->w_last && a->d_w_first && a->d_w_mid && a->d_w_last,
+               "fmlp_bwd: null weight / gradient pointer");
+  GNAN_REQUIRE((a->b_first == nullptr) == (a->d_b_first == nullptr) && (a->b_mid == nullptr) == (a->d_b_mid == nullptr) &&
+                   (a->b_last == nullptr) == (a->d_b_last == nullptr),
+               "fmlp_bwd: a bias gradient is wanted exactly where there is a bias");
+  const int64_t gw = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
+  GNAN_REQUIRE(a->n == 0 || (a->x && a->grad && a->x_stride >= a->F && a->grad_stride >= gw), "fmlp_bwd: bad x / grad");
+  BwdParams p;
+  p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F; p.H = a->H; p.C = a->C;
+  p.w_first = a->w_first; p.b_first = a->b_first; p.w_mid = a->w_mid; p.b_mid = a->b_mid;
+  p.w_last = a->w_last; p.b_last = a->b_last;
+  p.sum_features = a->sum_features; p.grad = a->grad; p.grad_stride = a->grad_stride;
+  p.d_w_first = a->d_w_first; p.d_b_first = a->d_b_first; p.d_w_mid = a->d_w_mid; p.d_b_mid = a->d_b_mid;
+  p.d_w_last = a->d_w_last; p.d_b_last = a->d_b_last;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a->C) {
+    case 1: return launch_bwd<1>(p, st);
+    case 2: return launch_bwd<2>(p, st);
+    case 3: return launch_bwd<3>(p, st);
+    case 4: return launch_bwd<4>(p, st);
+    case 5: return launch_bwd<5>(p, st);
+    case 6: return launch_bwd<6>(p, st);
+    case 7: return launch_bwd<7>(p, st);
+    default: return launch_bwd<8>(p, st);
+  }
+}

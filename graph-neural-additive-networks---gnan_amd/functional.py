@@ -233,6 +233,32 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
     return out
 
 
+HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
+
+
+def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
+    """``gnan_fmlp_bwd``: gradients of the six stacked parameter tensors (None where a bias is absent), in their order."""
+    xd = x.detach().float()
+    if xd.stride(1) != 1:
+        xd = xd.contiguous()
+    g = grad_out.detach().float()
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    keep = [None if t is None else t.detach().float().contiguous() for t in params]
+    outs = [None if t is None else torch.empty_like(t) for t in keep]
+    w_mid, d_w_mid = keep[2][0], outs[2][0]                      # [1, F, H, H] -> [F, H, H]
+    b_mid = None if keep[3] is None else keep[3][0]
+    d_b_mid = None if outs[3] is None else outs[3][0]
+    a = _lib.FmlpBwdArgs(x=_lib.ptr(xd), n=xd.shape[0], x_stride=xd.stride(0), F=F, L=L, H=H, C=C,
+                         w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]), w_mid=_lib.ptr(w_mid), b_mid=_lib.ptr(b_mid),
+                         w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]), sum_features=int(sum_features),
+                         grad=_lib.ptr(g), grad_stride=g.stride(0),
+                         d_w_first=_lib.ptr(outs[0]), d_b_first=_lib.ptr(outs[1]), d_w_mid=_lib.ptr(d_w_mid),
+                         d_b_mid=_lib.ptr(d_b_mid), d_w_last=_lib.ptr(outs[4]), d_b_last=_lib.ptr(outs[5]))
+    _lib.check(_lib.lib().gnan_fmlp_bwd(a, _lib.stream_of(xd)), "gnan_fmlp_bwd")
+    return outs
+
+
 def _fmlp_eager(x: torch.Tensor, p: StackedMLP, sum_features: bool, dropout: float = 0.0) -> torch.Tensor:
     """Batched-GEMM restatement on the device.  Used (a) inside backward passes to obtain parameter gradients
     (recompute + torch autograd on small batches; two probe points per piece on the table path) and (b) as the
@@ -309,6 +335,12 @@ class _FeatureMLPs(torch.autograd.Function):
             pg = [None if not present else next(it) for present in ctx.present]
             pg = [None if g is None else g.to(torch.float32) for g in pg]
             return (None, None, None, None, None, None, None, None, None, *pg)
+        if (HIP_SMALL_BACKWARD and L == 3 and H <= 64 and C <= 8 and not ctx.needs_input_grad[0] and x.is_cuda
+                and x.shape[0] > 0):
+            # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
+            # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch
+            # restatement below materialises [F, n, H] activations for the same sums (Cora-shaped: 1 GB per layer)
+            return (None,) * 9 + tuple(_fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F))
         grads = [torch.zeros_like(t) for t in live]
         n = x.shape[0]
         chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))

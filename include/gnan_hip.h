@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 17
+#define GNAN_ABI_VERSION 18
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -83,6 +83,35 @@ enum gnan_fmlp_algo { GNAN_FMLP_AUTO = 0, GNAN_FMLP_LANE = 1, GNAN_FMLP_MFMA = 2
 
 size_t gnan_fmlp_fwd_workspace_bytes(const gnan_fmlp_args* a);
 int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream);
+
+/* Parameter gradients of the shape functions for small batches — what autograd computes behind GNAN.py:57-62 when
+ * trainer.py:66 calls backward() on a graph of a few thousand nodes (the forward was gnan_fmlp_fwd):
+ *   d_w_first[k, j] = sum_n dLoss/df_k(x[n,k]) . df_k/dw1_j   etc., one workgroup per feature, no atomics (reproducible).
+ * grad is [n, C] with sum_features (every feature sees the same upstream gradient) or [n, F*C].  Covers L == 3, H <= 64,
+ * C <= 8; d_b_* must be NULL exactly where the bias is NULL.  Large batches use gnan_fpwl_moments instead. */
+typedef struct gnan_fmlp_bwd_args {
+  const float* x;        /* [n, F], row stride x_stride floats */
+  int64_t n;
+  int64_t x_stride;
+  int32_t F, L, H, C;
+  const float* w_first;  /* [F, H] */
+  const float* b_first;  /* [F, H] or NULL */
+  const float* w_mid;    /* [F, H, H] */
+  const float* b_mid;    /* [F, H] or NULL */
+  const float* w_last;   /* [F, C, H] */
+  const float* b_last;   /* [F, C] or NULL */
+  int32_t sum_features;
+  const float* grad;
+  int64_t grad_stride;
+  float* d_w_first;
+  float* d_b_first;
+  float* d_w_mid;
+  float* d_b_mid;
+  float* d_w_last;
+  float* d_b_last;
+} gnan_fmlp_bwd_args;
+
+int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shape functions by exact piecewise-linear table look-up — same outputs as gnan_fmlp_fwd.

@@ -415,6 +415,43 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("F,H,C,bias,n", [(3, 8, 1, True, 203), (20, 64, 3, True, 1000), (7, 33, 7, False, 5),
+                                           (15, 64, 1, False, 31), (2, 64, 8, True, 1), (129, 64, 1, True, 3000)])
+@pytest.mark.parametrize("sum_features", [True, False])
+def test_small_batch_backward_kernel_vs_autograd(F, H, C, bias, n, sum_features, monkeypatch):
+    """gnan_fmlp_bwd (one workgroup per feature, gradients accumulated in registers) == the batched-GEMM restatement
+    differentiated by torch, and both == autograd through the float64 oracle; bit-identical from run to run."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    L = 3
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_AUTO)
+    sd = _mlp_state(F, L, H, C, bias, seed=F * 3 + H + C)
+    x = (torch.rand(n, F, generator=torch.Generator().manual_seed(3)) * 4 - 2).to(DEV)
+    width = C if sum_features else F * C
+    gup = torch.randn(n, width, generator=torch.Generator().manual_seed(4)).to(DEV)
+    got = {}
+    for tag, on in (("hip", True), ("torch", False), ("hip2", True)):
+        monkeypatch.setattr(functional, "HIP_SMALL_BACKWARD", on)
+        st = _stack(sd, F, L, H, C, bias)
+        leaves = [t for t in st[:6] if t is not None]
+        for t in leaves:
+            t.requires_grad_(True)
+        out = feature_mlps(x, st, sum_features)
+        got[tag] = torch.autograd.grad(out, leaves, gup)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.feature_mlps(x.cpu().double(), sd64)                      # [n, F, C]
+    ref = ref.sum(1) if sum_features else ref.reshape(n, -1)
+    ref.backward(gup.cpu().double())
+    scale = max(float(v.grad.abs().max()) for v in sd64.values())
+    for a, b, c in zip(got["hip"], got["torch"], got["hip2"]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-30), (float((a - b).abs().max()), scale)
+        assert torch.equal(a, c)
+    # against the oracle's autograd: first-layer weights of all features
+    w1 = torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)])
+    assert O.rel_err(got["hip"][0].cpu(), w1) <= 1e-5
+
+
 @pytest.mark.parametrize("F,L,bias", [(21, 3, True), (33, 2, False), (5, 3, True)])
 def test_ragged_feature_counts_are_padded(F, L, bias, monkeypatch):
     """F = raw features + the ones column is rarely a multiple of 16: large inputs are evaluated with all-zero shape
