@@ -2,7 +2,7 @@
 // GNAN.py:57-62 when trainer.py:66 calls backward() on graphs of a few thousand nodes (Cora, Mutagenicity), where the
 // forward evaluates the MLPs directly (gnan_fmlp_fwd) and the table route's moments do not pay.
 //
-//   f_k(x) = W3 relu(W2 relu(w1 x + b1) + b2) + b3          (L == 3, H <= 64, C <= 8)
+//   f_k(x) = W3 relu(W2 relu(w1 x + b1) + b2) + b3          (L == 3; L == 2 without the middle layer; H <= 64, C <= 8)
 //   given g[n, c] = dLoss / d f_k(x[n, k])[c]:   d{w1, b1, W2, b2, W3, b3} of every feature k, summed over the nodes.
 //
 // One 256-thread workgroup per feature, nothing crosses workgroups (no atomics: the result does not depend on the
@@ -153,8 +153,77 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
   }
 }
 
+// L == 2:  f_k(x) = W3 relu(w1 x + b1) + b3  — no hidden-to-hidden matrix, the same mapping without the readlane loops.
+template <int C>
+__global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdParams p) {
+  const int k = blockIdx.x;
+  const int j = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x / kWave;
+  const int H = p.H;
+  const bool unit = j < H;
+  __shared__ float red[kWaves][kH][17];
+  const float w1 = unit ? p.w_first[static_cast<int64_t>(k) * H + j] : 0.f;
+  const float b1 = unit && p.b_first ? p.b_first[static_cast<int64_t>(k) * H + j] : 0.f;
+  float w3[C], dw3[C], db3[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    w3[c] = unit ? p.w_last[(static_cast<int64_t>(k) * C + c) * H + j] : 0.f;
+    dw3[c] = db3[c] = 0.f;
+  }
+  float dw1 = 0.f, db1 = 0.f;
+  for (int64_t node = wv; node < p.n; node += kWaves) {
+    const float x = p.x[node * p.x_stride + k];
+    const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
+    const float a1 = fmaf(w1, x, b1);
+    const float h1 = unit && a1 > 0.f ? a1 : 0.f;
+    float dh1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float gv = g[c];
+      dh1 = fmaf(gv, w3[c], dh1);
+      dw3[c] = fmaf(gv, h1, dw3[c]);
+      db3[c] += gv;
+    }
+    const float dz1 = unit && a1 > 0.f ? dh1 : 0.f;
+    dw1 = fmaf(dz1, x, dw1);
+    db1 += dz1;
+  }
+  red[wv][j][0] = dw1; red[wv][j][1] = db1;
+#pragma unroll
+  for (int c = 0; c < C; ++c) red[wv][j][2 + c] = dw3[c];
+  __syncthreads();
+  if (wv == 0 && unit) {
+    float s[2 + C];
+#pragma unroll
+    for (int t = 0; t < 2 + C; ++t) {
+      s[t] = red[0][j][t];
+      for (int w = 1; w < kWaves; ++w) s[t] += red[w][j][t];
+    }
+    p.d_w_first[static_cast<int64_t>(k) * H + j] = s[0];
+    if (p.d_b_first) p.d_b_first[static_cast<int64_t>(k) * H + j] = s[1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p.d_w_last[(static_cast<int64_t>(k) * C + c) * H + j] = s[2 + c];
+  }
+  if (p.d_b_last) {
+    __syncthreads();
+    if (j == 0)
+#pragma unroll
+      for (int c = 0; c < C; ++c) red[wv][0][c] = db3[c];
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float s = red[0][0][threadIdx.x];
+      for (int w = 1; w < kWaves; ++w) s += red[w][0][threadIdx.x];
+      p.d_b_last[static_cast<int64_t>(k) * C + threadIdx.x] = s;
+    }
+  }
+}
+
 template <int C>
 int launch_bwd(const BwdParams& p, hipStream_t st) {
+  if (p.w_mid == nullptr) {
+    hipLaunchKernelGGL((fmlp_bwd2_kernel<C>), dim3(static_cast<unsigned>(p.F)), dim3(kWaves * kWave), 0, st, p);
+    return gnan::check_launch("fmlp_bwd2_kernel");
+  }
   hipLaunchKernelGGL((fmlp_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F)), dim3(kWaves * kWave), 0, st, p);
   return gnan::check_launch("fmlp_bwd_kernel");
 }
@@ -164,19 +233,21 @@ int launch_bwd(const BwdParams& p, hipStream_t st) {
 extern "C" int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "fmlp_bwd: null args");
   GNAN_REQUIRE(a->n >= 0 && a->F >= 1, "fmlp_bwd: bad sizes");
-  if (a->L != 3 || a->H < 1 || a->H > kH || a->C < 1 || a->C > kCmax)
-    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fmlp_bwd: covers L == 3, H <= %d, C <= %d (got L=%d H=%d C=%d)", kH, kCmax,
+  if ((a->L != 2 && a->L != 3) || a->H < 1 || a->H > kH || a->C < 1 || a->C > kCmax)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fmlp_bwd: covers L in {2, 3}, H <= %d, C <= %d (got L=%d H=%d C=%d)", kH, kCmax,
                       a->L, a->H, a->C);
-  GNAN_REQUIRE(a->w_first && a->w_mid && a->w_last && a->d_w_first && a->d_w_mid && a->d_w_last,
-               "fmlp_bwd: null weight / gradient pointer");
-  GNAN_REQUIRE((a->b_first == nullptr) == (a->d_b_first == nullptr) && (a->b_mid == nullptr) == (a->d_b_mid == nullptr) &&
+  GNAN_REQUIRE(a->w_first && a->w_last && a->d_w_first && a->d_w_last, "fmlp_bwd: null weight / gradient pointer");
+  GNAN_REQUIRE(a->L == 2 || (a->w_mid && a->d_w_mid), "fmlp_bwd: L == 3 needs w_mid and d_w_mid");
+  GNAN_REQUIRE((a->b_first == nullptr) == (a->d_b_first == nullptr) &&
+                   (a->L == 2 || (a->b_mid == nullptr) == (a->d_b_mid == nullptr)) &&
                    (a->b_last == nullptr) == (a->d_b_last == nullptr),
                "fmlp_bwd: a bias gradient is wanted exactly where there is a bias");
   const int64_t gw = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(a->n == 0 || (a->x && a->grad && a->x_stride >= a->F && a->grad_stride >= gw), "fmlp_bwd: bad x / grad");
   BwdParams p;
   p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F; p.H = a->H; p.C = a->C;
-  p.w_first = a->w_first; p.b_first = a->b_first; p.w_mid = a->w_mid; p.b_mid = a->b_mid;
+  p.w_first = a->w_first; p.b_first = a->b_first;
+  p.w_mid = a->L == 3 ? a->w_mid : nullptr; p.b_mid = a->L == 3 ? a->b_mid : nullptr;
   p.w_last = a->w_last; p.b_last = a->b_last;
   p.sum_features = a->sum_features; p.grad = a->grad; p.grad_stride = a->grad_stride;
   p.d_w_first = a->d_w_first; p.d_b_first = a->d_b_first; p.d_w_mid = a->d_w_mid; p.d_b_mid = a->d_b_mid;

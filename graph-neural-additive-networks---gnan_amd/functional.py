@@ -246,7 +246,8 @@ def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
         g = g.contiguous()
     keep = [None if t is None else t.detach().float().contiguous() for t in params]
     outs = [None if t is None else torch.empty_like(t) for t in keep]
-    w_mid, d_w_mid = keep[2][0], outs[2][0]                      # [1, F, H, H] -> [F, H, H]
+    w_mid = None if keep[2] is None else keep[2][0]              # [1, F, H, H] -> [F, H, H]   (absent for L == 2)
+    d_w_mid = None if outs[2] is None else outs[2][0]
     b_mid = None if keep[3] is None else keep[3][0]
     d_b_mid = None if outs[3] is None else outs[3][0]
     a = _lib.FmlpBwdArgs(x=_lib.ptr(xd), n=xd.shape[0], x_stride=xd.stride(0), F=F, L=L, H=H, C=C,
@@ -335,7 +336,7 @@ class _FeatureMLPs(torch.autograd.Function):
             pg = [None if not present else next(it) for present in ctx.present]
             pg = [None if g is None else g.to(torch.float32) for g in pg]
             return (None, None, None, None, None, None, None, None, None, *pg)
-        if (HIP_SMALL_BACKWARD and L == 3 and H <= 64 and C <= 8 and not ctx.needs_input_grad[0] and x.is_cuda
+        if (HIP_SMALL_BACKWARD and L in (2, 3) and 1 <= H <= 64 and C <= 8 and not ctx.needs_input_grad[0] and x.is_cuda
                 and x.shape[0] > 0):
             # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
             # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch

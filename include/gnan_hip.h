@@ -87,8 +87,9 @@ int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream);
 /* Parameter gradients of the shape functions for small batches — what autograd computes behind GNAN.py:57-62 when
  * trainer.py:66 calls backward() on a graph of a few thousand nodes (the forward was gnan_fmlp_fwd):
  *   d_w_first[k, j] = sum_n dLoss/df_k(x[n,k]) . df_k/dw1_j   etc., one workgroup per feature, no atomics (reproducible).
- * grad is [n, C] with sum_features (every feature sees the same upstream gradient) or [n, F*C].  Covers L == 3, H <= 64,
- * C <= 8; d_b_* must be NULL exactly where the bias is NULL.  Large batches use gnan_fpwl_moments instead. */
+ * grad is [n, C] with sum_features (every feature sees the same upstream gradient) or [n, F*C].  Covers L in {2, 3}
+ * (L == 2: w_mid / b_mid / d_w_mid / d_b_mid are ignored), H <= 64, C <= 8; d_b_* must be NULL exactly where the bias is
+ * NULL.  Large batches use gnan_fpwl_moments instead. */
 typedef struct gnan_fmlp_bwd_args {
   const float* x;        /* [n, F], row stride x_stride floats */
   int64_t n;

@@ -415,15 +415,15 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("F,H,C,bias,n", [(3, 8, 1, True, 203), (20, 64, 3, True, 1000), (7, 33, 7, False, 5),
-                                           (15, 64, 1, False, 31), (2, 64, 8, True, 1), (129, 64, 1, True, 3000)])
+@pytest.mark.parametrize("F,L,H,C,bias,n", [(3, 3, 8, 1, True, 203), (20, 3, 64, 3, True, 1000), (7, 3, 33, 7, False, 5),
+                                             (15, 3, 64, 1, False, 31), (2, 3, 64, 8, True, 1), (129, 3, 64, 1, True, 3000),
+                                             (9, 2, 64, 2, True, 77), (4, 2, 20, 5, False, 300)])
 @pytest.mark.parametrize("sum_features", [True, False])
-def test_small_batch_backward_kernel_vs_autograd(F, H, C, bias, n, sum_features, monkeypatch):
+def test_small_batch_backward_kernel_vs_autograd(F, L, H, C, bias, n, sum_features, monkeypatch):
     """gnan_fmlp_bwd (one workgroup per feature, gradients accumulated in registers) == the batched-GEMM restatement
     differentiated by torch, and both == autograd through the float64 oracle; bit-identical from run to run."""
     from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
-    L = 3
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_AUTO)
     sd = _mlp_state(F, L, H, C, bias, seed=F * 3 + H + C)
     x = (torch.rand(n, F, generator=torch.Generator().manual_seed(3)) * 4 - 2).to(DEV)
