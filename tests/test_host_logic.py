@@ -1,0 +1,88 @@
+"""CPU tests of host-side logic that needs no kernel: the deferred rest-bucket term, the degree-sorted CSR copy, the
+padding of ragged feature counts, the speculative table sizes (gnan_amd/functional.py, graph.py, pwl.py)."""
+import numpy as np
+import pytest
+import torch
+
+import gnan_amd  # noqa: F401
+from gnan_amd import HopGraph, functional, pwl
+from gnan_amd.functional import StackedMLP
+from oracle import gnan_oracle as O
+
+
+def _csr(n_rows, n_cols, K, rng, hubs=()):
+    deg = rng.poisson(5, n_rows)
+    deg[rng.random(n_rows) < 0.15] = 0
+    for r, d in hubs:
+        deg[r] = d
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n_cols, int(rowptr[-1])).astype(np.int32)
+    code = rng.integers(0, K + 1, int(rowptr[-1])).astype(np.uint8)
+    return rowptr, col, code
+
+
+@pytest.mark.parametrize("W,Cw,cr,per_row,use_cnt", [(8, 1, 1, False, True), (8, 1, 0, False, True), (12, 4, 4, False, True),
+                                                      (12, 4, 2, False, False), (6, 3, 0, True, False), (1, 1, 0, False, True)])
+def test_rest_total_term_is_the_rest_bucket_weight_times_the_column_sums(W, Cw, cr, per_row, use_cnt):
+    rng = np.random.default_rng(W + Cw + cr)
+    n, K = 50, 1
+    D = K + 2
+    rowptr, col, code = _csr(n, n, K, rng)
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(code), n_cols=n, n_codes=D)
+    lut = torch.from_numpy(rng.standard_normal((n, D, Cw) if per_row else (D, Cw)).astype(np.float32))
+    total = torch.from_numpy(rng.standard_normal(W).astype(np.float32))
+    got = functional.rest_total_term(g, lut, use_cnt, total, cr)
+    w_rest = (lut[:, D - 1, :] if per_row else lut[D - 1].expand(n, Cw)).double()
+    if use_cnt:
+        w_rest = w_rest / g.cnt[:, D - 1:D].clamp_min(1).double()
+    full = w_rest[:, torch.arange(W) % Cw] * total.double()                 # [n, W]
+    want = full.view(n, W // cr, cr).sum(1) if cr else full
+    assert got.shape == want.shape
+    assert O.rel_err(got, want) <= 1e-6
+
+
+def test_degree_sorted_copy_is_a_row_permutation_of_the_csr():
+    rng = np.random.default_rng(3)
+    n, K = 400, 2
+    rowptr, col, code = _csr(n, n, K, rng, hubs=[(7, 900), (300, 40)])
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(code), n_cols=n, n_codes=K + 2)
+    gs, order, plan = g.degree_sorted_copy()
+    o = order.numpy()
+    deg = np.diff(rowptr)
+    assert np.array_equal(np.sort(o), np.arange(n)) and np.all(np.diff(deg[o]) >= 0)
+    rp = gs.rowptr.numpy()
+    assert np.array_equal(np.diff(rp), deg[o]) and gs.rowptr.dtype == g.rowptr.dtype
+    for q in range(n):
+        a, b = rowptr[o[q]], rowptr[o[q] + 1]
+        assert np.array_equal(gs.col.numpy()[rp[q]:rp[q + 1]], col[a:b])
+        assert np.array_equal(gs.code.numpy()[rp[q]:rp[q + 1]], code[a:b])
+    assert torch.equal(gs.cnt, g.cnt[order.long()])
+    assert plan.n_long == 1 and int(plan.rows[0]) == n - 1                    # the 900-pair row is last in degree order
+    assert g.degree_sorted_copy()[0] is gs                                    # cached
+
+
+def test_padded_stack_appends_zero_functions():
+    F, H, C, Fp = 5, 4, 1, 16
+    g = torch.Generator().manual_seed(0)
+    p = StackedMLP(torch.randn(F, H, generator=g), torch.randn(F, H, generator=g), torch.randn(1, F, H, H, generator=g),
+                   None, torch.randn(F, C, H, generator=g), torch.randn(F, C, generator=g), 3, H, C, F)
+    pp = functional._padded_stack(p, Fp)
+    assert pp.F == Fp and pp.w_first.shape == (Fp, H) and pp.w_mid.shape == (1, Fp, H, H) and pp.b_mid is None
+    assert pp.w_last.shape == (Fp, C, H) and pp.b_last.shape == (Fp, C)
+    assert torch.equal(pp.w_first[:F], p.w_first) and float(pp.w_first[F:].abs().max()) == 0.0
+    assert torch.equal(pp.w_mid[:, :F], p.w_mid) and float(pp.w_mid[:, F:].abs().max()) == 0.0
+    assert float(pp.w_last[F:].abs().max()) == 0.0 and float(pp.b_last[F:].abs().max()) == 0.0
+    x = torch.rand(7, F)
+    xp = functional._padded_x(x, Fp)
+    assert xp.shape == (7, Fp) and torch.equal(xp[:, :F], x) and float(xp[:, F:].abs().max()) == 0.0
+    assert functional._padded_x(x, Fp) is xp                                  # cached per (static) feature matrix
+
+
+def test_speculative_table_sizes_cover_only_what_they_can_hold():
+    exact = pwl.PwlTables(None, None, None, None, 130, 16, 2080)
+    assert pwl.covers(pwl.PwlTables(None, None, None, None, 256, 16, 2348), exact)
+    assert not pwl.covers(pwl.PwlTables(None, None, None, None, 128, 16, 2348), exact)      # search too shallow
+    assert not pwl.covers(pwl.PwlTables(None, None, None, None, 256, 16, 2000), exact)      # LDS image too small
+    assert pwl.covers(pwl.PwlTables(None, None, None, None, 256, 8, 8 * 130), exact)        # another grouping, worst case fits
+    assert not pwl.covers(pwl.PwlTables(None, None, None, None, 256, 8, 8 * 130 - 1), exact)
