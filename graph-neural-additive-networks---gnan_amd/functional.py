@@ -234,6 +234,10 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
 
 
 HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
+# gnan_fmlp_bwd walks a feature's nodes inside ONE workgroup: with few features and many nodes it leaves CUs idle
+# (tools/bwd_small.py: n = 30, F = 15: 0.19 vs 0.56 ms for the torch route; 3000 x 129: 0.61 vs 1.0; 2708 x 1434 x 7 channels:
+# 2.4 vs 7.5; but 16000 x 64: 3.1 vs 2.0) — nodes per workgroup, scaled by how many workgroups short of the chip a launch is
+HIP_SMALL_BACKWARD_MAX_NODES = 32768
 
 
 def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
@@ -337,7 +341,7 @@ class _FeatureMLPs(torch.autograd.Function):
             pg = [None if g is None else g.to(torch.float32) for g in pg]
             return (None, None, None, None, None, None, None, None, None, *pg)
         if (HIP_SMALL_BACKWARD and L in (2, 3) and 1 <= H <= 64 and C <= 8 and not ctx.needs_input_grad[0] and x.is_cuda
-                and x.shape[0] > 0):
+                and 0 < x.shape[0] * max(1, 256 // F) <= HIP_SMALL_BACKWARD_MAX_NODES):
             # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
             # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch
             # restatement below materialises [F, n, H] activations for the same sums (Cora-shaped: 1 GB per layer)
