@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -67,6 +67,7 @@ class FmlpBwdArgs(C.Structure):
         ("sum_features", C.c_int32), ("grad", C.c_void_p), ("grad_stride", C.c_int64),
         ("d_w_first", C.c_void_p), ("d_b_first", C.c_void_p), ("d_w_mid", C.c_void_p), ("d_b_mid", C.c_void_p),
         ("d_w_last", C.c_void_p), ("d_b_last", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -95,6 +96,7 @@ SYMBOLS = {
     "gnan_last_error": (C.c_char_p, []),
     "gnan_fmlp_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpArgs)]),
     "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
+    "gnan_fmlp_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpBwdArgs)]),
     "gnan_fmlp_bwd": (C.c_int, [C.POINTER(FmlpBwdArgs), C.c_void_p]),
     "gnan_pwl_build_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_pwl_build": (C.c_int, [C.POINTER(PwlBuildArgs), C.c_void_p]),

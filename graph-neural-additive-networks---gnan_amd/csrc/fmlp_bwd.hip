@@ -26,6 +26,8 @@ struct BwdParams {
   const float* grad;
   int64_t grad_stride;
   float *d_w_first, *d_b_first, *d_w_mid, *d_b_mid, *d_w_last, *d_b_last;
+  int64_t nodes_per_split;   // blockIdx.y walks nodes [y * nodes_per_split, (y + 1) * nodes_per_split)
+  int64_t split_stride;      // floats between the gradient blocks of consecutive splits (0: one split, final outputs)
 };
 
 constexpr int kH = 64;      // lanes = hidden units (H <= 64: the rest idle with zero weights)
@@ -68,7 +70,10 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
 #pragma unroll
   for (int c = 0; c < C; ++c) db3[c] = 0.f;
 
-  for (int64_t node = wv; node < p.n; node += kWaves) {
+  const int64_t n_lo = static_cast<int64_t>(blockIdx.y) * p.nodes_per_split;
+  const int64_t n_hi = n_lo + p.nodes_per_split < p.n ? n_lo + p.nodes_per_split : p.n;
+  const int64_t so = static_cast<int64_t>(blockIdx.y) * p.split_stride;     // this split's block of partial gradients
+  for (int64_t node = n_lo + wv; node < n_hi; node += kWaves) {
     const float x = p.x[node * p.x_stride + k];
     const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
     float gv[C];
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
   }
 
   // waves -> wave 0, in wave order: dW2 sixteen columns at a time, then the vectors
-  float* dW2 = p.d_w_mid + static_cast<int64_t>(k) * H * H;
+  float* dW2 = p.d_w_mid + so + static_cast<int64_t>(k) * H * H;
   for (int t0 = 0; t0 < kH; t0 += 16) {
     __syncthreads();
 #pragma unroll
@@ -133,11 +138,11 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
       s[t] = red[0][j][t];
       for (int w = 1; w < kWaves; ++w) s[t] += red[w][j][t];
     }
-    p.d_w_first[static_cast<int64_t>(k) * H + j] = s[0];
-    if (p.d_b_first) p.d_b_first[static_cast<int64_t>(k) * H + j] = s[1];
-    if (p.d_b_mid) p.d_b_mid[static_cast<int64_t>(k) * H + j] = s[2];
+    p.d_w_first[so + static_cast<int64_t>(k) * H + j] = s[0];
+    if (p.d_b_first) p.d_b_first[so + static_cast<int64_t>(k) * H + j] = s[1];
+    if (p.d_b_mid) p.d_b_mid[so + static_cast<int64_t>(k) * H + j] = s[2];
 #pragma unroll
-    for (int c = 0; c < C; ++c) p.d_w_last[(static_cast<int64_t>(k) * C + c) * H + j] = s[3 + c];
+    for (int c = 0; c < C; ++c) p.d_w_last[so + (static_cast<int64_t>(k) * C + c) * H + j] = s[3 + c];
   }
   if (p.d_b_last) {       // db3 is the same in every lane of a wave: lane 0 of each wave, then wave order
     __syncthreads();
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
     if (threadIdx.x < C) {
       float s = red[0][0][threadIdx.x];
       for (int w = 1; w < kWaves; ++w) s += red[w][0][threadIdx.x];
-      p.d_b_last[static_cast<int64_t>(k) * C + threadIdx.x] = s;
+      p.d_b_last[so + static_cast<int64_t>(k) * C + threadIdx.x] = s;
     }
   }
 }
@@ -171,7 +176,10 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdPara
     dw3[c] = db3[c] = 0.f;
   }
   float dw1 = 0.f, db1 = 0.f;
-  for (int64_t node = wv; node < p.n; node += kWaves) {
+  const int64_t n_lo = static_cast<int64_t>(blockIdx.y) * p.nodes_per_split;
+  const int64_t n_hi = n_lo + p.nodes_per_split < p.n ? n_lo + p.nodes_per_split : p.n;
+  const int64_t so = static_cast<int64_t>(blockIdx.y) * p.split_stride;     // this split's block of partial gradients
+  for (int64_t node = n_lo + wv; node < n_hi; node += kWaves) {
     const float x = p.x[node * p.x_stride + k];
     const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
     const float a1 = fmaf(w1, x, b1);
@@ -199,10 +207,10 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdPara
       s[t] = red[0][j][t];
       for (int w = 1; w < kWaves; ++w) s[t] += red[w][j][t];
     }
-    p.d_w_first[static_cast<int64_t>(k) * H + j] = s[0];
-    if (p.d_b_first) p.d_b_first[static_cast<int64_t>(k) * H + j] = s[1];
+    p.d_w_first[so + static_cast<int64_t>(k) * H + j] = s[0];
+    if (p.d_b_first) p.d_b_first[so + static_cast<int64_t>(k) * H + j] = s[1];
 #pragma unroll
-    for (int c = 0; c < C; ++c) p.d_w_last[(static_cast<int64_t>(k) * C + c) * H + j] = s[2 + c];
+    for (int c = 0; c < C; ++c) p.d_w_last[so + (static_cast<int64_t>(k) * C + c) * H + j] = s[2 + c];
   }
   if (p.d_b_last) {
     __syncthreads();
@@ -213,18 +221,42 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdPara
     if (threadIdx.x < C) {
       float s = red[0][0][threadIdx.x];
       for (int w = 1; w < kWaves; ++w) s += red[w][0][threadIdx.x];
-      p.d_b_last[static_cast<int64_t>(k) * C + threadIdx.x] = s;
+      p.d_b_last[so + static_cast<int64_t>(k) * C + threadIdx.x] = s;
     }
   }
 }
 
+// out[i] = sum over the splits of partial[s * stride + i], in split order
+__global__ __launch_bounds__(256) void fmlp_bwd_reduce_kernel(const float* __restrict__ partial, int64_t stride, int splits,
+                                                              float* __restrict__ out, int64_t count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= count) return;
+  float a = partial[i];
+  for (int s = 1; s < splits; ++s) a += partial[static_cast<int64_t>(s) * stride + i];
+  out[i] = a;
+}
+
+// How many node ranges a feature's nodes are cut into: enough workgroups to fill the chip twice over, at least 256 nodes each.
+int node_splits(int64_t n, int F) {
+  int64_t want = (512 + F - 1) / F;
+  const int64_t most = (n + 255) / 256;
+  if (want > most) want = most;
+  if (want > 1024) want = 1024;
+  return want < 1 ? 1 : static_cast<int>(want);
+}
+
+int64_t block_floats(const gnan_fmlp_bwd_args* a) {       // one split's gradients: [w_first | b_first | w_mid | b_mid | w_last | b_last]
+  const int64_t F = a->F, H = a->H, C = a->C;
+  return 2 * F * H + (a->L == 3 ? F * H * H + F * H : 0) + F * C * H + F * C;
+}
+
 template <int C>
-int launch_bwd(const BwdParams& p, hipStream_t st) {
+int launch_bwd(const BwdParams& p, unsigned splits, hipStream_t st) {
   if (p.w_mid == nullptr) {
-    hipLaunchKernelGGL((fmlp_bwd2_kernel<C>), dim3(static_cast<unsigned>(p.F)), dim3(kWaves * kWave), 0, st, p);
+    hipLaunchKernelGGL((fmlp_bwd2_kernel<C>), dim3(static_cast<unsigned>(p.F), splits), dim3(kWaves * kWave), 0, st, p);
     return gnan::check_launch("fmlp_bwd2_kernel");
   }
-  hipLaunchKernelGGL((fmlp_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F)), dim3(kWaves * kWave), 0, st, p);
+  hipLaunchKernelGGL((fmlp_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F), splits), dim3(kWaves * kWave), 0, st, p);
   return gnan::check_launch("fmlp_bwd_kernel");
 }
 
@@ -253,14 +285,61 @@ extern "C" int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream) 
   p.d_w_first = a->d_w_first; p.d_b_first = a->d_b_first; p.d_w_mid = a->d_w_mid; p.d_b_mid = a->d_b_mid;
   p.d_w_last = a->d_w_last; p.d_b_last = a->d_b_last;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (a->C) {
-    case 1: return launch_bwd<1>(p, st);
-    case 2: return launch_bwd<2>(p, st);
-    case 3: return launch_bwd<3>(p, st);
-    case 4: return launch_bwd<4>(p, st);
-    case 5: return launch_bwd<5>(p, st);
-    case 6: return launch_bwd<6>(p, st);
-    case 7: return launch_bwd<7>(p, st);
-    default: return launch_bwd<8>(p, st);
+  // few features and many nodes: a feature's nodes are cut into ranges, one workgroup each; the ranges' gradients land in
+  // the workspace and are added in range order (still no atomics)
+  const int splits = a->n > 0 ? node_splits(a->n, a->F) : 1;
+  const int64_t blk = block_floats(a);
+  p.nodes_per_split = a->n;
+  p.split_stride = 0;
+  const int64_t F = a->F, H = a->H, C = a->C;
+  const int64_t off_b1 = F * H, off_w2 = 2 * F * H, off_b2 = off_w2 + (a->L == 3 ? F * H * H : 0),
+                off_w3 = off_b2 + (a->L == 3 ? F * H : 0), off_b3 = off_w3 + F * C * H;
+  if (splits > 1) {
+    const size_t need = static_cast<size_t>(splits) * blk * sizeof(float);
+    if (a->workspace == nullptr || a->workspace_bytes < need)
+      return gnan::fail(GNAN_ERR_WORKSPACE, "fmlp_bwd: workspace %zu B < required %zu B", a->workspace_bytes, need);
+    float* ws = static_cast<float*>(a->workspace);
+    p.nodes_per_split = ((a->n + splits - 1) / splits + kWaves - 1) / kWaves * kWaves;
+    p.split_stride = blk;
+    p.d_w_first = ws;
+    p.d_b_first = a->d_b_first ? ws + off_b1 : nullptr;
+    p.d_w_mid = ws + off_w2;
+    p.d_b_mid = a->d_b_mid ? ws + off_b2 : nullptr;
+    p.d_w_last = ws + off_w3;
+    p.d_b_last = a->d_b_last ? ws + off_b3 : nullptr;
   }
+  int rc;
+  const unsigned sp = static_cast<unsigned>(splits);
+  switch (a->C) {
+    case 1: rc = launch_bwd<1>(p, sp, st); break;
+    case 2: rc = launch_bwd<2>(p, sp, st); break;
+    case 3: rc = launch_bwd<3>(p, sp, st); break;
+    case 4: rc = launch_bwd<4>(p, sp, st); break;
+    case 5: rc = launch_bwd<5>(p, sp, st); break;
+    case 6: rc = launch_bwd<6>(p, sp, st); break;
+    case 7: rc = launch_bwd<7>(p, sp, st); break;
+    default: rc = launch_bwd<8>(p, sp, st); break;
+  }
+  if (rc || splits == 1) return rc;
+  const float* ws = static_cast<const float*>(a->workspace);
+  auto reduce = [&](float* out, int64_t off, int64_t count) -> int {
+    if (out == nullptr || count == 0) return GNAN_OK;
+    hipLaunchKernelGGL(fmlp_bwd_reduce_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, ws + off, blk,
+                       splits, out, count);
+    return gnan::check_launch("fmlp_bwd_reduce_kernel");
+  };
+  if ((rc = reduce(a->d_w_first, 0, F * H))) return rc;
+  if ((rc = reduce(a->d_b_first, off_b1, F * H))) return rc;
+  if (a->L == 3) {
+    if ((rc = reduce(a->d_w_mid, off_w2, F * H * H))) return rc;
+    if ((rc = reduce(a->d_b_mid, off_b2, F * H))) return rc;
+  }
+  if ((rc = reduce(a->d_w_last, off_w3, F * C * H))) return rc;
+  return reduce(a->d_b_last, off_b3, F * C);
+}
+
+extern "C" size_t gnan_fmlp_bwd_workspace_bytes(const gnan_fmlp_bwd_args* a) {
+  if (!a || a->n <= 0 || a->F < 1 || a->H < 1 || a->C < 1) return 0;
+  const int splits = node_splits(a->n, a->F);
+  return splits > 1 ? static_cast<size_t>(splits) * block_floats(a) * sizeof(float) : 0;
 }

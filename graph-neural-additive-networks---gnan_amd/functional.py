@@ -234,10 +234,9 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
 
 
 HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
-# gnan_fmlp_bwd walks a feature's nodes inside ONE workgroup: with few features and many nodes it leaves CUs idle
-# (tools/bwd_small.py: n = 30, F = 15: 0.19 vs 0.56 ms for the torch route; 3000 x 129: 0.61 vs 1.0; 2708 x 1434 x 7 channels:
-# 2.4 vs 7.5; but 16000 x 64: 3.1 vs 2.0) — nodes per workgroup, scaled by how many workgroups short of the chip a launch is
-HIP_SMALL_BACKWARD_MAX_NODES = 32768
+# gnan_fmlp_bwd recomputes the activations of every (node, feature) pair (3 H^2 fmas each, fp32 vector units): beyond a few
+# million pairs the batched GEMMs of the torch route (matrix cores) catch up; AUTO sends such sizes to the table route anyway
+HIP_SMALL_BACKWARD_MAX_WORK = 1 << 23
 
 
 def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
@@ -260,6 +259,10 @@ def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
                          grad=_lib.ptr(g), grad_stride=g.stride(0),
                          d_w_first=_lib.ptr(outs[0]), d_b_first=_lib.ptr(outs[1]), d_w_mid=_lib.ptr(d_w_mid),
                          d_b_mid=_lib.ptr(d_b_mid), d_w_last=_lib.ptr(outs[4]), d_b_last=_lib.ptr(outs[5]))
+    need = _lib.lib().gnan_fmlp_bwd_workspace_bytes(a)
+    if need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=xd.device)
+        a.workspace, a.workspace_bytes = _lib.ptr(ws), need
     _lib.check(_lib.lib().gnan_fmlp_bwd(a, _lib.stream_of(xd)), "gnan_fmlp_bwd")
     return outs
 
@@ -341,7 +344,7 @@ class _FeatureMLPs(torch.autograd.Function):
             pg = [None if g is None else g.to(torch.float32) for g in pg]
             return (None, None, None, None, None, None, None, None, None, *pg)
         if (HIP_SMALL_BACKWARD and L in (2, 3) and 1 <= H <= 64 and C <= 8 and not ctx.needs_input_grad[0] and x.is_cuda
-                and 0 < x.shape[0] * max(1, 256 // F) <= HIP_SMALL_BACKWARD_MAX_NODES):
+                and 0 < x.shape[0] * F <= HIP_SMALL_BACKWARD_MAX_WORK):
             # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
             # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch
             # restatement below materialises [F, n, H] activations for the same sums (Cora-shaped: 1 GB per layer)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 18
+#define GNAN_ABI_VERSION 19
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -110,8 +110,12 @@ typedef struct gnan_fmlp_bwd_args {
   float* d_b_mid;
   float* d_w_last;
   float* d_b_last;
+  void* workspace;       /* gnan_fmlp_bwd_workspace_bytes(): partial gradients when a feature's nodes are cut into ranges
+                            (few features, many nodes), added in range order */
+  size_t workspace_bytes;
 } gnan_fmlp_bwd_args;
 
+size_t gnan_fmlp_bwd_workspace_bytes(const gnan_fmlp_bwd_args* a);
 int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

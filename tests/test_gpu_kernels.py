@@ -417,7 +417,8 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
 
 @pytest.mark.parametrize("F,L,H,C,bias,n", [(3, 3, 8, 1, True, 203), (20, 3, 64, 3, True, 1000), (7, 3, 33, 7, False, 5),
                                              (15, 3, 64, 1, False, 31), (2, 3, 64, 8, True, 1), (129, 3, 64, 1, True, 3000),
-                                             (9, 2, 64, 2, True, 77), (4, 2, 20, 5, False, 300)])
+                                             (9, 2, 64, 2, True, 77), (4, 2, 20, 5, False, 300),
+                                             (2, 3, 64, 2, True, 9001), (3, 2, 16, 1, True, 5000)])   # node ranges
 @pytest.mark.parametrize("sum_features", [True, False])
 def test_small_batch_backward_kernel_vs_autograd(F, L, H, C, bias, n, sum_features, monkeypatch):
     """gnan_fmlp_bwd (one workgroup per feature, gradients accumulated in registers) == the batched-GEMM restatement
