@@ -65,10 +65,9 @@ class TensorGNAN(_PathBase):
     def forward(self, x_batch, dist_batch, batch_vector):
         self._check_dropout()
         _lib.require_device(x_batch, dist_batch)
-        key = (dist_batch.data_ptr(), dist_batch._version, tuple(dist_batch.shape))
-        if self._graph_cache is None or self._graph_cache[0] != key:
-            self._graph_cache = (key, hop_graph_from_counts(dist_batch))
-        g = self._graph_cache[1]
+        g = self._graph_cache.get((dist_batch,), "counts")
+        if g is None:
+            g = self._graph_cache.put((dist_batch,), "counts", hop_graph_from_counts(dist_batch))
         S = self._features(x_batch, "fs", self.fs, True)                                    # [N, C]
         hops = torch.arange(g.n_codes - 1, dtype=torch.float32, device=x_batch.device).view(-1, 1)
         lut = torch.cat([self.rho(hops), torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)

@@ -19,6 +19,7 @@ import os
 import torch
 
 from . import _lib
+from ._cache import TensorKeyedCache
 from .graph import HopGraph
 
 
@@ -117,20 +118,18 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
 
 SPECULATIVE_LOOKUP = os.environ.get("GNAN_SPECULATIVE_LOOKUP", "1") != "0"   # queue the look-up before the piece counts are read back
 MOMENTS_FIXED_POINT = True    # accumulate the per-piece moments in 64-bit fixed point (integer LDS atomics, reproducible)
-_ABS_MAX_CACHE = {}           # (data_ptr, version, shape) -> device scalar: max |x| of the (static) feature matrix
+_ABS_MAX_CACHE = TensorKeyedCache(16)   # feature matrix (object identity + version) -> device scalar max |x|
 
 
 def _abs_max_cached(x: torch.Tensor) -> torch.Tensor:
-    key = (x.data_ptr(), x._version, tuple(x.shape), x.device)
-    hit = _ABS_MAX_CACHE.get(key)
+    hit = _ABS_MAX_CACHE.get((x,))
     if hit is None:
-        if len(_ABS_MAX_CACHE) > 16:
-            _ABS_MAX_CACHE.clear()
-        hit = _ABS_MAX_CACHE[key] = x.abs().max().double()
+        hit = _ABS_MAX_CACHE.put((x,), None, x.abs().max().double())
     return hit
 
 
-def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) -> torch.Tensor:
+def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
+                  x_abs_max: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-piece moments of the upstream gradient (``gnan_fpwl_moments[_fixed]``) -> ``[T, 2, C]`` float32.
 
     Fixed-point route (default where the 64-bit bins fit LDS): every term is added as ``round(v * 2^e)`` with ``e``
@@ -155,7 +154,9 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool) ->
         bits = 61 - max(1, (max(n, 2) - 1).bit_length())            # a bin receives at most n terms
         tiny = torch.finfo(torch.float64).tiny
         g_max = grad.abs().max().double().clamp_min(tiny)
-        d_max = (_abs_max_cached(x) + t.anchor.abs().max().double()).clamp_min(tiny)
+        if x_abs_max is None:
+            x_abs_max = x.abs().max().double()
+        d_max = (x_abs_max + t.anchor.abs().max().double()).clamp_min(tiny)
         e = torch.stack([torch.floor(bits - torch.log2(g_max)), torch.floor(bits - torch.log2(g_max * d_max))])
         scales = torch.exp2(e.clamp(-1000.0, 1000.0))
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
@@ -313,6 +314,9 @@ class _FeatureMLPs(torch.autograd.Function):
             raise ValueError(f"total_rows={total_rows} outside [0, {x.shape[0]}]")
         fused_total = want_total and total_rows != 0           # 0 rows: the kernel reads that as "all", sum nothing instead
         out, ctx.tables, total = _fmlp_forward(x, p, sum_features, fused_total, needs_grad, out_dtype, total_rows)
+        # max |x| scales the fixed-point moments of the backward pass; it is looked up here because this is where the
+        # caller's own tensor object is in hand (backward sees a fresh unpacked copy of the saved tensor every time)
+        ctx.x_abs_max = _abs_max_cached(x) if (needs_grad and ctx.tables is not None and x.numel()) else None
         if not want_total:
             return out
         if total_rows == 0:
@@ -335,7 +339,7 @@ class _FeatureMLPs(torch.autograd.Function):
             # table path: one streaming pass bins the upstream gradient per piece (HIP), then the exact
             # parameter gradients follow from 2 probe points per piece through the tiny batched MLP
             from .pwl import parameter_grads_from_moments
-            M = _fpwl_moments(x, ctx.tables, grad_out, sum_features)
+            M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max)
             got = parameter_grads_from_moments(
                 p, ctx.tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()
                                                                           for t in q[:6]], *q[6:]), False))
@@ -373,18 +377,15 @@ class _FeatureMLPs(torch.autograd.Function):
 PAD_FEATURES = 16            # the fast look-up / moment kernels and the 16-byte operand gathers want whole 16-feature groups
 PAD_MIN_WORK = 1 << 26       # n * F from which a ragged feature count is padded: the arxiv-shaped graph (n * F = 2^24.4) is
                              # bound by the host, the six concatenations (and their backward) cost it 0.1 / 1.5 ms
-_X_PAD_CACHE = {}            # (data_ptr, version, shape, ...) -> zero-padded copy of a (static) feature matrix
+_X_PAD_CACHE = TensorKeyedCache(4)   # feature matrix (object identity + version), padded width -> zero-padded copy
 
 
 def _padded_x(x: torch.Tensor, Fp: int) -> torch.Tensor:
     if x.requires_grad:
         return torch.nn.functional.pad(x.float(), (0, Fp - x.shape[1]))
-    key = (x.data_ptr(), x._version, tuple(x.shape), x.stride(0), x.device, x.dtype, Fp)
-    hit = _X_PAD_CACHE.get(key)
+    hit = _X_PAD_CACHE.get((x,), Fp)
     if hit is None:
-        if len(_X_PAD_CACHE) >= 4:
-            _X_PAD_CACHE.clear()
-        hit = _X_PAD_CACHE[key] = torch.nn.functional.pad(x.detach().float(), (0, Fp - x.shape[1]))
+        hit = _X_PAD_CACHE.put((x,), Fp, torch.nn.functional.pad(x.detach().float(), (0, Fp - x.shape[1])))
     return hit
 
 

@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from ._cache import TensorKeyedCache
 from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps
 from .graph import HopGraph, hop_inputs
 
@@ -51,6 +52,9 @@ def _tiny_init(module: nn.Module) -> None:
             nn.init.xavier_normal_(p, gain=0.01)
         elif "bias" in name:
             nn.init.constant_(p, 0)
+
+
+GRAPH_CACHE_ENTRIES = 8192   # hop-coded graphs kept per model (graph tasks cycle through a few thousand small graphs per epoch)
 
 
 class FlatMLPStore:
@@ -161,7 +165,9 @@ class _PathBase(nn.Module):
 
     def _init_caches(self):
         self._stores = {}
-        self._graph_cache = None
+        # hop-coded graphs derived from the inputs' tensors, found again by the identity of those tensor objects (not by
+        # their addresses: the allocator recycles those between the graphs of a batch_size=1 loop, trainer.py:46)
+        self._graph_cache = TensorKeyedCache(GRAPH_CACHE_ENTRIES)
 
     def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): every Parameter moved on its own
         out = super()._apply(fn, *args, **kwargs)
@@ -209,20 +215,21 @@ class _PathBase(nn.Module):
         if g is not None:
             return g
         if hasattr(inputs, "gnan_rowptr"):
-            key = ("csr", inputs.gnan_rowptr.data_ptr(), inputs.gnan_col.data_ptr(), inputs.gnan_code.data_ptr())
-            if self._graph_cache is None or self._graph_cache[0] != key:
-                g = HopGraph.from_csr(inputs.gnan_rowptr, inputs.gnan_col, inputs.gnan_code,
-                                      n_cols=inputs.x.shape[0], n_codes=int(inputs.gnan_n_codes),
-                                      cnt=getattr(inputs, "gnan_cnt", None))
-                self._graph_cache = (key, g)
-            return self._graph_cache[1]
+            cnt = getattr(inputs, "gnan_cnt", None)
+            src = (inputs.gnan_rowptr, inputs.gnan_col, inputs.gnan_code, cnt)
+            extra = ("csr", int(inputs.x.shape[0]), int(inputs.gnan_n_codes))
+            g = self._graph_cache.get(src, extra)
+            if g is None:
+                g = self._graph_cache.put(src, extra, HopGraph.from_csr(
+                    inputs.gnan_rowptr, inputs.gnan_col, inputs.gnan_code, n_cols=inputs.x.shape[0],
+                    n_codes=int(inputs.gnan_n_codes), cnt=cnt))
+            return g
         nd = inputs.node_distances
         norm = inputs.normalization_matrix if want_norm else getattr(inputs, "normalization_matrix", None)
-        key = ("dense", nd.data_ptr(), nd._version, tuple(nd.shape),
-               None if norm is None else (norm.data_ptr(), norm._version))
-        if self._graph_cache is None or self._graph_cache[0] != key:
-            self._graph_cache = (key, HopGraph.from_dense(nd, norm))
-        return self._graph_cache[1]
+        g = self._graph_cache.get((nd, norm), "dense")
+        if g is None:
+            g = self._graph_cache.put((nd, norm), "dense", HopGraph.from_dense(nd, norm))
+        return g
 
     # ---- rho on the distinct distances -------------------------------------------------------
     def _lut_global(self, g: HopGraph) -> torch.Tensor:

@@ -282,3 +282,56 @@ def test_training_mode_dropout_is_supported(gpu):
     mod.eval()
     with torch.no_grad():
         assert torch.equal(mod.forward(data), y_eval)
+
+
+@pytest.mark.parametrize("variant", ["models_tensor_graph", "models_gnan", "batched"])
+def test_same_shaped_graphs_back_to_back_are_not_confused(gpu, variant):
+    """The reference's loops upload one graph per step and drop it (trainer.py:46 with batch_size=1): the allocator hands
+    the next same-sized graph the previous one's addresses.  Every forward must see ITS graph and ITS features."""
+    from gnan_amd import batched, models
+    rng = np.random.default_rng(0)
+    n, F, H = 12, 4, 8
+    torch.manual_seed(0)
+    if variant == "batched":
+        mod = batched.TensorGNAN(F, 2, 2, hidden_channels=H, device="cuda")
+    elif variant == "models_gnan":
+        mod = models.GNAN(F, 2, num_layers=3, hidden_channels=H, device="cuda")
+    else:
+        mod = models.TensorGNAN(F, 2, 3, hidden_channels=H, is_graph_task=True, readout_n_layers=0, device="cuda")
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape) * 0.7)
+    mod = mod.to(gpu.DEV).eval()
+    sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+    seen_ptrs, recycled = set(), 0
+    for step in range(6):
+        m = n + 3 * step                                              # more edges every step: different hop structure
+        ei = np.stack([rng.integers(0, n, m), rng.integers(0, n, m)])
+        ei = np.concatenate([ei, ei[::-1]], axis=1)
+        nd, norm = O.pre_process_dense(ei, n)
+        x = torch.rand(n, F, generator=torch.Generator().manual_seed(step))
+        if variant == "batched":
+            hops = torch.from_numpy(O.hop_codes_from_dense(nd).astype(np.float32))          # -1 marks unreachable pairs
+            batch = torch.zeros(n, dtype=torch.long)
+            want = O.batched_tensor_gnan_forward(x.double(), hops.double(), batch, {k: v.double() for k, v in sd.items()})
+            xd, dd = x.to(gpu.DEV), hops.to(gpu.DEV)
+            recycled += dd.data_ptr() in seen_ptrs
+            seen_ptrs.add(dd.data_ptr())
+            with torch.no_grad():
+                got = mod(xd, dd, batch.to(gpu.DEV)).cpu()
+            del xd, dd
+        else:
+            data = gpu.Bag(x=x.to(gpu.DEV), edge_index=None, node_distances=nd.to(gpu.DEV),
+                           normalization_matrix=norm.to(gpu.DEV))
+            recycled += data.node_distances.data_ptr() in seen_ptrs
+            seen_ptrs.add(data.node_distances.data_ptr())
+            p64 = {k: v.double() for k, v in sd.items()}
+            if variant == "models_gnan":
+                want = O.gnan_forward(x.double(), nd.double(), norm.double(), p64, True)
+            else:
+                want = O.tensor_gnan_forward_models(x.double(), nd.double(), norm.double(), p64, True, True, 0)
+            with torch.no_grad():
+                got = mod(data).cpu()
+            del data
+        assert O.rel_err(got, want) <= 1e-5, f"step {step}"
+    assert recycled > 0, "the allocator never recycled an address: the test did not exercise what it is about"

@@ -86,3 +86,47 @@ def test_speculative_table_sizes_cover_only_what_they_can_hold():
     assert not pwl.covers(pwl.PwlTables(None, None, None, None, 256, 16, 2000), exact)      # LDS image too small
     assert pwl.covers(pwl.PwlTables(None, None, None, None, 256, 8, 8 * 130), exact)        # another grouping, worst case fits
     assert not pwl.covers(pwl.PwlTables(None, None, None, None, 256, 8, 8 * 130 - 1), exact)
+
+
+def test_tensor_keyed_cache_matches_objects_not_addresses():
+    """The reference loops upload one graph per step (trainer.py:46); the allocator recycles the freed graph's addresses
+    for the next one of the same size, so a derived value may only be found again through the tensor OBJECT it came from."""
+    import copy
+    import gc
+    import pickle
+    from gnan_amd._cache import TensorKeyedCache
+    c = TensorKeyedCache(3)
+    a = torch.zeros(4, 4)
+    assert c.get((a, None), "dense") is None
+    assert c.put((a, None), "dense", "graph of a") == "graph of a"
+    assert c.get((a, None), "dense") == "graph of a"
+    assert c.get((a, None), "csr") is None and c.get((a,), "dense") is None and c.get((a, a), "dense") is None
+    twin = a.detach()                                  # same storage, same data_ptr, same version counter: another object
+    assert twin.data_ptr() == a.data_ptr() and c.get((twin, None), "dense") is None
+    a.add_(1)                                          # in-place write: the derived value is stale
+    assert c.get((a, None), "dense") is None and len(c) == 0
+    c.put((a, None), "dense", "graph of a'")
+    twin.mul_(2)                                       # ... also through an alias (views share the version counter)
+    assert c.get((a, None), "dense") is None
+    c.put((a, None), "dense", 1)
+    del a, twin
+    gc.collect()
+    assert len(c) == 0                                 # the entry went with its source
+    b = torch.zeros(4, 4)                              # may or may not land on the old address / id: must miss either way
+    assert c.get((b, None), "dense") is None
+    keep = [torch.zeros(2) for _ in range(5)]
+    for i, t in enumerate(keep):
+        c.put((t,), None, i)
+    assert len(c) == 3 and c.get((keep[0],)) is None and c.get((keep[4],)) == 4      # least recently used dropped
+    assert len(copy.deepcopy(c)) == 0 and len(pickle.loads(pickle.dumps(c))) == 0
+
+
+def test_padded_feature_matrix_is_not_reused_for_another_tensor():
+    Fp = 16
+    x1 = torch.rand(6, 5)
+    p1 = functional._padded_x(x1, Fp)
+    x2 = x1.detach()                                   # the look-alike a recycled allocation would be: same address, version, shape
+    x2_expected = torch.nn.functional.pad(x2, (0, Fp - 5))
+    assert functional._padded_x(x2, Fp) is not p1 and torch.equal(functional._padded_x(x2, Fp), x2_expected)
+    x1.mul_(3)
+    assert torch.equal(functional._padded_x(x1, Fp)[:, :5], x1)
