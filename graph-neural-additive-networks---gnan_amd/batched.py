@@ -70,8 +70,18 @@ class TensorGNAN(_PathBase):
             g = self._graph_cache.put((dist_batch,), "counts", hop_graph_from_counts(dist_batch))
         S = self._features(x_batch, "fs", self.fs, True)                                    # [N, C]
         hops = torch.arange(g.n_codes - 1, dtype=torch.float32, device=x_batch.device).view(-1, 1)
-        lut = torch.cat([self.rho(hops), torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)
-        Y = rho_aggregate(g, S, lut, use_cnt=False, with_rest=False)                        # [N, C]
+        if self._dropout_active():
+            # rho carries a Dropout here (batched_pyg_main.py:126-131) and the reference draws one mask per PAIR
+            # (rho runs on all N*N distances, :151).  A table of rho at the distinct hop counts would share one mask
+            # among all pairs of a hop count, so while Dropout is active rho is evaluated per listed pair and the
+            # weighted sum runs in torch on the device — the cold path, like the shape functions' (_check_dropout).
+            deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
+            row_of_pair = torch.repeat_interleave(torch.arange(g.n_rows, device=deg.device), deg)
+            w_pair = self.rho(hops[g.code.long()])                                          # [nnz, C], one mask per pair
+            Y = torch.zeros_like(S).index_add(0, row_of_pair, w_pair * S[g.col.long()])
+        else:
+            lut = torch.cat([self.rho(hops), torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)
+            Y = rho_aggregate(g, S, lut, use_cnt=False, with_rest=False)                    # [N, C]
         if not self.is_graph_task:
             return Y
         n_graphs = int(batch_vector.max()) + 1

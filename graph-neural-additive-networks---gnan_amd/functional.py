@@ -64,6 +64,15 @@ def stack_mlps(mlps: Sequence[torch.nn.Sequential]) -> StackedMLP:
                       st(L - 1, "weight"), st(L - 1, "bias") if has_bias else None, L, H, C, F)
 
 
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """``t [n, w]`` as the kernels want it: unit stride inside a row and rows that do not overlap (``stride(0) >= w``).
+    An expanded tensor — e.g. the gradient ``feature_mlps(...).sum(0)`` sends back, strides (0, 1) — passes a plain
+    ``stride(1) == 1`` test and is then refused by the kernels' argument checks; it is materialised here instead."""
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        return t.contiguous()
+    return t
+
+
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.detach().float().contiguous()
 
@@ -84,8 +93,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
     when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
     x = x.detach().float()
-    if x.stride(1) != 1:
-        x = x.contiguous()
+    x = _rows(x)
     n, F = x.shape
     C = t.val.shape[1]
     if (sum_features and C > 1 and F >= 16 and n < SUM_VIA_FEATURES_MAX_NODES and n * F * C * 4 <= (1 << 30)
@@ -137,11 +145,9 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
     per-term resolution 2^-(61 - log2 n) of the largest term, i.e. far below fp32 — and the sums do not depend on
     the order of the atomics."""
     x = x.detach().float()
-    if x.stride(1) != 1:
-        x = x.contiguous()
+    x = _rows(x)
     grad = grad.detach().float()
-    if grad.stride(1) != 1:
-        grad = grad.contiguous()
+    grad = _rows(grad)
     n, F = x.shape
     C = t.val.shape[1]
     T = t.anchor.numel()
@@ -216,8 +222,7 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
 
 def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int = 0) -> torch.Tensor:
     x = x.detach().float()
-    if x.stride(1) != 1:
-        x = x.contiguous()
+    x = _rows(x)
     n = x.shape[0]
     width = p.C if sum_features else p.F * p.C
     out = torch.empty((n, width), dtype=torch.float32, device=x.device)
@@ -243,11 +248,9 @@ HIP_SMALL_BACKWARD_MAX_WORK = 1 << 23
 def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
     """``gnan_fmlp_bwd``: gradients of the six stacked parameter tensors (None where a bias is absent), in their order."""
     xd = x.detach().float()
-    if xd.stride(1) != 1:
-        xd = xd.contiguous()
+    xd = _rows(xd)
     g = grad_out.detach().float()
-    if g.stride(1) != 1:
-        g = g.contiguous()
+    g = _rows(g)
     keep = [None if t is None else t.detach().float().contiguous() for t in params]
     outs = [None if t is None else torch.empty_like(t) for t in keep]
     w_mid = None if keep[2] is None else keep[2][0]              # [1, F, H, H] -> [F, H, H]   (absent for L == 2)
@@ -464,8 +467,7 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
     bf16 = S.dtype == torch.bfloat16
     if not bf16:
         S = S.float()
-    if S.stride(1) != 1:
-        S = S.contiguous()
+    S = _rows(S)
     n, W = S.shape
     total = torch.empty(W, dtype=torch.float32, device=S.device)
     need = _lib.lib().gnan_colsum_workspace_bytes(W)
@@ -493,8 +495,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     S = S.detach()
     if S.dtype != torch.bfloat16:                        # bf16 rows: storage format only, accumulation stays fp32
         S = S.float()
-    if S.stride(1) != 1:
-        S = S.contiguous()
+    S = _rows(S)
     lut = lut.detach().float().contiguous()
     per_row = lut.dim() == 3
     if lut.shape[-2] != g.n_codes:
@@ -537,8 +538,7 @@ def shell_sums_launch(g: HopGraph, S: torch.Tensor, lut_like: torch.Tensor, with
                       row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``T[q, d, w]`` = sum of operand rows per hop shell (``gnan_spmm_shell_sums``)."""
     S = S.detach().float()
-    if S.stride(1) != 1:
-        S = S.contiguous()
+    S = _rows(S)
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
     D = g.n_codes
     T = torch.zeros((n_out, D, S.shape[1]), dtype=torch.float32, device=S.device)
@@ -554,8 +554,7 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
     """``gnan_spmm_lut_grad``: ``dwt[q, d] = inv(q, d) * sum_w dY[q, w % dY.shape[1]] * T[q, d, w]`` without the
     ``[n, D, W]`` shell sums; ``reduce_rows`` sums over the rows -> ``[D, 1]``, else ``[n_out, D, 1]``."""
     S = S.detach().float()
-    if S.stride(1) != 1:
-        S = S.contiguous()
+    S = _rows(S)
     dY = dY.detach().float().contiguous()
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
     if with_rest and s_total is None:

@@ -54,6 +54,7 @@ class HopGraph:
     _dense_plans: dict = field(default_factory=dict, repr=False)
     _sorted_copy: Optional["HopGraph"] = field(default=None, repr=False)
     _inv_rest: Optional[torch.Tensor] = field(default=None, repr=False)
+    _cnt_by_col: bool = field(default=False, repr=False)     # transposed graphs: ``cnt`` rows belong to the neighbours
 
     @property
     def is_dense(self) -> bool:
@@ -82,7 +83,7 @@ class HopGraph:
         if nd.dim() != 2:
             raise ValueError(f"node_distances must be 2-D, got {tuple(nd.shape)}")
         nd = nd.float()
-        if nd.stride(1) != 1:
+        if nd.stride(1) != 1 or (nd.shape[0] > 1 and nd.stride(0) < nd.shape[1]):     # transposed or expanded views
             nd = nd.contiguous()
         norm = normalization_matrix
         if norm is not None:
@@ -268,8 +269,11 @@ class HopGraph:
                 code_s[e0:e1] = self.code[src]
                 del src
             rp = rowptr_s if self.rowptr.dtype == torch.int64 else rowptr_s.to(torch.int32)
+            # a transposed graph carries the FORWARD graph's count table (one row per neighbour, `transposed`): it is
+            # indexed by column there and must not be permuted with the rows (nor can it be when the graph is rectangular)
+            cnt_s = self.cnt[o].contiguous() if self.cnt.shape[0] == self.n_rows and not self._cnt_by_col else self.cnt
             g = HopGraph(n_rows=self.n_rows, n_cols=self.n_cols, n_codes=self.n_codes, code=code_s,
-                         cnt=self.cnt[o].contiguous(), rowptr=rp, col=col_s)
+                         cnt=cnt_s, rowptr=rp, col=col_s)
             g.long_row_plan()
             self._sorted_copy = g
         return self._sorted_copy, self._degree_order, self._sorted_copy._plan
@@ -305,6 +309,7 @@ class HopGraph:
             t = HopGraph(n_rows=self.n_cols, n_cols=self.n_rows, n_codes=self.n_codes,
                          code=self.code[order].contiguous(), cnt=self.cnt,
                          rowptr=rowptr_t.to(self.rowptr.dtype), col=row_of_edge[order].to(torch.int32).contiguous())
+        t._cnt_by_col = True
         self._transposed = t
         return t
 

@@ -453,6 +453,32 @@ def test_small_batch_backward_kernel_vs_autograd(F, L, H, C, bias, n, sum_featur
     assert O.rel_err(got["hip"][0].cpu(), w1) <= 1e-5
 
 
+@pytest.mark.parametrize("algo", ["auto", "pwl"])
+def test_expanded_upstream_gradient(algo, monkeypatch):
+    """``feature_mlps(...).sum(0)`` sends back an EXPANDED gradient (strides (0, 1)); both backward routes — the
+    per-feature kernel of small batches and the moment kernel of the table path — must take it (they read rows)."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_AUTO if algo == "auto" else _lib.FMLP_PWL)
+    F, L, H, C, n = 6, 3, 16, 2, 500
+    sd = _mlp_state(F, L, H, C, True, seed=11)
+    x = (torch.rand(n, F, generator=torch.Generator().manual_seed(3)) * 4 - 2).to(DEV)
+    wcol = torch.randn(F * C, generator=torch.Generator().manual_seed(5)).to(DEV)
+    st = _stack(sd, F, L, H, C, True)
+    leaves = [t for t in st[:6] if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    out = feature_mlps(x, st, False)                                  # [n, F*C]
+    got = torch.autograd.grad((out.sum(0) * wcol).sum(), leaves)      # d/d out = wcol expanded over the rows
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.feature_mlps(x.cpu().double(), sd64).reshape(n, -1)
+    (ref.sum(0) * wcol.cpu().double()).sum().backward()
+    w1 = torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)])
+    wl = torch.stack([sd64[f"fs.{k}.6.weight"].grad for k in range(F)])
+    assert O.rel_err(got[0].cpu(), w1) <= 1e-5
+    assert O.rel_err(got[4].cpu(), wl) <= 1e-5
+
+
 @pytest.mark.parametrize("F,L,bias", [(21, 3, True), (33, 2, False), (5, 3, True)])
 def test_ragged_feature_counts_are_padded(F, L, bias, monkeypatch):
     """F = raw features + the ones column is rarely a multiple of 16: large inputs are evaluated with all-zero shape

@@ -335,3 +335,42 @@ def test_same_shaped_graphs_back_to_back_are_not_confused(gpu, variant):
             del data
         assert O.rel_err(got, want) <= 1e-5, f"step {step}"
     assert recycled > 0, "the allocator never recycled an address: the test did not exercise what it is about"
+
+
+def test_batched_variant_draws_one_dropout_mask_per_pair(gpu):
+    """rho of the batched script carries a Dropout (batched_pyg_main.py:126-131) and runs on all N*N distances (:151): one
+    mask per pair.  In training mode the build must not share a mask among the pairs of a hop count, and — the Dropout
+    sitting in front of the last Linear — the mean over many draws must be the eval-mode output."""
+    import warnings
+    from gnan_amd import batched
+    torch.manual_seed(0)
+    F, C, H = 3, 2, 16
+    mod = batched.TensorGNAN(F, C, 2, hidden_channels=H, dropout=0.5, device="cuda").to(gpu.DEV)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape) * 0.7)
+        for f in mod.fs:                                   # S = F for every node, whatever the shape functions' masks do
+            f[3].weight.zero_()
+            f[3].bias.fill_(1.0)
+    dist = torch.full((4, 4), -1.0)
+    for i in range(4):
+        dist[i, i] = 0.0
+    dist[0, 1] = dist[2, 3] = 1.0                           # rows 0 and 2 list the same hop counts
+    x = torch.rand(4, F).to(gpu.DEV)
+    dd, batch = dist.to(gpu.DEV), torch.zeros(4, dtype=torch.long, device=gpu.DEV)
+    mod.is_graph_task = False
+    mod.eval()
+    with torch.no_grad():
+        want = mod(x, dd, batch)
+    assert torch.equal(want[0], want[2])
+    mod.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            draws = torch.stack([mod(x, dd, batch) for _ in range(600)])
+    assert float((draws[:, 0] - draws[:, 2]).abs().max()) > 0          # a shared mask would make rows 0 and 2 equal
+    se = draws.std(0) / 600 ** 0.5
+    assert bool(((draws.mean(0) - want).abs() <= 5 * se + 1e-6).all())
+    y = mod(x, dd, batch)                                               # and it is differentiable
+    y.sum().backward()
+    assert mod.rho[0].weight.grad is not None and float(mod.rho[0].weight.grad.abs().max()) > 0

@@ -130,3 +130,36 @@ def test_padded_feature_matrix_is_not_reused_for_another_tensor():
     assert functional._padded_x(x2, Fp) is not p1 and torch.equal(functional._padded_x(x2, Fp), x2_expected)
     x1.mul_(3)
     assert torch.equal(functional._padded_x(x1, Fp)[:, :5], x1)
+
+
+def test_degree_sorted_copy_of_a_transposed_rectangular_graph_keeps_the_count_table():
+    """A transposed graph carries the forward graph's count table (rows = its neighbours); the degree-sorted copy the
+    narrow-operand backward asks for (s_by_code) must leave it alone — permuting it with the rows indexed out of range
+    whenever the graph is rectangular (halo or row-partitioned graphs: more operand rows than output rows)."""
+    rng = np.random.default_rng(5)
+    n_rows, n_cols, K = 60, 150, 1
+    rowptr, col, code = _csr(n_rows, n_cols, K, rng)
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(code), n_cols=n_cols, n_codes=K + 2)
+    t = g.transposed()
+    assert (t.n_rows, t.n_cols) == (n_cols, n_rows) and t.cnt is g.cnt
+    ts, order, _ = t.degree_sorted_copy()
+    assert ts.cnt is g.cnt and ts.n_rows == n_cols
+    o = order.numpy()
+    trp, tsrp = t.rowptr.numpy(), ts.rowptr.numpy()
+    for q in range(n_cols):
+        a, b = trp[o[q]], trp[o[q] + 1]
+        assert np.array_equal(ts.col.numpy()[tsrp[q]:tsrp[q + 1]], t.col.numpy()[a:b])
+    sq = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col % n_rows), torch.from_numpy(code), n_cols=n_rows,
+                           n_codes=K + 2)
+    assert sq.transposed().degree_sorted_copy()[0].cnt is sq.cnt               # square: same rule, no meaningless permutation
+
+
+def test_rows_helper_materialises_expanded_and_transposed_views():
+    g = torch.ones(3).expand(5, 3)                                             # strides (0, 1): what .sum(0) sends back
+    assert g.stride() == (0, 1) and functional._rows(g).stride() == (3, 1)
+    t = torch.rand(4, 6).t()
+    assert functional._rows(t).stride() == (4, 1)
+    v = torch.rand(8, 10)[:, :6]                                               # wide row stride: fine as it is
+    assert functional._rows(v) is v
+    one = torch.ones(3).expand(1, 3)
+    assert functional._rows(one) is one
