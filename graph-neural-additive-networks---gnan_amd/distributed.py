@@ -25,8 +25,15 @@ of its rows lists (its halo, found once per graph) and evaluates the shape funct
 size ``N`` crosses xGMI any more — the only collective is an all-reduce of the ``W`` column sums for the rest bucket
 — at the price of ``n_halo * F`` redundant table look-ups per rank (1.4 ms per 10M x 64 on an MI355X, against
 2-4 ms for the 320 MB shard every link would have to carry in the all-gather) and of HBM capacity, which is what a
-288 GB device has to spare.  Backward needs no exchange either: the loss of the owned rows depends on the
-parameters through locally computed values only, so the ranks just add their parameter gradients.
+288 GB device has to spare.
+
+Backward (every variant): each rank back-propagates the loss of ITS output rows and the ranks add their parameter
+gradients (``all_reduce`` of ``p.grad``, SUM — the caller's job, as with any data-parallel step).  What crosses ranks
+inside the backward pass mirrors the forward: the all-gather of the operand becomes a reduce-scatter of its gradient
+(:class:`_GatherOperand`); the all-reduced column sums of the rest bucket become an all-reduce of one W-float vector
+(``rho_aggregate(total_group=...)``: every rank's rows pull on every rank's summed operand rows through ``total``);
+the feature partition's all-reduce of the output passes the gradient through unchanged (every rank evaluates the same
+loss on the full output).  All ranks must therefore run the backward pass together.
 """
 from __future__ import annotations
 
@@ -62,18 +69,59 @@ def _hip_compute() -> Dict[str, Callable]:
             "rest_total_term": rest_total_term}
 
 
+def _reduce_scatter_sum(full: torch.Tensor, n_local: int, group) -> torch.Tensor:
+    """Sum ``full [world * n_local, W]`` over the ranks and keep this rank's block.  RCCL: one reduce-scatter; backends
+    without one (gloo, the CPU tests): all-reduce and slice."""
+    out = full.new_empty((n_local, full.shape[1]))
+    try:
+        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
+    except (RuntimeError, NotImplementedError):
+        full = full.clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        r = dist.get_rank(group)
+        out = full[r * n_local:(r + 1) * n_local].clone()
+    return out
+
+
+class _GatherOperand(torch.autograd.Function):
+    """All-gather of equally sized row blocks; backward = reduce-scatter of the gradient."""
+
+    @staticmethod
+    def forward(ctx, local, group):
+        ctx.group, ctx.n_local = group, local.shape[0]
+        world = dist.get_world_size(group)
+        full = local.new_empty((local.shape[0] * world, local.shape[1]))
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+        return full
+
+    @staticmethod
+    def backward(ctx, d_full):
+        return _reduce_scatter_sum(d_full.contiguous(), ctx.n_local, ctx.group), None
+
+
+class _SumOverRanks(torch.autograd.Function):
+    """All-reduce (SUM) of partial outputs every rank then evaluates the SAME loss on: the gradient passes through."""
+
+    @staticmethod
+    def forward(ctx, partial, group):
+        out = partial.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return d_out, None
+
+
 def gather_operand(local: torch.Tensor, part: VertexPartition, group=None) -> torch.Tensor:
-    """All-gather the per-node operand rows; returns the ``[n_nodes, W]`` prefix of the padded buffer."""
+    """All-gather the per-node operand rows; returns the ``[n_nodes, W]`` prefix of the padded buffer.  Differentiable:
+    the gradient of the gathered operand is reduce-scattered back to the owners of its rows."""
     if part.world == 1:
         return local
     W = local.shape[1]
     if local.shape[0] != part.block:
-        padded = local.new_zeros((part.block, W))
-        padded[: local.shape[0]] = local
-        local = padded
-    full = local.new_empty((part.block * part.world, W))
-    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
-    return full[: part.n_nodes]
+        local = torch.cat([local, local.new_zeros((part.block - local.shape[0], W))], dim=0)
+    return _GatherOperand.apply(local, group)[: part.n_nodes]
 
 
 def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.Tensor, use_cnt: bool,
@@ -103,7 +151,9 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
         mark("gather")
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         mark("total")
-    # reference order: the feature sum of models.py:375-376 rides in the aggregation kernel's epilogue
+    # reference order: the feature sum of models.py:375-376 rides in the aggregation kernel's epilogue.  `total` holds
+    # the column sums of ALL gathered rows, so the backward pass needs no extra exchange for it: the rest-bucket vector
+    # every rank adds to its gradient of the gathered operand is summed over the ranks by the reduce-scatter.
     Y = ops["aggregate"](graph_local, operand, lut, use_cnt, s_total=total,
                          reduce_channels=out_channels if order == "reference" else 0)
     mark("spmm")
@@ -181,7 +231,10 @@ def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lu
         Y = x_cols.new_zeros((n, out_channels))
     mark("spmm")
     if part.world > 1:
-        dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=group)
+        if torch.is_grad_enabled() and Y.requires_grad:
+            Y = _SumOverRanks.apply(Y, group)
+        else:
+            dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=group)
     mark("reduce")
     return Y
 
@@ -254,9 +307,13 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
         Y += ops["rest_total_term"](plan.graph, lut, use_cnt, total, rc)
         mark("spmm")
         return Y
+    shared = {}
     if part.world > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         mark("total")
-    Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total, reduce_channels=rc)
+        shared = {"total_group": group}          # backward: the ranks add their rest-bucket vectors over the same group
+    # only the owned rows went into `total` (halo rows are some other rank's owned rows)
+    Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total, reduce_channels=rc, total_rows=plan.n_own,
+                         **shared)
     mark("spmm")
     return Y

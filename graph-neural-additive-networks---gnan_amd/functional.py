@@ -535,14 +535,18 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
 
 
 def shell_sums_launch(g: HopGraph, S: torch.Tensor, lut_like: torch.Tensor, with_rest: bool,
-                      row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``T[q, d, w]`` = sum of operand rows per hop shell (``gnan_spmm_shell_sums``)."""
+                      row_ids: Optional[torch.Tensor] = None, s_total: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``T[q, d, w]`` = sum of operand rows per hop shell (``gnan_spmm_shell_sums``); the rest shell is ``s_total``
+    (default: the column sums of ``S``) minus the listed rows."""
     S = S.detach().float()
     S = _rows(S)
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
     D = g.n_codes
     T = torch.zeros((n_out, D, S.shape[1]), dtype=torch.float32, device=S.device)
-    s_total = column_sums(S) if with_rest else None
+    if with_rest and s_total is None:
+        s_total = column_sums(S)
+    if not with_rest:
+        s_total = None
     lut = lut_like.detach().float().contiguous()
     a = _spmm_args(g, S, lut, False, s_total, T.view(n_out, -1), row_ids, lut.dim() == 3)
     _lib.check(_lib.lib().gnan_spmm_shell_sums(a, _lib.stream_of(S)), "gnan_spmm_shell_sums")
@@ -578,13 +582,24 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
     return out.unsqueeze(-1)
 
 
+class _NotShared:
+    """Sentinel: the rest-bucket total is this process's own (``None`` already means "the default process group")."""
+    def __repr__(self):
+        return "NOT_SHARED"
+
+
+NOT_SHARED = _NotShared()
+
+
 class _RhoAggregate(torch.autograd.Function):
     """Y = A_w(lut, cnt) @ S  with the rest-bucket term; gradients for S and the weight table."""
 
     @staticmethod
-    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids, s_total=None, reduce_cr=0):
+    def forward(ctx, S, lut, g: HopGraph, use_cnt: bool, with_rest: bool, row_ids, s_total=None, reduce_cr=0,
+                total_rows=None, total_group=NOT_SHARED):
         ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids, ctx.reduce_cr = g, use_cnt, with_rest, row_ids, reduce_cr
         ctx.s_total = None if s_total is None else s_total.detach()
+        ctx.total_rows, ctx.total_group = total_rows, total_group
         ctx.save_for_backward(S, lut)
         return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr)
 
@@ -632,7 +647,16 @@ class _RhoAggregate(torch.autograd.Function):
                 l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
                 w_rest = l_rest * inv[:, D - 1:D] if inv is not None else l_rest   # [n_out or 1, Cw]
                 w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
-                dS = dS + (w_rest * dY).sum(0, keepdim=True)
+                v = (w_rest * dY).sum(0, keepdim=True)
+                if ctx.total_group is not NOT_SHARED:
+                    # the total was summed over the ranks of a group: every rank's output rows pull on every rank's
+                    # summed operand rows, so the ranks add their vectors (W floats) before handing them down
+                    import torch.distributed as dist
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ctx.total_group)
+                if ctx.total_rows is None:
+                    dS = dS + v
+                else:                          # only the first rows of S went into the total (owned rows ahead of halo rows)
+                    dS[: ctx.total_rows] += v
 
         if ctx.needs_input_grad[1] and fused_lut_grad and not per_row:
             dlut = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, True)       # [D, 1]
@@ -640,7 +664,7 @@ class _RhoAggregate(torch.autograd.Function):
             if fused_lut_grad:
                 dwt = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, False)   # [n_out, D, 1]
             else:
-                T = shell_sums_launch(g, S, lut, with_rest, row_ids)              # [n_out, D, W]
+                T = shell_sums_launch(g, S, lut, with_rest, row_ids, ctx.s_total)  # [n_out, D, W]
                 dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
                 if inv is not None:
                     dwt = dwt * inv.unsqueeze(-1)                                 # [n_out, D, Cw]
@@ -652,7 +676,7 @@ class _RhoAggregate(torch.autograd.Function):
                     dlut.index_add_(0, rows, dwt)
             else:
                 dlut = dwt.sum(0)
-        return dS, dlut, None, None, None, None, None, None
+        return dS, dlut, None, None, None, None, None, None, None, None
 
 
 def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor, reduce_channels: int = 0,
@@ -691,13 +715,20 @@ def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.
 
 def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
                   with_rest: Optional[bool] = None, row_ids: Optional[torch.Tensor] = None,
-                  s_total: Optional[torch.Tensor] = None, reduce_channels: int = 0) -> torch.Tensor:
+                  s_total: Optional[torch.Tensor] = None, reduce_channels: int = 0,
+                  total_rows: Optional[int] = None, total_group=NOT_SHARED) -> torch.Tensor:
     """``Y[q] = sum_j wt(i_q, hop(i_q, j)) * S[j]`` over the hop-coded adjacency ``g``.
 
     ``lut [D, Cw]`` (post-rho / un-normalised: ``rho`` at the D distinct distances) or
     ``lut [N, D, Cw]`` (pre-rho: ``rho(u_d / cnt[i, d])``); ``use_cnt`` divides by the shell size
     (models.py:369-370).  ``with_rest`` defaults to True for CSR graphs (unlisted pairs get the
     ``rho(0)`` weight) and False for dense ones (every pair is listed).
+
+    ``s_total`` replaces the column sums of ``S`` as the rest bucket's total; it is treated as a constant by autograd and
+    its dependence on ``S`` is accounted for in this operator's backward: ``total_rows`` says that only the first rows of
+    ``S`` were summed into it (a rank's owned rows ahead of its halo rows), ``total_group`` that it was then summed over
+    the ranks of that process group (``None`` = the default group) — the backward pass all-reduces the matching W-float
+    vector over the same group, so EVERY rank of the group must run it.
     """
     if with_rest is None:
         with_rest = not g.is_dense
@@ -706,6 +737,6 @@ def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
     if row_ids is not None:
         row_ids = row_ids.to(device=g.device, dtype=torch.int32).contiguous()
     if reduce_channels and reduce_channels not in FUSABLE_READOUT:
-        Y = _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, 0)
+        Y = _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, 0, total_rows, total_group)
         return Y.view(Y.shape[0], -1, reduce_channels).sum(dim=1)
-    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, reduce_channels)
+    return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, reduce_channels, total_rows, total_group)

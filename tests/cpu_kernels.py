@@ -1,0 +1,97 @@
+"""Plain-torch stand-ins for the ``gnan_spmm_*`` launchers — TEST INFRASTRUCTURE ONLY.
+
+They let the CPU suite drive the product's host logic around the kernels (``functional._RhoAggregate``: which
+launches a backward pass makes, with which operands, and what it adds on top — the rest-bucket terms, the
+collectives of the multi-rank variants) without a GPU: ``install()`` swaps them in for
+``functional.spmm_launch`` / ``shell_sums_launch`` / ``lut_grad_launch`` / ``column_sums`` inside the calling (test)
+process.  Each restates the documented semantics of its launcher (functional.py, include/gnan_hip.h) with index
+arithmetic in float64; the GPU suite checks the real kernels against the oracle, this file is checked against the
+oracle in tests/test_host_logic.py.  CSR graphs only.
+"""
+import torch
+
+
+def _pairs(g):
+    rowptr = g.rowptr.long()
+    deg = rowptr[1:] - rowptr[:-1]
+    row_of_pair = torch.repeat_interleave(torch.arange(g.n_rows), deg)
+    return row_of_pair, g.col.long(), g.code.long()
+
+
+def column_sums(S):
+    return S.detach().float().sum(0)
+
+
+def spmm_launch(g, S, lut, use_cnt, with_rest, row_ids=None, weight_by_col=False, minus_rest=False, s_total=None,
+                reduce_cr=0, s_by_code=False):
+    assert not g.is_dense
+    S, lut = S.detach().double(), lut.detach().double()
+    D, Cw = lut.shape[-2], lut.shape[-1]
+    per_row = lut.dim() == 3
+    W = S.shape[1]
+    row_of_pair, col, code = _pairs(g)
+    cnt = g.cnt.clamp_min(1).double()
+    owner = col if weight_by_col else row_of_pair               # whose table row weights the pair
+    w = lut[owner, code] if per_row else lut[code]               # [nnz, Cw]
+    if use_cnt:
+        w = w / cnt[owner, code].unsqueeze(-1)
+    if minus_rest:
+        wr = lut[owner, D - 1] if per_row else lut[D - 1].expand(col.numel(), Cw)
+        if use_cnt:
+            wr = wr / cnt[owner, D - 1].unsqueeze(-1)
+        w = w - wr
+    src = S[col * D + code] if s_by_code else S[col]
+    Y = torch.zeros((g.n_rows, W), dtype=torch.float64).index_add_(0, row_of_pair, w.repeat(1, W // Cw) * src)
+    if with_rest:
+        total = S.sum(0) if s_total is None else s_total.detach().double()
+        listed = torch.zeros((g.n_rows, W), dtype=torch.float64).index_add_(0, row_of_pair, src)
+        w_rest = lut[:, D - 1] if per_row else lut[D - 1].expand(g.n_rows, Cw)
+        if use_cnt:
+            w_rest = w_rest / cnt[:, D - 1].unsqueeze(-1)
+        Y = Y + w_rest.repeat(1, W // Cw) * (total.unsqueeze(0) - listed)
+    if row_ids is not None:
+        Y = Y[row_ids.long()]
+    if reduce_cr:
+        Y = Y.view(Y.shape[0], -1, reduce_cr).sum(1)
+    return Y.float()
+
+
+def shell_sums_launch(g, S, lut_like, with_rest, row_ids=None, s_total=None):
+    S = S.detach().double()
+    D, W = g.n_codes, S.shape[1]
+    row_of_pair, col, code = _pairs(g)
+    T = torch.zeros((g.n_rows * D, W), dtype=torch.float64).index_add_(0, row_of_pair * D + code, S[col]).view(g.n_rows, D, W)
+    if with_rest:
+        total = S.sum(0) if s_total is None else s_total.detach().double()
+        T[:, D - 1] = total.unsqueeze(0) - T[:, : D - 1].sum(1)
+    if row_ids is not None:
+        T = T[row_ids.long()]
+    return T.float()
+
+
+def lut_grad_launch(g, S, dY, D, use_cnt, with_rest, row_ids, s_total, reduce_rows):
+    T = shell_sums_launch(g, S, None, with_rest, row_ids, s_total).double()          # [n_out, D, W]
+    dY = dY.detach().double()
+    W = T.shape[2]
+    dwt = (T * dY.repeat(1, W // dY.shape[1]).unsqueeze(1)).sum(2)                   # [n_out, D]
+    if use_cnt:
+        cnt = g.cnt if row_ids is None else g.cnt[row_ids.long()]
+        dwt = dwt / cnt.clamp_min(1).double()
+    out = dwt.sum(0) if reduce_rows else dwt
+    return out.float().unsqueeze(-1)
+
+
+def install():
+    """Swap the stand-ins in (call inside the test process / spawned worker; undo with the returned function)."""
+    from gnan_amd import _lib, functional
+    saved = {name: getattr(functional, name) for name in ("spmm_launch", "shell_sums_launch", "lut_grad_launch", "column_sums")}
+    saved_req = _lib.require_device
+    functional.spmm_launch, functional.shell_sums_launch = spmm_launch, shell_sums_launch
+    functional.lut_grad_launch, functional.column_sums = lut_grad_launch, column_sums
+    _lib.require_device = lambda *a, **k: None
+
+    def undo():
+        for name, fn in saved.items():
+            setattr(functional, name, fn)
+        _lib.require_device = saved_req
+    return undo

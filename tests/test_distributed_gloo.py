@@ -34,7 +34,7 @@ def _oracle_compute(sd, C):
     def column_sums(S):
         return S.sum(0)
 
-    def aggregate(g, S, lut, use_cnt, s_total=None, reduce_channels=0):
+    def aggregate(g, S, lut, use_cnt, s_total=None, reduce_channels=0, **_backward_only):
         rowptr, col, code = g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy()
         cnt = g.cnt.long().numpy() if use_cnt else None
         wt = O.weight_table(lut, cnt).expand(g.n_rows, -1, -1)
@@ -128,7 +128,7 @@ def test_feature_parallel_forward_equals_single_process(world, F, tmp_path):
 def _halo_compute(sd, C):
     base = _oracle_compute(sd, C)
 
-    def aggregate(g, S, lut, use_cnt, s_total=None, reduce_channels=0):
+    def aggregate(g, S, lut, use_cnt, s_total=None, reduce_channels=0, **_backward_only):
         rowptr, col, code = g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy()
         wt = O.weight_table(lut, g.cnt.long().numpy() if use_cnt else None).expand(g.n_rows, -1, -1)
         # the oracle forms the rest bucket from the operand it is given; the compact operand is not the whole graph
@@ -180,6 +180,90 @@ def test_halo_recompute_forward_equals_single_process(world, n, order, overlap, 
     want = O.spmm_csr(g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy(), S, wt)
     assert got.shape == (n, C)
     assert O.rel_err(torch.from_numpy(got), want.double()) <= 1e-5
+
+
+def _grad_problem(n, F):
+    src, dst, x, sd = _problem(n, F, 1)
+    return src, dst, x, {k: v.double() for k, v in sd.items()}
+
+
+def _grad_worker(rank, world, port, n, F, partition, order, out_dir):
+    """One rank of a multi-rank forward + backward.  The aggregation is the product's own autograd function running on
+    the stand-in launchers of tests/cpu_kernels.py, the shape functions are the oracle's (differentiable torch); the
+    collectives — and what the backward pass sends through them — are the product's."""
+    import cpu_kernels
+    from gnan_amd.distributed import (FeaturePartition, build_halo_plan, feature_parallel_forward, halo_recompute_forward,
+                                      slice_features)
+    from gnan_amd.functional import rho_aggregate
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu_kernels.install()
+    try:
+        src, dst, x, sd = _grad_problem(n, F)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        lut = O.rho_lut(leaves, 3, dtype=torch.float64).float()
+
+        def features_of(keys_lo, keys_hi):
+            def feature_mlps(xx, stacked, sum_features, return_total=False, total_rows=None, **_):
+                local = {f"fs.{k - keys_lo}." + key.split(".", 2)[2]: v for key, v in leaves.items()
+                         for k in range(keys_lo, keys_hi) if key.startswith(f"fs.{k}.")}
+                fx = O.feature_mlps(xx.double(), local).float()
+                out = fx.sum(1) if sum_features else fx.reshape(xx.shape[0], -1)
+                return (out, out[:total_rows].sum(0).detach()) if return_total else out
+            return feature_mlps
+        compute = {"feature_mlps": features_of(0, F), "aggregate": rho_aggregate}
+        part = VertexPartition(n, world, rank)
+        if partition == "halo":
+            plan = build_halo_plan(syn.hop1_csr(src, dst, n, part.lo, part.hi), part)
+            y = halo_recompute_forward(x[plan.node_ids()], plan, None, lut, True, order=order, out_channels=1,
+                                       compute=compute)
+            rows = slice(part.lo, part.hi)
+        elif partition == "vertex":
+            g = syn.hop1_csr(src, dst, n, part.lo, part.hi)
+            y = partitioned_forward(x[part.lo:part.hi], g, None, lut, True, part, order=order, out_channels=1,
+                                    compute=compute)
+            rows = slice(part.lo, part.hi)
+        else:
+            fpart = FeaturePartition(F, world, rank)
+            compute["feature_mlps"] = features_of(fpart.lo, fpart.hi)
+            y = feature_parallel_forward(x[:, fpart.lo:fpart.hi].contiguous(), syn.hop1_csr(src, dst, n), None, lut, True,
+                                         fpart, out_channels=1, compute=compute)
+            rows = slice(0, n)
+        target = torch.sin(torch.arange(n, dtype=torch.float32)).view(-1, 1)
+        loss = ((y - target[rows]) ** 2).sum()
+        # feature partition: every rank evaluates the SAME loss on the whole (summed) output and back-propagates it into
+        # its own partial output, so the ranks' gradients add up like the partials did
+        loss.backward()
+        grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in leaves.items()}
+        np.savez(os.path.join(out_dir, f"g{rank}.npz"), **grads)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,partition,order", [(2, 120, "halo", "reference"), (3, 121, "halo", "sum_first"),
+                                                     (2, 120, "vertex", "sum_first"), (3, 121, "vertex", "reference"),
+                                                     (2, 120, "feature", "reference")])
+def test_multi_rank_backward_adds_up_to_the_single_process_gradient(world, n, partition, order, tmp_path):
+    """Sum over the ranks of the parameter gradients == the single-process gradient (float64 oracle autograd).  The
+    rest-bucket total couples every output row to every operand row of every rank; the backward pass has to carry that
+    through the same collectives as the forward."""
+    F = 4
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(world, port, n, F, partition, order, str(tmp_path)), nprocs=world, join=True)
+    src, dst, x, sd = _grad_problem(n, F)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    g = syn.hop1_csr(src, dst, n)
+    S = O.feature_mlps(x.double(), leaves).sum(1)
+    wt = O.weight_table(O.rho_lut(leaves, 3, dtype=torch.float64), g.cnt.long().numpy()).expand(n, -1, -1)
+    y = O.spmm_csr(g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy(), S, wt)
+    target = torch.sin(torch.arange(n, dtype=torch.float32)).view(-1, 1).double()
+    ((y - target) ** 2).sum().backward()
+    scale = max(float(v.grad.abs().max()) for v in leaves.values())
+    parts = [np.load(tmp_path / f"g{r}.npz") for r in range(world)]
+    for k, v in leaves.items():
+        got = sum(p[k] for p in parts)
+        err = float(np.abs(got - v.grad.numpy()).max()) / scale
+        assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
 def test_choose_partition_by_exchanged_bytes():

@@ -163,3 +163,70 @@ def test_rows_helper_materialises_expanded_and_transposed_views():
     assert functional._rows(v) is v
     one = torch.ones(3).expand(1, 3)
     assert functional._rows(one) is one
+
+
+@pytest.fixture
+def cpu_kernels():
+    import cpu_kernels as ck
+    undo = ck.install()
+    yield ck
+    undo()
+
+
+@pytest.mark.parametrize("W,Cw,K,use_cnt,per_row,cr,subset", [
+    (4, 1, 1, True, False, 0, False),        # narrow operand: pre-weighted (node, hop code) rows, fused table gradient
+    (48, 1, 1, True, False, 1, False),       # wide operand with the fused feature sum
+    (6, 3, 2, True, False, 0, False),        # several weight channels: shell-sums route
+    (6, 3, 1, False, True, 0, False),        # per-row tables (pre-rho normalisation)
+    (8, 1, 4, True, False, 0, True),         # more shells than the fused table gradient takes, row subset
+    (2, 1, 1, True, False, 0, True),
+])
+def test_aggregation_backward_host_logic_vs_oracle_autograd(cpu_kernels, W, Cw, K, use_cnt, per_row, cr, subset):
+    """functional._RhoAggregate on stand-in launchers (tests/cpu_kernels.py) == autograd through the oracle: checks which
+    launches the backward pass makes and what it adds around them (rest-bucket terms, fused-sum broadcast, row subsets)."""
+    rng = np.random.default_rng(W * 7 + Cw + K)
+    n, D = 40, K + 2
+    rowptr, col, code = _csr(n, n, K, rng, hubs=[(3, 30)])
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(code), n_cols=n, n_codes=D)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).requires_grad_(True)
+    lut = torch.from_numpy(rng.standard_normal((n, D, Cw) if per_row else (D, Cw)).astype(np.float32)).requires_grad_(True)
+    rows = torch.from_numpy(rng.permutation(n)[:11].astype(np.int32)) if subset else None
+    Y = functional.rho_aggregate(g, S, lut, use_cnt, row_ids=rows, reduce_channels=cr)
+    up = torch.from_numpy(rng.standard_normal(tuple(Y.shape)).astype(np.float32))
+    dS, dlut = torch.autograd.grad(Y, [S, lut], up)
+    S64, lut64 = S.detach().double().requires_grad_(True), lut.detach().double().requires_grad_(True)
+    wt = lut64 if per_row else lut64.unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.clamp_min(1).double().unsqueeze(-1)
+    want = O.spmm_csr(rowptr, col, code, S64, wt)
+    if rows is not None:
+        want = want[rows.long()]
+    if cr:
+        want = want.view(want.shape[0], -1, cr).sum(1)
+    assert O.rel_err(Y.detach(), want.detach()) <= 1e-5
+    dS64, dlut64 = torch.autograd.grad(want, [S64, lut64], up.double())
+    assert O.rel_err(dS, dS64) <= 1e-5 and O.rel_err(dlut, dlut64) <= 1e-5
+
+
+def test_rest_bucket_total_over_the_first_rows_only(cpu_kernels):
+    """``total_rows``: only the first rows of the operand were summed into ``s_total`` (owned rows ahead of halo rows), so
+    only they receive the rest-bucket part of the operand gradient."""
+    rng = np.random.default_rng(9)
+    n_rows, n_cols, n_own, W, D = 30, 50, 30, 8, 3
+    rowptr, col, code = _csr(n_rows, n_cols, 1, rng)
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(code), n_cols=n_cols, n_codes=D)
+    S = torch.from_numpy(rng.standard_normal((n_cols, W)).astype(np.float32)).requires_grad_(True)
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).requires_grad_(True)
+    total = S[:n_own].sum(0).detach()
+    Y = functional.rho_aggregate(g, S, lut, True, s_total=total, total_rows=n_own)
+    up = torch.from_numpy(rng.standard_normal(tuple(Y.shape)).astype(np.float32))
+    dS, dlut = torch.autograd.grad(Y, [S, lut], up)
+    S64, lut64 = S.detach().double().requires_grad_(True), lut.detach().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0) / g.cnt.clamp_min(1).double().unsqueeze(-1)
+    listed = O.spmm_csr(rowptr, col, code, S64, wt, with_rest=False)
+    ones = torch.ones_like(wt)
+    plain = O.spmm_csr(rowptr, col, code, S64, ones, with_rest=False)              # unweighted sum of the listed rows
+    want = listed + wt[:, D - 1] * (S64[:n_own].sum(0).unsqueeze(0) - plain)
+    assert O.rel_err(Y.detach(), want.detach()) <= 1e-5
+    dS64, dlut64 = torch.autograd.grad(want, [S64, lut64], up.double())
+    assert O.rel_err(dS, dS64) <= 1e-5 and O.rel_err(dlut, dlut64) <= 1e-5
