@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -71,6 +71,18 @@ class FmlpBwdArgs(C.Structure):
     ]
 
 
+class FpwlGradArgs(C.Structure):
+    _fields_ = [
+        ("off", C.c_void_p), ("anchor", C.c_void_p), ("moments", C.c_void_p), ("moments_fixed", C.c_void_p),
+        ("scales", C.c_void_p),
+        ("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
+        ("w_last", C.c_void_p), ("b_last", C.c_void_p),
+        ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32),
+        ("d_w_first", C.c_void_p), ("d_b_first", C.c_void_p), ("d_w_mid", C.c_void_p), ("d_b_mid", C.c_void_p),
+        ("d_w_last", C.c_void_p), ("d_b_last", C.c_void_p),
+    ]
+
+
 class SpmmArgs(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_cols", C.c_int64),
@@ -105,6 +117,9 @@ SYMBOLS = {
     "gnan_fpwl_moments": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gnan_fpwl_moments_fixed": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "gnan_fpwl_moment_scales": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "gnan_fpwl_param_grads": (C.c_int, [C.POINTER(FpwlGradArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),

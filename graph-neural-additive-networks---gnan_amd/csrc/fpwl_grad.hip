@@ -1,0 +1,375 @@
+// Parameter gradients of the shape functions from the per-piece moments (gfx950): the last step of the table path's
+// backward pass, i.e. of autograd through GNAN.py:57-62 w.r.t. the f_k parameters (trainer.py:66).
+//
+// On piece t of feature k (anchor a) the network is affine, f(x) = f(a) + s (x - a), with a fixed activation pattern
+// (D1, D2 = 0/1 masks of the two hidden layers at any interior point of the piece), so the loss of all nodes that
+// fell into the piece depends on the parameters only through  <M0, f(a)> + <M1, s>  (M0 = sum g, M1 = sum g (x - a):
+// gnan_fpwl_moments).  With  h1a = D1 (w1 a + b1),  h1' = D1 w1,  h2a = D2 (W2 h1a + b2),  h2' = D2 W2 h1'
+// (value and x-derivative of the hidden layers at the anchor) the exact gradient of that expression is
+//     dW3 = M0 (x) h2a + M1 (x) h2'        db3 = M0
+//     e0 = D2 W3^T M0,  e1 = D2 W3^T M1    dW2 = e0 (x) h1a + e1 (x) h1'     db2 = e0
+//     q0 = D1 W2^T e0,  q1 = D1 W2^T e1    dw1 = q0 a + q1                   db1 = q0
+// summed over the pieces of the feature — one reverse pass for the value, one for the slope, sharing the masks.
+// One workgroup per feature walks its pieces (empty ones are skipped), float64 throughout, every gradient element
+// owned by one thread: no atomics, bit-reproducible.  It replaces ~110 tiny framework launches of the torch
+// restatement of the same sum (gnan_amd/pwl.py:parameter_grads_from_moments, two probe points per piece through the
+// batched MLP in float64 — still the route for L >= 4 and the reference this kernel is tested against).
+//
+// gnan_fpwl_moment_scales: the two power-of-two scales of the fixed-point moments, from max|grad| and max|x - anchor|,
+// in one pass + one single-thread kernel instead of ~20 framework launches.
+#include "common.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+constexpr int kBI = 16;   // elements of a 4-lane split: ceil(64 / 4)
+
+struct GradParams {
+  const int32_t* off;
+  const float* anchor;
+  const float* M;         // [T, 2, C] float32, or null
+  const int64_t* Mi;      // [T, 2, C] fixed point, or null
+  const double* scales;   // [2] (with Mi)
+  const float* w1;
+  const float* b1;
+  const float* W2;
+  const float* b2;
+  const float* Wl;
+  const float* bl;
+  int F, L, H, C;
+  float* d_w1;
+  float* d_b1;
+  float* d_W2;
+  float* d_b2;
+  float* d_Wl;
+  float* d_bl;
+};
+
+__device__ __forceinline__ double quad_sum(double v) {   // the 4 lanes of a quad are adjacent: fixed butterfly
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  return v;
+}
+
+// moments of piece t -> Mv[0..C) = M0, Mv[C..2C) = M1 (float64, LDS); returns whether any of them is non-zero
+__device__ __forceinline__ bool piece_moment(const GradParams& p, int64_t t, int c2, double inv0, double inv1, double* val) {
+  const int C = p.C;
+  if (p.Mi) {
+    const int64_t v = p.Mi[t * 2 * C + c2];
+    *val = static_cast<double>(v) * (c2 < C ? inv0 : inv1);
+    return v != 0;
+  }
+  const float v = p.M[t * 2 * C + c2];
+  *val = static_cast<double>(v);
+  return v != 0.f;
+}
+
+// anchor of piece li (of P) and a point strictly inside it: piece 0 is the ray left of the first kink (anchored at that
+// kink), the last piece the ray right of the last kink; a zero-width piece (coinciding kinks) holds no node
+__device__ __forceinline__ void piece_points(const float* A, int li, int P, double* a, double* xi) {
+  *a = static_cast<double>(A[li]);
+  if (li == 0) *xi = *a - 1.0;
+  else if (li == P - 1) *xi = *a + 1.0;
+  else *xi = 0.5 * (*a + static_cast<double>(A[li + 1]));
+}
+
+// ---- L == 3, H <= 64: thread (j, ib) = (unit of layer 2, quarter of the layer-1 units) -------------------------------
+__global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int H = p.H, C = p.C, HS = H + 1;
+  float* w1 = reinterpret_cast<float*>(smem_raw);
+  float* b1 = w1 + H;
+  float* b2 = b1 + H;
+  float* W2s = b2 + H;                 // [H][HS]: W2[j][i], padded rows (column reads in the W2^T products)
+  float* Wl = W2s + H * HS;            // [C][H]
+  double* h1i = reinterpret_cast<double*>(smem_raw + (((3 * H + H * HS + C * H) * sizeof(float) + 7) & ~size_t(7)));
+  double* h1a = h1i + H;
+  double* h1p = h1a + H;
+  double* e0 = h1p + H;
+  double* e1 = e0 + H;
+  double* Mv = e1 + H;                 // [2C]
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int j = tid >> 2, ib = tid & 3;
+  const int BI = (H + 3) >> 2;
+  const int64_t kH = static_cast<int64_t>(k) * H;
+
+  for (int i = tid; i < H; i += 256) {
+    w1[i] = p.w1[kH + i];
+    b1[i] = p.b1 ? p.b1[kH + i] : 0.f;
+    b2[i] = p.b2 ? p.b2[kH + i] : 0.f;
+  }
+  for (int i = tid; i < H * H; i += 256) W2s[(i / H) * HS + i % H] = p.W2[kH * H + i];
+  for (int i = tid; i < C * H; i += 256) Wl[i] = p.Wl[kH * C + i];
+  float w2r[kBI];
+#pragma unroll
+  for (int r = 0; r < kBI; ++r) {
+    const int i = ib * BI + r;
+    w2r[r] = (j < H && r < BI && i < H) ? p.W2[(kH + j) * H + i] : 0.f;
+  }
+  double dW2[kBI], dW3[kBI];
+#pragma unroll
+  for (int r = 0; r < kBI; ++r) dW2[r] = dW3[r] = 0.0;
+  double db2 = 0.0, dw1 = 0.0, db1 = 0.0, db3 = 0.0;
+  const int base = p.off[k], P = p.off[k + 1] - base;
+  const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
+  __syncthreads();
+
+  for (int li = 0; li < P; ++li) {
+    double mval = 0.0;
+    const bool mine = tid < 2 * C && piece_moment(p, base + li, tid, inv0, inv1, &mval);
+    if (!__syncthreads_or(mine)) continue;          // no node fell into this piece (also the barrier of the LDS vectors)
+    double a, xi;
+    piece_points(p.anchor + base, li, P, &a, &xi);
+    if (tid < 2 * C) Mv[tid] = mval;
+    if (tid < H) {
+      const double wv = static_cast<double>(w1[tid]), bv = static_cast<double>(b1[tid]);
+      const double z = fma(wv, xi, bv);
+      const bool on = z > 0.0;
+      h1i[tid] = on ? z : 0.0;
+      h1a[tid] = on ? fma(wv, a, bv) : 0.0;
+      h1p[tid] = on ? wv : 0.0;
+    }
+    __syncthreads();
+    if (j < H) {
+      double si = 0.0, sa = 0.0, sp = 0.0;
+#pragma unroll
+      for (int r = 0; r < kBI; ++r) {
+        const int i = ib * BI + r;
+        if (r < BI && i < H) {
+          const double w = static_cast<double>(w2r[r]);
+          si = fma(w, h1i[i], si);
+          sa = fma(w, h1a[i], sa);
+          sp = fma(w, h1p[i], sp);
+        }
+      }
+      si = quad_sum(si); sa = quad_sum(sa); sp = quad_sum(sp);
+      const double bj = static_cast<double>(b2[j]);
+      const bool on2 = si + bj > 0.0;
+      const double h2a = on2 ? sa + bj : 0.0, h2p = on2 ? sp : 0.0;
+      double p0 = 0.0, p1 = 0.0;
+      for (int c = ib; c < C; c += 4) {
+        const double wl = static_cast<double>(Wl[c * H + j]);
+        p0 = fma(wl, Mv[c], p0);
+        p1 = fma(wl, Mv[C + c], p1);
+      }
+      p0 = quad_sum(p0); p1 = quad_sum(p1);
+      const double e0v = on2 ? p0 : 0.0, e1v = on2 ? p1 : 0.0;
+#pragma unroll
+      for (int r = 0; r < kBI; ++r) {
+        const int i = ib * BI + r;
+        if (r < BI && i < H) dW2[r] = fma(e0v, h1a[i], fma(e1v, h1p[i], dW2[r]));
+      }
+#pragma unroll
+      for (int r = 0; r < kBI; ++r) {
+        const int c = ib + 4 * r;
+        if (c < C) dW3[r] = fma(Mv[c], h2a, fma(Mv[C + c], h2p, dW3[r]));
+      }
+      if (ib == 0) {
+        db2 += e0v;
+        e0[j] = e0v;
+        e1[j] = e1v;
+      }
+    }
+    if (tid < C) db3 += Mv[tid];
+    __syncthreads();
+    if (j < H) {                        // same quad, other role: i = j, the quad splits the layer-2 units
+      const int i = j;
+      double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < kBI; ++r) {
+        const int jj = ib * BI + r;
+        if (r < BI && jj < H) {
+          const double w = static_cast<double>(W2s[jj * HS + i]);
+          q0 = fma(w, e0[jj], q0);
+          q1 = fma(w, e1[jj], q1);
+        }
+      }
+      q0 = quad_sum(q0); q1 = quad_sum(q1);
+      if (ib == 0 && fma(static_cast<double>(w1[i]), xi, static_cast<double>(b1[i])) > 0.0) {
+        dw1 += fma(q0, a, q1);
+        db1 += q0;
+      }
+    }
+    // the next piece's __syncthreads_or separates these reads of e0 / e1 from their next writes
+  }
+
+  if (j < H) {
+#pragma unroll
+    for (int r = 0; r < kBI; ++r) {
+      const int i = ib * BI + r;
+      if (r < BI && i < H) p.d_W2[(kH + j) * H + i] = static_cast<float>(dW2[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kBI; ++r) {
+      const int c = ib + 4 * r;
+      if (c < C) p.d_Wl[(static_cast<int64_t>(k) * C + c) * H + j] = static_cast<float>(dW3[r]);
+    }
+    if (ib == 0) {
+      if (p.d_b2) p.d_b2[kH + j] = static_cast<float>(db2);
+      p.d_w1[kH + j] = static_cast<float>(dw1);
+      if (p.d_b1) p.d_b1[kH + j] = static_cast<float>(db1);
+    }
+  }
+  if (tid < C && p.d_bl) p.d_bl[static_cast<int64_t>(k) * C + tid] = static_cast<float>(db3);
+}
+
+// ---- L == 2, H <= 128: thread (i, cb) = (hidden unit, quarter of the output channels) --------------------------------
+__global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
+  __shared__ double Mv[128];
+  const int H = p.H, C = p.C;
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int i = tid >> 2, cb = tid & 3;
+  const int64_t kH = static_cast<int64_t>(k) * H;
+  const bool live = i < H;
+  const double wv = live ? static_cast<double>(p.w1[kH + i]) : 0.0;
+  const double bv = (live && p.b1) ? static_cast<double>(p.b1[kH + i]) : 0.0;
+  float wlr[kBI];
+  double dWl[kBI];
+#pragma unroll
+  for (int r = 0; r < kBI; ++r) {
+    const int c = cb + 4 * r;
+    wlr[r] = (live && c < C) ? p.Wl[(static_cast<int64_t>(k) * C + c) * H + i] : 0.f;
+    dWl[r] = 0.0;
+  }
+  double dw1 = 0.0, db1 = 0.0, db3 = 0.0;
+  const int base = p.off[k], P = p.off[k + 1] - base;
+  const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
+  for (int li = 0; li < P; ++li) {
+    double mval = 0.0;
+    const bool mine = tid < 2 * C && piece_moment(p, base + li, tid, inv0, inv1, &mval);
+    if (!__syncthreads_or(mine)) continue;
+    double a, xi;
+    piece_points(p.anchor + base, li, P, &a, &xi);
+    if (tid < 2 * C) Mv[tid] = mval;
+    __syncthreads();
+    const bool on = live && fma(wv, xi, bv) > 0.0;
+    const double h1a = on ? fma(wv, a, bv) : 0.0, h1p = on ? wv : 0.0;
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < kBI; ++r) {
+      const int c = cb + 4 * r;
+      if (c < C) {
+        const double wl = static_cast<double>(wlr[r]);
+        p0 = fma(wl, Mv[c], p0);
+        p1 = fma(wl, Mv[C + c], p1);
+        dWl[r] = fma(Mv[c], h1a, fma(Mv[C + c], h1p, dWl[r]));
+      }
+    }
+    p0 = quad_sum(p0); p1 = quad_sum(p1);
+    if (on && cb == 0) {
+      dw1 += fma(p0, a, p1);
+      db1 += p0;
+    }
+    if (tid < C) db3 += Mv[tid];
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < kBI; ++r) {
+      const int c = cb + 4 * r;
+      if (c < C) p.d_Wl[(static_cast<int64_t>(k) * C + c) * H + i] = static_cast<float>(dWl[r]);
+    }
+    if (cb == 0) {
+      p.d_w1[kH + i] = static_cast<float>(dw1);
+      if (p.d_b1) p.d_b1[kH + i] = static_cast<float>(db1);
+    }
+  }
+  if (tid < C && p.d_bl) p.d_bl[static_cast<int64_t>(k) * C + tid] = static_cast<float>(db3);
+}
+
+// ---- scales of the fixed-point moments --------------------------------------------------------------------------------
+// bits[0] = max |grad| over the [n, width] gradient, bits[1] = max |anchor| over the T anchors, as the bit patterns of
+// non-negative floats (their order is the order of the values; a NaN ends up on top and poisons the scales, as it would
+// poison the sums).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, int64_t n, int width, int64_t stride,
+                                                     const float* __restrict__ anchor, int64_t T, unsigned* bits) {
+  const int64_t total = n * width;
+  float m = 0.f, ma = 0.f;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const float v = fabsf(width == stride ? g[e] : g[(e / width) * stride + e % width]);
+    m = (v > m || v != v) ? v : m;
+  }
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < T; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const float v = fabsf(anchor[e]);
+    ma = (v > ma || v != v) ? v : ma;
+  }
+  unsigned u = __float_as_uint(m), ua = __float_as_uint(ma);
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_xor(u, off), oa = __shfl_xor(ua, off);
+    u = o > u ? o : u;
+    ua = oa > ua ? oa : ua;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (u) atomicMax(bits, u);
+    if (ua) atomicMax(bits + 1, ua);
+  }
+}
+
+__global__ void scales_kernel(const unsigned* bits, const double* x_abs_max, int nbits, double* scales) {
+  const float gf = __uint_as_float(bits[0]), af = __uint_as_float(bits[1]);
+  const double xm = *x_abs_max;
+  if (gf != gf || af != af || xm != xm) {            // a NaN in the gradient poisons the sums, as it would in float
+    scales[0] = scales[1] = static_cast<double>(NAN);
+    return;
+  }
+  const double g = fmax(static_cast<double>(gf), DBL_MIN);
+  const double d = fmax(xm + static_cast<double>(af), DBL_MIN);
+  const double e0 = fmin(fmax(floor(nbits - log2(g)), -1000.0), 1000.0);
+  const double e1 = fmin(fmax(floor(nbits - log2(g * d)), -1000.0), 1000.0);
+  scales[0] = ldexp(1.0, static_cast<int>(e0));
+  scales[1] = ldexp(1.0, static_cast<int>(e1));
+}
+
+}  // namespace
+
+extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "fpwl_param_grads: null args");
+  GNAN_REQUIRE(a->F >= 1 && a->H >= 1 && a->C >= 1, "fpwl_param_grads: bad sizes");
+  if (a->L != 2 && a->L != 3) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_param_grads: kernel covers L in {2, 3} (got %d)", a->L);
+  if (a->C > 64 || a->H > (a->L == 3 ? 64 : 128))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_param_grads: H <= %d and C <= 64 (got H=%d, C=%d)", a->L == 3 ? 64 : 128, a->H, a->C);
+  GNAN_REQUIRE(a->off && a->anchor && a->w_first && a->w_last && a->d_w_first && a->d_w_last, "fpwl_param_grads: null pointer");
+  GNAN_REQUIRE((a->moments != nullptr) != (a->moments_fixed != nullptr), "fpwl_param_grads: exactly one of moments / moments_fixed");
+  GNAN_REQUIRE(a->moments_fixed == nullptr || a->scales != nullptr, "fpwl_param_grads: moments_fixed needs scales");
+  if (a->L == 3) GNAN_REQUIRE(a->w_mid && a->d_w_mid, "fpwl_param_grads: L == 3 needs w_mid / d_w_mid");
+  GNAN_REQUIRE((a->b_first == nullptr) == (a->d_b_first == nullptr) && (a->b_last == nullptr) == (a->d_b_last == nullptr) &&
+               (a->L == 2 || (a->b_mid == nullptr) == (a->d_b_mid == nullptr)),
+               "fpwl_param_grads: d_b_* must be NULL exactly where the bias is NULL");
+  GradParams p;
+  p.off = a->off; p.anchor = a->anchor; p.M = a->moments; p.Mi = a->moments_fixed; p.scales = a->scales;
+  p.w1 = a->w_first; p.b1 = a->b_first; p.W2 = a->w_mid; p.b2 = a->b_mid; p.Wl = a->w_last; p.bl = a->b_last;
+  p.F = a->F; p.L = a->L; p.H = a->H; p.C = a->C;
+  p.d_w1 = a->d_w_first; p.d_b1 = a->d_b_first; p.d_W2 = a->d_w_mid; p.d_b2 = a->d_b_mid;
+  p.d_Wl = a->d_w_last; p.d_bl = a->d_b_last;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->L == 3) {
+    const size_t H = a->H, C = a->C;
+    size_t lds = ((3 * H + H * (H + 1) + C * H) * sizeof(float) + 7) & ~size_t(7);
+    lds += (5 * H + 2 * C) * sizeof(double);
+    hipLaunchKernelGGL(fpwl_grad3_kernel, dim3(a->F), dim3(256), lds, st, p);
+    return gnan::check_launch("fpwl_grad3_kernel");
+  }
+  hipLaunchKernelGGL(fpwl_grad2_kernel, dim3(a->F), dim3(512), 0, st, p);
+  return gnan::check_launch("fpwl_grad2_kernel");
+}
+
+extern "C" int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
+                                       int64_t T, const double* x_abs_max, int32_t bits, void* workspace,
+                                       size_t workspace_bytes, double* scales, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && width >= 1 && grad_stride >= width && T >= 0, "fpwl_moment_scales: bad sizes");
+  GNAN_REQUIRE((grad || n == 0) && (anchor || T == 0) && x_abs_max && scales, "fpwl_moment_scales: null pointer");
+  GNAN_REQUIRE(workspace && workspace_bytes >= 2 * sizeof(unsigned), "fpwl_moment_scales: workspace of 8 bytes needed");
+  GNAN_REQUIRE(bits >= 1 && bits <= 62, "fpwl_moment_scales: bits must be in [1, 62]");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned* b = static_cast<unsigned*>(workspace);
+  hipError_t e = hipMemsetAsync(b, 0, 2 * sizeof(unsigned), st);
+  if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl_moment_scales: hipMemsetAsync: %s", hipGetErrorString(e));
+  const int64_t work = n * width > T ? n * width : T;
+  int64_t blocks = (work + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(absmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad, n, width, grad_stride, anchor, T, b);
+  if (int rc = gnan::check_launch("absmax_kernel")) return rc;
+  hipLaunchKernelGGL(scales_kernel, dim3(1), dim3(1), 0, st, b, x_abs_max, bits, scales);
+  return gnan::check_launch("scales_kernel");
+}

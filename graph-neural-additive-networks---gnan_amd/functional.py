@@ -137,8 +137,10 @@ def _abs_max_cached(x: torch.Tensor) -> torch.Tensor:
 
 
 def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
-                  x_abs_max: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-piece moments of the upstream gradient (``gnan_fpwl_moments[_fixed]``) -> ``[T, 2, C]`` float32.
+                  x_abs_max: Optional[torch.Tensor] = None, raw: bool = False):
+    """Per-piece moments of the upstream gradient (``gnan_fpwl_moments[_fixed]``) -> ``[T, 2, C]`` float32; with ``raw``
+    the fixed-point route returns ``(moments int64 [T, 2, C], scales float64 [2])`` undivided (``gnan_fpwl_param_grads``
+    takes them as they are).
 
     Fixed-point route (default where the 64-bit bins fit LDS): every term is added as ``round(v * 2^e)`` with ``e``
     chosen on the device from ``max |grad|`` and ``max |x - anchor|`` such that n terms cannot overflow 62 bits —
@@ -158,16 +160,20 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
     mgp = t.max_group_pieces
     if MOMENTS_FIXED_POINT and n > 0 and (mgp + 1) // 2 * 8 + mgp * 2 * C * 8 <= 150 * 1024:
         bits = 61 - max(1, (max(n, 2) - 1).bit_length())            # a bin receives at most n terms
-        tiny = torch.finfo(torch.float64).tiny
-        g_max = grad.abs().max().double().clamp_min(tiny)
         if x_abs_max is None:
             x_abs_max = x.abs().max().double()
-        d_max = (x_abs_max + t.anchor.abs().max().double()).clamp_min(tiny)
-        e = torch.stack([torch.floor(bits - torch.log2(g_max)), torch.floor(bits - torch.log2(g_max * d_max))])
-        scales = torch.exp2(e.clamp(-1000.0, 1000.0))
+        # scales[0] = 2^floor(bits - log2 max|grad|), scales[1] = 2^floor(bits - log2(max|grad| max|x - anchor|)):
+        # one pass over the gradient on the device (gnan_fpwl_moment_scales), no host round trip
+        scales = torch.empty(3, dtype=torch.float64, device=x.device)        # [2] scales | 8 bytes of workspace
+        _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(grad), n, grad.shape[1], grad.stride(0), _lib.ptr(t.anchor),
+                                                      T, _lib.ptr(x_abs_max), bits, _lib.ptr(scales[2:]), 8,
+                                                      _lib.ptr(scales), _lib.stream_of(x)), "gnan_fpwl_moment_scales")
+        scales = scales[:2]
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
         _lib.check(_lib.lib().gnan_fpwl_moments_fixed(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(scales), _lib.ptr(Mi),
                                                       _lib.stream_of(x)), "gnan_fpwl_moments_fixed")
+        if raw:
+            return Mi, scales
         return (Mi.double() / scales.view(1, 2, 1)).float()
     M = torch.zeros((T, 2, C), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().gnan_fpwl_moments(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(M), _lib.stream_of(x)),
@@ -237,6 +243,33 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
         a.workspace, a.workspace_bytes = _lib.ptr(ws), need
     _lib.check(_lib.lib().gnan_fmlp_fwd(a, _lib.stream_of(x)), "gnan_fmlp_fwd")
     return out
+
+
+HIP_TABLE_GRADS = os.environ.get("GNAN_HIP_TABLE_GRADS", "1") != "0"   # table path: parameter gradients by gnan_fpwl_param_grads
+
+
+def _table_grads_applies(L: int, H: int, C: int) -> bool:
+    return HIP_TABLE_GRADS and C <= 64 and ((L == 3 and H <= 64) or (L == 2 and H <= 128))
+
+
+def _fpwl_param_grads_launch(params, t, moments, L, H, C, F):
+    """``gnan_fpwl_param_grads``: gradients of the six stacked parameter tensors (None where a bias is absent) from the
+    per-piece moments — ``moments`` is ``[T, 2, C]`` float32 or the ``(int64 moments, scales)`` pair of the fixed-point route."""
+    keep = [None if q is None else q.detach().float().contiguous() for q in params]
+    outs = [None if q is None else torch.empty_like(q) for q in keep]
+    fixed = isinstance(moments, tuple)
+    M = None if fixed else moments.detach().float().contiguous()
+    a = _lib.FpwlGradArgs(
+        off=_lib.ptr(t.off), anchor=_lib.ptr(t.anchor), moments=_lib.ptr(M),
+        moments_fixed=_lib.ptr(moments[0]) if fixed else None, scales=_lib.ptr(moments[1]) if fixed else None,
+        w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]),
+        w_mid=None if keep[2] is None else _lib.ptr(keep[2][0]), b_mid=None if keep[3] is None else _lib.ptr(keep[3][0]),
+        w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]), F=F, L=L, H=H, C=C,
+        d_w_first=_lib.ptr(outs[0]), d_b_first=_lib.ptr(outs[1]),
+        d_w_mid=None if outs[2] is None else _lib.ptr(outs[2][0]), d_b_mid=None if outs[3] is None else _lib.ptr(outs[3][0]),
+        d_w_last=_lib.ptr(outs[4]), d_b_last=_lib.ptr(outs[5]))
+    _lib.check(_lib.lib().gnan_fpwl_param_grads(a, _lib.stream_of(t.anchor)), "gnan_fpwl_param_grads")
+    return outs
 
 
 HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
@@ -342,6 +375,10 @@ class _FeatureMLPs(torch.autograd.Function):
             # table path: one streaming pass bins the upstream gradient per piece (HIP), then the exact
             # parameter gradients follow from 2 probe points per piece through the tiny batched MLP
             from .pwl import parameter_grads_from_moments
+            if _table_grads_applies(L, H, C) and x.is_cuda:
+                # ... exactly, in one kernel: one reverse pass for the value and one for the slope of every non-empty piece
+                M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max, raw=True)
+                return (None,) * 9 + tuple(_fpwl_param_grads_launch(params, ctx.tables, M, L, H, C, F))
             M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max)
             got = parameter_grads_from_moments(
                 p, ctx.tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()

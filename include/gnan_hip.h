@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 19
+#define GNAN_ABI_VERSION 20
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -173,6 +173,46 @@ int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_s
  * Integer LDS atomics run ~12x faster than float ones on gfx950 and the sums are bit-reproducible. */
 int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, const double* scales,
                             int64_t* moments, gnan_stream_t stream);
+
+/* The two scales of gnan_fpwl_moments_fixed, computed on the device:
+ *   scales[0] = 2^floor(bits - log2(max|grad|)),  scales[1] = 2^floor(bits - log2(max|grad| * (x_abs_max + max|anchor|)))
+ * (exponents clamped to +-1000) with grad [n, width] (row stride grad_stride), anchor [T], x_abs_max one double in
+ * DEVICE memory (max |x| of the feature matrix) and bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits.
+ * workspace: 8 bytes.  One pass over grad + a single-thread kernel; no host round trip. */
+int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
+                            int64_t T, const double* x_abs_max, int32_t bits, void* workspace, size_t workspace_bytes,
+                            double* scales, gnan_stream_t stream);
+
+/* Parameter gradients of the shape functions from the per-piece moments — the last step of the table path's backward
+ * pass (autograd through GNAN.py:57-62 w.r.t. every fs[k] parameter, trainer.py:66).  On a piece the network is affine
+ * with a fixed activation pattern, so  d/dtheta sum_n <g_n, f_k(x_n)>  =  sum over pieces of
+ * d/dtheta ( <M0, f(anchor)> + <M1, slope> ): one reverse pass for the value and one for the slope per piece, float64,
+ * one workgroup per feature, no atomics (bit-reproducible).  Moments as gnan_fpwl_moments wrote them (`moments`) or in
+ * fixed point (`moments_fixed` + the `scales` they were accumulated with); tables as gnan_pwl_build wrote them (only
+ * off / anchor are read).  Weight and gradient layouts as gnan_fmlp_bwd_args.  Covers L in {2, 3}, H <= 64 (L == 3) /
+ * 128 (L == 2), C <= 64. */
+typedef struct gnan_fpwl_grad_args {
+  const int32_t* off;           /* [F+1] */
+  const float* anchor;          /* [T] */
+  const float* moments;         /* [T, 2, C] float32, or NULL */
+  const int64_t* moments_fixed; /* [T, 2, C] int64, or NULL */
+  const double* scales;         /* [2], device memory (with moments_fixed) */
+  const float* w_first;         /* [F, H] */
+  const float* b_first;         /* [F, H] or NULL */
+  const float* w_mid;           /* [F, H, H] (L == 3) */
+  const float* b_mid;           /* [F, H] or NULL */
+  const float* w_last;          /* [F, C, H] */
+  const float* b_last;          /* [F, C] or NULL */
+  int32_t F, L, H, C;
+  float* d_w_first;
+  float* d_b_first;
+  float* d_w_mid;
+  float* d_b_mid;
+  float* d_w_last;
+  float* d_b_last;
+} gnan_fpwl_grad_args;
+
+int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t stream);
 
 /* Build the look-up tables on the device: one workgroup per feature finds the kinks of f_k (zero crossings
  * of its hidden pre-activations, float64) and tabulates the network at them.  Covers L in {2, 3}, H <= 128.

@@ -41,7 +41,8 @@ def test_struct_layout_matches_header():
     """Field order of the ctypes structs == field order of the C structs (names must line up)."""
     text = open(os.path.join(ROOT, "include", "gnan_hip.h")).read()
     for struct, cls in (("gnan_fmlp_args", _lib.FmlpArgs), ("gnan_spmm_args", _lib.SpmmArgs),
-                        ("gnan_fpwl_args", _lib.FpwlArgs), ("gnan_pwl_build_args", _lib.PwlBuildArgs)):
+                        ("gnan_fpwl_args", _lib.FpwlArgs), ("gnan_pwl_build_args", _lib.PwlBuildArgs),
+                        ("gnan_fpwl_grad_args", _lib.FpwlGradArgs), ("gnan_fmlp_bwd_args", _lib.FmlpBwdArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

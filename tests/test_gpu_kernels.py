@@ -453,6 +453,86 @@ def test_small_batch_backward_kernel_vs_autograd(F, L, H, C, bias, n, sum_featur
     assert O.rel_err(got["hip"][0].cpu(), w1) <= 1e-5
 
 
+@pytest.mark.parametrize("F,L,H,C,bias,n", [(5, 3, 64, 1, True, 4000), (3, 3, 33, 40, True, 900), (7, 3, 8, 3, False, 2500),
+                                             (4, 2, 100, 5, True, 3000), (2, 2, 16, 64, False, 700), (1, 3, 64, 2, True, 50),
+                                             (129, 3, 64, 1, True, 2000)])
+@pytest.mark.parametrize("sum_features", [True, False])
+def test_table_path_parameter_gradients_kernel(F, L, H, C, bias, n, sum_features, monkeypatch):
+    """gnan_fpwl_param_grads (analytic reverse passes per piece, float64, one workgroup per feature) == the torch route
+    (two probe points per piece through the batched MLP) == autograd through the float64 oracle; bit-reproducible."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    sd = _mlp_state(F, L, H, C, bias, seed=F + 5 * H + C)
+    x = (torch.rand(n, F, generator=torch.Generator().manual_seed(3)) * 4 - 2).to(DEV)
+    width = C if sum_features else F * C
+    gup = torch.randn(n, width, generator=torch.Generator().manual_seed(4)).to(DEV)
+    got = {}
+    for tag, on in (("hip", True), ("torch", False), ("hip2", True)):
+        monkeypatch.setattr(functional, "HIP_TABLE_GRADS", on)
+        st = _stack(sd, F, L, H, C, bias)
+        leaves = [t for t in st[:6] if t is not None]
+        for t in leaves:
+            t.requires_grad_(True)
+        out = feature_mlps(x, st, sum_features)
+        got[tag] = torch.autograd.grad(out, leaves, gup)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.feature_mlps(x.cpu().double(), sd64)
+    ref = ref.sum(1) if sum_features else ref.reshape(n, -1)
+    ref.backward(gup.cpu().double())
+    scale = max(float(v.grad.abs().max()) for v in sd64.values())
+    for a, b, c in zip(got["hip"], got["torch"], got["hip2"]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-5 * scale, (float((a - b).abs().max()), scale)
+        assert torch.equal(a, c)
+    last = 3 * (L - 1)
+    names = [("0.weight", lambda t: t[:, 0]), ("0.bias", None)] if bias else [("0.weight", lambda t: t[:, 0])]
+    want = {"w_first": torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)]),
+            "w_last": torch.stack([sd64[f"fs.{k}.{last}.weight"].grad for k in range(F)])}
+    leaves_names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), _stack(sd, F, L, H, C, bias)[:6])
+                    if t is not None]
+    by_name = dict(zip(leaves_names, got["hip"]))
+    assert float((by_name["w_first"].cpu().double() - want["w_first"]).abs().max()) <= 1e-5 * scale
+    assert float((by_name["w_last"].cpu().double() - want["w_last"]).abs().max()) <= 1e-5 * scale
+    if L == 3:
+        w_mid = torch.stack([sd64[f"fs.{k}.3.weight"].grad for k in range(F)])
+        assert float((by_name["w_mid"][0].cpu().double() - w_mid).abs().max()) <= 1e-5 * scale
+        if bias:
+            b_mid = torch.stack([sd64[f"fs.{k}.3.bias"].grad for k in range(F)])
+            assert float((by_name["b_mid"][0].cpu().double() - b_mid).abs().max()) <= 1e-5 * scale
+    if bias:
+        b_first = torch.stack([sd64[f"fs.{k}.0.bias"].grad for k in range(F)])
+        b_last = torch.stack([sd64[f"fs.{k}.{last}.bias"].grad for k in range(F)])
+        assert float((by_name["b_first"].cpu().double() - b_first).abs().max()) <= 1e-5 * scale
+        assert float((by_name["b_last"].cpu().double() - b_last).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("n,width,gscale", [(1000, 3, 1.0), (70000, 1, 1e-12), (5, 64, 1e20), (100, 2, 0.0)])
+def test_moment_scales_kernel(n, width, gscale):
+    """gnan_fpwl_moment_scales == the framework formula it replaced (powers of two from max|grad| and max|x - anchor|)."""
+    from gnan_amd import _lib
+    g = (torch.randn(n, width + 2, generator=torch.Generator().manual_seed(n)) * gscale).to(DEV)[:, :width]     # strided rows
+    anchor = (torch.randn(300, generator=torch.Generator().manual_seed(1)) * 5).to(DEV)
+    xmax = torch.tensor(3.25, dtype=torch.float64, device=DEV)
+    bits = 61 - max(1, (max(n, 2) - 1).bit_length())
+    out = torch.empty(3, dtype=torch.float64, device=DEV)
+    _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(g), n, width, g.stride(0), _lib.ptr(anchor), anchor.numel(),
+                                                  _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
+                                                  _lib.stream_of(g)), "gnan_fpwl_moment_scales")
+    tiny = torch.finfo(torch.float64).tiny
+    g_max = g.abs().max().double().clamp_min(tiny)
+    d_max = (xmax + anchor.abs().max().double()).clamp_min(tiny)
+    e = torch.stack([torch.floor(bits - torch.log2(g_max)), torch.floor(bits - torch.log2(g_max * d_max))])
+    want = torch.exp2(e.clamp(-1000.0, 1000.0))
+    assert torch.equal(out[:2].cpu(), want.cpu()), (out[:2], want)
+    gn = g.clone()
+    gn[n // 2, 0] = float("nan")
+    _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(gn), n, width, gn.stride(0), _lib.ptr(anchor), anchor.numel(),
+                                                  _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
+                                                  _lib.stream_of(g)), "gnan_fpwl_moment_scales")
+    assert bool(torch.isnan(out[:2]).all())
+
+
 @pytest.mark.parametrize("algo", ["auto", "pwl"])
 def test_expanded_upstream_gradient(algo, monkeypatch):
     """``feature_mlps(...).sum(0)`` sends back an EXPANDED gradient (strides (0, 1)); both backward routes — the

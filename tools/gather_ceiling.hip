@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -57,14 +58,19 @@ int run(const float4* tab, uint64_t table_bytes, float* out, int wgs) {
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
   const uint64_t cap = 16ull << 30;
   float4* tab; float* out;
   CK(hipMalloc(&tab, cap));
   CK(hipMemset(tab, 0, cap));
   CK(hipMalloc(&out, 1 << 28));
   const int wgs = 256 * 64;
-  for (uint64_t bytes : {1280ull << 20, 2560ull << 20, 14ull << 30}) {
+  // ./gather_ceiling [table sizes in MiB ...]: small tables show what L2- (4 MiB per XCD) and MALL-resident (256 MiB)
+  // rows reach — does the request-rate wall belong to L2 misses or to L2 requests?
+  std::vector<uint64_t> sizes;
+  for (int i = 1; i < argc; ++i) sizes.push_back(static_cast<uint64_t>(atoll(argv[i])) << 20);
+  if (sizes.empty()) sizes = {1280ull << 20, 2560ull << 20, 14ull << 30};
+  for (uint64_t bytes : sizes) {
     if (run<4, 4>(tab, bytes, out, wgs)) return 1;      // 64-B rows
     if (run<8, 4>(tab, bytes, out, wgs)) return 1;      // 128-B rows (64 bf16)
     if (run<8, 8>(tab, bytes, out, wgs)) return 1;
