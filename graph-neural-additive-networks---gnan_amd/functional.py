@@ -124,6 +124,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     return (out, total) if want_total else out
 
 
+CAPTURED_BUILDS = []          # (sizes a look-up was captured with, the stacked weights it tabulates) of the capture in progress
 SPECULATIVE_LOOKUP = os.environ.get("GNAN_SPECULATIVE_LOOKUP", "1") != "0"   # queue the look-up before the piece counts are read back
 MOMENTS_FIXED_POINT = True    # accumulate the per-piece moments in 64-bit fixed point (integer LDS atomics, reproducible)
 _ABS_MAX_CACHE = TensorKeyedCache(16)   # feature matrix (object identity + version) -> device scalar max |x|
@@ -198,6 +199,17 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
             return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows) \
                 if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype), None)
 
+        if hip_build_applies(stacked) and torch.cuda.is_current_stream_capturing():
+            # hipGraph capture (gnan_amd/graphed.py): no device->host copy may happen here, so the look-up is sized like
+            # the speculative one — from the piece counts of the LAST eager forward, with room — and whoever replays the
+            # graph checks before every replay that the tables of the current weights still fit (CAPTURED_BUILDS)
+            pending = build_tables_lazy(stacked)
+            guess = pending.speculative()
+            if guess is None:
+                raise _lib.GnanHipError("graph capture needs one eager forward of this model first (table sizes unknown)")
+            res = look_up(guess)
+            CAPTURED_BUILDS.append((guess, stacked))
+            return res[0], guess, res[1]
         if SPECULATIVE_LOOKUP and hip_build_applies(stacked) and not torch.cuda.is_current_stream_capturing():
             # Sizing the look-up needs the tables' piece counts, i.e. a device->host copy between the table build and the
             # look-up during which the GPU idles (60-70 us: 1 % of the C4 forward, 6 % of a 1/8 share).  The look-up is

@@ -1,0 +1,181 @@
+"""hipGraph replay of whole forward / training steps on a FIXED input (node-level tasks: one graph, every epoch).
+
+The reference's node-level loop (trainer.py:23-86 on Cora / ogbn-arxiv) runs the same computation on the same tensors
+every epoch: zero the gradients, forward, mask, loss, backward, Adam.  On an MI355X the kernels of such a step take
+~1 ms on the arxiv-shaped graph while Python, the autograd engine and ~70 kernel launches take 2.5 ms — the step is
+bound by the host.  A hipGraph removes the host from the loop: the step is captured ONCE (all launches of this library
+go to the capturing stream like any other; the table build's piece counts, the one value a forward normally reads
+back, stay on the device) and every further epoch is a single ``graph.replay()``.
+
+What a captured step freezes, and how it is guarded:
+* tensor ADDRESSES of the inputs, parameters and optimizer state — :meth:`GraphedStep.stale` compares the parameters'
+  addresses and the hyper-parameters before every replay; ``harness`` re-captures when it reports a change;
+* the SIZES of the shape-function tables (search depth, LDS image) — they follow the weights, which training moves;
+  the captured look-up has the same head-room as the speculative look-up of the eager path, and before every replay
+  :meth:`GraphedCallable.fits` builds the tables of the CURRENT weights eagerly (one 0.05-ms kernel and the one small
+  device->host read a forward always made) and compares: a step whose tables outgrew the capture is never replayed —
+  its optimizer update would be computed from a truncated look-up — but run eagerly and captured again;
+* the learning rate lives in a device tensor the schedulers' floats are copied into before each replay.
+Dropout in training mode is stochastic per call and is never captured (``GraphedStep.supported``).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from . import functional
+
+
+class CaptureFailed(RuntimeError):
+    pass
+
+
+class GraphedCallable:
+    """``fn()`` — no arguments, closes over static tensors — captured into a hipGraph after ``warmup`` eager runs."""
+
+    def __init__(self, fn: Callable[[], object], warmup: int = 2, before_capture: Optional[Callable[[], None]] = None):
+        dev = torch.cuda.current_device()
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):              # lazy initialisations, caches (hop-graph plans, table sizes), allocator
+                fn()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if before_capture is not None:
+            before_capture()
+        functional.CAPTURED_BUILDS.clear()
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+        except Exception as e:                   # a host synchronisation on the path, an unsupported op, ...
+            functional.CAPTURED_BUILDS.clear()
+            raise CaptureFailed(f"{type(e).__name__}: {e}") from e
+        self.builds = list(functional.CAPTURED_BUILDS)
+        functional.CAPTURED_BUILDS.clear()
+        self.replays = 0
+
+    def replay(self):
+        self.graph.replay()
+        self.replays += 1
+        return self.out
+
+    def fits(self) -> bool:
+        """Do the shape-function tables of the CURRENT weights fit the sizes the look-ups were captured with?"""
+        from . import pwl
+        for spec, stacked in self.builds:
+            tables = pwl.build_tables(stacked)
+            if tables is None or not pwl.covers(spec, tables):
+                return False
+        return True
+
+
+def _param_signature(model: torch.nn.Module):
+    ps = list(model.parameters())
+    return (len(ps), ps[0].data_ptr() if ps else 0, ps[-1].data_ptr() if ps else 0, ps[len(ps) // 2].data_ptr() if ps else 0)
+
+
+def _group_signature(optimizer):
+    return tuple(tuple(sorted((k, v) for k, v in g.items() if k not in ("params", "lr") and isinstance(v, (int, float, bool, tuple, type(None)))))
+                 for g in optimizer.param_groups)
+
+
+def _make_capturable(optimizer) -> List[torch.Tensor]:
+    """Adam-family optimizers: step counters and learning rate on the device (``capturable=True``).  Returns the static
+    learning-rate tensors, one per group (the floats schedulers write into ``group['lr']`` are copied into them)."""
+    lrs = []
+    for group in optimizer.param_groups:
+        if "capturable" not in group:
+            raise CaptureFailed(f"{type(optimizer).__name__} has no capturable mode")
+        group["capturable"] = True
+        dev = group["params"][0].device
+        lr = group["lr"]
+        static = lr if torch.is_tensor(lr) and lr.device == dev else torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        group["lr"] = static
+        lrs.append(static)
+        for p in group["params"]:
+            st = optimizer.state.get(p)
+            if st and "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
+                st["step"] = st["step"].to(p.device, torch.float32)
+    return lrs
+
+
+class GraphedStep:
+    """One captured step on fixed inputs: ``outputs = model(data)``, optionally followed by
+    ``loss = loss_of(outputs)``, ``loss.backward()``, ``optimizer.step()``.
+
+    ``loss_of(outputs) -> (loss, extras)`` must be free of host synchronisations (index with precomputed integer
+    indices, not boolean masks).  After :meth:`replay`, ``self.outputs``, ``self.loss`` and ``self.extras`` hold the
+    replay's results in static tensors."""
+
+    @staticmethod
+    def supported(model, optimizer=None) -> bool:
+        if not torch.cuda.is_available():
+            return False
+        if getattr(model, "_dropout_active", lambda: False)():
+            return False
+        return optimizer is None or all("capturable" in g for g in optimizer.param_groups)
+
+    def __init__(self, model, data, loss_of=None, optimizer=None, forward: Optional[Callable] = None, warmup: int = 2):
+        self.model, self.data, self.optimizer = model, data, optimizer
+        self.training = optimizer is not None
+        fwd = forward or (lambda: model.forward(data))
+        self.lrs = _make_capturable(optimizer) if self.training else []
+        self.outputs = self.loss = self.extras = None
+
+        def step():
+            if self.training:
+                out = fwd()
+                out = out[0] if isinstance(out, tuple) else out
+                loss, extras = loss_of(out)
+                loss.backward()
+                optimizer.step()
+                return out.detach(), loss.detach(), extras
+            with torch.no_grad():
+                out = fwd()
+                out = out[0] if isinstance(out, tuple) else out
+                loss, extras = loss_of(out) if loss_of is not None else (None, None)
+            return out, loss, extras
+
+        def eager_step():
+            if self.training:
+                optimizer.zero_grad(set_to_none=True)
+            return step()
+
+        # gradients must be None when the capture starts: the captured backward then ASSIGNS them (rewritten by every
+        # replay) instead of accumulating into the previous epoch's
+        clear = (lambda: optimizer.zero_grad(set_to_none=True)) if self.training else None
+        self.eager_step = eager_step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = GraphedCallable(step, warmup=0, before_capture=clear)
+        self.outputs, self.loss, self.extras = self.graph.out
+        self._params = _param_signature(model)
+        self._groups = _group_signature(optimizer) if self.training else None
+        self._mode = model.training
+
+    def stale(self) -> bool:
+        """Something the graph froze has changed: parameter storage (``.to()``, ``load_state_dict`` into new tensors),
+        optimizer hyper-parameters other than the learning rate, train/eval mode."""
+        if _param_signature(self.model) != self._params or self.model.training != self._mode:
+            return True
+        return self.training and _group_signature(self.optimizer) != self._groups
+
+    def replay(self):
+        """Replay the captured step; returns ``(outputs, loss, extras)`` (static tensors), or None if the step must not be
+        replayed (see :meth:`stale`, :meth:`GraphedCallable.fits`) — the caller then runs it eagerly and captures anew."""
+        if self.stale() or not self.graph.fits():
+            return None
+        for group, static in zip(self.optimizer.param_groups if self.training else [], self.lrs):
+            if group["lr"] is not static:                     # a scheduler wrote a float: keep the tensor, take the value
+                static.fill_(float(group["lr"]))
+                group["lr"] = static
+        self.graph.replay()
+        return self.outputs, self.loss, self.extras

@@ -8,11 +8,26 @@ mode (:97).  What they do differently, for the GPU: batches that already live on
 again (the reference re-uploads both N x N matrices on every call, trainer.py:46,109), losses and hit counts
 are accumulated on the device and read back once per epoch instead of one ``.item()`` sync per batch, and the
 autograd anomaly mode that wraps every reference epoch (trainer.py:24) is not switched on.
+
+Node-level tasks run the same step on the same tensors every epoch (one full-batch graph).  When the loader hands out
+ONE batch that already lives on the device — the same objects every epoch, e.g. ``[data.to(device)]`` — the third and
+every later epoch replays a hipGraph of the whole step (forward, mask, loss, backward, Adam update, hit count;
+``gnan_amd/graphed.py``) instead of re-issuing ~70 launches from Python: same arithmetic, same kernels, no host in the
+loop.  ``GNAN_GRAPHED_STEPS=0`` switches it off; anything a capture cannot hold (training-mode Dropout, an optimizer
+without a capturable mode, a loader that uploads fresh tensors per epoch) silently keeps the eager loop.
 """
 from __future__ import annotations
 
+import os
+import warnings
+import weakref
+
 import numpy as np
 import torch
+
+GRAPHED_STEPS = os.environ.get("GNAN_GRAPHED_STEPS", "1") != "0"
+GRAPH_AFTER = 2                      # eager epochs before a step is captured (they are the capture's warm-up)
+_STEPS = weakref.WeakKeyDictionary()     # model -> TensorKeyedCache of per-(data, mask, loss, optimizer) step records
 
 
 def _labels_of(data, label_index: int, loss_fn) -> torch.Tensor:
@@ -57,7 +72,83 @@ def _finish(total_loss, hits, n_batches, n_samples, classify, compute_auc, proba
     return loss, float(hits) / n_samples, auc
 
 
+def _single_resident_batch(loader, device):
+    """The loader's one batch if it is a full-batch node task whose tensors already live on ``device``, else None."""
+    try:
+        if len(loader) != 1:
+            return None
+    except TypeError:
+        return None
+    data = next(iter(loader))
+    x = getattr(data, "x", None)
+    dev = torch.device(device)
+    if not torch.is_tensor(x) or x.device.type != "cuda" or (dev.index is not None and x.device != dev):
+        return None
+    return data
+
+
+def _step_record(model, data, mask_name, label_index, loss_fn, optimizer, classify):
+    from ._cache import TensorKeyedCache
+    cache = _STEPS.get(model)
+    if cache is None:
+        cache = _STEPS[model] = TensorKeyedCache(8)
+    src = (data.x, getattr(data, mask_name), data.y)
+    extra = (mask_name, int(label_index), bool(classify), optimizer is None)
+    rec = cache.get(src, extra)
+    if (rec is None or rec["loss_fn"]() is not loss_fn
+            or (optimizer is not None and (rec["optimizer"] is None or rec["optimizer"]() is not optimizer))):
+        rec = cache.put(src, extra, {"calls": 0, "step": None, "dead": False, "loss_fn": weakref.ref(loss_fn),
+                                     "optimizer": None if optimizer is None else weakref.ref(optimizer)})
+    return rec
+
+
+def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compute_auc, mask_name):
+    """One epoch of a full-batch node task through a captured step; None if this epoch has to run eagerly."""
+    from .graphed import CaptureFailed, GraphedStep
+    if not GraphedStep.supported(model, optimizer):
+        return None
+    rec = _step_record(model, data, mask_name, label_index, loss_fn, optimizer, classify)
+    if rec["dead"]:
+        return None
+    if rec["step"] is None:
+        if rec["calls"] < GRAPH_AFTER:
+            rec["calls"] += 1
+            return None
+        labels = _labels_of(data, label_index, loss_fn).to(data.x.device)
+        idx = getattr(data, mask_name).nonzero().flatten()           # integer indices: a boolean mask would synchronise
+        labels_m = labels[idx]
+
+        def loss_of(outputs):
+            picked = outputs.index_select(0, idx)
+            loss = _loss_of(loss_fn, picked, labels_m)
+            hits = _hits(picked.detach(), labels_m) if classify else None
+            return loss, (hits, picked.detach())
+        try:
+            rec["step"] = GraphedStep(model, data, loss_of, optimizer, warmup=0)
+            rec["labels"] = labels_m
+        except CaptureFailed as e:
+            rec["dead"] = True
+            warnings.warn(f"gnan_amd: the step could not be captured into a hipGraph ({e}); staying on the eager loop")
+            return None
+    got = rec["step"].replay()
+    if got is None:                       # parameters moved, hyper-parameters changed or the tables outgrew the capture
+        rec["step"], rec["calls"] = None, GRAPH_AFTER
+        return None
+    _, loss, (hits, picked) = got
+    probas = targets = None
+    if compute_auc:
+        probas = [torch.sigmoid(picked).reshape(-1).cpu().numpy()]
+        targets = [rec["labels"].cpu().numpy()]
+    return _finish(loss, hits if classify else 0, 1, int(rec["labels"].numel()), classify, compute_auc, probas, targets)
+
+
 def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compute_auc, mask_name, is_graph_task):
+    if GRAPHED_STEPS and not is_graph_task and (optimizer is not None or not torch.is_grad_enabled()):
+        data = _single_resident_batch(loader, device)
+        if data is not None:
+            done = _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compute_auc, mask_name)
+            if done is not None:
+                return done
     total_loss = torch.zeros((), device=device)
     hits = torch.zeros((), device=device)
     n_samples, probas, targets = 0, [], []

@@ -247,6 +247,10 @@ def _build_tables_hip(p, lazy: bool = False):
                           slope=_lib.ptr(slope), off=_lib.ptr(meta), overflow=meta[F + 1:].data_ptr(),
                           scratch=_lib.ptr(scratch), scratch_bytes=scratch.numel() * 8)
     _lib.check(_lib.lib().gnan_pwl_build(a, _lib.stream_of(anchor)), "gnan_pwl_build")
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture nothing may wait for the device: no read-back.  Whoever replays the graph checks
+        # BEFORE each replay (an eager build of the same weights) that the tables still fit the captured look-up
+        return _PendingTables(meta, None, None, anchor, val, slope, F, C, (dev, F, p.L, p.H, C), keepalive + [scratch])
     # the ONE device->host copy of the build: into a cached pinned buffer, asynchronously; an event marks its arrival
     pinned = _pinned_meta(dev, F + 2)
     pinned.copy_(meta, non_blocking=True)

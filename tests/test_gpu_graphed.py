@@ -1,0 +1,139 @@
+"""hipGraph replay of whole training / evaluation steps (gnan_amd/graphed.py, harness): same numbers as the eager loop."""
+import copy
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class Bag:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def to(self, device):
+        return self
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+
+
+def _node_task(n, F, C, dense, seed=0):
+    from gnan_amd import HopGraph, synthetic as syn
+    from oracle import gnan_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, F, generator=g)
+    x[:, -1] = 1.0
+    y = torch.randint(0, max(C, 2), (n,), generator=g)
+    masks = torch.rand(n, generator=g)
+    data = Bag(x=x.to(DEV), y=y.to(DEV), edge_index=None, train_mask=(masks < 0.6).to(DEV),
+               val_mask=((masks >= 0.6) & (masks < 0.8)).to(DEV), test_mask=(masks >= 0.8).to(DEV))
+    if dense:
+        ei = np.stack([np.random.default_rng(seed).integers(0, n, 3 * n), np.random.default_rng(seed + 1).integers(0, n, 3 * n)])
+        nd, norm = O.pre_process_dense(np.concatenate([ei, ei[::-1]], axis=1), n)
+        data.node_distances, data.normalization_matrix = nd.to(DEV), norm.to(DEV)
+    else:
+        src, dst = syn.uniform_edges(n, 6 * n, seed, DEV)
+        data.gnan_graph = syn.hop1_csr(src, dst, n)
+    return data
+
+
+def _model(F, C, seed=0):
+    from gnan_amd.models import TensorGNAN
+    torch.manual_seed(seed)
+    m = TensorGNAN(F, C, 3, hidden_channels=32, device=DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 2:
+                torch.nn.init.xavier_normal_(p, gain=1.0)
+            else:
+                p.normal_(0.0, 0.3)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("n,F,C,dense,loss", [(3000, 129, 1, False, "BCEWithLogitsLoss"), (300, 9, 4, True, "CrossEntropyLoss"),
+                                              (2500, 120, 3, False, "CrossEntropyLoss")])
+def test_graphed_epochs_match_eager_epochs(n, F, C, dense, loss, monkeypatch):
+    """Eight epochs of harness.train_epoch / test_epoch on a full-batch node task: with hipGraph replay (from the third
+    epoch on) and without — same losses, accuracies and final parameters."""
+    _need_gpu()
+    from gnan_amd import harness
+    data = _node_task(n, F, C, dense)
+    loss_fn = getattr(torch.nn, loss)()
+    runs = {}
+    for tag, on in (("eager", False), ("graphed", True)):
+        monkeypatch.setattr(harness, "GRAPHED_STEPS", on)
+        m = _model(F, C)
+        opt = torch.optim.Adam(m.parameters(), lr=3e-3, weight_decay=1e-4)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=3, gamma=0.5)       # the learning rate moves between replays
+        hist = []
+        for epoch in range(8):
+            tr = harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, compute_auc=False, is_graph_task=False)
+            te = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, compute_auc=(loss == "BCEWithLogitsLoss"),
+                                    val_mask=True, is_graph_task=False)
+            sched.step()
+            hist.append(list(tr) + list(te))
+        runs[tag] = (np.array(hist, dtype=np.float64), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+        if on:
+            recs = [r for r in harness._STEPS[m].entries.values()]
+            assert any(r.value["step"] is not None and r.value["step"].graph.replays >= 5 for r in recs), "nothing was replayed"
+    a, b = runs["eager"], runs["graphed"]
+    assert a[0].shape == b[0].shape
+    assert np.allclose(a[0], b[0], rtol=2e-4, atol=1e-6), np.abs(a[0] - b[0]).max()
+    scale = max(float(v.abs().max()) for v in a[1].values())
+    for k in a[1]:
+        assert float((a[1][k] - b[1][k]).abs().max()) <= 2e-4 * scale, k
+
+
+def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
+    _need_gpu()
+    from gnan_amd import harness, pwl
+    data = _node_task(3000, 129, 1, False)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    m = _model(129, 1)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for _ in range(4):
+        harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)
+    rec = [r.value for r in harness._STEPS[m].entries.values() if r.value["optimizer"] is not None][0]
+    first = rec["step"]
+    assert first is not None and first.graph.replays == 2
+    real = pwl.covers
+    calls = {"n": 0}
+
+    def covers_once_false(spec, exact):
+        calls["n"] += 1
+        return False if calls["n"] == 1 else real(spec, exact)
+    monkeypatch.setattr(pwl, "covers", covers_once_false)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)      # eager: the capture is dropped
+    assert rec["step"] is None and first.graph.replays == 2
+    assert any(not torch.equal(before[k], v) for k, v in m.state_dict().items())                # ... and the step still happened
+    harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)      # captured anew and replayed
+    assert rec["step"] is not None and rec["step"] is not first and rec["step"].graph.replays == 1
+
+
+def test_moved_parameters_invalidate_the_capture(monkeypatch):
+    _need_gpu()
+    from gnan_amd import harness
+    data = _node_task(3000, 129, 1, False)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    m = _model(129, 1)
+    for _ in range(4):
+        out = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+    rec = [r.value for r in harness._STEPS[m].entries.values()][0]
+    assert rec["step"] is not None and rec["step"].graph.replays == 2
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)                                   # in place: the graph reads the new values
+    changed = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+    assert rec["step"].graph.replays == 3 and abs(changed[0] - out[0]) > 1e-6
+    m.double().float()                                    # re-homes every parameter: new storage
+    again = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+    assert rec["step"] is None and abs(again[0] - changed[0]) <= 1e-5 * max(1.0, abs(changed[0]))
