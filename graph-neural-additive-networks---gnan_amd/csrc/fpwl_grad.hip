@@ -283,8 +283,10 @@ __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
 // non-negative floats (their order is the order of the values; a NaN ends up on top and poisons the scales, as it would
 // poison the sums).
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, int64_t n, int width, int64_t stride,
-                                                     const float* __restrict__ anchor, int64_t T, unsigned* bits) {
+                                                     const float* __restrict__ anchor, int64_t T, const int32_t* off_end,
+                                                     unsigned* bits) {
   const int64_t total = n * width;
+  if (off_end && *off_end < T) T = *off_end;       // tables held in a buffer of full capacity: only off[F] anchors are real
   float m = 0.f, ma = 0.f;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
     const float v = fabsf(width == stride ? g[e] : g[(e / width) * stride + e % width]);
@@ -305,6 +307,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
     if (ua) atomicMax(bits + 1, ua);
   }
 }
+
+// (a kernel, not hipMemsetAsync: inside a hipGraph capture the 8-byte memset was not replayed with the graph — measured:
+// the bits kept whatever a later tenant of the block had left there, the scales collapsed and every gradient came out 0)
+__global__ void zero_bits_kernel(unsigned* bits) { bits[0] = bits[1] = 0u; }
 
 __global__ void scales_kernel(const unsigned* bits, const double* x_abs_max, int nbits, double* scales) {
   const float gf = __uint_as_float(bits[0]), af = __uint_as_float(bits[1]);
@@ -355,7 +361,7 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
 }
 
 extern "C" int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
-                                       int64_t T, const double* x_abs_max, int32_t bits, void* workspace,
+                                       int64_t T, const int32_t* n_anchors, const double* x_abs_max, int32_t bits, void* workspace,
                                        size_t workspace_bytes, double* scales, gnan_stream_t stream) {
   GNAN_REQUIRE(n >= 0 && width >= 1 && grad_stride >= width && T >= 0, "fpwl_moment_scales: bad sizes");
   GNAN_REQUIRE((grad || n == 0) && (anchor || T == 0) && x_abs_max && scales, "fpwl_moment_scales: null pointer");
@@ -363,12 +369,12 @@ extern "C" int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t wid
   GNAN_REQUIRE(bits >= 1 && bits <= 62, "fpwl_moment_scales: bits must be in [1, 62]");
   hipStream_t st = static_cast<hipStream_t>(stream);
   unsigned* b = static_cast<unsigned*>(workspace);
-  hipError_t e = hipMemsetAsync(b, 0, 2 * sizeof(unsigned), st);
-  if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl_moment_scales: hipMemsetAsync: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(zero_bits_kernel, dim3(1), dim3(1), 0, st, b);
+  if (int rc = gnan::check_launch("zero_bits_kernel")) return rc;
   const int64_t work = n * width > T ? n * width : T;
   int64_t blocks = (work + 256 * 8 - 1) / (256 * 8);
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  hipLaunchKernelGGL(absmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad, n, width, grad_stride, anchor, T, b);
+  hipLaunchKernelGGL(absmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad, n, width, grad_stride, anchor, T, n_anchors, b);
   if (int rc = gnan::check_launch("absmax_kernel")) return rc;
   hipLaunchKernelGGL(scales_kernel, dim3(1), dim3(1), 0, st, b, x_abs_max, bits, scales);
   return gnan::check_launch("scales_kernel");

@@ -166,8 +166,9 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
         # scales[0] = 2^floor(bits - log2 max|grad|), scales[1] = 2^floor(bits - log2(max|grad| max|x - anchor|)):
         # one pass over the gradient on the device (gnan_fpwl_moment_scales), no host round trip
         scales = torch.empty(3, dtype=torch.float64, device=x.device)        # [2] scales | 8 bytes of workspace
+        # (tables captured into a hipGraph sit in a buffer of full capacity: only the first off[F] anchors are real)
         _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(grad), n, grad.shape[1], grad.stride(0), _lib.ptr(t.anchor),
-                                                      T, _lib.ptr(x_abs_max), bits, _lib.ptr(scales[2:]), 8,
+                                                      T, _lib.ptr(t.off[F:]), _lib.ptr(x_abs_max), bits, _lib.ptr(scales[2:]), 8,
                                                       _lib.ptr(scales), _lib.stream_of(x)), "gnan_fpwl_moment_scales")
         scales = scales[:2]
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)

@@ -24,7 +24,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from . import functional
+from . import _lib, functional
 
 
 class CaptureFailed(RuntimeError):
@@ -47,10 +47,18 @@ class GraphedCallable:
         if before_capture is not None:
             before_capture()
         functional.CAPTURED_BUILDS.clear()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         try:
             with torch.cuda.graph(self.graph):
                 self.out = fn()
+            # a captured hipMemsetAsync replays correctly only once on this ROCm (csrc/graph_fix.hip); the framework's
+            # multi-block reductions (a loss's mean, a column sum) zero their semaphores with one: swap the nodes for kernels
+            import ctypes
+            swapped = ctypes.c_int32(0)
+            _lib.check(_lib.lib().gnan_graph_replace_memsets(self.graph.raw_cuda_graph(), ctypes.byref(swapped)),
+                       "gnan_graph_replace_memsets")
+            self.memsets_replaced = int(swapped.value)
+            self.graph.instantiate()
         except Exception as e:                   # a host synchronisation on the path, an unsupported op, ...
             functional.CAPTURED_BUILDS.clear()
             raise CaptureFailed(f"{type(e).__name__}: {e}") from e
@@ -73,9 +81,11 @@ class GraphedCallable:
         return True
 
 
-def _param_signature(model: torch.nn.Module):
+def _probe_params(model: torch.nn.Module):
+    """A few Parameter objects whose storage addresses stand for the whole module's (``.to()`` and ``FlatMLPStore.rebuild``
+    move all of them together); walking all F x L parameters before every replay would cost more than the replay."""
     ps = list(model.parameters())
-    return (len(ps), ps[0].data_ptr() if ps else 0, ps[-1].data_ptr() if ps else 0, ps[len(ps) // 2].data_ptr() if ps else 0)
+    return [ps[i] for i in sorted({0, len(ps) // 3, len(ps) // 2, (2 * len(ps)) // 3, len(ps) - 1})] if ps else []
 
 
 def _group_signature(optimizer):
@@ -91,6 +101,11 @@ def _make_capturable(optimizer) -> List[torch.Tensor]:
         if "capturable" not in group:
             raise CaptureFailed(f"{type(optimizer).__name__} has no capturable mode")
         group["capturable"] = True
+        if "fused" in group and all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
+            # F x L small parameter tensors (774 on the arxiv shape): the for-each implementation needs ~15 launches per
+            # 30 tensors and falls back to one launch per tensor for the operations that take the learning-rate TENSOR
+            # (1300 launches, 4 ms per replayed step); the fused kernel updates 36 tensors per launch in one pass
+            group["fused"], group["foreach"] = True, False
         dev = group["params"][0].device
         lr = group["lr"]
         static = lr if torch.is_tensor(lr) and lr.device == dev else torch.tensor(float(lr), dtype=torch.float32, device=dev)
@@ -157,14 +172,15 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = GraphedCallable(step, warmup=0, before_capture=clear)
         self.outputs, self.loss, self.extras = self.graph.out
-        self._params = _param_signature(model)
+        self._probes = _probe_params(model)
+        self._params = [p.data_ptr() for p in self._probes]
         self._groups = _group_signature(optimizer) if self.training else None
         self._mode = model.training
 
     def stale(self) -> bool:
         """Something the graph froze has changed: parameter storage (``.to()``, ``load_state_dict`` into new tensors),
         optimizer hyper-parameters other than the learning rate, train/eval mode."""
-        if _param_signature(self.model) != self._params or self.model.training != self._mode:
+        if [p.data_ptr() for p in self._probes] != self._params or self.model.training != self._mode:
             return True
         return self.training and _group_signature(self.optimizer) != self._groups
 

@@ -176,11 +176,14 @@ int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t 
 
 /* The two scales of gnan_fpwl_moments_fixed, computed on the device:
  *   scales[0] = 2^floor(bits - log2(max|grad|)),  scales[1] = 2^floor(bits - log2(max|grad| * (x_abs_max + max|anchor|)))
- * (exponents clamped to +-1000) with grad [n, width] (row stride grad_stride), anchor [T], x_abs_max one double in
- * DEVICE memory (max |x| of the feature matrix) and bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits.
+ * (exponents clamped to +-1000) with grad [n, width] (row stride grad_stride), anchor [T] — of which only the first
+ * *n_anchors are read when n_anchors (one int32 in DEVICE memory, e.g. &off[F] of tables held in a buffer of full
+ * capacity) is not NULL —, x_abs_max one double in DEVICE memory (max |x| of the feature matrix) and
+ * bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits.
  * workspace: 8 bytes.  One pass over grad + a single-thread kernel; no host round trip. */
 int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
-                            int64_t T, const double* x_abs_max, int32_t bits, void* workspace, size_t workspace_bytes,
+                            int64_t T, const int32_t* n_anchors, const double* x_abs_max, int32_t bits, void* workspace,
+                            size_t workspace_bytes,
                             double* scales, gnan_stream_t stream);
 
 /* Parameter gradients of the shape functions from the per-piece moments — the last step of the table path's backward
@@ -405,6 +408,16 @@ int gnan_bfs_khop(const void* rowptr, int32_t rowptr_is64, const int32_t* col, i
                   const int64_t* out_rowptr, int32_t* out_col, uint8_t* out_code, int32_t queue_cap,
                   int32_t n_workgroups, int32_t* status /* [1] */, void* workspace, size_t workspace_bytes,
                   gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * hipGraph hygiene for captured steps (gnan_amd/graphed.py; nothing comparable in the reference, which issues every
+ * epoch's launches from Python, trainer.py:23-86).  `graph` is a hipGraph_t obtained by stream capture and not yet
+ * instantiated: every memset node is replaced by a kernel node performing the same fill, with the same dependencies
+ * and dependents.  On ROCm 7.2 a captured hipMemsetAsync replays correctly only once (garbage fill values afterwards);
+ * the framework's multi-block reductions zero their semaphores that way.  *n_replaced (optional, host memory) receives
+ * the number of nodes swapped.
+ * ------------------------------------------------------------------------------------------- */
+int gnan_graph_replace_memsets(void* graph, int32_t* n_replaced);
 
 #ifdef __cplusplus
 }

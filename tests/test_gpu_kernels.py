@@ -516,8 +516,10 @@ def test_moment_scales_kernel(n, width, gscale):
     xmax = torch.tensor(3.25, dtype=torch.float64, device=DEV)
     bits = 61 - max(1, (max(n, 2) - 1).bit_length())
     out = torch.empty(3, dtype=torch.float64, device=DEV)
-    _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(g), n, width, g.stride(0), _lib.ptr(anchor), anchor.numel(),
-                                                  _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
+    padded = torch.cat([anchor, torch.full((50,), float("inf"), device=DEV)])     # a buffer of full capacity: the tail is not data
+    n_real = torch.tensor([anchor.numel()], dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(g), n, width, g.stride(0), _lib.ptr(padded), padded.numel(),
+                                                  _lib.ptr(n_real), _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
                                                   _lib.stream_of(g)), "gnan_fpwl_moment_scales")
     tiny = torch.finfo(torch.float64).tiny
     g_max = g.abs().max().double().clamp_min(tiny)
@@ -528,7 +530,7 @@ def test_moment_scales_kernel(n, width, gscale):
     gn = g.clone()
     gn[n // 2, 0] = float("nan")
     _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(gn), n, width, gn.stride(0), _lib.ptr(anchor), anchor.numel(),
-                                                  _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
+                                                  None, _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
                                                   _lib.stream_of(g)), "gnan_fpwl_moment_scales")
     assert bool(torch.isnan(out[:2]).all())
 

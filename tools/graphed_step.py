@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Full-batch node-task training epochs through the harness: eager loop vs hipGraph replay (BASELINE config 3 shape and
+the Cora shape).  Prints one JSON line per configuration: ms per epoch (train step incl. Adam; evaluation pass)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import microbench as mb  # noqa: E402
+from gnan_amd import harness  # noqa: E402
+
+DEV = "cuda"
+
+
+class Data(mb.Bag):
+    def to(self, device):
+        return self
+
+
+def arxiv_shaped(C=1):
+    N, E, F = 169_343, 1_166_243, 129
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    src = torch.randint(0, N, (E,), generator=gen, device=DEV)
+    dst = (torch.rand(E, generator=gen, device=DEV) ** 3 * N).long().clamp_(0, N - 1)
+    d = Data(x=mb.syn.block_features(N, F, 0, N, 1, DEV), edge_index=None, gnan_graph=mb.syn.hop1_csr(src, dst, N))
+    return d, N, F, C
+
+
+def cora_shaped():
+    rng = np.random.default_rng(0)
+    n, F, C = 2708, 1434, 7
+    ei, (nd, norm) = mb.dense_graph(n, 3.9, rng)
+    x = torch.rand(n, F)
+    x = x / x.sum(1, keepdim=True)
+    x[:, -1] = 1
+    return Data(x=x.to(DEV), edge_index=None, node_distances=nd.to(DEV), normalization_matrix=norm.to(DEV)), n, F, C
+
+
+def run(name, make):
+    d, n, F, C = make()
+    g = torch.Generator().manual_seed(1)
+    d.y = torch.randint(0, max(C, 2), (n,), generator=g).to(DEV)
+    r = torch.rand(n, generator=g)
+    d.train_mask, d.val_mask, d.test_mask = (r < 0.6).to(DEV), ((r >= 0.6) & (r < 0.8)).to(DEV), (r >= 0.8).to(DEV)
+    loss_fn = torch.nn.BCEWithLogitsLoss() if C == 1 else torch.nn.CrossEntropyLoss()
+    out = {"what": name, "nodes": n, "features": F, "channels": C}
+    for tag, on in (("eager", False), ("graphed", True)):
+        harness.GRAPHED_STEPS = on
+        torch.manual_seed(0)
+        m = mb.TensorGNAN(F, C, 3, hidden_channels=64, device=DEV)
+        mb.redraw(m)
+        m = m.to(DEV).eval()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        tr = lambda: harness.train_epoch(m, [d], loss_fn, opt, DEV, classify=True, is_graph_task=False)
+        te = lambda: harness.test_epoch(m, [d], loss_fn, DEV, classify=True, val_mask=True, is_graph_task=False)
+        out[tag + "_train_ms"] = mb.timeit(tr, reps=30, warm=5)
+        out[tag + "_eval_ms"] = mb.timeit(te, reps=30, warm=5)
+        out[tag + "_last_loss"] = tr()[0]
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["arxiv", "arxiv40", "cora"]
+    if "arxiv" in which:
+        run("arxiv_shaped_C1", lambda: arxiv_shaped(1))
+    if "arxiv40" in which:
+        run("arxiv_shaped_C40", lambda: arxiv_shaped(40))
+    if "cora" in which:
+        run("cora_shaped", cora_shaped)
