@@ -531,6 +531,7 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
 FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum over features in its epilogue
 DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
 DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
+NARROW_ROW_SLICING = os.environ.get("GNAN_NARROW_ROW_SLICING", "1") != "0"   # A/B switch of LONG_ROW_THRESHOLD_NARROW
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
 
 
@@ -572,7 +573,8 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
             row_ids, plan = g.degree_schedule()      # process rows by degree, store them in place
             scatter = True
     else:
-        plan = g.long_row_plan(row_ids)
+        narrow = S.shape[1] * S.element_size() <= 8        # one or two lanes per row: see LONG_ROW_THRESHOLD_NARROW
+        plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING and row_ids is None) else g.long_row_plan(row_ids)
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
                    reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)

@@ -24,6 +24,9 @@ import torch
 from . import _lib
 
 LONG_ROW_THRESHOLD = 512   # rows with more listed pairs than this go through the slice kernel
+LONG_ROW_THRESHOLD_NARROW = 64   # ... for operand rows of one or two lanes: a single LANE walks such a row, and the few rows
+                                 # of a few hundred pairs set the kernel's duration (arxiv-shaped backward: 127 -> 25 us)
+NARROW_PLAN_MAX_ROWS = 8192
 SLICE_EDGES = 2048         # pairs per slice of a hub row
 
 
@@ -52,6 +55,7 @@ class HopGraph:
     _degree_order: Optional[torch.Tensor] = field(default=None, repr=False)
     _degree_plan: Optional[LongRowPlan] = field(default=None, repr=False)
     _dense_plans: dict = field(default_factory=dict, repr=False)
+    _plans: dict = field(default_factory=dict, repr=False)          # hub-row plans by threshold (other than the default)
     _sorted_copy: Optional["HopGraph"] = field(default=None, repr=False)
     _inv_rest: Optional[torch.Tensor] = field(default=None, repr=False)
     _cnt_by_col: bool = field(default=False, repr=False)     # transposed graphs: ``cnt`` rows belong to the neighbours
@@ -193,27 +197,40 @@ class HopGraph:
         return HopGraph(n_rows=n, n_cols=n, n_codes=D, code=code, cnt=cnt)
 
     # ------------------------------------------------------------------ derived structures
-    def long_row_plan(self, row_ids: Optional[torch.Tensor] = None) -> LongRowPlan:
-        """Hub rows and their slices; cached for the identity row order."""
+    def long_row_plan(self, row_ids: Optional[torch.Tensor] = None, threshold: int = LONG_ROW_THRESHOLD) -> LongRowPlan:
+        """Hub rows (more than ``threshold`` listed pairs) and their slices; cached for the identity row order."""
         if self.is_dense:
             return LongRowPlan(None, None)
-        if row_ids is None and self._plan is not None:
-            return self._plan
+        if row_ids is None:
+            if threshold == LONG_ROW_THRESHOLD and self._plan is not None:
+                return self._plan
+            if threshold in self._plans:
+                return self._plans[threshold]
         deg = (self.rowptr[1:] - self.rowptr[:-1])
         if row_ids is not None:
             deg = deg[row_ids.long()]
-        long_rows = torch.nonzero(deg > LONG_ROW_THRESHOLD).flatten()
+        long_rows = torch.nonzero(deg > threshold).flatten()
         n_long = int(long_rows.numel())
         if n_long == 0:
-            plan = LongRowPlan(None, None)
+            plan = LongRowPlan(None, None, threshold=threshold)
         else:
             n_sl = (deg[long_rows] + SLICE_EDGES - 1) // SLICE_EDGES
             ptr = torch.zeros(n_long + 1, dtype=torch.int64, device=self.device)
             ptr[1:] = torch.cumsum(n_sl, 0)
-            plan = LongRowPlan(long_rows.to(torch.int32), ptr.to(torch.int32), n_long, int(ptr[-1]))
+            plan = LongRowPlan(long_rows.to(torch.int32), ptr.to(torch.int32), n_long, int(ptr[-1]), threshold=threshold)
         if row_ids is None:
-            self._plan = plan
+            if threshold == LONG_ROW_THRESHOLD:
+                self._plan = plan
+            else:
+                self._plans[threshold] = plan
         return plan
+
+    def narrow_row_plan(self) -> LongRowPlan:
+        """Hub-row plan for operand rows of one or two lanes: the low threshold while only a FEW rows exceed it (the tail
+        of a skewed graph, which a single lane per row would serialise) — with many such rows (R-MAT 10M/100M: hundreds of
+        thousands) a workgroup per row costs more than the tail (1.88 -> 2.51 ms), so they stay with the default plan."""
+        plan = self.long_row_plan(None, LONG_ROW_THRESHOLD_NARROW)
+        return plan if plan.n_long <= NARROW_PLAN_MAX_ROWS else self.long_row_plan()
 
     def dense_slice_plan(self, n_out: int) -> LongRowPlan:
         """Dense layout with few output rows: cut EVERY row into column slices, one workgroup each (a dense row has

@@ -187,7 +187,8 @@ def train_epoch(model, dloader, loss_fn, optimizer, device, classify=True, label
 def test_epoch(model, dloader, loss_fn, device, classify=True, label_index=0, compute_auc=False, val_mask=False,
                is_graph_task=True):
     """One evaluation pass — same signature and return value as trainer.py:89-154 (leaves ``model.eval()`` on)."""
-    model.eval()
+    if model.training:               # trainer.py:97; walking the F x L sub-modules again costs 10 ms on the Cora shape
+        model.eval()
     with torch.no_grad():
         return _run(model, dloader, loss_fn, device, None, classify, label_index, compute_auc,
                     "val_mask" if val_mask else "test_mask", is_graph_task)

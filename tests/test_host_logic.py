@@ -230,3 +230,17 @@ def test_rest_bucket_total_over_the_first_rows_only(cpu_kernels):
     assert O.rel_err(Y.detach(), want.detach()) <= 1e-5
     dS64, dlut64 = torch.autograd.grad(want, [S64, lut64], up.double())
     assert O.rel_err(dS, dS64) <= 1e-5 and O.rel_err(dlut, dlut64) <= 1e-5
+
+
+def test_narrow_row_plan_takes_the_low_threshold_only_for_a_short_tail(monkeypatch):
+    from gnan_amd import graph as G
+    rng = np.random.default_rng(11)
+    n = 300
+    rowptr, col, code = _csr(n, n, 1, rng, hubs=[(5, 100), (9, 700), (200, 65)])
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(code), n_cols=n, n_codes=3)
+    default, narrow = g.long_row_plan(), g.narrow_row_plan()
+    assert default.n_long == 1 and default.threshold == G.LONG_ROW_THRESHOLD and int(default.rows[0]) == 9
+    assert narrow.n_long == 3 and narrow.threshold == G.LONG_ROW_THRESHOLD_NARROW and narrow.rows.tolist() == [5, 9, 200]
+    assert narrow.slice_ptr.tolist() == [0, 1, 2, 3] and g.narrow_row_plan() is narrow and g.long_row_plan() is default
+    monkeypatch.setattr(G, "NARROW_PLAN_MAX_ROWS", 2)                   # "many" rows above the low threshold: default plan
+    assert g.narrow_row_plan() is default
