@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -77,7 +77,7 @@ class FpwlGradArgs(C.Structure):
         ("scales", C.c_void_p),
         ("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
         ("w_last", C.c_void_p), ("b_last", C.c_void_p),
-        ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32),
+        ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("max_pieces", C.c_int32),
         ("d_w_first", C.c_void_p), ("d_b_first", C.c_void_p), ("d_w_mid", C.c_void_p), ("d_b_mid", C.c_void_p),
         ("d_w_last", C.c_void_p), ("d_b_last", C.c_void_p),
     ]

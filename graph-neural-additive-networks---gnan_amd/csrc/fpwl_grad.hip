@@ -75,8 +75,14 @@ __device__ __forceinline__ void piece_points(const float* A, int li, int P, doub
   else *xi = 0.5 * (*a + static_cast<double>(A[li + 1]));
 }
 
-// ---- L == 3, H <= 64: thread (j, ib) = (unit of layer 2, quarter of the layer-1 units) -------------------------------
-__global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
+// ---- L == 3, H <= 64: NG groups of 256 threads walk the pieces NG at a time; in a group thread (j, ib) = (unit of
+// layer 2, quarter of the layer-1 units).  One group per workgroup needed 110 us on the arxiv shape (129 features x ~130
+// pieces, two barriers per piece, 129 workgroups on 256 CUs); four groups share the weights in LDS and a piece's
+// latency: 110 -> ~35 us.  The groups' accumulators meet in LDS in group order (fixed order: bit-reproducible).
+// CQ = ceil(C / 4) channel accumulators per thread: a template parameter so that the common one-channel case does not pay
+// 32 registers for them (1024 threads leave 128 VGPRs per lane; with CQ = 16 the kernel spilled 120 of them).
+template <int kNG, int CQ>
+__global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int H = p.H, C = p.C, HS = H + 1;
   float* w1 = reinterpret_cast<float*>(smem_raw);
@@ -84,52 +90,82 @@ __global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
   float* b2 = b1 + H;
   float* W2s = b2 + H;                 // [H][HS]: W2[j][i], padded rows (column reads in the W2^T products)
   float* Wl = W2s + H * HS;            // [C][H]
-  double* h1i = reinterpret_cast<double*>(smem_raw + (((3 * H + H * HS + C * H) * sizeof(float) + 7) & ~size_t(7)));
+  double* vec = reinterpret_cast<double*>(smem_raw + (((3 * H + H * HS + C * H) * sizeof(float) + 7) & ~size_t(7)));
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int grp = tid >> 8, lt = tid & 255;
+  double* h1i = vec + grp * (5 * H + 2 * C);      // per group: h1i | h1a | h1p | e0 | e1 | Mv[2C]
   double* h1a = h1i + H;
   double* h1p = h1a + H;
   double* e0 = h1p + H;
   double* e1 = e0 + H;
-  double* Mv = e1 + H;                 // [2C]
-  const int tid = threadIdx.x, k = blockIdx.x;
-  const int j = tid >> 2, ib = tid & 3;
+  double* Mv = e1 + H;
+  double* red = vec + kNG * (5 * H + 2 * C);      // [256]: one accumulator of every thread of a group at a time
+  int* live = reinterpret_cast<int*>(red + 256);  // [P]: the pieces that hold at least one node, ascending
+  __shared__ int n_live;
+  const int j = lt >> 2, ib = lt & 3;
   const int BI = (H + 3) >> 2;
   const int64_t kH = static_cast<int64_t>(k) * H;
 
-  for (int i = tid; i < H; i += 256) {
+  for (int i = tid; i < H; i += 256 * kNG) {
     w1[i] = p.w1[kH + i];
     b1[i] = p.b1 ? p.b1[kH + i] : 0.f;
     b2[i] = p.b2 ? p.b2[kH + i] : 0.f;
   }
-  for (int i = tid; i < H * H; i += 256) W2s[(i / H) * HS + i % H] = p.W2[kH * H + i];
-  for (int i = tid; i < C * H; i += 256) Wl[i] = p.Wl[kH * C + i];
+  for (int i = tid; i < H * H; i += 256 * kNG) W2s[(i / H) * HS + i % H] = p.W2[kH * H + i];
+  for (int i = tid; i < C * H; i += 256 * kNG) Wl[i] = p.Wl[kH * C + i];
   float w2r[kBI];
 #pragma unroll
   for (int r = 0; r < kBI; ++r) {
     const int i = ib * BI + r;
     w2r[r] = (j < H && r < BI && i < H) ? p.W2[(kH + j) * H + i] : 0.f;
   }
-  double dW2[kBI], dW3[kBI];
+  double dW2[kBI], dW3[CQ];
 #pragma unroll
-  for (int r = 0; r < kBI; ++r) dW2[r] = dW3[r] = 0.0;
+  for (int r = 0; r < kBI; ++r) dW2[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < CQ; ++r) dW3[r] = 0.0;
   double db2 = 0.0, dw1 = 0.0, db1 = 0.0, db3 = 0.0;
   const int base = p.off[k], P = p.off[k + 1] - base;
   const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
+  // Most pieces hold no node (the kinks of a feature spread far beyond the range of its values): list the others first —
+  // one parallel pass over the moments instead of a dependent global read and a barrier per piece (the kernel spent its
+  // time there: 110 us on the arxiv shape with ~130 pieces of which ~25 are live)
+  for (int li = tid; li < P; li += 256 * kNG) {
+    bool nz = false;
+    double unused;
+    for (int c2 = 0; c2 < 2 * C; ++c2) nz |= piece_moment(p, base + li, c2, inv0, inv1, &unused);
+    live[li] = nz ? 1 : 0;
+  }
   __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int li = 0; li < P; ++li)
+      if (live[li]) live[n++] = li;                 // in place: n <= li
+    n_live = n;
+  }
+  __syncthreads();
+  const int nl = n_live;
+  double mval = 0.0;                                // this thread's moment of the group's NEXT piece, requested a round ahead
+  if (grp < nl && lt < 2 * C) piece_moment(p, base + live[grp], lt, inv0, inv1, &mval);
 
-  for (int li = 0; li < P; ++li) {
-    double mval = 0.0;
-    const bool mine = tid < 2 * C && piece_moment(p, base + li, tid, inv0, inv1, &mval);
-    if (!__syncthreads_or(mine)) continue;          // no node fell into this piece (also the barrier of the LDS vectors)
-    double a, xi;
-    piece_points(p.anchor + base, li, P, &a, &xi);
-    if (tid < 2 * C) Mv[tid] = mval;
-    if (tid < H) {
-      const double wv = static_cast<double>(w1[tid]), bv = static_cast<double>(b1[tid]);
+  for (int l0 = 0; l0 < nl; l0 += kNG) {
+    const int at = l0 + grp;                        // this group's piece of the round (a group beyond the list: zeros)
+    const int li = at < nl ? live[at] : -1;
+    __syncthreads();                                // the previous round's readers of the LDS vectors are done
+    double a = 0.0, xi = 0.0;
+    if (li >= 0) piece_points(p.anchor + base, li, P, &a, &xi);
+    if (lt < 2 * C) {
+      Mv[lt] = li >= 0 ? mval : 0.0;
+      mval = 0.0;
+      if (at + kNG < nl) piece_moment(p, base + live[at + kNG], lt, inv0, inv1, &mval);
+    }
+    if (lt < H) {
+      const double wv = static_cast<double>(w1[lt]), bv = static_cast<double>(b1[lt]);
       const double z = fma(wv, xi, bv);
       const bool on = z > 0.0;
-      h1i[tid] = on ? z : 0.0;
-      h1a[tid] = on ? fma(wv, a, bv) : 0.0;
-      h1p[tid] = on ? wv : 0.0;
+      h1i[lt] = on ? z : 0.0;
+      h1a[lt] = on ? fma(wv, a, bv) : 0.0;
+      h1p[lt] = on ? wv : 0.0;
     }
     __syncthreads();
     if (j < H) {
@@ -162,7 +198,7 @@ __global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
         if (r < BI && i < H) dW2[r] = fma(e0v, h1a[i], fma(e1v, h1p[i], dW2[r]));
       }
 #pragma unroll
-      for (int r = 0; r < kBI; ++r) {
+      for (int r = 0; r < CQ; ++r) {
         const int c = ib + 4 * r;
         if (c < C) dW3[r] = fma(Mv[c], h2a, fma(Mv[C + c], h2p, dW3[r]));
       }
@@ -172,7 +208,7 @@ __global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
         e1[j] = e1v;
       }
     }
-    if (tid < C) db3 += Mv[tid];
+    if (lt < C) db3 += Mv[lt];
     __syncthreads();
     if (j < H) {                        // same quad, other role: i = j, the quad splits the layer-2 units
       const int i = j;
@@ -192,8 +228,26 @@ __global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
         db1 += q0;
       }
     }
-    // the next piece's __syncthreads_or separates these reads of e0 / e1 from their next writes
+    // the next round's first barrier separates these reads of e0 / e1 from their next writes
   }
+
+  // groups 1 .. NG-1 hand their accumulators to group 0, one value per thread at a time, in group order
+  auto gather = [&](double& v) {
+    for (int g = 1; g < kNG; ++g) {
+      __syncthreads();
+      if (grp == g) red[lt] = v;
+      __syncthreads();
+      if (grp == 0) v += red[lt];
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < kBI; ++r)
+    if (r < BI) gather(dW2[r]);
+#pragma unroll
+  for (int r = 0; r < CQ; ++r)
+    if (r * 4 < C) gather(dW3[r]);
+  gather(db2); gather(dw1); gather(db1); gather(db3);
+  if (grp != 0) return;
 
   if (j < H) {
 #pragma unroll
@@ -202,7 +256,7 @@ __global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
       if (r < BI && i < H) p.d_W2[(kH + j) * H + i] = static_cast<float>(dW2[r]);
     }
 #pragma unroll
-    for (int r = 0; r < kBI; ++r) {
+    for (int r = 0; r < CQ; ++r) {
       const int c = ib + 4 * r;
       if (c < C) p.d_Wl[(static_cast<int64_t>(k) * C + c) * H + j] = static_cast<float>(dW3[r]);
     }
@@ -212,12 +266,15 @@ __global__ __launch_bounds__(256) void fpwl_grad3_kernel(const GradParams p) {
       if (p.d_b1) p.d_b1[kH + j] = static_cast<float>(db1);
     }
   }
-  if (tid < C && p.d_bl) p.d_bl[static_cast<int64_t>(k) * C + tid] = static_cast<float>(db3);
+  if (lt < C && p.d_bl) p.d_bl[static_cast<int64_t>(k) * C + lt] = static_cast<float>(db3);
 }
 
 // ---- L == 2, H <= 128: thread (i, cb) = (hidden unit, quarter of the output channels) --------------------------------
 __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ double Mv[128];
+  __shared__ int n_live;
+  int* pieces = reinterpret_cast<int*>(smem_raw);   // [P]: the pieces that hold at least one node
   const int H = p.H, C = p.C;
   const int tid = threadIdx.x, k = blockIdx.x;
   const int i = tid >> 2, cb = tid & 3;
@@ -236,13 +293,32 @@ __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
   double dw1 = 0.0, db1 = 0.0, db3 = 0.0;
   const int base = p.off[k], P = p.off[k + 1] - base;
   const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
-  for (int li = 0; li < P; ++li) {
-    double mval = 0.0;
-    const bool mine = tid < 2 * C && piece_moment(p, base + li, tid, inv0, inv1, &mval);
-    if (!__syncthreads_or(mine)) continue;
+  for (int li = tid; li < P; li += 512) {            // list the non-empty pieces first (see fpwl_grad3_kernel)
+    bool nz = false;
+    double unused;
+    for (int c2 = 0; c2 < 2 * C; ++c2) nz |= piece_moment(p, base + li, c2, inv0, inv1, &unused);
+    pieces[li] = nz ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int li = 0; li < P; ++li)
+      if (pieces[li]) pieces[n++] = li;
+    n_live = n;
+  }
+  __syncthreads();
+  const int nl = n_live;
+  double mval = 0.0;
+  if (nl > 0 && tid < 2 * C) piece_moment(p, base + pieces[0], tid, inv0, inv1, &mval);
+  for (int at = 0; at < nl; ++at) {
+    const int li = pieces[at];
+    __syncthreads();                                 // the previous piece's readers of Mv are done
     double a, xi;
     piece_points(p.anchor + base, li, P, &a, &xi);
-    if (tid < 2 * C) Mv[tid] = mval;
+    if (tid < 2 * C) {
+      Mv[tid] = mval;
+      if (at + 1 < nl) piece_moment(p, base + pieces[at + 1], tid, inv0, inv1, &mval);
+    }
     __syncthreads();
     const bool on = live && fma(wv, xi, bv) > 0.0;
     const double h1a = on ? fma(wv, a, bv) : 0.0, h1p = on ? wv : 0.0;
@@ -336,6 +412,7 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
   if (a->C > 64 || a->H > (a->L == 3 ? 64 : 128))
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_param_grads: H <= %d and C <= 64 (got H=%d, C=%d)", a->L == 3 ? 64 : 128, a->H, a->C);
   GNAN_REQUIRE(a->off && a->anchor && a->w_first && a->w_last && a->d_w_first && a->d_w_last, "fpwl_param_grads: null pointer");
+  GNAN_REQUIRE(a->max_pieces >= 1 && a->max_pieces <= 8192, "fpwl_param_grads: max_pieces must be in [1, 8192] (got %d)", a->max_pieces);
   GNAN_REQUIRE((a->moments != nullptr) != (a->moments_fixed != nullptr), "fpwl_param_grads: exactly one of moments / moments_fixed");
   GNAN_REQUIRE(a->moments_fixed == nullptr || a->scales != nullptr, "fpwl_param_grads: moments_fixed needs scales");
   if (a->L == 3) GNAN_REQUIRE(a->w_mid && a->d_w_mid, "fpwl_param_grads: L == 3 needs w_mid / d_w_mid");
@@ -352,11 +429,16 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
   if (a->L == 3) {
     const size_t H = a->H, C = a->C;
     size_t lds = ((3 * H + H * (H + 1) + C * H) * sizeof(float) + 7) & ~size_t(7);
-    lds += (5 * H + 2 * C) * sizeof(double);
-    hipLaunchKernelGGL(fpwl_grad3_kernel, dim3(a->F), dim3(256), lds, st, p);
+    const int ng = 2;        // many channels: two groups (512 threads leave 256 registers per lane)
+    lds += (ng * (5 * H + 2 * C) + 256) * sizeof(double) + (static_cast<size_t>(a->max_pieces) + 8) * sizeof(int);   // + live pieces
+    const dim3 grid(a->F), block(256 * ng);
+    if (C <= 4) hipLaunchKernelGGL((fpwl_grad3_kernel<2, 1>), grid, block, lds, st, p);
+    else if (C <= 8) hipLaunchKernelGGL((fpwl_grad3_kernel<2, 2>), grid, block, lds, st, p);
+    else if (C <= 16) hipLaunchKernelGGL((fpwl_grad3_kernel<2, 4>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((fpwl_grad3_kernel<2, 16>), grid, block, lds, st, p);
     return gnan::check_launch("fpwl_grad3_kernel");
   }
-  hipLaunchKernelGGL(fpwl_grad2_kernel, dim3(a->F), dim3(512), 0, st, p);
+  hipLaunchKernelGGL(fpwl_grad2_kernel, dim3(a->F), dim3(512), (static_cast<size_t>(a->max_pieces) + 8) * sizeof(int), st, p);
   return gnan::check_launch("fpwl_grad2_kernel");
 }
 

@@ -277,7 +277,7 @@ def _fpwl_param_grads_launch(params, t, moments, L, H, C, F):
         moments_fixed=_lib.ptr(moments[0]) if fixed else None, scales=_lib.ptr(moments[1]) if fixed else None,
         w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]),
         w_mid=None if keep[2] is None else _lib.ptr(keep[2][0]), b_mid=None if keep[3] is None else _lib.ptr(keep[3][0]),
-        w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]), F=F, L=L, H=H, C=C,
+        w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]), F=F, L=L, H=H, C=C, max_pieces=int(t.max_pieces),
         d_w_first=_lib.ptr(outs[0]), d_b_first=_lib.ptr(outs[1]),
         d_w_mid=None if outs[2] is None else _lib.ptr(outs[2][0]), d_b_mid=None if outs[3] is None else _lib.ptr(outs[3][0]),
         d_w_last=_lib.ptr(outs[4]), d_b_last=_lib.ptr(outs[5]))

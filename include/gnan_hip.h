@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 20
+#define GNAN_ABI_VERSION 21
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -207,6 +207,7 @@ typedef struct gnan_fpwl_grad_args {
   const float* w_last;          /* [F, C, H] */
   const float* b_last;          /* [F, C] or NULL */
   int32_t F, L, H, C;
+  int32_t max_pieces;           /* >= max_k (off[k+1] - off[k]); sizes the list of non-empty pieces in LDS */
   float* d_w_first;
   float* d_b_first;
   float* d_w_mid;
