@@ -95,6 +95,22 @@ def fmlp_flops(n, F, H, L, C):
     return 2.0 * n * F * (H + max(L - 2, 0) * H * H + H * C) if L >= 2 else 2.0 * n * F * C
 
 
+def fmlp_stage(args, x, H, L, C, W_out, ms):
+    """The shape-function stage against the roofline that bounds the strategy in use: the exact table look-up (what AUTO
+    picks at this size) streams x in and the operand rows out — HBM-bound; the matrix-core kernel is fp32-MFMA-bound."""
+    if ms <= 0:
+        return None
+    n, F = int(x.shape[0]), int(x.shape[1])
+    out_bytes = n * W_out * (2 if args.operand == "bf16" else 4)
+    if args.fmlp_algo in ("auto", "pwl"):
+        b = n * F * 4 + out_bytes
+        return {"algo": "table look-up (pwl_build + fpwl)", "bound": "hbm", "algorithmic_bytes": b,
+                "achieved_GBps": b / (ms / 1e3) / 1e9, "frac": b / (ms / 1e3) / 1e9 / HBM_PEAK_GBPS}
+    fl = fmlp_flops(n, F, H, L, C)
+    return {"algo": args.fmlp_algo, "bound": "mfma", "flops": fl, "achieved_TFLOPs": fl / (ms / 1e3) / 1e12,
+            "frac": fl / (ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+
+
 def cpu_baseline(args, model, g, x, operand_full):
     """Time the oracle (PyTorch-CPU restatement of the reference path) on a bounded sample of the same workload.
 
@@ -321,9 +337,7 @@ def main():
             "step_ms_device": {"min": per_step[0], "median": per_step[len(per_step) // 2]} if per_step else None,
             "seeds": {"graph": 0, "features": 1, "weights": 0}, "git_sha": git_sha(),
             "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
-            "fmlp_effective_tflops": fmlp_flops(x.shape[0], x.shape[1], H, L, C) / (stages["fmlp"] / 1e3) / 1e12
-            if stages["fmlp"] > 0 else None,
-            "fmlp_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "fmlp_algo": args.fmlp_algo,
+            "fmlp": fmlp_stage(args, x, H, L, C, W if args.order == "reference" else C, stages["fmlp"]),
             "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": checksum,
             "operand_rows_rank0": int(x.shape[0]),
         }

@@ -95,3 +95,39 @@ def test_full_size_adjoint_linearity_and_row_subsets(c4):
     sub = spmm_launch(g, s, lut, True, True, row_ids=ids)
     ref = spmm_launch(g, s, lut, True, True)
     assert torch.equal(sub, ref[ids.long()])
+
+
+def test_full_size_training_step_gradients(c4, monkeypatch):
+    """Backward at the full size (sum-first, as the modules train): (i) the parameter gradients of the table path from
+    gnan_fpwl_param_grads == the torch route's (probe points, float64); (ii) a directional derivative of the loss along a
+    random parameter direction, by central differences of two more forwards, matches <grad, direction>."""
+    from gnan_amd import functional
+    from gnan_amd.functional import feature_mlps, rho_aggregate
+    g, x, st, sd, lut = c4
+    target = torch.randn(N, 1, generator=torch.Generator(device=DEV).manual_seed(9), device=DEV)
+
+    def loss_of(stacked, lut_):
+        S, total = feature_mlps(x, stacked, True, return_total=True)              # [N, 1]
+        Y = rho_aggregate(g, S, lut_, True, s_total=total)
+        return ((Y - target) ** 2).mean()
+
+    grads = {}
+    for tag, on in (("hip", True), ("torch", False)):
+        monkeypatch.setattr(functional, "HIP_TABLE_GRADS", on)
+        leaves = [t.detach().clone().requires_grad_(True) for t in st[:6]]
+        lut_leaf = lut.detach().clone().requires_grad_(True)
+        loss = loss_of(type(st)(*leaves, *st[6:]), lut_leaf)
+        grads[tag] = torch.autograd.grad(loss, leaves + [lut_leaf])
+    scale = max(float(t.abs().max()) for t in grads["torch"][:6])
+    for a, b in zip(grads["hip"], grads["torch"]):
+        assert float((a - b).abs().max()) <= 1e-5 * scale
+    monkeypatch.setattr(functional, "HIP_TABLE_GRADS", True)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    direction = [torch.randn(t.shape, generator=gen, device=DEV) for t in st[:6]] + [torch.randn(lut.shape, generator=gen, device=DEV)]
+    analytic = sum(float((a.double() * d.double()).sum()) for a, d in zip(grads["hip"], direction))
+    eps = 1e-3
+    with torch.no_grad():
+        up = loss_of(type(st)(*[t + eps * d for t, d in zip(st[:6], direction)], *st[6:]), lut + eps * direction[6])
+        dn = loss_of(type(st)(*[t - eps * d for t, d in zip(st[:6], direction)], *st[6:]), lut - eps * direction[6])
+    numeric = (float(up) - float(dn)) / (2 * eps)
+    assert abs(numeric - analytic) <= 2e-2 * max(abs(analytic), 1e-6), (numeric, analytic)
