@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--operand", default="f32", choices=["f32", "bf16"],
                     help="storage format of the aggregated operand rows (bf16: storage only, fp32 accumulation; the "
                          "papers100M-shaped configuration of BASELINE.json; not comparable with the fp32 reference at 1e-5)")
-    ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature", "halo"],
-                    help="multi-GPU decomposition: vertex blocks + all-gather of the operand, or feature columns + "
-                         "all-reduce of the [N, C] partial outputs; auto = fewer bytes over xGMI")
+    ap.add_argument("--partition", default="auto", choices=["auto", "vertex", "feature", "halo", "exchange"],
+                    help="multi-GPU decomposition: vertex blocks + all-gather of the operand; feature columns + all-reduce of "
+                         "the [N, C] partial outputs; halo = vertex blocks, the halo's shape functions recomputed (nothing of "
+                         "size N on the wire); exchange = vertex blocks, only the listed remote operand rows travel "
+                         "(x stays sharded); auto = fewer bytes over xGMI")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL on ROCm); gloo + --same-device is a dry run of the "
                          "multi-rank code path on a 1-GPU box")
@@ -183,9 +185,9 @@ def main():
 
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
-    from gnan_amd.distributed import (FeaturePartition, VertexPartition, build_halo_plan, choose_partition,
-                                      feature_parallel_forward, halo_recompute_forward, partitioned_forward,
-                                      slice_features)
+    from gnan_amd.distributed import (FeaturePartition, VertexPartition, build_exchange_plan, build_halo_plan,
+                                      choose_partition, feature_parallel_forward, halo_exchange_forward,
+                                      halo_recompute_forward, partitioned_forward, slice_features)
     from gnan_amd import _lib, functional
     from gnan_amd.functional import stack_mlps
     from gnan_amd.graph import hop_inputs
@@ -197,8 +199,8 @@ def main():
     emulated = args.emulate_world > 1 and world == 1
     pworld = args.emulate_world if emulated else world       # how many shares the work is cut into
     partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, pworld, args.order)
-    if emulated and partition == "vertex":
-        raise SystemExit("--emulate-world covers the halo and feature partitions (a vertex share needs the other ranks' operand)")
+    if emulated and partition in ("vertex", "exchange"):
+        raise SystemExit("--emulate-world covers the halo and feature partitions (these shares need the other ranks' operand rows)")
     if partition == "feature" and args.order != "reference":
         raise SystemExit("--partition feature needs --order reference (sum-first exchanges the narrow operand)")
     part = VertexPartition(N, pworld, rank)
@@ -214,6 +216,10 @@ def main():
         plan = build_halo_plan(syn.hop1_csr(src, dst, N, part.lo, part.hi), part)
         g = plan.graph
         x = syn.block_features(N, F, 0, N, seed=1, device=dev)[plan.node_ids()].contiguous()
+    elif partition == "exchange":                # owned rows only; the listed remote operand rows arrive per forward
+        xplan = build_exchange_plan(syn.hop1_csr(src, dst, N, part.lo, part.hi), part)
+        g = xplan.halo.graph
+        x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
     elif partition == "vertex":
         g = syn.hop1_csr(src, dst, N, part.lo, part.hi)
         x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
@@ -255,6 +261,9 @@ def main():
             if partition == "halo":
                 out = halo_recompute_forward(x, plan, stacked, lut, True, order=args.order, out_channels=C,
                                              marks=mark, operand_dtype=op_dtype)
+            elif partition == "exchange":
+                out = halo_exchange_forward(x, xplan, stacked, lut, True, order=args.order, out_channels=C,
+                                            marks=mark, operand_dtype=op_dtype)
             elif partition == "vertex":
                 out = partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
                                           marks=mark, operand_dtype=op_dtype)
@@ -328,8 +337,9 @@ def main():
             "config": {"workload": workload, "nodes": N, "edges": E, "stored_pairs_rank0": g.nnz,
                        "operand_width": W, "partition": f"{partition} x{world}", "exchange":
                        "none" if world == 1 else ("all_reduce(column sums [W])" if partition == "halo" else
-                                                  "all_gather(operand [N,W])" if partition == "vertex"
-                                                  else "all_reduce(out [N,C])")},
+                                                  "all_gather(operand [N,W])" if partition == "vertex" else
+                                                  "all_to_all_v(listed remote operand rows [n_halo,W]) + all_reduce(column sums [W])"
+                                                  if partition == "exchange" else "all_reduce(out [N,C])")},
             "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},

@@ -27,10 +27,16 @@ size ``N`` crosses xGMI any more — the only collective is an all-reduce of the
 2-4 ms for the 320 MB shard every link would have to carry in the all-gather) and of HBM capacity, which is what a
 288 GB device has to spare.
 
+Halo exchange (``x`` must stay sharded: no rank may hold other ranks' input rows): the edge-cut scheme of SURVEY.md §8e
+taken literally — rank ``p`` evaluates the shape functions of its OWN rows only and receives, from each owner, exactly the
+operand rows its adjacency lists (deduplicated: its halo), as one all-to-all-v of point-to-point transfers; every
+directed pair of ranks uses its own xGMI link.  Cheaper on the wire than gathering the whole operand (R-MAT 10M/100M at
+8 ranks: 1.47M of 8.75M remote rows), dearer than recomputing the halo when ``x`` may be replicated.
+
 Backward (every variant): each rank back-propagates the loss of ITS output rows and the ranks add their parameter
 gradients (``all_reduce`` of ``p.grad``, SUM — the caller's job, as with any data-parallel step).  What crosses ranks
 inside the backward pass mirrors the forward: the all-gather of the operand becomes a reduce-scatter of its gradient
-(:class:`_GatherOperand`); the all-reduced column sums of the rest bucket become an all-reduce of one W-float vector
+(:class:`_GatherOperand`); the halo exchange runs in reverse and the owners add what comes back (:class:`_HaloExchange`); the all-reduced column sums of the rest bucket become an all-reduce of one W-float vector
 (``rho_aggregate(total_group=...)``: every rank's rows pull on every rank's summed operand rows through ``total``);
 the feature partition's all-reduce of the output passes the gradient through unchanged (every rank evaluates the same
 loss on the full output).  All ranks must therefore run the backward pass together.
@@ -193,7 +199,8 @@ def slice_features(stacked, lo: int, hi: int):
 
 def choose_partition(n_nodes: int, n_features: int, out_channels: int, world: int, order: str,
                      replicated_inputs: bool = True) -> str:
-    """'vertex', 'feature' or 'halo', by the bytes each rank receives over xGMI per forward.
+    """'vertex', 'feature' or 'halo', by the bytes each rank receives over xGMI per forward ('exchange' — the halo-only
+    transfer of :func:`halo_exchange_forward` — is chosen explicitly: how many rows it moves depends on the graph).
 
     Sum-first exchanges the narrow ``[N, C]`` operand: vertex partition with one all-gather.  The reference order
     (``[N, F*C]`` operand) exchanges nothing if every rank may hold the ``x`` rows of its halo (halo recompute);
@@ -315,5 +322,123 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     # only the owned rows went into `total` (halo rows are some other rank's owned rows)
     Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total, reduce_channels=rc, total_rows=plan.n_own,
                          **shared)
+    mark("spmm")
+    return Y
+
+
+# =============================================================================
+# halo exchange: vertex partition, only the listed remote operand rows travel
+# =============================================================================
+@dataclass
+class ExchangePlan:
+    """Who sends which of its owned operand rows to whom (static per graph and partition)."""
+    halo: HaloPlan
+    send_rows: list               # per peer rank: int64 local indices (into the owned rows) this rank sends, in the peer's halo order
+    recv_counts: list             # per peer rank: how many halo rows it owns (the halo is sorted by global id = grouped by owner)
+
+    @property
+    def n_own(self) -> int:
+        return self.halo.n_own
+
+
+def _peer_exchange(send: list, recv: list, group=None) -> None:
+    """All-to-all-v as a batch of point-to-point transfers (RCCL groups them; gloo, which has no all_to_all, takes them too)."""
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) == "gloo" and any(t is not None and t.is_cuda for t in list(send) + list(recv)):
+        # gloo moves point-to-point messages through host memory only (the 1-GPU dry run of the multi-rank bench)
+        host_send = [None if t is None else t.cpu() for t in send]
+        host_recv = [None if t is None else torch.empty(t.shape, dtype=t.dtype) for t in recv]
+        _peer_exchange(host_send, host_recv, group)
+        for dst, src in zip(recv, host_recv):
+            if dst is not None and dst.numel():
+                dst.copy_(src)
+        return
+    ops = []
+    for r, (s_buf, r_buf) in enumerate(zip(send, recv)):
+        if r == rank:
+            continue
+        peer = dist.get_global_rank(group, r) if group is not None else r
+        if r_buf is not None and r_buf.numel():
+            ops.append(dist.P2POp(dist.irecv, r_buf, peer, group))
+        if s_buf is not None and s_buf.numel():
+            ops.append(dist.P2POp(dist.isend, s_buf, peer, group))
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+
+
+def build_exchange_plan(graph_local, part: VertexPartition, group=None) -> ExchangePlan:
+    """Halo plan (:func:`build_halo_plan`) plus the send lists: every rank tells the owners of its halo rows which rows it
+    needs (one exchange of counts, one of index lists — once per graph).  Index work only, bit-exact."""
+    plan = build_halo_plan(graph_local, part)
+    world, dev = part.world, plan.halo.device
+    owner = torch.div(plan.halo, part.block, rounding_mode="floor")
+    recv_counts = torch.bincount(owner, minlength=world).tolist()
+    if world == 1:
+        return ExchangePlan(plan, [None], recv_counts)
+    counts = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)              # all_counts[q][r]: rows rank q needs from rank r
+    want = list(torch.split(plan.halo - owner * part.block, recv_counts))    # per owner: ITS local indices, in my halo order
+    asked = [torch.empty(int(all_counts[q][part.rank]), dtype=torch.int64, device=dev) for q in range(world)]
+    _peer_exchange([w.contiguous() for w in want], asked, group)
+    return ExchangePlan(plan, asked, recv_counts)
+
+
+class _HaloExchange(torch.autograd.Function):
+    """``halo_rows = exchange(owned_rows)``: each peer receives the owned rows it listed; backward sends the gradients of
+    the halo rows back to their owners, which add them to their rows."""
+
+    @staticmethod
+    def forward(ctx, own, xplan: ExchangePlan, group):
+        ctx.xplan, ctx.group, ctx.n_own = xplan, group, own.shape[0]
+        W = own.shape[1]
+        send = [None if idx is None else own.index_select(0, idx) for idx in xplan.send_rows]
+        halo = own.new_empty((sum(xplan.recv_counts), W))
+        recv = list(torch.split(halo, xplan.recv_counts))
+        _peer_exchange(send, recv, group)
+        return halo
+
+    @staticmethod
+    def backward(ctx, d_halo):
+        xplan = ctx.xplan
+        d_halo = d_halo.contiguous()
+        send = list(torch.split(d_halo, xplan.recv_counts))
+        recv = [None if idx is None else d_halo.new_empty((idx.numel(), d_halo.shape[1])) for idx in xplan.send_rows]
+        _peer_exchange(send, recv, ctx.group)
+        d_own = d_halo.new_zeros((ctx.n_own, d_halo.shape[1]))
+        for idx, buf in zip(xplan.send_rows, recv):
+            if idx is not None and idx.numel():
+                d_own.index_add_(0, idx, buf)
+        return d_own, None, None
+
+
+def halo_exchange_forward(x_own: torch.Tensor, xplan: ExchangePlan, stacked, lut: torch.Tensor, use_cnt: bool,
+                          order: str = "sum_first", out_channels: int = 1, group=None,
+                          compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
+                          operand_dtype=torch.float32):
+    """Forward on the owned rows from the OWNED rows of ``x`` only; returns ``out[lo:hi, :out_channels]``.
+    Stages / ``marks``: "fmlp" (own shape functions), "gather" (the halo rows arrive), "total", "spmm"."""
+    ops = compute or _hip_compute()
+    mark = marks or (lambda name: None)
+    plan = xplan.halo
+    part = plan.part
+    mark("start")
+    kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
+    if compute is None and out_channels == 1:
+        kw["pad_ok"] = True
+    own, total = ops["feature_mlps"](x_own, stacked, order == "sum_first", return_total=True, **kw)
+    mark("fmlp")
+    shared = {}
+    if part.world > 1:
+        operand = torch.cat([own, _HaloExchange.apply(own, xplan, group)], dim=0)       # [own | halo]: the plan's column order
+        mark("gather")
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        mark("total")
+        shared = {"total_group": group}
+    else:
+        operand = own
+    Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total,
+                         reduce_channels=out_channels if order == "reference" else 0, total_rows=plan.n_own, **shared)
     mark("spmm")
     return Y

@@ -266,6 +266,68 @@ def test_multi_rank_backward_adds_up_to_the_single_process_gradient(world, n, pa
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
+def _exchange_worker(rank, world, port, n, F, order, out_dir, with_grad):
+    import cpu_kernels
+    from gnan_amd.distributed import build_exchange_plan, halo_exchange_forward
+    from gnan_amd.functional import rho_aggregate
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu_kernels.install()
+    try:
+        src, dst, x, sd = _grad_problem(n, F)
+        leaves = {k: v.clone().requires_grad_(with_grad) for k, v in sd.items()}
+        lut = O.rho_lut(leaves, 3, dtype=torch.float64).float()
+        part = VertexPartition(n, world, rank)
+        g = syn.hop1_csr(src, dst, n, part.lo, part.hi)
+        xplan = build_exchange_plan(g, part)
+        # index work is bit-exact: what a rank is asked to send is what the asker's halo lists, in the asker's order
+        halo = xplan.halo.halo
+        assert sum(xplan.recv_counts) == halo.numel() and xplan.recv_counts[rank] == 0
+        for idx in xplan.send_rows:
+            assert idx is None or (idx.numel() == 0) or (0 <= int(idx.min()) and int(idx.max()) < part.hi - part.lo)
+
+        def feature_mlps(xx, stacked, sum_features, return_total=False, total_rows=None, **_):
+            fx = O.feature_mlps(xx.double(), leaves).float()
+            out = fx.sum(1) if sum_features else fx.reshape(xx.shape[0], -1)
+            return (out, out[:total_rows].sum(0).detach()) if return_total else out
+        compute = {"feature_mlps": feature_mlps, "aggregate": rho_aggregate}
+        ctx = torch.enable_grad() if with_grad else torch.no_grad()
+        with ctx:
+            y = halo_exchange_forward(x[part.lo:part.hi], xplan, None, lut, True, order=order, out_channels=1, compute=compute)
+            if with_grad:
+                target = torch.sin(torch.arange(n, dtype=torch.float32)).view(-1, 1)
+                ((y - target[part.lo:part.hi]) ** 2).sum().backward()
+                np.savez(os.path.join(out_dir, f"g{rank}.npz"),
+                         **{k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in leaves.items()})
+        np.save(os.path.join(out_dir, f"y{rank}.npy"), y.detach().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,order", [(2, 120, "sum_first"), (3, 121, "reference"), (4, 90, "sum_first")])
+def test_halo_exchange_forward_and_backward_equal_single_process(world, n, order, tmp_path):
+    """Only the listed remote operand rows travel (point-to-point all-to-all-v); forward == single process, and the sum
+    over the ranks of the parameter gradients == the single-process gradient (the exchange runs in reverse in backward)."""
+    F = 4
+    port = _free_port()
+    mp.spawn(_exchange_worker, args=(world, port, n, F, order, str(tmp_path), True), nprocs=world, join=True)
+    src, dst, x, sd = _grad_problem(n, F)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    g = syn.hop1_csr(src, dst, n)
+    S = O.feature_mlps(x.double(), leaves).sum(1)
+    wt = O.weight_table(O.rho_lut(leaves, 3, dtype=torch.float64), g.cnt.long().numpy()).expand(n, -1, -1)
+    y = O.spmm_csr(g.rowptr.long().numpy(), g.col.numpy(), g.code.numpy(), S, wt)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    assert O.rel_err(torch.from_numpy(got), y.detach()) <= 1e-5
+    target = torch.sin(torch.arange(n, dtype=torch.float32)).view(-1, 1).double()
+    ((y - target) ** 2).sum().backward()
+    scale = max(float(v.grad.abs().max()) for v in leaves.values())
+    parts = [np.load(tmp_path / f"g{r}.npz") for r in range(world)]
+    for k, v in leaves.items():
+        err = float(np.abs(sum(p[k] for p in parts) - v.grad.numpy()).max()) / scale
+        assert err <= 2e-5, f"{k}: {err:.3e}"
+
+
 def test_choose_partition_by_exchanged_bytes():
     from gnan_amd.distributed import choose_partition
     assert choose_partition(10_000_000, 64, 1, 8, "reference") == "halo"        # inputs replicated: no exchange
