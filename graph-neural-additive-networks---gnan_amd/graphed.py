@@ -195,3 +195,44 @@ class GraphedStep:
                 group["lr"] = static
         self.graph.replay()
         return self.outputs, self.loss, self.extras
+
+
+class _Slots:
+    """Duck-typed ``Data`` whose tensors are the static input buffers of a captured graph-task step."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class SlottedGraphStep:
+    """A captured training step for ALL graphs of one shape ``(nodes, features, shells)`` of a graph-level task.
+
+    Graph-level tasks see a different small graph every step (trainer.py:23-86 with batch_size = 1), so a captured step
+    cannot be tied to one input.  It is tied to a SHAPE instead: the step is captured over static buffers (feature matrix,
+    dense hop codes, shell counts, label) and each graph of that shape is copied into them — four tiny device copies — before
+    the replay.  ``loss_of(outputs, label) -> loss`` as in :class:`GraphedStep`; the caller's running totals are updated
+    inside the captured step (``totals = (loss_sum, hit_count)``, device scalars)."""
+
+    def __init__(self, model, optimizer, loss_of, graph, x, label):
+        from .graph import HopGraph
+        if not graph.is_dense:
+            raise CaptureFailed("graph-task steps are captured for the dense layout only")
+        self.x, self.code, self.cnt = torch.empty_like(x), torch.empty_like(graph.code), torch.empty_like(graph.cnt)
+        self.label = torch.empty_like(label)
+        self.load(graph, x, label)
+        static_graph = HopGraph(n_rows=graph.n_rows, n_cols=graph.n_cols, n_codes=graph.n_codes, code=self.code, cnt=self.cnt)
+        self.data = _Slots(x=self.x, edge_index=None, gnan_graph=static_graph)
+        self.step = GraphedStep(model, self.data, lambda out: loss_of(out, self.label), optimizer, warmup=0)
+
+    def load(self, graph, x, label) -> None:
+        self.x.copy_(x)
+        self.code.copy_(graph.code)
+        self.cnt.copy_(graph.cnt)
+        self.label.copy_(label)
+
+    def run(self, graph, x, label):
+        """Copy the graph into the slots and replay; None if the capture has gone stale (the caller steps eagerly)."""
+        if self.step.stale():
+            return None
+        self.load(graph, x, label)
+        return self.step.replay()

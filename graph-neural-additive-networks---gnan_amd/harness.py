@@ -13,7 +13,9 @@ Node-level tasks run the same step on the same tensors every epoch (one full-bat
 ONE batch that already lives on the device — the same objects every epoch, e.g. ``[data.to(device)]`` — the third and
 every later epoch replays a hipGraph of the whole step (forward, mask, loss, backward, Adam update, hit count;
 ``gnan_amd/graphed.py``) instead of re-issuing ~70 launches from Python: same arithmetic, same kernels, no host in the
-loop.  ``GNAN_GRAPHED_STEPS=0`` switches it off; anything a capture cannot hold (training-mode Dropout, an optimizer
+loop.  Graph-level tasks (a different small graph per step, batch_size = 1) get one captured step per graph SHAPE
+(nodes, features, shells): the third graph of a shape captures it over static buffers and every later graph of that shape
+is copied into them and replayed (``SlottedGraphStep``).  ``GNAN_GRAPHED_STEPS=0`` switches it off; anything a capture cannot hold (training-mode Dropout, an optimizer
 without a capturable mode, a loader that uploads fresh tensors per epoch) silently keeps the eager loop.
 """
 from __future__ import annotations
@@ -28,6 +30,7 @@ import torch
 GRAPHED_STEPS = os.environ.get("GNAN_GRAPHED_STEPS", "1") != "0"
 GRAPH_AFTER = 2                      # eager epochs before a step is captured (they are the capture's warm-up)
 _STEPS = weakref.WeakKeyDictionary()     # model -> TensorKeyedCache of per-(data, mask, loss, optimizer) step records
+_GRAPH_STEPS = weakref.WeakKeyDictionary()   # model -> _GraphTaskSteps (graph-level tasks: one captured step per graph shape)
 
 
 def _labels_of(data, label_index: int, loss_fn) -> torch.Tensor:
@@ -142,6 +145,78 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
     return _finish(loss, hits if classify else 0, 1, int(rec["labels"].numel()), classify, compute_auc, probas, targets)
 
 
+class _GraphTaskSteps:
+    """Captured training steps of a graph-level task, one per graph shape (``graphed.SlottedGraphStep``)."""
+
+    def __init__(self, model, optimizer, loss_fn, classify, device):
+        self.model, self.optimizer, self.loss_fn, self.classify = weakref.ref(model), weakref.ref(optimizer), weakref.ref(loss_fn), classify
+        self.buckets = {}
+        self.total_loss = torch.zeros((), device=device)
+        self.hits = torch.zeros((), device=device)
+        self.labels = None
+
+    def matches(self, model, optimizer, loss_fn, classify) -> bool:
+        return (self.model() is model and self.optimizer() is optimizer and self.loss_fn() is loss_fn
+                and self.classify == classify)
+
+    def labels_of(self, data, label_index, loss_fn):
+        """``_labels_of`` without its host synchronisation, cached per label tensor."""
+        from ._cache import TensorKeyedCache
+        if self.labels is None:
+            self.labels = TensorKeyedCache(1 << 16)
+        hit = self.labels.get((data.y,), label_index)
+        if hit is None:
+            y = data.y
+            lab = y[:, label_index].reshape(-1).float() if y.dim() > 1 else y.reshape(-1)
+            lab = torch.where((lab == -1).any(), (lab + 1) / 2, lab)
+            lab = lab.long() if type(loss_fn).__name__ == "CrossEntropyLoss" else lab
+            hit = self.labels.put((data.y,), label_index, lab.to(self.total_loss.device))
+        return hit
+
+    def step(self, data, labels) -> bool:
+        """Run this graph's training step from a captured graph if its shape has one (or can get one now)."""
+        from .graphed import CaptureFailed, SlottedGraphStep
+        model = self.model()
+        graph = model.hop_graph(data)
+        if not graph.is_dense:
+            return False
+        key = (graph.n_rows, graph.n_cols, graph.n_codes, tuple(data.x.shape), data.x.dtype, tuple(labels.shape), labels.dtype)
+        rec = self.buckets.get(key)
+        if rec is None:
+            rec = self.buckets[key] = {"calls": 0, "step": None, "dead": False}
+        if rec["dead"]:
+            return False
+        if rec["step"] is None:
+            if rec["calls"] < GRAPH_AFTER:
+                rec["calls"] += 1
+                return False
+            loss_fn, classify = self.loss_fn(), self.classify
+
+            def loss_of(outputs, label):
+                loss = _loss_of(loss_fn, outputs, label)
+                self.total_loss.add_(loss.detach())
+                if classify:
+                    self.hits.add_(_hits(outputs.detach(), label))
+                return loss, None
+            try:
+                rec["step"] = SlottedGraphStep(model, self.optimizer(), loss_of, graph, data.x, labels)
+            except CaptureFailed as e:
+                rec["dead"] = True
+                warnings.warn(f"gnan_amd: the graph-task step could not be captured into a hipGraph ({e}); shape stays eager")
+                return False
+        if rec["step"].run(graph, data.x, labels) is None:
+            rec["step"], rec["calls"] = None, GRAPH_AFTER
+            return False
+        return True
+
+
+def _graph_task_steps(model, optimizer, loss_fn, classify, device):
+    steps = _GRAPH_STEPS.get(model)
+    if steps is None or not steps.matches(model, optimizer, loss_fn, classify):
+        steps = _GRAPH_STEPS[model] = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)
+    return steps
+
+
 def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compute_auc, mask_name, is_graph_task):
     if GRAPHED_STEPS and not is_graph_task and (optimizer is not None or not torch.is_grad_enabled()):
         data = _single_resident_batch(loader, device)
@@ -152,7 +227,20 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
     total_loss = torch.zeros((), device=device)
     hits = torch.zeros((), device=device)
     n_samples, probas, targets = 0, [], []
+    replayer = None
+    if (GRAPHED_STEPS and is_graph_task and optimizer is not None and not compute_auc and torch.device(device).type == "cuda"
+            and hasattr(model, "hop_graph")):
+        from .graphed import GraphedStep
+        if GraphedStep.supported(model, optimizer):
+            replayer = _graph_task_steps(model, optimizer, loss_fn, classify, device)
+            replayer.total_loss.zero_()
+            replayer.hits.zero_()
     for data in loader:
+        if replayer is not None and torch.is_tensor(getattr(data, "x", None)) and data.x.is_cuda:
+            labels = replayer.labels_of(data, label_index, loss_fn)
+            if replayer.step(data, labels):              # this graph's whole step was one replayed hipGraph
+                n_samples += len(labels)
+                continue
         labels = _labels_of(data, label_index, loss_fn).to(device)
         data = _resident(data, device)
         if optimizer is not None:
@@ -174,6 +262,11 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
         if compute_auc:
             probas.append(torch.sigmoid(outputs.detach()).reshape(-1).cpu().numpy())
             targets.append(labels.detach().cpu().numpy())
+        # nothing of this step's autograd graph may outlive it: a capture of the NEXT graph's step would meet its
+        # AccumulateGrad nodes, bound to this (default) stream — a cross-stream dependency inside a capture (a crash on ROCm)
+        del loss, outputs
+    if replayer is not None:
+        total_loss, hits = total_loss + replayer.total_loss, hits + replayer.hits
     return _finish(total_loss, hits, len(loader), n_samples, classify, compute_auc, probas, targets)
 
 

@@ -231,6 +231,11 @@ class _PathBase(nn.Module):
             g = self._graph_cache.put((nd, norm), "dense", HopGraph.from_dense(nd, norm))
         return g
 
+    def hop_graph(self, inputs) -> HopGraph:
+        """The hop-coded graph ``forward(inputs)`` aggregates over (built from the dense inputs on first sight, then cached)."""
+        want = True if isinstance(self, _GNANCore) else bool(getattr(self, "normalize_rho", True))
+        return self._graph(inputs, want_norm=want)
+
     # ---- rho on the distinct distances -------------------------------------------------------
     def _lut_global(self, g: HopGraph) -> torch.Tensor:
         """``lut[d] = rho(float32(1/(1+d)))``, ``lut[D-1] = rho(0)`` — D rows instead of N^2 (models.py:368)."""

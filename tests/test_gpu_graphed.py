@@ -166,3 +166,68 @@ def test_captured_memsets_are_swapped_for_kernels():
             torch.cuda.synchronize()
             assert bool((buf[lo:hi] == 1).all()), (offset, nbytes, r, buf[lo:hi][:4].tolist())
             assert int(buf[-1]) == 8 + r and (lo == 0 or int(buf[lo - 1]) == 8 + r)      # the neighbours are not touched
+
+
+def _graph_task(n_graphs, F, sizes, seed=0):
+    from oracle import gnan_oracle as O
+    rng = np.random.default_rng(seed)
+    data = []
+    for i in range(n_graphs):
+        n = int(sizes[i % len(sizes)])
+        tree = np.stack([np.arange(1, n), rng.integers(0, np.arange(1, n))])              # a random tree: connected
+        extra = np.stack([rng.integers(0, n, n // 4 + 1), rng.integers(0, n, n // 4 + 1)])
+        ei = np.concatenate([tree, extra], axis=1)
+        if i % 5 == 0 and n > 6:
+            ei = ei[:, ei.max(0) < n - 2]                                                 # two isolated nodes: a rest shell
+        nd, norm = O.pre_process_dense(np.concatenate([ei, ei[::-1]], axis=1), n)
+        x = torch.zeros(n, F)
+        x[torch.arange(n), torch.from_numpy(rng.integers(0, F - 1, n))] = 1.0             # one-hot atom types + ones column
+        x[:, -1] = 1.0
+        y = torch.tensor([[1.0 if rng.random() < 0.5 else -1.0]])                         # {-1, +1} targets (trainer.py:35-38)
+        data.append(Bag(x=x.to(DEV), y=y.to(DEV), edge_index=None, node_distances=nd.to(DEV), normalization_matrix=norm.to(DEV)))
+    return data
+
+
+@pytest.mark.parametrize("readout", [0, 2])
+def test_graph_task_steps_replayed_per_shape_match_eager_steps(readout, monkeypatch):
+    """Graph-level task, batch_size = 1: one captured step per graph shape, every later graph of the shape copied into its
+    static buffers and replayed.  Two copies of the model walk the same graphs in lock-step — one eagerly, one through the
+    replayer — and after EVERY step losses, parameters and optimizer moments must agree; the replayed copy is then reset to
+    the eager one's state, so every replayed step is checked from the same starting point (with the NAM read-out and O(1)
+    random weights the trajectory itself is chaotic: for-each and fused Adam — no graphs involved — drift apart by 20 %
+    of the epoch loss within three epochs, which says nothing about a step being right)."""
+    _need_gpu()
+    from gnan_amd import harness
+    from gnan_amd.models import TensorGNAN
+    F = 15
+    graphs = _graph_task(45, F, sizes=[12, 30, 12, 23, 30, 12, 41])
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+
+    def make():
+        torch.manual_seed(0)
+        m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, readout_n_layers=readout, device=DEV)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape) * 0.5)
+        m = m.to(DEV).eval()
+        return m, torch.optim.Adam(m.parameters(), lr=2e-3, capturable=True, fused=True)
+    (ma, oa), (mb_, ob) = make(), make()
+    replayed = worst = 0
+    for epoch in range(3):
+        for g in graphs:
+            monkeypatch.setattr(harness, "GRAPHED_STEPS", False)
+            ra = harness.train_epoch(ma, [g], loss_fn, oa, DEV, classify=True, is_graph_task=True)
+            monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+            rb = harness.train_epoch(mb_, [g], loss_fn, ob, DEV, classify=True, is_graph_task=True)
+            assert abs(ra[0] - rb[0]) <= 1e-5 * max(1.0, abs(ra[0])) and ra[1] == rb[1], (epoch, ra, rb)
+            with torch.no_grad():
+                for pa, pb in zip(ma.parameters(), mb_.parameters()):
+                    scale = float(pa.abs().max()) + 1e-12
+                    worst = max(worst, float((pa - pb).abs().max()) / scale)
+                    pb.copy_(pa)
+                    for key in ("exp_avg", "exp_avg_sq", "step"):
+                        ob.state[pb][key].copy_(oa.state[pa][key])
+            assert worst <= 1e-5, (epoch, worst)
+    steps = harness._GRAPH_STEPS[mb_]
+    replayed = sum(r["step"].step.graph.replays for r in steps.buckets.values() if r["step"] is not None)
+    assert replayed >= 70, replayed                                # 135 steps, a dozen shapes, two eager sightings each

@@ -64,8 +64,56 @@ def run(name, make):
     print(json.dumps(out), flush=True)
 
 
+def muta_shaped():
+    """Mutagenicity-shaped graph-level task: 600 graphs, N ~ clip(round(LogNormal(3.3, 0.45)), 4, 417), random
+    trees + N/30 extra edges, one-hot of 14 atom types + ones, batch_size = 1."""
+    rng = np.random.default_rng(0)
+    F, graphs = 15, []
+    for i in range(600):
+        n = int(np.clip(np.round(rng.lognormal(3.3, 0.45)), 4, 417))
+        tree = np.stack([np.arange(1, n), rng.integers(0, np.arange(1, n))])
+        extra = np.stack([rng.integers(0, n, n // 30 + 1), rng.integers(0, n, n // 30 + 1)])
+        ei = np.concatenate([tree, extra], axis=1)
+        nd, norm = mb.dense_inputs(np.concatenate([ei, ei[::-1]], axis=1), n)
+        x = torch.zeros(n, F)
+        x[torch.arange(n), torch.from_numpy(rng.integers(0, F - 1, n))] = 1.0
+        x[:, -1] = 1.0
+        y = torch.tensor([[1.0 if rng.random() < 0.5 else -1.0]])
+        graphs.append(Data(x=x.to(DEV), y=y.to(DEV), edge_index=None, node_distances=nd.to(DEV), normalization_matrix=norm.to(DEV)))
+    return graphs
+
+
+def run_graph_task():
+    graphs = muta_shaped()
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    out = {"what": "muta_shaped_600_graphs", "graphs": len(graphs)}
+    for tag, on in (("eager", False), ("graphed", True)):
+        harness.GRAPHED_STEPS = on
+        torch.manual_seed(0)
+        m = mb.TensorGNAN(15, 1, 3, hidden_channels=64, is_graph_task=True, readout_n_layers=0, device=DEV)
+        mb.redraw(m)
+        m = m.to(DEV).eval()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        ts = []
+        for epoch in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret = harness.train_epoch(m, graphs, loss_fn, opt, DEV, classify=True, is_graph_task=True)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / len(graphs) * 1e3)
+        out[tag + "_ms_per_graph_by_epoch"] = [round(t, 3) for t in ts]
+        out[tag + "_last"] = ret
+        if on:
+            st = harness._GRAPH_STEPS[m]
+            out["shapes"] = len(st.buckets)
+            out["captured"] = sum(r["step"] is not None for r in st.buckets.values())
+    print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["arxiv", "arxiv40", "cora"]
+    if "muta" in which:
+        run_graph_task()
     if "arxiv" in which:
         run("arxiv_shaped_C1", lambda: arxiv_shaped(1))
     if "arxiv40" in which:

@@ -62,11 +62,20 @@ def pwl_split():
                       "lookup_sum_ms": t_look_sum, "pieces_max": tb.max_pieces, "fpg": tb.features_per_group}))
 
 
+def dense_inputs(ei, n):
+    """The reference's two dense matrices (pre_process_datasets.py:104-142) from ``edge_index``, through the product's own
+    preprocessing (all-pairs BFS on the device, HopGraph.from_edge_index): nd = 1/(1+hop) or 0, norm = shell size."""
+    g = HopGraph.from_edge_index(torch.as_tensor(ei).to(DEV), n)
+    code = g.code.long()
+    nd = torch.where(code == 255, torch.zeros((), device=DEV), 1.0 / (1.0 + code.float()))
+    norm = torch.gather(g.cnt.float(), 1, code.clamp_max(g.n_codes - 1))
+    return nd, norm
+
+
 def dense_graph(n, avg_deg, rng):
-    from oracle import gnan_oracle as O
     ei = np.stack([rng.integers(0, n, int(n * avg_deg / 2)), rng.integers(0, n, int(n * avg_deg / 2))])
     ei = np.concatenate([ei, ei[::-1]], 1)
-    return ei, O.pre_process_dense(ei, n)
+    return ei, dense_inputs(ei, n)
 
 
 def cora_shaped():
@@ -95,7 +104,6 @@ def cora_shaped():
 
 
 def mutagenicity_shaped():
-    from oracle import gnan_oracle as O
     rng = np.random.default_rng(0)
     graphs = []
     for _ in range(200):
@@ -104,7 +112,7 @@ def mutagenicity_shaped():
         ei = np.stack([np.arange(1, n), par])
         extra = rng.integers(0, n, (2, max(1, n // 30)))
         ei = np.concatenate([ei, ei[::-1], extra, extra[::-1]], 1)
-        nd, norm = O.pre_process_dense(ei, n)
+        nd, norm = dense_inputs(ei, n)
         x = torch.zeros(n, 15)
         x[torch.arange(n), torch.from_numpy(rng.integers(0, 14, n))] = 1
         x[:, -1] = 1

@@ -3,7 +3,7 @@ import cProfile, pstats, os, sys, io
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import microbench as mb
 import numpy as np, torch
-from oracle import gnan_oracle as O
+
 rng = np.random.default_rng(0)
 graphs = []
 for _ in range(50):
@@ -11,7 +11,7 @@ for _ in range(50):
     par = np.array([rng.integers(0, i) for i in range(1, n)])
     ei = np.stack([np.arange(1, n), par])
     ei = np.concatenate([ei, ei[::-1]], 1)
-    nd, norm = O.pre_process_dense(ei, n)
+    nd, norm = mb.dense_inputs(ei, n)
     x = torch.zeros(n, 15); x[torch.arange(n), torch.from_numpy(rng.integers(0, 14, n))] = 1; x[:, -1] = 1
     graphs.append(mb.Bag(x=x.to("cuda"), edge_index=torch.from_numpy(ei).to("cuda"), node_distances=nd.to("cuda"),
                          normalization_matrix=norm.to("cuda")))
