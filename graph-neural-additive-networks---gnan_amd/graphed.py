@@ -134,7 +134,10 @@ class GraphedStep:
             return False
         return optimizer is None or all("capturable" in g for g in optimizer.param_groups)
 
-    def __init__(self, model, data, loss_of=None, optimizer=None, forward: Optional[Callable] = None, warmup: int = 2):
+    def __init__(self, model, data, loss_of=None, optimizer=None, forward: Optional[Callable] = None, warmup: int = 0):
+        """``warmup`` eager steps are run first — REAL steps (they update the parameters when an optimizer is given).  A
+        capture needs the step to have run eagerly at least once (lazy initialisations, table sizes); ``harness`` passes
+        0 because its first epochs already did."""
         self.model, self.data, self.optimizer = model, data, optimizer
         self.training = optimizer is not None
         fwd = forward or (lambda: model.forward(data))

@@ -29,6 +29,7 @@ import torch
 
 GRAPHED_STEPS = os.environ.get("GNAN_GRAPHED_STEPS", "1") != "0"
 GRAPH_AFTER = 2                      # eager epochs before a step is captured (they are the capture's warm-up)
+GRAPH_TASK_MAX_SHAPES = 4096         # captured steps a graph-level task may hold (each owns a private memory pool: >= 2 MB)
 _STEPS = weakref.WeakKeyDictionary()     # model -> TensorKeyedCache of per-(data, mask, loss, optimizer) step records
 _GRAPH_STEPS = weakref.WeakKeyDictionary()   # model -> _GraphTaskSteps (graph-level tasks: one captured step per graph shape)
 
@@ -151,6 +152,7 @@ class _GraphTaskSteps:
     def __init__(self, model, optimizer, loss_fn, classify, device):
         self.model, self.optimizer, self.loss_fn, self.classify = weakref.ref(model), weakref.ref(optimizer), weakref.ref(loss_fn), classify
         self.buckets = {}
+        self.captured = 0
         self.total_loss = torch.zeros((), device=device)
         self.hits = torch.zeros((), device=device)
         self.labels = None
@@ -187,7 +189,7 @@ class _GraphTaskSteps:
         if rec["dead"]:
             return False
         if rec["step"] is None:
-            if rec["calls"] < GRAPH_AFTER:
+            if rec["calls"] < GRAPH_AFTER or self.captured >= GRAPH_TASK_MAX_SHAPES:
                 rec["calls"] += 1
                 return False
             loss_fn, classify = self.loss_fn(), self.classify
@@ -200,6 +202,7 @@ class _GraphTaskSteps:
                 return loss, None
             try:
                 rec["step"] = SlottedGraphStep(model, self.optimizer(), loss_of, graph, data.x, labels)
+                self.captured += 1
             except CaptureFailed as e:
                 rec["dead"] = True
                 warnings.warn(f"gnan_amd: the graph-task step could not be captured into a hipGraph ({e}); shape stays eager")

@@ -107,6 +107,7 @@ def run_graph_task():
             st = harness._GRAPH_STEPS[m]
             out["shapes"] = len(st.buckets)
             out["captured"] = sum(r["step"] is not None for r in st.buckets.values())
+            out["reserved_GB"] = round(torch.cuda.memory_reserved() / 2**30, 2)
     print(json.dumps(out), flush=True)
 
 
