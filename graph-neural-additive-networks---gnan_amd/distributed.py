@@ -133,7 +133,7 @@ def gather_operand(local: torch.Tensor, part: VertexPartition, group=None) -> to
 def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.Tensor, use_cnt: bool,
                         part: VertexPartition, order: str = "sum_first", out_channels: int = 1, group=None,
                         compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
-                        operand_dtype=torch.float32):
+                        operand_dtype=torch.float32, tables=None):
     """Forward of the node-level path on this rank's block; returns ``out[lo:hi, :out_channels]``.
 
     ``order='sum_first'`` exchanges the narrow ``[N, C]`` operand (what the drop-in modules do);
@@ -150,6 +150,8 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
     if compute is None and out_channels == 1:
         kw["pad_ok"] = True        # a ragged feature count may come back padded with zero columns: the read-out sums them away
+    if tables is not None:
+        kw["tables"] = tables
     operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True, **kw)
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
@@ -287,7 +289,7 @@ def build_halo_plan(graph_local, part: VertexPartition) -> HaloPlan:
 def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut: torch.Tensor, use_cnt: bool,
                            order: str = "reference", out_channels: int = 1, group=None,
                            compute: Optional[Dict[str, Callable]] = None, marks: Optional[Callable] = None,
-                           operand_dtype=torch.float32):
+                           operand_dtype=torch.float32, tables=None):
     """Forward on the owned rows from ``x_compact = x[plan.node_ids()]``; returns ``out[lo:hi, :out_channels]``.
     Same stages and ``marks`` as :func:`partitioned_forward`; there is no "gather" stage, and "total" only with > 1 rank."""
     ops = compute or _hip_compute()
@@ -297,6 +299,8 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     kw = {} if operand_dtype == torch.float32 else {"out_dtype": operand_dtype}
     if compute is None and out_channels == 1:
         kw["pad_ok"] = True        # a ragged feature count may come back padded with zero columns: the read-out sums them away
+    if tables is not None:
+        kw["tables"] = tables      # built ahead of time on a side stream (functional.TablePrefetch; inference loops)
     sum_first = order == "sum_first"
     # the column sums ride in the shape-function pass, restricted to the owned rows: they partition the nodes, so the
     # ranks' sums add up to the whole graph's without double counting

@@ -184,7 +184,7 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
 
 
 def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False,
-                  needs_grad: bool = False, out_dtype=torch.float32, total_rows: Optional[int] = None):
+                  needs_grad: bool = False, out_dtype=torch.float32, total_rows: Optional[int] = None, prebuilt=None):
     """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
     Returns ``(out, tables or None, total or None)``."""
     algo = FMLP_ALGO
@@ -200,6 +200,25 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
             return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows) \
                 if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype), None)
 
+        if prebuilt is not None:
+            # tables of THESE weights queued earlier, possibly on another stream (TablePrefetch): wait for that stream's
+            # build on the device, then look up as the speculative path does
+            prebuilt.join(torch.cuda.current_stream(x.device))
+            guess = prebuilt.speculative()
+            res = None
+            if guess is not None:
+                try:
+                    res = look_up(guess)
+                except _lib.GnanHipError:
+                    res = None
+            tables = prebuilt.resolve()
+            if tables is not None:
+                if res is None or not covers(guess, tables):
+                    res = look_up(tables)
+                return res[0], tables, res[1]
+            if algo == _lib.FMLP_PWL:
+                raise _lib.GnanHipError("shape functions need more pieces than the look-up kernel supports")
+            return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO), None, None
         if hip_build_applies(stacked) and torch.cuda.is_current_stream_capturing():
             # hipGraph capture (gnan_amd/graphed.py): no device->host copy may happen here, so the look-up is sized like
             # the speculative one — from the piece counts of the LAST eager forward, with room — and whoever replays the
@@ -256,6 +275,32 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
         a.workspace, a.workspace_bytes = _lib.ptr(ws), need
     _lib.check(_lib.lib().gnan_fmlp_fwd(a, _lib.stream_of(x)), "gnan_fmlp_fwd")
     return out
+
+
+class TablePrefetch:
+    """Software pipeline for inference loops: the tables of the NEXT forward are built on a side stream while the current
+    forward's look-up and aggregation run (the build occupies 64-129 workgroups for 0.05 ms and depends on the weights
+    only).  ``launch()`` queues a build of the current weights and returns a handle for ``feature_mlps(tables=...)``; the
+    consumer's stream waits for the build on the device, never on the host.  Every forward still gets a build of its own —
+    nothing is cached across forwards."""
+
+    def __init__(self, stacked: StackedMLP):
+        from .pwl import hip_build_applies
+        self.stacked = StackedMLP(*[_c(t) for t in stacked[:6]], *stacked[6:])
+        self.applies = hip_build_applies(self.stacked)
+        self.side = torch.cuda.Stream(device=self.stacked.w_last.device) if self.applies else None
+
+    def launch(self):
+        if not self.applies:
+            return None
+        from .pwl import build_tables_lazy
+        main = torch.cuda.current_stream(self.stacked.w_last.device)
+        self.side.wait_stream(main)               # the weights (and the allocator's reuse of freed blocks) are ordered
+        self.slot = 1 + (getattr(self, "slot", 1) % 2)          # two builds can be in flight: alternate read-back buffers
+        with torch.cuda.stream(self.side):
+            pending = build_tables_lazy(self.stacked, pinned_slot=self.slot)
+        pending.owner_stream = self.side
+        return pending
 
 
 HIP_TABLE_GRADS = os.environ.get("GNAN_HIP_TABLE_GRADS", "1") != "0"   # table path: parameter gradients by gnan_fpwl_param_grads
@@ -455,17 +500,31 @@ def _padded_stack(p: StackedMLP, Fp: int) -> StackedMLP:
 
 
 def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False,
-                 out_dtype=torch.float32, total_rows: Optional[int] = None, pad_ok: bool = False):
+                 out_dtype=torch.float32, total_rows: Optional[int] = None, pad_ok: bool = False, tables=None):
     """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157.
     ``return_total`` additionally returns the column sums of the result (the aggregation's rest-bucket operand),
     fused into the look-up kernel where possible.  ``out_dtype=torch.bfloat16`` stores the per-feature rows in bf16
     (inference only; one output channel), the operand format of the bf16-storage aggregation.  ``total_rows`` limits
     the column sums to the first rows (a rank's owned rows ahead of its halo rows, ``distributed.halo_recompute_forward``).
     ``pad_ok``: the caller accepts extra all-zero feature columns in the per-feature result (large inputs with a ragged
-    feature count are evaluated padded to a multiple of 16 features; without ``pad_ok`` the result is a strided view)."""
+    feature count are evaluated padded to a multiple of 16 features; without ``pad_ok`` the result is a strided view).
+    ``tables``: the tables of ``p`` queued ahead of time (:class:`TablePrefetch`; inference only — ignored where the table
+    path does not apply)."""
     _lib.require_device(x, p.w_last)
     if x.shape[1] != p.F:
         raise ValueError(f"x has {x.shape[1]} feature columns, the model was built for {p.F}")
+    if tables is not None and not (PAD_FEATURES and p.F % PAD_FEATURES and p.C == 1):
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in p[:6]):
+            raise _lib.GnanHipError("prefetched tables are an inference feature: run under torch.no_grad()")
+        fused_total = return_total and total_rows != 0
+        out, _, total = _fmlp_forward(x, p, sum_features, fused_total, False, out_dtype, total_rows, prebuilt=tables)
+        if not return_total:
+            return out
+        if total_rows == 0:
+            total = out.new_zeros(out.shape[1], dtype=torch.float32)
+        if total is None:
+            total = column_sums(out if total_rows is None else out[:total_rows])
+        return out, total
     if PAD_FEATURES and p.F % PAD_FEATURES and p.C == 1 and p.L >= 2 and x.shape[0] * p.F >= PAD_MIN_WORK:
         # Real inputs have F = raw features + the ones column (129 for arxiv / papers100M): rows that are not 16-byte
         # aligned and a last feature group that is not whole, i.e. the general look-up kernel, scalar operand gathers

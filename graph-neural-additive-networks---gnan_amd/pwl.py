@@ -215,15 +215,15 @@ class _GraphedBuild:
 _PINNED_META = {}
 
 
-def _pinned_meta(dev, n: int) -> torch.Tensor:
-    key = (dev, n)
+def _pinned_meta(dev, n: int, slot: int = 0) -> torch.Tensor:
+    key = (dev, n, slot)
     buf = _PINNED_META.get(key)
     if buf is None:
         buf = _PINNED_META[key] = torch.empty(n, dtype=torch.int32, pin_memory=True)
     return buf
 
 
-def _build_tables_hip(p, lazy: bool = False):
+def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0):
     """Tables by TWO kernel launches (``gnan_pwl_build``: a workgroup per feature finds the kinks and tabulates the
     network in float64, LDS-resident; a second tiny kernel packs the features back to back) and one
     device->host copy of the F+1 offsets.  Covers L in {2, 3}, H <= 128; same result as :func:`_build_padded`."""
@@ -252,7 +252,7 @@ def _build_tables_hip(p, lazy: bool = False):
         # BEFORE each replay (an eager build of the same weights) that the tables still fit the captured look-up
         return _PendingTables(meta, None, None, anchor, val, slope, F, C, (dev, F, p.L, p.H, C), keepalive + [scratch])
     # the ONE device->host copy of the build: into a cached pinned buffer, asynchronously; an event marks its arrival
-    pinned = _pinned_meta(dev, F + 2)
+    pinned = _pinned_meta(dev, F + 2, pinned_slot)      # builds in flight at the same time (TablePrefetch) use their own slots
     pinned.copy_(meta, non_blocking=True)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(dev))
@@ -270,6 +270,16 @@ class _PendingTables:
         self.meta, self.pinned, self.done = meta, pinned, done
         self.anchor, self.val, self.slope = anchor, val, slope
         self.F, self.C, self.key, self.keepalive = F, C, key, keepalive
+
+    def join(self, stream) -> None:
+        """Make ``stream`` wait (on the device) for this build if it was queued on another stream, and tell the allocator
+        that the tables are used there."""
+        owner = getattr(self, "owner_stream", None)
+        if owner is None or owner == stream:
+            return
+        stream.wait_event(self.done)
+        for t in (self.meta, self.anchor, self.val, self.slope):
+            t.record_stream(stream)
 
     def speculative(self) -> Optional[PwlTables]:
         """Tables sized from the LAST forward's piece counts (same power-of-two search depth, 1/8 more room per feature
@@ -323,9 +333,9 @@ def hip_build_applies(p) -> bool:
 
 
 @torch.no_grad()
-def build_tables_lazy(p):
+def build_tables_lazy(p, pinned_slot: int = 0):
     """Queue the table build and return a :class:`_PendingTables` (kernel route only; check :func:`hip_build_applies`)."""
-    return _build_tables_hip(p, lazy=True)
+    return _build_tables_hip(p, lazy=True, pinned_slot=pinned_slot)
 
 
 @torch.no_grad()

@@ -632,6 +632,34 @@ def test_speculative_lookup_survives_a_wrong_guess(C, monkeypatch):
     assert O.rel_err(fourth.cpu(), want.double().view(n, F, C).sum(1).cpu()) <= 1e-6
 
 
+def test_prefetched_tables_give_the_same_forward(monkeypatch):
+    """functional.TablePrefetch: the tables built ahead of time on a side stream are the tables the in-line build makes;
+    outputs, fused column sums and bf16 rows are bit-identical, several builds may be in flight, and gradients refuse them."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import TablePrefetch, feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    F, L, H, C, n = 32, 3, 64, 1, 50_000
+    sd = _mlp_state(F, L, H, C, True, seed=21)
+    st = _stack(sd, F, L, H, C, True)
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(3)).to(DEV)
+    pre = TablePrefetch(st)
+    assert pre.applies
+    with torch.no_grad():
+        want, want_total = feature_mlps(x, st, False, return_total=True, total_rows=n // 2)
+        first, second = pre.launch(), pre.launch()                     # two builds in flight
+        got, got_total = feature_mlps(x, st, False, return_total=True, total_rows=n // 2, tables=first)
+        again = feature_mlps(x, st, True, tables=second)
+        assert torch.equal(got, want) and torch.equal(got_total, want_total)
+        assert torch.equal(again, feature_mlps(x, st, True))
+        b16 = feature_mlps(x, st, False, out_dtype=torch.bfloat16, tables=pre.launch())
+        assert torch.equal(b16, feature_mlps(x, st, False, out_dtype=torch.bfloat16))
+    for t in st[:6]:
+        if t is not None:
+            t.requires_grad_(True)
+    with pytest.raises(_lib.GnanHipError, match="inference"):
+        feature_mlps(x, st, False, tables=pre.launch())
+
+
 @pytest.mark.parametrize("n,F", [(70_000, 64), (300_000, 16), (5000, 32)])
 def test_fused_column_sums_of_table_lookup(n, F, monkeypatch):
     """feature_mlps(return_total=True): the look-up kernel's fused column sums == a separate pass over its output."""
