@@ -507,6 +507,35 @@ def test_table_path_parameter_gradients_kernel(F, L, H, C, bias, n, sum_features
         assert float((by_name["b_last"].cpu().double() - b_last).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("fixed", [True, False])
+def test_table_path_parameter_gradients_edge_cases(fixed, monkeypatch):
+    """gnan_fpwl_param_grads on the float moments as well as the fixed-point ones; an all-zero upstream gradient (every piece
+    empty: nothing is walked) gives exact zeros; a single node; nodes far outside the kinks (only the two outer rays live)."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    monkeypatch.setattr(functional, "MOMENTS_FIXED_POINT", fixed)
+    F, L, H, C = 6, 3, 16, 2
+    sd = _mlp_state(F, L, H, C, True, seed=33)
+    for n, spread, gscale in [(700, 4.0, 1.0), (700, 4.0, 0.0), (1, 4.0, 1.0), (300, 1e4, 1.0)]:
+        x = ((torch.rand(n, F, generator=torch.Generator().manual_seed(n)) - 0.5) * spread).to(DEV)
+        gup = (torch.randn(n, F * C, generator=torch.Generator().manual_seed(4)) * gscale).to(DEV)
+        got = {}
+        for tag, on in (("hip", True), ("torch", False)):
+            monkeypatch.setattr(functional, "HIP_TABLE_GRADS", on)
+            st = _stack(sd, F, L, H, C, True)
+            leaves = [t for t in st[:6] if t is not None]
+            for t in leaves:
+                t.requires_grad_(True)
+            got[tag] = torch.autograd.grad(feature_mlps(x, st, False), leaves, gup)
+        scale = max(float(t.abs().max()) for t in got["torch"])
+        for a, b in zip(got["hip"], got["torch"]):
+            if gscale == 0.0:
+                assert float(a.abs().max()) == 0.0
+            else:
+                assert float((a - b).abs().max()) <= 2e-5 * scale, (n, spread, float((a - b).abs().max()), scale)
+
+
 @pytest.mark.parametrize("n,width,gscale", [(1000, 3, 1.0), (70000, 1, 1e-12), (5, 64, 1e20), (100, 2, 0.0)])
 def test_moment_scales_kernel(n, width, gscale):
     """gnan_fpwl_moment_scales == the framework formula it replaced (powers of two from max|grad| and max|x - anchor|)."""
