@@ -802,7 +802,54 @@ struct GradParams {
   float* slice_T;        // [n_slices, 4, W]
   int reduce_rows;
   int64_t n_row_blocks;
+  // BWD mode (gnan_spmm_bwd_narrow): the traversal runs over the TRANSPOSED adjacency, p.S holds one row per (neighbour,
+  // hop code), 2 * half wide: [ dY_i / cnt(i, d) | dY_i / cnt(i, rest) ]; row j's own operand row S_j is contracted with
+  // the per-code sums for the table gradient and the same sums, weighted by the table, are its operand gradient
+  const float* s_rows;   // [n_rows, w_real] operand rows of the OUTPUT rows
+  int64_t s_rows_stride;
+  int half, w_real;      // p.W == 2 * half (half a power of two >= w_real)
+  float* dS;             // [n_rows, w_real]
+  int64_t ds_stride;
+  int with_rest;
 };
+
+// BWD epilogue of one row for this lane's VEC columns: lanes of the first half hold A_d = sum over the row's code-d pairs
+// of dY / cnt(., d), their partners (half columns further) Q = sum over ALL pairs of dY / cnt(., rest).
+//   dS_j = sum_{d < rest} lut[d] A_d - lut[rest] Q        dlut[d] += <S_j, A_d>      dlut[rest] -= <S_j, Q>
+template <int VEC, int LPR>
+__device__ __forceinline__ void bwd_finish(const Params& p, const GradParams& gp, int64_t oq, int cw,
+                                           Vec<VEC> (&t)[4], float (&pd)[4]) {
+  const int rest = p.D - 1;
+  const bool listed_rest = !gp.with_rest;        // no rest bucket: code D-1 is an ordinary listed shell
+  float all[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) all[v] = t[0].v[v] + t[1].v[v] + t[2].v[v] + t[3].v[v];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    // Q of this column: the partner lane's sum over all codes (same v) — or, with one lane per row (rows of 2 or 4
+    // floats), the value `half` positions further in this lane's own vector
+    float q;
+    if constexpr (LPR == 1) q = all[(v + VEC / 2) % VEC];
+    else q = __shfl_xor(all[v], LPR / 2);
+    const int w = cw + v;
+    if (w < gp.w_real) {
+      const float sj = gp.s_rows[oq * gp.s_rows_stride + w];
+      float ds = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        if (d < rest || (listed_rest && d == rest)) {
+          ds = fmaf(p.lut[d], t[d].v[v], ds);
+          pd[d] = fmaf(sj, t[d].v[v], pd[d]);
+        }
+      }
+      if (gp.with_rest) {
+        ds = fmaf(-p.lut[rest], q, ds);
+        pd[rest & 3] = fmaf(-sj, q, pd[rest & 3]);
+      }
+      gp.dS[oq * gp.ds_stride + w] = ds;
+    }
+  }
+}
 
 template <int VEC>
 __device__ __forceinline__ void grad_finish(const Params& p, const GradParams& gp, int64_t i, int64_t oq, int cw,
@@ -837,7 +884,7 @@ __device__ __forceinline__ float grad_inv(const Params& p, int64_t i, int d) {
   return 1.f / static_cast<float>(c > 1 ? c : 1);
 }
 
-template <int VEC, int LPR>
+template <int VEC, int LPR, bool BWD = false>
 __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, const GradParams gp) {
   constexpr int G = kWave / LPR;
   constexpr int TILE = LPR * VEC;
@@ -883,7 +930,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
           int d = __shfl(codev, j);
           d = d < rest ? d : rest;
           if (j < m && col_ok) {
-            const Vec<VEC> sv = load_operand<VEC>(p.S, c, p.s_stride, cw);
+            const Vec<VEC> sv = load_operand<VEC>(p.S, BWD ? static_cast<int64_t>(c) * p.D + d : static_cast<int64_t>(c), p.s_stride, cw);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd)
 #pragma unroll
@@ -966,7 +1013,8 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
               d[u] = d[u] < rest ? d[u] : rest;
 #pragma unroll
               for (int v = 0; v < VEC; ++v) sv[u].v[v] = 0.f;
-              if (j < m && col_ok) sv[u] = load_operand<VEC>(p.S, c, p.s_stride, cw);
+              if (j < m && col_ok)
+                sv[u] = load_operand<VEC>(p.S, BWD ? static_cast<int64_t>(c) * p.D + d[u] : static_cast<int64_t>(c), p.s_stride, cw);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -977,14 +1025,17 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
                   for (int v = 0; v < VEC; ++v) t[dd].v[v] += d[u] == dd ? sv[u].v[v] : 0.f;
           }
         }
-        grad_finish<VEC>(p, gp, i, oq, cw, col_ok, t, pd);
+        if constexpr (BWD) bwd_finish<VEC, LPR>(p, gp, oq, cw, t, pd);       // one pass: 2 * half == LPR * VEC
+        else grad_finish<VEC>(p, gp, i, oq, cw, col_ok, t, pd);
       }
 #pragma unroll
       for (int off = 1; off < LPR; off <<= 1)
 #pragma unroll
         for (int d = 0; d < 4; ++d) pd[d] += __shfl_xor(pd[d], off);
+      if constexpr (!BWD) {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) pd[d] *= grad_inv(p, i, d);
+        for (int d = 0; d < 4; ++d) pd[d] *= grad_inv(p, i, d);
+      }
       if (!gp.reduce_rows && sub == 0)
         for (int d = 0; d < p.D; ++d) gp.dwt[oq * p.D + d] = pd[d];
     }
@@ -1003,6 +1054,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
 }
 
 // hub rows: add the slices in order, contract with dY, scale; one workgroup per hub row
+template <bool BWD = false>
 __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p, const GradParams gp) {
   // one wave per hub row (four rows per workgroup, no barriers), as in spmm_long_fixup_kernel: lane = column, operands
   // narrower than a wave put K = 64 / W' lanes on a column, lane k takes slices k, k + K, ...
@@ -1041,7 +1093,26 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
     for (int off = wp; off < kWave; off <<= 1)   // slice lanes of a column: fixed butterfly, every lane ends with the sum
 #pragma unroll
       for (int d = 0; d < 4; ++d) t[d] += __shfl_xor(t[d], off);
-    if (k == 0 && w < p.W) {
+    if constexpr (BWD) {
+      // one pass (2 * half <= 64 columns): the lane `half` columns further holds this column's Q
+      const float all = t[0] + t[1] + t[2] + t[3];
+      const float qv = __shfl_xor(all, gp.half);
+      if (k == 0 && w < gp.w_real) {
+        const float sj = gp.s_rows[oq * gp.s_rows_stride + w];
+        float ds = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          if (d < rest || (!gp.with_rest && d == rest)) {
+            ds = fmaf(p.lut[d], t[d], ds);
+            pd[d] += static_cast<double>(sj) * t[d];
+          }
+        if (gp.with_rest) {
+          ds = fmaf(-p.lut[rest], qv, ds);
+          pd[rest & 3] -= static_cast<double>(sj) * qv;
+        }
+        gp.dS[oq * gp.ds_stride + w] = ds;
+      }
+    } else if (k == 0 && w < p.W) {
       if (p.s_total) {
         float lower = 0.f;
 #pragma unroll
@@ -1064,7 +1135,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
     mine = d == 1 ? pd[1] : mine;
     mine = d == 2 ? pd[2] : mine;
     mine = d == 3 ? pd[3] : mine;
-    const double v = mine * grad_inv(p, i, d);
+    const double v = BWD ? mine : mine * grad_inv(p, i, d);
     if (gp.reduce_rows) gp.blk[(gp.n_row_blocks + r) * 4 + d] = v;
     else if (d < p.D) gp.dwt[oq * p.D + d] = static_cast<float>(v);
   }
@@ -1107,17 +1178,17 @@ __global__ __launch_bounds__(1024) void spmm_lut_grad_final_kernel(const double*
   if (static_cast<int>(threadIdx.x) < D && threadIdx.x < 4) out[threadIdx.x] = static_cast<float>(red[threadIdx.x][0]);
 }
 
-template <int VEC, int LPR>
+template <int VEC, int LPR, bool BWD = false>
 int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut) {
   constexpr int G = kWave / LPR;
   const int64_t row_blocks = (p.n_rows + 4 * G - 1) / (4 * G);
   gp.n_row_blocks = row_blocks;
   const int64_t blocks = row_blocks + p.n_slices;
   if (blocks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "lut_grad: too many rows for one launch");
-  hipLaunchKernelGGL((spmm_lut_grad_kernel<VEC, LPR>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p, gp);
+  hipLaunchKernelGGL((spmm_lut_grad_kernel<VEC, LPR, BWD>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p, gp);
   if (int rc = gnan::check_launch("spmm_lut_grad_kernel")) return rc;
   if (p.n_slices > 0) {
-    hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p, gp);
+    hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel<BWD>, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p, gp);
     if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
   }
   if (gp.reduce_rows) {
@@ -1125,6 +1196,10 @@ int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut)
     return gnan::check_launch("spmm_lut_grad_final_kernel");
   }
   return GNAN_OK;
+}
+
+__global__ void zero_floats_kernel(float* out, int n) {     // (a kernel: captured memsets replay wrongly on ROCm 7.2)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = 0.f;
 }
 
 template <int VEC>
@@ -1165,8 +1240,8 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->n_rows == 0) {
     if (reduce_rows) {
-      hipError_t e = hipMemsetAsync(dwt, 0, static_cast<size_t>(a->D) * sizeof(float), st);
-      if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "lut_grad: hipMemsetAsync: %s", hipGetErrorString(e));
+      hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, dwt, a->D);
+      return gnan::check_launch("zero_floats_kernel");
     }
     return GNAN_OK;
   }
@@ -1188,6 +1263,58 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
   gp.blk = reinterpret_cast<double*>(static_cast<char*>(workspace) + off);
   gp.n_row_blocks = 0;
   return vec == 4 ? launch_lut_grad_lpr<4>(p, gp, lpr, st, dwt) : launch_lut_grad_lpr<1>(p, gp, lpr, st, dwt);
+}
+
+extern "C" size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a) {
+  if (!a || a->n_rows <= 0) return 0;
+  const int half = a->W / 2;
+  const int vec = half <= 2 ? 2 * (half < 1 ? 1 : half) : 4;
+  const int lpr = a->W / vec >= 1 ? a->W / vec : 1;
+  size_t bytes = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
+  bytes = (bytes + 15) / 16 * 16;
+  return bytes + lut_grad_blk_entries(a, vec, lpr) * 4 * sizeof(double);
+}
+
+extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows, int64_t s_rows_stride, int32_t w_real,
+                                    int32_t with_rest, float* dS, int64_t ds_stride, float* dlut, void* workspace,
+                                    size_t workspace_bytes, gnan_stream_t stream) {
+  if (int rc = validate(a)) return rc;
+  GNAN_REQUIRE(dS != nullptr && dlut != nullptr && (s_rows != nullptr || a->n_rows == 0), "bwd_narrow: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->s_dtype != GNAN_F32 || a->lut_row_stride != 0 || a->cnt != nullptr)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "bwd_narrow: needs the CSR layout, D <= 4, one global weight channel, fp32 rows, no cnt");
+  const int half = a->W / 2;
+  if (a->W < 2 || a->W > 64 || (a->W & (a->W - 1)) != 0 || w_real < 1 || w_real > half || a->s_stride != a->W)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "bwd_narrow: operand rows must be 2 * half floats, half a power of two in [w_real, 32] (got W=%d, w_real=%d)", a->W, w_real);
+  GNAN_REQUIRE(s_rows_stride >= w_real && ds_stride >= w_real, "bwd_narrow: row stride smaller than the width");
+  if (a->n_rows == 0) {
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, dlut, a->D);
+    return gnan::check_launch("zero_floats_kernel");
+  }
+  const size_t need = gnan_spmm_bwd_narrow_workspace_bytes(a);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "bwd_narrow: workspace %zu B < required %zu B", workspace_bytes, need);
+  const Params p = make_params(a);
+  // the two halves of a row must sit in different lanes, partner = lane + LPR / 2: VEC = min(4, half), LPR = 2 * half / VEC
+  if (reinterpret_cast<uintptr_t>(a->S) % 16 != 0)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "bwd_narrow: operand rows must be 16-byte aligned");
+  GradParams gp;
+  gp.dY = nullptr; gp.dy_stride = 0; gp.dy_channels = 1; gp.dwt = dlut; gp.reduce_rows = 1;
+  gp.slice_T = static_cast<float*>(workspace);
+  size_t off = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
+  off = (off + 15) / 16 * 16;
+  gp.blk = reinterpret_cast<double*>(static_cast<char*>(workspace) + off);
+  gp.n_row_blocks = 0;
+  gp.s_rows = s_rows; gp.s_rows_stride = s_rows_stride; gp.half = half; gp.w_real = w_real;
+  gp.dS = dS; gp.ds_stride = ds_stride; gp.with_rest = with_rest;
+  switch (half) {      // one lane per row while a row is one 8- or 16-byte load (64 rows per wavefront instead of 32)
+    case 1: return launch_lut_grad<2, 1, true>(p, gp, st, dlut);
+    case 2: return launch_lut_grad<4, 1, true>(p, gp, st, dlut);
+    case 4: return launch_lut_grad<4, 2, true>(p, gp, st, dlut);
+    case 8: return launch_lut_grad<4, 4, true>(p, gp, st, dlut);
+    case 16: return launch_lut_grad<4, 8, true>(p, gp, st, dlut);
+    default: return launch_lut_grad<4, 16, true>(p, gp, st, dlut);
+  }
 }
 
 extern "C" int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream) {

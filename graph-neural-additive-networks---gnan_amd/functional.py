@@ -693,6 +693,32 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
     return out.unsqueeze(-1)
 
 
+NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"   # dS and dlut from one transposed pass
+
+
+def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int):
+    """``gnan_spmm_bwd_narrow`` over the transposed adjacency ``gt``: returns ``(dS [n, W], dlut [D])`` — see the header for
+    the layout of ``V [n_fwd_rows * D, 2 * half]``."""
+    _lib.require_device(V, S_rows, lut, gt.code)
+    V = _rows(V.detach().float())
+    S_rows = _rows(S_rows.detach().float())
+    lut = lut.detach().float().reshape(-1, 1).contiguous()
+    D = lut.shape[0]
+    n_out = gt.n_rows
+    dS = torch.empty((n_out, W), dtype=torch.float32, device=V.device)
+    dlut = torch.empty(D, dtype=torch.float32, device=V.device)
+    plan = gt.narrow_row_plan() if (V.shape[1] * 4 <= 8 and NARROW_ROW_SLICING) else gt.long_row_plan()
+    a = _spmm_args(gt, V, lut, False, None, dS, None, False, plan=plan)
+    a.n_cols = gt.n_cols                              # rows of V = n_cols * D (checked by the kernel's addressing only)
+    a.y_stride = V.shape[1]                           # Y is not written by this entry point (dS is); keeps validate() content
+    need = _lib.lib().gnan_spmm_bwd_narrow_workspace_bytes(a)
+    ws = torch.empty(need // 8 + 2, dtype=torch.float64, device=V.device)
+    _lib.check(_lib.lib().gnan_spmm_bwd_narrow(a, _lib.ptr(S_rows), S_rows.stride(0), W, int(with_rest), _lib.ptr(dS), dS.stride(0),
+                                               _lib.ptr(dlut), _lib.ptr(ws), ws.numel() * 8, _lib.stream_of(V)),
+               "gnan_spmm_bwd_narrow")
+    return dS, dlut
+
+
 class _NotShared:
     """Sentinel: the rest-bucket total is this process's own (``None`` already means "the default process group")."""
     def __repr__(self):
@@ -732,8 +758,27 @@ class _RhoAggregate(torch.autograd.Function):
         cnt = g.cnt if rows is None else g.cnt[rows]
         inv = (1.0 / cnt.clamp_min(1).float()) if use_cnt else None            # [n_out, D]
         dS = dlut = None
+        fused_bwd = (NARROW_FUSED_BACKWARD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not g.is_dense
+                     and Cw == 1 and D <= 4 and not per_row and rows is None and not ctx.reduce_cr and W <= 16
+                     and S.dtype == torch.float32)
+        if fused_bwd:
+            # narrow operand, both gradients wanted: ONE pass over the transposed adjacency gathers, per pair, the packed row
+            # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
+            # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
+            half = 1 << max(0, (W - 1).bit_length())
+            invc = (1.0 / g.cnt.clamp_min(1).float()) if use_cnt else torch.ones((g.n_rows, D), device=dY.device)
+            V = torch.zeros((g.n_rows, D, 2 * half), dtype=torch.float32, device=dY.device)
+            V[:, :, :W] = dY.unsqueeze(1) * invc.unsqueeze(-1)
+            Q = dY * invc[:, D - 1:D] if with_rest else None
+            if with_rest:
+                V[:, :, half:half + W] = Q.unsqueeze(1)
+            dS, dl = bwd_narrow_launch(g.transposed(), V.view(g.n_rows * D, 2 * half), S, lut[:, 0], with_rest, W)
+            if with_rest:
+                total = ctx.s_total if ctx.s_total is not None else column_sums(S)
+                dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * Q.sum(0)).sum()).reshape(1)])
+            dlut = dl.view(D, 1)
 
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not fused_bwd:
             dY_full = dY
             if rows is not None:
                 dY_full = torch.zeros((g.n_rows, W), dtype=torch.float32, device=dY.device)
@@ -753,6 +798,7 @@ class _RhoAggregate(torch.autograd.Function):
             else:
                 dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
                                  weight_by_col=True, minus_rest=with_rest)
+        if ctx.needs_input_grad[0]:
             if with_rest:
                 # d/dS_j of  wt(i, rest) * total  : the same vector for every j
                 l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
@@ -769,7 +815,9 @@ class _RhoAggregate(torch.autograd.Function):
                 else:                          # only the first rows of S went into the total (owned rows ahead of halo rows)
                     dS[: ctx.total_rows] += v
 
-        if ctx.needs_input_grad[1] and fused_lut_grad and not per_row:
+        if fused_bwd:
+            pass                                  # both gradients came out of the one transposed pass above
+        elif ctx.needs_input_grad[1] and fused_lut_grad and not per_row:
             dlut = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, True)       # [D, 1]
         elif ctx.needs_input_grad[1]:
             if fused_lut_grad:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 21
+#define GNAN_ABI_VERSION 22
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -377,6 +377,26 @@ size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduc
 int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stride, int32_t dy_channels,
                        float* dwt, int32_t reduce_rows, void* workspace, size_t workspace_bytes,
                        gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of gnan_spmm_fwd for NARROW operands, both gradients from ONE pass over the transposed adjacency (CSR layout,
+ * D <= 4, one global weight channel, fp32) — autograd through GNAN.py:67-73 / models.py:368-376 w.r.t. f_sums and rho's
+ * outputs, for the sum-first evaluation (W = out_channels).
+ * `a` describes the TRANSPOSED adjacency (row j = a node as neighbour, its pairs (i, code) = the forward rows that list it);
+ * a->S holds one row per (forward row i, hop code d), a->W = 2 * half floats wide (half a power of two >= w_real):
+ *     [ dY_i / cnt(i, d)  (w_real floats, zero padded to half) | dY_i / cnt(i, D-1)  (likewise; zeros without a rest bucket) ]
+ * a->lut is the global table [D] (a->Cw = 1, a->lut_row_stride = 0, a->cnt = NULL: the counts are folded into a->S).
+ *   dS[j, :]   = sum_{d} lut[d] * A_d[j] - lut[D-1] * Q[j]       A_d[j] = sum of the first halves over j's code-d pairs,
+ *                                                                 Q[j]  = sum of the second halves over all of j's pairs
+ *   dlut[d]    = sum_j < s_rows[j, :], A_d[j] >   (d < D-1, or every d without a rest bucket)
+ *   dlut[D-1]  = - sum_j < s_rows[j, :], Q[j] >   (with_rest; the caller adds < s_total, sum_i dY_i / cnt(i, D-1) >)
+ * s_rows [n_rows, w_real] are the operand rows of the forward pass (S itself).  Fixed-order float64 partials: bit-reproducible.
+ * It replaces gnan_spmm_fwd(s_by_code) + gnan_spmm_lut_grad — two traversals of the same pairs — by one.
+ * ------------------------------------------------------------------------------------------- */
+size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a);
+int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows, int64_t s_rows_stride, int32_t w_real,
+                         int32_t with_rest, float* dS, int64_t ds_stride, float* dlut, void* workspace,
+                         size_t workspace_bytes, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs hop distances on the GPU (graphs small enough for N x N bytes)

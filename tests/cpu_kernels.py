@@ -81,13 +81,35 @@ def lut_grad_launch(g, S, dY, D, use_cnt, with_rest, row_ids, s_total, reduce_ro
     return out.float().unsqueeze(-1)
 
 
+def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W):
+    D = lut.numel()
+    half = V.shape[1] // 2
+    row_of_pair, col, code = _pairs(gt)                     # rows of gt = nodes as neighbours; col = the forward row listing them
+    Vd = V.detach().double()[col * D + code]
+    n = gt.n_rows
+    A = torch.zeros((n * D, half), dtype=torch.float64).index_add_(0, row_of_pair * D + code, Vd[:, :half]).view(n, D, half)[:, :, :W]
+    Q = torch.zeros((n, half), dtype=torch.float64).index_add_(0, row_of_pair, Vd[:, half:])[:, :W]
+    l, Sd, rest = lut.detach().double().reshape(-1), S_rows.detach().double(), D - 1
+    ds, dl = torch.zeros((n, W), dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
+    for d in range(D):
+        if d < rest or not with_rest:
+            ds += l[d] * A[:, d]
+            dl[d] = (Sd * A[:, d]).sum()
+    if with_rest:
+        ds -= l[rest] * Q
+        dl[rest] = -(Sd * Q).sum()
+    return ds.float(), dl.float()
+
+
 def install():
     """Swap the stand-ins in (call inside the test process / spawned worker; undo with the returned function)."""
     from gnan_amd import _lib, functional
-    saved = {name: getattr(functional, name) for name in ("spmm_launch", "shell_sums_launch", "lut_grad_launch", "column_sums")}
+    saved = {name: getattr(functional, name) for name in ("spmm_launch", "shell_sums_launch", "lut_grad_launch", "column_sums",
+                                                          "bwd_narrow_launch")}
     saved_req = _lib.require_device
     functional.spmm_launch, functional.shell_sums_launch = spmm_launch, shell_sums_launch
     functional.lut_grad_launch, functional.column_sums = lut_grad_launch, column_sums
+    functional.bwd_narrow_launch = bwd_narrow_launch
     _lib.require_device = lambda *a, **k: None
 
     def undo():

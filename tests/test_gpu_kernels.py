@@ -784,6 +784,42 @@ def test_fused_table_gradient_equals_shell_sums_route(W, dyc, use_cnt, with_rest
         assert torch.equal(total, lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, True))   # fixed order
 
 
+@pytest.mark.parametrize("W,K,use_cnt,with_rest", [(1, 1, True, True), (1, 2, True, True), (2, 1, False, True), (3, 2, True, True),
+                                                     (4, 1, True, False), (8, 2, True, True), (16, 1, True, True), (5, 2, False, False)])
+def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, monkeypatch):
+    """gnan_spmm_bwd_narrow (operand gradient AND table gradient from one pass over the transposed adjacency) == the
+    two-pass route (pre-weighted gather + gnan_spmm_lut_grad) == autograd through the float64 oracle; hub columns (sliced
+    rows of the transposed graph), empty rows, padded widths; bit-reproducible."""
+    from gnan_amd import functional
+    from gnan_amd.functional import rho_aggregate
+    rng = np.random.default_rng(W * 11 + K)
+    n, D = 3000, K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 2500)])
+    col[rng.random(col.shape[0]) < 0.25] = 11                      # node 11 is listed by ~5000 rows: a hub of the transposed graph
+    col[(rng.random(col.shape[0]) < 0.03)] = 12                    # ... and node 12 by ~600 (between the two hub thresholds)
+    g = _graph(rowptr, col, code, n, D)
+    S0 = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut0 = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    got = {}
+    for tag, on in (("fused", True), ("two_pass", False), ("fused2", True)):
+        monkeypatch.setattr(functional, "NARROW_FUSED_BACKWARD", on)
+        S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+        Y = rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest)
+        got[tag] = torch.autograd.grad(Y, [S, lut], up)
+    S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    want = O.spmm_csr(rowptr, col, code, S64, wt, with_rest=with_rest)
+    dS64, dlut64 = torch.autograd.grad(want, [S64, lut64], up.cpu().double())
+    for k, ref in ((0, dS64), (1, dlut64)):
+        scale = float(ref.abs().max())
+        assert float((got["fused"][k].cpu().double() - ref).abs().max()) <= 2e-5 * scale, (k, scale)
+        assert float((got["two_pass"][k].cpu().double() - ref).abs().max()) <= 2e-5 * scale
+        assert torch.equal(got["fused"][k], got["fused2"][k])
+
+
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
     place == rows processed in natural order (same arithmetic per row)."""
