@@ -1265,6 +1265,48 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
   return vec == 4 ? launch_lut_grad_lpr<4>(p, gp, lpr, st, dwt) : launch_lut_grad_lpr<1>(p, gp, lpr, st, dwt);
 }
 
+namespace {
+// V[i * D + d, :] = [ dY_i / cnt(i, d) | dY_i / cnt(i, D-1) ]  (the packed operand of gnan_spmm_bwd_narrow), zero padded
+__global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restrict__ dY, int64_t dy_stride, int W,
+                                                            const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
+                                                            int64_t n, int with_rest, float* __restrict__ V, int half) {
+  const int64_t total = n * D * 2 * half;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int c = static_cast<int>(e % (2 * half));
+    const int64_t id = e / (2 * half);
+    const int d = static_cast<int>(id % D);
+    const int64_t i = id / D;
+    const bool second = c >= half;
+    const int w = second ? c - half : c;
+    float v = 0.f;
+    if (w < W && (!second || with_rest)) {
+      const int dd = second ? D - 1 : d;
+      float r = 1.f;
+      if (cnt) {
+        const int k = cnt[i * cnt_stride + dd];
+        r = static_cast<float>(k > 1 ? k : 1);
+      }
+      v = dY[i * dy_stride + w] / r;
+    }
+    V[e] = v;
+  }
+}
+}  // namespace
+
+extern "C" int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32_t W, const int32_t* cnt, int64_t cnt_stride,
+                                       int32_t D, int64_t n, int32_t with_rest, float* V, int32_t half, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && W >= 1 && D >= 1 && half >= W && (half & (half - 1)) == 0, "pack_bwd_rows: bad sizes");
+  GNAN_REQUIRE((dY && V) || n == 0, "pack_bwd_rows: null pointer");
+  GNAN_REQUIRE(dy_stride >= W && (cnt == nullptr || cnt_stride >= D), "pack_bwd_rows: row stride smaller than the width");
+  if (n == 0) return GNAN_OK;
+  const int64_t total = n * D * 2 * half;
+  int64_t blocks = (total + 256 * 4 - 1) / (256 * 4);
+  blocks = blocks > 65536 ? 65536 : blocks;
+  hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half);
+  return gnan::check_launch("pack_bwd_rows_kernel");
+}
+
 extern "C" size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a) {
   if (!a || a->n_rows <= 0) return 0;
   const int half = a->W / 2;

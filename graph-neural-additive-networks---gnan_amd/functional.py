@@ -696,6 +696,18 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
 NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"   # dS and dlut from one transposed pass
 
 
+def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int) -> torch.Tensor:
+    """``V[i, d] = [dY_i / cnt(i, d) | dY_i / cnt(i, D-1)]``, halves zero padded to ``half`` floats (``gnan_spmm_pack_bwd_rows``)."""
+    _lib.require_device(dY)
+    dY = _rows(dY.detach().float())
+    n, W = dY.shape
+    V = torch.empty((n, D, 2 * half), dtype=torch.float32, device=dY.device)
+    c = None if cnt is None else cnt.contiguous()
+    _lib.check(_lib.lib().gnan_spmm_pack_bwd_rows(_lib.ptr(dY), dY.stride(0), W, _lib.ptr(c), 0 if c is None else c.stride(0), D, n,
+                                                  int(with_rest), _lib.ptr(V), half, _lib.stream_of(dY)), "gnan_spmm_pack_bwd_rows")
+    return V
+
+
 def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int):
     """``gnan_spmm_bwd_narrow`` over the transposed adjacency ``gt``: returns ``(dS [n, W], dlut [D])`` — see the header for
     the layout of ``V [n_fwd_rows * D, 2 * half]``."""
@@ -766,16 +778,12 @@ class _RhoAggregate(torch.autograd.Function):
             # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
             # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
             half = 1 << max(0, (W - 1).bit_length())
-            invc = (1.0 / g.cnt.clamp_min(1).float()) if use_cnt else torch.ones((g.n_rows, D), device=dY.device)
-            V = torch.zeros((g.n_rows, D, 2 * half), dtype=torch.float32, device=dY.device)
-            V[:, :, :W] = dY.unsqueeze(1) * invc.unsqueeze(-1)
-            Q = dY * invc[:, D - 1:D] if with_rest else None
-            if with_rest:
-                V[:, :, half:half + W] = Q.unsqueeze(1)
+            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half)              # [n, D, 2 * half]
             dS, dl = bwd_narrow_launch(g.transposed(), V.view(g.n_rows * D, 2 * half), S, lut[:, 0], with_rest, W)
             if with_rest:
                 total = ctx.s_total if ctx.s_total is not None else column_sums(S)
-                dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * Q.sum(0)).sum()).reshape(1)])
+                q_sum = column_sums(V[:, 0, half:half + W])                                    # sum_i dY_i / cnt(i, rest)
+                dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
             dlut = dl.view(D, 1)
 
         if ctx.needs_input_grad[0] and not fused_bwd:

@@ -81,6 +81,17 @@ def lut_grad_launch(g, S, dY, D, use_cnt, with_rest, row_ids, s_total, reduce_ro
     return out.float().unsqueeze(-1)
 
 
+def pack_bwd_rows(dY, cnt, D, with_rest, half):
+    dY = dY.detach().float()
+    n, W = dY.shape
+    den = torch.ones((n, D)) if cnt is None else cnt.clamp_min(1).float()
+    V = torch.zeros((n, D, 2 * half))
+    V[:, :, :W] = dY.unsqueeze(1) / den.unsqueeze(-1)
+    if with_rest:
+        V[:, :, half:half + W] = (dY / den[:, D - 1:D]).unsqueeze(1)
+    return V
+
+
 def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W):
     D = lut.numel()
     half = V.shape[1] // 2
@@ -105,11 +116,11 @@ def install():
     """Swap the stand-ins in (call inside the test process / spawned worker; undo with the returned function)."""
     from gnan_amd import _lib, functional
     saved = {name: getattr(functional, name) for name in ("spmm_launch", "shell_sums_launch", "lut_grad_launch", "column_sums",
-                                                          "bwd_narrow_launch")}
+                                                          "bwd_narrow_launch", "pack_bwd_rows")}
     saved_req = _lib.require_device
     functional.spmm_launch, functional.shell_sums_launch = spmm_launch, shell_sums_launch
     functional.lut_grad_launch, functional.column_sums = lut_grad_launch, column_sums
-    functional.bwd_narrow_launch = bwd_narrow_launch
+    functional.bwd_narrow_launch, functional.pack_bwd_rows = bwd_narrow_launch, pack_bwd_rows
     _lib.require_device = lambda *a, **k: None
 
     def undo():

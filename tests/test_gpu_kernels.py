@@ -820,6 +820,26 @@ def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, m
         assert torch.equal(got["fused"][k], got["fused2"][k])
 
 
+@pytest.mark.parametrize("W,D,use_cnt,with_rest", [(1, 3, True, True), (3, 4, True, True), (4, 3, False, True), (16, 3, True, False),
+                                                     (5, 2, False, False)])
+def test_packed_backward_rows_kernel(W, D, use_cnt, with_rest):
+    """gnan_spmm_pack_bwd_rows == the slicing restatement (tests/cpu_kernels.py): [dY / cnt(i, d) | dY / cnt(i, rest)],
+    zero padded halves, strided gradient rows, counts of 0 treated as 1; empty input."""
+    from gnan_amd.functional import pack_bwd_rows
+    import cpu_kernels
+    rng = np.random.default_rng(W * 7 + D)
+    n = 4097
+    half = 1 << max(0, (W - 1).bit_length())
+    wide = torch.from_numpy(rng.standard_normal((n, W + 3)).astype(np.float32)).to(DEV)
+    dY = wide[:, 1:1 + W]                                                                   # row stride W + 3
+    cnt = torch.from_numpy(rng.integers(0, 50, (n, D)).astype(np.int32)).to(DEV) if use_cnt else None
+    V = pack_bwd_rows(dY, cnt, D, with_rest, half)
+    want = cpu_kernels.pack_bwd_rows(dY.cpu(), None if cnt is None else cnt.cpu(), D, with_rest, half)
+    assert V.shape == (n, D, 2 * half)
+    assert torch.equal(V.cpu(), want)                                    # correctly rounded division, zero padding
+    assert pack_bwd_rows(dY[:0], None if cnt is None else cnt[:0], D, with_rest, half).shape == (0, D, 2 * half)
+
+
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
     place == rows processed in natural order (same arithmetic per row)."""
