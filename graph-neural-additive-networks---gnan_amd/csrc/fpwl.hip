@@ -12,6 +12,7 @@
 // of a node cover one 64-B sector of x and of fx.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -419,6 +420,8 @@ __global__ __launch_bounds__(256) void fpwl_total_kernel(const double* __restric
 // two points per piece.  Same traversal as the forward; bins live in LDS (ds_add_f32) and are flushed with
 // one global atomic per bin per workgroup.
 // ---------------------------------------------------------------------------------------------
+int tuned_moment_block(int64_t n, int n_groups, size_t lds, int bs);
+
 struct MomentParams {
   Params f;            // x, tables, grouping as in the forward (val / slope / out unused)
   const float* g;      // upstream gradient: [n, F*C] (per feature) or [n, C] (sum_features)
@@ -429,6 +432,7 @@ struct MomentParams {
   // and — integer addition being associative — bit-reproducible.  scales = {2^e0, 2^e1} for M0 / M1 terms.
   const double* scales;
   unsigned long long* Mi;   // [T, 2, C] two's-complement sums, zeroed by the caller
+  int vec_g;                // gradient rows may be read as 16-byte quads (C == 1, per-feature gradient)
 };
 
 template <int FG, int BS, bool FIXED>
@@ -593,6 +597,150 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
   }
 }
 
+// round(v * s) as a two's-complement 64-bit integer for a power of two s and |v * s| < 2^51: one fused multiply-add onto
+// 1.5 * 2^52 leaves the integer in the low mantissa bits (round to nearest even, like __double2ll_rn, whose library
+// routine costs ~10 float64 instructions — v_rndne, v_ldexp, v_floor, v_fma, two conversions).  gnan_fpwl_moment_scales
+// caps its exponents so that every term stays below 2^50.
+__device__ __forceinline__ unsigned long long fixed_bits(float v, double s) {
+  const double d = fma(static_cast<double>(v), s, 6755399441055744.0);
+  return static_cast<unsigned long long>(__double_as_longlong(d)) - 0x4338000000000000ull;
+}
+
+// C == 1 specialisation of the fixed-point moments (round 2).  The general kernel above spends, per (node, feature) and
+// AFTER the search, a dependent global load of the gradient (the channel loop is a run-time loop), two library
+// float64 -> int64 conversions and a random LDS read of the piece's anchor: five dependent memory latencies per node and
+// 4 waves per SIMD (58 KB of LDS per 512 threads).  Here the gradient travels with the x row (one request each, issued
+// together), the anchor of the piece is the last tree entry the search stepped right at (one v_cndmask per step, no
+// anchor array in LDS: 50 KB per workgroup, three workgroups = 6 waves per SIMD), the bins are two arrays [2][tot]
+// (8-byte stride: the 64-bit atomics of a wave spread over all banks; interleaved (M0, M1) pairs used every other
+// bank pair), a conversion is fixed_bits() and the workgroup map is the forward's (the groups of a node block run back
+// to back on one XCD and share the 128-B lines of x in its L2).  SUMF: the gradient is [n, 1] (feature sum) and its M0
+// term is converted once per node; otherwise [n, F] and read as one 16-byte load next to x.
+template <int FG, int NSTEP, int BS, bool SUMF>
+__global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams mp) {
+  static_assert(FG % 4 == 0, "feature quads");
+  constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
+  constexpr int kTreeWords = FG * P2 + TPN * kTreeSkew;                 // even: the bins behind it are 8-byte aligned
+  const Params& p = mp.f;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int q = tid % TPN, nl = tid / TPN;
+  const int64_t id = blockIdx.x;                                        // (id % 8) = XCD, groups of a node block adjacent inside it
+  const int grp = static_cast<int>((id >> 3) % p.n_groups);
+  const int64_t nb = ((id >> 3) / p.n_groups) * 8 + (id & 7);
+  const int64_t n_lo = nb * p.nodes_per_block;
+  if (n_lo >= p.n) return;
+  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
+  const int k0 = grp * FG;
+  const int base = p.off[k0];
+  const int tot = p.off[k0 + FG] - base;
+  unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + kTreeWords);   // [2][tot]
+  int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float*)smem));
+  if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
+  for (int i = tid; i < 2 * tot; i += BS) bins[i] = 0ull;
+  __syncthreads();
+  for (int i = tid; i < FG * P2; i += BS) {
+    const int f = i >> NSTEP, k = i & (P2 - 1);
+    float v = INFINITY;
+    if (k) {
+      const int j = tree_sorted_index<NSTEP>(k);
+      if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
+    }
+    smem[i + (f / FPT) * kTreeSkew] = v;
+  }
+  __syncthreads();
+  const int Q = static_cast<int>(lds_base) + q * ((FPT * P2 + kTreeSkew) * 4);   // tree of the thread's first feature
+  int nQ = -Q, nQ4 = 4 - Q;
+  asm volatile("" : "+v"(nQ), "+v"(nQ4));           // two opaque registers: compare, select, shift-add per step
+  int binoff[FPT];
+  float a0[FPT];                                    // anchor of piece 0 (what the search keeps when it never steps right)
+#pragma unroll
+  for (int f = 0; f < FPT; ++f) {
+    binoff[f] = s_off[q * FPT + f] - P2;
+    a0[f] = p.anchor[base + s_off[q * FPT + f]];
+  }
+  const double s0 = mp.scales[0], s1 = mp.scales[1];
+  for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
+    const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
+    float gv[FPT];
+    if constexpr (SUMF) {
+      gv[0] = gv[1] = gv[2] = gv[3] = mp.g[n * mp.g_stride];
+    } else {
+      const float* gr = mp.g + n * mp.g_stride + k0 + q * FPT;
+      if (mp.vec_g) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gr);
+        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+      } else {
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) gv[f] = gr[f];
+      }
+    }
+    const float xv[FPT] = {t.x, t.y, t.z, t.w};
+    int a[FPT];
+    float last[FPT];
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      a[f] = Q + 4;                                 // node 1 = root
+      last[f] = a0[f];
+    }
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const float e = lds_f32(a[f] + f * (P2 * 4));
+        const bool right = e <= xv[f];
+        a[f] = (a[f] << 1) + (right ? nQ4 : nQ);
+        last[f] = right ? e : last[f];
+      }
+    }
+    unsigned long long t0 = 0ull;
+    if constexpr (SUMF) t0 = fixed_bits(gv[0], s0);
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const int piece = binoff[f] + ((a[f] - Q) >> 2);
+      if constexpr (!SUMF) t0 = fixed_bits(gv[f], s0);
+      const float m1 = gv[f] * (xv[f] - last[f]);
+      atomicAdd(bins + piece, t0);
+      atomicAdd(bins + tot + piece, fixed_bits(m1, s1));
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2;      // [T][2]
+  for (int i = tid; i < 2 * tot; i += BS) {
+    const unsigned long long v = bins[i];
+    const int m = i >= tot ? 1 : 0;
+    if (v != 0ull) atomicAdd(out + 2 * (i - m * tot) + m, v);
+  }
+}
+
+template <int FG, int NSTEP, int BS>
+int launch_moments_c1(MomentParams mp, hipStream_t st) {
+  Params& p = mp.f;
+  const size_t pieces = static_cast<size_t>(p.max_group_pieces);
+  size_t lds = ((static_cast<size_t>(FG) << NSTEP) + (FG / 4) * kTreeSkew) * sizeof(float) + pieces * 2 * sizeof(unsigned long long);
+  p.soff_offset = static_cast<int>(lds / sizeof(float));
+  lds += (FG + 1) * sizeof(int);
+  if (lds > 150 * 1024) return -1;                       // caller falls back to the general kernels
+  const void* fn = p.sum_features ? reinterpret_cast<const void*>(&fpwl_moments_c1_kernel<FG, NSTEP, BS, true>)
+                                  : reinterpret_cast<const void*>(&fpwl_moments_c1_kernel<FG, NSTEP, BS, false>);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  p.nodes_per_block = tuned_moment_block(p.n, p.n_groups, lds, BS);
+  const int64_t bx = ((p.n + p.nodes_per_block - 1) / p.nodes_per_block + 7) / 8 * 8;   // whole rounds of the 8 XCDs
+  if (bx * p.n_groups > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
+  const dim3 grid(static_cast<unsigned>(bx * p.n_groups));
+  if (p.sum_features) {
+    hipLaunchKernelGGL((fpwl_moments_c1_kernel<FG, NSTEP, BS, true>), grid, dim3(BS), lds, st, mp);
+  } else {
+    hipLaunchKernelGGL((fpwl_moments_c1_kernel<FG, NSTEP, BS, false>), grid, dim3(BS), lds, st, mp);
+  }
+  return gnan::check_launch("fpwl_moments_c1_kernel");
+}
+
 template <int FG, int NSTEP, int BS>
 int launch_moments_fast(MomentParams mp, hipStream_t st) {
   Params& p = mp.f;
@@ -622,6 +770,21 @@ int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
       int nstep = 6;
       while ((1 << nstep) < mp.f.max_pieces) ++nstep;
       int rc = -1;
+      if (mp.f.C == 1 && mp.f.vec_x) {
+        const char* env = std::getenv("GNAN_MOMENTS_GENERAL");   // A/B aid (tools/moments_ab.py, tests): "1" keeps the general kernel
+        if (!(env && env[0] == '1')) {
+          // 512 threads = three workgroups (24 waves) per CU; 640 (30 waves): +13 %/+6 %, 1024 (32 waves): +-0 on C4
+          switch (nstep) {
+            case 6: rc = launch_moments_c1<FG, 6, BS>(mp, st); break;
+            case 7: rc = launch_moments_c1<FG, 7, BS>(mp, st); break;
+            case 8: rc = launch_moments_c1<FG, 8, BS>(mp, st); break;
+            case 9: rc = launch_moments_c1<FG, 9, BS>(mp, st); break;
+            case 10: rc = launch_moments_c1<FG, 10, BS>(mp, st); break;
+            default: break;
+          }
+          if (rc != -1) return rc;
+        }
+      }
       switch (nstep) {
         case 6: rc = launch_moments_fast<FG, 6, BS>(mp, st); break;
         case 7: rc = launch_moments_fast<FG, 7, BS>(mp, st); break;
@@ -767,7 +930,7 @@ int common_checks(const gnan_fpwl_args* a) {
 // block wants them <= 4096 (measured on C4: 2048 +6 %, 8192 +2 %, 16384 +7 %); and the grid should be a whole number
 // of rounds of the workgroups the chip holds at once (LDS-limited: 3 per CU for 16-feature groups), which matters for
 // shares of a few million rows (2.7M rows: 5.04 rounds of 2816-node blocks -> 4 rounds of 3584-node blocks, -15 %).
-int tuned_nodes_per_block(const gnan_fpwl_args* a, int n_groups) {
+int cu_count() {
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -775,6 +938,35 @@ int tuned_nodes_per_block(const gnan_fpwl_args* a, int n_groups) {
       n = 256;
     return n;
   }();
+  return cus;
+}
+
+// The same trade-off for fpwl_moments_c1_kernel: its image (trees + 64-bit bins) is zeroed / built at the start and
+// flushed with one global atomic per touched bin at the end — worth ~600 rows — and x lines are shared between the
+// groups of a node block in L2, so blocks of 1024..8192 nodes in whole rounds of the resident workgroups.
+int tuned_moment_block(int64_t n, int n_groups, size_t lds, int bs) {
+  if (n < 262144) {
+    const int64_t npb = (n / 1024 + 255) / 256 * 256;
+    return static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
+  }
+  int per_cu = static_cast<int>((160 * 1024) / lds);
+  if (per_cu > 2048 / bs) per_cu = 2048 / bs;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t resident = static_cast<int64_t>(cu_count()) * per_cu;
+  const int unit = 128, overhead = 600;
+  int64_t best_cost = -1;
+  int best = 4096;
+  for (int npb = 1024; npb <= 8192; npb += unit) {
+    const int64_t wgs = (n + npb - 1) / npb * n_groups;
+    const int64_t rounds = (wgs + resident - 1) / resident;
+    const int64_t cost = rounds * (npb + overhead);
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && npb > best)) { best_cost = cost; best = npb; }
+  }
+  return best;
+}
+
+int tuned_nodes_per_block(const gnan_fpwl_args* a, int n_groups) {
+  const int cus = cu_count();
   const int fg = a->features_per_group;
   if (a->C != 1 || fg < 4 || a->n < 262144) {              // general kernel / small inputs: ~1024 blocks along the node axis
     const int64_t npb = (a->n / 1024 + 255) / 256 * 256;
@@ -837,6 +1029,7 @@ int moments_common(const gnan_fpwl_args* a, const float* grad, int64_t grad_stri
   mp.scales = scales; mp.Mi = reinterpret_cast<unsigned long long*>(moments_fixed);
   mp.f.vec_x = a->features_per_group % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 &&
                reinterpret_cast<uintptr_t>(a->x) % 16 == 0;
+  mp.vec_g = !a->sum_features && a->C == 1 && grad_stride % 4 == 0 && reinterpret_cast<uintptr_t>(grad) % 16 == 0;
   const size_t bin = moments_fixed ? sizeof(unsigned long long) : sizeof(float);
   const size_t pieces = static_cast<size_t>(a->max_group_pieces);
   const size_t lds = (pieces + 1) / 2 * 2 * sizeof(float) + pieces * 2 * static_cast<size_t>(a->C) * bin;

@@ -400,6 +400,7 @@ __global__ void scales_kernel(const unsigned* bits, const double* x_abs_max, int
     scales[0] = scales[1] = static_cast<double>(NAN);
     return;
   }
+  nbits = nbits < 50 ? nbits : 50;                   // fpwl_moments_c1_kernel converts terms exactly only below 2^51
   const double g = fmax(static_cast<double>(gf), DBL_MIN);
   const double d = fmax(xm + static_cast<double>(af), DBL_MIN);
   const double e0 = fmin(fmax(floor(nbits - log2(g)), -1000.0), 1000.0);

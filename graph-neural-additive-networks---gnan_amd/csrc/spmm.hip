@@ -1266,29 +1266,30 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
 }
 
 namespace {
-// V[i * D + d, :] = [ dY_i / cnt(i, d) | dY_i / cnt(i, D-1) ]  (the packed operand of gnan_spmm_bwd_narrow), zero padded
+// V[i * D + d, :] = [ dY_i / cnt(i, d) | dY_i / cnt(i, D-1) ]  (the packed operand of gnan_spmm_bwd_narrow), zero padded.
+// Thread = node: its gradient row and counts are read once, its D packed rows are one contiguous run of the output.
 __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restrict__ dY, int64_t dy_stride, int W,
                                                             const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
                                                             int64_t n, int with_rest, float* __restrict__ V, int half) {
-  const int64_t total = n * D * 2 * half;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
-    const int c = static_cast<int>(e % (2 * half));
-    const int64_t id = e / (2 * half);
-    const int d = static_cast<int>(id % D);
-    const int64_t i = id / D;
-    const bool second = c >= half;
-    const int w = second ? c - half : c;
-    float v = 0.f;
-    if (w < W && (!second || with_rest)) {
-      const int dd = second ? D - 1 : d;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+    float r_rest = 1.f;
+    if (cnt) {
+      const int k = cnt[i * cnt_stride + D - 1];
+      r_rest = static_cast<float>(k > 1 ? k : 1);
+    }
+    float* out = V + i * D * 2 * half;
+    for (int d = 0; d < D; ++d) {
       float r = 1.f;
       if (cnt) {
-        const int k = cnt[i * cnt_stride + dd];
+        const int k = cnt[i * cnt_stride + d];
         r = static_cast<float>(k > 1 ? k : 1);
       }
-      v = dY[i * dy_stride + w] / r;
+      for (int w = 0; w < half; ++w) {
+        const float g = w < W ? dY[i * dy_stride + w] : 0.f;
+        out[d * 2 * half + w] = g / r;
+        out[d * 2 * half + half + w] = with_rest ? g / r_rest : 0.f;
+      }
     }
-    V[e] = v;
   }
 }
 }  // namespace
@@ -1299,8 +1300,7 @@ extern "C" int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32
   GNAN_REQUIRE((dY && V) || n == 0, "pack_bwd_rows: null pointer");
   GNAN_REQUIRE(dy_stride >= W && (cnt == nullptr || cnt_stride >= D), "pack_bwd_rows: row stride smaller than the width");
   if (n == 0) return GNAN_OK;
-  const int64_t total = n * D * 2 * half;
-  int64_t blocks = (total + 256 * 4 - 1) / (256 * 4);
+  int64_t blocks = (n + 255) / 256;
   blocks = blocks > 65536 ? 65536 : blocks;
   hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half);

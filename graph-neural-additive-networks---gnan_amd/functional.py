@@ -160,7 +160,7 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features), out=None, out_stride=0)
     mgp = t.max_group_pieces
     if MOMENTS_FIXED_POINT and n > 0 and (mgp + 1) // 2 * 8 + mgp * 2 * C * 8 <= 150 * 1024:
-        bits = 61 - max(1, (max(n, 2) - 1).bit_length())            # a bin receives at most n terms
+        bits = min(50, 61 - max(1, (max(n, 2) - 1).bit_length()))   # a bin receives at most n terms; a term stays below 2^51
         if x_abs_max is None:
             x_abs_max = x.abs().max().double()
         # scales[0] = 2^floor(bits - log2 max|grad|), scales[1] = 2^floor(bits - log2(max|grad| max|x - anchor|)):

@@ -179,7 +179,8 @@ int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t 
  * (exponents clamped to +-1000) with grad [n, width] (row stride grad_stride), anchor [T] — of which only the first
  * *n_anchors are read when n_anchors (one int32 in DEVICE memory, e.g. &off[F] of tables held in a buffer of full
  * capacity) is not NULL —, x_abs_max one double in DEVICE memory (max |x| of the feature matrix) and
- * bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits.
+ * bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits (values above 50 are treated as 50: the kernels
+ * convert a term with one fused multiply-add onto 1.5 * 2^52, exact below 2^51).
  * workspace: 8 bytes.  One pass over grad + a single-thread kernel; no host round trip. */
 int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
                             int64_t T, const int32_t* n_anchors, const double* x_abs_max, int32_t bits, void* workspace,

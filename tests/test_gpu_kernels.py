@@ -389,7 +389,8 @@ def test_fused_feature_sum_gradients():
 
 
 @pytest.mark.parametrize("F,L,H,C,sum_features", [(5, 3, 8, 1, True), (20, 3, 16, 2, False), (64, 3, 64, 1, False),
-                                                   (3, 3, 16, 40, True)])
+                                                   (3, 3, 16, 40, True), (64, 3, 64, 1, True), (32, 2, 20, 1, True),
+                                                   (8, 3, 16, 1, False), (48, 3, 64, 1, False)])
 @pytest.mark.parametrize("fixed", [True, False])
 def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkeypatch):
     from gnan_amd import functional, pwl
@@ -413,6 +414,16 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         tiny = _fpwl_moments(xd, t, gd * 1e-30, sum_features).cpu().double()          # the scale follows the gradient's size
         assert float((tiny - want * 1e-30).abs().max()) <= 2e-6 * scale * 1e-30
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
+        # the C = 1 kernel (gradient read next to x, anchor tracked by the search, one-fma fixed-point conversion) and the
+        # general kernel add the same integers: identical bins, also for gradient rows that cannot be read as quads
+        monkeypatch.setenv("GNAN_MOMENTS_GENERAL", "1")
+        general = _fpwl_moments(xd, t, gd, sum_features, raw=True)[0]
+        monkeypatch.delenv("GNAN_MOMENTS_GENERAL")
+        assert torch.equal(_fpwl_moments(xd, t, gd, sum_features, raw=True)[0], general)
+        if not sum_features and C == 1:
+            wide = torch.zeros(n, F + 3, device=DEV)
+            wide[:, 1:F + 1] = gd
+            assert torch.equal(_fpwl_moments(xd, t, wide[:, 1:F + 1], sum_features, raw=True)[0], general)
 
 
 @pytest.mark.parametrize("F,L,H,C,bias,n", [(3, 3, 8, 1, True, 203), (20, 3, 64, 3, True, 1000), (7, 3, 33, 7, False, 5),
@@ -553,7 +564,8 @@ def test_moment_scales_kernel(n, width, gscale):
     tiny = torch.finfo(torch.float64).tiny
     g_max = g.abs().max().double().clamp_min(tiny)
     d_max = (xmax + anchor.abs().max().double()).clamp_min(tiny)
-    e = torch.stack([torch.floor(bits - torch.log2(g_max)), torch.floor(bits - torch.log2(g_max * d_max))])
+    eb = min(bits, 50)                          # the library caps the exponent: every term stays below 2^51 (fixed_bits)
+    e = torch.stack([torch.floor(eb - torch.log2(g_max)), torch.floor(eb - torch.log2(g_max * d_max))])
     want = torch.exp2(e.clamp(-1000.0, 1000.0))
     assert torch.equal(out[:2].cpu(), want.cpu()), (out[:2], want)
     gn = g.clone()
