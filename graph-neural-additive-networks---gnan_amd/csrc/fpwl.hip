@@ -435,6 +435,15 @@ struct MomentParams {
   int vec_g;                // gradient rows may be read as 16-byte quads (C == 1, per-feature gradient)
 };
 
+// round(v * s) as a two's-complement 64-bit integer for a power of two s and |v * s| < 2^51: one fused multiply-add onto
+// 1.5 * 2^52 leaves the integer in the low mantissa bits (round to nearest even, like __double2ll_rn, whose library
+// routine costs ~10 float64 instructions — v_rndne, v_ldexp, v_floor, v_fma, two conversions).  gnan_fpwl_moment_scales
+// caps its exponents so that every term stays below 2^50.
+__device__ __forceinline__ unsigned long long fixed_bits(float v, double s) {
+  const double d = fma(static_cast<double>(v), s, 6755399441055744.0);
+  return static_cast<unsigned long long>(__double_as_longlong(d)) - 0x4338000000000000ull;
+}
+
 template <int FG, int BS, bool FIXED>
 __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp) {
   using bin_t = std::conditional_t<FIXED, unsigned long long, float>;
@@ -476,19 +485,29 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
     int idx[FPT];
     search<FPT>(anchor_l, po, pn, xv, p.step0, idx);
     const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0 + q * FPT) * C);
+    float d[FPT];
+    bin_t* b[FPT];
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {
-      if (live[f]) {
-        const float d = xv[f] - anchor_l[idx[f]];
-        bin_t* b = bins + static_cast<int64_t>(idx[f]) * 2 * C;
-        for (int c = 0; c < C; ++c) {
-          const float gv = gr[p.sum_features ? c : f * C + c];
+      d[f] = xv[f] - anchor_l[idx[f]];
+      b[f] = bins + static_cast<int64_t>(idx[f]) * 2 * C;
+    }
+    // channel-major: in feature-sum mode a channel's gradient is read (and converted) once for the thread's features
+    for (int c = 0; c < C; ++c) {
+      float gs = 0.f;
+      if (p.sum_features) gs = gr[c];
+      unsigned long long t0s = 0ull;
+      if constexpr (FIXED) t0s = fixed_bits(gs, s0);
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        if (live[f]) {
+          const float gv = p.sum_features ? gs : gr[f * C + c];
           if constexpr (FIXED) {
-            atomicAdd(b + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv) * s0)));
-            atomicAdd(b + C + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv * d) * s1)));
+            atomicAdd(b[f] + c, p.sum_features ? t0s : fixed_bits(gv, s0));
+            atomicAdd(b[f] + C + c, fixed_bits(gv * d[f], s1));
           } else {
-            atomicAdd(b + c, gv);
-            atomicAdd(b + C + c, gv * d);
+            atomicAdd(b[f] + c, gv);
+            atomicAdd(b[f] + C + c, gv * d[f]);
           }
         }
       }
@@ -577,15 +596,23 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
       }
     }
     const float* gr = mp.g + n * mp.g_stride + (p.sum_features ? 0 : static_cast<int64_t>(k0 + q * FPT) * C);
+    float d[FPT];
+    unsigned long long* b[FPT];
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {
       const int piece = binoff[f] + (((a[f] - Q) >> 2) - P2);
-      const float d = xv[f] - an_l[piece];
-      unsigned long long* b = bins + static_cast<int64_t>(piece) * 2 * C;
-      for (int c = 0; c < C; ++c) {
-        const float gv = gr[p.sum_features ? c : f * C + c];
-        atomicAdd(b + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv) * s0)));
-        atomicAdd(b + C + c, static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(gv * d) * s1)));
+      d[f] = xv[f] - an_l[piece];
+      b[f] = bins + static_cast<int64_t>(piece) * 2 * C;
+    }
+    for (int c = 0; c < C; ++c) {                   // channel-major (see fpwl_moments_kernel)
+      float gs = 0.f;
+      if (p.sum_features) gs = gr[c];
+      const unsigned long long t0s = fixed_bits(gs, s0);
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const float gv = p.sum_features ? gs : gr[f * C + c];
+        atomicAdd(b[f] + c, p.sum_features ? t0s : fixed_bits(gv, s0));
+        atomicAdd(b[f] + C + c, fixed_bits(gv * d[f], s1));
       }
     }
   }
@@ -595,15 +622,6 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
     const unsigned long long v = bins[i];
     if (v != 0ull) atomicAdd(out + i, v);
   }
-}
-
-// round(v * s) as a two's-complement 64-bit integer for a power of two s and |v * s| < 2^51: one fused multiply-add onto
-// 1.5 * 2^52 leaves the integer in the low mantissa bits (round to nearest even, like __double2ll_rn, whose library
-// routine costs ~10 float64 instructions — v_rndne, v_ldexp, v_floor, v_fma, two conversions).  gnan_fpwl_moment_scales
-// caps its exponents so that every term stays below 2^50.
-__device__ __forceinline__ unsigned long long fixed_bits(float v, double s) {
-  const double d = fma(static_cast<double>(v), s, 6755399441055744.0);
-  return static_cast<unsigned long long>(__double_as_longlong(d)) - 0x4338000000000000ull;
 }
 
 // C == 1 specialisation of the fixed-point moments (round 2).  The general kernel above spends, per (node, feature) and

@@ -169,7 +169,9 @@ int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_s
                       gnan_stream_t stream);
 /* The same moments in 64-bit fixed point: every term v is added as round(v * scales[m]) (m = 0 / 1 for the two
  * moments; scales: two doubles in DEVICE memory, powers of two chosen by the caller such that n * max|v| * scale
- * < 2^62) into `moments` [T, 2, C] int64 (ZEROED by the caller); the caller divides by the scales afterwards.
+ * < 2^62 AND max|v| * scale < 2^51 — what gnan_fpwl_moment_scales produces: a term is converted by one fused
+ * multiply-add onto 1.5 * 2^52, which is exact only below 2^51) into `moments` [T, 2, C] int64 (ZEROED by the caller);
+ * the caller divides by the scales afterwards.
  * Integer LDS atomics run ~12x faster than float ones on gfx950 and the sums are bit-reproducible. */
 int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, const double* scales,
                             int64_t* moments, gnan_stream_t stream);
