@@ -591,7 +591,20 @@ FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum ov
 DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
 DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
 NARROW_ROW_SLICING = os.environ.get("GNAN_NARROW_ROW_SLICING", "1") != "0"   # A/B switch of LONG_ROW_THRESHOLD_NARROW
+NARROW_SORTED_WALK = os.environ.get("GNAN_NARROW_SORTED", "1") != "0"   # narrow operand rows walk the degree-sorted copy too
+HOT_COLUMN_ROWS = os.environ.get("GNAN_HOT_COLUMNS", "1") != "0"        # ... and read the most listed neighbours from a compact copy
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
+
+
+def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1) -> torch.Tensor:
+    """``S`` ([n * group, W], ``group`` consecutive rows per node) followed by the rows of the nodes ``hot``: the operand of
+    a graph whose column ids point hot neighbours at ``n + rank`` (``HopGraph.hot_columns``)."""
+    W = S.shape[1]
+    n = S.shape[0] // group
+    ext = torch.empty(((n + hot.numel()) * group, W), dtype=S.dtype, device=S.device)
+    ext[: n * group].copy_(S)
+    torch.index_select(S.contiguous().view(n, group * W), 0, hot, out=ext[n * group:].view(hot.numel(), group * W))
+    return ext
 
 
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
@@ -621,9 +634,20 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     if not with_rest:
         s_total = None
     scatter = False
+    narrow = S.shape[1] * S.element_size() <= 8        # one or two lanes per row: see LONG_ROW_THRESHOLD_NARROW
     if g.is_dense:
         # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
         plan = g.dense_slice_plan(n_out) if (n_out < DENSE_SLICE_MAX_ROWS and g.n_cols >= DENSE_SLICE_MIN_COLS) else None
+    elif (NARROW_SORTED_WALK and DEGREE_SORTED_COPY and row_ids is None and S.shape[1] < DEGREE_SCHEDULE_MIN_WIDTH
+          and S.dtype == torch.float32 and not per_row and not weight_by_col and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS):
+        # narrow operand rows: the degree-sorted copy as well (a lane per row idles behind the longest of the 16..64 rows
+        # of its wavefront: W = 2 on the 10M-node graph 2.68 -> 1.68 ms), and a compact copy of the most listed
+        # neighbours' rows behind the operand (HopGraph.hot_columns: -> 1.33 ms; W = 1: 1.86 -> 1.79 -> 1.52 ms)
+        g, row_ids, hot = g.degree_sorted_copy_hot() if HOT_COLUMN_ROWS else (*g.degree_sorted_copy()[:2], None)
+        plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING) else g.long_row_plan()
+        if hot is not None:
+            S = append_hot_rows(S, hot, g.n_codes if s_by_code else 1)
+        scatter = 2
     elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
         if DEGREE_SORTED_COPY and not per_row and not weight_by_col and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
             g, row_ids, plan = g.degree_sorted_copy()   # walk a degree-sorted copy of the CSR, store rows at their own index
@@ -632,7 +656,6 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
             row_ids, plan = g.degree_schedule()      # process rows by degree, store them in place
             scatter = True
     else:
-        narrow = S.shape[1] * S.element_size() <= 8        # one or two lanes per row: see LONG_ROW_THRESHOLD_NARROW
         plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING and row_ids is None) else g.long_row_plan(row_ids)
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
                    reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code)
@@ -719,8 +742,16 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
     n_out = gt.n_rows
     dS = torch.empty((n_out, W), dtype=torch.float32, device=V.device)
     dlut = torch.empty(D, dtype=torch.float32, device=V.device)
+    order, scatter = None, 0
+    if NARROW_SORTED_WALK and DEGREE_SORTED_COPY and gt.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
+        # rows of equal length share a wavefront, and the packed rows of the most listed nodes are read from a compact copy
+        # behind V (see spmm_launch); dS is bit-identical, the table gradient adds its float64 partials in processing order
+        gt, order, hot = gt.degree_sorted_copy_hot() if HOT_COLUMN_ROWS else (*gt.degree_sorted_copy()[:2], None)
+        if hot is not None:
+            V = append_hot_rows(V, hot, D)
+        scatter = 2
     plan = gt.narrow_row_plan() if (V.shape[1] * 4 <= 8 and NARROW_ROW_SLICING) else gt.long_row_plan()
-    a = _spmm_args(gt, V, lut, False, None, dS, None, False, plan=plan)
+    a = _spmm_args(gt, V, lut, False, None, dS, order, False, plan=plan, scatter_out=scatter)
     a.n_cols = gt.n_cols                              # rows of V = n_cols * D (checked by the kernel's addressing only)
     a.y_stride = V.shape[1]                           # Y is not written by this entry point (dS is); keeps validate() content
     need = _lib.lib().gnan_spmm_bwd_narrow_workspace_bytes(a)

@@ -852,6 +852,74 @@ def test_packed_backward_rows_kernel(W, D, use_cnt, with_rest):
     assert pack_bwd_rows(dY[:0], None if cnt is None else cnt[:0], D, with_rest, half).shape == (0, D, 2 * half)
 
 
+@pytest.mark.parametrize("W,K,with_rest", [(1, 1, True), (2, 2, True), (4, 1, False)])
+def test_fused_narrow_backward_walks_sorted_copy_with_hot_columns(W, K, with_rest, monkeypatch):
+    """gnan_spmm_bwd_narrow over the degree-sorted copy of the transposed adjacency with the hot packed rows appended ==
+    the natural-order call: operand gradient bit for bit, table gradient to float64 round-off (its partials are added in
+    processing order); both == float64 oracle autograd."""
+    from gnan_amd import functional, graph as G
+    from gnan_amd.functional import rho_aggregate
+    rng = np.random.default_rng(W * 13 + K)
+    n, D = 4000, K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 2500)])
+    col[rng.random(col.shape[0]) < 0.25] = 11                      # hub columns = hub rows of the transposed graph
+    g = _graph(rowptr, col, code, n, D)
+    S0 = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut0 = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    monkeypatch.setattr(G, "HOT_COLUMNS", 64)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
+    got = {}
+    for tag, min_rows in (("natural", 1 << 30), ("sorted_hot", 1)):
+        monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
+        S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+        Y = rho_aggregate(g, S, lut, True, with_rest=with_rest)
+        got[tag] = torch.autograd.grad(Y, [S, lut], up)
+    gt = g.transposed()
+    assert gt._sorted_copy_hot is not None and gt._sorted_copy_hot.n_cols == n + 64
+    assert torch.equal(got["natural"][0], got["sorted_hot"][0])
+    scale = float(got["natural"][1].abs().max())
+    assert float((got["natural"][1] - got["sorted_hot"][1]).abs().max()) <= 1e-6 * scale
+    S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0).expand(n, -1, -1) / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    want = O.spmm_csr(rowptr, col, code, S64, wt, with_rest=with_rest)
+    for k, ref in enumerate(torch.autograd.grad(want, [S64, lut64], up.cpu().double())):
+        assert float((got["sorted_hot"][k].cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("W,s_by_code", [(1, False), (2, False), (3, False), (4, False), (2, True)])
+def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch):
+    """Narrow operand rows walked through the degree-sorted copy of the CSR, with and without the compact copy of the
+    most listed neighbours' rows behind the operand (HopGraph.hot_columns) == natural order, bit for bit; hub rows,
+    empty rows, pre-weighted (node, hop code) rows (s_by_code)."""
+    from gnan_amd import functional, graph as G
+    from gnan_amd.functional import spmm_launch
+    monkeypatch.setattr(G, "HOT_COLUMNS", 64)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
+    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
+    rng = np.random.default_rng(W + 40)
+    n, K = 5000, 2
+    D = K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 2500), (4999, 90)])
+    hot = rng.random(col.shape[0]) < 0.4
+    col[hot] = rng.integers(0, 50, int(hot.sum())) * 97                    # 50 nodes are listed by 40 % of the pairs
+    g = _graph(rowptr, col, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n * (D if s_by_code else 1), W)).astype(np.float32)).to(DEV)
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    out = {}
+    for tag, walk, hot_rows in (("natural", False, False), ("sorted", True, False), ("hot", True, True)):
+        monkeypatch.setattr(functional, "NARROW_SORTED_WALK", walk)
+        monkeypatch.setattr(functional, "HOT_COLUMN_ROWS", hot_rows)
+        out[tag] = spmm_launch(g, S, lut, not s_by_code, not s_by_code, s_by_code=s_by_code)
+    assert g._sorted_copy_hot is not None and g._sorted_copy_hot.n_cols == n + 64
+    assert int((g._sorted_copy_hot.col >= n).sum()) >= int(hot.sum())
+    assert torch.equal(out["natural"], out["sorted"]) and torch.equal(out["natural"], out["hot"])
+    if not s_by_code:
+        wt = lut.cpu().double().unsqueeze(0) / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+        want = O.spmm_csr(rowptr, col, code, S.cpu().double(), wt, with_rest=True)
+        assert O.rel_err(out["hot"].cpu(), want) <= 1e-5
+
+
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
     place == rows processed in natural order (same arithmetic per row)."""

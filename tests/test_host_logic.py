@@ -244,3 +244,42 @@ def test_narrow_row_plan_takes_the_low_threshold_only_for_a_short_tail(monkeypat
     assert narrow.slice_ptr.tolist() == [0, 1, 2, 3] and g.narrow_row_plan() is narrow and g.long_row_plan() is default
     monkeypatch.setattr(G, "NARROW_PLAN_MAX_ROWS", 2)                   # "many" rows above the low threshold: default plan
     assert g.narrow_row_plan() is default
+
+
+def test_hot_columns_point_at_the_appended_rows(monkeypatch):
+    """HopGraph.hot_columns / degree_sorted_copy_hot (pure index work): the K most listed neighbours, most listed first,
+    ties by id; every pair that lists one of them points at n_cols + rank in the copy, all other ids are untouched;
+    flat or small graphs get no hot set."""
+    from gnan_amd import HopGraph, graph as G
+    from gnan_amd.functional import append_hot_rows
+    monkeypatch.setattr(G, "HOT_COLUMNS", 8)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
+    rng = np.random.default_rng(3)
+    n = 400
+    deg = rng.integers(0, 9, n)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, n, nnz)
+    hot = rng.random(nnz) < 0.5
+    col[hot] = rng.integers(0, 8, int(hot.sum())) * 31 + 5
+    code = rng.integers(0, 2, nnz).astype(np.uint8)
+    g = HopGraph.from_csr(torch.from_numpy(rowptr), torch.from_numpy(col).int(), torch.from_numpy(code), n_cols=n, n_codes=3)
+    ids = g.hot_columns()
+    listed = np.bincount(col, minlength=n)
+    want = np.lexsort((np.arange(n), -listed))[:8]
+    assert ids.tolist() == want.tolist()
+    copy, order, hot_ids = g.degree_sorted_copy_hot()
+    plain, order2, _ = g.degree_sorted_copy()
+    assert hot_ids is ids and torch.equal(order, order2) and copy.n_cols == n + 8
+    assert torch.equal(copy.rowptr, plain.rowptr) and torch.equal(copy.code, plain.code)
+    rank = {int(v): k for k, v in enumerate(want)}
+    expect = [n + rank[c] if c in rank else c for c in plain.col.tolist()]
+    assert copy.col.tolist() == expect
+    S = torch.arange(n * 2 * 3, dtype=torch.float32).view(n * 2, 3)        # two rows per node (s_by_code layout)
+    ext = append_hot_rows(S, ids, 2)
+    assert ext.shape == ((n + 8) * 2, 3) and torch.equal(ext[: n * 2], S)
+    assert torch.equal(ext[n * 2:].view(8, 6), S.view(n, 6)[ids])
+    flat = HopGraph.from_csr(torch.arange(0, 4 * n + 1, 4), torch.arange(4 * n).int() % n, torch.zeros(4 * n, dtype=torch.uint8),
+                             n_cols=n, n_codes=3)
+    assert flat.hot_columns() is None and flat.degree_sorted_copy_hot()[2] is None
