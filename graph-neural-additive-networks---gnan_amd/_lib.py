@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -128,7 +128,7 @@ SYMBOLS = {
     "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnan_spmm_pack_bwd_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32,
-                                          C.c_void_p, C.c_int32, C.c_void_p]),
+                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gnan_spmm_bwd_narrow_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_bwd_narrow": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1270,14 +1270,16 @@ namespace {
 // Thread = node: its gradient row and counts are read once, its D packed rows are one contiguous run of the output.
 __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restrict__ dY, int64_t dy_stride, int W,
                                                             const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
-                                                            int64_t n, int with_rest, float* __restrict__ V, int half) {
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+                                                            int64_t n, int with_rest, float* __restrict__ V, int half,
+                                                            const int64_t* __restrict__ hot, int64_t n_hot) {
+  for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < n + n_hot; o += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = o < n ? o : hot[o - n];         // packed rows [n, n + n_hot): second copies of the nodes hot[]
     float r_rest = 1.f;
     if (cnt) {
       const int k = cnt[i * cnt_stride + D - 1];
       r_rest = static_cast<float>(k > 1 ? k : 1);
     }
-    float* out = V + i * D * 2 * half;
+    float* out = V + o * D * 2 * half;
     for (int d = 0; d < D; ++d) {
       float r = 1.f;
       if (cnt) {
@@ -1295,15 +1297,17 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
 }  // namespace
 
 extern "C" int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32_t W, const int32_t* cnt, int64_t cnt_stride,
-                                       int32_t D, int64_t n, int32_t with_rest, float* V, int32_t half, gnan_stream_t stream) {
+                                       int32_t D, int64_t n, int32_t with_rest, float* V, int32_t half, const int64_t* hot,
+                                       int64_t n_hot, gnan_stream_t stream) {
   GNAN_REQUIRE(n >= 0 && W >= 1 && D >= 1 && half >= W && (half & (half - 1)) == 0, "pack_bwd_rows: bad sizes");
   GNAN_REQUIRE((dY && V) || n == 0, "pack_bwd_rows: null pointer");
   GNAN_REQUIRE(dy_stride >= W && (cnt == nullptr || cnt_stride >= D), "pack_bwd_rows: row stride smaller than the width");
+  GNAN_REQUIRE(n_hot >= 0 && (n_hot == 0 || hot != nullptr), "pack_bwd_rows: n_hot without hot");
   if (n == 0) return GNAN_OK;
-  int64_t blocks = (n + 255) / 256;
+  int64_t blocks = (n + n_hot + 255) / 256;
   blocks = blocks > 65536 ? 65536 : blocks;
   hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half);
+                     dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot);
   return gnan::check_launch("pack_bwd_rows_kernel");
 }
 

@@ -643,7 +643,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
         # narrow operand rows: the degree-sorted copy as well (a lane per row idles behind the longest of the 16..64 rows
         # of its wavefront: W = 2 on the 10M-node graph 2.68 -> 1.68 ms), and a compact copy of the most listed
         # neighbours' rows behind the operand (HopGraph.hot_columns: -> 1.33 ms; W = 1: 1.86 -> 1.79 -> 1.52 ms)
-        g, row_ids, hot = g.degree_sorted_copy_hot() if HOT_COLUMN_ROWS else (*g.degree_sorted_copy()[:2], None)
+        g, row_ids, hot = narrow_walk(g)
         plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING) else g.long_row_plan()
         if hot is not None:
             S = append_hot_rows(S, hot, g.n_codes if s_by_code else 1)
@@ -719,21 +719,37 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
 NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"   # dS and dlut from one transposed pass
 
 
-def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int) -> torch.Tensor:
-    """``V[i, d] = [dY_i / cnt(i, d) | dY_i / cnt(i, D-1)]``, halves zero padded to ``half`` floats (``gnan_spmm_pack_bwd_rows``)."""
+def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int,
+                  hot: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``V[i, d] = [dY_i / cnt(i, d) | dY_i / cnt(i, D-1)]``, halves zero padded to ``half`` floats (``gnan_spmm_pack_bwd_rows``);
+    with ``hot`` (node ids) the rows of those nodes are repeated behind the n real ones: ``V[n + k] = V[hot[k]]``."""
     _lib.require_device(dY)
     dY = _rows(dY.detach().float())
     n, W = dY.shape
-    V = torch.empty((n, D, 2 * half), dtype=torch.float32, device=dY.device)
+    k = 0 if hot is None else int(hot.numel())
+    V = torch.empty((n + k, D, 2 * half), dtype=torch.float32, device=dY.device)
     c = None if cnt is None else cnt.contiguous()
+    h = None if hot is None else hot.to(torch.int64).contiguous()
     _lib.check(_lib.lib().gnan_spmm_pack_bwd_rows(_lib.ptr(dY), dY.stride(0), W, _lib.ptr(c), 0 if c is None else c.stride(0), D, n,
-                                                  int(with_rest), _lib.ptr(V), half, _lib.stream_of(dY)), "gnan_spmm_pack_bwd_rows")
+                                                  int(with_rest), _lib.ptr(V), half, _lib.ptr(h), k, _lib.stream_of(dY)),
+               "gnan_spmm_pack_bwd_rows")
     return V
 
 
-def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int):
+def narrow_walk(g: HopGraph):
+    """``(graph to walk, processing order, hot ids)`` for narrow operand rows: the degree-sorted copy of a large CSR —
+    rows of equal length share a wavefront — whose column ids point the most listed neighbours at a compact copy of
+    their rows behind the operand (``HopGraph.degree_sorted_copy_hot``); ``(g, None, None)`` for small or dense graphs."""
+    if NARROW_SORTED_WALK and DEGREE_SORTED_COPY and not g.is_dense and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
+        return g.degree_sorted_copy_hot() if HOT_COLUMN_ROWS else (*g.degree_sorted_copy()[:2], None)
+    return g, None, None
+
+
+def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int,
+                      walk=None):
     """``gnan_spmm_bwd_narrow`` over the transposed adjacency ``gt``: returns ``(dS [n, W], dlut [D])`` — see the header for
-    the layout of ``V [n_fwd_rows * D, 2 * half]``."""
+    the layout of ``V [n_fwd_rows * D, 2 * half]``.  ``walk = narrow_walk(gt)`` when the caller has already put the hot
+    rows behind ``V`` (``pack_bwd_rows(hot=...)``)."""
     _lib.require_device(V, S_rows, lut, gt.code)
     V = _rows(V.detach().float())
     S_rows = _rows(S_rows.detach().float())
@@ -742,14 +758,13 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
     n_out = gt.n_rows
     dS = torch.empty((n_out, W), dtype=torch.float32, device=V.device)
     dlut = torch.empty(D, dtype=torch.float32, device=V.device)
-    order, scatter = None, 0
-    if NARROW_SORTED_WALK and DEGREE_SORTED_COPY and gt.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
-        # rows of equal length share a wavefront, and the packed rows of the most listed nodes are read from a compact copy
-        # behind V (see spmm_launch); dS is bit-identical, the table gradient adds its float64 partials in processing order
-        gt, order, hot = gt.degree_sorted_copy_hot() if HOT_COLUMN_ROWS else (*gt.degree_sorted_copy()[:2], None)
-        if hot is not None:
-            V = append_hot_rows(V, hot, D)
-        scatter = 2
+    # rows of equal length share a wavefront, and the packed rows of the most listed nodes are read from a compact copy
+    # behind V (see spmm_launch); dS is bit-identical, the table gradient adds its float64 partials in processing order
+    appended = walk is not None
+    gt, order, hot = walk if appended else narrow_walk(gt)
+    if hot is not None and not appended:
+        V = append_hot_rows(V, hot, D)
+    scatter = 0 if order is None else 2
     plan = gt.narrow_row_plan() if (V.shape[1] * 4 <= 8 and NARROW_ROW_SLICING) else gt.long_row_plan()
     a = _spmm_args(gt, V, lut, False, None, dS, order, False, plan=plan, scatter_out=scatter)
     a.n_cols = gt.n_cols                              # rows of V = n_cols * D (checked by the kernel's addressing only)
@@ -809,11 +824,12 @@ class _RhoAggregate(torch.autograd.Function):
             # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
             # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
             half = 1 << max(0, (W - 1).bit_length())
-            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half)              # [n, D, 2 * half]
-            dS, dl = bwd_narrow_launch(g.transposed(), V.view(g.n_rows * D, 2 * half), S, lut[:, 0], with_rest, W)
+            walk = narrow_walk(g.transposed())
+            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [n (+ hot), D, 2 * half]
+            dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk)
             if with_rest:
                 total = ctx.s_total if ctx.s_total is not None else column_sums(S)
-                q_sum = column_sums(V[:, 0, half:half + W])                                    # sum_i dY_i / cnt(i, rest)
+                q_sum = column_sums(V[:g.n_rows, 0, half:half + W])                            # sum_i dY_i / cnt(i, rest)
                 dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
             dlut = dl.view(D, 1)
 

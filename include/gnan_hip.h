@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 23
+#define GNAN_ABI_VERSION 24
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -397,9 +397,12 @@ int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stri
  * It replaces gnan_spmm_fwd(s_by_code) + gnan_spmm_lut_grad — two traversals of the same pairs — by one.
  * ------------------------------------------------------------------------------------------- */
 /* builds that packed operand: V[i*D + d, :] = [ dY[i, :W] / max(cnt[i, d], 1) | dY[i, :W] / max(cnt[i, D-1], 1) ], each half
- * zero padded to `half` floats (cnt == NULL: no division; with_rest == 0: second halves zero) */
+ * zero padded to `half` floats (cnt == NULL: no division; with_rest == 0: second halves zero).  With n_hot > 0, V has
+ * (n + n_hot) * D rows and rows (n + k)*D + d repeat node hot[k] (int64 ids in DEVICE memory): the compact second copy
+ * of the most listed nodes' rows that a column array remapped to n + k reads (HopGraph.hot_columns). */
 int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32_t W, const int32_t* cnt, int64_t cnt_stride, int32_t D,
-                            int64_t n, int32_t with_rest, float* V, int32_t half, gnan_stream_t stream);
+                            int64_t n, int32_t with_rest, float* V, int32_t half, const int64_t* hot, int64_t n_hot,
+                            gnan_stream_t stream);
 size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a);
 int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows, int64_t s_rows_stride, int32_t w_real,
                          int32_t with_rest, float* dS, int64_t ds_stride, float* dlut, void* workspace,

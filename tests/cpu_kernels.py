@@ -81,7 +81,8 @@ def lut_grad_launch(g, S, dY, D, use_cnt, with_rest, row_ids, s_total, reduce_ro
     return out.float().unsqueeze(-1)
 
 
-def pack_bwd_rows(dY, cnt, D, with_rest, half):
+def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None):
+    assert hot is None
     dY = dY.detach().float()
     n, W = dY.shape
     den = torch.ones((n, D)) if cnt is None else cnt.clamp_min(1).float()
@@ -92,7 +93,7 @@ def pack_bwd_rows(dY, cnt, D, with_rest, half):
     return V
 
 
-def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W):
+def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None):
     D = lut.numel()
     half = V.shape[1] // 2
     row_of_pair, col, code = _pairs(gt)                     # rows of gt = nodes as neighbours; col = the forward row listing them
