@@ -24,6 +24,7 @@ using gnan::kWave;
 
 struct Params {
   int64_t n_rows, n_cols;
+  int64_t nnz;     // listed pairs (length of col / code), 0 = unknown: index runs are then read entry by entry
   const void* rowptr;
   int rowptr_is64;
   const int32_t* col;
@@ -225,6 +226,21 @@ __device__ __forceinline__ SmallW small_weights(const Params& p, int64_t i) {
   return s;
 }
 
+// A lane's run of N consecutive (col, code) entries as wide loads: N * 4 bytes of column ids (4-byte aligned) and N bytes of
+// hop codes (byte aligned; gfx950 runs HSA code in unaligned-access mode) instead of 2 N scalar loads.  With one lane per
+// row (W = 1: 16 entries per lane and round) the scalar loads were 32 of the 48 memory instructions of a round, each
+// touching ~20 different lines per wavefront.  The caller guarantees e0 + N <= nnz; entries past the row end are read
+// (they belong to the next row) and ignored.
+template <int N>
+__device__ __forceinline__ void load_index_run(const int32_t* col, const uint8_t* code, int (&colv)[N], int (&codev)[N]) {
+  static_assert(N % 4 == 0, "whole dwords of codes");
+  unsigned cw[N / 4];
+  __builtin_memcpy(colv, col, N * 4);
+  __builtin_memcpy(cw, code, N);
+#pragma unroll
+  for (int r = 0; r < N; ++r) codev[r] = static_cast<int>((cw[r / 4] >> (8 * (r % 4))) & 0xffu);
+}
+
 // ---------------------------------------------------------------------------------------------
 // rows kernel: one LPR-lane group per output row
 // ---------------------------------------------------------------------------------------------
@@ -282,13 +298,21 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
     // rows (few lanes per group) still see 16 gathers between two dependent index loads.
     for (int64_t base = lo; base < hi; base += IW) {
       int colv[IPL], codev[IPL];
+      bool wide = false;
+      if constexpr (!DENSE && IPL % 4 == 0) {
+        const int64_t e0 = base + sub * IPL;
+        wide = e0 + IPL <= p.nnz;
+        if (wide) load_index_run<IPL>(p.col + e0, p.code + e0, colv, codev);
+      }
+      if (!wide) {
 #pragma unroll
-      for (int r = 0; r < IPL; ++r) {
-        const int64_t e = base + sub * IPL + r;
-        colv[r] = codev[r] = 0;
-        if (e < hi) {
-          if constexpr (!DENSE) colv[r] = p.col[e];
-          codev[r] = p.code[code_base + e];
+        for (int r = 0; r < IPL; ++r) {
+          const int64_t e = base + sub * IPL + r;
+          colv[r] = codev[r] = 0;
+          if (e < hi) {
+            if constexpr (!DENSE) colv[r] = p.col[e];
+            codev[r] = p.code[code_base + e];
+          }
         }
       }
       const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
@@ -750,7 +774,7 @@ namespace {
 
 Params make_params(const gnan_spmm_args* a) {
   Params p;
-  p.n_rows = a->n_rows; p.n_cols = a->n_cols;
+  p.n_rows = a->n_rows; p.n_cols = a->n_cols; p.nnz = a->nnz > 0 ? a->nnz : 0;
   p.rowptr = a->rowptr; p.rowptr_is64 = a->rowptr_is64;
   p.col = a->col; p.code = a->code; p.row_ids = a->row_ids;
   p.S = a->S; p.W = a->W; p.s_stride = a->s_stride;
@@ -993,11 +1017,19 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
         constexpr int IPL = IW / LPR;
         for (int64_t base = lo; base < hi; base += IW) {
           int colv[IPL], codev[IPL];
+          bool wide = false;
+          if constexpr (IPL % 4 == 0) {
+            const int64_t e0 = base + sub * IPL;
+            wide = e0 + IPL <= p.nnz;
+            if (wide) load_index_run<IPL>(p.col + e0, p.code + e0, colv, codev);
+          }
+          if (!wide) {
 #pragma unroll
-          for (int r = 0; r < IPL; ++r) {
-            const int64_t e = base + sub * IPL + r;
-            colv[r] = codev[r] = 0;
-            if (e < hi) { colv[r] = p.col[e]; codev[r] = p.code[e]; }
+            for (int r = 0; r < IPL; ++r) {
+              const int64_t e = base + sub * IPL + r;
+              colv[r] = codev[r] = 0;
+              if (e < hi) { colv[r] = p.col[e]; codev[r] = p.code[e]; }
+            }
           }
           const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
 #pragma unroll(IPL > 1 ? IW / 4 : 1)

@@ -565,7 +565,7 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         n_long=(plan.n_long if plan is not None else 0), n_slices=(plan.n_slices if plan is not None else 0),
         slice_edges=(plan.slice_edges if plan is not None else 0),
         workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0),
-        s_by_code=int(s_by_code))
+        s_by_code=int(s_by_code), nnz=(0 if g.col is None else int(g.col.numel())))
     return a
 
 

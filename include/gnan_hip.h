@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 24
+#define GNAN_ABI_VERSION 25
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -325,6 +325,8 @@ typedef struct gnan_spmm_args {
                                     backward w.r.t. a narrow S folds the per-pair weight into a pre-weighted operand
                                     Z[i, d, :] = (wt(i, d) - wt(i, D-1)) * dY[i, :] and gathers it with unit weights.
                                     CSR layout, fp32 rows, no s_total, W <= 32 (GNAN_ERR_UNSUPPORTED beyond) */
+  int64_t nnz;                   /* listed pairs = readable length of col / code (CSR); 0 = unknown.  Known, the kernels read a
+                                  * lane's run of index entries with wide loads (which may reach past the row end, never past nnz) */
 } gnan_spmm_args;
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
