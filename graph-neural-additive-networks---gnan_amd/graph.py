@@ -312,7 +312,9 @@ class HopGraph:
         if self._hot is None:
             ids = None
             if not self.is_dense and self.nnz >= HOT_COLUMNS_MIN_NNZ and self.n_cols >= 16 * HOT_COLUMNS:
-                listed = torch.bincount(self.col.long(), minlength=self.n_cols)
+                listed = torch.zeros(self.n_cols, dtype=torch.int64, device=self.device)
+                for e0 in range(0, self.nnz, 1 << 27):                # pairs per pass: bounds the int64 temporaries
+                    listed += torch.bincount(self.col[e0:e0 + (1 << 27)].long(), minlength=self.n_cols)
                 top = torch.argsort(listed, descending=True, stable=True)[:HOT_COLUMNS]
                 if float(listed[top].sum()) >= HOT_COLUMNS_MIN_SHARE * self.nnz:
                     ids = top.contiguous()
