@@ -311,7 +311,8 @@ class HopGraph:
         1.79 -> 1.52 ms on top of the degree-sorted walk).  Pure index work; cached per graph."""
         if self._hot is None:
             ids = None
-            if not self.is_dense and self.nnz >= HOT_COLUMNS_MIN_NNZ and self.n_cols >= 16 * HOT_COLUMNS:
+            if (not self.is_dense and self.nnz >= HOT_COLUMNS_MIN_NNZ and self.n_cols >= 16 * HOT_COLUMNS
+                    and self.n_cols + HOT_COLUMNS < 2 ** 31):                     # the renumbered ids stay int32
                 listed = torch.zeros(self.n_cols, dtype=torch.int64, device=self.device)
                 for e0 in range(0, self.nnz, 1 << 27):                # pairs per pass: bounds the int64 temporaries
                     listed += torch.bincount(self.col[e0:e0 + (1 << 27)].long(), minlength=self.n_cols)
