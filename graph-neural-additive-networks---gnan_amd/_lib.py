@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -96,7 +96,7 @@ class SpmmArgs(C.Structure):
         ("long_threshold", C.c_int64), ("long_rows", C.c_void_p), ("long_slice_ptr", C.c_void_p),
         ("n_long", C.c_int32), ("n_slices", C.c_int32), ("slice_edges", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("s_by_code", C.c_int32), ("nnz", C.c_int64),
+        ("s_by_code", C.c_int32), ("nnz", C.c_int64), ("packed_index", C.c_int32),
     ]
 
 

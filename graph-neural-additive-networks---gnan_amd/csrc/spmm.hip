@@ -43,6 +43,7 @@ struct Params {
   int reduce_cr;  // > 0: store only the per-channel sums over columns w = c (mod reduce_cr)
   int scatter_out;  // output row q is stored at Y[row_ids[q]] (rows are PROCESSED in row_ids order, e.g. by degree)
   int s_by_code;    // the operand row of pair (i, c, d) is S[c * D + d]: one pre-weighted row per (node, hop code)
+  int packed;       // col entries carry the hop code in their top kPackBits bits (code is not read)
   float* Y;
   int64_t y_stride;
   int64_t long_threshold;
@@ -231,6 +232,12 @@ __device__ __forceinline__ SmallW small_weights(const Params& p, int64_t i) {
 // row (W = 1: 16 entries per lane and round) the scalar loads were 32 of the 48 memory instructions of a round, each
 // touching ~20 different lines per wavefront.  The caller guarantees e0 + N <= nnz; entries past the row end are read
 // (they belong to the next row) and ignored.
+// Packed index entries: column id in the low 29 bits, hop code in the top 3 (graphs below 2^29 neighbours, D <= 8).  One
+// 4-byte stream instead of a 4-byte and a 1-byte one: the index loads of a lane group are then ONE L2 request per round
+// instead of two — 3 % of the W = 64 kernel's requests, 10 % of the bf16 kernel's (8 pairs per round, one request per row).
+constexpr int kPackShift = 29;
+constexpr unsigned kPackMask = (1u << kPackShift) - 1u;
+
 template <int N>
 __device__ __forceinline__ void load_index_run(const int32_t* col, const uint8_t* code, int (&colv)[N], int (&codev)[N]) {
   static_assert(N % 4 == 0, "whole dwords of codes");
@@ -244,7 +251,7 @@ __device__ __forceinline__ void load_index_run(const int32_t* col, const uint8_t
 // ---------------------------------------------------------------------------------------------
 // rows kernel: one LPR-lane group per output row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE>
+template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE, bool PACKED = false>
 __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_id) {
   constexpr int G = kWave / LPR;     // groups (rows) per wave
   constexpr int TILE = LPR * VEC;    // operand columns one pass covers
@@ -302,7 +309,10 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
       if constexpr (!DENSE && IPL % 4 == 0) {
         const int64_t e0 = base + sub * IPL;
         wide = e0 + IPL <= p.nnz;
-        if (wide) load_index_run<IPL>(p.col + e0, p.code + e0, colv, codev);
+        if (wide) {
+          if constexpr (PACKED) __builtin_memcpy(colv, p.col + e0, IPL * 4);
+          else load_index_run<IPL>(p.col + e0, p.code + e0, colv, codev);
+        }
       }
       if (!wide) {
 #pragma unroll
@@ -311,8 +321,15 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           colv[r] = codev[r] = 0;
           if (e < hi) {
             if constexpr (!DENSE) colv[r] = p.col[e];
-            codev[r] = p.code[code_base + e];
+            if constexpr (!PACKED) codev[r] = p.code[code_base + e];
           }
+        }
+      }
+      if constexpr (PACKED) {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          codev[r] = static_cast<int>(static_cast<unsigned>(colv[r]) >> kPackShift);
+          colv[r] = static_cast<int>(static_cast<unsigned>(colv[r]) & kPackMask);
         }
       }
       const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
@@ -395,7 +412,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 // ---------------------------------------------------------------------------------------------
 // long kernel: one 256-thread workgroup per slice of a hub row
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPR, bool SMALLD, bool DENSE, bool BYCODE>
+template <int VEC, int LPR, bool SMALLD, bool DENSE, bool BYCODE, bool PACKED = false>
 __device__ __forceinline__ void slice_body(const Params& p, const int s) {
   constexpr int G = kWave / LPR;
   constexpr int TILE = LPR * VEC;
@@ -434,7 +451,11 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
       int colv = 0, codev = 0;
       if (e < hi) {
         colv = DENSE ? static_cast<int>(e) : p.col[e];
-        codev = p.code[code_base + e];
+        if constexpr (!PACKED) codev = p.code[code_base + e];
+      }
+      if constexpr (PACKED) {
+        codev = static_cast<int>(static_cast<unsigned>(colv) >> kPackShift);
+        colv = static_cast<int>(static_cast<unsigned>(colv) & kPackMask);
       }
       const int m = static_cast<int>(hi - base < kWave ? hi - base : kWave);
 #pragma unroll 4
@@ -498,15 +519,15 @@ __device__ __forceinline__ void slice_body(const Params& p, const int s) {
 // so the long-latency slices overlap the bulk), the rest take 4*G ordinary rows each.
 // BYCODE (operand row = (neighbour, hop code), the narrow-operand backward) is a template parameter: as a run-time
 // flag its address arithmetic cost the W = 64 kernels 4 VGPRs and the bf16 variant 20 B of scratch (bf16 rows 2.85 -> 3.35 ms).
-template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE = false>
+template <int VEC, int LPR, bool DENSE, bool SMALLD, bool BYCODE = false, bool PACKED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SMALLD && LPR >= 8) ? 8 : 1)))
 void spmm_kernel(const Params p) {
   if constexpr (!DENSE) {
     if (static_cast<int>(blockIdx.x) < p.n_slices) {
-      slice_body<VEC, LPR, SMALLD, false, BYCODE>(p, static_cast<int>(blockIdx.x));
+      slice_body<VEC, LPR, SMALLD, false, BYCODE, PACKED>(p, static_cast<int>(blockIdx.x));
       return;
     }
-    rows_body<VEC, LPR, false, SMALLD, BYCODE>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
+    rows_body<VEC, LPR, false, SMALLD, BYCODE, PACKED>(p, static_cast<int64_t>(blockIdx.x) - p.n_slices);
   } else {
     if (p.n_slices > 0) {      // few rows, many neighbours: every row is cut into slices, there are no row blocks
       slice_body<VEC, LPR, SMALLD, true, false>(p, static_cast<int>(blockIdx.x));
@@ -696,7 +717,11 @@ int launch(const Params& p, bool dense, bool smalld, hipStream_t st) {
   } else if (dense) {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, true, false>), grid, block, 0, st, p);
   } else if (smalld) {
-    hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true>), grid, block, 0, st, p);
+    if (p.packed) {
+      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true, false, true>), grid, block, 0, st, p);
+    } else {
+      hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, true>), grid, block, 0, st, p);
+    }
   } else {
     hipLaunchKernelGGL((spmm_kernel<VEC, LPR, false, false>), grid, block, 0, st, p);
   }
@@ -729,7 +754,7 @@ int validate(const gnan_spmm_args* a) {
   GNAN_REQUIRE(a->Cw >= 1, "spmm: Cw must be >= 1");
   GNAN_REQUIRE(a->n_cols <= 0x7fffffffLL, "spmm: n_cols exceeds int32 column ids");
   if (a->n_rows == 0) return GNAN_OK;
-  GNAN_REQUIRE(a->S && a->lut && a->Y && a->code, "spmm: null S / lut / Y / code");
+  GNAN_REQUIRE(a->S && a->lut && a->Y && (a->code || a->packed_index), "spmm: null S / lut / Y / code");
   GNAN_REQUIRE((a->rowptr == nullptr) == (a->col == nullptr), "spmm: rowptr and col must both be set (CSR) or both NULL (dense)");
   GNAN_REQUIRE(a->s_stride >= a->W && (a->reduce_cr != 0 || a->y_stride >= a->W), "spmm: row stride smaller than W");
   if (a->s_dtype != GNAN_F32 && a->s_dtype != GNAN_BF16) return gnan::fail(GNAN_ERR_BAD_ARG, "spmm: unknown operand dtype %d", a->s_dtype);
@@ -747,6 +772,10 @@ int validate(const gnan_spmm_args* a) {
   if (a->s_by_code && a->W > 32)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: s_by_code covers operand rows of at most 32 columns (got W=%d)", a->W);
   GNAN_REQUIRE(!a->scatter_out || a->row_ids, "spmm: scatter_out needs row_ids");
+  if (a->packed_index && (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->weight_by_col || a->minus_rest || a->s_by_code ||
+                          a->n_cols > static_cast<int64_t>(kPackMask) + 1))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: packed index entries need the CSR layout, D <= 4, one weight channel, plain "
+                      "forward weights and n_cols <= 2^29");
   if (a->reduce_cr != 0) {
     const int cr = a->reduce_cr;
     if (!(cr == 1 || cr == 2 || cr == 4) || a->W % cr != 0)
@@ -783,6 +812,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.weight_by_col = a->weight_by_col; p.minus_rest = a->minus_rest; p.reduce_cr = a->reduce_cr;
   p.scatter_out = a->scatter_out;
   p.s_by_code = a->s_by_code;
+  p.packed = a->packed_index;
   p.Y = a->Y; p.y_stride = a->y_stride;
   p.long_threshold = a->n_long > 0 ? a->long_threshold : INT64_MAX;
   p.long_rows = a->long_rows; p.long_slice_ptr = a->long_slice_ptr;
@@ -1268,6 +1298,7 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
                                   float* dwt, int32_t reduce_rows, void* workspace, size_t workspace_bytes,
                                   gnan_stream_t stream) {
   if (int rc = validate(a)) return rc;
+  GNAN_REQUIRE(!a->packed_index, "lut_grad: packed index entries are read by gnan_spmm_fwd only");
   GNAN_REQUIRE(dwt != nullptr, "lut_grad: null output");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->n_rows == 0) {
@@ -1357,6 +1388,7 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows
                                     int32_t with_rest, float* dS, int64_t ds_stride, float* dlut, void* workspace,
                                     size_t workspace_bytes, gnan_stream_t stream) {
   if (int rc = validate(a)) return rc;
+  GNAN_REQUIRE(!a->packed_index, "bwd_narrow: packed index entries are read by gnan_spmm_fwd only");
   GNAN_REQUIRE(dS != nullptr && dlut != nullptr && (s_rows != nullptr || a->n_rows == 0), "bwd_narrow: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->s_dtype != GNAN_F32 || a->lut_row_stride != 0 || a->cnt != nullptr)
@@ -1397,6 +1429,7 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows
 
 extern "C" int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream) {
   if (int rc = validate(a)) return rc;
+  GNAN_REQUIRE(!a->packed_index, "shell_sums: packed index entries are read by gnan_spmm_fwd only");
   if (a->n_rows == 0) return GNAN_OK;
   GNAN_REQUIRE(!a->weight_by_col, "shell_sums: weight_by_col has no meaning here");
   if (a->s_dtype != GNAN_F32) return gnan::fail(GNAN_ERR_UNSUPPORTED, "shell_sums: fp32 operand rows only (no backward for bf16 storage)");

@@ -547,12 +547,15 @@ def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_tota
 # =============================================================================
 def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut, weight_by_col=False,
                minus_rest=False, plan=None, workspace=None, reduce_cr=0, scatter_out=False,
-               s_by_code=False) -> _lib.SpmmArgs:
+               s_by_code=False, packed=False) -> _lib.SpmmArgs:
     D, Cw = lut.shape[-2], lut.shape[-1]
+    # one index stream (col | code << 29) where the graph carries it and the kernel variant reads it (gnan_hip.h)
+    packed = bool(packed and PACKED_INDEX and g.colp is not None and D <= 4 and Cw == 1 and not weight_by_col
+                  and not minus_rest and not s_by_code)
     a = _lib.SpmmArgs(
         n_rows=out.shape[0], n_cols=g.n_cols,
         rowptr=_lib.ptr(g.rowptr), rowptr_is64=int(g.rowptr is not None and g.rowptr.dtype == torch.int64),
-        col=_lib.ptr(g.col), code=_lib.ptr(g.code), row_ids=_lib.ptr(row_ids),
+        col=_lib.ptr(g.colp if packed else g.col), code=_lib.ptr(g.code), row_ids=_lib.ptr(row_ids),
         S=_lib.ptr(S), s_dtype=_lib.GNAN_BF16 if S.dtype == torch.bfloat16 else _lib.GNAN_F32, W=S.shape[1],
         s_stride=S.stride(0),
         lut=_lib.ptr(lut), lut_row_stride=(D * Cw if per_row_lut else 0), D=D, Cw=Cw,
@@ -565,7 +568,7 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         n_long=(plan.n_long if plan is not None else 0), n_slices=(plan.n_slices if plan is not None else 0),
         slice_edges=(plan.slice_edges if plan is not None else 0),
         workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0),
-        s_by_code=int(s_by_code), nnz=(0 if g.col is None else int(g.col.numel())))
+        s_by_code=int(s_by_code), nnz=(0 if g.col is None else int(g.col.numel())), packed_index=int(packed))
     return a
 
 
@@ -591,6 +594,7 @@ FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum ov
 DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
 DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
 NARROW_ROW_SLICING = os.environ.get("GNAN_NARROW_ROW_SLICING", "1") != "0"   # A/B switch of LONG_ROW_THRESHOLD_NARROW
+PACKED_INDEX = os.environ.get("GNAN_PACKED_INDEX", "1") != "0"         # degree-sorted copies are read as one (col | code << 29) stream
 NARROW_SORTED_WALK = os.environ.get("GNAN_NARROW_SORTED", "1") != "0"   # narrow operand rows walk the degree-sorted copy too
 HOT_COLUMN_ROWS = os.environ.get("GNAN_HOT_COLUMNS", "1") != "0"        # ... and read the most listed neighbours from a compact copy
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
@@ -658,7 +662,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
     else:
         plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING and row_ids is None) else g.long_row_plan(row_ids)
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
-                   reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code)
+                   reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code, packed=True)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
     ws = None
     if need:

@@ -28,6 +28,7 @@ LONG_ROW_THRESHOLD_NARROW = 64   # ... for operand rows of one or two lanes: a s
                                  # of a few hundred pairs set the kernel's duration (arxiv-shaped backward: 127 -> 25 us)
 NARROW_PLAN_MAX_ROWS = 8192
 SLICE_EDGES = 2048         # pairs per slice of a hub row
+PACK_SHIFT = 29            # packed index entries: column id in the low 29 bits, hop code above (gnan_spmm_args.packed_index)
 HOT_COLUMNS = 65536        # neighbours whose operand rows get a compact second copy (narrow operands, HopGraph.hot_columns)
 HOT_COLUMNS_MIN_NNZ = 1 << 24    # below this the two extra launches that fill the copy cost more than the gathers save
 HOT_COLUMNS_MIN_SHARE = 0.15     # ... and so does a graph whose K most listed neighbours receive less than this share of the pairs
@@ -53,6 +54,7 @@ class HopGraph:
     cnt: torch.Tensor                    # int32 [n_rows, D]
     rowptr: Optional[torch.Tensor] = None   # int32/int64 [n_rows + 1]; None => dense layout
     col: Optional[torch.Tensor] = None      # int32 [nnz]
+    colp: Optional[torch.Tensor] = None     # int32 [nnz]: col | code << 29 (degree-sorted copies of graphs below 2^29 neighbours)
     _plan: Optional[LongRowPlan] = field(default=None, repr=False)
     _transposed: Optional["HopGraph"] = field(default=None, repr=False)
     _degree_order: Optional[torch.Tensor] = field(default=None, repr=False)
@@ -296,6 +298,7 @@ class HopGraph:
             cnt_s = self.cnt[o].contiguous() if self.cnt.shape[0] == self.n_rows and not self._cnt_by_col else self.cnt
             g = HopGraph(n_rows=self.n_rows, n_cols=self.n_cols, n_codes=self.n_codes, code=code_s,
                          cnt=cnt_s, rowptr=rp, col=col_s)
+            g.colp = g._packed_index()
             g.long_row_plan()
             self._sorted_copy = g
         return self._sorted_copy, self._degree_order, self._sorted_copy._plan
@@ -322,6 +325,18 @@ class HopGraph:
             self._hot = (ids,)
         return self._hot[0]
 
+    def _packed_index(self) -> Optional[torch.Tensor]:
+        """``col | code << 29`` as int32, one 4-byte index stream for the aggregation kernel instead of two (its index
+        loads are L2 requests like its gathers); ``None`` when ids or codes do not fit."""
+        if self.is_dense or self.n_cols > (1 << PACK_SHIFT) or self.n_codes > 4:
+            return None
+        out = torch.empty_like(self.col)
+        chunk = 1 << 27                                       # pairs per pass: bounds the int64 temporaries
+        for e0 in range(0, int(self.col.numel()), chunk):
+            v = self.col[e0:e0 + chunk].long() | (self.code[e0:e0 + chunk].long() << PACK_SHIFT)
+            out[e0:e0 + chunk] = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)
+        return out
+
     def _with_hot_columns(self, hot: torch.Tensor) -> "HopGraph":
         """This graph with the column id of every pair that lists ``hot[k]`` replaced by ``n_cols + k``."""
         rank = torch.full((self.n_cols,), -1, dtype=torch.int32, device=self.device)
@@ -335,6 +350,7 @@ class HopGraph:
         g = HopGraph(n_rows=self.n_rows, n_cols=self.n_cols + int(hot.numel()), n_codes=self.n_codes, code=self.code,
                      cnt=self.cnt, rowptr=self.rowptr, col=col_h)
         g._plan, g._plans, g._cnt_by_col = self._plan, self._plans, self._cnt_by_col     # same rows, same hub-row plans
+        g.colp = g._packed_index()
         return g
 
     def degree_sorted_copy_hot(self):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 25
+#define GNAN_ABI_VERSION 26
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -327,6 +327,9 @@ typedef struct gnan_spmm_args {
                                     CSR layout, fp32 rows, no s_total, W <= 32 (GNAN_ERR_UNSUPPORTED beyond) */
   int64_t nnz;                   /* listed pairs = readable length of col / code (CSR); 0 = unknown.  Known, the kernels read a
                                   * lane's run of index entries with wide loads (which may reach past the row end, never past nnz) */
+  int32_t packed_index;          /* gnan_spmm_fwd only: every col entry is  column | hop code << 29  and `code` is not read (may be
+                                  * NULL): one index stream instead of two.  CSR layout, n_cols <= 2^29, D <= 4, Cw == 1, no
+                                  * weight_by_col / minus_rest / s_by_code (GNAN_ERR_UNSUPPORTED otherwise) */
 } gnan_spmm_args;
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);

@@ -923,6 +923,35 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
         assert O.rel_err(out["hot"].cpu(), want) <= 1e-5
 
 
+@pytest.mark.parametrize("W,K,bf16", [(64, 1, False), (64, 2, False), (64, 1, True), (1, 2, False), (16, 1, False)])
+def test_packed_index_entries_give_the_same_bits(W, K, bf16, monkeypatch):
+    """The degree-sorted copy read as ONE index stream (col | code << 29, gnan_spmm_args.packed_index) == the same copy
+    read as separate col / code arrays, bit for bit: rows, hub-row slices, wide index runs, bf16 rows; the packed array
+    itself is checked against its definition, and shapes it cannot carry keep the two arrays."""
+    from gnan_amd import functional, graph as G
+    from gnan_amd.functional import spmm_launch
+    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
+    rng = np.random.default_rng(W + K)
+    n, D = 6000, K + 2
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 5000), (5999, 2100)])
+    g = _graph(rowptr, col, code, n, D)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    if bf16:
+        S = S.bfloat16()
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    out = {}
+    for packed in (False, True):
+        monkeypatch.setattr(functional, "PACKED_INDEX", packed)
+        out[packed] = spmm_launch(g, S, lut, True, True, reduce_cr=1 if W == 64 else 0)
+    copy = g.degree_sorted_copy()[0]
+    assert copy.colp is not None
+    want = copy.col.long() | (copy.code.long() << G.PACK_SHIFT)
+    assert torch.equal(copy.colp.long() & 0xffffffff, want)
+    assert torch.equal(out[False], out[True])
+    wide = _graph(rowptr, col, np.minimum(code, 1), n, 6)               # six shells: codes no longer fit the kernel variant
+    assert wide.degree_sorted_copy()[0].colp is None
+
+
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
     place == rows processed in natural order (same arithmetic per row)."""
