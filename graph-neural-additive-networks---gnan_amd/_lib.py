@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -117,6 +117,11 @@ SYMBOLS = {
     "gnan_fpwl_moments": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gnan_fpwl_moments_fixed": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "gnan_fpwl_locate_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),
+    "gnan_fpwl_locate": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnan_fpwl_rows_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnan_fpwl_rows_moments_fixed": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]),
     "gnan_fpwl_moment_scales": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "gnan_fpwl_param_grads": (C.c_int, [C.POINTER(FpwlGradArgs), C.c_void_p]),

@@ -42,6 +42,13 @@ struct Params {
                          // the workgroup then owns ONE pass of nodes and walks all feature groups for them
 };
 
+// LDS row strides of the per-piece tables: an odd number of words per piece for C > 1.  The threads of a wavefront
+// read channel c of DIFFERENT pieces (thread = node), i.e. addresses `piece * stride + c`: with stride = C = 40 those
+// fall on 4 of the 32 banks (16-way conflicts; C = 32: one bank), and the 64-bit bins of the moment kernels, stride 2 C
+// quad-words, on a single bank pair.  arxiv-shaped C = 40: look-up 2.30 -> ? ms, moments 4.53 -> ? ms.
+__host__ __device__ __forceinline__ int table_stride(int C) { return C > 1 ? (C | 1) : 1; }          // floats per (val | slope) row
+__host__ __device__ __forceinline__ int bin_stride(int C) { return C > 1 ? 2 * C + 1 : 2; }          // bins per piece: [2][C] (+ 1)
+
 // Thread = (node, feature quad): FPT = min(FG, 4) features per thread, TPN = FG / FPT threads per node, so a
 // node's FG x values are one contiguous 16-B load per thread (a 64-B sector per node for FG = 16), the
 // per-thread state is a handful of registers (8 waves/SIMD), and every thread runs FPT independent searches.
@@ -115,14 +122,23 @@ __global__ __launch_bounds__(BS) void fpwl_kernel(const Params p) {
     const int nf = FAST ? FG : (p.F - k0 < FG ? p.F - k0 : FG);
     const int base = p.off[k0];
     const int tot = p.off[k0 + nf] - base;
+    const int Cs = table_stride(C);
     float* anchor_l = smem;
     float* val_l = smem + tot;
-    float* slope_l = val_l + static_cast<int64_t>(tot) * C;
+    float* slope_l = val_l + static_cast<int64_t>(tot) * Cs;
     __syncthreads();  // previous group's searches are done with the LDS tables
     for (int i = tid; i < tot; i += BS) anchor_l[i] = p.anchor[base + i];
-    for (int i = tid; i < tot * C; i += BS) {
-      val_l[i] = p.val[static_cast<int64_t>(base) * C + i];
-      slope_l[i] = p.slope[static_cast<int64_t>(base) * C + i];
+    if (Cs == C) {
+      for (int i = tid; i < tot * C; i += BS) {
+        val_l[i] = p.val[static_cast<int64_t>(base) * C + i];
+        slope_l[i] = p.slope[static_cast<int64_t>(base) * C + i];
+      }
+    } else {
+      for (int i = tid; i < tot * C; i += BS) {
+        const int r = i / C, j = r * Cs + (i - r * C);
+        val_l[j] = p.val[static_cast<int64_t>(base) * C + i];
+        slope_l[j] = p.slope[static_cast<int64_t>(base) * C + i];
+      }
     }
     if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
     __syncthreads();
@@ -157,17 +173,38 @@ __global__ __launch_bounds__(BS) void fpwl_kernel(const Params p) {
 
       if constexpr (SUM) {
         float* o = p.out + n * p.out_stride;
-        for (int c = 0; c < (FAST ? 1 : C); ++c) {
-          float a = 0.f;
+        // channels in chunks of CU: the run-time loop over C is not unrolled by the compiler, and one channel per iteration
+        // is a chain of four dependent LDS round trips (table reads, accumulator read, write) — at one workgroup per CU
+        // (C = 40: 129 KB of LDS) that chain, not bandwidth, set the kernel's time (arxiv-shaped C = 40: 2.3 ms)
+        constexpr int CU = FAST ? 1 : 8;
+        for (int c0 = 0; c0 < (FAST ? 1 : C); c0 += CU) {
+          float a[CU];
 #pragma unroll
-          for (int f = 0; f < FPT; ++f)
-            if (live[f]) a += fmaf(slope_l[idx[f] * C + c], d[f], val_l[idx[f] * C + c]);
+          for (int u = 0; u < CU; ++u) {
+            const int c = c0 + u < C ? c0 + u : C - 1;       // tail: an in-range read whose result is dropped
+            a[u] = 0.f;
 #pragma unroll
-          for (int off = 1; off < TPN; off <<= 1) a += __shfl_xor(a, off);   // the node's TPN threads
+            for (int f = 0; f < FPT; ++f)
+              if (live[f]) a[u] += fmaf(slope_l[idx[f] * Cs + c], d[f], val_l[idx[f] * Cs + c]);
+          }
+#pragma unroll
+          for (int off = 1; off < TPN; off <<= 1)            // the node's TPN threads
+#pragma unroll
+            for (int u = 0; u < CU; ++u) a[u] += __shfl_xor(a[u], off);
           // groups run one after the other inside the workgroup and a node keeps its thread: no race
           if (q == 0) {
-            if (p.acc_offset) acc_l[c * NODES + nl] += a;      // many channels: accumulate on chip, store once
-            else o[c] = g == 0 ? a : o[c] + a;
+            if (p.acc_offset) {                              // many channels: accumulate on chip, store once
+              float old[CU];
+#pragma unroll
+              for (int u = 0; u < CU; ++u) old[u] = acc_l[(c0 + u < C ? c0 + u : C - 1) * NODES + nl];
+#pragma unroll
+              for (int u = 0; u < CU; ++u)
+                if (c0 + u < C) acc_l[(c0 + u) * NODES + nl] = old[u] + a[u];
+            } else {
+#pragma unroll
+              for (int u = 0; u < CU; ++u)
+                if (c0 + u < C) o[c0 + u] = g == 0 ? a[u] : o[c0 + u] + a[u];
+            }
           }
         }
       } else {
@@ -193,7 +230,7 @@ __global__ __launch_bounds__(BS) void fpwl_kernel(const Params p) {
 #pragma unroll
           for (int f = 0; f < FPT; ++f)
             if (live[f])
-              for (int c = 0; c < C; ++c) o[f * C + c] = fmaf(slope_l[idx[f] * C + c], d[f], val_l[idx[f] * C + c]);
+              for (int c = 0; c < C; ++c) o[f * C + c] = fmaf(slope_l[idx[f] * Cs + c], d[f], val_l[idx[f] * Cs + c]);
         }
       }
     }
@@ -461,9 +498,10 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
   const int base = p.off[k0];
   const int tot = p.off[k0 + nf] - base;
   float* anchor_l = smem;
-  bin_t* bins = reinterpret_cast<bin_t*>(smem + (tot + 1) / 2 * 2);   // [tot][2][C], 8-byte aligned
+  const int Rb = bin_stride(C);
+  bin_t* bins = reinterpret_cast<bin_t*>(smem + (tot + 1) / 2 * 2);   // [tot][2][C] (+ 1 bin of padding per piece), 8-byte aligned
   for (int i = tid; i < tot; i += BS) anchor_l[i] = p.anchor[base + i];
-  for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = bin_t(0);
+  for (int i = tid; i < tot * Rb; i += BS) bins[i] = bin_t(0);
   double s0 = 1.0, s1 = 1.0;
   if constexpr (FIXED) { s0 = mp.scales[0]; s1 = mp.scales[1]; }
   if (tid <= nf) s_off[tid] = p.off[k0 + tid] - base;
@@ -490,24 +528,33 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {
       d[f] = xv[f] - anchor_l[idx[f]];
-      b[f] = bins + static_cast<int64_t>(idx[f]) * 2 * C;
+      b[f] = bins + static_cast<int64_t>(idx[f]) * Rb;
     }
-    // channel-major: in feature-sum mode a channel's gradient is read (and converted) once for the thread's features
-    for (int c = 0; c < C; ++c) {
-      float gs = 0.f;
-      if (p.sum_features) gs = gr[c];
-      unsigned long long t0s = 0ull;
-      if constexpr (FIXED) t0s = fixed_bits(gs, s0);
+    // channel-major: in feature-sum mode a channel's gradient is read (and converted) once for the thread's features;
+    // channels in chunks of 8 so that the (node-strided, i.e. uncoalesced) gradient loads of a chunk are in flight
+    // together — one channel per iteration of the run-time loop waited a full memory latency per channel
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float gs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gs[u] = (p.sum_features && c0 + u < C) ? gr[c0 + u] : 0.f;
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
         if (live[f]) {
-          const float gv = p.sum_features ? gs : gr[f * C + c];
-          if constexpr (FIXED) {
-            atomicAdd(b[f] + c, p.sum_features ? t0s : fixed_bits(gv, s0));
-            atomicAdd(b[f] + C + c, fixed_bits(gv * d[f], s1));
-          } else {
-            atomicAdd(b[f] + c, gv);
-            atomicAdd(b[f] + C + c, gv * d[f]);
+          float gf[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gf[u] = p.sum_features ? gs[u] : (c0 + u < C ? gr[f * C + c0 + u] : 0.f);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c < C) {
+              if constexpr (FIXED) {
+                atomicAdd(b[f] + c, fixed_bits(gf[u], s0));
+                atomicAdd(b[f] + C + c, fixed_bits(gf[u] * d[f], s1));
+              } else {
+                atomicAdd(b[f] + c, gf[u]);
+                atomicAdd(b[f] + C + c, gf[u] * d[f]);
+              }
+            }
           }
         }
       }
@@ -517,13 +564,13 @@ __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp)
   if constexpr (FIXED) {
     unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2 * C;
     for (int i = tid; i < tot * 2 * C; i += BS) {
-      const unsigned long long v = bins[i];
+      const unsigned long long v = bins[(i / (2 * C)) * Rb + i % (2 * C)];
       if (v != 0ull) atomicAdd(out + i, v);
     }
   } else {
     float* out = mp.M + static_cast<int64_t>(base) * 2 * C;
     for (int i = tid; i < tot * 2 * C; i += BS) {
-      const float v = bins[i];
+      const float v = bins[(i / (2 * C)) * Rb + i % (2 * C)];
       if (v != 0.f) atomicAdd(out + i, v);
     }
   }
@@ -548,13 +595,14 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
   const int k0 = blockIdx.y * FG;
   const int base = p.off[k0];
   const int tot = p.off[k0 + FG] - base;
+  const int Rb = bin_stride(C);
   unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + kTreeWords);
-  float* an_l = reinterpret_cast<float*>(bins + static_cast<int64_t>(tot) * 2 * C);
+  float* an_l = reinterpret_cast<float*>(bins + static_cast<int64_t>(tot) * Rb);
   int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
   if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
-  for (int i = tid; i < tot * 2 * C; i += BS) bins[i] = 0ull;
+  for (int i = tid; i < tot * Rb; i += BS) bins[i] = 0ull;
   for (int i = tid; i < tot; i += BS) an_l[i] = p.anchor[base + i];
   __syncthreads();
   for (int i = tid; i < FG * P2; i += BS) {
@@ -602,24 +650,32 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
     for (int f = 0; f < FPT; ++f) {
       const int piece = binoff[f] + (((a[f] - Q) >> 2) - P2);
       d[f] = xv[f] - an_l[piece];
-      b[f] = bins + static_cast<int64_t>(piece) * 2 * C;
+      b[f] = bins + static_cast<int64_t>(piece) * Rb;
     }
-    for (int c = 0; c < C; ++c) {                   // channel-major (see fpwl_moments_kernel)
-      float gs = 0.f;
-      if (p.sum_features) gs = gr[c];
-      const unsigned long long t0s = fixed_bits(gs, s0);
+    for (int c0 = 0; c0 < C; c0 += 8) {             // channel-major, chunks of 8 (see fpwl_moments_kernel)
+      float gs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gs[u] = (p.sum_features && c0 + u < C) ? gr[c0 + u] : 0.f;
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const float gv = p.sum_features ? gs : gr[f * C + c];
-        atomicAdd(b[f] + c, p.sum_features ? t0s : fixed_bits(gv, s0));
-        atomicAdd(b[f] + C + c, fixed_bits(gv * d[f], s1));
+        float gf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gf[u] = p.sum_features ? gs[u] : (c0 + u < C ? gr[f * C + c0 + u] : 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + u;
+          if (c < C) {
+            atomicAdd(b[f] + c, fixed_bits(gf[u], s0));
+            atomicAdd(b[f] + C + c, fixed_bits(gf[u] * d[f], s1));
+          }
+        }
       }
     }
   }
   __syncthreads();
   unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2 * C;
   for (int i = tid; i < tot * 2 * C; i += BS) {
-    const unsigned long long v = bins[i];
+    const unsigned long long v = bins[(i / (2 * C)) * Rb + i % (2 * C)];
     if (v != 0ull) atomicAdd(out + i, v);
   }
 }
@@ -764,7 +820,7 @@ int launch_moments_fast(MomentParams mp, hipStream_t st) {
   Params& p = mp.f;
   const size_t pieces = static_cast<size_t>(p.max_group_pieces);
   size_t lds = ((static_cast<size_t>(FG) << NSTEP) + (FG / 4) * kTreeSkew) * sizeof(float) +
-               pieces * 2 * static_cast<size_t>(p.C) * sizeof(unsigned long long) + pieces * sizeof(float);
+               pieces * static_cast<size_t>(bin_stride(p.C)) * sizeof(unsigned long long) + pieces * sizeof(float);
   p.soff_offset = static_cast<int>(lds / sizeof(float));
   lds += (FG + 1) * sizeof(int);
   if (lds > 150 * 1024) return -1;                       // caller falls back to the plain kernel
@@ -936,7 +992,7 @@ int common_checks(const gnan_fpwl_args* a) {
   GNAN_REQUIRE(a->max_pieces >= 1 && a->max_group_pieces >= 1, "fpwl: max_pieces / max_group_pieces must be >= 1");
   const int fg = a->features_per_group;
   GNAN_REQUIRE(fg == 1 || fg == 2 || fg == 4 || fg == 8 || fg == 16, "fpwl: features_per_group must be 1, 2, 4, 8 or 16");
-  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
+  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(table_stride(a->C))) * sizeof(float);
   if (lds > 150 * 1024)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: %zu B of tables per feature group exceed LDS; use fewer features per group",
                       lds);
@@ -1050,7 +1106,7 @@ int moments_common(const gnan_fpwl_args* a, const float* grad, int64_t grad_stri
   mp.vec_g = !a->sum_features && a->C == 1 && grad_stride % 4 == 0 && reinterpret_cast<uintptr_t>(grad) % 16 == 0;
   const size_t bin = moments_fixed ? sizeof(unsigned long long) : sizeof(float);
   const size_t pieces = static_cast<size_t>(a->max_group_pieces);
-  const size_t lds = (pieces + 1) / 2 * 2 * sizeof(float) + pieces * 2 * static_cast<size_t>(a->C) * bin;
+  const size_t lds = (pieces + 1) / 2 * 2 * sizeof(float) + pieces * static_cast<size_t>(bin_stride(a->C)) * bin;
   if (lds > 150 * 1024)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_moments: %zu B of bins per feature group exceed LDS", lds);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1086,7 +1142,7 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   const int fg = a->features_per_group;
   const int64_t ow = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(a->out_stride >= ow, "fpwl: out row stride smaller than the output width");
-  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(a->C)) * sizeof(float);
+  const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(table_stride(a->C))) * sizeof(float);
   Params p = base_params(a);
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
   p.vec_x = fg % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 && aligned(a->x);

@@ -84,7 +84,36 @@ PWL_MIN_NODES = 1 << 14      # inference on small graphs: the matrix-core kernel
 SUM_VIA_FEATURES_MAX_NODES = 32768   # table look-up with a feature sum and C > 1 on small graphs: per-feature pass + sum
 DENSE_SLICE_MAX_ROWS = 16384  # dense layout: slice every row over workgroups while row blocks alone would not fill the GPU
 DENSE_SLICE_MIN_COLS = 512
+WEIGHT_TABLE_MAX_BYTES = 1 << 30   # backward w.r.t. a wide S: per-node table of the pairs' weights while it stays below 1 GiB
 NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) operand while its rows stay <= 128 B
+
+
+FPWL_ROWS = os.environ.get("GNAN_FPWL_ROWS", "1") != "0"   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
+FPWL_ROWS_MIN_NODES = 32768
+
+
+def _fpwl_args(x: torch.Tensor, t, sum_features: bool, out=None) -> "_lib.FpwlArgs":
+    n, F = x.shape
+    return _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=t.val.shape[1], off=_lib.ptr(t.off),
+                         anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
+                         max_pieces=t.max_pieces, features_per_group=t.features_per_group,
+                         max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
+                         out=_lib.ptr(out), out_stride=0 if out is None else out.stride(0), out_dtype=_lib.GNAN_F32)
+
+
+def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
+    """Several channels on a large batch: the piece of every (node, feature) is located once (``gnan_fpwl_locate``) and the
+    channel work runs with lane = channel — arxiv-shaped C = 40: look-up 2.3 -> ? ms, moments 4.5 -> ? ms."""
+    return (FPWL_ROWS and 1 < C <= 64 and n >= FPWL_ROWS_MIN_NODES
+            and (not bins or t.max_pieces * (2 * C + 1) * 8 <= 150 * 1024))        # backward: a feature's 64-bit bins in LDS
+
+
+def _fpwl_locate(x: torch.Tensor, t, a):
+    n, F = x.shape
+    piece = torch.empty((n, F), dtype=torch.int32, device=x.device)
+    dx = torch.empty((n, F), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().gnan_fpwl_locate(a, _lib.ptr(piece), _lib.ptr(dx), _lib.stream_of(x)), "gnan_fpwl_locate")
+    return piece, dx
 
 
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32,
@@ -105,6 +134,11 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         out = per.view(n, F, C).sum(dim=1)
         return (out, None) if want_total else out
     out = torch.empty((n, C if sum_features else F * C), dtype=out_dtype, device=x.device)
+    if out_dtype == torch.float32 and _fpwl_rows_applies(n, C, t, bins=False):
+        a = _fpwl_args(x, t, sum_features, out)
+        piece, dx = _fpwl_locate(x, t, a)
+        _lib.check(_lib.lib().gnan_fpwl_rows_fwd(a, _lib.ptr(piece), _lib.ptr(dx), _lib.stream_of(x)), "gnan_fpwl_rows_fwd")
+        return (out, None) if want_total else out
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
@@ -159,7 +193,8 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features), out=None, out_stride=0)
     mgp = t.max_group_pieces
-    if MOMENTS_FIXED_POINT and n > 0 and (mgp + 1) // 2 * 8 + mgp * 2 * C * 8 <= 150 * 1024:
+    rows = _fpwl_rows_applies(n, C, t)                  # several channels, large batch: per-feature bins, lane = channel
+    if MOMENTS_FIXED_POINT and n > 0 and (rows or (mgp + 1) // 2 * 8 + mgp * (2 * C + 1 if C > 1 else 2) * 8 <= 150 * 1024):
         bits = min(50, 61 - max(1, (max(n, 2) - 1).bit_length()))   # a bin receives at most n terms; a term stays below 2^51
         if x_abs_max is None:
             x_abs_max = x.abs().max().double()
@@ -172,8 +207,14 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
                                                       _lib.ptr(scales), _lib.stream_of(x)), "gnan_fpwl_moment_scales")
         scales = scales[:2]
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
-        _lib.check(_lib.lib().gnan_fpwl_moments_fixed(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(scales), _lib.ptr(Mi),
-                                                      _lib.stream_of(x)), "gnan_fpwl_moments_fixed")
+        if rows:
+            piece, dx = _fpwl_locate(x, t, a)
+            _lib.check(_lib.lib().gnan_fpwl_rows_moments_fixed(a, _lib.ptr(piece), _lib.ptr(dx), _lib.ptr(grad), grad.stride(0),
+                                                               _lib.ptr(scales), _lib.ptr(Mi), _lib.stream_of(x)),
+                       "gnan_fpwl_rows_moments_fixed")
+        else:
+            _lib.check(_lib.lib().gnan_fpwl_moments_fixed(a, _lib.ptr(grad), grad.stride(0), _lib.ptr(scales), _lib.ptr(Mi),
+                                                          _lib.stream_of(x)), "gnan_fpwl_moments_fixed")
         if raw:
             return Mi, scales
         return (Mi.double() / scales.view(1, 2, 1)).float()
@@ -854,6 +895,17 @@ class _RhoAggregate(torch.autograd.Function):
                 Z = (wt.unsqueeze(-1) * dY_full.unsqueeze(1)).reshape(g.n_rows * D, W)
                 dS = spmm_launch(g.transposed(), Z, torch.ones((D, 1), device=Z.device), False, False, None,
                                  s_by_code=True)
+            elif g.n_rows * D * Cw * 4 <= WEIGHT_TABLE_MAX_BYTES:
+                # wide operand: the weight of a pair belongs to the NEIGHBOUR's row there.  Read from (lut, cnt) that is two
+                # random count reads, two divisions and a subtraction per pair; a per-node table wt(i, d) - wt(i, rest)
+                # built once per backward pass makes it one 4-byte read (arxiv-shaped W = 40: 0.55 -> ? ms)
+                wt = (lut if per_row else lut.unsqueeze(0)).float()                               # [N or 1, D, Cw]
+                if use_cnt:
+                    wt = wt / g.cnt.clamp_min(1).float().unsqueeze(-1)
+                if with_rest:
+                    wt = wt - wt[:, D - 1:D]
+                dS = spmm_launch(g.transposed(), dY_full, wt.expand(g.n_rows, D, Cw).contiguous(), False, False, None,
+                                 weight_by_col=True)
             else:
                 dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
                                  weight_by_col=True, minus_rest=with_rest)

@@ -41,18 +41,29 @@ class PwlTables(NamedTuple):
     max_group_pieces: int
 
 
+def table_stride(C: int) -> int:
+    """Floats per (val | slope) row of the LDS tables: odd for C > 1 (bank conflicts, csrc/fpwl.hip ``table_stride``)."""
+    return (C | 1) if C > 1 else 1
+
+
 def _plan_groups(off, C):
-    """Largest power-of-two group (<= 16 features) whose tables fit the preferred LDS budget."""
+    """Largest power-of-two group (<= 16 features) whose tables fit the preferred LDS budget; if none does (many
+    channels), the largest group whose 64-bit moment bins ALSO fit LDS — the float-bin fallback of the backward pass is an
+    order of magnitude slower (LDS float atomics are a compare-and-swap loop on gfx950) —, else the largest that fits."""
     F = len(off) - 1
-    best = None
+    fits = []
     for fg in (16, 8, 4, 2, 1):
         mg = max(off[min(F, k + fg)] - off[k] for k in range(0, F, fg))
-        nbytes = mg * (1 + 2 * C) * 4
+        nbytes = mg * (1 + 2 * table_stride(C)) * 4
         if nbytes <= LDS_PREFERRED:
             return fg, mg
-        if nbytes <= LDS_LIMIT and best is None:
-            best = (fg, mg)
-    return best
+        if nbytes <= LDS_LIMIT:
+            bins = (mg + 1) // 2 * 8 + mg * (2 * C + 1 if C > 1 else 2) * 8
+            fits.append((fg, mg, bins <= LDS_LIMIT))
+    for fg, mg, bins_fit in fits:
+        if bins_fit:
+            return fg, mg
+    return fits[0][:2] if fits else None
 
 
 def _prefix(x: torch.Tensor, p, depth: int, w, b):
@@ -292,7 +303,7 @@ class _PendingTables:
         p2 = 1
         while p2 < biggest:
             p2 <<= 1
-        room = min(mg + mg // 8 + 8, LDS_LIMIT // ((1 + 2 * self.C) * 4))     # never ask for more LDS than the kernel accepts
+        room = min(mg + mg // 8 + 8, LDS_LIMIT // ((1 + 2 * table_stride(self.C)) * 4))     # never ask for more LDS than the kernel accepts
         if room < mg:
             return None
         return PwlTables(self.meta[: self.F + 1], self.anchor, self.val, self.slope, max(p2, 64), fg, room)

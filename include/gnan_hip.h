@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 26
+#define GNAN_ABI_VERSION 27
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -175,6 +175,25 @@ int gnan_fpwl_moments(const gnan_fpwl_args* a, const float* grad, int64_t grad_s
  * Integer LDS atomics run ~12x faster than float ones on gfx950 and the sums are bit-reproducible. */
 int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t grad_stride, const double* scales,
                             int64_t* moments, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Table look-up with SEVERAL output channels in two phases (csrc/fpwl_rows.hip; node classification: C = classes).
+ * The piece a value falls into does not depend on the channel, so it is found once per (node, feature) and the
+ * channel work runs with lane = channel (coalesced table / gradient rows, no node-strided accesses):
+ *   gnan_fpwl_locate            piece[n, k] = row of the stacked tables (off[k] + piece of x[n, k]), dx[n, k] = x[n, k] -
+ *                               anchor[piece[n, k]]; both [n, F] row-major (gnan_fpwl_locate_bytes(a) bytes EACH); of the
+ *                               args x, n, x_stride, F, off, anchor, max_pieces are read;
+ *   gnan_fpwl_rows_fwd          out as gnan_fpwl_fwd (fp32; sum_features: [n, C], else [n, F*C]) from piece / dx and
+ *                               val / slope; args read: n, F, C, val, slope, sum_features, out, out_stride, out_dtype;
+ *   gnan_fpwl_rows_moments_fixed  the moments of gnan_fpwl_moments_fixed (same integers) from piece / dx and the upstream
+ *                               gradient; args read: n, F, C, off, max_pieces, sum_features.  C <= 64,
+ *                               max_pieces * (2 C + 1) * 8 bytes of LDS bins per feature (GNAN_ERR_UNSUPPORTED beyond).
+ * ------------------------------------------------------------------------------------------- */
+size_t gnan_fpwl_locate_bytes(const gnan_fpwl_args* a);
+int gnan_fpwl_locate(const gnan_fpwl_args* a, int32_t* piece, float* dx, gnan_stream_t stream);
+int gnan_fpwl_rows_fwd(const gnan_fpwl_args* a, const int32_t* piece, const float* dx, gnan_stream_t stream);
+int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32_t* piece, const float* dx, const float* grad,
+                                 int64_t grad_stride, const double* scales, int64_t* moments, gnan_stream_t stream);
 
 /* The two scales of gnan_fpwl_moments_fixed, computed on the device:
  *   scales[0] = 2^floor(bits - log2(max|grad|)),  scales[1] = 2^floor(bits - log2(max|grad| * (x_abs_max + max|anchor|)))

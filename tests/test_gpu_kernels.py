@@ -547,6 +547,47 @@ def test_table_path_parameter_gradients_edge_cases(fixed, monkeypatch):
                 assert float((a - b).abs().max()) <= 2e-5 * scale, (n, spread, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("F,L,H,C,sum_features", [(129, 3, 32, 40, True), (20, 3, 16, 7, True), (9, 2, 24, 2, True),
+                                                   (33, 3, 16, 64, True), (12, 3, 16, 5, False), (70, 3, 8, 17, False)])
+def test_two_phase_lookup_for_several_channels(F, L, H, C, sum_features, monkeypatch):
+    """csrc/fpwl_rows.hip: piece / dx located once per (node, feature) (bit-exact index work against the reference search),
+    forward rows == the thread-per-node kernel (same arithmetic per term; the feature sum in the same order when a thread
+    owns one feature) == float64 oracle; moments == the general fixed-point kernel, the same integers."""
+    from gnan_amd import _lib, functional, pwl
+    from gnan_amd.functional import _fpwl_launch, _fpwl_moments
+    monkeypatch.setattr(functional, "FPWL_ROWS_MIN_NODES", 1)
+    monkeypatch.setattr(functional, "SUM_VIA_FEATURES_MAX_NODES", 0)     # (the small-graph detour around the summing kernel)
+    sd = _mlp_state(F, L, H, C, True, seed=F + C)
+    st = _stack(sd, F, L, H, C, True)
+    t = pwl.build_tables(st)
+    n = 5000
+    x = (torch.rand(n, F, generator=torch.Generator().manual_seed(1)) * 4 - 2).to(DEV)
+    x[:, 0] = 0.25                                                       # a constant column: every node in the same piece
+    g = torch.randn(n, C if sum_features else F * C, generator=torch.Generator().manual_seed(2)).to(DEV)
+    # phase 1 against the definition
+    a = functional._fpwl_args(x, t, sum_features)
+    piece, dx = functional._fpwl_locate(x, t, a)
+    off, anchor = t.off.cpu().long(), t.anchor.cpu()
+    xc = x.cpu()
+    for k in (0, 1, F // 2, F - 1):
+        seg = anchor[off[k]:off[k + 1]]
+        want = off[k] + torch.searchsorted(seg[1:].contiguous(), xc[:, k].contiguous(), right=True)
+        assert torch.equal(piece[:, k].cpu().long(), want)
+        assert torch.equal(dx[:, k].cpu(), xc[:, k] - anchor[want])
+    out = {}
+    for rows in (True, False):
+        monkeypatch.setattr(functional, "FPWL_ROWS", rows)
+        out[rows] = (_fpwl_launch(x, t, sum_features), _fpwl_moments(x, t, g, sum_features, raw=True)[0])
+    assert torch.equal(out[True][1], out[False][1])                      # the same integers in the bins
+    truth = O.feature_mlps(x.cpu().double(), {k: v.double() for k, v in sd.items()})          # [n, F, C]
+    truth = truth.sum(1) if sum_features else truth.reshape(n, F * C)
+    assert O.rel_err(out[True][0].cpu(), truth) <= 1e-5
+    if t.features_per_group == 1 or not sum_features:
+        assert torch.equal(out[True][0], out[False][0])
+    else:
+        assert O.rel_err(out[True][0].cpu(), out[False][0].cpu().double()) <= 2e-6
+
+
 @pytest.mark.parametrize("n,width,gscale", [(1000, 3, 1.0), (70000, 1, 1e-12), (5, 64, 1e20), (100, 2, 0.0)])
 def test_moment_scales_kernel(n, width, gscale):
     """gnan_fpwl_moment_scales == the framework formula it replaced (powers of two from max|grad| and max|x - anchor|)."""
