@@ -1,12 +1,12 @@
 """arxiv-shaped forward+backward with C output channels (C in {1, 40}): kernel split from torch.profiler.
-    python tools/experiments/profile_arxiv_c.py [C]"""
+    python tools/experiments/profile_arxiv_c.py [C [nodes edges features]]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import microbench as mb
 import torch
 from torch.profiler import profile, ProfilerActivity
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-N, E, F = 169_343, 1_166_243, 129
+N, E, F = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (169_343, 1_166_243, 129)
 gen = torch.Generator(device="cuda").manual_seed(0)
 src = torch.randint(0, N, (E,), generator=gen, device="cuda")
 dst = (torch.rand(E, generator=gen, device="cuda") ** 3 * N).long().clamp_(0, N - 1)
