@@ -412,7 +412,9 @@ extern "C" int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32
   const int64_t gw = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(grad_stride >= gw, "fpwl_rows_moments: grad row stride smaller than its width");
   GNAN_REQUIRE(a->max_pieces >= 1, "fpwl_rows_moments: max_pieces must be >= 1");
-  const size_t lds = static_cast<size_t>(a->max_pieces) * (2 * static_cast<size_t>(a->C) + 1) * sizeof(unsigned long long);
+  // pieces of one feature: at most max_pieces, and at most max_group_pieces when the caller states it (> 0)
+  const int per_feature = (a->max_group_pieces > 0 && a->max_group_pieces < a->max_pieces) ? a->max_group_pieces : a->max_pieces;
+  const size_t lds = static_cast<size_t>(per_feature) * (2 * static_cast<size_t>(a->C) + 1) * sizeof(unsigned long long);
   if (lds > 150 * 1024)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_moments: %zu B of bins per feature exceed LDS", lds);
   RowsMomentParams p;

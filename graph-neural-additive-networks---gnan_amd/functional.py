@@ -105,7 +105,9 @@ def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
     """Several channels on a large batch: the piece of every (node, feature) is located once (``gnan_fpwl_locate``) and the
     channel work runs with lane = channel — arxiv-shaped C = 40: look-up 2.3 -> ? ms, moments 4.5 -> ? ms."""
     return (FPWL_ROWS and 1 < C <= 64 and n >= FPWL_ROWS_MIN_NODES
-            and (not bins or t.max_pieces * (2 * C + 1) * 8 <= 150 * 1024))        # backward: a feature's 64-bit bins in LDS
+            # backward: a feature's 64-bit bins in LDS (tables sized for a hipGraph carry max_pieces rounded up to a power of
+            # two, but a group — hence a feature — has at most max_group_pieces)
+            and (not bins or min(t.max_pieces, t.max_group_pieces) * (2 * C + 1) * 8 <= 150 * 1024))
 
 
 def _fpwl_locate(x: torch.Tensor, t, a):
