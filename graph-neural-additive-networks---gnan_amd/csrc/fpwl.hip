@@ -321,9 +321,14 @@ __device__ __forceinline__ void load_tree_tables(const Params& p, float* smem, c
   }
 }
 
-template <int FG, bool SUM, bool OUT16, int NSTEP, int BS>
+// RAGGED (feature-sum mode only): F need not be a multiple of FG and the rows of x need not be 16-byte aligned — the
+// reference's inputs are raw features + a ones column (129, 1434: pre_process_datasets.py:108), which sent every real
+// feature matrix below the padding threshold to the general kernel above (arxiv-shaped: 0.109 ms against ~0.05 ms).
+// The last group is partial: its missing features get empty (+inf) trees, their x is not read and their terms are dropped.
+template <int FG, bool SUM, bool OUT16, int NSTEP, int BS, bool RAGGED = false>
 __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
   static_assert(FG % 4 == 0, "feature quads");
+  static_assert(!RAGGED || (SUM && !OUT16), "ragged feature counts: feature-sum mode");
   constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
   // addresses are raw LDS byte addresses (LDS base folded in once per group): addressing through the `smem` symbol
   // costs a fourth instruction per step, because its base is only resolved at link time
@@ -350,10 +355,11 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
 
   for (int g = g_lo; g < g_hi; ++g) {
     const int k0 = g * FG;
+    const int nf = RAGGED ? (p.F - k0 < FG ? p.F - k0 : FG) : FG;     // live features of the group
     const int base = p.off[k0];
-    const int tot = p.off[k0 + FG] - base;
+    const int tot = p.off[k0 + nf] - base;
     __syncthreads();                                // previous group's look-ups are done with the LDS tables
-    if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
+    if (tid <= FG) s_off[tid] = p.off[k0 + (tid < nf ? tid : nf)] - base;
     __syncthreads();
     load_tree_tables<FG, NSTEP, BS>(p, smem, s_off, base, tot, true);
     __syncthreads();
@@ -367,9 +373,19 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
       dA[f] = static_cast<int>(lds_base) + kTreeBytes + 8 * tot + 4 * s_off[q * FPT + f] - 4 * P2 - Q;
 
     float ps[FPT] = {0.f, 0.f, 0.f, 0.f};           // column sums of the output (per-feature mode)
+    bool live[FPT];
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) live[f] = !RAGGED || q * FPT + f < nf;
     for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
-      const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
-      const float xv[FPT] = {t.x, t.y, t.z, t.w};
+      float xv[FPT];
+      if constexpr (RAGGED) {
+        const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) xv[f] = live[f] ? xr[f] : 0.f;
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
+        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      }
       int a[FPT];
 #pragma unroll
       for (int f = 0; f < FPT; ++f) a[f] = Q + 4;   // node 1 = root
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
       if constexpr (SUM) {
         float acc = 0.f;
 #pragma unroll
-        for (int f = 0; f < FPT; ++f) acc += y[f];
+        for (int f = 0; f < FPT; ++f) acc += (!RAGGED || live[f]) ? y[f] : 0.f;
 #pragma unroll
         for (int off = 1; off < TPN; off <<= 1) acc += __shfl_xor(acc, off);   // the node's TPN threads
         if (q == 0) {                               // groups run one after the other and a node keeps its thread
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
 // bank pair), a conversion is fixed_bits() and the workgroup map is the forward's (the groups of a node block run back
 // to back on one XCD and share the 128-B lines of x in its L2).  SUMF: the gradient is [n, 1] (feature sum) and its M0
 // term is converted once per node; otherwise [n, F] and read as one 16-byte load next to x.
-template <int FG, int NSTEP, int BS, bool SUMF>
+template <int FG, int NSTEP, int BS, bool SUMF, bool RAGGED = false>
 __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams mp) {
   static_assert(FG % 4 == 0, "feature quads");
   constexpr int FPT = 4, TPN = FG / FPT, NODES = BS / TPN, P2 = 1 << NSTEP;
@@ -706,13 +722,14 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
   if (n_lo >= p.n) return;
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
   const int k0 = grp * FG;
+  const int nf = RAGGED ? (p.F - k0 < FG ? p.F - k0 : FG) : FG;       // live features of the group (see fpwl_fast_kernel)
   const int base = p.off[k0];
-  const int tot = p.off[k0 + FG] - base;
+  const int tot = p.off[k0 + nf] - base;
   unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + kTreeWords);   // [2][tot]
   int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
-  if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
+  if (tid <= FG) s_off[tid] = p.off[k0 + (tid < nf ? tid : nf)] - base;
   for (int i = tid; i < 2 * tot; i += BS) bins[i] = 0ull;
   __syncthreads();
   for (int i = tid; i < FG * P2; i += BS) {
@@ -730,28 +747,37 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
   asm volatile("" : "+v"(nQ), "+v"(nQ4));           // two opaque registers: compare, select, shift-add per step
   int binoff[FPT];
   float a0[FPT];                                    // anchor of piece 0 (what the search keeps when it never steps right)
+  bool live[FPT];
 #pragma unroll
   for (int f = 0; f < FPT; ++f) {
+    live[f] = !RAGGED || q * FPT + f < nf;
     binoff[f] = s_off[q * FPT + f] - P2;
-    a0[f] = p.anchor[base + s_off[q * FPT + f]];
+    a0[f] = live[f] ? p.anchor[base + s_off[q * FPT + f]] : 0.f;
   }
   const double s0 = mp.scales[0], s1 = mp.scales[1];
   for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
-    const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
+    float xv[FPT];
+    if constexpr (RAGGED) {
+      const float* xr = p.x + n * p.x_stride + k0 + q * FPT;
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) xv[f] = live[f] ? xr[f] : 0.f;
+    } else {
+      const float4 t = *reinterpret_cast<const float4*>(p.x + n * p.x_stride + k0 + q * FPT);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+    }
     float gv[FPT];
     if constexpr (SUMF) {
       gv[0] = gv[1] = gv[2] = gv[3] = mp.g[n * mp.g_stride];
     } else {
       const float* gr = mp.g + n * mp.g_stride + k0 + q * FPT;
-      if (mp.vec_g) {
+      if (!RAGGED && mp.vec_g) {
         const float4 g4 = *reinterpret_cast<const float4*>(gr);
         gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
       } else {
 #pragma unroll
-        for (int f = 0; f < FPT; ++f) gv[f] = gr[f];
+        for (int f = 0; f < FPT; ++f) gv[f] = live[f] ? gr[f] : 0.f;
       }
     }
-    const float xv[FPT] = {t.x, t.y, t.z, t.w};
     int a[FPT];
     float last[FPT];
 #pragma unroll
@@ -776,8 +802,10 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
       const int piece = binoff[f] + ((a[f] - Q) >> 2);
       if constexpr (!SUMF) t0 = fixed_bits(gv[f], s0);
       const float m1 = gv[f] * (xv[f] - last[f]);
-      atomicAdd(bins + piece, t0);
-      atomicAdd(bins + tot + piece, fixed_bits(m1, s1));
+      if (!RAGGED || live[f]) {
+        atomicAdd(bins + piece, t0);
+        atomicAdd(bins + tot + piece, fixed_bits(m1, s1));
+      }
     }
   }
   __syncthreads();
@@ -789,7 +817,7 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
   }
 }
 
-template <int FG, int NSTEP, int BS>
+template <int FG, int NSTEP, int BS, bool RAGGED = false>
 int launch_moments_c1(MomentParams mp, hipStream_t st) {
   Params& p = mp.f;
   const size_t pieces = static_cast<size_t>(p.max_group_pieces);
@@ -797,8 +825,8 @@ int launch_moments_c1(MomentParams mp, hipStream_t st) {
   p.soff_offset = static_cast<int>(lds / sizeof(float));
   lds += (FG + 1) * sizeof(int);
   if (lds > 150 * 1024) return -1;                       // caller falls back to the general kernels
-  const void* fn = p.sum_features ? reinterpret_cast<const void*>(&fpwl_moments_c1_kernel<FG, NSTEP, BS, true>)
-                                  : reinterpret_cast<const void*>(&fpwl_moments_c1_kernel<FG, NSTEP, BS, false>);
+  const void* fn = p.sum_features ? reinterpret_cast<const void*>(&fpwl_moments_c1_kernel<FG, NSTEP, BS, true, RAGGED>)
+                                  : reinterpret_cast<const void*>(&fpwl_moments_c1_kernel<FG, NSTEP, BS, false, RAGGED>);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -808,9 +836,9 @@ int launch_moments_c1(MomentParams mp, hipStream_t st) {
   if (bx * p.n_groups > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
   const dim3 grid(static_cast<unsigned>(bx * p.n_groups));
   if (p.sum_features) {
-    hipLaunchKernelGGL((fpwl_moments_c1_kernel<FG, NSTEP, BS, true>), grid, dim3(BS), lds, st, mp);
+    hipLaunchKernelGGL((fpwl_moments_c1_kernel<FG, NSTEP, BS, true, RAGGED>), grid, dim3(BS), lds, st, mp);
   } else {
-    hipLaunchKernelGGL((fpwl_moments_c1_kernel<FG, NSTEP, BS, false>), grid, dim3(BS), lds, st, mp);
+    hipLaunchKernelGGL((fpwl_moments_c1_kernel<FG, NSTEP, BS, false, RAGGED>), grid, dim3(BS), lds, st, mp);
   }
   return gnan::check_launch("fpwl_moments_c1_kernel");
 }
@@ -840,6 +868,24 @@ template <int FG, int BS>
 int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
   const bool fixed = mp.Mi != nullptr;
   if constexpr (FG % 4 == 0) {
+    const bool whole = mp.f.F % FG == 0 && mp.f.vec_x;
+    if (fixed && mp.f.C == 1 && !whole) {               // ragged feature count / unaligned rows: the C == 1 kernel's RAGGED variant
+      int nstep = 6;
+      while ((1 << nstep) < mp.f.max_pieces) ++nstep;
+      const char* env = std::getenv("GNAN_MOMENTS_GENERAL");
+      int rc = -1;
+      if (!(env && env[0] == '1')) {
+        switch (nstep) {
+          case 6: rc = launch_moments_c1<FG, 6, BS, true>(mp, st); break;
+          case 7: rc = launch_moments_c1<FG, 7, BS, true>(mp, st); break;
+          case 8: rc = launch_moments_c1<FG, 8, BS, true>(mp, st); break;
+          case 9: rc = launch_moments_c1<FG, 9, BS, true>(mp, st); break;
+          case 10: rc = launch_moments_c1<FG, 10, BS, true>(mp, st); break;
+          default: break;
+        }
+        if (rc != -1) return rc;
+      }
+    }
     if (fixed && mp.f.F % FG == 0) {
       int nstep = 6;
       while ((1 << nstep) < mp.f.max_pieces) ++nstep;
@@ -903,7 +949,9 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
   const dim3 grid(static_cast<unsigned>(wgs));
   if (p.acc_offset) lds += static_cast<size_t>(p.C) * Map<FG, BS>::NODES * sizeof(float);
   // FAST: one output channel, whole groups only, 16-B aligned x (and fx) rows
-  const bool fast = FG % 4 == 0 && p.C == 1 && p.F % FG == 0 && p.vec_x && (p.sum_features || p.vec_out);
+  const bool whole = p.F % FG == 0 && p.vec_x;                       // whole groups, 16-B aligned rows of x
+  const bool ragged = FG % 4 == 0 && p.C == 1 && p.sum_features && !whole && !p.out_bf16 && !p.col_partial;
+  const bool fast = FG % 4 == 0 && p.C == 1 && ((whole && (p.sum_features || p.vec_out)) || ragged);
   if (p.col_partial) {
     if (!fast || p.sum_features)
       return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: fused column sums need C == 1, F %% %d == 0, 16-B aligned rows, per-feature output", FG);
@@ -931,6 +979,7 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
         constexpr int NS = decltype(ns)::value;
         if (p.out_bf16) return p.sum_features ? gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: bf16 output is per-feature only")
                                               : fgo(fpwl_fast_kernel<FG, false, true, NS, BS>);
+        if (ragged) return fgo(fpwl_fast_kernel<FG, true, false, NS, BS, true>);
         return p.sum_features ? fgo(fpwl_fast_kernel<FG, true, false, NS, BS>)
                               : fgo(fpwl_fast_kernel<FG, false, false, NS, BS>);
       };

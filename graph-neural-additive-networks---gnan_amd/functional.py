@@ -638,6 +638,8 @@ DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row
 DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
 NARROW_ROW_SLICING = os.environ.get("GNAN_NARROW_ROW_SLICING", "1") != "0"   # A/B switch of LONG_ROW_THRESHOLD_NARROW
 PACKED_INDEX = os.environ.get("GNAN_PACKED_INDEX", "1") != "0"         # degree-sorted copies are read as one (col | code << 29) stream
+NARROW_SORTED_MIN_NNZ = 1 << 23   # below ~8M pairs the sorted walk's tail (the longest rows run last) and its scattered stores cost
+                                   # more than the divergence they remove (arxiv-shaped, 1.3M pairs: 11.6 -> 26 us at W = 1)
 NARROW_SORTED_WALK = os.environ.get("GNAN_NARROW_SORTED", "1") != "0"   # narrow operand rows walk the degree-sorted copy too
 HOT_COLUMN_ROWS = os.environ.get("GNAN_HOT_COLUMNS", "1") != "0"        # ... and read the most listed neighbours from a compact copy
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
@@ -686,7 +688,8 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
         # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
         plan = g.dense_slice_plan(n_out) if (n_out < DENSE_SLICE_MAX_ROWS and g.n_cols >= DENSE_SLICE_MIN_COLS) else None
     elif (NARROW_SORTED_WALK and DEGREE_SORTED_COPY and row_ids is None and S.shape[1] < DEGREE_SCHEDULE_MIN_WIDTH
-          and S.dtype == torch.float32 and not per_row and not weight_by_col and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS):
+          and S.dtype == torch.float32 and not per_row and not weight_by_col and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS
+          and g.nnz >= NARROW_SORTED_MIN_NNZ):
         # narrow operand rows: the degree-sorted copy as well (a lane per row idles behind the longest of the 16..64 rows
         # of its wavefront: W = 2 on the 10M-node graph 2.68 -> 1.68 ms), and a compact copy of the most listed
         # neighbours' rows behind the operand (HopGraph.hot_columns: -> 1.33 ms; W = 1: 1.86 -> 1.79 -> 1.52 ms)
@@ -787,7 +790,8 @@ def narrow_walk(g: HopGraph):
     """``(graph to walk, processing order, hot ids)`` for narrow operand rows: the degree-sorted copy of a large CSR —
     rows of equal length share a wavefront — whose column ids point the most listed neighbours at a compact copy of
     their rows behind the operand (``HopGraph.degree_sorted_copy_hot``); ``(g, None, None)`` for small or dense graphs."""
-    if NARROW_SORTED_WALK and DEGREE_SORTED_COPY and not g.is_dense and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
+    if (NARROW_SORTED_WALK and DEGREE_SORTED_COPY and not g.is_dense and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS
+            and g.nnz >= NARROW_SORTED_MIN_NNZ):
         return g.degree_sorted_copy_hot() if HOT_COLUMN_ROWS else (*g.degree_sorted_copy()[:2], None)
     return g, None, None
 

@@ -48,6 +48,7 @@ def _stack(sd, F, L, H, C, bias):
     (3, 1, 0, 2, True), (4, 2, 8, 3, True), (5, 3, 8, 1, True), (9, 3, 32, 5, False),
     (15, 3, 64, 1, True), (7, 4, 16, 7, True), (3, 3, 20, 40, True), (64, 3, 64, 1, True),
     (6, 3, 33, 2, True), (5, 4, 64, 8, False), (2, 5, 16, 3, True), (3, 3, 96, 2, True), (1, 3, 64, 4, True),
+    (129, 3, 32, 1, True), (33, 3, 16, 1, False),                        # ragged feature counts: partial last group
 ])
 @pytest.mark.parametrize("sum_features", [True, False])
 @pytest.mark.parametrize("algo", ["lane", "auto", "pwl"])
@@ -390,7 +391,8 @@ def test_fused_feature_sum_gradients():
 
 @pytest.mark.parametrize("F,L,H,C,sum_features", [(5, 3, 8, 1, True), (20, 3, 16, 2, False), (64, 3, 64, 1, False),
                                                    (3, 3, 16, 40, True), (64, 3, 64, 1, True), (32, 2, 20, 1, True),
-                                                   (8, 3, 16, 1, False), (48, 3, 64, 1, False)])
+                                                   (8, 3, 16, 1, False), (48, 3, 64, 1, False),
+                                                   (129, 3, 32, 1, True), (33, 3, 16, 1, False), (17, 2, 8, 1, True)])
 @pytest.mark.parametrize("fixed", [True, False])
 def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkeypatch):
     from gnan_amd import functional, pwl
@@ -913,6 +915,7 @@ def test_fused_narrow_backward_walks_sorted_copy_with_hot_columns(W, K, with_res
     up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     monkeypatch.setattr(G, "HOT_COLUMNS", 64)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
+    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
     got = {}
     for tag, min_rows in (("natural", 1 << 30), ("sorted_hot", 1)):
         monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
@@ -941,6 +944,7 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
     monkeypatch.setattr(G, "HOT_COLUMNS", 64)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
     monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
+    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
     rng = np.random.default_rng(W + 40)
     n, K = 5000, 2
     D = K + 2
@@ -972,6 +976,7 @@ def test_packed_index_entries_give_the_same_bits(W, K, bf16, monkeypatch):
     from gnan_amd import functional, graph as G
     from gnan_amd.functional import spmm_launch
     monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
+    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
     rng = np.random.default_rng(W + K)
     n, D = 6000, K + 2
     rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 5000), (5999, 2100)])
