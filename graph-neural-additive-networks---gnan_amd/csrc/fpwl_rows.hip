@@ -115,7 +115,6 @@ struct RowsParams {
   int sum_features;
   float* out;
   int64_t out_stride;
-  int k_lo, k_hi;        // features [k_lo, k_hi) of this launch; sum_features: the launch ADDS to out when k_lo > 0 (unused: one pass)
 };
 
 // One node per wavefront (C > 32): the (piece, dx) pair of look-up j is wave-uniform, so it is moved to scalar registers
@@ -165,14 +164,14 @@ __global__ __launch_bounds__(256) void fpwl_rows_fwd_kernel(const RowsParams p) 
   const int cs = c < p.C ? c : p.C - 1;
   const int64_t row = (node_ok ? n : 0) * p.F;
   float* orow = p.out + (node_ok ? n : 0) * p.out_stride;
-  float acc = (SUMF && live && p.k_lo > 0) ? orow[c] : 0.f;
-  for (int k0 = p.k_lo; k0 < p.k_hi; k0 += CP2) {
+  float acc = 0.f;
+  for (int k0 = 0; k0 < p.F; k0 += CP2) {
     // the node's CP2 lanes read its next CP2 (piece, dx) pairs with one coalesced load each and broadcast them in turn
     const int kk = k0 + c;
     int pv = 0;
     float dv = 0.f;
-    if (node_ok && kk < p.k_hi) { pv = p.piece[row + kk]; dv = p.dx[row + kk]; }
-    const int m = p.k_hi - k0 < CP2 ? p.k_hi - k0 : CP2;
+    if (node_ok && kk < p.F) { pv = p.piece[row + kk]; dv = p.dx[row + kk]; }
+    const int m = p.F - k0 < CP2 ? p.F - k0 : CP2;
     if (m == CP2) rows_chunk<CP2, true, SUMF>(p, k0, m, pv, dv, slot, c, cs, live, acc, orow);
     else rows_chunk<CP2, false, SUMF>(p, k0, m, pv, dv, slot, c, cs, live, acc, orow);
   }
@@ -393,8 +392,6 @@ extern "C" int gnan_fpwl_rows_fwd(const gnan_fpwl_args* a, const int32_t* piece,
   // (one pass over all features: launching the features in chunks whose table rows stay resident in a 4-MiB L2 — and
   // carrying the accumulators through memory between the launches — measured 0.46 ms against 0.42 ms: the kernel is bound
   // by vector issue, not by the table rows' L2 misses)
-  p.k_lo = 0;
-  p.k_hi = a->F;
   switch (cp2_of(a->C)) {
     case 8: return launch_rows_fwd<8>(p, st);
     case 16: return launch_rows_fwd<16>(p, st);

@@ -90,6 +90,7 @@ NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) 
 
 FPWL_ROWS = os.environ.get("GNAN_FPWL_ROWS", "1") != "0"   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
 FPWL_ROWS_MIN_NODES = 32768
+FPWL_ROWS_MIN_CHANNELS, FPWL_ROWS_MIN_CHANNELS_BWD = 12, 6   # fewer channels: locating the pieces separately costs more than it saves
 
 
 def _fpwl_args(x: torch.Tensor, t, sum_features: bool, out=None) -> "_lib.FpwlArgs":
@@ -104,7 +105,9 @@ def _fpwl_args(x: torch.Tensor, t, sum_features: bool, out=None) -> "_lib.FpwlAr
 def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
     """Several channels on a large batch: the piece of every (node, feature) is located once (``gnan_fpwl_locate``) and the
     channel work runs with lane = channel — arxiv-shaped C = 40: look-up 2.3 -> ? ms, moments 4.5 -> ? ms."""
-    return (FPWL_ROWS and 1 < C <= 64 and n >= FPWL_ROWS_MIN_NODES
+    # (10M nodes x 64 features, look-up: C = 8 7.4 ms against 6.2 ms for the thread-per-node kernel, C = 12 9.2 / 9.3,
+    #  C = 16 9.0 / 9.7, C = 32 12.2 / 35.7; arxiv-shaped moments at C = 7: 0.26 + 0.17 ms against 0.65 ms)
+    return (FPWL_ROWS and (FPWL_ROWS_MIN_CHANNELS_BWD if bins else FPWL_ROWS_MIN_CHANNELS) <= C <= 64 and n >= FPWL_ROWS_MIN_NODES
             # backward: a feature's 64-bit bins in LDS (tables sized for a hipGraph carry max_pieces rounded up to a power of
             # two, but a group — hence a feature — has at most max_group_pieces)
             and (not bins or min(t.max_pieces, t.max_group_pieces) * (2 * C + 1) * 8 <= 150 * 1024))
