@@ -156,26 +156,35 @@ template <int CP2, bool SUMF>
 __global__ __launch_bounds__(256) void fpwl_rows_fwd_kernel(const RowsParams p) {
   constexpr int NPW = kWave / CP2;                     // nodes per wavefront
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int c = lane % CP2, slot = lane / CP2;
+  const int slot = lane / CP2;
   const int64_t n = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * NPW + slot;
   const bool node_ok = n < p.n;
   if (CP2 == kWave && !node_ok) return;                // one node per wavefront: nothing to do (wave-uniform)
-  const bool live = node_ok && c < p.C;
-  const int cs = c < p.C ? c : p.C - 1;
   const int64_t row = (node_ok ? n : 0) * p.F;
   float* orow = p.out + (node_ok ? n : 0) * p.out_stride;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < p.F; k0 += CP2) {
-    // the node's CP2 lanes read its next CP2 (piece, dx) pairs with one coalesced load each and broadcast them in turn
-    const int kk = k0 + c;
-    int pv = 0;
-    float dv = 0.f;
-    if (node_ok && kk < p.F) { pv = p.piece[row + kk]; dv = p.dx[row + kk]; }
-    const int m = p.F - k0 < CP2 ? p.F - k0 : CP2;
-    if (m == CP2) rows_chunk<CP2, true, SUMF>(p, k0, m, pv, dv, slot, c, cs, live, acc, orow);
-    else rows_chunk<CP2, false, SUMF>(p, k0, m, pv, dv, slot, c, cs, live, acc, orow);
+  // more than 64 channels (CP2 == 64 only): the wavefront walks the node's look-ups once per chunk of 64 channels
+  auto pass = [&](const int cb) {
+    const int c = cb + lane % CP2;
+    const bool live = node_ok && c < p.C;
+    const int cs = c < p.C ? c : p.C - 1;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < p.F; k0 += CP2) {
+      // the node's CP2 lanes read its next CP2 (piece, dx) pairs with one coalesced load each and broadcast them in turn
+      const int kk = k0 + lane % CP2;
+      int pv = 0;
+      float dv = 0.f;
+      if (node_ok && kk < p.F) { pv = p.piece[row + kk]; dv = p.dx[row + kk]; }
+      const int m = p.F - k0 < CP2 ? p.F - k0 : CP2;
+      if (m == CP2) rows_chunk<CP2, true, SUMF>(p, k0, m, pv, dv, slot, c, cs, live, acc, orow);
+      else rows_chunk<CP2, false, SUMF>(p, k0, m, pv, dv, slot, c, cs, live, acc, orow);
+    }
+    if (SUMF && live) orow[c] = acc;
+  };
+  if (p.C <= kWave) {
+    pass(0);                                            // (the common case keeps its constant channel offset)
+  } else {
+    for (int cb = 0; cb < p.C; cb += kWave) pass(cb);
   }
-  if (SUMF && live) orow[c] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,6 +203,8 @@ struct RowsMomentParams {
   const double* scales;
   unsigned long long* Mi;   // [T, 2, C]
   int nodes_per_block;
+  int cc;                   // channels per workgroup (a chunk of the C channels whose bins fit LDS; <= 64)
+  int64_t wgs_per_chunk;    // workgroups of one channel chunk
 };
 
 template <int CP2>
@@ -206,11 +217,15 @@ __global__ __launch_bounds__(1024) void fpwl_rows_moments_kernel(const RowsMomen
   const int c = lane % CP2, slot = lane / CP2;
   // (id % 8) = XCD; inside an XCD the features of ONE node block run back to back, so the block's gradient rows (read once
   // per feature: F times) stay in that XCD's L2 instead of costing a fabric request per row and feature
-  const int64_t id = blockIdx.x;
-  const int k = static_cast<int>((id >> 3) % p.F);
-  const int64_t nb = ((id >> 3) / p.F) * 8 + (id & 7);
-  const int C = p.C;
-  const int Rb = 2 * C + 1;                            // odd stride: rows of consecutive pieces start on different banks
+  // (32-bit unsigned arithmetic on wave-uniform values, pinned to scalar registers: the row addresses below build on them)
+  const unsigned wpc = static_cast<unsigned>(p.wgs_per_chunk);
+  const unsigned chunk = __builtin_amdgcn_readfirstlane(blockIdx.x / wpc);
+  const unsigned id = __builtin_amdgcn_readfirstlane(blockIdx.x - chunk * wpc);
+  const int k = __builtin_amdgcn_readfirstlane(static_cast<int>((id >> 3) % static_cast<unsigned>(p.F)));
+  const int64_t nb = static_cast<int64_t>(__builtin_amdgcn_readfirstlane(((id >> 3) / static_cast<unsigned>(p.F)) * 8 + (id & 7)));
+  const int c_lo = static_cast<int>(chunk) * p.cc;     // this workgroup's channels: [c_lo, c_lo + C) of the p.C
+  const int C = p.C - c_lo < p.cc ? p.C - c_lo : p.cc;
+  const int Rb = 2 * p.cc + 1;                         // odd stride: rows of consecutive pieces start on different banks
   const int base = p.off[k];
   const int tot = p.off[k + 1] - base;
   const int64_t n_lo = nb * p.nodes_per_block;
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(1024) void fpwl_rows_moments_kernel(const RowsMomen
   __syncthreads();
   const double s0 = p.scales[0], s1 = p.scales[1];
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
-  const int64_t gbase = p.sum_features ? 0 : static_cast<int64_t>(k) * C;
+  const int64_t gbase = (p.sum_features ? 0 : static_cast<int64_t>(k) * p.C) + c_lo;
   const int cs = c < C ? c : C - 1;
   // a wavefront takes 64 consecutive nodes at a time: lane j reads (piece, dx) of node n0 + j (feature k), then the lanes
   // of a slot walk the nodes NPW at a time, lane = channel: coalesced gradient rows, consecutive bins
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(1024) void fpwl_rows_moments_kernel(const RowsMomen
             if (i0 + u < m) {
               unsigned long long* b = bins + static_cast<int64_t>(t[u]) * Rb + c;
               atomicAdd(b, fixed_bits(gv[u], s0));
-              atomicAdd(b + C, fixed_bits(gv[u] * dd[u], s1));
+              atomicAdd(b + p.cc, fixed_bits(gv[u] * dd[u], s1));
             }
           }
         }
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(1024) void fpwl_rows_moments_kernel(const RowsMomen
             if (i0 + u * NPW + slot < m) {
               unsigned long long* b = bins + static_cast<int64_t>(t[u]) * Rb + c;
               atomicAdd(b, fixed_bits(gv[u], s0));
-              atomicAdd(b + C, fixed_bits(gv[u] * dd[u], s1));
+              atomicAdd(b + p.cc, fixed_bits(gv[u] * dd[u], s1));
             }
           }
         }
@@ -285,10 +300,11 @@ __global__ __launch_bounds__(1024) void fpwl_rows_moments_kernel(const RowsMomen
     }
   }
   __syncthreads();
-  unsigned long long* out = p.Mi + static_cast<int64_t>(base) * 2 * C;
+  unsigned long long* out = p.Mi + static_cast<int64_t>(base) * 2 * p.C;
   for (int i = tid; i < tot * 2 * C; i += 1024) {
-    const unsigned long long v = bins[(i / (2 * C)) * Rb + i % (2 * C)];
-    if (v != 0ull) atomicAdd(out + i, v);
+    const int t = i / (2 * C), r = i - t * 2 * C, m = r / C, c2 = r - m * C;
+    const unsigned long long v = bins[t * Rb + m * p.cc + c2];
+    if (v != 0ull) atomicAdd(out + static_cast<int64_t>(t) * 2 * p.C + m * p.C + c_lo + c2, v);
   }
 }
 
@@ -301,7 +317,7 @@ int cp2_of(int C) {
 int rows_checks(const gnan_fpwl_args* a, const int32_t* piece, const float* dx, const char* who) {
   GNAN_REQUIRE(a != nullptr, "%s: null args", who);
   GNAN_REQUIRE(a->n >= 0 && a->F >= 1 && a->C >= 1, "%s: bad sizes", who);
-  if (a->C > kWave) return gnan::fail(GNAN_ERR_UNSUPPORTED, "%s: at most %d output channels (got %d)", who, kWave, a->C);
+  if (a->C > 4096) return gnan::fail(GNAN_ERR_UNSUPPORTED, "%s: at most 4096 output channels (got %d)", who, a->C);
   if (a->n == 0) return GNAN_OK;
   GNAN_REQUIRE(piece && dx && a->off, "%s: null pointer", who);
   GNAN_REQUIRE(a->n * static_cast<int64_t>(a->F) < (1LL << 40), "%s: n * F too large", who);
@@ -411,24 +427,32 @@ extern "C" int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32
   GNAN_REQUIRE(a->max_pieces >= 1, "fpwl_rows_moments: max_pieces must be >= 1");
   // pieces of one feature: at most max_pieces, and at most max_group_pieces when the caller states it (> 0)
   const int per_feature = (a->max_group_pieces > 0 && a->max_group_pieces < a->max_pieces) ? a->max_group_pieces : a->max_pieces;
-  const size_t lds = static_cast<size_t>(per_feature) * (2 * static_cast<size_t>(a->C) + 1) * sizeof(unsigned long long);
+  // channels per workgroup: all of them if they fit a wavefront and their bins fit LDS, else equal chunks that do
+  int cc = a->C < kWave ? a->C : kWave;
+  auto bins_bytes = [&](int ch) { return static_cast<size_t>(per_feature) * (2 * static_cast<size_t>(ch) + 1) * sizeof(unsigned long long); };
+  while (cc > 1 && bins_bytes(cc) > 150 * 1024) --cc;
+  const int n_chunks = (a->C + cc - 1) / cc;
+  cc = (a->C + n_chunks - 1) / n_chunks;               // equal chunks
+  const size_t lds = bins_bytes(cc);
   if (lds > 150 * 1024)
-    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_moments: %zu B of bins per feature exceed LDS", lds);
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_moments: %zu B of bins per feature and channel exceed LDS", lds);
   RowsMomentParams p;
   p.n = a->n; p.F = a->F; p.C = a->C; p.off = a->off; p.piece = piece; p.dx = dx; p.g = grad; p.g_stride = grad_stride;
   p.sum_features = a->sum_features; p.scales = scales; p.Mi = reinterpret_cast<unsigned long long*>(moments);
   // node blocks: each (feature, block) workgroup zeroes and flushes the feature's bins, so blocks should be large; their
   // gradient rows should fit an XCD's L2 with room to spare (<= 2 MiB); and F * blocks workgroups should fill the chip
   int64_t npb = a->n * static_cast<int64_t>(a->F) / 2048;
-  const int64_t l2_rows = (2 << 20) / (static_cast<int64_t>(a->sum_features ? a->C : a->C) * 4);
+  const int64_t l2_rows = (2 << 20) / (static_cast<int64_t>(a->C) * 4);
   if (npb > l2_rows) npb = l2_rows;
   npb = npb < 1024 ? 1024 : (npb > 16384 ? 16384 : (npb + 1023) / 1024 * 1024);
   p.nodes_per_block = static_cast<int>(npb);
   const int64_t bx = ((a->n + npb - 1) / npb + 7) / 8 * 8;          // whole rounds of the 8 XCDs
-  if (bx * a->F > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_moments: too many nodes for one launch");
-  const dim3 grid(static_cast<unsigned>(bx * a->F));
+  p.cc = cc;
+  p.wgs_per_chunk = bx * a->F;
+  if (p.wgs_per_chunk * n_chunks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_moments: too many nodes for one launch");
+  const dim3 grid(static_cast<unsigned>(p.wgs_per_chunk * n_chunks));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (cp2_of(a->C)) {
+  switch (cp2_of(cc)) {
     case 8: return launch_rows_moments<8>(p, lds, grid, st);
     case 16: return launch_rows_moments<16>(p, lds, grid, st);
     case 32: return launch_rows_moments<32>(p, lds, grid, st);

@@ -107,10 +107,8 @@ def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
     channel work runs with lane = channel — arxiv-shaped C = 40: look-up 2.3 -> ? ms, moments 4.5 -> ? ms."""
     # (10M nodes x 64 features, look-up: C = 8 7.4 ms against 6.2 ms for the thread-per-node kernel, C = 12 9.2 / 9.3,
     #  C = 16 9.0 / 9.7, C = 32 12.2 / 35.7; arxiv-shaped moments at C = 7: 0.26 + 0.17 ms against 0.65 ms)
-    return (FPWL_ROWS and (FPWL_ROWS_MIN_CHANNELS_BWD if bins else FPWL_ROWS_MIN_CHANNELS) <= C <= 64 and n >= FPWL_ROWS_MIN_NODES
-            # backward: a feature's 64-bit bins in LDS (tables sized for a hipGraph carry max_pieces rounded up to a power of
-            # two, but a group — hence a feature — has at most max_group_pieces)
-            and (not bins or min(t.max_pieces, t.max_group_pieces) * (2 * C + 1) * 8 <= 150 * 1024))
+    # more than 64 channels: in chunks of 64 (forward) / of as many channels as have their 64-bit bins in LDS (backward)
+    return FPWL_ROWS and (FPWL_ROWS_MIN_CHANNELS_BWD if bins else FPWL_ROWS_MIN_CHANNELS) <= C <= 4096 and n >= FPWL_ROWS_MIN_NODES
 
 
 def _fpwl_locate(x: torch.Tensor, t, a):

@@ -186,9 +186,9 @@ int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* grad, int64_t 
  *   gnan_fpwl_rows_fwd          out as gnan_fpwl_fwd (fp32; sum_features: [n, C], else [n, F*C]) from piece / dx and
  *                               val / slope; args read: n, F, C, val, slope, sum_features, out, out_stride, out_dtype;
  *   gnan_fpwl_rows_moments_fixed  the moments of gnan_fpwl_moments_fixed (same integers) from piece / dx and the upstream
- *                               gradient; args read: n, F, C, off, max_pieces, max_group_pieces, sum_features.  C <= 64,
- *                               min(max_pieces, max_group_pieces) * (2 C + 1) * 8 bytes of LDS bins per feature
- *                               (GNAN_ERR_UNSUPPORTED beyond 150 KiB).
+ *                               gradient; args read: n, F, C, off, max_pieces, max_group_pieces, sum_features.  The
+ *                               channels are cut into equal chunks of at most 64 whose bins — min(max_pieces,
+ *                               max_group_pieces) * (2 chunk + 1) * 8 bytes per feature — fit 150 KiB of LDS.
  * ------------------------------------------------------------------------------------------- */
 size_t gnan_fpwl_locate_bytes(const gnan_fpwl_args* a);
 int gnan_fpwl_locate(const gnan_fpwl_args* a, int32_t* piece, float* dx, gnan_stream_t stream);
