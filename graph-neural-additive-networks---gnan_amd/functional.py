@@ -107,8 +107,12 @@ def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
     channel work runs with lane = channel — arxiv-shaped C = 40: look-up 2.3 -> ? ms, moments 4.5 -> ? ms."""
     # (10M nodes x 64 features, look-up: C = 8 7.4 ms against 6.2 ms for the thread-per-node kernel, C = 12 9.2 / 9.3,
     #  C = 16 9.0 / 9.7, C = 32 12.2 / 35.7; arxiv-shaped moments at C = 7: 0.26 + 0.17 ms against 0.65 ms)
-    # more than 64 channels: in chunks of 64 (forward) / of as many channels as have their 64-bit bins in LDS (backward)
-    return FPWL_ROWS and (FPWL_ROWS_MIN_CHANNELS_BWD if bins else FPWL_ROWS_MIN_CHANNELS) <= C <= 4096 and n >= FPWL_ROWS_MIN_NODES
+    # more than 64 channels: in chunks of 64 (forward) / of as many channels as have their 64-bit bins in LDS (backward);
+    # tables too large for the LDS image of the thread-per-node kernels (C > ~110) have no other kernel: any batch size
+    from .pwl import oversize
+    if not FPWL_ROWS or not 1 < C <= 4096:
+        return False
+    return oversize(t) or ((FPWL_ROWS_MIN_CHANNELS_BWD if bins else FPWL_ROWS_MIN_CHANNELS) <= C and n >= FPWL_ROWS_MIN_NODES)
 
 
 def _fpwl_locate(x: torch.Tensor, t, a):

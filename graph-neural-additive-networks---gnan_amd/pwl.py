@@ -63,7 +63,17 @@ def _plan_groups(off, C):
     for fg, mg, bins_fit in fits:
         if bins_fit:
             return fg, mg
-    return fits[0][:2] if fits else None
+    if fits:
+        return fits[0][:2]
+    # not even one feature's tables fit LDS (C > ~110 channels): the thread-per-node kernels cannot run, the two-phase
+    # kernels (csrc/fpwl_rows.hip: tables stay in global memory) can — functional._fpwl_rows_applies sends such tables there
+    return (1, max(off[k + 1] - off[k] for k in range(F))) if C > 1 else None
+
+
+def oversize(t: "PwlTables") -> bool:
+    """Tables whose largest feature group does not fit the LDS image of the thread-per-node kernels."""
+    C = t.val.shape[1]
+    return t.max_group_pieces * (1 + 2 * table_stride(C)) * 4 > LDS_LIMIT
 
 
 def _prefix(x: torch.Tensor, p, depth: int, w, b):

@@ -593,6 +593,36 @@ def test_two_phase_lookup_for_several_channels(F, L, H, C, sum_features, monkeyp
         assert O.rel_err(out[True][0].cpu(), out[False][0].cpu().double()) <= 2e-6
 
 
+@pytest.mark.parametrize("sum_features", [True, False])
+def test_tables_too_large_for_lds_use_the_two_phase_kernels(sum_features):
+    """172 output channels x ~130 pieces: not even one feature's tables fit the LDS image of the thread-per-node kernels
+    (before round 2 such models fell back to the lane kernel).  The planner still returns tables, the two-phase kernels
+    evaluate them from global memory at any batch size: look-up == float64 oracle, moments == the torch restatement,
+    and the whole autograd path == oracle autograd."""
+    from gnan_amd import functional, pwl
+    from gnan_amd.functional import _fpwl_launch, _fpwl_moments, feature_mlps
+    F, L, H, C, n = 3, 3, 64, 172, 3000
+    sd = _mlp_state(F, L, H, C, True, seed=9)
+    st = _stack(sd, F, L, H, C, True)
+    t = pwl.build_tables(st)
+    assert t is not None and pwl.oversize(t) and t.features_per_group == 1
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(n, F, generator=gen) * 4 - 2
+    g = torch.randn(n, C if sum_features else F * C, generator=gen)
+    out = _fpwl_launch(x.to(DEV), t, sum_features)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()})
+    truth = truth.sum(1) if sum_features else truth.reshape(n, F * C)
+    assert O.rel_err(out.cpu(), truth) <= 1e-5
+    tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t])
+    want = pwl.moments_reference(x, g, tc, sum_features)
+    got = _fpwl_moments(x.to(DEV), t, g.to(DEV), sum_features).cpu().double()
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    # end to end through the autograd function (whatever strategy AUTO picks for this batch size)
+    params = [None if q is None else q.clone().requires_grad_(True) for q in st[:6]]
+    y = feature_mlps(x.to(DEV), functional.StackedMLP(*params, *st[6:]), sum_features)
+    assert O.rel_err(y.detach().cpu(), truth) <= 1e-5
+
+
 @pytest.mark.parametrize("n,width,gscale", [(1000, 3, 1.0), (70000, 1, 1e-12), (5, 64, 1e20), (100, 2, 0.0)])
 def test_moment_scales_kernel(n, width, gscale):
     """gnan_fpwl_moment_scales == the framework formula it replaced (powers of two from max|grad| and max|x - anchor|)."""

@@ -125,3 +125,23 @@ def test_builder_refuses_when_pieces_overflow(monkeypatch):
     assert pwl.build_tables(st) is not None
     monkeypatch.setattr(pwl, "MAX_PIECES", 8)
     assert pwl.build_tables(st) is None
+
+
+def test_group_planner():
+    """pwl._plan_groups (host logic): the largest group that fits the preferred budget; with many channels the largest
+    group whose 64-bit moment bins fit LDS as well; tables that fit no LDS image at all still get a plan (one feature per
+    group) when there are several channels — the two-phase kernels read them from global memory — and none for C = 1."""
+    from gnan_amd import pwl
+    off = [0] + [130 * (k + 1) for k in range(32)]
+    assert pwl._plan_groups(off, 1) == (16, 16 * 130)                  # 16 x 130 x 12 B = 25 KB
+    assert pwl._plan_groups(off, 7) == (4, 4 * 130)                    # 4 x 130 x 60 B = 31 KB; 8 features: 62 KB
+    fg, mg = pwl._plan_groups(off, 40)                                  # 130 x 332 B = 43 KB per feature
+    assert (fg, mg) == (1, 130)
+    off148 = [0] + [148 * (k + 1) for k in range(8)]
+    assert pwl._plan_groups(off148, 40) == (1, 148)                     # 49 KB > preferred; two features: bins 191 KB
+    assert pwl._plan_groups(off148, 172) == (1, 148)                    # 204 KB: no LDS image, two-phase kernels only
+    t = pwl.PwlTables(None, None, torch.zeros(8 * 148, 172), None, 148, 1, 148)
+    assert pwl.oversize(t)
+    assert not pwl.oversize(pwl.PwlTables(None, None, torch.zeros(8 * 148, 40), None, 148, 1, 148))
+    huge = [0, 20000, 40000]
+    assert pwl._plan_groups(huge, 1) is None
