@@ -704,7 +704,9 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
             S = append_hot_rows(S, hot, g.n_codes if s_by_code else 1)
         scatter = 2
     elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
-        if DEGREE_SORTED_COPY and not per_row and not weight_by_col and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
+        # (a table indexed by COLUMN — the wide backward's per-node weights — does not care in which order the rows are walked)
+        by_col_table = per_row and weight_by_col and not use_cnt
+        if DEGREE_SORTED_COPY and (by_col_table or (not per_row and not weight_by_col)) and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
             g, row_ids, plan = g.degree_sorted_copy()   # walk a degree-sorted copy of the CSR, store rows at their own index
             scatter = 2
         else:
@@ -756,8 +758,12 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
         s_total = None
     scatter = False
     if row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
-        row_ids, plan = g.degree_schedule()
-        scatter = True
+        if DEGREE_SORTED_COPY and not g.is_dense and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
+            g, row_ids, plan = g.degree_sorted_copy()   # as the forward: adjacent index ranges for neighbouring lane groups
+            scatter = 2
+        else:
+            row_ids, plan = g.degree_schedule()
+            scatter = True
     else:
         plan = g.long_row_plan(row_ids)
     out = torch.zeros((D,) if reduce_rows else (n_out, D), dtype=torch.float32, device=S.device)
