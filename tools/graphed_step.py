@@ -31,6 +31,14 @@ def arxiv_shaped(C=1):
     return d, N, F, C
 
 
+def rmat_shaped(C=1):
+    """R-MAT 2M nodes / 20M edges, F = 64: large enough for the degree-sorted walk of narrow operands and their hot rows."""
+    N, E, F = 2_000_000, 20_000_000, 64
+    src, dst = mb.syn.rmat_edges(21, N, E, seed=0, device=DEV)
+    d = Data(x=mb.syn.block_features(N, F, 0, N, 1, DEV), edge_index=None, gnan_graph=mb.syn.hop1_csr(src, dst, N))
+    return d, N, F, C
+
+
 def cora_shaped():
     rng = np.random.default_rng(0)
     n, F, C = 2708, 1434, 7
@@ -121,3 +129,5 @@ if __name__ == "__main__":
         run("arxiv_shaped_C40", lambda: arxiv_shaped(40))
     if "cora" in which:
         run("cora_shaped", cora_shaped)
+    if "rmat" in which:
+        run("rmat_2M_20M_C1", lambda: rmat_shaped(1))
