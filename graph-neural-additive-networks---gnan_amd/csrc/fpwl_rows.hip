@@ -143,10 +143,18 @@ __device__ __forceinline__ void rows_chunk(const RowsParams& p, int k0, int m, i
     if (!FULL && j >= m) break;
     const int t = Bcast<CP2, FULL>::i(pv, slot, j);
     const float dd = Bcast<CP2, FULL>::f(dv, slot, j);
-    gfloat* vr = as_global(p.val + static_cast<int64_t>(t) * p.C);
-    gfloat* sr = as_global(p.slope + static_cast<int64_t>(t) * p.C);
-    if constexpr (CP2 == 64 && FULL) asm volatile("" : "+s"(vr), "+s"(sr));   // row bases stay scalar: saddr + lane offset
-    const float y = fmaf(sr[cs], dd, vr[cs]);
+    float y;
+    if constexpr (CP2 == 64 && FULL) {
+      gfloat* vr = as_global(p.val + static_cast<int64_t>(t) * p.C);
+      gfloat* sr = as_global(p.slope + static_cast<int64_t>(t) * p.C);
+      asm volatile("" : "+s"(vr), "+s"(sr));             // row bases stay scalar: saddr + lane offset
+      y = fmaf(sr[cs], dd, vr[cs]);
+    } else {
+      // several nodes per wavefront: the piece differs between the node slots, but the element index fits 32 bits
+      // (gnan_fpwl_rows_fwd checks F * max_pieces * C), so it is one multiply-add on top of the scalar table bases
+      const unsigned o = static_cast<unsigned>(t) * static_cast<unsigned>(p.C) + static_cast<unsigned>(cs);
+      y = fmaf(as_global(p.slope)[o], dd, as_global(p.val)[o]);
+    }
     if constexpr (SUMF) acc += y;
     else if (live) orow[static_cast<int64_t>(k0 + j) * p.C + c] = y;
   }
@@ -399,6 +407,9 @@ extern "C" int gnan_fpwl_rows_fwd(const gnan_fpwl_args* a, const int32_t* piece,
   if (a->n == 0) return GNAN_OK;
   GNAN_REQUIRE(a->val && a->slope && a->out, "fpwl_rows_fwd: null pointer");
   GNAN_REQUIRE(a->out_dtype == GNAN_F32, "fpwl_rows_fwd: fp32 output only");
+  GNAN_REQUIRE(a->max_pieces >= 1, "fpwl_rows_fwd: max_pieces must be >= 1");
+  if (static_cast<int64_t>(a->F) * a->max_pieces * a->C >= (1LL << 32))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_fwd: tables of F * max_pieces * C >= 2^32 floats");
   const int64_t ow = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(a->out_stride >= ow, "fpwl_rows_fwd: out row stride smaller than the output width");
   RowsParams p;
