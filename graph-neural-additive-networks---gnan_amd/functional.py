@@ -123,8 +123,11 @@ def _fpwl_locate(x: torch.Tensor, t, a):
     return piece, dx
 
 
+LOCATED_KEEP_MAX_BYTES = 2 << 30   # (piece, dx) of a forward are kept for its backward pass while they stay below 2 GiB
+
+
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32,
-                 total_rows: Optional[int] = None):
+                 total_rows: Optional[int] = None, located: Optional[list] = None):
     """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``.
     With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
     when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
@@ -145,6 +148,8 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         a = _fpwl_args(x, t, sum_features, out)
         piece, dx = _fpwl_locate(x, t, a)
         _lib.check(_lib.lib().gnan_fpwl_rows_fwd(a, _lib.ptr(piece), _lib.ptr(dx), _lib.stream_of(x)), "gnan_fpwl_rows_fwd")
+        if located is not None and 2 * piece.numel() * 4 <= LOCATED_KEEP_MAX_BYTES:
+            located[:] = [piece, dx]                    # the backward pass bins the gradient by the same pieces
         return (out, None) if want_total else out
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
@@ -179,7 +184,7 @@ def _abs_max_cached(x: torch.Tensor) -> torch.Tensor:
 
 
 def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
-                  x_abs_max: Optional[torch.Tensor] = None, raw: bool = False):
+                  x_abs_max: Optional[torch.Tensor] = None, raw: bool = False, located=None):
     """Per-piece moments of the upstream gradient (``gnan_fpwl_moments[_fixed]``) -> ``[T, 2, C]`` float32; with ``raw``
     the fixed-point route returns ``(moments int64 [T, 2, C], scales float64 [2])`` undivided (``gnan_fpwl_param_grads``
     takes them as they are).
@@ -215,7 +220,7 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
         scales = scales[:2]
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
         if rows:
-            piece, dx = _fpwl_locate(x, t, a)
+            piece, dx = located if located else _fpwl_locate(x, t, a)    # (kept by the forward pass, or located again)
             _lib.check(_lib.lib().gnan_fpwl_rows_moments_fixed(a, _lib.ptr(piece), _lib.ptr(dx), _lib.ptr(grad), grad.stride(0),
                                                                _lib.ptr(scales), _lib.ptr(Mi), _lib.stream_of(x)),
                        "gnan_fpwl_rows_moments_fixed")
@@ -232,7 +237,8 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
 
 
 def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_total: bool = False,
-                  needs_grad: bool = False, out_dtype=torch.float32, total_rows: Optional[int] = None, prebuilt=None):
+                  needs_grad: bool = False, out_dtype=torch.float32, total_rows: Optional[int] = None, prebuilt=None,
+                  located: Optional[list] = None):
     """Strategy choice: exact table look-up for large batches, matrix-core / lane kernel otherwise.
     Returns ``(out, tables or None, total or None)``."""
     algo = FMLP_ALGO
@@ -245,8 +251,9 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
         stacked = StackedMLP(*[_c(t) for t in p[:6]], *p[6:])
 
         def look_up(t):
-            return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows) \
-                if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype), None)
+            return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows,
+                                located=located) \
+                if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype, located=located), None)
 
         if prebuilt is not None:
             # tables of THESE weights queued earlier, possibly on another stream (TablePrefetch): wait for that stream's
@@ -455,7 +462,9 @@ class _FeatureMLPs(torch.autograd.Function):
         if total_rows is not None and not 0 <= total_rows <= x.shape[0]:
             raise ValueError(f"total_rows={total_rows} outside [0, {x.shape[0]}]")
         fused_total = want_total and total_rows != 0           # 0 rows: the kernel reads that as "all", sum nothing instead
-        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, fused_total, needs_grad, out_dtype, total_rows)
+        ctx.located = [] if needs_grad else None
+        out, ctx.tables, total = _fmlp_forward(x, p, sum_features, fused_total, needs_grad, out_dtype, total_rows,
+                                               located=ctx.located)
         # max |x| scales the fixed-point moments of the backward pass; it is looked up here because this is where the
         # caller's own tensor object is in hand (backward sees a fresh unpacked copy of the saved tensor every time)
         ctx.x_abs_max = _abs_max_cached(x) if (needs_grad and ctx.tables is not None and x.numel()) else None
@@ -483,9 +492,11 @@ class _FeatureMLPs(torch.autograd.Function):
             from .pwl import parameter_grads_from_moments
             if _table_grads_applies(L, H, C) and x.is_cuda:
                 # ... exactly, in one kernel: one reverse pass for the value and one for the slope of every non-empty piece
-                M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max, raw=True)
+                M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max, raw=True, located=ctx.located)
+                ctx.located = None
                 return (None,) * 9 + tuple(_fpwl_param_grads_launch(params, ctx.tables, M, L, H, C, F))
-            M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max)
+            M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max, located=ctx.located)
+            ctx.located = None
             got = parameter_grads_from_moments(
                 p, ctx.tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()
                                                                           for t in q[:6]], *q[6:]), False))
