@@ -339,6 +339,8 @@ extern "C" size_t gnan_fpwl_locate_bytes(const gnan_fpwl_args* a) {
   return static_cast<size_t>(a->n) * static_cast<size_t>(a->F) * 4;   // bytes of EACH of piece and dx
 }
 
+int gnan_locate_tree(const gnan_fpwl_args* a, int32_t* piece, float* dx, hipStream_t st);   // csrc/fpwl.hip
+
 extern "C" int gnan_fpwl_locate(const gnan_fpwl_args* a, int32_t* piece, float* dx, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "fpwl_locate: null args");
   GNAN_REQUIRE(a->n >= 0 && a->F >= 1, "fpwl_locate: bad sizes");
@@ -346,6 +348,8 @@ extern "C" int gnan_fpwl_locate(const gnan_fpwl_args* a, int32_t* piece, float* 
   GNAN_REQUIRE(a->x && a->off && a->anchor && piece && dx, "fpwl_locate: null pointer");
   GNAN_REQUIRE(a->x_stride >= a->F, "fpwl_locate: x row stride smaller than F");
   GNAN_REQUIRE(a->max_pieces >= 1, "fpwl_locate: max_pieces must be >= 1");
+  // the tree search of the C == 1 kernels (skewed breadth-first trees, thread = (node, 4 features)) where it applies
+  if (int rc = gnan_locate_tree(a, piece, dx, static_cast<hipStream_t>(stream)); rc != -1) return rc;
   LocateParams p;
   p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F; p.off = a->off; p.anchor = a->anchor;
   int step0 = 0;

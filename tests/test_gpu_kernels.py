@@ -551,7 +551,8 @@ def test_table_path_parameter_gradients_edge_cases(fixed, monkeypatch):
 
 @pytest.mark.parametrize("F,L,H,C,sum_features", [(129, 3, 32, 40, True), (20, 3, 16, 7, True), (9, 2, 24, 2, True),
                                                    (33, 3, 16, 64, True), (12, 3, 16, 5, False), (70, 3, 8, 17, False),
-                                                   (20, 3, 16, 100, True), (6, 3, 8, 130, False)])    # > 64 channels: chunks
+                                                   (20, 3, 16, 100, True), (6, 3, 8, 130, False),    # > 64 channels: chunks
+                                                   (32, 3, 16, 13, True)])
 def test_two_phase_lookup_for_several_channels(F, L, H, C, sum_features, monkeypatch):
     """csrc/fpwl_rows.hip: piece / dx located once per (node, feature) (bit-exact index work against the reference search),
     forward rows == the thread-per-node kernel (same arithmetic per term; the feature sum in the same order when a thread
@@ -572,6 +573,10 @@ def test_two_phase_lookup_for_several_channels(F, L, H, C, sum_features, monkeyp
     # phase 1 against the definition
     a = functional._fpwl_args(x, t, sum_features)
     piece, dx = functional._fpwl_locate(x, t, a)
+    if F % 16 in (0, 1, 4):                                               # the tree-search kernel of large batches == the sorted-array one
+        xb = x.repeat(53, 1)[:262144]
+        pb, db = functional._fpwl_locate(xb, t, functional._fpwl_args(xb, t, sum_features))
+        assert torch.equal(pb[:n], piece) and torch.equal(db[:n], dx) and torch.equal(pb[n:2 * n], piece)
     off, anchor = t.off.cpu().long(), t.anchor.cpu()
     xc = x.cpu()
     for k in (0, 1, F // 2, F - 1):
