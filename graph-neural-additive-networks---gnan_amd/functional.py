@@ -90,7 +90,12 @@ NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) 
 
 FPWL_ROWS = os.environ.get("GNAN_FPWL_ROWS", "1") != "0"   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
 FPWL_ROWS_MIN_NODES = 32768
-FPWL_ROWS_MIN_CHANNELS, FPWL_ROWS_MIN_CHANNELS_BWD = 12, 6   # fewer channels: locating the pieces separately costs more than it saves
+# fewer channels: locating the pieces separately costs more than it saves (GNAN_FPWL_ROWS_MIN_C: A/B aid).  10M nodes x 64
+# features, look-up, two-phase / thread-per-node: C = 2 4.4 / 3.9 ms, C = 4 4.6 / 5.7, C = 8 5.2 / 6.2, C = 12 7.0 / 9.3,
+# C = 32 11.8 / 35.7; arxiv-shaped forward+backward: C = 4 2.91 / 2.84, C = 7 2.77 / 2.86
+FPWL_ROWS_MIN_CHANNELS = int(os.environ.get("GNAN_FPWL_ROWS_MIN_C", "6"))
+FPWL_ROWS_MIN_CHANNELS_LARGE = min(4, FPWL_ROWS_MIN_CHANNELS)       # from FPWL_ROWS_LARGE nodes (tree-search locate kernel)
+FPWL_ROWS_LARGE = 262144
 
 
 def _fpwl_args(x: torch.Tensor, t, sum_features: bool, out=None) -> "_lib.FpwlArgs":
@@ -105,14 +110,13 @@ def _fpwl_args(x: torch.Tensor, t, sum_features: bool, out=None) -> "_lib.FpwlAr
 def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
     """Several channels on a large batch: the piece of every (node, feature) is located once (``gnan_fpwl_locate``) and the
     channel work runs with lane = channel — arxiv-shaped C = 40: look-up 2.3 -> ? ms, moments 4.5 -> ? ms."""
-    # (10M nodes x 64 features, look-up: C = 8 7.4 ms against 6.2 ms for the thread-per-node kernel, C = 12 9.2 / 9.3,
-    #  C = 16 9.0 / 9.7, C = 32 12.2 / 35.7; arxiv-shaped moments at C = 7: 0.26 + 0.17 ms against 0.65 ms)
     # more than 64 channels: in chunks of 64 (forward) / of as many channels as have their 64-bit bins in LDS (backward);
     # tables too large for the LDS image of the thread-per-node kernels (C > ~110) have no other kernel: any batch size
     from .pwl import oversize
     if not FPWL_ROWS or not 1 < C <= 4096:
         return False
-    return oversize(t) or ((FPWL_ROWS_MIN_CHANNELS_BWD if bins else FPWL_ROWS_MIN_CHANNELS) <= C and n >= FPWL_ROWS_MIN_NODES)
+    min_c = FPWL_ROWS_MIN_CHANNELS_LARGE if n >= FPWL_ROWS_LARGE else FPWL_ROWS_MIN_CHANNELS
+    return oversize(t) or (min_c <= C and n >= FPWL_ROWS_MIN_NODES)
 
 
 def _fpwl_locate(x: torch.Tensor, t, a):

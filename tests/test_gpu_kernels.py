@@ -561,7 +561,7 @@ def test_two_phase_lookup_for_several_channels(F, L, H, C, sum_features, monkeyp
     from gnan_amd.functional import _fpwl_launch, _fpwl_moments
     monkeypatch.setattr(functional, "FPWL_ROWS_MIN_NODES", 1)
     monkeypatch.setattr(functional, "FPWL_ROWS_MIN_CHANNELS", 2)
-    monkeypatch.setattr(functional, "FPWL_ROWS_MIN_CHANNELS_BWD", 2)
+    monkeypatch.setattr(functional, "FPWL_ROWS_MIN_CHANNELS_LARGE", 2)
     monkeypatch.setattr(functional, "SUM_VIA_FEATURES_MAX_NODES", 0)     # (the small-graph detour around the summing kernel)
     sd = _mlp_state(F, L, H, C, True, seed=F + C)
     st = _stack(sd, F, L, H, C, True)
