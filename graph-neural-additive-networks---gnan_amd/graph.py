@@ -29,7 +29,8 @@ LONG_ROW_THRESHOLD_NARROW = 64   # ... for operand rows of one or two lanes: a s
 NARROW_PLAN_MAX_ROWS = 8192
 SLICE_EDGES = 2048         # pairs per slice of a hub row
 PACK_SHIFT = 29            # packed index entries: column id in the low 29 bits, hop code above (gnan_spmm_args.packed_index)
-HOT_COLUMNS = 65536        # neighbours whose operand rows get a compact second copy (narrow operands, HopGraph.hot_columns)
+HOT_COLUMNS_MIN = 16384     # ... and no fewer than this (smaller graphs: their hot values survive in L2 as they are)
+HOT_COLUMNS = 262144        # neighbours whose operand rows get a compact second copy (narrow operands, HopGraph.hot_columns)
 HOT_COLUMNS_MIN_NNZ = 1 << 24    # below this the two extra launches that fill the copy cost more than the gathers save
 HOT_COLUMNS_MIN_SHARE = 0.15     # ... and so does a graph whose K most listed neighbours receive less than this share of the pairs
 
@@ -314,12 +315,15 @@ class HopGraph:
         1.79 -> 1.52 ms on top of the degree-sorted walk).  Pure index work; cached per graph."""
         if self._hot is None:
             ids = None
-            if (not self.is_dense and self.nnz >= HOT_COLUMNS_MIN_NNZ and self.n_cols >= 16 * HOT_COLUMNS
-                    and self.n_cols + HOT_COLUMNS < 2 ** 31):                     # the renumbered ids stay int32
+            K = HOT_COLUMNS                                           # at most a sixteenth of the neighbours, a power of two
+            while K > 1 and 16 * K > self.n_cols:
+                K //= 2
+            if (not self.is_dense and self.nnz >= HOT_COLUMNS_MIN_NNZ and K >= min(HOT_COLUMNS, HOT_COLUMNS_MIN)
+                    and self.n_cols + K < 2 ** 31):                               # the renumbered ids stay int32
                 listed = torch.zeros(self.n_cols, dtype=torch.int64, device=self.device)
                 for e0 in range(0, self.nnz, 1 << 27):                # pairs per pass: bounds the int64 temporaries
                     listed += torch.bincount(self.col[e0:e0 + (1 << 27)].long(), minlength=self.n_cols)
-                top = torch.argsort(listed, descending=True, stable=True)[:HOT_COLUMNS]
+                top = torch.argsort(listed, descending=True, stable=True)[:K]
                 if float(listed[top].sum()) >= HOT_COLUMNS_MIN_SHARE * self.nnz:
                     ids = top.contiguous()
             self._hot = (ids,)
