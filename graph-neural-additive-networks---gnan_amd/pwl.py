@@ -315,7 +315,9 @@ class _PendingTables:
             p2 <<= 1
         room = min(mg + mg // 8 + 8, LDS_LIMIT // ((1 + 2 * table_stride(self.C)) * 4))     # never ask for more LDS than the kernel accepts
         if room < mg:
-            return None
+            if self.C == 1 or fg != 1:
+                return None
+            room = mg + mg // 8 + 8      # tables no LDS image holds (C > ~110): the two-phase kernels read them from global memory
         return PwlTables(self.meta[: self.F + 1], self.anchor, self.val, self.slope, max(p2, 64), fg, room)
 
     def resolve(self) -> Optional[PwlTables]:

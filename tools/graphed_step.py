@@ -127,6 +127,8 @@ if __name__ == "__main__":
         run("arxiv_shaped_C1", lambda: arxiv_shaped(1))
     if "arxiv40" in which:
         run("arxiv_shaped_C40", lambda: arxiv_shaped(40))
+    if "arxiv172" in which:
+        run("arxiv_shaped_C172", lambda: arxiv_shaped(172))
     if "cora" in which:
         run("cora_shaped", cora_shaped)
     if "rmat" in which:
