@@ -454,14 +454,23 @@ def parameter_grads_from_moments(p, t: PwlTables, M: torch.Tensor, evaluate):
     off = t.off.long()
     F = off.numel() - 1
     C = M.shape[2]
-    pieces = off[1:] - off[:-1]
-    feat = torch.repeat_interleave(torch.arange(F, device=M.device), pieces)      # feature of every piece
-    local = torch.arange(M.shape[0], device=M.device) - off[:-1][feat]
+    # feature and in-feature index of every table row, without a device->host copy (the table may sit in a buffer of full
+    # capacity when it was sized for a hipGraph: rows behind off[F] are not pieces — they get zero weights and a clamped slot)
+    T = M.shape[0]
+    row = torch.arange(T, device=M.device)
+    real = row < off[F]
+    feat = torch.searchsorted(off[1:].contiguous(), row, right=True).clamp_(max=F - 1)
     rows = 2 * t.max_pieces                                   # host-known: no device->host copy in the backward
+    local = (row - off[:-1][feat]).clamp_(0, t.max_pieces - 1)
+    zero = torch.zeros((), dtype=torch.float64, device=M.device)
+    u1, u2 = torch.where(real, u1, zero), torch.where(real, u2, zero)
+    c1, c2 = torch.where(real.unsqueeze(1), c1, zero), torch.where(real.unsqueeze(1), c2, zero)
     U = torch.zeros(rows, F, dtype=torch.float64, device=M.device)
     W = torch.zeros(rows, F, C, dtype=torch.float64, device=M.device)
-    U[2 * local, feat], U[2 * local + 1, feat] = u1, u2
-    W[2 * local, feat], W[2 * local + 1, feat] = c1, c2
+    U.index_put_((2 * local, feat), u1, accumulate=True)      # (accumulate: the clamped slots of non-pieces add zeros)
+    U.index_put_((2 * local + 1, feat), u2, accumulate=True)
+    W.index_put_((2 * local, feat), c1, accumulate=True)
+    W.index_put_((2 * local + 1, feat), c2, accumulate=True)
     live = [q for q in p[:6] if q is not None]
     with torch.enable_grad():
         y = evaluate(U, p).view(rows, F, C)                   # float64 through the casts inside `evaluate`
