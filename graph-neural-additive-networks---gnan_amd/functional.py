@@ -366,15 +366,39 @@ HIP_TABLE_GRADS = os.environ.get("GNAN_HIP_TABLE_GRADS", "1") != "0"   # table p
 
 
 def _table_grads_applies(L: int, H: int, C: int) -> bool:
-    return HIP_TABLE_GRADS and C <= 64 and ((L == 3 and H <= 64) or (L == 2 and H <= 128))
+    return HIP_TABLE_GRADS and C <= 4096 and ((L == 3 and H <= 64) or (L == 2 and H <= 128))
 
 
 def _fpwl_param_grads_launch(params, t, moments, L, H, C, F):
     """``gnan_fpwl_param_grads``: gradients of the six stacked parameter tensors (None where a bias is absent) from the
     per-piece moments — ``moments`` is ``[T, 2, C]`` float32 or the ``(int64 moments, scales)`` pair of the fixed-point route."""
+    fixed = isinstance(moments, tuple)
+    if C > 64:
+        # the kernel covers 64 output channels.  Its result is linear in (moments, last-layer rows) channel by channel — the
+        # activation masks depend on the hidden layers only — so chunks of channels are run one after the other: the last
+        # layer's gradients are theirs, the hidden layers' gradients add up
+        total = None
+        for c0 in range(0, C, 64):
+            c1 = min(C, c0 + 64)
+            sub = list(params)
+            sub[4] = params[4][:, c0:c1].contiguous()
+            sub[5] = None if params[5] is None else params[5][:, c0:c1].contiguous()
+            m = (moments[0][:, :, c0:c1].contiguous(), moments[1]) if fixed else moments[:, :, c0:c1].contiguous()
+            got = _fpwl_param_grads_launch(sub, t, m, L, H, c1 - c0, F)
+            if total is None:
+                total = [None if q is None else q.clone() for q in got]
+                total[4] = torch.empty_like(params[4], dtype=torch.float32)
+                total[5] = None if params[5] is None else torch.empty_like(params[5], dtype=torch.float32)
+            else:
+                for i in range(4):
+                    if total[i] is not None:
+                        total[i] += got[i]
+            total[4][:, c0:c1] = got[4]
+            if total[5] is not None:
+                total[5][:, c0:c1] = got[5]
+        return total
     keep = [None if q is None else q.detach().float().contiguous() for q in params]
     outs = [None if q is None else torch.empty_like(q) for q in keep]
-    fixed = isinstance(moments, tuple)
     M = None if fixed else moments.detach().float().contiguous()
     a = _lib.FpwlGradArgs(
         off=_lib.ptr(t.off), anchor=_lib.ptr(t.anchor), moments=_lib.ptr(M),

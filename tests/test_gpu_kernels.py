@@ -468,7 +468,8 @@ def test_small_batch_backward_kernel_vs_autograd(F, L, H, C, bias, n, sum_featur
 
 @pytest.mark.parametrize("F,L,H,C,bias,n", [(5, 3, 64, 1, True, 4000), (3, 3, 33, 40, True, 900), (7, 3, 8, 3, False, 2500),
                                              (4, 2, 100, 5, True, 3000), (2, 2, 16, 64, False, 700), (1, 3, 64, 2, True, 50),
-                                             (129, 3, 64, 1, True, 2000)])
+                                             (129, 3, 64, 1, True, 2000),
+                                             (3, 3, 16, 100, True, 800), (2, 2, 32, 130, False, 600)])   # > 64 channels: chunks
 @pytest.mark.parametrize("sum_features", [True, False])
 def test_table_path_parameter_gradients_kernel(F, L, H, C, bias, n, sum_features, monkeypatch):
     """gnan_fpwl_param_grads (analytic reverse passes per piece, float64, one workgroup per feature) == the torch route
