@@ -655,7 +655,8 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         n_long=(plan.n_long if plan is not None else 0), n_slices=(plan.n_slices if plan is not None else 0),
         slice_edges=(plan.slice_edges if plan is not None else 0),
         workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0),
-        s_by_code=int(s_by_code), nnz=(0 if g.col is None else int(g.col.numel())), packed_index=int(packed))
+        s_by_code=int(s_by_code), nnz=(0 if (g.col is None or not WIDE_INDEX_LOADS) else int(g.col.numel())),
+        packed_index=int(packed))
     return a
 
 
@@ -681,6 +682,7 @@ FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum ov
 DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
 DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
 NARROW_ROW_SLICING = os.environ.get("GNAN_NARROW_ROW_SLICING", "1") != "0"   # A/B switch of LONG_ROW_THRESHOLD_NARROW
+WIDE_INDEX_LOADS = os.environ.get("GNAN_WIDE_INDEX", "1") != "0"      # a lane's run of index entries as 16-byte loads (gnan_spmm_args.nnz)
 PACKED_INDEX = os.environ.get("GNAN_PACKED_INDEX", "1") != "0"         # degree-sorted copies are read as one (col | code << 29) stream
 NARROW_SORTED_MIN_NNZ = 1 << 23   # below ~8M pairs the sorted walk's tail (the longest rows run last) and its scattered stores cost
                                    # more than the divergence they remove (arxiv-shaped, 1.3M pairs: 11.6 -> 26 us at W = 1)
