@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
           int d = __shfl(codev, j);
           d = d < rest ? d : rest;
           if (j < m && col_ok) {
-            const Vec<VEC> sv = load_operand<VEC>(p.S, BWD ? static_cast<int64_t>(c) * p.D + d : static_cast<int64_t>(c), p.s_stride, cw);
+            const Vec<VEC> sv = load_operand<VEC>(p.S, BWD ? static_cast<int64_t>(d) * p.n_cols + c : static_cast<int64_t>(c), p.s_stride, cw);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd)
 #pragma unroll
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_kernel(const Params p, cons
 #pragma unroll
               for (int v = 0; v < VEC; ++v) sv[u].v[v] = 0.f;
               if (j < m && col_ok)
-                sv[u] = load_operand<VEC>(p.S, BWD ? static_cast<int64_t>(c) * p.D + d[u] : static_cast<int64_t>(c), p.s_stride, cw);
+                sv[u] = load_operand<VEC>(p.S, BWD ? static_cast<int64_t>(d[u]) * p.n_cols + c : static_cast<int64_t>(c), p.s_stride, cw);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -1355,7 +1355,7 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
 }
 
 namespace {
-// V[i * D + d, :] = [ dY_i / cnt(i, d) | dY_i / cnt(i, D-1) ]  (the packed operand of gnan_spmm_bwd_narrow), zero padded.
+// V[d * n + i, :] = [ dY_i / cnt(i, d) | dY_i / cnt(i, D-1) ]  (the packed operand of gnan_spmm_bwd_narrow), zero padded.
 // Thread = node: its gradient row and counts are read once, its D packed rows are one contiguous run of the output.
 __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restrict__ dY, int64_t dy_stride, int W,
                                                             const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
@@ -1368,8 +1368,11 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
       const int k = cnt[i * cnt_stride + D - 1];
       r_rest = static_cast<float>(k > 1 ? k : 1);
     }
-    float* out = V + o * D * 2 * half;
+    // code-major: V[d * (n + n_hot) + o, :] — the rows of ONE hop code are contiguous, so the lines a pass over the code-1
+    // pairs fetches hold sixteen useful rows each (node-major (o, d) rows: a third of every line was the never-gathered
+    // rest code and the once-per-node self code) and the hot block of a code is 2 MB instead of 6
     for (int d = 0; d < D; ++d) {
+      float* out = V + (static_cast<int64_t>(d) * (n + n_hot) + o) * 2 * half;
       float r = 1.f;
       if (cnt) {
         const int k = cnt[i * cnt_stride + d];
@@ -1377,8 +1380,8 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
       }
       for (int w = 0; w < half; ++w) {
         const float g = w < W ? dY[i * dy_stride + w] : 0.f;
-        out[d * 2 * half + w] = g / r;
-        out[d * 2 * half + half + w] = with_rest ? g / r_rest : 0.f;
+        out[w] = g / r;
+        out[half + w] = with_rest ? g / r_rest : 0.f;
       }
     }
   }

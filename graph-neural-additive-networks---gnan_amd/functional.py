@@ -823,13 +823,14 @@ NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"
 
 def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int,
                   hot: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``V[i, d] = [dY_i / cnt(i, d) | dY_i / cnt(i, D-1)]``, halves zero padded to ``half`` floats (``gnan_spmm_pack_bwd_rows``);
-    with ``hot`` (node ids) the rows of those nodes are repeated behind the n real ones: ``V[n + k] = V[hot[k]]``."""
+    """``V[d, i] = [dY_i / cnt(i, d) | dY_i / cnt(i, D-1)]`` (code-major ``[D, n (+ hot), 2 * half]``), halves zero padded to
+    ``half`` floats (``gnan_spmm_pack_bwd_rows``); with ``hot`` (node ids) the rows of those nodes are repeated behind the n
+    real ones of every code block: ``V[d, n + k] = V[d, hot[k]]``."""
     _lib.require_device(dY)
     dY = _rows(dY.detach().float())
     n, W = dY.shape
     k = 0 if hot is None else int(hot.numel())
-    V = torch.empty((n + k, D, 2 * half), dtype=torch.float32, device=dY.device)
+    V = torch.empty((D, n + k, 2 * half), dtype=torch.float32, device=dY.device)
     c = None if cnt is None else cnt.contiguous()
     h = None if hot is None else hot.to(torch.int64).contiguous()
     _lib.check(_lib.lib().gnan_spmm_pack_bwd_rows(_lib.ptr(dY), dY.stride(0), W, _lib.ptr(c), 0 if c is None else c.stride(0), D, n,
@@ -851,7 +852,7 @@ def narrow_walk(g: HopGraph):
 def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int,
                       walk=None):
     """``gnan_spmm_bwd_narrow`` over the transposed adjacency ``gt``: returns ``(dS [n, W], dlut [D])`` — see the header for
-    the layout of ``V [n_fwd_rows * D, 2 * half]``.  ``walk = narrow_walk(gt)`` when the caller has already put the hot
+    the layout of ``V [D * n_fwd_rows, 2 * half]`` (code-major).  ``walk = narrow_walk(gt)`` when the caller has already put the hot
     rows behind ``V`` (``pack_bwd_rows(hot=...)``)."""
     _lib.require_device(V, S_rows, lut, gt.code)
     V = _rows(V.detach().float())
@@ -865,8 +866,9 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
     # behind V (see spmm_launch); dS is bit-identical, the table gradient adds its float64 partials in processing order
     appended = walk is not None
     gt, order, hot = walk if appended else narrow_walk(gt)
-    if hot is not None and not appended:
-        V = append_hot_rows(V, hot, D)
+    if hot is not None and not appended:                      # V [D * n, 2 * half], code-major: the hot rows go behind every code block
+        V3 = V.view(D, -1, V.shape[1])
+        V = torch.cat([V3, V3.index_select(1, hot)], dim=1).view(-1, V.shape[1])
     scatter = 0 if order is None else 2
     plan = gt.narrow_row_plan() if (V.shape[1] * 4 <= 8 and NARROW_ROW_SLICING) else gt.long_row_plan()
     a = _spmm_args(gt, V, lut, False, None, dS, order, False, plan=plan, scatter_out=scatter)
@@ -928,11 +930,11 @@ class _RhoAggregate(torch.autograd.Function):
             # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
             half = 1 << max(0, (W - 1).bit_length())
             walk = narrow_walk(g.transposed())
-            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [n (+ hot), D, 2 * half]
+            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
             dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk)
             if with_rest:
                 total = ctx.s_total if ctx.s_total is not None else column_sums(S)
-                q_sum = column_sums(V[:g.n_rows, 0, half:half + W])                            # sum_i dY_i / cnt(i, rest)
+                q_sum = column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
                 dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
             dlut = dl.view(D, 1)
 

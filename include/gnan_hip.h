@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 27
+#define GNAN_ABI_VERSION 28
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -411,7 +411,8 @@ int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stri
  * D <= 4, one global weight channel, fp32) — autograd through GNAN.py:67-73 / models.py:368-376 w.r.t. f_sums and rho's
  * outputs, for the sum-first evaluation (W = out_channels).
  * `a` describes the TRANSPOSED adjacency (row j = a node as neighbour, its pairs (i, code) = the forward rows that list it);
- * a->S holds one row per (forward row i, hop code d), a->W = 2 * half floats wide (half a power of two >= w_real):
+ * a->S holds one row per (hop code d, forward row i) — row d * a->n_cols + i, code-major: the rows of one code are contiguous —,
+ * a->W = 2 * half floats wide (half a power of two >= w_real):
  *     [ dY_i / cnt(i, d)  (w_real floats, zero padded to half) | dY_i / cnt(i, D-1)  (likewise; zeros without a rest bucket) ]
  * a->lut is the global table [D] (a->Cw = 1, a->lut_row_stride = 0, a->cnt = NULL: the counts are folded into a->S).
  *   dS[j, :]   = sum_{d} lut[d] * A_d[j] - lut[D-1] * Q[j]       A_d[j] = sum of the first halves over j's code-d pairs,
@@ -421,10 +422,11 @@ int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stri
  * s_rows [n_rows, w_real] are the operand rows of the forward pass (S itself).  Fixed-order float64 partials: bit-reproducible.
  * It replaces gnan_spmm_fwd(s_by_code) + gnan_spmm_lut_grad — two traversals of the same pairs — by one.
  * ------------------------------------------------------------------------------------------- */
-/* builds that packed operand: V[i*D + d, :] = [ dY[i, :W] / max(cnt[i, d], 1) | dY[i, :W] / max(cnt[i, D-1], 1) ], each half
- * zero padded to `half` floats (cnt == NULL: no division; with_rest == 0: second halves zero).  With n_hot > 0, V has
- * (n + n_hot) * D rows and rows (n + k)*D + d repeat node hot[k] (int64 ids in DEVICE memory): the compact second copy
- * of the most listed nodes' rows that a column array remapped to n + k reads (HopGraph.hot_columns). */
+/* builds that packed operand, code-major: V[d*(n + n_hot) + i, :] = [ dY[i, :W] / max(cnt[i, d], 1) | dY[i, :W] /
+ * max(cnt[i, D-1], 1) ], each half zero padded to `half` floats (cnt == NULL: no division; with_rest == 0: second halves
+ * zero).  With n_hot > 0 every code block has n + n_hot rows and row n + k repeats node hot[k] (int64 ids in DEVICE
+ * memory): the compact second copy of the most listed nodes' rows that a column array remapped to n + k reads
+ * (HopGraph.hot_columns). */
 int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32_t W, const int32_t* cnt, int64_t cnt_stride, int32_t D,
                             int64_t n, int32_t with_rest, float* V, int32_t half, const int64_t* hot, int64_t n_hot,
                             gnan_stream_t stream);

@@ -90,14 +90,14 @@ def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None):
     V[:, :, :W] = dY.unsqueeze(1) / den.unsqueeze(-1)
     if with_rest:
         V[:, :, half:half + W] = (dY / den[:, D - 1:D]).unsqueeze(1)
-    return V
+    return V.permute(1, 0, 2).contiguous()                      # code-major [D, n, 2 * half]
 
 
 def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None):
     D = lut.numel()
     half = V.shape[1] // 2
     row_of_pair, col, code = _pairs(gt)                     # rows of gt = nodes as neighbours; col = the forward row listing them
-    Vd = V.detach().double()[col * D + code]
+    Vd = V.detach().double()[code * gt.n_cols + col]           # code-major rows
     n = gt.n_rows
     A = torch.zeros((n * D, half), dtype=torch.float64).index_add_(0, row_of_pair * D + code, Vd[:, :half]).view(n, D, half)[:, :, :W]
     Q = torch.zeros((n, half), dtype=torch.float64).index_add_(0, row_of_pair, Vd[:, half:])[:, :W]

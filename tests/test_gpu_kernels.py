@@ -929,12 +929,12 @@ def test_packed_backward_rows_kernel(W, D, use_cnt, with_rest):
     cnt = torch.from_numpy(rng.integers(0, 50, (n, D)).astype(np.int32)).to(DEV) if use_cnt else None
     V = pack_bwd_rows(dY, cnt, D, with_rest, half)
     want = cpu_kernels.pack_bwd_rows(dY.cpu(), None if cnt is None else cnt.cpu(), D, with_rest, half)
-    assert V.shape == (n, D, 2 * half)
+    assert V.shape == (D, n, 2 * half)                                   # code-major
     assert torch.equal(V.cpu(), want)                                    # correctly rounded division, zero padding
-    assert pack_bwd_rows(dY[:0], None if cnt is None else cnt[:0], D, with_rest, half).shape == (0, D, 2 * half)
+    assert pack_bwd_rows(dY[:0], None if cnt is None else cnt[:0], D, with_rest, half).shape == (D, 0, 2 * half)
     ids = torch.from_numpy(rng.integers(0, n, 37)).to(DEV)                 # second copies of 37 nodes behind the n real rows
     Vh = pack_bwd_rows(dY, cnt, D, with_rest, half, hot=ids)
-    assert Vh.shape == (n + 37, D, 2 * half) and torch.equal(Vh[:n], V) and torch.equal(Vh[n:], V[ids])
+    assert Vh.shape == (D, n + 37, 2 * half) and torch.equal(Vh[:, :n], V) and torch.equal(Vh[:, n:], V[:, ids])
 
 
 @pytest.mark.parametrize("W,K,with_rest", [(1, 1, True), (2, 2, True), (4, 1, False)])
