@@ -34,6 +34,9 @@ struct Params {
   int64_t out_stride;
   double* col_partial;   // optional [gridDim.x, F]: per-workgroup column sums of the output (FAST, per-feature mode)
   int out_bf16;          // per-feature output stored as bf16 rows (FAST path only)
+  uint8_t* piece_out;    // optional [n, F] (fast feature-sum kernel): the piece of every (node, feature) within its feature,
+                         // kept for gnan_fpwl_moments_fixed(piece_in) — the backward pass then skips the search
+  const uint8_t* piece_in;
   int64_t total_rows;    // column sums cover nodes [0, total_rows) only
   int max_pieces;        // largest piece count of one feature
   int max_group_pieces;  // largest piece count of one feature group
@@ -406,6 +409,14 @@ __global__ __launch_bounds__(BS) void fpwl_fast_kernel(const Params p) {
         y[f] = fmaf(vs.y, xv[f] - an, vs.x);
       }
       if constexpr (SUM) {
+        if (p.piece_out) {                          // (uniform) keep the pieces for the backward pass: one byte per look-up
+          // group-major [n_groups][n][FG]: the pass over a feature group writes one contiguous FG-byte run per node (node-
+          // major [n, F] rows got a quarter of every line per pass: the stores doubled the kernel's time)
+          unsigned packed = 0u;
+#pragma unroll
+          for (int f = 0; f < FPT; ++f) packed |= static_cast<unsigned>(((a[f] - Q) >> 2) - P2) << (8 * f);
+          *reinterpret_cast<unsigned*>(p.piece_out + (static_cast<int64_t>(g) * p.n + n) * FG + q * FPT) = packed;
+        }
         float acc = 0.f;
 #pragma unroll
         for (int f = 0; f < FPT; ++f) acc += (!RAGGED || live[f]) ? y[f] : 0.f;
@@ -732,14 +743,19 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
   if (tid <= FG) s_off[tid] = p.off[k0 + (tid < nf ? tid : nf)] - base;
   for (int i = tid; i < 2 * tot; i += BS) bins[i] = 0ull;
   __syncthreads();
-  for (int i = tid; i < FG * P2; i += BS) {
-    const int f = i >> NSTEP, k = i & (P2 - 1);
-    float v = INFINITY;
-    if (k) {
-      const int j = tree_sorted_index<NSTEP>(k);
-      if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
+  const bool saved = p.piece_in != nullptr;          // (uniform) the forward pass kept the pieces: no trees, no search
+  if (saved) {
+    for (int i = tid; i < tot; i += BS) smem[i] = p.anchor[base + i];       // anchors in piece order (tot <= FG * P2)
+  } else {
+    for (int i = tid; i < FG * P2; i += BS) {
+      const int f = i >> NSTEP, k = i & (P2 - 1);
+      float v = INFINITY;
+      if (k) {
+        const int j = tree_sorted_index<NSTEP>(k);
+        if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
+      }
+      smem[i + (f / FPT) * kTreeSkew] = v;
     }
-    smem[i + (f / FPT) * kTreeSkew] = v;
   }
   __syncthreads();
   const int Q = static_cast<int>(lds_base) + q * ((FPT * P2 + kTreeSkew) * 4);   // tree of the thread's first feature
@@ -780,19 +796,29 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
     }
     int a[FPT];
     float last[FPT];
-#pragma unroll
-    for (int f = 0; f < FPT; ++f) {
-      a[f] = Q + 4;                                 // node 1 = root
-      last[f] = a0[f];
-    }
-#pragma unroll
-    for (int step = 0; step < NSTEP; ++step) {
+    if (saved) {
+      const unsigned packed = *reinterpret_cast<const unsigned*>(p.piece_in + (static_cast<int64_t>(grp) * p.n + n) * FG + q * FPT);
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const float e = lds_f32(a[f] + f * (P2 * 4));
-        const bool right = e <= xv[f];
-        a[f] = (a[f] << 1) + (right ? nQ4 : nQ);
-        last[f] = right ? e : last[f];
+        const int pc = static_cast<int>((packed >> (8 * f)) & 0xffu);
+        a[f] = Q + ((pc + P2) << 2);                // the tree address the search would have ended at
+        last[f] = live[f] ? smem[binoff[f] + P2 + pc] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        a[f] = Q + 4;                               // node 1 = root
+        last[f] = a0[f];
+      }
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+          const float e = lds_f32(a[f] + f * (P2 * 4));
+          const bool right = e <= xv[f];
+          a[f] = (a[f] << 1) + (right ? nQ4 : nQ);
+          last[f] = right ? e : last[f];
+        }
       }
     }
     unsigned long long t0 = 0ull;
@@ -865,7 +891,9 @@ int launch_moments_fast(MomentParams mp, hipStream_t st) {
 }
 
 template <int FG, int BS>
-int launch_moments(const MomentParams& mp, size_t lds, hipStream_t st) {
+int launch_moments(const MomentParams& mp_in, size_t lds, hipStream_t st) {
+  MomentParams mp = mp_in;
+  if (mp.f.max_pieces > 256) mp.f.piece_in = nullptr;      // one byte per look-up: searched again instead
   const bool fixed = mp.Mi != nullptr;
   if constexpr (FG % 4 == 0) {
     const bool whole = mp.f.F % FG == 0 && mp.f.vec_x;
@@ -965,6 +993,8 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
     if (p.col_partial && lds_fast < BS * 4 * sizeof(float)) lds_fast = BS * 4 * sizeof(float);
     p.soff_offset = static_cast<int>(lds_fast / sizeof(float));
     lds_fast += (FG + 1) * sizeof(int);
+    if (p.piece_out && !(fast && p.sum_features && nstep <= 8 && lds_fast <= 150 * 1024))
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: piece_out needs the fast feature-sum kernel (C == 1, feature quads) and at most 256 pieces per feature");
     if (fast && nstep <= 10 && lds_fast <= 150 * 1024) {
       auto fgo = [&](auto kernel) {
         if (lds_fast > 64 * 1024) {
@@ -1000,6 +1030,7 @@ int launch(Params p, size_t lds, hipStream_t st, float* total_out) {
       return GNAN_OK;
     }
   }
+  if (p.piece_out) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: piece_out needs the fast feature-sum kernel");
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -1135,6 +1166,7 @@ Params base_params(const gnan_fpwl_args* a) {
   p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
   p.acc_offset = 0;
   p.out_bf16 = a->out_dtype == GNAN_BF16;
+  p.piece_out = a->piece_out; p.piece_in = a->piece_in;
   return p;
 }
 }  // namespace

@@ -127,6 +127,7 @@ def _fpwl_locate(x: torch.Tensor, t, a):
     return piece, dx
 
 
+KEEP_PIECES = os.environ.get("GNAN_KEEP_PIECES", "1") != "0"   # C == 1 training: the forward's pieces (a byte each) serve the backward
 LOCATED_KEEP_MAX_BYTES = 2 << 30   # (piece, dx) of a forward are kept for its backward pass while they stay below 2 GiB
 
 
@@ -170,6 +171,16 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
         a.total, a.total_workspace, a.total_workspace_bytes = _lib.ptr(total), _lib.ptr(ws), need
         a.total_rows = n if total_rows is None else int(total_rows)
+    if (located is not None and KEEP_PIECES and C == 1 and sum_features and fpg % 4 == 0 and t.max_pieces <= 256 and n > 0
+            and n * F <= LOCATED_KEEP_MAX_BYTES):
+        # training, one channel: the fast feature-sum kernel also stores the piece of every look-up (one byte each) and the
+        # moment kernel of the backward pass skips its search (C4 training step: moments 1.25 -> ? ms)
+        piece8 = torch.empty(((F + fpg - 1) // fpg, n, fpg), dtype=torch.uint8, device=x.device)    # group-major
+        a.piece_out = _lib.ptr(piece8)
+        if _lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)) == 0:
+            located[:] = [piece8]
+            return (out, total) if want_total else out
+        a.piece_out = None                              # another kernel serves this shape: plain look-up
     _lib.check(_lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)), "gnan_fpwl_fwd")
     return (out, total) if want_total else out
 
@@ -223,8 +234,10 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
                                                       _lib.ptr(scales), _lib.stream_of(x)), "gnan_fpwl_moment_scales")
         scales = scales[:2]
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
+        if located and len(located) == 1 and not rows:          # one channel: the forward's pieces, one byte per look-up
+            a.piece_in = _lib.ptr(located[0])
         if rows:
-            piece, dx = located if located else _fpwl_locate(x, t, a)    # (kept by the forward pass, or located again)
+            piece, dx = located if (located and len(located) == 2) else _fpwl_locate(x, t, a)    # kept by the forward pass, or located again
             _lib.check(_lib.lib().gnan_fpwl_rows_moments_fixed(a, _lib.ptr(piece), _lib.ptr(dx), _lib.ptr(grad), grad.stride(0),
                                                                _lib.ptr(scales), _lib.ptr(Mi), _lib.stream_of(x)),
                        "gnan_fpwl_rows_moments_fixed")

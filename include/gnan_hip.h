@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 28
+#define GNAN_ABI_VERSION 29
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -153,6 +153,12 @@ typedef struct gnan_fpwl_args {
   size_t total_workspace_bytes;
   int64_t total_rows;      /* `total` covers rows [0, total_rows) only (a rank's owned rows ahead of its halo rows);
                               <= 0 or >= n: all rows */
+  uint8_t* piece_out;      /* gnan_fpwl_fwd, optional [ceil(F / features_per_group), n, features_per_group] bytes (group-major, 4-byte
+                              aligned): the piece of every (node, feature) within its feature, kept
+                              for the backward pass.  Needs the fast feature-sum kernel (C == 1, sum_features, feature quads) and
+                              max_pieces <= 256; GNAN_ERR_UNSUPPORTED otherwise (call again without it) */
+  const uint8_t* piece_in; /* gnan_fpwl_moments_fixed, optional: those bytes — the C == 1 kernel then skips the search (ignored
+                              by the other moment kernels and above 256 pieces per feature) */
 } gnan_fpwl_args;
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);

@@ -426,6 +426,17 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
             wide = torch.zeros(n, F + 3, device=DEV)
             wide[:, 1:F + 1] = gd
             assert torch.equal(_fpwl_moments(xd, t, wide[:, 1:F + 1], sum_features, raw=True)[0], general)
+        if sum_features and C == 1 and t.features_per_group % 4 == 0:
+            # the forward pass can keep the piece of every look-up (a byte each); the moment kernel then skips its search
+            kept = []
+            functional._fpwl_launch(xd, t, True, located=kept)
+            fg = t.features_per_group
+            assert len(kept) == 1 and kept[0].dtype == torch.uint8 and kept[0].shape == ((F + fg - 1) // fg, n, fg)   # group-major
+            off, anchor = t.off.cpu().long(), t.anchor.cpu()
+            for k in (0, F - 1):
+                want_piece = torch.searchsorted(anchor[off[k]:off[k + 1]][1:].contiguous(), x[:, k].contiguous(), right=True)
+                assert torch.equal(kept[0][k // fg, :, k % fg].cpu().long(), want_piece)
+            assert torch.equal(_fpwl_moments(xd, t, gd, True, raw=True, located=kept)[0], general)
 
 
 @pytest.mark.parametrize("F,L,H,C,bias,n", [(3, 3, 8, 1, True, 203), (20, 3, 64, 3, True, 1000), (7, 3, 33, 7, False, 5),
