@@ -1048,6 +1048,95 @@ def test_packed_index_entries_give_the_same_bits(W, K, bf16, monkeypatch):
     assert wide.degree_sorted_copy()[0].colp is None
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_aggregation_paths_agree_on_random_shapes(seed, monkeypatch):
+    """Seeded random shapes (rows, degrees, hubs, shells, widths, skewed columns) through every walk of the aggregation —
+    natural order, degree-sorted copy, hot rows appended, packed / wide index loads on and off: the same bits from all of
+    them, and the float64 oracle within 1e-5."""
+    from gnan_amd import functional, graph as G
+    from gnan_amd.functional import spmm_launch
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(300, 9000))
+    K = int(rng.integers(1, 3))
+    D = K + 2
+    W = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 40, 64]))
+    hubs = [(int(rng.integers(0, n)), int(rng.integers(600, 4000))) for _ in range(int(rng.integers(0, 3)))]
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=hubs)
+    if rng.random() < 0.7:                                                # a few neighbours listed by many pairs
+        hot = rng.random(col.shape[0]) < rng.uniform(0.1, 0.6)
+        col[hot] = rng.integers(0, 70, int(hot.sum())) * (n // 70)
+    use_cnt, with_rest = bool(rng.random() < 0.7), bool(rng.random() < 0.7)
+    g = _graph(rowptr, col, code, n, D, idx_dtype=torch.int64 if rng.random() < 0.5 else torch.int32)
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    monkeypatch.setattr(G, "HOT_COLUMNS", 64)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN", 1)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_SHARE", 0.0)
+    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    out = []
+    for min_rows, walk, hot_rows, packed, wide in ((1 << 30, False, False, False, False), (1, True, False, False, True),
+                                                   (1, True, True, True, True), (1, True, True, False, False),
+                                                   (1 << 30, False, False, False, True)):
+        monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
+        monkeypatch.setattr(functional, "NARROW_SORTED_WALK", walk)
+        monkeypatch.setattr(functional, "HOT_COLUMN_ROWS", hot_rows)
+        monkeypatch.setattr(functional, "PACKED_INDEX", packed)
+        monkeypatch.setattr(functional, "WIDE_INDEX_LOADS", wide)
+        out.append(spmm_launch(g, S, lut, use_cnt, with_rest))
+    for y in out[1:]:
+        assert torch.equal(out[0], y)
+    wt = lut.cpu().double().unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    want = O.spmm_csr(rowptr, col, code, S.cpu().double(), wt, with_rest=with_rest)
+    assert O.rel_err(out[0].cpu(), want) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_aggregation_gradients_agree_on_random_shapes(seed, monkeypatch):
+    """Seeded random shapes through the aggregation's autograd function — one-pass narrow backward over natural order and
+    over the degree-sorted copy with hot packed rows, wide operands through the per-node weight table: operand gradients
+    identical between the walks, everything within 2e-5 of float64 oracle autograd."""
+    from gnan_amd import functional, graph as G
+    from gnan_amd.functional import rho_aggregate
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(300, 6000))
+    K = int(rng.integers(1, 3))
+    D = K + 2
+    W = int(rng.choice([1, 2, 3, 4, 7, 16, 24, 40]))
+    hubs = [(int(rng.integers(0, n)), int(rng.integers(600, 3000))) for _ in range(int(rng.integers(0, 3)))]
+    rowptr, col, code = _random_csr(n, n, K, rng, hubs=hubs)
+    if rng.random() < 0.7:
+        hot = rng.random(col.shape[0]) < rng.uniform(0.1, 0.5)
+        col[hot] = rng.integers(0, 50, int(hot.sum())) * (n // 50)
+    use_cnt, with_rest = bool(rng.random() < 0.7), bool(rng.random() < 0.7)
+    g = _graph(rowptr, col, code, n, D)
+    S0 = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    lut0 = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    monkeypatch.setattr(G, "HOT_COLUMNS", 64)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN", 1)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
+    monkeypatch.setattr(G, "HOT_COLUMNS_MIN_SHARE", 0.0)
+    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    got = []
+    for min_rows in (1 << 30, 1):
+        monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
+        S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+        got.append(torch.autograd.grad(rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest), [S, lut], up))
+    assert torch.equal(got[0][0], got[1][0])
+    S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    ref = torch.autograd.grad(O.spmm_csr(rowptr, col, code, S64, wt, with_rest=with_rest), [S64, lut64], up.cpu().double())
+    for k in range(2):
+        scale = float(ref[k].abs().max())
+        for run in got:
+            assert float((run[k].cpu().double() - ref[k]).abs().max()) <= 2e-5 * scale, (k, scale)
+
+
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
     place == rows processed in natural order (same arithmetic per row)."""
