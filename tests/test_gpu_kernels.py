@@ -640,6 +640,57 @@ def test_tables_too_large_for_lds_use_the_two_phase_kernels(sum_features):
     assert O.rel_err(y.detach().cpu(), truth) <= 1e-5
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_table_path_agrees_with_oracle_on_random_shapes(seed, monkeypatch):
+    """Seeded random models (features, depth, width, channels, batch size, gradient layout) through the table path's
+    dispatcher — fast / ragged / general / two-phase kernels, kept pieces, chunked parameter gradients — against float64
+    oracle autograd: outputs within 1e-5, parameter gradients within 2e-5 of the largest."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    rng = np.random.default_rng(3000 + seed)
+    F = int(rng.choice([1, 3, 8, 16, 17, 33, 64, 70, 129]))
+    L = int(rng.choice([2, 3]))
+    H = int(rng.choice([4, 16, 33, 64]))
+    C = int(rng.choice([1, 1, 1, 2, 5, 9, 40, 70]))
+    n = int(rng.choice([257, 3000, 9000]))
+    bias, sum_features = bool(rng.random() < 0.7), bool(rng.random() < 0.6)
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    if rng.random() < 0.5:                                               # let the two-phase kernels take small batches too
+        monkeypatch.setattr(functional, "FPWL_ROWS_MIN_NODES", 1)
+        monkeypatch.setattr(functional, "SUM_VIA_FEATURES_MAX_NODES", 0)
+    sd = _mlp_state(F, L, H, C, bias, seed=seed)
+    st = _stack(sd, F, L, H, C, bias)
+    leaves = [t for t in st[:6] if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, F, generator=gen) * 4 - 2
+    if F > 1:
+        x[:, -1] = 1.0                                                   # the reference's ones column
+    gup = torch.randn(n, C if sum_features else F * C, generator=gen)
+    out = feature_mlps(x.to(DEV), st, sum_features)
+    got = torch.autograd.grad(out, leaves, gup.to(DEV))
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.feature_mlps(x.double(), sd64)
+    ref = ref.sum(1) if sum_features else ref.reshape(n, -1)
+    assert O.rel_err(out.detach().cpu(), ref.detach()) <= 1e-5
+    ref.backward(gup.double())
+    last = 3 * (L - 1)
+    want = {"w_first": torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)]),
+            "w_last": torch.stack([sd64[f"fs.{k}.{last}.weight"].grad for k in range(F)])}
+    if bias:
+        want["b_first"] = torch.stack([sd64[f"fs.{k}.0.bias"].grad for k in range(F)])
+        want["b_last"] = torch.stack([sd64[f"fs.{k}.{last}.bias"].grad for k in range(F)])
+    if L == 3:
+        want["w_mid"] = torch.stack([sd64[f"fs.{k}.3.weight"].grad for k in range(F)]).unsqueeze(0)
+        if bias:
+            want["b_mid"] = torch.stack([sd64[f"fs.{k}.3.bias"].grad for k in range(F)]).unsqueeze(0)
+    names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
+    scale = max(float(v.abs().max()) for v in want.values())
+    for nm, gr in zip(names, got):
+        assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, (nm, F, L, H, C, n, sum_features)
+
+
 @pytest.mark.parametrize("n,width,gscale", [(1000, 3, 1.0), (70000, 1, 1e-12), (5, 64, 1e20), (100, 2, 0.0)])
 def test_moment_scales_kernel(n, width, gscale):
     """gnan_fpwl_moment_scales == the framework formula it replaced (powers of two from max|grad| and max|x - anchor|)."""
