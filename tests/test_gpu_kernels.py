@@ -644,7 +644,11 @@ def test_tables_too_large_for_lds_use_the_two_phase_kernels(sum_features):
 def test_table_path_agrees_with_oracle_on_random_shapes(seed, monkeypatch):
     """Seeded random models (features, depth, width, channels, batch size, gradient layout) through the table path's
     dispatcher — fast / ragged / general / two-phase kernels, kept pieces, chunked parameter gradients — against float64
-    oracle autograd: outputs within 1e-5, parameter gradients within 2e-5 of the largest."""
+    oracle autograd: outputs within 1e-5, parameter gradients within 2e-5 of the largest.
+    (Fixed seeds: a wider sweep — 60 seeds — fails once, seed 19, identically on EVERY kernel route including round 1's: a
+    node whose x lies within an ulp of a kink of its shape function falls on the other side of the float32-rounded
+    breakpoint, and the ReLU subgradient there is a choice — 6e-4 of the largest gradient, the same ambiguity the float32
+    reference has against float64.)"""
     from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
     rng = np.random.default_rng(3000 + seed)
