@@ -48,7 +48,7 @@ struct Params {
 // LDS row strides of the per-piece tables: an odd number of words per piece for C > 1.  The threads of a wavefront
 // read channel c of DIFFERENT pieces (thread = node), i.e. addresses `piece * stride + c`: with stride = C = 40 those
 // fall on 4 of the 32 banks (16-way conflicts; C = 32: one bank), and the 64-bit bins of the moment kernels, stride 2 C
-// quad-words, on a single bank pair.  arxiv-shaped C = 40: look-up 2.30 -> ? ms, moments 4.53 -> ? ms.
+// quad-words, on a single bank pair.  arxiv-shaped C = 40: look-up 2.33 -> 2.30 ms, moments 4.5 -> 4.0 ms (the structure, not the conflicts, was the bound: fpwl_rows.hip).
 __host__ __device__ __forceinline__ int table_stride(int C) { return C > 1 ? (C | 1) : 1; }          // floats per (val | slope) row
 __host__ __device__ __forceinline__ int bin_stride(int C) { return C > 1 ? 2 * C + 1 : 2; }          // bins per piece: [2][C] (+ 1)
 
