@@ -68,10 +68,15 @@ __device__ __forceinline__ bool piece_moment(const GradParams& p, int64_t t, int
 
 // anchor of piece li (of P) and a point strictly inside it: piece 0 is the ray left of the first kink (anchored at that
 // kink), the last piece the ray right of the last kink; a zero-width piece (coinciding kinks) holds no node
+// A piece one float32 step wide, [a, nextafter(a)), holds the nodes with x == a and nothing else (the table builder puts one
+// behind every anchor on which a hidden unit's pre-activation is exactly zero, pwl_build.hip): its masks are taken AT a,
+// strictly (z > 0), which is torch's relu'(0) = 0 — with zero biases (GNAN.py:49-53) and one-hot features that is every
+// unit of most nodes, and the masks of the piece to the right would hand their bias gradients to the wrong units.
 __device__ __forceinline__ void piece_points(const float* A, int li, int P, double* a, double* xi) {
   *a = static_cast<double>(A[li]);
   if (li == 0) *xi = *a - 1.0;
   else if (li == P - 1) *xi = *a + 1.0;
+  else if (A[li + 1] <= nextafterf(A[li], INFINITY)) *xi = *a;
   else *xi = 0.5 * (*a + static_cast<double>(A[li + 1]));
 }
 

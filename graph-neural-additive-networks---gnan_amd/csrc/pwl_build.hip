@@ -210,42 +210,100 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   }
 
   // ---- 3. table: float32 anchors, float64 network values ----------------------------------------------
-  const int P = n_bp;
-  for (int i = tid; i < P; i += kBT) {
+  // Anchors are rounded UP: a node goes to piece #{anchors <= x}, so x >= anchor must imply x >= the true kink — a float32
+  // x that equals an anchor is then never on the wrong side of a kink lying strictly between two float32 numbers.
+  for (int i = tid; i < n_bp; i += kBT) {
     double t = bp[i];
     t = t > 3.0e38 ? 3.0e38 : (t < -3.0e38 ? -3.0e38 : t);
-    bp[i] = static_cast<double>(static_cast<float>(t));
+    float f = static_cast<float>(t);
+    if (static_cast<double>(f) < t) f = nextafterf(f, INFINITY);
+    bp[i] = static_cast<double>(f);
+  }
+  // Point pieces (pwl.py:_with_point_pieces): behind every anchor a at which some hidden unit's pre-activation is EXACTLY
+  // zero — zero biases put every first-layer kink at x = 0 (GNAN.py:49-53), and one-hot / bag-of-words features are mostly
+  // exact zeros — nextafter(a) becomes an anchor too: the piece [a, nextafter(a)) holds the nodes with x == a and nothing
+  // else, and gnan_fpwl_param_grads differentiates it AT a (relu'(0) = 0, as torch does) instead of inside the piece to the
+  // right.  The pre-activations are those of the table evaluation below; only if an anchor was marked is the table
+  // evaluated a second time, with the new anchors in place.
+  int* on_kink = reinterpret_cast<int*>(cand);              // [kCap] (the candidates of step 2 are in bp by now)
+  float* extra = reinterpret_cast<float*>(cand) + kCap;     // [kCap]
+  double* V = p.scratch + static_cast<int64_t>(k) * (p.cap + 2) * C;
+  const float* Wl = p.w_last + static_cast<int64_t>(k) * C * H;
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();
+    const int P = n_bp;
+    const bool mark = round == 0 && P > 0;
+    if (mark) {
+      for (int i = tid; i < P; i += kBT) on_kink[i] = 0;
+      if (tid == 0) n_cand = 0;
+      __syncthreads();
+    }
+    const double t_first = P ? bp[0] : 0.0, t_last = P ? bp[P - 1] : 0.0;
+    auto tnode = [&](int i) -> double {                     // P + 2 nodes (P == 0: -1, 0, +1 with a virtual kink at 0)
+      if (i == 0) return t_first - 1.0;
+      if (i <= (P ? P : 1)) return P ? bp[i - 1] : 0.0;
+      return t_last + 1.0;
+    };
+    const int Pn = P ? P : 1;                               // table nodes between the two outer ones
+    // the network at the table nodes, p.chunk nodes at a time: the last hidden layer into LDS (eval_nodes), then
+    // (node, channel) pairs take the output dot products
+    for (int n0 = 0; n0 < Pn + 2; n0 += p.chunk) {
+      const int nn = Pn + 2 - n0 < p.chunk ? Pn + 2 - n0 : p.chunk;
+      eval_nodes(tnode, n0, nn, H, p.L == 3, w1, b1, b2, W2, h1, zt, tid);
+      if (mark) {
+        for (int it = tid; it < nn * H; it += kBT) {
+          const int g = n0 + it / H, j = it % H;            // table node g is anchor g - 1
+          if (g < 1 || g > P) continue;
+          bool zero = w1[j] != 0.f && fma(static_cast<double>(w1[j]), bp[g - 1], static_cast<double>(b1[j])) == 0.0;
+          if (p.L == 3) zero |= zt[it] == 0.0;
+          if (zero) on_kink[g - 1] = 1;
+        }
+      }
+      const double* hid = h1;                               // L == 2: relu(layer 1) is the last hidden layer
+      if (p.L == 3) {
+        if (mark) __syncthreads();
+        for (int it = tid; it < nn * H; it += kBT) zt[it] = zt[it] > 0.0 ? zt[it] : 0.0;
+        __syncthreads();
+        hid = zt;
+      }
+      for (int it = tid; it < nn * C; it += kBT) {
+        const int ni = it / C, c = it % C;
+        double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
+#pragma unroll 8
+        for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
+        V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
+      }
+      __syncthreads();
+    }
+    if (!mark) break;
+    // behind the last of a run of coinciding anchors only, and only where the next anchor does not already end the piece there
+    for (int i = tid; i < P; i += kBT) {
+      if (!on_kink[i]) continue;
+      const float up = nextafterf(static_cast<float>(bp[i]), INFINITY);
+      if (i == P - 1 || static_cast<float>(bp[i + 1]) > up) extra[atomicAdd(&n_cand, 1)] = up;
+    }
+    __syncthreads();
+    const int nf = n_cand;
+    if (nf == 0) break;
+    if (P + nf > p.cap) {                                   // no room: the host drops the tables (overflow) anyway
+      if (tid == 0) over = 1;
+      break;
+    }
+    for (int i = tid; i < nf; i += kBT) bp[P + i] = static_cast<double>(extra[i]);     // bp[P ..] held +inf
+    __syncthreads();
+    pow2 = 2;
+    while (pow2 < P + nf) pow2 <<= 1;
+    bitonic_sort(bp, pow2, tid);
+    if (tid == 0) n_bp = P + nf;
   }
   __syncthreads();
+  const int P = n_bp;
   const double t_first = P ? bp[0] : 0.0, t_last = P ? bp[P - 1] : 0.0;
-  auto tnode = [&](int i) -> double {                       // P + 2 nodes (P == 0: -1, 0, +1 with a virtual kink at 0)
+  auto tnode = [&](int i) -> double {
     if (i == 0) return t_first - 1.0;
     if (i <= (P ? P : 1)) return P ? bp[i - 1] : 0.0;
     return t_last + 1.0;
   };
-  const int Pn = P ? P : 1;                                 // table nodes between the two outer ones
-  double* V = p.scratch + static_cast<int64_t>(k) * (p.cap + 2) * C;
-  const float* Wl = p.w_last + static_cast<int64_t>(k) * C * H;
-  // the network at the table nodes, p.chunk nodes at a time: the last hidden layer into LDS (eval_nodes), then
-  // (node, channel) pairs take the output dot products
-  for (int n0 = 0; n0 < Pn + 2; n0 += p.chunk) {
-    const int nn = Pn + 2 - n0 < p.chunk ? Pn + 2 - n0 : p.chunk;
-    eval_nodes(tnode, n0, nn, H, p.L == 3, w1, b1, b2, W2, h1, zt, tid);
-    const double* hid = h1;                                 // L == 2: relu(layer 1) is the last hidden layer
-    if (p.L == 3) {
-      for (int it = tid; it < nn * H; it += kBT) zt[it] = zt[it] > 0.0 ? zt[it] : 0.0;
-      __syncthreads();
-      hid = zt;
-    }
-    for (int it = tid; it < nn * C; it += kBT) {
-      const int ni = it / C, c = it % C;
-      double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
-#pragma unroll 8
-      for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
-      V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
-    }
-    __syncthreads();
-  }
   __threadfence_block();
   __syncthreads();
   const int pieces = P + 1;

@@ -100,6 +100,40 @@ def _network(x: torch.Tensor, p, w, b, w_last, b_last):
     return y
 
 
+def _round_up_f32(bp: torch.Tensor) -> torch.Tensor:
+    """Float64 kinks -> the smallest float32 not below them (+inf padding stays).  A node is sent to piece
+    ``#{anchors <= x}``; with anchors rounded UP, ``x >= anchor`` implies ``x >=`` the true kink, so a float32 ``x`` that
+    equals an anchor is never put on the wrong side of a kink that lies strictly between two float32 numbers."""
+    c = torch.where(torch.isfinite(bp), bp.clamp(-3.0e38, 3.0e38), bp)
+    f = c.float()
+    below = torch.isfinite(f) & (f.double() < c)
+    return torch.where(below, torch.nextafter(f, torch.full_like(f, float("inf"))), f)
+
+
+def _with_point_pieces(bp32: torch.Tensor, p, w, b) -> torch.Tensor:
+    """Anchors ``[F, P]`` (sorted, +inf padded) -> ``[F, 2P]`` with ``nextafter(a)`` inserted behind every anchor ``a``
+    at which some hidden unit's pre-activation is EXACTLY zero (zero biases put every first-layer kink at x = 0,
+    GNAN.py:49-53; one-hot and bag-of-words features are mostly exact zeros).  The piece ``[a, nextafter(a))`` then
+    holds the nodes with ``x == a`` and nothing else, and the backward pass differentiates it AT ``a`` — where torch
+    takes relu'(0) = 0 for the unit that sits on its kink — instead of inside the piece to the right
+    (:func:`piece_probe_points`, ``csrc/fpwl_grad.hip:piece_points``).  The tabulated function is unchanged."""
+    F, P = bp32.shape
+    INF = float("inf")
+    finite = torch.isfinite(bp32)
+    t = torch.where(finite, bp32, torch.zeros_like(bp32)).double()
+    on_kink = torch.zeros_like(finite)
+    for depth in range(p.L - 1):
+        hit = _prefix(t, p, depth, w, b) == 0                        # [F, P, H]
+        if depth == 0:
+            hit = hit & (w[0] != 0).unsqueeze(1)                     # w = 0: a constant unit has no kink
+        on_kink = on_kink | hit.any(dim=-1)
+    up = torch.nextafter(bp32, torch.full_like(bp32, INF))
+    nxt = torch.cat([bp32[:, 1:], torch.full_like(bp32[:, :1], INF)], dim=1)
+    # only behind the last of a run of coinciding anchors, and only where the next anchor does not already end the piece there
+    extra = torch.where(on_kink & finite & (nxt > up), up, torch.full_like(up, INF))
+    return torch.sort(torch.cat([bp32, extra], dim=1), dim=1)[0]
+
+
 def _build_padded(p):
     """Device part of the build — static shapes only, no host round trip (so it can live in a hipGraph):
     returns ``(off [F+1] int64, overflow [] bool, anchor [F, P+1], val [F, P+1, C], slope [F, P+1, C], keep [F, P+1])``
@@ -158,7 +192,7 @@ def _build_padded(p):
         bp = torch.full((F, 1), INF, dtype=f64, device=dev)
 
     # float32 anchors (what the kernel compares x against), network values there in float64
-    bp32 = torch.where(torch.isfinite(bp), bp.clamp(-3.0e38, 3.0e38), bp).float()
+    bp32 = _with_point_pieces(_round_up_f32(bp), p, w, b)
     finite = torch.isfinite(bp32)
     n_bp = finite.sum(dim=1)                                          # [F]
     P = bp32.shape[1]
@@ -418,7 +452,12 @@ def piece_probe_points(t: PwlTables):
     h = torch.where(w > 0, w / 3.0, torch.ones_like(w))
     h = torch.where(first, -torch.ones_like(h), h)
     h = torch.where(last, torch.ones_like(h), h)          # a single-piece (affine) feature is both: +1 wins
-    return a + h, a + 2.0 * h, h
+    # a piece one float32 step wide holds the nodes with x == a and nothing else (_with_point_pieces): both probes sit
+    # ON the anchor, where autograd takes relu'(0) = 0; its slope moment is zero (x - a = 0), h only has to be finite
+    up = torch.nextafter(t.anchor, torch.full_like(t.anchor, float("inf")))
+    nxt32 = torch.cat([t.anchor[1:], t.anchor[-1:]])
+    point = (nxt32 > t.anchor) & (nxt32 <= up) & ~first & ~last
+    return torch.where(point, a, a + h), torch.where(point, a, a + 2.0 * h), h
 
 
 def moments_reference(x: torch.Tensor, g: torch.Tensor, t: PwlTables, sum_features: bool) -> torch.Tensor:

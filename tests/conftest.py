@@ -33,6 +33,9 @@ class Golden:
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         self.name = name
         self.meta = json.loads(bytes(z["meta"]).decode())
+        if self.meta.get("variant", "").startswith("kink_"):     # inputs exactly on ReLU kinks: same variants, marked
+            self.meta["variant"] = self.meta["variant"][5:]
+            self.meta["kink"] = True
         self.inputs = {k[3:]: z[k] for k in z.files if k.startswith("in/")}
         self.sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
         self.g32 = {k[4:]: z[k] for k in z.files if k.startswith("g32/")}

@@ -97,8 +97,9 @@ def random_graph(rng, n, directed, n_isolated, avg_deg=2.2):
     return ei.astype(np.int64)
 
 
-def run_pre_process(ei, n, f_raw, rng, graph_task):
-    x = torch.from_numpy(rng.random((n, f_raw), dtype=np.float32))
+def run_pre_process(ei, n, f_raw, rng, graph_task, x=None):
+    if x is None:
+        x = torch.from_numpy(rng.random((n, f_raw), dtype=np.float32))
     data = Bag(x=x, edge_index=torch.from_numpy(ei))
     tmp = tempfile.mkdtemp()
     if graph_task:
@@ -119,12 +120,41 @@ def redraw(model, seed):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.5)
 
 
-def capture(build, call, data32, seed):
+def redraw_on_kinks(mode):
+    """Weights for the cases whose inputs sit EXACTLY on ReLU kinks (torch: relu'(0) = 0).
+
+    ``zero``: O(1) weights, biases left at the reference's own initial value 0 (GNAN.py:49-53) — every first-layer kink of
+    every shape function is at x = 0, and every later pre-activation is 0 there too.
+    ``exact``: first-layer weights are multiples of 1/64 and first-layer biases ``-w * a`` with ``a`` in {0, 1/4, 1/2, 1}, so
+    the kinks are float32 numbers the inputs take; the other biases are non-zero."""
+    def fn(model, seed):
+        redraw(model, seed)
+        g = torch.Generator().manual_seed(seed + 77)
+        with torch.no_grad():
+            named = dict(model.named_parameters())
+            for name, p in named.items():
+                if not name.endswith("bias"):
+                    continue
+                if mode == "zero":
+                    p.zero_()
+                elif name.startswith("fs.") and name.split(".")[2] == "0" and p.numel() > 1:
+                    w = named[name[:-4] + "weight"]
+                    if w.shape[1] != 1:
+                        continue
+                    q = torch.round(w * 64.0) / 64.0
+                    q[q == 0] = 1.0 / 64.0
+                    w.copy_(q)
+                    a = torch.tensor([0.0, 0.25, 0.5, 1.0])[torch.randint(0, 4, (w.shape[0],), generator=g)]
+                    p.copy_(-(w[:, 0] * a))
+    return fn
+
+
+def capture(build, call, data32, seed, redraw_fn=redraw):
     """Run the reference in fp32 and fp64 with identical weights; return arrays to store."""
     torch.set_default_dtype(torch.float32)
     torch.manual_seed(seed)
     m32 = build().eval()
-    redraw(m32, seed)
+    redraw_fn(m32, seed)
     out32 = call(m32, data32)
     m32.zero_grad()
     out32.pow(2).sum().backward()
@@ -367,6 +397,112 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
         manifest.append(name)
         print(name, tr, te)
+
+    # f-3 with the path itself: the reference's epoch loops driving the reference's GNAN classes (trainer.py:23-154 over
+    # models.py:304-477 / GNAN.py:9-79) — one SGD epoch and one evaluation pass; inputs, initial and updated state_dict
+    class GraphData(Bag):
+        def to(self, device):
+            return self
+
+    def trainer_case(tid, variant, C, loss_name, n_batches, n, f_raw=4, H=8, L=3):
+        graph_task = variant.endswith("graph")
+        rng = np.random.default_rng(9100 + tid)
+        batches = []
+        for b in range(n_batches):
+            nb = n if not graph_task else int(rng.integers(5, 12))
+            ei = random_graph(rng, nb, False, 1)
+            if not graph_task:
+                perm = np.arange(nb)
+                top = int(ei.max())
+                perm[[top, nb - 1]] = perm[[nb - 1, top]]
+                ei = perm[ei]
+            d = run_pre_process(ei, nb, f_raw, rng, graph_task)
+            ny = 1 if graph_task else nb
+            if loss_name == "CrossEntropyLoss":
+                y = torch.from_numpy(rng.integers(0, C, ny))
+            elif loss_name == "MSELoss":
+                y = torch.from_numpy(rng.standard_normal(ny).astype(np.float32))
+            else:
+                y = torch.from_numpy(rng.choice([-1.0, 1.0], ny).astype(np.float32))
+            fields = dict(x=d.x, edge_index=d.edge_index, node_distances=d.node_distances,
+                          normalization_matrix=d.normalization_matrix, y=y)
+            if not graph_task:
+                for m in ("train_mask", "val_mask", "test_mask"):
+                    mask = torch.from_numpy(rng.random(nb) < 0.6)
+                    mask[0] = True
+                    fields[m] = mask
+            batches.append(GraphData(**fields))
+        F = batches[0].x.shape[1]
+        c = dict(variant=variant, C=C, H=H, L=L, bias=True, normalize_rho=True, rho_per_feature=(C > 1),
+                 readout_n_layers=0)
+        build, _ = build_and_call(c, F)
+        torch.manual_seed(60 + tid)
+        model = build()
+        redraw(model, 60 + tid)
+        model.train()
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        loss_fn = getattr(torch.nn, loss_name)()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        classify = loss_name != "MSELoss"
+        tr = ref_trainer.train_epoch(model, batches, loss_fn, opt, "cpu", classify=classify, compute_auc=False,
+                                     is_graph_task=graph_task)
+        sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+        te = ref_trainer.test_epoch(model, batches, loss_fn, "cpu", classify=classify, compute_auc=False,
+                                    val_mask=True, is_graph_task=graph_task)
+        arrays = {"train_ret": np.array(tr, dtype=np.float64), "test_ret": np.array(te, dtype=np.float64)}
+        for k, v in sd0.items():
+            arrays["sd0/" + k] = v.numpy()
+        for k, v in sd1.items():
+            arrays["sd1/" + k] = v.numpy()
+        for b, d in enumerate(batches):
+            for k, v in d.__dict__.items():
+                arrays[f"b{b}/{k}"] = v.numpy()
+        meta = dict(variant="trainer_gnan", model=variant, id=310 + tid, C=C, H=H, L=L, F=F, graph=graph_task, loss=loss_name,
+                    classify=classify, n_batches=n_batches, lr=0.05, rho_per_feature=(C > 1))
+        name = f"case_{310 + tid:03d}_trainer_gnan"
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        manifest.append(name)
+        print(name, tr, te)
+
+    trainer_case(0, "models_tensor_node", 3, "CrossEntropyLoss", 1, 40)
+    trainer_case(1, "models_gnan", 1, "BCEWithLogitsLoss", 1, 30)
+    trainer_case(2, "models_tensor_graph", 1, "BCEWithLogitsLoss", 4, 0)
+    trainer_case(3, "standalone_tensor_node", 3, "CrossEntropyLoss", 1, 40)
+    trainer_case(4, "models_tensor_graph", 1, "MSELoss", 3, 0)
+
+    # inputs EXACTLY on ReLU kinks: zero biases (the reference's own initial state) with one-hot / bag-of-words style
+    # features, and kinks placed on float32 numbers the inputs take.  torch differentiates relu at 0 as 0.
+    kink_cases = [
+        dict(variant="models_tensor_node", mode="zero", n=40, f_raw=5, H=8, C=3, L=3, rho_per_feature=True),
+        dict(variant="standalone_tensor_node", mode="zero", n=300, f_raw=8, H=32, C=1, L=3),
+        dict(variant="models_gnan", mode="zero", n=40, f_raw=5, H=8, C=3, L=2, rho_per_feature=False),
+        dict(variant="models_tensor_node", mode="exact", n=300, f_raw=8, H=16, C=2, L=3, rho_per_feature=False),
+        dict(variant="models_tensor_graph", mode="zero", n=40, f_raw=5, H=8, C=1, L=3, rho_per_feature=False,
+             readout_n_layers=0),
+        dict(variant="models_tensor_node", mode="exact", n=40, f_raw=5, H=8, C=1, L=2, rho_per_feature=False),
+    ]
+    for kid, kc in enumerate(kink_cases):
+        c = dict(seed=kid % 3, bias=True, normalize_rho=True, directed=False, n_isolated=2, id=400 + kid)
+        c.update(kc)
+        rng = np.random.default_rng(11000 + kid)
+        graph_task = c["variant"].endswith("graph")
+        ei = random_graph(rng, c["n"], False, c["n_isolated"])
+        if not graph_task:
+            perm = np.arange(c["n"])
+            top = int(ei.max())
+            perm[[top, c["n"] - 1]] = perm[[c["n"] - 1, top]]
+            ei = perm[ei]
+        levels = np.array([0.0, 0.0, 0.0, 1.0, 1.0, 0.25, 0.5, 0.75], dtype=np.float32)
+        x = torch.from_numpy(levels[rng.integers(0, len(levels), (c["n"], c["f_raw"]))])
+        data = run_pre_process(ei, c["n"], c["f_raw"], rng, graph_task, x=x)
+        build, call = build_and_call(c, data.x.shape[1])
+        arrays = capture(build, call, data, c["seed"], redraw_fn=redraw_on_kinks(c["mode"]))
+        name = f"case_{400 + kid:03d}_kink_{c['variant']}"
+        c["variant"] = "kink_" + c["variant"]
+        total += save(name, c, data, arrays)
+        manifest.append(name)
+        print(f"{name}: out {arrays['out32'].shape}")
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

@@ -1264,3 +1264,104 @@ def test_bf16_rows_from_the_table_lookup(monkeypatch):
     assert float((y16.float() - y32).abs().max()) <= 2 ** -7 * float(y32.abs().max())
     want = y16.double().sum(0)
     assert float((tot.double() - want).abs().max()) <= 1e-5 * float(y16.double().abs().sum(0).max())
+
+
+def _on_kink_state(F, L, H, C, mode, seed):
+    """``zero``: the reference's initial biases (GNAN.py:49-53) under O(1) weights — every kink at x = 0;
+    ``exact``: first-layer kinks on the float32 numbers {0, 1/4, 1/2, 1} (weights multiples of 1/64, b = -w a)."""
+    sd = _mlp_state(F, L, H, C, True, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in range(F):
+        if mode == "zero":
+            for li in range(L):
+                sd[f"fs.{k}.{3 * li}.bias"].zero_()
+        else:
+            w = torch.round(sd[f"fs.{k}.0.weight"] * 64.0) / 64.0
+            w[w == 0] = 1.0 / 64.0
+            a = torch.tensor([0.0, 0.25, 0.5, 1.0])[torch.randint(0, 4, (H,), generator=g)]
+            sd[f"fs.{k}.0.weight"], sd[f"fs.{k}.0.bias"] = w, -(w[:, 0] * a)
+    return sd
+
+
+def _on_kink_inputs(n, F, seed):
+    g0 = torch.Generator().manual_seed(seed)
+    levels = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.25, 0.5, 0.75, -0.0])
+    x = levels[torch.randint(0, len(levels), (n, F), generator=g0)]
+    x[:, -1] = 1.0                                                       # the reference's ones column
+    return x, g0
+
+
+@pytest.mark.parametrize("mode", ["zero", "exact"])
+@pytest.mark.parametrize("F,L,H,C,bias_unused", [(5, 3, 8, 1, 0), (64, 3, 64, 1, 0), (6, 3, 33, 2, 0), (4, 2, 8, 3, 0), (2, 3, 128, 2, 0)])
+def test_table_build_kernel_point_pieces_match_torch_builder(F, L, H, C, bias_unused, mode, monkeypatch):
+    """Anchors on which a hidden pre-activation is exactly zero get a one-float32-step piece behind them, from the kernel
+    and from the torch builder alike (same piece counts, same anchors); the tabulated function is unchanged."""
+    from gnan_amd import pwl
+    sd = _on_kink_state(F, L, H, C, mode, seed=F + H)
+    st = _stack(sd, F, L, H, C, True)
+    monkeypatch.setattr(pwl, "BUILD_BACKEND", "torch")
+    t_ref = pwl.build_tables(st)
+    monkeypatch.setattr(pwl, "BUILD_BACKEND", "auto")
+    t_hip = pwl.build_tables(st)
+    assert torch.equal(t_ref.off, t_hip.off), "same number of pieces per feature"
+    a = t_hip.anchor.cpu()
+    up = torch.nextafter(a, torch.full_like(a, float("inf")))
+    assert bool(((a[1:] > a[:-1]) & (a[1:] <= up[:-1])).any()), "no point piece in the tables"
+    assert torch.equal(t_ref.anchor.cpu(), a)                             # exact kinks are exact in both builders
+    x, _ = _on_kink_inputs(4000, F, 2)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(4000, -1)
+    tc = pwl.PwlTables(*[q.cpu() if torch.is_tensor(q) else q for q in t_hip])
+    assert O.rel_err(pwl.evaluate_reference(x, tc, False), truth) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", ["zero", "exact"])
+@pytest.mark.parametrize("route,F,L,H,C,sum_features", [
+    ("fast", 64, 3, 64, 1, True),        # whole 16-feature groups, one channel, feature sum: kept pieces (a byte per look-up)
+    ("fast", 32, 3, 16, 1, False),
+    ("ragged", 17, 3, 16, 1, True), ("ragged", 129, 2, 8, 1, False),
+    ("general", 6, 3, 16, 3, True), ("general", 5, 2, 8, 2, False),
+    ("two-phase", 20, 3, 16, 7, True), ("two-phase", 12, 3, 16, 5, False), ("two-phase", 3, 3, 16, 100, True),
+])
+@pytest.mark.parametrize("fixed", [True, False])
+@pytest.mark.parametrize("hip_grads", [True, False])
+def test_table_path_gradients_with_inputs_on_kinks(route, F, L, H, C, sum_features, fixed, hip_grads, mode, monkeypatch):
+    """x EXACTLY on a ReLU kink — zero biases (the reference's own initial state, GNAN.py:49-53) with one-hot style
+    features, or kinks placed on float32 numbers the inputs take.  torch differentiates relu at 0 as 0; every table route
+    (fast / ragged / general / two-phase look-up, kept pieces, fixed-point and float moments, kernel and torch parameter
+    gradients) must hand the bias gradients to the same units: within 2e-5 of the largest gradient of float64 oracle autograd."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    monkeypatch.setattr(functional, "MOMENTS_FIXED_POINT", fixed)
+    monkeypatch.setattr(functional, "HIP_TABLE_GRADS", hip_grads)
+    monkeypatch.setattr(functional, "SUM_VIA_FEATURES_MAX_NODES", 0)
+    if route == "two-phase":
+        monkeypatch.setattr(functional, "FPWL_ROWS_MIN_NODES", 1)
+        monkeypatch.setattr(functional, "FPWL_ROWS_MIN_CHANNELS", 2)
+    n = 3000
+    sd = _on_kink_state(F, L, H, C, mode, seed=F + C)
+    st = _stack(sd, F, L, H, C, True)
+    leaves = [t for t in st[:6] if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    x, gen = _on_kink_inputs(n, F, 7)
+    gup = torch.randn(n, C if sum_features else F * C, generator=gen)
+    out = feature_mlps(x.to(DEV), st, sum_features)
+    got = torch.autograd.grad(out, leaves, gup.to(DEV))
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.feature_mlps(x.double(), sd64)
+    ref = ref.sum(1) if sum_features else ref.reshape(n, -1)
+    assert O.rel_err(out.detach().cpu(), ref.detach()) <= 1e-5
+    ref.backward(gup.double())
+    last = 3 * (L - 1)
+    want = {"w_first": torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)]),
+            "b_first": torch.stack([sd64[f"fs.{k}.0.bias"].grad for k in range(F)]),
+            "w_last": torch.stack([sd64[f"fs.{k}.{last}.weight"].grad for k in range(F)]),
+            "b_last": torch.stack([sd64[f"fs.{k}.{last}.bias"].grad for k in range(F)])}
+    if L == 3:
+        want["w_mid"] = torch.stack([sd64[f"fs.{k}.3.weight"].grad for k in range(F)]).unsqueeze(0)
+        want["b_mid"] = torch.stack([sd64[f"fs.{k}.3.bias"].grad for k in range(F)]).unsqueeze(0)
+    names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
+    scale = max(float(v.abs().max()) for v in want.values())
+    for nm, gr in zip(names, got):
+        assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, (nm, route, mode)

@@ -145,3 +145,64 @@ def test_group_planner():
     assert not pwl.oversize(pwl.PwlTables(None, None, torch.zeros(8 * 148, 40), None, 148, 1, 148))
     huge = [0, 20000, 40000]
     assert pwl._plan_groups(huge, 1) is None
+
+
+def _on_kink_state(F, L, H, C, mode, seed):
+    """``zero``: the reference's initial biases (GNAN.py:49-53) under O(1) weights — every kink at x = 0;
+    ``exact``: first-layer kinks on the float32 numbers {0, 1/4, 1/2, 1} (weights multiples of 1/64, b = -w a)."""
+    sd = mlp_state(F, L, H, C, True, seed=seed, b_scale=0.0 if mode == "zero" else 0.5)
+    if mode == "exact":
+        g = torch.Generator().manual_seed(seed + 1)
+        for k in range(F):
+            w = torch.round(sd[f"fs.{k}.0.weight"] * 64.0) / 64.0
+            w[w == 0] = 1.0 / 64.0
+            a = torch.tensor([0.0, 0.25, 0.5, 1.0])[torch.randint(0, 4, (H,), generator=g)]
+            sd[f"fs.{k}.0.weight"], sd[f"fs.{k}.0.bias"] = w, -(w[:, 0] * a)
+    return sd
+
+
+@pytest.mark.parametrize("F,L,H,C,mode,sum_features", [
+    (15, 3, 64, 1, "zero", True), (6, 3, 16, 3, "zero", False), (5, 2, 8, 2, "zero", True), (4, 4, 8, 2, "zero", False),
+    (6, 3, 16, 2, "exact", True), (5, 2, 8, 1, "exact", False), (3, 4, 8, 1, "exact", True),
+])
+def test_moment_backward_with_inputs_on_kinks(F, L, H, C, mode, sum_features):
+    """x EXACTLY on a kink: torch differentiates relu at 0 as 0, so the unit sitting on its kink gets no gradient.  The
+    tables carry a one-float32-step piece behind such anchors and its gradient is taken AT the anchor (round-2 verdict:
+    b_first / b_mid were off by 2x their magnitude with zero biases and one-hot features)."""
+    from gnan_amd.functional import _fmlp_eager
+    sd = _on_kink_state(F, L, H, C, mode, seed=3 * F + L)
+    st = stack(sd, F, L, H, C, True)
+    t = pwl.build_tables(st)
+    assert t is not None
+    up = torch.nextafter(t.anchor, torch.full_like(t.anchor, float("inf")))
+    assert bool(((t.anchor[1:] > t.anchor[:-1]) & (t.anchor[1:] <= up[:-1])).any()), "no point piece in the tables"
+    n = 600
+    g0 = torch.Generator().manual_seed(11)
+    levels = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.25, 0.5, 0.75, -0.0])
+    x = levels[torch.randint(0, len(levels), (n, F), generator=g0)]
+    x[:, -1] = 1.0
+    g = torch.randn(n, C if sum_features else F * C, generator=g0)
+    leaves = [None if q is None else q.double().requires_grad_(True) for q in st[:6]]
+    y = _fmlp_eager(x.double(), StackedMLP(*leaves, *st[6:]), sum_features)
+    want = torch.autograd.grad((y * g.double()).sum(), [q for q in leaves if q is not None])
+    # forward: the extra anchors do not change the tabulated function
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()}).reshape(n, -1)
+    assert O.rel_err(pwl.evaluate_reference(x, t, False), truth) <= 1e-5
+    M = pwl.moments_reference(x, g, t, sum_features)
+    leaves32 = [None if q is None else q.clone().requires_grad_(True) for q in st[:6]]
+    got = pwl.parameter_grads_from_moments(
+        StackedMLP(*leaves32, *st[6:]), t, M,
+        lambda U, q: _fmlp_eager(U, StackedMLP(*[None if a is None else a.double() for a in q[:6]], *q[6:]), False))
+    scale = max(float(w.abs().max()) for w in want)
+    for a, b in zip(got, want):
+        assert float((a.double() - b).abs().max()) <= 2e-5 * scale
+
+
+def test_anchors_round_up():
+    """An anchor is never below the kink it stands for: x >= anchor implies x >= kink for every float32 x."""
+    k = torch.tensor([[0.1, 1.0 / 3.0, -0.7, 0.5, 3.0e38 * 10, float("inf")]], dtype=torch.float64)
+    a = pwl._round_up_f32(k)
+    assert a.dtype == torch.float32
+    assert bool((a[0, :4].double() >= k[0, :4]).all())
+    assert bool((torch.nextafter(a[0, :4], torch.full((4,), -float("inf"))).double() < k[0, :4]).all())
+    assert float(a[0, 3]) == 0.5 and bool(torch.isfinite(a[0, 4])) and bool(torch.isinf(a[0, 5]))
