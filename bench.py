@@ -117,7 +117,7 @@ def fmlp_stage(args, x, H, L, C, W_out, ms):
             "frac": fl / (ms / 1e3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
 
 
-def cpu_baseline(args, model, g, x, operand_full):
+def cpu_baseline(args, model, g, x, operand_full, out_gpu):
     """Time the oracle (PyTorch-CPU restatement of the reference path) on a bounded sample of the same workload.
 
     Shape functions: the reference's own per-feature Python loop of nn.Linear calls (GNAN.py:58-62); the thread
@@ -139,8 +139,12 @@ def cpu_baseline(args, model, g, x, operand_full):
     torch.set_num_threads(th_f)
     n_f = int(min(x_host.shape[0], max(10000, rates[th_f] * 10)))
     t0 = time.perf_counter()
-    O.feature_mlps(x_host[:n_f], sd)                               # Python loop over features, GNAN.py:58-62
+    fx_cpu = O.feature_mlps(x_host[:n_f], sd)                      # Python loop over features, GNAN.py:58-62
     t_f = time.perf_counter() - t0
+    # every bench run is a parity run: the oracle's sample against the rows the GPU produced for the same nodes
+    fx_cpu = fx_cpu.sum(1) if args.order == "sum_first" else fx_cpu.reshape(n_f, -1)
+    fx_gpu = operand_full[:n_f].float().cpu()[:, : fx_cpu.shape[1]]
+    parity_f = float((fx_gpu.double() - fx_cpu.double()).abs().max() / fx_cpu.double().abs().max())
 
     torch.set_num_threads(ncpu)
     n_r = min(args.cpu_rows, g.n_rows)
@@ -156,6 +160,14 @@ def cpu_baseline(args, model, g, x, operand_full):
     y = O.spmm_csr_sparse(rowptr, col, code, S, lut, cnt)
     y = y.sum(dim=1)
     t_s = time.perf_counter() - t0
+    # parity of the aggregation: the GPU's output rows against the same restatement in FLOAT64 on a slice of the sample
+    # (the float32 host run above is itself ~2e-4 off: torch's CPU column sum of 10^7 float32 rows for the rest bucket)
+    n_p = min(n_r, 250_000)
+    nnz_p = int(rowptr[n_p])
+    y64 = O.spmm_csr_sparse(rowptr[: n_p + 1], col[:nnz_p], code[:nnz_p], S.double(), lut.double(), cnt[:n_p]).sum(dim=1)
+    got = out_gpu[:n_p].float().cpu().reshape(n_p, -1).sum(1).double()
+    parity_s = float((got - y64).abs().max() / y64.abs().max())
+    parity_cpu32 = float((y[:n_p].double() - y64).abs().max() / y64.abs().max())
     n_tot, nnz_tot = args.nodes, args.edges + args.nodes
     est = t_f * n_tot / n_f + t_s * nnz_tot / nnz_s
     return {
@@ -167,6 +179,10 @@ def cpu_baseline(args, model, g, x, operand_full):
                    f"rows / {nnz_s} pairs against the full {S.shape[0]}x{S.shape[1]} operand with {ncpu} threads "
                    f"({t_s:.2f} s); both legs scaled to the full graph"),
         "fmlp_nodes_per_s": n_f / t_f, "spmm_pairs_per_s": nnz_s / t_s, "fmlp_cores": th_f, "spmm_cores": ncpu,
+        # max |gpu - oracle| / max |oracle| on sampled rows: shape functions of the first n_f nodes (float32 oracle),
+        # aggregated output of the first n_p rows (torch.sparse_csr in float64 over the GPU's operand rows)
+        "parity_max_rel_err": max(parity_f, parity_s), "parity_fmlp_rel_err": parity_f, "parity_spmm_rel_err": parity_s,
+        "parity_rows": {"fmlp": n_f, "spmm": n_p}, "cpu_f32_vs_f64_rel_err": parity_cpu32,
     }
 
 
@@ -250,6 +266,18 @@ def main():
         lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
     op_dtype = torch.bfloat16 if args.operand == "bf16" else torch.float32
     stage_names = ["fmlp", "gather", "total", "spmm"] + (["reduce"] if partition == "feature" else [])
+    # One GPU: the timed call is the drop-in itself, TensorGNAN.forward(data) (models.py:358-384) on a data object that
+    # carries the hop-coded graph — graph lookup, weight views, rho on the D distinct distances, look-up, aggregation.
+    # More than one rank: gnan_amd.distributed's forward of this rank's share (the reference has no multi-process path).
+    use_module = world == 1 and not emulated and partition == "vertex" and not args.pipeline
+    if use_module:
+        class Bag:
+            pass
+        data = Bag()
+        data.x, data.edge_index, data.gnan_graph = x, None, g
+        model.aggregation_order = args.order
+        model.operand_dtype = op_dtype
+        stage_names = ["lut", "fmlp", "spmm"]
     stacked_local = slice_features(stacked, fpart.lo, fpart.hi) if partition == "feature" else None
     events = []
     # Software pipeline of the inference loop: the table build (64 workgroups, 0.05 ms, a function of the weights only) of
@@ -275,7 +303,11 @@ def main():
         if prefetch is not None:
             tables, pipe["next"] = pipe["next"], prefetch.launch()      # this forward's tables; the next forward's build starts now
         with torch.no_grad():
-            if partition == "halo":
+            if use_module:
+                model.stage_hook = mark
+                out = model.forward(data)
+                model.stage_hook = None
+            elif partition == "halo":
                 out = halo_recompute_forward(x, plan, stacked, lut, True, order=args.order, out_channels=C,
                                              marks=mark, operand_dtype=op_dtype, tables=tables)
             elif partition == "exchange":
@@ -337,10 +369,13 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     workload = f"rmat_s{args.scale}_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_{args.order}_K1" + ("" if args.operand == "f32" else "_bf16")
+    traffic_source = None
     if os.path.exists(tpath):
         rec = json.load(open(tpath))
         if rec.get("workload") == workload and rec.get("n_gpus") == world:
             traffic = rec.get("bytes_per_launch")
+            # PMC counters need rocprofv3 around the process: the figure is the committed one of the same command, not of this run
+            traffic_source = "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of this command, not measured in this run)" % rec.get("source", "committed")
 
     result = None
     if rank == 0:
@@ -359,6 +394,7 @@ def main():
                                                   if partition == "exchange" else "all_reduce(out [N,C])")},
             "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},
             "stages_ms": stages,
             "step_ms_device": {"min": per_step[0], "median": per_step[len(per_step) // 2]} if per_step else None,
@@ -366,6 +402,7 @@ def main():
             "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
             "fmlp": fmlp_stage(args, x, H, L, C, W if args.order == "reference" else C, stages["fmlp"]),
             "pipelined_table_build": prefetch is not None,
+            "timed_call": "gnan_amd.models.TensorGNAN.forward(data)" if use_module else f"gnan_amd.distributed ({partition})",
             "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": checksum,
             "operand_rows_rank0": int(x.shape[0]),
         }
@@ -373,7 +410,7 @@ def main():
             with torch.no_grad():
                 from gnan_amd.functional import feature_mlps
                 operand = feature_mlps(x, stacked, args.order == "sum_first")
-            result["cpu_baseline"] = cpu_baseline(args, model, g, x, operand)
+            result["cpu_baseline"] = cpu_baseline(args, model, g, x, operand, out)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

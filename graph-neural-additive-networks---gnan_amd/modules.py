@@ -200,14 +200,34 @@ class _PathBase(nn.Module):
     def _dropout_active(self) -> bool:
         return bool(self.training and self.dropout and self.dropout > 0)
 
-    def _features(self, x, name, mlps, sum_features: bool, pad_ok: bool = False):
+    def _features(self, x, name, mlps, sum_features: bool, pad_ok: bool = False, want_total: bool = False,
+                  out_dtype=torch.float32):
         """Shape functions of all features: fused HIP kernels, or the Dropout cold path described above.
-        ``pad_ok``: the per-feature result may carry extra all-zero columns (``functional.feature_mlps``)."""
+        ``pad_ok``: the per-feature result may carry extra all-zero columns (``functional.feature_mlps``).
+        ``want_total``: returns ``(rows, column sums or None)`` — the rest bucket's operand comes out of the look-up pass
+        instead of a second pass over the rows (``rho_aggregate(s_total=...)`` accounts for it in its backward)."""
         if self._dropout_active():
             from .functional import _fmlp_eager
             _lib.require_device(x)
-            return _fmlp_eager(x.float(), stack_mlps(mlps), sum_features, dropout=float(self.dropout))
-        return feature_mlps(x, self._stacked(name, mlps), sum_features=sum_features, pad_ok=pad_ok)
+            out = _fmlp_eager(x.float(), stack_mlps(mlps), sum_features, dropout=float(self.dropout))
+            return (out, None) if want_total else out
+        kw = {} if out_dtype == torch.float32 else {"out_dtype": out_dtype}
+        return feature_mlps(x, self._stacked(name, mlps), sum_features=sum_features, pad_ok=pad_ok,
+                            return_total=want_total, **kw)
+
+    def _operand(self, x, name, mlps, sum_features: bool, with_total: bool, pad_ok: bool = False, out_dtype=torch.float32):
+        """``(rows, column sums)`` of the shape functions — the sums are ``None`` unless ``with_total`` (a CSR's rest bucket
+        needs them; a dense adjacency lists every pair)."""
+        if not with_total:
+            return self._features(x, name, mlps, sum_features, pad_ok=pad_ok, out_dtype=out_dtype), None
+        return self._features(x, name, mlps, sum_features, pad_ok=pad_ok, want_total=True, out_dtype=out_dtype)
+
+    def _mark(self, name: str) -> None:
+        """Stage boundary of a forward (``start`` / ``lut`` / ``fmlp`` / ``spmm``): ``stage_hook`` — unset by default — is
+        what bench.py records its HIP events through."""
+        hook = getattr(self, "stage_hook", None)
+        if hook is not None:
+            hook(name)
 
     # ---- inputs -> hop-coded adjacency -----------------------------------------------------
     def _graph(self, inputs, want_norm: bool) -> HopGraph:
@@ -279,10 +299,14 @@ class StandaloneTensorGNAN(_PathBase):
         self._check_dropout()
         x = inputs.x
         _lib.require_device(x)
+        self._mark("start")
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
-        S = self._features(x, "fs", self.fs, True)                                    # [N, C]
         lut = self._lut_pre_rho(g) if self.normalize_rho else self._lut_global(g)
-        Y = rho_aggregate(g, S, lut, use_cnt=False)                                   # [N, C]
+        self._mark("lut")
+        S, total = self._operand(x, "fs", self.fs, True, not g.is_dense)             # [N, C]
+        self._mark("fmlp")
+        Y = rho_aggregate(g, S, lut, use_cnt=False, s_total=total)                    # [N, C]
+        self._mark("spmm")
         if not self.is_graph_task:
             return Y                                                                  # GNAN.py:72-73,79
         return Y.sum(dim=0).view(-1, 1)                                               # [C, 1]  GNAN.py:75-79
@@ -320,13 +344,19 @@ class _GNANCore(_PathBase):
         self._check_dropout()
         x = inputs.x
         _lib.require_device(x)
+        self._mark("start")
         g = self._graph(inputs, want_norm=True)            # GNAN.py:161 reads it unconditionally
-        S = self._features(x, "fs", self.fs, True)                                    # f_sums, GNAN.py:157
+        lut = self._lut_global(g)
+        self._mark("lut")
+        S, total = self._operand(x, "fs", self.fs, True, not g.is_dense)             # f_sums, GNAN.py:157
+        self._mark("fmlp")
         rows = None
         if node_ids is not None:
             rows = torch.as_tensor(list(node_ids) if not torch.is_tensor(node_ids) else node_ids,
                                    dtype=torch.int32, device=x.device)
-        return rho_aggregate(g, S, self._lut_global(g), use_cnt=bool(self.normalize_rho), row_ids=rows)
+        Y = rho_aggregate(g, S, lut, use_cnt=bool(self.normalize_rho), row_ids=rows, s_total=total)
+        self._mark("spmm")
+        return Y
 
     def print_rho_params(self):
         for name, param in self.rho.named_parameters():
@@ -386,6 +416,7 @@ class TensorGNAN(_PathBase):
         self.is_graph_task = is_graph_task
         self.readout_n_layers = readout_n_layers
         self.aggregation_order = "sum_first"          # or "reference" (models.py:373-376 evaluation order)
+        self.operand_dtype = torch.float32            # or torch.bfloat16: storage of the reference order's [N, F*C] rows (inference)
         with_readout = bool(is_graph_task and readout_n_layers > 0)
         self.actual_output_dim_f = 1 if with_readout else out_channels                       # models.py:320
         self.actual_output_dim_rho = 1 if (not rho_per_feature or with_readout) else out_channels  # :321
@@ -402,24 +433,33 @@ class TensorGNAN(_PathBase):
         self._check_dropout()
         x = inputs.x
         _lib.require_device(x)
+        self._mark("start")
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
         lut = self._lut_global(g)
+        self._mark("lut")
         use_cnt = bool(self.normalize_rho)
         with_readout = self.is_graph_task and self.readout_n_layers > 0
+        rest = not g.is_dense                 # a CSR lists some pairs only: the others weigh rho(0) on the column sums
         if with_readout:
-            fx = self._features(x, "fs", self.fs, False, pad_ok=True)                 # [N, F]   (f is 1-wide; + zero columns)
-            hidden = rho_aggregate(g, fx, lut, use_cnt).sum(dim=0).view(1, -1)[:, :x.shape[1]]   # [1, F]   models.py:379
+            fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True)     # [N, F]   (f is 1-wide; + zero columns)
+            self._mark("fmlp")
+            hidden = rho_aggregate(g, fx, lut, use_cnt, s_total=total).sum(dim=0).view(1, -1)[:, :x.shape[1]]   # [1, F]   models.py:379
+            self._mark("spmm")
             return self.readout_nam(hidden).T                                         # [C, 1]   models.py:380-384
         if self.aggregation_order == "reference":
             # the upstream evaluation order (models.py:373-376): aggregate every feature column, then sum
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate
             # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
             # in this order.
-            fx = self._features(x, "fs", self.fs, False, pad_ok=True)                 # [N, F*C] (+ zero columns when C == 1)
-            Y = rho_aggregate(g, fx, lut, use_cnt, reduce_channels=self.actual_output_dim_f)   # [N, C]
+            fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True,
+                                      out_dtype=self.operand_dtype)                   # [N, F*C] (+ zero columns when C == 1)
+            self._mark("fmlp")
+            Y = rho_aggregate(g, fx, lut, use_cnt, s_total=total, reduce_channels=self.actual_output_dim_f)   # [N, C]
         else:
-            S = self._features(x, "fs", self.fs, True)                                # [N, C]  sum-first
-            Y = rho_aggregate(g, S, lut, use_cnt)                                     # [N, C]
+            S, total = self._operand(x, "fs", self.fs, True, rest)                    # [N, C]  sum-first
+            self._mark("fmlp")
+            Y = rho_aggregate(g, S, lut, use_cnt, s_total=total)                      # [N, C]
+        self._mark("spmm")
         if not self.is_graph_task:
             return Y                                                                  # models.py:375-376,384
         return Y.sum(dim=0).view(-1, 1)                                               # [C, 1]  models.py:383-384

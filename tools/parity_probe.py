@@ -1,0 +1,44 @@
+"""Who is off in bench.py's cpu_baseline parity figure: the float32 host restatement or the GPU?  (float64 host truth)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gnan_amd  # noqa
+from gnan_amd import synthetic as syn
+from gnan_amd.functional import feature_mlps, rho_aggregate
+from gnan_amd.models import TensorGNAN
+from gnan_amd.graph import hop_inputs
+from gnan_amd.functional import stack_mlps
+from oracle import gnan_oracle as O
+dev = "cuda"
+N, E, F = 10_000_000, 100_000_000, 64
+src, dst = syn.rmat_edges(24, N, E, seed=0, device=dev)
+g = syn.hop1_csr(src, dst, N)
+x = syn.block_features(N, F, 0, N, seed=1, device=dev)
+torch.manual_seed(0)
+model = TensorGNAN(F, 1, 3, hidden_channels=64, device="cuda")
+with torch.no_grad():
+    for p in model.parameters():
+        if p.dim() == 2:
+            torch.nn.init.xavier_normal_(p, gain=1.0)
+        else:
+            p.normal_(0.0, 0.5)
+model = model.to(dev).eval()
+with torch.no_grad():
+    st = stack_mlps(model.fs)
+    lut = model.rho(hop_inputs(g.n_codes, dev).view(-1, 1))
+    S, total = feature_mlps(x, st, False, return_total=True)
+    out = rho_aggregate(g, S, lut, True, s_total=total, reduce_channels=1)
+n_r = 200_000
+rowptr = g.rowptr[: n_r + 1].cpu().long().numpy()
+nnz = int(rowptr[-1])
+col, code = g.col[:nnz].cpu().numpy(), g.code[:nnz].cpu().numpy()
+cnt = g.cnt[:n_r].cpu().long().numpy()
+Sc = S.cpu()
+sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+l32 = O.rho_lut(sd, g.n_codes)
+y32 = O.spmm_csr_sparse(rowptr, col, code, Sc, l32, cnt).sum(1)
+y64 = O.spmm_csr_sparse(rowptr, col, code, Sc.double(), l32.double(), cnt).sum(1)
+got = out[:n_r, 0].cpu().double()
+den = float(y64.abs().max())
+print("gpu vs f64", float((got - y64).abs().max()) / den, "cpu32 vs f64", float((y32.double() - y64).abs().max()) / den,
+      "lut gpu vs cpu", float((lut.cpu() - l32).abs().max()), "total gpu vs f64", float((total.cpu().double() - Sc.double().sum(0)).abs().max() / Sc.double().sum(0).abs().max()))
