@@ -78,14 +78,15 @@ def _hip_compute() -> Dict[str, Callable]:
 def _reduce_scatter_sum(full: torch.Tensor, n_local: int, group) -> torch.Tensor:
     """Sum ``full [world * n_local, W]`` over the ranks and keep this rank's block.  RCCL: one reduce-scatter; backends
     without one (gloo, the CPU tests): all-reduce and slice."""
-    out = full.new_empty((n_local, full.shape[1]))
-    try:
-        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
-    except (RuntimeError, NotImplementedError):
+    # chosen from the backend, on every rank alike — never by catching an error around a collective: a failure on one
+    # rank only would leave the others inside a different collective
+    if dist.get_backend(group) == "gloo":
         full = full.clone()
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         r = dist.get_rank(group)
-        out = full[r * n_local:(r + 1) * n_local].clone()
+        return full[r * n_local:(r + 1) * n_local].clone()
+    out = full.new_empty((n_local, full.shape[1]))
+    dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
     return out
 
 
