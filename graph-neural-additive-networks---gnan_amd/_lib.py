@@ -83,6 +83,14 @@ class FpwlGradArgs(C.Structure):
     ]
 
 
+class RhoLutArgs(C.Structure):
+    _fields_ = [
+        ("cnt", C.c_void_p), ("cnt_stride", C.c_int64), ("n_rows", C.c_int64), ("D", C.c_int32), ("C", C.c_int32),
+        ("u", C.c_void_p), ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p), ("n_pieces", C.c_void_p),
+        ("max_pieces", C.c_int32), ("lut", C.c_void_p), ("arg", C.c_void_p),
+    ]
+
+
 class SpmmArgs(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_cols", C.c_int64),
@@ -112,6 +120,7 @@ SYMBOLS = {
     "gnan_fmlp_bwd": (C.c_int, [C.POINTER(FmlpBwdArgs), C.c_void_p]),
     "gnan_pwl_build_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_pwl_build": (C.c_int, [C.POINTER(PwlBuildArgs), C.c_void_p]),
+    "gnan_rho_row_lut": (C.c_int, [C.POINTER(RhoLutArgs), C.c_void_p]),
     "gnan_fpwl_total_workspace_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),
     "gnan_fpwl_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p]),
     "gnan_fpwl_moments": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -572,6 +572,95 @@ class _FeatureMLPs(torch.autograd.Function):
         return (gx, None, None, None, None, None, None, None, None, *pg)
 
 
+# =============================================================================
+# pre-rho normalisation: per-row weight table from the shell counts
+# =============================================================================
+PRE_RHO_TABLE_MIN = 1 << 16  # (row, hop code) pairs from which rho is tabulated and looked up by gnan_rho_row_lut; below,
+                             # the lane / matrix-core shape-function kernels evaluate it (table build + read-back cost more)
+
+
+def _rho_row_lut_launch(cnt: torch.Tensor, u: torch.Tensor, tables, C: int, want_arg: bool):
+    """``(lut [n, D, C], arg [n, D] or None)`` by ``gnan_rho_row_lut``."""
+    n, D = cnt.shape
+    cnt = cnt if cnt.stride(1) == 1 else cnt.contiguous()
+    lut = torch.empty((n, D, C), dtype=torch.float32, device=cnt.device)
+    arg = torch.empty((n, D), dtype=torch.float32, device=cnt.device) if want_arg else None
+    a = _lib.RhoLutArgs(cnt=_lib.ptr(cnt), cnt_stride=cnt.stride(0), n_rows=n, D=D, C=C, u=_lib.ptr(u),
+                        anchor=_lib.ptr(tables.anchor), val=_lib.ptr(tables.val), slope=_lib.ptr(tables.slope),
+                        n_pieces=_lib.ptr(tables.off[1:]), max_pieces=int(tables.max_pieces), lut=_lib.ptr(lut),
+                        arg=_lib.ptr(arg))
+    _lib.check(_lib.lib().gnan_rho_row_lut(a, _lib.stream_of(lut)), "gnan_rho_row_lut")
+    return lut, arg
+
+
+def _rho_param_grads(arg: torch.Tensor, dlut: torch.Tensor, tables, params, present, L: int, H: int, C: int):
+    """Gradients of rho's stacked parameters from the gradient of its per-row table: binned by the pieces of the table's
+    arguments (one feature), then exact (``gnan_fpwl_param_grads`` / two probe points per piece in float64)."""
+    x = arg.reshape(-1, 1)
+    g = dlut.reshape(-1, C)
+    x_abs_max = x.abs().max().double() if x.numel() else None
+    if _table_grads_applies(L, H, C):
+        M = _fpwl_moments(x, tables, g, False, x_abs_max, raw=True)
+        return tuple(_fpwl_param_grads_launch(params, tables, M, L, H, C, 1))
+    from .pwl import parameter_grads_from_moments
+    M = _fpwl_moments(x, tables, g, False, x_abs_max)
+    leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
+    got = parameter_grads_from_moments(
+        StackedMLP(*leaves, L, H, C, 1), tables, M,
+        lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double() for t in q[:6]], *q[6:]), False))
+    it = iter(got)
+    pg = [None if not pr else next(it) for pr in present]
+    return tuple(None if t is None else t.to(torch.float32) for t in pg)
+
+
+class _RhoRowLut(torch.autograd.Function):
+    """``lut[i, d, :] = rho(u[d] / max(cnt[i, d], 1))`` from rho's piecewise-linear table (``gnan_rho_row_lut``); backward:
+    the gradient of the table binned by the pieces of its arguments (``gnan_fpwl_moments*``, one feature), then the exact
+    parameter gradients (``gnan_fpwl_param_grads`` / ``pwl.parameter_grads_from_moments``) — GNAN.py:65-67 under autograd."""
+
+    @staticmethod
+    def forward(ctx, cnt, u, tables, L, H, C, *params):
+        lut, arg = _rho_row_lut_launch(cnt, u, tables, C, any(ctx.needs_input_grad[6:]))
+        ctx.tables, ctx.meta = tables, (L, H, C)
+        ctx.present = [t is not None for t in params]
+        ctx.save_for_backward(arg, *[t for t in params if t is not None])
+        return lut
+
+    @staticmethod
+    def backward(ctx, dlut):
+        L, H, C = ctx.meta
+        saved = list(ctx.saved_tensors)
+        arg = saved.pop(0)
+        params = [saved.pop(0) if present else None for present in ctx.present]
+        return (None,) * 6 + _rho_param_grads(arg, dlut, ctx.tables, params, ctx.present, L, H, C)
+
+
+def _rho_tables(p: StackedMLP, n_lookups: int):
+    """rho's piecewise-linear table when the table route applies to ``n_lookups`` (row, hop code) pairs, else None."""
+    if (FMLP_ALGO == _lib.FMLP_PWL or (FMLP_ALGO == _lib.FMLP_AUTO and n_lookups >= PRE_RHO_TABLE_MIN)) \
+            and not torch.cuda.is_current_stream_capturing():
+        from .pwl import build_tables
+        return build_tables(StackedMLP(*[_c(t) for t in p[:6]], *p[6:]))
+    return None
+
+
+def rho_row_lut(cnt: torch.Tensor, u: torch.Tensor, p: StackedMLP) -> torch.Tensor:
+    """Per-row weight table of the pre-rho normalisation (GNAN.py:65-67): ``lut[i, d, :] = rho(u[d] / max(cnt[i, d], 1))``,
+    ``[n, D, C]``.  ``p``: rho's Linear layers stacked as a ONE-feature StackedMLP; ``u``: the values ``node_distances`` takes
+    (``graph.hop_inputs``); ``cnt``: shell counts ``[n, D]`` int32.  Differentiable w.r.t. rho's parameters.  Large tables go
+    through rho's exact piecewise-linear tabulation (D look-ups per row, nothing of size N x H is ever formed); small ones
+    through the lane / matrix-core kernels of :func:`feature_mlps`."""
+    _lib.require_device(cnt, u, p.w_last)
+    if p.F != 1:
+        raise ValueError("rho is one scalar function: a one-feature StackedMLP is expected")
+    n, D = cnt.shape
+    tables = _rho_tables(p, n * D)
+    if tables is not None:
+        return _RhoRowLut.apply(cnt, u.contiguous(), tables, p.L, p.H, p.C, *p[:6])
+    arg = (u.unsqueeze(0) / cnt.clamp_min(1).float()).view(-1, 1)              # torch.div, GNAN.py:66
+    return feature_mlps(arg, p, False).view(n, D, p.C)
+
+
 PAD_FEATURES = 16            # the fast look-up / moment kernels and the 16-byte operand gathers want whole 16-feature groups
 PAD_MIN_WORK = 1 << 26       # n * F from which a ragged feature count is padded: the arxiv-shaped graph (n * F = 2^24.4) is
                              # bound by the host, the six concatenations (and their backward) cost it 0.1 / 1.5 ms
@@ -715,25 +804,35 @@ def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1) -> torch
     return ext
 
 
-def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
+def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_cnt: bool, with_rest: bool,
                 row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
                 minus_rest: bool = False, s_total: Optional[torch.Tensor] = None, reduce_cr: int = 0,
-                s_by_code: bool = False) -> torch.Tensor:
+                s_by_code: bool = False, lut_of_counts=None, lut_channels: int = 1) -> torch.Tensor:
     """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``.
     ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns.
-    ``s_by_code``: ``S`` is ``[n_cols * D, W]`` and the pair with neighbour ``c`` and hop code ``d`` reads row ``c*D + d``."""
+    ``s_by_code``: ``S`` is ``[n_cols * D, W]`` and the pair with neighbour ``c`` and hop code ``d`` reads row ``c*D + d``.
+    ``lut_of_counts`` (with ``lut=None``): a function ``cnt [n, D] -> [n, D, lut_channels]`` giving the per-row table of a
+    graph from its shell counts (the pre-rho normalisation, :func:`pre_rho_aggregate`); it is called on the counts of the
+    graph that is actually walked, so a degree-sorted copy gets its table in its own row order and nothing is permuted."""
     _lib.require_device(S, lut, g.code)
     S = S.detach()
     if S.dtype != torch.bfloat16:                        # bf16 rows: storage format only, accumulation stays fp32
         S = S.float()
     S = _rows(S)
-    lut = lut.detach().float().contiguous()
-    per_row = lut.dim() == 3
-    if lut.shape[-2] != g.n_codes:
-        raise ValueError(f"weight table has {lut.shape[-2]} codes, graph has {g.n_codes}")
+    from_counts = lut is None
+    if from_counts:
+        if lut_of_counts is None:
+            raise ValueError("spmm_launch needs a weight table or a function of the shell counts")
+        lut_shape, per_row = (g.n_codes, lut_channels), False       # (per_row: a table the walk's order does not constrain)
+    else:
+        lut = lut.detach().float().contiguous()
+        per_row = lut.dim() == 3
+        lut_shape = (lut.shape[-2], lut.shape[-1])
+    if lut_shape[0] != g.n_codes:
+        raise ValueError(f"weight table has {lut_shape[0]} codes, graph has {g.n_codes}")
     if S.shape[0] != g.n_cols * (g.n_codes if s_by_code else 1):
         raise ValueError(f"operand has {S.shape[0]} rows, graph has {g.n_cols} neighbour nodes")
-    if S.shape[1] % lut.shape[-1] != 0:
+    if S.shape[1] % lut_shape[1] != 0:
         raise ValueError("operand width must be a multiple of the weight-channel count")
     n_out = g.n_rows if row_ids is None else int(row_ids.numel())
     out = torch.empty((n_out, reduce_cr if reduce_cr else S.shape[1]), dtype=torch.float32, device=S.device)
@@ -768,6 +867,9 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, 
             scatter = True
     else:
         plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING and row_ids is None) else g.long_row_plan(row_ids)
+    if from_counts:
+        lut = lut_of_counts(g.cnt).detach().float().contiguous()          # rows of THIS graph (a sorted copy carries its own counts)
+        per_row = True
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
                    reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code, packed=True)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
@@ -919,107 +1021,167 @@ class _RhoAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         S, lut = ctx.saved_tensors
-        g, use_cnt, with_rest, row_ids = ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids
-        dY = dY.contiguous().float()
-        dY_out = dY                           # as the forward returned it: [n_out, W] or, with the fused sum, [n_out, cr]
-        W = S.shape[1]
-        D, Cw = lut.shape[-2], lut.shape[-1]
-        per_row = lut.dim() == 3
-        # truncated-hop graphs: the table gradient comes out of one pass over the listed pairs (gnan_spmm_lut_grad)
-        fused_lut_grad = (ctx.needs_input_grad[1] and not g.is_dense and D <= 4 and Cw == 1
-                          and S.dtype == torch.float32)
-        if ctx.reduce_cr and (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not fused_lut_grad)):
-            dY = dY.repeat(1, W // ctx.reduce_cr)   # the fused feature sum broadcasts its gradient over the features
-        rows = None if row_ids is None else row_ids.long()
-        cnt = g.cnt if rows is None else g.cnt[rows]
-        inv = (1.0 / cnt.clamp_min(1).float()) if use_cnt else None            # [n_out, D]
-        dS = dlut = None
-        fused_bwd = (NARROW_FUSED_BACKWARD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not g.is_dense
-                     and Cw == 1 and D <= 4 and not per_row and rows is None and not ctx.reduce_cr and W <= 16
-                     and S.dtype == torch.float32)
-        if fused_bwd:
-            # narrow operand, both gradients wanted: ONE pass over the transposed adjacency gathers, per pair, the packed row
-            # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
-            # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
-            half = 1 << max(0, (W - 1).bit_length())
-            walk = narrow_walk(g.transposed())
-            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
-            dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk)
-            if with_rest:
-                total = ctx.s_total if ctx.s_total is not None else column_sums(S)
-                q_sum = column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
-                dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
-            dlut = dl.view(D, 1)
-
-        if ctx.needs_input_grad[0] and not fused_bwd:
-            dY_full = dY
-            if rows is not None:
-                dY_full = torch.zeros((g.n_rows, W), dtype=torch.float32, device=dY.device)
-                dY_full.index_add_(0, rows, dY)
-            if not g.is_dense and Cw == 1 and W * D <= NARROW_DS_MAX_WIDTH:
-                # narrow operand: fold the per-pair weight into a pre-weighted operand with one row per (node, hop code),
-                # Z[i, d] = (wt(i, d) - wt(i, rest)) dY[i], and gather it over the transposed adjacency with unit weights —
-                # one random request per listed pair instead of the operand row plus the neighbour's table row
-                wt = (lut[..., 0] if per_row else lut[:, 0].unsqueeze(0)).float()                 # [N or 1, D]
-                if use_cnt:
-                    wt = wt / g.cnt.clamp_min(1).float()
-                if with_rest:
-                    wt = wt - wt[:, D - 1:D]
-                Z = (wt.unsqueeze(-1) * dY_full.unsqueeze(1)).reshape(g.n_rows * D, W)
-                dS = spmm_launch(g.transposed(), Z, torch.ones((D, 1), device=Z.device), False, False, None,
-                                 s_by_code=True)
-            elif g.n_rows * D * Cw * 4 <= WEIGHT_TABLE_MAX_BYTES:
-                # wide operand: the weight of a pair belongs to the NEIGHBOUR's row there.  Read from (lut, cnt) that is two
-                # random count reads, two divisions and a subtraction per pair; a per-node table wt(i, d) - wt(i, rest)
-                # built once per backward pass makes it one 4-byte read (arxiv-shaped W = 40: 0.55 -> 0.28 ms)
-                wt = (lut if per_row else lut.unsqueeze(0)).float()                               # [N or 1, D, Cw]
-                if use_cnt:
-                    wt = wt / g.cnt.clamp_min(1).float().unsqueeze(-1)
-                if with_rest:
-                    wt = wt - wt[:, D - 1:D]
-                dS = spmm_launch(g.transposed(), dY_full, wt.expand(g.n_rows, D, Cw).contiguous(), False, False, None,
-                                 weight_by_col=True)
-            else:
-                dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
-                                 weight_by_col=True, minus_rest=with_rest)
-        if ctx.needs_input_grad[0]:
-            if with_rest:
-                # d/dS_j of  wt(i, rest) * total  : the same vector for every j
-                l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
-                w_rest = l_rest * inv[:, D - 1:D] if inv is not None else l_rest   # [n_out or 1, Cw]
-                w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
-                v = (w_rest * dY).sum(0, keepdim=True)
-                if ctx.total_group is not NOT_SHARED:
-                    # the total was summed over the ranks of a group: every rank's output rows pull on every rank's
-                    # summed operand rows, so the ranks add their vectors (W floats) before handing them down
-                    import torch.distributed as dist
-                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ctx.total_group)
-                if ctx.total_rows is None:
-                    dS = dS + v
-                else:                          # only the first rows of S went into the total (owned rows ahead of halo rows)
-                    dS[: ctx.total_rows] += v
-
-        if fused_bwd:
-            pass                                  # both gradients came out of the one transposed pass above
-        elif ctx.needs_input_grad[1] and fused_lut_grad and not per_row:
-            dlut = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, True)       # [D, 1]
-        elif ctx.needs_input_grad[1]:
-            if fused_lut_grad:
-                dwt = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, False)   # [n_out, D, 1]
-            else:
-                T = shell_sums_launch(g, S, lut, with_rest, row_ids, ctx.s_total)  # [n_out, D, W]
-                dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
-                if inv is not None:
-                    dwt = dwt * inv.unsqueeze(-1)                                 # [n_out, D, Cw]
-            if per_row:
-                if rows is None:
-                    dlut = dwt
-                else:
-                    dlut = torch.zeros_like(lut)
-                    dlut.index_add_(0, rows, dwt)
-            else:
-                dlut = dwt.sum(0)
+        dS, dlut = _aggregate_backward(ctx, S, lut, dY, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dS, dlut, None, None, None, None, None, None, None, None
+
+
+def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
+    """Gradients of ``Y = A_w(lut, cnt) @ S`` (+ rest bucket) w.r.t. the operand and the weight table; ``ctx`` carries
+    ``g, use_cnt, with_rest, row_ids, reduce_cr, s_total, total_rows, total_group`` as :class:`_RhoAggregate` stores them."""
+    g, use_cnt, with_rest, row_ids = ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids
+    dY = dY.contiguous().float()
+    dY_out = dY                           # as the forward returned it: [n_out, W] or, with the fused sum, [n_out, cr]
+    W = S.shape[1]
+    D, Cw = lut.shape[-2], lut.shape[-1]
+    per_row = lut.dim() == 3
+    # truncated-hop graphs: the table gradient comes out of one pass over the listed pairs (gnan_spmm_lut_grad)
+    fused_lut_grad = (need_dlut and not g.is_dense and D <= 4 and Cw == 1
+                      and S.dtype == torch.float32)
+    if ctx.reduce_cr and (need_dS or (need_dlut and not fused_lut_grad)):
+        dY = dY.repeat(1, W // ctx.reduce_cr)   # the fused feature sum broadcasts its gradient over the features
+    rows = None if row_ids is None else row_ids.long()
+    cnt = g.cnt if rows is None else g.cnt[rows]
+    inv = (1.0 / cnt.clamp_min(1).float()) if use_cnt else None            # [n_out, D]
+    dS = dlut = None
+    fused_bwd = (NARROW_FUSED_BACKWARD and need_dS and need_dlut and not g.is_dense
+                 and Cw == 1 and D <= 4 and not per_row and rows is None and not ctx.reduce_cr and W <= 16
+                 and S.dtype == torch.float32)
+    if fused_bwd:
+        # narrow operand, both gradients wanted: ONE pass over the transposed adjacency gathers, per pair, the packed row
+        # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
+        # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
+        half = 1 << max(0, (W - 1).bit_length())
+        walk = narrow_walk(g.transposed())
+        V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
+        dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk)
+        if with_rest:
+            total = ctx.s_total if ctx.s_total is not None else column_sums(S)
+            q_sum = column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
+            dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
+        dlut = dl.view(D, 1)
+
+    if need_dS and not fused_bwd:
+        dY_full = dY
+        if rows is not None:
+            dY_full = torch.zeros((g.n_rows, W), dtype=torch.float32, device=dY.device)
+            dY_full.index_add_(0, rows, dY)
+        if not g.is_dense and Cw == 1 and W * D <= NARROW_DS_MAX_WIDTH:
+            # narrow operand: fold the per-pair weight into a pre-weighted operand with one row per (node, hop code),
+            # Z[i, d] = (wt(i, d) - wt(i, rest)) dY[i], and gather it over the transposed adjacency with unit weights —
+            # one random request per listed pair instead of the operand row plus the neighbour's table row
+            wt = (lut[..., 0] if per_row else lut[:, 0].unsqueeze(0)).float()                 # [N or 1, D]
+            if use_cnt:
+                wt = wt / g.cnt.clamp_min(1).float()
+            if with_rest:
+                wt = wt - wt[:, D - 1:D]
+            Z = (wt.unsqueeze(-1) * dY_full.unsqueeze(1)).reshape(g.n_rows * D, W)
+            dS = spmm_launch(g.transposed(), Z, torch.ones((D, 1), device=Z.device), False, False, None,
+                             s_by_code=True)
+        elif g.n_rows * D * Cw * 4 <= WEIGHT_TABLE_MAX_BYTES:
+            # wide operand: the weight of a pair belongs to the NEIGHBOUR's row there.  Read from (lut, cnt) that is two
+            # random count reads, two divisions and a subtraction per pair; a per-node table wt(i, d) - wt(i, rest)
+            # built once per backward pass makes it one 4-byte read (arxiv-shaped W = 40: 0.55 -> 0.28 ms)
+            wt = (lut if per_row else lut.unsqueeze(0)).float()                               # [N or 1, D, Cw]
+            if use_cnt:
+                wt = wt / g.cnt.clamp_min(1).float().unsqueeze(-1)
+            if with_rest:
+                wt = wt - wt[:, D - 1:D]
+            dS = spmm_launch(g.transposed(), dY_full, wt.expand(g.n_rows, D, Cw).contiguous(), False, False, None,
+                             weight_by_col=True)
+        else:
+            dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
+                             weight_by_col=True, minus_rest=with_rest)
+    if need_dS:
+        if with_rest:
+            # d/dS_j of  wt(i, rest) * total  : the same vector for every j
+            l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
+            w_rest = l_rest * inv[:, D - 1:D] if inv is not None else l_rest   # [n_out or 1, Cw]
+            w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
+            v = (w_rest * dY).sum(0, keepdim=True)
+            if ctx.total_group is not NOT_SHARED:
+                # the total was summed over the ranks of a group: every rank's output rows pull on every rank's
+                # summed operand rows, so the ranks add their vectors (W floats) before handing them down
+                import torch.distributed as dist
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ctx.total_group)
+            if ctx.total_rows is None:
+                dS = dS + v
+            else:                          # only the first rows of S went into the total (owned rows ahead of halo rows)
+                dS[: ctx.total_rows] += v
+
+    if fused_bwd:
+        pass                                  # both gradients came out of the one transposed pass above
+    elif need_dlut and fused_lut_grad and not per_row:
+        dlut = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, True)       # [D, 1]
+    elif need_dlut:
+        if fused_lut_grad:
+            dwt = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, False)   # [n_out, D, 1]
+        else:
+            T = shell_sums_launch(g, S, lut, with_rest, row_ids, ctx.s_total)  # [n_out, D, W]
+            dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
+            if inv is not None:
+                dwt = dwt * inv.unsqueeze(-1)                                 # [n_out, D, Cw]
+        if per_row:
+            if rows is None:
+                dlut = dwt
+            else:
+                dlut = torch.zeros_like(lut)
+                dlut.index_add_(0, rows, dwt)
+        else:
+            dlut = dwt.sum(0)
+    return dS, dlut
+
+
+class _Bag:
+    pass
+
+
+class _PreRhoAggregate(torch.autograd.Function):
+    """``Y[i] = sum_j rho(u_ij / c_ij) (.) S[j]`` — GNAN.py:64-70 with the pre-rho normalisation of GNAN.py:65-67 — from
+    rho's table: the per-row weights are looked up (``gnan_rho_row_lut``) for the rows in the order the aggregation walks
+    them, nothing is permuted and no table of the natural order exists in the forward pass.  Backward: the natural-order
+    table and its arguments (one more launch), the aggregation's own gradients, then rho's parameter gradients from the
+    gradient of the table binned by the pieces of its arguments."""
+
+    @staticmethod
+    def forward(ctx, S, g, with_rest, row_ids, s_total, total_rows, total_group, tables, u, L, H, C, *params):
+        ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids, ctx.reduce_cr = g, False, with_rest, row_ids, 0
+        ctx.s_total = None if s_total is None else s_total.detach()
+        ctx.total_rows, ctx.total_group = total_rows, total_group
+        ctx.tables, ctx.u, ctx.meta = tables, u, (L, H, C)
+        ctx.present = [t is not None for t in params]
+        ctx.save_for_backward(S, *[t for t in params if t is not None])
+        return spmm_launch(g, S, None, False, with_rest, row_ids, s_total=s_total,
+                           lut_of_counts=lambda cnt: _rho_row_lut_launch(cnt, u, tables, C, False)[0], lut_channels=C)
+
+    @staticmethod
+    def backward(ctx, dY):
+        L, H, C = ctx.meta
+        saved = list(ctx.saved_tensors)
+        S = saved.pop(0)
+        params = [saved.pop(0) if present else None for present in ctx.present]
+        need_rho = any(ctx.needs_input_grad[12:])
+        lut, arg = _rho_row_lut_launch(ctx.g.cnt, ctx.u, ctx.tables, C, need_rho)
+        dS, dlut = _aggregate_backward(ctx, S, lut, dY, ctx.needs_input_grad[0], need_rho)
+        pg = _rho_param_grads(arg, dlut, ctx.tables, params, ctx.present, L, H, C) if need_rho else (None,) * 6
+        return (dS,) + (None,) * 11 + tuple(pg)
+
+
+def pre_rho_aggregate(g: HopGraph, S: torch.Tensor, p: StackedMLP, u: torch.Tensor, with_rest: Optional[bool] = None,
+                      row_ids: Optional[torch.Tensor] = None, s_total: Optional[torch.Tensor] = None,
+                      total_rows: Optional[int] = None, total_group=NOT_SHARED) -> torch.Tensor:
+    """The aggregation with the pre-rho normalisation of the stand-alone model file (GNAN.py:65-70):
+    ``Y[q] = sum_j rho(u(i_q, j) / c(i_q, j)) (.) S[j]``; ``p`` = rho's layers as a one-feature :class:`StackedMLP`,
+    ``u`` = the distinct values of ``node_distances`` (``graph.hop_inputs``).  Differentiable w.r.t. ``S`` and rho."""
+    if with_rest is None:
+        with_rest = not g.is_dense
+    if row_ids is not None:
+        row_ids = row_ids.to(device=g.device, dtype=torch.int32).contiguous()
+    tables = _rho_tables(p, g.n_rows * g.n_codes) if S.dtype == torch.float32 else None
+    if tables is None:                      # small graphs / graph capture: the table through the shape-function kernels
+        return rho_aggregate(g, S, rho_row_lut(g.cnt, u, p), False, with_rest, row_ids, s_total,
+                             total_rows=total_rows, total_group=total_group)
+    return _PreRhoAggregate.apply(S, g, with_rest, row_ids, s_total, total_rows, total_group, tables, u.contiguous(),
+                                  p.L, p.H, p.C, *p[:6])
 
 
 def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor, reduce_channels: int = 0,

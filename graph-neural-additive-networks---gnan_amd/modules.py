@@ -262,9 +262,11 @@ class _PathBase(nn.Module):
         return self.rho(hop_inputs(g.n_codes, g.device).view(-1, 1))
 
     def _lut_pre_rho(self, g: HopGraph) -> torch.Tensor:
-        """``lut[i, d] = rho(u_d / cnt[i, d])`` — the pre-rho normalisation of GNAN.py:65-67, per shell."""
-        arg = hop_inputs(g.n_codes, g.device).unsqueeze(0) / g.cnt.clamp_min(1).float()
-        return self.rho(arg.view(-1, 1)).view(g.n_rows, g.n_codes, -1)
+        """``lut[i, d] = rho(u_d / cnt[i, d])`` — the pre-rho normalisation of GNAN.py:65-67, per shell: rho's exact
+        piecewise-linear table looked up D times per row (``gnan_rho_row_lut``), or, for small graphs, the shape-function
+        kernels on the N*D arguments.  No torch MLP pass, nothing of size N x H."""
+        from .functional import rho_row_lut
+        return rho_row_lut(g.cnt, hop_inputs(g.n_codes, g.device), self._stacked("rho", [self.rho]))
 
 
 # =============================================================================
@@ -301,11 +303,17 @@ class StandaloneTensorGNAN(_PathBase):
         _lib.require_device(x)
         self._mark("start")
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
-        lut = self._lut_pre_rho(g) if self.normalize_rho else self._lut_global(g)
+        lut = None if self.normalize_rho else self._lut_global(g)
         self._mark("lut")
         S, total = self._operand(x, "fs", self.fs, True, not g.is_dense)             # [N, C]
         self._mark("fmlp")
-        Y = rho_aggregate(g, S, lut, use_cnt=False, s_total=total)                    # [N, C]
+        if self.normalize_rho:
+            # GNAN.py:65-67: rho(node_distances / normalization_matrix) — rho's exact table, D look-ups per row, in the
+            # order the aggregation walks the rows (functional.pre_rho_aggregate)
+            from .functional import pre_rho_aggregate
+            Y = pre_rho_aggregate(g, S, self._stacked("rho", [self.rho]), hop_inputs(g.n_codes, g.device), s_total=total)
+        else:
+            Y = rho_aggregate(g, S, lut, use_cnt=False, s_total=total)                # [N, C]
         self._mark("spmm")
         if not self.is_graph_task:
             return Y                                                                  # GNAN.py:72-73,79

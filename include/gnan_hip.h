@@ -274,6 +274,33 @@ size_t gnan_pwl_build_scratch_bytes(int32_t F, int32_t C, int32_t cap);
 int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-row weight table of the pre-rho normalisation:  lut[i, d, :] = rho(u[d] / max(cnt[i, d], 1))
+ * replaces GNAN.py:65-67 — torch.div(node_distances, normalization_matrix) followed by the rho MLP on all N^2 pairs —
+ * by D table look-ups per row: rho : R -> R^C is a ReLU MLP of a scalar, tabulated by gnan_pwl_build as a ONE-feature
+ * table (F = 1: off = {0, T}); u[d] = float32(1 / (1 + d)), u[D-1] = 0 are the values node_distances takes
+ * (pre_process_datasets.py:112-114), cnt the shell sizes (pre_process_datasets.py:136-140).  Same look-up arithmetic as
+ * gnan_fpwl_fwd.  `arg` (optional) receives the arguments u[d] / cnt[i, d]: the backward pass bins the gradient of the
+ * table by their pieces (gnan_fpwl_moments* with x = arg, F = 1, then gnan_fpwl_param_grads).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gnan_rho_lut_args {
+  const int32_t* cnt;        /* [n_rows, cnt_stride] shell counts */
+  int64_t cnt_stride;
+  int64_t n_rows;
+  int32_t D;                 /* hop codes incl. the rest bucket */
+  int32_t C;                 /* output channels of rho */
+  const float* u;            /* [D] */
+  const float* anchor;       /* [T] tables of rho as gnan_pwl_build wrote them */
+  const float* val;          /* [T, C] */
+  const float* slope;        /* [T, C] */
+  const int32_t* n_pieces;   /* optional device pointer to T (= off[1]) when the tables sit in a buffer of full capacity */
+  int32_t max_pieces;        /* host-side bound on T (LDS bytes = 4 * max_pieces) */
+  float* lut;                /* [n_rows, D, C] */
+  float* arg;                /* optional [n_rows, D] */
+} gnan_rho_lut_args;
+
+int gnan_rho_row_lut(const gnan_rho_lut_args* a, gnan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * rho(distance)-weighted neighbourhood sum over a hop-coded adjacency
  *
  *   Y[i, w] = sum_{e in row i} wt(i, code_e, w) * S[col_e, w]

@@ -42,7 +42,8 @@ def test_struct_layout_matches_header():
     text = open(os.path.join(ROOT, "include", "gnan_hip.h")).read()
     for struct, cls in (("gnan_fmlp_args", _lib.FmlpArgs), ("gnan_spmm_args", _lib.SpmmArgs),
                         ("gnan_fpwl_args", _lib.FpwlArgs), ("gnan_pwl_build_args", _lib.PwlBuildArgs),
-                        ("gnan_fpwl_grad_args", _lib.FpwlGradArgs), ("gnan_fmlp_bwd_args", _lib.FmlpBwdArgs)):
+                        ("gnan_fpwl_grad_args", _lib.FpwlGradArgs), ("gnan_fmlp_bwd_args", _lib.FmlpBwdArgs),
+                        ("gnan_rho_lut_args", _lib.RhoLutArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

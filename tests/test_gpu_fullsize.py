@@ -131,3 +131,60 @@ def test_full_size_training_step_gradients(c4, monkeypatch):
         dn = loss_of(type(st)(*[t - eps * d for t, d in zip(st[:6], direction)], *st[6:]), lut - eps * direction[6])
     numeric = (float(up) - float(dn)) / (2 * eps)
     assert abs(numeric - analytic) <= 2e-2 * max(abs(analytic), 1e-6), (numeric, analytic)
+
+
+def test_full_size_pre_rho_normalisation(c4):
+    """The stand-alone TensorGNAN (GNAN.py:55-79: rho(node_distances / normalization_matrix)) at the full size: the per-row
+    weight table comes from gnan_rho_row_lut (rho's exact table, 3 look-ups per row); sampled rows against a float64
+    restatement; and the forward costs what the post-rho forward costs (the table replaces the count table one for one)."""
+    import time
+    from gnan_amd import GNAN as standalone
+    from gnan_amd import models
+    g, x, st, sd, lut = c4
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(1)
+    mods = {}
+    for name, cls in (("pre", standalone.TensorGNAN), ("post", models.TensorGNAN)):
+        m = cls(F, 1, 3, hidden_channels=64, device=DEV)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
+        mods[name] = m.to(DEV).eval()
+
+    class Bag:
+        pass
+    data = Bag()
+    data.x, data.edge_index, data.gnan_graph = x, None, g
+    times = {}
+    with torch.no_grad():
+        for name, m in mods.items():
+            for _ in range(3):
+                out = m.forward(data)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                out = m.forward(data)
+            torch.cuda.synchronize()
+            times[name] = (time.perf_counter() - t0) / 10
+            if name == "pre":
+                y = out
+    assert times["pre"] <= 1.05 * times["post"] + 2e-4, times          # within 5 % (+ 0.2 ms of timer noise on a shared box)
+    m = mods["pre"]
+    p64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(0)
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
+    rows = np.unique(np.concatenate([rng.integers(0, N, 120), torch.topk(deg, 2).indices.cpu().numpy()]))
+    with torch.no_grad():
+        S, total = m._operand(x, "fs", m.fs, True, True)                 # [N, 1] and its column sum, as the forward forms them
+    tot64 = total.double().cpu()
+    cnt = g.cnt.cpu().numpy()
+    worst = 0.0
+    for i in rows:
+        lo, hi = int(g.rowptr[i]), int(g.rowptr[i + 1])
+        cols = g.col[lo:hi].long()
+        codes = g.code[lo:hi].long().cpu()
+        fx = O.feature_mlps(x[cols].double().cpu(), p64).sum(1)                                  # [deg, 1]
+        w = O.row_lut_pre_rho(p64, cnt[i:i + 1], torch.float64)[0]                               # [3, 1]
+        acc = (w[codes] * fx).sum(0) + w[-1] * (tot64 - fx.sum(0))
+        worst = max(worst, float((acc - y[i].double().cpu()).abs().max()))
+    assert worst <= 1e-5 * float(y.abs().max()), (worst, float(y.abs().max()))

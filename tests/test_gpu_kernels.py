@@ -1365,3 +1365,77 @@ def test_table_path_gradients_with_inputs_on_kinks(route, F, L, H, C, sum_featur
     scale = max(float(v.abs().max()) for v in want.values())
     for nm, gr in zip(names, got):
         assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, (nm, route, mode)
+
+
+def _rho_state(L, H, C, bias, seed, zero_bias=False):
+    g = torch.Generator().manual_seed(seed)
+    dims = [1] + [H] * (L - 1) + [C]
+    sd = {}
+    for li in range(L):
+        sd[f"rho.{2 * li}.weight"] = torch.randn(dims[li + 1], dims[li], generator=g) * (2.0 / (dims[li] + dims[li + 1])) ** 0.5
+        if bias:
+            sd[f"rho.{2 * li}.bias"] = torch.zeros(dims[li + 1]) if zero_bias else torch.randn(dims[li + 1], generator=g) * 0.5
+    return sd
+
+
+def _stack_rho(sd, L, H, C, bias):
+    from gnan_amd.functional import StackedMLP
+
+    def get(li, what):
+        return sd[f"rho.{2 * li}.{what}"].unsqueeze(0).to(DEV)                     # the feature axis: one function
+    if L == 1:
+        return StackedMLP(None, None, None, None, get(0, "weight")[..., 0], get(0, "bias") if bias else None, 1, 0, C, 1)
+    w_mid = b_mid = None
+    if L > 2:
+        w_mid = torch.stack([get(li, "weight") for li in range(1, L - 1)], 0)
+        b_mid = torch.stack([get(li, "bias") for li in range(1, L - 1)], 0) if bias else None
+    return StackedMLP(get(0, "weight")[..., 0], get(0, "bias") if bias else None, w_mid, b_mid,
+                      get(L - 1, "weight"), get(L - 1, "bias") if bias else None, L, H, C, 1)
+
+
+@pytest.mark.parametrize("route", ["table", "kernels"])
+@pytest.mark.parametrize("L,H,C,bias,D,zero_bias", [(3, 16, 1, True, 3, False), (3, 64, 3, True, 5, False), (2, 8, 2, False, 3, False),
+                                                     (1, 1, 2, True, 4, False), (3, 32, 1, True, 3, True), (4, 8, 2, True, 3, False)])
+def test_pre_rho_row_table_vs_oracle(L, H, C, bias, D, zero_bias, route, monkeypatch):
+    """GNAN.py:65-67 per shell: lut[i, d] = rho(u_d / cnt[i, d]) — gnan_rho_row_lut on rho's exact table (and the small-size
+    route through the shape-function kernels) against the float64 oracle, forward and parameter gradients.  The rest
+    bucket's argument is exactly 0: with zero biases (graph tasks build rho without bias, GNAN.py:36-37) it sits on every kink."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import rho_row_lut
+    from gnan_amd.graph import hop_inputs
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL if route == "table" else _lib.FMLP_AUTO)
+    monkeypatch.setattr(functional, "PRE_RHO_TABLE_MIN", 1 << 40)                 # AUTO: small-size route at this size
+    n = 5000
+    rng = np.random.default_rng(L * 10 + C)
+    cnt = rng.integers(0, 40, (n, D)).astype(np.int32)                              # zeros: empty shells (clamped to 1)
+    cnt[:, 0] = 1
+    cnt[:, D - 1] = rng.integers(1, 10 ** 7, n)
+    sd = _rho_state(L, max(H, 1), C, bias, seed=7 * L + C, zero_bias=zero_bias)
+    st = _stack_rho(sd, L, H if L > 1 else 0, C, bias)
+    leaves = [t for t in st[:6] if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    lut = rho_row_lut(torch.from_numpy(cnt).to(DEV), hop_inputs(D, DEV), st)
+    assert lut.shape == (n, D, C)
+    gup = torch.randn(n, D, C, generator=torch.Generator().manual_seed(3))
+    got = torch.autograd.grad(lut, leaves, gup.to(DEV))
+    p64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    want = O.row_lut_pre_rho(p64, cnt, torch.float64)
+    assert O.rel_err(lut.detach().cpu(), want.detach()) <= 1e-5
+    want.backward(gup.double())
+    names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
+    last = 2 * (L - 1)
+    ref = {"w_last": p64[f"rho.{last}.weight"].grad if L > 1 else p64["rho.0.weight"].grad[:, 0]}
+    if bias:
+        ref["b_last"] = p64[f"rho.{last}.bias"].grad
+    if L > 1:
+        ref["w_first"] = p64["rho.0.weight"].grad[:, 0]
+        if bias:
+            ref["b_first"] = p64["rho.0.bias"].grad
+    if L > 2:
+        ref["w_mid"] = torch.stack([p64[f"rho.{2 * li}.weight"].grad for li in range(1, L - 1)])
+        if bias:
+            ref["b_mid"] = torch.stack([p64[f"rho.{2 * li}.bias"].grad for li in range(1, L - 1)])
+    scale = max(float(v.abs().max()) for v in ref.values())
+    for nm, gr in zip(names, got):
+        assert float((gr.cpu().double().reshape(ref[nm].shape) - ref[nm]).abs().max()) <= 2e-5 * scale, (nm, route)
