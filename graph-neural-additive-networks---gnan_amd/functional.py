@@ -186,6 +186,14 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
 
 
 CAPTURED_BUILDS = []          # (sizes a look-up was captured with, the stacked weights it tabulates) of the capture in progress
+CAPTURE_PINS = None           # list while graphed.GraphedCallable captures: cache-owned tensors the captured step reads
+
+
+def _pin_for_capture(obj):
+    if CAPTURE_PINS is not None:
+        CAPTURE_PINS.append(obj)
+    return obj
+
 SPECULATIVE_LOOKUP = os.environ.get("GNAN_SPECULATIVE_LOOKUP", "1") != "0"   # queue the look-up before the piece counts are read back
 MOMENTS_FIXED_POINT = True    # accumulate the per-piece moments in 64-bit fixed point (integer LDS atomics, reproducible)
 _ABS_MAX_CACHE = TensorKeyedCache(16)   # feature matrix (object identity + version) -> device scalar max |x|
@@ -195,7 +203,7 @@ def _abs_max_cached(x: torch.Tensor) -> torch.Tensor:
     hit = _ABS_MAX_CACHE.get((x,))
     if hit is None:
         hit = _ABS_MAX_CACHE.put((x,), None, x.abs().max().double())
-    return hit
+    return _pin_for_capture(hit)
 
 
 def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
@@ -673,7 +681,7 @@ def _padded_x(x: torch.Tensor, Fp: int) -> torch.Tensor:
     hit = _X_PAD_CACHE.get((x,), Fp)
     if hit is None:
         hit = _X_PAD_CACHE.put((x,), Fp, torch.nn.functional.pad(x.detach().float(), (0, Fp - x.shape[1])))
-    return hit
+    return _pin_for_capture(hit)
 
 
 def _padded_stack(p: StackedMLP, Fp: int) -> StackedMLP:

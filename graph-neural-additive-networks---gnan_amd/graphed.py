@@ -72,6 +72,10 @@ class GraphedCallable:
         if before_capture is not None:
             before_capture()
         functional.CAPTURED_BUILDS.clear()
+        # tensors the step reads that are owned by nobody but an LRU cache (max |x| of the fixed-point scales, the padded
+        # feature matrix, the hop-coded graph derived from the inputs): the graph bakes their ADDRESSES in, so the step
+        # keeps them alive — an eviction would hand their blocks to someone else under a replay
+        functional.CAPTURE_PINS = pins = []
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         try:
             with torch.cuda.graph(self.graph):
@@ -86,9 +90,12 @@ class GraphedCallable:
             self.graph.instantiate()
         except Exception as e:                   # a host synchronisation on the path, an unsupported op, ...
             functional.CAPTURED_BUILDS.clear()
+            functional.CAPTURE_PINS = None
             raise CaptureFailed(f"{type(e).__name__}: {e}") from e
         self.builds = list(functional.CAPTURED_BUILDS)
         functional.CAPTURED_BUILDS.clear()
+        functional.CAPTURE_PINS = None
+        self.pins = pins
         self.replays = 0
         _LIVE.add(self)
 
@@ -119,29 +126,65 @@ def _group_signature(optimizer):
                  for g in optimizer.param_groups)
 
 
-def _make_capturable(optimizer) -> List[torch.Tensor]:
-    """Adam-family optimizers: step counters and learning rate on the device (``capturable=True``).  Returns the static
-    learning-rate tensors, one per group (the floats schedulers write into ``group['lr']`` are copied into them)."""
-    lrs = []
-    for group in optimizer.param_groups:
-        if "capturable" not in group:
-            raise CaptureFailed(f"{type(optimizer).__name__} has no capturable mode")
-        group["capturable"] = True
-        if "fused" in group and all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
-            # F x L small parameter tensors (774 on the arxiv shape): the for-each implementation needs ~15 launches per
-            # 30 tensors and falls back to one launch per tensor for the operations that take the learning-rate TENSOR
-            # (1300 launches, 4 ms per replayed step); the fused kernel updates 36 tensors per launch in one pass
-            group["fused"], group["foreach"] = True, False
-        dev = group["params"][0].device
-        lr = group["lr"]
-        static = lr if torch.is_tensor(lr) and lr.device == dev else torch.tensor(float(lr), dtype=torch.float32, device=dev)
-        group["lr"] = static
-        lrs.append(static)
-        for p in group["params"]:
-            st = optimizer.state.get(p)
-            if st and "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
-                st["step"] = st["step"].to(p.device, torch.float32)
-    return lrs
+class PreparedOptimizer:
+    """An Adam-family optimizer switched to the mode a captured step needs — step counters and learning rate on the device
+    (``capturable=True``), the fused multi-tensor update — together with what it was before.
+
+    The switch changes the caller's object: ``group['lr']`` becomes a device tensor, ``optimizer.state_dict()`` carries it
+    and device ``step`` counters, and the update arithmetic is the fused kernel's.  It is therefore made ONCE, before the
+    first epoch of a loop that will be captured (``harness`` does so on its first call), never in the middle of a run, and
+    :meth:`restore` gives the optimizer its own flags and a float learning rate back — when a capture fails, when the
+    captured steps are released, or on request (e.g. before writing a checkpoint the reference's trainer should read)."""
+
+    def __init__(self, optimizer):
+        self.optimizer = weakref.ref(optimizer)
+        self.saved = []
+        self.lrs: List[torch.Tensor] = []
+        for group in optimizer.param_groups:
+            if "capturable" not in group:
+                raise CaptureFailed(f"{type(optimizer).__name__} has no capturable mode")
+        for group in optimizer.param_groups:
+            self.saved.append({k: group.get(k) for k in ("capturable", "fused", "foreach", "lr") if k in group})
+            group["capturable"] = True
+            if "fused" in group and all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
+                # F x L small parameter tensors (774 on the arxiv shape): the for-each implementation needs ~15 launches per
+                # 30 tensors and falls back to one launch per tensor for the operations that take the learning-rate TENSOR
+                # (1300 launches, 4 ms per replayed step); the fused kernel updates 36 tensors per launch in one pass
+                group["fused"], group["foreach"] = True, False
+            dev = group["params"][0].device
+            lr = group["lr"]
+            static = lr if torch.is_tensor(lr) and lr.device == dev else torch.tensor(float(lr), dtype=torch.float32, device=dev)
+            group["lr"] = static
+            self.lrs.append(static)
+            for p in group["params"]:
+                st = optimizer.state.get(p)
+                if st and "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
+                    st["step"] = st["step"].to(p.device, torch.float32)
+
+    def restore(self) -> None:
+        opt = self.optimizer()
+        if opt is None or self.saved is None:
+            return
+        for group, saved, static in zip(opt.param_groups, self.saved, self.lrs):
+            now = group["lr"]
+            group.update(saved)                               # incl. the caller's own learning-rate object ...
+            if torch.is_tensor(now):                          # ... unless a scheduler has moved the rate since
+                was = saved.get("lr")
+                same = (not torch.is_tensor(was)) and float(torch.tensor(float(was), dtype=torch.float32)) == float(now)
+                if not same:
+                    group["lr"] = float(now)
+            else:
+                group["lr"] = now
+            if not saved.get("capturable", False):
+                for p in group["params"]:                     # the non-capturable update wants its step counters on the host
+                    st = opt.state.get(p)
+                    if st and torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                        st["step"] = st["step"].detach().cpu()
+        self.saved = None
+
+
+def prepare_optimizer(optimizer) -> PreparedOptimizer:
+    return PreparedOptimizer(optimizer)
 
 
 class GraphedStep:
@@ -160,14 +203,20 @@ class GraphedStep:
             return False
         return optimizer is None or all("capturable" in g for g in optimizer.param_groups)
 
-    def __init__(self, model, data, loss_of=None, optimizer=None, forward: Optional[Callable] = None, warmup: int = 0):
+    def __init__(self, model, data, loss_of=None, optimizer=None, forward: Optional[Callable] = None, warmup: int = 0,
+                 prepared: Optional[PreparedOptimizer] = None):
         """``warmup`` eager steps are run first — REAL steps (they update the parameters when an optimizer is given).  A
         capture needs the step to have run eagerly at least once (lazy initialisations, table sizes); ``harness`` passes
-        0 because its first epochs already did."""
+        0 because its first epochs already did.  ``prepared``: the optimizer's capturable mode if the caller switched it on
+        already (:func:`prepare_optimizer`); otherwise it is switched on here and undone if the capture fails."""
         self.model, self.data, self.optimizer = model, data, optimizer
         self.training = optimizer is not None
         fwd = forward or (lambda: model.forward(data))
-        self.lrs = _make_capturable(optimizer) if self.training else []
+        self.prepared = prepared if self.training else None
+        self._own_prepared = False
+        if self.training and self.prepared is None:
+            self.prepared, self._own_prepared = PreparedOptimizer(optimizer), True
+        self.lrs = self.prepared.lrs if self.training else []
         self.outputs = self.loss = self.extras = None
 
         def step():
@@ -199,12 +248,33 @@ class GraphedStep:
             for _ in range(warmup):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = GraphedCallable(step, warmup=0, before_capture=clear)
+        try:
+            self.graph = GraphedCallable(step, warmup=0, before_capture=clear)
+        except CaptureFailed:
+            if self._own_prepared:
+                self.prepared.restore()
+            raise
         self.outputs, self.loss, self.extras = self.graph.out
         self._probes = _probe_params(model)
         self._params = [p.data_ptr() for p in self._probes]
         self._groups = _group_signature(optimizer) if self.training else None
         self._mode = model.training
+
+    def release(self, restore_optimizer: bool = True) -> None:
+        """Free the captured graph (and its private memory pool) and drop what the step kept alive; with
+        ``restore_optimizer`` the optimizer gets its own settings back (:meth:`PreparedOptimizer.restore`)."""
+        g, self.graph = getattr(self, "graph", None), None
+        if g is not None:
+            try:
+                g.graph.reset()
+            except Exception:
+                pass
+            g.out = g.pins = None
+            _LIVE.discard(g)
+        if restore_optimizer and self.prepared is not None:
+            self.prepared.restore()
+        self.outputs = self.loss = self.extras = None
+        self.model = self.data = self.optimizer = self.eager_step = None
 
     def stale(self) -> bool:
         """Something the graph froze has changed: parameter storage (``.to()``, ``load_state_dict`` into new tensors),
@@ -216,7 +286,7 @@ class GraphedStep:
     def replay(self):
         """Replay the captured step; returns ``(outputs, loss, extras)`` (static tensors), or None if the step must not be
         replayed (see :meth:`stale`, :meth:`GraphedCallable.fits`) — the caller then runs it eagerly and captures anew."""
-        if self.stale() or not self.graph.fits():
+        if self.graph is None or self.stale() or not self.graph.fits():
             return None
         for group, static in zip(self.optimizer.param_groups if self.training else [], self.lrs):
             if group["lr"] is not static:                     # a scheduler wrote a float: keep the tensor, take the value
@@ -242,7 +312,7 @@ class SlottedGraphStep:
     the replay.  ``loss_of(outputs, label) -> loss`` as in :class:`GraphedStep`; the caller's running totals are updated
     inside the captured step (``totals = (loss_sum, hit_count)``, device scalars)."""
 
-    def __init__(self, model, optimizer, loss_of, graph, x, label):
+    def __init__(self, model, optimizer, loss_of, graph, x, label, prepared: Optional[PreparedOptimizer] = None):
         from .graph import HopGraph
         if not graph.is_dense:
             raise CaptureFailed("graph-task steps are captured for the dense layout only")
@@ -251,7 +321,7 @@ class SlottedGraphStep:
         self.load(graph, x, label)
         static_graph = HopGraph(n_rows=graph.n_rows, n_cols=graph.n_cols, n_codes=graph.n_codes, code=self.code, cnt=self.cnt)
         self.data = _Slots(x=self.x, edge_index=None, gnan_graph=static_graph)
-        self.step = GraphedStep(model, self.data, lambda out: loss_of(out, self.label), optimizer, warmup=0)
+        self.step = GraphedStep(model, self.data, lambda out: loss_of(out, self.label), optimizer, warmup=0, prepared=prepared)
 
     def load(self, graph, x, label) -> None:
         self.x.copy_(x)
@@ -261,7 +331,7 @@ class SlottedGraphStep:
 
     def run(self, graph, x, label):
         """Copy the graph into the slots and replay; None if the capture has gone stale (the caller steps eagerly)."""
-        if self.step.stale():
+        if self.step.graph is None or self.step.stale():
             return None
         self.load(graph, x, label)
         return self.step.replay()

@@ -30,8 +30,56 @@ import torch
 GRAPHED_STEPS = os.environ.get("GNAN_GRAPHED_STEPS", "1") != "0"
 GRAPH_AFTER = 2                      # eager epochs before a step is captured (they are the capture's warm-up)
 GRAPH_TASK_MAX_SHAPES = 4096         # captured steps a graph-level task may hold (each owns a private memory pool: >= 2 MB)
-_STEPS = weakref.WeakKeyDictionary()     # model -> TensorKeyedCache of per-(data, mask, loss, optimizer) step records
-_GRAPH_STEPS = weakref.WeakKeyDictionary()   # model -> _GraphTaskSteps (graph-level tasks: one captured step per graph shape)
+
+
+class _StepStore:
+    """Captured steps of ONE model, kept on the model instance itself (``model.__dict__['_gnan_steps']``): a captured step
+    holds its model, data and optimizer strongly, so a registry keyed by the model — even a weak one — would keep every
+    model of a cross-validation loop (main.py builds a fresh one per fold and seed) and its graphs' private memory pools
+    alive.  Hung off the model, records and model form a cycle the garbage collector frees when the model is dropped.
+    A copied or pickled model starts without captured steps."""
+
+    def __init__(self):
+        from ._cache import TensorKeyedCache
+        self.node = TensorKeyedCache(8)      # per-(data tensors, mask, loss, optimizer) step records of full-batch node tasks
+        self.graph = None                    # _GraphTaskSteps: one captured step per graph shape
+
+    def __deepcopy__(self, memo):
+        return _StepStore()
+
+    def __reduce__(self):
+        return (_StepStore, ())
+
+
+def _steps_of(model) -> "_StepStore":
+    store = model.__dict__.get("_gnan_steps")
+    if store is None:
+        store = _StepStore()
+        object.__setattr__(model, "_gnan_steps", store)      # a plain attribute: not a sub-module, not in the state_dict
+    return store
+
+
+def release_steps(model) -> None:
+    """Drop every captured step of ``model`` now (their hipGraphs and private memory pools) and give an optimizer that was
+    switched to its capturable mode its own settings back.  Dropping the model does the same once it is collected."""
+    store = model.__dict__.pop("_gnan_steps", None)
+    if store is None:
+        return
+    recs = [e.value for e in store.node.entries.values()]
+    if store.graph is not None:
+        recs += list(store.graph.buckets.values())
+        store.graph.restore_optimizer()
+    for rec in recs:
+        _drop_step(rec)
+    store.node.clear()
+    store.graph = None
+
+
+def _drop_step(rec) -> None:
+    step, rec["step"] = rec.get("step"), None
+    inner = getattr(step, "step", step)                       # SlottedGraphStep wraps a GraphedStep
+    if inner is not None and hasattr(inner, "release"):
+        inner.release()
 
 
 def _labels_of(data, label_index: int, loss_fn) -> torch.Tensor:
@@ -77,13 +125,12 @@ def _finish(total_loss, hits, n_batches, n_samples, classify, compute_auc, proba
 
 
 def _single_resident_batch(loader, device):
-    """The loader's one batch if it is a full-batch node task whose tensors already live on ``device``, else None."""
-    try:
-        if len(loader) != 1:
-            return None
-    except TypeError:
+    """The loader's one batch if it is a full-batch node task whose tensors already live on ``device``, else None.
+    Only plain sequences are looked into: iterating a ``DataLoader`` here would start a second iterator per epoch (worker
+    start-up, collation) and draw a base seed from the global RNG the reference's loop does not draw."""
+    if not isinstance(loader, (list, tuple)) or len(loader) != 1:
         return None
-    data = next(iter(loader))
+    data = loader[0]
     x = getattr(data, "x", None)
     dev = torch.device(device)
     if not torch.is_tensor(x) or x.device.type != "cuda" or (dev.index is not None and x.device != dev):
@@ -91,18 +138,30 @@ def _single_resident_batch(loader, device):
     return data
 
 
+_GRAPH_FIELDS = ("node_distances", "normalization_matrix", "gnan_rowptr", "gnan_col", "gnan_code", "gnan_cnt", "edge_index")
+
+
 def _step_record(model, data, mask_name, label_index, loss_fn, optimizer, classify):
-    from ._cache import TensorKeyedCache
-    cache = _STEPS.get(model)
-    if cache is None:
-        cache = _STEPS[model] = TensorKeyedCache(8)
-    src = (data.x, getattr(data, mask_name), data.y)
-    extra = (mask_name, int(label_index), bool(classify), optimizer is None)
+    """The record of this (inputs, mask, loss, optimizer) combination, or None if it cannot be keyed (a loss callable that
+    cannot be weakly referenced): the epoch then runs eagerly.  The key holds every tensor the step reads — features, mask,
+    labels AND the adjacency (swapping or editing it on the same ``Data`` object must not replay the old graph)."""
+    cache = _steps_of(model).node
+    graph = getattr(data, "gnan_graph", None)
+    src = (data.x, getattr(data, mask_name), data.y) + tuple(
+        t if torch.is_tensor(t) else None for t in (getattr(data, f, None) for f in _GRAPH_FIELDS))
+    extra = (mask_name, int(label_index), bool(classify), optimizer is None, None if graph is None else id(graph))
     rec = cache.get(src, extra)
     if (rec is None or rec["loss_fn"]() is not loss_fn
             or (optimizer is not None and (rec["optimizer"] is None or rec["optimizer"]() is not optimizer))):
-        rec = cache.put(src, extra, {"calls": 0, "step": None, "dead": False, "loss_fn": weakref.ref(loss_fn),
-                                     "optimizer": None if optimizer is None else weakref.ref(optimizer)})
+        if rec is not None:
+            _drop_step(rec)
+        try:
+            loss_ref = weakref.ref(loss_fn)
+        except TypeError:
+            return None
+        rec = cache.put(src, extra, {"calls": 0, "step": None, "dead": False, "loss_fn": loss_ref,
+                                     "optimizer": None if optimizer is None else weakref.ref(optimizer),
+                                     "graph": graph})
     return rec
 
 
@@ -112,10 +171,19 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
     if not GraphedStep.supported(model, optimizer):
         return None
     rec = _step_record(model, data, mask_name, label_index, loss_fn, optimizer, classify)
-    if rec["dead"]:
+    if rec is None or rec["dead"]:
         return None
     if rec["step"] is None:
         if rec["calls"] < GRAPH_AFTER:
+            if rec["calls"] == 0 and optimizer is not None:
+                # the capturable (fused) update from the FIRST epoch on: the arithmetic of the update never changes in the
+                # middle of a run (graphed.prepare_optimizer; undone if the capture fails or the step is released)
+                from .graphed import prepare_optimizer
+                try:
+                    rec["prepared"] = prepare_optimizer(optimizer)
+                except CaptureFailed:
+                    rec["dead"] = True
+                    return None
             rec["calls"] += 1
             return None
         labels = _labels_of(data, label_index, loss_fn).to(data.x.device)
@@ -128,14 +196,17 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
             hits = _hits(picked.detach(), labels_m) if classify else None
             return loss, (hits, picked.detach())
         try:
-            rec["step"] = GraphedStep(model, data, loss_of, optimizer, warmup=0)
+            rec["step"] = GraphedStep(model, data, loss_of, optimizer, warmup=0, prepared=rec.get("prepared"))
             rec["labels"] = labels_m
         except CaptureFailed as e:
             rec["dead"] = True
+            if rec.get("prepared") is not None:
+                rec.pop("prepared").restore()                  # the eager loop goes on with the caller's own optimizer settings
             warnings.warn(f"gnan_amd: the step could not be captured into a hipGraph ({e}); staying on the eager loop")
             return None
     got = rec["step"].replay()
     if got is None:                       # parameters moved, hyper-parameters changed or the tables outgrew the capture
+        rec["step"].release(restore_optimizer=False)           # (the optimizer stays prepared: the step is captured again)
         rec["step"], rec["calls"] = None, GRAPH_AFTER
         return None
     _, loss, (hits, picked) = got
@@ -153,6 +224,7 @@ class _GraphTaskSteps:
         self.model, self.optimizer, self.loss_fn, self.classify = weakref.ref(model), weakref.ref(optimizer), weakref.ref(loss_fn), classify
         self.buckets = {}
         self.captured = 0
+        self.prepared = None
         self.total_loss = torch.zeros((), device=device)
         self.hits = torch.zeros((), device=device)
         self.labels = None
@@ -160,6 +232,11 @@ class _GraphTaskSteps:
     def matches(self, model, optimizer, loss_fn, classify) -> bool:
         return (self.model() is model and self.optimizer() is optimizer and self.loss_fn() is loss_fn
                 and self.classify == classify)
+
+    def restore_optimizer(self) -> None:
+        if self.prepared is not None:
+            self.prepared.restore()
+            self.prepared = None
 
     def labels_of(self, data, label_index, loss_fn):
         """``_labels_of`` without its host synchronisation, cached per label tensor."""
@@ -201,22 +278,35 @@ class _GraphTaskSteps:
                     self.hits.add_(_hits(outputs.detach(), label))
                 return loss, None
             try:
-                rec["step"] = SlottedGraphStep(model, self.optimizer(), loss_of, graph, data.x, labels)
+                if self.prepared is None:
+                    from .graphed import prepare_optimizer
+                    self.prepared = prepare_optimizer(self.optimizer())
+                rec["step"] = SlottedGraphStep(model, self.optimizer(), loss_of, graph, data.x, labels, prepared=self.prepared)
                 self.captured += 1
             except CaptureFailed as e:
                 rec["dead"] = True
                 warnings.warn(f"gnan_amd: the graph-task step could not be captured into a hipGraph ({e}); shape stays eager")
                 return False
         if rec["step"].run(graph, data.x, labels) is None:
+            rec["step"].step.release(restore_optimizer=False)
             rec["step"], rec["calls"] = None, GRAPH_AFTER
             return False
         return True
 
 
 def _graph_task_steps(model, optimizer, loss_fn, classify, device):
-    steps = _GRAPH_STEPS.get(model)
+    store = _steps_of(model)
+    steps = store.graph
     if steps is None or not steps.matches(model, optimizer, loss_fn, classify):
-        steps = _GRAPH_STEPS[model] = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)
+        if steps is not None:
+            for rec in steps.buckets.values():
+                _drop_step(rec)
+            steps.restore_optimizer()
+        try:
+            steps = store.graph = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)
+        except TypeError:                                   # a loss / optimizer that cannot be weakly referenced: eager loop
+            store.graph = None
+            return None
     return steps
 
 
@@ -236,8 +326,9 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
         from .graphed import GraphedStep
         if GraphedStep.supported(model, optimizer):
             replayer = _graph_task_steps(model, optimizer, loss_fn, classify, device)
-            replayer.total_loss.zero_()
-            replayer.hits.zero_()
+            if replayer is not None:
+                replayer.total_loss.zero_()
+                replayer.hits.zero_()
     for data in loader:
         if replayer is not None and torch.is_tensor(getattr(data, "x", None)) and data.x.is_cuda:
             labels = replayer.labels_of(data, label_index, loss_fn)

@@ -231,6 +231,10 @@ class _PathBase(nn.Module):
 
     # ---- inputs -> hop-coded adjacency -----------------------------------------------------
     def _graph(self, inputs, want_norm: bool) -> HopGraph:
+        from .functional import _pin_for_capture
+        return _pin_for_capture(self._graph_lookup(inputs, want_norm))    # a captured step keeps its graph alive
+
+    def _graph_lookup(self, inputs, want_norm: bool) -> HopGraph:
         g = getattr(inputs, "gnan_graph", None)
         if g is not None:
             return g

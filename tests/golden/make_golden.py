@@ -404,7 +404,7 @@ def main():
         def to(self, device):
             return self
 
-    def trainer_case(tid, variant, C, loss_name, n_batches, n, f_raw=4, H=8, L=3):
+    def trainer_case(tid, variant, C, loss_name, n_batches, n, f_raw=4, H=8, L=3, opt_name="SGD", epochs=1):
         graph_task = variant.endswith("graph")
         rng = np.random.default_rng(9100 + tid)
         batches = []
@@ -442,14 +442,22 @@ def main():
         model.train()
         sd0 = {k: v.clone() for k, v in model.state_dict().items()}
         loss_fn = getattr(torch.nn, loss_name)()
-        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        lr = 0.05 if opt_name == "SGD" else 0.01
+        opt = torch.optim.SGD(model.parameters(), lr=lr) if opt_name == "SGD" else torch.optim.Adam(model.parameters(), lr=lr)
         classify = loss_name != "MSELoss"
-        tr = ref_trainer.train_epoch(model, batches, loss_fn, opt, "cpu", classify=classify, compute_auc=False,
-                                     is_graph_task=graph_task)
-        sd1 = {k: v.clone() for k, v in model.state_dict().items()}
-        te = ref_trainer.test_epoch(model, batches, loss_fn, "cpu", classify=classify, compute_auc=False,
-                                    val_mask=True, is_graph_task=graph_task)
+        hist_tr, hist_te = [], []
+        for _ in range(epochs):               # main.py:176-215: a training pass, then an evaluation pass, every epoch
+            tr = ref_trainer.train_epoch(model, batches, loss_fn, opt, "cpu", classify=classify, compute_auc=False,
+                                         is_graph_task=graph_task)
+            sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+            te = ref_trainer.test_epoch(model, batches, loss_fn, "cpu", classify=classify, compute_auc=False,
+                                        val_mask=True, is_graph_task=graph_task)
+            hist_tr.append(tr)
+            hist_te.append(te)
         arrays = {"train_ret": np.array(tr, dtype=np.float64), "test_ret": np.array(te, dtype=np.float64)}
+        if epochs > 1:
+            arrays["train_hist"] = np.array(hist_tr, dtype=np.float64)
+            arrays["test_hist"] = np.array(hist_te, dtype=np.float64)
         for k, v in sd0.items():
             arrays["sd0/" + k] = v.numpy()
         for k, v in sd1.items():
@@ -458,7 +466,7 @@ def main():
             for k, v in d.__dict__.items():
                 arrays[f"b{b}/{k}"] = v.numpy()
         meta = dict(variant="trainer_gnan", model=variant, id=310 + tid, C=C, H=H, L=L, F=F, graph=graph_task, loss=loss_name,
-                    classify=classify, n_batches=n_batches, lr=0.05, rho_per_feature=(C > 1))
+                    classify=classify, n_batches=n_batches, lr=lr, rho_per_feature=(C > 1), optimizer=opt_name, epochs=epochs)
         name = f"case_{310 + tid:03d}_trainer_gnan"
         arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
@@ -470,6 +478,10 @@ def main():
     trainer_case(2, "models_tensor_graph", 1, "BCEWithLogitsLoss", 4, 0)
     trainer_case(3, "standalone_tensor_node", 3, "CrossEntropyLoss", 1, 40)
     trainer_case(4, "models_tensor_graph", 1, "MSELoss", 3, 0)
+    # Adam over several epochs (main.py:141): long enough for the harness to capture the step and replay it
+    trainer_case(5, "models_tensor_node", 3, "CrossEntropyLoss", 1, 60, f_raw=6, H=16, opt_name="Adam", epochs=6)
+    trainer_case(6, "models_tensor_graph", 1, "BCEWithLogitsLoss", 3, 0, opt_name="Adam", epochs=6)
+    trainer_case(7, "standalone_tensor_node", 2, "CrossEntropyLoss", 1, 50, opt_name="Adam", epochs=5)
 
     # inputs EXACTLY on ReLU kinks: zero biases (the reference's own initial state) with one-hot / bag-of-words style
     # features, and kinks placed on float32 numbers the inputs take.  torch differentiates relu at 0 as 0.

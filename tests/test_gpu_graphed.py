@@ -82,7 +82,7 @@ def test_graphed_epochs_match_eager_epochs(n, F, C, dense, loss, monkeypatch):
             hist.append(list(tr) + list(te))
         runs[tag] = (np.array(hist, dtype=np.float64), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
         if on:
-            recs = [r for r in harness._STEPS[m].entries.values()]
+            recs = [r for r in harness._steps_of(m).node.entries.values()]
             assert all(r.value["step"] is not None and r.value["step"].graph.replays >= 20 for r in recs), "nothing was replayed"
     a, b = runs["eager"], runs["graphed"]
     assert a[0].shape == b[0].shape
@@ -102,9 +102,10 @@ def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     for _ in range(4):
         harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)
-    rec = [r.value for r in harness._STEPS[m].entries.values() if r.value["optimizer"] is not None][0]
+    rec = [r.value for r in harness._steps_of(m).node.entries.values() if r.value["optimizer"] is not None][0]
     first = rec["step"]
     assert first is not None and first.graph.replays == 2
+    first_graph = first.graph                                  # (a dropped step releases its graph)
     real = pwl.covers
     calls = {"n": 0}
 
@@ -114,7 +115,7 @@ def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
     monkeypatch.setattr(pwl, "covers", covers_once_false)
     before = {k: v.detach().clone() for k, v in m.state_dict().items()}
     harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)      # eager: the capture is dropped
-    assert rec["step"] is None and first.graph.replays == 2
+    assert rec["step"] is None and first.graph is None and first_graph.replays == 2
     assert any(not torch.equal(before[k], v) for k, v in m.state_dict().items())                # ... and the step still happened
     harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)      # captured anew and replayed
     assert rec["step"] is not None and rec["step"] is not first and rec["step"].graph.replays == 1
@@ -129,7 +130,7 @@ def test_moved_parameters_invalidate_the_capture(monkeypatch):
     m = _model(129, 1)
     for _ in range(4):
         out = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
-    rec = [r.value for r in harness._STEPS[m].entries.values()][0]
+    rec = [r.value for r in harness._steps_of(m).node.entries.values()][0]
     assert rec["step"] is not None and rec["step"].graph.replays == 2
     with torch.no_grad():
         for p in m.parameters():
@@ -228,6 +229,74 @@ def test_graph_task_steps_replayed_per_shape_match_eager_steps(readout, monkeypa
                     for key in ("exp_avg", "exp_avg_sq", "step"):
                         ob.state[pb][key].copy_(oa.state[pa][key])
             assert worst <= 1e-5, (epoch, worst)
-    steps = harness._GRAPH_STEPS[mb_]
+    steps = harness._steps_of(mb_).graph
     replayed = sum(r["step"].step.graph.replays for r in steps.buckets.values() if r["step"] is not None)
     assert replayed >= 70, replayed                                # 135 steps, a dozen shapes, two eager sightings each
+
+
+def test_captured_steps_die_with_their_model_and_hand_the_optimizer_back(monkeypatch):
+    """Cross-validation loops build a fresh model per fold and seed (main.py): every run's captured graphs (and their
+    private memory pools) must go when the model goes — device memory returns to the baseline — and an optimizer that was
+    switched to its capturable mode gets its own settings (a float learning rate, its foreach / fused choice) back when the
+    steps are released."""
+    _need_gpu()
+    import gc
+    from gnan_amd import harness
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    data = _node_task(3000, 129, 1, False)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+
+    def one_fold(release):
+        m = _model(129, 1)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        for _ in range(5):
+            harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)
+            harness.test_epoch(m, [data], loss_fn, DEV, classify=True, val_mask=True, is_graph_task=False)
+        recs = [r.value for r in harness._steps_of(m).node.entries.values()]
+        assert len(recs) == 2 and all(r["step"] is not None and r["step"].graph.replays >= 2 for r in recs)
+        assert torch.is_tensor(opt.param_groups[0]["lr"]) and opt.param_groups[0]["capturable"]
+        if release:
+            harness.release_steps(m)
+            g = opt.param_groups[0]
+            assert isinstance(g["lr"], float) and abs(g["lr"] - 1e-3) < 1e-12 and not g["capturable"] and not g["fused"]
+            harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)   # and it still steps
+            harness.release_steps(m)
+        return None
+
+    one_fold(False)
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    reserved = torch.cuda.memory_reserved()
+    for fold in range(4):
+        one_fold(fold % 2 == 1)
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        assert torch.cuda.memory_allocated() <= base + (1 << 20), (fold, torch.cuda.memory_allocated(), base)
+        assert torch.cuda.memory_reserved() <= reserved + (8 << 20), (fold, torch.cuda.memory_reserved(), reserved)
+
+
+def test_an_edited_adjacency_is_not_replayed(monkeypatch):
+    """The step record is keyed on every tensor the step reads: swapping the graph on the same Data object runs the new
+    graph (eagerly, then captured anew), never the captured old one."""
+    _need_gpu()
+    from gnan_amd import harness
+    from gnan_amd import synthetic as syn
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    n = 3000
+    data = _node_task(n, 129, 1, False)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    m = _model(129, 1)
+    for _ in range(4):
+        first = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+    src, dst = syn.uniform_edges(n, 2 * n, 99, DEV)
+    other = syn.hop1_csr(src, dst, n)
+    data.gnan_graph = other
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", False)
+    want = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    for _ in range(4):
+        got = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+        assert abs(got[0] - want[0]) <= 1e-6 * max(1.0, abs(want[0])) and abs(got[0] - first[0]) > 1e-6

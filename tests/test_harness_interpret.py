@@ -53,21 +53,13 @@ def test_epoch_loops_match_reference_trainer(name):
     assert not model.training                      # trainer.py:97 leaves eval mode on
 
 
-def test_interpretability_exports():
+def test_interpretability_exports_need_the_device():
+    """The exports are read off the kernels' tables (tests/test_gpu_harness.py checks them against the oracle): a CPU model
+    is refused like every other CPU input, there is no torch re-evaluation to fall back to."""
+    from gnan_amd import _lib
     from gnan_amd.models import TensorGNAN
-    torch.manual_seed(0)
     m = TensorGNAN(4, 2, 3, hidden_channels=8, rho_per_feature=True)
-    with torch.no_grad():
-        for p in m.parameters():
-            p.normal_(0, 0.7)
-    sd = {k: v.detach() for k, v in m.state_dict().items()}
-    r = interpret.rho_curve(m, 5)
-    assert torch.allclose(r, O.rho_lut(sd, 7), atol=1e-6)
-    grid = torch.linspace(-1, 2, 9)
-    f = interpret.shape_functions(m, grid)
-    want = O.feature_mlps(grid.view(-1, 1).expand(-1, 4).contiguous(), sd).permute(1, 0, 2)
-    assert torch.allclose(f, want, atol=1e-6)
-    h = interpret.contribution_heatmap(m, 5)
-    assert h.shape == (4, 6, 2)
-    f1 = interpret.shape_functions(m, torch.tensor([1.0]))[:, 0]
-    assert torch.allclose(h[2, 3], f1[2] * r[3], atol=1e-6)
+    for call in (lambda: interpret.rho_curve(m, 5), lambda: interpret.shape_functions(m, torch.linspace(-1, 2, 9)),
+                 lambda: interpret.contribution_heatmap(m, 5), lambda: interpret.shape_function_tables(m)):
+        with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
+            call()
