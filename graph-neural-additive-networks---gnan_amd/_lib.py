@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -44,8 +44,11 @@ class FpwlArgs(C.Structure):
         ("max_pieces", C.c_int32), ("features_per_group", C.c_int32), ("max_group_pieces", C.c_int32),
         ("sum_features", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64),
         ("out_dtype", C.c_int32), ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
-        ("total_rows", C.c_int64), ("piece_out", C.c_void_p), ("piece_in", C.c_void_p),
+        ("total_rows", C.c_int64), ("piece_out", C.c_void_p), ("piece_in", C.c_void_p), ("flags", C.c_int32),
     ]
+
+
+FPWL_MOMENTS_GENERAL, FPWL_LOCATE_SORTED = 1, 2      # gnan_fpwl_args.flags
 
 
 class PwlBuildArgs(C.Structure):
@@ -108,6 +111,53 @@ class SpmmArgs(C.Structure):
     ]
 
 
+class MomentScalesArgs(C.Structure):
+    _fields_ = [
+        ("grad", C.c_void_p), ("n", C.c_int64), ("width", C.c_int32), ("bits", C.c_int32), ("grad_stride", C.c_int64),
+        ("anchor", C.c_void_p), ("T", C.c_int64), ("n_anchors", C.c_void_p), ("x_abs_max", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("scales", C.c_void_p),
+    ]
+
+
+class SpmmLutGradArgs(C.Structure):
+    _fields_ = [
+        ("spmm", SpmmArgs), ("dY", C.c_void_p), ("dy_stride", C.c_int64), ("dy_channels", C.c_int32),
+        ("reduce_rows", C.c_int32), ("dwt", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class PackBwdRowsArgs(C.Structure):
+    _fields_ = [
+        ("dY", C.c_void_p), ("dy_stride", C.c_int64), ("W", C.c_int32), ("D", C.c_int32), ("cnt", C.c_void_p),
+        ("cnt_stride", C.c_int64), ("n", C.c_int64), ("with_rest", C.c_int32), ("half", C.c_int32), ("V", C.c_void_p),
+        ("hot", C.c_void_p), ("n_hot", C.c_int64),
+    ]
+
+
+class SpmmBwdNarrowArgs(C.Structure):
+    _fields_ = [
+        ("spmm", SpmmArgs), ("s_rows", C.c_void_p), ("s_rows_stride", C.c_int64), ("w_real", C.c_int32),
+        ("with_rest", C.c_int32), ("dS", C.c_void_p), ("ds_stride", C.c_int64), ("dlut", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class BfsDenseArgs(C.Structure):
+    _fields_ = [
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("n", C.c_int32), ("max_hops", C.c_int32), ("code", C.c_void_p),
+        ("cnt", C.c_void_p), ("status", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class BfsKhopArgs(C.Structure):
+    _fields_ = [
+        ("rowptr", C.c_void_p), ("rowptr_is64", C.c_int32), ("max_hops", C.c_int32), ("col", C.c_void_p), ("n", C.c_int64),
+        ("row_lo", C.c_int64), ("row_hi", C.c_int64), ("level_cnt", C.c_void_p), ("out_rowptr", C.c_void_p),
+        ("out_col", C.c_void_p), ("out_code", C.c_void_p), ("queue_cap", C.c_int32), ("n_workgroups", C.c_int32),
+        ("status", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/gnan_hip.h declares: (name, restype, argtypes)
@@ -131,31 +181,24 @@ SYMBOLS = {
     "gnan_fpwl_rows_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnan_fpwl_rows_moments_fixed": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),
-    "gnan_fpwl_moment_scales": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "gnan_fpwl_moment_scales": (C.c_int, [C.POINTER(MomentScalesArgs), C.c_void_p]),
     "gnan_fpwl_param_grads": (C.c_int, [C.POINTER(FpwlGradArgs), C.c_void_p]),
     "gnan_graph_replace_memsets": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
-    "gnan_spmm_lut_grad_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs), C.c_int32]),
-    "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
-                                     C.c_void_p, C.c_size_t, C.c_void_p]),
-    "gnan_spmm_pack_bwd_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32,
-                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
-    "gnan_spmm_bwd_narrow_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
-    "gnan_spmm_bwd_narrow": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
-                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnan_spmm_lut_grad_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmLutGradArgs)]),
+    "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmLutGradArgs), C.c_void_p]),
+    "gnan_spmm_pack_bwd_rows": (C.c_int, [C.POINTER(PackBwdRowsArgs), C.c_void_p]),
+    "gnan_spmm_bwd_narrow_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmBwdNarrowArgs)]),
+    "gnan_spmm_bwd_narrow": (C.c_int, [C.POINTER(SpmmBwdNarrowArgs), C.c_void_p]),
     "gnan_colsum_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
     "gnan_bfs_dense_workspace_bytes": (C.c_size_t, [C.c_int32]),
-    "gnan_bfs_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnan_bfs_dense": (C.c_int, [C.POINTER(BfsDenseArgs), C.c_void_p]),
     "gnan_bfs_khop_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "gnan_bfs_khop": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
-                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnan_bfs_khop": (C.c_int, [C.POINTER(BfsKhopArgs), C.c_void_p]),
     "gnan_colsum_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
     "gnan_dense_to_code": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

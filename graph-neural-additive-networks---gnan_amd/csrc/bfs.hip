@@ -83,9 +83,16 @@ extern "C" size_t gnan_bfs_dense_workspace_bytes(int32_t n) {
   return blocks * (2 * static_cast<size_t>(n) + (n + 31) / 32) * sizeof(int32_t);
 }
 
-extern "C" int gnan_bfs_dense(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t max_hops, uint8_t* code,
-                              int32_t* cnt, int32_t* status, void* workspace, size_t workspace_bytes,
-                              gnan_stream_t stream) {
+extern "C" int gnan_bfs_dense(const gnan_bfs_dense_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "bfs_dense: null args");
+  const int32_t* rowptr = a->rowptr;
+  const int32_t* col = a->col;
+  const int32_t n = a->n, max_hops = a->max_hops;
+  uint8_t* code = a->code;
+  int32_t* cnt = a->cnt;
+  int32_t* status = a->status;
+  void* workspace = a->workspace;
+  const size_t workspace_bytes = a->workspace_bytes;
   GNAN_REQUIRE(n >= 0, "bfs_dense: negative size");
   if (n == 0) return GNAN_OK;
   GNAN_REQUIRE(rowptr && col && code && cnt && status && workspace, "bfs_dense: null pointer");
@@ -213,10 +220,19 @@ extern "C" size_t gnan_bfs_khop_workspace_bytes(int64_t n, int32_t queue_cap, in
   return static_cast<size_t>(n_workgroups) * (static_cast<size_t>(queue_cap) + words) * sizeof(int32_t);
 }
 
-extern "C" int gnan_bfs_khop(const void* rowptr, int32_t rowptr_is64, const int32_t* col, int64_t n, int32_t max_hops,
-                             int64_t row_lo, int64_t row_hi, int32_t* level_cnt, const int64_t* out_rowptr,
-                             int32_t* out_col, uint8_t* out_code, int32_t queue_cap, int32_t n_workgroups,
-                             int32_t* status, void* workspace, size_t workspace_bytes, gnan_stream_t stream) {
+extern "C" int gnan_bfs_khop(const gnan_bfs_khop_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "bfs_khop: null args");
+  const void* rowptr = a->rowptr;
+  const int32_t rowptr_is64 = a->rowptr_is64, max_hops = a->max_hops, queue_cap = a->queue_cap, n_workgroups = a->n_workgroups;
+  const int32_t* col = a->col;
+  const int64_t n = a->n, row_lo = a->row_lo, row_hi = a->row_hi;
+  int32_t* level_cnt = a->level_cnt;
+  const int64_t* out_rowptr = a->out_rowptr;
+  int32_t* out_col = a->out_col;
+  uint8_t* out_code = a->out_code;
+  int32_t* status = a->status;
+  void* workspace = a->workspace;
+  const size_t workspace_bytes = a->workspace_bytes;
   GNAN_REQUIRE(n >= 0 && n <= 0x7fffffffLL, "bfs_khop: n must fit int32 node ids");
   GNAN_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= n, "bfs_khop: bad row range");
   if (row_hi == row_lo) return GNAN_OK;

@@ -497,6 +497,7 @@ struct MomentParams {
   const double* scales;
   unsigned long long* Mi;   // [T, 2, C] two's-complement sums, zeroed by the caller
   int vec_g;                // gradient rows may be read as 16-byte quads (C == 1, per-feature gradient)
+  int general_only;         // GNAN_FPWL_MOMENTS_GENERAL: keep the general kernel where the one-channel kernel applies
 };
 
 // round(v * s) as a two's-complement 64-bit integer for a power of two s and |v * s| < 2^51: one fused multiply-add onto
@@ -900,9 +901,8 @@ int launch_moments(const MomentParams& mp_in, size_t lds, hipStream_t st) {
     if (fixed && mp.f.C == 1 && !whole) {               // ragged feature count / unaligned rows: the C == 1 kernel's RAGGED variant
       int nstep = 6;
       while ((1 << nstep) < mp.f.max_pieces) ++nstep;
-      const char* env = std::getenv("GNAN_MOMENTS_GENERAL");
       int rc = -1;
-      if (!(env && env[0] == '1')) {
+      if (!mp.general_only) {
         switch (nstep) {
           case 6: rc = launch_moments_c1<FG, 6, BS, true>(mp, st); break;
           case 7: rc = launch_moments_c1<FG, 7, BS, true>(mp, st); break;
@@ -919,8 +919,7 @@ int launch_moments(const MomentParams& mp_in, size_t lds, hipStream_t st) {
       while ((1 << nstep) < mp.f.max_pieces) ++nstep;
       int rc = -1;
       if (mp.f.C == 1 && mp.f.vec_x) {
-        const char* env = std::getenv("GNAN_MOMENTS_GENERAL");   // A/B aid (tools/moments_ab.py, tests): "1" keeps the general kernel
-        if (!(env && env[0] == '1')) {
+        if (!mp.general_only) {                              // (GNAN_FPWL_MOMENTS_GENERAL: A/B aid, tests)
           // 512 threads = three workgroups (24 waves) per CU; 640 (30 waves): +13 %/+6 %, 1024 (32 waves): +-0 on C4
           switch (nstep) {
             case 6: rc = launch_moments_c1<FG, 6, BS>(mp, st); break;
@@ -1300,7 +1299,7 @@ int launch_locate_tree(LocateTreeParams lp, hipStream_t st) {
 int gnan_locate_tree(const gnan_fpwl_args* a, int32_t* piece, float* dx, hipStream_t st) {
   // (small batches: the sorted-array kernel's few large workgroups win — arxiv-shaped 0.102 against 0.141 ms; 10M nodes
   //  x 64 features: 3.4 ms against 1.6 ms the other way)
-  if (a->max_pieces > 1024 || a->n < 262144 || std::getenv("GNAN_LOCATE_SORTED")) return -1;
+  if (a->max_pieces > 1024 || a->n < 262144 || (a->flags & GNAN_FPWL_LOCATE_SORTED)) return -1;
   LocateTreeParams lp;
   gnan_fpwl_args b = *a;
   b.features_per_group = 16;                        // the search has its own grouping, whatever the tables were planned for
@@ -1332,6 +1331,7 @@ int moments_common(const gnan_fpwl_args* a, const float* grad, int64_t grad_stri
   mp.f = base_params(a);
   mp.g = grad; mp.g_stride = grad_stride; mp.M = moments;
   mp.scales = scales; mp.Mi = reinterpret_cast<unsigned long long*>(moments_fixed);
+  mp.general_only = (a->flags & GNAN_FPWL_MOMENTS_GENERAL) != 0;
   mp.f.vec_x = a->features_per_group % 4 == 0 && a->F % 4 == 0 && a->x_stride % 4 == 0 &&
                reinterpret_cast<uintptr_t>(a->x) % 16 == 0;
   mp.vec_g = !a->sum_features && a->C == 1 && grad_stride % 4 == 0 && reinterpret_cast<uintptr_t>(grad) % 16 == 0;

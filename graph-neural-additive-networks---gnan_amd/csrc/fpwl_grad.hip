@@ -453,9 +453,17 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
   return gnan::check_launch("fpwl_grad2_kernel");
 }
 
-extern "C" int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
-                                       int64_t T, const int32_t* n_anchors, const double* x_abs_max, int32_t bits, void* workspace,
-                                       size_t workspace_bytes, double* scales, gnan_stream_t stream) {
+extern "C" int gnan_fpwl_moment_scales(const gnan_moment_scales_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "fpwl_moment_scales: null args");
+  const float* grad = a->grad;
+  const int64_t n = a->n, grad_stride = a->grad_stride, T = a->T;
+  const int32_t width = a->width, bits = a->bits;
+  const float* anchor = a->anchor;
+  const int32_t* n_anchors = a->n_anchors;
+  const double* x_abs_max = a->x_abs_max;
+  void* workspace = a->workspace;
+  const size_t workspace_bytes = a->workspace_bytes;
+  double* scales = a->scales;
   GNAN_REQUIRE(n >= 0 && width >= 1 && grad_stride >= width && T >= 0, "fpwl_moment_scales: bad sizes");
   GNAN_REQUIRE((grad || n == 0) && (anchor || T == 0) && x_abs_max && scales, "fpwl_moment_scales: null pointer");
   GNAN_REQUIRE(workspace && workspace_bytes >= 2 * sizeof(unsigned), "fpwl_moment_scales: workspace of 8 bytes needed");

@@ -1310,7 +1310,7 @@ size_t lut_grad_blk_entries(const gnan_spmm_args* a, int vec, int lpr) {
 
 }  // namespace
 
-extern "C" size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduce_rows) {
+static size_t lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduce_rows) {
   if (!a || a->n_rows <= 0) return 0;
   int vec, lpr;
   pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
@@ -1320,9 +1320,19 @@ extern "C" size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, in
   return bytes;
 }
 
-extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stride, int32_t dy_channels,
-                                  float* dwt, int32_t reduce_rows, void* workspace, size_t workspace_bytes,
-                                  gnan_stream_t stream) {
+extern "C" size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_lut_grad_args* g) {
+  return g ? lut_grad_workspace_bytes(&g->spmm, g->reduce_rows) : 0;
+}
+
+extern "C" int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* g, gnan_stream_t stream) {
+  GNAN_REQUIRE(g != nullptr, "lut_grad: null args");
+  const gnan_spmm_args* a = &g->spmm;
+  const float* dY = g->dY;
+  const int64_t dy_stride = g->dy_stride;
+  const int32_t dy_channels = g->dy_channels, reduce_rows = g->reduce_rows;
+  float* dwt = g->dwt;
+  void* workspace = g->workspace;
+  const size_t workspace_bytes = g->workspace_bytes;
   if (int rc = validate(a)) return rc;
   GNAN_REQUIRE(!a->packed_index, "lut_grad: packed index entries are read by gnan_spmm_fwd only");
   GNAN_REQUIRE(dwt != nullptr, "lut_grad: null output");
@@ -1338,7 +1348,7 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int6
   if (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->s_dtype != GNAN_F32 || a->weight_by_col)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "lut_grad: needs the CSR layout, D <= 4, one weight channel, fp32 operand rows");
   GNAN_REQUIRE(a->W % dy_channels == 0, "lut_grad: dy_channels must divide W");
-  const size_t need = gnan_spmm_lut_grad_workspace_bytes(a, reduce_rows);
+  const size_t need = lut_grad_workspace_bytes(a, reduce_rows);
   if (need > 0 && (workspace == nullptr || workspace_bytes < need))
     return gnan::fail(GNAN_ERR_WORKSPACE, "lut_grad: workspace %zu B < required %zu B", workspace_bytes, need);
   const Params p = make_params(a);
@@ -1388,9 +1398,14 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
 }
 }  // namespace
 
-extern "C" int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32_t W, const int32_t* cnt, int64_t cnt_stride,
-                                       int32_t D, int64_t n, int32_t with_rest, float* V, int32_t half, const int64_t* hot,
-                                       int64_t n_hot, gnan_stream_t stream) {
+extern "C" int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "pack_bwd_rows: null args");
+  const float* dY = a->dY;
+  const int64_t dy_stride = a->dy_stride, cnt_stride = a->cnt_stride, n = a->n, n_hot = a->n_hot;
+  const int32_t W = a->W, D = a->D, with_rest = a->with_rest, half = a->half;
+  const int32_t* cnt = a->cnt;
+  float* V = a->V;
+  const int64_t* hot = a->hot;
   GNAN_REQUIRE(n >= 0 && W >= 1 && D >= 1 && half >= W && (half & (half - 1)) == 0, "pack_bwd_rows: bad sizes");
   GNAN_REQUIRE((dY && V) || n == 0, "pack_bwd_rows: null pointer");
   GNAN_REQUIRE(dy_stride >= W && (cnt == nullptr || cnt_stride >= D), "pack_bwd_rows: row stride smaller than the width");
@@ -1403,7 +1418,7 @@ extern "C" int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32
   return gnan::check_launch("pack_bwd_rows_kernel");
 }
 
-extern "C" size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a) {
+static size_t bwd_narrow_workspace_bytes(const gnan_spmm_args* a) {
   if (!a || a->n_rows <= 0) return 0;
   const int half = a->W / 2;
   const int vec = half <= 2 ? 2 * (half < 1 ? 1 : half) : 4;
@@ -1413,9 +1428,20 @@ extern "C" size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a) 
   return bytes + lut_grad_blk_entries(a, vec, lpr) * 4 * sizeof(double);
 }
 
-extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows, int64_t s_rows_stride, int32_t w_real,
-                                    int32_t with_rest, float* dS, int64_t ds_stride, float* dlut, void* workspace,
-                                    size_t workspace_bytes, gnan_stream_t stream) {
+extern "C" size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_bwd_narrow_args* g) {
+  return g ? bwd_narrow_workspace_bytes(&g->spmm) : 0;
+}
+
+extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* g, gnan_stream_t stream) {
+  GNAN_REQUIRE(g != nullptr, "bwd_narrow: null args");
+  const gnan_spmm_args* a = &g->spmm;
+  const float* s_rows = g->s_rows;
+  const int64_t s_rows_stride = g->s_rows_stride, ds_stride = g->ds_stride;
+  const int32_t w_real = g->w_real, with_rest = g->with_rest;
+  float* dS = g->dS;
+  float* dlut = g->dlut;
+  void* workspace = g->workspace;
+  const size_t workspace_bytes = g->workspace_bytes;
   if (int rc = validate(a)) return rc;
   GNAN_REQUIRE(!a->packed_index, "bwd_narrow: packed index entries are read by gnan_spmm_fwd only");
   GNAN_REQUIRE(dS != nullptr && dlut != nullptr && (s_rows != nullptr || a->n_rows == 0), "bwd_narrow: null pointer");
@@ -1430,7 +1456,7 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows
     hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, dlut, a->D);
     return gnan::check_launch("zero_floats_kernel");
   }
-  const size_t need = gnan_spmm_bwd_narrow_workspace_bytes(a);
+  const size_t need = bwd_narrow_workspace_bytes(a);
   if (need > 0 && (workspace == nullptr || workspace_bytes < need))
     return gnan::fail(GNAN_ERR_WORKSPACE, "bwd_narrow: workspace %zu B < required %zu B", workspace_bytes, need);
   const Params p = make_params(a);

@@ -88,6 +88,15 @@ WEIGHT_TABLE_MAX_BYTES = 1 << 30   # backward w.r.t. a wide S: per-node table of
 NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) operand while its rows stay <= 128 B
 
 
+MOMENTS_GENERAL = os.environ.get("GNAN_MOMENTS_GENERAL", "0") == "1"   # A/B aid: the general moment kernel where the C = 1 kernel applies
+LOCATE_SORTED = bool(os.environ.get("GNAN_LOCATE_SORTED"))              # A/B aid: the sorted-array search where the tree search applies
+
+
+def _fpwl_flags() -> int:
+    """``gnan_fpwl_args.flags`` from this module's switches (the library itself reads no environment variables)."""
+    return (_lib.FPWL_MOMENTS_GENERAL if MOMENTS_GENERAL else 0) | (_lib.FPWL_LOCATE_SORTED if LOCATE_SORTED else 0)
+
+
 FPWL_ROWS = os.environ.get("GNAN_FPWL_ROWS", "1") != "0"   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
 FPWL_ROWS_MIN_NODES = 32768
 # fewer channels: locating the pieces separately costs more than it saves (GNAN_FPWL_ROWS_MIN_C: A/B aid).  10M nodes x 64
@@ -104,7 +113,8 @@ def _fpwl_args(x: torch.Tensor, t, sum_features: bool, out=None) -> "_lib.FpwlAr
                          anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
                          max_pieces=t.max_pieces, features_per_group=t.features_per_group,
                          max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
-                         out=_lib.ptr(out), out_stride=0 if out is None else out.stride(0), out_dtype=_lib.GNAN_F32)
+                         out=_lib.ptr(out), out_stride=0 if out is None else out.stride(0), out_dtype=_lib.GNAN_F32,
+                         flags=_fpwl_flags())
 
 
 def _fpwl_rows_applies(n: int, C: int, t, bins: bool = True) -> bool:
@@ -161,7 +171,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
                       out=_lib.ptr(out), out_stride=out.stride(0),
-                      out_dtype=_lib.GNAN_BF16 if out_dtype == torch.bfloat16 else _lib.GNAN_F32)
+                      out_dtype=_lib.GNAN_BF16 if out_dtype == torch.bfloat16 else _lib.GNAN_F32, flags=_fpwl_flags())
     total = None
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
@@ -226,7 +236,8 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
     a = _lib.FpwlArgs(x=_lib.ptr(x), n=n, x_stride=x.stride(0), F=F, C=C, off=_lib.ptr(t.off),
                       anchor=_lib.ptr(t.anchor), val=_lib.ptr(t.val), slope=_lib.ptr(t.slope),
                       max_pieces=t.max_pieces, features_per_group=t.features_per_group,
-                      max_group_pieces=t.max_group_pieces, sum_features=int(sum_features), out=None, out_stride=0)
+                      max_group_pieces=t.max_group_pieces, sum_features=int(sum_features), out=None, out_stride=0,
+                      flags=_fpwl_flags())
     mgp = t.max_group_pieces
     rows = _fpwl_rows_applies(n, C, t)                  # several channels, large batch: per-feature bins, lane = channel
     if MOMENTS_FIXED_POINT and n > 0 and (rows or (mgp + 1) // 2 * 8 + mgp * (2 * C + 1 if C > 1 else 2) * 8 <= 150 * 1024):
@@ -237,9 +248,10 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
         # one pass over the gradient on the device (gnan_fpwl_moment_scales), no host round trip
         scales = torch.empty(3, dtype=torch.float64, device=x.device)        # [2] scales | 8 bytes of workspace
         # (tables captured into a hipGraph sit in a buffer of full capacity: only the first off[F] anchors are real)
-        _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(grad), n, grad.shape[1], grad.stride(0), _lib.ptr(t.anchor),
-                                                      T, _lib.ptr(t.off[F:]), _lib.ptr(x_abs_max), bits, _lib.ptr(scales[2:]), 8,
-                                                      _lib.ptr(scales), _lib.stream_of(x)), "gnan_fpwl_moment_scales")
+        sa = _lib.MomentScalesArgs(grad=_lib.ptr(grad), n=n, width=grad.shape[1], bits=bits, grad_stride=grad.stride(0),
+                                   anchor=_lib.ptr(t.anchor), T=T, n_anchors=_lib.ptr(t.off[F:]), x_abs_max=_lib.ptr(x_abs_max),
+                                   workspace=_lib.ptr(scales[2:]), workspace_bytes=8, scales=_lib.ptr(scales))
+        _lib.check(_lib.lib().gnan_fpwl_moment_scales(sa, _lib.stream_of(x)), "gnan_fpwl_moment_scales")
         scales = scales[:2]
         Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
         if located and len(located) == 1 and not rows:          # one channel: the forward's pieces, one byte per look-up
@@ -934,10 +946,12 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
     lut_like = torch.empty((D, 1), dtype=torch.float32, device=S.device)       # only its shape is read
     a = _spmm_args(g, S, lut_like, use_cnt, s_total, out.view(-1, 1), row_ids, False, plan=plan, scatter_out=scatter)
     a.n_rows, a.y_stride = n_out, S.shape[1]                                   # Y is not written by this entry point
-    need = _lib.lib().gnan_spmm_lut_grad_workspace_bytes(a, int(reduce_rows))
+    ga = _lib.SpmmLutGradArgs(spmm=a, dY=_lib.ptr(dY), dy_stride=dY.stride(0), dy_channels=dY.shape[1],
+                              reduce_rows=int(reduce_rows), dwt=_lib.ptr(out))
+    need = _lib.lib().gnan_spmm_lut_grad_workspace_bytes(ga)
     ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=S.device)
-    _lib.check(_lib.lib().gnan_spmm_lut_grad(a, _lib.ptr(dY), dY.stride(0), dY.shape[1], _lib.ptr(out), int(reduce_rows),
-                                             _lib.ptr(ws), ws.numel() * 8, _lib.stream_of(S)), "gnan_spmm_lut_grad")
+    ga.workspace, ga.workspace_bytes = _lib.ptr(ws), ws.numel() * 8
+    _lib.check(_lib.lib().gnan_spmm_lut_grad(ga, _lib.stream_of(S)), "gnan_spmm_lut_grad")
     return out.unsqueeze(-1)
 
 
@@ -956,9 +970,10 @@ def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_re
     V = torch.empty((D, n + k, 2 * half), dtype=torch.float32, device=dY.device)
     c = None if cnt is None else cnt.contiguous()
     h = None if hot is None else hot.to(torch.int64).contiguous()
-    _lib.check(_lib.lib().gnan_spmm_pack_bwd_rows(_lib.ptr(dY), dY.stride(0), W, _lib.ptr(c), 0 if c is None else c.stride(0), D, n,
-                                                  int(with_rest), _lib.ptr(V), half, _lib.ptr(h), k, _lib.stream_of(dY)),
-               "gnan_spmm_pack_bwd_rows")
+    pa = _lib.PackBwdRowsArgs(dY=_lib.ptr(dY), dy_stride=dY.stride(0), W=W, D=D, cnt=_lib.ptr(c),
+                              cnt_stride=0 if c is None else c.stride(0), n=n, with_rest=int(with_rest), half=half,
+                              V=_lib.ptr(V), hot=_lib.ptr(h), n_hot=k)
+    _lib.check(_lib.lib().gnan_spmm_pack_bwd_rows(pa, _lib.stream_of(dY)), "gnan_spmm_pack_bwd_rows")
     return V
 
 
@@ -997,11 +1012,12 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
     a = _spmm_args(gt, V, lut, False, None, dS, order, False, plan=plan, scatter_out=scatter)
     a.n_cols = gt.n_cols                              # rows of V = n_cols * D (checked by the kernel's addressing only)
     a.y_stride = V.shape[1]                           # Y is not written by this entry point (dS is); keeps validate() content
-    need = _lib.lib().gnan_spmm_bwd_narrow_workspace_bytes(a)
+    na = _lib.SpmmBwdNarrowArgs(spmm=a, s_rows=_lib.ptr(S_rows), s_rows_stride=S_rows.stride(0), w_real=W,
+                                with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0), dlut=_lib.ptr(dlut))
+    need = _lib.lib().gnan_spmm_bwd_narrow_workspace_bytes(na)
     ws = torch.empty(need // 8 + 2, dtype=torch.float64, device=V.device)
-    _lib.check(_lib.lib().gnan_spmm_bwd_narrow(a, _lib.ptr(S_rows), S_rows.stride(0), W, int(with_rest), _lib.ptr(dS), dS.stride(0),
-                                               _lib.ptr(dlut), _lib.ptr(ws), ws.numel() * 8, _lib.stream_of(V)),
-               "gnan_spmm_bwd_narrow")
+    na.workspace, na.workspace_bytes = _lib.ptr(ws), ws.numel() * 8
+    _lib.check(_lib.lib().gnan_spmm_bwd_narrow(na, _lib.stream_of(V)), "gnan_spmm_bwd_narrow")
     return dS, dlut
 
 

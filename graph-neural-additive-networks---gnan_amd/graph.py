@@ -194,9 +194,10 @@ class HopGraph:
         status = torch.zeros(2, dtype=torch.int32, device=dev)
         need = _lib.lib().gnan_bfs_dense_workspace_bytes(n)
         ws = torch.empty(max(1, need // 4), dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().gnan_bfs_dense(_lib.ptr(rowptr), _lib.ptr(col), n, 254 if max_hops is None else max_hops,
-                                             _lib.ptr(code), _lib.ptr(cnt256), _lib.ptr(status), _lib.ptr(ws), need,
-                                             _lib.stream_of(code)), "gnan_bfs_dense")
+        a = _lib.BfsDenseArgs(rowptr=_lib.ptr(rowptr), col=_lib.ptr(col), n=n, max_hops=254 if max_hops is None else max_hops,
+                              code=_lib.ptr(code), cnt=_lib.ptr(cnt256), status=_lib.ptr(status), workspace=_lib.ptr(ws),
+                              workspace_bytes=need)
+        _lib.check(_lib.lib().gnan_bfs_dense(a, _lib.stream_of(code)), "gnan_bfs_dense")
         flags, max_hop = (int(v) for v in status.tolist())
         if flags & 1:
             raise _lib.GnanHipError("a shortest path longer than 254 hops cannot be coded in one byte")
@@ -428,9 +429,11 @@ def _khop_csr(src: torch.Tensor, dst: torch.Tensor, n: int, K: int, rows: Option
     while True:                                   # count pass; the queue capacity grows until every ball fits
         need = _lib.lib().gnan_bfs_khop_workspace_bytes(n, cap, wgs)
         ws = torch.empty(need // 4 + 1, dtype=torch.int32, device=dev)
-        args = (_lib.ptr(adj_ptr), 1, _lib.ptr(adj_col), n, K, lo, hi)
-        tail = (cap, wgs, _lib.ptr(status), _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(ws))
-        _lib.check(_lib.lib().gnan_bfs_khop(*args, _lib.ptr(level_cnt), None, None, None, *tail), "gnan_bfs_khop")
+        a = _lib.BfsKhopArgs(rowptr=_lib.ptr(adj_ptr), rowptr_is64=1, max_hops=K, col=_lib.ptr(adj_col), n=n, row_lo=lo,
+                             row_hi=hi, level_cnt=_lib.ptr(level_cnt), out_rowptr=None, out_col=None, out_code=None,
+                             queue_cap=cap, n_workgroups=wgs, status=_lib.ptr(status), workspace=_lib.ptr(ws),
+                             workspace_bytes=ws.numel() * 4)
+        _lib.check(_lib.lib().gnan_bfs_khop(a, _lib.stream_of(ws)), "gnan_bfs_khop")      # count pass
         if not int(status.item()) & 1:
             break
         if cap >= n:
@@ -445,8 +448,8 @@ def _khop_csr(src: torch.Tensor, dst: torch.Tensor, n: int, K: int, rows: Option
         raise _lib.GnanHipError(f"{K}-hop lists of this graph hold {nnz:.3g} pairs (> {KHOP_MAX_PAIRS:.3g}); lower max_hops")
     col = torch.empty(nnz, dtype=torch.int32, device=dev)
     code = torch.empty(nnz, dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().gnan_bfs_khop(*args, None, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(code), *tail),
-               "gnan_bfs_khop")
+    a.level_cnt, a.out_rowptr, a.out_col, a.out_code = None, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(code)
+    _lib.check(_lib.lib().gnan_bfs_khop(a, _lib.stream_of(ws)), "gnan_bfs_khop")          # fill pass
     # hop levels are contiguous inside a row but the order inside a level depends on scheduling: fix it by node id,
     # so that the same graph always gives the same lists (and the same floating-point summation order downstream)
     seg = torch.repeat_interleave(torch.arange(n_rows, device=dev), per_row) * (K + 1) + code.long()

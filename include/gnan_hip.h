@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 29
+#define GNAN_ABI_VERSION 30
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -159,7 +159,14 @@ typedef struct gnan_fpwl_args {
                               max_pieces <= 256; GNAN_ERR_UNSUPPORTED otherwise (call again without it) */
   const uint8_t* piece_in; /* gnan_fpwl_moments_fixed, optional: those bytes — the C == 1 kernel then skips the search (ignored
                               by the other moment kernels and above 256 pieces per feature) */
+  int32_t flags;             /* gnan_fpwl_flags: kernel selection switches (A/B measurements, tests); 0 = the library's choice */
 } gnan_fpwl_args;
+
+/* gnan_fpwl_args.flags (the library reads no environment variables: switches are the caller's, passed per call) */
+enum gnan_fpwl_flags {
+  GNAN_FPWL_MOMENTS_GENERAL = 1, /* gnan_fpwl_moments_fixed: the general kernel also where the one-channel kernel applies */
+  GNAN_FPWL_LOCATE_SORTED = 2    /* gnan_fpwl_locate: the sorted-array search also where the tree search applies */
+};
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);
 int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
@@ -210,10 +217,21 @@ int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32_t* piece, 
  * bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits (values above 50 are treated as 50: the kernels
  * convert a term with one fused multiply-add onto 1.5 * 2^52, exact below 2^51).
  * workspace: 8 bytes.  One pass over grad + a single-thread kernel; no host round trip. */
-int gnan_fpwl_moment_scales(const float* grad, int64_t n, int32_t width, int64_t grad_stride, const float* anchor,
-                            int64_t T, const int32_t* n_anchors, const double* x_abs_max, int32_t bits, void* workspace,
-                            size_t workspace_bytes,
-                            double* scales, gnan_stream_t stream);
+typedef struct gnan_moment_scales_args {
+  const float* grad;         /* [n, width], row stride grad_stride */
+  int64_t n;
+  int32_t width;
+  int32_t bits;              /* terms stay below 2^bits */
+  int64_t grad_stride;
+  const float* anchor;       /* [T] */
+  int64_t T;
+  const int32_t* n_anchors;  /* optional device pointer: only the first *n_anchors anchors are real */
+  const double* x_abs_max;   /* device scalar max |x| */
+  void* workspace;           /* >= 8 bytes */
+  size_t workspace_bytes;
+  double* scales;            /* [2] out */
+} gnan_moment_scales_args;
+int gnan_fpwl_moment_scales(const gnan_moment_scales_args* a, gnan_stream_t stream);
 
 /* Parameter gradients of the shape functions from the per-piece moments — the last step of the table path's backward
  * pass (autograd through GNAN.py:57-62 w.r.t. every fs[k] parameter, trainer.py:66).  On a piece the network is affine
@@ -434,10 +452,18 @@ int gnan_dense_to_code(const float* nd, const float* norm, int64_t n_rows, int64
  * reduce_rows == 0: dwt is [n_rows, D];  != 0: dwt is [D] = the sum over rows (fixed-order float64 partials).
  * This is the backward of models.py:368-371 w.r.t. rho's outputs at the D distinct distances.
  * ------------------------------------------------------------------------------------------- */
-size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduce_rows);
-int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stride, int32_t dy_channels,
-                       float* dwt, int32_t reduce_rows, void* workspace, size_t workspace_bytes,
-                       gnan_stream_t stream);
+typedef struct gnan_spmm_lut_grad_args {
+  gnan_spmm_args spmm;       /* graph, operand and row addressing as in the forward */
+  const float* dY;           /* [n_rows, dy_channels] */
+  int64_t dy_stride;
+  int32_t dy_channels;
+  int32_t reduce_rows;
+  float* dwt;                /* [n_rows, D] or, with reduce_rows, [D] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_spmm_lut_grad_args;
+size_t gnan_spmm_lut_grad_workspace_bytes(const gnan_spmm_lut_grad_args* a);
+int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of gnan_spmm_fwd for NARROW operands, both gradients from ONE pass over the transposed adjacency (CSR layout,
@@ -460,13 +486,35 @@ int gnan_spmm_lut_grad(const gnan_spmm_args* a, const float* dY, int64_t dy_stri
  * zero).  With n_hot > 0 every code block has n + n_hot rows and row n + k repeats node hot[k] (int64 ids in DEVICE
  * memory): the compact second copy of the most listed nodes' rows that a column array remapped to n + k reads
  * (HopGraph.hot_columns). */
-int gnan_spmm_pack_bwd_rows(const float* dY, int64_t dy_stride, int32_t W, const int32_t* cnt, int64_t cnt_stride, int32_t D,
-                            int64_t n, int32_t with_rest, float* V, int32_t half, const int64_t* hot, int64_t n_hot,
-                            gnan_stream_t stream);
-size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_args* a);
-int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows, int64_t s_rows_stride, int32_t w_real,
-                         int32_t with_rest, float* dS, int64_t ds_stride, float* dlut, void* workspace,
-                         size_t workspace_bytes, gnan_stream_t stream);
+typedef struct gnan_pack_bwd_rows_args {
+  const float* dY;           /* [n, W], row stride dy_stride */
+  int64_t dy_stride;
+  int32_t W, D;
+  const int32_t* cnt;        /* optional [n, cnt_stride] */
+  int64_t cnt_stride;
+  int64_t n;
+  int32_t with_rest;
+  int32_t half;              /* floats per half row: a power of two >= W */
+  float* V;                  /* [D, n + n_hot, 2 * half] */
+  const int64_t* hot;        /* optional [n_hot] node ids (device memory) */
+  int64_t n_hot;
+} gnan_pack_bwd_rows_args;
+int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_stream_t stream);
+
+typedef struct gnan_spmm_bwd_narrow_args {
+  gnan_spmm_args spmm;       /* the TRANSPOSED adjacency and the packed operand, as described above */
+  const float* s_rows;       /* [n_rows, w_real] operand rows of the forward pass */
+  int64_t s_rows_stride;
+  int32_t w_real;
+  int32_t with_rest;
+  float* dS;                 /* [n_rows, w_real] */
+  int64_t ds_stride;
+  float* dlut;               /* [D] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_spmm_bwd_narrow_args;
+size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_bwd_narrow_args* a);
+int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * All-pairs hop distances on the GPU (graphs small enough for N x N bytes)
@@ -477,9 +525,18 @@ int gnan_spmm_bwd_narrow(const gnan_spmm_args* a, const float* s_rows, int64_t s
  * status[0] |= 1 if a hop distance >= 255 occurred; status[1] = max hop seen.  status zeroed by the caller.
  * ------------------------------------------------------------------------------------------- */
 size_t gnan_bfs_dense_workspace_bytes(int32_t n);
-int gnan_bfs_dense(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t max_hops, uint8_t* code,
-                   int32_t* cnt /* [n, 256] */, int32_t* status /* [2] */, void* workspace, size_t workspace_bytes,
-                   gnan_stream_t stream);
+typedef struct gnan_bfs_dense_args {
+  const int32_t* rowptr;     /* [n + 1] */
+  const int32_t* col;
+  int32_t n;
+  int32_t max_hops;
+  uint8_t* code;             /* [n, n] */
+  int32_t* cnt;              /* [n, 256] */
+  int32_t* status;           /* [2] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_bfs_dense_args;
+int gnan_bfs_dense(const gnan_bfs_dense_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K-hop truncated hop-coded CSR, for graphs too large for N x N bytes (pre_process_datasets.py:104-142 truncated at
@@ -494,11 +551,24 @@ int gnan_bfs_dense(const int32_t* rowptr, const int32_t* col, int32_t n, int32_t
  * the caller.  workspace: gnan_bfs_khop_workspace_bytes(n, queue_cap, n_workgroups).
  * ------------------------------------------------------------------------------------------- */
 size_t gnan_bfs_khop_workspace_bytes(int64_t n, int32_t queue_cap, int32_t n_workgroups);
-int gnan_bfs_khop(const void* rowptr, int32_t rowptr_is64, const int32_t* col, int64_t n, int32_t max_hops,
-                  int64_t row_lo, int64_t row_hi, int32_t* level_cnt /* [rows, max_hops+1] */,
-                  const int64_t* out_rowptr, int32_t* out_col, uint8_t* out_code, int32_t queue_cap,
-                  int32_t n_workgroups, int32_t* status /* [1] */, void* workspace, size_t workspace_bytes,
-                  gnan_stream_t stream);
+typedef struct gnan_bfs_khop_args {
+  const void* rowptr;        /* [n + 1] int32 or int64 */
+  int32_t rowptr_is64;
+  int32_t max_hops;
+  const int32_t* col;
+  int64_t n;
+  int64_t row_lo, row_hi;
+  int32_t* level_cnt;        /* count pass: [rows, max_hops + 1] */
+  const int64_t* out_rowptr; /* fill pass: exclusive prefix sum of the row totals; NULL = count pass */
+  int32_t* out_col;
+  uint8_t* out_code;
+  int32_t queue_cap;
+  int32_t n_workgroups;
+  int32_t* status;           /* [1] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_bfs_khop_args;
+int gnan_bfs_khop(const gnan_bfs_khop_args* a, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * hipGraph hygiene for captured steps (gnan_amd/graphed.py; nothing comparable in the reference, which issues every

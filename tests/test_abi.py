@@ -43,7 +43,10 @@ def test_struct_layout_matches_header():
     for struct, cls in (("gnan_fmlp_args", _lib.FmlpArgs), ("gnan_spmm_args", _lib.SpmmArgs),
                         ("gnan_fpwl_args", _lib.FpwlArgs), ("gnan_pwl_build_args", _lib.PwlBuildArgs),
                         ("gnan_fpwl_grad_args", _lib.FpwlGradArgs), ("gnan_fmlp_bwd_args", _lib.FmlpBwdArgs),
-                        ("gnan_rho_lut_args", _lib.RhoLutArgs)):
+                        ("gnan_rho_lut_args", _lib.RhoLutArgs), ("gnan_moment_scales_args", _lib.MomentScalesArgs),
+                        ("gnan_spmm_lut_grad_args", _lib.SpmmLutGradArgs), ("gnan_pack_bwd_rows_args", _lib.PackBwdRowsArgs),
+                        ("gnan_spmm_bwd_narrow_args", _lib.SpmmBwdNarrowArgs), ("gnan_bfs_dense_args", _lib.BfsDenseArgs),
+                        ("gnan_bfs_khop_args", _lib.BfsKhopArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

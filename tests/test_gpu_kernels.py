@@ -418,9 +418,9 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
         assert float(_fpwl_moments(xd, t, gd * 0, sum_features).abs().max()) == 0.0
         # the C = 1 kernel (gradient read next to x, anchor tracked by the search, one-fma fixed-point conversion) and the
         # general kernel add the same integers: identical bins, also for gradient rows that cannot be read as quads
-        monkeypatch.setenv("GNAN_MOMENTS_GENERAL", "1")
+        monkeypatch.setattr(functional, "MOMENTS_GENERAL", True)        # gnan_fpwl_args.flags & GNAN_FPWL_MOMENTS_GENERAL
         general = _fpwl_moments(xd, t, gd, sum_features, raw=True)[0]
-        monkeypatch.delenv("GNAN_MOMENTS_GENERAL")
+        monkeypatch.setattr(functional, "MOMENTS_GENERAL", False)
         assert torch.equal(_fpwl_moments(xd, t, gd, sum_features, raw=True)[0], general)
         if not sum_features and C == 1:
             wide = torch.zeros(n, F + 3, device=DEV)
@@ -706,9 +706,10 @@ def test_moment_scales_kernel(n, width, gscale):
     out = torch.empty(3, dtype=torch.float64, device=DEV)
     padded = torch.cat([anchor, torch.full((50,), float("inf"), device=DEV)])     # a buffer of full capacity: the tail is not data
     n_real = torch.tensor([anchor.numel()], dtype=torch.int32, device=DEV)
-    _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(g), n, width, g.stride(0), _lib.ptr(padded), padded.numel(),
-                                                  _lib.ptr(n_real), _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
-                                                  _lib.stream_of(g)), "gnan_fpwl_moment_scales")
+    a = _lib.MomentScalesArgs(grad=_lib.ptr(g), n=n, width=width, bits=bits, grad_stride=g.stride(0), anchor=_lib.ptr(padded),
+                              T=padded.numel(), n_anchors=_lib.ptr(n_real), x_abs_max=_lib.ptr(xmax), workspace=_lib.ptr(out[2:]),
+                              workspace_bytes=8, scales=_lib.ptr(out))
+    _lib.check(_lib.lib().gnan_fpwl_moment_scales(a, _lib.stream_of(g)), "gnan_fpwl_moment_scales")
     tiny = torch.finfo(torch.float64).tiny
     g_max = g.abs().max().double().clamp_min(tiny)
     d_max = (xmax + anchor.abs().max().double()).clamp_min(tiny)
@@ -718,9 +719,10 @@ def test_moment_scales_kernel(n, width, gscale):
     assert torch.equal(out[:2].cpu(), want.cpu()), (out[:2], want)
     gn = g.clone()
     gn[n // 2, 0] = float("nan")
-    _lib.check(_lib.lib().gnan_fpwl_moment_scales(_lib.ptr(gn), n, width, gn.stride(0), _lib.ptr(anchor), anchor.numel(),
-                                                  None, _lib.ptr(xmax), bits, _lib.ptr(out[2:]), 8, _lib.ptr(out),
-                                                  _lib.stream_of(g)), "gnan_fpwl_moment_scales")
+    a = _lib.MomentScalesArgs(grad=_lib.ptr(gn), n=n, width=width, bits=bits, grad_stride=gn.stride(0), anchor=_lib.ptr(anchor),
+                              T=anchor.numel(), n_anchors=None, x_abs_max=_lib.ptr(xmax), workspace=_lib.ptr(out[2:]),
+                              workspace_bytes=8, scales=_lib.ptr(out))
+    _lib.check(_lib.lib().gnan_fpwl_moment_scales(a, _lib.stream_of(g)), "gnan_fpwl_moment_scales")
     assert bool(torch.isnan(out[:2]).all())
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the table path's moment kernels on a C4-sized batch (10M nodes x 64 features, H = 64, L = 3):
-    python tools/moments_ab.py [nodes]        GNAN_MOMENTS_GENERAL = 1: the general kernel"""
+    python tools/moments_ab.py [nodes]        functional.MOMENTS_GENERAL: the general kernel"""
 import json
 import os
 import sys
@@ -32,7 +32,7 @@ def main():
         g = torch.randn(N, 1 if sum_features else F, device=DEV)
         ref = None
         for bs in ("1", "0"):
-            os.environ["GNAN_MOMENTS_GENERAL"] = bs
+            functional.MOMENTS_GENERAL = bs == "1"             # gnan_fpwl_args.flags & GNAN_FPWL_MOMENTS_GENERAL
             for _ in range(2):
                 M = functional._fpwl_moments(x, t, g, sum_features, x_abs_max=xm, raw=True)[0]
             torch.cuda.synchronize()
