@@ -108,6 +108,7 @@ class SpmmArgs(C.Structure):
         ("n_long", C.c_int32), ("n_slices", C.c_int32), ("slice_edges", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("s_by_code", C.c_int32), ("nnz", C.c_int64), ("packed_index", C.c_int32),
+        ("hot_lo", C.c_int64), ("hot_rows", C.c_int32),
     ]
 
 
@@ -195,6 +196,7 @@ SYMBOLS = {
     "gnan_colsum_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
+    "gnan_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnan_bfs_dense_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_bfs_dense": (C.c_int, [C.POINTER(BfsDenseArgs), C.c_void_p]),
     "gnan_bfs_khop_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

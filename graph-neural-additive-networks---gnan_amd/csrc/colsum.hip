@@ -118,3 +118,30 @@ extern "C" int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride,
   hipLaunchKernelGGL(colsum_final_kernel, dim3(W), dim3(256), 0, st, partial, blocks, W, total);
   return gnan::check_launch("colsum_final_kernel");
 }
+
+
+// dst[k, :] = src[ids[k], :] for W floats per row: the compact copy of the most listed nodes' operand rows that narrow
+// aggregations read instead of the scattered originals (HopGraph.hot_columns).  The destination usually sits right behind
+// the operand, in room the table look-up left there (functional.feature_mlps(room_rows=...)).
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t src_stride, const int64_t* __restrict__ ids,
+                                                          int64_t k, int W, float* __restrict__ dst) {
+  const int64_t total = k * W;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t r = e / W;
+    dst[e] = src[ids[r] * src_stride + (e - r * W)];
+  }
+}
+}  // namespace
+
+extern "C" int gnan_gather_rows(const float* src, int64_t src_stride, const int64_t* ids, int64_t k, int32_t W, float* dst,
+                                gnan_stream_t stream) {
+  GNAN_REQUIRE(k >= 0 && W >= 1 && src_stride >= W, "gather_rows: bad sizes");
+  if (k == 0) return GNAN_OK;
+  GNAN_REQUIRE(src && ids && dst, "gather_rows: null pointer");
+  int64_t blocks = (k * W + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                     src_stride, ids, k, W, dst);
+  return gnan::check_launch("gather_rows_kernel");
+}

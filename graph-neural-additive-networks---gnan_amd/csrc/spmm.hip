@@ -51,6 +51,8 @@ struct Params {
   const int32_t* long_slice_ptr;
   int n_long, n_slices, slice_edges;
   float* partial;  // [n_slices, 2, W]
+  int64_t hot_lo;  // spmm_hot_kernel: operand rows [hot_lo, hot_lo + hot_n) are served from an LDS copy
+  int hot_n;
 };
 
 __device__ __forceinline__ int64_t load_rowptr(const Params& p, int64_t i) {
@@ -563,6 +565,198 @@ void spmm_kernel(const Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow operand rows (W in {1, 2, 4} floats, the sum-first order of GNAN.py:157: S = f_sums) with the hottest rows in LDS.
+//
+// A W = 1 aggregation is one 4-byte gather per listed pair, and every gather is a request to the L2 (TCC): the kernel
+// sits on the L2 request rate (10M-node R-MAT: 1.1e8 pairs in 1.0 ms = 109 G requests/s; the operand itself is 40 MB and
+// never leaves the Infinity Cache).  A power-law graph sends a large share of those requests to very few rows — the
+// 32 768 most listed of the 10M nodes receive 42 % of the pairs (tools/hot_coverage.py) — and the host already keeps a
+// compact copy of the most listed rows behind the operand, most listed first, with the column ids of the degree-sorted
+// copy pointing there (HopGraph.hot_columns).  This kernel loads the head of that copy (hot_n rows, 64 KB: the 16 384 most
+// listed at W = 1, 32 % of the pairs) into LDS once per workgroup and serves their gathers from there: no L2 request at
+// all for them.  Two 1024-thread workgroups per CU (32 waves, 64 VGPRs: the kernel is as much bound by the latency of its
+// dependent rowptr -> index -> gather chains as by the request rate — with one workgroup and a 128-KB table it LOST 7 %),
+// persistent: each loads the table once and then walks its share of the hub-row slices and of the row blocks (rows are
+// degree-sorted: a round-robin share is balanced).  Sixteen waves = four "virtual" 4-wave workgroups, numbered like the
+// blocks of spmm_kernel for the ordinary rows; hub slices share spmm_kernel's partial-sum layout and its fix-up kernel.
+// 10M-node R-MAT, W = 1: 1.04 -> 0.91 ms.  One lane per row, the same arithmetic per row as spmm_kernel<VEC, 1, false, true, false, true>
+// (weights folded with the rest bucket): ordinary rows come out bit-identical, hub rows add their pairs in another order.
+// ---------------------------------------------------------------------------------------------
+// Branch-free: a divergent `if (hot) ds_read else global_load` makes the compiler wait at every join, i.e. one gather in
+// flight per lane (measured: 1.46 ms against 1.04 ms for the plain kernel).  Both loads are always issued — the hot lanes
+// of the global load all read row hot_lo (one line: a single request per wavefront, an L1 hit), the cold lanes of the LDS
+// read all read entry 0 (a broadcast) — and the value is selected afterwards.
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> hot_gather(const Params& p, const float* hot, int c) {
+  const int64_t r = static_cast<int64_t>(c) - p.hot_lo;
+  const bool is_hot = r >= 0 && r < p.hot_n;
+  const Vec<VEC> g = load_vec<VEC>(static_cast<const float*>(p.S) + (is_hot ? p.hot_lo : static_cast<int64_t>(c)) * VEC);
+  const int rl = is_hot ? static_cast<int>(r) : 0;
+  Vec<VEC> l;
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(hot + rl * 4);
+    l.v[0] = t.x; l.v[1] = t.y; l.v[2] = t.z; l.v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(hot + rl * 2);
+    l.v[0] = t.x; l.v[1] = t.y;
+  } else {
+    l.v[0] = hot[rl];
+  }
+  Vec<VEC> out;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) out.v[v] = is_hot ? l.v[v] : g.v[v];
+  return out;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))     // two workgroups = 32 waves per CU
+void spmm_hot_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float hot[];        // [hot_n * VEC]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int sub = wave >> 2, w4 = wave & 3;                           // virtual 4-wave workgroup, wave inside it
+  {
+    const float* src = static_cast<const float*>(p.S) + p.hot_lo * p.s_stride;      // rows are contiguous: s_stride == W
+    for (int i = tid; i < p.hot_n * VEC; i += 1024) hot[i] = src[i];
+  }
+  __syncthreads();
+  const int rest = p.D - 1;
+
+  // ---- hub-row slices: one WAVE per slice, a contiguous run of slices per wave -----------------------------------------
+  // (a workgroup per slice as in spmm_kernel would leave 4 slices in flight per CU, and every slice starts with a chain of
+  // dependent loads — which hub row, its bounds, its weights: 45 rounds of that chain cost 0.6 ms.  A wave walks its run
+  // front to back, so the row of the next slice is found by stepping, not by searching; no barriers.  The partial sums of
+  // a slice are added in lane order by a fixed butterfly: deterministic, though not in spmm_kernel's order.)
+  {
+    const int n_waves = static_cast<int>(gridDim.x) * 16;
+    const int per = (p.n_slices + n_waves - 1) / n_waves;
+    const int gw = static_cast<int>(blockIdx.x) * 16 + wave;
+    const int s_lo = gw * per, s_hi = s_lo + per < p.n_slices ? s_lo + per : p.n_slices;
+    int a = 0;
+    if (s_lo < s_hi) {
+      int b = p.n_long;
+      while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (p.long_slice_ptr[mid] <= s_lo) a = mid; else b = mid;
+      }
+    }
+    for (int sidx = s_lo; sidx < s_hi; ++sidx) {
+      while (p.long_slice_ptr[a + 1] <= sidx) ++a;
+      const int64_t q = p.long_rows[a];
+      const int64_t i = adj_row(p, q);
+      const int64_t row_lo = load_rowptr(p, i), row_hi = load_rowptr(p, i + 1);
+      const int64_t lo = row_lo + static_cast<int64_t>(sidx - p.long_slice_ptr[a]) * p.slice_edges;
+      const int64_t hi = lo + p.slice_edges < row_hi ? lo + p.slice_edges : row_hi;
+      const SmallW sw = small_weights(p, i);
+      Vec<VEC> acc, all;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc.v[v] = all.v[v] = 0.f;
+      constexpr int SF = 8;                              // pairs in flight per lane
+      for (int64_t base = lo + lane; base < hi; base += SF * kWave) {
+        unsigned ce[SF];
+#pragma unroll
+        for (int k = 0; k < SF; ++k) {
+          const int64_t e = base + static_cast<int64_t>(k) * kWave;
+          ce[k] = e < hi ? static_cast<unsigned>(p.col[e]) : 0u;
+        }
+        // no branch around a gather (a guarded region ends in s_waitcnt 0: one gather in flight): pairs past the end read the
+        // first hot row — an LDS hit, no request — and are dropped by a select
+        Vec<VEC> sv[SF];
+#pragma unroll
+        for (int k = 0; k < SF; ++k) {
+          const bool ok = base + static_cast<int64_t>(k) * kWave < hi;
+          sv[k] = hot_gather<VEC>(p, hot, ok ? static_cast<int>(ce[k] & kPackMask) : static_cast<int>(p.hot_lo));
+        }
+#pragma unroll
+        for (int k = 0; k < SF; ++k) {
+          const bool ok = base + static_cast<int64_t>(k) * kWave < hi;
+          int d = static_cast<int>(ce[k] >> kPackShift);
+          d = d < rest ? d : rest;
+          const float w = sw.pick(d);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            acc.v[v] = ok ? fmaf(w, sv[k].v[v], acc.v[v]) : acc.v[v];
+            all.v[v] = ok ? all.v[v] + sv[k].v[v] : all.v[v];
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          acc.v[v] += __shfl_xor(acc.v[v], off);
+          all.v[v] += __shfl_xor(all.v[v], off);
+        }
+      }
+      if (lane == 0) {
+        float* out = p.partial + static_cast<int64_t>(sidx) * 2 * p.W;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          out[v] = acc.v[v];
+          out[p.W + v] = all.v[v];
+        }
+      }
+    }
+  }
+
+  // ---- ordinary rows: virtual workgroup = 256 rows, one lane per row (as rows_body<VEC, 1, false, true, false, true>) ----
+  const int64_t n_vblocks = (p.n_rows + 255) / 256;
+  for (int64_t vb = static_cast<int64_t>(blockIdx.x) * 4 + sub; vb < n_vblocks; vb += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t q = (vb * 4 + w4) * kWave + lane;
+    if (q >= p.n_rows) continue;
+    const int64_t i = adj_row(p, q);
+    const int64_t lo = load_rowptr(p, i), hi = load_rowptr(p, i + 1);
+    if (hi - lo > p.long_threshold) continue;           // hub row: sliced above
+    SmallW sw = small_weights(p, i);
+    float w_rest = 0.f;
+    if (p.s_total) {
+      w_rest = sw.pick(rest);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) sw.w[d] = d < rest ? sw.w[d] - w_rest : 0.f;
+    }
+    Vec<VEC> acc;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc.v[v] = 0.f;
+    for (int64_t base = lo; base < hi; base += 16) {
+      int colv[16];
+      if (base + 16 <= p.nnz) {
+        load_col_run<16>(p.col + base, colv);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) colv[r] = base + r < hi ? p.col[base + r] : 0;
+      }
+      const int m = static_cast<int>(hi - base < 16 ? hi - base : 16);
+      constexpr int FLY = VEC == 1 ? 8 : (VEC == 2 ? 4 : 2);      // gathers in flight per lane (64 VGPRs: 8 waves per SIMD)
+#pragma unroll
+      for (int j0 = 0; j0 < 16; j0 += FLY) {
+        if (j0 >= m) break;
+        Vec<VEC> sv[FLY];
+        int d[FLY];
+#pragma unroll
+        for (int u = 0; u < FLY; ++u) {
+          const unsigned ce = static_cast<unsigned>(colv[j0 + u]);
+          d[u] = static_cast<int>(ce >> kPackShift);
+          d[u] = d[u] < rest ? d[u] : rest;
+          // (no branch around a gather, see the slice loop: entries past the row end read the first hot row from LDS)
+          sv[u] = hot_gather<VEC>(p, hot, j0 + u < m ? static_cast<int>(ce & kPackMask) : static_cast<int>(p.hot_lo));
+        }
+#pragma unroll
+        for (int u = 0; u < FLY; ++u) {
+          const float w = sw.pick(d[u]);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc.v[v] = j0 + u < m ? fmaf(w, sv[u].v[v], acc.v[v]) : acc.v[v];
+        }
+      }
+    }
+    if (p.s_total) {
+      const Vec<VEC> tot = load_vec<VEC>(p.s_total);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w_rest, tot.v[v], acc.v[v]);
+    }
+    store_vec<VEC>(p.Y + out_row(p, q, i) * p.y_stride, acc);
+  }
+}
+
 // fix-up: add a hub row's slices in a fixed order, apply the rest-bucket term, store the row.
 // One WAVE per hub row, four rows per workgroup, no barriers: a power-law graph has tens of thousands of hub rows with
 // one or two slices each (R-MAT 10M/100M: 33 068 rows, 45 284 slices, at most 114 per row), so a workgroup per row was
@@ -625,6 +819,44 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
     }
   }
   if (p.reduce_cr && lane < p.reduce_cr) p.Y[out_row(p, q, i) * p.y_stride + lane] = chan;
+}
+
+constexpr int kHotLdsFloats = 16384;   // 64 KB of hot operand rows per workgroup: two workgroups per CU
+
+// can the persistent hot-row kernel take this call?  (what the host wrapper sets up: functional.spmm_launch, narrow walk)
+bool hot_kernel_applies(const gnan_spmm_args* a) {
+  auto aligned = [](const void* ptr, size_t n) { return (reinterpret_cast<uintptr_t>(ptr) % n) == 0; };
+  const int W = a->W;
+  return a->hot_rows > 0 && a->rowptr != nullptr && a->packed_index && a->s_dtype == GNAN_F32 && (W == 1 || W == 2 || W == 4) &&
+         a->s_stride == W && a->Cw == 1 && a->D <= 4 && !a->weight_by_col && !a->minus_rest && !a->s_by_code && a->reduce_cr == 0 &&
+         aligned(a->S, 16) && aligned(a->Y, 4 * static_cast<size_t>(W)) && a->y_stride % W == 0 &&
+         (!a->s_total || aligned(a->s_total, 4 * static_cast<size_t>(W))) && a->hot_lo >= 0 &&
+         a->hot_lo + a->hot_rows <= a->n_cols && static_cast<int64_t>(a->hot_rows) * W <= kHotLdsFloats && a->nnz > 0;
+}
+
+template <int VEC>
+int launch_hot(const Params& p, hipStream_t st) {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  const size_t lds = static_cast<size_t>(p.hot_n) * VEC * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_hot_kernel<VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(kHotLdsFloats * sizeof(float)));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "spmm_hot: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  hipLaunchKernelGGL((spmm_hot_kernel<VEC>), dim3(static_cast<unsigned>(cus) * 2), dim3(1024), lds, st, p);
+  if (int rc = gnan::check_launch("spmm_hot_kernel")) return rc;
+  if (p.n_slices > 0) {
+    hipLaunchKernelGGL(spmm_long_fixup_kernel, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p);
+    if (int rc = gnan::check_launch("spmm_long_fixup_kernel")) return rc;
+  }
+  return GNAN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -846,6 +1078,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.n_slices = a->n_long > 0 ? a->n_slices : 0;
   p.slice_edges = a->slice_edges;
   p.partial = static_cast<float*>(a->workspace);
+  p.hot_lo = a->hot_lo; p.hot_n = a->hot_rows;
   return p;
 }
 
@@ -1518,5 +1751,7 @@ extern "C" int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream) {
     while (lpr * 8 < a->W && lpr < kWave) lpr <<= 1;
     return launch_lpr<8>(p, lpr, false, smalld, st);
   }
+  if (smalld && hot_kernel_applies(a))                // narrow rows, hottest operand rows in LDS (persistent workgroups)
+    return a->W == 1 ? launch_hot<1>(p, st) : (a->W == 2 ? launch_hot<2>(p, st) : launch_hot<4>(p, st));
   return vec == 4 ? launch_lpr<4>(p, lpr, dense, smalld, st) : launch_lpr<1>(p, lpr, dense, smalld, st);
 }

@@ -158,7 +158,15 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         per = _fpwl_launch(x, t, False)
         out = per.view(n, F, C).sum(dim=1)
         return (out, None) if want_total else out
-    out = torch.empty((n, C if sum_features else F * C), dtype=out_dtype, device=x.device)
+    global _ROOM_RESULT
+    if sum_features and _ROOM_REQUEST and out_dtype == torch.float32:
+        # room behind the rows for the compact copy of the most listed nodes' rows (append_hot_rows): the aggregation then
+        # gathers the copy into place instead of copying the whole operand into a larger buffer first (40 MB at 10M nodes)
+        room = torch.empty((n + _ROOM_REQUEST, C), dtype=out_dtype, device=x.device)
+        out = room[:n]
+        _ROOM_RESULT = (out.data_ptr(), room)
+    else:
+        out = torch.empty((n, C if sum_features else F * C), dtype=out_dtype, device=x.device)
     if out_dtype == torch.float32 and _fpwl_rows_applies(n, C, t, bins=False):
         a = _fpwl_args(x, t, sum_features, out)
         piece, dx = _fpwl_locate(x, t, a)
@@ -195,6 +203,8 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     return (out, total) if want_total else out
 
 
+_ROOM_REQUEST = 0             # rows of room feature_mlps(room_rows=...) asks the table look-up to leave behind its [n, C] result
+_ROOM_RESULT = None           # (data_ptr of the result, the larger buffer it heads) of the last look-up that did
 CAPTURED_BUILDS = []          # (sizes a look-up was captured with, the stacked weights it tabulates) of the capture in progress
 CAPTURE_PINS = None           # list while graphed.GraphedCallable captures: cache-owned tensors the captured step reads
 
@@ -709,7 +719,28 @@ def _padded_stack(p: StackedMLP, Fp: int) -> StackedMLP:
 
 
 def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False,
-                 out_dtype=torch.float32, total_rows: Optional[int] = None, pad_ok: bool = False, tables=None):
+                 out_dtype=torch.float32, total_rows: Optional[int] = None, pad_ok: bool = False, tables=None,
+                 room_rows: int = 0):
+    """See :func:`_feature_mlps`.  ``room_rows`` (with ``sum_features``): the ``[n, C]`` result may head a buffer with that
+    many more rows — marked by its ``gnan_room`` attribute — which :func:`rho_aggregate` fills with the compact copy of the
+    most listed nodes' rows instead of copying the operand (``append_hot_rows``)."""
+    global _ROOM_REQUEST, _ROOM_RESULT
+    if not (room_rows and sum_features):
+        return _feature_mlps(x, p, sum_features, return_total, out_dtype, total_rows, pad_ok, tables)
+    _ROOM_REQUEST, _ROOM_RESULT = int(room_rows), None
+    try:
+        res = _feature_mlps(x, p, sum_features, return_total, out_dtype, total_rows, pad_ok, tables)
+    finally:
+        _ROOM_REQUEST = 0
+    out = res[0] if return_total else res
+    if _ROOM_RESULT is not None and _ROOM_RESULT[0] == out.data_ptr() and out.shape[0] + room_rows == _ROOM_RESULT[1].shape[0]:
+        out.gnan_room = _ROOM_RESULT[1]
+    _ROOM_RESULT = None
+    return res
+
+
+def _feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False,
+                  out_dtype=torch.float32, total_rows: Optional[int] = None, pad_ok: bool = False, tables=None):
     """``fx[n, k*C + c] = f_k(x[n, k])[c]`` or, with ``sum_features``, ``sum_k f_k(x[n, k])`` — GNAN.py:57-62,157.
     ``return_total`` additionally returns the column sums of the result (the aggregation's rest-bucket operand),
     fused into the look-up kernel where possible.  ``out_dtype=torch.bfloat16`` stores the per-feature rows in bf16
@@ -741,7 +772,7 @@ def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_tota
         # problem is padded to a multiple of 16 features with all-zero shape functions instead: x once per (static)
         # feature matrix, the stacked weights per call (a few tiny concatenations autograd sees through).
         Fp = (p.F + PAD_FEATURES - 1) // PAD_FEATURES * PAD_FEATURES
-        res = feature_mlps(_padded_x(x, Fp), _padded_stack(p, Fp), sum_features, return_total, out_dtype, total_rows)
+        res = _feature_mlps(_padded_x(x, Fp), _padded_stack(p, Fp), sum_features, return_total, out_dtype, total_rows)
         if sum_features or pad_ok:              # [n, C] either way; or the caller takes the zero columns along
             return res
         if return_total:
@@ -756,7 +787,7 @@ def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_tota
 # =============================================================================
 def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut, weight_by_col=False,
                minus_rest=False, plan=None, workspace=None, reduce_cr=0, scatter_out=False,
-               s_by_code=False, packed=False) -> _lib.SpmmArgs:
+               s_by_code=False, packed=False, hot_rows=0) -> _lib.SpmmArgs:
     D, Cw = lut.shape[-2], lut.shape[-1]
     # one index stream (col | code << 29) where the graph carries it and the kernel variant reads it (gnan_hip.h)
     packed = bool(packed and PACKED_INDEX and g.colp is not None and D <= 4 and Cw == 1 and not weight_by_col
@@ -779,6 +810,10 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         workspace=_lib.ptr(workspace), workspace_bytes=(workspace.numel() * 4 if workspace is not None else 0),
         s_by_code=int(s_by_code), nnz=(0 if (g.col is None or not WIDE_INDEX_LOADS) else int(g.col.numel())),
         packed_index=int(packed))
+    if hot_rows and packed and HOT_ROWS_IN_LDS:
+        # the appended compact copy of the most listed rows sits behind the real ones: its head is served from LDS
+        W = S.shape[1]
+        a.hot_lo, a.hot_rows = g.n_cols - int(hot_rows), min(int(hot_rows), HOT_LDS_FLOATS // max(W, 1))
     return a
 
 
@@ -810,14 +845,25 @@ NARROW_SORTED_MIN_NNZ = 1 << 23   # below ~8M pairs the sorted walk's tail (the 
                                    # more than the divergence they remove (arxiv-shaped, 1.3M pairs: 11.6 -> 26 us at W = 1)
 NARROW_SORTED_WALK = os.environ.get("GNAN_NARROW_SORTED", "1") != "0"   # narrow operand rows walk the degree-sorted copy too
 HOT_COLUMN_ROWS = os.environ.get("GNAN_HOT_COLUMNS", "1") != "0"        # ... and read the most listed neighbours from a compact copy
+HOT_ROWS_IN_LDS = os.environ.get("GNAN_HOT_LDS", "1") != "0"           # ... and serve the head of that copy from LDS (spmm_hot_kernel)
+HOT_LDS_FLOATS = 16384                                                   # 64 KB per workgroup, two workgroups per CU
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
 
 
-def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1) -> torch.Tensor:
+def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1, room: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``S`` ([n * group, W], ``group`` consecutive rows per node) followed by the rows of the nodes ``hot``: the operand of
-    a graph whose column ids point hot neighbours at ``n + rank`` (``HopGraph.hot_columns``)."""
+    a graph whose column ids point hot neighbours at ``n + rank`` (``HopGraph.hot_columns``).  ``room``: a buffer whose first
+    rows ARE ``S`` with space for the copy behind them (``feature_mlps(room_rows=...)``): the copy is gathered in place."""
     W = S.shape[1]
     n = S.shape[0] // group
+    if (room is not None and group == 1 and room.data_ptr() == S.data_ptr() and room.shape[1] == W and room.dtype == S.dtype
+            and room.is_contiguous() and S.is_contiguous() and room.shape[0] >= n + hot.numel()):
+        # written through the library, not through torch: S is an autograd Function's output heading `room`, and a tracked
+        # in-place write into its base would (rightly, in general) invalidate it for the backward pass — these rows are not S
+        h = hot.to(torch.int64).contiguous()
+        _lib.check(_lib.lib().gnan_gather_rows(_lib.ptr(S), S.stride(0), _lib.ptr(h), int(h.numel()), W,
+                                               room.data_ptr() + n * W * 4, _lib.stream_of(S)), "gnan_gather_rows")
+        return room[: n + hot.numel()]
     ext = torch.empty(((n + hot.numel()) * group, W), dtype=S.dtype, device=S.device)
     ext[: n * group].copy_(S)
     torch.index_select(S.contiguous().view(n, group * W), 0, hot, out=ext[n * group:].view(hot.numel(), group * W))
@@ -827,7 +873,7 @@ def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1) -> torch
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_cnt: bool, with_rest: bool,
                 row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
                 minus_rest: bool = False, s_total: Optional[torch.Tensor] = None, reduce_cr: int = 0,
-                s_by_code: bool = False, lut_of_counts=None, lut_channels: int = 1) -> torch.Tensor:
+                s_by_code: bool = False, lut_of_counts=None, lut_channels: int = 1, room=None) -> torch.Tensor:
     """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``.
     ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns.
     ``s_by_code``: ``S`` is ``[n_cols * D, W]`` and the pair with neighbour ``c`` and hop code ``d`` reads row ``c*D + d``.
@@ -861,6 +907,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
     if not with_rest:
         s_total = None
     scatter = False
+    n_hot = 0
     narrow = S.shape[1] * S.element_size() <= 8        # one or two lanes per row: see LONG_ROW_THRESHOLD_NARROW
     if g.is_dense:
         # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
@@ -874,7 +921,8 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
         g, row_ids, hot = narrow_walk(g)
         plan = g.narrow_row_plan() if (narrow and NARROW_ROW_SLICING) else g.long_row_plan()
         if hot is not None:
-            S = append_hot_rows(S, hot, g.n_codes if s_by_code else 1)
+            S = append_hot_rows(S, hot, g.n_codes if s_by_code else 1, room=room)
+            n_hot = 0 if s_by_code else int(hot.numel())
         scatter = 2
     elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
         # (a table indexed by COLUMN — the wide backward's per-node weights — does not care in which order the rows are walked)
@@ -891,7 +939,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
         lut = lut_of_counts(g.cnt).detach().float().contiguous()          # rows of THIS graph (a sorted copy carries its own counts)
         per_row = True
     a = _spmm_args(g, S, lut, use_cnt, s_total, out, row_ids, per_row, weight_by_col, minus_rest, plan,
-                   reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code, packed=True)
+                   reduce_cr=reduce_cr, scatter_out=scatter, s_by_code=s_by_code, packed=True, hot_rows=n_hot)
     need = _lib.lib().gnan_spmm_fwd_workspace_bytes(a)
     ws = None
     if need:
@@ -1040,7 +1088,8 @@ class _RhoAggregate(torch.autograd.Function):
         ctx.s_total = None if s_total is None else s_total.detach()
         ctx.total_rows, ctx.total_group = total_rows, total_group
         ctx.save_for_backward(S, lut)
-        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr)
+        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr,
+                           room=getattr(S, "gnan_room", None))
 
     @staticmethod
     def backward(ctx, dY):
@@ -1174,7 +1223,7 @@ class _PreRhoAggregate(torch.autograd.Function):
         ctx.tables, ctx.u, ctx.meta = tables, u, (L, H, C)
         ctx.present = [t is not None for t in params]
         ctx.save_for_backward(S, *[t for t in params if t is not None])
-        return spmm_launch(g, S, None, False, with_rest, row_ids, s_total=s_total,
+        return spmm_launch(g, S, None, False, with_rest, row_ids, s_total=s_total, room=getattr(S, "gnan_room", None),
                            lut_of_counts=lambda cnt: _rho_row_lut_launch(cnt, u, tables, C, False)[0], lut_channels=C)
 
     @staticmethod

@@ -201,7 +201,7 @@ class _PathBase(nn.Module):
         return bool(self.training and self.dropout and self.dropout > 0)
 
     def _features(self, x, name, mlps, sum_features: bool, pad_ok: bool = False, want_total: bool = False,
-                  out_dtype=torch.float32):
+                  out_dtype=torch.float32, room_rows: int = 0):
         """Shape functions of all features: fused HIP kernels, or the Dropout cold path described above.
         ``pad_ok``: the per-feature result may carry extra all-zero columns (``functional.feature_mlps``).
         ``want_total``: returns ``(rows, column sums or None)`` — the rest bucket's operand comes out of the look-up pass
@@ -212,15 +212,23 @@ class _PathBase(nn.Module):
             out = _fmlp_eager(x.float(), stack_mlps(mlps), sum_features, dropout=float(self.dropout))
             return (out, None) if want_total else out
         kw = {} if out_dtype == torch.float32 else {"out_dtype": out_dtype}
+        if room_rows:
+            kw["room_rows"] = room_rows
         return feature_mlps(x, self._stacked(name, mlps), sum_features=sum_features, pad_ok=pad_ok,
                             return_total=want_total, **kw)
 
-    def _operand(self, x, name, mlps, sum_features: bool, with_total: bool, pad_ok: bool = False, out_dtype=torch.float32):
+    def _operand(self, x, name, mlps, sum_features: bool, with_total: bool, pad_ok: bool = False, out_dtype=torch.float32,
+                 graph: Optional[HopGraph] = None):
         """``(rows, column sums)`` of the shape functions — the sums are ``None`` unless ``with_total`` (a CSR's rest bucket
-        needs them; a dense adjacency lists every pair)."""
+        needs them; a dense adjacency lists every pair).  ``graph``: the graph the rows will be aggregated over — a large
+        CSR wants room behind narrow rows for the compact copy of its most listed nodes' rows (``HopGraph.hot_columns``)."""
+        room = 0
+        if sum_features and graph is not None and not graph.is_dense and not self._dropout_active():
+            from .graph import HOT_COLUMNS, HOT_COLUMNS_MIN_NNZ
+            room = HOT_COLUMNS if graph.nnz >= HOT_COLUMNS_MIN_NNZ else 0
         if not with_total:
-            return self._features(x, name, mlps, sum_features, pad_ok=pad_ok, out_dtype=out_dtype), None
-        return self._features(x, name, mlps, sum_features, pad_ok=pad_ok, want_total=True, out_dtype=out_dtype)
+            return self._features(x, name, mlps, sum_features, pad_ok=pad_ok, out_dtype=out_dtype, room_rows=room), None
+        return self._features(x, name, mlps, sum_features, pad_ok=pad_ok, want_total=True, out_dtype=out_dtype, room_rows=room)
 
     def _mark(self, name: str) -> None:
         """Stage boundary of a forward (``start`` / ``lut`` / ``fmlp`` / ``spmm``): ``stage_hook`` — unset by default — is
@@ -262,8 +270,10 @@ class _PathBase(nn.Module):
 
     # ---- rho on the distinct distances -------------------------------------------------------
     def _lut_global(self, g: HopGraph) -> torch.Tensor:
-        """``lut[d] = rho(float32(1/(1+d)))``, ``lut[D-1] = rho(0)`` — D rows instead of N^2 (models.py:368)."""
-        return self.rho(hop_inputs(g.n_codes, g.device).view(-1, 1))
+        """``lut[d] = rho(float32(1/(1+d)))``, ``lut[D-1] = rho(0)`` — D rows instead of N^2 (models.py:368).  One launch of
+        the shape-function kernel on rho's stacked layers (and one of ``gnan_fmlp_bwd`` in the backward pass) instead of the
+        six to ten framework launches of ``self.rho(...)`` — 0.04 ms of a 2-ms forward on the 10M-node graph."""
+        return feature_mlps(hop_inputs(g.n_codes, g.device).view(-1, 1), self._stacked("rho", [self.rho]), sum_features=False)
 
     def _lut_pre_rho(self, g: HopGraph) -> torch.Tensor:
         """``lut[i, d] = rho(u_d / cnt[i, d])`` — the pre-rho normalisation of GNAN.py:65-67, per shell: rho's exact
@@ -309,7 +319,7 @@ class StandaloneTensorGNAN(_PathBase):
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
         lut = None if self.normalize_rho else self._lut_global(g)
         self._mark("lut")
-        S, total = self._operand(x, "fs", self.fs, True, not g.is_dense)             # [N, C]
+        S, total = self._operand(x, "fs", self.fs, True, not g.is_dense, graph=g)    # [N, C]
         self._mark("fmlp")
         if self.normalize_rho:
             # GNAN.py:65-67: rho(node_distances / normalization_matrix) — rho's exact table, D look-ups per row, in the
@@ -360,7 +370,7 @@ class _GNANCore(_PathBase):
         g = self._graph(inputs, want_norm=True)            # GNAN.py:161 reads it unconditionally
         lut = self._lut_global(g)
         self._mark("lut")
-        S, total = self._operand(x, "fs", self.fs, True, not g.is_dense)             # f_sums, GNAN.py:157
+        S, total = self._operand(x, "fs", self.fs, True, not g.is_dense, graph=g)    # f_sums, GNAN.py:157
         self._mark("fmlp")
         rows = None
         if node_ids is not None:
@@ -468,7 +478,7 @@ class TensorGNAN(_PathBase):
             self._mark("fmlp")
             Y = rho_aggregate(g, fx, lut, use_cnt, s_total=total, reduce_channels=self.actual_output_dim_f)   # [N, C]
         else:
-            S, total = self._operand(x, "fs", self.fs, True, rest)                    # [N, C]  sum-first
+            S, total = self._operand(x, "fs", self.fs, True, rest, graph=g)           # [N, C]  sum-first
             self._mark("fmlp")
             Y = rho_aggregate(g, S, lut, use_cnt, s_total=total)                      # [N, C]
         self._mark("spmm")

@@ -401,6 +401,10 @@ typedef struct gnan_spmm_args {
   int32_t packed_index;          /* gnan_spmm_fwd only: every col entry is  column | hop code << 29  and `code` is not read (may be
                                   * NULL): one index stream instead of two.  CSR layout, n_cols <= 2^29, D <= 4, Cw == 1, no
                                   * weight_by_col / minus_rest / s_by_code (GNAN_ERR_UNSUPPORTED otherwise) */
+  int64_t hot_lo;                /* gnan_spmm_fwd, narrow fp32 rows (W in {1, 2, 4}, packed index): operand rows [hot_lo, hot_lo +  */
+  int32_t hot_rows;              /* hot_rows) are the most listed neighbours' rows, most listed first, and the column ids of their
+                                  * pairs point there (a compact copy behind the operand).  hot_rows > 0 lets the library serve them
+                                  * from LDS (persistent workgroups, hot_rows * W <= 32768 floats); 0 = off.  Same output bits */
 } gnan_spmm_args;
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
@@ -420,6 +424,11 @@ int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream);
 size_t gnan_colsum_workspace_bytes(int32_t W);
 int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                 size_t workspace_bytes, gnan_stream_t stream);
+/* dst[k, :] = src[ids[k], :] (W fp32 columns, dst rows contiguous; ids int64 in device memory): the compact second copy of
+ * the most listed nodes' operand rows behind the operand, which gnan_spmm_args.hot_lo / hot_rows describe. */
+int gnan_gather_rows(const float* src, int64_t src_stride, const int64_t* ids, int64_t k, int32_t W, float* dst,
+                     gnan_stream_t stream);
+
 /* same for bf16 operand rows (stride in elements, W % 4 == 0, 8-B aligned rows) */
 int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                      size_t workspace_bytes, gnan_stream_t stream);

@@ -1068,7 +1068,15 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
         out[tag] = spmm_launch(g, S, lut, not s_by_code, not s_by_code, s_by_code=s_by_code)
     assert g._sorted_copy_hot is not None and g._sorted_copy_hot.n_cols == n + 64
     assert int((g._sorted_copy_hot.col >= n).sum()) >= int(hot.sum())
-    assert torch.equal(out["natural"], out["sorted"]) and torch.equal(out["natural"], out["hot"])
+    assert torch.equal(out["natural"], out["sorted"])
+    # W in {1, 2, 4} with the hot copy: spmm_hot_kernel (the head of the copy in LDS, persistent workgroups) — ordinary rows
+    # bit for bit, hub rows add their pairs wave by wave instead of workgroup by workgroup
+    hub = torch.from_numpy(np.diff(rowptr) > 64).to(DEV)                  # (narrow rows: sliced from 64 pairs, graph.LONG_ROW_THRESHOLD_NARROW)
+    assert torch.equal(out["natural"][~hub], out["hot"][~hub])
+    assert O.rel_err(out["hot"].cpu(), out["natural"].cpu().double()) <= 2e-6
+    if W in (1, 2, 4) and not s_by_code:
+        monkeypatch.setattr(functional, "HOT_ROWS_IN_LDS", False)
+        assert torch.equal(spmm_launch(g, S, lut, True, True), out["natural"])            # the plain kernel on the same copy
     if not s_by_code:
         wt = lut.cpu().double().unsqueeze(0) / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
         want = O.spmm_csr(rowptr, col, code, S.cpu().double(), wt, with_rest=True)
@@ -1141,8 +1149,14 @@ def test_aggregation_paths_agree_on_random_shapes(seed, monkeypatch):
         monkeypatch.setattr(functional, "PACKED_INDEX", packed)
         monkeypatch.setattr(functional, "WIDE_INDEX_LOADS", wide)
         out.append(spmm_launch(g, S, lut, use_cnt, with_rest))
-    for y in out[1:]:
-        assert torch.equal(out[0], y)
+    sliced = torch.from_numpy(np.diff(rowptr) > 64).to(DEV)     # rows some plan may slice (narrow rows: from 64 pairs)
+    for k, y in enumerate(out[1:]):
+        if k == 1 and W in (1, 2, 4):
+            # hot rows + packed index at W in {1, 2, 4}: spmm_hot_kernel — ordinary rows bit for bit, hub rows (added wave by
+            # wave there) to round-off
+            assert torch.equal(out[0][~sliced], y[~sliced]) and O.rel_err(y.cpu(), out[0].cpu().double()) <= 2e-6
+        else:
+            assert torch.equal(out[0], y)
     wt = lut.cpu().double().unsqueeze(0).expand(n, -1, -1)
     if use_cnt:
         wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)

