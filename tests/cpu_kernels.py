@@ -23,8 +23,10 @@ def column_sums(S):
 
 
 def spmm_launch(g, S, lut, use_cnt, with_rest, row_ids=None, weight_by_col=False, minus_rest=False, s_total=None,
-                reduce_cr=0, s_by_code=False):
+                reduce_cr=0, s_by_code=False, lut_of_counts=None, lut_channels=1, room=None):
     assert not g.is_dense
+    if lut is None:
+        lut = lut_of_counts(g.cnt)
     S, lut = S.detach().double(), lut.detach().double()
     D, Cw = lut.shape[-2], lut.shape[-1]
     per_row = lut.dim() == 3
