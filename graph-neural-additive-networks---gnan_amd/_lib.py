@@ -139,7 +139,7 @@ class SpmmBwdNarrowArgs(C.Structure):
     _fields_ = [
         ("spmm", SpmmArgs), ("s_rows", C.c_void_p), ("s_rows_stride", C.c_int64), ("w_real", C.c_int32),
         ("with_rest", C.c_int32), ("dS", C.c_void_p), ("ds_stride", C.c_int64), ("dlut", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("ds_add", C.c_void_p),
     ]
 
 

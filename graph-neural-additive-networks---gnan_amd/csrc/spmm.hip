@@ -1124,6 +1124,7 @@ struct GradParams {
   float* dS;             // [n_rows, w_real]
   int64_t ds_stride;
   int with_rest;
+  const float* ds_add;   // optional [w_real]: added to every row of dS (the rest bucket's column-sum term)
 };
 
 // BWD epilogue of one row for this lane's VEC columns: lanes of the first half hold A_d = sum over the row's code-d pairs
@@ -1159,6 +1160,7 @@ __device__ __forceinline__ void bwd_finish(const Params& p, const GradParams& gp
         ds = fmaf(-p.lut[rest], q, ds);
         pd[rest & 3] = fmaf(-sj, q, pd[rest & 3]);
       }
+      if (gp.ds_add) ds += gp.ds_add[w];
       gp.dS[oq * gp.ds_stride + w] = ds;
     }
   }
@@ -1431,6 +1433,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
           ds = fmaf(-p.lut[rest], qv, ds);
           pd[rest & 3] -= static_cast<double>(sj) * qv;
         }
+        if (gp.ds_add) ds += gp.ds_add[w];
         gp.dS[oq * gp.ds_stride + w] = ds;
       }
     } else if (k == 0 && w < p.W) {
@@ -1589,6 +1592,7 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* g, gnan_stream_
   pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
   GradParams gp;
   gp.dY = dY; gp.dy_stride = dy_stride; gp.dy_channels = dy_channels; gp.dwt = dwt; gp.reduce_rows = reduce_rows;
+  gp.ds_add = nullptr;
   gp.slice_T = static_cast<float*>(workspace);
   size_t off = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
   off = (off + 15) / 16 * 16;   // the final reduction reads 16-byte halves of the [4] records
@@ -1704,7 +1708,7 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* g, gnan_str
   gp.blk = reinterpret_cast<double*>(static_cast<char*>(workspace) + off);
   gp.n_row_blocks = 0;
   gp.s_rows = s_rows; gp.s_rows_stride = s_rows_stride; gp.half = half; gp.w_real = w_real;
-  gp.dS = dS; gp.ds_stride = ds_stride; gp.with_rest = with_rest;
+  gp.dS = dS; gp.ds_stride = ds_stride; gp.with_rest = with_rest; gp.ds_add = g->ds_add;
   switch (half) {      // one lane per row while a row is one 8- or 16-byte load (64 rows per wavefront instead of 32)
     case 1: return launch_lut_grad<2, 1, true>(p, gp, st, dlut);
     case 2: return launch_lut_grad<4, 1, true>(p, gp, st, dlut);

@@ -1036,7 +1036,7 @@ def narrow_walk(g: HopGraph):
 
 
 def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int,
-                      walk=None):
+                      walk=None, ds_add: Optional[torch.Tensor] = None):
     """``gnan_spmm_bwd_narrow`` over the transposed adjacency ``gt``: returns ``(dS [n, W], dlut [D])`` — see the header for
     the layout of ``V [D * n_fwd_rows, 2 * half]`` (code-major).  ``walk = narrow_walk(gt)`` when the caller has already put the hot
     rows behind ``V`` (``pack_bwd_rows(hot=...)``)."""
@@ -1061,7 +1061,8 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
     a.n_cols = gt.n_cols                              # rows of V = n_cols * D (checked by the kernel's addressing only)
     a.y_stride = V.shape[1]                           # Y is not written by this entry point (dS is); keeps validate() content
     na = _lib.SpmmBwdNarrowArgs(spmm=a, s_rows=_lib.ptr(S_rows), s_rows_stride=S_rows.stride(0), w_real=W,
-                                with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0), dlut=_lib.ptr(dlut))
+                                with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0), dlut=_lib.ptr(dlut),
+                                ds_add=None if ds_add is None else _lib.ptr(ds_add))
     need = _lib.lib().gnan_spmm_bwd_narrow_workspace_bytes(na)
     ws = torch.empty(need // 8 + 2, dtype=torch.float64, device=V.device)
     na.workspace, na.workspace_bytes = _lib.ptr(ws), ws.numel() * 8
@@ -1113,9 +1114,15 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
     if ctx.reduce_cr and (need_dS or (need_dlut and not fused_lut_grad)):
         dY = dY.repeat(1, W // ctx.reduce_cr)   # the fused feature sum broadcasts its gradient over the features
     rows = None if row_ids is None else row_ids.long()
-    cnt = g.cnt if rows is None else g.cnt[rows]
-    inv = (1.0 / cnt.clamp_min(1).float()) if use_cnt else None            # [n_out, D]
+    _inv = []
+
+    def inv_counts():                       # [n_out, D] 1 / shell size — three element-wise passes over N x D: only where needed
+        if not _inv:
+            cnt = g.cnt if rows is None else g.cnt[rows]
+            _inv.append(1.0 / cnt.clamp_min(1).float())
+        return _inv[0]
     dS = dlut = None
+    rest_added = False
     fused_bwd = (NARROW_FUSED_BACKWARD and need_dS and need_dlut and not g.is_dense
                  and Cw == 1 and D <= 4 and not per_row and rows is None and not ctx.reduce_cr and W <= 16
                  and S.dtype == torch.float32)
@@ -1126,10 +1133,16 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         half = 1 << max(0, (W - 1).bit_length())
         walk = narrow_walk(g.transposed())
         V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
-        dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk)
+        q_sum = ds_add = None
+        if with_rest:
+            q_sum = column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
+            if ctx.total_group is NOT_SHARED and ctx.total_rows is None:
+                # d/dS_j of  wt(i, rest) * total : the same vector rho(0) * q_sum for every j — added by the kernel's epilogue
+                ds_add = (lut[D - 1, 0].float() * q_sum).contiguous()
+                rest_added = True
+        dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk, ds_add=ds_add)
         if with_rest:
             total = ctx.s_total if ctx.s_total is not None else column_sums(S)
-            q_sum = column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
             dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
         dlut = dl.view(D, 1)
 
@@ -1165,10 +1178,10 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
             dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
                              weight_by_col=True, minus_rest=with_rest)
     if need_dS:
-        if with_rest:
+        if with_rest and not rest_added:
             # d/dS_j of  wt(i, rest) * total  : the same vector for every j
             l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
-            w_rest = l_rest * inv[:, D - 1:D] if inv is not None else l_rest   # [n_out or 1, Cw]
+            w_rest = l_rest * inv_counts()[:, D - 1:D] if use_cnt else l_rest   # [n_out or 1, Cw]
             w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
             v = (w_rest * dY).sum(0, keepdim=True)
             if ctx.total_group is not NOT_SHARED:
@@ -1191,8 +1204,8 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         else:
             T = shell_sums_launch(g, S, lut, with_rest, row_ids, ctx.s_total)  # [n_out, D, W]
             dwt = (T.view(T.shape[0], D, W // Cw, Cw) * dY.view(dY.shape[0], 1, W // Cw, Cw)).sum(2)
-            if inv is not None:
-                dwt = dwt * inv.unsqueeze(-1)                                 # [n_out, D, Cw]
+            if use_cnt:
+                dwt = dwt * inv_counts().unsqueeze(-1)                        # [n_out, D, Cw]
         if per_row:
             if rows is None:
                 dlut = dwt

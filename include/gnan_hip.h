@@ -521,6 +521,8 @@ typedef struct gnan_spmm_bwd_narrow_args {
   float* dlut;               /* [D] */
   void* workspace;
   size_t workspace_bytes;
+  const float* ds_add;       /* optional [w_real]: a vector added to every row of dS — d/dS_j of the rest bucket's
+                                wt(i, rest) * total term is the same for every j (the caller forms it from the packed rows) */
 } gnan_spmm_bwd_narrow_args;
 size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_bwd_narrow_args* a);
 int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* a, gnan_stream_t stream);

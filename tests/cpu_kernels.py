@@ -95,7 +95,7 @@ def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None):
     return V.permute(1, 0, 2).contiguous()                      # code-major [D, n, 2 * half]
 
 
-def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None):
+def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None, ds_add=None):
     D = lut.numel()
     half = V.shape[1] // 2
     row_of_pair, col, code = _pairs(gt)                     # rows of gt = nodes as neighbours; col = the forward row listing them
@@ -112,6 +112,8 @@ def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None):
     if with_rest:
         ds -= l[rest] * Q
         dl[rest] = -(Sd * Q).sum()
+    if ds_add is not None:
+        ds += ds_add.detach().double().reshape(1, -1)
     return ds.float(), dl.float()
 
 
