@@ -62,10 +62,11 @@ def parse():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on a 1-GPU box: run rank 0's share of a P-rank job WITHOUT the collectives "
                          "(stage times only; the printed value is not a result)")
-    ap.add_argument("--pipeline", action="store_true",
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="build the shape-function tables of forward k+1 on a side stream while forward k's look-up and "
-                         "aggregation run (one build per forward either way; default: inside the forward).  Measured: +-0 on "
-                         "one GPU, -1 % wall / -4 % device time on a 1/8 share")
+                         "aggregation run (one build per forward either way).  auto: on for a rank's share of a multi-rank job "
+                         "(the 0.057-ms build is 6 %% of a 1/8 share: 1.00 -> 0.94 ms), off on one GPU (+-0 there, and the timed "
+                         "call is the drop-in module's forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="upper bound of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
@@ -219,6 +220,7 @@ def main():
     N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
     emulated = args.emulate_world > 1 and world == 1
     pworld = args.emulate_world if emulated else world       # how many shares the work is cut into
+    args.pipeline = args.pipeline == "on" or (args.pipeline == "auto" and pworld > 1)
     partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, pworld, args.order)
     if emulated and partition in ("vertex", "exchange"):
         raise SystemExit("--emulate-world covers the halo and feature partitions (these shares need the other ranks' operand rows)")

@@ -554,52 +554,58 @@ class _FeatureMLPs(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         x = saved.pop(0)
         params = [saved.pop(0) if present else None for present in ctx.present]
-        leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
-        p = StackedMLP(*leaves, L, H, C, F)
-        live = [t for t in leaves if t is not None]
-        if ctx.tables is not None and not ctx.needs_input_grad[0]:
-            # table path: one streaming pass bins the upstream gradient per piece (HIP), then the exact
-            # parameter gradients follow from 2 probe points per piece through the tiny batched MLP
-            from .pwl import parameter_grads_from_moments
-            if _table_grads_applies(L, H, C) and x.is_cuda:
-                # ... exactly, in one kernel: one reverse pass for the value and one for the slope of every non-empty piece
-                M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max, raw=True, located=ctx.located)
-                ctx.located = None
-                return (None,) * 9 + tuple(_fpwl_param_grads_launch(params, ctx.tables, M, L, H, C, F))
-            M = _fpwl_moments(x, ctx.tables, grad_out, sum_features, ctx.x_abs_max, located=ctx.located)
-            ctx.located = None
-            got = parameter_grads_from_moments(
-                p, ctx.tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()
-                                                                          for t in q[:6]], *q[6:]), False))
-            it = iter(got)
-            pg = [None if not present else next(it) for present in ctx.present]
-            pg = [None if g is None else g.to(torch.float32) for g in pg]
-            return (None, None, None, None, None, None, None, None, None, *pg)
-        if (HIP_SMALL_BACKWARD and L in (2, 3) and 1 <= H <= 64 and C <= 8 and not ctx.needs_input_grad[0] and x.is_cuda
-                and 0 < x.shape[0] * F <= HIP_SMALL_BACKWARD_MAX_WORK):
-            # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
-            # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch
-            # restatement below materialises [F, n, H] activations for the same sums (Cora-shaped: 1 GB per layer)
-            return (None,) * 9 + tuple(_fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F))
-        grads = [torch.zeros_like(t) for t in live]
-        n = x.shape[0]
-        chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))
-        xd = x.detach().float()
-        gx = torch.zeros_like(xd) if ctx.needs_input_grad[0] else None
-        for lo in range(0, n, chunk):
-            xs = xd[lo:lo + chunk]
-            if gx is not None:
-                xs = xs.clone().requires_grad_(True)
-            with torch.enable_grad():
-                out = _fmlp_eager(xs, p, sum_features)
-            got = torch.autograd.grad(out, live + ([xs] if gx is not None else []), grad_out[lo:lo + chunk])
-            for g, d in zip(grads, got):
-                g += d
-            if gx is not None:
-                gx[lo:lo + chunk] = got[-1]
-        it = iter(grads)
-        pg = [next(it) if present else None for present in ctx.present]
+        located, ctx.located = ctx.located, None
+        gx, pg = _shape_function_grads(x, params, ctx.present, ctx.tables, grad_out, sum_features, L, H, C, F, ctx.x_abs_max,
+                                       located, ctx.needs_input_grad[0])
         return (gx, None, None, None, None, None, None, None, None, *pg)
+
+
+def _shape_function_grads(x, params, present, tables, grad_out, sum_features, L, H, C, F, x_abs_max=None, located=None,
+                          want_x_grad=False):
+    """``(d x or None, [gradients of the six stacked parameter tensors, None where absent])`` of
+    ``sum_n <grad_out[n], f(x[n])>`` — autograd through GNAN.py:57-62 (``sum_features``: through GNAN.py:157 as well)."""
+    leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
+    p = StackedMLP(*leaves, L, H, C, F)
+    live = [t for t in leaves if t is not None]
+    if tables is not None and not want_x_grad:
+        # table path: one streaming pass bins the upstream gradient per piece (HIP), then the exact
+        # parameter gradients follow from 2 probe points per piece through the tiny batched MLP
+        from .pwl import parameter_grads_from_moments
+        if _table_grads_applies(L, H, C) and x.is_cuda:
+            # ... exactly, in one kernel: one reverse pass for the value and one for the slope of every non-empty piece
+            M = _fpwl_moments(x, tables, grad_out, sum_features, x_abs_max, raw=True, located=located)
+            return None, _fpwl_param_grads_launch(params, tables, M, L, H, C, F)
+        M = _fpwl_moments(x, tables, grad_out, sum_features, x_abs_max, located=located)
+        got = parameter_grads_from_moments(
+            p, tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()
+                                                                  for t in q[:6]], *q[6:]), False))
+        it = iter(got)
+        pg = [None if not pr else next(it) for pr in present]
+        return None, [None if g is None else g.to(torch.float32) for g in pg]
+    if (HIP_SMALL_BACKWARD and L in (2, 3) and 1 <= H <= 64 and C <= 8 and not want_x_grad and x.is_cuda
+            and 0 < x.shape[0] * F <= HIP_SMALL_BACKWARD_MAX_WORK):
+        # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
+        # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch
+        # restatement below materialises [F, n, H] activations for the same sums (Cora-shaped: 1 GB per layer)
+        return None, _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F)
+    grads = [torch.zeros_like(t) for t in live]
+    n = x.shape[0]
+    chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))
+    xd = x.detach().float()
+    gx = torch.zeros_like(xd) if want_x_grad else None
+    for lo in range(0, n, chunk):
+        xs = xd[lo:lo + chunk]
+        if gx is not None:
+            xs = xs.clone().requires_grad_(True)
+        with torch.enable_grad():
+            out = _fmlp_eager(xs, p, sum_features)
+        got = torch.autograd.grad(out, live + ([xs] if gx is not None else []), grad_out[lo:lo + chunk])
+        for g, d in zip(grads, got):
+            g += d
+        if gx is not None:
+            gx[lo:lo + chunk] = got[-1]
+    it = iter(grads)
+    return gx, [next(it) if pr else None for pr in present]
 
 
 # =============================================================================
@@ -1268,6 +1274,81 @@ def pre_rho_aggregate(g: HopGraph, S: torch.Tensor, p: StackedMLP, u: torch.Tens
                              total_rows=total_rows, total_group=total_group)
     return _PreRhoAggregate.apply(S, g, with_rest, row_ids, s_total, total_rows, total_group, tables, u.contiguous(),
                                   p.L, p.H, p.C, *p[:6])
+
+
+REFERENCE_ORDER_KEEP_MAX_BYTES = 16 << 30   # the [N, F*C] rows of a reference-order forward are kept for its backward below this
+
+
+class _ReferenceOrderAggregate(torch.autograd.Function):
+    """The reference's evaluation order with the feature sum fused (models.py:360-376): ``fx = f(x)`` per feature,
+    ``Y[i, c] = sum_k sum_j m_ij fx[j, k, c]``, as ONE autograd node over the table path.
+
+    Forward: look-up of the ``[N, F*C]`` rows, aggregation with the read-out in its epilogue (as :func:`feature_mlps` +
+    :func:`rho_aggregate`).  Backward: ``Y`` depends on the rows only through their feature sum ``S1 = sum_k fx[:, k, :]``, so
+    ``d loss / d fx[j, k, c] = (A^T dY)[j, c]`` for EVERY feature k and the table gradient is that of the narrow aggregation
+    of ``S1`` — the backward pass of the sum-first order: one narrow transposed pass for both aggregation gradients, and the
+    per-piece moments of all features from the one ``[N, C]`` gradient.  The composed nodes walk the transposed graph with
+    ``[N, F*C]`` rows, contract a second wide pass for the table, and bin an ``[N, F*C]`` gradient whose F blocks are
+    equal (10M-node graph, F = 64: 20 ms of backward against 3)."""
+
+    @staticmethod
+    def forward(ctx, x, lut, g, use_cnt, with_rest, L, H, C, F, *params):
+        p = StackedMLP(*params, L, H, C, F)
+        needs_grad = any(ctx.needs_input_grad[9:])
+        located = None
+        fx, tables, total = _fmlp_forward(x, p, False, with_rest, needs_grad, torch.float32, None, located=located)
+        if with_rest and total is None:
+            total = column_sums(fx)
+        ctx.g, ctx.use_cnt, ctx.with_rest, ctx.row_ids, ctx.reduce_cr = g, use_cnt, with_rest, None, 0
+        ctx.total_rows, ctx.total_group = None, NOT_SHARED
+        ctx.tables, ctx.meta = tables, (L, H, C, F)
+        ctx.present = [t is not None for t in params]
+        keep = fx if (fx.numel() * 4 <= REFERENCE_ORDER_KEEP_MAX_BYTES or tables is None) else None
+        ctx.kept_rows = keep is not None
+        ctx.x_abs_max = _abs_max_cached(x) if needs_grad and x.numel() else None
+        ctx.save_for_backward(x, lut, *([keep] if keep is not None else []), *[t for t in params if t is not None])
+        return spmm_launch(g, fx, lut, use_cnt, with_rest, None, s_total=total if with_rest else None, reduce_cr=C)
+
+    @staticmethod
+    def backward(ctx, dY):
+        L, H, C, F = ctx.meta
+        saved = list(ctx.saved_tensors)
+        x, lut = saved.pop(0), saved.pop(0)
+        fx = saved.pop(0) if ctx.kept_rows else None
+        params = [saved.pop(0) if present else None for present in ctx.present]
+        n = x.shape[0]
+        if fx is not None:
+            # [N, C] feature sum (padded features are zero columns) as a tall-skinny GEMM: the framework's reduction over the
+            # inner 64 columns of 10M rows takes 2.7 ms, the library GEMM streams the 2.56 GB once (0.5 ms)
+            W = fx.shape[1]
+            sel = (torch.arange(W, device=fx.device).unsqueeze(1) % C == torch.arange(C, device=fx.device).unsqueeze(0)).float()
+            S1 = torch.mm(fx, sel)
+        else:                                                       # rows too large to keep: the feature sum is looked up again
+            S1 = _fpwl_launch(x, ctx.tables, True)
+        ctx.s_total = None
+        dS1, dlut = _aggregate_backward(ctx, S1, lut, dY, True, ctx.needs_input_grad[1])
+        pg = (None,) * 6
+        if any(ctx.needs_input_grad[9:]):
+            # every feature's rows have the gradient dS1: the shape functions' gradients are those of the feature-SUM mode
+            _, pg = _shape_function_grads(x, params, ctx.present, ctx.tables, dS1, True, L, H, C, F, ctx.x_abs_max)
+        return (None, dlut, None, None, None, None, None, None, None, *pg)
+
+
+def reference_order_applies(x: torch.Tensor, p: StackedMLP, lut: torch.Tensor, g: HopGraph) -> bool:
+    """Can :func:`reference_order_forward` take this call?  Training through the table path (what AUTO picks from 2^18
+    look-ups), a global weight table, a read-out width the aggregation kernel fuses, features without a gradient."""
+    grads = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in p[:6])
+    return (grads and not x.requires_grad and lut.dim() == 2 and p.C in FUSABLE_READOUT and p.L >= 2 and not g.is_dense
+            and (FMLP_ALGO == _lib.FMLP_PWL or (FMLP_ALGO == _lib.FMLP_AUTO and x.shape[0] * p.F >= PWL_MIN_WORK_GRAD))
+            and not torch.cuda.is_current_stream_capturing() and not (PAD_FEATURES and p.F % PAD_FEATURES and p.C == 1
+                                                                      and x.shape[0] * p.F >= PAD_MIN_WORK))
+
+
+def reference_order_forward(g: HopGraph, x: torch.Tensor, p: StackedMLP, lut: torch.Tensor, use_cnt: bool) -> torch.Tensor:
+    """``Y [N, C]`` in the reference's evaluation order (per-feature rows, aggregate, sum over features) as one autograd node
+    whose backward pass is the sum-first order's (see :class:`_ReferenceOrderAggregate`).  Check :func:`reference_order_applies`."""
+    _lib.require_device(x, p.w_last, lut)
+    return _ReferenceOrderAggregate.apply(x, lut, g, use_cnt, not g.is_dense, p.L, p.H, p.C, p.F, *p[:6])
 
 
 def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor, reduce_channels: int = 0,

@@ -473,6 +473,15 @@ class TensorGNAN(_PathBase):
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate
             # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
             # in this order.
+            from .functional import reference_order_applies, reference_order_forward
+            stacked = None if self._dropout_active() or self.operand_dtype != torch.float32 else self._stacked("fs", self.fs)
+            if stacked is not None and reference_order_applies(x, stacked, lut, g):
+                # training at scale: one node whose backward pass is the sum-first order's (the read-out makes every
+                # feature's row gradient the same [N, C] vector)
+                Y = reference_order_forward(g, x, stacked, lut, use_cnt)
+                self._mark("fmlp")
+                self._mark("spmm")
+                return Y if not self.is_graph_task else Y.sum(dim=0).view(-1, 1)
             fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True,
                                       out_dtype=self.operand_dtype)                   # [N, F*C] (+ zero columns when C == 1)
             self._mark("fmlp")

@@ -374,3 +374,58 @@ def test_batched_variant_draws_one_dropout_mask_per_pair(gpu):
     y = mod(x, dd, batch)                                               # and it is differentiable
     y.sum().backward()
     assert mod.rho[0].weight.grad is not None and float(mod.rho[0].weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("C,rho_per_feature,L", [(1, False, 3), (2, True, 3), (4, False, 2), (3, True, 3)])
+def test_reference_order_training_uses_the_sum_first_backward(gpu, C, rho_per_feature, L, monkeypatch):
+    """models.py:373-376 under autograd on a CSR graph through the table path: one node whose backward pass is the sum-first
+    order's (the fused read-out makes every feature's row gradient the same [N, C] vector).  Outputs and every parameter
+    gradient against float64 oracle autograd; C = 3 is not a read-out width the kernel fuses and takes the composed nodes."""
+    from gnan_amd import HopGraph, _lib, functional, models
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    used = {"n": 0}
+    real = functional._ReferenceOrderAggregate.forward
+
+    def counting(ctx, *a):
+        used["n"] += 1
+        return real(ctx, *a)
+    monkeypatch.setattr(functional._ReferenceOrderAggregate, "forward", staticmethod(counting))
+    rng = np.random.default_rng(C)
+    n, F = 3000, 9
+    ei = rng.integers(0, n, (2, 4 * n))
+    ei = np.unique(np.concatenate([ei, ei[::-1]], axis=1), axis=1)
+    ei = ei[:, ei[0] != ei[1]]
+    hops = np.full((n, n), -1, dtype=np.int64)
+    hops[ei[0], ei[1]] = 1
+    np.fill_diagonal(hops, 0)
+    rowptr, col, code = O.csr_from_hops(hops, 1)
+    g = HopGraph.from_csr(torch.from_numpy(rowptr).to(gpu.DEV), torch.from_numpy(col).to(gpu.DEV), torch.from_numpy(code).to(gpu.DEV),
+                          n_cols=n, n_codes=3)
+    x = torch.from_numpy(rng.random((n, F), dtype=np.float32))
+    x[:, :2] = (x[:, :2] > 0.5).float()
+    x[:, -1] = 1.0
+    torch.manual_seed(C)
+    mod = models.TensorGNAN(F, C, L, hidden_channels=16, rho_per_feature=rho_per_feature, device=gpu.DEV)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
+    sd64 = {k: v.detach().double().clone() for k, v in mod.state_dict().items()}
+    mod = mod.to(gpu.DEV).eval()
+    mod.aggregation_order = "reference"
+    data = gpu.Bag(x=x.to(gpu.DEV), edge_index=None, gnan_graph=g)
+    target = torch.randn(n, C, generator=gen, dtype=torch.float64)
+    y = mod.forward(data)
+    ((y - target.to(gpu.DEV).float()) ** 2).sum().backward()
+    assert used["n"] == (1 if C in (1, 2, 4) else 0)
+    p64 = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    S = O.feature_mlps(x.double(), p64).sum(1)
+    wt = O.weight_table(O.rho_lut(p64, 3, dtype=torch.float64), g.cnt.cpu().long().numpy()).expand(n, -1, -1)
+    truth = O.spmm_csr(rowptr, col, code, S, wt)
+    assert O.rel_err(y.detach().cpu(), truth.detach()) <= 1e-5
+    ((truth - target) ** 2).sum().backward()
+    scale = max(float(v.grad.abs().max()) for v in p64.values() if v.grad is not None)
+    for k, p in mod.named_parameters():
+        want = p64[k].grad if p64[k].grad is not None else torch.zeros_like(p64[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * scale, k

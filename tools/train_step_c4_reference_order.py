@@ -1,5 +1,5 @@
 import os, sys, time, json
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import gnan_amd
 from gnan_amd import synthetic as syn
