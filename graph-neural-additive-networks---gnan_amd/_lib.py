@@ -34,6 +34,7 @@ class FmlpArgs(C.Structure):
         ("sum_features", C.c_int32),
         ("out", C.c_void_p), ("out_stride", C.c_int64),
         ("algo", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -71,6 +72,7 @@ class FmlpBwdArgs(C.Structure):
         ("d_w_first", C.c_void_p), ("d_b_first", C.c_void_p), ("d_w_mid", C.c_void_p), ("d_b_mid", C.c_void_p),
         ("d_w_last", C.c_void_p), ("d_b_last", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -169,6 +171,7 @@ SYMBOLS = {
     "gnan_fmlp_fwd": (C.c_int, [C.POINTER(FmlpArgs), C.c_void_p]),
     "gnan_fmlp_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FmlpBwdArgs)]),
     "gnan_fmlp_bwd": (C.c_int, [C.POINTER(FmlpBwdArgs), C.c_void_p]),
+    "gnan_dropout_mask": (C.c_int, [C.c_uint64, C.c_float, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnan_pwl_build_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_pwl_build": (C.c_int, [C.POINTER(PwlBuildArgs), C.c_void_p]),
     "gnan_rho_row_lut": (C.c_int, [C.POINTER(RhoLutArgs), C.c_void_p]),

@@ -20,6 +20,7 @@
 // Per feature the packed weights (16 KiB for H = 64) reach LDS by LDS-DMA (global_load_lds_dwordx4) once per
 // workgroup, double-buffered against the MFMA work; [N, F, H] activations are never materialised.
 #include "common.hpp"
+#include "dropout.hpp"
 
 namespace {
 
@@ -42,6 +43,10 @@ struct Params {
   // features (Cora: 2.7k x 1434) still fill the chip; with sum_features the chunks meet in `sum_partial`
   int feat_chunk;
   float* sum_partial;  // [chunks, n, C] or nullptr (single chunk)
+  // training-mode Dropout (lane kernel): keep iff hash(seed, node, feature, layer, unit) >= drop_thresh, scale 1 / (1 - p)
+  uint32_t drop_thresh;
+  float drop_scale;
+  uint64_t drop_seed;
 };
 
 constexpr int JB = 8;
@@ -100,16 +105,23 @@ __global__ __launch_bounds__(256) void fmlp_lane_kernel(const Params p) {
       }
       continue;
     }
+    const bool drop = p.drop_thresh != 0u;
+    const uint32_t dbase = drop ? gnan::drop_base(p.drop_seed, node, k) : 0u;
     for (int j = 0; j < H; ++j) {
       const float b = p.b_first ? p.b_first[k * H + j] : 0.f;
-      buf_a[j * kWave] = fmaxf(fmaf(xv, p.w_first[k * H + j], b), 0.f);
+      float h = fmaxf(fmaf(xv, p.w_first[k * H + j], b), 0.f);
+      if (drop) h = gnan::drop_keep(dbase, 0, j, p.drop_thresh) ? h * p.drop_scale : 0.f;
+      buf_a[j * kWave] = h;
     }
     float* cur = buf_a;
     float* nxt = buf_b;
     for (int l = 0; l < p.L - 2; ++l) {
       const int64_t f = static_cast<int64_t>(l) * p.F + k;
       dense_layer<true>(p.w_mid + f * H * H, p.b_mid ? p.b_mid + f * H : nullptr, H, H, cur,
-                        [&](int j, float v) { nxt[j * kWave] = v; });
+                        [&](int j, float v) {
+                          if (drop) v = gnan::drop_keep(dbase, l + 1, j, p.drop_thresh) ? v * p.drop_scale : 0.f;
+                          nxt[j * kWave] = v;
+                        });
       float* t = cur; cur = nxt; nxt = t;
     }
     dense_layer<false>(p.w_last + static_cast<int64_t>(k) * C * H, p.b_last ? p.b_last + k * C : nullptr, C, H, cur,
@@ -438,6 +450,10 @@ Params make_params(const gnan_fmlp_args* a) {
   p.w_last = a->w_last; p.b_last = a->b_last;
   p.sum_features = a->sum_features; p.out = a->out; p.out_stride = a->out_stride;
   p.feat_chunk = a->F; p.sum_partial = nullptr;
+  const bool drop = a->dropout_p > 0.f && a->L >= 2;
+  p.drop_thresh = drop ? gnan::drop_threshold(a->dropout_p) : 0u;
+  p.drop_scale = drop ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.drop_seed = a->dropout_seed;
   return p;
 }
 
@@ -447,7 +463,7 @@ extern "C" size_t gnan_fmlp_fwd_workspace_bytes(const gnan_fmlp_args* a) {
   if (!a || a->algo == GNAN_FMLP_LANE) return 0;
   const Params p = make_params(a);
   MfmaShape s;
-  if (!mfma_shape(p, &s)) return 0;
+  if (!mfma_shape(p, &s) || p.drop_thresh != 0u) return 0;
   size_t bytes = packed_bytes(p, s);
   if (p.sum_features) {                               // room for the per-chunk partial sums (upper bound)
     const int chunks = feature_chunks(p.n, p.F);
@@ -468,10 +484,13 @@ extern "C" int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream) {
   const int64_t ow = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(a->out_stride >= ow, "fmlp: out row stride smaller than the output width");
 
+  GNAN_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "fmlp: dropout_p must be in [0, 1)");
   const Params p = make_params(a);
   hipStream_t st = static_cast<hipStream_t>(stream);
   MfmaShape shape;
-  const bool can_mfma = mfma_shape(p, &shape);
+  const bool can_mfma = mfma_shape(p, &shape) && p.drop_thresh == 0u;        // Dropout: lane kernel
+  if (a->algo == GNAN_FMLP_MFMA && p.drop_thresh != 0u)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fmlp: training-mode Dropout runs on the lane kernel (algo AUTO or LANE)");
   if (a->algo == GNAN_FMLP_MFMA && !can_mfma)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "fmlp: MFMA path covers 3 <= L <= 4, H <= 64, C <= 8 (got L=%d H=%d C=%d)",
                       p.L, p.H, p.C);
@@ -500,4 +519,32 @@ extern "C" int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream) {
   }
   hipLaunchKernelGGL(fmlp_lane_kernel, dim3(static_cast<unsigned>(blocks)), dim3(waves * gnan::kWave), lds, st, p);
   return gnan::check_launch("fmlp_lane_kernel");
+}
+
+
+namespace {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint64_t seed, uint32_t thresh, int64_t n, int F, int LH, int H,
+                                                           uint8_t* __restrict__ mask) {
+  const int64_t total = n * F * LH * H;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int j = static_cast<int>(e % H);
+    const int l = static_cast<int>((e / H) % LH);
+    const int k = static_cast<int>((e / (static_cast<int64_t>(H) * LH)) % F);
+    const int64_t node = e / (static_cast<int64_t>(H) * LH * F);
+    mask[e] = gnan::drop_keep(gnan::drop_base(seed, node, k), l, j, thresh) ? 1 : 0;
+  }
+}
+}  // namespace
+
+extern "C" int gnan_dropout_mask(uint64_t seed, float p, int64_t n_nodes, int32_t F, int32_t n_hidden_layers, int32_t H,
+                                 uint8_t* mask, gnan_stream_t stream) {
+  GNAN_REQUIRE(p >= 0.f && p < 1.f && n_nodes >= 0 && F >= 1 && n_hidden_layers >= 1 && H >= 1, "dropout_mask: bad arguments");
+  if (n_nodes == 0) return GNAN_OK;
+  GNAN_REQUIRE(mask != nullptr, "dropout_mask: null output");
+  const int64_t total = n_nodes * F * n_hidden_layers * H;
+  int64_t blocks = (total + 255) / 256;
+  blocks = blocks > 65536 ? 65536 : blocks;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
+                     gnan::drop_threshold(p), n_nodes, F, n_hidden_layers, H, mask);
+  return gnan::check_launch("dropout_mask_kernel");
 }

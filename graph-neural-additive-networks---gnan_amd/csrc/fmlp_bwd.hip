@@ -12,6 +12,7 @@
 // loop.  Per node and wave: 3 H^2 fmas (z2, dW2 += dz2 x h1, dh1 = W2^T dz2).  The four waves' partial sums meet in LDS
 // in wave order at the end.
 #include "common.hpp"
+#include "dropout.hpp"
 
 namespace {
 
@@ -28,6 +29,9 @@ struct BwdParams {
   float *d_w_first, *d_b_first, *d_w_mid, *d_b_mid, *d_w_last, *d_b_last;
   int64_t nodes_per_split;   // blockIdx.y walks nodes [y * nodes_per_split, (y + 1) * nodes_per_split)
   int64_t split_stride;      // floats between the gradient blocks of consecutive splits (0: one split, final outputs)
+  uint32_t drop_thresh;      // training-mode Dropout of the forward pass (csrc/dropout.hpp); 0 = none
+  float drop_scale;
+  uint64_t drop_seed;
 };
 
 constexpr int kH = 64;      // lanes = hidden units (H <= 64: the rest idle with zero weights)
@@ -79,13 +83,19 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
     float gv[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) gv[c] = g[c];
-    // forward
+    // forward (m1, m2: this unit's Dropout factors of the two hidden layers, 0 or 1 / (1 - p); 1 without Dropout)
+    float m1 = 1.f, m2 = 1.f;
+    if (p.drop_thresh != 0u) {
+      const uint32_t dbase = gnan::drop_base(p.drop_seed, node, k);
+      m1 = gnan::drop_keep(dbase, 0, j, p.drop_thresh) ? p.drop_scale : 0.f;
+      m2 = gnan::drop_keep(dbase, 1, j, p.drop_thresh) ? p.drop_scale : 0.f;
+    }
     const float a1 = fmaf(w1, x, b1);
-    const float h1 = unit && a1 > 0.f ? a1 : 0.f;
+    const float h1 = unit && a1 > 0.f ? a1 * m1 : 0.f;
     float z2 = b2;
 #pragma unroll
     for (int t = 0; t < kH; ++t) z2 = fmaf(w2row[t], lane_value(h1, t), z2);
-    const float h2 = unit && z2 > 0.f ? z2 : 0.f;
+    const float h2 = unit && z2 > 0.f ? z2 * m2 : 0.f;
     // backward through the output layer
     float dh2 = 0.f;
 #pragma unroll
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
       dw3[c] = fmaf(gv[c], h2, dw3[c]);
       db3[c] += gv[c];
     }
-    const float dz2 = unit && z2 > 0.f ? dh2 : 0.f;
+    const float dz2 = unit && z2 > 0.f ? dh2 * m2 : 0.f;
     db2 += dz2;
     // dW2[j, t] += dz2_j h1_t;   dh1_j = sum_t W2[t, j] dz2_t
     float dh1 = 0.f;
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
       dw2[t] = fmaf(dz2, lane_value(h1, t), dw2[t]);
       dh1 = fmaf(w2col[t], lane_value(dz2, t), dh1);
     }
-    const float dz1 = unit && a1 > 0.f ? dh1 : 0.f;
+    const float dz1 = unit && a1 > 0.f ? dh1 * m1 : 0.f;
     dw1 = fmaf(dz1, x, dw1);
     db1 += dz1;
   }
@@ -182,8 +192,10 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdPara
   for (int64_t node = n_lo + wv; node < n_hi; node += kWaves) {
     const float x = p.x[node * p.x_stride + k];
     const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
+    float m1 = 1.f;
+    if (p.drop_thresh != 0u) m1 = gnan::drop_keep(gnan::drop_base(p.drop_seed, node, k), 0, j, p.drop_thresh) ? p.drop_scale : 0.f;
     const float a1 = fmaf(w1, x, b1);
-    const float h1 = unit && a1 > 0.f ? a1 : 0.f;
+    const float h1 = unit && a1 > 0.f ? a1 * m1 : 0.f;
     float dh1 = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdPara
       dw3[c] = fmaf(gv, h1, dw3[c]);
       db3[c] += gv;
     }
-    const float dz1 = unit && a1 > 0.f ? dh1 : 0.f;
+    const float dz1 = unit && a1 > 0.f ? dh1 * m1 : 0.f;
     dw1 = fmaf(dz1, x, dw1);
     db1 += dz1;
   }
@@ -284,6 +296,10 @@ extern "C" int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream) 
   p.sum_features = a->sum_features; p.grad = a->grad; p.grad_stride = a->grad_stride;
   p.d_w_first = a->d_w_first; p.d_b_first = a->d_b_first; p.d_w_mid = a->d_w_mid; p.d_b_mid = a->d_b_mid;
   p.d_w_last = a->d_w_last; p.d_b_last = a->d_b_last;
+  GNAN_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "fmlp_bwd: dropout_p must be in [0, 1)");
+  p.drop_thresh = a->dropout_p > 0.f ? gnan::drop_threshold(a->dropout_p) : 0u;
+  p.drop_scale = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.drop_seed = a->dropout_seed;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // few features and many nodes: a feature's nodes are cut into ranges, one workgroup each; the ranges' gradients land in
   // the workspace and are added in range order (still no atomics)

@@ -360,7 +360,7 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
     return _fmlp_launch(x, p, sum_features, _lib.FMLP_AUTO if algo == _lib.FMLP_PWL else algo), None, None
 
 
-def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int = 0) -> torch.Tensor:
+def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int = 0, dropout=None) -> torch.Tensor:
     x = x.detach().float()
     x = _rows(x)
     n = x.shape[0]
@@ -371,6 +371,8 @@ def _fmlp_launch(x: torch.Tensor, p: StackedMLP, sum_features: bool, algo: int =
                       w_first=_lib.ptr(keep[0]), b_first=_lib.ptr(keep[1]), w_mid=_lib.ptr(keep[2]),
                       b_mid=_lib.ptr(keep[3]), w_last=_lib.ptr(keep[4]), b_last=_lib.ptr(keep[5]),
                       sum_features=int(sum_features), out=_lib.ptr(out), out_stride=out.stride(0), algo=algo)
+    if dropout is not None:
+        a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1])
     need = _lib.lib().gnan_fmlp_fwd_workspace_bytes(a)
     if need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)   # packed weights (caching allocator)
@@ -462,7 +464,7 @@ HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
 HIP_SMALL_BACKWARD_MAX_WORK = 1 << 23
 
 
-def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
+def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F, dropout=None):
     """``gnan_fmlp_bwd``: gradients of the six stacked parameter tensors (None where a bias is absent), in their order."""
     xd = x.detach().float()
     xd = _rows(xd)
@@ -480,6 +482,8 @@ def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F):
                          grad=_lib.ptr(g), grad_stride=g.stride(0),
                          d_w_first=_lib.ptr(outs[0]), d_b_first=_lib.ptr(outs[1]), d_w_mid=_lib.ptr(d_w_mid),
                          d_b_mid=_lib.ptr(d_b_mid), d_w_last=_lib.ptr(outs[4]), d_b_last=_lib.ptr(outs[5]))
+    if dropout is not None:
+        a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1])
     need = _lib.lib().gnan_fmlp_bwd_workspace_bytes(a)
     if need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=xd.device)
@@ -518,6 +522,105 @@ def _fmlp_eager(x: torch.Tensor, p: StackedMLP, sum_features: bool, dropout: flo
 
 
 _BWD_CHUNK_ELEMS = 1 << 28   # activation floats per recompute chunk (1 GiB)
+
+
+def dropout_masks(seed: int, p: float, n: int, F: int, n_hidden: int, H: int, device) -> torch.Tensor:
+    """The keep-mask the kernels apply for ``(p, seed)`` (``gnan_dropout_mask``): uint8 ``[n, F, n_hidden, H]``."""
+    m = torch.empty((n, F, n_hidden, H), dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().gnan_dropout_mask(int(seed), float(p), n, F, n_hidden, H, _lib.ptr(m), _lib.stream_of(m)),
+               "gnan_dropout_mask")
+    return m
+
+
+def _fmlp_eager_masked(x: torch.Tensor, p: StackedMLP, sum_features: bool, masks: torch.Tensor, drop_p: float) -> torch.Tensor:
+    """:func:`_fmlp_eager` with the kernels' Dropout masks (``dropout_masks``): the backward route of shapes
+    ``gnan_fmlp_bwd`` does not cover (deeper / wider than the reference's defaults) under training-mode Dropout."""
+    scale = 1.0 / (1.0 - drop_p)
+    xt = x.t().unsqueeze(-1)                                            # [F, n, 1]
+    h = xt * p.w_first.unsqueeze(1)
+    if p.b_first is not None:
+        h = h + p.b_first.unsqueeze(1)
+    h = torch.relu(h) * (masks[:, :, 0].permute(1, 0, 2).to(h.dtype) * scale)
+    for l in range(p.L - 2):
+        h = torch.bmm(h, p.w_mid[l].transpose(1, 2))
+        if p.b_mid is not None:
+            h = h + p.b_mid[l].unsqueeze(1)
+        h = torch.relu(h) * (masks[:, :, l + 1].permute(1, 0, 2).to(h.dtype) * scale)
+    h = torch.bmm(h, p.w_last.transpose(1, 2))
+    if p.b_last is not None:
+        h = h + p.b_last.unsqueeze(1)
+    return h.sum(0) if sum_features else h.permute(1, 0, 2).reshape(x.shape[0], -1)
+
+
+class _DropoutMLPs(torch.autograd.Function):
+    """The shape functions with training-mode Dropout behind every hidden ReLU (GNAN.py:28,32; run.sh trains with p = 0.6),
+    in the kernels: forward ``gnan_fmlp_fwd`` (lane kernel), backward ``gnan_fmlp_bwd`` — both recompute the masks from
+    ``(p, seed)`` (csrc/dropout.hpp), no mask or activation tensor is formed.  Shapes the backward kernel does not cover
+    (L > 3, H > 64, C > 8) back-propagate through the batched restatement in chunks of nodes, with the kernels' masks."""
+
+    @staticmethod
+    def forward(ctx, x, sum_features, drop_p, seed, L, H, C, F, *params):
+        p = StackedMLP(*params, L, H, C, F)
+        ctx.meta = (sum_features, float(drop_p), int(seed), L, H, C, F)
+        ctx.present = [t is not None for t in params]
+        ctx.save_for_backward(x, *[t for t in params if t is not None])
+        return _fmlp_launch(x, p, sum_features, _lib.FMLP_LANE, dropout=(drop_p, seed))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        sum_features, drop_p, seed, L, H, C, F = ctx.meta
+        saved = list(ctx.saved_tensors)
+        x = saved.pop(0)
+        params = [saved.pop(0) if present else None for present in ctx.present]
+        if L in (2, 3) and 1 <= H <= 64 and C <= 8 and not ctx.needs_input_grad[0]:
+            pg = _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F, dropout=(drop_p, seed))
+            return (None,) * 8 + tuple(pg)
+        leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
+        p = StackedMLP(*leaves, L, H, C, F)
+        live = [t for t in leaves if t is not None]
+        grads = [torch.zeros_like(t) for t in live]
+        n = x.shape[0]
+        chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C) * 2))
+        xd = x.detach().float()
+        gx = torch.zeros_like(xd) if ctx.needs_input_grad[0] else None
+        masks = dropout_masks(seed, drop_p, n, F, L - 1, H, x.device) if n * F * (L - 1) * H <= (1 << 31) else None
+        for lo in range(0, n, chunk):
+            xs = xd[lo:lo + chunk]
+            if gx is not None:
+                xs = xs.clone().requires_grad_(True)
+            if masks is not None:
+                mk = masks[lo:lo + chunk]
+            else:                       # (the hash takes the global node index: a chunk's masks are cut from a window's)
+                raise _lib.GnanHipError("training-mode Dropout: this shape's backward needs more than 2 GiB of masks")
+            with torch.enable_grad():
+                out = _fmlp_eager_masked(xs, p, sum_features, mk, drop_p)
+            got = torch.autograd.grad(out, live + ([xs] if gx is not None else []), grad_out[lo:lo + chunk])
+            for g, d in zip(grads, got):
+                g += d
+            if gx is not None:
+                gx[lo:lo + chunk] = got[-1]
+        it = iter(grads)
+        pg = [next(it) if present else None for present in ctx.present]
+        return (gx, None, None, None, None, None, None, None, *pg)
+
+
+def feature_mlps_dropout(x: torch.Tensor, p: StackedMLP, sum_features: bool, drop_p: float, seed: Optional[int] = None,
+                         return_total: bool = False):
+    """:func:`feature_mlps` in training mode with Dropout ``drop_p`` behind every hidden ReLU (GNAN.py:28,32).  ``seed``:
+    64 bits that fix the masks; by default drawn from torch's CPU generator (so ``torch.manual_seed`` makes a run
+    repeatable, as it does for ``nn.Dropout``).  The masks are a function of (seed, node, feature, layer, unit) —
+    :func:`dropout_masks` — not torch's Bernoulli stream."""
+    _lib.require_device(x, p.w_last)
+    if x.shape[1] != p.F:
+        raise ValueError(f"x has {x.shape[1]} feature columns, the model was built for {p.F}")
+    if not 0.0 < drop_p < 1.0:
+        raise ValueError("drop_p must be in (0, 1)")
+    if p.L == 1:                                         # a single Linear has no hidden ReLU: nothing to drop (GNAN.py:25-26)
+        return feature_mlps(x, p, sum_features, return_total=return_total)
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    out = _DropoutMLPs.apply(x, sum_features, float(drop_p), int(seed) & ((1 << 63) - 1), p.L, p.H, p.C, p.F, *p[:6])
+    return (out, column_sums(out)) if return_total else out
 
 
 class _FeatureMLPs(torch.autograd.Function):

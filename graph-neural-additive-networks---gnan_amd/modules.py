@@ -23,7 +23,7 @@ from torch import nn
 
 from . import _lib
 from ._cache import TensorKeyedCache
-from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps
+from .functional import StackedMLP, feature_mlps, rho_aggregate
 from .graph import HopGraph, hop_inputs
 
 
@@ -187,14 +187,17 @@ class _PathBase(nn.Module):
         return store.stacked(torch.is_grad_enabled() and store.lin[0][0].weight.requires_grad)
 
     def _check_dropout(self):
-        """Training-mode Dropout (GNAN.py:28,32) is stochastic and tied to torch's RNG stream, which a fused kernel
-        cannot reproduce; while it is active the shape functions run as batched torch GEMMs with ``F.dropout`` on
-        the device (:meth:`_features`).  The reference only ever trains with Dropout in its first epoch — it never
-        leaves eval mode again after ``trainer.py:97`` — so this is the cold path; a one-time note says so."""
+        """Training-mode Dropout (GNAN.py:28,32; run.sh trains with 0.6) runs in the kernels: ``gnan_fmlp_fwd`` /
+        ``gnan_fmlp_bwd`` apply a keep-mask that is a counter-based hash of (seed, node, feature, layer, unit), the seed
+        drawn from torch's generator once per forward (``functional.feature_mlps_dropout``).  Same distribution as
+        ``nn.Dropout``, not torch's Bernoulli stream — which depends on the order of the reference's Python loop and is not
+        part of any contract.  The table path cannot hold per-node masks, so these steps use the direct kernels (the
+        reference only trains with Dropout in its first epoch: it never leaves eval mode again after ``trainer.py:97``);
+        a one-time note says so."""
         if self._dropout_active() and not getattr(self, "_dropout_noted", False):
             import warnings
-            warnings.warn("gnan_amd: training-mode Dropout (p=%g) is active: shape functions run as batched torch "
-                          "GEMMs on the GPU instead of the fused HIP kernels until .eval() is called" % self.dropout)
+            warnings.warn("gnan_amd: training-mode Dropout (p=%g) is active: the shape functions run through the direct "
+                          "kernels with hash-generated masks (not the table look-up) until .eval() is called" % self.dropout)
             self._dropout_noted = True
 
     def _dropout_active(self) -> bool:
@@ -207,10 +210,8 @@ class _PathBase(nn.Module):
         ``want_total``: returns ``(rows, column sums or None)`` — the rest bucket's operand comes out of the look-up pass
         instead of a second pass over the rows (``rho_aggregate(s_total=...)`` accounts for it in its backward)."""
         if self._dropout_active():
-            from .functional import _fmlp_eager
-            _lib.require_device(x)
-            out = _fmlp_eager(x.float(), stack_mlps(mlps), sum_features, dropout=float(self.dropout))
-            return (out, None) if want_total else out
+            from .functional import feature_mlps_dropout
+            return feature_mlps_dropout(x, self._stacked(name, mlps), sum_features, float(self.dropout), return_total=want_total)
         kw = {} if out_dtype == torch.float32 else {"out_dtype": out_dtype}
         if room_rows:
             kw["room_rows"] = room_rows

@@ -77,6 +77,9 @@ typedef struct gnan_fmlp_args {
   int32_t algo;          /* gnan_fmlp_algo; AUTO picks the matrix-core kernel when the shape allows */
   void* workspace;       /* packed weights for the matrix-core kernel, 16-byte aligned */
   size_t workspace_bytes;
+  float dropout_p;       /* > 0: training-mode Dropout behind every hidden ReLU (GNAN.py:28,32), kept units scaled by    */
+  uint64_t dropout_seed; /* 1 / (1 - p); the mask is a counter-based hash of (seed, node, feature, layer, unit) —        */
+                         /* gnan_dropout_mask writes it out.  Lane kernel only (algo AUTO picks it; MFMA is refused)     */
 } gnan_fmlp_args;
 
 enum gnan_fmlp_algo { GNAN_FMLP_AUTO = 0, GNAN_FMLP_LANE = 1, GNAN_FMLP_MFMA = 2 };
@@ -113,10 +116,18 @@ typedef struct gnan_fmlp_bwd_args {
   void* workspace;       /* gnan_fmlp_bwd_workspace_bytes(): partial gradients when a feature's nodes are cut into ranges
                             (few features, many nodes), added in range order */
   size_t workspace_bytes;
+  float dropout_p;       /* the forward's Dropout (gnan_fmlp_args): the same masks are recomputed from the same seed */
+  uint64_t dropout_seed;
 } gnan_fmlp_bwd_args;
 
 size_t gnan_fmlp_bwd_workspace_bytes(const gnan_fmlp_bwd_args* a);
 int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream);
+
+/* The Dropout keep-mask gnan_fmlp_fwd / gnan_fmlp_bwd apply for (dropout_p, dropout_seed), written out:
+ * mask[n, k, l, j] in {0, 1} (uint8, [n_nodes, F, n_hidden_layers, H]) for hidden layer l, unit j of feature k at node n.
+ * For tests and for callers that evaluate a shape outside the kernels' coverage with the same masks. */
+int gnan_dropout_mask(uint64_t seed, float p, int64_t n_nodes, int32_t F, int32_t n_hidden_layers, int32_t H, uint8_t* mask,
+                      gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shape functions by exact piecewise-linear table look-up — same outputs as gnan_fmlp_fwd.

@@ -55,11 +55,13 @@ def n_features(params: Params, prefix: str = "fs") -> int:
     return 1 + max(int(m.group(1)) for k in params for m in [pat.match(k)] if m)
 
 
-def mlp_apply(layers: Sequence[Layer], v: Tensor) -> Tensor:
+def mlp_apply(layers: Sequence[Layer], v: Tensor, keep: Optional[Sequence[Tensor]] = None, drop_p: float = 0.0) -> Tensor:
     """``Linear -> ReLU -> ... -> Linear`` on ``v [M, in]`` (eval mode: Dropout is identity).
 
     Follows the ``nn.Sequential`` built at GNAN.py:24-34 / GNAN.py:38-47
-    (``n_layers == 1`` degenerates to one Linear, GNAN.py:25-26).
+    (``n_layers == 1`` degenerates to one Linear, GNAN.py:25-26).  Training mode: ``keep[i] [M, H]`` is the Bernoulli
+    keep-mask of the ``nn.Dropout`` behind hidden layer ``i`` (GNAN.py:28,32) — whatever drew it — and kept units are
+    scaled by ``1 / (1 - drop_p)``, which is what ``nn.Dropout`` computes.
     """
     h = v
     last = len(layers) - 1
@@ -67,18 +69,22 @@ def mlp_apply(layers: Sequence[Layer], v: Tensor) -> Tensor:
         h = torch.nn.functional.linear(h, w.to(h.dtype), None if b is None else b.to(h.dtype))
         if i != last:
             h = torch.relu(h)
+            if keep is not None:
+                h = h * keep[i].to(h.dtype) / (1.0 - drop_p)
     return h
 
 
 # --------------------------------------------------------------------------
 # a2: per-feature shape functions
 # --------------------------------------------------------------------------
-def feature_mlps(x: Tensor, params: Params, prefix: str = "fs") -> Tensor:
-    """``fx[n, k, :] = f_k(x[n, k])`` — GNAN.py:57-62, models.py:360-365, models.py:292-297."""
+def feature_mlps(x: Tensor, params: Params, prefix: str = "fs", keep: Optional[Tensor] = None, drop_p: float = 0.0) -> Tensor:
+    """``fx[n, k, :] = f_k(x[n, k])`` — GNAN.py:57-62, models.py:360-365, models.py:292-297.
+    ``keep [N, F, n_hidden, H]``: training-mode Dropout keep-masks (see :func:`mlp_apply`)."""
     F = x.shape[1]
     cols = []
     for k in range(F):
-        cols.append(mlp_apply(mlp_layers(params, f"{prefix}.{k}"), x[:, k].reshape(-1, 1)))
+        masks = None if keep is None else [keep[:, k, l] for l in range(keep.shape[2])]
+        cols.append(mlp_apply(mlp_layers(params, f"{prefix}.{k}"), x[:, k].reshape(-1, 1), masks, drop_p))
     return torch.stack(cols, dim=1)  # [N, F, C]
 
 

@@ -1455,3 +1455,59 @@ def test_pre_rho_row_table_vs_oracle(L, H, C, bias, D, zero_bias, route, monkeyp
     scale = max(float(v.abs().max()) for v in ref.values())
     for nm, gr in zip(names, got):
         assert float((gr.cpu().double().reshape(ref[nm].shape) - ref[nm]).abs().max()) <= 2e-5 * scale, (nm, route)
+
+
+@pytest.mark.parametrize("F,L,H,C,bias", [(5, 3, 16, 1, True), (4, 2, 8, 3, True), (6, 3, 64, 7, False), (3, 4, 8, 2, True),
+                                           (2, 3, 96, 2, True), (3, 1, 0, 2, True)])
+@pytest.mark.parametrize("sum_features", [True, False])
+def test_training_mode_dropout_in_the_kernels(F, L, H, C, bias, sum_features):
+    """GNAN.py:28,32 (run.sh: dropout 0.6): nn.Dropout behind every hidden ReLU, inside gnan_fmlp_fwd / gnan_fmlp_bwd.  The
+    masks are a hash of (seed, node, feature, layer, unit); gnan_dropout_mask writes them out and the oracle — the same
+    Linear / ReLU / Dropout chain with those masks, float64 — must agree, forward and every parameter gradient.  (L = 4 and
+    H = 96 are beyond gnan_fmlp_bwd: their backward runs the batched restatement with the kernels' masks.)"""
+    from gnan_amd.functional import dropout_masks, feature_mlps_dropout
+    n, drop_p, seed = 700, 0.6, 123456789012345
+    sd = _mlp_state(F, L, max(H, 1), C, bias, seed=F + L)
+    st = _stack(sd, F, L, H, C, bias)
+    leaves = [t for t in st[:6] if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(n, F, generator=gen) * 2 - 0.5
+    gup = torch.randn(n, C if sum_features else F * C, generator=gen)
+    y = feature_mlps_dropout(x.to(DEV), st, sum_features, drop_p, seed=seed)
+    got = torch.autograd.grad(y, leaves, gup.to(DEV))
+    keep = None
+    if L > 1:
+        keep = dropout_masks(seed, drop_p, n, F, L - 1, H, DEV).cpu()
+        rate = float(keep.float().mean())
+        assert abs(rate - (1 - drop_p)) < 4 * (drop_p * (1 - drop_p) / keep.numel()) ** 0.5 + 1e-3, rate
+        assert float(keep[:, 0, 0].float().mean(0).min()) > 0.2          # no unit or node is always dropped
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = O.feature_mlps(x.double(), sd64, keep=keep, drop_p=drop_p)
+    ref = ref.sum(1) if sum_features else ref.reshape(n, -1)
+    assert O.rel_err(y.detach().cpu(), ref.detach()) <= 1e-5
+    ref.backward(gup.double())
+    last = 3 * (L - 1)
+    want = {"w_last": torch.stack([sd64[f"fs.{k}.{last}.weight"].grad for k in range(F)])}
+    if L == 1:
+        want["w_last"] = want["w_last"][..., 0]
+    if bias:
+        want["b_last"] = torch.stack([sd64[f"fs.{k}.{last}.bias"].grad for k in range(F)])
+    if L > 1:
+        want["w_first"] = torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)])
+        if bias:
+            want["b_first"] = torch.stack([sd64[f"fs.{k}.0.bias"].grad for k in range(F)])
+    if L > 2:
+        want["w_mid"] = torch.stack([torch.stack([sd64[f"fs.{k}.{3 * li}.weight"].grad for k in range(F)]) for li in range(1, L - 1)])
+        if bias:
+            want["b_mid"] = torch.stack([torch.stack([sd64[f"fs.{k}.{3 * li}.bias"].grad for k in range(F)]) for li in range(1, L - 1)])
+    names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
+    scale = max(float(v.abs().max()) for v in want.values())
+    for nm, gr in zip(names, got):
+        assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, nm
+    if L > 1:
+        with torch.no_grad():
+            again = feature_mlps_dropout(x.to(DEV), st, sum_features, drop_p, seed=seed)
+            other = feature_mlps_dropout(x.to(DEV), st, sum_features, drop_p, seed=seed + 1)
+        assert torch.equal(again, y.detach()) and not torch.equal(other, y.detach())
