@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnan_amd  # noqa
 from gnan_amd import HopGraph, synthetic as syn
 from gnan_amd.functional import spmm_launch

@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnan_amd  # noqa
 from gnan_amd import functional, synthetic as syn
 from gnan_amd.functional import column_sums, spmm_launch
