@@ -920,9 +920,14 @@ def _spmm_args(g: HopGraph, S, lut, use_cnt, s_total, out, row_ids, per_row_lut,
         s_by_code=int(s_by_code), nnz=(0 if (g.col is None or not WIDE_INDEX_LOADS) else int(g.col.numel())),
         packed_index=int(packed))
     if hot_rows and packed and HOT_ROWS_IN_LDS:
-        # the appended compact copy of the most listed rows sits behind the real ones: its head is served from LDS
+        # the appended compact copy of the most listed rows sits behind the real ones: its head is served from LDS — where it
+        # receives enough of the pairs to pay for the persistent kernel's lower occupancy (10M-node R-MAT: 32 % at W = 1,
+        # 1.04 -> 0.91 ms; the 111M-node graph: 20.1 -> 20.7 ms, so not there)
         W = S.shape[1]
-        a.hot_lo, a.hot_rows = g.n_cols - int(hot_rows), min(int(hot_rows), HOT_LDS_FLOATS // max(W, 1))
+        head = min(int(hot_rows), HOT_LDS_FLOATS // max(W, 1))
+        share = (getattr(g, "_hot_head_share", None) or {}).get(head, 0.0)
+        if share >= HOT_LDS_MIN_SHARE:
+            a.hot_lo, a.hot_rows = g.n_cols - int(hot_rows), head
     return a
 
 
@@ -956,6 +961,7 @@ NARROW_SORTED_WALK = os.environ.get("GNAN_NARROW_SORTED", "1") != "0"   # narrow
 HOT_COLUMN_ROWS = os.environ.get("GNAN_HOT_COLUMNS", "1") != "0"        # ... and read the most listed neighbours from a compact copy
 HOT_ROWS_IN_LDS = os.environ.get("GNAN_HOT_LDS", "1") != "0"           # ... and serve the head of that copy from LDS (spmm_hot_kernel)
 HOT_LDS_FLOATS = 16384                                                   # 64 KB per workgroup, two workgroups per CU
+HOT_LDS_MIN_SHARE = 0.25                                                 # ... from this share of the pairs listing the LDS-resident rows
 DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
 
 

@@ -65,6 +65,7 @@ class HopGraph:
     _sorted_copy: Optional["HopGraph"] = field(default=None, repr=False)
     _hot: Optional[tuple] = field(default=None, repr=False)           # hot_columns(): (ids or None,)
     _sorted_copy_hot: Optional["HopGraph"] = field(default=None, repr=False)
+    _hot_head_share: Optional[dict] = field(default=None, repr=False)   # share of the pairs listing the first K hot neighbours
     _inv_rest: Optional[torch.Tensor] = field(default=None, repr=False)
     _cnt_by_col: bool = field(default=False, repr=False)     # transposed graphs: ``cnt`` rows belong to the neighbours
 
@@ -327,6 +328,10 @@ class HopGraph:
                 top = torch.argsort(listed, descending=True, stable=True)[:K]
                 if float(listed[top].sum()) >= HOT_COLUMNS_MIN_SHARE * self.nnz:
                     ids = top.contiguous()
+                    # share of the pairs listing the first 4096 / 8192 / 16384 of them: what an LDS-resident head of the copy
+                    # would serve (functional.HOT_LDS_MIN_SHARE decides whether spmm_hot_kernel is worth its lower occupancy)
+                    cum = torch.cumsum(listed[top].double(), 0) / max(self.nnz, 1)
+                    self._hot_head_share = {min(k, K): float(cum[min(k, K) - 1]) for k in (4096, 8192, 16384)}
             self._hot = (ids,)
         return self._hot[0]
 
@@ -355,6 +360,7 @@ class HopGraph:
         g = HopGraph(n_rows=self.n_rows, n_cols=self.n_cols + int(hot.numel()), n_codes=self.n_codes, code=self.code,
                      cnt=self.cnt, rowptr=self.rowptr, col=col_h)
         g._plan, g._plans, g._cnt_by_col = self._plan, self._plans, self._cnt_by_col     # same rows, same hub-row plans
+
         g.colp = g._packed_index()
         return g
 
@@ -367,6 +373,7 @@ class HopGraph:
             return copy, order, None
         if self._sorted_copy_hot is None:
             self._sorted_copy_hot = copy._with_hot_columns(hot)
+            self._sorted_copy_hot._hot_head_share = dict(self._hot_head_share or {})
         return self._sorted_copy_hot, order, hot
 
     def degree_schedule(self):
