@@ -137,7 +137,9 @@ class PreparedOptimizer:
     captured steps are released, or on request (e.g. before writing a checkpoint the reference's trainer should read)."""
 
     def __init__(self, optimizer):
-        self.optimizer = weakref.ref(optimizer)
+        # a STRONG reference (the optimizer does not own the model, so this keeps no model alive): the cycle collector clears
+        # weak references held by the garbage it is about to finalise, and restore() has to work from such a finaliser
+        self.optimizer = lambda: optimizer
         self.saved = []
         self.lrs: List[torch.Tensor] = []
         for group in optimizer.param_groups:

@@ -50,6 +50,21 @@ class _StepStore:
     def __reduce__(self):
         return (_StepStore, ())
 
+    def prepared_optimizers(self):
+        found = [e.value.get("prepared") for e in self.node.entries.values()]
+        if self.graph is not None:
+            found.append(self.graph.prepared)
+        return [p for p in found if p is not None]
+
+    def __del__(self):
+        # the model is gone (a fold of a cross-validation loop ended): an optimizer that outlives it gets its own settings
+        # back, as release_steps() would have done
+        try:
+            for prepared in self.prepared_optimizers():
+                prepared.restore()
+        except Exception:
+            pass
+
 
 def _steps_of(model) -> "_StepStore":
     store = model.__dict__.get("_gnan_steps")
@@ -71,6 +86,8 @@ def release_steps(model) -> None:
         store.graph.restore_optimizer()
     for rec in recs:
         _drop_step(rec)
+        if rec.get("prepared") is not None:                # prepared on the first epoch, never captured (fewer than three epochs)
+            rec.pop("prepared").restore()
     store.node.clear()
     store.graph = None
 

@@ -261,9 +261,13 @@ def test_captured_steps_die_with_their_model_and_hand_the_optimizer_back(monkeyp
             assert isinstance(g["lr"], float) and abs(g["lr"] - 1e-3) < 1e-12 and not g["capturable"] and not g["fused"]
             harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)   # and it still steps
             harness.release_steps(m)
-        return None
+        return opt
 
-    one_fold(False)
+    survivor = one_fold(False)                       # the optimizer outlives its model
+    gc.collect()
+    g0 = survivor.param_groups[0]
+    assert isinstance(g0["lr"], float) and not g0["capturable"], "the collected model's steps did not hand the optimizer back"
+    del survivor
     gc.collect()
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
