@@ -42,7 +42,8 @@ class _StepStore:
     def __init__(self):
         from ._cache import TensorKeyedCache
         self.node = TensorKeyedCache(8)      # per-(data tensors, mask, loss, optimizer) step records of full-batch node tasks
-        self.graph = None                    # _GraphTaskSteps: one captured step per graph shape
+        self.graph = None                    # _GraphTaskSteps: one captured training step per graph shape
+        self.graph_eval = None               # ... and one captured evaluation step per graph shape
 
     def __deepcopy__(self, memo):
         return _StepStore()
@@ -84,12 +85,14 @@ def release_steps(model) -> None:
     if store.graph is not None:
         recs += list(store.graph.buckets.values())
         store.graph.restore_optimizer()
+    if store.graph_eval is not None:
+        recs += list(store.graph_eval.buckets.values())
     for rec in recs:
         _drop_step(rec)
         if rec.get("prepared") is not None:                # prepared on the first epoch, never captured (fewer than three epochs)
             rec.pop("prepared").restore()
     store.node.clear()
-    store.graph = None
+    store.graph = store.graph_eval = None
 
 
 def _drop_step(rec) -> None:
@@ -238,7 +241,9 @@ class _GraphTaskSteps:
     """Captured training steps of a graph-level task, one per graph shape (``graphed.SlottedGraphStep``)."""
 
     def __init__(self, model, optimizer, loss_fn, classify, device):
-        self.model, self.optimizer, self.loss_fn, self.classify = weakref.ref(model), weakref.ref(optimizer), weakref.ref(loss_fn), classify
+        self.model, self.loss_fn, self.classify = weakref.ref(model), weakref.ref(loss_fn), classify
+        self.optimizer = (lambda: None) if optimizer is None else weakref.ref(optimizer)     # None: evaluation steps
+        self.training = optimizer is not None
         self.buckets = {}
         self.captured = 0
         self.prepared = None
@@ -295,7 +300,7 @@ class _GraphTaskSteps:
                     self.hits.add_(_hits(outputs.detach(), label))
                 return loss, None
             try:
-                if self.prepared is None:
+                if self.prepared is None and self.training:
                     from .graphed import prepare_optimizer
                     self.prepared = prepare_optimizer(self.optimizer())
                 rec["step"] = SlottedGraphStep(model, self.optimizer(), loss_of, graph, data.x, labels, prepared=self.prepared)
@@ -313,17 +318,18 @@ class _GraphTaskSteps:
 
 def _graph_task_steps(model, optimizer, loss_fn, classify, device):
     store = _steps_of(model)
-    steps = store.graph
+    slot = "graph" if optimizer is not None else "graph_eval"
+    steps = getattr(store, slot)
     if steps is None or not steps.matches(model, optimizer, loss_fn, classify):
         if steps is not None:
             for rec in steps.buckets.values():
                 _drop_step(rec)
             steps.restore_optimizer()
         try:
-            steps = store.graph = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)
+            steps = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)
         except TypeError:                                   # a loss / optimizer that cannot be weakly referenced: eager loop
-            store.graph = None
-            return None
+            steps = None
+        setattr(store, slot, steps)
     return steps
 
 
@@ -338,8 +344,10 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
     hits = torch.zeros((), device=device)
     n_samples, probas, targets = 0, [], []
     replayer = None
-    if (GRAPHED_STEPS and is_graph_task and optimizer is not None and not compute_auc and torch.device(device).type == "cuda"
-            and hasattr(model, "hop_graph")):
+    # graph-level tasks (a different small graph per step): one captured step per graph SHAPE — training steps, and evaluation
+    # passes too (test_epoch runs after every training epoch, main.py:176-215; eager, a 30-node graph costs ~15 launches)
+    if (GRAPHED_STEPS and is_graph_task and (optimizer is not None or not torch.is_grad_enabled()) and not compute_auc
+            and torch.device(device).type == "cuda" and hasattr(model, "hop_graph")):
         from .graphed import GraphedStep
         if GraphedStep.supported(model, optimizer):
             replayer = _graph_task_steps(model, optimizer, loss_fn, classify, device)

@@ -304,3 +304,38 @@ def test_an_edited_adjacency_is_not_replayed(monkeypatch):
     for _ in range(4):
         got = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
         assert abs(got[0] - want[0]) <= 1e-6 * max(1.0, abs(want[0])) and abs(got[0] - first[0]) > 1e-6
+
+
+@pytest.mark.parametrize("readout", [0, 2])
+def test_graph_task_evaluation_passes_are_replayed_per_shape(readout, monkeypatch):
+    """test_epoch on a graph-level task (trainer.py:89-154 runs after every training epoch): from the third graph of a shape on,
+    the forward + loss + hit count of a graph is one replayed hipGraph; same epoch returns as the eager pass."""
+    _need_gpu()
+    from gnan_amd import harness
+    from gnan_amd.models import TensorGNAN
+    F = 15
+    graphs = _graph_task(60, F, sizes=[12, 30, 12, 23, 30, 12, 41])
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    torch.manual_seed(0)
+    m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, readout_n_layers=readout, device=DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    m = m.to(DEV).eval()
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", False)
+    want = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    for epoch in range(3):
+        got = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+        assert abs(got[0] - want[0]) <= 1e-6 * max(1.0, abs(want[0])) and got[1] == want[1], (epoch, got, want)
+    steps = harness._steps_of(m).graph_eval
+    replays = sum(r["step"].step.graph.replays for r in steps.buckets.values() if r["step"] is not None)
+    assert replays >= 120, replays                             # 180 graphs, a handful of shapes, two eager sightings each
+    with torch.no_grad():                                      # the weights move: the replay reads the new values
+        for p in m.parameters():
+            p.mul_(1.1)
+    moved = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", False)
+    moved_eager = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+    assert abs(moved[0] - moved_eager[0]) <= 1e-6 * max(1.0, abs(moved_eager[0])) and abs(moved[0] - want[0]) > 1e-6
+    harness.release_steps(m)

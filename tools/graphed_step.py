@@ -111,8 +111,16 @@ def run_graph_task():
             ts.append((time.perf_counter() - t0) / len(graphs) * 1e3)
         out[tag + "_ms_per_graph_by_epoch"] = [round(t, 3) for t in ts]
         out[tag + "_last"] = ret
+        te = []
+        for epoch in range(4):                               # evaluation passes (trainer.py:89-154, after every training epoch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+            torch.cuda.synchronize()
+            te.append((time.perf_counter() - t0) / len(graphs) * 1e3)
+        out[tag + "_eval_ms_per_graph_by_epoch"] = [round(t, 3) for t in te]
         if on:
-            st = harness._GRAPH_STEPS[m]
+            st = harness._steps_of(m).graph
             out["shapes"] = len(st.buckets)
             out["captured"] = sum(r["step"] is not None for r in st.buckets.values())
             out["reserved_GB"] = round(torch.cuda.memory_reserved() / 2**30, 2)
