@@ -1125,6 +1125,7 @@ struct GradParams {
   int64_t ds_stride;
   int with_rest;
   const float* ds_add;   // optional [w_real]: added to every row of dS (the rest bucket's column-sum term)
+  int hot_code_lo, hot_codes;   // spmm_bwd_hot_kernel: packed rows [hot_lo, hot_lo + hot_n) of these code blocks are served from LDS
 };
 
 // BWD epilogue of one row for this lane's VEC columns: lanes of the first half hold A_d = sum over the row's code-d pairs
@@ -1522,6 +1523,224 @@ int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut)
   return GNAN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// spmm_bwd_hot_kernel — spmm_lut_grad_kernel<2, 1, true> (one-channel operands: packed rows of 2 floats, one lane per row)
+// the way spmm_hot_kernel runs the forward: the degree-sorted copy of the TRANSPOSED adjacency read as one packed index
+// stream, persistent 1024-thread workgroups (two per CU), and the packed rows of the most listed nodes — [hot_lo,
+// hot_lo + hot_n) of the code blocks [hot_code_lo, hot_code_lo + hot_codes) of V — served from a 64-KB LDS copy.
+// Ordinary rows: the arithmetic of spmm_lut_grad_kernel pair by pair (dS bit-identical); the table gradient's partials
+// are per WAVE — 64 rows at a time through a fixed float64 butterfly, added up over the wave's blocks: one record per
+// wave of the grid, so the order is fixed for a given device (the grid is two workgroups per CU); hub-row slices are summed
+// by one wave each (fixed butterfly) and finished by spmm_lut_grad_fixup_kernel<true>.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Vec<2> bwd_hot_gather(const Params& p, const GradParams& gp, const float2* hot, int c, int d) {
+  // branch-free, as hot_gather: both loads are issued, the hot lanes of the global load share one row
+  const int r = c - static_cast<int>(p.hot_lo);
+  const int dl = d - gp.hot_code_lo;
+  const bool is_hot = static_cast<unsigned>(r) < static_cast<unsigned>(p.hot_n) &&
+                      static_cast<unsigned>(dl) < static_cast<unsigned>(gp.hot_codes);
+  const int64_t row = is_hot ? static_cast<int64_t>(gp.hot_code_lo) * p.n_cols + p.hot_lo
+                             : static_cast<int64_t>(d) * p.n_cols + c;
+  const float2 g = *reinterpret_cast<const float2*>(static_cast<const float*>(p.S) + row * 2);
+  const float2 l = hot[is_hot ? dl * p.hot_n + r : 0];
+  Vec<2> out;
+  out.v[0] = is_hot ? l.x : g.x;
+  out.v[1] = is_hot ? l.y : g.y;
+  return out;
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void spmm_bwd_hot_kernel(const Params p, const GradParams gp) {
+  extern __shared__ __attribute__((aligned(16))) float2 hot2[];      // [hot_codes][hot_n]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int sub = wave >> 2, w4 = wave & 3;
+  for (int i = tid; i < gp.hot_codes * p.hot_n; i += 1024) {
+    const int dl = i / p.hot_n, r = i - dl * p.hot_n;
+    hot2[i] = *reinterpret_cast<const float2*>(static_cast<const float*>(p.S) +
+                                               (static_cast<int64_t>(gp.hot_code_lo + dl) * p.n_cols + p.hot_lo + r) * 2);
+  }
+  __syncthreads();
+  const int rest = p.D - 1;
+  const int idle_c = static_cast<int>(p.hot_lo), idle_d = gp.hot_code_lo;   // what a pair past the end reads: no request
+
+  // ---- hub-row slices: one wave per slice, a contiguous run of slices per wave (see spmm_hot_kernel) --------------------
+  {
+    const int n_waves = static_cast<int>(gridDim.x) * 16;
+    const int per = (p.n_slices + n_waves - 1) / n_waves;
+    const int gw = static_cast<int>(blockIdx.x) * 16 + wave;
+    const int s_lo = gw * per, s_hi = s_lo + per < p.n_slices ? s_lo + per : p.n_slices;
+    int a = 0;
+    if (s_lo < s_hi) {
+      int b = p.n_long;
+      while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (p.long_slice_ptr[mid] <= s_lo) a = mid; else b = mid;
+      }
+    }
+    for (int sidx = s_lo; sidx < s_hi; ++sidx) {
+      while (p.long_slice_ptr[a + 1] <= sidx) ++a;
+      const int64_t i = adj_row(p, p.long_rows[a]);
+      const int64_t row_lo = load_rowptr(p, i), row_hi = load_rowptr(p, i + 1);
+      const int64_t lo = row_lo + static_cast<int64_t>(sidx - p.long_slice_ptr[a]) * p.slice_edges;
+      const int64_t hi = lo + p.slice_edges < row_hi ? lo + p.slice_edges : row_hi;
+      Vec<2> t[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) t[d].v[0] = t[d].v[1] = 0.f;
+      constexpr int SF = 4;                              // pairs in flight per lane
+      for (int64_t base = lo + lane; base < hi; base += SF * kWave) {
+        unsigned ce[SF];
+#pragma unroll
+        for (int k = 0; k < SF; ++k) {
+          const int64_t e = base + static_cast<int64_t>(k) * kWave;
+          ce[k] = e < hi ? static_cast<unsigned>(p.col[e]) : 0u;
+        }
+        Vec<2> sv[SF];
+        int dk[SF];
+#pragma unroll
+        for (int k = 0; k < SF; ++k) {
+          const bool ok = base + static_cast<int64_t>(k) * kWave < hi;
+          int d = static_cast<int>(ce[k] >> kPackShift);
+          d = d < rest ? d : rest;
+          dk[k] = ok ? d : -1;
+          sv[k] = bwd_hot_gather(p, gp, hot2, ok ? static_cast<int>(ce[k] & kPackMask) : idle_c, ok ? d : idle_d);
+        }
+#pragma unroll
+        for (int k = 0; k < SF; ++k)
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) {
+            t[dd].v[0] += dk[k] == dd ? sv[k].v[0] : 0.f;
+            t[dd].v[1] += dk[k] == dd ? sv[k].v[1] : 0.f;
+          }
+      }
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          t[d].v[0] += __shfl_xor(t[d].v[0], off);
+          t[d].v[1] += __shfl_xor(t[d].v[1], off);
+        }
+      if (lane < 8) {                                    // slice_T[s][d][w], W == 2: lane = 2 d + w
+        float x = t[0].v[0];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) x = lane == 2 * d + v ? t[d].v[v] : x;
+        gp.slice_T[static_cast<int64_t>(sidx) * 8 + lane] = x;
+      }
+    }
+  }
+
+  // ---- ordinary rows: one lane per row, virtual 256-row blocks as in spmm_hot_kernel --------------------------------------
+  const int64_t n_vblocks = (p.n_rows + 255) / 256;
+  double run = 0.0;                                      // lane d < 4: this wave's share of dlut[d], 64 rows at a time
+  for (int64_t vb = static_cast<int64_t>(blockIdx.x) * 4 + sub; vb < n_vblocks; vb += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t q = (vb * 4 + w4) * kWave + lane;
+    float pd[4] = {0.f, 0.f, 0.f, 0.f};
+    bool live = q < p.n_rows;
+    int64_t lo = 0, hi = 0, oq = 0;
+    if (live) {
+      const int64_t i = adj_row(p, q);
+      oq = out_row(p, q, i);
+      lo = load_rowptr(p, i);
+      hi = load_rowptr(p, i + 1);
+      live = hi - lo <= p.long_threshold;               // hub row: sliced above, finished by the fix-up kernel
+    }
+    if (live) {
+      Vec<2> t[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) t[d].v[0] = t[d].v[1] = 0.f;
+      constexpr int RUN = 8;                             // index entries per round (16 as in the forward: spills at 64 VGPRs)
+      for (int64_t base = lo; base < hi; base += RUN) {
+        int colv[RUN];
+        if (base + RUN <= p.nnz) {
+          load_col_run<RUN>(p.col + base, colv);
+        } else {
+#pragma unroll
+          for (int r = 0; r < RUN; ++r) colv[r] = base + r < hi ? p.col[base + r] : 0;
+        }
+        const int m = static_cast<int>(hi - base < RUN ? hi - base : RUN);
+        constexpr int FLY = 4;
+#pragma unroll
+        for (int j0 = 0; j0 < RUN; j0 += FLY) {
+          if (j0 >= m) break;
+          Vec<2> sv[FLY];
+          int d[FLY];
+#pragma unroll
+          for (int u = 0; u < FLY; ++u) {
+            const unsigned ce = static_cast<unsigned>(colv[j0 + u]);
+            const bool ok = j0 + u < m;
+            int dd = static_cast<int>(ce >> kPackShift);
+            dd = dd < rest ? dd : rest;
+            d[u] = ok ? dd : -1;
+            sv[u] = bwd_hot_gather(p, gp, hot2, ok ? static_cast<int>(ce & kPackMask) : idle_c, ok ? dd : idle_d);
+          }
+#pragma unroll
+          for (int u = 0; u < FLY; ++u)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+              t[dd].v[0] += d[u] == dd ? sv[u].v[0] : 0.f;
+              t[dd].v[1] += d[u] == dd ? sv[u].v[1] : 0.f;
+            }
+        }
+      }
+      bwd_finish<2, 1>(p, gp, oq, 0, t, pd);
+    }
+    // the table gradient's partial of these 64 rows: float64, fixed butterfly
+    double s[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s[d] = live ? static_cast<double>(pd[d]) : 0.0;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) s[d] += __shfl_xor(s[d], off);
+    double mine = s[0];
+    mine = lane == 1 ? s[1] : mine;
+    mine = lane == 2 ? s[2] : mine;
+    mine = lane == 3 ? s[3] : mine;
+    run += mine;
+  }
+  if (lane < 4) gp.blk[(static_cast<int64_t>(blockIdx.x) * 16 + wave) * 4 + lane] = run;
+}
+
+// does gnan_spmm_bwd_narrow run on spmm_bwd_hot_kernel?  (packed index stream: only that kernel reads it)
+bool bwd_hot_applies(const gnan_spmm_args* a) { return a->packed_index && a->W == 2; }
+
+int bwd_hot_grid() {                              // two workgroups per CU
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus * 2;
+}
+
+size_t bwd_hot_blk_entries(const gnan_spmm_args* a) {    // one record per wave of the grid + one per hub row
+  return static_cast<size_t>(bwd_hot_grid()) * 16 + static_cast<size_t>(a->n_long > 0 ? a->n_long : 0);
+}
+
+int launch_bwd_hot(const Params& p, GradParams gp, hipStream_t st, float* dlut) {
+  const int grid = bwd_hot_grid();
+  size_t lds = static_cast<size_t>(gp.hot_codes) * p.hot_n * 2 * sizeof(float);
+  lds = lds < 16 ? 16 : lds;                      // the idle LDS read of a launch without hot rows
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_bwd_hot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(kHotLdsFloats * sizeof(float)));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "spmm_bwd_hot: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  gp.n_row_blocks = static_cast<int64_t>(grid) * 16;
+  hipLaunchKernelGGL(spmm_bwd_hot_kernel, dim3(static_cast<unsigned>(grid)), dim3(1024), lds, st, p, gp);
+  if (int rc = gnan::check_launch("spmm_bwd_hot_kernel")) return rc;
+  if (p.n_slices > 0) {
+    hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel<true>, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p, gp);
+    if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
+  }
+  hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(1), dim3(1024), 0, st, gp.blk, gp.n_row_blocks + p.n_long, p.D, dlut);
+  return gnan::check_launch("spmm_lut_grad_final_kernel");
+}
+
 __global__ void zero_floats_kernel(float* out, int n) {     // (a kernel: captured memsets replay wrongly on ROCm 7.2)
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = 0.f;
 }
@@ -1662,7 +1881,8 @@ static size_t bwd_narrow_workspace_bytes(const gnan_spmm_args* a) {
   const int lpr = a->W / vec >= 1 ? a->W / vec : 1;
   size_t bytes = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
   bytes = (bytes + 15) / 16 * 16;
-  return bytes + lut_grad_blk_entries(a, vec, lpr) * 4 * sizeof(double);
+  const size_t entries = bwd_hot_applies(a) ? bwd_hot_blk_entries(a) : lut_grad_blk_entries(a, vec, lpr);
+  return bytes + entries * 4 * sizeof(double);
 }
 
 extern "C" size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_bwd_narrow_args* g) {
@@ -1680,7 +1900,7 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* g, gnan_str
   void* workspace = g->workspace;
   const size_t workspace_bytes = g->workspace_bytes;
   if (int rc = validate(a)) return rc;
-  GNAN_REQUIRE(!a->packed_index, "bwd_narrow: packed index entries are read by gnan_spmm_fwd only");
+  GNAN_REQUIRE(!a->packed_index || a->W == 2, "bwd_narrow: packed index entries are read for one-channel operands only (W == 2)");
   GNAN_REQUIRE(dS != nullptr && dlut != nullptr && (s_rows != nullptr || a->n_rows == 0), "bwd_narrow: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->s_dtype != GNAN_F32 || a->lut_row_stride != 0 || a->cnt != nullptr)
@@ -1709,6 +1929,21 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* g, gnan_str
   gp.n_row_blocks = 0;
   gp.s_rows = s_rows; gp.s_rows_stride = s_rows_stride; gp.half = half; gp.w_real = w_real;
   gp.dS = dS; gp.ds_stride = ds_stride; gp.with_rest = with_rest; gp.ds_add = g->ds_add;
+  gp.hot_code_lo = 0; gp.hot_codes = 0;
+  if (bwd_hot_applies(a)) {
+    // one-channel operands over a packed index stream: the persistent kernel, with the head of the appended hot rows in LDS
+    Params ph = p;
+    if (a->hot_rows > 0) {
+      GNAN_REQUIRE(g->hot_codes >= 1 && g->hot_code_lo >= 0 && g->hot_code_lo + g->hot_codes <= a->D,
+                   "bwd_narrow: hot code blocks outside [0, D)");
+      GNAN_REQUIRE(a->hot_lo >= 0 && a->hot_lo + a->hot_rows <= a->n_cols, "bwd_narrow: hot rows outside the packed rows");
+      GNAN_REQUIRE(static_cast<int64_t>(a->hot_rows) * g->hot_codes * 2 <= kHotLdsFloats, "bwd_narrow: hot rows exceed 64 KB of LDS");
+      gp.hot_code_lo = g->hot_code_lo; gp.hot_codes = g->hot_codes;
+    } else {
+      ph.hot_lo = 0; ph.hot_n = 0;
+    }
+    return launch_bwd_hot(ph, gp, st, dlut);
+  }
   switch (half) {      // one lane per row while a row is one 8- or 16-byte load (64 rows per wavefront instead of 32)
     case 1: return launch_lut_grad<2, 1, true>(p, gp, st, dlut);
     case 2: return launch_lut_grad<4, 1, true>(p, gp, st, dlut);

@@ -1119,6 +1119,7 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
 
 
 NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"   # dS and dlut from one transposed pass
+NARROW_BWD_PERSISTENT = os.environ.get("GNAN_NARROW_BWD_PERSISTENT", "1") != "0"   # ... one channel: packed index, persistent workgroups, hot rows in LDS
 
 
 def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int,
@@ -1172,12 +1173,29 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
         V = torch.cat([V3, V3.index_select(1, hot)], dim=1).view(-1, V.shape[1])
     scatter = 0 if order is None else 2
     plan = gt.narrow_row_plan() if (V.shape[1] * 4 <= 8 and NARROW_ROW_SLICING) else gt.long_row_plan()
-    a = _spmm_args(gt, V, lut, False, None, dS, order, False, plan=plan, scatter_out=scatter)
+    # one channel (packed rows of 2 floats) over a sorted copy: one packed index stream, persistent workgroups
+    # (spmm_bwd_hot_kernel) — 10M-node R-MAT: 1.19 -> see DESIGN.md section 4.6
+    packed = V.shape[1] == 2 and order is not None and NARROW_BWD_PERSISTENT
+    a = _spmm_args(gt, V, lut, False, None, dS, order, False, plan=plan, scatter_out=scatter, packed=packed)
     a.n_cols = gt.n_cols                              # rows of V = n_cols * D (checked by the kernel's addressing only)
     a.y_stride = V.shape[1]                           # Y is not written by this entry point (dS is); keeps validate() content
     na = _lib.SpmmBwdNarrowArgs(spmm=a, s_rows=_lib.ptr(S_rows), s_rows_stride=S_rows.stride(0), w_real=W,
                                 with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0), dlut=_lib.ptr(dlut),
                                 ds_add=None if ds_add is None else _lib.ptr(ds_add))
+    if a.packed_index and hot is not None and HOT_ROWS_IN_LDS:
+        # ... with the head of the appended hot rows in LDS.  Code 0 is the self pair of a hop-coded graph (one pair per
+        # row, never a hot one): the LDS copy covers the other listed codes
+        listed = D - 1 if with_rest else D
+        code_lo = 1 if listed > 1 else 0
+        codes = listed - code_lo
+        head = HOT_LDS_FLOATS // (2 * codes)
+        head = 1 << (head.bit_length() - 1)           # the shares are known for 4096 / 8192 / 16384 rows
+        head = min(int(hot.numel()), head)
+        share = (getattr(gt, "_hot_head_share", None) or {}).get(head, 0.0)
+        if share >= HOT_LDS_MIN_SHARE:
+            a.hot_lo, a.hot_rows = gt.n_cols - int(hot.numel()), head
+            na.spmm.hot_lo, na.spmm.hot_rows = a.hot_lo, a.hot_rows       # (the struct was copied into na)
+            na.hot_code_lo, na.hot_codes = code_lo, codes
     need = _lib.lib().gnan_spmm_bwd_narrow_workspace_bytes(na)
     ws = torch.empty(need // 8 + 2, dtype=torch.float64, device=V.device)
     na.workspace, na.workspace_bytes = _lib.ptr(ws), ws.numel() * 8

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 30
+#define GNAN_ABI_VERSION 31
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -500,6 +500,11 @@ int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* a, gnan_stream_t stream);
  *   dlut[D-1]  = - sum_j < s_rows[j, :], Q[j] >   (with_rest; the caller adds < s_total, sum_i dY_i / cnt(i, D-1) >)
  * s_rows [n_rows, w_real] are the operand rows of the forward pass (S itself).  Fixed-order float64 partials: bit-reproducible.
  * It replaces gnan_spmm_fwd(s_by_code) + gnan_spmm_lut_grad — two traversals of the same pairs — by one.
+ * One-channel operands (a->W == 2) may come with a->packed_index = 1 (col entries = column | code << 29, a->code unread):
+ * spmm_bwd_hot_kernel then walks the rows with persistent workgroups, and with a->hot_rows > 0 the packed rows
+ * [a->hot_lo, a->hot_lo + a->hot_rows) of the code blocks [hot_code_lo, hot_code_lo + hot_codes) — a->hot_rows * hot_codes
+ * * 8 bytes <= 64 KB — are served from LDS.  Ordinary rows give the same dS bits as the generic kernel; hub-row slices and the
+ * table gradient's float64 partials are added wave by wave (fixed order, bit-reproducible).
  * ------------------------------------------------------------------------------------------- */
 /* builds that packed operand, code-major: V[d*(n + n_hot) + i, :] = [ dY[i, :W] / max(cnt[i, d], 1) | dY[i, :W] /
  * max(cnt[i, D-1], 1) ], each half zero padded to `half` floats (cnt == NULL: no division; with_rest == 0: second halves
@@ -534,6 +539,8 @@ typedef struct gnan_spmm_bwd_narrow_args {
   size_t workspace_bytes;
   const float* ds_add;       /* optional [w_real]: a vector added to every row of dS — d/dS_j of the rest bucket's
                                 wt(i, rest) * total term is the same for every j (the caller forms it from the packed rows) */
+  int32_t hot_code_lo;       /* with spmm.hot_rows > 0: first code block whose hot rows sit in LDS ... */
+  int32_t hot_codes;         /* ... and how many blocks (>= 1) */
 } gnan_spmm_bwd_narrow_args;
 size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_bwd_narrow_args* a);
 int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* a, gnan_stream_t stream);

@@ -50,15 +50,20 @@ def main():
         opt.step()
         return loss
 
-    for name, fn, reps in (("fwd_ms", fwd, 5), ("fwd_bwd_adam_ms", step, 5)):
-        for _ in range(2):
+    for name, fn, reps in (("fwd_ms", fwd, 20), ("fwd_bwd_adam_ms", step, 20)):
+        for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         t0 = time.perf_counter()
-        for _ in range(reps):
+        marks[0].record()
+        for r in range(reps):
             fn()
+            marks[r + 1].record()
         torch.cuda.synchronize()
-        out[name] = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = (time.perf_counter() - t0) / reps * 1e3                          # wall clock, mean
+        per = sorted(marks[r].elapsed_time(marks[r + 1]) for r in range(reps))
+        out[name.replace("_ms", "_device_ms")] = {"min": round(per[0], 3), "median": round(per[reps // 2], 3)}
     out["loss"] = float(step())
     print(json.dumps(out))
     if os.environ.get("GNAN_STEP_PROFILE"):        # kernel split of the steady-state step (torch.profiler, 3 steps)
