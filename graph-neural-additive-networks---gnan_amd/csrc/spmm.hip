@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const Params p) {
   if (p.reduce_cr && lane < p.reduce_cr) p.Y[out_row(p, q, i) * p.y_stride + lane] = chan;
 }
 
-constexpr int kHotLdsFloats = 16384;   // 64 KB of hot operand rows per workgroup: two workgroups per CU
+constexpr int kHotLdsFloats = 16384;   // 64 KB of hot operand rows per workgroup (the default dynamic-LDS limit): two workgroups per CU
 
 // can the persistent hot-row kernel take this call?  (what the host wrapper sets up: functional.spmm_launch, narrow walk)
 bool hot_kernel_applies(const gnan_spmm_args* a) {
@@ -843,13 +843,6 @@ int launch_hot(const Params& p, hipStream_t st) {
     return n;
   }();
   const size_t lds = static_cast<size_t>(p.hot_n) * VEC * sizeof(float);
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_hot_kernel<VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(kHotLdsFloats * sizeof(float)));
-    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "spmm_hot: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    raised = true;
-  }
   hipLaunchKernelGGL((spmm_hot_kernel<VEC>), dim3(static_cast<unsigned>(cus) * 2), dim3(1024), lds, st, p);
   if (int rc = gnan::check_launch("spmm_hot_kernel")) return rc;
   if (p.n_slices > 0) {
@@ -1723,13 +1716,6 @@ int launch_bwd_hot(const Params& p, GradParams gp, hipStream_t st, float* dlut) 
   const int grid = bwd_hot_grid();
   size_t lds = static_cast<size_t>(gp.hot_codes) * p.hot_n * 2 * sizeof(float);
   lds = lds < 16 ? 16 : lds;                      // the idle LDS read of a launch without hot rows
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_bwd_hot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(kHotLdsFloats * sizeof(float)));
-    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "spmm_bwd_hot: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    raised = true;
-  }
   gp.n_row_blocks = static_cast<int64_t>(grid) * 16;
   hipLaunchKernelGGL(spmm_bwd_hot_kernel, dim3(static_cast<unsigned>(grid)), dim3(1024), lds, st, p, gp);
   if (int rc = gnan::check_launch("spmm_bwd_hot_kernel")) return rc;
