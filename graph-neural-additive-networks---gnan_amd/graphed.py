@@ -21,6 +21,7 @@ Dropout in training mode is stochastic per call and is never captured (``Graphed
 from __future__ import annotations
 
 import atexit
+import os
 import weakref
 from typing import Callable, List, Optional
 
@@ -189,6 +190,128 @@ def prepare_optimizer(optimizer) -> PreparedOptimizer:
     return PreparedOptimizer(optimizer)
 
 
+FLAT_OPTIMIZER_STEP = os.environ.get("GNAN_FLAT_OPTIMIZER", "1") != "0"   # captured steps update the FlatMLPStore buffers with one fused launch
+
+
+class FlatAdamStep:
+    """``optimizer.step()`` of a fused Adam / AdamW over a model whose Parameters are views of ``FlatMLPStore`` buffers, as
+    ONE fused update over the flat buffers.
+
+    The reference model owns F x L tiny ``nn.Linear`` tensors (8604 on the Cora shape, 1170 on the arxiv shape) and torch's
+    fused update takes ~70 of them per launch: 120 launches = 0.86 ms of a 4.9-ms replayed Cora-shaped step, 30 launches =
+    0.18 of 0.9 ms on the arxiv shape.  The Parameters and their gradients already lie in a dozen contiguous buffers; here
+    the optimizer STATE is re-homed the same way — ``state[p]['exp_avg']``, ``['exp_avg_sq']`` and ``['step']`` become
+    views of flat tensors, values kept — and the update is one ``torch._fused_adam_`` call over the flat tensors: the same
+    kernel applied to the same elements, bit for bit what ``optimizer.step()`` computes, and ``optimizer.step()`` itself,
+    ``state_dict()`` and ``load_state_dict()`` keep working on the views.
+
+    :meth:`build` returns None whenever the equivalence is not obvious: another optimizer class, several parameter groups,
+    ``amsgrad`` / ``maximize`` / ``differentiable``, parameters outside the stores, gradients missing, step counters that
+    differ between parameters."""
+
+    def __init__(self):
+        self.P, self.G, self.M, self.V, self.step_of = [], [], [], [], []
+        self.steps = None
+        self.decoupled = False
+
+    @staticmethod
+    def build(model, optimizer) -> Optional["FlatAdamStep"]:
+        if not FLAT_OPTIMIZER_STEP or type(optimizer) not in (torch.optim.Adam, torch.optim.AdamW):
+            return None
+        if len(optimizer.param_groups) != 1:
+            return None
+        group = optimizer.param_groups[0]
+        if group.get("amsgrad") or group.get("maximize") or group.get("differentiable") or not group.get("fused"):
+            return None
+        stores = [st for m in model.modules() for st in getattr(m, "_stores", {}).values()]
+        names = [(st, name) for st in stores for name in st.buf]
+        if not names or any(not st.consistent() or name not in st.grad for st, name in names):
+            return None
+        pairs = [st.views_like(name, st.buf[name]) for st, name in names]
+        covered = {id(p) for pr in pairs for p, _ in pr}
+        if covered != {id(p) for p in group["params"]} or len(covered) != sum(len(pr) for pr in pairs):
+            return None
+        if any(p.grad is not None and p.grad.is_sparse for p in group["params"]):
+            return None
+        self = FlatAdamStep()
+        self.decoupled = bool(group.get("decoupled_weight_decay", False))
+        dev = names[0][0].buf[names[0][1]].device
+        state = optimizer.state
+        seen = [state[p]["step"] for p in group["params"] if p in state and "step" in state[p]]
+        if seen and len(seen) != len(covered):
+            return None                                  # some parameters have stepped and some have not
+        if seen:
+            all_steps = torch.stack([s.detach().to(dev, torch.float32).reshape(()) for s in seen])
+            if bool((all_steps != all_steps[0]).any()):
+                return None
+            start = all_steps[0].clone()
+        else:
+            start = torch.zeros((), dtype=torch.float32, device=dev)
+        self.steps = start.repeat(len(covered)).contiguous()       # one float32 counter per Parameter, as the fused update keeps them
+        at = 0
+        for (st, name), pr in zip(names, pairs):
+            P, G = st.buf[name], st.grad[name]
+            M, V = torch.zeros_like(P), torch.zeros_like(P)
+            for (p, _), (_, m), (_, v) in zip(pr, st.views_like(name, M), st.views_like(name, V)):
+                old = state.get(p)
+                if old and "exp_avg" in old:
+                    m.copy_(old["exp_avg"])
+                    v.copy_(old["exp_avg_sq"])
+                state[p] = {"step": self.steps[at], "exp_avg": m, "exp_avg_sq": v}
+                at += 1
+            self.P.append(P); self.G.append(G); self.M.append(M); self.V.append(V)
+            self.step_of.append(self.steps[at - 1])
+        self.optimizer = optimizer
+        self.whole = list(zip(self.P, self.G))                       # the stores' own tensors (valid() compares identities)
+        self._split()
+        return self
+
+    def _split(self, target: int = 24, floor: int = 4096) -> None:
+        """The multi-tensor kernel gives every 65 536-element chunk of a tensor to ONE workgroup: a small model's flat
+        buffers would be updated by a dozen workgroups, each walking tens of thousands of elements (the 15-feature graph-task
+        model: +19 us per step against its 96 separate tensors).  Buffers are therefore cut into about ``target`` pieces of
+        at least ``floor`` elements in total — still one launch (36 tensors fit), but the pieces of a small model are short;
+        large models keep chunk-sized work per workgroup."""
+        total = sum(t.numel() for t in self.P)
+        piece = max(floor, -(-total // target))
+        piece = -(-piece // 4) * 4                                   # whole 16-byte vectors
+        lists = ([], [], [], [], [])
+        for P, G, M, V, st in zip(self.P, self.G, self.M, self.V, self.step_of):
+            flat = [t.view(-1) for t in (P, G, M, V)]
+            for lo in range(0, P.numel(), piece):
+                for dst, t in zip(lists, flat):
+                    dst.append(t[lo:lo + piece])
+                lists[4].append(st)
+        self.buffers = len(self.P)
+        self.P, self.G, self.M, self.V, self.step_of = lists
+
+    def valid(self, model, optimizer) -> bool:
+        """Still the flat form of THIS optimizer over THIS model's current buffers?  (Every captured step of a model — one
+        per graph shape in a graph-level task — shares one instance: a second ``build`` would re-home the state again and
+        strand the steps captured over the first.)"""
+        if optimizer is not self.optimizer or not self.intact(optimizer):
+            return False
+        stores = [st for m in model.modules() for st in getattr(m, "_stores", {}).values()]
+        now = [(st.buf[name], st.grad.get(name)) for st in stores for name in st.buf]
+        return len(now) == len(self.whole) and all(a is p and b is g for (a, b), (p, g) in zip(now, self.whole))
+
+    def intact(self, optimizer) -> bool:
+        """The optimizer state still consists of the flat tensors' views (``load_state_dict`` replaces the state tensors)."""
+        group = optimizer.param_groups[0]
+        p0, p1 = group["params"][0], group["params"][-1]
+        s0, s1 = optimizer.state.get(p0), optimizer.state.get(p1)
+        lo, hi = self.steps.data_ptr(), self.steps.data_ptr() + self.steps.numel() * 4
+        return bool(s0 and s1 and lo <= s0["step"].data_ptr() < hi and lo <= s1["step"].data_ptr() < hi)
+
+    def step(self) -> None:
+        g = self.optimizer.param_groups[0]
+        self.steps.add_(1)
+        fn = torch._fused_adamw_ if self.decoupled else torch._fused_adam_
+        beta1, beta2 = g["betas"]
+        fn(self.P, self.G, self.M, self.V, [], self.step_of, amsgrad=False, lr=g["lr"], beta1=float(beta1), beta2=float(beta2),
+           weight_decay=g["weight_decay"], eps=g["eps"], maximize=False, grad_scale=None, found_inf=None)
+
+
 class GraphedStep:
     """One captured step on fixed inputs: ``outputs = model(data)``, optionally followed by
     ``loss = loss_of(outputs)``, ``loss.backward()``, ``optimizer.step()``.
@@ -220,6 +343,7 @@ class GraphedStep:
             self.prepared, self._own_prepared = PreparedOptimizer(optimizer), True
         self.lrs = self.prepared.lrs if self.training else []
         self.outputs = self.loss = self.extras = None
+        self.flat = None
 
         def step():
             if self.training:
@@ -227,7 +351,7 @@ class GraphedStep:
                 out = out[0] if isinstance(out, tuple) else out
                 loss, extras = loss_of(out)
                 loss.backward()
-                optimizer.step()
+                self.flat.step() if self.flat is not None else optimizer.step()
                 return out.detach(), loss.detach(), extras
             with torch.no_grad():
                 out = fwd()
@@ -250,6 +374,12 @@ class GraphedStep:
             for _ in range(warmup):
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        # the update as one launch over the flat parameter buffers where that is the same computation (FlatAdamStep)
+        if self.training:
+            flat = getattr(self.prepared, "flat", None)
+            if flat is None or not flat.valid(model, optimizer):
+                flat = FlatAdamStep.build(model, optimizer)
+            self.flat = self.prepared.flat = flat
         try:
             self.graph = GraphedCallable(step, warmup=0, before_capture=clear)
         except CaptureFailed:
@@ -276,12 +406,14 @@ class GraphedStep:
         if restore_optimizer and self.prepared is not None:
             self.prepared.restore()
         self.outputs = self.loss = self.extras = None
-        self.model = self.data = self.optimizer = self.eager_step = None
+        self.model = self.data = self.optimizer = self.eager_step = self.flat = None
 
     def stale(self) -> bool:
         """Something the graph froze has changed: parameter storage (``.to()``, ``load_state_dict`` into new tensors),
         optimizer hyper-parameters other than the learning rate, train/eval mode."""
         if [p.data_ptr() for p in self._probes] != self._params or self.model.training != self._mode:
+            return True
+        if self.training and self.flat is not None and not self.flat.intact(self.optimizer):
             return True
         return self.training and _group_signature(self.optimizer) != self._groups
 

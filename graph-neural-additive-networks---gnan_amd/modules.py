@@ -127,6 +127,14 @@ class FlatMLPStore:
         for param, view in pairs:
             param.grad = view
 
+    def views_like(self, name: str, flat: torch.Tensor):
+        """``[(Parameter, view of flat)]`` for a tensor shaped like ``buf[name]``: the slice of ``flat`` that lies where the
+        Parameter lies in its buffer (optimizer state kept flat, ``graphed.FlatAdamStep``)."""
+        part, attr = name.split("_")
+        which = "weight" if attr == "w" else "bias"
+        return [(getattr(self.lin[k][l], which), view)
+                for i, l in enumerate(self.slots[part]) for k, view in enumerate(flat[i].unbind(0))]
+
     def _linked(self, name: str) -> bool:
         g = self.grad.get(name)
         if g is None:

@@ -92,6 +92,47 @@ def test_graphed_epochs_match_eager_epochs(n, F, C, dense, loss, monkeypatch):
         assert float((a[1][k] - b[1][k]).abs().max()) <= 2e-4 * scale, k
 
 
+@pytest.mark.parametrize("n,F,C,dense,opt_cls", [(3000, 129, 1, False, "Adam"), (300, 9, 4, True, "AdamW")])
+def test_captured_steps_update_the_flat_buffers_bit_for_bit(n, F, C, dense, opt_cls, monkeypatch):
+    """The captured step's update is ONE fused Adam launch over the FlatMLPStore buffers (graphed.FlatAdamStep) instead of
+    the optimizer's ~F x L / 70 launches: parameters AND optimizer state after twelve epochs are bit-identical to the same
+    run with the optimizer's own step captured; state_dict / load_state_dict keep working, and a loaded state is noticed."""
+    _need_gpu()
+    from gnan_amd import graphed, harness
+    data = _node_task(n, F, C, dense)
+    loss_fn = torch.nn.BCEWithLogitsLoss() if C == 1 else torch.nn.CrossEntropyLoss()
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    runs = {}
+    for flat in (False, True):
+        monkeypatch.setattr(graphed, "FLAT_OPTIMIZER_STEP", flat)
+        m = _model(F, C)
+        opt = getattr(torch.optim, opt_cls)(m.parameters(), lr=3e-3, weight_decay=1e-2)
+        for _ in range(12):
+            harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)
+        rec = [r.value for r in harness._steps_of(m).node.entries.values() if r.value["optimizer"] is not None][0]
+        assert rec["step"] is not None and rec["step"].graph.replays >= 9
+        assert (rec["step"].flat is not None) == flat
+        if flat:
+            assert rec["step"].flat.buffers <= 12 < len(list(m.parameters())) and len(rec["step"].flat.P) <= 36
+        runs[flat] = ({k: v.detach().clone() for k, v in m.state_dict().items()}, copy.deepcopy(opt.state_dict()), m, opt, rec)
+    for k, v in runs[False][0].items():
+        assert torch.equal(v, runs[True][0][k]), k
+    sa, sb = runs[False][1]["state"], runs[True][1]["state"]
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        for f in ("step", "exp_avg", "exp_avg_sq"):
+            assert sa[k][f].shape == sb[k][f].shape and torch.equal(sa[k][f], sb[k][f]), (k, f)
+    # a state loaded into the optimizer replaces the flat views: the captured step is dropped, the next epoch runs eagerly
+    # on the loaded state and is captured again
+    _, _, m, opt, rec = runs[True]
+    step = rec["step"]
+    opt.load_state_dict(copy.deepcopy(runs[False][1]))
+    harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)
+    assert rec["step"] is None or rec["step"] is not step
+    harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)
+    assert rec["step"] is not None and rec["step"] is not step and rec["step"].flat is not None
+
+
 def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
     _need_gpu()
     from gnan_amd import harness, pwl
