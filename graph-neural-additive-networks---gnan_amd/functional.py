@@ -414,7 +414,21 @@ def _table_grads_applies(L: int, H: int, C: int) -> bool:
     return HIP_TABLE_GRADS and C <= 4096 and ((L == 3 and H <= 64) or (L == 2 and H <= 128))
 
 
-def _fpwl_param_grads_launch(params, t, moments, L, H, C, F):
+def _grad_outputs(keep, dests):
+    """Output tensors of a parameter-gradient kernel: the caller's destinations (``FlatMLPStore.grad_dest`` — the kernel then
+    writes straight into the flat gradient buffer the Parameters' ``.grad`` views are cut from, no copy) where they fit."""
+    outs = []
+    for i, q in enumerate(keep):
+        if q is None:
+            outs.append(None)
+            continue
+        claim = None if dests is None else dests[i]
+        d = None if claim is None else claim(q.shape, q.device)      # claimed only if it fits: a claim must be used
+        outs.append(d if d is not None else torch.empty_like(q))
+    return outs
+
+
+def _fpwl_param_grads_launch(params, t, moments, L, H, C, F, dests=None):
     """``gnan_fpwl_param_grads``: gradients of the six stacked parameter tensors (None where a bias is absent) from the
     per-piece moments — ``moments`` is ``[T, 2, C]`` float32 or the ``(int64 moments, scales)`` pair of the fixed-point route."""
     fixed = isinstance(moments, tuple)
@@ -443,7 +457,7 @@ def _fpwl_param_grads_launch(params, t, moments, L, H, C, F):
                 total[5][:, c0:c1] = got[5]
         return total
     keep = [None if q is None else q.detach().float().contiguous() for q in params]
-    outs = [None if q is None else torch.empty_like(q) for q in keep]
+    outs = _grad_outputs(keep, dests)
     M = None if fixed else moments.detach().float().contiguous()
     a = _lib.FpwlGradArgs(
         off=_lib.ptr(t.off), anchor=_lib.ptr(t.anchor), moments=_lib.ptr(M),
@@ -464,14 +478,14 @@ HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
 HIP_SMALL_BACKWARD_MAX_WORK = 1 << 23
 
 
-def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F, dropout=None):
+def _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F, dropout=None, dests=None):
     """``gnan_fmlp_bwd``: gradients of the six stacked parameter tensors (None where a bias is absent), in their order."""
     xd = x.detach().float()
     xd = _rows(xd)
     g = grad_out.detach().float()
     g = _rows(g)
     keep = [None if t is None else t.detach().float().contiguous() for t in params]
-    outs = [None if t is None else torch.empty_like(t) for t in keep]
+    outs = _grad_outputs(keep, dests)
     w_mid = None if keep[2] is None else keep[2][0]              # [1, F, H, H] -> [F, H, H]   (absent for L == 2)
     d_w_mid = None if outs[2] is None else outs[2][0]
     b_mid = None if keep[3] is None else keep[3][0]
@@ -630,6 +644,7 @@ class _FeatureMLPs(torch.autograd.Function):
         ctx.meta = (sum_features, L, H, C, F)
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
+        ctx.grad_dests = _grad_dests_of(params)
         needs_grad = any(ctx.needs_input_grad[9:]) and not ctx.needs_input_grad[0]
         if needs_grad and out_dtype != torch.float32:
             raise _lib.GnanHipError("bf16 operand storage is an inference format: no backward pass")
@@ -659,12 +674,17 @@ class _FeatureMLPs(torch.autograd.Function):
         params = [saved.pop(0) if present else None for present in ctx.present]
         located, ctx.located = ctx.located, None
         gx, pg = _shape_function_grads(x, params, ctx.present, ctx.tables, grad_out, sum_features, L, H, C, F, ctx.x_abs_max,
-                                       located, ctx.needs_input_grad[0])
+                                       located, ctx.needs_input_grad[0], dests=ctx.grad_dests)
         return (gx, None, None, None, None, None, None, None, None, *pg)
 
 
+def _grad_dests_of(params):
+    """Per stacked parameter tensor: the getter of its direct gradient destination (set by ``FlatMLPStore.stacked``) or None."""
+    return [None if t is None else getattr(t, "gnan_grad_dest", None) for t in params]
+
+
 def _shape_function_grads(x, params, present, tables, grad_out, sum_features, L, H, C, F, x_abs_max=None, located=None,
-                          want_x_grad=False):
+                          want_x_grad=False, dests=None):
     """``(d x or None, [gradients of the six stacked parameter tensors, None where absent])`` of
     ``sum_n <grad_out[n], f(x[n])>`` — autograd through GNAN.py:57-62 (``sum_features``: through GNAN.py:157 as well)."""
     leaves = [None if t is None else t.detach().requires_grad_(True) for t in params]
@@ -677,7 +697,7 @@ def _shape_function_grads(x, params, present, tables, grad_out, sum_features, L,
         if _table_grads_applies(L, H, C) and x.is_cuda:
             # ... exactly, in one kernel: one reverse pass for the value and one for the slope of every non-empty piece
             M = _fpwl_moments(x, tables, grad_out, sum_features, x_abs_max, raw=True, located=located)
-            return None, _fpwl_param_grads_launch(params, tables, M, L, H, C, F)
+            return None, _fpwl_param_grads_launch(params, tables, M, L, H, C, F, dests=dests)
         M = _fpwl_moments(x, tables, grad_out, sum_features, x_abs_max, located=located)
         got = parameter_grads_from_moments(
             p, tables, M, lambda U, q: _fmlp_eager(U, StackedMLP(*[None if t is None else t.double()
@@ -690,7 +710,7 @@ def _shape_function_grads(x, params, present, tables, grad_out, sum_features, L,
         # small batches (the forward evaluated the MLPs directly): one workgroup per feature recomputes the
         # activations node by node and accumulates every parameter gradient in registers (gnan_fmlp_bwd) — the torch
         # restatement below materialises [F, n, H] activations for the same sums (Cora-shaped: 1 GB per layer)
-        return None, _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F)
+        return None, _fmlp_backward_launch(x, params, grad_out, sum_features, L, H, C, F, dests=dests)
     grads = [torch.zeros_like(t) for t in live]
     n = x.shape[0]
     chunk = max(1, _BWD_CHUNK_ELEMS // max(1, F * max(H, C)))

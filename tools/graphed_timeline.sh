@@ -11,12 +11,9 @@ for fn in glob.glob("$OUT/*kernel_trace.csv"):
     for r in csv.DictReader(open(fn)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-# the last training step: from the last-but-one fused Adam block backwards to the pwl_build before it
+# the last replayed training step: between the last two optimizer updates (one fused launch each, graphed.FlatAdamStep)
 adam = [i for i, r in enumerate(rows) if "FusedOptimizer" in r[2]]
-last = adam[-1]
-first = last
-while first > 0 and not ("FusedOptimizer" in rows[first - 1][2] and rows[first][0] - rows[first - 1][1] > 0 and "FusedOptimizer" not in rows[first][2]):
-    first -= 1
+last, first = adam[-1], adam[-2] + 1
 t0 = rows[first][0]
 prev_end = None
 busy = 0
