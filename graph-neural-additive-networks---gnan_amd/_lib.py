@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -146,6 +146,18 @@ class SpmmBwdNarrowArgs(C.Structure):
     ]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p), ("n_rows", C.c_int64), ("C", C.c_int32), ("kind", C.c_int32), ("stride", C.c_int64),
+        ("index", C.c_void_p), ("n", C.c_int64), ("labels", C.c_void_p), ("loss", C.c_void_p), ("hits", C.c_void_p),
+        ("grad", C.c_void_p), ("grad_stride", C.c_int64), ("loss_sum", C.c_void_p), ("hits_sum", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+LOSS_BCE_LOGITS, LOSS_CROSS_ENTROPY = 0, 1
+
+
 class BfsDenseArgs(C.Structure):
     _fields_ = [
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("n", C.c_int32), ("max_hops", C.c_int32), ("code", C.c_void_p),
@@ -189,6 +201,8 @@ SYMBOLS = {
     "gnan_fpwl_moment_scales": (C.c_int, [C.POINTER(MomentScalesArgs), C.c_void_p]),
     "gnan_fpwl_param_grads": (C.c_int, [C.POINTER(FpwlGradArgs), C.c_void_p]),
     "gnan_graph_replace_memsets": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gnan_loss_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnan_loss_step": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),

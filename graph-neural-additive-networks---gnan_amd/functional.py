@@ -1559,3 +1559,77 @@ def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
         Y = _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, 0, total_rows, total_group)
         return Y.view(Y.shape[0], -1, reduce_channels).sum(dim=1)
     return _RhoAggregate.apply(S, lut, g, use_cnt, with_rest, row_ids, s_total, reduce_channels, total_rows, total_group)
+
+
+# =============================================================================
+# the epoch loops' loss step (harness.py): selection, loss, gradient, hit count, running totals in one launch
+# =============================================================================
+def loss_kind(loss_fn, outputs: torch.Tensor) -> Optional[int]:
+    """``_lib.LOSS_*`` if ``loss_fn(outputs-as-the-trainer-feeds-them, labels)`` (trainer.py:61-64) is one of the two losses
+    ``gnan_loss_step`` computes, with the default options it assumes; None otherwise (the caller keeps ``loss_fn``)."""
+    if not FUSED_LOSS or not outputs.is_cuda or outputs.dim() != 2 or outputs.dtype != torch.float32:
+        return None
+    if (type(loss_fn) is torch.nn.BCEWithLogitsLoss and outputs.shape[1] == 1 and loss_fn.weight is None
+            and loss_fn.pos_weight is None and loss_fn.reduction == "mean"):
+        return _lib.LOSS_BCE_LOGITS
+    if (type(loss_fn) is torch.nn.CrossEntropyLoss and outputs.shape[1] > 1 and loss_fn.weight is None
+            and loss_fn.reduction == "mean" and loss_fn.ignore_index == -100 and loss_fn.label_smoothing == 0.0):
+        return _lib.LOSS_CROSS_ENTROPY
+    return None
+
+
+FUSED_LOSS = os.environ.get("GNAN_FUSED_LOSS", "1") != "0"
+
+
+def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, hits_sum):
+    x = _rows(outputs.detach())
+    n_rows, C = x.shape
+    n = int(labels.numel())
+    lab = labels.detach().contiguous()
+    lab = lab.float() if kind == _lib.LOSS_BCE_LOGITS else lab.long()
+    idx = None if index is None else index.detach().long().contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    hits = torch.empty((), dtype=torch.int64, device=x.device) if want_hits else None
+    grad = torch.empty((n_rows, C), dtype=torch.float32, device=x.device) if want_grad else None
+    need = _lib.lib().gnan_loss_workspace_bytes(n)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=x.device) if need else None
+    a = _lib.LossArgs(logits=_lib.ptr(x), n_rows=n_rows, C=C, kind=kind, stride=x.stride(0), index=_lib.ptr(idx), n=n,
+                      labels=_lib.ptr(lab), loss=_lib.ptr(loss), hits=_lib.ptr(hits), grad=_lib.ptr(grad),
+                      grad_stride=0 if grad is None else grad.stride(0), loss_sum=_lib.ptr(loss_sum), hits_sum=_lib.ptr(hits_sum),
+                      workspace=_lib.ptr(ws), workspace_bytes=need)
+    _lib.check(_lib.lib().gnan_loss_step(a, _lib.stream_of(x)), "gnan_loss_step")
+    return loss, hits, grad
+
+
+class _LossStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum):
+        loss, hits, grad = _loss_launch(outputs, labels, kind, index, want_hits, ctx.needs_input_grad[0], loss_sum, hits_sum)
+        ctx.grad = grad
+        if hits is not None:
+            ctx.mark_non_differentiable(hits)
+        return (loss, hits) if hits is not None else loss
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        grad, ctx.grad = ctx.grad, None
+        return grad * g_loss, None, None, None, None, None, None
+
+
+def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Optional[torch.Tensor] = None,
+              want_hits: bool = True, loss_sum: Optional[torch.Tensor] = None, hits_sum: Optional[torch.Tensor] = None):
+    """``(loss, hits)`` of the rows ``index`` of ``outputs`` (all rows without it) by ``gnan_loss_step``: the mean loss as a
+    0-d tensor that back-propagates into ``outputs`` (its gradient was formed in the same launch), the hit count as a 0-d
+    int64 tensor (None unless ``want_hits``); ``loss_sum`` / ``hits_sum`` (0-d float32 device tensors) are added to in place."""
+    _lib.require_device(outputs, labels)
+    if labels.numel() == 0:
+        raise ValueError("loss_step: no rows selected (the mean of an empty set)")
+    if index is not None and index.numel() != labels.numel():
+        raise ValueError("loss_step: index and labels differ in length")
+    if index is None and labels.numel() != outputs.shape[0]:
+        raise ValueError("loss_step: one label per output row")
+    for t in (loss_sum, hits_sum):
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.numel() != 1):
+            raise ValueError("loss_step: the running totals are 0-d float32 device tensors")
+    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum)
+    return got if want_hits else (got, None)

@@ -126,6 +126,14 @@ def _loss_of(loss_fn, outputs, labels):
     return loss_fn(outputs, labels)
 
 
+def _fused_kind(loss_fn, outputs):
+    """The loss as ``gnan_loss_step`` knows it, or None: stock torch then computes it (any other loss, CPU tensors)."""
+    if not torch.is_tensor(outputs) or not outputs.is_cuda:
+        return None
+    from .functional import loss_kind
+    return loss_kind(loss_fn, outputs)
+
+
 def _hits(outputs, labels) -> torch.Tensor:
     """Number of correct predictions as a 0-d tensor: arg-max for multi-class logits, sigmoid > 0.5 otherwise."""
     if outputs.dim() == 2 and outputs.shape[-1] > 1:
@@ -211,6 +219,11 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
         labels_m = labels[idx]
 
         def loss_of(outputs):
+            kind = _fused_kind(loss_fn, outputs)
+            if kind is not None:                     # selection, loss, its gradient and the hit count in one launch
+                from .functional import loss_step
+                loss, hits = loss_step(outputs, labels_m, kind, index=idx, want_hits=classify)
+                return loss, (hits, outputs.detach().index_select(0, idx) if compute_auc else None)
             picked = outputs.index_select(0, idx)
             loss = _loss_of(loss_fn, picked, labels_m)
             hits = _hits(picked.detach(), labels_m) if classify else None
@@ -294,6 +307,12 @@ class _GraphTaskSteps:
             loss_fn, classify = self.loss_fn(), self.classify
 
             def loss_of(outputs, label):
+                kind = _fused_kind(loss_fn, outputs)
+                if kind is not None and outputs.shape[0] == label.numel():
+                    from .functional import loss_step
+                    loss, _ = loss_step(outputs, label, kind, want_hits=False, loss_sum=self.total_loss,
+                                        hits_sum=self.hits if classify else None)
+                    return loss, None
                 loss = _loss_of(loss_fn, outputs, label)
                 self.total_loss.add_(loss.detach())
                 if classify:
@@ -367,6 +386,26 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
         outputs = model.forward(data)
         if isinstance(outputs, tuple):
             outputs = outputs[0]
+        kind = _fused_kind(loss_fn, outputs)
+        if kind is not None and (not is_graph_task or outputs.shape[0] == labels.numel()):
+            # gnan_loss_step: the mask's rows, the loss, its gradient, the hit count and the running totals in one launch
+            from .functional import loss_step
+            idx = None
+            if not is_graph_task:
+                idx = getattr(data, mask_name).nonzero().flatten()
+                labels = labels[idx]
+            n_samples += len(labels)
+            loss, _ = loss_step(outputs, labels, kind, index=idx, want_hits=False, loss_sum=total_loss,
+                                hits_sum=hits if classify else None)
+            if optimizer is not None:
+                loss.backward()
+                optimizer.step()
+            if compute_auc:
+                picked = outputs.detach() if idx is None else outputs.detach().index_select(0, idx)
+                probas.append(torch.sigmoid(picked).reshape(-1).cpu().numpy())
+                targets.append(labels.detach().cpu().numpy())
+            del loss, outputs
+            continue
         if not is_graph_task:
             mask = getattr(data, mask_name)
             labels, outputs = labels[mask], outputs[mask]

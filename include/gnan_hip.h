@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 31
+#define GNAN_ABI_VERSION 32
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -439,6 +439,39 @@ int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* tot
  * the most listed nodes' operand rows behind the operand, which gnan_spmm_args.hot_lo / hot_rows describe. */
 int gnan_gather_rows(const float* src, int64_t src_stride, const int64_t* ids, int64_t k, int32_t W, float* dst,
                      gnan_stream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * The loss step of the epoch loops (trainer.py:53-71 / :125-147) in one launch (two past 2048 rows, one more to zero the
+ * gradient rows a mask leaves out): rows index[0..n) of the logits (all rows 0..n-1 without index),
+ *   GNAN_LOSS_BCE_LOGITS   (C == 1, labels float32 [n]): mean_i (1 - t_i) x_i - logsigmoid(x_i)   = nn.BCEWithLogitsLoss()
+ *   GNAN_LOSS_CROSS_ENTROPY (C >= 2, labels int64 [n]):  mean_i logsumexp(x_i) - x_i[t_i]          = nn.CrossEntropyLoss()
+ * (default options: mean reduction, no weights, no label smoothing, no ignored class), float32 terms as torch forms them,
+ * float64 across rows in a fixed order.  Optional outputs: hits = #{(sigmoid(x_i) > 0.5) == t_i} or #{argmax x_i == t_i}
+ * (trainer.py:5-20); grad [n_rows, C] = d loss / d logits (rows outside index: zero; index entries must be distinct);
+ * loss_sum += loss and hits_sum += hits (the epoch's running totals, trainer.py:67-71, device scalars).
+ * Replaces the 20-25 element-wise / reduction launches stock torch needs for the same numbers.
+ * ------------------------------------------------------------------------------------------- */
+enum gnan_loss_kind { GNAN_LOSS_BCE_LOGITS = 0, GNAN_LOSS_CROSS_ENTROPY = 1 };
+typedef struct gnan_loss_args {
+  const float* logits;       /* [n_rows, C], row stride `stride` */
+  int64_t n_rows;
+  int32_t C;
+  int32_t kind;              /* enum gnan_loss_kind */
+  int64_t stride;
+  const int64_t* index;      /* optional [n] rows that count (device memory) */
+  int64_t n;                 /* >= 1 */
+  const void* labels;        /* [n] float32 (BCE) / int64 (cross entropy), aligned with index */
+  float* loss;               /* [1] */
+  int64_t* hits;             /* optional [1] */
+  float* grad;               /* optional [n_rows, C], row stride grad_stride */
+  int64_t grad_stride;
+  float* loss_sum;           /* optional [1] accumulators */
+  float* hits_sum;
+  void* workspace;           /* gnan_loss_workspace_bytes(n) */
+  size_t workspace_bytes;
+} gnan_loss_args;
+size_t gnan_loss_workspace_bytes(int64_t n);
+int gnan_loss_step(const gnan_loss_args* a, gnan_stream_t stream);
 
 /* same for bf16 operand rows (stride in elements, W % 4 == 0, 8-B aligned rows) */
 int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,

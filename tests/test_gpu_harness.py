@@ -16,6 +16,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+
+
 class Bag:
     def __init__(self, **kw):
         self.__dict__.update(kw)
@@ -121,3 +126,65 @@ def test_interpretability_exports_come_from_the_kernels_tables():
     f1 = O.feature_mlps(torch.ones(1, F, dtype=torch.float64), sd)[0]              # [F, C]
     assert h.shape == (F, 7, C)
     assert O.rel_err(h.cpu(), f1.unsqueeze(1) * O.rho_lut(sd, 8, dtype=torch.float64)[:7].unsqueeze(0)) <= 1e-5
+
+
+@pytest.mark.parametrize("kind,n_rows,C,masked", [("bce", 1, 1, False), ("bce", 37, 1, True), ("bce", 300_000, 1, True),
+                                                   ("ce", 50, 4, False), ("ce", 5000, 7, True), ("ce", 200_000, 3, True)])
+def test_fused_loss_step_matches_torch(kind, n_rows, C, masked):
+    """gnan_loss_step (row selection, mean loss, gradient w.r.t. the logits, hit count, running totals: one launch, two past
+    2048 rows) == nn.BCEWithLogitsLoss / nn.CrossEntropyLoss + the trainer's accuracy rule (trainer.py:5-20, 61-71) on the
+    same rows; strided logits, float64 truth for the loss."""
+    _need_gpu()
+    from gnan_amd import _lib
+    from gnan_amd.functional import loss_kind, loss_step
+    g = torch.Generator().manual_seed(n_rows + C)
+    wide = (torch.randn(n_rows, C + 2, generator=g) * 3).to(DEV)
+    logits = wide[:, 1:1 + C].clone().requires_grad_(True)                      # contiguous leaf ...
+    strided = wide[:, 1:1 + C].detach().requires_grad_(True)                    # ... and a strided one
+    idx = torch.nonzero(torch.rand(n_rows, generator=g) < 0.6).flatten().to(DEV) if masked else None
+    n = n_rows if idx is None else int(idx.numel())
+    if kind == "bce":
+        loss_fn, labels = torch.nn.BCEWithLogitsLoss(), (torch.rand(n, generator=g) < 0.5).float().to(DEV)
+    else:
+        loss_fn, labels = torch.nn.CrossEntropyLoss(), torch.randint(0, C, (n,), generator=g).to(DEV)
+    k = loss_kind(loss_fn, logits)
+    assert k == (_lib.LOSS_BCE_LOGITS if kind == "bce" else _lib.LOSS_CROSS_ENTROPY)
+    total, hit_total = torch.full((), 2.5, device=DEV), torch.full((), 10.0, device=DEV)
+    loss, hits = loss_step(logits, labels, k, index=idx, loss_sum=total, hits_sum=hit_total)
+    (3.0 * loss).backward()
+    # torch on the same rows
+    ref_in = wide[:, 1:1 + C].detach().clone().requires_grad_(True)
+    picked = ref_in if idx is None else ref_in.index_select(0, idx)
+    want = loss_fn(picked.flatten(), labels) if kind == "bce" else loss_fn(picked, labels)
+    (3.0 * want).backward()
+    want_hits = int(((torch.sigmoid(picked.detach()).reshape(-1) > 0.5) == labels).sum()) if kind == "bce" \
+        else int((picked.detach().argmax(-1) == labels).sum())
+    p64 = picked.detach().double()
+    truth = float(torch.nn.functional.binary_cross_entropy_with_logits(p64.flatten(), labels.double())) if kind == "bce" \
+        else float(torch.nn.functional.cross_entropy(p64, labels))
+    assert abs(float(loss) - truth) <= 2e-6 * abs(truth) and abs(float(want) - truth) <= 1e-5 * abs(truth)
+    assert int(hits) == want_hits
+    scale = float(ref_in.grad.abs().max())
+    assert float((logits.grad - ref_in.grad).abs().max()) <= 2e-6 * scale
+    assert abs(float(total) - 2.5 - float(loss)) <= 1e-6 * max(1.0, abs(float(loss))) and float(hit_total) == 10.0 + want_hits
+    loss2, none = loss_step(strided, labels, k, index=idx, want_hits=False)
+    loss2.backward()
+    assert none is None and float(loss2) == float(loss)
+    assert torch.equal(strided.grad * 3.0, logits.grad) or float((strided.grad * 3.0 - logits.grad).abs().max()) <= 1e-6 * scale
+    with torch.no_grad():                                                        # evaluation: no gradient buffer
+        loss3, hits3 = loss_step(logits, labels, k, index=idx)
+    assert float(loss3) == float(loss) and int(hits3) == want_hits
+
+
+def test_fused_loss_step_declines_other_losses():
+    _need_gpu()
+    from gnan_amd.functional import loss_kind
+    x1, x4 = torch.zeros(3, 1, device=DEV), torch.zeros(3, 4, device=DEV)
+    assert loss_kind(torch.nn.MSELoss(), x1) is None
+    assert loss_kind(torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones(1, device=DEV)), x1) is None
+    assert loss_kind(torch.nn.BCEWithLogitsLoss(reduction="sum"), x1) is None
+    assert loss_kind(torch.nn.BCEWithLogitsLoss(), x4) is None
+    assert loss_kind(torch.nn.CrossEntropyLoss(label_smoothing=0.1), x4) is None
+    assert loss_kind(torch.nn.CrossEntropyLoss(weight=torch.ones(4, device=DEV)), x4) is None
+    assert loss_kind(torch.nn.CrossEntropyLoss(), x4.cpu()) is None
+    assert loss_kind(torch.nn.CrossEntropyLoss(), x4.double()) is None
