@@ -1727,6 +1727,104 @@ int launch_bwd_hot(const Params& p, GradParams gp, hipStream_t st, float* dlut) 
   return gnan::check_launch("spmm_lut_grad_final_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Table gradient on the DENSE layout (every pair listed, up to 256 hop codes; Cw == 1, global table):
+//   dlut[d] = sum_q inv(q, d) * sum_{j : code(q, j) == d} < dY[q, :], S[j, :] >
+// — what gnan_spmm_shell_sums + six framework launches computed through a [n, D, W] tensor of read-modify-writes in
+// global memory (Cora-shaped: 0.59 ms of a 2.7-ms training step; a 30-node graph: 8 of its 34 launches).  One wave per
+// row: lane l takes neighbours l, l + 64, ..., forms the W-term dot product and adds it to ITS column of the wave's
+// [D][64] LDS bins (no atomics, no conflicts by construction); lane d then adds bin row d front to back, scales by
+// 1 / count and keeps a float64 running sum over the wave's rows.  One record per wave, a fixed-order final pass:
+// bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBinStride = kWave + 1;        // bin rows one bank apart: lane d's walk along row d does not collide with lane d + 1's
+
+__global__ __launch_bounds__(256) void dense_lut_grad_kernel(const Params p, const GradParams gp, int waves_total) {
+  extern __shared__ __attribute__((aligned(16))) float dense_bins[];    // [waves per block][D][65]
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int wpb = blockDim.x / kWave;
+  float* mine = dense_bins + static_cast<size_t>(wave) * p.D * kBinStride;
+  const int rest = p.D - 1;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};      // codes lane, lane + 64, lane + 128, lane + 192
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * wpb; base < p.n_rows; base += waves_total) {
+    const int64_t q = base + wave;
+    const bool live = q < p.n_rows;
+    const int64_t i = live ? adj_row(p, q) : 0;
+    for (int d = 0; d < p.D; ++d) mine[d * kBinStride + lane] = 0.f;
+    if (live) {
+      const float* dy = gp.dY + q * gp.dy_stride;
+      const uint8_t* codes = p.code + i * p.n_cols;
+      for (int64_t j = lane; j < p.n_cols; j += kWave) {
+        int d = codes[j];
+        d = d < rest ? d : rest;
+        const float* srow = static_cast<const float*>(p.S) + j * p.s_stride;
+        float dot = 0.f;
+        for (int w = 0; w < p.W; ++w) dot = fmaf(dy[w % gp.dy_channels], srow[w], dot);
+        mine[d * kBinStride + lane] += dot;
+      }
+    }
+    __syncthreads();                           // (uniform trip count: every wave of the block sees the same `base`)
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = lane + k * kWave;
+        if (d < p.D) {
+          float s = 0.f;
+          for (int l = 0; l < kWave; ++l) s += mine[d * kBinStride + l];
+          if (p.cnt) {
+            const int c = p.cnt[i * p.cnt_stride + d];
+            s *= 1.f / static_cast<float>(c > 1 ? c : 1);
+          }
+          acc[k] += static_cast<double>(s);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * wpb + wave;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = lane + k * kWave;
+    if (d < p.D && gw < waves_total) gp.blk[gw * p.D + d] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_lut_grad_final_kernel(const double* __restrict__ blk, int waves_total, int D,
+                                                                   float* __restrict__ out) {
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  double s = 0.0;
+  for (int w = 0; w < waves_total; ++w) s += blk[static_cast<int64_t>(w) * D + d];
+  out[d] = static_cast<float>(s);
+}
+
+bool dense_lut_grad_applies(const gnan_spmm_args* a, int32_t reduce_rows) {
+  return a->rowptr == nullptr && a->Cw == 1 && a->D <= 256 && reduce_rows && a->s_dtype == GNAN_F32 && !a->weight_by_col &&
+         a->s_total == nullptr && a->lut_row_stride == 0 && !a->s_by_code;
+}
+
+int dense_lut_grad_waves(const gnan_spmm_args* a) {      // one wave per row up to 2048 waves
+  return static_cast<int>(a->n_rows < 2048 ? (a->n_rows < 1 ? 1 : a->n_rows) : 2048);
+}
+
+int launch_dense_lut_grad(const Params& p, GradParams gp, const gnan_spmm_args* a, hipStream_t st, float* dlut) {
+  const size_t per_wave = static_cast<size_t>(p.D) * kBinStride * sizeof(float);
+  int wpb = static_cast<int>((64 * 1024) / per_wave);
+  wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+  int waves = dense_lut_grad_waves(a);
+  waves = (waves + wpb - 1) / wpb * wpb;                    // whole workgroups
+  const size_t lds = per_wave * wpb;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_lut_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "lut_grad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(dense_lut_grad_kernel, dim3(static_cast<unsigned>(waves / wpb)), dim3(wpb * kWave), lds, st, p, gp, waves);
+  if (int rc = gnan::check_launch("dense_lut_grad_kernel")) return rc;
+  hipLaunchKernelGGL(dense_lut_grad_final_kernel, dim3(1), dim3(256), 0, st, gp.blk, waves, p.D, dlut);
+  return gnan::check_launch("dense_lut_grad_final_kernel");
+}
+
 __global__ void zero_floats_kernel(float* out, int n) {     // (a kernel: captured memsets replay wrongly on ROCm 7.2)
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = 0.f;
 }
@@ -1753,6 +1851,8 @@ size_t lut_grad_blk_entries(const gnan_spmm_args* a, int vec, int lpr) {
 
 static size_t lut_grad_workspace_bytes(const gnan_spmm_args* a, int32_t reduce_rows) {
   if (!a || a->n_rows <= 0) return 0;
+  if (dense_lut_grad_applies(a, reduce_rows))              // one [D] float64 record per wave (rounded up to whole workgroups)
+    return (static_cast<size_t>(dense_lut_grad_waves(a)) + 4) * static_cast<size_t>(a->D) * sizeof(double);
   int vec, lpr;
   pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
   size_t bytes = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
@@ -1786,8 +1886,20 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* g, gnan_stream_
     return GNAN_OK;
   }
   GNAN_REQUIRE(dY != nullptr && dy_channels >= 1 && dy_stride >= dy_channels, "lut_grad: bad dY");
+  if (dense_lut_grad_applies(a, reduce_rows)) {
+    GNAN_REQUIRE(a->W % dy_channels == 0, "lut_grad: dy_channels must be a divisor of W");
+    const size_t need = lut_grad_workspace_bytes(a, reduce_rows);
+    if (workspace == nullptr || workspace_bytes < need)
+      return gnan::fail(GNAN_ERR_WORKSPACE, "lut_grad: workspace %zu B < required %zu B", workspace_bytes, need);
+    const Params p = make_params(a);
+    GradParams gp{};
+    gp.dY = dY; gp.dy_stride = dy_stride; gp.dy_channels = dy_channels; gp.dwt = dwt; gp.reduce_rows = 1;
+    gp.blk = static_cast<double*>(workspace);
+    return launch_dense_lut_grad(p, gp, a, st, dwt);
+  }
   if (a->rowptr == nullptr || a->D > 4 || a->Cw != 1 || a->s_dtype != GNAN_F32 || a->weight_by_col)
-    return gnan::fail(GNAN_ERR_UNSUPPORTED, "lut_grad: needs the CSR layout, D <= 4, one weight channel, fp32 operand rows");
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "lut_grad: needs the CSR layout with D <= 4 — or the dense layout with a global table, "
+                      "reduce_rows and no rest-bucket total —, one weight channel and fp32 operand rows");
   GNAN_REQUIRE(a->W % dy_channels == 0, "lut_grad: dy_channels must divide W");
   const size_t need = lut_grad_workspace_bytes(a, reduce_rows);
   if (need > 0 && (workspace == nullptr || workspace_bytes < need))

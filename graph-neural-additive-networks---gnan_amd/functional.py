@@ -1116,7 +1116,9 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
     if not with_rest:
         s_total = None
     scatter = False
-    if row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
+    if g.is_dense:
+        plan = None                              # dense_lut_grad_kernel: one wave per row, no schedule, every output written
+    elif row_ids is None and S.shape[1] >= DEGREE_SCHEDULE_MIN_WIDTH and g.n_rows > 1:
         if DEGREE_SORTED_COPY and not g.is_dense and g.n_rows >= DEGREE_SORTED_COPY_MIN_ROWS:
             g, row_ids, plan = g.degree_sorted_copy()   # as the forward: adjacent index ranges for neighbouring lane groups
             scatter = 2
@@ -1125,7 +1127,7 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
             scatter = True
     else:
         plan = g.long_row_plan(row_ids)
-    out = torch.zeros((D,) if reduce_rows else (n_out, D), dtype=torch.float32, device=S.device)
+    out = (torch.empty if g.is_dense else torch.zeros)((D,) if reduce_rows else (n_out, D), dtype=torch.float32, device=S.device)
     lut_like = torch.empty((D, 1), dtype=torch.float32, device=S.device)       # only its shape is read
     a = _spmm_args(g, S, lut_like, use_cnt, s_total, out.view(-1, 1), row_ids, False, plan=plan, scatter_out=scatter)
     a.n_rows, a.y_stride = n_out, S.shape[1]                                   # Y is not written by this entry point
@@ -1139,6 +1141,9 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
 
 
 NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"   # dS and dlut from one transposed pass
+DENSE_LUT_GRAD = os.environ.get("GNAN_DENSE_LUT_GRAD", "1") != "0"   # dense layout: the table gradient in one pass (dense_lut_grad_kernel)
+SMALL_DENSE_ROWS = 1024     # dense graphs up to this size read (lut, cnt) per pair in the operand-gradient pass: building the per-node
+                            # weight table first is four more launches than the whole pass on a 30-node graph
 NARROW_BWD_PERSISTENT = os.environ.get("GNAN_NARROW_BWD_PERSISTENT", "1") != "0"   # ... one channel: packed index, persistent workgroups, hot rows in LDS
 
 
@@ -1264,7 +1269,11 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
     # truncated-hop graphs: the table gradient comes out of one pass over the listed pairs (gnan_spmm_lut_grad)
     fused_lut_grad = (need_dlut and not g.is_dense and D <= 4 and Cw == 1
                       and S.dtype == torch.float32)
-    if ctx.reduce_cr and (need_dS or (need_dlut and not fused_lut_grad)):
+    # dense layout (every pair listed, up to 256 shells), global table: one pass as well (dense_lut_grad_kernel) — the
+    # shell-sum route below goes through a [n, D, W] tensor and six framework launches
+    dense_lut_grad = (need_dlut and DENSE_LUT_GRAD and g.is_dense and Cw == 1 and D <= 256 and not per_row and not with_rest
+                      and S.dtype == torch.float32)
+    if ctx.reduce_cr and (need_dS or (need_dlut and not (fused_lut_grad or dense_lut_grad))):
         dY = dY.repeat(1, W // ctx.reduce_cr)   # the fused feature sum broadcasts its gradient over the features
     rows = None if row_ids is None else row_ids.long()
     _inv = []
@@ -1316,7 +1325,7 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
             Z = (wt.unsqueeze(-1) * dY_full.unsqueeze(1)).reshape(g.n_rows * D, W)
             dS = spmm_launch(g.transposed(), Z, torch.ones((D, 1), device=Z.device), False, False, None,
                              s_by_code=True)
-        elif g.n_rows * D * Cw * 4 <= WEIGHT_TABLE_MAX_BYTES:
+        elif g.n_rows * D * Cw * 4 <= WEIGHT_TABLE_MAX_BYTES and not (g.is_dense and g.n_rows <= SMALL_DENSE_ROWS and not per_row):
             # wide operand: the weight of a pair belongs to the NEIGHBOUR's row there.  Read from (lut, cnt) that is two
             # random count reads, two divisions and a subtraction per pair; a per-node table wt(i, d) - wt(i, rest)
             # built once per backward pass makes it one 4-byte read (arxiv-shaped W = 40: 0.55 -> 0.28 ms)
@@ -1349,7 +1358,7 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
 
     if fused_bwd:
         pass                                  # both gradients came out of the one transposed pass above
-    elif need_dlut and fused_lut_grad and not per_row:
+    elif need_dlut and (dense_lut_grad or (fused_lut_grad and not per_row)):
         dlut = lut_grad_launch(g, S, dY_out, D, use_cnt, with_rest, row_ids, ctx.s_total, True)       # [D, 1]
     elif need_dlut:
         if fused_lut_grad:

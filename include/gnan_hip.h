@@ -495,8 +495,10 @@ int gnan_dense_to_code(const float* nd, const float* norm, int64_t n_rows, int64
                        int32_t* status /* [2] */, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Gradient of gnan_spmm_fwd w.r.t. its weight table, fused (the truncated-hop case: CSR layout, D <= 4, Cw == 1,
- * fp32 operand rows; anything else returns GNAN_ERR_UNSUPPORTED — use gnan_spmm_shell_sums then).
+ * Gradient of gnan_spmm_fwd w.r.t. its weight table, fused.  Two cases: the truncated-hop case (CSR layout, D <= 4,
+ * Cw == 1, fp32 operand rows), and the DENSE layout (rowptr NULL: every pair listed, D <= 256, Cw == 1, a global table,
+ * reduce_rows != 0, no s_total — one wave per row, the pairs' dot products binned by hop code in LDS);
+ * anything else returns GNAN_ERR_UNSUPPORTED — use gnan_spmm_shell_sums then.
  *   dwt[q, d] = inv(q, d) * sum_w dY[q, w % dy_channels] * T[q, d, w]
  * with T the per-shell sums of the operand over row q's listed pairs (rest bucket: s_total - lower shells when
  * a->s_total is set) and inv = 1 / max(cnt, 1) when a->cnt is set.  dy_channels == W, or the fused read-out's

@@ -946,6 +946,59 @@ def test_fused_table_gradient_equals_shell_sums_route(W, dyc, use_cnt, with_rest
         assert torch.equal(total, lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, True))   # fixed order
 
 
+@pytest.mark.parametrize("n,D,W,dyc,use_cnt", [(30, 7, 1, 1, True), (90, 12, 7, 7, True), (700, 40, 5, 5, False), (1500, 200, 3, 3, True),
+                                                (333, 255, 8, 2, True), (2708, 15, 7, 7, True)])
+def test_dense_table_gradient_in_one_pass(n, D, W, dyc, use_cnt, monkeypatch):
+    """gnan_spmm_lut_grad on the DENSE layout (dense_lut_grad_kernel: one wave per row, dot products binned by hop code in LDS,
+    up to 256 shells) == shell sums contracted with dY in float64; row subsets; the broadcast gradient of the fused read-out;
+    bit-reproducible — and rho_aggregate's backward through it == the shell-sum route == float64 oracle autograd, with the
+    operand gradient of small dense graphs read from (lut, cnt) per pair instead of a per-node weight table."""
+    from gnan_amd import HopGraph, functional
+    from gnan_amd.functional import lut_grad_launch, rho_aggregate, shell_sums_launch
+    rng = np.random.default_rng(n + D)
+    hops = rng.integers(-1, D - 1, (n, n)).astype(np.int32)          # -1 = unreachable: the last code
+    hops[np.arange(n), np.arange(n)] = 0
+    nd = torch.zeros(n, n)
+    nd[torch.from_numpy(hops >= 0)] = 1.0 / (torch.from_numpy(hops[hops >= 0]).float() + 1.0)
+    g = HopGraph.from_dense(nd.to(DEV))
+    Dg = g.n_codes
+    S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    dummy = torch.zeros((Dg, 1), device=DEV)
+    for ids in (None, torch.from_numpy(rng.integers(0, n, 17).astype(np.int32)).to(DEV)):
+        n_out = n if ids is None else 17
+        dY = torch.from_numpy(rng.standard_normal((n_out, dyc)).astype(np.float32)).to(DEV)
+        T = shell_sums_launch(g, S, dummy, False, ids).double()
+        want = (T * dY.double().repeat(1, W // dyc).unsqueeze(1)).sum(2)
+        if use_cnt:
+            cnt = g.cnt if ids is None else g.cnt[ids.long()]
+            want = want / cnt.clamp_min(1).double()
+        total = lut_grad_launch(g, S, dY, Dg, use_cnt, False, ids, None, True)
+        assert total.shape == (Dg, 1)
+        assert float((total[:, 0].double() - want.sum(0)).abs().max()) <= 2e-5 * float(want.abs().sum(0).max())
+        assert torch.equal(total, lut_grad_launch(g, S, dY, Dg, use_cnt, False, ids, None, True))
+    if dyc != W:
+        return
+    lut0 = torch.from_numpy(rng.standard_normal((Dg, 1)).astype(np.float32)).to(DEV)
+    up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
+    got = {}
+    for tag, fused in (("one_pass", True), ("shell_sums", False)):
+        monkeypatch.setattr(functional, "DENSE_LUT_GRAD", fused)
+        monkeypatch.setattr(functional, "SMALL_DENSE_ROWS", 1024 if fused else 0)
+        Sx, lut = S.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+        got[tag] = torch.autograd.grad(rho_aggregate(g, Sx, lut, use_cnt, with_rest=False), [Sx, lut], up)
+    S64, lut64 = S.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    codes = torch.from_numpy(np.where(hops >= 0, hops, Dg - 1)).long()
+    A = wt[torch.arange(n).unsqueeze(1), codes, 0]                         # [n, n] pair weights
+    ref = torch.autograd.grad(A @ S64, [S64, lut64], up.cpu().double())
+    for k in range(2):
+        scale = float(ref[k].abs().max())
+        for tag in got:
+            assert float((got[tag][k].cpu().double() - ref[k]).abs().max()) <= 2e-5 * scale, (tag, k)
+
+
 @pytest.mark.parametrize("W,K,use_cnt,with_rest", [(1, 1, True, True), (1, 2, True, True), (2, 1, False, True), (3, 2, True, True),
                                                      (4, 1, True, False), (8, 2, True, True), (16, 1, True, True), (5, 2, False, False)])
 def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, monkeypatch):
