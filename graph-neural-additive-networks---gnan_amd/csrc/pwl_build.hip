@@ -424,3 +424,36 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   hipLaunchKernelGGL(pwl_compact_kernel, dim3(a->F), dim3(256), 0, st, c);
   return gnan::check_launch("pwl_compact_kernel");
 }
+
+namespace {
+// Do the tables just built (off[F + 1] | overflow, as gnan_pwl_build left them on the device) fit a look-up that was sized
+// for max_pieces per feature and max_group_pieces per group of fg features?  flag[0] = 1 if not (never cleared here).
+__global__ __launch_bounds__(256) void pwl_check_fit_kernel(const int32_t* __restrict__ meta, int F, int fg, int max_pieces,
+                                                            int max_group_pieces, float* __restrict__ flag) {
+  __shared__ int bad[256];
+  int b = 0;
+  for (int k = threadIdx.x; k < F; k += 256) {
+    if (meta[k + 1] - meta[k] > max_pieces) b = 1;
+    if (k % fg == 0) {
+      const int hi = k + fg < F ? k + fg : F;
+      if (meta[hi] - meta[k] > max_group_pieces) b = 1;
+    }
+  }
+  if (threadIdx.x == 0 && meta[F + 1] != 0) b = 1;          // the build itself ran out of room
+  bad[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) bad[threadIdx.x] |= bad[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && bad[0]) flag[0] = 1.f;
+}
+}  // namespace
+
+extern "C" int gnan_pwl_check_fit(const int32_t* meta, int32_t F, int32_t features_per_group, int32_t max_pieces,
+                                  int32_t max_group_pieces, float* flag, gnan_stream_t stream) {
+  GNAN_REQUIRE(meta != nullptr && flag != nullptr && F >= 1 && features_per_group >= 1, "pwl_check_fit: bad arguments");
+  hipLaunchKernelGGL(pwl_check_fit_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), meta, F, features_per_group,
+                     max_pieces, max_group_pieces, flag);
+  return gnan::check_launch("pwl_check_fit_kernel");
+}

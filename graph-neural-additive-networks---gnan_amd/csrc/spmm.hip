@@ -1789,13 +1789,20 @@ __global__ __launch_bounds__(256) void dense_lut_grad_kernel(const Params p, con
   }
 }
 
+// one workgroup per hop code: 256 threads stride over the waves' records, then a fixed tree
 __global__ __launch_bounds__(256) void dense_lut_grad_final_kernel(const double* __restrict__ blk, int waves_total, int D,
                                                                    float* __restrict__ out) {
-  const int d = threadIdx.x;
-  if (d >= D) return;
+  __shared__ double red[256];
+  const int d = blockIdx.x;
   double s = 0.0;
-  for (int w = 0; w < waves_total; ++w) s += blk[static_cast<int64_t>(w) * D + d];
-  out[d] = static_cast<float>(s);
+  for (int w = threadIdx.x; w < waves_total; w += 256) s += blk[static_cast<int64_t>(w) * D + d];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[d] = static_cast<float>(red[0]);
 }
 
 bool dense_lut_grad_applies(const gnan_spmm_args* a, int32_t reduce_rows) {
@@ -1821,7 +1828,7 @@ int launch_dense_lut_grad(const Params& p, GradParams gp, const gnan_spmm_args* 
   }
   hipLaunchKernelGGL(dense_lut_grad_kernel, dim3(static_cast<unsigned>(waves / wpb)), dim3(wpb * kWave), lds, st, p, gp, waves);
   if (int rc = gnan::check_launch("dense_lut_grad_kernel")) return rc;
-  hipLaunchKernelGGL(dense_lut_grad_final_kernel, dim3(1), dim3(256), 0, st, gp.blk, waves, p.D, dlut);
+  hipLaunchKernelGGL(dense_lut_grad_final_kernel, dim3(static_cast<unsigned>(p.D)), dim3(256), 0, st, gp.blk, waves, p.D, dlut);
   return gnan::check_launch("dense_lut_grad_final_kernel");
 }
 

@@ -207,6 +207,7 @@ _ROOM_REQUEST = 0             # rows of room feature_mlps(room_rows=...) asks th
 _ROOM_RESULT = None           # (data_ptr of the result, the larger buffer it heads) of the last look-up that did
 CAPTURED_BUILDS = []          # (sizes a look-up was captured with, the stacked weights it tabulates) of the capture in progress
 CAPTURE_PINS = None           # list while graphed.GraphedCallable captures: cache-owned tensors the captured step reads
+CAPTURE_GUARD = None          # float32 [1] while a guarded step is captured: set to 1 by a look-up whose tables outgrew its sizes
 
 
 def _pin_for_capture(obj):
@@ -331,6 +332,12 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
                 raise _lib.GnanHipError("graph capture needs one eager forward of this model first (table sizes unknown)")
             res = look_up(guess)
             CAPTURED_BUILDS.append((guess, stacked))
+            if CAPTURE_GUARD is not None:
+                # the step's guard: set on the device if the tables of the weights a REPLAY finds outgrew these sizes — the
+                # captured update is skipped then and the replayer re-runs the step eagerly (graphed.GraphedStep.replay)
+                _lib.check(_lib.lib().gnan_pwl_check_fit(_lib.ptr(pending.meta), stacked.F, int(guess.features_per_group),
+                                                         int(guess.max_pieces), int(guess.max_group_pieces),
+                                                         _lib.ptr(CAPTURE_GUARD), _lib.stream_of(x)), "gnan_pwl_check_fit")
             return res[0], guess, res[1]
         if SPECULATIVE_LOOKUP and hip_build_applies(stacked) and not torch.cuda.is_current_stream_capturing():
             # Sizing the look-up needs the tables' piece counts, i.e. a device->host copy between the table build and the

@@ -11,10 +11,12 @@ What a captured step freezes, and how it is guarded:
 * tensor ADDRESSES of the inputs, parameters and optimizer state — :meth:`GraphedStep.stale` compares the parameters'
   addresses and the hyper-parameters before every replay; ``harness`` re-captures when it reports a change;
 * the SIZES of the shape-function tables (search depth, LDS image) — they follow the weights, which training moves;
-  the captured look-up has the same head-room as the speculative look-up of the eager path, and before every replay
-  :meth:`GraphedCallable.fits` builds the tables of the CURRENT weights eagerly (one 0.05-ms kernel and the one small
-  device->host read a forward always made) and compares: a step whose tables outgrew the capture is never replayed —
-  its optimizer update would be computed from a truncated look-up — but run eagerly and captured again;
+  the captured look-up has the same head-room as the speculative look-up of the eager path and checks, on the device, that
+  the tables its own build produced fit it (``gnan_pwl_check_fit`` sets the step's guard flag); the captured optimizer
+  update takes the flag as its skip flag (torch's ``found_inf``), so a step whose tables outgrew the capture changes
+  nothing; the flag is read after the replay and such a step is run eagerly and captured again.  (Optimizers whose
+  update is not the flat fused one cannot be skipped on the device: :meth:`GraphedCallable.fits` then builds the tables
+  of the current weights BEFORE every replay — one more table build, a read-back and a host synchronisation per epoch;)
 * the learning rate lives in a device tensor the schedulers' floats are copied into before each replay.
 Dropout in training mode is stochastic per call and is never captured (``GraphedStep.supported``).
 """
@@ -60,7 +62,8 @@ atexit.register(_release_graphs_at_exit)
 class GraphedCallable:
     """``fn()`` — no arguments, closes over static tensors — captured into a hipGraph after ``warmup`` eager runs."""
 
-    def __init__(self, fn: Callable[[], object], warmup: int = 2, before_capture: Optional[Callable[[], None]] = None):
+    def __init__(self, fn: Callable[[], object], warmup: int = 2, before_capture: Optional[Callable[[], None]] = None,
+                 guard: Optional[torch.Tensor] = None):
         dev = torch.cuda.current_device()
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
@@ -77,6 +80,7 @@ class GraphedCallable:
         # feature matrix, the hop-coded graph derived from the inputs): the graph bakes their ADDRESSES in, so the step
         # keeps them alive — an eviction would hand their blocks to someone else under a replay
         functional.CAPTURE_PINS = pins = []
+        functional.CAPTURE_GUARD = guard
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         try:
             with torch.cuda.graph(self.graph):
@@ -91,11 +95,11 @@ class GraphedCallable:
             self.graph.instantiate()
         except Exception as e:                   # a host synchronisation on the path, an unsupported op, ...
             functional.CAPTURED_BUILDS.clear()
-            functional.CAPTURE_PINS = None
+            functional.CAPTURE_PINS = functional.CAPTURE_GUARD = None
             raise CaptureFailed(f"{type(e).__name__}: {e}") from e
         self.builds = list(functional.CAPTURED_BUILDS)
         functional.CAPTURED_BUILDS.clear()
-        functional.CAPTURE_PINS = None
+        functional.CAPTURE_PINS = functional.CAPTURE_GUARD = None
         self.pins = pins
         self.replays = 0
         _LIVE.add(self)
@@ -190,6 +194,7 @@ def prepare_optimizer(optimizer) -> PreparedOptimizer:
     return PreparedOptimizer(optimizer)
 
 
+GUARDED_REPLAY = os.environ.get("GNAN_GUARDED_REPLAY", "1") != "0"        # table-size check inside the captured step instead of before every replay
 FLAT_OPTIMIZER_STEP = os.environ.get("GNAN_FLAT_OPTIMIZER", "1") != "0"   # captured steps update the FlatMLPStore buffers with one fused launch
 
 
@@ -303,13 +308,18 @@ class FlatAdamStep:
         lo, hi = self.steps.data_ptr(), self.steps.data_ptr() + self.steps.numel() * 4
         return bool(s0 and s1 and lo <= s0["step"].data_ptr() < hi and lo <= s1["step"].data_ptr() < hi)
 
-    def step(self) -> None:
+    def step(self, skip: Optional[torch.Tensor] = None) -> None:
+        """``skip``: float32 [1] device flag — 1.0 makes the kernel leave parameters and moments alone (torch's ``found_inf``);
+        the step counters are advanced regardless (:meth:`undo_count` takes that back)."""
         g = self.optimizer.param_groups[0]
         self.steps.add_(1)
         fn = torch._fused_adamw_ if self.decoupled else torch._fused_adam_
         beta1, beta2 = g["betas"]
         fn(self.P, self.G, self.M, self.V, [], self.step_of, amsgrad=False, lr=g["lr"], beta1=float(beta1), beta2=float(beta2),
-           weight_decay=g["weight_decay"], eps=g["eps"], maximize=False, grad_scale=None, found_inf=None)
+           weight_decay=g["weight_decay"], eps=g["eps"], maximize=False, grad_scale=None, found_inf=skip)
+
+    def undo_count(self) -> None:
+        self.steps.sub_(1)
 
 
 class GraphedStep:
@@ -345,13 +355,22 @@ class GraphedStep:
         self.outputs = self.loss = self.extras = None
         self.flat = None
 
+        # Guarded steps: instead of building the tables of the current weights BEFORE every replay (one more table build, a
+        # read-back and a host synchronisation: 0.14 ms of a 0.7-ms arxiv-shaped epoch, 0.5 of 2.1 ms on the Cora shape) the
+        # captured look-up checks its own tables on the device (gnan_pwl_check_fit), the captured update is skipped by the
+        # kernel when they outgrew the capture (torch's found_inf), and the flag is read AFTER the replay — next to the loss the
+        # caller reads anyway.  Needs the flat update (the optimizer's own step takes no skip flag); evaluation steps always can.
+        self.guard = torch.zeros(1, dtype=torch.float32, device=next(model.parameters()).device) if GUARDED_REPLAY else None
+
         def step():
+            if self.guard is not None:
+                self.guard.zero_()
             if self.training:
                 out = fwd()
                 out = out[0] if isinstance(out, tuple) else out
                 loss, extras = loss_of(out)
                 loss.backward()
-                self.flat.step() if self.flat is not None else optimizer.step()
+                self.flat.step(skip=self.guard) if self.flat is not None else optimizer.step()
                 return out.detach(), loss.detach(), extras
             with torch.no_grad():
                 out = fwd()
@@ -380,8 +399,10 @@ class GraphedStep:
             if flat is None or not flat.valid(model, optimizer):
                 flat = FlatAdamStep.build(model, optimizer)
             self.flat = self.prepared.flat = flat
+        if self.training and self.flat is None:
+            self.guard = None                     # the optimizer's own update cannot be skipped on the device: check before replaying
         try:
-            self.graph = GraphedCallable(step, warmup=0, before_capture=clear)
+            self.graph = GraphedCallable(step, warmup=0, before_capture=clear, guard=self.guard)
         except CaptureFailed:
             if self._own_prepared:
                 self.prepared.restore()
@@ -420,13 +441,22 @@ class GraphedStep:
     def replay(self):
         """Replay the captured step; returns ``(outputs, loss, extras)`` (static tensors), or None if the step must not be
         replayed (see :meth:`stale`, :meth:`GraphedCallable.fits`) — the caller then runs it eagerly and captures anew."""
-        if self.graph is None or self.stale() or not self.graph.fits():
+        if self.graph is None or self.stale():
+            return None
+        guarded = self.guard is not None and bool(self.graph.builds)
+        if not guarded and not self.graph.fits():
             return None
         for group, static in zip(self.optimizer.param_groups if self.training else [], self.lrs):
             if group["lr"] is not static:                     # a scheduler wrote a float: keep the tensor, take the value
                 static.fill_(float(group["lr"]))
                 group["lr"] = static
         self.graph.replay()
+        if guarded and bool(self.guard.item()):
+            # the tables of these weights outgrew the captured look-up: its outputs are not the model's, and the update was
+            # skipped on the device; only the step counters moved
+            if self.training:
+                self.flat.undo_count()
+            return None
         return self.outputs, self.loss, self.extras
 
 

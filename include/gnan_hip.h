@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 32
+#define GNAN_ABI_VERSION 33
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -301,6 +301,13 @@ typedef struct gnan_pwl_build_args {
 
 size_t gnan_pwl_build_scratch_bytes(int32_t F, int32_t C, int32_t cap);
 int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream);
+/* The guard of a captured look-up (hipGraph replay: no read-back between build and look-up): `meta` = off[F + 1] | overflow as
+ * gnan_pwl_build left them; flag[0] = 1.0f if the build overflowed, a feature has more than max_pieces pieces or a group of
+ * features_per_group consecutive features more than max_group_pieces — i.e. the look-up sized with those numbers did not see the
+ * whole tables.  Never cleared here: the caller zeroes it once per step, hands it to the optimizer update as its skip flag
+ * (torch's found_inf) and reads it after the replay. */
+int gnan_pwl_check_fit(const int32_t* meta, int32_t F, int32_t features_per_group, int32_t max_pieces,
+                       int32_t max_group_pieces, float* flag, gnan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-row weight table of the pre-rho normalisation:  lut[i, d, :] = rho(u[d] / max(cnt[i, d], 1))

@@ -134,8 +134,11 @@ def test_captured_steps_update_the_flat_buffers_bit_for_bit(n, F, C, dense, opt_
 
 
 def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
+    """The unguarded route (an optimizer whose update cannot be skipped on the device, GNAN_GUARDED_REPLAY=0): the tables of
+    the current weights are built and compared BEFORE every replay."""
     _need_gpu()
-    from gnan_amd import harness, pwl
+    from gnan_amd import graphed, harness, pwl
+    monkeypatch.setattr(graphed, "GUARDED_REPLAY", False)
     data = _node_task(3000, 129, 1, False)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
@@ -160,6 +163,71 @@ def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
     assert any(not torch.equal(before[k], v) for k, v in m.state_dict().items())                # ... and the step still happened
     harness.train_epoch(m, [data], loss_fn, opt, DEV, classify=True, is_graph_task=False)      # captured anew and replayed
     assert rec["step"] is not None and rec["step"] is not first and rec["step"].graph.replays == 1
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_tables_that_outgrow_a_captured_step_trip_its_guard(training, monkeypatch):
+    """Guarded replay: the captured look-up checks ITS OWN tables on the device (gnan_pwl_check_fit) instead of the host
+    building them before every replay.  Weights whose tables really outgrow the captured sizes (most hidden units switched
+    off at capture time, back on afterwards): the replay runs, the guard trips, the captured update is skipped by the kernel
+    (found_inf) and the step counters are put back, the epoch runs eagerly — loss, parameters and optimizer state equal a
+    twin that never used a graph."""
+    _need_gpu()
+    from gnan_amd import graphed, harness
+    from gnan_amd import functional
+    monkeypatch.setattr(functional, "PWL_MIN_WORK", 1 << 18)     # (inference tabulates from 2^24 look-ups on: keep the test small)
+    monkeypatch.setattr(functional, "PWL_MIN_NODES", 1 << 12)
+    data = _node_task(5000, 64, 1, False)                        # 320k look-ups: the table route
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    assert graphed.GUARDED_REPLAY
+    m = _model(64, 1)
+    full = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():                                        # three of four hidden units off: few kinks, small tables
+        for k, p in m.named_parameters():
+            if k.startswith("fs") and (".0." in k or ".2." in k):
+                p[8:] = 0.0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4) if training else None
+
+    def epoch(model, optimizer):
+        if training:
+            return harness.train_epoch(model, [data], loss_fn, optimizer, DEV, classify=True, is_graph_task=False)
+        return harness.test_epoch(model, [data], loss_fn, DEV, classify=True, is_graph_task=False)
+    for _ in range(4):
+        epoch(m, opt)
+    rec = [r.value for r in harness._steps_of(m).node.entries.values()][0]
+    step = rec["step"]
+    assert step is not None and step.graph.replays == 2 and step.guard is not None and step.graph.builds
+    fits_calls = {"n": 0}
+    real_fits = graphed.GraphedCallable.fits
+    monkeypatch.setattr(graphed.GraphedCallable, "fits", lambda self: (fits_calls.__setitem__("n", fits_calls["n"] + 1), real_fits(self))[1])
+    epoch(m, opt)
+    assert step.graph.replays == 3 and fits_calls["n"] == 0      # no table build before the replay any more
+    with torch.no_grad():                                        # all hidden units back: ~4x the pieces per feature
+        for k, p in m.named_parameters():
+            p.copy_(full[k])
+    twin = copy.deepcopy(m)
+    harness.release_steps(twin)
+    topt = None
+    if training:
+        topt = torch.optim.Adam(twin.parameters(), lr=1e-4, capturable=True, fused=True)
+        topt.load_state_dict(copy.deepcopy(opt.state_dict()))
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", False)
+    want = epoch(twin, topt)
+    monkeypatch.setattr(harness, "GRAPHED_STEPS", True)
+    graph = step.graph
+    got = epoch(m, opt)
+    assert graph.replays == 4 and rec["step"] is None            # replayed, guard tripped, dropped; the epoch ran eagerly
+    assert abs(got[0] - want[0]) <= 1e-6 * abs(want[0]) and got[1] == want[1]
+    for (k, a), (_, b) in zip(m.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b), k
+    if training:
+        sa, sb = opt.state_dict()["state"], topt.state_dict()["state"]
+        for k in sa:
+            assert float(sa[k]["step"]) == float(sb[k]["step"]) and torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]), k
+    for _ in range(2):
+        epoch(m, opt)                                            # captured again with the larger tables
+    assert rec["step"] is not None and rec["step"] is not step
 
 
 def test_moved_parameters_invalidate_the_capture(monkeypatch):

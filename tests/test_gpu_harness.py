@@ -162,7 +162,7 @@ def test_fused_loss_step_matches_torch(kind, n_rows, C, masked):
     p64 = picked.detach().double()
     truth = float(torch.nn.functional.binary_cross_entropy_with_logits(p64.flatten(), labels.double())) if kind == "bce" \
         else float(torch.nn.functional.cross_entropy(p64, labels))
-    assert abs(float(loss) - truth) <= 2e-6 * abs(truth) and abs(float(want) - truth) <= 1e-5 * abs(truth)
+    assert abs(float(loss.detach()) - truth) <= 2e-6 * abs(truth) and abs(float(want.detach()) - truth) <= 1e-5 * abs(truth)
     assert int(hits) == want_hits
     scale = float(ref_in.grad.abs().max())
     assert float((logits.grad - ref_in.grad).abs().max()) <= 2e-6 * scale
