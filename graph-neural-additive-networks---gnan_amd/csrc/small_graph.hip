@@ -1,0 +1,343 @@
+// The whole forward of a SMALL dense-coded graph in ONE launch (GNAN.py:146-172 / models.py:358-384, post-rho
+// normalisation): shape functions of all features summed per node, rho on the D distinct distances, the rho-weighted
+// shell-normalised aggregation and the graph read-out.  Graph-level tasks (trainer.py:23-86 with batch_size = 1) see a
+// 30-node graph per step: the general path spends seven launches on it (two weight packs, two matrix-core MLP launches,
+// a chunk sum, the aggregation, the read-out sum) and every one of them is shorter than the gap between two launches.
+//
+//   workgroup k < F   : f_k on all nodes.  Four waves share a block of 64 nodes (lane = node): every wave computes a
+//                       quarter of each hidden layer's units into LDS columns, weights are wave-uniform (scalar loads);
+//                       the C outputs of the block go to part[k, node, :] in the workspace.
+//   workgroup F       : lut[d, :] = rho(u_d), u_d = float32(1 / (1 + d)) for d < D - 1, u_{D-1} = 0 (lane = d).
+//   the LAST workgroup to finish (a counter in the workspace; __threadfence before the increment) adds the features in
+//   order, S[j, :] = sum_k part[k, j, :], aggregates Y[i, c] = sum_j lut[code(i, j), c] / max(cnt(i, code), 1) * S[j, c]
+//   (a thread per row and channel over LDS-resident tables, neighbours in ascending order) and sums the rows for the graph
+//   read-out.  Fixed orders throughout: bit-reproducible.
+// S and lut are written out as well — the backward pass of the general path takes them from there.
+#include "common.hpp"
+
+namespace {
+
+using gnan::kWave;
+
+struct Mlp {
+  int L, H, C;
+  const float *w_first, *b_first, *w_mid, *b_mid, *w_last, *b_last;
+};
+
+struct SmallParams {
+  const float* x;
+  int64_t x_stride;
+  int n, F;
+  Mlp f, r;
+  const uint8_t* code;
+  int D;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  float* S;
+  float* lut;
+  float* Y;
+  float* Ysum;
+  float* part;          // [F, n, C]
+  unsigned* counter;    // zero before the first launch; the last workgroup zeroes it again
+};
+
+constexpr int kMaxH = 64, kMaxC = 8, kWaves = 4, kMaxNodes = 64;
+
+// LDS image of one scalar MLP's weights (scalar loads straight from memory made every inner-loop step wait ~150 cycles for
+// its weights: 33 us for a 30-node graph; read as LDS broadcasts the same loop is bound by LDS issue)
+struct MlpLds {
+  float* w1;   // [H]
+  float* b1;   // [H]
+  float* w2;   // [H, H]
+  float* b2;   // [H]
+  float* w3;   // [C, H]
+  float* b3;   // [C]
+};
+
+__device__ __forceinline__ MlpLds carve(float* base) {
+  MlpLds w;
+  w.w2 = base;
+  w.w1 = base + kMaxH * kMaxH;
+  w.b1 = w.w1 + kMaxH;
+  w.b2 = w.b1 + kMaxH;
+  w.w3 = w.b2 + kMaxH;
+  w.b3 = w.w3 + kMaxC * kMaxH;
+  return w;
+}
+constexpr int kWeightFloats = kMaxH * kMaxH + 3 * kMaxH + kMaxC * kMaxH + kMaxC;
+
+// (every load is issued before the first LDS store: a load -> store loop keeps ONE load in flight, and a cold load costs
+// more than a microsecond — sixteen of them in a row were most of the kernel's time)
+__device__ __forceinline__ void stage_weights(const Mlp& m, int k, const MlpLds& w) {
+  const int H = m.H, C = m.C, tid = threadIdx.x;
+  constexpr int kPer = kMaxH * kMaxH / (kWaves * kWave);           // 16 hidden-to-hidden weights per thread
+  float v2[kPer], v3[2];
+  const float* w2 = m.L == 3 ? m.w_mid + static_cast<int64_t>(k) * H * H : nullptr;
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int i = tid + t * (kWaves * kWave);
+    v2[t] = (w2 && i < H * H) ? w2[i] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = tid + t * (kWaves * kWave);
+    v3[t] = i < C * H ? m.w_last[static_cast<int64_t>(k) * C * H + i] : 0.f;
+  }
+  const bool hid = tid < H;
+  const float a1 = hid ? m.w_first[k * H + tid] : 0.f;
+  const float a2 = (hid && m.b_first) ? m.b_first[k * H + tid] : 0.f;
+  const float a3 = (hid && m.L == 3 && m.b_mid) ? m.b_mid[k * H + tid] : 0.f;
+  const float a4 = (tid < C && m.b_last) ? m.b_last[k * C + tid] : 0.f;
+#pragma unroll
+  for (int t = 0; t < kPer; ++t) {
+    const int i = tid + t * (kWaves * kWave);
+    if (i < H * H) w.w2[i] = v2[t];
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = tid + t * (kWaves * kWave);
+    if (i < C * H) w.w3[i] = v3[t];
+  }
+  if (hid) { w.w1[tid] = a1; w.b1[tid] = a2; w.b2[tid] = a3; }
+  if (tid < C) w.b3[tid] = a4;
+  __syncthreads();
+}
+
+// One scalar MLP on the 64 inputs of this node block: lane = input, the four waves split every hidden layer's units;
+// activations live in LDS columns a / b ([H][64]).  Wave 0 ends with the C outputs of its lane in out[].
+__device__ __forceinline__ void mlp_block(const Mlp& m, const MlpLds& w, float xv, float* a, float* b, int lane, int wave,
+                                          float (&out)[kMaxC]) {
+  const int H = m.H, C = m.C;
+  for (int j = wave; j < H; j += kWaves) a[j * kWave + lane] = fmaxf(fmaf(xv, w.w1[j], w.b1[j]), 0.f);
+  __syncthreads();
+  float* cur = a;
+  float* nxt = b;
+  if (m.L == 3) {                                    // the one hidden-to-hidden layer: rows of w2 = output units
+    const int per = (H + kWaves - 1) / kWaves;       // a contiguous run of output units per wave, four at a time
+    const int o_lo = wave * per, o_hi = o_lo + per < H ? o_lo + per : H;
+    for (int o0 = o_lo; o0 < o_hi; o0 += 4) {
+      float acc[4];
+      const float* row[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int o = o0 + t < o_hi ? o0 + t : o_hi - 1;             // clamp: uniform, keeps the reads in range
+        acc[t] = w.b2[o];
+        row[t] = w.w2 + o * H;
+      }
+#pragma unroll 16
+      for (int i = 0; i < H; ++i) {
+        const float h = cur[i * kWave + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = fmaf(row[t][i], h, acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (o0 + t < o_hi) nxt[(o0 + t) * kWave + lane] = fmaxf(acc[t], 0.f);
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  if (wave == 0) {
+    for (int c = 0; c < C; ++c) {
+      float acc = w.b3[c];
+#pragma unroll 16
+      for (int i = 0; i < H; ++i) acc = fmaf(w.w3[c * H + i], cur[i * kWave + lane], acc);
+      out[c] = acc;
+    }
+  }
+  __syncthreads();                                   // the columns are free for the next node block
+}
+
+__global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
+  __shared__ __attribute__((aligned(16))) float cols[2 * kMaxH * kWave];     // activation columns; the aggregation's tables later
+  __shared__ __attribute__((aligned(16))) float weights[kWeightFloats];
+  __shared__ unsigned s_last;
+  float* col_a = cols;
+  float* col_b = cols + kMaxH * kWave;
+  float* s_S = cols;                                 // [n, C]      (phase 3: the columns are dead by then)
+  float* s_Y = cols + kMaxNodes * kMaxC;             // [n, C]
+  float* s_lut = cols + 2 * kMaxNodes * kMaxC;       // [D, rho C]
+  static_assert(2 * kMaxNodes * kMaxC + 256 * kMaxC + kMaxNodes * kWave + kMaxNodes * kMaxNodes / 4 <= 2 * kMaxH * kWave,
+                "the aggregation's tables (node sums, outputs, rho table, row weights, hop codes) fit the activation columns");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int k = blockIdx.x;
+  float out[kMaxC];
+  const MlpLds wl_ = carve(weights);
+  // What the aggregation will read from memory that does not depend on the other workgroups — hop codes and shell sizes — is
+  // requested NOW, by every workgroup (any of them may be the last), into registers: the loads fly while the MLP runs.  A cold
+  // load costs more than a microsecond on this part and the kernel is a chain of them; this takes two links out.
+  constexpr int kWordsPer = kMaxNodes * kMaxNodes / 4 / (kWaves * kWave);      // 4 code words per thread
+  constexpr int kCntPer = kMaxNodes * kWave / (kWaves * kWave);                 // 16 shell sizes per thread (D <= 64)
+  const bool fast = p.D <= kWave && p.r.C == 1;      // per-row weights lut[d] / max(cnt[i, d], 1) fit LDS
+  const int code_words = p.n * p.n / 4;
+  uint32_t pre_code[kWordsPer];
+  int pre_cnt[kCntPer];
+  {
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(p.code);
+#pragma unroll
+    for (int t = 0; t < kWordsPer; ++t) {
+      const int i = threadIdx.x + t * 256;
+      pre_code[t] = i < code_words ? cw[i] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < kCntPer; ++t) {
+      const int e = threadIdx.x + t * 256;
+      pre_cnt[t] = (fast && p.cnt && e < p.n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
+    }
+  }
+  if (k < p.F) {
+    stage_weights(p.f, k, wl_);
+    const int j = lane;                              // n <= 64: one block of nodes
+    const float xv = j < p.n ? p.x[static_cast<int64_t>(j) * p.x_stride + k] : 0.f;
+    mlp_block(p.f, wl_, xv, col_a, col_b, lane, wave, out);
+    if (wave == 0 && j < p.n)
+      for (int c = 0; c < p.f.C; ++c) p.part[(static_cast<int64_t>(k) * p.n + j) * p.f.C + c] = out[c];
+  } else {
+    stage_weights(p.r, 0, wl_);
+    for (int d0 = 0; d0 < p.D; d0 += kWave) {
+      const int d = d0 + lane;
+      const float u = d < p.D - 1 ? 1.0f / (static_cast<float>(d) + 1.0f) : 0.f;     // graph.hop_inputs
+      mlp_block(p.r, wl_, u, col_a, col_b, lane, wave, out);
+      if (wave == 0 && d < p.D)
+        for (int c = 0; c < p.r.C; ++c) p.lut[d * p.r.C + c] = out[c];
+    }
+  }
+  // ---- join: the last workgroup to arrive finishes the graph --------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(p.counter, 1u);
+  __syncthreads();
+  if (s_last != gridDim.x - 1) return;
+  __threadfence();
+  const int C = p.f.C, Cr = p.r.C, n = p.n;
+  // (the fence above made the other workgroups' results visible to this one: plain loads from here on.  Every table the
+  // aggregation reads — node sums, rho table, hop codes, the rows' weights — is staged in LDS; the per-row loop never waits
+  // for memory)
+  uint8_t* s_code = reinterpret_cast<uint8_t*>(cols + 2 * kMaxNodes * kMaxC + 256 * kMaxC + kMaxNodes * kWave);   // [n, n]
+  float* s_w = cols + 2 * kMaxNodes * kMaxC + 256 * kMaxC;                                                         // [n, 64]
+  // the other workgroups' results: node sums (eight feature terms in flight at a time) and the rho table — one more batch
+  float lut_v[kMaxC * 256 / (kWaves * kWave)];       // 8 table entries per thread at most
+#pragma unroll
+  for (int t = 0; t < kMaxC; ++t) {
+    const int e = threadIdx.x + t * 256;
+    lut_v[t] = e < p.D * Cr ? p.lut[e] : 0.f;
+  }
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) {
+    const int j = e / C, c = e % C;
+    const float* src = p.part + static_cast<int64_t>(j) * C + c;
+    const int64_t step = static_cast<int64_t>(n) * C;
+    float s = 0.f;
+    int kk = 0;
+    for (; kk + 8 <= p.F; kk += 8) {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = src[(kk + t) * step];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s += v[t];         // features in order
+    }
+    for (; kk < p.F; ++kk) s += src[kk * step];
+    s_S[e] = s;
+    p.S[e] = s;
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxC; ++t) {
+    const int e = threadIdx.x + t * 256;
+    if (e < p.D * Cr) s_lut[e] = lut_v[t];
+  }
+  {
+    uint32_t* dw = reinterpret_cast<uint32_t*>(s_code);
+#pragma unroll
+    for (int t = 0; t < kWordsPer; ++t) {
+      const int i = threadIdx.x + t * 256;
+      if (i < code_words) dw[i] = pre_code[t];
+    }
+    for (int i = code_words * 4 + threadIdx.x; i < n * n; i += blockDim.x) s_code[i] = p.code[i];
+  }
+  __syncthreads();
+  if (fast) {
+#pragma unroll
+    for (int t = 0; t < kCntPer; ++t) {
+      const int e = threadIdx.x + t * 256;
+      if (e < n * p.D) {
+        const float l = s_lut[e % p.D];
+        s_w[(e / p.D) * kWave + e % p.D] = p.cnt ? l / static_cast<float>(pre_cnt[t] > 1 ? pre_cnt[t] : 1) : l;
+      }
+    }
+    __syncthreads();
+  }
+  // one thread per (row, channel), neighbours in ascending order
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) {
+    const int i = e / C, c = e % C;
+    const int cr = Cr == 1 ? 0 : c;
+    const uint8_t* codes = s_code + i * n;
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) {
+      int d = codes[j];
+      d = d < p.D - 1 ? d : p.D - 1;
+      float w;
+      if (fast) {
+        w = s_w[i * kWave + d];
+      } else {
+        w = s_lut[d * Cr + cr];
+        if (p.cnt) {
+          const int q = p.cnt[i * p.cnt_stride + d];
+          w = w / static_cast<float>(q > 1 ? q : 1);
+        }
+      }
+      acc = fmaf(w, s_S[j * C + c], acc);
+    }
+    s_Y[e] = acc;
+    if (p.Y) p.Y[e] = acc;
+  }
+  __syncthreads();
+  if (p.Ysum && static_cast<int>(threadIdx.x) < C) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += s_Y[i * C + threadIdx.x];
+    p.Ysum[threadIdx.x] = s;
+  }
+  if (threadIdx.x == 0) *p.counter = 0u;
+}
+
+bool mlp_ok(const gnan_small_mlp* m, int max_c) {
+  return (m->L == 2 || m->L == 3) && m->H >= 1 && m->H <= kMaxH && m->C >= 1 && m->C <= max_c && m->w_first && m->w_last &&
+         (m->L == 2 || m->w_mid);
+}
+
+Mlp to_mlp(const gnan_small_mlp* m) {
+  Mlp r;
+  r.L = m->L; r.H = m->H; r.C = m->C;
+  r.w_first = m->w_first; r.b_first = m->b_first; r.w_mid = m->w_mid; r.b_mid = m->b_mid; r.w_last = m->w_last; r.b_last = m->b_last;
+  return r;
+}
+
+}  // namespace
+
+extern "C" size_t gnan_small_graph_workspace_bytes(int32_t n, int32_t F, int32_t C) {
+  return 16 + static_cast<size_t>(F) * n * C * sizeof(float);      // counter (own 16 bytes) | part [F, n, C]
+}
+
+extern "C" int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "small_graph: null args");
+  GNAN_REQUIRE(a->n >= 1 && a->F >= 1 && a->D >= 1, "small_graph: bad sizes n=%d F=%d D=%d", a->n, a->F, a->D);
+  if (a->n > kMaxNodes || a->D > 256 || !mlp_ok(&a->f, kMaxC) || !mlp_ok(&a->rho, kMaxC) ||
+      (a->rho.C != 1 && a->rho.C != a->f.C))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_graph: covers n <= %d nodes, D <= 256 shells, L in {2, 3}, H <= %d, C <= %d and a "
+                      "rho of one channel or one per output channel (got n=%d D=%d L=%d/%d H=%d/%d C=%d/%d)", kMaxNodes, kMaxH,
+                      kMaxC, a->n, a->D, a->f.L, a->rho.L, a->f.H, a->rho.H, a->f.C, a->rho.C);
+  GNAN_REQUIRE(a->x && a->code && a->S && a->lut && (a->Y || a->Ysum), "small_graph: null x / code / S / lut / outputs");
+  GNAN_REQUIRE(a->x_stride >= a->F && (a->cnt == nullptr || a->cnt_stride >= a->D), "small_graph: row stride smaller than the width");
+  const size_t need = gnan_small_graph_workspace_bytes(a->n, a->F, a->f.C);
+  if (a->workspace == nullptr || a->workspace_bytes < need)
+    return gnan::fail(GNAN_ERR_WORKSPACE, "small_graph: workspace %zu B < required %zu B", a->workspace_bytes, need);
+  SmallParams p;
+  p.x = a->x; p.x_stride = a->x_stride; p.n = a->n; p.F = a->F;
+  p.f = to_mlp(&a->f); p.r = to_mlp(&a->rho);
+  p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
+  p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
+  p.counter = static_cast<unsigned*>(a->workspace);
+  p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 16);
+  hipLaunchKernelGGL(small_graph_kernel, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return gnan::check_launch("small_graph_kernel");
+}

@@ -306,6 +306,20 @@ class _PathBase(nn.Module):
         want = True if isinstance(self, _GNANCore) else bool(getattr(self, "normalize_rho", True))
         return self._graph(inputs, want_norm=want)
 
+    def _small_graph(self, x, g: HopGraph, use_cnt: bool, graph_sum: bool):
+        """The whole forward by one launch where ``gnan_small_graph_fwd`` applies (a small dense-coded graph, post-rho
+        normalisation, features summed per node: what a graph-level task feeds per step), else None."""
+        from .functional import small_graph_applies, small_graph_forward
+        if not g.is_dense or x.shape[0] > 64:
+            return None
+        f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
+        if not small_graph_applies(x, g, f, rho):
+            return None
+        out = small_graph_forward(x, g, f, rho, use_cnt, graph_sum)
+        for name in ("lut", "fmlp", "spmm"):
+            self._mark(name)
+        return out
+
     # ---- rho on the distinct distances -------------------------------------------------------
     def _lut_global(self, g: HopGraph) -> torch.Tensor:
         """``lut[d] = rho(float32(1/(1+d)))``, ``lut[D-1] = rho(0)`` — D rows instead of N^2 (models.py:368).  One launch of
@@ -406,6 +420,10 @@ class _GNANCore(_PathBase):
         _lib.require_device(x)
         self._mark("start")
         g = self._graph(inputs, want_norm=True)            # GNAN.py:161 reads it unconditionally
+        if node_ids is None and not self._dropout_active():
+            small = self._small_graph(x, g, bool(self.normalize_rho), False)
+            if small is not None:
+                return small
         lut = self._lut_global(g)
         self._mark("lut")
         S, total = self._operand(x, "fs", self.fs, True, not g.is_dense, graph=g)    # f_sums, GNAN.py:157
@@ -495,10 +513,14 @@ class TensorGNAN(_PathBase):
         _lib.require_device(x)
         self._mark("start")
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
+        with_readout = self.is_graph_task and self.readout_n_layers > 0
+        if not with_readout and self.aggregation_order != "reference" and not self._dropout_active():
+            small = self._small_graph(x, g, bool(self.normalize_rho), bool(self.is_graph_task))
+            if small is not None:
+                return small
         lut = self._lut_global(g)
         self._mark("lut")
         use_cnt = bool(self.normalize_rho)
-        with_readout = self.is_graph_task and self.readout_n_layers > 0
         rest = not g.is_dense                 # a CSR lists some pairs only: the others weigh rho(0) on the column sums
         if with_readout:
             fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True)     # [N, F]   (f is 1-wide; + zero columns)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 33
+#define GNAN_ABI_VERSION 34
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -479,6 +479,49 @@ typedef struct gnan_loss_args {
 } gnan_loss_args;
 size_t gnan_loss_workspace_bytes(int64_t n);
 int gnan_loss_step(const gnan_loss_args* a, gnan_stream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * The whole forward of a SMALL dense-coded graph in one launch (GNAN.py:146-172 / models.py:358-384 with the post-rho
+ * normalisation of models.py:368-370; graph-level tasks feed one ~30-node graph per step, trainer.py:23-86):
+ *   S[j, :]   = sum_k f_k(x[j, k])                                   (features added in order k = 0 .. F-1)
+ *   lut[d, :] = rho(u_d),  u_d = float32(1 / (1 + d)) for d < D-1, u_{D-1} = 0
+ *   Y[i, c]   = sum_j lut[code[i, j], c or 0] / max(cnt[i, code[i, j]], 1) * S[j, c]       (cnt == NULL: no division)
+ *   Ysum[c]   = sum_i Y[i, c]                                          (the graph read-out, GNAN.py:75-79)
+ * One workgroup per feature + one for rho; the last to finish aggregates (a counter in the workspace).  Covers n <= 64,
+ * D <= 256, L in {2, 3}, H <= 64, C <= 8, rho.C in {1, f.C}; GNAN_ERR_UNSUPPORTED otherwise (gnan_fmlp_fwd + gnan_spmm_fwd
+ * compute the same).  S and lut are outputs too: gnan_spmm_fwd on the transposed codes, gnan_spmm_lut_grad and gnan_fmlp_bwd
+ * take them for the backward pass.  The MLP weights are stacked as in gnan_fmlp_args (rho: one "feature").
+ * workspace: gnan_small_graph_workspace_bytes(n, F, f.C) bytes whose first 4 are ZERO before the first launch (the kernel
+ * leaves them zero); one workspace per stream.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gnan_small_mlp {
+  int32_t L, H, C;
+  const float* w_first;      /* [F, H] */
+  const float* b_first;      /* [F, H] or NULL */
+  const float* w_mid;        /* [F, H, H] (L == 3) */
+  const float* b_mid;        /* [F, H] or NULL */
+  const float* w_last;       /* [F, C, H] */
+  const float* b_last;       /* [F, C] or NULL */
+} gnan_small_mlp;
+typedef struct gnan_small_graph_args {
+  const float* x;            /* [n, F], row stride x_stride */
+  int64_t x_stride;
+  int32_t n, F;
+  gnan_small_mlp f;          /* the F shape functions */
+  gnan_small_mlp rho;        /* one scalar MLP */
+  const uint8_t* code;       /* [n, n] hop codes (gnan_dense_to_code) */
+  int32_t D;
+  const int32_t* cnt;        /* optional [n, cnt_stride] shell sizes */
+  int64_t cnt_stride;
+  float* S;                  /* [n, f.C] */
+  float* lut;                /* [D, rho.C] */
+  float* Y;                  /* optional [n, f.C] */
+  float* Ysum;               /* optional [f.C] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_small_graph_args;
+size_t gnan_small_graph_workspace_bytes(int32_t n, int32_t F, int32_t C);
+int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_t stream);
 
 /* same for bf16 operand rows (stride in elements, W % 4 == 0, 8-B aligned rows) */
 int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,

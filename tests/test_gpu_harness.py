@@ -166,7 +166,7 @@ def test_fused_loss_step_matches_torch(kind, n_rows, C, masked):
     assert int(hits) == want_hits
     scale = float(ref_in.grad.abs().max())
     assert float((logits.grad - ref_in.grad).abs().max()) <= 2e-6 * scale
-    assert abs(float(total) - 2.5 - float(loss)) <= 1e-6 * max(1.0, abs(float(loss))) and float(hit_total) == 10.0 + want_hits
+    assert abs(float(total) - 2.5 - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach()))) and float(hit_total) == 10.0 + want_hits
     loss2, none = loss_step(strided, labels, k, index=idx, want_hits=False)
     loss2.backward()
     assert none is None and float(loss2) == float(loss)

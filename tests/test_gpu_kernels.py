@@ -1581,3 +1581,72 @@ def test_training_mode_dropout_in_the_kernels(F, L, H, C, bias, sum_features):
             again = feature_mlps_dropout(x.to(DEV), st, sum_features, drop_p, seed=seed)
             other = feature_mlps_dropout(x.to(DEV), st, sum_features, drop_p, seed=seed + 1)
         assert torch.equal(again, y.detach()) and not torch.equal(other, y.detach())
+
+
+@pytest.mark.parametrize("n,F,C,L,H,rho_c,D_hops,use_cnt,graph_sum", [
+    (1, 3, 1, 3, 64, 1, 1, True, True), (30, 15, 1, 3, 64, 1, 9, True, True), (64, 7, 2, 3, 64, 2, 20, True, False),
+    (17, 5, 8, 2, 32, 1, 6, False, True), (40, 9, 3, 3, 48, 3, 70, True, False), (64, 64, 1, 3, 64, 1, 12, True, True),
+    (33, 4, 4, 2, 64, 4, 200, True, True)])
+def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt, graph_sum):
+    """gnan_small_graph_fwd (shape functions of all features, rho on the distinct distances, normalised aggregation and the
+    graph read-out of a small dense-coded graph: ONE launch) == the float64 oracle chain; S and the rho table it leaves behind
+    feed the general backward kernels: gradients of every parameter == oracle autograd; bit-reproducible; more than 64
+    shells, one node, rho per channel, two-layer MLPs, hidden widths below 64; what it does not cover is refused."""
+    from gnan_amd import HopGraph, functional
+    from gnan_amd.functional import StackedMLP, small_graph_applies, small_graph_forward
+    rng = np.random.default_rng(n * 7 + F)
+    hops = rng.integers(-1, D_hops, (n, n)).astype(np.int32)           # -1 = unreachable
+    hops[np.arange(n), np.arange(n)] = 0
+    nd = torch.zeros(n, n)
+    nd[torch.from_numpy(hops >= 0)] = 1.0 / (torch.from_numpy(hops[hops >= 0]).float() + 1.0)
+    g = HopGraph.from_dense(nd.to(DEV))
+    D = g.n_codes
+
+    def mlp(Fk, Ck, bias):
+        t = lambda *s: torch.from_numpy((rng.standard_normal(s) * 0.5).astype(np.float32))
+        return [t(Fk, H), t(Fk, H) if bias else None, t(1, Fk, H, H) if L == 3 else None, t(1, Fk, H) if (L == 3 and bias) else None,
+                t(Fk, Ck, H), t(Fk, Ck) if bias else None]
+    fp, rp = mlp(F, C, True), mlp(1, rho_c, False)
+    x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+
+    def run(dtype, dev, fused):
+        fl = [None if t is None else t.to(dev, dtype).requires_grad_(True) for t in fp]
+        rl = [None if t is None else t.to(dev, dtype).requires_grad_(True) for t in rp]
+        xs = x.to(dev, dtype)
+        if fused:
+            f, r = StackedMLP(*fl, L, H, C, F), StackedMLP(*rl, L, H, rho_c, 1)
+            assert small_graph_applies(xs, g, f, r)
+            out = small_graph_forward(xs, g, f, r, use_cnt, graph_sum)
+        else:                                                         # the chain, written out in float64
+            def net(v, p, k):                                         # v [m] -> [m, C]
+                h = torch.relu(v[:, None] * p[0][k] + (0 if p[1] is None else p[1][k]))
+                if L == 3:
+                    h = torch.relu(h @ p[2][0, k].T + (0 if p[3] is None else p[3][0, k]))
+                return h @ p[4][k].T + (0 if p[5] is None else p[5][k])
+            S = sum(net(xs[:, k], fl, k) for k in range(F))
+            u = torch.zeros(D, dtype=dtype)
+            u[: D - 1] = (1.0 / (torch.arange(D - 1, dtype=torch.float32) + 1.0)).to(dtype)
+            lut = net(u, rl, 0)                                       # [D, rho_c]
+            codes = torch.from_numpy(np.where(hops >= 0, hops, D - 1)).long()
+            w = lut[codes]                                            # [n, n, rho_c]
+            if use_cnt:
+                cnt = g.cnt.cpu().clamp_min(1).to(dtype)
+                w = w / cnt[torch.arange(n)[:, None], codes][..., None]
+            out = (w * S[None, :, :]).sum(1)
+            out = out.sum(0).view(-1, 1) if graph_sum else out
+        up = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(out.shape))).to(dev, dtype)
+        live = [t for t in fl + rl if t is not None]
+        return out.detach(), torch.autograd.grad(out, live, up)
+    got, got_g = run(torch.float32, DEV, True)
+    want, want_g = run(torch.float64, "cpu", False)
+    assert got.shape == ((C, 1) if graph_sum else (n, C))
+    assert O.rel_err(got.cpu(), want) <= 1e-5
+    for a, b in zip(got_g, want_g):
+        assert float((a.cpu().double() - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
+    again, again_g = run(torch.float32, DEV, True)
+    assert torch.equal(got, again) and all(torch.equal(a, b) for a, b in zip(got_g, again_g))
+    # refused shapes: more nodes than the kernel holds, a CSR graph, inputs that want a gradient
+    f, r = StackedMLP(*[None if t is None else t.to(DEV) for t in fp], L, H, C, F), StackedMLP(*[None if t is None else t.to(DEV) for t in rp], L, H, rho_c, 1)
+    assert not small_graph_applies(x.to(DEV).requires_grad_(True), g, f, r)
+    big = HopGraph.from_dense(torch.eye(65, device=DEV))
+    assert not small_graph_applies(torch.zeros(65, F, device=DEV), big, f, r)
