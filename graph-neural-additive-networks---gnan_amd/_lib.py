@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -219,6 +219,7 @@ SYMBOLS = {
     "gnan_graph_replace_memsets": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gnan_small_graph_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_small_graph_fwd": (C.c_int, [C.POINTER(SmallGraphArgs), C.c_void_p]),
+    "gnan_multi_copy": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]),
     "gnan_loss_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_loss_step": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
@@ -266,6 +267,21 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().gnan_last_error()
         raise GnanHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def multi_copy(pairs) -> None:
+    """``dst.copy_(src)`` for up to eight (dst, src) pairs of contiguous same-shape, same-dtype device tensors in one launch."""
+    pairs = [(d, s) for d, s in pairs if d.numel()]
+    if not pairs:
+        return
+    for d, s in pairs:
+        if d.shape != s.shape or d.dtype != s.dtype or not (d.is_contiguous() and s.is_contiguous() and d.is_cuda and s.is_cuda):
+            raise GnanHipError("multi_copy: contiguous device tensors of equal shape and dtype")
+    n = len(pairs)
+    src = (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    nbytes = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    check(lib().gnan_multi_copy(n, src, dst, nbytes, stream_of(pairs[0][0])), "gnan_multi_copy")
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -145,3 +145,45 @@ extern "C" int gnan_gather_rows(const float* src, int64_t src_stride, const int6
                      src_stride, ids, k, W, dst);
   return gnan::check_launch("gather_rows_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Up to eight small device-to-device copies in ONE launch: the static input slots of a captured graph-task step (features,
+// hop codes, shell sizes, label — four cudaMemcpyAsync of a few hundred bytes each cost four launch slots, 10 us of a 45-us
+// evaluation pass).  One workgroup per copy; 16-byte words where both ends are aligned, bytes otherwise.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct MultiCopy {
+  const void* src[8];
+  void* dst[8];
+  int64_t bytes[8];
+};
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopy m) {
+  const int c = blockIdx.x;
+  const char* s = static_cast<const char*>(m.src[c]);
+  char* d = static_cast<char*>(m.dst[c]);
+  const int64_t n = m.bytes[c];
+  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+    const int64_t words = n / 16;
+    for (int64_t i = threadIdx.x; i < words; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (int64_t i = words * 16 + threadIdx.x; i < n; i += 256) d[i] = s[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+  }
+}
+}  // namespace
+
+extern "C" int gnan_multi_copy(int32_t count, const void* const* src, void* const* dst, const int64_t* bytes, gnan_stream_t stream) {
+  GNAN_REQUIRE(count >= 0 && count <= 8, "multi_copy: up to eight copies per call (got %d)", count);
+  if (count == 0) return GNAN_OK;
+  GNAN_REQUIRE(src && dst && bytes, "multi_copy: null argument arrays");
+  MultiCopy m;
+  for (int i = 0; i < 8; ++i) {
+    m.src[i] = i < count ? src[i] : nullptr;
+    m.dst[i] = i < count ? dst[i] : nullptr;
+    m.bytes[i] = i < count ? bytes[i] : 0;
+    if (i < count) GNAN_REQUIRE(bytes[i] >= 0 && (bytes[i] == 0 || (src[i] && dst[i])), "multi_copy: bad copy %d", i);
+  }
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(static_cast<unsigned>(count)), dim3(256), 0, static_cast<hipStream_t>(stream), m);
+  return gnan::check_launch("multi_copy_kernel");
+}

@@ -488,10 +488,12 @@ class SlottedGraphStep:
         self.step = GraphedStep(model, self.data, lambda out: loss_of(out, self.label), optimizer, warmup=0, prepared=prepared)
 
     def load(self, graph, x, label) -> None:
-        self.x.copy_(x)
-        self.code.copy_(graph.code)
-        self.cnt.copy_(graph.cnt)
-        self.label.copy_(label)
+        pairs = [(self.x, x), (self.code, graph.code), (self.cnt, graph.cnt), (self.label, label)]
+        if all(s.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape and s.is_cuda for d, s in pairs):
+            _lib.multi_copy(pairs)                    # one launch instead of four
+            return
+        for d, s in pairs:
+            d.copy_(s)
 
     def run(self, graph, x, label):
         """Copy the graph into the slots and replay; None if the capture has gone stale (the caller steps eagerly)."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 34
+#define GNAN_ABI_VERSION 35
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -522,6 +522,10 @@ typedef struct gnan_small_graph_args {
 } gnan_small_graph_args;
 size_t gnan_small_graph_workspace_bytes(int32_t n, int32_t F, int32_t C);
 int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_t stream);
+
+/* Up to eight small device-to-device copies in one launch (host arrays of `count` device pointers and byte counts; ranges
+ * must not overlap): the input slots of a captured graph-task step are refilled with it. */
+int gnan_multi_copy(int32_t count, const void* const* src, void* const* dst, const int64_t* bytes, gnan_stream_t stream);
 
 /* same for bf16 operand rows (stride in elements, W % 4 == 0, 8-B aligned rows) */
 int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
