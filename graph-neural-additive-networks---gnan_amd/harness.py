@@ -17,6 +17,11 @@ loop.  Graph-level tasks (a different small graph per step, batch_size = 1) get 
 (nodes, features, shells): the third graph of a shape captures it over static buffers and every later graph of that shape
 is copied into them and replayed (``SlottedGraphStep``).  ``GNAN_GRAPHED_STEPS=0`` switches it off; anything a capture cannot hold (training-mode Dropout, an optimizer
 without a capturable mode, a loader that uploads fresh tensors per epoch) silently keeps the eager loop.
+
+The loss step itself — rows of the task mask, ``nn.BCEWithLogitsLoss()`` / ``nn.CrossEntropyLoss()`` at their default options,
+the gradient w.r.t. the logits, the hit count and the epoch's running totals — is one launch (``functional.loss_step`` ->
+``gnan_loss_step``) in the eager loop and in the captured steps alike; any other loss callable runs as given
+(``GNAN_FUSED_LOSS=0``: always).
 """
 from __future__ import annotations
 

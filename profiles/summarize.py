@@ -18,7 +18,7 @@ import re
 import sys
 
 src, prefix = sys.argv[1], sys.argv[2]
-ours = ("spmm", "fmlp", "fpwl", "pwl_", "dense_to_code", "colsum", "bfs_")
+ours = ("spmm", "fmlp", "fpwl", "pwl_", "dense_to_code", "colsum", "bfs_", "loss_", "small_graph", "dense_lut", "multi_copy", "rho_row", "gather_rows", "absmax", "scales_kernel", "pack_bwd")
 
 rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "*_kernel_stats.csv"))[0])))
 with open(prefix + "_kernel_stats.csv", "w", newline="") as f:

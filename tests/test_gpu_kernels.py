@@ -1650,3 +1650,22 @@ def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt
     assert not small_graph_applies(x.to(DEV).requires_grad_(True), g, f, r)
     big = HopGraph.from_dense(torch.eye(65, device=DEV))
     assert not small_graph_applies(torch.zeros(65, F, device=DEV), big, f, r)
+
+
+def test_multi_copy_in_one_launch():
+    """gnan_multi_copy: up to eight device-to-device copies per launch — aligned and unaligned ends, odd byte counts, empty
+    tensors, several dtypes; more than eight and mismatched pairs are refused."""
+    from gnan_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    srcs = [torch.randn(37, 5, generator=g).to(DEV), torch.randint(0, 255, (33, 33), generator=g, dtype=torch.uint8).to(DEV),
+            torch.randint(0, 9, (30, 11), generator=g, dtype=torch.int32).to(DEV), torch.randn(1, generator=g).to(DEV),
+            torch.randn(4097, generator=g).to(DEV)[1:], torch.empty(0, 3, device=DEV)]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    dsts[4] = torch.zeros(4098, device=DEV)[2:]                         # both ends off the 16-byte grid, differently
+    _lib.multi_copy(list(zip(dsts, srcs)))
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    with pytest.raises(_lib.GnanHipError):
+        _lib.multi_copy([(torch.zeros(3, device=DEV), torch.zeros(4, device=DEV))])
+    with pytest.raises(_lib.GnanHipError):
+        _lib.multi_copy([(torch.zeros(3, device=DEV), torch.ones(3, device=DEV))] * 9)

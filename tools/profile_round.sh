@@ -14,6 +14,10 @@ python3 bench.py --scale 27 --nodes 111059956 --edges 1615685872 --operand bf16 
 python3 bench.py --scale 27 --nodes 111059956 --edges 1615685872 --order sum_first --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_sum_first_bench.log 2>&1
 bash tools/emulate_shares.sh > $OUT/emulated_shares.txt 2>&1
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_full.log 2>&1
+python3 tools/graphed_step.py arxiv cora muta arxiv40 > $OUT/graphed_steps.log 2>&1          # harness epochs, eager vs replayed
+python3 tools/small_graph_bench.py > $OUT/small_graph.log 2>&1
+bash tools/graphed_timeline.sh $OUT/tl_muta muta > $OUT/timeline_muta.txt 2>&1                 # one replayed graph-task training step, kernel by kernel
+bash tools/graphed_timeline.sh $OUT/tl_arxiv arxiv > $OUT/timeline_arxiv.txt 2>&1
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT
