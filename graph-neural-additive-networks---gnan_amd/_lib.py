@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -161,6 +161,19 @@ class SmallGraphArgs(C.Structure):
     ]
 
 
+class SmallMlpGrads(C.Structure):
+    _fields_ = [("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
+                ("w_last", C.c_void_p), ("b_last", C.c_void_p)]
+
+
+class SmallGraphBwdArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_stride", C.c_int64), ("n", C.c_int32), ("F", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp),
+        ("code", C.c_void_p), ("D", C.c_int32), ("cnt", C.c_void_p), ("cnt_stride", C.c_int64), ("S", C.c_void_p),
+        ("lut", C.c_void_p), ("dY", C.c_void_p), ("dYsum", C.c_void_p), ("df", SmallMlpGrads), ("drho", SmallMlpGrads),
+    ]
+
+
 class LossArgs(C.Structure):
     _fields_ = [
         ("logits", C.c_void_p), ("n_rows", C.c_int64), ("C", C.c_int32), ("kind", C.c_int32), ("stride", C.c_int64),
@@ -219,6 +232,7 @@ SYMBOLS = {
     "gnan_graph_replace_memsets": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gnan_small_graph_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_small_graph_fwd": (C.c_int, [C.POINTER(SmallGraphArgs), C.c_void_p]),
+    "gnan_small_graph_bwd": (C.c_int, [C.POINTER(SmallGraphBwdArgs), C.c_void_p]),
     "gnan_multi_copy": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]),
     "gnan_loss_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_loss_step": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),

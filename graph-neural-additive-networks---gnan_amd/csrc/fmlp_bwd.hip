@@ -11,12 +11,14 @@
 // other units reach it through v_readlane with constant lane numbers — scalar operands of the fmas, no LDS in the node
 // loop.  Per node and wave: 3 H^2 fmas (z2, dW2 += dz2 x h1, dh1 = W2^T dz2).  The four waves' partial sums meet in LDS
 // in wave order at the end.
-#include "common.hpp"
-#include "dropout.hpp"
+#include "fmlp_bwd_body.hpp"
 
 namespace {
 
 using gnan::kWave;
+using gnan_bwd::kCmax;
+using gnan_bwd::kH;
+using gnan_bwd::kWaves;
 
 struct BwdParams {
   const float* x;
@@ -34,208 +36,26 @@ struct BwdParams {
   uint64_t drop_seed;
 };
 
-constexpr int kH = 64;      // lanes = hidden units (H <= 64: the rest idle with zero weights)
-constexpr int kCmax = 8;
-constexpr int kWaves = 4;
-
-__device__ __forceinline__ float lane_value(float v, int lane) {      // lane must be a compile-time constant
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-template <int C>
+// One 256-thread workgroup per feature (and node range), nothing crosses workgroups (no atomics: the result does not depend on
+// the schedule); the work is gnan_bwd::feature_grads (csrc/fmlp_bwd_body.hpp).  MID: L == 3; L == 2 has no hidden-to-hidden
+// matrix — the same mapping without the readlane loops.
+template <int C, bool MID>
 __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParams p) {
+  __shared__ gnan_bwd::RedBuffer red;
   const int k = blockIdx.x;                       // feature
-  const int j = threadIdx.x & (kWave - 1);        // hidden unit
-  const int wv = threadIdx.x / kWave;             // node slot
-  const int H = p.H;
-  const bool unit = j < H;
-  __shared__ float red[kWaves][kH][17];           // chunked reduction of the waves' partial sums (16 values + pad)
-
-  // this unit's weights
-  const float w1 = unit ? p.w_first[static_cast<int64_t>(k) * H + j] : 0.f;
-  const float b1 = unit && p.b_first ? p.b_first[static_cast<int64_t>(k) * H + j] : 0.f;
-  const float b2 = unit && p.b_mid ? p.b_mid[static_cast<int64_t>(k) * H + j] : 0.f;
-  const float* W2 = p.w_mid + static_cast<int64_t>(k) * H * H;
-  float w2row[kH], w2col[kH], dw2[kH];
-#pragma unroll
-  for (int t = 0; t < kH; ++t) {
-    w2row[t] = unit && t < H ? W2[j * H + t] : 0.f;       // W2[j, t]
-    w2col[t] = unit && t < H ? W2[t * H + j] : 0.f;       // W2[t, j]
-    dw2[t] = 0.f;
-  }
-  float w3[C], dw3[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    w3[c] = unit ? p.w_last[(static_cast<int64_t>(k) * C + c) * H + j] : 0.f;
-    dw3[c] = 0.f;
-  }
-  float dw1 = 0.f, db1 = 0.f, db2 = 0.f;
-  float db3[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) db3[c] = 0.f;
-
+  gnan_bwd::Weights w;
+  w.H = p.H;
+  w.w_first = p.w_first; w.b_first = p.b_first; w.w_mid = p.w_mid; w.b_mid = p.b_mid; w.w_last = p.w_last; w.b_last = p.b_last;
+  w.d_w_first = p.d_w_first; w.d_b_first = p.d_b_first; w.d_w_mid = p.d_w_mid; w.d_b_mid = p.d_b_mid;
+  w.d_w_last = p.d_w_last; w.d_b_last = p.d_b_last;
+  const gnan_bwd::Drop drop{p.drop_thresh, p.drop_scale, p.drop_seed};
   const int64_t n_lo = static_cast<int64_t>(blockIdx.y) * p.nodes_per_split;
   const int64_t n_hi = n_lo + p.nodes_per_split < p.n ? n_lo + p.nodes_per_split : p.n;
   const int64_t so = static_cast<int64_t>(blockIdx.y) * p.split_stride;     // this split's block of partial gradients
-  for (int64_t node = n_lo + wv; node < n_hi; node += kWaves) {
-    const float x = p.x[node * p.x_stride + k];
-    const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
-    float gv[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) gv[c] = g[c];
-    // forward (m1, m2: this unit's Dropout factors of the two hidden layers, 0 or 1 / (1 - p); 1 without Dropout)
-    float m1 = 1.f, m2 = 1.f;
-    if (p.drop_thresh != 0u) {
-      const uint32_t dbase = gnan::drop_base(p.drop_seed, node, k);
-      m1 = gnan::drop_keep(dbase, 0, j, p.drop_thresh) ? p.drop_scale : 0.f;
-      m2 = gnan::drop_keep(dbase, 1, j, p.drop_thresh) ? p.drop_scale : 0.f;
-    }
-    const float a1 = fmaf(w1, x, b1);
-    const float h1 = unit && a1 > 0.f ? a1 * m1 : 0.f;
-    float z2 = b2;
-#pragma unroll
-    for (int t = 0; t < kH; ++t) z2 = fmaf(w2row[t], lane_value(h1, t), z2);
-    const float h2 = unit && z2 > 0.f ? z2 * m2 : 0.f;
-    // backward through the output layer
-    float dh2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      dh2 = fmaf(gv[c], w3[c], dh2);
-      dw3[c] = fmaf(gv[c], h2, dw3[c]);
-      db3[c] += gv[c];
-    }
-    const float dz2 = unit && z2 > 0.f ? dh2 * m2 : 0.f;
-    db2 += dz2;
-    // dW2[j, t] += dz2_j h1_t;   dh1_j = sum_t W2[t, j] dz2_t
-    float dh1 = 0.f;
-#pragma unroll
-    for (int t = 0; t < kH; ++t) {
-      dw2[t] = fmaf(dz2, lane_value(h1, t), dw2[t]);
-      dh1 = fmaf(w2col[t], lane_value(dz2, t), dh1);
-    }
-    const float dz1 = unit && a1 > 0.f ? dh1 * m1 : 0.f;
-    dw1 = fmaf(dz1, x, dw1);
-    db1 += dz1;
-  }
-
-  // waves -> wave 0, in wave order: dW2 sixteen columns at a time, then the vectors
-  float* dW2 = p.d_w_mid + so + static_cast<int64_t>(k) * H * H;
-  for (int t0 = 0; t0 < kH; t0 += 16) {
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) red[wv][j][t] = dw2[t0 + t];
-    __syncthreads();
-    if (wv == 0 && unit) {
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (t0 + t < H) {
-          float s = red[0][j][t];
-          for (int w = 1; w < kWaves; ++w) s += red[w][j][t];
-          dW2[j * H + t0 + t] = s;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  red[wv][j][0] = dw1; red[wv][j][1] = db1; red[wv][j][2] = db2;
-#pragma unroll
-  for (int c = 0; c < C; ++c) { red[wv][j][3 + c] = dw3[c]; }
-  __syncthreads();
-  if (wv == 0 && unit) {
-    float s[3 + C];
-#pragma unroll
-    for (int t = 0; t < 3 + C; ++t) {
-      s[t] = red[0][j][t];
-      for (int w = 1; w < kWaves; ++w) s[t] += red[w][j][t];
-    }
-    p.d_w_first[so + static_cast<int64_t>(k) * H + j] = s[0];
-    if (p.d_b_first) p.d_b_first[so + static_cast<int64_t>(k) * H + j] = s[1];
-    if (p.d_b_mid) p.d_b_mid[so + static_cast<int64_t>(k) * H + j] = s[2];
-#pragma unroll
-    for (int c = 0; c < C; ++c) p.d_w_last[so + (static_cast<int64_t>(k) * C + c) * H + j] = s[3 + c];
-  }
-  if (p.d_b_last) {       // db3 is the same in every lane of a wave: lane 0 of each wave, then wave order
-    __syncthreads();
-    if (j == 0)
-#pragma unroll
-      for (int c = 0; c < C; ++c) red[wv][0][c] = db3[c];
-    __syncthreads();
-    if (threadIdx.x < C) {
-      float s = red[0][0][threadIdx.x];
-      for (int w = 1; w < kWaves; ++w) s += red[w][0][threadIdx.x];
-      p.d_b_last[so + static_cast<int64_t>(k) * C + threadIdx.x] = s;
-    }
-  }
-}
-
-// L == 2:  f_k(x) = W3 relu(w1 x + b1) + b3  — no hidden-to-hidden matrix, the same mapping without the readlane loops.
-template <int C>
-__global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd2_kernel(const BwdParams p) {
-  const int k = blockIdx.x;
-  const int j = threadIdx.x & (kWave - 1);
-  const int wv = threadIdx.x / kWave;
-  const int H = p.H;
-  const bool unit = j < H;
-  __shared__ float red[kWaves][kH][17];
-  const float w1 = unit ? p.w_first[static_cast<int64_t>(k) * H + j] : 0.f;
-  const float b1 = unit && p.b_first ? p.b_first[static_cast<int64_t>(k) * H + j] : 0.f;
-  float w3[C], dw3[C], db3[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    w3[c] = unit ? p.w_last[(static_cast<int64_t>(k) * C + c) * H + j] : 0.f;
-    dw3[c] = db3[c] = 0.f;
-  }
-  float dw1 = 0.f, db1 = 0.f;
-  const int64_t n_lo = static_cast<int64_t>(blockIdx.y) * p.nodes_per_split;
-  const int64_t n_hi = n_lo + p.nodes_per_split < p.n ? n_lo + p.nodes_per_split : p.n;
-  const int64_t so = static_cast<int64_t>(blockIdx.y) * p.split_stride;     // this split's block of partial gradients
-  for (int64_t node = n_lo + wv; node < n_hi; node += kWaves) {
-    const float x = p.x[node * p.x_stride + k];
-    const float* g = p.grad + node * p.grad_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
-    float m1 = 1.f;
-    if (p.drop_thresh != 0u) m1 = gnan::drop_keep(gnan::drop_base(p.drop_seed, node, k), 0, j, p.drop_thresh) ? p.drop_scale : 0.f;
-    const float a1 = fmaf(w1, x, b1);
-    const float h1 = unit && a1 > 0.f ? a1 * m1 : 0.f;
-    float dh1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float gv = g[c];
-      dh1 = fmaf(gv, w3[c], dh1);
-      dw3[c] = fmaf(gv, h1, dw3[c]);
-      db3[c] += gv;
-    }
-    const float dz1 = unit && a1 > 0.f ? dh1 * m1 : 0.f;
-    dw1 = fmaf(dz1, x, dw1);
-    db1 += dz1;
-  }
-  red[wv][j][0] = dw1; red[wv][j][1] = db1;
-#pragma unroll
-  for (int c = 0; c < C; ++c) red[wv][j][2 + c] = dw3[c];
-  __syncthreads();
-  if (wv == 0 && unit) {
-    float s[2 + C];
-#pragma unroll
-    for (int t = 0; t < 2 + C; ++t) {
-      s[t] = red[0][j][t];
-      for (int w = 1; w < kWaves; ++w) s[t] += red[w][j][t];
-    }
-    p.d_w_first[so + static_cast<int64_t>(k) * H + j] = s[0];
-    if (p.d_b_first) p.d_b_first[so + static_cast<int64_t>(k) * H + j] = s[1];
-#pragma unroll
-    for (int c = 0; c < C; ++c) p.d_w_last[so + (static_cast<int64_t>(k) * C + c) * H + j] = s[2 + c];
-  }
-  if (p.d_b_last) {
-    __syncthreads();
-    if (j == 0)
-#pragma unroll
-      for (int c = 0; c < C; ++c) red[wv][0][c] = db3[c];
-    __syncthreads();
-    if (threadIdx.x < C) {
-      float s = red[0][0][threadIdx.x];
-      for (int w = 1; w < kWaves; ++w) s += red[w][0][threadIdx.x];
-      p.d_b_last[so + static_cast<int64_t>(k) * C + threadIdx.x] = s;
-    }
-  }
+  const int64_t goff = p.sum_features ? 0 : static_cast<int64_t>(k) * C;
+  gnan_bwd::feature_grads<C, MID>(
+      w, k, n_lo, n_hi, so, drop, [&](int64_t node) { return p.x[node * p.x_stride + k]; },
+      [&](int64_t node, int c) { return p.grad[node * p.grad_stride + goff + c]; }, red);
 }
 
 // out[i] = sum over the splits of partial[s * stride + i], in split order
@@ -265,10 +85,10 @@ int64_t block_floats(const gnan_fmlp_bwd_args* a) {       // one split's gradien
 template <int C>
 int launch_bwd(const BwdParams& p, unsigned splits, hipStream_t st) {
   if (p.w_mid == nullptr) {
-    hipLaunchKernelGGL((fmlp_bwd2_kernel<C>), dim3(static_cast<unsigned>(p.F), splits), dim3(kWaves * kWave), 0, st, p);
-    return gnan::check_launch("fmlp_bwd2_kernel");
+    hipLaunchKernelGGL((fmlp_bwd_kernel<C, false>), dim3(static_cast<unsigned>(p.F), splits), dim3(kWaves * kWave), 0, st, p);
+    return gnan::check_launch("fmlp_bwd_kernel<L=2>");
   }
-  hipLaunchKernelGGL((fmlp_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F), splits), dim3(kWaves * kWave), 0, st, p);
+  hipLaunchKernelGGL((fmlp_bwd_kernel<C, true>), dim3(static_cast<unsigned>(p.F), splits), dim3(kWaves * kWave), 0, st, p);
   return gnan::check_launch("fmlp_bwd_kernel");
 }
 

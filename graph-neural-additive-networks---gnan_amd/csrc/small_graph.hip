@@ -14,6 +14,7 @@
 //   read-out.  Fixed orders throughout: bit-reproducible.
 // S and lut are written out as well — the backward pass of the general path takes them from there.
 #include "common.hpp"
+#include "fmlp_bwd_body.hpp"
 
 namespace {
 
@@ -299,6 +300,178 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
   if (threadIdx.x == 0) *p.counter = 0u;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The backward pass of the same small graph in ONE launch: gradients of every parameter of f and rho from the gradient of the
+// node outputs (or of their sum).  No workgroup waits for another: workgroup k < F forms the operand gradient
+//   dS[j, c] = sum_i lut[code(i, j)] / max(cnt(i, code), 1) * dY[i, c]
+// itself (n^2 multiply-adds: cheaper than a launch that would share it) and then runs gnan_fmlp_bwd's body on feature k with
+// dS read from LDS; workgroup F forms the table gradient
+//   dlut[d] = sum_i 1 / max(cnt(i, d), 1) * sum_{j : code(i, j) == d} < dY[i, :], S[j, :] >
+// (two waves, a row each at a time, the neighbours' dot products binned by hop code in lane-private LDS columns, float64
+// across rows — dense_lut_grad_kernel's scheme) and runs the same body on rho with the D distances as its inputs.
+// Covers what the default models produce: one rho channel, D <= 64 shells, n <= 64 nodes.  Fixed orders: bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+struct SmallBwdParams {
+  const float* x;
+  int64_t x_stride;
+  int n, F;
+  gnan_bwd::Weights f, r;
+  int f_mid, r_mid;          // L == 3
+  const uint8_t* code;
+  int D;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const float* S;
+  const float* lut;
+  const float* dY;
+  const float* dYsum;
+};
+
+constexpr int kBinStride = kWave + 1;
+
+template <int C>
+__global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdParams p) {
+  __shared__ gnan_bwd::RedBuffer red;
+  __shared__ __attribute__((aligned(16))) uint8_t s_code[kMaxNodes * kMaxNodes];
+  __shared__ __attribute__((aligned(16))) float s_u[2 * kWave * kBinStride];    // row weights [n][64] (features) | bins [2][D][65] (rho)
+  __shared__ float s_dY[kMaxNodes * kMaxC];
+  __shared__ float s_S[kMaxNodes * kMaxC];
+  __shared__ float s_g[kMaxNodes * kMaxC];            // dS [n, C]  |  dlut [D]
+  __shared__ double s_part[2][kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int k = blockIdx.x, n = p.n;
+  const bool is_rho = k == p.F;
+  // ---- everything from memory in one batch ----------------------------------------------------------------------------------
+  {
+    constexpr int kWordsPer = kMaxNodes * kMaxNodes / 4 / 256;
+    const int words = n * n / 4;
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(p.code);
+    uint32_t v[kWordsPer];
+#pragma unroll
+    for (int t = 0; t < kWordsPer; ++t) {
+      const int i = threadIdx.x + t * 256;
+      v[t] = i < words ? cw[i] : 0u;
+    }
+    float gy[2], sv[2];
+    int q[16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int e = threadIdx.x + t * 256;
+      gy[t] = e < n * C ? (p.dY ? p.dY[e] : p.dYsum[e % C]) : 0.f;
+      sv[t] = (is_rho && e < n * C) ? p.S[e] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = threadIdx.x + t * 256;
+      q[t] = (!is_rho && p.cnt && e < n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
+    }
+    const float l = lane < p.D ? p.lut[lane] : 0.f;       // (e % D below: re-read per entry from this register is not possible; see s_g)
+    uint32_t* dw = reinterpret_cast<uint32_t*>(s_code);
+#pragma unroll
+    for (int t = 0; t < kWordsPer; ++t) {
+      const int i = threadIdx.x + t * 256;
+      if (i < words) dw[i] = v[t];
+    }
+    for (int i = words * 4 + threadIdx.x; i < n * n; i += 256) s_code[i] = p.code[i];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int e = threadIdx.x + t * 256;
+      if (e < n * C) { s_dY[e] = gy[t]; s_S[e] = sv[t]; }
+    }
+    if (wave == 0 && lane < p.D) s_g[lane] = l;            // the rho table, for a moment
+    __syncthreads();
+    if (!is_rho) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = threadIdx.x + t * 256;
+        if (e < n * p.D) {
+          const float lv = s_g[e % p.D];
+          s_u[(e / p.D) * kWave + e % p.D] = p.cnt ? lv / static_cast<float>(q[t] > 1 ? q[t] : 1) : lv;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const gnan_bwd::Drop nodrop{0u, 1.f, 0ull};
+  if (!is_rho) {
+    // ---- operand gradient of every node, then this feature's parameter gradients ---------------------------------------------
+    for (int e = threadIdx.x; e < n * C; e += 256) {
+      const int j = e / C, c = e % C;
+      float acc = 0.f;
+      for (int i = 0; i < n; ++i) {
+        int d = s_code[i * n + j];
+        d = d < p.D - 1 ? d : p.D - 1;
+        acc = fmaf(s_u[i * kWave + d], s_dY[i * C + c], acc);
+      }
+      s_g[e] = acc;
+    }
+    __syncthreads();
+    auto x_of = [&](int64_t node) { return p.x[node * p.x_stride + k]; };
+    auto g_of = [&](int64_t node, int c) { return s_g[node * C + c]; };
+    if (p.f_mid) gnan_bwd::feature_grads<C, true>(p.f, k, 0, n, 0, nodrop, x_of, g_of, red);
+    else gnan_bwd::feature_grads<C, false>(p.f, k, 0, n, 0, nodrop, x_of, g_of, red);
+    return;
+  }
+  // ---- table gradient, then rho's parameter gradients ---------------------------------------------------------------------------
+  float* bins = s_u + wave * p.D * kBinStride;             // waves 0 and 1
+  double acc = 0.0;                                        // lane d: dlut[d] over this wave's rows
+  for (int r = 0; 2 * r < n; ++r) {
+    const int i = 2 * r + wave;
+    const bool live = wave < 2 && i < n;
+    if (live) {
+      for (int d = 0; d < p.D; ++d) bins[d * kBinStride + lane] = 0.f;
+      if (lane < n) {
+        int d = s_code[i * n + lane];
+        d = d < p.D - 1 ? d : p.D - 1;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v = fmaf(s_dY[i * C + c], s_S[lane * C + c], v);
+        bins[d * kBinStride + lane] = v;                   // (a lane owns its column: no other lane wrote it)
+      }
+    }
+    __syncthreads();
+    if (live && lane < p.D) {
+      float sum = 0.f;
+      for (int l = 0; l < kWave; ++l) sum += bins[lane * kBinStride + l];
+      if (p.cnt) {
+        const int c = p.cnt[i * p.cnt_stride + lane];
+        sum *= 1.f / static_cast<float>(c > 1 ? c : 1);
+      }
+      acc += static_cast<double>(sum);
+    }
+    __syncthreads();
+  }
+  if (wave < 2) s_part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < p.D) s_g[lane] = static_cast<float>(s_part[0][lane] + s_part[1][lane]);
+  __syncthreads();
+  auto u_of = [&](int64_t node) { return node < p.D - 1 ? 1.0f / (static_cast<float>(node) + 1.0f) : 0.f; };
+  auto gl_of = [&](int64_t node, int) { return s_g[node]; };
+  if (p.r_mid) gnan_bwd::feature_grads<1, true>(p.r, 0, 0, p.D, 0, nodrop, u_of, gl_of, red);
+  else gnan_bwd::feature_grads<1, false>(p.r, 0, 0, p.D, 0, nodrop, u_of, gl_of, red);
+}
+
+template <int C>
+int launch_small_bwd(const SmallBwdParams& p, hipStream_t st) {
+  hipLaunchKernelGGL((small_graph_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256), 0, st, p);
+  return gnan::check_launch("small_graph_bwd_kernel");
+}
+
+gnan_bwd::Weights to_weights(const gnan_small_mlp* m, const gnan_small_mlp_grads* g) {
+  gnan_bwd::Weights w;
+  w.H = m->H;
+  w.w_first = m->w_first; w.b_first = m->b_first; w.w_mid = m->L == 3 ? m->w_mid : nullptr; w.b_mid = m->L == 3 ? m->b_mid : nullptr;
+  w.w_last = m->w_last; w.b_last = m->b_last;
+  w.d_w_first = g->w_first; w.d_b_first = g->b_first; w.d_w_mid = g->w_mid; w.d_b_mid = g->b_mid; w.d_w_last = g->w_last;
+  w.d_b_last = g->b_last;
+  return w;
+}
+
+bool grads_ok(const gnan_small_mlp* m, const gnan_small_mlp_grads* g) {
+  return g->w_first && g->w_last && (m->L == 2 || g->w_mid) && ((m->b_first == nullptr) == (g->b_first == nullptr)) &&
+         (m->L == 2 || ((m->b_mid == nullptr) == (g->b_mid == nullptr))) && ((m->b_last == nullptr) == (g->b_last == nullptr));
+}
+
 bool mlp_ok(const gnan_small_mlp* m, int max_c) {
   return (m->L == 2 || m->L == 3) && m->H >= 1 && m->H <= kMaxH && m->C >= 1 && m->C <= max_c && m->w_first && m->w_last &&
          (m->L == 2 || m->w_mid);
@@ -340,4 +513,34 @@ extern "C" int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_
   hipLaunchKernelGGL(small_graph_kernel, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave), 0,
                      static_cast<hipStream_t>(stream), p);
   return gnan::check_launch("small_graph_kernel");
+}
+
+extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "small_graph_bwd: null args");
+  GNAN_REQUIRE(a->n >= 1 && a->F >= 1 && a->D >= 1, "small_graph_bwd: bad sizes n=%d F=%d D=%d", a->n, a->F, a->D);
+  if (a->n > kMaxNodes || a->D > kWave || !mlp_ok(&a->f, kMaxC) || !mlp_ok(&a->rho, 1))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_graph_bwd: covers n <= %d nodes, D <= %d shells, L in {2, 3}, H <= %d, C <= %d and a "
+                      "one-channel rho (got n=%d D=%d L=%d/%d H=%d/%d C=%d/%d)", kMaxNodes, kWave, kMaxH, kMaxC, a->n, a->D,
+                      a->f.L, a->rho.L, a->f.H, a->rho.H, a->f.C, a->rho.C);
+  GNAN_REQUIRE(a->x && a->code && a->S && a->lut && (a->dY || a->dYsum), "small_graph_bwd: null x / code / S / lut / output gradient");
+  GNAN_REQUIRE(a->x_stride >= a->F && (a->cnt == nullptr || a->cnt_stride >= a->D), "small_graph_bwd: row stride smaller than the width");
+  GNAN_REQUIRE(grads_ok(&a->f, &a->df) && grads_ok(&a->rho, &a->drho),
+               "small_graph_bwd: a gradient pointer for every weight, and for a bias exactly where there is one");
+  SmallBwdParams p;
+  p.x = a->x; p.x_stride = a->x_stride; p.n = a->n; p.F = a->F;
+  p.f = to_weights(&a->f, &a->df); p.r = to_weights(&a->rho, &a->drho);
+  p.f_mid = a->f.L == 3; p.r_mid = a->rho.L == 3;
+  p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
+  p.S = a->S; p.lut = a->lut; p.dY = a->dY; p.dYsum = a->dYsum;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a->f.C) {
+    case 1: return launch_small_bwd<1>(p, st);
+    case 2: return launch_small_bwd<2>(p, st);
+    case 3: return launch_small_bwd<3>(p, st);
+    case 4: return launch_small_bwd<4>(p, st);
+    case 5: return launch_small_bwd<5>(p, st);
+    case 6: return launch_small_bwd<6>(p, st);
+    case 7: return launch_small_bwd<7>(p, st);
+    default: return launch_small_bwd<8>(p, st);
+  }
 }

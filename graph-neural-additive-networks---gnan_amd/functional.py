@@ -1656,6 +1656,7 @@ def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Opt
 # =============================================================================
 SMALL_GRAPH_FORWARD = os.environ.get("GNAN_SMALL_GRAPH", "1") != "0"
 SMALL_GRAPH_MAX_NODES = 64
+SMALL_GRAPH_BACKWARD = os.environ.get("GNAN_SMALL_GRAPH_BWD", "1") != "0"   # ... and its backward pass (gnan_small_graph_bwd)
 _SMALL_WS = {}               # (device index, stream) -> workspace whose counter word the kernel leaves zero
 
 
@@ -1721,11 +1722,30 @@ class _SmallGraph(torch.autograd.Function):
         Lf, Hf, Cf, F = ctx.fm
         Lr, Hr, Cr = ctx.rm
         n = x.shape[0]
+        need_f, need_r = any(ctx.needs_input_grad[6:12]), any(ctx.needs_input_grad[12:])
+        if (SMALL_GRAPH_BACKWARD and need_f and need_r and Cr == 1 and ctx.g.n_codes <= 64 and d_out.dtype == torch.float32
+                and all(t is None or t.dtype == torch.float32 for t in params)):
+            # one launch: every workgroup forms the operand (or table) gradient it needs itself, then the small-batch MLP backward
+            keep = [None if t is None else _c(t.detach()) for t in params]
+            outs_f, outs_r = _grad_outputs(keep[:6], ctx.dests[:6]), _grad_outputs(keep[6:], ctx.dests[6:])
+
+            def grads(o):
+                return _lib.SmallMlpGrads(w_first=_lib.ptr(o[0]), b_first=_lib.ptr(o[1]),
+                                          w_mid=None if o[2] is None else _lib.ptr(o[2][0]),
+                                          b_mid=None if o[3] is None else _lib.ptr(o[3][0]), w_last=_lib.ptr(o[4]), b_last=_lib.ptr(o[5]))
+            g_out = d_out.detach().contiguous()
+            cnt = ctx.g.cnt if ctx.use_cnt else None
+            a = _lib.SmallGraphBwdArgs(x=_lib.ptr(x), x_stride=x.stride(0), n=n, F=F, f=_small_mlp(keep[:6], Lf, Hf, Cf),
+                                       rho=_small_mlp(keep[6:], Lr, Hr, Cr), code=_lib.ptr(ctx.g.code), D=ctx.g.n_codes,
+                                       cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0), S=_lib.ptr(S),
+                                       lut=_lib.ptr(lut), dY=None if ctx.graph_sum else _lib.ptr(g_out),
+                                       dYsum=_lib.ptr(g_out) if ctx.graph_sum else None, df=grads(outs_f), drho=grads(outs_r))
+            _lib.check(_lib.lib().gnan_small_graph_bwd(a, _lib.stream_of(x)), "gnan_small_graph_bwd")
+            return (None, None, None, None, None, None, *outs_f, *outs_r)
         dY = d_out.reshape(1, Cf).expand(n, Cf).contiguous() if ctx.graph_sum else d_out.contiguous()
         bag = _Bag()
         bag.g, bag.use_cnt, bag.with_rest, bag.row_ids, bag.reduce_cr = ctx.g, ctx.use_cnt, False, None, 0
         bag.s_total, bag.total_rows, bag.total_group = None, None, NOT_SHARED
-        need_f, need_r = any(ctx.needs_input_grad[6:12]), any(ctx.needs_input_grad[12:])
         dS, dlut = _aggregate_backward(bag, S, lut, dY, need_f, need_r)
         pg_f = pg_r = [None] * 6
         if need_f:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 35
+#define GNAN_ABI_VERSION 36
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -522,6 +522,40 @@ typedef struct gnan_small_graph_args {
 } gnan_small_graph_args;
 size_t gnan_small_graph_workspace_bytes(int32_t n, int32_t F, int32_t C);
 int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_t stream);
+
+/* ... and its backward pass in one launch: the gradients of every stacked parameter tensor of f and rho (autograd through
+ * GNAN.py:146-172 / models.py:358-384 + trainer.py:66) from dY [n, f.C] — or dYsum [f.C], the gradient of the graph read-out,
+ * which every row shares — and the S and lut the forward left behind.  Workgroup k < F forms the operand gradient
+ * dS[j, :] = sum_i lut[code[i, j]] / max(cnt[i, code[i, j]], 1) * dY[i, :] itself and runs gnan_fmlp_bwd's body on feature k;
+ * workgroup F forms dlut[d] = sum_i 1 / max(cnt[i, d], 1) * sum_{j : code[i, j] == d} <dY[i, :], S[j, :]> and runs it on rho.
+ * Covers n <= 64, D <= 64, a one-channel rho, L in {2, 3}, H <= 64, C <= 8; GNAN_ERR_UNSUPPORTED otherwise (the general
+ * kernels then: gnan_spmm_fwd on the transposed codes, gnan_spmm_lut_grad, gnan_fmlp_bwd twice).  No workspace, no atomics. */
+typedef struct gnan_small_mlp_grads {
+  float* w_first;
+  float* b_first;            /* NULL exactly where the MLP has no such bias */
+  float* w_mid;
+  float* b_mid;
+  float* w_last;
+  float* b_last;
+} gnan_small_mlp_grads;
+typedef struct gnan_small_graph_bwd_args {
+  const float* x;
+  int64_t x_stride;
+  int32_t n, F;
+  gnan_small_mlp f;
+  gnan_small_mlp rho;
+  const uint8_t* code;
+  int32_t D;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const float* S;            /* [n, f.C] node sums of the forward */
+  const float* lut;          /* [D] rho table of the forward */
+  const float* dY;           /* [n, f.C] or NULL */
+  const float* dYsum;        /* [f.C] or NULL (used when dY is NULL) */
+  gnan_small_mlp_grads df;
+  gnan_small_mlp_grads drho;
+} gnan_small_graph_bwd_args;
+int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_stream_t stream);
 
 /* Up to eight small device-to-device copies in one launch (host arrays of `count` device pointers and byte counts; ranges
  * must not overlap): the input slots of a captured graph-task step are refilled with it. */

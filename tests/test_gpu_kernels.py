@@ -1645,6 +1645,17 @@ def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt
         assert float((a.cpu().double() - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
     again, again_g = run(torch.float32, DEV, True)
     assert torch.equal(got, again) and all(torch.equal(a, b) for a, b in zip(got_g, again_g))
+    # the backward pass is ONE launch too where rho has one channel and there are at most 64 shells (gnan_small_graph_bwd);
+    # the general kernels on the saved node sums and rho table otherwise — and on request: same gradients
+    one_launch = rho_c == 1 and D <= 64
+    old_flag = functional.SMALL_GRAPH_BACKWARD
+    functional.SMALL_GRAPH_BACKWARD = False
+    try:
+        _, general_g = run(torch.float32, DEV, True)
+    finally:
+        functional.SMALL_GRAPH_BACKWARD = old_flag
+    for a, b, w in zip(got_g, general_g, want_g):
+        assert float((a - b).abs().max()) <= (2e-5 if one_launch else 0.0) * float(w.abs().max())
     # refused shapes: more nodes than the kernel holds, a CSR graph, inputs that want a gradient
     f, r = StackedMLP(*[None if t is None else t.to(DEV) for t in fp], L, H, C, F), StackedMLP(*[None if t is None else t.to(DEV) for t in rp], L, H, rho_c, 1)
     assert not small_graph_applies(x.to(DEV).requires_grad_(True), g, f, r)
