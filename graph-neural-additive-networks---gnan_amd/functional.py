@@ -1619,9 +1619,9 @@ def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, h
 
 class _LossStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum):
+    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum, unit_upstream):
         loss, hits, grad = _loss_launch(outputs, labels, kind, index, want_hits, ctx.needs_input_grad[0], loss_sum, hits_sum)
-        ctx.grad = grad
+        ctx.grad, ctx.unit_upstream = grad, unit_upstream
         if hits is not None:
             ctx.mark_non_differentiable(hits)
         return (loss, hits) if hits is not None else loss
@@ -1629,14 +1629,17 @@ class _LossStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         grad, ctx.grad = ctx.grad, None
-        return grad * g_loss, None, None, None, None, None, None
+        return (grad if ctx.unit_upstream else grad * g_loss), None, None, None, None, None, None, None
 
 
 def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Optional[torch.Tensor] = None,
-              want_hits: bool = True, loss_sum: Optional[torch.Tensor] = None, hits_sum: Optional[torch.Tensor] = None):
+              want_hits: bool = True, loss_sum: Optional[torch.Tensor] = None, hits_sum: Optional[torch.Tensor] = None,
+              unit_upstream: bool = False):
     """``(loss, hits)`` of the rows ``index`` of ``outputs`` (all rows without it) by ``gnan_loss_step``: the mean loss as a
     0-d tensor that back-propagates into ``outputs`` (its gradient was formed in the same launch), the hit count as a 0-d
-    int64 tensor (None unless ``want_hits``); ``loss_sum`` / ``hits_sum`` (0-d float32 device tensors) are added to in place."""
+    int64 tensor (None unless ``want_hits``); ``loss_sum`` / ``hits_sum`` (0-d float32 device tensors) are added to in place.
+    ``unit_upstream``: the caller promises to call ``backward()`` on this very loss (upstream gradient 1, as the epoch loops
+    do, trainer.py:66) — the stored gradient is then handed down as it is instead of being multiplied by it (a launch)."""
     _lib.require_device(outputs, labels)
     if labels.numel() == 0:
         raise ValueError("loss_step: no rows selected (the mean of an empty set)")
@@ -1647,7 +1650,7 @@ def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Opt
     for t in (loss_sum, hits_sum):
         if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.numel() != 1):
             raise ValueError("loss_step: the running totals are 0-d float32 device tensors")
-    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum)
+    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum, bool(unit_upstream))
     return got if want_hits else (got, None)
 
 

@@ -362,14 +362,21 @@ class GraphedStep:
         # caller reads anyway.  Needs the flat update (the optimizer's own step takes no skip flag); evaluation steps always can.
         self.guard = torch.zeros(1, dtype=torch.float32, device=next(model.parameters()).device) if GUARDED_REPLAY else None
 
+        # (the guard is never reset: a step whose guard tripped is dropped by its replayer, and a fresh capture gets a fresh flag)
+        one = None
+
         def step():
-            if self.guard is not None:
-                self.guard.zero_()
+            nonlocal one
             if self.training:
                 out = fwd()
                 out = out[0] if isinstance(out, tuple) else out
                 loss, extras = loss_of(out)
-                loss.backward()
+                if loss.dim() == 0 and loss.dtype == torch.float32:
+                    if one is None or one.device != loss.device:
+                        one = torch.ones((), dtype=torch.float32, device=loss.device)
+                    torch.autograd.backward(loss, one)       # (loss.backward() fills a fresh tensor of ones every step: a launch)
+                else:
+                    loss.backward()
                 self.flat.step(skip=self.guard) if self.flat is not None else optimizer.step()
                 return out.detach(), loss.detach(), extras
             with torch.no_grad():

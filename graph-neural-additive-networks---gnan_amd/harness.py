@@ -227,7 +227,7 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
             kind = _fused_kind(loss_fn, outputs)
             if kind is not None:                     # selection, loss, its gradient and the hit count in one launch
                 from .functional import loss_step
-                loss, hits = loss_step(outputs, labels_m, kind, index=idx, want_hits=classify)
+                loss, hits = loss_step(outputs, labels_m, kind, index=idx, want_hits=classify, unit_upstream=True)
                 return loss, (hits, outputs.detach().index_select(0, idx) if compute_auc else None)
             picked = outputs.index_select(0, idx)
             loss = _loss_of(loss_fn, picked, labels_m)
@@ -316,7 +316,7 @@ class _GraphTaskSteps:
                 if kind is not None and outputs.shape[0] == label.numel():
                     from .functional import loss_step
                     loss, _ = loss_step(outputs, label, kind, want_hits=False, loss_sum=self.total_loss,
-                                        hits_sum=self.hits if classify else None)
+                                        hits_sum=self.hits if classify else None, unit_upstream=True)
                     return loss, None
                 loss = _loss_of(loss_fn, outputs, label)
                 self.total_loss.add_(loss.detach())
@@ -401,7 +401,7 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
                 labels = labels[idx]
             n_samples += len(labels)
             loss, _ = loss_step(outputs, labels, kind, index=idx, want_hits=False, loss_sum=total_loss,
-                                hits_sum=hits if classify else None)
+                                hits_sum=hits if classify else None, unit_upstream=True)
             if optimizer is not None:
                 loss.backward()
                 optimizer.step()
