@@ -363,7 +363,7 @@ class GraphedStep:
         self.guard = torch.zeros(1, dtype=torch.float32, device=next(model.parameters()).device) if GUARDED_REPLAY else None
 
         # (the guard is never reset: a step whose guard tripped is dropped by its replayer, and a fresh capture gets a fresh flag)
-        one = None
+        one = torch.ones((), dtype=torch.float32, device=next(model.parameters()).device) if self.training else None
 
         def step():
             nonlocal one
