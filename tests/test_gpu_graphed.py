@@ -343,6 +343,58 @@ def test_graph_task_steps_replayed_per_shape_match_eager_steps(readout, monkeypa
     assert replayed >= 70, replayed                                # 135 steps, a dozen shapes, two eager sightings each
 
 
+@pytest.mark.parametrize("task", ["graph", "node"])
+def test_optimizers_the_flat_update_declines_are_replayed_with_their_own_step(task, monkeypatch):
+    """An optimizer over a SUBSET of the parameters (rho frozen) or with two parameter groups is not re-homed
+    (graphed.FlatAdamStep declines): its own fused step is captured, such a step is checked BEFORE every replay instead of
+    guarded on the device, the small-graph backward leaves the frozen MLP alone — and the replayed epochs still equal the eager
+    ones, parameter for parameter."""
+    _need_gpu()
+    from gnan_amd import harness
+    from gnan_amd.models import TensorGNAN
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    if task == "graph":
+        F = 15
+        loader = _graph_task(30, F, sizes=[12, 30, 12, 23, 30])
+    else:
+        F = 129
+        loader = [_node_task(3000, F, 1, False)]
+
+    def make(frozen):
+        torch.manual_seed(0)
+        m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=(task == "graph"), readout_n_layers=0, device=DEV)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape) * 0.3)
+        m = m.to(DEV).eval()
+        if frozen:
+            for p in m.rho.parameters():
+                p.requires_grad_(False)
+            opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=True)
+        else:
+            fs, rho = list(m.fs.parameters()), list(m.rho.parameters())
+            opt = torch.optim.Adam([{"params": fs}, {"params": rho, "lr": 3e-4}], lr=1e-3, capturable=True, fused=True)
+        return m, opt
+    for frozen in (True, False):
+        runs = {}
+        for on in (False, True):
+            monkeypatch.setattr(harness, "GRAPHED_STEPS", on)
+            m, opt = make(frozen)
+            hist = [harness.train_epoch(m, loader, loss_fn, opt, DEV, classify=True, is_graph_task=(task == "graph"))[0]
+                    for _ in range(6)]
+            runs[on] = (hist, {k: v.detach().clone() for k, v in m.state_dict().items()}, m)
+        assert np.allclose(runs[False][0], runs[True][0], rtol=1e-5, atol=1e-7), (frozen, runs[False][0], runs[True][0])
+        scale = max(float(v.abs().max()) for v in runs[False][1].values())
+        for k, v in runs[False][1].items():
+            assert float((v - runs[True][1][k]).abs().max()) <= 1e-5 * scale, (frozen, k)
+        store = harness._steps_of(runs[True][2])
+        steps = ([r["step"].step for r in store.graph.buckets.values() if r["step"] is not None] if task == "graph"
+                 else [r.value["step"] for r in store.node.entries.values() if r.value["step"] is not None])
+        assert steps and all(s.flat is None and s.guard is None and s.graph.replays >= 1 for s in steps), (frozen, len(steps))
+        if frozen:
+            assert all(p.grad is None for p in runs[True][2].rho.parameters())
+
+
 def test_captured_steps_die_with_their_model_and_hand_the_optimizer_back(monkeypatch):
     """Cross-validation loops build a fresh model per fold and seed (main.py): every run's captured graphs (and their
     private memory pools) must go when the model goes — device memory returns to the baseline — and an optimizer that was
