@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
 // itself (n^2 multiply-adds: cheaper than a launch that would share it) and then runs gnan_fmlp_bwd's body on feature k with
 // dS read from LDS; workgroup F forms the table gradient
 //   dlut[d] = sum_i 1 / max(cnt(i, d), 1) * sum_{j : code(i, j) == d} < dY[i, :], S[j, :] >
-// (two waves, a row each at a time, the neighbours' dot products binned by hop code in lane-private LDS columns, float64
-// across rows — dense_lut_grad_kernel's scheme) and runs the same body on rho with the D distances as its inputs.
+// (a row per wave at a time, the neighbours' dot products binned by hop code in lane-private LDS columns, float64 across
+// rows — dense_lut_grad_kernel's scheme) and runs the same body on rho with the D distances as its inputs.
 // Covers what the default models produce: one rho channel, D <= 64 shells, n <= 64 nodes.  Fixed orders: bit-reproducible.
 // ---------------------------------------------------------------------------------------------
 struct SmallBwdParams {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   __shared__ float s_dY[kMaxNodes * kMaxC];
   __shared__ float s_S[kMaxNodes * kMaxC];
   __shared__ float s_g[kMaxNodes * kMaxC];            // dS [n, C]  |  dlut [D]
-  __shared__ double s_part[2][kWave];
+  __shared__ double s_part[kWaves][kWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int k = blockIdx.x, n = p.n;
   const bool is_rho = k == p.F;
@@ -413,26 +413,30 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     return;
   }
   // ---- table gradient, then rho's parameter gradients ---------------------------------------------------------------------------
-  float* bins = s_u + wave * p.D * kBinStride;             // waves 0 and 1
+  // (this workgroup is the kernel's critical path: a row per wave and round, all four waves where their bins fit — they do
+  // for the graphs this kernel is for — and bin rows only as long as there are neighbours)
+  const int stride = n | 1;                                // odd: lane d's walk along bin row d does not collide with lane d + 1's
+  const int nw = 4 * p.D * stride <= 2 * kWave * kBinStride ? 4 : 2;        // waves that bin
+  float* bins = s_u + wave * p.D * stride;
   double acc = 0.0;                                        // lane d: dlut[d] over this wave's rows
-  for (int r = 0; 2 * r < n; ++r) {
-    const int i = 2 * r + wave;
-    const bool live = wave < 2 && i < n;
+  for (int r = 0; nw * r < n; ++r) {
+    const int i = nw * r + wave;
+    const bool live = wave < nw && i < n;
     if (live) {
-      for (int d = 0; d < p.D; ++d) bins[d * kBinStride + lane] = 0.f;
       if (lane < n) {
+        for (int d = 0; d < p.D; ++d) bins[d * stride + lane] = 0.f;
         int d = s_code[i * n + lane];
         d = d < p.D - 1 ? d : p.D - 1;
         float v = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) v = fmaf(s_dY[i * C + c], s_S[lane * C + c], v);
-        bins[d * kBinStride + lane] = v;                   // (a lane owns its column: no other lane wrote it)
+        bins[d * stride + lane] = v;                       // (a lane owns its column: no other lane wrote it)
       }
     }
     __syncthreads();
     if (live && lane < p.D) {
       float sum = 0.f;
-      for (int l = 0; l < kWave; ++l) sum += bins[lane * kBinStride + l];
+      for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];
       if (p.cnt) {
         const int c = p.cnt[i * p.cnt_stride + lane];
         sum *= 1.f / static_cast<float>(c > 1 ? c : 1);
@@ -441,9 +445,9 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     }
     __syncthreads();
   }
-  if (wave < 2) s_part[wave][lane] = acc;
+  s_part[wave][lane] = wave < nw ? acc : 0.0;
   __syncthreads();
-  if (wave == 0 && lane < p.D) s_g[lane] = static_cast<float>(s_part[0][lane] + s_part[1][lane]);
+  if (wave == 0 && lane < p.D) s_g[lane] = static_cast<float>(((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]);
   __syncthreads();
   auto u_of = [&](int64_t node) { return node < p.D - 1 ? 1.0f / (static_cast<float>(node) + 1.0f) : 0.f; };
   auto gl_of = [&](int64_t node, int) { return s_g[node]; };
