@@ -52,12 +52,33 @@ __device__ __forceinline__ void feature_grads(const Weights& p, int k, int64_t n
   if constexpr (MID) {
     b2 = unit && p.b_mid ? p.b_mid[static_cast<int64_t>(k) * H + j] : 0.f;
     const float* W2 = p.w_mid + static_cast<int64_t>(k) * H * H;
+    // W2 through LDS: read straight from memory, lane j's ROW is 64 loads that each touch 64 different lines per wave (16k
+    // line requests per workgroup, 5 us of an 18-us launch on a 30-node graph); staged coalesced into the reduction buffer
+    // ([64][65]: rows and columns both conflict-free) it is 16 loads per thread, all in flight together
+    static_assert(sizeof(RedBuffer) >= kH * (kH + 1) * sizeof(float), "W2 tile fits the reduction buffer");
+    float* tile = &red[0][0][0];
+    {
+      constexpr int kPer = kH * kH / (kWaves * kWave);
+      float v[kPer];
+#pragma unroll
+      for (int t = 0; t < kPer; ++t) {
+        const int e = static_cast<int>(threadIdx.x) + t * kWaves * kWave;
+        v[t] = e < H * H ? W2[e] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < kPer; ++t) {
+        const int e = static_cast<int>(threadIdx.x) + t * kWaves * kWave;
+        if (e < H * H) tile[(e / H) * (kH + 1) + e % H] = v[t];
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < kH; ++t) {
-      w2row[t] = unit && t < H ? W2[j * H + t] : 0.f;       // W2[j, t]
-      w2col[t] = unit && t < H ? W2[t * H + j] : 0.f;       // W2[t, j]
+      w2row[t] = unit && t < H ? tile[j * (kH + 1) + t] : 0.f;       // W2[j, t]
+      w2col[t] = unit && t < H ? tile[t * (kH + 1) + j] : 0.f;       // W2[t, j]
       dw2[t] = 0.f;
     }
+    __syncthreads();                                                // (the buffer goes back to the reductions)
   }
   float w3[C], dw3[C], db3[C];
 #pragma unroll
