@@ -125,11 +125,28 @@ __device__ __forceinline__ void mlp_block(const Mlp& m, const MlpLds& w, float x
         acc[t] = w.b2[o];
         row[t] = w.w2 + o * H;
       }
-#pragma unroll 16
-      for (int i = 0; i < H; ++i) {
-        const float h = cur[i * kWave + lane];
+      if ((H & 3) == 0) {                              // four inputs per step: the weights as 16-byte LDS broadcasts
+#pragma unroll 4
+        for (int i = 0; i < H; i += 4) {
+          float h[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = fmaf(row[t][i], h, acc[t]);
+          for (int u = 0; u < 4; ++u) h[u] = cur[(i + u) * kWave + lane];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 w4 = *reinterpret_cast<const float4*>(row[t] + i);
+            acc[t] = fmaf(w4.x, h[0], acc[t]);
+            acc[t] = fmaf(w4.y, h[1], acc[t]);
+            acc[t] = fmaf(w4.z, h[2], acc[t]);
+            acc[t] = fmaf(w4.w, h[3], acc[t]);
+          }
+        }
+      } else {
+#pragma unroll 16
+        for (int i = 0; i < H; ++i) {
+          const float h = cur[i * kWave + lane];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = fmaf(row[t][i], h, acc[t]);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
