@@ -80,7 +80,11 @@ class TensorGNAN(_PathBase):
             w_pair = self.rho(hops[g.code.long()])                                          # [nnz, C], one mask per pair
             Y = torch.zeros_like(S).index_add(0, row_of_pair, w_pair * S[g.col.long()])
         else:
-            lut = torch.cat([self.rho(hops), torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)
+            # rho on the handful of distinct hop counts: one launch of the shape-function kernel (one of gnan_fmlp_bwd in the
+            # backward pass) instead of the six framework launches of self.rho(hops), as modules._lut_global
+            from .functional import feature_mlps
+            listed = feature_mlps(hops, self._stacked("rho", [self.rho]), sum_features=False)
+            lut = torch.cat([listed, torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)
             Y = rho_aggregate(g, S, lut, use_cnt=False, with_rest=False)                    # [N, C]
         if not self.is_graph_task:
             return Y
