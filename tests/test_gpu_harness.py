@@ -129,7 +129,9 @@ def test_interpretability_exports_come_from_the_kernels_tables():
 
 
 @pytest.mark.parametrize("kind,n_rows,C,masked", [("bce", 1, 1, False), ("bce", 37, 1, True), ("bce", 300_000, 1, True),
-                                                   ("ce", 50, 4, False), ("ce", 5000, 7, True), ("ce", 200_000, 3, True)])
+                                                   ("ce", 50, 4, False), ("ce", 5000, 7, True), ("ce", 200_000, 3, True),
+                                                   ("ce", 3, 40, False), ("ce", 100_000, 40, True), ("ce", 5001, 128, True),
+                                                   ("ce", 777, 9, True), ("ce", 64, 130, False)])
 def test_fused_loss_step_matches_torch(kind, n_rows, C, masked):
     """gnan_loss_step (row selection, mean loss, gradient w.r.t. the logits, hit count, running totals: one launch, two past
     2048 rows) == nn.BCEWithLogitsLoss / nn.CrossEntropyLoss + the trainer's accuracy rule (trainer.py:5-20, 61-71) on the
