@@ -321,6 +321,8 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
     }
   }
   float red[4] = {0.f, 0.f, 0.f, 0.f};  // fused feature sum (reduce_cr in {1, 2, 4}): channel partials of this lane
+  // (uniform) one weight per pair from a per-neighbour table, no counts, no rest subtraction: see the index loads below
+  const bool pair_weights = !SMALLD && !DENSE && p.weight_by_col && p.Cw == 1 && p.cnt == nullptr && !p.minus_rest && p.lut_row_stride != 0;
 
   for (int w0 = 0; w0 < p.W; w0 += TILE) {
     const int cw = w0 + sub * VEC;
@@ -361,12 +363,27 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
         }
       }
       const int m = static_cast<int>(hi - base < IW ? hi - base : IW);
+      // Per-neighbour weight table (the wide backward pass: weight = wt[c, d], one channel): the lane that holds a pair's index
+      // entry fetches its weight too — ONE load instruction per round and group — and hands it out by shuffle like the column id.
+      // Read inside the pair loop it was a second memory instruction per pair and lane: 133 -> 271 us on the arxiv shape.
+      float wv[IPL];
+      if constexpr (!SMALLD) {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          wv[r] = 0.f;
+          if (pair_weights && base + sub * IPL + r < hi) {
+            const int dd = codev[r] < rest ? codev[r] : rest;
+            wv[r] = p.lut[static_cast<int64_t>(colv[r]) * p.lut_row_stride + dd];
+          }
+        }
+      }
       // IPL > 1: fully unrolled so that the register index j % IPL is static; IPL == 1: plain runtime loop
 #pragma unroll(IPL > 1 ? IW / UNROLL : 1)
       for (int j0 = 0; j0 < (IPL > 1 ? IW : m); j0 += UNROLL) {
         if (IPL > 1 && j0 >= m) break;
         Raw<VEC> s[UNROLL];
         int d[UNROLL], c[UNROLL];
+        float wp[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           const int j = j0 + u;              // compile-time after unrolling: lane j / IPL holds it in register j % IPL
@@ -377,6 +394,7 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           }
           d[u] = __shfl(codev[j % IPL], j / IPL, LPR);
           d[u] = d[u] < rest ? d[u] : rest;
+          if constexpr (!SMALLD) wp[u] = __shfl(wv[j % IPL], j / IPL, LPR);
           s[u].zero();
           if (j < m && col_ok)
             s[u].load(p.S, BYCODE ? static_cast<int64_t>(c[u]) * p.D + d[u] : static_cast<int64_t>(c[u]), p.s_stride, cw);
@@ -390,7 +408,13 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
 #pragma unroll
               for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w, sv.v[v], acc.v[v]);
             } else {
-              const Vec<VEC> w = edge_weights<VEC>(p, i, c[u], d[u], cw);
+              Vec<VEC> w;
+              if (pair_weights) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) w.v[v] = wp[u];
+              } else {
+                w = edge_weights<VEC>(p, i, c[u], d[u], cw);
+              }
 #pragma unroll
               for (int v = 0; v < VEC; ++v) {
                 acc.v[v] = fmaf(w.v[v], sv.v[v], acc.v[v]);
