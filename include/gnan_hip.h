@@ -448,7 +448,7 @@ int gnan_gather_rows(const float* src, int64_t src_stride, const int64_t* ids, i
                      gnan_stream_t stream);
 
 /* -------------------------------------------------------------------------------------------
- * The loss step of the epoch loops (trainer.py:53-71 / :125-147) in one launch (two past 2048 rows, one more to zero the
+ * The loss step of the epoch loops (trainer.py:53-71 / :125-147) in one launch (two past 512 rows, one more to zero the
  * gradient rows a mask leaves out): rows index[0..n) of the logits (all rows 0..n-1 without index),
  *   GNAN_LOSS_BCE_LOGITS   (C == 1, labels float32 [n]): mean_i (1 - t_i) x_i - logsigmoid(x_i)   = nn.BCEWithLogitsLoss()
  *   GNAN_LOSS_CROSS_ENTROPY (C >= 2, labels int64 [n]):  mean_i logsumexp(x_i) - x_i[t_i]          = nn.CrossEntropyLoss()
