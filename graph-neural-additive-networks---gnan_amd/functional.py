@@ -1597,15 +1597,17 @@ def loss_kind(loss_fn, outputs: torch.Tensor) -> Optional[int]:
 FUSED_LOSS = os.environ.get("GNAN_FUSED_LOSS", "1") != "0"
 
 
-def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, hits_sum):
+def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, hits_sum, out_loss=None, out_hits=None):
     x = _rows(outputs.detach())
     n_rows, C = x.shape
     n = int(labels.numel())
     lab = labels.detach().contiguous()
     lab = lab.float() if kind == _lib.LOSS_BCE_LOGITS else lab.long()
     idx = None if index is None else index.detach().long().contiguous()
-    loss = torch.empty((), dtype=torch.float32, device=x.device)
-    hits = torch.empty((), dtype=torch.int64, device=x.device) if want_hits else None
+    loss = torch.empty((), dtype=torch.float32, device=x.device) if out_loss is None else out_loss.view(())
+    hits = None
+    if want_hits:
+        hits = torch.empty((), dtype=torch.int64, device=x.device) if out_hits is None else out_hits.view(())
     grad = torch.empty((n_rows, C), dtype=torch.float32, device=x.device) if want_grad else None
     need = _lib.lib().gnan_loss_workspace_bytes(n)
     ws = torch.empty(need // 8, dtype=torch.float64, device=x.device) if need else None
@@ -1619,8 +1621,9 @@ def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, h
 
 class _LossStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum, unit_upstream):
-        loss, hits, grad = _loss_launch(outputs, labels, kind, index, want_hits, ctx.needs_input_grad[0], loss_sum, hits_sum)
+    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum, unit_upstream, out_loss, out_hits):
+        loss, hits, grad = _loss_launch(outputs, labels, kind, index, want_hits, ctx.needs_input_grad[0], loss_sum, hits_sum,
+                                        out_loss, out_hits)
         ctx.grad, ctx.unit_upstream = grad, unit_upstream
         if hits is not None:
             ctx.mark_non_differentiable(hits)
@@ -1629,17 +1632,19 @@ class _LossStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         grad, ctx.grad = ctx.grad, None
-        return (grad if ctx.unit_upstream else grad * g_loss), None, None, None, None, None, None, None
+        return (grad if ctx.unit_upstream else grad * g_loss), None, None, None, None, None, None, None, None, None
 
 
 def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Optional[torch.Tensor] = None,
               want_hits: bool = True, loss_sum: Optional[torch.Tensor] = None, hits_sum: Optional[torch.Tensor] = None,
-              unit_upstream: bool = False):
+              unit_upstream: bool = False, out_loss: Optional[torch.Tensor] = None, out_hits: Optional[torch.Tensor] = None):
     """``(loss, hits)`` of the rows ``index`` of ``outputs`` (all rows without it) by ``gnan_loss_step``: the mean loss as a
     0-d tensor that back-propagates into ``outputs`` (its gradient was formed in the same launch), the hit count as a 0-d
     int64 tensor (None unless ``want_hits``); ``loss_sum`` / ``hits_sum`` (0-d float32 device tensors) are added to in place.
     ``unit_upstream``: the caller promises to call ``backward()`` on this very loss (upstream gradient 1, as the epoch loops
-    do, trainer.py:66) — the stored gradient is then handed down as it is instead of being multiplied by it (a launch)."""
+    do, trainer.py:66) — the stored gradient is then handed down as it is instead of being multiplied by it (a launch).
+    ``out_loss`` / ``out_hits``: one-element float32 / int64 device tensors to write the results into (a caller that wants to
+    read several results with ONE device-to-host copy lays them out next to each other)."""
     _lib.require_device(outputs, labels)
     if labels.numel() == 0:
         raise ValueError("loss_step: no rows selected (the mean of an empty set)")
@@ -1650,7 +1655,11 @@ def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Opt
     for t in (loss_sum, hits_sum):
         if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.numel() != 1):
             raise ValueError("loss_step: the running totals are 0-d float32 device tensors")
-    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum, bool(unit_upstream))
+    if out_loss is not None and (out_loss.dtype != torch.float32 or out_loss.numel() != 1 or not out_loss.is_cuda):
+        raise ValueError("loss_step: out_loss is a one-element float32 device tensor")
+    if out_hits is not None and (out_hits.dtype != torch.int64 or out_hits.numel() != 1 or not out_hits.is_cuda):
+        raise ValueError("loss_step: out_hits is a one-element int64 device tensor")
+    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum, bool(unit_upstream), out_loss, out_hits)
     return got if want_hits else (got, None)
 
 

@@ -339,7 +339,7 @@ class GraphedStep:
         return optimizer is None or all("capturable" in g for g in optimizer.param_groups)
 
     def __init__(self, model, data, loss_of=None, optimizer=None, forward: Optional[Callable] = None, warmup: int = 0,
-                 prepared: Optional[PreparedOptimizer] = None):
+                 prepared: Optional[PreparedOptimizer] = None, guard: Optional[torch.Tensor] = None):
         """``warmup`` eager steps are run first — REAL steps (they update the parameters when an optimizer is given).  A
         capture needs the step to have run eagerly at least once (lazy initialisations, table sizes); ``harness`` passes
         0 because its first epochs already did.  ``prepared``: the optimizer's capturable mode if the caller switched it on
@@ -360,7 +360,10 @@ class GraphedStep:
         # captured look-up checks its own tables on the device (gnan_pwl_check_fit), the captured update is skipped by the
         # kernel when they outgrew the capture (torch's found_inf), and the flag is read AFTER the replay — next to the loss the
         # caller reads anyway.  Needs the flat update (the optimizer's own step takes no skip flag); evaluation steps always can.
-        self.guard = torch.zeros(1, dtype=torch.float32, device=next(model.parameters()).device) if GUARDED_REPLAY else None
+        # (``guard``: the caller's own zeroed float32 [1] — it then reads the flag itself, next to its other results, and
+        # tells :meth:`replay` through ``tripped``)
+        self.guard = (guard if guard is not None else
+                      torch.zeros(1, dtype=torch.float32, device=next(model.parameters()).device)) if GUARDED_REPLAY else None
 
         # (the guard is never reset: a step whose guard tripped is dropped by its replayer, and a fresh capture gets a fresh flag)
         one = torch.ones((), dtype=torch.float32, device=next(model.parameters()).device) if self.training else None
@@ -445,9 +448,11 @@ class GraphedStep:
             return True
         return self.training and _group_signature(self.optimizer) != self._groups
 
-    def replay(self):
+    def replay(self, tripped: Optional[Callable[[], bool]] = None):
         """Replay the captured step; returns ``(outputs, loss, extras)`` (static tensors), or None if the step must not be
-        replayed (see :meth:`stale`, :meth:`GraphedCallable.fits`) — the caller then runs it eagerly and captures anew."""
+        replayed (see :meth:`stale`, :meth:`GraphedCallable.fits`) — the caller then runs it eagerly and captures anew.
+        ``tripped``: called after the replay instead of reading the guard flag here (the caller reads it together with its
+        own results: one device-to-host copy instead of two)."""
         if self.graph is None or self.stale():
             return None
         guarded = self.guard is not None and bool(self.graph.builds)
@@ -458,7 +463,7 @@ class GraphedStep:
                 static.fill_(float(group["lr"]))
                 group["lr"] = static
         self.graph.replay()
-        if guarded and bool(self.guard.item()):
+        if guarded and (tripped() if tripped is not None else bool(self.guard.item())):
             # the tables of these weights outgrew the captured look-up: its outputs are not the model's, and the update was
             # skipped on the device; only the step counters moved
             if self.training:
