@@ -241,22 +241,39 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
     const int e = threadIdx.x + t * 256;
     lut_v[t] = e < p.D * Cr ? p.lut[e] : 0.f;
   }
-  for (int e = threadIdx.x; e < n * C; e += blockDim.x) {
-    const int j = e / C, c = e % C;
-    const float* src = p.part + static_cast<int64_t>(j) * C + c;
-    const int64_t step = static_cast<int64_t>(n) * C;
-    float s = 0.f;
-    int kk = 0;
-    for (; kk + 8 <= p.F; kk += 8) {
-      float v[8];
+  // node sums: every (feature, node, channel) term is fetched by a thread of its own — all loads in flight at once — into the
+  // (now free) weight area, then a thread per (node, channel) adds the features in order.  (A thread per (node, channel)
+  // walking its F terms itself left 30 of 256 threads with two rounds of loads: 2 us of a 20-us launch.)
+  {
+    const int nc = n * C;
+    const int per_chunk = kWeightFloats / nc;                     // features per pass (>= 9 at 64 nodes x 8 channels)
+    for (int e = threadIdx.x; e < nc; e += blockDim.x) s_S[e] = 0.f;
+    for (int k0 = 0; k0 < p.F; k0 += per_chunk) {
+      const int kn = p.F - k0 < per_chunk ? p.F - k0 : per_chunk;
+      __syncthreads();
+      for (int e0 = 0; e0 < kn * nc; e0 += 4 * 256) {
+        float v[4];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = src[(kk + t) * step];
+        for (int t = 0; t < 4; ++t) {
+          const int e = e0 + t * 256 + threadIdx.x;
+          v[t] = e < kn * nc ? p.part[static_cast<int64_t>(k0) * nc + e] : 0.f;
+        }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) s += v[t];         // features in order
+        for (int t = 0; t < 4; ++t) {
+          const int e = e0 + t * 256 + threadIdx.x;
+          if (e < kn * nc) weights[e] = v[t];
+        }
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < nc; e += blockDim.x) {
+        float sum = s_S[e];
+#pragma unroll 8
+        for (int kk = 0; kk < kn; ++kk) sum += weights[kk * nc + e];
+        s_S[e] = sum;
+      }
     }
-    for (; kk < p.F; ++kk) s += src[kk * step];
-    s_S[e] = s;
-    p.S[e] = s;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc; e += blockDim.x) p.S[e] = s_S[e];
   }
 #pragma unroll
   for (int t = 0; t < kMaxC; ++t) {
@@ -290,7 +307,8 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
     const int cr = Cr == 1 ? 0 : c;
     const uint8_t* codes = s_code + i * n;
     float acc = 0.f;
-    for (int j = 0; j < n; ++j) {
+#pragma unroll 8
+    for (int j = 0; j < n; ++j) {                      // (unrolled: the code -> weight reads of eight neighbours overlap)
       int d = codes[j];
       d = d < p.D - 1 ? d : p.D - 1;
       float w;
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
   __syncthreads();
   if (p.Ysum && static_cast<int>(threadIdx.x) < C) {
     float s = 0.f;
+#pragma unroll 8
     for (int i = 0; i < n; ++i) s += s_Y[i * C + threadIdx.x];
     p.Ysum[threadIdx.x] = s;
   }
@@ -415,6 +434,7 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     for (int e = threadIdx.x; e < n * C; e += 256) {
       const int j = e / C, c = e % C;
       float acc = 0.f;
+#pragma unroll 8
       for (int i = 0; i < n; ++i) {
         int d = s_code[i * n + j];
         d = d < p.D - 1 ? d : p.D - 1;
