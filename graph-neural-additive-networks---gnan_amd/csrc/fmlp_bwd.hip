@@ -58,20 +58,32 @@ __global__ __launch_bounds__(kWaves * kWave) void fmlp_bwd_kernel(const BwdParam
       [&](int64_t node, int c) { return p.grad[node * p.grad_stride + goff + c]; }, red);
 }
 
-// out[i] = sum over the splits of partial[s * stride + i], in split order
+// out[i] = sum over the splits of partial[s * stride + i], in split order — all six gradient tensors in ONE launch (a launch per
+// tensor was six launches behind a 15-us kernel on a few hundred inputs)
+struct ReduceOuts {
+  float* out[6];
+  int64_t off[6];       // start of the tensor inside a split's block; off[t + 1] - off[t] elements (off[6] = block size)
+  int64_t end;
+};
+
 __global__ __launch_bounds__(256) void fmlp_bwd_reduce_kernel(const float* __restrict__ partial, int64_t stride, int splits,
-                                                              float* __restrict__ out, int64_t count) {
+                                                              const ReduceOuts r) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= count) return;
+  if (i >= r.end) return;
   float a = partial[i];
   for (int s = 1; s < splits; ++s) a += partial[static_cast<int64_t>(s) * stride + i];
-  out[i] = a;
+  int t = 0;
+#pragma unroll
+  for (int u = 1; u < 6; ++u) t = i >= r.off[u] ? u : t;
+  if (r.out[t]) r.out[t][i - r.off[t]] = a;
 }
 
 // How many node ranges a feature's nodes are cut into: enough workgroups to fill the chip twice over, at least 256 nodes each.
 int node_splits(int64_t n, int F) {
   int64_t want = (512 + F - 1) / F;
-  const int64_t most = (n + 255) / 256;
+  // (at least 32 inputs each — 8 per wave: a single scalar MLP over a few hundred inputs, rho under the pre-rho normalisation
+  // of a small graph, used to be ONE workgroup walking 80 inputs per wave: 50 us)
+  const int64_t most = (n + 31) / 32;
   if (want > most) want = most;
   if (want > 1024) want = 1024;
   return want < 1 ? 1 : static_cast<int>(want);
@@ -158,20 +170,13 @@ extern "C" int gnan_fmlp_bwd(const gnan_fmlp_bwd_args* a, gnan_stream_t stream) 
   }
   if (rc || splits == 1) return rc;
   const float* ws = static_cast<const float*>(a->workspace);
-  auto reduce = [&](float* out, int64_t off, int64_t count) -> int {
-    if (out == nullptr || count == 0) return GNAN_OK;
-    hipLaunchKernelGGL(fmlp_bwd_reduce_kernel, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, st, ws + off, blk,
-                       splits, out, count);
-    return gnan::check_launch("fmlp_bwd_reduce_kernel");
-  };
-  if ((rc = reduce(a->d_w_first, 0, F * H))) return rc;
-  if ((rc = reduce(a->d_b_first, off_b1, F * H))) return rc;
-  if (a->L == 3) {
-    if ((rc = reduce(a->d_w_mid, off_w2, F * H * H))) return rc;
-    if ((rc = reduce(a->d_b_mid, off_b2, F * H))) return rc;
-  }
-  if ((rc = reduce(a->d_w_last, off_w3, F * C * H))) return rc;
-  return reduce(a->d_b_last, off_b3, F * C);
+  ReduceOuts r;
+  r.out[0] = a->d_w_first; r.out[1] = a->d_b_first; r.out[2] = a->L == 3 ? a->d_w_mid : nullptr;
+  r.out[3] = a->L == 3 ? a->d_b_mid : nullptr; r.out[4] = a->d_w_last; r.out[5] = a->d_b_last;
+  r.off[0] = 0; r.off[1] = off_b1; r.off[2] = off_w2; r.off[3] = off_b2; r.off[4] = off_w3; r.off[5] = off_b3;
+  r.end = blk;
+  hipLaunchKernelGGL(fmlp_bwd_reduce_kernel, dim3(static_cast<unsigned>((blk + 255) / 256)), dim3(256), 0, st, ws, blk, splits, r);
+  return gnan::check_launch("fmlp_bwd_reduce_kernel");
 }
 
 extern "C" size_t gnan_fmlp_bwd_workspace_bytes(const gnan_fmlp_bwd_args* a) {
