@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configuration (SURVEY.md section 8d): c4 = R-MAT 10M nodes / 100M edges, the headline "
+                         "(default); c5 = papers100M-shaped, bf16 operand rows; c3 = ogbn-arxiv-shaped forward+backward; "
+                         "c2 = Mutagenicity-shaped graph-level task (one small graph per forward)")
+    ap.add_argument("--graphs", type=int, default=4337, help="c2: number of graphs (Mutagenicity has 4337)")
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--edges", type=int, default=100_000_000)
     ap.add_argument("--scale", type=int, default=24)
@@ -70,7 +75,26 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="upper bound of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == "c5":                                  # papers100M-shaped: same generator, scale 27, bf16 operand rows
+        given = set(a.split("=")[0] for a in sys.argv[1:])
+        if "--scale" not in given:
+            args.scale = 27
+        if "--nodes" not in given:
+            args.nodes = 111_059_956
+        if "--edges" not in given:
+            args.edges = 1_615_685_872
+        if "--operand" not in given:
+            args.operand = "bf16"
+    if args.config == "c3":
+        given = set(a.split("=")[0] for a in sys.argv[1:])
+        if "--nodes" not in given:
+            args.nodes = 169_343
+        if "--edges" not in given:
+            args.edges = 1_166_243
+        if "--feat" not in given:
+            args.feat = 129
+    return args
 
 
 def spmm_algorithmic_bytes(g, W, W_out, elem=4):
@@ -96,6 +120,18 @@ def git_sha():
             return f.read().strip() or None
     except OSError:
         return None
+
+
+def cpu_model():
+    """Model string of the host CPU (SURVEY.md section 8d asks for it next to the core count)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def fmlp_flops(n, F, H, L, C):
@@ -173,7 +209,7 @@ def cpu_baseline(args, model, g, x, operand_full, out_gpu):
     est = t_f * n_tot / n_f + t_s * nnz_tot / nnz_s
     return {
         # cores: the most threads any leg used (the shape-function loop runs fastest on fewer: fmlp_cores)
-        "value": args.edges / est, "unit": "edges/s", "cores": max(th_f, ncpu), "kind": "port",
+        "value": args.edges / est, "unit": "edges/s", "cores": max(th_f, ncpu), "kind": "port", "cpu_model": cpu_model(),
         "sample": (f"oracle/gnan_oracle.py on the host ({ncpu} hardware threads): shape functions on the first {n_f} "
                    f"nodes with {th_f} threads ({t_f:.2f} s; calibrated nodes/s by threads: "
                    f"{ {k: round(v) for k, v in rates.items()} }) + torch.sparse_csr aggregation of the first {n_r} "
@@ -187,14 +223,357 @@ def cpu_baseline(args, model, g, x, operand_full, out_gpu):
     }
 
 
+def _redraw(model):
+    """O(1)-scale weights (the upstream init, xavier with gain 0.01, gives ~1e-14 outputs)."""
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 2:
+                torch.nn.init.xavier_normal_(p, gain=1.0)
+            else:
+                p.normal_(0.0, 0.5)
+
+
+class _Bag:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def to(self, device):
+        return self
+
+
+def _event_ms(fn, steps, warmup):
+    """Device time of ``fn`` per call: HIP events on torch's current stream (the stream every kernel of the library is
+    launched on), median and min over ``steps`` calls after ``warmup``."""
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def run_c3(args):
+    """BASELINE config 3: ogbn-arxiv-shaped TensorGNAN forward + backward on one GPU (SURVEY.md section 8d C3;
+    /root/reference datasets.py:273-291: N = 169 343, E = 1 166 243, 128 features + the ones column, num_classes = 1 as the
+    reference sets it; --out 40 = the data set's true class count).  Preferential-attachment edges (seed 0) + one self pair
+    per node, K = 1 hop codes, rest bucket on; models.TensorGNAN in its default (sum-first) order, fp32.
+    A step = forward + loss + backward of the drop-in module (eager autograd, gradients reset as trainer.py:66 does)."""
+    import gnan_amd  # noqa: F401
+    from gnan_amd import synthetic as syn
+    from gnan_amd.models import TensorGNAN
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
+    t_setup = time.perf_counter()
+    src, dst = syn.preferential_attachment_edges(N, E, seed=0, device=dev)
+    g = syn.hop1_csr(src, dst, N)
+    x = syn.block_features(N, F, 0, N, seed=1, device=dev)
+    torch.manual_seed(0)
+    model = TensorGNAN(F, C, L, hidden_channels=H, normalize_rho=True, rho_per_feature=False, device="cuda")
+    _redraw(model)
+    model = model.to(dev).eval()
+    data = _Bag(x=x, edge_index=None, gnan_graph=g)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    target = torch.randn(N, C, generator=gen, device=dev)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    marks_all = []
+
+    def fwd(record=False):
+        marks = {}
+        if record:
+            def mark(name):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks[name] = ev
+            model.stage_hook = mark
+        with torch.no_grad():
+            out = model.forward(data)
+        model.stage_hook = None
+        if record:
+            marks_all.append(marks)
+        return out
+
+    def fwd_bwd():
+        for p in model.parameters():
+            p.grad = None
+        out = model.forward(data)
+        loss = ((out - target) ** 2).mean()
+        loss.backward()
+        return out
+
+    for _ in range(args.warmup):
+        fwd()
+        fwd_bwd()
+    fwd_ms, fwd_min = _event_ms(lambda: fwd(True), args.steps, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = fwd_bwd()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fb_ms, fb_min = _event_ms(fwd_bwd, args.steps, 0)
+
+    stage_names = ["lut", "fmlp", "spmm"]
+    stages = {n: 0.0 for n in stage_names}
+    for m in marks_all:
+        prev = m["start"]
+        for n in stage_names:
+            if n in m:
+                stages[n] += prev.elapsed_time(m[n])
+                prev = m[n]
+    stages = {n: v / max(1, len(marks_all)) for n, v in stages.items()}
+    # dominant kernel of the forward: the shape-function look-up with the feature sum (x in, [N, C] out) — HBM-bound by
+    # bytes, latency-bound at this size (87 MB of x): SURVEY section 8d expects no meaningful fraction here
+    b_fmlp = N * F * 4 + N * C * 4
+    b_spmm = spmm_algorithmic_bytes(g, C, C)
+    result = {
+        "metric": "edges aggregated/sec, TensorGNAN forward+backward", "value": E / (elapsed / args.steps), "unit": "edges/s",
+        "n_gpus": 1, "ranks_seen": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c3_arxiv_shaped_pa_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_sum_first_K1", "nodes": N, "edges": E,
+                   "stored_pairs": g.nnz, "step": "forward + MSE loss + backward of models.TensorGNAN (eager autograd)"},
+        "fwd_ms": fwd_ms, "fwd_ms_min": fwd_min, "fwd_bwd_ms": fb_ms, "fwd_bwd_ms_min": fb_min,
+        "fwd_edges_per_s": E / (fwd_ms / 1e3),
+        "roofline": {"bound": "hbm", "kernel": "fpwl_fast_kernel (shape-function look-up, feature sum)",
+                     "achieved": b_fmlp / (stages["fmlp"] / 1e3) / 1e9 if stages["fmlp"] > 0 else 0.0, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": b_fmlp / (stages["fmlp"] / 1e3) / 1e9 / HBM_PEAK_GBPS if stages["fmlp"] > 0 else 0.0,
+                     "traffic": None, "algorithmic_bytes_per_launch": b_fmlp, "avg_launch_ms": stages["fmlp"],
+                     "note": "stage time incl. the table build; 87 MB of x: latency-bound, not bandwidth-bound"},
+        "spmm_roofline": {"bound": "hbm", "kernel": "spmm_kernel<1,...> (narrow rows)", "algorithmic_bytes_per_launch": b_spmm,
+                          "avg_launch_ms": stages["spmm"],
+                          "achieved": b_spmm / (stages["spmm"] / 1e3) / 1e9 if stages["spmm"] > 0 else 0.0,
+                          "frac": b_spmm / (stages["spmm"] / 1e3) / 1e9 / HBM_PEAK_GBPS if stages["spmm"] > 0 else 0.0},
+        "stages_ms": stages, "seeds": {"graph": 0, "features": 1, "weights": 0, "target": 2}, "git_sha": git_sha(),
+        "timed_call": "gnan_amd.models.TensorGNAN.forward(data) + loss.backward()", "setup_s": t_setup,
+        "checksum": float(out.double().sum()), "backward": True,
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_c3(args, model, g, x, fwd())
+    print(json.dumps(result), flush=True)
+
+
+def cpu_baseline_c3(args, model, g, x, out_gpu):
+    """The oracle's forward on a bounded sample: the per-feature Python loop of nn.Linear calls (GNAN.py:58-62) on the first
+    rows, torch.sparse_csr aggregation of all rows; and the parity of the GPU's output on sampled rows (float64)."""
+    from oracle import gnan_oracle as O
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ncpu = os.cpu_count()
+    torch.set_num_threads(min(ncpu, 16))
+    N, F = x.shape
+    n_f = min(N, 20000)
+    xh = x.cpu()
+    O.feature_mlps(xh[:256], sd)
+    t0 = time.perf_counter()
+    O.feature_mlps(xh[:n_f], sd)
+    t_f = time.perf_counter() - t0
+    # parity: the whole forward in float64 on the rows of a node sample (their neighbours' shape functions included)
+    p64 = {k: v.double() for k, v in sd.items()}
+    rowptr = g.rowptr.cpu().long().numpy()
+    col, code, cnt = g.col.cpu().numpy(), g.code.cpu().numpy(), g.cnt.cpu().long().numpy()
+    S64 = torch.cat([O.feature_mlps(xh[i:i + 8192].double(), p64).sum(1) for i in range(0, N, 8192)])      # [N, C] float64
+    lut64 = O.rho_lut(p64, g.n_codes, dtype=torch.float64)
+    torch.set_num_threads(ncpu)
+    t0 = time.perf_counter()
+    y32 = O.spmm_csr_sparse(rowptr, col, code, S64.float(), lut64.float(), cnt)
+    t_s = time.perf_counter() - t0
+    y64 = O.spmm_csr_sparse(rowptr, col, code, S64, lut64, cnt)
+    parity = float((out_gpu.double().cpu() - y64).abs().max() / y64.abs().max())
+    est = t_f * N / n_f + t_s
+    return {"value": args.edges / est, "unit": "edges/s", "cores": ncpu, "kind": "port", "cpu_model": cpu_model(),
+            "sample": (f"oracle/gnan_oracle.py forward only: shape functions on the first {n_f} of {N} nodes with "
+                       f"{min(ncpu, 16)} threads ({t_f:.2f} s, scaled) + torch.sparse_csr aggregation of all rows with {ncpu} "
+                       f"threads ({t_s:.2f} s)"),
+            "parity_max_rel_err": parity, "parity_rows": N, "cpu_f32_vs_f64_rel_err":
+            float((y32.double() - y64).abs().max() / y64.abs().max())}
+
+
+def run_c2(args, rank=0, world=1):
+    """BASELINE config 2: Mutagenicity-shaped graph-level task, one small graph per forward (trainer.py:23-86 feeds
+    batch_size = 1; SURVEY.md section 8d C2: 4337 graphs, N_g ~ clip(round(LogNormal(3.3, 0.45)), 4, 417), F = 14 + 1, C = 1,
+    models.TensorGNAN(is_graph_task=True)), dense inputs as pre_process_datasets.py:104-142 emits them, fp32.
+    A step = one evaluation pass over all graphs (forward of every graph).  An 'edge' is one (i, j) pair of a graph's dense
+    N_g x N_g aggregation.  More than one rank: replicas only — the graphs are dealt out round-robin, no collective."""
+    import gnan_amd  # noqa: F401
+    from gnan_amd import HopGraph
+    from gnan_amd import synthetic as syn
+    from gnan_amd.models import TensorGNAN
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    t_setup = time.perf_counter()
+    graphs, pairs, host = [], 0, []
+    for i, (ei, x, y) in enumerate(syn.mutagenicity_shaped_graphs(args.graphs, seed=0)):
+        if i % world != rank:
+            continue
+        n = x.shape[0]
+        hg = HopGraph.from_edge_index(torch.as_tensor(ei).to(dev), n)           # all-pairs BFS on the device (csrc/bfs.hip)
+        code = hg.code.long()
+        nd = torch.where(code == 255, torch.zeros((), device=dev), 1.0 / (1.0 + code.float()))
+        norm = torch.gather(hg.cnt.float(), 1, code.clamp_max(hg.n_codes - 1))
+        graphs.append(_Bag(x=x.to(dev), edge_index=None, node_distances=nd, normalization_matrix=norm,
+                           y=torch.tensor([[y]], device=dev)))
+        pairs += n * n
+        if len(host) < 64:
+            host.append((ei, x, n))
+    torch.manual_seed(0)
+    model = TensorGNAN(15, 1, args.layers, hidden_channels=args.hidden, is_graph_task=True, readout_n_layers=0, device="cuda")
+    _redraw(model)
+    model = model.to(dev).eval()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def epoch():
+        with torch.no_grad():
+            return [model.forward(d) for d in graphs]
+
+    for _ in range(args.warmup):
+        epoch()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = epoch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    total_pairs = pairs
+    if world > 1:
+        t = torch.tensor([elapsed, float(pairs)], device=dev, dtype=torch.float64)
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_pairs = float(tm[0]), int(t[1])
+    if rank != 0:
+        return
+    # replayed per shape through the harness (what a training run does after every epoch: trainer.py:89-154)
+    from gnan_amd import harness
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    replay_ms = None
+    try:
+        for _ in range(3):
+            harness.test_epoch(model, graphs, loss_fn, dev, classify=True, val_mask=True, is_graph_task=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        harness.test_epoch(model, graphs, loss_fn, dev, classify=True, val_mask=True, is_graph_task=True)
+        torch.cuda.synchronize()
+        replay_ms = (time.perf_counter() - t0) / len(graphs) * 1e3
+    except Exception as e:                                   # the replayed pass is an extra figure, not the timed call
+        replay_ms = f"failed: {type(e).__name__}: {e}"
+    ms = elapsed / args.steps * 1e3
+    # the forward of a 30-node graph is one launch (small_graph_kernel) of ~20 us: a chain of latencies.  Algorithmic bytes
+    # per graph: N_g^2 hop codes (1 B) + N_g x D counts + x + the weights (F MLPs of 4.3k floats)
+    n_params = sum(p.numel() for p in model.parameters())
+    b_alg = sum(d.x.shape[0] ** 2 + d.x.numel() * 4 for d in graphs) + len(graphs) * n_params * 4
+    result = {
+        "metric": "edges aggregated/sec, TensorGNAN forward (graph-level, one graph per forward)",
+        "value": total_pairs / (elapsed / args.steps), "unit": "edges/s", "n_gpus": world, "ranks_seen": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c2_mutagenicity_shaped_{args.graphs}graphs_F15_H{args.hidden}_L{args.layers}_C1_dense",
+                   "graphs": args.graphs, "pairs": total_pairs, "partition": f"replicas x{world}", "exchange": "none",
+                   "step": "one evaluation pass: models.TensorGNAN.forward(data) per graph, batch_size = 1"},
+        "ms_per_graph": ms / max(1, len(graphs)), "graphs_per_s": args.graphs / (elapsed / args.steps),
+        "replayed_eval_ms_per_graph": replay_ms,
+        "roofline": {"bound": "hbm", "kernel": "small_graph_kernel (whole forward of a graph in one launch)",
+                     "achieved": b_alg / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": b_alg / max(1, len(graphs)), "avg_launch_ms": ms / max(1, len(graphs)),
+                     "note": "latency-bound by construction (one ~30-node graph per launch, host-issued); bytes are not the limit"},
+        "seeds": {"graphs": 0, "weights": 0}, "git_sha": git_sha(), "setup_s": t_setup,
+        "timed_call": "gnan_amd.models.TensorGNAN.forward(data), eager, per graph",
+        "checksum": float(sum(float(o.double().sum()) for o in outs)),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import gnan_oracle as O
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        p64 = {k: v.double() for k, v in sd.items()}
+        torch.set_num_threads(min(os.cpu_count(), 16))
+        t_cpu, cpu_pairs = 0.0, 0
+        got, ref32, truth = [], [], []
+        for k, (ei, x, n) in enumerate(host):
+            nd, norm = O.pre_process_dense(ei, n)
+            t0 = time.perf_counter()
+            r32 = O.tensor_gnan_forward_models(x, nd, norm, sd, True, True, 0)
+            t_cpu += time.perf_counter() - t0
+            cpu_pairs += n * n
+            ref32.append(r32.double().reshape(-1))
+            truth.append(O.tensor_gnan_forward_models(x.double(), nd.double(), norm.double(), p64, True, True, 0).reshape(-1))
+            got.append(outs[k].double().cpu().reshape(-1))
+        got, ref32, truth = torch.cat(got), torch.cat(ref32), torch.cat(truth)
+        # a graph's output is ONE number (a sum over nodes and features that may cancel): the sample's outputs are compared
+        # as one vector, max |y - y64| / max |y64| (SURVEY section 8c), next to the same figure of the fp32 oracle
+        worst = float((got - truth).abs().max() / truth.abs().max())
+        worst32 = float((ref32 - truth).abs().max() / truth.abs().max())
+        single = float(((got - truth).abs() / truth.abs().clamp_min(1e-30)).max())
+        single32 = float(((ref32 - truth).abs() / truth.abs().clamp_min(1e-30)).max())
+        result["cpu_baseline"] = {"value": cpu_pairs / t_cpu, "unit": "edges/s", "cores": min(os.cpu_count(), 16), "kind": "port",
+                                  "cpu_model": cpu_model(),
+                                  "sample": f"oracle/gnan_oracle.py (dense restatement of models.py:358-384) on the first "
+                                            f"{len(host)} graphs ({cpu_pairs} pairs, {t_cpu:.2f} s), inputs from the oracle's "
+                                            f"pre_process_dense",
+                                  "parity_max_rel_err": worst, "cpu_f32_vs_f64_rel_err": worst32, "parity_graphs": len(host),
+                                  "worst_single_graph_rel_err": single, "cpu_f32_worst_single_graph_rel_err": single32}
+    print(json.dumps(result), flush=True)
+
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks ourselves.
+
+    The parent makes no GPU call (``torch.cuda.device_count()`` does not initialise the device on this image); it runs
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py …``
+    as a CHILD process (never an exec), forwards its output — rank 0 prints the one JSON line — and returns its exit code.
+    Fewer visible GPUs than ranks is an error unless ``--same-device`` (dry run, all ranks on cuda:0) was asked for: the
+    bench never falls through to a one-rank run labelled otherwise."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.same_device:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to time fewer ranks than asked "
+              f"(dry run of the multi-rank path on one GPU: --same-device --backend gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    if args.config == "c3":
+        if world > 1:
+            raise SystemExit("config c3 (169k nodes) is a one-GPU configuration: run it with --gpus 1")
+        return run_c3(args)
+    if args.config == "c2":
+        if world > 1:
+            dist.init_process_group("gloo" if args.backend == "gloo" else "nccl",
+                                    **({} if args.backend == "gloo" else {"device_id": torch.device("cuda", local_rank)}))
+        run_c2(args, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -204,6 +583,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
@@ -384,7 +765,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         result = {
             "metric": "edges aggregated/sec, TensorGNAN forward", "value": E / (elapsed / args.steps),
-            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "unit": "edges/s", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.operand == "f32" else "bf16 operand storage, f32 accumulate",
             "data": "synthetic",
@@ -407,6 +788,8 @@ def main():
             "timed_call": "gnan_amd.models.TensorGNAN.forward(data)" if use_module else f"gnan_amd.distributed ({partition})",
             "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": checksum,
             "operand_rows_rank0": int(x.shape[0]),
+            # bf16 operand rows are an inference format: the library has no backward through them
+            "backward": False if args.operand == "bf16" else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():

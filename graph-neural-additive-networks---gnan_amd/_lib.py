@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -46,6 +46,14 @@ class FpwlArgs(C.Structure):
         ("sum_features", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64),
         ("out_dtype", C.c_int32), ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
         ("total_rows", C.c_int64), ("piece_out", C.c_void_p), ("piece_in", C.c_void_p), ("flags", C.c_int32),
+        ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32), ("index_max_fast", C.c_int32),
+    ]
+
+
+class FpwlIndexArgs(C.Structure):
+    _fields_ = [
+        ("off", C.c_void_p), ("anchor", C.c_void_p), ("F", C.c_int32), ("buckets", C.c_int32), ("max_fast", C.c_int32),
+        ("range", C.c_void_p), ("table", C.c_void_p), ("key", C.c_void_p), ("stats", C.c_void_p),
     ]
 
 
@@ -219,6 +227,8 @@ SYMBOLS = {
     "gnan_rho_row_lut": (C.c_int, [C.POINTER(RhoLutArgs), C.c_void_p]),
     "gnan_fpwl_total_workspace_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),
     "gnan_fpwl_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p]),
+    "gnan_fpwl_index_build": (C.c_int, [C.POINTER(FpwlIndexArgs), C.c_void_p]),
+    "gnan_feature_range": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnan_fpwl_moments": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gnan_fpwl_moments_fixed": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),

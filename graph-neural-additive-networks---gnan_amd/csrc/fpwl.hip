@@ -1366,6 +1366,11 @@ extern "C" int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* gra
   return moments_common(a, grad, grad_stride, nullptr, scales, moments, stream);
 }
 
+// csrc/fpwl_index.hip: the direct-index look-up (one channel, whole 16-feature groups, aligned rows)
+bool gnan_index_applies(const gnan_fpwl_args* a);
+int gnan_index_nodes_per_block(const gnan_fpwl_args* a);
+int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st);
+
 extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   if (int rc = common_checks(a)) return rc;
   if (a->n == 0) return GNAN_OK;
@@ -1373,6 +1378,24 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   const int fg = a->features_per_group;
   const int64_t ow = a->sum_features ? a->C : static_cast<int64_t>(a->F) * a->C;
   GNAN_REQUIRE(a->out_stride >= ow, "fpwl: out row stride smaller than the output width");
+  GNAN_REQUIRE(a->out_dtype == GNAN_F32 || a->out_dtype == GNAN_BF16, "fpwl: unknown out_dtype");
+  if (fg == 16 && !(a->total && a->sum_features) && gnan_index_applies(a)) {
+    hipStream_t ist = static_cast<hipStream_t>(stream);
+    double* partial = nullptr;
+    const int64_t ibx = (a->n + gnan_index_nodes_per_block(a) - 1) / gnan_index_nodes_per_block(a);
+    if (a->total) {
+      const size_t need = static_cast<size_t>(ibx) * a->F * sizeof(double);
+      if (a->total_workspace == nullptr || a->total_workspace_bytes < need)
+        return gnan::fail(GNAN_ERR_WORKSPACE, "fpwl: total workspace %zu B < required %zu B", a->total_workspace_bytes, need);
+      partial = static_cast<double*>(a->total_workspace);
+    }
+    if (int rc = gnan_index_fwd(a, partial, ist)) return rc;
+    if (partial) {
+      hipLaunchKernelGGL(fpwl_total_kernel, dim3(a->F), dim3(256), 0, ist, partial, static_cast<int>(ibx), a->F, a->total);
+      return gnan::check_launch("fpwl_total_kernel");
+    }
+    return GNAN_OK;
+  }
   const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(table_stride(a->C))) * sizeof(float);
   Params p = base_params(a);
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
@@ -1416,6 +1439,10 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
 extern "C" size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a) {
   if (!a || a->n <= 0) return 0;
   const Params p = base_params(a);
-  const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+  int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+  if (a->features_per_group == 16 && gnan_index_applies(a)) {       // whichever kernel serves the call: room for both
+    const int64_t ibx = (a->n + gnan_index_nodes_per_block(a) - 1) / gnan_index_nodes_per_block(a);
+    if (ibx > bx) bx = ibx;
+  }
   return static_cast<size_t>(bx) * a->F * sizeof(double);
 }

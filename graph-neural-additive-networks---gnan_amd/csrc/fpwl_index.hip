@@ -1,0 +1,519 @@
+// Shape functions by DIRECT-INDEX table look-up (gfx950): the piece of x is found by arithmetic, not by a search.
+//
+// fpwl_fast_kernel (csrc/fpwl.hip) walks an 8-level search tree per look-up: ~10 dependent LDS round trips and ~38 vector
+// instructions, which — not HBM — set its time (SQ counters, profiles/r04_sq_fpwl.csv).  Here every feature gets a
+// uniform grid of B buckets over the range the data actually takes (`range`, one column min / max pass per feature
+// matrix: a HINT — any x is looked up exactly, see below), and a table entry per bucket:
+//     key(x)   = (int) med3(fma(x, ks, ko), 0, B - 1)                 monotone non-decreasing in x
+//     entry[k] = 4 * #{ breakpoints a_j : key(a_j) < k }  |  (more than KF breakpoints have key == k ? 1 : 0)
+// key is monotone, so every breakpoint with key(a_j) < key(x) is <= x and every one with key(a_j) > key(x) is > x:
+// the piece of x is entry[key(x)] / 4 plus the number of the (at most KF) breakpoints INSIDE its bucket that are <= x —
+// found by comparing x with the next KF anchors of the sorted array (one ds_read2_b32 for KF = 1).  The builder computes
+// key(a_j) with the very same instructions, so the look-up is exact for every float x whatever the range hint was; a
+// bucket holding more than KF breakpoints (typically the two end buckets, which take everything outside the hinted
+// range) is flagged and its lanes take a plain binary search over the sorted anchors (rare; wave-level branch).
+// Per look-up: 3 dependent LDS reads (entry, anchors, (val, slope)) and ~13 vector instructions; same formula
+// val + slope * (x - anchor) on the same piece as fpwl_fast_kernel, hence bit-identical results.
+//
+// Mapping as fpwl_fast_kernel: workgroup = (node block, 16-feature group), thread = (node, 4 features), one 16-B load
+// of x and one 16-B store per node and thread; linear workgroup ids are mapped so that the groups of a node block run on
+// the same XCD (they share the block's 128-B lines of x in that L2); column sums / feature sum / kept pieces in the epilogue.
+#include "common.hpp"
+
+#include <cstdint>
+#include <type_traits>
+
+namespace {
+
+constexpr int FG = 16, FPT = 4, TPN = FG / FPT;
+
+struct IndexParams {
+  const float* x;
+  int64_t n, x_stride;
+  int F;
+  const int32_t* off;
+  const float* anchor;
+  const float* val;
+  const float* slope;
+  const uint16_t* table;   // [F][B]
+  const float* key;        // [F][2]: ks, ko
+  int n_groups, nodes_per_block;
+  int tot_cap;             // pieces the LDS image holds per feature group
+  int step0;               // slow path: largest power of two <= max breakpoints per feature
+  int sum_features;
+  float* out;
+  int64_t out_stride;
+  double* col_partial;
+  int64_t total_rows;
+  uint8_t* piece_out;
+};
+
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x2_t lds_cfloat2;
+__device__ __forceinline__ float lds_f32(int addr) { return *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(static_cast<unsigned>(addr))); }
+__device__ __forceinline__ int lds_u16(int addr) { return *reinterpret_cast<lds_cu16*>(static_cast<uintptr_t>(static_cast<unsigned>(addr))); }
+__device__ __forceinline__ float2 lds_f32x2(int addr) {
+  const f32x2_t v = *reinterpret_cast<lds_cfloat2*>(static_cast<uintptr_t>(static_cast<unsigned>(addr)));
+  return make_float2(v.x, v.y);
+}
+
+__device__ __forceinline__ unsigned bf16_bits(float f) {      // round-to-nearest-even, as torch.bfloat16
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// The bucket of x: ONE definition for the look-up and for the builder (which buckets the anchors with it).
+__device__ __forceinline__ int bucket_of(float x, float ks, float ko, float top) {
+  return static_cast<int>(__builtin_amdgcn_fmed3f(__fmaf_rn(x, ks, ko), 0.0f, top));   // NaN -> 0 (med3 = min3 on NaN)
+}
+
+// ---------------------------------------------------------------------------------------------
+// column minima / maxima of the feature matrix: the range hint.  Order-preserving integer images of the floats and
+// integer atomics; NaNs are skipped, an all-NaN / empty column ends as (+inf, -inf) and the builder copes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ordered(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float unordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ __launch_bounds__(256) void range_init_kernel(int* __restrict__ lohi, int F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < F) { lohi[2 * i] = ordered(INFINITY); lohi[2 * i + 1] = ordered(-INFINITY); }
+}
+
+__global__ __launch_bounds__(256) void range_kernel(const float* __restrict__ x, int64_t n, int64_t stride, int F,
+                                                    int64_t rows_per_block, int* __restrict__ lohi) {
+  // thread = column (blockIdx.y covers columns in chunks of 256), rows of this block in order: coalesced along the row
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  if (c >= F) return;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float v = x[r * stride + c];
+    lo = fminf(lo, v);                       // fminf / fmaxf drop NaN operands
+    hi = fmaxf(hi, v);
+  }
+  atomicMin(&lohi[2 * c], ordered(lo));
+  atomicMax(&lohi[2 * c + 1], ordered(hi));
+}
+
+__global__ __launch_bounds__(256) void range_finish_kernel(const int* __restrict__ lohi, int F, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 2 * F) out[i] = unordered(lohi[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the bucket tables of all features: one workgroup per feature
+// ---------------------------------------------------------------------------------------------
+template <int LOGB>
+__global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restrict__ off, const float* __restrict__ anchor,
+                                                          const float* __restrict__ range, int max_fast,
+                                                          uint16_t* __restrict__ table, float* __restrict__ key,
+                                                          int32_t* __restrict__ stats) {
+  constexpr int B = 1 << LOGB;
+  __shared__ int cnt[B];
+  __shared__ int part[256];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  float lo = range[2 * f], hi = range[2 * f + 1];
+  if (!(lo <= hi) || !(fabsf(lo) < 3.0e38f) || !(fabsf(hi) < 3.0e38f)) { lo = 0.f; hi = 0.f; }     // empty / non-finite hint
+  // buckets 1 .. B-2 span [lo, hi]: key(lo) = 1.5, key(hi) = B - 1.5.  The span is at least 2^-10 of the larger magnitude:
+  // |lo * ks| then stays below 2^20 * B / 1024, so ko's rounding moves a key by < 0.1 bucket — x = lo never slips into
+  // the end bucket — and a constant column (the ones column of pre_process_datasets.py:127) still gets a bucket of its own
+  const float span = fmaxf(hi - lo, fmaxf(fmaxf(fabsf(lo), fabsf(hi)) * 0.0009765625f, 1e-30f));
+  const float ks = static_cast<float>(B - 3) / span;
+  const float ko = __fmaf_rn(-lo, ks, 1.5f);
+  const float top = static_cast<float>(B - 1);
+  for (int i = tid; i < B; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const int base = off[f], pn = off[f + 1] - base - 1;          // breakpoints are entries 1 .. pn (entry 0: anchor of piece 0)
+  for (int j = 1 + tid; j <= pn; j += 256) atomicAdd(&cnt[bucket_of(anchor[base + j], ks, ko, top)], 1);
+  __syncthreads();
+  // exclusive prefix over the B buckets: thread t owns buckets [t * B / 256, (t + 1) * B / 256)
+  constexpr int PER = B / 256 > 0 ? B / 256 : 1;
+  int s = 0;
+  if (tid * PER < B)
+    for (int i = 0; i < PER; ++i) s += cnt[tid * PER + i];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int flagged = 0;
+  if (tid * PER < B) {
+    int run = part[tid] - s;
+    for (int i = 0; i < PER; ++i) {
+      const int k = tid * PER + i, c = cnt[k];
+      const int slow = c > max_fast;
+      table[static_cast<int64_t>(f) * B + k] = static_cast<uint16_t>(run * 4 | slow);
+      if (slow && k > 0 && k < B - 1) ++flagged;
+      run += c;
+    }
+  }
+  if (tid == 0) { key[2 * f] = ks; key[2 * f + 1] = ko; }
+  if (stats) {                                  // flagged buckets inside the hinted range: the fast path's health
+    __syncthreads();
+    part[tid] = flagged;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) part[tid] += part[tid + st];
+      __syncthreads();
+    }
+    if (tid == 0) stats[f] = part[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the look-up
+// LDS image of a feature group: [FG][B] uint16 entries | anchors, feature f's run at s_off[f] + f * KF (KF +inf behind
+// every feature: the correction reads never see the next feature's anchors) | [tot] (val, slope) pairs | s_off[FG + 1]
+// ---------------------------------------------------------------------------------------------
+template <bool SUM, bool OUT16, int KF, int LOGB, int BS>
+__global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
+  static_assert(KF == 1 || KF == 3, "anchors read per look-up: 2 or 4");
+  constexpr int B = 1 << LOGB, NODES = BS / TPN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)smem));
+  constexpr int kTableBytes = FG * B * 2;
+  const int a_words = (p.tot_cap + FG * KF + 1) & ~1;            // even: the (val, slope) pairs stay 8-byte aligned
+  float* an_l = smem + kTableBytes / 4;
+  float2* vs_l = reinterpret_cast<float2*>(an_l + a_words);
+  int* s_off = reinterpret_cast<int*>(vs_l + p.tot_cap);
+  const int a_base = static_cast<int>(lds_base) + kTableBytes;
+  const int vs_base = a_base + 4 * a_words;
+  const int tid = threadIdx.x;
+  const int q = tid % TPN;
+  const int nl = tid / TPN;
+  int64_t nb = blockIdx.x;
+  int g_first = 0;
+  if (!SUM) {                                       // (id % 8) = XCD, groups of a node block adjacent inside it
+    const int64_t id = blockIdx.x;
+    g_first = static_cast<int>((id >> 3) % p.n_groups);
+    nb = ((id >> 3) / p.n_groups) * 8 + (id & 7);
+  }
+  const int64_t n_lo = nb * p.nodes_per_block;
+  if (n_lo >= p.n) return;
+  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
+  const int g_lo = SUM ? 0 : g_first;
+  const int g_hi = SUM ? p.n_groups : g_lo + 1;
+  const float top = static_cast<float>(B - 1);
+
+  for (int g = g_lo; g < g_hi; ++g) {
+    const int k0 = g * FG;
+    const int base = p.off[k0];
+    const int tot = p.off[k0 + FG] - base;
+    __syncthreads();                                // previous group's look-ups are done with the LDS image
+    if (tid <= FG) s_off[tid] = p.off[k0 + tid] - base;
+    {                                               // bucket entries of the group: one contiguous run, 16 bytes per lane
+      const uint4* src = reinterpret_cast<const uint4*>(p.table + static_cast<int64_t>(k0) * B);
+      uint4* dst = reinterpret_cast<uint4*>(smem);
+      for (int i = tid; i < kTableBytes / 16; i += BS) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < tot + FG * KF; i += BS) an_l[i] = INFINITY;
+    __syncthreads();
+    for (int i = tid; i < tot; i += BS) {
+      // feature of global piece i: the largest f with s_off[f] <= i (16 features: a 4-step search on the LDS offsets)
+      int f = 0;
+#pragma unroll
+      for (int st = 8; st > 0; st >>= 1) f += (s_off[f + st] <= i) ? st : 0;
+      an_l[i + f * KF] = p.anchor[base + i];
+      vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
+    }
+    __syncthreads();
+
+    float ks[FPT], ko[FPT];
+    int tb, a0[FPT], cvs[FPT];
+    tb = static_cast<int>(lds_base) + q * (FPT * B * 2);
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const int fg = q * FPT + f;
+      ks[f] = p.key[2 * (k0 + fg)];
+      ko[f] = p.key[2 * (k0 + fg) + 1];
+      a0[f] = a_base + 4 * (s_off[fg] + fg * KF);              // LDS byte address of the feature's anchor 0
+      cvs[f] = vs_base - 2 * a_base - 8 * fg * KF;             // (val, slope) address = 2 * anchor address + cvs
+    }
+
+    float ps[FPT] = {0.f, 0.f, 0.f, 0.f};           // column sums of the output (per-feature mode)
+    auto look_up = [&](const int64_t n, const float4 t) {
+      const float xv[FPT] = {t.x, t.y, t.z, t.w};
+      int e[FPT];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const int k = bucket_of(xv[f], ks[f], ko[f], top);
+        e[f] = lds_u16(tb + 2 * k + f * (B * 2));
+      }
+      int pa[FPT];                                  // LDS byte address of the piece's anchor
+      float an[FPT];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const int a = a0[f] + e[f];                 // (a flagged lane's odd address is never used)
+        const float A0 = lds_f32(a), A1 = lds_f32(a + 4);
+        int adv = xv[f] >= A1 ? 4 : 0;
+        float av = xv[f] >= A1 ? A1 : A0;
+        if constexpr (KF == 3) {
+          const float A2 = lds_f32(a + 8), A3 = lds_f32(a + 12);
+          adv += xv[f] >= A2 ? 4 : 0;
+          av = xv[f] >= A2 ? A2 : av;
+          adv += xv[f] >= A3 ? 4 : 0;
+          av = xv[f] >= A3 ? A3 : av;
+        }
+        pa[f] = a + adv;
+        an[f] = av;
+      }
+      if ((e[0] | e[1] | e[2] | e[3]) & 1) {        // some bucket holds more breakpoints than the fast path compares: search
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+          if (e[f] & 1) {
+            const int fg = q * FPT + f;
+            const float* A = an_l + s_off[fg] + fg * KF;
+            const int pn = s_off[fg + 1] - s_off[fg] - 1;
+            int idx = 0;
+            for (int step = p.step0; step > 0; step >>= 1) {
+              const int j = idx + step;
+              const int jj = j <= pn ? j : 0;
+              idx = (j <= pn && A[jj] <= xv[f]) ? j : idx;
+            }
+            pa[f] = a0[f] + 4 * idx;
+            an[f] = A[idx];
+          }
+        }
+      }
+      float y[FPT];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const float2 vs = lds_f32x2(2 * pa[f] + cvs[f]);
+        y[f] = fmaf(vs.y, xv[f] - an[f], vs.x);
+      }
+      if constexpr (SUM) {
+        if (p.piece_out) {                          // (uniform) keep the pieces for the backward pass, group-major
+          unsigned packed = 0u;
+#pragma unroll
+          for (int f = 0; f < FPT; ++f) packed |= static_cast<unsigned>((pa[f] - a0[f]) >> 2) << (8 * f);
+          *reinterpret_cast<unsigned*>(p.piece_out + (static_cast<int64_t>(g) * p.n + n) * FG + q * FPT) = packed;
+        }
+        float acc = ((y[0] + y[1]) + y[2]) + y[3];          // fpwl_fast_kernel's association: bit-identical sums
+#pragma unroll
+        for (int o = 1; o < TPN; o <<= 1) acc += __shfl_xor(acc, o);
+        if (q == 0) {
+          float* o = p.out + n * p.out_stride;
+          o[0] = g == 0 ? acc : o[0] + acc;
+        }
+      } else {
+        float4 r = make_float4(y[0], y[1], y[2], y[3]);
+        if constexpr (OUT16) {
+          const unsigned b0 = bf16_bits(r.x), b1 = bf16_bits(r.y), b2 = bf16_bits(r.z), b3 = bf16_bits(r.w);
+          uint16_t* o16 = reinterpret_cast<uint16_t*>(p.out) + n * p.out_stride + (k0 + q * FPT);
+          *reinterpret_cast<uint2*>(o16) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+          r = make_float4(__uint_as_float(b0 << 16), __uint_as_float(b1 << 16), __uint_as_float(b2 << 16),
+                          __uint_as_float(b3 << 16));
+        } else {
+          *reinterpret_cast<float4*>(p.out + n * p.out_stride + k0 + q * FPT) = r;
+        }
+        if (n < p.total_rows) { ps[0] += r.x; ps[1] += r.y; ps[2] += r.z; ps[3] += r.w; }
+      }
+    };
+    // U nodes per thread and round, the x rows of the NEXT round requested before this round's look-ups start: a look-up
+    // is ~16 vector instructions and 3 LDS round trips, so without loads in flight across rounds a wave would spend its
+    // time waiting for one 16-byte load at a time (16 waves per CU x 1 KB = 4 MB in flight chip-wide: < 3 TB/s)
+    constexpr int U = 2;
+    // (unconditional loads from a clamped address: a guarded load would hide the number of loads in flight from the
+    //  compiler, which then waits for ALL of them — the prefetch included — before the first look-up)
+    const float* xq = p.x + k0 + q * FPT;
+    const float* xlast = xq + (n_hi - 1) * p.x_stride;
+    const int64_t xstep = static_cast<int64_t>(NODES) * p.x_stride;
+    const float* xp = xq + (n_lo + nl) * p.x_stride;
+    auto row = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr <= xlast ? ptr : xlast); };
+    float4 cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = row(xp + u * xstep);
+    for (int64_t n = n_lo + nl; n < n_hi; n += U * NODES) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) nxt[u] = row(xp + (U + u) * xstep);
+      xp += U * xstep;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (n + u * NODES < n_hi) look_up(n + u * NODES, cur[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+    if constexpr (!SUM) {
+      if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64 (as fpwl_fast_kernel)
+        float* red = smem;
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) red[tid * FPT + f] = ps[f];
+        __syncthreads();
+        if (tid < FG) {
+          const int qq = tid / FPT, ff = tid % FPT;
+          double acc = 0.0;
+          for (int s2 = 0; s2 < NODES; ++s2) acc += red[(s2 * TPN + qq) * FPT + ff];
+          p.col_partial[nb * p.F + k0 + tid] = acc;
+        }
+      }
+    }
+  }
+}
+
+int cu_count_() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus;
+}
+
+size_t image_bytes(int logb, int tot_cap, int kf) {
+  const size_t a_words = (static_cast<size_t>(tot_cap) + FG * kf + 1) & ~static_cast<size_t>(1);
+  return (static_cast<size_t>(FG) << logb) * 2 + a_words * 4 + static_cast<size_t>(tot_cap) * 8 + (FG + 1) * 4;
+}
+
+}  // namespace
+
+// Nodes per workgroup of the direct-index look-up (also what gnan_fpwl_total_workspace_bytes sizes the column-sum
+// partials with): the LDS image (bucket entries + tables, ~50 KB) is worth ~500 look-up rows, x lines are shared between
+// the groups of a node block in L2, and the grid should be whole rounds of the resident workgroups.
+int gnan_index_nodes_per_block(const gnan_fpwl_args* a) {
+  if (a->n < 262144) {
+    const int64_t npb = (a->n / 1024 + 255) / 256 * 256;
+    return static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
+  }
+  int logb = 6;
+  while ((1 << logb) < a->index_buckets) ++logb;
+  const size_t lds = image_bytes(logb, a->max_group_pieces, a->index_max_fast >= 3 ? 3 : 1);
+  const int bs = 512;
+  int per_cu = static_cast<int>((160 * 1024) / lds);
+  if (per_cu > 2048 / bs) per_cu = 2048 / bs;
+  if (per_cu < 1) per_cu = 1;
+  const int64_t resident = static_cast<int64_t>(cu_count_()) * per_cu;
+  const int64_t groups = a->sum_features ? 1 : (a->F + FG - 1) / FG;
+  const int unit = 128, overhead = 500;
+  int64_t best_cost = -1;
+  int best = 4096;
+  for (int npb = 2048; npb <= 8192; npb += unit) {
+    const int64_t wgs = (a->n + npb - 1) / npb * groups;
+    const int64_t rounds = (wgs + resident - 1) / resident;
+    const int64_t cost = rounds * (npb + overhead);
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && npb > best)) { best_cost = cost; best = npb; }
+  }
+  return best;
+}
+
+// Does the direct-index kernel serve these arguments?  (one channel, whole 16-feature groups, 16-byte aligned rows)
+bool gnan_index_applies(const gnan_fpwl_args* a) {
+  auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
+  if (!a->index_table || !a->index_key || a->C != 1 || a->F % FG != 0 || a->x_stride % 4 != 0 || !aligned(a->x)) return false;
+  const int B = a->index_buckets;
+  if (B != 256 && B != 512 && B != 1024 && B != 2048) return false;
+  if (!aligned(a->index_table)) return false;
+  if (a->max_pieces > 4096) return false;                                  // entries hold 4 * piece + flag in 16 bits
+  if (!a->sum_features && (a->out_stride % 4 != 0 || !aligned(a->out))) return false;
+  if (a->sum_features && a->out_dtype != GNAN_F32) return false;
+  if (a->piece_out && (!a->sum_features || a->max_pieces > 256)) return false;
+  int logb = 6;
+  while ((1 << logb) < B) ++logb;
+  return image_bytes(logb, a->max_group_pieces, a->index_max_fast >= 3 ? 3 : 1) <= 150 * 1024;
+}
+
+// (called by gnan_fpwl_fwd, csrc/fpwl.hip, after its checks; col_partial: the column-sum partials or NULL)
+int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st) {
+  IndexParams p;
+  p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F;
+  p.off = a->off; p.anchor = a->anchor; p.val = a->val; p.slope = a->slope;
+  p.table = a->index_table; p.key = a->index_key;
+  p.n_groups = a->F / FG;
+  p.nodes_per_block = gnan_index_nodes_per_block(a);
+  p.tot_cap = a->max_group_pieces;
+  int step0 = 0;
+  while ((step0 ? step0 * 2 : 1) <= a->max_pieces - 1) step0 = step0 ? step0 * 2 : 1;
+  p.step0 = step0;
+  p.sum_features = a->sum_features;
+  p.out = static_cast<float*>(a->out); p.out_stride = a->out_stride;
+  p.col_partial = col_partial;
+  p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
+  p.piece_out = a->piece_out;
+  const int kf = a->index_max_fast >= 3 ? 3 : 1;
+  int logb = 6;
+  while ((1 << logb) < a->index_buckets) ++logb;
+  constexpr int BS = 512;
+  size_t lds = image_bytes(logb, p.tot_cap, kf);
+  if (col_partial && lds < BS * 4 * sizeof(float)) lds = BS * 4 * sizeof(float);
+  const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
+  const int64_t wgs = a->sum_features ? bx : (bx + 7) / 8 * 8 * p.n_groups;
+  if (wgs > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds));
+      if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl_index: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(wgs)), dim3(BS), lds, st, p);
+    return gnan::check_launch("fpwl_index_kernel");
+  };
+  auto by_mode = [&](auto kf_c, auto lb_c) {
+    constexpr int K = decltype(kf_c)::value, LB = decltype(lb_c)::value;
+    if (a->out_dtype == GNAN_BF16) return go(fpwl_index_kernel<false, true, K, LB, BS>);
+    return a->sum_features ? go(fpwl_index_kernel<true, false, K, LB, BS>) : go(fpwl_index_kernel<false, false, K, LB, BS>);
+  };
+  auto by_b = [&](auto kf_c) {
+    switch (logb) {
+      case 8: return by_mode(kf_c, std::integral_constant<int, 8>{});
+      case 9: return by_mode(kf_c, std::integral_constant<int, 9>{});
+      case 10: return by_mode(kf_c, std::integral_constant<int, 10>{});
+      default: return by_mode(kf_c, std::integral_constant<int, 11>{});
+    }
+  };
+  return kf == 3 ? by_b(std::integral_constant<int, 3>{}) : by_b(std::integral_constant<int, 1>{});
+}
+
+extern "C" int gnan_feature_range(const float* x, int64_t n, int64_t x_stride, int32_t F, float* range, void* workspace,
+                                  size_t workspace_bytes, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && F >= 1, "feature_range: bad sizes");
+  GNAN_REQUIRE(range && workspace && (n == 0 || x), "feature_range: null pointer");
+  GNAN_REQUIRE(x_stride >= F, "feature_range: x row stride smaller than F");
+  if (workspace_bytes < static_cast<size_t>(F) * 2 * sizeof(int))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "feature_range: workspace %zu B < required %zu B", workspace_bytes,
+                      static_cast<size_t>(F) * 2 * sizeof(int));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int* lohi = static_cast<int*>(workspace);
+  hipLaunchKernelGGL(range_init_kernel, dim3((F + 255) / 256), dim3(256), 0, st, lohi, F);
+  if (n > 0) {
+    const int col_blocks = (F + 255) / 256;
+    int64_t row_blocks = 4096 / col_blocks;
+    if (row_blocks > n) row_blocks = n;
+    if (row_blocks < 1) row_blocks = 1;
+    const int64_t rpb = (n + row_blocks - 1) / row_blocks;
+    row_blocks = (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL(range_kernel, dim3(static_cast<unsigned>(row_blocks), col_blocks), dim3(256), 0, st, x, n, x_stride, F,
+                       rpb, lohi);
+  }
+  hipLaunchKernelGGL(range_finish_kernel, dim3((2 * F + 255) / 256), dim3(256), 0, st, lohi, F, range);
+  return gnan::check_launch("range_kernel");
+}
+
+extern "C" int gnan_fpwl_index_build(const gnan_fpwl_index_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "fpwl_index_build: null args");
+  GNAN_REQUIRE(a->F >= 1 && a->off && a->anchor && a->range && a->table && a->key, "fpwl_index_build: null pointer / bad sizes");
+  GNAN_REQUIRE(a->max_fast == 1 || a->max_fast == 3, "fpwl_index_build: max_fast must be 1 or 3");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(a->F), dim3(256), 0, st, a->off, a->anchor, a->range, a->max_fast, a->table, a->key, a->stats);
+    return gnan::check_launch("index_build_kernel");
+  };
+  switch (a->buckets) {
+    case 256: return go(index_build_kernel<8>);
+    case 512: return go(index_build_kernel<9>);
+    case 1024: return go(index_build_kernel<10>);
+    case 2048: return go(index_build_kernel<11>);
+    default: return gnan::fail(GNAN_ERR_BAD_ARG, "fpwl_index_build: buckets must be 256, 512, 1024 or 2048");
+  }
+}

@@ -137,12 +137,62 @@ def _fpwl_locate(x: torch.Tensor, t, a):
     return piece, dx
 
 
+INDEX_LOOKUP = True           # one channel, whole 16-feature groups: find the piece by arithmetic (csrc/fpwl_index.hip), not by a search
+INDEX_BUCKETS = 1024          # cells per feature over the range its values take
+INDEX_MAX_FAST = 1            # breakpoints per cell resolved by comparisons (1 or 3); fuller cells are searched
+INDEX_MIN_NODES = 1 << 16     # below, the look-up is latency-bound either way and the range pass would not pay
+_RANGE_CACHE = TensorKeyedCache(8)    # feature matrix (object identity + version) -> [F, 2] column minima / maxima
+_RANGE_CHURN = {}                     # (n, F) -> consecutive misses of that cache
+
+
+def _feature_range(x: torch.Tensor) -> Optional[torch.Tensor]:
+    """``[F, 2]`` column (min, max) of the caller's feature matrix — the range hint of the direct-index look-up
+    (``gnan_feature_range``: one pass over x, kept per tensor object and version like the other derived inputs).  The hint
+    only steers speed: the look-up is exact for values outside it.  None when the caller hands a NEW feature matrix every
+    call (three misses in a row for a shape): the pass would then cost more than the index saves."""
+    if not INDEX_LOOKUP or x.dim() != 2 or x.shape[0] < INDEX_MIN_NODES or x.shape[1] % 16:
+        return None
+    hit = _RANGE_CACHE.get((x,))
+    shape = tuple(x.shape)
+    if hit is not None:
+        _RANGE_CHURN[shape] = 0
+        return _pin_for_capture(hit)
+    if _RANGE_CHURN.get(shape, 0) >= 3:
+        return None
+    _RANGE_CHURN[shape] = _RANGE_CHURN.get(shape, 0) + 1
+    xr = _rows(x.detach().float())
+    n, F = xr.shape
+    rng = torch.empty((F, 2), dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * F, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().gnan_feature_range(_lib.ptr(xr), n, xr.stride(0), F, _lib.ptr(rng), _lib.ptr(ws), ws.numel() * 4,
+                                             _lib.stream_of(x)), "gnan_feature_range")
+    return _pin_for_capture(_RANGE_CACHE.put((x,), None, rng))
+
+
+def _fpwl_index(a: "_lib.FpwlArgs", x: torch.Tensor, t, x_range: torch.Tensor) -> Optional[list]:
+    """Build the direct-index tables of ``t`` over ``x_range`` (``gnan_fpwl_index_build``: one small workgroup per feature,
+    queued behind the table build) and attach them to the look-up's arguments; returns the tensors to keep alive."""
+    n, F = x.shape
+    if (x_range is None or a.C != 1 or t.features_per_group != 16 or F % 16 or x.stride(0) % 4 or x.data_ptr() % 16
+            or t.max_pieces > 4096 or tuple(x_range.shape) != (F, 2)):
+        return None
+    table = torch.empty((F, INDEX_BUCKETS), dtype=torch.int16, device=x.device)
+    key = torch.empty((F, 2), dtype=torch.float32, device=x.device)
+    ia = _lib.FpwlIndexArgs(off=_lib.ptr(t.off), anchor=_lib.ptr(t.anchor), F=F, buckets=INDEX_BUCKETS,
+                            max_fast=INDEX_MAX_FAST, range=_lib.ptr(x_range), table=_lib.ptr(table), key=_lib.ptr(key),
+                            stats=None)
+    _lib.check(_lib.lib().gnan_fpwl_index_build(ia, _lib.stream_of(x)), "gnan_fpwl_index_build")
+    a.index_table, a.index_key = _lib.ptr(table), _lib.ptr(key)
+    a.index_buckets, a.index_max_fast = INDEX_BUCKETS, INDEX_MAX_FAST
+    return [table, key]
+
+
 KEEP_PIECES = os.environ.get("GNAN_KEEP_PIECES", "1") != "0"   # C == 1 training: the forward's pieces (a byte each) serve the backward
 LOCATED_KEEP_MAX_BYTES = 2 << 30   # (piece, dx) of a forward are kept for its backward pass while they stay below 2 GiB
 
 
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32,
-                 total_rows: Optional[int] = None, located: Optional[list] = None):
+                 total_rows: Optional[int] = None, located: Optional[list] = None, x_range: Optional[torch.Tensor] = None):
     """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``.
     With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
     when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
@@ -180,6 +230,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
                       out=_lib.ptr(out), out_stride=out.stride(0),
                       out_dtype=_lib.GNAN_BF16 if out_dtype == torch.bfloat16 else _lib.GNAN_F32, flags=_fpwl_flags())
+    index_keep = _fpwl_index(a, x, t, x_range)          # noqa: F841  (alive until the look-up is queued)
     total = None
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
@@ -298,10 +349,13 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
         from .pwl import build_tables, build_tables_lazy, covers, hip_build_applies
         stacked = StackedMLP(*[_c(t) for t in p[:6]], *p[6:])
 
+        x_range = _feature_range(x) if p.C == 1 else None
+
         def look_up(t):
             return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows,
-                                located=located) \
-                if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype, located=located), None)
+                                located=located, x_range=x_range) \
+                if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype, located=located,
+                                                 x_range=x_range), None)
 
         if prebuilt is not None:
             # tables of THESE weights queued earlier, possibly on another stream (TablePrefetch): wait for that stream's

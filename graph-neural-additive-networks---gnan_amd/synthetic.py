@@ -79,3 +79,51 @@ def block_features(n_nodes: int, n_feat: int, row_lo: int, row_hi: int, seed: in
         b += 1
     out[:, -1] = 1.0
     return out
+
+
+def preferential_attachment_edges(n_nodes: int, n_edges: int, seed: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``n_edges`` directed edges ``src -> dst`` of a preferential-attachment graph (the ogbn-arxiv shape,
+    ``datasets.py:273-291``).
+
+    Batagelj-Brandes: nodes arrive in order, edge ``e`` leaves node ``floor(e * N / E)`` (about E/N citations each) and its
+    head is the endpoint stored in a uniformly drawn slot of the half-edge list written so far, hence
+    ``P(dst = v)`` is proportional to ``deg(v)``.  A slot that holds an earlier edge's head is a reference to that edge;
+    the references are resolved by pointer jumping (O(log E) vectorised rounds) instead of the sequential loop.  Node ids
+    are then permuted at random, as a real data set's are not sorted by arrival.  Generated on the CPU generator, so the
+    graph is the same on every device."""
+    gen = torch.Generator().manual_seed(seed)
+    e = torch.arange(n_edges, dtype=torch.int64)
+    src = (e * n_nodes) // n_edges
+    r = (torch.rand(n_edges, generator=gen, dtype=torch.float64) * (2 * e + 1).double()).long().clamp_(max=2 * n_edges - 1)
+    r = torch.minimum(r, 2 * e)                                   # slot 2e is the edge's own tail (e = 0: a self loop)
+    ptr = torch.where(r % 2 == 1, r // 2, torch.full_like(r, -1))       # the earlier edge whose head this edge copies
+    val = src[r // 2].clone()                                     # meaningful where ptr < 0 (an even slot holds a tail)
+    while True:
+        todo = torch.nonzero(ptr >= 0).flatten()
+        if todo.numel() == 0:
+            break
+        p = ptr[todo]
+        done = ptr[p] < 0
+        val[todo] = torch.where(done, val[p], val[todo])
+        ptr[todo] = torch.where(done, torch.full_like(p, -1), ptr[p])
+    perm = torch.randperm(n_nodes, generator=gen)
+    return perm[src].to(device), perm[val].to(device)
+
+
+def mutagenicity_shaped_graphs(count: int, seed: int = 0, n_types: int = 14, max_nodes: int = 417):
+    """``count`` small undirected graphs of the Mutagenicity shape: ``N_g = clip(round(LogNormal(3.3,
+    0.45)), 4, max_nodes)`` nodes (mean about 30), a random tree plus ``N_g // 30 + 1`` extra edges, one-hot atom type of
+    ``n_types`` + the ones column (``pre_process_datasets.py:108``).  Yields ``(edge_index [2, 2m] int64 numpy, x [N_g,
+    n_types + 1] float32 tensor, label +-1)`` — CPU objects; the caller pre-processes and moves them."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    F = n_types + 1
+    for _ in range(count):
+        n = int(np.clip(np.round(rng.lognormal(3.3, 0.45)), 4, max_nodes))
+        tree = np.stack([np.arange(1, n), rng.integers(0, np.arange(1, n))])
+        extra = np.stack([rng.integers(0, n, n // 30 + 1), rng.integers(0, n, n // 30 + 1)])
+        ei = np.concatenate([tree, extra], axis=1)
+        x = torch.zeros(n, F)
+        x[torch.arange(n), torch.from_numpy(rng.integers(0, n_types, n))] = 1.0
+        x[:, -1] = 1.0
+        yield np.concatenate([ei, ei[::-1]], axis=1), x, (1.0 if rng.random() < 0.5 else -1.0)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GNAN_ABI_VERSION 36
+#define GNAN_ABI_VERSION 37
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -54,8 +54,8 @@ const char* gnan_last_error(void);
  *   L >= 2 : w_first [F, H], b_first [F, H]                       Linear(1, H)
  *            w_mid [L-2, F, H, H] (out, in), b_mid [L-2, F, H]    Linear(H, H)
  *            w_last [F, C, H], b_last [F, C]                      Linear(H, C)
- * Bias pointers may be NULL (bias=False).  ReLU after every layer but the last; Dropout is the
- * caller's business (eval mode / p = 0 only).
+ * Bias pointers may be NULL (bias=False).  ReLU after every layer but the last; training-mode Dropout
+ * (GNAN.py:28,32) runs inside the lane kernel when dropout_p > 0 (see the struct), else none is applied.
  *
  * sum_features == 0 : out[n, k*C + c]               ("reference order", fx of GNAN.py:57)
  * sum_features == 1 : out[n, c] = sum_k fx[n, k, c]  (f_sums of GNAN.py:157)
@@ -171,6 +171,10 @@ typedef struct gnan_fpwl_args {
   const uint8_t* piece_in; /* gnan_fpwl_moments_fixed, optional: those bytes — the C == 1 kernel then skips the search (ignored
                               by the other moment kernels and above 256 pieces per feature) */
   int32_t flags;             /* gnan_fpwl_flags: kernel selection switches (A/B measurements, tests); 0 = the library's choice */
+  const uint16_t* index_table; /* gnan_fpwl_fwd, optional: the direct-index tables gnan_fpwl_index_build wrote for THESE tables   */
+  const float* index_key;      /* ([F, buckets] entries and [F, 2] key coefficients).  With C == 1, whole 16-feature groups and   */
+  int32_t index_buckets;       /* 16-byte aligned rows the look-up then finds a value's piece by arithmetic + at most              */
+  int32_t index_max_fast;      /* index_max_fast comparisons instead of a search (csrc/fpwl_index.hip); same results bit for bit   */
 } gnan_fpwl_args;
 
 /* gnan_fpwl_args.flags (the library reads no environment variables: switches are the caller's, passed per call) */
@@ -181,6 +185,29 @@ enum gnan_fpwl_flags {
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);
 int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
+
+/* Direct-index acceleration of the one-channel look-up (csrc/fpwl_index.hip; no counterpart in the reference, whose
+ * GNAN.py:57-62 evaluates the MLPs).  Per feature a uniform grid of `buckets` cells over [range[k][0], range[k][1]] —
+ * the values the feature actually takes (gnan_feature_range: column minima / maxima, one pass per feature matrix) — maps
+ * x to a cell by one fused multiply-add; table[k][cell] = 4 * (breakpoints of f_k below the cell) | (more than max_fast
+ * breakpoints inside the cell).  The range is a HINT: the look-up compares x with the breakpoints inside its cell and
+ * searches flagged cells (among them the two end cells, which take everything outside the range), so every x is looked
+ * up exactly whatever the range says.  stats[k] (optional) = flagged cells strictly inside the range.
+ * gnan_feature_range: range [F][2] out; workspace F * 8 bytes; NaNs are skipped. */
+typedef struct gnan_fpwl_index_args {
+  const int32_t* off;      /* [F + 1] piece offsets (gnan_pwl_build / gnan_amd.pwl) */
+  const float* anchor;     /* [T] */
+  int32_t F;
+  int32_t buckets;         /* 256, 512, 1024 or 2048 */
+  int32_t max_fast;        /* 1 or 3: breakpoints per cell the look-up resolves by comparisons */
+  const float* range;      /* [F][2] (lo, hi) */
+  uint16_t* table;         /* [F][buckets] out, 16-byte aligned */
+  float* key;              /* [F][2] out: cell(x) = (int) clamp(x * key[k][0] + key[k][1], 0, buckets - 1) */
+  int32_t* stats;          /* optional [F] out */
+} gnan_fpwl_index_args;
+int gnan_fpwl_index_build(const gnan_fpwl_index_args* a, gnan_stream_t stream);
+int gnan_feature_range(const float* x, int64_t n, int64_t x_stride, int32_t F, float* range, void* workspace,
+                       size_t workspace_bytes, gnan_stream_t stream);
 
 /* Backward of the table look-up (autograd through GNAN.py:57-62 w.r.t. the f_k parameters): per-piece
  * moments of the upstream gradient `grad` ([n, F*C], or [n, C] when sum_features),

@@ -314,6 +314,32 @@ def spmm_csr(rowptr: np.ndarray, col: np.ndarray, code: np.ndarray, S: Tensor, w
     return out
 
 
+def spmm_csr_vectorised(rowptr: np.ndarray, col: np.ndarray, code: np.ndarray, S: Tensor, lut: Tensor,
+                        cnt: Optional[np.ndarray]) -> Tensor:
+    """:func:`spmm_csr` with the post-rho table ``lut[d] / cnt[i, d]`` (models.py:368-370 per shell), written with
+    ``index_add`` so that it runs on graphs of 10^5..10^6 rows and stays differentiable w.r.t. ``S`` and ``lut`` (the
+    float64 truth of the full-shape config-3 test).  Same identity as :func:`spmm_csr_sparse`:
+    ``out[i] = sum_e (w_e - w_rest[i]) * S[col_e] + w_rest[i] * sum_j S[j]``; weight channel ``w % Cw`` for column ``w``."""
+    n = len(rowptr) - 1
+    W = S.shape[1]
+    rp = torch.from_numpy(np.asarray(rowptr, dtype=np.int64))
+    row_of = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    codet = torch.from_numpy(np.asarray(code, dtype=np.int64))
+    colt = torch.from_numpy(np.asarray(col, dtype=np.int64))
+    cw = lut.shape[1]
+    l = lut.to(S.dtype)
+    if cw not in (1, W):
+        l = l.repeat(1, (W + cw - 1) // cw)[:, :W]
+    if cnt is None:
+        w_e, w_rest = l[codet], l[-1].unsqueeze(0).expand(n, -1)
+    else:
+        c = torch.from_numpy(np.maximum(cnt, 1)).to(S.dtype)
+        w_e = l[codet] / c[row_of, codet].unsqueeze(1)
+        w_rest = l[-1].unsqueeze(0) / c[:, -1:]
+    out = torch.zeros(n, W, dtype=S.dtype).index_add(0, row_of, (w_e - w_rest[row_of]) * S[colt])
+    return out + w_rest * S.sum(dim=0, keepdim=True)
+
+
 def weight_table(lut: Tensor, cnt: Optional[np.ndarray]) -> Tensor:
     """Post-rho normalised table ``wtab[i, d, :] = lut[d, :] / cnt[i, d]`` (models.py:369-370 per shell)."""
     if cnt is None:

@@ -4,6 +4,10 @@
   column) through ``models.GNAN`` (what main.py:79 picks) and ``models.TensorGNAN``: forward on a sample of nodes and one
   backward against the float64 oracle's per-node loop (GNAN.py:146-172).  TensorGNAN keeps the reference's zero biases
   (GNAN.py:49-53), so most inputs sit exactly on the kinks of their shape functions.
+* C3 — ogbn-arxiv-shaped (datasets.py:273-291: N = 169 343, E = 1 166 243, F = 128 + 1; C = 1 as the reference sets it and
+  C = 40, the data set's class count): preferential-attachment edges + self pairs, K = 1, ``models.TensorGNAN`` forward +
+  backward at the configuration's OWN shape — the WHOLE output (the 8 193-citation hub included) and EVERY parameter
+  gradient against float64 oracle autograd (shape functions back-propagated in node chunks).
 * C5 — papers100M-shaped R-MAT (scale 27, 111M nodes / 1.6G edges), bf16 operand storage: sampled rows against a
   float64 restatement on the rounded operand, reference order == sum-first, row subsets bit-identical.
 * more than 2^31 listed pairs (int64 row offsets, pair indices beyond 32 bits, a hub row at the far end): sampled rows
@@ -93,6 +97,69 @@ def test_c1_cora_shaped_dense_inputs(cora_shaped, cls):
         # (dense rows are sliced over workgroups by the number of requested rows: same sums, another association)
         assert O.rel_err(sub.cpu(), y.detach().cpu()[ids].double()) <= 2e-6
         assert O.rel_err(sub.cpu(), truth.detach()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------- C3
+@pytest.mark.parametrize("C", [1, 40])
+def test_c3_arxiv_shaped_forward_backward_at_its_own_shape(C):
+    import gnan_amd  # noqa: F401
+    from gnan_amd import models
+    from gnan_amd import synthetic as syn
+    N, E, F, H, L = 169_343, 1_166_243, 129, 64, 3
+    src, dst = syn.preferential_attachment_edges(N, E, seed=0, device=DEV)
+    indeg = torch.bincount(dst, minlength=N)
+    assert int(indeg.max()) > 2000                          # a hub: its operand row is gathered by thousands of rows
+    g = syn.hop1_csr(src, dst, N)
+    assert g.nnz == E + N and g.n_codes == 3
+    x = syn.block_features(N, F, 0, N, seed=1, device=DEV)
+    torch.manual_seed(0)
+    mod = models.TensorGNAN(F, C, L, hidden_channels=H, device=DEV)
+    gen = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
+    sd = {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+    mod = mod.to(DEV).eval()
+    target = torch.randn(N, C, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    data = Bag(x=x, edge_index=None, gnan_graph=g)
+
+    y = mod.forward(data)
+    assert y.shape == (N, C)
+    ((y - target.to(DEV).float()) ** 2).mean().backward()
+
+    # ---- float64 truth: oracle shape functions (GNAN.py:57-62) in node chunks, shell-form aggregation
+    rowptr, col, code = g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy()
+    cnt = g.cnt.cpu().long().numpy()
+    xh = x.cpu()
+    p64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    chunk = 16384
+    with torch.no_grad():
+        S64 = torch.cat([O.feature_mlps(xh[i:i + chunk].double(), p64).sum(1) for i in range(0, N, chunk)])     # [N, C]
+        S32 = torch.cat([O.feature_mlps(xh[i:i + chunk], sd).sum(1) for i in range(0, N, chunk)])
+        ref32 = O.spmm_csr_vectorised(rowptr, col, code, S32, O.rho_lut(sd, 3), cnt)
+    S_leaf = S64.clone().requires_grad_(True)
+    truth = O.spmm_csr_vectorised(rowptr, col, code, S_leaf, O.rho_lut(p64, 3, torch.float64), cnt)
+    e_ref = O.rel_err(ref32, truth.detach())                # the tolerance rule: max(1e-5, the fp32 reference's error)
+    err = O.rel_err(y.detach().cpu(), truth.detach())
+    assert err <= max(1e-5, e_ref), (err, e_ref)
+    hub = int(torch.argmax(indeg))
+    rows_of_hub = torch.nonzero(dst == hub).flatten()[:64]
+    sub = src[rows_of_hub].cpu()
+    assert O.rel_err(y.detach().cpu()[sub], truth.detach()[sub]) <= max(1e-5, e_ref)
+
+    ((truth - target) ** 2).mean().backward()               # rho's parameters and dS
+    dS = S_leaf.grad
+    for i in range(0, N, chunk):                            # the shape functions' parameters, chunk by chunk
+        O.feature_mlps(xh[i:i + chunk].double(), p64).sum(1).backward(dS[i:i + chunk])
+    scale = max(float(v.grad.abs().max()) for v in p64.values() if v.grad is not None)
+    worst, where = 0.0, None
+    for k, p in mod.named_parameters():
+        want = p64[k].grad if p64[k].grad is not None else torch.zeros_like(p64[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        e = float((got.cpu().double() - want).abs().max()) / scale
+        if e > worst:
+            worst, where = e, k
+    assert worst <= 2e-5, (worst, where)
 
 
 # ---------------------------------------------------------------------------------------------------------- sampled rows

@@ -1680,3 +1680,112 @@ def test_multi_copy_in_one_launch():
         _lib.multi_copy([(torch.zeros(3, device=DEV), torch.zeros(4, device=DEV))])
     with pytest.raises(_lib.GnanHipError):
         _lib.multi_copy([(torch.zeros(3, device=DEV), torch.ones(3, device=DEV))] * 9)
+
+
+# ---------------------------------------------------------------------------------------------------------- direct index
+def _index_inputs(kind, n, F, seed):
+    g0 = torch.Generator().manual_seed(seed)
+    if kind == "uniform":
+        x = torch.rand(n, F, generator=g0) * 2 - 1
+    elif kind == "one_hot":                         # bag-of-words style: mostly exact zeros, a few ones, the ones column
+        x = (torch.rand(n, F, generator=g0) < 0.1).float()
+    elif kind == "heavy_tail":                      # a few huge values stretch the hinted range: the grid turns coarse
+        x = torch.randn(n, F, generator=g0)
+        x[::997] *= 1e4
+    else:                                           # "levels": exact kink positions, signed zero, non-finite values
+        levels = torch.tensor([0.0, -0.0, 1.0, 0.25, 0.5, 0.75, 2.0, -1.0, float("inf"), -float("inf"), float("nan")])
+        x = levels[torch.randint(0, len(levels), (n, F), generator=g0)]
+    x[:, -1] = 1.0                                  # pre_process_datasets.py:127
+    return x.to(DEV)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "one_hot", "heavy_tail", "levels"])
+@pytest.mark.parametrize("mode", ["rows", "rows_bf16", "sum"])
+@pytest.mark.parametrize("buckets,max_fast", [(1024, 1), (256, 3), (2048, 1)])
+def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets, max_fast, monkeypatch):
+    """csrc/fpwl_index.hip finds the piece of a value by arithmetic on a per-feature grid over the data's range plus
+    comparisons inside the cell; it must give the bits of the tree-search kernel (same piece, same formula) for ANY
+    input — on kinks, outside the hinted range, non-finite — and for a range hint that is wrong."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    monkeypatch.setattr(functional, "INDEX_BUCKETS", buckets)
+    monkeypatch.setattr(functional, "INDEX_MAX_FAST", max_fast)
+    n, F, L, H = 70_001, 32, 3, 24
+    sd = _on_kink_state(F, L, H, 1, "exact", seed=3) if kind in ("levels", "one_hot") else _mlp_state(F, L, H, 1, True, seed=3)
+    st = _stack(sd, F, L, H, 1, True)
+    x = _index_inputs(kind, n, F, seed=5)
+    calls = []
+    real = _lib.lib().gnan_fpwl_index_build
+
+    def run(on, hint=None):
+        monkeypatch.setattr(functional, "INDEX_LOOKUP", on)
+        if hint is not None:
+            monkeypatch.setattr(functional, "_feature_range", lambda t: hint)
+        with torch.no_grad():
+            if mode == "sum":
+                return feature_mlps(x, st, True, return_total=True)
+            return feature_mlps(x, st, False, return_total=True,
+                                out_dtype=torch.bfloat16 if mode == "rows_bf16" else torch.float32)
+
+    want, want_total = run(False)
+    before = functional._RANGE_CACHE.__len__()
+    got, got_total = run(True)
+    assert functional._RANGE_CACHE.__len__() >= max(before, 1)            # the index path ran (its range pass was cached)
+    assert torch.equal(got.view(torch.int16 if mode == "rows_bf16" else torch.int32),
+                       want.view(torch.int16 if mode == "rows_bf16" else torch.int32))      # bit for bit, NaNs included
+    assert torch.equal(got_total.view(torch.int32), want_total.view(torch.int32))
+    # a WRONG hint (narrower than the data, shifted, degenerate): still exact — the hint steers speed only
+    for lo, hi in ((0.2, 0.3), (5.0, 9.0), (0.0, 0.0), (float("nan"), 1.0), (-float("inf"), float("inf"))):
+        hint = torch.tensor([[lo, hi]] * F, device=DEV)
+        got2, tot2 = run(True, hint)
+        assert torch.equal(got2.view(torch.int16 if mode == "rows_bf16" else torch.int32),
+                           want.view(torch.int16 if mode == "rows_bf16" else torch.int32)), (lo, hi)
+
+
+def test_direct_index_keeps_the_pieces_for_the_backward_pass(monkeypatch):
+    """Training, one channel: the direct-index feature-sum kernel stores the same piece bytes as the tree-search kernel,
+    so the moment kernel bins the same terms — parameter gradients bit for bit."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    n, F, L, H = 80_000, 32, 3, 16
+    sd = _mlp_state(F, L, H, 1, True, seed=11)
+    x = _index_inputs("uniform", n, F, seed=2)
+    target = torch.randn(n, 1, generator=torch.Generator().manual_seed(1)).to(DEV)
+    grads = {}
+    for on in (False, True):
+        monkeypatch.setattr(functional, "INDEX_LOOKUP", on)
+        st = _stack(sd, F, L, H, 1, True)
+        leaves = [t.detach().clone().requires_grad_(True) for t in st[:6]]
+        S = feature_mlps(x, type(st)(*leaves, *st[6:]), True)
+        ((S - target) ** 2).mean().backward()
+        grads[on] = [S.detach()] + [t.grad for t in leaves]
+    for a, b in zip(grads[False], grads[True]):
+        assert torch.equal(a, b)
+
+
+def test_feature_range_kernel():
+    import gnan_amd  # noqa: F401
+    from gnan_amd import functional
+    x = torch.randn(100_003, 48, device=DEV)
+    x[5, 3] = float("nan")
+    x[:, 7] = 1.0
+    x[17, 9] = float("inf")
+    x = x.contiguous()
+    functional._RANGE_CHURN.clear()
+    r = functional._feature_range(x)
+    ok = torch.ones(48, dtype=torch.bool)
+    xm = torch.where(torch.isnan(x), torch.zeros_like(x), x)
+    lo, hi = xm.min(0).values, xm.max(0).values
+    lo[3] = torch.where(torch.isnan(x[:, 3]), torch.full_like(x[:, 3], float("inf")), x[:, 3]).min()
+    hi[3] = torch.where(torch.isnan(x[:, 3]), torch.full_like(x[:, 3], -float("inf")), x[:, 3]).max()
+    assert torch.equal(r[:, 0], lo) and torch.equal(r[:, 1], hi)
+    assert functional._feature_range(x) is r                             # cached per tensor object and version
+    x[0, 0] = 1e9                                                        # an in-place write invalidates it
+    assert float(functional._feature_range(x)[0, 1]) == 1e9
+    # a new feature matrix every call: after three misses the range pass is no longer paid for that shape
+    functional._RANGE_CHURN.clear()
+    seen = [functional._feature_range(torch.randn(70_000, 16, device=DEV)) is not None for _ in range(5)]
+    assert seen == [True, True, True, False, False]
+    functional._RANGE_CHURN.clear()

@@ -159,3 +159,36 @@ def test_ranks_with_the_hip_kernels_equal_single_process_and_oracle(world, varia
         assert err <= 2e-5, f"{k}: ranks vs oracle {err:.3e}"
         e1 = float((single[k].grad.cpu().double() - want).abs().max()) / scale
         assert e1 <= 2e-5, f"{k}: single process vs oracle {e1:.3e}"
+
+
+def _bench_line(extra, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--scale", "18", "--nodes", "200000", "--edges", "2000000"] + extra
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("partition", ["halo", "vertex"])
+def test_bench_starts_its_own_ranks(partition):
+    """``python bench.py --gpus 2`` with no launcher around it (WORLD_SIZE unset) must run TWO ranks — the parent starts
+    ``torch.distributed.run`` as a child before touching the GPU — and say so in its line; here both share cuda:0 over gloo.
+    The partitioned result equals the one-rank run of the same graph."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    env_had = os.environ.pop("WORLD_SIZE", None)
+    try:
+        two = _bench_line(["--gpus", "2", "--same-device", "--backend", "gloo", "--partition", partition])
+        one = _bench_line(["--gpus", "1"])
+    finally:
+        if env_had is not None:
+            os.environ["WORLD_SIZE"] = env_had
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["config"]["partition"] == f"{partition} x2"
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert abs(two["checksum"] - one["checksum"]) <= 1e-5 * abs(one["checksum"]), (two["checksum"], one["checksum"])

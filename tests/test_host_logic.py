@@ -283,3 +283,22 @@ def test_hot_columns_point_at_the_appended_rows(monkeypatch):
     flat = HopGraph.from_csr(torch.arange(0, 4 * n + 1, 4), torch.arange(4 * n).int() % n, torch.zeros(4 * n, dtype=torch.uint8),
                              n_cols=n, n_codes=3)
     assert flat.hot_columns() is None and flat.degree_sorted_copy_hot()[2] is None
+
+
+def test_bench_refuses_to_time_fewer_ranks_than_asked():
+    """``python bench.py --gpus 2`` with fewer than two visible GPUs exits non-zero instead of timing one rank and labelling
+    it two (the parent counts devices without initialising one and starts no ranks)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
+    # a launcher's world size that disagrees with --gpus is an error too, before any device work
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "2", "0", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -79,3 +79,6 @@ def test_shell_csr_restatement_matches_dense(name):
             wtab = O.weight_table(O.rho_lut(p, D, torch.float64), cnt)
         y = O.spmm_csr(rowptr, col, code, S, wtab)
         assert O.rel_err(y, truth) <= 1e-12, (K, O.rel_err(y, truth))
+        if not pre_rho:     # the vectorised, differentiable form the full-shape config-3 test uses as float64 truth
+            yv = O.spmm_csr_vectorised(rowptr, col, code, S, O.rho_lut(p, D, torch.float64), cnt if m["normalize_rho"] else None)
+            assert O.rel_err(yv, truth) <= 1e-12, (K, O.rel_err(yv, truth))
