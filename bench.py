@@ -72,6 +72,15 @@ def parse():
                          "aggregation run (one build per forward either way).  auto: on for a rank's share of a multi-rank job "
                          "(the 0.057-ms build is 6 %% of a 1/8 share: 1.00 -> 0.94 ms), off on one GPU (+-0 there, and the timed "
                          "call is the drop-in module's forward)")
+    ap.add_argument("--share-graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay a rank's share of the forward from two alternating hipGraphs (distributed.SharePipeline: one "
+                         "graph launch per forward, the next forward's table build on a forked branch, the all-reduce of the "
+                         "column sums captured with RCCL).  auto: on where --pipeline is on (a multi-rank share), falling back "
+                         "to the eager loop if the step cannot be captured or its first replay disagrees with the eager forward")
+    ap.add_argument("--share-fork", default="start", choices=["start", "fmlp"],
+                    help="where the next forward's table build branches off inside a replayed share: under the look-up or "
+                         "under the aggregation")
+    ap.add_argument("--index-buckets", type=int, default=0, help="cells per feature of the direct-index look-up (0: the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="upper bound of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
@@ -589,11 +598,13 @@ def main():
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
     from gnan_amd.distributed import (FeaturePartition, VertexPartition, build_exchange_plan, build_halo_plan,
-                                      choose_partition, feature_parallel_forward, halo_exchange_forward,
+                                      SharePipeline, choose_partition, feature_parallel_forward, halo_exchange_forward,
                                       halo_recompute_forward, partitioned_forward, slice_features)
     from gnan_amd import _lib, functional
     from gnan_amd.functional import stack_mlps
     from gnan_amd.graph import hop_inputs
+    if args.index_buckets:
+        functional.INDEX_BUCKETS = args.index_buckets
     functional.FMLP_ALGO = {"auto": _lib.FMLP_AUTO, "lane": _lib.FMLP_LANE, "mfma": _lib.FMLP_MFMA,
                             "pwl": _lib.FMLP_PWL}[args.fmlp_algo]
     from gnan_amd.models import TensorGNAN
@@ -672,6 +683,31 @@ def main():
         if not prefetch.applies:
             prefetch = None
     pipe = {"next": prefetch.launch() if prefetch else None}
+    # ... and the whole share as one graph launch per forward (halo / vertex partitions, inference)
+    share, share_note = None, None
+    if world > 1 and args.backend != "nccl" and args.share_graph != "off":
+        share_note = f"{args.backend} collectives go through the host and cannot be captured: eager loop"
+    elif args.share_graph != "off" and prefetch is not None and (args.share_graph == "on" or args.pipeline):
+        from gnan_amd.graphed import CaptureFailed
+
+        def share_forward(tables, marks=None):
+            if partition == "halo":
+                return halo_recompute_forward(x, plan, stacked, lut, True, order=args.order, out_channels=C,
+                                              operand_dtype=op_dtype, tables=tables, marks=marks)
+            return partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
+                                       operand_dtype=op_dtype, tables=tables, marks=marks)
+        try:
+            with torch.no_grad():
+                want = share_forward(prefetch.launch()).clone()
+            share = SharePipeline(share_forward, stacked, x=x, fork_at=args.share_fork)
+            got = [share.step().clone() for _ in range(2)]          # both graphs once
+            torch.cuda.synchronize()
+            scale = float(want.abs().max())
+            worst = max(float((o - want).abs().max()) for o in got)
+            if share.tripped() or not worst <= 1e-6 * scale:
+                share, share_note = None, f"first replays off by {worst / max(scale, 1e-30):.2e} (or guard tripped): eager loop"
+        except (CaptureFailed, RuntimeError) as e:
+            share, share_note = None, f"not capturable ({type(e).__name__}: {str(e)[:200]}): eager loop"
 
     def step(record):
         marks = {}
@@ -682,6 +718,14 @@ def main():
                 marks[name] = ev
         else:
             mark = None
+        if share is not None:                       # one graph launch: look-up, collective, aggregation + the next table build
+            if record:
+                mark("start")
+            out = share.step()
+            if record:
+                mark("spmm")
+                events.append(marks)
+            return out
         tables = None
         if prefetch is not None:
             tables, pipe["next"] = pipe["next"], prefetch.launch()      # this forward's tables; the next forward's build starts now
@@ -785,6 +829,8 @@ def main():
             "spmm_edges_per_s": (g.nnz - g.n_rows) / spmm_s if spmm_s > 0 else None,
             "fmlp": fmlp_stage(args, x, H, L, C, W if args.order == "reference" else C, stages["fmlp"]),
             "pipelined_table_build": prefetch is not None,
+            "share_replayed_from_hipgraphs": share is not None, "share_graph_note": share_note,
+            "share_guard_tripped": share.tripped() if share is not None else None,
             "timed_call": "gnan_amd.models.TensorGNAN.forward(data)" if use_module else f"gnan_amd.distributed ({partition})",
             "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": checksum,
             "operand_rows_rank0": int(x.shape[0]),

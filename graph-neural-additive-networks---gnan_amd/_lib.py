@@ -46,18 +46,18 @@ class FpwlArgs(C.Structure):
         ("sum_features", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64),
         ("out_dtype", C.c_int32), ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
         ("total_rows", C.c_int64), ("piece_out", C.c_void_p), ("piece_in", C.c_void_p), ("flags", C.c_int32),
-        ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32), ("index_max_fast", C.c_int32),
+        ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32),
     ]
 
 
 class FpwlIndexArgs(C.Structure):
     _fields_ = [
-        ("off", C.c_void_p), ("anchor", C.c_void_p), ("F", C.c_int32), ("buckets", C.c_int32), ("max_fast", C.c_int32),
+        ("off", C.c_void_p), ("anchor", C.c_void_p), ("F", C.c_int32), ("buckets", C.c_int32),
         ("range", C.c_void_p), ("table", C.c_void_p), ("key", C.c_void_p), ("stats", C.c_void_p),
     ]
 
 
-FPWL_MOMENTS_GENERAL, FPWL_LOCATE_SORTED = 1, 2      # gnan_fpwl_args.flags
+FPWL_MOMENTS_GENERAL, FPWL_LOCATE_SORTED, FPWL_INDEX_HALF_LINES, FPWL_INDEX_BS512, FPWL_INDEX_BS1024 = 1, 2, 4, 8, 16   # gnan_fpwl_args.flags
 
 
 class PwlBuildArgs(C.Structure):

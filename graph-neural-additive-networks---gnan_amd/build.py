@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "libgnan_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
 
 
@@ -50,7 +50,12 @@ def build(force: bool = False, verbose: bool = True, out: str = OUT) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(lambda s: _compile(s, force, verbose), sources()))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
+    # exports: exactly the C ABI (include/gnan_hip.h).  -fvisibility=hidden hides the library's own C++ helpers; the version
+    # script also keeps template instantiations of the standard library (default visibility by their namespace) local
+    vs = os.path.join(OBJ_DIR, "exports.map")
+    with open(vs, "w") as f:
+        f.write("{ global: gnan_*; local: *; };\n")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

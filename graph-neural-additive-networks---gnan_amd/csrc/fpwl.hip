@@ -308,7 +308,7 @@ __device__ __forceinline__ void load_tree_tables(const Params& p, float* smem, c
   const int tid = threadIdx.x;
   for (int i = tid; i < FG * P2; i += BS) {
     const int f = i >> NSTEP, k = i & (P2 - 1);
-    float v = INFINITY;
+    float v = __builtin_nanf("");          // padding: NaN <= x is false for EVERY x (+inf <= +inf would be true)
     if (k) {
       const int j = tree_sorted_index<NSTEP>(k);
       if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
   __syncthreads();
   for (int i = tid; i < FG * P2; i += BS) {
     const int f = i >> NSTEP, k = i & (P2 - 1);
-    float v = INFINITY;
+    float v = __builtin_nanf("");          // padding: NaN <= x is false for EVERY x (+inf <= +inf would be true)
     if (k) {
       const int j = tree_sorted_index<NSTEP>(k);
       if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
   } else {
     for (int i = tid; i < FG * P2; i += BS) {
       const int f = i >> NSTEP, k = i & (P2 - 1);
-      float v = INFINITY;
+      float v = __builtin_nanf("");          // padding: NaN <= x is false for EVERY x (+inf <= +inf would be true)
       if (k) {
         const int j = tree_sorted_index<NSTEP>(k);
         if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];
@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(BS) void fpwl_locate_tree_kernel(const LocateTreePa
   __syncthreads();
   for (int i = tid; i < FG * P2; i += BS) {
     const int f = i >> NSTEP, k = i & (P2 - 1);
-    float v = INFINITY;
+    float v = __builtin_nanf("");          // padding: NaN <= x is false for EVERY x (+inf <= +inf would be true)
     if (k) {
       const int j = tree_sorted_index<NSTEP>(k);
       if (j < s_off[f + 1] - s_off[f]) v = p.anchor[base + s_off[f] + j];

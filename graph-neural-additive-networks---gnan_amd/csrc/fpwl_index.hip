@@ -5,19 +5,26 @@
 // uniform grid of B buckets over the range the data actually takes (`range`, one column min / max pass per feature
 // matrix: a HINT — any x is looked up exactly, see below), and a table entry per bucket:
 //     key(x)   = (int) med3(fma(x, ks, ko), 0, B - 1)                 monotone non-decreasing in x
-//     entry[k] = 4 * #{ breakpoints a_j : key(a_j) < k }  |  (more than KF breakpoints have key == k ? 1 : 0)
+//     entry[k] = 4 * #{ breakpoints a_j : key(a_j) < k }  |  code(#{ a_j : key(a_j) == k }) << 14
 // key is monotone, so every breakpoint with key(a_j) < key(x) is <= x and every one with key(a_j) > key(x) is > x:
-// the piece of x is entry[key(x)] / 4 plus the number of the (at most KF) breakpoints INSIDE its bucket that are <= x —
-// found by comparing x with the next KF anchors of the sorted array (one ds_read2_b32 for KF = 1).  The builder computes
-// key(a_j) with the very same instructions, so the look-up is exact for every float x whatever the range hint was; a
-// bucket holding more than KF breakpoints (typically the two end buckets, which take everything outside the hinted
-// range) is flagged and its lanes take a plain binary search over the sorted anchors (rare; wave-level branch).
-// Per look-up: 3 dependent LDS reads (entry, anchors, (val, slope)) and ~13 vector instructions; same formula
+// the piece of x is entry[key(x)] / 4 plus the number of the breakpoints INSIDE its bucket that are <= x — found by
+// comparing x with the next anchors of the sorted array.  The builder computes key(a_j) with the very same
+// instructions, so the look-up is exact for every float x whatever the range hint was.  code 0: at most one breakpoint
+// in the bucket — one ds_read2_b32 (the piece's anchor and the next) and one comparison, the straight-line path; code 1:
+// two or three (the pair a, nextafter(a) that stands behind a kink some input sits on EXACTLY, csrc/pwl_build.hip, is
+// the common case: zero biases and one-hot features put most inputs there) — a second ds_read2_b32 and two more
+// comparisons under a wave-level branch; code 3: more (typically the two end buckets, which take everything outside
+// the hinted range) — a plain binary search over the sorted anchors, rare.
+// Per look-up: 3 dependent LDS reads (entry, anchors, (val, slope)) and ~16 vector instructions; same formula
 // val + slope * (x - anchor) on the same piece as fpwl_fast_kernel, hence bit-identical results.
 //
-// Mapping as fpwl_fast_kernel: workgroup = (node block, 16-feature group), thread = (node, 4 features), one 16-B load
-// of x and one 16-B store per node and thread; linear workgroup ids are mapped so that the groups of a node block run on
-// the same XCD (they share the block's 128-B lines of x in that L2); column sums / feature sum / kept pieces in the epilogue.
+// Mapping: workgroup = (node block, group of FGX features), thread = (node, 4 features), one 16-B load of x and one 16-B
+// store per node and thread.  FGX = 32 where F allows: a node's 32 features are ONE full 128-byte line of x and of the
+// output, so a wave reads and writes whole lines and no line is shared between workgroups — with the look-up itself this
+// cheap the kernel is bound by the copy pattern, and tools/lookup_ceiling.hip (y = 2x with these mappings, no look-up)
+// gives 0.98-1.18 ms for half lines (FGX = 16, what fpwl_fast_kernel does) against 0.90 ms for full lines on the
+// 10M x 64 matrix (a framework element-wise kernel: 0.86).  The x rows of the next round are requested before the
+// current round's look-ups.  Column sums / feature sum / kept pieces in the epilogue as in fpwl_fast_kernel.
 #include "common.hpp"
 
 #include <cstdint>
@@ -25,7 +32,7 @@
 
 namespace {
 
-constexpr int FG = 16, FPT = 4, TPN = FG / FPT;
+constexpr int FPT = 4;
 
 struct IndexParams {
   const float* x;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void range_finish_kernel(const int* __restrict
 // ---------------------------------------------------------------------------------------------
 template <int LOGB>
 __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restrict__ off, const float* __restrict__ anchor,
-                                                          const float* __restrict__ range, int max_fast,
+                                                          const float* __restrict__ range,
                                                           uint16_t* __restrict__ table, float* __restrict__ key,
                                                           int32_t* __restrict__ stats) {
   constexpr int B = 1 << LOGB;
@@ -150,14 +157,14 @@ __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restr
     int run = part[tid] - s;
     for (int i = 0; i < PER; ++i) {
       const int k = tid * PER + i, c = cnt[k];
-      const int slow = c > max_fast;
-      table[static_cast<int64_t>(f) * B + k] = static_cast<uint16_t>(run * 4 | slow);
-      if (slow && k > 0 && k < B - 1) ++flagged;
+      const int code = c <= 1 ? 0 : (c <= 3 ? 1 : 3);
+      table[static_cast<int64_t>(f) * B + k] = static_cast<uint16_t>(run * 4 | code << 14);
+      if (code == 3 && k > 0 && k < B - 1) ++flagged;
       run += c;
     }
   }
   if (tid == 0) { key[2 * f] = ks; key[2 * f + 1] = ko; }
-  if (stats) {                                  // flagged buckets inside the hinted range: the fast path's health
+  if (stats) {                                  // searched buckets inside the hinted range: the fast path's health
     __syncthreads();
     part[tid] = flagged;
     __syncthreads();
@@ -171,13 +178,14 @@ __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restr
 
 // ---------------------------------------------------------------------------------------------
 // the look-up
-// LDS image of a feature group: [FG][B] uint16 entries | anchors, feature f's run at s_off[f] + f * KF (KF +inf behind
+// LDS image of a feature group: [FG][B] uint16 entries | anchors, feature f's run at s_off[f] + f * KF (KF NaNs behind
 // every feature: the correction reads never see the next feature's anchors) | [tot] (val, slope) pairs | s_off[FG + 1]
 // ---------------------------------------------------------------------------------------------
-template <bool SUM, bool OUT16, int KF, int LOGB, int BS>
+template <int FG, bool SUM, bool OUT16, int LOGB, int BS>
 __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
-  static_assert(KF == 1 || KF == 3, "anchors read per look-up: 2 or 4");
-  constexpr int B = 1 << LOGB, NODES = BS / TPN;
+  constexpr int KF = 3;                             // NaNs behind every feature's anchors: what the comparisons may read
+  static_assert(FG == 16 || FG == 32, "feature groups of 16 (half lines) or 32 (full lines)");
+  constexpr int TPN = FG / FPT, B = 1 << LOGB, NODES = BS / TPN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)smem));
   constexpr int kTableBytes = FG * B * 2;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
   const int nl = tid / TPN;
   int64_t nb = blockIdx.x;
   int g_first = 0;
-  if (!SUM) {                                       // (id % 8) = XCD, groups of a node block adjacent inside it
+  if (!SUM) {                                       // (id % 8) = XCD, groups of a node block adjacent inside it (FG = 16: shared lines)
     const int64_t id = blockIdx.x;
     g_first = static_cast<int>((id >> 3) % p.n_groups);
     nb = ((id >> 3) / p.n_groups) * 8 + (id & 7);
@@ -216,13 +224,13 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
       for (int i = tid; i < kTableBytes / 16; i += BS) dst[i] = src[i];
     }
     __syncthreads();
-    for (int i = tid; i < tot + FG * KF; i += BS) an_l[i] = INFINITY;
+    for (int i = tid; i < tot + FG * KF; i += BS) an_l[i] = __builtin_nanf("");    // x >= NaN is false for every x, +inf included
     __syncthreads();
     for (int i = tid; i < tot; i += BS) {
-      // feature of global piece i: the largest f with s_off[f] <= i (16 features: a 4-step search on the LDS offsets)
+      // feature of global piece i: the largest f with s_off[f] <= i (a 4- or 5-step search on the LDS offsets)
       int f = 0;
 #pragma unroll
-      for (int st = 8; st > 0; st >>= 1) f += (s_off[f + st] <= i) ? st : 0;
+      for (int st = FG / 2; st > 0; st >>= 1) f += (s_off[f + st] <= i) ? st : 0;
       an_l[i + f * KF] = p.anchor[base + i];
       vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
     }
@@ -253,35 +261,37 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
       float an[FPT];
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const int a = a0[f] + e[f];                 // (a flagged lane's odd address is never used)
+        const int a = a0[f] + (e[f] & 0x3fff);
         const float A0 = lds_f32(a), A1 = lds_f32(a + 4);
-        int adv = xv[f] >= A1 ? 4 : 0;
-        float av = xv[f] >= A1 ? A1 : A0;
-        if constexpr (KF == 3) {
-          const float A2 = lds_f32(a + 8), A3 = lds_f32(a + 12);
-          adv += xv[f] >= A2 ? 4 : 0;
-          av = xv[f] >= A2 ? A2 : av;
-          adv += xv[f] >= A3 ? 4 : 0;
-          av = xv[f] >= A3 ? A3 : av;
-        }
-        pa[f] = a + adv;
-        an[f] = av;
+        pa[f] = a + (xv[f] >= A1 ? 4 : 0);
+        an[f] = xv[f] >= A1 ? A1 : A0;
       }
-      if ((e[0] | e[1] | e[2] | e[3]) & 1) {        // some bucket holds more breakpoints than the fast path compares: search
+      if ((e[0] | e[1] | e[2] | e[3]) >> 14) {      // some bucket holds more than one breakpoint
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
-          if (e[f] & 1) {
-            const int fg = q * FPT + f;
-            const float* A = an_l + s_off[fg] + fg * KF;
-            const int pn = s_off[fg + 1] - s_off[fg] - 1;
-            int idx = 0;
-            for (int step = p.step0; step > 0; step >>= 1) {
-              const int j = idx + step;
-              const int jj = j <= pn ? j : 0;
-              idx = (j <= pn && A[jj] <= xv[f]) ? j : idx;
+          if (e[f] >> 14) {                         // two or three: compare with the next two anchors as well
+            const int a = a0[f] + (e[f] & 0x3fff);
+            const float A2 = lds_f32(a + 8), A3 = lds_f32(a + 12);
+            pa[f] += (xv[f] >= A2 ? 4 : 0) + (xv[f] >= A3 ? 4 : 0);
+            an[f] = xv[f] >= A3 ? A3 : (xv[f] >= A2 ? A2 : an[f]);
+          }
+        }
+        if (((e[0] & e[0] >> 1) | (e[1] & e[1] >> 1) | (e[2] & e[2] >> 1) | (e[3] & e[3] >> 1)) >> 14) {   // code 3 somewhere
+#pragma unroll
+          for (int f = 0; f < FPT; ++f) {
+            if ((e[f] >> 14) == 3) {                // more: search the feature's sorted anchors
+              const int fg = q * FPT + f;
+              const float* A = an_l + s_off[fg] + fg * KF;
+              const int pn = s_off[fg + 1] - s_off[fg] - 1;
+              int idx = 0;
+              for (int step = p.step0; step > 0; step >>= 1) {
+                const int j = idx + step;
+                const int jj = j <= pn ? j : 0;
+                idx = (j <= pn && A[jj] <= xv[f]) ? j : idx;
+              }
+              pa[f] = a0[f] + 4 * idx;
+              an[f] = A[idx];
             }
-            pa[f] = a0[f] + 4 * idx;
-            an[f] = A[idx];
           }
         }
       }
@@ -296,7 +306,9 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
           unsigned packed = 0u;
 #pragma unroll
           for (int f = 0; f < FPT; ++f) packed |= static_cast<unsigned>((pa[f] - a0[f]) >> 2) << (8 * f);
-          *reinterpret_cast<unsigned*>(p.piece_out + (static_cast<int64_t>(g) * p.n + n) * FG + q * FPT) = packed;
+          // (16-feature groups whatever FG is: the layout gnan_fpwl_moments_fixed reads)
+          constexpr int G16 = FG / 16;
+          *reinterpret_cast<unsigned*>(p.piece_out + (static_cast<int64_t>(g * G16 + q / 4) * p.n + n) * 16 + (q % 4) * FPT) = packed;
         }
         float acc = ((y[0] + y[1]) + y[2]) + y[3];          // fpwl_fast_kernel's association: bit-identical sums
 #pragma unroll
@@ -372,67 +384,90 @@ int cu_count_() {
   return cus;
 }
 
-size_t image_bytes(int logb, int tot_cap, int kf) {
-  const size_t a_words = (static_cast<size_t>(tot_cap) + FG * kf + 1) & ~static_cast<size_t>(1);
-  return (static_cast<size_t>(FG) << logb) * 2 + a_words * 4 + static_cast<size_t>(tot_cap) * 8 + (FG + 1) * 4;
+struct IndexPlan {
+  bool ok;
+  int fg, logb, bs, tot_cap, npb;
+  size_t lds;
+};
+
+size_t image_bytes(int fg, int logb, int tot_cap) {
+  const size_t a_words = (static_cast<size_t>(tot_cap) + fg * 3 + 1) & ~static_cast<size_t>(1);
+  return (static_cast<size_t>(fg) << logb) * 2 + a_words * 4 + static_cast<size_t>(tot_cap) * 8 + (fg + 1) * 4;
+}
+
+// Which instance serves these arguments, if any (one channel, whole feature groups, 16-byte aligned rows), and its node
+// block: the LDS image (bucket entries + tables, 50-100 KB) is worth ~500 look-up rows, so blocks should be large, and
+// the grid should be whole rounds of the resident workgroups.
+IndexPlan index_plan(const gnan_fpwl_args* a) {
+  IndexPlan pl{};
+  auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
+  if (!a->index_table || !a->index_key || a->C != 1 || a->F % 16 != 0 || a->x_stride % 4 != 0 || !aligned(a->x)) return pl;
+  const int B = a->index_buckets;
+  if (B != 256 && B != 512 && B != 1024 && B != 2048) return pl;
+  if (!aligned(a->index_table) || a->max_pieces > 4096) return pl;          // entries hold 4 * piece + flag in 16 bits
+  if (!a->sum_features && (a->out_stride % 4 != 0 || !aligned(a->out))) return pl;
+  if (a->sum_features && a->out_dtype != GNAN_F32) return pl;
+  if (a->piece_out && (!a->sum_features || a->max_pieces > 256)) return pl;
+  pl.logb = 6;
+  while ((1 << pl.logb) < B) ++pl.logb;
+  // full lines where the feature count allows and the image of a 32-feature group fits one workgroup per CU
+  pl.fg = (a->F % 32 == 0 && !(a->flags & GNAN_FPWL_INDEX_HALF_LINES)) ? 32 : 16;
+  pl.tot_cap = a->max_group_pieces * (pl.fg / 16);      // (max_group_pieces: the largest run of 16 consecutive features)
+  pl.lds = image_bytes(pl.fg, pl.logb, pl.tot_cap);
+  if (pl.fg == 32 && pl.lds > 150 * 1024) {
+    pl.fg = 16;
+    pl.tot_cap = a->max_group_pieces;
+    pl.lds = image_bytes(16, pl.logb, pl.tot_cap);
+  }
+  if (pl.lds > 150 * 1024) return pl;
+  // measured on the 10M x 64 matrix (tools/lookup_ab.py): per-feature rows 0.99 ms / bf16 rows 0.82 ms with 512 threads
+  // against 1.01 / 0.95 with 1024; the feature sum the other way round (0.97 against 0.69: its 8-lane sums and the
+  // read-modify-write of the output want the 16 waves)
+  pl.bs = 512;
+  if (pl.fg == 32 && a->sum_features) pl.bs = 1024;
+  if (pl.fg == 32 && (a->flags & GNAN_FPWL_INDEX_BS512)) pl.bs = 512;
+  if (pl.fg == 32 && (a->flags & GNAN_FPWL_INDEX_BS1024)) pl.bs = 1024;
+  if (a->n < 262144) {
+    const int64_t npb = (a->n / 1024 + 255) / 256 * 256;
+    pl.npb = static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
+  } else {
+    int per_cu = static_cast<int>((160 * 1024) / pl.lds);
+    if (per_cu > 2048 / pl.bs) per_cu = 2048 / pl.bs;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = static_cast<int64_t>(cu_count_()) * per_cu;
+    const int64_t groups = a->sum_features ? 1 : a->F / pl.fg;
+    const int unit = 128, overhead = 500;
+    int64_t best_cost = -1;
+    int best = 4096;
+    for (int npb = 2048; npb <= 8192; npb += unit) {
+      const int64_t wgs = (a->n + npb - 1) / npb * groups;
+      const int64_t rounds = (wgs + resident - 1) / resident;
+      const int64_t cost = rounds * (npb + overhead);
+      if (best_cost < 0 || cost < best_cost || (cost == best_cost && npb > best)) { best_cost = cost; best = npb; }
+    }
+    pl.npb = best;
+  }
+  pl.ok = true;
+  return pl;
 }
 
 }  // namespace
 
-// Nodes per workgroup of the direct-index look-up (also what gnan_fpwl_total_workspace_bytes sizes the column-sum
-// partials with): the LDS image (bucket entries + tables, ~50 KB) is worth ~500 look-up rows, x lines are shared between
-// the groups of a node block in L2, and the grid should be whole rounds of the resident workgroups.
-int gnan_index_nodes_per_block(const gnan_fpwl_args* a) {
-  if (a->n < 262144) {
-    const int64_t npb = (a->n / 1024 + 255) / 256 * 256;
-    return static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
-  }
-  int logb = 6;
-  while ((1 << logb) < a->index_buckets) ++logb;
-  const size_t lds = image_bytes(logb, a->max_group_pieces, a->index_max_fast >= 3 ? 3 : 1);
-  const int bs = 512;
-  int per_cu = static_cast<int>((160 * 1024) / lds);
-  if (per_cu > 2048 / bs) per_cu = 2048 / bs;
-  if (per_cu < 1) per_cu = 1;
-  const int64_t resident = static_cast<int64_t>(cu_count_()) * per_cu;
-  const int64_t groups = a->sum_features ? 1 : (a->F + FG - 1) / FG;
-  const int unit = 128, overhead = 500;
-  int64_t best_cost = -1;
-  int best = 4096;
-  for (int npb = 2048; npb <= 8192; npb += unit) {
-    const int64_t wgs = (a->n + npb - 1) / npb * groups;
-    const int64_t rounds = (wgs + resident - 1) / resident;
-    const int64_t cost = rounds * (npb + overhead);
-    if (best_cost < 0 || cost < best_cost || (cost == best_cost && npb > best)) { best_cost = cost; best = npb; }
-  }
-  return best;
-}
+// (called by gnan_fpwl_fwd / gnan_fpwl_total_workspace_bytes, csrc/fpwl.hip)
+bool gnan_index_applies(const gnan_fpwl_args* a) { return index_plan(a).ok; }
+int gnan_index_nodes_per_block(const gnan_fpwl_args* a) { return index_plan(a).npb; }
 
-// Does the direct-index kernel serve these arguments?  (one channel, whole 16-feature groups, 16-byte aligned rows)
-bool gnan_index_applies(const gnan_fpwl_args* a) {
-  auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
-  if (!a->index_table || !a->index_key || a->C != 1 || a->F % FG != 0 || a->x_stride % 4 != 0 || !aligned(a->x)) return false;
-  const int B = a->index_buckets;
-  if (B != 256 && B != 512 && B != 1024 && B != 2048) return false;
-  if (!aligned(a->index_table)) return false;
-  if (a->max_pieces > 4096) return false;                                  // entries hold 4 * piece + flag in 16 bits
-  if (!a->sum_features && (a->out_stride % 4 != 0 || !aligned(a->out))) return false;
-  if (a->sum_features && a->out_dtype != GNAN_F32) return false;
-  if (a->piece_out && (!a->sum_features || a->max_pieces > 256)) return false;
-  int logb = 6;
-  while ((1 << logb) < B) ++logb;
-  return image_bytes(logb, a->max_group_pieces, a->index_max_fast >= 3 ? 3 : 1) <= 150 * 1024;
-}
-
-// (called by gnan_fpwl_fwd, csrc/fpwl.hip, after its checks; col_partial: the column-sum partials or NULL)
+// col_partial: the column-sum partials ([node blocks][F] doubles) or NULL
 int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st) {
+  const IndexPlan pl = index_plan(a);
+  if (!pl.ok) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_index: arguments outside what the direct-index kernel serves");
   IndexParams p;
   p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F;
   p.off = a->off; p.anchor = a->anchor; p.val = a->val; p.slope = a->slope;
   p.table = a->index_table; p.key = a->index_key;
-  p.n_groups = a->F / FG;
-  p.nodes_per_block = gnan_index_nodes_per_block(a);
-  p.tot_cap = a->max_group_pieces;
+  p.n_groups = a->F / pl.fg;
+  p.nodes_per_block = pl.npb;
+  p.tot_cap = pl.tot_cap;
   int step0 = 0;
   while ((step0 ? step0 * 2 : 1) <= a->max_pieces - 1) step0 = step0 ? step0 * 2 : 1;
   p.step0 = step0;
@@ -441,12 +476,8 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
   p.col_partial = col_partial;
   p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
   p.piece_out = a->piece_out;
-  const int kf = a->index_max_fast >= 3 ? 3 : 1;
-  int logb = 6;
-  while ((1 << logb) < a->index_buckets) ++logb;
-  constexpr int BS = 512;
-  size_t lds = image_bytes(logb, p.tot_cap, kf);
-  if (col_partial && lds < BS * 4 * sizeof(float)) lds = BS * 4 * sizeof(float);
+  size_t lds = pl.lds;
+  if (col_partial && lds < static_cast<size_t>(pl.bs) * 4 * sizeof(float)) lds = static_cast<size_t>(pl.bs) * 4 * sizeof(float);
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
   const int64_t wgs = a->sum_features ? bx : (bx + 7) / 8 * 8 * p.n_groups;
   if (wgs > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
@@ -456,23 +487,28 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
                                          static_cast<int>(lds));
       if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl_index: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(wgs)), dim3(BS), lds, st, p);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(wgs)), dim3(pl.bs), lds, st, p);
     return gnan::check_launch("fpwl_index_kernel");
   };
-  auto by_mode = [&](auto kf_c, auto lb_c) {
-    constexpr int K = decltype(kf_c)::value, LB = decltype(lb_c)::value;
-    if (a->out_dtype == GNAN_BF16) return go(fpwl_index_kernel<false, true, K, LB, BS>);
-    return a->sum_features ? go(fpwl_index_kernel<true, false, K, LB, BS>) : go(fpwl_index_kernel<false, false, K, LB, BS>);
+  auto by_mode = [&](auto fg_c, auto bs_c, auto lb_c) {
+    constexpr int G = decltype(fg_c)::value, S = decltype(bs_c)::value, LB = decltype(lb_c)::value;
+    if (a->out_dtype == GNAN_BF16) return go(fpwl_index_kernel<G, false, true, LB, S>);
+    return a->sum_features ? go(fpwl_index_kernel<G, true, false, LB, S>) : go(fpwl_index_kernel<G, false, false, LB, S>);
   };
-  auto by_b = [&](auto kf_c) {
-    switch (logb) {
-      case 8: return by_mode(kf_c, std::integral_constant<int, 8>{});
-      case 9: return by_mode(kf_c, std::integral_constant<int, 9>{});
-      case 10: return by_mode(kf_c, std::integral_constant<int, 10>{});
-      default: return by_mode(kf_c, std::integral_constant<int, 11>{});
+  auto by_kf = [&](auto fg_c, auto bs_c) {
+    switch (pl.logb) {
+      case 8: return by_mode(fg_c, bs_c, std::integral_constant<int, 8>{});
+      case 9: return by_mode(fg_c, bs_c, std::integral_constant<int, 9>{});
+      case 10: return by_mode(fg_c, bs_c, std::integral_constant<int, 10>{});
+      default: return by_mode(fg_c, bs_c, std::integral_constant<int, 11>{});
     }
   };
-  return kf == 3 ? by_b(std::integral_constant<int, 3>{}) : by_b(std::integral_constant<int, 1>{});
+  using I16 = std::integral_constant<int, 16>;
+  using I32 = std::integral_constant<int, 32>;
+  using S512 = std::integral_constant<int, 512>;
+  using S1024 = std::integral_constant<int, 1024>;
+  if (pl.fg == 32) return pl.bs == 1024 ? by_kf(I32{}, S1024{}) : by_kf(I32{}, S512{});
+  return by_kf(I16{}, S512{});
 }
 
 extern "C" int gnan_feature_range(const float* x, int64_t n, int64_t x_stride, int32_t F, float* range, void* workspace,
@@ -503,10 +539,9 @@ extern "C" int gnan_feature_range(const float* x, int64_t n, int64_t x_stride, i
 extern "C" int gnan_fpwl_index_build(const gnan_fpwl_index_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "fpwl_index_build: null args");
   GNAN_REQUIRE(a->F >= 1 && a->off && a->anchor && a->range && a->table && a->key, "fpwl_index_build: null pointer / bad sizes");
-  GNAN_REQUIRE(a->max_fast == 1 || a->max_fast == 3, "fpwl_index_build: max_fast must be 1 or 3");
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(a->F), dim3(256), 0, st, a->off, a->anchor, a->range, a->max_fast, a->table, a->key, a->stats);
+    hipLaunchKernelGGL(kernel, dim3(a->F), dim3(256), 0, st, a->off, a->anchor, a->range, a->table, a->key, a->stats);
     return gnan::check_launch("index_build_kernel");
   };
   switch (a->buckets) {

@@ -447,3 +447,84 @@ def halo_exchange_forward(x_own: torch.Tensor, xplan: ExchangePlan, stacked, lut
                          reduce_channels=out_channels if order == "reference" else 0, total_rows=plan.n_own, **shared)
     mark("spmm")
     return Y
+
+
+# =============================================================================
+# a rank's inference loop without the host in it
+# =============================================================================
+class SharePipeline:
+    """Inference loop of one rank's share, replayed from hipGraphs: ``step()`` is ONE graph launch.
+
+    A share of the 10M-node graph on 8 ranks is ~0.9 ms of kernels behind ~12 launches; issued from Python the loop is
+    bound by the host.  Two captured graphs alternate.  Graph ``p`` holds the whole forward — look-up from table set ``p``,
+    the all-reduce of the column sums (captured with the RCCL backend; the aggregation does not wait for it), aggregation —
+    and, on a forked branch that runs under them, everything the NEXT forward needs built from the weights: its tables
+    into set ``1 - p`` (``functional.TablePrefetch``), their direct-index tables and the check that they fit the captured
+    look-up.  Every forward still consumes a build of its own, made from the weights as they are while the previous
+    forward runs — an inference loop.  :meth:`tripped` reads the guard the checks set.
+
+    ``forward(tables, marks)`` is the share's forward given pre-built tables (e.g. a ``halo_recompute_forward`` closure
+    passing both on).  ``fork_at``: the stage mark at which the branch starts ("start": under the look-up, "fmlp": under
+    the aggregation).  ``x``: the feature matrix the look-up reads (its value range positions the direct-index grid).
+    Raises ``graphed.CaptureFailed`` when the step cannot be captured (a backend whose collectives need the host, e.g.
+    gloo); the caller then keeps its eager loop."""
+
+    def __init__(self, forward: Callable, stacked, x: Optional[torch.Tensor] = None, warmup: int = 2, fork_at: str = "start"):
+        from . import functional, pwl
+        from .graphed import CaptureFailed, GraphedCallable
+        self.prefetch = functional.TablePrefetch(stacked)
+        if not self.prefetch.applies:
+            raise CaptureFailed("the table build of these shape functions is not a kernel (L > 3 or H > 128)")
+        st = self.prefetch.stacked
+        dev = st.w_last.device
+        self.bufs = [pwl.table_buffers(st) for _ in range(2)]
+        self.guard = torch.zeros(1, dtype=torch.float32, device=dev)
+        x_range = functional._feature_range(x) if (x is not None and st.C == 1) else None
+        self.index = [None, None]
+        if x_range is not None:
+            self.index = [(torch.empty((st.F, functional.INDEX_BUCKETS), dtype=torch.int16, device=dev),
+                           torch.empty((st.F, 2), dtype=torch.float32, device=dev)) for _ in range(2)]
+        main = torch.cuda.current_stream(dev)
+
+        def launch(slot, guard=None):
+            return self.prefetch.launch(buffers=self.bufs[slot], x_range=x_range, index_buffers=self.index[slot], guard=guard)
+
+        first = launch(0)
+        main.wait_stream(self.prefetch.side)
+        with torch.no_grad():
+            forward(first, None)                            # eager: table sizes become known (the speculative plan)
+        self.pending = [first, None]
+        self.graphs = []
+        for p in (0, 1):
+            if p == 1:
+                # graph 1 looks up from set 1: an eager build of it for the warm-up forwards (what graph 0's CAPTURE left
+                # in pending[1] describes a build that has not run)
+                self.pending[1] = launch(1)
+                main.wait_stream(self.prefetch.side)
+
+            def fn(p=p):
+                made = []
+
+                def marks(name):
+                    if name == fork_at and not made:
+                        made.append(launch(1 - p, self.guard))          # forked branch: the next forward's tables
+                with torch.no_grad():
+                    out = forward(self.pending[p], marks)
+                if not made:
+                    made.append(launch(1 - p, self.guard))
+                torch.cuda.current_stream(dev).wait_stream(self.prefetch.side)   # join
+                self.pending[1 - p] = made[0]
+                return out
+            self.graphs.append(GraphedCallable(fn, warmup=warmup, guard=self.guard))
+        self.parity = 0          # set 0 holds a build of the current weights: graph 1's eager warm-ups wrote it last
+        self.guard.zero_()
+
+    def step(self) -> torch.Tensor:
+        """One forward; the returned tensor is overwritten by the next-but-one call."""
+        out = self.graphs[self.parity].replay()
+        self.parity ^= 1
+        return out
+
+    def tripped(self) -> bool:
+        """Did any replay meet tables that outgrew the captured look-up (its output is then not to be trusted)?"""
+        return bool(self.guard.item() != 0)

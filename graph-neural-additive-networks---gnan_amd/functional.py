@@ -92,9 +92,12 @@ MOMENTS_GENERAL = os.environ.get("GNAN_MOMENTS_GENERAL", "0") == "1"   # A/B aid
 LOCATE_SORTED = bool(os.environ.get("GNAN_LOCATE_SORTED"))              # A/B aid: the sorted-array search where the tree search applies
 
 
+INDEX_FLAGS = 0               # A/B aid: _lib.FPWL_INDEX_HALF_LINES / FPWL_INDEX_BS512 for the direct-index look-up
+
+
 def _fpwl_flags() -> int:
     """``gnan_fpwl_args.flags`` from this module's switches (the library itself reads no environment variables)."""
-    return (_lib.FPWL_MOMENTS_GENERAL if MOMENTS_GENERAL else 0) | (_lib.FPWL_LOCATE_SORTED if LOCATE_SORTED else 0)
+    return (_lib.FPWL_MOMENTS_GENERAL if MOMENTS_GENERAL else 0) | (_lib.FPWL_LOCATE_SORTED if LOCATE_SORTED else 0) | INDEX_FLAGS
 
 
 FPWL_ROWS = os.environ.get("GNAN_FPWL_ROWS", "1") != "0"   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
@@ -138,8 +141,7 @@ def _fpwl_locate(x: torch.Tensor, t, a):
 
 
 INDEX_LOOKUP = True           # one channel, whole 16-feature groups: find the piece by arithmetic (csrc/fpwl_index.hip), not by a search
-INDEX_BUCKETS = 1024          # cells per feature over the range its values take
-INDEX_MAX_FAST = 1            # breakpoints per cell resolved by comparisons (1 or 3); fuller cells are searched
+INDEX_BUCKETS = 512           # cells per feature over the range its values take (82 KB of LDS per 32-feature group)
 INDEX_MIN_NODES = 1 << 16     # below, the look-up is latency-bound either way and the range pass would not pay
 _RANGE_CACHE = TensorKeyedCache(8)    # feature matrix (object identity + version) -> [F, 2] column minima / maxima
 _RANGE_CHURN = {}                     # (n, F) -> consecutive misses of that cache
@@ -178,12 +180,11 @@ def _fpwl_index(a: "_lib.FpwlArgs", x: torch.Tensor, t, x_range: torch.Tensor) -
         return None
     table = torch.empty((F, INDEX_BUCKETS), dtype=torch.int16, device=x.device)
     key = torch.empty((F, 2), dtype=torch.float32, device=x.device)
-    ia = _lib.FpwlIndexArgs(off=_lib.ptr(t.off), anchor=_lib.ptr(t.anchor), F=F, buckets=INDEX_BUCKETS,
-                            max_fast=INDEX_MAX_FAST, range=_lib.ptr(x_range), table=_lib.ptr(table), key=_lib.ptr(key),
+    ia = _lib.FpwlIndexArgs(off=_lib.ptr(t.off), anchor=_lib.ptr(t.anchor), F=F, buckets=INDEX_BUCKETS, range=_lib.ptr(x_range), table=_lib.ptr(table), key=_lib.ptr(key),
                             stats=None)
     _lib.check(_lib.lib().gnan_fpwl_index_build(ia, _lib.stream_of(x)), "gnan_fpwl_index_build")
     a.index_table, a.index_key = _lib.ptr(table), _lib.ptr(key)
-    a.index_buckets, a.index_max_fast = INDEX_BUCKETS, INDEX_MAX_FAST
+    a.index_buckets = INDEX_BUCKETS
     return [table, key]
 
 
@@ -192,7 +193,8 @@ LOCATED_KEEP_MAX_BYTES = 2 << 30   # (piece, dx) of a forward are kept for its b
 
 
 def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = False, out_dtype=torch.float32,
-                 total_rows: Optional[int] = None, located: Optional[list] = None, x_range: Optional[torch.Tensor] = None):
+                 total_rows: Optional[int] = None, located: Optional[list] = None, x_range: Optional[torch.Tensor] = None,
+                 index=None):
     """Evaluate pre-built piecewise-linear tables (``pwl.build_tables``) with ``gnan_fpwl_fwd``.
     With ``want_total`` returns ``(out, total)`` where ``total[w] = sum_n out[n, w]`` comes out of the same pass
     when the kernel's fast path applies (one output channel, whole feature groups), else ``total`` is None."""
@@ -230,7 +232,11 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
                       out=_lib.ptr(out), out_stride=out.stride(0),
                       out_dtype=_lib.GNAN_BF16 if out_dtype == torch.bfloat16 else _lib.GNAN_F32, flags=_fpwl_flags())
-    index_keep = _fpwl_index(a, x, t, x_range)          # noqa: F841  (alive until the look-up is queued)
+    if index is not None and a.C == 1 and t.features_per_group == 16 and F % 16 == 0:
+        # direct-index tables built ahead of time for THESE tables (TablePrefetch(x_range=...): on the side stream)
+        a.index_table, a.index_key, a.index_buckets = _lib.ptr(index[0]), _lib.ptr(index[1]), int(index[0].shape[1])
+    else:
+        index_keep = _fpwl_index(a, x, t, x_range)      # noqa: F841  (alive until the look-up is queued)
     total = None
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
@@ -350,13 +356,28 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
         stacked = StackedMLP(*[_c(t) for t in p[:6]], *p[6:])
 
         x_range = _feature_range(x) if p.C == 1 else None
+        index = getattr(prebuilt, "index", None) if prebuilt is not None else None
 
         def look_up(t):
             return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows,
-                                located=located, x_range=x_range) \
+                                located=located, x_range=x_range, index=index) \
                 if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype, located=located,
-                                                 x_range=x_range), None)
+                                                 x_range=x_range, index=index), None)
 
+        if prebuilt is not None and torch.cuda.is_current_stream_capturing():
+            # a captured inference step (distributed.SharePipeline): the tables sit in caller-owned buffers the PREVIOUS
+            # replay filled; sized like every captured look-up — from the last eager forward's counts — and guarded on the
+            # device (the replayer reads the guard, a tripped loop falls back to eager forwards)
+            guess = prebuilt.speculative()
+            if guess is None:
+                raise _lib.GnanHipError("graph capture needs one eager forward of this model first (table sizes unknown)")
+            res = look_up(guess)
+            CAPTURED_BUILDS.append((guess, stacked))
+            if CAPTURE_GUARD is not None and not getattr(prebuilt, "fit_checked", False):
+                _lib.check(_lib.lib().gnan_pwl_check_fit(_lib.ptr(prebuilt.meta), stacked.F, int(guess.features_per_group),
+                                                         int(guess.max_pieces), int(guess.max_group_pieces),
+                                                         _lib.ptr(CAPTURE_GUARD), _lib.stream_of(x)), "gnan_pwl_check_fit")
+            return res[0], guess, res[1]
         if prebuilt is not None:
             # tables of THESE weights queued earlier, possibly on another stream (TablePrefetch): wait for that stream's
             # build on the device, then look up as the speculative path does
@@ -455,7 +476,13 @@ class TablePrefetch:
         self.applies = hip_build_applies(self.stacked)
         self.side = torch.cuda.Stream(device=self.stacked.w_last.device) if self.applies else None
 
-    def launch(self):
+    def launch(self, buffers=None, x_range=None, index_buffers=None, guard=None):
+        """``buffers``: caller-owned outputs (``pwl.table_buffers``) instead of fresh ones — what a captured loop needs.
+        ``x_range`` (+ ``index_buffers = (table [F, B] int16, key [F, 2] float32)``): the direct-index tables of the look-up
+        are built right behind the tables, on the side stream too.  ``guard``: the tables are checked against the
+        speculative look-up sizes there as well (``gnan_pwl_check_fit``; a captured loop reads the flag afterwards).
+        Under a hipGraph capture all of it becomes a forked branch of the graph: the caller joins it
+        (``current_stream.wait_stream(prefetch.side)``) before the capture ends."""
         if not self.applies:
             return None
         from .pwl import build_tables_lazy
@@ -463,7 +490,22 @@ class TablePrefetch:
         self.side.wait_stream(main)               # the weights (and the allocator's reuse of freed blocks) are ordered
         self.slot = 1 + (getattr(self, "slot", 1) % 2)          # two builds can be in flight: alternate read-back buffers
         with torch.cuda.stream(self.side):
-            pending = build_tables_lazy(self.stacked, pinned_slot=self.slot)
+            pending = build_tables_lazy(self.stacked, pinned_slot=self.slot, buffers=buffers)
+            F = self.stacked.F
+            if x_range is not None and index_buffers is not None and self.stacked.C == 1 and F % 16 == 0:
+                table, key = index_buffers
+                ia = _lib.FpwlIndexArgs(off=_lib.ptr(pending.meta), anchor=_lib.ptr(pending.anchor), F=F,
+                                        buckets=int(table.shape[1]), range=_lib.ptr(x_range), table=_lib.ptr(table),
+                                        key=_lib.ptr(key), stats=None)
+                _lib.check(_lib.lib().gnan_fpwl_index_build(ia, _lib.stream_of(table)), "gnan_fpwl_index_build")
+                pending.index = (table, key)
+            if guard is not None:
+                spec = pending.speculative()
+                if spec is not None:
+                    _lib.check(_lib.lib().gnan_pwl_check_fit(_lib.ptr(pending.meta), F, int(spec.features_per_group),
+                                                             int(spec.max_pieces), int(spec.max_group_pieces),
+                                                             _lib.ptr(guard), _lib.stream_of(guard)), "gnan_pwl_check_fit")
+                    pending.fit_checked = True
         pending.owner_stream = self.side
         return pending
 

@@ -131,12 +131,31 @@ def _loss_of(loss_fn, outputs, labels):
     return loss_fn(outputs, labels)
 
 
-def _fused_kind(loss_fn, outputs):
-    """The loss as ``gnan_loss_step`` knows it, or None: stock torch then computes it (any other loss, CPU tensors)."""
+_LABEL_RANGE = None       # TensorKeyedCache: class labels (object identity + version) -> (min, max) as Python ints
+
+
+def _fused_kind(loss_fn, outputs, labels=None):
+    """The loss as ``gnan_loss_step`` knows it, or None: stock torch then computes it (any other loss, CPU tensors).
+    Cross entropy: ``gnan_loss_step`` averages over ALL rows it is given, so class labels outside ``[0, C)`` —
+    ``ignore_index`` rows (-100 by default), which torch skips and leaves out of the mean — keep the eager loss; the
+    range of a label tensor (the batch's ``y``: conservative for masked tasks) is read once per tensor object and version."""
     if not torch.is_tensor(outputs) or not outputs.is_cuda:
         return None
+    from . import _lib
     from .functional import loss_kind
-    return loss_kind(loss_fn, outputs)
+    kind = loss_kind(loss_fn, outputs)
+    if kind == _lib.LOSS_CROSS_ENTROPY and labels is not None and labels.numel():
+        global _LABEL_RANGE
+        if _LABEL_RANGE is None:
+            from ._cache import TensorKeyedCache
+            _LABEL_RANGE = TensorKeyedCache(32)
+        rng = _LABEL_RANGE.get((labels,))
+        if rng is None:
+            lo_hi = torch.stack([labels.min(), labels.max()]).tolist()
+            rng = _LABEL_RANGE.put((labels,), None, (int(lo_hi[0]), int(lo_hi[1])))
+        if rng[0] < 0 or rng[1] >= outputs.shape[1]:
+            return None
+    return kind
 
 
 def _hits(outputs, labels) -> torch.Tensor:
@@ -229,7 +248,7 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
         rec["fused"] = False
 
         def loss_of(outputs):
-            kind = _fused_kind(loss_fn, outputs)
+            kind = _fused_kind(loss_fn, outputs, data.y)
             if kind is not None:                     # selection, loss, its gradient and the hit count in one launch
                 from .functional import loss_step
                 rec["fused"] = True
@@ -409,7 +428,7 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
         outputs = model.forward(data)
         if isinstance(outputs, tuple):
             outputs = outputs[0]
-        kind = _fused_kind(loss_fn, outputs)
+        kind = _fused_kind(loss_fn, outputs, data.y)     # (the caller's label tensor: a stable object to remember the range of)
         if kind is not None and (not is_graph_task or outputs.shape[0] == labels.numel()):
             # gnan_loss_step: the mask's rows, the loss, its gradient, the hit count and the running totals in one launch
             from .functional import loss_step

@@ -278,7 +278,21 @@ def _pinned_meta(dev, n: int, slot: int = 0) -> torch.Tensor:
     return buf
 
 
-def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0):
+def table_buffers(p):
+    """Caller-owned output buffers of one table build (``_build_tables_hip(buffers=...)``): a loop that replays captured
+    look-ups needs its tables at fixed addresses (``distributed.SharePipeline`` alternates between two sets)."""
+    from . import _lib
+    dev = p.w_last.device
+    F, C = p.F, p.C
+    cap = min(1024, max(64, 4 * p.H) * (p.L - 1))
+    T = F * (cap + 1)
+    need = _lib.lib().gnan_pwl_build_scratch_bytes(F, C, cap)
+    return (torch.empty(T, dtype=torch.float32, device=dev), torch.empty((T, C), dtype=torch.float32, device=dev),
+            torch.empty((T, C), dtype=torch.float32, device=dev), torch.zeros(F + 2, dtype=torch.int32, device=dev),
+            torch.empty(need // 8 + 1, dtype=torch.float64, device=dev))
+
+
+def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0, buffers=None):
     """Tables by TWO kernel launches (``gnan_pwl_build``: a workgroup per feature finds the kinks and tabulates the
     network in float64, LDS-resident; a second tiny kernel packs the features back to back) and one
     device->host copy of the F+1 offsets.  Covers L in {2, 3}, H <= 128; same result as :func:`_build_padded`."""
@@ -286,13 +300,11 @@ def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0):
     dev = p.w_last.device
     F, C = p.F, p.C
     cap = min(1024, max(64, 4 * p.H) * (p.L - 1))
-    T = F * (cap + 1)
-    anchor = torch.empty(T, dtype=torch.float32, device=dev)
-    val = torch.empty((T, C), dtype=torch.float32, device=dev)
-    slope = torch.empty((T, C), dtype=torch.float32, device=dev)
-    meta = torch.zeros(F + 2, dtype=torch.int32, device=dev)          # off[F+1] | overflow
-    need = _lib.lib().gnan_pwl_build_scratch_bytes(F, C, cap)
-    scratch = torch.empty(need // 8 + 1, dtype=torch.float64, device=dev)
+    if buffers is None:
+        buffers = table_buffers(p)
+    else:
+        buffers[3].zero_()                                            # off[F+1] | overflow start from zero
+    anchor, val, slope, meta, scratch = buffers
     keepalive = [t if t is None else t.detach().float().contiguous() for t in p[:6]]
     w_mid = keepalive[2][0] if keepalive[2] is not None else None      # [1, F, H, H] -> [F, H, H]
     b_mid = keepalive[3][0] if keepalive[3] is not None else None
@@ -330,7 +342,7 @@ class _PendingTables:
         """Make ``stream`` wait (on the device) for this build if it was queued on another stream, and tell the allocator
         that the tables are used there."""
         owner = getattr(self, "owner_stream", None)
-        if owner is None or owner == stream:
+        if owner is None or owner == stream or self.done is None:     # (built inside a captured graph: ordered by its joins)
             return
         stream.wait_event(self.done)
         for t in (self.meta, self.anchor, self.val, self.slope):
@@ -390,9 +402,9 @@ def hip_build_applies(p) -> bool:
 
 
 @torch.no_grad()
-def build_tables_lazy(p, pinned_slot: int = 0):
+def build_tables_lazy(p, pinned_slot: int = 0, buffers=None):
     """Queue the table build and return a :class:`_PendingTables` (kernel route only; check :func:`hip_build_applies`)."""
-    return _build_tables_hip(p, lazy=True, pinned_slot=pinned_slot)
+    return _build_tables_hip(p, lazy=True, pinned_slot=pinned_slot, buffers=buffers)
 
 
 @torch.no_grad()

@@ -113,7 +113,7 @@ def preferential_attachment_edges(n_nodes: int, n_edges: int, seed: int, device)
 def mutagenicity_shaped_graphs(count: int, seed: int = 0, n_types: int = 14, max_nodes: int = 417):
     """``count`` small undirected graphs of the Mutagenicity shape: ``N_g = clip(round(LogNormal(3.3,
     0.45)), 4, max_nodes)`` nodes (mean about 30), a random tree plus ``N_g // 30 + 1`` extra edges, one-hot atom type of
-    ``n_types`` + the ones column (``pre_process_datasets.py:108``).  Yields ``(edge_index [2, 2m] int64 numpy, x [N_g,
+    ``n_types`` + the ones column (``pre_process_datasets.py:108``).  Yields ``(edge_index [2, m'] int64 numpy (both directions, coalesced), x [N_g,
     n_types + 1] float32 tensor, label +-1)`` — CPU objects; the caller pre-processes and moves them."""
     import numpy as np
     rng = np.random.default_rng(seed)
@@ -126,4 +126,8 @@ def mutagenicity_shaped_graphs(count: int, seed: int = 0, n_types: int = 14, max
         x = torch.zeros(n, F)
         x[torch.arange(n), torch.from_numpy(rng.integers(0, n_types, n))] = 1.0
         x[:, -1] = 1.0
-        yield np.concatenate([ei, ei[::-1]], axis=1), x, (1.0 if rng.random() < 0.5 else -1.0)
+        ei = np.concatenate([ei, ei[::-1]], axis=1)
+        # coalesced, no self loops — what a PyG data set holds.  (The reference's COO -> LIL conversion would turn a duplicate
+        # edge into a weight-2 edge for its Dijkstra; HopGraph.from_edge_index counts it once.)
+        ei = np.unique(ei[:, ei[0] != ei[1]], axis=1)
+        yield ei, x, (1.0 if rng.random() < 0.5 else -1.0)

@@ -23,6 +23,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
+#pragma GCC visibility push(default)
 
 #define GNAN_ABI_VERSION 37
 
@@ -173,14 +175,17 @@ typedef struct gnan_fpwl_args {
   int32_t flags;             /* gnan_fpwl_flags: kernel selection switches (A/B measurements, tests); 0 = the library's choice */
   const uint16_t* index_table; /* gnan_fpwl_fwd, optional: the direct-index tables gnan_fpwl_index_build wrote for THESE tables   */
   const float* index_key;      /* ([F, buckets] entries and [F, 2] key coefficients).  With C == 1, whole 16-feature groups and   */
-  int32_t index_buckets;       /* 16-byte aligned rows the look-up then finds a value's piece by arithmetic + at most              */
-  int32_t index_max_fast;      /* index_max_fast comparisons instead of a search (csrc/fpwl_index.hip); same results bit for bit   */
+  int32_t index_buckets;       /* 16-byte aligned rows the look-up then finds a value's piece by arithmetic + one to three         */
+                               /* comparisons instead of a search (csrc/fpwl_index.hip); same results bit for bit                  */
 } gnan_fpwl_args;
 
 /* gnan_fpwl_args.flags (the library reads no environment variables: switches are the caller's, passed per call) */
 enum gnan_fpwl_flags {
   GNAN_FPWL_MOMENTS_GENERAL = 1, /* gnan_fpwl_moments_fixed: the general kernel also where the one-channel kernel applies */
-  GNAN_FPWL_LOCATE_SORTED = 2    /* gnan_fpwl_locate: the sorted-array search also where the tree search applies */
+  GNAN_FPWL_LOCATE_SORTED = 2,   /* gnan_fpwl_locate: the sorted-array search also where the tree search applies */
+  GNAN_FPWL_INDEX_HALF_LINES = 4, /* direct-index look-up: 16-feature groups (half lines of x per workgroup) where 32 would fit */
+  GNAN_FPWL_INDEX_BS512 = 8,     /* direct-index look-up with 32-feature groups: 512-thread workgroups whatever the mode */
+  GNAN_FPWL_INDEX_BS1024 = 16    /* ... 1024-thread workgroups whatever the mode */
 };
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);
@@ -189,17 +194,17 @@ int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
 /* Direct-index acceleration of the one-channel look-up (csrc/fpwl_index.hip; no counterpart in the reference, whose
  * GNAN.py:57-62 evaluates the MLPs).  Per feature a uniform grid of `buckets` cells over [range[k][0], range[k][1]] —
  * the values the feature actually takes (gnan_feature_range: column minima / maxima, one pass per feature matrix) — maps
- * x to a cell by one fused multiply-add; table[k][cell] = 4 * (breakpoints of f_k below the cell) | (more than max_fast
- * breakpoints inside the cell).  The range is a HINT: the look-up compares x with the breakpoints inside its cell and
- * searches flagged cells (among them the two end cells, which take everything outside the range), so every x is looked
- * up exactly whatever the range says.  stats[k] (optional) = flagged cells strictly inside the range.
+ * x to a cell by one fused multiply-add; table[k][cell] = 4 * (breakpoints of f_k below the cell) | code << 14 with
+ * code 0 / 1 / 3 for at most one / two or three / more breakpoints inside the cell.  The range is a HINT: the look-up
+ * compares x with the breakpoints inside its cell and searches code-3 cells (among them the two end cells, which take
+ * everything outside the range), so every x is looked up exactly whatever the range says.  stats[k] (optional) = code-3
+ * cells strictly inside the range.
  * gnan_feature_range: range [F][2] out; workspace F * 8 bytes; NaNs are skipped. */
 typedef struct gnan_fpwl_index_args {
   const int32_t* off;      /* [F + 1] piece offsets (gnan_pwl_build / gnan_amd.pwl) */
   const float* anchor;     /* [T] */
   int32_t F;
   int32_t buckets;         /* 256, 512, 1024 or 2048 */
-  int32_t max_fast;        /* 1 or 3: breakpoints per cell the look-up resolves by comparisons */
   const float* range;      /* [F][2] (lo, hi) */
   uint16_t* table;         /* [F][buckets] out, 16-byte aligned */
   float* key;              /* [F][2] out: cell(x) = (int) clamp(x * key[k][0] + key[k][1], 0, buckets - 1) */
@@ -759,6 +764,7 @@ int gnan_bfs_khop(const gnan_bfs_khop_args* a, gnan_stream_t stream);
  * ------------------------------------------------------------------------------------------- */
 int gnan_graph_replace_memsets(void* graph, int32_t* n_replaced);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

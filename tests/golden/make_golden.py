@@ -273,6 +273,112 @@ def build_and_call(c, F):
     raise ValueError(v)
 
 
+# f-3 with the path itself: the reference's epoch loops driving the reference's GNAN classes (trainer.py:23-154 over
+# models.py:304-477 / GNAN.py:9-79) — one SGD epoch and one evaluation pass; inputs, initial and updated state_dict
+class GraphData(Bag):
+    def to(self, device):
+        return self
+
+
+def trainer_case(manifest, tid, variant, C, loss_name, n_batches, n, f_raw=4, H=8, L=3, opt_name="SGD", epochs=1,
+                 with_f64=False):
+    """``with_f64`` (make_golden_run.py, the Adam cases): the same run once more under ``torch.set_default_dtype(float64)``
+    from the SAME data and initial weights — ``train_hist64`` / ``test_hist64`` / ``sd1_64``: the gap to the float32 run is
+    the reference's own float32 trajectory error, the bound the GPU harness is held to."""
+    import trainer as ref_trainer
+    graph_task = variant.endswith("graph")
+    rng = np.random.default_rng(9100 + tid)
+    batches = []
+    for b in range(n_batches):
+        nb = n if not graph_task else int(rng.integers(5, 12))
+        ei = random_graph(rng, nb, False, 1)
+        if not graph_task:
+            perm = np.arange(nb)
+            top = int(ei.max())
+            perm[[top, nb - 1]] = perm[[nb - 1, top]]
+            ei = perm[ei]
+        d = run_pre_process(ei, nb, f_raw, rng, graph_task)
+        ny = 1 if graph_task else nb
+        if loss_name == "CrossEntropyLoss":
+            y = torch.from_numpy(rng.integers(0, C, ny))
+        elif loss_name == "MSELoss":
+            y = torch.from_numpy(rng.standard_normal(ny).astype(np.float32))
+        else:
+            y = torch.from_numpy(rng.choice([-1.0, 1.0], ny).astype(np.float32))
+        fields = dict(x=d.x, edge_index=d.edge_index, node_distances=d.node_distances,
+                      normalization_matrix=d.normalization_matrix, y=y)
+        if not graph_task:
+            for m in ("train_mask", "val_mask", "test_mask"):
+                mask = torch.from_numpy(rng.random(nb) < 0.6)
+                mask[0] = True
+                fields[m] = mask
+        batches.append(GraphData(**fields))
+    F = batches[0].x.shape[1]
+    c = dict(variant=variant, C=C, H=H, L=L, bias=True, normalize_rho=True, rho_per_feature=(C > 1),
+             readout_n_layers=0)
+    build, _ = build_and_call(c, F)
+    torch.manual_seed(60 + tid)
+    model = build()
+    redraw(model, 60 + tid)
+    model.train()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = getattr(torch.nn, loss_name)()
+    lr = 0.05 if opt_name == "SGD" else 0.01
+    opt = torch.optim.SGD(model.parameters(), lr=lr) if opt_name == "SGD" else torch.optim.Adam(model.parameters(), lr=lr)
+    classify = loss_name != "MSELoss"
+    hist_tr, hist_te = [], []
+    for _ in range(epochs):               # main.py:176-215: a training pass, then an evaluation pass, every epoch
+        tr = ref_trainer.train_epoch(model, batches, loss_fn, opt, "cpu", classify=classify, compute_auc=False,
+                                     is_graph_task=graph_task)
+        sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+        te = ref_trainer.test_epoch(model, batches, loss_fn, "cpu", classify=classify, compute_auc=False,
+                                    val_mask=True, is_graph_task=graph_task)
+        hist_tr.append(tr)
+        hist_te.append(te)
+    arrays = {"train_ret": np.array(tr, dtype=np.float64), "test_ret": np.array(te, dtype=np.float64)}
+    if epochs > 1:
+        arrays["train_hist"] = np.array(hist_tr, dtype=np.float64)
+        arrays["test_hist"] = np.array(hist_te, dtype=np.float64)
+    if with_f64:
+        real_bce = torch.nn.BCEWithLogitsLoss.forward
+        torch.nn.BCEWithLogitsLoss.forward = lambda self, inp, target: real_bce(self, inp, target.to(inp.dtype))   # trainer.py:62 hands float32 labels over
+        try:
+            m64 = build()
+            m64.load_state_dict(sd0)
+            m64.double().train()
+            torch.set_default_dtype(torch.float64)            # GNAN.py:57 / models.py:360 allocate fx in the DEFAULT dtype
+            b64 = [GraphData(**{k: (v.double() if v.is_floating_point() else v) for k, v in d.__dict__.items()}) for d in batches]
+            opt64 = torch.optim.SGD(m64.parameters(), lr=lr) if opt_name == "SGD" else torch.optim.Adam(m64.parameters(), lr=lr)
+            h_tr, h_te = [], []
+            for _ in range(epochs):
+                h_tr.append(ref_trainer.train_epoch(m64, b64, loss_fn, opt64, "cpu", classify=classify, compute_auc=False,
+                                                    is_graph_task=graph_task))
+                h_te.append(ref_trainer.test_epoch(m64, b64, loss_fn, "cpu", classify=classify, compute_auc=False,
+                                                   val_mask=True, is_graph_task=graph_task))
+        finally:
+            torch.set_default_dtype(torch.float32)
+            torch.nn.BCEWithLogitsLoss.forward = real_bce
+        arrays["train_hist64"] = np.array(h_tr, dtype=np.float64)
+        arrays["test_hist64"] = np.array(h_te, dtype=np.float64)
+        for k, v in m64.state_dict().items():
+            arrays["sd1_64/" + k] = v.numpy()
+    for k, v in sd0.items():
+        arrays["sd0/" + k] = v.numpy()
+    for k, v in sd1.items():
+        arrays["sd1/" + k] = v.numpy()
+    for b, d in enumerate(batches):
+        for k, v in d.__dict__.items():
+            arrays[f"b{b}/{k}"] = v.numpy()
+    meta = dict(variant="trainer_gnan", model=variant, id=310 + tid, C=C, H=H, L=L, F=F, graph=graph_task, loss=loss_name,
+                classify=classify, n_batches=n_batches, lr=lr, rho_per_feature=(C > 1), optimizer=opt_name, epochs=epochs)
+    name = f"case_{310 + tid:03d}_trainer_gnan"
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    if name not in manifest:
+        manifest.append(name)
+    print(name, tr, te)
+
+
 def main():
     total = 0
     manifest = []
@@ -398,90 +504,15 @@ def main():
         manifest.append(name)
         print(name, tr, te)
 
-    # f-3 with the path itself: the reference's epoch loops driving the reference's GNAN classes (trainer.py:23-154 over
-    # models.py:304-477 / GNAN.py:9-79) — one SGD epoch and one evaluation pass; inputs, initial and updated state_dict
-    class GraphData(Bag):
-        def to(self, device):
-            return self
-
-    def trainer_case(tid, variant, C, loss_name, n_batches, n, f_raw=4, H=8, L=3, opt_name="SGD", epochs=1):
-        graph_task = variant.endswith("graph")
-        rng = np.random.default_rng(9100 + tid)
-        batches = []
-        for b in range(n_batches):
-            nb = n if not graph_task else int(rng.integers(5, 12))
-            ei = random_graph(rng, nb, False, 1)
-            if not graph_task:
-                perm = np.arange(nb)
-                top = int(ei.max())
-                perm[[top, nb - 1]] = perm[[nb - 1, top]]
-                ei = perm[ei]
-            d = run_pre_process(ei, nb, f_raw, rng, graph_task)
-            ny = 1 if graph_task else nb
-            if loss_name == "CrossEntropyLoss":
-                y = torch.from_numpy(rng.integers(0, C, ny))
-            elif loss_name == "MSELoss":
-                y = torch.from_numpy(rng.standard_normal(ny).astype(np.float32))
-            else:
-                y = torch.from_numpy(rng.choice([-1.0, 1.0], ny).astype(np.float32))
-            fields = dict(x=d.x, edge_index=d.edge_index, node_distances=d.node_distances,
-                          normalization_matrix=d.normalization_matrix, y=y)
-            if not graph_task:
-                for m in ("train_mask", "val_mask", "test_mask"):
-                    mask = torch.from_numpy(rng.random(nb) < 0.6)
-                    mask[0] = True
-                    fields[m] = mask
-            batches.append(GraphData(**fields))
-        F = batches[0].x.shape[1]
-        c = dict(variant=variant, C=C, H=H, L=L, bias=True, normalize_rho=True, rho_per_feature=(C > 1),
-                 readout_n_layers=0)
-        build, _ = build_and_call(c, F)
-        torch.manual_seed(60 + tid)
-        model = build()
-        redraw(model, 60 + tid)
-        model.train()
-        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-        loss_fn = getattr(torch.nn, loss_name)()
-        lr = 0.05 if opt_name == "SGD" else 0.01
-        opt = torch.optim.SGD(model.parameters(), lr=lr) if opt_name == "SGD" else torch.optim.Adam(model.parameters(), lr=lr)
-        classify = loss_name != "MSELoss"
-        hist_tr, hist_te = [], []
-        for _ in range(epochs):               # main.py:176-215: a training pass, then an evaluation pass, every epoch
-            tr = ref_trainer.train_epoch(model, batches, loss_fn, opt, "cpu", classify=classify, compute_auc=False,
-                                         is_graph_task=graph_task)
-            sd1 = {k: v.clone() for k, v in model.state_dict().items()}
-            te = ref_trainer.test_epoch(model, batches, loss_fn, "cpu", classify=classify, compute_auc=False,
-                                        val_mask=True, is_graph_task=graph_task)
-            hist_tr.append(tr)
-            hist_te.append(te)
-        arrays = {"train_ret": np.array(tr, dtype=np.float64), "test_ret": np.array(te, dtype=np.float64)}
-        if epochs > 1:
-            arrays["train_hist"] = np.array(hist_tr, dtype=np.float64)
-            arrays["test_hist"] = np.array(hist_te, dtype=np.float64)
-        for k, v in sd0.items():
-            arrays["sd0/" + k] = v.numpy()
-        for k, v in sd1.items():
-            arrays["sd1/" + k] = v.numpy()
-        for b, d in enumerate(batches):
-            for k, v in d.__dict__.items():
-                arrays[f"b{b}/{k}"] = v.numpy()
-        meta = dict(variant="trainer_gnan", model=variant, id=310 + tid, C=C, H=H, L=L, F=F, graph=graph_task, loss=loss_name,
-                    classify=classify, n_batches=n_batches, lr=lr, rho_per_feature=(C > 1), optimizer=opt_name, epochs=epochs)
-        name = f"case_{310 + tid:03d}_trainer_gnan"
-        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
-        manifest.append(name)
-        print(name, tr, te)
-
-    trainer_case(0, "models_tensor_node", 3, "CrossEntropyLoss", 1, 40)
-    trainer_case(1, "models_gnan", 1, "BCEWithLogitsLoss", 1, 30)
-    trainer_case(2, "models_tensor_graph", 1, "BCEWithLogitsLoss", 4, 0)
-    trainer_case(3, "standalone_tensor_node", 3, "CrossEntropyLoss", 1, 40)
-    trainer_case(4, "models_tensor_graph", 1, "MSELoss", 3, 0)
+    trainer_case(manifest, 0, "models_tensor_node", 3, "CrossEntropyLoss", 1, 40)
+    trainer_case(manifest, 1, "models_gnan", 1, "BCEWithLogitsLoss", 1, 30)
+    trainer_case(manifest, 2, "models_tensor_graph", 1, "BCEWithLogitsLoss", 4, 0)
+    trainer_case(manifest, 3, "standalone_tensor_node", 3, "CrossEntropyLoss", 1, 40)
+    trainer_case(manifest, 4, "models_tensor_graph", 1, "MSELoss", 3, 0)
     # Adam over several epochs (main.py:141): long enough for the harness to capture the step and replay it
-    trainer_case(5, "models_tensor_node", 3, "CrossEntropyLoss", 1, 60, f_raw=6, H=16, opt_name="Adam", epochs=6)
-    trainer_case(6, "models_tensor_graph", 1, "BCEWithLogitsLoss", 3, 0, opt_name="Adam", epochs=6)
-    trainer_case(7, "standalone_tensor_node", 2, "CrossEntropyLoss", 1, 50, opt_name="Adam", epochs=5)
+    trainer_case(manifest, 5, "models_tensor_node", 3, "CrossEntropyLoss", 1, 60, f_raw=6, H=16, opt_name="Adam", epochs=6, with_f64=True)
+    trainer_case(manifest, 6, "models_tensor_graph", 1, "BCEWithLogitsLoss", 3, 0, opt_name="Adam", epochs=6, with_f64=True)
+    trainer_case(manifest, 7, "standalone_tensor_node", 2, "CrossEntropyLoss", 1, 50, opt_name="Adam", epochs=5, with_f64=True)
 
     # inputs EXACTLY on ReLU kinks: zero biases (the reference's own initial state) with one-hot / bag-of-words style
     # features, and kinks placed on float32 numbers the inputs take.  torch differentiates relu at 0 as 0.

@@ -26,6 +26,34 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, "ctypes binding and header disagree"
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """-fvisibility=hidden + the header's visibility pragma: the dynamic symbol table holds the C ABI and nothing else
+    (no C++ helpers of the library; `__hip_*` / `__hipRegister*` objects are the toolchain's fat-binary registration data)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.strip()})
+    ours = [s for s in exported if not s.startswith(("__hip_", "__hipRegister", "_init", "_fini"))]
+    assert ours == declared_symbols(), sorted(set(ours) ^ set(declared_symbols()))
+
+
+def integration_stub():
+    """The python block of INTEGRATION.md section 2 (what a maintainer of the reference would paste into GNAN.py)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. Binding the C ABI directly"):]
+    block = re.search(r"```python\n(.*?)```", sec, flags=re.S).group(1)
+    return block.replace('C.CDLL("libgnan_hip.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+
+
+def test_integration_stub_runs_against_the_built_library():
+    """The stub loads the library, passes its own ABI assertion, and its struct is the header's (so the document cannot
+    drift from the library unnoticed)."""
+    ns = {}
+    exec(integration_stub(), ns)                     # asserts gnan_abi_version() itself
+    assert [f[0] for f in ns["FmlpArgs"]._fields_] == [f[0] for f in _lib.FmlpArgs._fields_]
+    assert [f[1] for f in ns["FmlpArgs"]._fields_] == [f[1] for f in _lib.FmlpArgs._fields_]
+    assert callable(ns["f_sums"])
+
+
 def test_abi_version_and_error_channel():
     lib = _lib.lib()
     assert lib.gnan_abi_version() == _lib.ABI_VERSION

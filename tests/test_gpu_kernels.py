@@ -1701,8 +1701,8 @@ def _index_inputs(kind, n, F, seed):
 
 @pytest.mark.parametrize("kind", ["uniform", "one_hot", "heavy_tail", "levels"])
 @pytest.mark.parametrize("mode", ["rows", "rows_bf16", "sum"])
-@pytest.mark.parametrize("buckets,max_fast", [(1024, 1), (256, 3), (2048, 1)])
-def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets, max_fast, monkeypatch):
+@pytest.mark.parametrize("buckets,flags", [(512, 0), (1024, 16), (256, 8), (2048, 4), (512, 4)])
+def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets, flags, monkeypatch):
     """csrc/fpwl_index.hip finds the piece of a value by arithmetic on a per-feature grid over the data's range plus
     comparisons inside the cell; it must give the bits of the tree-search kernel (same piece, same formula) for ANY
     input — on kinks, outside the hinted range, non-finite — and for a range hint that is wrong."""
@@ -1710,13 +1710,15 @@ def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets,
     from gnan_amd.functional import feature_mlps
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
     monkeypatch.setattr(functional, "INDEX_BUCKETS", buckets)
-    monkeypatch.setattr(functional, "INDEX_MAX_FAST", max_fast)
+    monkeypatch.setattr(functional, "INDEX_FLAGS", flags)       # 0: 32-feature groups (full lines); 8 / 16: 512 / 1024 threads; 4: 16-feature groups
     n, F, L, H = 70_001, 32, 3, 24
     sd = _on_kink_state(F, L, H, 1, "exact", seed=3) if kind in ("levels", "one_hot") else _mlp_state(F, L, H, 1, True, seed=3)
     st = _stack(sd, F, L, H, 1, True)
     x = _index_inputs(kind, n, F, seed=5)
-    calls = []
-    real = _lib.lib().gnan_fpwl_index_build
+    functional._RANGE_CHURN.clear()                 # (every test hands over a new feature matrix: not the churn this guards against)
+    built = []
+    real_index = functional._fpwl_index
+    monkeypatch.setattr(functional, "_fpwl_index", lambda *a: built.append(real_index(*a)) or built[-1])
 
     def run(on, hint=None):
         monkeypatch.setattr(functional, "INDEX_LOOKUP", on)
@@ -1729,18 +1731,27 @@ def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets,
                                 out_dtype=torch.bfloat16 if mode == "rows_bf16" else torch.float32)
 
     want, want_total = run(False)
-    before = functional._RANGE_CACHE.__len__()
+    assert built and all(b is None for b in built)
+    del built[:]
     got, got_total = run(True)
-    assert functional._RANGE_CACHE.__len__() >= max(before, 1)            # the index path ran (its range pass was cached)
-    assert torch.equal(got.view(torch.int16 if mode == "rows_bf16" else torch.int32),
-                       want.view(torch.int16 if mode == "rows_bf16" else torch.int32))      # bit for bit, NaNs included
-    assert torch.equal(got_total.view(torch.int32), want_total.view(torch.int32))
+    assert built and built[-1] is not None          # the direct-index tables were built and handed to the look-up
+    def same(a, b):         # bit for bit; a NaN matches a NaN (its sign follows the order of the operands of a sum)
+        a, b = a.float(), b.float()
+        na, nb_ = torch.isnan(a), torch.isnan(b)
+        return torch.equal(na, nb_) and torch.equal(torch.where(na, torch.zeros_like(a), a).view(torch.int32),
+                                                    torch.where(nb_, torch.zeros_like(b), b).view(torch.int32))
+
+    assert same(got, want)
+    # the column sums add float32 partial sums per thread: their grouping follows the kernel's node-to-thread map
+    finite = torch.isfinite(want_total) & torch.isfinite(got_total)
+    assert torch.equal(torch.isnan(got_total), torch.isnan(want_total))
+    bound = 1e-6 * float(torch.nan_to_num(want.float(), nan=0.0, posinf=0.0, neginf=0.0).abs().sum(0).max()) if mode != "sum" else 0.0
+    assert float((got_total - want_total)[finite].abs().max() if finite.any() else 0.0) <= bound + 1e-30
     # a WRONG hint (narrower than the data, shifted, degenerate): still exact — the hint steers speed only
     for lo, hi in ((0.2, 0.3), (5.0, 9.0), (0.0, 0.0), (float("nan"), 1.0), (-float("inf"), float("inf"))):
         hint = torch.tensor([[lo, hi]] * F, device=DEV)
         got2, tot2 = run(True, hint)
-        assert torch.equal(got2.view(torch.int16 if mode == "rows_bf16" else torch.int32),
-                           want.view(torch.int16 if mode == "rows_bf16" else torch.int32)), (lo, hi)
+        assert same(got2, want), (lo, hi)
 
 
 def test_direct_index_keeps_the_pieces_for_the_backward_pass(monkeypatch):
@@ -1754,6 +1765,7 @@ def test_direct_index_keeps_the_pieces_for_the_backward_pass(monkeypatch):
     x = _index_inputs("uniform", n, F, seed=2)
     target = torch.randn(n, 1, generator=torch.Generator().manual_seed(1)).to(DEV)
     grads = {}
+    functional._RANGE_CHURN.clear()
     for on in (False, True):
         monkeypatch.setattr(functional, "INDEX_LOOKUP", on)
         st = _stack(sd, F, L, H, 1, True)

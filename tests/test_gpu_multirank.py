@@ -140,13 +140,21 @@ def test_ranks_with_the_hip_kernels_equal_single_process_and_oracle(world, varia
     S = O.feature_mlps(x.double(), p64).sum(1)
     wt = O.weight_table(O.rho_lut(p64, 3, dtype=torch.float64), g.cnt.cpu().long().numpy()).expand(N, -1, -1)
     truth = O.spmm_csr(g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy(), S, wt)
-    # Reference order on THIS problem is ill-conditioned in float32: every feature column carries a rest-bucket term
-    # w_rest * total_k of ~0.13 (column sums up to 3140 over 3000 nodes) that cancels against the other columns' down to
-    # outputs of ~0.02, so ~1.5e-7 of absolute round-off — 0.5..1.5e-5 of the largest output — is in ANY float32 evaluation
-    # of models.py:373-376 (measured: the kernel on the matrix-core operand 5.6e-6, on the table operand 1.5e-5, operands
-    # that agree to 1e-7; the sum-first order of the same model: 4e-7).  The bound is therefore 3e-5 for that order.
-    floor = 3e-5 if order == "reference" else 1e-5
-    assert O.rel_err(torch.from_numpy(got), truth.detach()) <= floor, (O.rel_err(torch.from_numpy(got), truth.detach()), floor)
+    # The tolerance rule: max(1e-5, the error of the float32 reference against the same float64 truth).
+    # The float32 reference here is the oracle in the order under test — models.py:373-376 aggregates every per-feature
+    # column and sums afterwards (on this problem each column carries a rest-bucket term of ~0.13 that cancels against
+    # the other columns' down to outputs of ~0.02: ill-conditioned in float32 for ANY evaluation), GNAN.py:157 sums first.
+    sd32 = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    fx32 = O.feature_mlps(x.float(), sd32)                                               # [N, F, C] float32
+    wt32 = O.weight_table(O.rho_lut(sd32, 3), g.cnt.cpu().long().numpy()).expand(N, -1, -1)
+    rp, cl, cd = g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy()
+    if order == "reference":
+        ref32 = O.spmm_csr(rp, cl, cd, fx32.reshape(N, -1), wt32).reshape(N, -1, C).sum(1)
+    else:
+        ref32 = O.spmm_csr(rp, cl, cd, fx32.sum(1), wt32)
+    e_ref = O.rel_err(ref32, truth.detach())
+    err = O.rel_err(torch.from_numpy(got), truth.detach())
+    assert err <= max(1e-5, e_ref), (err, e_ref, order)
     ((truth - _target(C).double()) ** 2).sum().backward()
     scale = max(float(v.grad.abs().max()) for v in p64.values() if v.grad is not None)
     single = dict(m.named_parameters())
@@ -169,7 +177,7 @@ def _bench_line(extra, timeout=1500):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
            "--scale", "18", "--nodes", "200000", "--edges", "2000000"] + extra
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-6000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
     return json.loads(lines[0])

@@ -14,7 +14,7 @@ from oracle import gnan_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODEL_CASES = [n for n in golden_names() if not any(t in n for t in ("pre_process", "batched", "trainer"))]
+MODEL_CASES = [n for n in golden_names() if not any(t in n for t in ("pre_process", "batched", "trainer", "run_exp"))]
 
 
 @pytest.fixture(scope="module")

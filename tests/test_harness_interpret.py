@@ -63,3 +63,65 @@ def test_interpretability_exports_need_the_device():
                  lambda: interpret.contribution_heatmap(m, 5), lambda: interpret.shape_function_tables(m)):
         with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
             call()
+
+
+# ---------------------------------------------------------------------------------------------------------- run level
+def test_early_stopping_and_loss_rule():
+    """main.py:16-41 and main.py:343-352."""
+    from gnan_amd.run import EarlyStopping, loss_and_out_dim
+    es = EarlyStopping("Loss", patience=3, min_is_better=True)
+    for v, stop in ((1.0, False), (0.9, False), (0.95, False), (0.91, False), (0.9, False), (1.2, False), (1.1, False), (1.3, True)):
+        es(v)
+        assert es.early_stop == stop, v          # 0.9 again is not worse (resets the count); three worse ones in a row stop
+    assert loss_and_out_dim(2, False) == (torch.nn.BCEWithLogitsLoss, 1)
+    assert loss_and_out_dim(40, False) == (torch.nn.CrossEntropyLoss, 40)
+    assert loss_and_out_dim(1, True) == (torch.nn.MSELoss, 1)
+
+
+@pytest.mark.parametrize("name", golden_names("run_exp"))
+def test_run_exp_control_flow_follows_the_reference_run(name, tmp_path, monkeypatch):
+    """The run loop (scheduler on the training loss, early stopping on the validation loss, the three checkpoint rules and
+    their file names, the per-epoch order of passes) fed the per-epoch numbers of the REFERENCE's run (golden 320-321:
+    main.py's run_exp driving the reference's classes) must write the same checkpoints at the same epochs, set the same
+    learning rates and stop at the same epoch for the same reason."""
+    from gnan_amd import run
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    hist = z["hist32"]
+    calls = {"train": 0, "eval": []}
+
+    def fake_train(model, dloader, loss_fn, optimizer, classify, device, compute_auc, is_graph_task):
+        assert classify is True                     # main.py:159: ~is_regression is truthy whatever the flag
+        row = hist[calls["train"]]
+        calls["train"] += 1
+        return float(row[0]), float(row[1]), -1
+
+    def fake_test(model, dloader, loss_fn, classify, device, compute_auc, is_graph_task, val_mask=False):
+        row = hist[calls["train"] - 1]
+        calls["eval"].append((calls["train"] - 1, bool(val_mask)))
+        return (float(row[2]), float(row[3]), -1) if val_mask else (float(row[4]), float(row[5]), -1)
+
+    monkeypatch.setattr(run.harness, "train_epoch", fake_train)
+    monkeypatch.setattr(run.harness, "test_epoch", fake_test)
+    model = Probe(4, 2)
+    runs = run.run_exp([0], [0], [0], meta["F"], [meta["seed"]], meta["L"], meta["early_stop_flag"], 0.0, "gnan", meta["epochs"],
+                       0, meta["wd"], meta["H"], meta["lr"], 1e-5, meta["data_name"], "RUN", int(meta["rho_per_feature"]), 1,
+                       meta["graph"], meta["num_classes"], meta["C"], patience=meta["patience"], model=model, device="cpu",
+                       checkpoint_dir=str(tmp_path), log=lambda *_: None)
+    r = runs[0]
+    assert len(r["epochs"]) == meta["epochs_run"] and r["stopped"].startswith(
+        {"num_epochs": "num_epochs", "early stop": "early stop at epoch", "loss under": "loss under"}[meta["stopped"]])
+    assert [e["lr"] for e in r["epochs"]] == [float(v) for v in hist[:, 6]]
+    assert [(e, n) for e, n in r["checkpoints"]] == [tuple(c) for c in meta["checkpoints"]]
+    assert sorted(os.listdir(tmp_path)) == sorted({c[1] for c in meta["checkpoints"]})
+    sd = torch.load(os.path.join(tmp_path, meta["checkpoints"][-1][1]))
+    assert list(sd.keys()) == list(model.state_dict().keys())        # a checkpoint is the state_dict (main.py:172)
+    # one validation pass per epoch, a test pass per checkpoint, one more per epoch and one after the loop
+    per_epoch = {}
+    for e, is_val in calls["eval"]:
+        per_epoch.setdefault(e, []).append(is_val)
+    assert all(v[0] is True and v.count(True) == 1 for v in per_epoch.values())
+    n_ckpt = len(meta["checkpoints"])
+    assert sum(not v for _, v in calls["eval"]) == n_ckpt + meta["epochs_run"] + 1
+    with pytest.raises(ValueError, match="gnan"):
+        run.run_exp([0], [0], [0], 4, [1], 3, 0, 0.0, "gin", 1, 0, 0.0, 8, 0.01, 1e-5, "d", "RUN", 0, 1, False, 2, 1)

@@ -7,7 +7,7 @@ from conftest import Golden, golden_names
 from helpers import inputs_from, oracle_forward, params_from
 from oracle import gnan_oracle as O
 
-MODEL_CASES = [n for n in golden_names() if not any(t in n for t in ("pre_process", "trainer"))]
+MODEL_CASES = [n for n in golden_names() if not any(t in n for t in ("pre_process", "trainer", "run_exp"))]
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)

@@ -52,11 +52,16 @@ def main():
         tb = pwl.build_tables(st)
     rng = functional._feature_range(x)
     modes = {"rows": (False, torch.float32, 8.0), "rows_bf16": (False, torch.bfloat16, 6.0), "sum": (True, torch.float32, 4.0 + 4.0 / F)}
-    variants = [("tree", None, None)] + [(f"index_B{b}_K{k}", b, k) for b in (512, 1024, 2048) for k in (1, 3)]
-    for name, b, k in variants:
+    from gnan_amd import _lib
+    variants = [("tree", None, 0)]
+    variants += [(f"index_fg32_bs1024_B{b}", b, 0) for b in (256, 512, 1024)]
+    variants += [(f"index_fg32_bs512_B{b}", b, _lib.FPWL_INDEX_BS512) for b in (256, 512)]
+    variants += [(f"index_fg16_B{b}", b, _lib.FPWL_INDEX_HALF_LINES) for b in (1024,)]
+    for name, b, fl in variants:
         functional.INDEX_LOOKUP = b is not None
+        functional.INDEX_FLAGS = fl
         if b is not None:
-            functional.INDEX_BUCKETS, functional.INDEX_MAX_FAST = b, k
+            functional.INDEX_BUCKETS = b
         row = {"variant": name, "nodes": N, "pieces_max": tb.max_pieces, "group_pieces": tb.max_group_pieces}
         for mode, (sumf, dt, bpl) in modes.items():
             with torch.no_grad():
