@@ -81,6 +81,18 @@ def parse():
                     help="where the next forward's table build branches off inside a replayed share: under the look-up or "
                          "under the aggregation")
     ap.add_argument("--index-buckets", type=int, default=0, help="cells per feature of the direct-index look-up (0: the library's default)")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0,
+                    help="one GPU: after the timed region (and the CPU baseline) keep issuing the same step for this long, so "
+                         "that an outside sampler of GPU activity sees the kernels (the timed region is ~0.1 s of a run whose "
+                         "wall time is mostly the CPU baseline); reported as sustained_ms_per_step, never as `value`.  0: off")
+    ap.add_argument("--traffic", default="measure", choices=["measure", "committed", "off"],
+                    help="roofline.traffic: measure = two short rocprofv3 --pmc child runs of this very command (FETCH_SIZE, "
+                         "WRITE_SIZE; one GPU), falling back to the committed figure of profiles/hbm_traffic.json; committed = "
+                         "that figure only")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.NAME=VALUE",
+                    help="A/B aid: set a module-level constant of the package before the run, e.g. --set "
+                         "functional.HOT_ROWS_IN_LDS=False (the library and the package read no environment switches for "
+                         "kernel selection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="upper bound of the CPU shape-function sample")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU aggregation sample")
@@ -535,6 +547,58 @@ def run_c2(args, rank=0, world=1):
     print(json.dumps(result), flush=True)
 
 
+def measure_traffic(kernel_prefix="spmm_kernel<"):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this command under
+    ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` (separate passes, as MI355X_MICROARCH.md
+    prescribes; the program itself behind ``--``), 2 timed steps each.  FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 a
+    128-byte memory-side request is tallied as 64 bytes by FETCH_SIZE when the kernel's loads are 16 bytes per lane over
+    aligned 256-byte rows (profiles/hbm_traffic.json has the calibration), hence the factor 2 on the read side.
+    Returns ``(bytes, note)`` or ``(None, why)``."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    drop = {"--traffic", "--sustain-seconds", "--steps", "--warmup"}
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a.split("=")[0] in drop:
+            skip = "=" not in a
+            continue
+        if a != "--no-cpu-baseline":
+            argv.append(a)
+    argv += ["--traffic", "off", "--sustain-seconds", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    found = {}
+    tmp = tempfile.mkdtemp(prefix="gnan_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__)] + argv
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            vals = []
+            for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    if kernel_prefix in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(vals)} samples"
+            found[counter] = sum(vals) / len(vals)
+    except Exception as e:                           # the figure is an extra: never fail the bench line for it
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = found["FETCH_SIZE"] * 1024.0 * 2.0 + found["WRITE_SIZE"] * 1024.0
+    return total, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE ({found['FETCH_SIZE']:.6g} KiB x 2, gfx950 correction) + "
+                   f"--pmc WRITE_SIZE ({found['WRITE_SIZE']:.6g} KiB) per launch of {kernel_prefix}...>, separate child passes")
+
+
 def launch_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher around it: start the N ranks ourselves.
 
@@ -605,6 +669,15 @@ def main():
     from gnan_amd.graph import hop_inputs
     if args.index_buckets:
         functional.INDEX_BUCKETS = args.index_buckets
+    for item in args.set:
+        import ast
+        import importlib
+        target, value = item.split("=", 1)
+        mod_name, attr = target.rsplit(".", 1)
+        mod = importlib.import_module("gnan_amd." + mod_name)
+        if not hasattr(mod, attr):
+            raise SystemExit(f"--set: gnan_amd.{mod_name} has no {attr}")
+        setattr(mod, attr, ast.literal_eval(value))
     functional.FMLP_ALGO = {"auto": _lib.FMLP_AUTO, "lane": _lib.FMLP_LANE, "mfma": _lib.FMLP_MFMA,
                             "pwl": _lib.FMLP_PWL}[args.fmlp_algo]
     from gnan_amd.models import TensorGNAN
@@ -797,12 +870,18 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     workload = f"rmat_s{args.scale}_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_{args.order}_K1" + ("" if args.operand == "f32" else "_bf16")
     traffic_source = None
+    committed = None
     if os.path.exists(tpath):
         rec = json.load(open(tpath))
         if rec.get("workload") == workload and rec.get("n_gpus") == world:
-            traffic = rec.get("bytes_per_launch")
-            # PMC counters need rocprofv3 around the process: the figure is the committed one of the same command, not of this run
-            traffic_source = "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of this command, not measured in this run)" % rec.get("source", "committed")
+            committed = rec.get("bytes_per_launch")
+    if args.traffic == "measure" and world == 1 and not emulated and rank == 0:
+        traffic, traffic_source = measure_traffic()
+        if traffic is None and committed is not None:
+            traffic, traffic_source = committed, f"profiles/hbm_traffic.json (committed figure; live measurement failed: {traffic_source})"
+    elif args.traffic != "off" and committed is not None:
+        # PMC counters need rocprofv3 around the process: the figure is the committed one of the same command, not of this run
+        traffic, traffic_source = committed, "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of this command, not measured in this run)" % rec.get("source", "committed")
 
     result = None
     if rank == 0:
@@ -821,7 +900,7 @@ def main():
                                                   if partition == "exchange" else "all_reduce(out [N,C])")},
             "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": traffic_source,
+                         "traffic_source": traffic_source, "traffic_over_algorithmic": traffic / b_alg if traffic else None,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},
             "stages_ms": stages,
             "step_ms_device": {"min": per_step[0], "median": per_step[len(per_step) // 2]} if per_step else None,
@@ -842,6 +921,17 @@ def main():
                 from gnan_amd.functional import feature_mlps
                 operand = feature_mlps(x, stacked, args.order == "sum_first")
             result["cpu_baseline"] = cpu_baseline(args, model, g, x, operand, out)
+        if world == 1 and not emulated and args.sustain_seconds > 0:
+            # the same step, back to back, long enough for an outside observer of the GPU to see it
+            torch.cuda.synchronize()
+            t0, n_sus = time.perf_counter(), 0
+            while time.perf_counter() - t0 < args.sustain_seconds:
+                for _ in range(50):
+                    step(False)
+                n_sus += 50
+                torch.cuda.synchronize()
+            result["sustained_ms_per_step"] = (time.perf_counter() - t0) / n_sus * 1e3
+            result["sustained_steps"] = n_sus
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

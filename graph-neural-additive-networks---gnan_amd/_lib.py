@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -210,6 +210,16 @@ class BfsKhopArgs(C.Structure):
     ]
 
 
+class SmallBatchArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_stride", C.c_int64), ("total_nodes", C.c_int64), ("F", C.c_int32), ("n_graphs", C.c_int32),
+        ("max_nodes", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp), ("code", C.c_void_p), ("node_off", C.c_void_p),
+        ("code_off", C.c_void_p), ("D", C.c_int32), ("rho_raw_hops", C.c_int32), ("rest_zero", C.c_int32),
+        ("S", C.c_void_p), ("lut", C.c_void_p), ("Y", C.c_void_p), ("Ysum", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/gnan_hip.h declares: (name, restype, argtypes)
@@ -243,6 +253,11 @@ SYMBOLS = {
     "gnan_small_graph_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_small_graph_fwd": (C.c_int, [C.POINTER(SmallGraphArgs), C.c_void_p]),
     "gnan_small_graph_bwd": (C.c_int, [C.POINTER(SmallGraphBwdArgs), C.c_void_p]),
+    "gnan_small_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    "gnan_small_batch_fwd": (C.c_int, [C.POINTER(SmallBatchArgs), C.c_void_p]),
+    "gnan_hops_to_code": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnan_dense_blocks_to_code": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     "gnan_multi_copy": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]),
     "gnan_loss_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_loss_step": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
@@ -257,6 +272,7 @@ SYMBOLS = {
     "gnan_colsum_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
+    "gnan_feature_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gnan_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnan_bfs_dense_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_bfs_dense": (C.c_int, [C.POINTER(BfsDenseArgs), C.c_void_p]),

@@ -3,11 +3,24 @@
 Many graphs per call: ``dist_batch`` is the block-diagonal matrix of raw hop counts the reference's collate
 function builds (batched_pyg_main.py:54-91), ``-1`` marking cross-graph / unreachable pairs.  rho acts on the raw
 hop count, there is no shell normalisation, masked pairs contribute nothing (batched_pyg_main.py:151-159), and node
-outputs are summed per graph (batched_pyg_main.py:173-181).  In shell terms: hop code = the hop count, the rest
-bucket (``-1``) carries weight 0, so the same two kernels serve: rho on the handful of distinct hop counts, then
-the hop-coded aggregation.
+outputs are summed per graph (batched_pyg_main.py:173-181).
+
+The path here never needs the ``(sum N_g)^2`` matrix:
+
+* :func:`collate` is the device-side counterpart of ``distance_collate_fn``: the per-graph hop matrices become
+  :class:`HopBlocks` — packed ``[n_g, n_g]`` uint8 code blocks + offsets (``gnan_hops_to_code``); a dense ``dist_batch``
+  handed to ``forward`` as the reference does is cut into the same blocks by one kernel (``gnan_dense_blocks_to_code``,
+  which also checks that nothing outside the diagonal blocks is listed) and remembered per tensor;
+* the forward of ALL graphs of a batch is ONE launch (``gnan_small_batch_fwd``: per graph the workgroups of
+  ``gnan_small_graph_fwd`` — shape functions, rho on the distinct hop counts, aggregation — and the per-graph read-out
+  in the epilogue of the graph's last workgroup: no ``scatter_add``); graphs of more than 128 nodes, or training-mode
+  Dropout, take the hop-coded CSR of the blocks through the general kernels;
+* backward: the general kernels on the CSR (transposed aggregation, table gradient, ``gnan_fmlp_bwd`` twice) from the
+  node sums and the rho table the forward left behind.
 """
 from __future__ import annotations
+
+from typing import Optional, Sequence
 
 import torch
 from torch import nn
@@ -17,6 +30,9 @@ from .functional import rho_aggregate
 from .graph import HopGraph
 from .modules import _PathBase
 
+BATCH_KERNEL = True            # the one-launch forward where it applies (tests compare with the CSR route)
+BATCH_KERNEL_MAX_NODES = 128
+
 
 def _two_layer(hidden: int, out: int, bias: bool, dropout: float) -> nn.Sequential:
     """Linear(1,H) / ReLU / Dropout / Linear(H,out): keys 0 and 3 (batched_pyg_main.py:117-131)."""
@@ -24,11 +40,118 @@ def _two_layer(hidden: int, out: int, bias: bool, dropout: float) -> nn.Sequenti
                          nn.Linear(hidden, out, bias=bias))
 
 
-def hop_graph_from_counts(dist: torch.Tensor) -> HopGraph:
-    """Hop-coded CSR of the listed pairs (``dist >= 0``) of a raw hop-count matrix; ``-1`` pairs are simply absent.
+class HopBlocks:
+    """The hop matrices of a batch of graphs on the device: ``code`` (uint8, the ``[n_g, n_g]`` blocks back to back; 255 =
+    not listed), ``node_off`` int32 ``[G + 1]``, ``code_off`` int64 ``[G + 1]`` — what batched_pyg_main.py:69-76 spreads
+    over a ``[sum n_g, sum n_g]`` float matrix."""
 
-    Block-diagonal batches are almost entirely ``-1``, so only the per-graph blocks are kept: O(sum N_g^2) pairs
-    instead of (sum N_g)^2.  Integer work on the device (torch index ops); bit-exact."""
+    def __init__(self, code, node_off, code_off, sizes, max_hop):
+        self.code, self.node_off, self.code_off = code, node_off, code_off
+        self.sizes = [int(s) for s in sizes]
+        self.n_graphs = len(self.sizes)
+        self.total_nodes = sum(self.sizes)
+        self.max_nodes = max(self.sizes) if self.sizes else 0
+        self.n_codes = int(max_hop) + 2                      # hop counts 0 .. max_hop + the (weightless) rest code
+        self._csr = None
+        self._batch_vector = None
+
+    @staticmethod
+    def _offsets(sizes, device):
+        n = torch.tensor([0] + list(sizes), dtype=torch.int64)
+        node_off = torch.cumsum(n, 0)
+        code_off = torch.cumsum(n * n, 0)
+        return node_off.to(torch.int32).to(device), code_off.to(device)
+
+    @staticmethod
+    def _check(status, what):
+        flags, max_hop = (int(v) for v in status.tolist())
+        if flags & 1:
+            raise _lib.GnanHipError(f"{what} must hold integer hop counts in [0, 254] or -1")
+        if flags & 2:
+            raise _lib.GnanHipError(f"{what} lists a pair of nodes of two different graphs: not block-diagonal")
+        return max_hop
+
+    @staticmethod
+    def from_blocks(dists: Sequence[torch.Tensor]) -> "HopBlocks":
+        """From the per-graph ``[n_g, n_g]`` hop matrices (device tensors; batched_pyg_main.py:19-48)."""
+        _lib.require_device(*dists)
+        sizes = [int(d.shape[0]) for d in dists]
+        dev = dists[0].device
+        flat = torch.cat([d.reshape(-1).float() for d in dists]) if dists else torch.empty(0, device=dev)
+        code = torch.empty(flat.numel(), dtype=torch.uint8, device=dev)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().gnan_hops_to_code(_lib.ptr(flat), flat.numel(), _lib.ptr(code), _lib.ptr(status),
+                                                _lib.stream_of(code)), "gnan_hops_to_code")
+        node_off, code_off = HopBlocks._offsets(sizes, dev)
+        return HopBlocks(code, node_off, code_off, sizes, HopBlocks._check(status, "the hop matrices"))
+
+    @staticmethod
+    def from_dense(dist_batch: torch.Tensor, batch_vector: torch.Tensor) -> "HopBlocks":
+        """From the reference's dense block-diagonal ``dist_batch`` (batched_pyg_main.py:69-76) and ``batch_vector``
+        (sorted: node -> graph, batched_pyg_main.py:84-88)."""
+        _lib.require_device(dist_batch)
+        if dist_batch.dim() != 2 or dist_batch.shape[0] != dist_batch.shape[1]:
+            raise ValueError(f"dist_batch must be square, got {tuple(dist_batch.shape)}")
+        dev = dist_batch.device
+        bv = batch_vector.to(dev).long()
+        if bv.numel() != dist_batch.shape[0]:
+            raise ValueError("batch_vector must name the graph of every row of dist_batch")
+        sizes = torch.bincount(bv).tolist() if bv.numel() else []
+        if bv.numel() and bool((bv[1:] < bv[:-1]).any()):
+            raise _lib.GnanHipError("batch_vector must be sorted (the nodes of a graph are consecutive rows)")
+        node_off, code_off = HopBlocks._offsets(sizes, dev)
+        d = dist_batch.float()
+        d = d if d.stride(1) == 1 else d.contiguous()
+        code = torch.empty(sum(s * s for s in sizes), dtype=torch.uint8, device=dev)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        graph_of = bv.to(torch.int32)
+        _lib.check(_lib.lib().gnan_dense_blocks_to_code(_lib.ptr(d), d.stride(0), d.shape[0], _lib.ptr(graph_of),
+                                                        _lib.ptr(node_off), _lib.ptr(code_off), _lib.ptr(code), _lib.ptr(status),
+                                                        _lib.stream_of(code)), "gnan_dense_blocks_to_code")
+        blocks = HopBlocks(code, node_off, code_off, sizes, HopBlocks._check(status, "dist_batch"))
+        blocks._batch_vector = bv
+        return blocks
+
+    def batch_vector(self) -> torch.Tensor:
+        if self._batch_vector is None:
+            self._batch_vector = torch.repeat_interleave(torch.arange(self.n_graphs, device=self.code.device),
+                                                         torch.tensor(self.sizes, device=self.code.device))
+        return self._batch_vector
+
+    def csr(self) -> HopGraph:
+        """The hop-coded CSR of the listed pairs (global node ids) — what the general kernels walk: index work on the
+        ``sum n_g^2`` packed codes, never on ``(sum n_g)^2`` pairs."""
+        if self._csr is None:
+            dev = self.code.device
+            sizes = torch.tensor(self.sizes, dtype=torch.int64, device=dev)
+            node_off = self.node_off.long()
+            g_of_entry = torch.repeat_interleave(torch.arange(self.n_graphs, device=dev), sizes * sizes)
+            local = torch.arange(self.code.numel(), device=dev) - self.code_off[g_of_entry]
+            n_g = sizes[g_of_entry]
+            row = node_off[g_of_entry] + local // n_g
+            col = node_off[g_of_entry] + local % n_g
+            listed = self.code != 255
+            rows, cols, codes = row[listed], col[listed], self.code[listed]        # entry order == (row, col) order
+            rowptr = torch.zeros(self.total_nodes + 1, dtype=torch.int64, device=dev)
+            rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=self.total_nodes), 0)
+            if int(rowptr[-1]) < 2 ** 31:
+                rowptr = rowptr.to(torch.int32)
+            self._csr = HopGraph.from_csr(rowptr, cols.to(torch.int32), codes, n_cols=self.total_nodes, n_codes=self.n_codes)
+        return self._csr
+
+
+def collate(batch):
+    """Device-side counterpart of ``distance_collate_fn`` (batched_pyg_main.py:54-91): ``batch`` is a list of
+    ``(x [n_g, F], dist [n_g, n_g], y)`` device tensors; returns ``(x_batch, blocks, y_batch, batch_vector)`` where ``blocks``
+    (:class:`HopBlocks`) stands where the reference's ``dist_batch`` does — ``model(x_batch, blocks, batch_vector)``."""
+    xs, dists, ys = zip(*batch)
+    blocks = HopBlocks.from_blocks(dists)
+    return torch.cat(xs, dim=0), blocks, torch.cat([y.reshape(-1) for y in ys], dim=0), blocks.batch_vector()
+
+
+def hop_graph_from_counts(dist: torch.Tensor) -> HopGraph:
+    """Hop-coded CSR of the listed pairs (``dist >= 0``) of ANY raw hop-count matrix (not necessarily block-diagonal);
+    ``-1`` pairs are simply absent.  Integer work on the device (torch index ops over the dense matrix); bit-exact."""
     _lib.require_device(dist)
     if dist.dim() != 2 or dist.shape[0] != dist.shape[1]:
         raise ValueError(f"dist_batch must be square, got {tuple(dist.shape)}")
@@ -47,9 +170,71 @@ def hop_graph_from_counts(dist: torch.Tensor) -> HopGraph:
     return HopGraph.from_csr(rowptr, cols.to(torch.int32), codes.to(torch.uint8), n_cols=n, n_codes=max_hop + 2)
 
 
+class _BatchedGraphs(torch.autograd.Function):
+    """``[G, C]`` per-graph read-outs (or ``[N, C]`` node outputs) of a batch by ONE launch; backward: the general kernels
+    on the blocks' CSR from the saved node sums and rho table."""
+
+    @staticmethod
+    def forward(ctx, x, blocks: HopBlocks, graph_sum, fm, rm, *params):
+        from . import functional as Fn
+        Lf, Hf, Cf, F = fm
+        Lr, Hr, Cr = rm
+        xk = Fn._rows(x.detach().float())
+        dev = xk.device
+        G, N, D = blocks.n_graphs, blocks.total_nodes, blocks.n_codes
+        keep_f = [None if t is None else Fn._c(t.detach()) for t in params[:6]]
+        keep_r = [None if t is None else Fn._c(t.detach()) for t in params[6:]]
+        S = torch.empty((N, Cf), dtype=torch.float32, device=dev)
+        lut = torch.empty((G, D, Cr), dtype=torch.float32, device=dev)
+        Y = None if graph_sum else torch.empty((N, Cf), dtype=torch.float32, device=dev)
+        Ysum = torch.empty((G, Cf), dtype=torch.float32, device=dev) if graph_sum else None
+        need = _lib.lib().gnan_small_batch_workspace_bytes(G, N, F, Cf)
+        ws = torch.empty(need // 4 + 1, dtype=torch.int32, device=dev)
+        ws[: 4 * G].zero_()                                                  # the graphs' arrival counters
+        a = _lib.SmallBatchArgs(x=_lib.ptr(xk), x_stride=xk.stride(0), total_nodes=N, F=F, n_graphs=G,
+                                max_nodes=blocks.max_nodes, f=Fn._small_mlp(keep_f, Lf, Hf, Cf),
+                                rho=Fn._small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(blocks.code),
+                                node_off=_lib.ptr(blocks.node_off), code_off=_lib.ptr(blocks.code_off), D=D, rho_raw_hops=1,
+                                rest_zero=1, S=_lib.ptr(S), lut=_lib.ptr(lut), Y=_lib.ptr(Y), Ysum=_lib.ptr(Ysum),
+                                workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4)
+        _lib.check(_lib.lib().gnan_small_batch_fwd(a, _lib.stream_of(xk)), "gnan_small_batch_fwd")
+        ctx.blocks, ctx.graph_sum, ctx.fm, ctx.rm = blocks, graph_sum, fm, rm
+        ctx.present = [t is not None for t in params]
+        ctx.dests = Fn._grad_dests_of(params)
+        ctx.save_for_backward(xk, S, lut, *[t for t in params if t is not None])
+        return Ysum if graph_sum else Y
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from . import functional as Fn
+        saved = list(ctx.saved_tensors)
+        x, S, lut = saved[:3]
+        rest = saved[3:]
+        params = [rest.pop(0) if pr else None for pr in ctx.present]
+        Lf, Hf, Cf, F = ctx.fm
+        Lr, Hr, Cr = ctx.rm
+        need_f, need_r = any(ctx.needs_input_grad[5:11]), any(ctx.needs_input_grad[11:])
+        blocks = ctx.blocks
+        dY = d_out.index_select(0, blocks.batch_vector()) if ctx.graph_sum else d_out      # every node gets its graph's gradient
+        bag = Fn._Bag()
+        bag.g, bag.use_cnt, bag.with_rest, bag.row_ids, bag.reduce_cr = blocks.csr(), False, False, None, 0
+        bag.s_total, bag.total_rows, bag.total_group = None, None, Fn.NOT_SHARED
+        dS, dlut = Fn._aggregate_backward(bag, S, lut[0].contiguous(), dY.contiguous(), need_f, need_r)
+        pg_f = pg_r = [None] * 6
+        if need_f:
+            _, pg_f = Fn._shape_function_grads(x, params[:6], ctx.present[:6], None, dS, True, Lf, Hf, Cf, F, dests=ctx.dests[:6])
+        if need_r:
+            D = blocks.n_codes
+            hops = torch.arange(D - 1, dtype=torch.float32, device=x.device).view(-1, 1)     # rho's inputs: the raw hop counts
+            _, pg_r = Fn._shape_function_grads(hops, params[6:], ctx.present[6:], None, dlut[: D - 1].reshape(-1, Cr), False,
+                                               Lr, Hr, Cr, 1, dests=ctx.dests[6:])
+        return (None, None, None, None, None, *pg_f, *pg_r)
+
+
 class TensorGNAN(_PathBase):
     """``TensorGNAN`` of the batched script — constructor batched_pyg_main.py:99-131, forward :133-184.
-    The shape functions and rho are always two layers deep there (``n_layers`` is accepted and unused)."""
+    The shape functions and rho are always two layers deep there (``n_layers`` is accepted and unused).
+    ``dist_batch`` may be the reference's dense matrix or the :class:`HopBlocks` of :func:`collate`."""
 
     def __init__(self, in_channels, out_channels, n_layers, hidden_channels=16, device='cpu',
                  bias=True, dropout=0.0, is_graph_task=True):
@@ -62,12 +247,35 @@ class TensorGNAN(_PathBase):
         self.rho = _two_layer(hidden_channels, out_channels, bias, dropout)
         self._init_caches()
 
+    def _blocks(self, dist_batch, batch_vector) -> Optional[HopBlocks]:
+        if isinstance(dist_batch, HopBlocks):
+            return dist_batch
+        hit = self._graph_cache.get((dist_batch, batch_vector), "blocks")
+        if hit is None:
+            try:
+                hit = HopBlocks.from_dense(dist_batch, batch_vector)
+            except _lib.GnanHipError:
+                hit = False                              # not block-diagonal / unsorted: the general CSR of the whole matrix
+            self._graph_cache.put((dist_batch, batch_vector), "blocks", hit)
+        return hit or None
+
     def forward(self, x_batch, dist_batch, batch_vector):
         self._check_dropout()
-        _lib.require_device(x_batch, dist_batch)
-        g = self._graph_cache.get((dist_batch,), "counts")
-        if g is None:
-            g = self._graph_cache.put((dist_batch,), "counts", hop_graph_from_counts(dist_batch))
+        _lib.require_device(x_batch)
+        blocks = self._blocks(dist_batch, batch_vector)
+        f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
+        if (BATCH_KERNEL and blocks is not None and not self._dropout_active() and 1 <= blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
+                and blocks.n_codes <= 256 and f.H <= 64 and f.C <= 8 and x_batch.dtype == torch.float32
+                and not x_batch.requires_grad and blocks.n_graphs <= 65535):
+            fm, rm = (f.L, f.H, f.C, f.F), (rho.L, rho.H, rho.C)
+            return _BatchedGraphs.apply(x_batch, blocks, bool(self.is_graph_task), fm, rm, *f[:6], *rho[:6])
+        if blocks is not None:
+            g = blocks.csr()
+        else:
+            _lib.require_device(dist_batch)
+            g = self._graph_cache.get((dist_batch,), "counts")
+            if g is None:
+                g = self._graph_cache.put((dist_batch,), "counts", hop_graph_from_counts(dist_batch))
         S = self._features(x_batch, "fs", self.fs, True)                                    # [N, C]
         hops = torch.arange(g.n_codes - 1, dtype=torch.float32, device=x_batch.device).view(-1, 1)
         if self._dropout_active():
@@ -83,11 +291,12 @@ class TensorGNAN(_PathBase):
             # rho on the handful of distinct hop counts: one launch of the shape-function kernel (one of gnan_fmlp_bwd in the
             # backward pass) instead of the six framework launches of self.rho(hops), as modules._lut_global
             from .functional import feature_mlps
-            listed = feature_mlps(hops, self._stacked("rho", [self.rho]), sum_features=False)
+            listed = feature_mlps(hops, rho, sum_features=False)
             lut = torch.cat([listed, torch.zeros(1, self.out_channels, device=x_batch.device)], dim=0)
             Y = rho_aggregate(g, S, lut, use_cnt=False, with_rest=False)                    # [N, C]
         if not self.is_graph_task:
             return Y
-        n_graphs = int(batch_vector.max()) + 1
+        bv = blocks.batch_vector() if blocks is not None else batch_vector.to(Y.device).long()
+        n_graphs = blocks.n_graphs if blocks is not None else int(bv.max()) + 1
         out = torch.zeros(n_graphs, Y.shape[1], device=Y.device, dtype=Y.dtype)
-        return out.index_add(0, batch_vector.to(Y.device).long(), Y)                        # batched_pyg_main.py:176-181
+        return out.index_add(0, bv, Y)                                                      # batched_pyg_main.py:176-181

@@ -187,3 +187,72 @@ extern "C" int gnan_multi_copy(int32_t count, const void* const* src, void* cons
   hipLaunchKernelGGL(multi_copy_kernel, dim3(static_cast<unsigned>(count)), dim3(256), 0, static_cast<hipStream_t>(stream), m);
   return gnan::check_launch("multi_copy_kernel");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// out[i, c] = sum over features k of fx[i, k * C + c]  (C in {1, 2, 4}; rows 16-byte aligned, W % 4 == 0): the feature sum of
+// KEPT per-feature rows — what the backward pass of a reference-order forward aggregates (GNAN.py:157 applied to the rows of
+// models.py:360-365).  LPR lanes share a row, a 16-byte load each (every quad carries the same channel pattern), a butterfly
+// over the row's lanes, one store; HBM-bound: W * 4 bytes in, C * 4 out per row.
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <int LPR>
+__global__ __launch_bounds__(256) void feature_sum_kernel(const float* __restrict__ fx, int64_t n, int W, int64_t stride, int C,
+                                                          float* __restrict__ out, int64_t out_stride) {
+  constexpr int G = 256 / LPR;                       // rows per workgroup pass
+  const int sub = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+  const bool live = sub * 4 < W;
+  for (int64_t r0 = static_cast<int64_t>(blockIdx.x) * G; r0 < n; r0 += static_cast<int64_t>(gridDim.x) * G) {
+    const int64_t r = r0 + slot;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n) {
+      const float* row = fx + r * stride;
+      for (int c4 = sub; c4 * 4 < W; c4 += LPR) {   // (one trip unless a row is wider than 4 * LPR floats)
+        const float4 t = *reinterpret_cast<const float4*>(row + c4 * 4);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+    }
+    (void)live;
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+      acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    }
+    if (sub == 0 && r < n) {
+      float* o = out + r * out_stride;
+      if (C == 1) o[0] = (acc.x + acc.y) + (acc.z + acc.w);
+      else if (C == 2) { o[0] = acc.x + acc.z; o[1] = acc.y + acc.w; }
+      else { o[0] = acc.x; o[1] = acc.y; o[2] = acc.z; o[3] = acc.w; }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int gnan_feature_sum(const float* fx, int64_t n, int32_t W, int64_t stride, int32_t C, float* out,
+                                int64_t out_stride, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && W >= 1 && (C == 1 || C == 2 || C == 4), "feature_sum: bad sizes (C must be 1, 2 or 4)");
+  if (n == 0) return GNAN_OK;
+  GNAN_REQUIRE(fx && out, "feature_sum: null pointer");
+  GNAN_REQUIRE(W % 4 == 0 && W % C == 0 && stride % 4 == 0 && stride >= W && out_stride >= C &&
+                   reinterpret_cast<uintptr_t>(fx) % 16 == 0,
+               "feature_sum: rows must be whole 16-byte quads (W %% 4 == 0, aligned, stride %% 4 == 0)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int lpr = 1;
+  while (lpr * 4 < W && lpr < 64) lpr <<= 1;
+  const int64_t rows_per_pass = 256 / lpr;
+  int64_t blocks = (n + rows_per_pass - 1) / rows_per_pass;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, fx, n, W, stride, C, out, out_stride);
+    return gnan::check_launch("feature_sum_kernel");
+  };
+  switch (lpr) {
+    case 1: return go(feature_sum_kernel<1>);
+    case 2: return go(feature_sum_kernel<2>);
+    case 4: return go(feature_sum_kernel<4>);
+    case 8: return go(feature_sum_kernel<8>);
+    case 16: return go(feature_sum_kernel<16>);
+    case 32: return go(feature_sum_kernel<32>);
+    default: return go(feature_sum_kernel<64>);
+  }
+}

@@ -40,9 +40,19 @@ struct SmallParams {
   float* Ysum;
   float* part;          // [F, n, C]
   unsigned* counter;    // zero before the first launch; the last workgroup zeroes it again
+  int rho_raw;          // rho's inputs are the raw hop counts d (batched_pyg_main.py:151) instead of 1 / (1 + d)
+  int rest_zero;        // pairs beyond the last listed hop carry weight 0 (the -1 mask, batched_pyg_main.py:155-156) instead of rho(0)
 };
 
-constexpr int kMaxH = 64, kMaxC = 8, kWaves = 4, kMaxNodes = 64;
+// Many small graphs in one launch (batched_pyg_main.py:133-184): blockIdx.y = graph; nodes, codes, node sums, outputs, partial
+// sums and arrival counters of graph g are runs of the batch's arrays.
+struct BatchParams {
+  SmallParams base;              // pointers of graph 0; n unused
+  const int32_t* node_off;       // [G + 1]
+  const int64_t* code_off;       // [G + 1] byte offsets of the graphs' [n_g][n_g] code blocks
+};
+
+constexpr int kMaxH = 64, kMaxC = 8, kWaves = 4, kMaxNodes = 128;     // nodes: NB blocks of 64 (kernels are built for NB = 1 and 2)
 
 // LDS image of one scalar MLP's weights (scalar loads straight from memory made every inner-loop step wait ~150 cycles for
 // its weights: 33 us for a 30-node graph; read as LDS broadcasts the same loop is bound by LDS issue)
@@ -166,17 +176,27 @@ __device__ __forceinline__ void mlp_block(const Mlp& m, const MlpLds& w, float x
   __syncthreads();                                   // the columns are free for the next node block
 }
 
-__global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
-  __shared__ __attribute__((aligned(16))) float cols[2 * kMaxH * kWave];     // activation columns; the aggregation's tables later
+constexpr int small_cols_floats(int nb) {
+  const int nodes = 64 * nb;
+  const int tables = 2 * nodes * kMaxC + 256 * kMaxC + nodes * kWave + nodes * nodes / 4;
+  return tables > 2 * kMaxH * kWave ? tables : 2 * kMaxH * kWave;
+}
+
+// NB: node blocks of 64 the graph may have (1: n <= 64, the tables fit the activation columns as before; 2: n <= 128, the
+// aggregation's tables need 64 KB).  Config 2's graphs have 30 nodes on average and 3 % of them
+// more than 64; 128 covers 99.98 %.
+template <int NB>
+__device__ __forceinline__ void small_graph_body(const SmallParams& p, float* cols) {
+  constexpr int kNodes = 64 * NB;
+  // cols [small_cols_floats(NB)]: activation columns; the aggregation's tables later — node sums, outputs, rho table, row
+  // weights [n][64], hop codes [n][n]
   __shared__ __attribute__((aligned(16))) float weights[kWeightFloats];
   __shared__ unsigned s_last;
   float* col_a = cols;
   float* col_b = cols + kMaxH * kWave;
   float* s_S = cols;                                 // [n, C]      (phase 3: the columns are dead by then)
-  float* s_Y = cols + kMaxNodes * kMaxC;             // [n, C]
-  float* s_lut = cols + 2 * kMaxNodes * kMaxC;       // [D, rho C]
-  static_assert(2 * kMaxNodes * kMaxC + 256 * kMaxC + kMaxNodes * kWave + kMaxNodes * kMaxNodes / 4 <= 2 * kMaxH * kWave,
-                "the aggregation's tables (node sums, outputs, rho table, row weights, hop codes) fit the activation columns");
+  float* s_Y = cols + kNodes * kMaxC;                // [n, C]
+  float* s_lut = cols + 2 * kNodes * kMaxC;          // [D, rho C]
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   const int k = blockIdx.x;
@@ -185,8 +205,8 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
   // What the aggregation will read from memory that does not depend on the other workgroups — hop codes and shell sizes — is
   // requested NOW, by every workgroup (any of them may be the last), into registers: the loads fly while the MLP runs.  A cold
   // load costs more than a microsecond on this part and the kernel is a chain of them; this takes two links out.
-  constexpr int kWordsPer = kMaxNodes * kMaxNodes / 4 / (kWaves * kWave);      // 4 code words per thread
-  constexpr int kCntPer = kMaxNodes * kWave / (kWaves * kWave);                 // 16 shell sizes per thread (D <= 64)
+  constexpr int kWordsPer = kNodes * kNodes / 4 / (kWaves * kWave);            // 4 code words per thread (NB = 2: 16)
+  constexpr int kCntPer = kNodes * kWave / (kWaves * kWave);                    // 16 shell sizes per thread (D <= 64; NB = 2: 32)
   const bool fast = p.D <= kWave && p.r.C == 1;      // per-row weights lut[d] / max(cnt[i, d], 1) fit LDS
   const int code_words = p.n * p.n / 4;
   uint32_t pre_code[kWordsPer];
@@ -206,19 +226,29 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
   }
   if (k < p.F) {
     stage_weights(p.f, k, wl_);
-    const int j = lane;                              // n <= 64: one block of nodes
-    const float xv = j < p.n ? p.x[static_cast<int64_t>(j) * p.x_stride + k] : 0.f;
-    mlp_block(p.f, wl_, xv, col_a, col_b, lane, wave, out);
-    if (wave == 0 && j < p.n)
-      for (int c = 0; c < p.f.C; ++c) p.part[(static_cast<int64_t>(k) * p.n + j) * p.f.C + c] = out[c];
+    float xv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {                   // (all node blocks' inputs requested before the first MLP)
+      const int j = b * kWave + lane;
+      xv[b] = j < p.n ? p.x[static_cast<int64_t>(j) * p.x_stride + k] : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int j = b * kWave + lane;
+      if (b * kWave < p.n) {                         // (uniform)
+        mlp_block(p.f, wl_, xv[b], col_a, col_b, lane, wave, out);
+        if (wave == 0 && j < p.n)
+          for (int c = 0; c < p.f.C; ++c) p.part[(static_cast<int64_t>(k) * p.n + j) * p.f.C + c] = out[c];
+      }
+    }
   } else {
     stage_weights(p.r, 0, wl_);
     for (int d0 = 0; d0 < p.D; d0 += kWave) {
       const int d = d0 + lane;
-      const float u = d < p.D - 1 ? 1.0f / (static_cast<float>(d) + 1.0f) : 0.f;     // graph.hop_inputs
+      const float u = d < p.D - 1 ? (p.rho_raw ? static_cast<float>(d) : 1.0f / (static_cast<float>(d) + 1.0f)) : 0.f;     // graph.hop_inputs
       mlp_block(p.r, wl_, u, col_a, col_b, lane, wave, out);
       if (wave == 0 && d < p.D)
-        for (int c = 0; c < p.r.C; ++c) p.lut[d * p.r.C + c] = out[c];
+        for (int c = 0; c < p.r.C; ++c) p.lut[d * p.r.C + c] = (p.rest_zero && d == p.D - 1) ? 0.f : out[c];
     }
   }
   // ---- join: the last workgroup to arrive finishes the graph --------------------------------------------------------------
@@ -232,8 +262,8 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
   // (the fence above made the other workgroups' results visible to this one: plain loads from here on.  Every table the
   // aggregation reads — node sums, rho table, hop codes, the rows' weights — is staged in LDS; the per-row loop never waits
   // for memory)
-  uint8_t* s_code = reinterpret_cast<uint8_t*>(cols + 2 * kMaxNodes * kMaxC + 256 * kMaxC + kMaxNodes * kWave);   // [n, n]
-  float* s_w = cols + 2 * kMaxNodes * kMaxC + 256 * kMaxC;                                                         // [n, 64]
+  uint8_t* s_code = reinterpret_cast<uint8_t*>(cols + 2 * kNodes * kMaxC + 256 * kMaxC + kNodes * kWave);         // [n, n]
+  float* s_w = cols + 2 * kNodes * kMaxC + 256 * kMaxC;                                                            // [n, 64]
   // the other workgroups' results: node sums (eight feature terms in flight at a time) and the rho table — one more batch
   float lut_v[kMaxC * 256 / (kWaves * kWave)];       // 8 table entries per thread at most
 #pragma unroll
@@ -336,6 +366,30 @@ __global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
   if (threadIdx.x == 0) *p.counter = 0u;
 }
 
+template <int NB>
+__global__ __launch_bounds__(256) void small_graph_kernel(const SmallParams p) {
+  extern __shared__ __attribute__((aligned(16))) float cols[];               // small_cols_floats(NB) floats
+  small_graph_body<NB>(p, cols);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void small_graph_batch_kernel(const BatchParams bp) {
+  extern __shared__ __attribute__((aligned(16))) float cols[];
+  const int g = blockIdx.y;
+  SmallParams p = bp.base;
+  const int64_t o = bp.node_off[g];
+  p.n = static_cast<int>(bp.node_off[g + 1] - o);
+  p.x += o * p.x_stride;
+  p.code += bp.code_off[g];
+  p.S += o * p.f.C;
+  if (p.Y) p.Y += o * p.f.C;
+  if (p.Ysum) p.Ysum += static_cast<int64_t>(g) * p.f.C;
+  p.lut += static_cast<int64_t>(g) * p.D * p.r.C;
+  p.part += o * p.F * p.f.C;
+  p.counter += 4 * g;                                 // 16 bytes of its own per graph
+  small_graph_body<NB>(p, cols);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The backward pass of the same small graph in ONE launch: gradients of every parameter of f and rho from the gradient of the
 // node outputs (or of their sum).  No workgroup waits for another: workgroup k < F forms the operand gradient
@@ -365,21 +419,27 @@ struct SmallBwdParams {
 
 constexpr int kBinStride = kWave + 1;
 
-template <int C>
+// NB as in small_graph_kernel (2: n <= 128 — hop codes and the row-weight / bin area take 50 KB: dynamic LDS).
+template <int C, int NB>
 __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdParams p) {
+  constexpr int kNodes = 64 * NB;
+  constexpr int kUFloats = kNodes * kWave > 2 * kWave * kBinStride ? kNodes * kWave : 2 * kWave * kBinStride;
   __shared__ gnan_bwd::RedBuffer red;
-  __shared__ __attribute__((aligned(16))) uint8_t s_code[kMaxNodes * kMaxNodes];
-  __shared__ __attribute__((aligned(16))) float s_u[2 * kWave * kBinStride];    // row weights [n][64] (features) | bins [2][D][65] (rho)
-  __shared__ float s_dY[kMaxNodes * kMaxC];
-  __shared__ float s_S[kMaxNodes * kMaxC];
-  __shared__ float s_g[kMaxNodes * kMaxC];            // dS [n, C]  |  dlut [D]
+  extern __shared__ __attribute__((aligned(16))) float dyn[];                   // s_u | s_code
+  float* s_u = dyn;                                   // row weights [n][64] (features) | bins [waves][D][n | 1] (rho)
+  uint8_t* s_code = reinterpret_cast<uint8_t*>(dyn + kUFloats);                 // [n][n]
+  __shared__ float s_dY[kNodes * kMaxC];
+  __shared__ float s_S[kNodes * kMaxC];
+  __shared__ float s_g[kNodes * kMaxC];              // dS [n, C]  |  dlut [D]
   __shared__ double s_part[kWaves][kWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int k = blockIdx.x, n = p.n;
   const bool is_rho = k == p.F;
   // ---- everything from memory in one batch ----------------------------------------------------------------------------------
   {
-    constexpr int kWordsPer = kMaxNodes * kMaxNodes / 4 / 256;
+    constexpr int kWordsPer = kNodes * kNodes / 4 / 256;
+    constexpr int kRowsPer = kNodes * kMaxC / 256;     // (node, channel) entries per thread
+    constexpr int kCntPer = kNodes * kWave / 256;      // shell sizes per thread
     const int words = n * n / 4;
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(p.code);
     uint32_t v[kWordsPer];
@@ -388,16 +448,16 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
       const int i = threadIdx.x + t * 256;
       v[t] = i < words ? cw[i] : 0u;
     }
-    float gy[2], sv[2];
-    int q[16];
+    float gy[kRowsPer], sv[kRowsPer];
+    int q[kCntPer];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < kRowsPer; ++t) {
       const int e = threadIdx.x + t * 256;
       gy[t] = e < n * C ? (p.dY ? p.dY[e] : p.dYsum[e % C]) : 0.f;
       sv[t] = (is_rho && e < n * C) ? p.S[e] : 0.f;
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < kCntPer; ++t) {
       const int e = threadIdx.x + t * 256;
       q[t] = (!is_rho && p.cnt && e < n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
     }
@@ -410,15 +470,16 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     }
     for (int i = words * 4 + threadIdx.x; i < n * n; i += 256) s_code[i] = p.code[i];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < kRowsPer; ++t) {
       const int e = threadIdx.x + t * 256;
       if (e < n * C) { s_dY[e] = gy[t]; s_S[e] = sv[t]; }
     }
+    __syncthreads();                                       // (s_g doubles as dS / dlut below: nobody reads it yet)
     if (wave == 0 && lane < p.D) s_g[lane] = l;            // the rho table, for a moment
     __syncthreads();
     if (!is_rho) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < kCntPer; ++t) {
         const int e = threadIdx.x + t * 256;
         if (e < n * p.D) {
           const float lv = s_g[e % p.D];
@@ -453,21 +514,26 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   // (this workgroup is the kernel's critical path: a row per wave and round, all four waves where their bins fit — they do
   // for the graphs this kernel is for — and bin rows only as long as there are neighbours)
   const int stride = n | 1;                                // odd: lane d's walk along bin row d does not collide with lane d + 1's
-  const int nw = 4 * p.D * stride <= 2 * kWave * kBinStride ? 4 : 2;        // waves that bin
+  int nw = 1;                                              // waves that bin: as many as have room for their [D][stride] bins
+  while (nw < 4 && 2 * nw * p.D * stride <= kUFloats) nw *= 2;
   float* bins = s_u + wave * p.D * stride;
   double acc = 0.0;                                        // lane d: dlut[d] over this wave's rows
   for (int r = 0; nw * r < n; ++r) {
     const int i = nw * r + wave;
     const bool live = wave < nw && i < n;
     if (live) {
-      if (lane < n) {
-        for (int d = 0; d < p.D; ++d) bins[d * stride + lane] = 0.f;
-        int d = s_code[i * n + lane];
-        d = d < p.D - 1 ? d : p.D - 1;
-        float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) v = fmaf(s_dY[i * C + c], s_S[lane * C + c], v);
-        bins[d * stride + lane] = v;                       // (a lane owns its column: no other lane wrote it)
+      for (int b = 0; b < NB; ++b) {
+        const int j = b * kWave + lane;                   // the neighbour this lane takes in this block
+        if (j < n) {
+          for (int d = 0; d < p.D; ++d) bins[d * stride + j] = 0.f;
+          int d = s_code[i * n + j];
+          d = d < p.D - 1 ? d : p.D - 1;
+          float v = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) v = fmaf(s_dY[i * C + c], s_S[j * C + c], v);
+          bins[d * stride + j] = v;                       // (a lane owns its columns: no other lane wrote them)
+        }
       }
     }
     __syncthreads();
@@ -492,9 +558,24 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   else gnan_bwd::feature_grads<1, false>(p.r, 0, 0, p.D, 0, nodrop, u_of, gl_of, red);
 }
 
+template <int NB>
+constexpr size_t small_bwd_dyn_bytes() {
+  constexpr int nodes = 64 * NB;
+  constexpr int u = nodes * kWave > 2 * kWave * kBinStride ? nodes * kWave : 2 * kWave * kBinStride;
+  return static_cast<size_t>(u) * sizeof(float) + static_cast<size_t>(nodes) * nodes;
+}
+
 template <int C>
 int launch_small_bwd(const SmallBwdParams& p, hipStream_t st) {
-  hipLaunchKernelGGL((small_graph_bwd_kernel<C>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256), 0, st, p);
+  if (p.n <= 64) {
+    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 1>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256), small_bwd_dyn_bytes<1>(), st, p);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_bwd_kernel<C, 2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       static_cast<int>(small_bwd_dyn_bytes<2>()));
+    if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_graph_bwd: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 2>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256), small_bwd_dyn_bytes<2>(), st, p);
+  }
   return gnan::check_launch("small_graph_bwd_kernel");
 }
 
@@ -551,8 +632,18 @@ extern "C" int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_
   p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
   p.counter = static_cast<unsigned*>(a->workspace);
   p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 16);
-  hipLaunchKernelGGL(small_graph_kernel, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave), 0,
-                     static_cast<hipStream_t>(stream), p);
+  p.rho_raw = 0; p.rest_zero = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->n <= 64) {
+    hipLaunchKernelGGL(small_graph_kernel<1>, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave),
+                       small_cols_floats(1) * sizeof(float), st, p);
+  } else {
+    constexpr size_t lds = small_cols_floats(2) * sizeof(float);          // 64 KB of tables + the static weight image
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_kernel<2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_graph: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL(small_graph_kernel<2>, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave), lds, st, p);
+  }
   return gnan::check_launch("small_graph_kernel");
 }
 
@@ -584,4 +675,131 @@ extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_str
     case 7: return launch_small_bwd<7>(p, st);
     default: return launch_small_bwd<8>(p, st);
   }
+}
+
+
+extern "C" size_t gnan_small_batch_workspace_bytes(int32_t n_graphs, int64_t total_nodes, int32_t F, int32_t C) {
+  return static_cast<size_t>(n_graphs) * 16 + static_cast<size_t>(total_nodes) * F * C * sizeof(float);     // counters | part
+}
+
+extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "small_batch: null args");
+  GNAN_REQUIRE(a->n_graphs >= 0 && a->F >= 1 && a->D >= 1 && a->total_nodes >= 0, "small_batch: bad sizes");
+  if (a->n_graphs == 0) return GNAN_OK;
+  if (a->max_nodes < 1 || a->max_nodes > kMaxNodes || a->D > 256 || !mlp_ok(&a->f, kMaxC) || !mlp_ok(&a->rho, kMaxC) ||
+      (a->rho.C != 1 && a->rho.C != a->f.C))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_batch: covers graphs of <= %d nodes, D <= 256 shells, L in {2, 3}, H <= %d, C <= %d "
+                      "and a rho of one channel or one per output channel (got max n=%d D=%d L=%d/%d H=%d/%d C=%d/%d)", kMaxNodes,
+                      kMaxH, kMaxC, a->max_nodes, a->D, a->f.L, a->rho.L, a->f.H, a->rho.H, a->f.C, a->rho.C);
+  GNAN_REQUIRE(a->x && a->code && a->node_off && a->code_off && a->S && a->lut && (a->Y || a->Ysum),
+               "small_batch: null x / code / offsets / S / lut / outputs");
+  GNAN_REQUIRE(a->x_stride >= a->F, "small_batch: row stride smaller than the width");
+  GNAN_REQUIRE(a->n_graphs <= 65535, "small_batch: at most 65535 graphs per launch");
+  const size_t need = gnan_small_batch_workspace_bytes(a->n_graphs, a->total_nodes, a->F, a->f.C);
+  if (a->workspace == nullptr || a->workspace_bytes < need)
+    return gnan::fail(GNAN_ERR_WORKSPACE, "small_batch: workspace %zu B < required %zu B", a->workspace_bytes, need);
+  BatchParams bp;
+  SmallParams& p = bp.base;
+  p.x = a->x; p.x_stride = a->x_stride; p.n = 0; p.F = a->F;
+  p.f = to_mlp(&a->f); p.r = to_mlp(&a->rho);
+  p.code = a->code; p.D = a->D; p.cnt = nullptr; p.cnt_stride = 0;
+  p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
+  p.counter = static_cast<unsigned*>(a->workspace);
+  p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + static_cast<size_t>(a->n_graphs) * 16);
+  p.rho_raw = a->rho_raw_hops != 0; p.rest_zero = a->rest_zero != 0;
+  bp.node_off = a->node_off; bp.code_off = a->code_off;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(a->F) + 1, static_cast<unsigned>(a->n_graphs));
+  if (a->max_nodes <= 64) {
+    hipLaunchKernelGGL(small_graph_batch_kernel<1>, grid, dim3(kWaves * kWave), small_cols_floats(1) * sizeof(float), st, bp);
+  } else {
+    constexpr size_t lds = small_cols_floats(2) * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_batch_kernel<2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_batch: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL(small_graph_batch_kernel<2>, grid, dim3(kWaves * kWave), lds, st, bp);
+  }
+  return gnan::check_launch("small_graph_batch_kernel");
+}
+
+// Per-graph hop matrices (batched_pyg_main.py:19-48: float hop counts, -1 = unreachable) -> the packed uint8 codes the
+// batched kernel reads: code = hop for 0 <= hop <= 254, 255 for negative entries.  status[0] |= 1 for a value that is not
+// such an integer; status[1] = the largest hop seen.  From the packed concatenation of the blocks (src_stride == 0, count
+// values) or cut out of the dense block-diagonal matrix of the reference's collate function (batched_pyg_main.py:54-91:
+// [N, N] with row stride src_stride; status[0] |= 2 if an entry OUTSIDE the diagonal blocks is listed).
+namespace {
+__global__ __launch_bounds__(256) void hops_to_code_kernel(const float* __restrict__ src, int64_t count, uint8_t* __restrict__ code,
+                                                           int* __restrict__ status) {
+  int bad = 0, top = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float h = src[i];
+    int c = 255;
+    if (h >= 0.f) {
+      const float r = rintf(h);
+      if (r != h || r > 254.f) bad = 1;
+      c = static_cast<int>(fminf(r, 254.f));
+      top = c > top ? c : top;
+    } else if (!(h < 0.f)) {
+      bad = 1;                                       // NaN
+    }
+    code[i] = static_cast<uint8_t>(c);
+  }
+  if (bad) atomicOr(&status[0], 1);
+  if (top) atomicMax(&status[1], top);
+}
+
+// one workgroup per row of the dense [N, N] matrix: the row's block entries go to the packed codes, the rest must be < 0
+__global__ __launch_bounds__(256) void dense_blocks_to_code_kernel(const float* __restrict__ dist, int64_t stride, int64_t n,
+                                                                   const int32_t* __restrict__ graph_of, const int32_t* __restrict__ node_off,
+                                                                   const int64_t* __restrict__ code_off, uint8_t* __restrict__ code,
+                                                                   int* __restrict__ status) {
+  const int64_t i = blockIdx.x;
+  const int g = graph_of[i];
+  const int64_t lo = node_off[g], hi = node_off[g + 1];
+  const float* row = dist + i * stride;
+  uint8_t* out = code + code_off[g] + (i - lo) * (hi - lo);
+  int bad = 0, top = 0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) {
+    const float h = row[j];
+    if (j >= lo && j < hi) {
+      int c = 255;
+      if (h >= 0.f) {
+        const float r = rintf(h);
+        if (r != h || r > 254.f) bad |= 1;
+        c = static_cast<int>(fminf(r, 254.f));
+        top = c > top ? c : top;
+      } else if (!(h < 0.f)) {
+        bad |= 1;
+      }
+      out[j - lo] = static_cast<uint8_t>(c);
+    } else if (!(h < 0.f)) {
+      bad |= 2;                                      // a listed (or NaN) pair across two graphs: not block-diagonal
+    }
+  }
+  if (bad) atomicOr(&status[0], bad);
+  if (top) atomicMax(&status[1], top);
+}
+}  // namespace
+
+extern "C" int gnan_hops_to_code(const float* hops, int64_t count, uint8_t* code, int32_t* status, gnan_stream_t stream) {
+  GNAN_REQUIRE(count >= 0 && status, "hops_to_code: bad arguments");
+  if (count == 0) return GNAN_OK;
+  GNAN_REQUIRE(hops && code, "hops_to_code: null pointer");
+  int64_t blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(hops_to_code_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), hops,
+                     count, code, status);
+  return gnan::check_launch("hops_to_code_kernel");
+}
+
+extern "C" int gnan_dense_blocks_to_code(const float* dist, int64_t stride, int64_t n, const int32_t* graph_of,
+                                         const int32_t* node_off, const int64_t* code_off, uint8_t* code, int32_t* status,
+                                         gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && stride >= n && status, "dense_blocks_to_code: bad arguments");
+  if (n == 0) return GNAN_OK;
+  GNAN_REQUIRE(dist && graph_of && node_off && code_off && code, "dense_blocks_to_code: null pointer");
+  GNAN_REQUIRE(n <= 0x7fffffffLL, "dense_blocks_to_code: too many rows for one launch");
+  hipLaunchKernelGGL(dense_blocks_to_code_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dist,
+                     stride, n, graph_of, node_off, code_off, code, status);
+  return gnan::check_launch("dense_blocks_to_code_kernel");
 }

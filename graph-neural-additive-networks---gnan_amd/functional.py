@@ -88,8 +88,8 @@ WEIGHT_TABLE_MAX_BYTES = 1 << 30   # backward w.r.t. a wide S: per-node table of
 NARROW_DS_MAX_WIDTH = 32     # backward w.r.t. S: pre-weighted (node, hop code) operand while its rows stay <= 128 B
 
 
-MOMENTS_GENERAL = os.environ.get("GNAN_MOMENTS_GENERAL", "0") == "1"   # A/B aid: the general moment kernel where the C = 1 kernel applies
-LOCATE_SORTED = bool(os.environ.get("GNAN_LOCATE_SORTED"))              # A/B aid: the sorted-array search where the tree search applies
+MOMENTS_GENERAL = False   # A/B aid: the general moment kernel where the C = 1 kernel applies
+LOCATE_SORTED = False              # A/B aid: the sorted-array search where the tree search applies
 
 
 INDEX_FLAGS = 0               # A/B aid: _lib.FPWL_INDEX_HALF_LINES / FPWL_INDEX_BS512 for the direct-index look-up
@@ -100,12 +100,12 @@ def _fpwl_flags() -> int:
     return (_lib.FPWL_MOMENTS_GENERAL if MOMENTS_GENERAL else 0) | (_lib.FPWL_LOCATE_SORTED if LOCATE_SORTED else 0) | INDEX_FLAGS
 
 
-FPWL_ROWS = os.environ.get("GNAN_FPWL_ROWS", "1") != "0"   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
+FPWL_ROWS = True   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
 FPWL_ROWS_MIN_NODES = 32768
 # fewer channels: locating the pieces separately costs more than it saves (GNAN_FPWL_ROWS_MIN_C: A/B aid).  10M nodes x 64
 # features, look-up, two-phase / thread-per-node: C = 2 4.4 / 3.9 ms, C = 4 4.6 / 5.7, C = 8 5.2 / 6.2, C = 12 7.0 / 9.3,
 # C = 32 11.8 / 35.7; arxiv-shaped forward+backward: C = 4 2.91 / 2.84, C = 7 2.77 / 2.86
-FPWL_ROWS_MIN_CHANNELS = int(os.environ.get("GNAN_FPWL_ROWS_MIN_C", "6"))
+FPWL_ROWS_MIN_CHANNELS = 6
 FPWL_ROWS_MIN_CHANNELS_LARGE = min(4, FPWL_ROWS_MIN_CHANNELS)       # from FPWL_ROWS_LARGE nodes (tree-search locate kernel)
 FPWL_ROWS_LARGE = 262144
 
@@ -188,7 +188,7 @@ def _fpwl_index(a: "_lib.FpwlArgs", x: torch.Tensor, t, x_range: torch.Tensor) -
     return [table, key]
 
 
-KEEP_PIECES = os.environ.get("GNAN_KEEP_PIECES", "1") != "0"   # C == 1 training: the forward's pieces (a byte each) serve the backward
+KEEP_PIECES = True   # C == 1 training: the forward's pieces (a byte each) serve the backward
 LOCATED_KEEP_MAX_BYTES = 2 << 30   # (piece, dx) of a forward are kept for its backward pass while they stay below 2 GiB
 
 
@@ -265,6 +265,8 @@ _ROOM_RESULT = None           # (data_ptr of the result, the larger buffer it he
 CAPTURED_BUILDS = []          # (sizes a look-up was captured with, the stacked weights it tabulates) of the capture in progress
 CAPTURE_PINS = None           # list while graphed.GraphedCallable captures: cache-owned tensors the captured step reads
 CAPTURE_GUARD = None          # float32 [1] while a guarded step is captured: set to 1 by a look-up whose tables outgrew its sizes
+CAPTURE_SCRATCH = None        # int32 [64K], ZEROED EAGERLY by graphed.GraphedCallable before its capture and owned by that step:
+                              # workspaces whose invariant is "zero between launches" (the small-graph kernel's arrival counter)
 
 
 def _pin_for_capture(obj):
@@ -272,7 +274,7 @@ def _pin_for_capture(obj):
         CAPTURE_PINS.append(obj)
     return obj
 
-SPECULATIVE_LOOKUP = os.environ.get("GNAN_SPECULATIVE_LOOKUP", "1") != "0"   # queue the look-up before the piece counts are read back
+SPECULATIVE_LOOKUP = True   # queue the look-up before the piece counts are read back
 MOMENTS_FIXED_POINT = True    # accumulate the per-piece moments in 64-bit fixed point (integer LDS atomics, reproducible)
 _ABS_MAX_CACHE = TensorKeyedCache(16)   # feature matrix (object identity + version) -> device scalar max |x|
 
@@ -510,7 +512,7 @@ class TablePrefetch:
         return pending
 
 
-HIP_TABLE_GRADS = os.environ.get("GNAN_HIP_TABLE_GRADS", "1") != "0"   # table path: parameter gradients by gnan_fpwl_param_grads
+HIP_TABLE_GRADS = True   # table path: parameter gradients by gnan_fpwl_param_grads
 
 
 def _table_grads_applies(L: int, H: int, C: int) -> bool:
@@ -575,7 +577,7 @@ def _fpwl_param_grads_launch(params, t, moments, L, H, C, F, dests=None):
     return outs
 
 
-HIP_SMALL_BACKWARD = os.environ.get("GNAN_HIP_SMALL_BACKWARD", "1") != "0"
+HIP_SMALL_BACKWARD = True
 # gnan_fmlp_bwd recomputes the activations of every (node, feature) pair (3 H^2 fmas each, fp32 vector units): beyond a few
 # million pairs the batched GEMMs of the torch route (matrix cores) catch up; AUTO sends such sizes to the table route anyway
 HIP_SMALL_BACKWARD_MAX_WORK = 1 << 23
@@ -1072,20 +1074,50 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
     return total
 
 
+def feature_sum(fx: torch.Tensor, C: int) -> torch.Tensor:
+    """``out[i, c] = sum_k fx[i, k * C + c]`` (``gnan_feature_sum``; C in {1, 2, 4}, whole 16-byte quads per row)."""
+    _lib.require_device(fx)
+    fx = _rows(fx.detach().float())
+    n, W = fx.shape
+    out = torch.empty((n, C), dtype=torch.float32, device=fx.device)
+    _lib.check(_lib.lib().gnan_feature_sum(_lib.ptr(fx), n, W, fx.stride(0), C, _lib.ptr(out), out.stride(0),
+                                           _lib.stream_of(fx)), "gnan_feature_sum")
+    return out
+
+
+class _GraphReadout(torch.autograd.Function):
+    """``out[c] = sum_i Y[i, c]`` — the graph read-out of GNAN.py:75-79 / models.py:383-384 — by ``gnan_colsum`` (float64
+    across threads, fixed order); backward: every node receives the read-out's gradient (a broadcast view, no arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, Y):
+        ctx.n = Y.shape[0]
+        return column_sums(Y).to(Y.dtype)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d.reshape(1, -1).expand(ctx.n, -1)
+
+
+def graph_readout(Y: torch.Tensor) -> torch.Tensor:
+    """``[N, C] -> [C, 1]`` (what ``forward`` of a graph task returns, GNAN.py:79)."""
+    return _GraphReadout.apply(Y).view(-1, 1)
+
+
 FUSABLE_READOUT = (1, 2, 4)   # channel counts the aggregation kernel can sum over features in its epilogue
 DEGREE_SCHEDULE_MIN_WIDTH = 8  # operand widths from which the degree-sorted row schedule pays (measured: W >= 8)
 DEGREE_SORTED_COPY_MIN_ROWS = 1 << 16   # below this the copy's one-off index work outweighs what the kernel saves
-NARROW_ROW_SLICING = os.environ.get("GNAN_NARROW_ROW_SLICING", "1") != "0"   # A/B switch of LONG_ROW_THRESHOLD_NARROW
-WIDE_INDEX_LOADS = os.environ.get("GNAN_WIDE_INDEX", "1") != "0"      # a lane's run of index entries as 16-byte loads (gnan_spmm_args.nnz)
-PACKED_INDEX = os.environ.get("GNAN_PACKED_INDEX", "1") != "0"         # degree-sorted copies are read as one (col | code << 29) stream
+NARROW_ROW_SLICING = True   # A/B switch of LONG_ROW_THRESHOLD_NARROW
+WIDE_INDEX_LOADS = True      # a lane's run of index entries as 16-byte loads (gnan_spmm_args.nnz)
+PACKED_INDEX = True         # degree-sorted copies are read as one (col | code << 29) stream
 NARROW_SORTED_MIN_NNZ = 1 << 23   # below ~8M pairs the sorted walk's tail (the longest rows run last) and its scattered stores cost
                                    # more than the divergence they remove (arxiv-shaped, 1.3M pairs: 11.6 -> 26 us at W = 1)
-NARROW_SORTED_WALK = os.environ.get("GNAN_NARROW_SORTED", "1") != "0"   # narrow operand rows walk the degree-sorted copy too
-HOT_COLUMN_ROWS = os.environ.get("GNAN_HOT_COLUMNS", "1") != "0"        # ... and read the most listed neighbours from a compact copy
-HOT_ROWS_IN_LDS = os.environ.get("GNAN_HOT_LDS", "1") != "0"           # ... and serve the head of that copy from LDS (spmm_hot_kernel)
+NARROW_SORTED_WALK = True   # narrow operand rows walk the degree-sorted copy too
+HOT_COLUMN_ROWS = True        # ... and read the most listed neighbours from a compact copy
+HOT_ROWS_IN_LDS = True           # ... and serve the head of that copy from LDS (spmm_hot_kernel)
 HOT_LDS_FLOATS = 16384                                                   # 64 KB per workgroup, two workgroups per CU
 HOT_LDS_MIN_SHARE = 0.25                                                 # ... from this share of the pairs listing the LDS-resident rows
-DEGREE_SORTED_COPY = os.environ.get("GNAN_SORTED_COPY", "1") != "0"      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
+DEGREE_SORTED_COPY = True      # ... through a degree-sorted copy of the CSR (HopGraph.degree_sorted_copy) instead of an index
 
 
 def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1, room: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1243,11 +1275,11 @@ def lut_grad_launch(g: HopGraph, S: torch.Tensor, dY: torch.Tensor, D: int, use_
     return out.unsqueeze(-1)
 
 
-NARROW_FUSED_BACKWARD = os.environ.get("GNAN_NARROW_FUSED_BACKWARD", "1") != "0"   # dS and dlut from one transposed pass
-DENSE_LUT_GRAD = os.environ.get("GNAN_DENSE_LUT_GRAD", "1") != "0"   # dense layout: the table gradient in one pass (dense_lut_grad_kernel)
+NARROW_FUSED_BACKWARD = True   # dS and dlut from one transposed pass
+DENSE_LUT_GRAD = True   # dense layout: the table gradient in one pass (dense_lut_grad_kernel)
 SMALL_DENSE_ROWS = 1024     # dense graphs up to this size read (lut, cnt) per pair in the operand-gradient pass: building the per-node
                             # weight table first is four more launches than the whole pass on a 30-node graph
-NARROW_BWD_PERSISTENT = os.environ.get("GNAN_NARROW_BWD_PERSISTENT", "1") != "0"   # ... one channel: packed index, persistent workgroups, hot rows in LDS
+NARROW_BWD_PERSISTENT = True   # ... one channel: packed index, persistent workgroups, hot rows in LDS
 
 
 def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int,
@@ -1576,12 +1608,9 @@ class _ReferenceOrderAggregate(torch.autograd.Function):
         fx = saved.pop(0) if ctx.kept_rows else None
         params = [saved.pop(0) if present else None for present in ctx.present]
         n = x.shape[0]
-        if fx is not None:
-            # [N, C] feature sum (padded features are zero columns) as a tall-skinny GEMM: the framework's reduction over the
-            # inner 64 columns of 10M rows takes 2.7 ms, the library GEMM streams the 2.56 GB once (0.5 ms)
-            W = fx.shape[1]
-            sel = (torch.arange(W, device=fx.device).unsqueeze(1) % C == torch.arange(C, device=fx.device).unsqueeze(0)).float()
-            S1 = torch.mm(fx, sel)
+        if fx is not None and fx.shape[1] % 4 == 0 and fx.stride(0) % 4 == 0 and fx.data_ptr() % 16 == 0:
+            # [N, C] feature sum of the kept rows (padded features are zero columns): one streaming pass over the 2.56 GB
+            S1 = feature_sum(fx, C)
         else:                                                       # rows too large to keep: the feature sum is looked up again
             S1 = _fpwl_launch(x, ctx.tables, True)
         ctx.s_total = None
@@ -1762,9 +1791,9 @@ def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Opt
 # =============================================================================
 # the whole forward of a small dense-coded graph in one launch (csrc/small_graph.hip)
 # =============================================================================
-SMALL_GRAPH_FORWARD = os.environ.get("GNAN_SMALL_GRAPH", "1") != "0"
-SMALL_GRAPH_MAX_NODES = 64
-SMALL_GRAPH_BACKWARD = os.environ.get("GNAN_SMALL_GRAPH_BWD", "1") != "0"   # ... and its backward pass (gnan_small_graph_bwd)
+SMALL_GRAPH_FORWARD = True
+SMALL_GRAPH_MAX_NODES = 128   # gnan_small_graph_fwd / _bwd: one block of 64 nodes (static LDS) or two (64 KB of tables)
+SMALL_GRAPH_BACKWARD = True   # ... and its backward pass (gnan_small_graph_bwd)
 _SMALL_WS = {}               # (device index, stream) -> workspace whose counter word the kernel leaves zero
 
 
@@ -1804,10 +1833,18 @@ class _SmallGraph(torch.autograd.Function):
         Y = None if graph_sum else torch.empty((n, Cf), dtype=torch.float32, device=dev)
         Ysum = torch.empty(Cf, dtype=torch.float32, device=dev) if graph_sum else None
         need = _lib.lib().gnan_small_graph_workspace_bytes(n, F, Cf)
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        ws = _SMALL_WS.get(key)
-        if ws is None or ws.numel() * 4 < need:
-            ws = _SMALL_WS[key] = torch.zeros(max(need // 4 + 1, 1 << 16), dtype=torch.int32, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            # a captured step owns its workspace: zeroed eagerly BEFORE the capture (graphed.GraphedCallable) — every capture
+            # runs on the framework's one capture stream, so a buffer keyed by stream would be shared by all captured steps,
+            # and one allocated inside a capture would have its zero fill recorded, never run
+            ws = CAPTURE_SCRATCH
+            if ws is None or ws.numel() * 4 < need:
+                ws = torch.zeros(need // 4 + 1, dtype=torch.int32, device=dev)     # (recorded fill: runs at every replay)
+        else:
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            ws = _SMALL_WS.get(key)
+            if ws is None or ws.numel() * 4 < need:
+                ws = _SMALL_WS[key] = torch.zeros(max(need // 4 + 1, 1 << 16), dtype=torch.int32, device=dev)
         cnt = g.cnt if use_cnt else None
         a = _lib.SmallGraphArgs(x=_lib.ptr(xk), x_stride=xk.stride(0), n=n, F=F, f=_small_mlp(keep_f, Lf, Hf, Cf),
                                 rho=_small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(g.code), D=D, cnt=_lib.ptr(cnt),

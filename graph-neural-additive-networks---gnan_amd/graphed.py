@@ -81,6 +81,8 @@ class GraphedCallable:
         # keeps them alive — an eviction would hand their blocks to someone else under a replay
         functional.CAPTURE_PINS = pins = []
         functional.CAPTURE_GUARD = guard
+        functional.CAPTURE_SCRATCH = self.scratch = torch.zeros(1 << 16, dtype=torch.int32, device=dev)   # eager, owned by this step
+        torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         try:
             with torch.cuda.graph(self.graph):
@@ -95,11 +97,11 @@ class GraphedCallable:
             self.graph.instantiate()
         except Exception as e:                   # a host synchronisation on the path, an unsupported op, ...
             functional.CAPTURED_BUILDS.clear()
-            functional.CAPTURE_PINS = functional.CAPTURE_GUARD = None
+            functional.CAPTURE_PINS = functional.CAPTURE_GUARD = functional.CAPTURE_SCRATCH = None
             raise CaptureFailed(f"{type(e).__name__}: {e}") from e
         self.builds = list(functional.CAPTURED_BUILDS)
         functional.CAPTURED_BUILDS.clear()
-        functional.CAPTURE_PINS = functional.CAPTURE_GUARD = None
+        functional.CAPTURE_PINS = functional.CAPTURE_GUARD = functional.CAPTURE_SCRATCH = None
         self.pins = pins
         self.replays = 0
         _LIVE.add(self)
@@ -194,8 +196,8 @@ def prepare_optimizer(optimizer) -> PreparedOptimizer:
     return PreparedOptimizer(optimizer)
 
 
-GUARDED_REPLAY = os.environ.get("GNAN_GUARDED_REPLAY", "1") != "0"        # table-size check inside the captured step instead of before every replay
-FLAT_OPTIMIZER_STEP = os.environ.get("GNAN_FLAT_OPTIMIZER", "1") != "0"   # captured steps update the FlatMLPStore buffers with one fused launch
+GUARDED_REPLAY = True        # table-size check inside the captured step instead of before every replay
+FLAT_OPTIMIZER_STEP = True   # captured steps update the FlatMLPStore buffers with one fused launch
 
 
 class FlatAdamStep:

@@ -23,7 +23,7 @@ from torch import nn
 
 from . import _lib
 from ._cache import TensorKeyedCache
-from .functional import StackedMLP, feature_mlps, rho_aggregate
+from .functional import StackedMLP, feature_mlps, graph_readout, rho_aggregate
 from .graph import HopGraph, hop_inputs
 
 
@@ -383,7 +383,7 @@ class StandaloneTensorGNAN(_PathBase):
         self._mark("spmm")
         if not self.is_graph_task:
             return Y                                                                  # GNAN.py:72-73,79
-        return Y.sum(dim=0).view(-1, 1)                                               # [C, 1]  GNAN.py:75-79
+        return graph_readout(Y)                                                       # [C, 1]  GNAN.py:75-79
 
 
 class _GNANCore(_PathBase):
@@ -541,7 +541,7 @@ class TensorGNAN(_PathBase):
                 Y = reference_order_forward(g, x, stacked, lut, use_cnt)
                 self._mark("fmlp")
                 self._mark("spmm")
-                return Y if not self.is_graph_task else Y.sum(dim=0).view(-1, 1)
+                return Y if not self.is_graph_task else graph_readout(Y)
             fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True,
                                       out_dtype=self.operand_dtype)                   # [N, F*C] (+ zero columns when C == 1)
             self._mark("fmlp")
@@ -553,7 +553,7 @@ class TensorGNAN(_PathBase):
         self._mark("spmm")
         if not self.is_graph_task:
             return Y                                                                  # models.py:375-376,384
-        return Y.sum(dim=0).view(-1, 1)                                               # [C, 1]  models.py:383-384
+        return graph_readout(Y)                                                       # [C, 1]  models.py:383-384
 
     def feature_contributions(self, inputs, _g=None, _lut=None):
         """``mf[i, k, c] = sum_j m_ij[c] * f_k(x[j, k])[c]`` — the per-feature aggregate of models.py:373,

@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 37
+#define GNAN_ABI_VERSION 38
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -474,6 +474,10 @@ int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream);
 size_t gnan_colsum_workspace_bytes(int32_t W);
 int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                 size_t workspace_bytes, gnan_stream_t stream);
+/* Feature sum of kept per-feature rows: out[i, c] = sum_k fx[i, k * C + c] (GNAN.py:157 applied to the rows of
+ * models.py:360-365; C in {1, 2, 4}, W = F * C with W % 4 == 0, 16-byte aligned rows).  One streaming pass. */
+int gnan_feature_sum(const float* fx, int64_t n, int32_t W, int64_t stride, int32_t C, float* out, int64_t out_stride,
+                     gnan_stream_t stream);
 /* dst[k, :] = src[ids[k], :] (W fp32 columns, dst rows contiguous; ids int64 in device memory): the compact second copy of
  * the most listed nodes' operand rows behind the operand, which gnan_spmm_args.hot_lo / hot_rows describe. */
 int gnan_gather_rows(const float* src, int64_t src_stride, const int64_t* ids, int64_t k, int32_t W, float* dst,
@@ -519,7 +523,7 @@ int gnan_loss_step(const gnan_loss_args* a, gnan_stream_t stream);
  *   lut[d, :] = rho(u_d),  u_d = float32(1 / (1 + d)) for d < D-1, u_{D-1} = 0
  *   Y[i, c]   = sum_j lut[code[i, j], c or 0] / max(cnt[i, code[i, j]], 1) * S[j, c]       (cnt == NULL: no division)
  *   Ysum[c]   = sum_i Y[i, c]                                          (the graph read-out, GNAN.py:75-79)
- * One workgroup per feature + one for rho; the last to finish aggregates (a counter in the workspace).  Covers n <= 64,
+ * One workgroup per feature + one for rho; the last to finish aggregates (a counter in the workspace).  Covers n <= 128,
  * D <= 256, L in {2, 3}, H <= 64, C <= 8, rho.C in {1, f.C}; GNAN_ERR_UNSUPPORTED otherwise (gnan_fmlp_fwd + gnan_spmm_fwd
  * compute the same).  S and lut are outputs too: gnan_spmm_fwd on the transposed codes, gnan_spmm_lut_grad and gnan_fmlp_bwd
  * take them for the backward pass.  The MLP weights are stacked as in gnan_fmlp_args (rho: one "feature").
@@ -555,12 +559,50 @@ typedef struct gnan_small_graph_args {
 size_t gnan_small_graph_workspace_bytes(int32_t n, int32_t F, int32_t C);
 int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_t stream);
 
+/* MANY small graphs in one launch — the batched variant of the reference (batched_pyg_main.py:133-184): graph g owns nodes
+ * node_off[g] .. node_off[g + 1] - 1 of x / S / Y and the [n_g, n_g] block of hop codes at code + code_off[g] (what the
+ * reference's collate function lays out as one block-diagonal matrix, batched_pyg_main.py:54-91); Ysum [n_graphs, f.C] is the
+ * per-graph read-out (the scatter_add_ of batched_pyg_main.py:173-181), lut [n_graphs, D, rho.C] a rho table per graph.
+ * rho_raw_hops: rho is evaluated on the raw hop count d (batched_pyg_main.py:151) instead of 1 / (1 + d); rest_zero: codes
+ * beyond D - 2 (the -1 mask of :155-156) carry weight 0.  No shell normalisation.  Covers graphs of <= 128 nodes (max_nodes).
+ * workspace: gnan_small_batch_workspace_bytes(...) bytes whose first 16 * n_graphs are ZERO before the first launch (the
+ * kernel leaves them zero).  gnan_hops_to_code / gnan_dense_blocks_to_code make the packed codes from the hop matrices:
+ * status[0] |= 1 for an entry that is no integer in [0, 254] or negative, |= 2 for a listed pair outside the diagonal blocks
+ * (dense form), status[1] = the largest hop (ZEROED by the caller). */
+typedef struct gnan_small_batch_args {
+  const float* x;            /* [total_nodes, F], row stride x_stride */
+  int64_t x_stride;
+  int64_t total_nodes;
+  int32_t F;
+  int32_t n_graphs;
+  int32_t max_nodes;         /* largest graph */
+  gnan_small_mlp f;
+  gnan_small_mlp rho;
+  const uint8_t* code;       /* packed [n_g, n_g] blocks */
+  const int32_t* node_off;   /* [n_graphs + 1] */
+  const int64_t* code_off;   /* [n_graphs + 1] */
+  int32_t D;
+  int32_t rho_raw_hops;
+  int32_t rest_zero;
+  float* S;                  /* [total_nodes, f.C] */
+  float* lut;                /* [n_graphs, D, rho.C] */
+  float* Y;                  /* optional [total_nodes, f.C] */
+  float* Ysum;               /* optional [n_graphs, f.C] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_small_batch_args;
+size_t gnan_small_batch_workspace_bytes(int32_t n_graphs, int64_t total_nodes, int32_t F, int32_t C);
+int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_t stream);
+int gnan_hops_to_code(const float* hops, int64_t count, uint8_t* code, int32_t* status, gnan_stream_t stream);
+int gnan_dense_blocks_to_code(const float* dist, int64_t stride, int64_t n, const int32_t* graph_of, const int32_t* node_off,
+                              const int64_t* code_off, uint8_t* code, int32_t* status, gnan_stream_t stream);
+
 /* ... and its backward pass in one launch: the gradients of every stacked parameter tensor of f and rho (autograd through
  * GNAN.py:146-172 / models.py:358-384 + trainer.py:66) from dY [n, f.C] — or dYsum [f.C], the gradient of the graph read-out,
  * which every row shares — and the S and lut the forward left behind.  Workgroup k < F forms the operand gradient
  * dS[j, :] = sum_i lut[code[i, j]] / max(cnt[i, code[i, j]], 1) * dY[i, :] itself and runs gnan_fmlp_bwd's body on feature k;
  * workgroup F forms dlut[d] = sum_i 1 / max(cnt[i, d], 1) * sum_{j : code[i, j] == d} <dY[i, :], S[j, :]> and runs it on rho.
- * Covers n <= 64, D <= 64, a one-channel rho, L in {2, 3}, H <= 64, C <= 8; GNAN_ERR_UNSUPPORTED otherwise (the general
+ * Covers n <= 128, D <= 64, a one-channel rho, L in {2, 3}, H <= 64, C <= 8; GNAN_ERR_UNSUPPORTED otherwise (the general
  * kernels then: gnan_spmm_fwd on the transposed codes, gnan_spmm_lut_grad, gnan_fmlp_bwd twice).  No workspace, no atomics. */
 typedef struct gnan_small_mlp_grads {
   float* w_first;

@@ -263,7 +263,8 @@ def test_run_exp_reproduces_the_reference_run(name, tmp_path):
         err = np.abs(got[:, col] - h64[:n, col]).max() / scale
         assert err <= max(1e-5, ref_gap), (what, err, ref_gap)
     assert np.allclose(got[:, 6], h32[:n, 6], rtol=1e-6, atol=0)      # the scheduler's learning rates (a float32 device tensor here)
-    assert np.array_equal(np.nonzero(np.diff(got[:, 6]))[0], np.nonzero(np.diff(h32[:n, 6]))[0])    # changed at the same epochs
+    moved = lambda lr: np.nonzero(np.abs(np.diff(lr)) > 1e-6 * lr[:-1])[0]                          # (float <-> float32 tensor aside)
+    assert np.array_equal(moved(got[:, 6]), moved(h32[:n, 6]))                                     # changed at the same epochs
     for col in (1, 3, 5):                                              # accuracies: hit counts over sample counts, identical
         assert np.allclose(got[:, col], h32[:n, col], rtol=1e-6, atol=0), col
     assert [(e, f) for e, f in r["checkpoints"]] == [tuple(c) for c in meta["checkpoints"]]

@@ -1586,12 +1586,15 @@ def test_training_mode_dropout_in_the_kernels(F, L, H, C, bias, sum_features):
 @pytest.mark.parametrize("n,F,C,L,H,rho_c,D_hops,use_cnt,graph_sum", [
     (1, 3, 1, 3, 64, 1, 1, True, True), (30, 15, 1, 3, 64, 1, 9, True, True), (64, 7, 2, 3, 64, 2, 20, True, False),
     (17, 5, 8, 2, 32, 1, 6, False, True), (40, 9, 3, 3, 48, 3, 70, True, False), (64, 64, 1, 3, 64, 1, 12, True, True),
-    (33, 4, 4, 2, 64, 4, 200, True, True)])
+    (33, 4, 4, 2, 64, 4, 200, True, True),
+    # more than 64 nodes (two node blocks: 3 % of config 2's graphs): forward and backward stay one launch each up to 128
+    (65, 15, 1, 3, 64, 1, 11, True, True), (100, 15, 1, 3, 64, 1, 30, True, True), (128, 6, 2, 3, 32, 1, 64, True, False),
+    (97, 5, 8, 2, 64, 8, 90, False, True), (128, 15, 1, 3, 64, 1, 5, True, True)])
 def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt, graph_sum):
     """gnan_small_graph_fwd (shape functions of all features, rho on the distinct distances, normalised aggregation and the
     graph read-out of a small dense-coded graph: ONE launch) == the float64 oracle chain; S and the rho table it leaves behind
     feed the general backward kernels: gradients of every parameter == oracle autograd; bit-reproducible; more than 64
-    shells, one node, rho per channel, two-layer MLPs, hidden widths below 64; what it does not cover is refused."""
+    shells, one node, more than 64 nodes, rho per channel, two-layer MLPs, hidden widths below 64; what it does not cover is refused."""
     from gnan_amd import HopGraph, functional
     from gnan_amd.functional import StackedMLP, small_graph_applies, small_graph_forward
     rng = np.random.default_rng(n * 7 + F)
@@ -1659,8 +1662,8 @@ def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt
     # refused shapes: more nodes than the kernel holds, a CSR graph, inputs that want a gradient
     f, r = StackedMLP(*[None if t is None else t.to(DEV) for t in fp], L, H, C, F), StackedMLP(*[None if t is None else t.to(DEV) for t in rp], L, H, rho_c, 1)
     assert not small_graph_applies(x.to(DEV).requires_grad_(True), g, f, r)
-    big = HopGraph.from_dense(torch.eye(65, device=DEV))
-    assert not small_graph_applies(torch.zeros(65, F, device=DEV), big, f, r)
+    big = HopGraph.from_dense(torch.eye(129, device=DEV))
+    assert not small_graph_applies(torch.zeros(129, F, device=DEV), big, f, r)
 
 
 def test_multi_copy_in_one_launch():

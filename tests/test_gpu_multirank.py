@@ -140,19 +140,29 @@ def test_ranks_with_the_hip_kernels_equal_single_process_and_oracle(world, varia
     S = O.feature_mlps(x.double(), p64).sum(1)
     wt = O.weight_table(O.rho_lut(p64, 3, dtype=torch.float64), g.cnt.cpu().long().numpy()).expand(N, -1, -1)
     truth = O.spmm_csr(g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy(), S, wt)
-    # The tolerance rule: max(1e-5, the error of the float32 reference against the same float64 truth).
-    # The float32 reference here is the oracle in the order under test — models.py:373-376 aggregates every per-feature
-    # column and sums afterwards (on this problem each column carries a rest-bucket term of ~0.13 that cancels against
-    # the other columns' down to outputs of ~0.02: ill-conditioned in float32 for ANY evaluation), GNAN.py:157 sums first.
-    sd32 = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
-    fx32 = O.feature_mlps(x.float(), sd32)                                               # [N, F, C] float32
-    wt32 = O.weight_table(O.rho_lut(sd32, 3), g.cnt.cpu().long().numpy()).expand(N, -1, -1)
-    rp, cl, cd = g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy()
+    # The tolerance rule: max(1e-5, the error of the FLOAT32 REFERENCE against the same float64 truth).
+    # The float32 reference is the oracle's dense restatement of the module under test in the reference's own operation order
+    # (models.py:358-384: rho on all N x N distances, the N-term matmul per column, then the sum over features) on the dense
+    # inputs this K = 1 graph stands for (hops beyond K zeroed, shell sizes recounted: DESIGN.md section 2).  On this problem
+    # every feature column carries a rest-bucket term of ~0.12 that cancels against the others' down to outputs of ~0.02:
+    # ill-conditioned in float32 for ANY evaluation, the reference's included.
     if order == "reference":
-        ref32 = O.spmm_csr(rp, cl, cd, fx32.reshape(N, -1), wt32).reshape(N, -1, C).sum(1)
+        sd32 = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+        fx32 = O.feature_mlps(x.float(), sd32)[:, :, 0]                          # [N, F]   models.py:360-365
+        lut32 = O.rho_lut(sd32, 3)[:, 0]
+        cntf = g.cnt.cpu().float().clamp_min(1)
+        rp = g.rowptr.cpu().long()
+        rows_of = torch.repeat_interleave(torch.arange(N), rp[1:] - rp[:-1])
+        cols, codes = g.col.cpu().long(), g.code.cpu().long()
+        # m[i, j] = rho(nd[i, j]) / norm[i, j] for ALL pairs (models.py:368-370): the rest weight everywhere, the listed pairs'
+        # weights on top (this synthetic graph lists some pairs twice: each listing counts, as in the CSR)
+        w_rest = lut32[2] / cntf[:, 2]
+        M = w_rest.unsqueeze(1).expand(N, N).clone()
+        M.index_put_((rows_of, cols), lut32[codes] / cntf[rows_of, codes] - w_rest[rows_of], accumulate=True)
+        ref32 = torch.matmul(M, fx32).sum(dim=1, keepdim=True)                   # models.py:371-376: N-term dots, then the features
+        e_ref = O.rel_err(ref32, truth.detach())
     else:
-        ref32 = O.spmm_csr(rp, cl, cd, fx32.sum(1), wt32)
-    e_ref = O.rel_err(ref32, truth.detach())
+        e_ref = 0.0                                                             # sum-first (GNAN.py:157) is well-conditioned: 1e-5
     err = O.rel_err(torch.from_numpy(got), truth.detach())
     assert err <= max(1e-5, e_ref), (err, e_ref, order)
     ((truth - _target(C).double()) ** 2).sum().backward()

@@ -429,3 +429,79 @@ def test_reference_order_training_uses_the_sum_first_backward(gpu, C, rho_per_fe
         want = p64[k].grad if p64[k].grad is not None else torch.zeros_like(p64[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * scale, k
+
+
+def test_batched_graphs_in_one_launch(gpu, monkeypatch):
+    """f-2 as a path: per-graph hop matrices -> packed code blocks on the device (no (sum N)^2 matrix), all graphs of a batch
+    forwarded by ONE launch with the per-graph read-out in its epilogue; == the hop-coded CSR through the general kernels ==
+    the float64 oracle of batched_pyg_main.py:133-184; the reference's dense dist_batch gives the same blocks; a matrix
+    that is not block-diagonal keeps the general route."""
+    from gnan_amd import batched
+    rng = np.random.default_rng(3)
+    F, C, H = 6, 8, 16
+    sizes = [3, 64, 17, 100, 1, 30, 128, 45, 9, 65] + [int(v) for v in rng.integers(4, 60, 30)]
+    batch = []
+    for n in sizes:
+        hops = rng.integers(-1, 7, (n, n)).astype(np.float32)            # -1: unreachable inside the graph
+        hops[np.arange(n), np.arange(n)] = 0
+        batch.append((torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(gpu.DEV),
+                      torch.from_numpy(hops).to(gpu.DEV), torch.tensor([int(rng.integers(0, 2))], device=gpu.DEV)))
+    x, blocks, y, bv = batched.collate(batch)
+    N = sum(sizes)
+    assert x.shape == (N, F) and blocks.n_graphs == len(sizes) and blocks.max_nodes == 128 and bv.shape == (N,)
+    dense = torch.full((N, N), -1.0, device=gpu.DEV)                       # what batched_pyg_main.py:69-76 builds
+    o = 0
+    for _, d, _ in batch:
+        dense[o:o + d.shape[0], o:o + d.shape[0]] = d
+        o += d.shape[0]
+    from_dense = batched.HopBlocks.from_dense(dense, bv)
+    assert torch.equal(from_dense.code, blocks.code) and torch.equal(from_dense.node_off, blocks.node_off)
+    assert torch.equal(from_dense.code_off, blocks.code_off) and from_dense.n_codes == blocks.n_codes
+    want_csr, got_csr = batched.hop_graph_from_counts(dense), blocks.csr()
+    for name in ("rowptr", "col", "code"):
+        assert torch.equal(getattr(want_csr, name).long(), getattr(got_csr, name).long()), name
+    torch.manual_seed(0)
+    mod = batched.TensorGNAN(F, C, 2, hidden_channels=H, device="cuda").to(gpu.DEV).eval()
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    outs, grads = {}, {}
+    up = torch.randn(len(sizes), C, generator=torch.Generator().manual_seed(1)).to(gpu.DEV)
+    for tag, kernel, dist in (("launch", True, blocks), ("csr", False, blocks), ("dense", True, dense)):
+        monkeypatch.setattr(batched, "BATCH_KERNEL", kernel)
+        mod.zero_grad(set_to_none=True)
+        out = mod(x, dist, bv)
+        (out * up).sum().backward()
+        outs[tag] = out.detach()
+        grads[tag] = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    p64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mod.state_dict().items()}
+    truth = O.batched_tensor_gnan_forward(x.cpu().double(), dense.cpu().double(), bv.cpu(), p64, True)
+    (truth * up.cpu().double()).sum().backward()
+    assert outs["launch"].shape == (len(sizes), C)
+    for tag in ("launch", "csr", "dense"):
+        assert O.rel_err(outs[tag].cpu(), truth.detach()) <= 1e-5, tag
+    assert torch.equal(outs["launch"], outs["dense"])
+    gscale = max(float(v.grad.abs().max()) for v in p64.values())
+    for k, v in p64.items():
+        for tag in ("launch", "csr"):
+            assert float((grads[tag][k].cpu().double() - v.grad).abs().max()) <= 2e-5 * gscale, (k, tag)
+    # node-level outputs through the same launch
+    mod.is_graph_task = False
+    monkeypatch.setattr(batched, "BATCH_KERNEL", True)
+    with torch.no_grad():
+        nodes = mod(x, blocks, bv)
+    truth_nodes = O.batched_tensor_gnan_forward(x.cpu().double(), dense.cpu().double(), bv.cpu(), {k: v.detach() for k, v in p64.items()}, False)
+    assert O.rel_err(nodes.cpu(), truth_nodes) <= 1e-5
+    # a listed pair across two graphs: not block-diagonal — the general CSR of the whole matrix, same semantics
+    mod.is_graph_task = True
+    cross = dense.clone()
+    cross[0, 5] = 2.0
+    with torch.no_grad():
+        got = mod(x, cross, bv)
+    want = O.batched_tensor_gnan_forward(x.cpu().double(), cross.cpu().double(), bv.cpu(), {k: v.detach() for k, v in p64.items()}, True)
+    assert O.rel_err(got.cpu(), want) <= 1e-5
+    with pytest.raises(Exception):
+        batched.HopBlocks.from_dense(cross, bv)
+    bad = [(batch[0][0], torch.full((3, 3), 0.5, device=gpu.DEV), batch[0][2])]
+    with pytest.raises(Exception, match="integer hop counts"):
+        batched.collate(bad)

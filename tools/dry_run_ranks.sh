@@ -1,7 +1,7 @@
 # Dry run of the multi-rank bench on a 1-GPU box: P processes share cuda:0, collectives over gloo.  Checks that the
 # partitions agree with the single-rank checksum (times are meaningless: the ranks share one device).
 P=${1:-2}
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+python bench.py --traffic committed --sustain-seconds 0 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('single', 1, d['checksum'])"
 for part in ${PARTS:-halo vertex feature exchange}; do

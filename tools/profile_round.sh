@@ -6,12 +6,12 @@ OUT=gpurun_out/$TAG
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 mkdir -p $OUT
 bash tools/profile_bench.sh $OUT > $OUT/profile_bench.log 2>&1
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/sum_first -o sf -- python3 bench.py --order sum_first --no-cpu-baseline --steps 10 --warmup 3 > $OUT/sum_first_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/sum_first -o sf -- python3 bench.py --traffic committed --sustain-seconds 0 --order sum_first --no-cpu-baseline --steps 10 --warmup 3 > $OUT/sum_first_bench.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/train -o tr -- python3 tools/train_step_c4.py > $OUT/train_step.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/train_ref -o trr -- python3 tools/train_step_c4_reference_order.py > $OUT/train_step_reference.log 2>&1
 python3 tools/train_step_c4.py > $OUT/train_step_noprof.log 2>&1
-python3 bench.py --scale 27 --nodes 111059956 --edges 1615685872 --operand bf16 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_bench.log 2>&1
-python3 bench.py --scale 27 --nodes 111059956 --edges 1615685872 --order sum_first --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_sum_first_bench.log 2>&1
+python3 bench.py --traffic off --sustain-seconds 0 --scale 27 --nodes 111059956 --edges 1615685872 --operand bf16 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_bench.log 2>&1
+python3 bench.py --traffic off --sustain-seconds 0 --scale 27 --nodes 111059956 --edges 1615685872 --order sum_first --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_sum_first_bench.log 2>&1
 bash tools/emulate_shares.sh > $OUT/emulated_shares.txt 2>&1
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_full.log 2>&1
 python3 tools/graphed_step.py arxiv cora muta arxiv40 > $OUT/graphed_steps.log 2>&1          # harness epochs, eager vs replayed

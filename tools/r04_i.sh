@@ -3,7 +3,7 @@ mkdir -p $OUT
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 python -m pytest tests/test_gpu_harness.py -x -q -m gpu > $OUT/test_harness.log 2>&1; echo "harness tests rc=$?" >> $OUT/rc.log
 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu > $OUT/test_multirank.log 2>&1; echo "multirank tests rc=$?" >> $OUT/rc.log
-rocprofv3 --kernel-trace -f csv -d $OUT/trace8 -o t8 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --emulate-world 8 --partition halo > $OUT/trace8.log 2>&1
+rocprofv3 --kernel-trace -f csv -d $OUT/trace8 -o t8 -- python3 bench.py --traffic committed --sustain-seconds 0 --steps 6 --warmup 2 --no-cpu-baseline --emulate-world 8 --partition halo > $OUT/trace8.log 2>&1
 python3 - <<'PY' > $OUT/trace8_timeline.txt 2>&1
 import csv, glob
 fn = glob.glob("gpurun_out/r04i/trace8/*kernel_trace.csv")[0]

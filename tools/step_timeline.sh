@@ -2,7 +2,7 @@
 OUT=$1; shift
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 mkdir -p $OUT
-rocprofv3 --kernel-trace -f csv -d $OUT -o tl -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline "$@" > $OUT/tl.log 2>&1
+rocprofv3 --kernel-trace -f csv -d $OUT -o tl -- python3 bench.py --traffic committed --sustain-seconds 0 --steps 6 --warmup 3 --no-cpu-baseline "$@" > $OUT/tl.log 2>&1
 python3 - <<PY
 import csv, glob
 rows = []
