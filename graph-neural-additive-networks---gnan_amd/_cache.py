@@ -46,9 +46,10 @@ class TensorKeyedCache:
     """Up to ``capacity`` ``(source tensors, extra key) -> value`` entries, least recently used dropped first.
     Looked up by the ids of the source objects (O(1)), confirmed by identity through the weak references."""
 
-    def __init__(self, capacity: int):
+    def __init__(self, capacity: int, on_evict=None):
         self.capacity = int(capacity)
         self.entries = OrderedDict()
+        self.on_evict = on_evict          # called with the value of an entry the capacity pushes out (not on staleness / death)
 
     @staticmethod
     def _slot(tensors, extra):
@@ -74,7 +75,9 @@ class TensorKeyedCache:
         k = self._slot(tensors, extra)
         self.entries.pop(k, None)
         while len(self.entries) >= self.capacity:
-            self.entries.popitem(last=False)
+            _, old = self.entries.popitem(last=False)
+            if self.on_evict is not None:
+                self.on_evict(old.value)
         self.entries[k] = _Entry(tensors, extra, value, lambda _ref, k=k: self._drop(k))
         return value
 

@@ -187,7 +187,7 @@ class LossArgs(C.Structure):
         ("logits", C.c_void_p), ("n_rows", C.c_int64), ("C", C.c_int32), ("kind", C.c_int32), ("stride", C.c_int64),
         ("index", C.c_void_p), ("n", C.c_int64), ("labels", C.c_void_p), ("loss", C.c_void_p), ("hits", C.c_void_p),
         ("grad", C.c_void_p), ("grad_stride", C.c_int64), ("loss_sum", C.c_void_p), ("hits_sum", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("skip_sums", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -207,6 +207,14 @@ class BfsKhopArgs(C.Structure):
         ("row_lo", C.c_int64), ("row_hi", C.c_int64), ("level_cnt", C.c_void_p), ("out_rowptr", C.c_void_p),
         ("out_col", C.c_void_p), ("out_code", C.c_void_p), ("queue_cap", C.c_int32), ("n_workgroups", C.c_int32),
         ("status", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class RestTermArgs(C.Structure):
+    _fields_ = [
+        ("Y", C.c_void_p), ("y_stride", C.c_int64), ("n", C.c_int64), ("total", C.c_void_p), ("W", C.c_int32),
+        ("lut", C.c_void_p), ("lut_row_stride", C.c_int64), ("D", C.c_int32), ("Cw", C.c_int32), ("cnt", C.c_void_p),
+        ("cnt_stride", C.c_int64), ("row_ids", C.c_void_p), ("reduce_cr", C.c_int32),
     ]
 
 
@@ -272,6 +280,8 @@ SYMBOLS = {
     "gnan_colsum_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "gnan_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
+    "gnan_rest_term_add": (C.c_int, [C.POINTER(RestTermArgs), C.c_void_p]),
+    "gnan_segment_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnan_feature_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gnan_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnan_bfs_dense_workspace_bytes": (C.c_size_t, [C.c_int32]),

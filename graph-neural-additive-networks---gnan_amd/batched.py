@@ -11,10 +11,11 @@ The path here never needs the ``(sum N_g)^2`` matrix:
   :class:`HopBlocks` — packed ``[n_g, n_g]`` uint8 code blocks + offsets (``gnan_hops_to_code``); a dense ``dist_batch``
   handed to ``forward`` as the reference does is cut into the same blocks by one kernel (``gnan_dense_blocks_to_code``,
   which also checks that nothing outside the diagonal blocks is listed) and remembered per tensor;
-* the forward of ALL graphs of a batch is ONE launch (``gnan_small_batch_fwd``: per graph the workgroups of
-  ``gnan_small_graph_fwd`` — shape functions, rho on the distinct hop counts, aggregation — and the per-graph read-out
-  in the epilogue of the graph's last workgroup: no ``scatter_add``); graphs of more than 128 nodes, or training-mode
-  Dropout, take the hop-coded CSR of the blocks through the general kernels;
+* the forward of ALL graphs of a small batch (up to ~1500 nodes: 32-48 Mutagenicity-sized graphs) is ONE launch
+  (``gnan_small_batch_fwd``: per graph the workgroups of ``gnan_small_graph_fwd`` — shape functions, rho on the distinct hop
+  counts, aggregation — and the per-graph read-out in the epilogue of the graph's last workgroup); larger batches, graphs of
+  more than 128 nodes, or training-mode Dropout take the hop-coded CSR of the blocks through the general kernels (flat
+  ~0.13 ms per batch up to 512 graphs) and ``gnan_segment_sum`` for the per-graph read-out: no ``scatter_add`` either way;
 * backward: the general kernels on the CSR (transposed aggregation, table gradient, ``gnan_fmlp_bwd`` twice) from the
   node sums and the rho table the forward left behind.
 """
@@ -32,6 +33,29 @@ from .modules import _PathBase
 
 BATCH_KERNEL = True            # the one-launch forward where it applies (tests compare with the CSR route)
 BATCH_KERNEL_MAX_NODES = 128
+# ... and pays: the launch holds F + 1 workgroups per GRAPH (built for latency: 0.05 ms for one graph, 0.09 ms for 32), the
+# general kernels over the blocks' CSR take ~0.13 ms whatever the batch (tools/batched_bench.py: 128 graphs / 3.8k nodes:
+# 0.28 against 0.14 ms; 512 graphs: 1.12 against 0.14 ms = 3.6M graphs/s)
+BATCH_KERNEL_MAX_TOTAL_NODES = 1536
+
+
+class _SegmentSum(torch.autograd.Function):
+    """``out[g, :] = sum of Y's rows of graph g`` (``gnan_segment_sum``: a wave per graph, fixed order) — the scatter_add_ of
+    batched_pyg_main.py:173-181; backward: every node receives its graph's gradient (an index_select, no arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, Y, blocks):
+        Yc = Y.detach().float()
+        Yc = Yc if Yc.stride(1) == 1 else Yc.contiguous()
+        out = torch.empty((blocks.n_graphs, Yc.shape[1]), dtype=torch.float32, device=Yc.device)
+        _lib.check(_lib.lib().gnan_segment_sum(_lib.ptr(Yc), Yc.stride(0), Yc.shape[1], _lib.ptr(blocks.node_off),
+                                               blocks.n_graphs, _lib.ptr(out), _lib.stream_of(Yc)), "gnan_segment_sum")
+        ctx.blocks = blocks
+        return out.to(Y.dtype)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d.index_select(0, ctx.blocks.batch_vector()), None
 
 
 def _two_layer(hidden: int, out: int, bias: bool, dropout: float) -> nn.Sequential:
@@ -265,7 +289,7 @@ class TensorGNAN(_PathBase):
         blocks = self._blocks(dist_batch, batch_vector)
         f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
         if (BATCH_KERNEL and blocks is not None and not self._dropout_active() and 1 <= blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
-                and blocks.n_codes <= 256 and f.H <= 64 and f.C <= 8 and x_batch.dtype == torch.float32
+                and blocks.total_nodes <= BATCH_KERNEL_MAX_TOTAL_NODES and blocks.n_codes <= 256 and f.H <= 64 and f.C <= 8 and x_batch.dtype == torch.float32
                 and not x_batch.requires_grad and blocks.n_graphs <= 65535):
             fm, rm = (f.L, f.H, f.C, f.F), (rho.L, rho.H, rho.C)
             return _BatchedGraphs.apply(x_batch, blocks, bool(self.is_graph_task), fm, rm, *f[:6], *rho[:6])
@@ -296,7 +320,8 @@ class TensorGNAN(_PathBase):
             Y = rho_aggregate(g, S, lut, use_cnt=False, with_rest=False)                    # [N, C]
         if not self.is_graph_task:
             return Y
-        bv = blocks.batch_vector() if blocks is not None else batch_vector.to(Y.device).long()
-        n_graphs = blocks.n_graphs if blocks is not None else int(bv.max()) + 1
-        out = torch.zeros(n_graphs, Y.shape[1], device=Y.device, dtype=Y.dtype)
-        return out.index_add(0, bv, Y)                                                      # batched_pyg_main.py:176-181
+        if blocks is not None and Y.shape[1] <= 64:
+            return _SegmentSum.apply(Y, blocks)                                             # batched_pyg_main.py:176-181
+        bv = batch_vector.to(Y.device).long()               # a batch that is not block-diagonal: the reference's own scatter
+        out = torch.zeros(int(bv.max()) + 1, Y.shape[1], device=Y.device, dtype=Y.dtype)
+        return out.index_add(0, bv, Y)

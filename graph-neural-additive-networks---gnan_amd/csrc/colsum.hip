@@ -256,3 +256,119 @@ extern "C" int gnan_feature_sum(const float* fx, int64_t n, int32_t W, int64_t s
     default: return go(feature_sum_kernel<64>);
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Y[q, c] += sum over the operand columns w that read-out channel c collects of  wt(i_q, D - 1, w mod Cw) * total[w]
+// — the part of the aggregation that depends on the operand only through its column sums (the rest bucket's weight times
+// `total`): a multi-rank forward aggregates against zero sums while the all-reduce of `total` is in flight and adds this
+// afterwards (gnan_amd/distributed.py).  wt(i, D-1, cw) = lut[i or 0][D - 1][cw] / max(cnt[i][D - 1], 1).
+// reduce_cr == 0: c = w (Y has W columns); else c = w mod reduce_cr (the fused read-out's channels).
+// Thread = (row, output column); the per-(c, cw) sums of `total` sit in LDS (reduce_cr * Cw <= 64 entries).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RestTermParams {
+  float* Y;
+  int64_t y_stride, n;
+  const float* total;
+  int W;
+  const float* lut;
+  int64_t lut_row_stride;     // 0: one table for every row
+  int D, Cw;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const int32_t* row_ids;
+  int reduce_cr;
+};
+
+__global__ __launch_bounds__(256) void rest_term_kernel(const RestTermParams p) {
+  __shared__ float T[64];                              // [reduce_cr][Cw]
+  const int rc = p.reduce_cr;
+  if (rc) {
+    if (static_cast<int>(threadIdx.x) < rc * p.Cw) {
+      const int c = threadIdx.x / p.Cw, cw = threadIdx.x % p.Cw;
+      float s = 0.f;
+      for (int w = 0; w < p.W; ++w)
+        if (w % rc == c && w % p.Cw == cw) s += p.total[w];
+      T[threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
+  const int Co = rc ? rc : p.W;
+  const int64_t items = p.n * Co;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < items; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t q = e / Co;
+    const int c = static_cast<int>(e - q * Co);
+    const int64_t i = p.row_ids ? p.row_ids[q] : q;
+    const float* wr = p.lut + i * p.lut_row_stride + static_cast<int64_t>(p.D - 1) * p.Cw;
+    float inv = 1.f;
+    if (p.cnt) {
+      const int cn = p.cnt[i * p.cnt_stride + p.D - 1];
+      inv = 1.f / static_cast<float>(cn > 1 ? cn : 1);
+    }
+    float acc = 0.f;
+    if (rc) {
+      for (int cw = 0; cw < p.Cw; ++cw) acc = fmaf(wr[cw] * inv, T[c * p.Cw + cw], acc);
+    } else {
+      acc = wr[c % p.Cw] * inv * p.total[c];
+    }
+    p.Y[q * p.y_stride + c] += acc;
+  }
+}
+}  // namespace
+
+extern "C" int gnan_rest_term_add(const gnan_rest_term_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "rest_term: null args");
+  GNAN_REQUIRE(a->n >= 0 && a->W >= 1 && a->D >= 1 && a->Cw >= 1, "rest_term: bad sizes");
+  if (a->n == 0) return GNAN_OK;
+  GNAN_REQUIRE(a->Y && a->total && a->lut, "rest_term: null pointer");
+  const int rc = a->reduce_cr;
+  GNAN_REQUIRE(rc >= 0 && (rc == 0 || (a->W % rc == 0 && rc * a->Cw <= 64)), "rest_term: reduce_cr must divide W and reduce_cr * Cw <= 64");
+  GNAN_REQUIRE(a->y_stride >= (rc ? rc : a->W), "rest_term: y_stride smaller than the output width");
+  GNAN_REQUIRE(a->cnt == nullptr || a->cnt_stride >= a->D, "rest_term: cnt row stride smaller than D");
+  RestTermParams p;
+  p.Y = a->Y; p.y_stride = a->y_stride; p.n = a->n; p.total = a->total; p.W = a->W;
+  p.lut = a->lut; p.lut_row_stride = a->lut_row_stride; p.D = a->D; p.Cw = a->Cw;
+  p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.row_ids = a->row_ids; p.reduce_cr = rc;
+  const int64_t items = a->n * (rc ? rc : a->W);
+  int64_t blocks = (items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rest_term_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return gnan::check_launch("rest_term_kernel");
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// out[g, c] = sum of Y[i, c] over the rows node_off[g] <= i < node_off[g + 1]: the per-graph read-out of a batch of graphs
+// (the scatter_add_ of batched_pyg_main.py:173-181; a graph's nodes are consecutive rows).  One wave per graph, lanes
+// stride over (row, channel) pairs, a fixed butterfly at the end: no atomics, bit-reproducible.  C <= 64.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ Y, int64_t y_stride, int C,
+                                                          const int32_t* __restrict__ node_off, int n_graphs,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_graphs) return;
+  const int64_t lo = node_off[g], hi = node_off[g + 1];
+  const int rows_per_pass = 64 / C;                   // lanes [0, rows_per_pass * C) are busy: lane = (row slot, channel)
+  const int slot = lane / C, c = lane - slot * C;
+  float acc = 0.f;
+  if (slot < rows_per_pass)
+    for (int64_t i = lo + slot; i < hi; i += rows_per_pass) acc += Y[i * y_stride + c];
+  // add the row slots of a channel: lanes c, c + C, c + 2C, ... (fixed order, by lane 'c')
+  float total = 0.f;
+  for (int s2 = 0; s2 < rows_per_pass; ++s2) total += __shfl(acc, s2 * C + (lane < C ? lane : 0));
+  if (lane < C) out[static_cast<int64_t>(g) * C + lane] = total;
+}
+}  // namespace
+
+extern "C" int gnan_segment_sum(const float* Y, int64_t y_stride, int32_t C, const int32_t* node_off, int32_t n_graphs,
+                                float* out, gnan_stream_t stream) {
+  GNAN_REQUIRE(n_graphs >= 0 && C >= 1 && C <= 64 && y_stride >= C, "segment_sum: bad sizes (1 <= C <= 64)");
+  if (n_graphs == 0) return GNAN_OK;
+  GNAN_REQUIRE(Y && node_off && out, "segment_sum: null pointer");
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(static_cast<unsigned>((n_graphs + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), Y, y_stride, C, node_off, n_graphs, out);
+  return gnan::check_launch("segment_sum_kernel");
+}

@@ -436,10 +436,12 @@ IndexPlan index_plan(const gnan_fpwl_args* a) {
     if (per_cu < 1) per_cu = 1;
     const int64_t resident = static_cast<int64_t>(cu_count_()) * per_cu;
     const int64_t groups = a->sum_features ? 1 : a->F / pl.fg;
-    const int unit = 128, overhead = 500;
+    // (with one or two workgroups per CU the grid is only a handful of rounds: blocks up to 16384 nodes so that the last round
+    //  can be a full one — 10M rows, two groups: 9 rounds of 8704 nodes instead of 9.5 of 8192)
+    const int unit = 64, overhead = 500;
     int64_t best_cost = -1;
     int best = 4096;
-    for (int npb = 2048; npb <= 8192; npb += unit) {
+    for (int npb = 2048; npb <= 16384; npb += unit) {
       const int64_t wgs = (a->n + npb - 1) / npb * groups;
       const int64_t rounds = (wgs + resident - 1) / resident;
       const int64_t cost = rounds * (npb + overhead);

@@ -5,6 +5,8 @@
 //   BCE:  l_i = (1 - t_i) x_i - logsigmoid(x_i)        dl/dx_i = (sigmoid(x_i) - t_i) / n      hit: (sigmoid(x_i) > 0.5) == t_i
 //   CE:   l_i = logsumexp(x_i) - x_i[t_i]              dl/dx_i = (softmax(x_i) - e_{t_i}) / n  hit: argmax x_i == t_i
 //   loss = mean_i l_i   (float32 terms as torch computes them, float64 across rows, fixed order: bit-reproducible)
+// The mean is over ALL n rows handed over (torch's default options): class labels outside [0, C) — ignore_index rows, which
+// torch leaves out of the mean — are not this kernel's business; gnan_amd/harness.py keeps the eager loss for such labels.
 #include "common.hpp"
 
 namespace {
@@ -23,6 +25,7 @@ struct LossParams {
   int64_t grad_stride;
   float* loss_sum;
   float* hits_sum;
+  const float* skip_sums;   // optional flag: non-zero = leave the running totals alone (a replayed step whose guard tripped)
   double* partial;   // [blocks, 2]
   int blocks;
 };
@@ -33,6 +36,7 @@ __device__ __forceinline__ void finish(const LossParams& p, double loss_total, d
   const float loss = static_cast<float>(loss_total / static_cast<double>(p.n));
   *p.loss = loss;
   if (p.hits) *p.hits = static_cast<int64_t>(hit_total);
+  if (p.skip_sums && *p.skip_sums != 0.f) return;     // the caller re-runs this step eagerly and counts it then
   if (p.loss_sum) *p.loss_sum += loss;
   if (p.hits_sum) *p.hits_sum += static_cast<float>(hit_total);
 }
@@ -238,7 +242,7 @@ extern "C" int gnan_loss_step(const gnan_loss_args* a, gnan_stream_t stream) {
   p.t_f = a->kind == GNAN_LOSS_BCE_LOGITS ? static_cast<const float*>(a->labels) : nullptr;
   p.t_i = a->kind == GNAN_LOSS_CROSS_ENTROPY ? static_cast<const int64_t*>(a->labels) : nullptr;
   p.loss = a->loss; p.hits = a->hits; p.grad = a->grad; p.grad_stride = a->grad_stride;
-  p.loss_sum = a->loss_sum; p.hits_sum = a->hits_sum;
+  p.loss_sum = a->loss_sum; p.hits_sum = a->hits_sum; p.skip_sums = a->skip_sums;
   p.blocks = blocks_for(a->n);
   p.partial = static_cast<double*>(a->workspace);
   const size_t need = gnan_loss_workspace_bytes(a->n);

@@ -70,17 +70,17 @@ class VertexPartition:
 
 
 def _hip_compute() -> Dict[str, Callable]:
-    from .functional import column_sums, feature_mlps, rest_total_term, rho_aggregate
+    from .functional import add_rest_total_term, column_sums, feature_mlps, rest_total_term, rho_aggregate
     return {"feature_mlps": feature_mlps, "column_sums": column_sums, "aggregate": rho_aggregate,
-            "rest_total_term": rest_total_term}
+            "rest_total_term": rest_total_term, "add_rest_total_term": add_rest_total_term}
 
 
 def _reduce_scatter_sum(full: torch.Tensor, n_local: int, group) -> torch.Tensor:
-    """Sum ``full [world * n_local, W]`` over the ranks and keep this rank's block.  RCCL: one reduce-scatter; backends
-    without one (gloo, the CPU tests): all-reduce and slice."""
+    """Sum ``full [world * n_local, W]`` over the ranks and keep this rank's block.  RCCL: one reduce-scatter; any other
+    backend (gloo in the CPU tests, mpi, ...): all-reduce and slice."""
     # chosen from the backend, on every rank alike — never by catching an error around a collective: a failure on one
     # rank only would leave the others inside a different collective
-    if dist.get_backend(group) == "gloo":
+    if dist.get_backend(group) != "nccl":               # (gloo, mpi, ucc, custom backends: not every one has a reduce-scatter)
         full = full.clone()
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         r = dist.get_rank(group)
@@ -316,7 +316,10 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
         mark("total")
         Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=torch.zeros_like(total), reduce_channels=rc)
         work.wait()
-        Y += ops["rest_total_term"](plan.graph, lut, use_cnt, total, rc)
+        if "add_rest_total_term" in ops:                  # one launch, in place
+            ops["add_rest_total_term"](Y, plan.graph, lut, use_cnt, total, rc)
+        else:
+            Y += ops["rest_total_term"](plan.graph, lut, use_cnt, total, rc)
         mark("spmm")
         return Y
     shared = {}

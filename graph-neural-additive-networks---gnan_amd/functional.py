@@ -1639,38 +1639,33 @@ def reference_order_forward(g: HopGraph, x: torch.Tensor, p: StackedMLP, lut: to
     return _ReferenceOrderAggregate.apply(x, lut, g, use_cnt, not g.is_dense, p.L, p.H, p.C, p.F, *p[:6])
 
 
-def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor, reduce_channels: int = 0,
-                    row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The part of the aggregation that depends on the operand only through its column sums:
-    ``R[q, w] = wt(i_q, D-1, w) * total[w]`` (summed per channel ``w mod reduce_channels`` with the fused read-out).
+def add_rest_total_term(Y: torch.Tensor, g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor,
+                        reduce_channels: int = 0, row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``Y[q, c] += wt(i_q, D-1, .) * total`` in place (``gnan_rest_term_add``): the part of the aggregation that depends on
+    the operand only through its column sums.
 
-    ``rho_aggregate(..., s_total=total) == rho_aggregate(..., s_total=zeros) + rest_total_term(..., total)`` up to
-    rounding: a multi-rank forward can run the aggregation while the all-reduce of ``total`` is still in flight and add
-    this term afterwards (inference only: no autograd through it)."""
+    ``rho_aggregate(..., s_total=total) == add_rest_total_term(rho_aggregate(..., s_total=zeros), ..., total)`` up to
+    rounding: a multi-rank forward runs the aggregation while the all-reduce of ``total`` is still in flight and adds this
+    term afterwards (inference only: no autograd through it)."""
+    _lib.require_device(Y, lut, total)
     D, Cw = lut.shape[-2], lut.shape[-1]
     W = int(total.numel())
-    rows = None if row_ids is None else row_ids.long()
-    with torch.no_grad():
-        if lut.dim() == 2 and Cw == 1 and rows is None and (reduce_channels or W == 1):
-            # the common case in three small launches: per-channel sums of total, times rho(0), times the cached 1/|rest shell|
-            t = total.float().view(-1, max(reduce_channels, 1)).sum(0) * lut[D - 1, 0].float()
-            inv = g.inv_rest_count() if use_cnt else torch.ones((g.n_rows, 1), dtype=torch.float32, device=total.device)
-            return inv * t.unsqueeze(0)
-        if lut.dim() == 3:
-            w_rest = (lut[:, D - 1, :] if rows is None else lut[rows, D - 1, :]).float()          # [n, Cw]
-        else:
-            w_rest = lut[D - 1].float().unsqueeze(0)                                              # [1, Cw]
-        if use_cnt:
-            c = g.cnt[:, D - 1:D] if rows is None else g.cnt[rows, D - 1:D]
-            w_rest = w_rest / c.clamp_min(1).float()
-        n = g.n_rows if rows is None else int(rows.numel())
-        w_rest = w_rest.expand(n, Cw)
-        idx = torch.arange(W, device=total.device)
-        if reduce_channels:
-            A = torch.zeros((Cw, reduce_channels), dtype=torch.float32, device=total.device)
-            A.index_put_((idx % Cw, idx % reduce_channels), total.float(), accumulate=True)
-            return w_rest @ A
-        return w_rest[:, idx % Cw] * total.float().unsqueeze(0)
+    lutc, tot = _c(lut.detach().float()), _c(total.detach().float())
+    cnt = g.cnt if use_cnt else None
+    rows = None if row_ids is None else row_ids.to(device=Y.device, dtype=torch.int32).contiguous()
+    a = _lib.RestTermArgs(Y=_lib.ptr(Y), y_stride=Y.stride(0), n=Y.shape[0], total=_lib.ptr(tot), W=W, lut=_lib.ptr(lutc),
+                          lut_row_stride=(D * Cw if lut.dim() == 3 else 0), D=D, Cw=Cw, cnt=_lib.ptr(cnt),
+                          cnt_stride=0 if cnt is None else cnt.stride(0), row_ids=_lib.ptr(rows), reduce_cr=int(reduce_channels))
+    _lib.check(_lib.lib().gnan_rest_term_add(a, _lib.stream_of(Y)), "gnan_rest_term_add")
+    return Y
+
+
+def rest_total_term(g: HopGraph, lut: torch.Tensor, use_cnt: bool, total: torch.Tensor, reduce_channels: int = 0,
+                    row_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The term of :func:`add_rest_total_term` on its own: ``R[q, c]`` (``[n, reduce_channels or W]``)."""
+    n = g.n_rows if row_ids is None else int(row_ids.numel())
+    R = torch.zeros((n, reduce_channels or int(total.numel())), dtype=torch.float32, device=total.device)
+    return add_rest_total_term(R, g, lut, use_cnt, total, reduce_channels, row_ids)
 
 
 def rho_aggregate(g: HopGraph, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
@@ -1739,6 +1734,9 @@ def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, h
     a = _lib.LossArgs(logits=_lib.ptr(x), n_rows=n_rows, C=C, kind=kind, stride=x.stride(0), index=_lib.ptr(idx), n=n,
                       labels=_lib.ptr(lab), loss=_lib.ptr(loss), hits=_lib.ptr(hits), grad=_lib.ptr(grad),
                       grad_stride=0 if grad is None else grad.stride(0), loss_sum=_lib.ptr(loss_sum), hits_sum=_lib.ptr(hits_sum),
+                      # a guarded captured step: a replay whose tables outgrew the capture is rolled back and re-run eagerly —
+                      # its truncated look-up's loss must not reach the epoch's totals (it is counted by the re-run)
+                      skip_sums=_lib.ptr(CAPTURE_GUARD) if (loss_sum is not None or hits_sum is not None) else None,
                       workspace=_lib.ptr(ws), workspace_bytes=need)
     _lib.check(_lib.lib().gnan_loss_step(a, _lib.stream_of(x)), "gnan_loss_step")
     return loss, hits, grad

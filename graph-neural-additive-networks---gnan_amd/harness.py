@@ -46,7 +46,9 @@ class _StepStore:
 
     def __init__(self):
         from ._cache import TensorKeyedCache
-        self.node = TensorKeyedCache(8)      # per-(data tensors, mask, loss, optimizer) step records of full-batch node tasks
+        # per-(data tensors, mask, loss, optimizer) step records of full-batch node tasks; a record the capacity pushes out gives
+        # its captured graph back and, if it switched an optimizer to its capturable mode, the optimizer's own settings too
+        self.node = TensorKeyedCache(8, on_evict=_retire_record)
         self.graph = None                    # _GraphTaskSteps: one captured training step per graph shape
         self.graph_eval = None               # ... and one captured evaluation step per graph shape
 
@@ -98,6 +100,13 @@ def release_steps(model) -> None:
             rec.pop("prepared").restore()
     store.node.clear()
     store.graph = store.graph_eval = None
+
+
+def _retire_record(rec) -> None:
+    _drop_step(rec)
+    prepared = rec.pop("prepared", None)
+    if prepared is not None:
+        prepared.restore()
 
 
 def _drop_step(rec) -> None:
@@ -205,15 +214,26 @@ def _step_record(model, data, mask_name, label_index, loss_fn, optimizer, classi
     rec = cache.get(src, extra)
     if (rec is None or rec["loss_fn"]() is not loss_fn
             or (optimizer is not None and (rec["optimizer"] is None or rec["optimizer"]() is not optimizer))):
+        prepared = None
         if rec is not None:
+            # the replaced record's optimizer preparation: carried over when the optimizer is the same object (preparing it
+            # again would save the PREPARED state as "its own"), handed back otherwise
             _drop_step(rec)
+            prepared = rec.pop("prepared", None)
+            if prepared is not None and (optimizer is None or rec["optimizer"] is None or rec["optimizer"]() is not optimizer):
+                prepared.restore()
+                prepared = None
         try:
             loss_ref = weakref.ref(loss_fn)
         except TypeError:
+            if prepared is not None:
+                prepared.restore()
             return None
         rec = cache.put(src, extra, {"calls": 0, "step": None, "dead": False, "loss_fn": loss_ref,
                                      "optimizer": None if optimizer is None else weakref.ref(optimizer),
                                      "graph": graph})
+        if prepared is not None:
+            rec["prepared"] = prepared
     return rec
 
 

@@ -474,6 +474,30 @@ int gnan_spmm_shell_sums(const gnan_spmm_args* a, gnan_stream_t stream);
 size_t gnan_colsum_workspace_bytes(int32_t W);
 int gnan_colsum(const float* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                 size_t workspace_bytes, gnan_stream_t stream);
+/* Y[q, c] += (rest-bucket weight of row i_q) * (the column sums read-out channel c collects): the term of gnan_spmm_fwd
+ * that depends on the operand only through `s_total` — gnan_spmm_fwd(s_total = total) == gnan_spmm_fwd(s_total = zeros) followed
+ * by this, up to rounding — so that a multi-rank forward can aggregate while the all-reduce of the column sums is in flight.
+ * lut [D, Cw] (lut_row_stride == 0) or per row [n, D, Cw]; cnt optional [n, cnt_stride] shell sizes; row_ids optional [n]
+ * (the rows of lut / cnt the outputs belong to); reduce_cr as in gnan_spmm_args (0: Y has W columns). */
+typedef struct gnan_rest_term_args {
+  float* Y;
+  int64_t y_stride;
+  int64_t n;
+  const float* total;        /* [W] */
+  int32_t W;
+  const float* lut;
+  int64_t lut_row_stride;
+  int32_t D, Cw;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const int32_t* row_ids;
+  int32_t reduce_cr;
+} gnan_rest_term_args;
+int gnan_rest_term_add(const gnan_rest_term_args* a, gnan_stream_t stream);
+/* Per-graph read-out of a batch of graphs: out[g, :] = sum of the rows node_off[g] .. node_off[g + 1] - 1 of Y [N, C]
+ * (batched_pyg_main.py:173-181; C <= 64).  One wave per graph, fixed order. */
+int gnan_segment_sum(const float* Y, int64_t y_stride, int32_t C, const int32_t* node_off, int32_t n_graphs, float* out,
+                     gnan_stream_t stream);
 /* Feature sum of kept per-feature rows: out[i, c] = sum_k fx[i, k * C + c] (GNAN.py:157 applied to the rows of
  * models.py:360-365; C in {1, 2, 4}, W = F * C with W % 4 == 0, 16-byte aligned rows).  One streaming pass. */
 int gnan_feature_sum(const float* fx, int64_t n, int32_t W, int64_t stride, int32_t C, float* out, int64_t out_stride,
@@ -488,7 +512,8 @@ int gnan_gather_rows(const float* src, int64_t src_stride, const int64_t* ids, i
  * gradient rows a mask leaves out): rows index[0..n) of the logits (all rows 0..n-1 without index),
  *   GNAN_LOSS_BCE_LOGITS   (C == 1, labels float32 [n]): mean_i (1 - t_i) x_i - logsigmoid(x_i)   = nn.BCEWithLogitsLoss()
  *   GNAN_LOSS_CROSS_ENTROPY (C >= 2, labels int64 [n]):  mean_i logsumexp(x_i) - x_i[t_i]          = nn.CrossEntropyLoss()
- * (default options: mean reduction, no weights, no label smoothing, no ignored class), float32 terms as torch forms them,
+ * (default options: mean reduction, no weights, no label smoothing; every label in [0, C): rows torch would IGNORE
+ * (ignore_index) are not supported — the caller keeps its own loss for such labels), float32 terms as torch forms them,
  * float64 across rows in a fixed order.  Optional outputs: hits = #{(sigmoid(x_i) > 0.5) == t_i} or #{argmax x_i == t_i}
  * (trainer.py:5-20); grad [n_rows, C] = d loss / d logits (rows outside index: zero; index entries must be distinct);
  * loss_sum += loss and hits_sum += hits (the epoch's running totals, trainer.py:67-71, device scalars).
@@ -510,6 +535,8 @@ typedef struct gnan_loss_args {
   int64_t grad_stride;
   float* loss_sum;           /* optional [1] accumulators */
   float* hits_sum;
+  const float* skip_sums;    /* optional [1] device flag: non-zero = do not touch loss_sum / hits_sum (a captured step whose
+                                guard tripped is re-run eagerly and counted then) */
   void* workspace;           /* gnan_loss_workspace_bytes(n) */
   size_t workspace_bytes;
 } gnan_loss_args;

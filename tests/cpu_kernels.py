@@ -133,3 +133,36 @@ def install():
             setattr(functional, name, fn)
         _lib.require_device = saved_req
     return undo
+
+
+def rest_total_term(g, lut, use_cnt, total, reduce_channels=0, row_ids=None):
+    """The part of the aggregation that depends on the operand only through its column sums:
+    ``R[q, w] = wt(i_q, D-1, w) * total[w]`` (summed per channel ``w mod reduce_channels`` with the fused read-out).
+
+    ``rho_aggregate(..., s_total=total) == rho_aggregate(..., s_total=zeros) + rest_total_term(..., total)`` up to
+    rounding: a multi-rank forward can run the aggregation while the all-reduce of ``total`` is still in flight and add
+    this term afterwards (inference only: no autograd through it)."""
+    D, Cw = lut.shape[-2], lut.shape[-1]
+    W = int(total.numel())
+    rows = None if row_ids is None else row_ids.long()
+    with torch.no_grad():
+        if lut.dim() == 2 and Cw == 1 and rows is None and (reduce_channels or W == 1):
+            # the common case in three small launches: per-channel sums of total, times rho(0), times the cached 1/|rest shell|
+            t = total.float().view(-1, max(reduce_channels, 1)).sum(0) * lut[D - 1, 0].float()
+            inv = g.inv_rest_count() if use_cnt else torch.ones((g.n_rows, 1), dtype=torch.float32, device=total.device)
+            return inv * t.unsqueeze(0)
+        if lut.dim() == 3:
+            w_rest = (lut[:, D - 1, :] if rows is None else lut[rows, D - 1, :]).float()          # [n, Cw]
+        else:
+            w_rest = lut[D - 1].float().unsqueeze(0)                                              # [1, Cw]
+        if use_cnt:
+            c = g.cnt[:, D - 1:D] if rows is None else g.cnt[rows, D - 1:D]
+            w_rest = w_rest / c.clamp_min(1).float()
+        n = g.n_rows if rows is None else int(rows.numel())
+        w_rest = w_rest.expand(n, Cw)
+        idx = torch.arange(W, device=total.device)
+        if reduce_channels:
+            A = torch.zeros((Cw, reduce_channels), dtype=torch.float32, device=total.device)
+            A.index_put_((idx % Cw, idx % reduce_channels), total.float(), accumulate=True)
+            return w_rest @ A
+        return w_rest[:, idx % Cw] * total.float().unsqueeze(0)

@@ -155,7 +155,7 @@ def _halo_worker(rank, world, port, n, F, C, order, out_dir, overlap=False):
         assert set(halo.tolist()) == set(g.col.long().tolist()) - set(range(part.lo, part.hi))
         compute = _halo_compute(sd, C)
         if overlap:   # inference path: aggregate against zero column sums while their all-reduce is in flight, add the rest after
-            from gnan_amd.functional import rest_total_term
+            from cpu_kernels import rest_total_term                # (the product's gnan_rest_term_add needs the GPU)
             compute["rest_total_term"] = rest_total_term
         with torch.no_grad() if overlap else torch.enable_grad():
             y = halo_recompute_forward(x[ids], plan, stack(sd, F, 3, 8, C, True), O.rho_lut(sd, 3), True, order=order,

@@ -467,6 +467,7 @@ def test_batched_graphs_in_one_launch(gpu, monkeypatch):
             p.copy_(torch.randn(p.shape) * 0.5)
     outs, grads = {}, {}
     up = torch.randn(len(sizes), C, generator=torch.Generator().manual_seed(1)).to(gpu.DEV)
+    monkeypatch.setattr(batched, "BATCH_KERNEL_MAX_TOTAL_NODES", 1 << 30)        # (the policy sends batches this large to the CSR route)
     for tag, kernel, dist in (("launch", True, blocks), ("csr", False, blocks), ("dense", True, dense)):
         monkeypatch.setattr(batched, "BATCH_KERNEL", kernel)
         mod.zero_grad(set_to_none=True)

@@ -1,23 +1,33 @@
-# Every measurement behind profiles/<tag>_* in one go, on the GPU box:   bash tools/profile_round.sh r03
+# Every measurement behind profiles/<tag>_* in one go, on the GPU box:   bash tools/profile_round.sh r04
 #   default bench (4 rocprofv3 passes), sum-first forward, training steps (sum-first and reference order), config 5 on one
-#   GPU (both orders), emulated per-rank shares.  Condense with  python profiles/summarize.py gpurun_out/<tag> profiles/<tag>
-TAG=${1:-r03}
+#   GPU (both orders), configs 2 and 3 (bench.py --config), emulated per-rank shares (replayed from hipGraphs and eager),
+#   look-up A/B + the access-pattern ceiling + SQ counters, batched graphs, harness epochs.
+#   Condense with  python profiles/summarize.py gpurun_out/<tag> profiles/<tag>
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 mkdir -p $OUT
 bash tools/profile_bench.sh $OUT > $OUT/profile_bench.log 2>&1
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/sum_first -o sf -- python3 bench.py --traffic committed --sustain-seconds 0 --order sum_first --no-cpu-baseline --steps 10 --warmup 3 > $OUT/sum_first_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/sum_first -o sf -- python3 bench.py --traffic off --sustain-seconds 0 --order sum_first --no-cpu-baseline --steps 10 --warmup 3 > $OUT/sum_first_bench.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/train -o tr -- python3 tools/train_step_c4.py > $OUT/train_step.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/train_ref -o trr -- python3 tools/train_step_c4_reference_order.py > $OUT/train_step_reference.log 2>&1
 python3 tools/train_step_c4.py > $OUT/train_step_noprof.log 2>&1
-python3 bench.py --traffic off --sustain-seconds 0 --scale 27 --nodes 111059956 --edges 1615685872 --operand bf16 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_bench.log 2>&1
-python3 bench.py --traffic off --sustain-seconds 0 --scale 27 --nodes 111059956 --edges 1615685872 --order sum_first --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_sum_first_bench.log 2>&1
-bash tools/emulate_shares.sh > $OUT/emulated_shares.txt 2>&1
-python3 bench.py --steps 20 --warmup 5 > $OUT/bench_full.log 2>&1
+python3 bench.py --config c5 --traffic off --sustain-seconds 0 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_bench.log 2>&1
+python3 bench.py --config c5 --operand f32 --order sum_first --traffic off --sustain-seconds 0 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_sum_first_bench.log 2>&1
+python3 bench.py --config c3 --steps 20 --warmup 5 > $OUT/c3_bench.log 2>&1
+python3 bench.py --config c3 --out 40 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/c3_c40_bench.log 2>&1
+python3 bench.py --config c2 --steps 3 --warmup 1 > $OUT/c2_bench.log 2>&1
+bash tools/emulate_shares.sh --share-fork fmlp > $OUT/emulated_shares.txt 2>&1
+SHARE_GRAPH=off bash tools/emulate_shares.sh > $OUT/emulated_shares_eager.txt 2>&1
+python3 bench.py > $OUT/bench_full.log 2>&1                                                   # the driver's command: traffic measured, CPU baseline, sustained leg
+python3 tools/lookup_ab.py > $OUT/lookup_ab.jsonl 2> $OUT/lookup_ab.err
+tools/_bin/lookup_ceiling > $OUT/lookup_ceiling.jsonl 2>&1
+bash tools/pmc_sq_cmd.sh $OUT/sq_fwd python3 bench.py --traffic off --sustain-seconds 0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq_fwd.txt 2>&1
+bash tools/pmc_sq_cmd.sh $OUT/sq_train python3 tools/train_step_c4.py > $OUT/sq_train.txt 2>&1
+python3 tools/batched_bench.py > $OUT/batched_bench.jsonl 2> $OUT/batched_bench.err
 python3 tools/graphed_step.py arxiv cora muta arxiv40 > $OUT/graphed_steps.log 2>&1          # harness epochs, eager vs replayed
 python3 tools/small_graph_bench.py > $OUT/small_graph.log 2>&1
 bash tools/graphed_timeline.sh $OUT/tl_muta muta > $OUT/timeline_muta.txt 2>&1                 # one replayed graph-task training step, kernel by kernel
-bash tools/graphed_timeline.sh $OUT/tl_arxiv arxiv > $OUT/timeline_arxiv.txt 2>&1
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT
