@@ -134,7 +134,7 @@ def test_captured_steps_update_the_flat_buffers_bit_for_bit(n, F, C, dense, opt_
 
 
 def test_a_step_whose_tables_outgrew_the_capture_is_not_replayed(monkeypatch):
-    """The unguarded route (an optimizer whose update cannot be skipped on the device, GNAN_GUARDED_REPLAY=0): the tables of
+    """The unguarded route (an optimizer whose update cannot be skipped on the device, graphed.GUARDED_REPLAY = False): the tables of
     the current weights are built and compared BEFORE every replay."""
     _need_gpu()
     from gnan_amd import graphed, harness, pwl

@@ -27,6 +27,7 @@ bash tools/pmc_sq_cmd.sh $OUT/sq_train python3 tools/train_step_c4.py > $OUT/sq_
 python3 tools/batched_bench.py > $OUT/batched_bench.jsonl 2> $OUT/batched_bench.err
 python3 tools/graphed_step.py arxiv cora muta arxiv40 > $OUT/graphed_steps.log 2>&1          # harness epochs, eager vs replayed
 python3 tools/small_graph_bench.py > $OUT/small_graph.log 2>&1
+python3 tools/muta_epoch.py > $OUT/muta_epoch.json 2> $OUT/muta_epoch.err                   # config 2 at its own size: 4337 graphs per epoch
 bash tools/graphed_timeline.sh $OUT/tl_muta muta > $OUT/timeline_muta.txt 2>&1                 # one replayed graph-task training step, kernel by kernel
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
