@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(unsigned char* dst, uns
 #define HIP_TRY(call)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (call);                                                                             \
-    if (e_ != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "graph_replace_memsets: %s: %s", #call, hipGetErrorString(e_)); \
+    if (e_ != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "hipGraph surgery: %s: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
 }  // namespace
@@ -75,5 +75,23 @@ extern "C" int gnan_graph_replace_memsets(void* graph_handle, int32_t* n_replace
     ++replaced;
   }
   if (n_replaced) *n_replaced = replaced;
+  return GNAN_OK;
+}
+
+extern "C" int gnan_graph_node_count(void* graph_handle, int32_t* n_kernels, int32_t* n_nodes) {
+  GNAN_REQUIRE(graph_handle != nullptr, "graph_node_count: null graph");
+  hipGraph_t graph = static_cast<hipGraph_t>(graph_handle);
+  size_t n = 0;
+  HIP_TRY(hipGraphGetNodes(graph, nullptr, &n));
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) HIP_TRY(hipGraphGetNodes(graph, nodes.data(), &n));
+  int kernels = 0;
+  for (size_t k = 0; k < n; ++k) {
+    hipGraphNodeType type;
+    HIP_TRY(hipGraphNodeGetType(nodes[k], &type));
+    if (type == hipGraphNodeTypeKernel) ++kernels;
+  }
+  if (n_kernels) *n_kernels = kernels;
+  if (n_nodes) *n_nodes = static_cast<int32_t>(n);
   return GNAN_OK;
 }

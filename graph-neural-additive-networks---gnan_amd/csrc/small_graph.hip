@@ -40,6 +40,8 @@ struct SmallParams {
   float* Ysum;
   float* part;          // [F, n, C]
   unsigned* counter;    // zero before the first launch; the last workgroup zeroes it again
+  int pre_rho;          // GNAN.py:65-67: rho at u_d / max(cnt[i, d], 1) — n * D arguments, lut is the rows' table [n, D]; workgroups
+                        // F .. F + ceil(n D / 64) - 1 take 64 arguments each
   int rho_raw;          // rho's inputs are the raw hop counts d (batched_pyg_main.py:151) instead of 1 / (1 + d)
   int rest_zero;        // pairs beyond the last listed hop carry weight 0 (the -1 mask, batched_pyg_main.py:155-156) instead of rho(0)
 };
@@ -221,7 +223,7 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
 #pragma unroll
     for (int t = 0; t < kCntPer; ++t) {
       const int e = threadIdx.x + t * 256;
-      pre_cnt[t] = (fast && p.cnt && e < p.n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
+      pre_cnt[t] = (fast && !p.pre_rho && p.cnt && e < p.n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
     }
   }
   if (k < p.F) {
@@ -241,6 +243,17 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
           for (int c = 0; c < p.f.C; ++c) p.part[(static_cast<int64_t>(k) * p.n + j) * p.f.C + c] = out[c];
       }
     }
+  } else if (p.pre_rho) {
+    // rho at the n * D normalised distances (GNAN.py:66: torch.div(node_distances, normalization_matrix), IEEE division): this
+    // workgroup's 64 of them
+    stage_weights(p.r, 0, wl_);
+    const int e = (k - p.F) * kWave + lane;
+    const bool valid = e < p.n * p.D;
+    const int i = valid ? e / p.D : 0, d = valid ? e % p.D : 0;
+    const int q = valid ? p.cnt[i * p.cnt_stride + d] : 1;
+    const float ud = d < p.D - 1 ? 1.0f / (static_cast<float>(d) + 1.0f) : 0.f;
+    mlp_block(p.r, wl_, ud / static_cast<float>(q > 1 ? q : 1), col_a, col_b, lane, wave, out);
+    if (wave == 0 && valid) p.lut[e] = out[0];
   } else {
     stage_weights(p.r, 0, wl_);
     for (int d0 = 0; d0 < p.D; d0 += kWave) {
@@ -270,6 +283,13 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
   for (int t = 0; t < kMaxC; ++t) {
     const int e = threadIdx.x + t * 256;
     lut_v[t] = e < p.D * Cr ? p.lut[e] : 0.f;
+  }
+  if (p.pre_rho) {                                   // (uniform) the rows' weights are the rho workgroups' outputs themselves
+#pragma unroll
+    for (int t = 0; t < kCntPer; ++t) {
+      const int e = threadIdx.x + t * 256;
+      pre_cnt[t] = e < n * p.D ? __float_as_int(p.lut[e]) : 0;
+    }
   }
   // node sums: every (feature, node, channel) term is fetched by a thread of its own — all loads in flight at once — into the
   // (now free) weight area, then a thread per (node, channel) adds the features in order.  (A thread per (node, channel)
@@ -326,7 +346,8 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
       const int e = threadIdx.x + t * 256;
       if (e < n * p.D) {
         const float l = s_lut[e % p.D];
-        s_w[(e / p.D) * kWave + e % p.D] = p.cnt ? l / static_cast<float>(pre_cnt[t] > 1 ? pre_cnt[t] : 1) : l;
+        s_w[(e / p.D) * kWave + e % p.D] = p.pre_rho ? __int_as_float(pre_cnt[t])
+                                                     : (p.cnt ? l / static_cast<float>(pre_cnt[t] > 1 ? pre_cnt[t] : 1) : l);
       }
     }
     __syncthreads();
@@ -415,6 +436,7 @@ struct SmallBwdParams {
   const float* lut;
   const float* dY;
   const float* dYsum;
+  int pre_rho;               // lut is the rows' table [n, D] = rho(u_d / max(cnt[i, d], 1)) (GNAN.py:65-67)
 };
 
 constexpr int kBinStride = kWave + 1;
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   extern __shared__ __attribute__((aligned(16))) float dyn[];                   // s_u | s_code
   float* s_u = dyn;                                   // row weights [n][64] (features) | bins [waves][D][n | 1] (rho)
   uint8_t* s_code = reinterpret_cast<uint8_t*>(dyn + kUFloats);                 // [n][n]
+  float* s_dl = dyn + kUFloats + kNodes * kNodes / 4;                           // pre-rho only: table gradient [n][D]
   __shared__ float s_dY[kNodes * kMaxC];
   __shared__ float s_S[kNodes * kMaxC];
   __shared__ float s_g[kNodes * kMaxC];              // dS [n, C]  |  dlut [D]
@@ -459,7 +482,8 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
 #pragma unroll
     for (int t = 0; t < kCntPer; ++t) {
       const int e = threadIdx.x + t * 256;
-      q[t] = (!is_rho && p.cnt && e < n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
+      if (p.pre_rho) q[t] = (!is_rho && e < n * p.D) ? __float_as_int(p.lut[e]) : 0;       // the row's weight itself
+      else q[t] = (!is_rho && p.cnt && e < n * p.D) ? p.cnt[(e / p.D) * p.cnt_stride + e % p.D] : 1;
     }
     const float l = lane < p.D ? p.lut[lane] : 0.f;       // (e % D below: re-read per entry from this register is not possible; see s_g)
     uint32_t* dw = reinterpret_cast<uint32_t*>(s_code);
@@ -483,7 +507,8 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
         const int e = threadIdx.x + t * 256;
         if (e < n * p.D) {
           const float lv = s_g[e % p.D];
-          s_u[(e / p.D) * kWave + e % p.D] = p.cnt ? lv / static_cast<float>(q[t] > 1 ? q[t] : 1) : lv;
+          s_u[(e / p.D) * kWave + e % p.D] = p.pre_rho ? __int_as_float(q[t])
+                                                       : (p.cnt ? lv / static_cast<float>(q[t] > 1 ? q[t] : 1) : lv);
         }
       }
     }
@@ -540,13 +565,32 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     if (live && lane < p.D) {
       float sum = 0.f;
       for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];
-      if (p.cnt) {
-        const int c = p.cnt[i * p.cnt_stride + lane];
-        sum *= 1.f / static_cast<float>(c > 1 ? c : 1);
+      if (p.pre_rho) {
+        s_dl[i * p.D + lane] = sum;                        // every (row, shell) is an argument of rho of its own
+      } else {
+        if (p.cnt) {
+          const int c = p.cnt[i * p.cnt_stride + lane];
+          sum *= 1.f / static_cast<float>(c > 1 ? c : 1);
+        }
+        acc += static_cast<double>(sum);
       }
-      acc += static_cast<double>(sum);
     }
     __syncthreads();
+  }
+  if (p.pre_rho) {
+    // rho's parameter gradients over its n * D arguments u_d / max(cnt[i, d], 1) (the bins are dead: the arguments take their place)
+    for (int e = threadIdx.x; e < n * p.D; e += 256) {
+      const int d = e % p.D;
+      const int c = p.cnt[(e / p.D) * p.cnt_stride + d];
+      const float ud = d < p.D - 1 ? 1.0f / (static_cast<float>(d) + 1.0f) : 0.f;
+      s_u[e] = ud / static_cast<float>(c > 1 ? c : 1);
+    }
+    __syncthreads();
+    auto ua_of = [&](int64_t e) { return s_u[e]; };
+    auto ga_of = [&](int64_t e, int) { return s_dl[e]; };
+    if (p.r_mid) gnan_bwd::feature_grads<1, true>(p.r, 0, 0, n * p.D, 0, nodrop, ua_of, ga_of, red);
+    else gnan_bwd::feature_grads<1, false>(p.r, 0, 0, n * p.D, 0, nodrop, ua_of, ga_of, red);
+    return;
   }
   s_part[wave][lane] = wave < nw ? acc : 0.0;
   __syncthreads();
@@ -559,22 +603,25 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
 }
 
 template <int NB>
-constexpr size_t small_bwd_dyn_bytes() {
+constexpr size_t small_bwd_dyn_bytes(bool pre_rho) {
   constexpr int nodes = 64 * NB;
   constexpr int u = nodes * kWave > 2 * kWave * kBinStride ? nodes * kWave : 2 * kWave * kBinStride;
-  return static_cast<size_t>(u) * sizeof(float) + static_cast<size_t>(nodes) * nodes;
+  return static_cast<size_t>(u) * sizeof(float) + static_cast<size_t>(nodes) * nodes +
+         (pre_rho ? static_cast<size_t>(nodes) * kWave * sizeof(float) : 0);               // + the table gradient [n][D]
 }
 
 template <int C>
 int launch_small_bwd(const SmallBwdParams& p, hipStream_t st) {
   if (p.n <= 64) {
-    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 1>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256), small_bwd_dyn_bytes<1>(), st, p);
+    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 1>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256),
+                       small_bwd_dyn_bytes<1>(p.pre_rho != 0), st, p);
   } else {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_bwd_kernel<C, 2>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       static_cast<int>(small_bwd_dyn_bytes<2>()));
+                                                       static_cast<int>(small_bwd_dyn_bytes<2>(true)));
     if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_graph_bwd: hipFuncSetAttribute: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 2>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256), small_bwd_dyn_bytes<2>(), st, p);
+    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 2>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256),
+                       small_bwd_dyn_bytes<2>(p.pre_rho != 0), st, p);
   }
   return gnan::check_launch("small_graph_bwd_kernel");
 }
@@ -622,6 +669,9 @@ extern "C" int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_
                       kMaxC, a->n, a->D, a->f.L, a->rho.L, a->f.H, a->rho.H, a->f.C, a->rho.C);
   GNAN_REQUIRE(a->x && a->code && a->S && a->lut && (a->Y || a->Ysum), "small_graph: null x / code / S / lut / outputs");
   GNAN_REQUIRE(a->x_stride >= a->F && (a->cnt == nullptr || a->cnt_stride >= a->D), "small_graph: row stride smaller than the width");
+  if (a->pre_rho && (a->cnt == nullptr || a->rho.C != 1 || a->D > kWave))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_graph: pre-rho normalisation needs the shell sizes, a one-channel rho and D <= %d "
+                      "(got cnt=%p rho.C=%d D=%d)", kWave, static_cast<const void*>(a->cnt), a->rho.C, a->D);
   const size_t need = gnan_small_graph_workspace_bytes(a->n, a->F, a->f.C);
   if (a->workspace == nullptr || a->workspace_bytes < need)
     return gnan::fail(GNAN_ERR_WORKSPACE, "small_graph: workspace %zu B < required %zu B", a->workspace_bytes, need);
@@ -632,17 +682,18 @@ extern "C" int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_
   p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
   p.counter = static_cast<unsigned*>(a->workspace);
   p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 16);
-  p.rho_raw = 0; p.rest_zero = 0;
+  p.rho_raw = 0; p.rest_zero = 0; p.pre_rho = a->pre_rho != 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned rho_groups = p.pre_rho ? static_cast<unsigned>((a->n * a->D + kWave - 1) / kWave) : 1u;
   if (a->n <= 64) {
-    hipLaunchKernelGGL(small_graph_kernel<1>, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave),
+    hipLaunchKernelGGL(small_graph_kernel<1>, dim3(static_cast<unsigned>(a->F) + rho_groups), dim3(kWaves * kWave),
                        small_cols_floats(1) * sizeof(float), st, p);
   } else {
     constexpr size_t lds = small_cols_floats(2) * sizeof(float);          // 64 KB of tables + the static weight image
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_kernel<2>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_graph: hipFuncSetAttribute: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL(small_graph_kernel<2>, dim3(static_cast<unsigned>(a->F) + 1), dim3(kWaves * kWave), lds, st, p);
+    hipLaunchKernelGGL(small_graph_kernel<2>, dim3(static_cast<unsigned>(a->F) + rho_groups), dim3(kWaves * kWave), lds, st, p);
   }
   return gnan::check_launch("small_graph_kernel");
 }
@@ -663,7 +714,8 @@ extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_str
   p.f = to_weights(&a->f, &a->df); p.r = to_weights(&a->rho, &a->drho);
   p.f_mid = a->f.L == 3; p.r_mid = a->rho.L == 3;
   p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
-  p.S = a->S; p.lut = a->lut; p.dY = a->dY; p.dYsum = a->dYsum;
+  p.S = a->S; p.lut = a->lut; p.dY = a->dY; p.dYsum = a->dYsum; p.pre_rho = a->pre_rho != 0;
+  GNAN_REQUIRE(!p.pre_rho || a->cnt != nullptr, "small_graph_bwd: pre-rho normalisation needs the shell sizes");
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a->f.C) {
     case 1: return launch_small_bwd<1>(p, st);
@@ -706,7 +758,7 @@ extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_
   p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
   p.counter = static_cast<unsigned*>(a->workspace);
   p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + static_cast<size_t>(a->n_graphs) * 16);
-  p.rho_raw = a->rho_raw_hops != 0; p.rest_zero = a->rest_zero != 0;
+  p.rho_raw = a->rho_raw_hops != 0; p.rest_zero = a->rest_zero != 0; p.pre_rho = 0;
   bp.node_off = a->node_off; bp.code_off = a->code_off;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(a->F) + 1, static_cast<unsigned>(a->n_graphs));

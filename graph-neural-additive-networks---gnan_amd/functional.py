@@ -1795,8 +1795,11 @@ SMALL_GRAPH_BACKWARD = True   # ... and its backward pass (gnan_small_graph_bwd)
 _SMALL_WS = {}               # (device index, stream) -> workspace whose counter word the kernel leaves zero
 
 
-def small_graph_applies(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: StackedMLP) -> bool:
-    """Can ``gnan_small_graph_fwd`` take this forward (post-rho normalisation, features summed per node)?"""
+def small_graph_applies(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: StackedMLP, pre_rho: bool = False) -> bool:
+    """Can ``gnan_small_graph_fwd`` take this forward (features summed per node; post-rho normalisation, or — ``pre_rho`` — the
+    stand-alone file's rho(distance / shell size), GNAN.py:65-67, with a one-channel rho and at most 64 shells)?"""
+    if pre_rho and not (g.cnt is not None and rho.C == 1 and g.n_codes <= 64 and SMALL_GRAPH_BACKWARD):
+        return False
     return bool(SMALL_GRAPH_FORWARD and g.is_dense and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
                 and 1 <= x.shape[0] <= SMALL_GRAPH_MAX_NODES and g.n_rows == g.n_cols == x.shape[0] and g.n_codes <= 256
                 and x.shape[1] == f.F and rho.F == 1 and f.L in (2, 3) and rho.L in (2, 3) and 1 <= f.H <= 64
@@ -1812,9 +1815,10 @@ def _small_mlp(keep, L, H, C) -> "_lib.SmallMlp":
 
 
 class _SmallGraph(torch.autograd.Function):
-    """``Y`` (``[n, C]``) or its sum over the nodes (``[C, 1]``, ``graph_sum``) by ONE launch; backward: the general path's
-    kernels on the saved node sums and rho table — transposed aggregation, table gradient, the two small-batch MLP backward
-    launches (their gradients land in the flat gradient buffers directly)."""
+    """``Y`` (``[n, C]``) or its sum over the nodes (``[C, 1]``, ``graph_sum``) by ONE launch; backward: one launch too
+    (``gnan_small_graph_bwd``: one rho channel, <= 64 shells), else the general path's kernels on the saved node sums and rho
+    table — transposed aggregation, table gradient, the two small-batch MLP backward launches (their gradients land in the flat
+    gradient buffers directly).  ``use_cnt``: False / True (post-rho shell normalisation) / ``"pre"`` (GNAN.py:65-67)."""
 
     @staticmethod
     def forward(ctx, x, g, use_cnt, graph_sum, fm, rm, *params):
@@ -1826,8 +1830,9 @@ class _SmallGraph(torch.autograd.Function):
         dev = xk.device
         keep_f = [None if t is None else _c(t.detach()) for t in fp]
         keep_r = [None if t is None else _c(t.detach()) for t in rp]
+        pre_rho = use_cnt == "pre"
         S = torch.empty((n, Cf), dtype=torch.float32, device=dev)
-        lut = torch.empty((D, Cr), dtype=torch.float32, device=dev)
+        lut = torch.empty((n * D if pre_rho else D, Cr), dtype=torch.float32, device=dev)
         Y = None if graph_sum else torch.empty((n, Cf), dtype=torch.float32, device=dev)
         Ysum = torch.empty(Cf, dtype=torch.float32, device=dev) if graph_sum else None
         need = _lib.lib().gnan_small_graph_workspace_bytes(n, F, Cf)
@@ -1845,8 +1850,9 @@ class _SmallGraph(torch.autograd.Function):
                 ws = _SMALL_WS[key] = torch.zeros(max(need // 4 + 1, 1 << 16), dtype=torch.int32, device=dev)
         cnt = g.cnt if use_cnt else None
         a = _lib.SmallGraphArgs(x=_lib.ptr(xk), x_stride=xk.stride(0), n=n, F=F, f=_small_mlp(keep_f, Lf, Hf, Cf),
-                                rho=_small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(g.code), D=D, cnt=_lib.ptr(cnt),
-                                cnt_stride=0 if cnt is None else cnt.stride(0), S=_lib.ptr(S), lut=_lib.ptr(lut), Y=_lib.ptr(Y),
+                                rho=_small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(g.code), D=D, pre_rho=int(pre_rho),
+                                cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0), S=_lib.ptr(S),
+                                lut=_lib.ptr(lut), Y=_lib.ptr(Y),
                                 Ysum=_lib.ptr(Ysum), workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4)
         _lib.check(_lib.lib().gnan_small_graph_fwd(a, _lib.stream_of(xk)), "gnan_small_graph_fwd")
         ctx.g, ctx.use_cnt, ctx.graph_sum, ctx.fm, ctx.rm = g, use_cnt, graph_sum, fm, rm
@@ -1866,8 +1872,9 @@ class _SmallGraph(torch.autograd.Function):
         Lr, Hr, Cr = ctx.rm
         n = x.shape[0]
         need_f, need_r = any(ctx.needs_input_grad[6:12]), any(ctx.needs_input_grad[12:])
-        if (SMALL_GRAPH_BACKWARD and need_f and need_r and Cr == 1 and ctx.g.n_codes <= 64 and d_out.dtype == torch.float32
-                and all(t is None or t.dtype == torch.float32 for t in params)):
+        pre_rho = ctx.use_cnt == "pre"           # (small_graph_applies admitted it only where the one launch below covers it)
+        if ((SMALL_GRAPH_BACKWARD and Cr == 1 and ctx.g.n_codes <= 64 and d_out.dtype == torch.float32
+                and all(t is None or t.dtype == torch.float32 for t in params)) and ((need_f and need_r) or pre_rho)):
             # one launch: every workgroup forms the operand (or table) gradient it needs itself, then the small-batch MLP backward
             keep = [None if t is None else _c(t.detach()) for t in params]
             outs_f, outs_r = _grad_outputs(keep[:6], ctx.dests[:6]), _grad_outputs(keep[6:], ctx.dests[6:])
@@ -1880,11 +1887,19 @@ class _SmallGraph(torch.autograd.Function):
             cnt = ctx.g.cnt if ctx.use_cnt else None
             a = _lib.SmallGraphBwdArgs(x=_lib.ptr(x), x_stride=x.stride(0), n=n, F=F, f=_small_mlp(keep[:6], Lf, Hf, Cf),
                                        rho=_small_mlp(keep[6:], Lr, Hr, Cr), code=_lib.ptr(ctx.g.code), D=ctx.g.n_codes,
-                                       cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0), S=_lib.ptr(S),
+                                       pre_rho=int(pre_rho), cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0),
+                                       S=_lib.ptr(S),
                                        lut=_lib.ptr(lut), dY=None if ctx.graph_sum else _lib.ptr(g_out),
                                        dYsum=_lib.ptr(g_out) if ctx.graph_sum else None, df=grads(outs_f), drho=grads(outs_r))
             _lib.check(_lib.lib().gnan_small_graph_bwd(a, _lib.stream_of(x)), "gnan_small_graph_bwd")
+            if not need_f:
+                outs_f = [None] * 6
+            if not need_r:
+                outs_r = [None] * 6
             return (None, None, None, None, None, None, *outs_f, *outs_r)
+        if pre_rho:
+            raise RuntimeError("the one-launch small-graph forward with pre-rho normalisation was taken where its backward "
+                               "does not apply (float32 parameters and output gradient expected)")
         dY = d_out.reshape(1, Cf).expand(n, Cf).contiguous() if ctx.graph_sum else d_out.contiguous()
         bag = _Bag()
         bag.g, bag.use_cnt, bag.with_rest, bag.row_ids, bag.reduce_cr = ctx.g, ctx.use_cnt, False, None, 0
@@ -1900,9 +1915,10 @@ class _SmallGraph(torch.autograd.Function):
         return (None, None, None, None, None, None, *pg_f, *pg_r)
 
 
-def small_graph_forward(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: StackedMLP, use_cnt: bool, graph_sum: bool):
-    """The forward of GNAN.py:146-172 / models.py:358-384 (post-rho) on a small dense-coded graph by
-    ``gnan_small_graph_fwd``: ``[n, C]`` node outputs, or ``[C, 1]`` with ``graph_sum`` (GNAN.py:75-79)."""
+def small_graph_forward(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: StackedMLP, use_cnt, graph_sum: bool):
+    """The forward of GNAN.py:146-172 / models.py:358-384 (post-rho; ``use_cnt="pre"``: GNAN.py:55-79, pre-rho) on a small
+    dense-coded graph by ``gnan_small_graph_fwd``: ``[n, C]`` node outputs, or ``[C, 1]`` with ``graph_sum`` (GNAN.py:75-79)."""
     _lib.require_device(x, f.w_last, rho.w_last, g.code)
-    return _SmallGraph.apply(x, g, bool(use_cnt), bool(graph_sum), (f.L, f.H, f.C, f.F), (rho.L, rho.H, rho.C),
+    return _SmallGraph.apply(x, g, "pre" if use_cnt == "pre" else bool(use_cnt), bool(graph_sum), (f.L, f.H, f.C, f.F),
+                             (rho.L, rho.H, rho.C),
                              *f[:6], *rho[:6])

@@ -84,8 +84,12 @@ class GraphedCallable:
         functional.CAPTURE_SCRATCH = self.scratch = torch.zeros(1 << 16, dtype=torch.int32, device=dev)   # eager, owned by this step
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+        # with a process group up, its watchdog thread polls events of earlier collectives while this thread captures: a
+        # "global" capture would be invalidated by those calls, a thread-local one is not
+        import torch.distributed as dist
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.out = fn()
             # a captured hipMemsetAsync replays correctly only once on this ROCm (csrc/graph_fix.hip); the framework's
             # multi-block reductions (a loss's mean, a column sum) zero their semaphores with one: swap the nodes for kernels
@@ -94,6 +98,10 @@ class GraphedCallable:
             _lib.check(_lib.lib().gnan_graph_replace_memsets(self.graph.raw_cuda_graph(), ctypes.byref(swapped)),
                        "gnan_graph_replace_memsets")
             self.memsets_replaced = int(swapped.value)
+            kernels = ctypes.c_int32(0)
+            _lib.check(_lib.lib().gnan_graph_node_count(self.graph.raw_cuda_graph(), ctypes.byref(kernels), None),
+                       "gnan_graph_node_count")
+            self.kernel_nodes = int(kernels.value)          # launches per replay
             self.graph.instantiate()
         except Exception as e:                   # a host synchronisation on the path, an unsupported op, ...
             functional.CAPTURED_BUILDS.clear()

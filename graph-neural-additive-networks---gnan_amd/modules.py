@@ -306,14 +306,15 @@ class _PathBase(nn.Module):
         want = True if isinstance(self, _GNANCore) else bool(getattr(self, "normalize_rho", True))
         return self._graph(inputs, want_norm=want)
 
-    def _small_graph(self, x, g: HopGraph, use_cnt: bool, graph_sum: bool):
-        """The whole forward by one launch where ``gnan_small_graph_fwd`` applies (a small dense-coded graph, post-rho
-        normalisation, features summed per node: what a graph-level task feeds per step), else None."""
-        from .functional import small_graph_applies, small_graph_forward
-        if not g.is_dense or x.shape[0] > 64:
+    def _small_graph(self, x, g: HopGraph, use_cnt, graph_sum: bool):
+        """The whole forward by one launch where ``gnan_small_graph_fwd`` applies (a small dense-coded graph, features summed
+        per node: what a graph-level task feeds per step; ``use_cnt``: False, True = post-rho normalisation, "pre" =
+        GNAN.py:65-67), else None."""
+        from .functional import SMALL_GRAPH_MAX_NODES, small_graph_applies, small_graph_forward
+        if not g.is_dense or x.shape[0] > SMALL_GRAPH_MAX_NODES:
             return None
         f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
-        if not small_graph_applies(x, g, f, rho):
+        if not small_graph_applies(x, g, f, rho, pre_rho=use_cnt == "pre"):
             return None
         out = small_graph_forward(x, g, f, rho, use_cnt, graph_sum)
         for name in ("lut", "fmlp", "spmm"):
@@ -369,6 +370,10 @@ class StandaloneTensorGNAN(_PathBase):
         _lib.require_device(x)
         self._mark("start")
         g = self._graph(inputs, want_norm=bool(self.normalize_rho))
+        if not self._dropout_active():
+            small = self._small_graph(x, g, "pre" if self.normalize_rho else False, bool(self.is_graph_task))
+            if small is not None:
+                return small
         lut = None if self.normalize_rho else self._lut_global(g)
         self._mark("lut")
         S, total = self._operand(x, "fs", self.fs, True, not g.is_dense, graph=g)    # [N, C]

@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 38
+#define GNAN_ABI_VERSION 39
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -574,10 +574,12 @@ typedef struct gnan_small_graph_args {
   gnan_small_mlp rho;        /* one scalar MLP */
   const uint8_t* code;       /* [n, n] hop codes (gnan_dense_to_code) */
   int32_t D;
+  int32_t pre_rho;           /* != 0: the pre-rho normalisation of GNAN.py:65-67 — weight of pair (i, j) = rho(u_d / max(cnt[i, d], 1)),
+                                d = code[i, j]: rho at n * D arguments (64 per extra workgroup); needs cnt, rho.C == 1, D <= 64 */
   const int32_t* cnt;        /* optional [n, cnt_stride] shell sizes */
   int64_t cnt_stride;
   float* S;                  /* [n, f.C] */
-  float* lut;                /* [D, rho.C] */
+  float* lut;                /* [D, rho.C]; with pre_rho the rows' table [n, D] */
   float* Y;                  /* optional [n, f.C] */
   float* Ysum;               /* optional [f.C] */
   void* workspace;
@@ -647,10 +649,11 @@ typedef struct gnan_small_graph_bwd_args {
   gnan_small_mlp rho;
   const uint8_t* code;
   int32_t D;
+  int32_t pre_rho;           /* as in gnan_small_graph_args: lut is [n, D], rho's gradients come from its n * D arguments */
   const int32_t* cnt;
   int64_t cnt_stride;
   const float* S;            /* [n, f.C] node sums of the forward */
-  const float* lut;          /* [D] rho table of the forward */
+  const float* lut;          /* [D] rho table of the forward ([n, D] with pre_rho) */
   const float* dY;           /* [n, f.C] or NULL */
   const float* dYsum;        /* [f.C] or NULL (used when dY is NULL) */
   gnan_small_mlp_grads df;
@@ -832,6 +835,9 @@ int gnan_bfs_khop(const gnan_bfs_khop_args* a, gnan_stream_t stream);
  * the number of nodes swapped.
  * ------------------------------------------------------------------------------------------- */
 int gnan_graph_replace_memsets(void* graph, int32_t* n_replaced);
+/* How many nodes a captured hipGraph_t has, and how many of them are kernel launches (either pointer may be NULL; host
+ * memory): what "a training step is six launches" is checked with (tools/muta_epoch.py, tests). */
+int gnan_graph_node_count(void* graph, int32_t* n_kernels, int32_t* n_nodes);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

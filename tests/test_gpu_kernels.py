@@ -1666,6 +1666,72 @@ def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt
     assert not small_graph_applies(torch.zeros(129, F, device=DEV), big, f, r)
 
 
+@pytest.mark.parametrize("n,F,L,H,D_hops,graph_sum,bias_r", [
+    (1, 3, 3, 64, 1, True, False), (30, 15, 3, 64, 9, True, False), (64, 7, 3, 64, 20, False, True), (17, 5, 2, 32, 6, True, True),
+    (40, 9, 3, 48, 62, False, False), (65, 15, 3, 64, 11, True, False), (128, 6, 2, 32, 63, False, True),
+    (128, 15, 3, 64, 5, True, False), (100, 4, 3, 64, 40, True, True)])
+def test_small_graph_pre_rho_in_one_launch(n, F, L, H, D_hops, graph_sum, bias_r):
+    """The stand-alone file's normalisation (GNAN.py:65-67: rho at distance / shell size — n * D arguments instead of D) through
+    gnan_small_graph_fwd / _bwd with pre_rho: forward == the float64 chain, the gradients of every parameter of f and rho ==
+    float64 autograd (rho's from its n * D arguments), bit-reproducible; refused for a rho of several channels or > 64 shells."""
+    from gnan_amd import HopGraph
+    from gnan_amd.functional import StackedMLP, small_graph_applies, small_graph_forward
+    rng = np.random.default_rng(n * 11 + F)
+    hops = rng.integers(-1, D_hops, (n, n)).astype(np.int32)
+    hops[np.arange(n), np.arange(n)] = 0
+    nd = torch.zeros(n, n)
+    nd[torch.from_numpy(hops >= 0)] = 1.0 / (torch.from_numpy(hops[hops >= 0]).float() + 1.0)
+    g = HopGraph.from_dense(nd.to(DEV))
+    D = g.n_codes
+    assert D <= 64
+
+    def mlp(Fk, bias):
+        t = lambda *s: torch.from_numpy((rng.standard_normal(s) * 0.5).astype(np.float32))
+        return [t(Fk, H), t(Fk, H) if bias else None, t(1, Fk, H, H) if L == 3 else None, t(1, Fk, H) if (L == 3 and bias) else None,
+                t(Fk, 1, H), t(Fk, 1) if bias else None]
+    fp, rp = mlp(F, True), mlp(1, bias_r)
+    x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32))
+
+    def run(dtype, dev, fused):
+        fl = [None if t is None else t.to(dev, dtype).requires_grad_(True) for t in fp]
+        rl = [None if t is None else t.to(dev, dtype).requires_grad_(True) for t in rp]
+        xs = x.to(dev, dtype)
+        if fused:
+            f, r = StackedMLP(*fl, L, H, 1, F), StackedMLP(*rl, L, H, 1, 1)
+            assert small_graph_applies(xs, g, f, r, pre_rho=True)
+            out = small_graph_forward(xs, g, f, r, "pre", graph_sum)
+        else:
+            def net(v, p, k):
+                h = torch.relu(v[:, None] * p[0][k] + (0 if p[1] is None else p[1][k]))
+                if L == 3:
+                    h = torch.relu(h @ p[2][0, k].T + (0 if p[3] is None else p[3][0, k]))
+                return h @ p[4][k].T + (0 if p[5] is None else p[5][k])
+            S = sum(net(xs[:, k], fl, k) for k in range(F))                           # [n, 1]
+            codes = torch.from_numpy(np.where(hops >= 0, hops, D - 1)).long()
+            u = torch.zeros(D, dtype=torch.float32)
+            u[: D - 1] = 1.0 / (torch.arange(D - 1, dtype=torch.float32) + 1.0)
+            cnt = g.cnt.cpu().clamp_min(1).float()
+            arg = (u[codes] / cnt[torch.arange(n)[:, None], codes]).to(dtype)        # float32 division, as torch.div on the inputs
+            w = net(arg.reshape(-1), rl, 0).view(n, n, 1)
+            out = (w * S[None, :, :]).sum(1)
+            out = out.sum(0).view(-1, 1) if graph_sum else out
+        up = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(out.shape))).to(dev, dtype)
+        live = [t for t in fl + rl if t is not None]
+        return out.detach(), torch.autograd.grad(out, live, up)
+    got, got_g = run(torch.float32, DEV, True)
+    want, want_g = run(torch.float64, "cpu", False)
+    assert got.shape == ((1, 1) if graph_sum else (n, 1))
+    assert O.rel_err(got.cpu(), want) <= 1e-5
+    for a, b in zip(got_g, want_g):
+        assert float((a.cpu().double() - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
+    again, again_g = run(torch.float32, DEV, True)
+    assert torch.equal(got, again) and all(torch.equal(a, b) for a, b in zip(got_g, again_g))
+    f = StackedMLP(*[None if t is None else t.to(DEV) for t in fp], L, H, 1, F)
+    two = mlp(1, False)
+    two[4] = two[4].repeat(1, 2, 1)
+    assert not small_graph_applies(x.to(DEV), g, f, StackedMLP(*[None if t is None else t.to(DEV) for t in two], L, H, 2, 1), pre_rho=True)
+
+
 def test_multi_copy_in_one_launch():
     """gnan_multi_copy: up to eight device-to-device copies per launch — aligned and unaligned ends, odd byte counts, empty
     tensors, several dtypes; more than eight and mismatched pairs are refused."""

@@ -60,6 +60,28 @@ def test_backward_matches_golden(gpu, name, strategy):
         assert e_build <= max(2e-5, 2 * e_ref), f"{k}: build {e_build:.3e} vs fp32-reference {e_ref:.3e}"
 
 
+@pytest.mark.parametrize("name,use_cnt", [("case_004_standalone_tensor_node", "pre"), ("case_006_standalone_tensor_graph", "pre"),
+                                          ("case_008_standalone_tensor_graph", False), ("case_014_models_tensor_graph", True)])
+def test_small_golden_graphs_take_the_one_launch_path(gpu, name, use_cnt, monkeypatch):
+    """The golden cases of small graphs with one output channel — the stand-alone file's pre-rho normalisation included — run
+    through gnan_small_graph_fwd / _bwd (test_forward_matches_golden / test_backward_matches_golden above compare the values)."""
+    from gnan_amd import functional
+    g = Golden(name)
+    mod = gpu.build_module(g)
+    seen = []
+    real = functional.small_graph_forward
+    monkeypatch.setattr(functional, "small_graph_forward", lambda x, hg, f, r, uc, gs: seen.append(uc) or real(x, hg, f, r, uc, gs))
+    y = gpu.call(mod, g, gpu.device_inputs(g))
+    assert seen == [use_cnt]
+    ok, e_build, e_ref = tolerance_ok(y.detach().cpu(), g.out32, g.out64, floor=1e-5)
+    assert ok, f"build err {e_build:.3e} vs fp32-reference err {e_ref:.3e}"
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        y.pow(2).sum().backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages() if "small_graph_bwd_kernel" in e.key]
+    assert names, [e.key for e in prof.key_averages()]
+
+
 @pytest.mark.parametrize("name", golden_names(("standalone_tensor_node", "models_tensor_node", "models_gnan")))
 @pytest.mark.parametrize("K", [1, 2])
 def test_truncated_csr_matches_dense_definition(gpu, name, K):
