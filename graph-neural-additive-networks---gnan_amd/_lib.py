@@ -184,6 +184,25 @@ class SmallGraphBwdArgs(C.Structure):
     ]
 
 
+class SmallGraphNamArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_stride", C.c_int64), ("n", C.c_int32), ("F", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp),
+        ("nam", SmallMlp), ("code", C.c_void_p), ("D", C.c_int32), ("reserved", C.c_int32), ("cnt", C.c_void_p),
+        ("cnt_stride", C.c_int64), ("fx", C.c_void_p), ("lut", C.c_void_p), ("hidden", C.c_void_p), ("out", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class SmallGraphNamBwdArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_stride", C.c_int64), ("n", C.c_int32), ("F", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp),
+        ("nam", SmallMlp), ("code", C.c_void_p), ("D", C.c_int32), ("reserved", C.c_int32), ("cnt", C.c_void_p),
+        ("cnt_stride", C.c_int64), ("fx", C.c_void_p), ("lut", C.c_void_p), ("hidden", C.c_void_p), ("d_out", C.c_void_p),
+        ("df", SmallMlpGrads), ("drho", SmallMlpGrads), ("dnam", SmallMlpGrads), ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class LossArgs(C.Structure):
     _fields_ = [
         ("logits", C.c_void_p), ("n_rows", C.c_int64), ("C", C.c_int32), ("kind", C.c_int32), ("stride", C.c_int64),
@@ -264,6 +283,9 @@ SYMBOLS = {
     "gnan_small_graph_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_small_graph_fwd": (C.c_int, [C.POINTER(SmallGraphArgs), C.c_void_p]),
     "gnan_small_graph_bwd": (C.c_int, [C.POINTER(SmallGraphBwdArgs), C.c_void_p]),
+    "gnan_small_graph_nam_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gnan_small_graph_nam_fwd": (C.c_int, [C.POINTER(SmallGraphNamArgs), C.c_void_p]),
+    "gnan_small_graph_nam_bwd": (C.c_int, [C.POINTER(SmallGraphNamBwdArgs), C.c_void_p]),
     "gnan_small_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
     "gnan_small_batch_fwd": (C.c_int, [C.POINTER(SmallBatchArgs), C.c_void_p]),
     "gnan_hops_to_code": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -30,6 +30,7 @@ from . import _lib
 from .functional import rho_aggregate
 from .graph import HopGraph
 from .modules import _PathBase
+from .small_graph import _small_mlp
 
 BATCH_KERNEL = True            # the one-launch forward where it applies (tests compare with the CSR route)
 BATCH_KERNEL_MAX_NODES = 128
@@ -216,8 +217,8 @@ class _BatchedGraphs(torch.autograd.Function):
         ws = torch.empty(need // 4 + 1, dtype=torch.int32, device=dev)
         ws[: 4 * G].zero_()                                                  # the graphs' arrival counters
         a = _lib.SmallBatchArgs(x=_lib.ptr(xk), x_stride=xk.stride(0), total_nodes=N, F=F, n_graphs=G,
-                                max_nodes=blocks.max_nodes, f=Fn._small_mlp(keep_f, Lf, Hf, Cf),
-                                rho=Fn._small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(blocks.code),
+                                max_nodes=blocks.max_nodes, f=_small_mlp(keep_f, Lf, Hf, Cf),
+                                rho=_small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(blocks.code),
                                 node_off=_lib.ptr(blocks.node_off), code_off=_lib.ptr(blocks.code_off), D=D, rho_raw_hops=1,
                                 rest_zero=1, S=_lib.ptr(S), lut=_lib.ptr(lut), Y=_lib.ptr(Y), Ysum=_lib.ptr(Ysum),
                                 workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4)

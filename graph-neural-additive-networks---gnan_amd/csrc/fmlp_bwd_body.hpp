@@ -38,9 +38,10 @@ __device__ __forceinline__ float lane_value(float v, int lane) {      // lane mu
 
 // x_of(node) -> the MLP's input; g_of(node, c) -> dLoss / d output c at that input; nodes n_lo <= node < n_hi; outputs at
 // offset `so` of the gradient tensors (0, or a split's block of partial gradients).  MID: L == 3 (a hidden-to-hidden matrix).
-template <int C, bool MID, typename XFn, typename GFn>
+// DX: dLoss / d input of every node goes to dx[node - n_lo] as well (sum_j dz1_j w1_j, a fixed butterfly over the lanes).
+template <int C, bool MID, bool DX = false, typename XFn, typename GFn>
 __device__ __forceinline__ void feature_grads(const Weights& p, int k, int64_t n_lo, int64_t n_hi, int64_t so, const Drop& drop,
-                                              XFn x_of, GFn g_of, RedBuffer& red) {
+                                              XFn x_of, GFn g_of, RedBuffer& red, float* dx = nullptr) {
   const int j = threadIdx.x & (kWave - 1);        // hidden unit
   const int wv = threadIdx.x / kWave;             // node slot
   const int H = p.H;
@@ -127,6 +128,12 @@ __device__ __forceinline__ void feature_grads(const Weights& p, int k, int64_t n
       const float dz1 = unit && a1 > 0.f ? dh1 * m1 : 0.f;
       dw1 = fmaf(dz1, x, dw1);
       db1 += dz1;
+      if constexpr (DX) {
+        float v = dz1 * w1;
+#pragma unroll
+        for (int off = kWave / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+        if (j == 0) dx[node - n_lo] = v;
+      }
     } else {
       float dh1 = 0.f;
 #pragma unroll
@@ -138,6 +145,12 @@ __device__ __forceinline__ void feature_grads(const Weights& p, int k, int64_t n
       const float dz1 = unit && a1 > 0.f ? dh1 * m1 : 0.f;
       dw1 = fmaf(dz1, x, dw1);
       db1 += dz1;
+      if constexpr (DX) {
+        float v = dz1 * w1;
+#pragma unroll
+        for (int off = kWave / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+        if (j == 0) dx[node - n_lo] = v;
+      }
     }
   }
 

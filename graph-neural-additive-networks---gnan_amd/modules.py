@@ -310,7 +310,7 @@ class _PathBase(nn.Module):
         """The whole forward by one launch where ``gnan_small_graph_fwd`` applies (a small dense-coded graph, features summed
         per node: what a graph-level task feeds per step; ``use_cnt``: False, True = post-rho normalisation, "pre" =
         GNAN.py:65-67), else None."""
-        from .functional import SMALL_GRAPH_MAX_NODES, small_graph_applies, small_graph_forward
+        from .small_graph import SMALL_GRAPH_MAX_NODES, small_graph_applies, small_graph_forward
         if not g.is_dense or x.shape[0] > SMALL_GRAPH_MAX_NODES:
             return None
         f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
@@ -523,16 +523,28 @@ class TensorGNAN(_PathBase):
             small = self._small_graph(x, g, bool(self.normalize_rho), bool(self.is_graph_task))
             if small is not None:
                 return small
-        lut = self._lut_global(g)
-        self._mark("lut")
         use_cnt = bool(self.normalize_rho)
         rest = not g.is_dense                 # a CSR lists some pairs only: the others weigh rho(0) on the column sums
         if with_readout:
+            if not self._dropout_active() and not self.readout_nam._dropout_active() and g.is_dense:
+                # a small graph: shape functions, rho, aggregation and the NAM read-out in ONE launch (csrc/small_graph_nam.hip)
+                from .small_graph import small_graph_nam_applies, small_graph_nam_forward
+                f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
+                nam = self.readout_nam._stacked("fs", self.readout_nam.fs)
+                if small_graph_nam_applies(x, g, f, rho, nam):
+                    out = small_graph_nam_forward(x, g, f, rho, nam, use_cnt)
+                    for name in ("fmlp", "spmm"):
+                        self._mark(name)
+                    return out
+            lut = self._lut_global(g)
+            self._mark("lut")
             fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True)     # [N, F]   (f is 1-wide; + zero columns)
             self._mark("fmlp")
             hidden = rho_aggregate(g, fx, lut, use_cnt, s_total=total).sum(dim=0).view(1, -1)[:, :x.shape[1]]   # [1, F]   models.py:379
             self._mark("spmm")
             return self.readout_nam(hidden).T                                         # [C, 1]   models.py:380-384
+        lut = self._lut_global(g)
+        self._mark("lut")
         if self.aggregation_order == "reference":
             # the upstream evaluation order (models.py:373-376): aggregate every feature column, then sum
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate

@@ -661,6 +661,62 @@ typedef struct gnan_small_graph_bwd_args {
 } gnan_small_graph_bwd_args;
 int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_stream_t stream);
 
+/* The same small graph-level task with a NAM read-out over the per-feature aggregates (models.py:358-384 with is_graph_task
+ * and readout_n_layers > 0; models.py:259-300 for the read-out):
+ *   out[c] = sum_k nam_k(hidden[k])[c],   hidden[k] = sum_i sum_j w(i, j) f_k(x[j, k]),
+ *   w(i, j) = rho(u_d) / max(cnt[i, d], 1) (cnt NULL: no normalisation), d = min(code[i, j], D - 1).
+ * f and rho are one-wide (models.py:320-321), L in {2, 3}, H <= 64; nam: L in {1, 2, 3} (L == 1: w_last [F, C], b_last [F, C]
+ * or NULL — Linear(1, C) per feature), C <= 8; n <= 128, D <= 64; GNAN_ERR_UNSUPPORTED otherwise.  Forward: ONE launch of F
+ * workgroups (each evaluates rho on the D distances, the column sums of w, f_k, hidden[k] and nam_k; the last to arrive adds the
+ * features in order); it leaves fx [F, n] (feature-major), lut [D] and hidden [F] for the backward pass.  Backward: ONE
+ * launch of F + 1 workgroups: every parameter gradient of f, rho and nam from d_out [C].  workspace:
+ * gnan_small_graph_nam_workspace_bytes(F, nam.C) bytes whose first 16 are ZERO before the first launch (both kernels leave
+ * them zero).  Fixed summation orders: bit-reproducible. */
+typedef struct gnan_small_graph_nam_args {
+  const float* x;            /* [n, F], row stride x_stride */
+  int64_t x_stride;
+  int32_t n, F;
+  gnan_small_mlp f;          /* C == 1 */
+  gnan_small_mlp rho;        /* C == 1 */
+  gnan_small_mlp nam;        /* the read-out's F shape functions */
+  const uint8_t* code;       /* [n, n] */
+  int32_t D;
+  int32_t reserved;          /* 0 */
+  const int32_t* cnt;        /* optional [n, cnt_stride] */
+  int64_t cnt_stride;
+  float* fx;                 /* [F, n] */
+  float* lut;                /* [D] */
+  float* hidden;             /* [F] */
+  float* out;                /* [nam.C] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_small_graph_nam_args;
+typedef struct gnan_small_graph_nam_bwd_args {
+  const float* x;
+  int64_t x_stride;
+  int32_t n, F;
+  gnan_small_mlp f;
+  gnan_small_mlp rho;
+  gnan_small_mlp nam;
+  const uint8_t* code;
+  int32_t D;
+  int32_t reserved;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const float* fx;           /* what the forward left */
+  const float* lut;
+  const float* hidden;
+  const float* d_out;        /* [nam.C] */
+  gnan_small_mlp_grads df;
+  gnan_small_mlp_grads drho;
+  gnan_small_mlp_grads dnam;
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_small_graph_nam_bwd_args;
+size_t gnan_small_graph_nam_workspace_bytes(int32_t F, int32_t C);
+int gnan_small_graph_nam_fwd(const gnan_small_graph_nam_args* a, gnan_stream_t stream);
+int gnan_small_graph_nam_bwd(const gnan_small_graph_nam_bwd_args* a, gnan_stream_t stream);
+
 /* Up to eight small device-to-device copies in one launch (host arrays of `count` device pointers and byte counts; ranges
  * must not overlap): the input slots of a captured graph-task step are refilled with it. */
 int gnan_multi_copy(int32_t count, const void* const* src, void* const* dst, const int64_t* bytes, gnan_stream_t stream);

@@ -65,12 +65,12 @@ def test_backward_matches_golden(gpu, name, strategy):
 def test_small_golden_graphs_take_the_one_launch_path(gpu, name, use_cnt, monkeypatch):
     """The golden cases of small graphs with one output channel — the stand-alone file's pre-rho normalisation included — run
     through gnan_small_graph_fwd / _bwd (test_forward_matches_golden / test_backward_matches_golden above compare the values)."""
-    from gnan_amd import functional
+    from gnan_amd import small_graph
     g = Golden(name)
     mod = gpu.build_module(g)
     seen = []
-    real = functional.small_graph_forward
-    monkeypatch.setattr(functional, "small_graph_forward", lambda x, hg, f, r, uc, gs: seen.append(uc) or real(x, hg, f, r, uc, gs))
+    real = small_graph.small_graph_forward
+    monkeypatch.setattr(small_graph, "small_graph_forward", lambda x, hg, f, r, uc, gs: seen.append(uc) or real(x, hg, f, r, uc, gs))
     y = gpu.call(mod, g, gpu.device_inputs(g))
     assert seen == [use_cnt]
     ok, e_build, e_ref = tolerance_ok(y.detach().cpu(), g.out32, g.out64, floor=1e-5)
@@ -80,6 +80,33 @@ def test_small_golden_graphs_take_the_one_launch_path(gpu, name, use_cnt, monkey
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages() if "small_graph_bwd_kernel" in e.key]
     assert names, [e.key for e in prof.key_averages()]
+
+
+@pytest.mark.parametrize("name", ["case_016_models_tensor_graph", "case_017_models_tensor_graph", "case_018_models_tensor_graph"])
+def test_nam_readout_goldens_take_the_one_launch_path(gpu, name, monkeypatch):
+    """Golden cases 016-018 (graph task with a NAM read-out of one or two layers, one and three classes, with and without
+    normalisation) run through gnan_small_graph_nam_fwd / _bwd: outputs and every parameter gradient vs the reference's."""
+    from gnan_amd import small_graph
+    g = Golden(name)
+    mod = gpu.build_module(g)
+    seen = []
+    real = small_graph.small_graph_nam_forward
+    monkeypatch.setattr(small_graph, "small_graph_nam_forward", lambda *a: seen.append(1) or real(*a))
+    y = gpu.call(mod, g, gpu.device_inputs(g))
+    assert seen == [1]
+    ok, e_build, e_ref = tolerance_ok(y.detach().cpu(), g.out32, g.out64, floor=1e-5)
+    assert ok, f"build err {e_build:.3e} vs fp32-reference err {e_ref:.3e}"
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        y.pow(2).sum().backward()
+        torch.cuda.synchronize()
+    assert any("small_graph_nam_bwd_kernel" in e.key for e in prof.key_averages())
+    gscale = max(float(np.abs(v).max()) for v in g.g64.values())
+    for k, ref64 in g.g64.items():
+        p = dict(mod.named_parameters())[k]
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu().double().numpy()
+        e_build = np.abs(got - ref64).max() / gscale
+        e_ref = np.abs(g.g32[k].astype(np.float64) - ref64).max() / gscale
+        assert e_build <= max(2e-5, 2 * e_ref), f"{k}: build {e_build:.3e} vs fp32-reference {e_ref:.3e}"
 
 
 @pytest.mark.parametrize("name", golden_names(("standalone_tensor_node", "models_tensor_node", "models_gnan")))

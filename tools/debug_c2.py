@@ -3,7 +3,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gnan_amd
-from gnan_amd import HopGraph, functional
+from gnan_amd import HopGraph, functional, small_graph
 from gnan_amd import synthetic as syn
 from gnan_amd.models import TensorGNAN
 from oracle import gnan_oracle as O
@@ -32,11 +32,11 @@ for i, (ei, x, y) in enumerate(syn.mutagenicity_shaped_graphs(64, seed=0)):
     same_in = bool(torch.equal(nd.cpu(), nd_o)) and bool(torch.equal(norm.cpu(), norm_o))
     d = Bag(x=x.to(dev), edge_index=None, node_distances=nd, normalization_matrix=norm)
     with torch.no_grad():
-        functional.SMALL_GRAPH_FORWARD = True
+        small_graph.SMALL_GRAPH_FORWARD = True
         a = float(model.forward(d))
-        functional.SMALL_GRAPH_FORWARD = False
+        small_graph.SMALL_GRAPH_FORWARD = False
         b = float(model.forward(d))
-        functional.SMALL_GRAPH_FORWARD = True
+        small_graph.SMALL_GRAPH_FORWARD = True
     t = float(O.tensor_gnan_forward_models(x.double(), nd_o.double(), norm_o.double(), p64, True, True, 0))
     t32 = float(O.tensor_gnan_forward_models(x, nd_o, norm_o, sd, True, True, 0))
     flag = "" if abs(a - t) <= 1e-5 * max(abs(t), 1e-3) else "  <<<<"
