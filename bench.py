@@ -91,7 +91,7 @@ def parse():
                          "that figure only")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.NAME=VALUE",
                     help="A/B aid: set a module-level constant of the package before the run, e.g. --set "
-                         "functional.HOT_ROWS_IN_LDS=False (the library and the package read no environment switches for "
+                         "aggregate.HOT_ROWS_IN_LDS=False (the library and the package read no environment switches for "
                          "kernel selection)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=500_000, help="upper bound of the CPU shape-function sample")

@@ -7,7 +7,8 @@ The arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI in
 ``include/gnan_hip.h``; see DESIGN.md and INTEGRATION.md.
 """
 from . import GNAN, batched, harness, interpret, models  # noqa: F401  (mirror modules + f-3 / f-4)
-from .functional import StackedMLP, feature_mlps, rho_aggregate, stack_mlps  # noqa: F401
+from .aggregate import rho_aggregate  # noqa: F401
+from .functional import StackedMLP, feature_mlps, stack_mlps  # noqa: F401
 from .graph import HopGraph, hop_inputs, shell_counts_csr  # noqa: F401
 
 __all__ = ["GNAN", "models", "batched", "HopGraph", "StackedMLP", "feature_mlps", "rho_aggregate", "stack_mlps",

@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .functional import rho_aggregate
+from .aggregate import rho_aggregate
 from .graph import HopGraph
 from .modules import _PathBase
 from .small_graph import _small_mlp
@@ -241,10 +241,11 @@ class _BatchedGraphs(torch.autograd.Function):
         need_f, need_r = any(ctx.needs_input_grad[5:11]), any(ctx.needs_input_grad[11:])
         blocks = ctx.blocks
         dY = d_out.index_select(0, blocks.batch_vector()) if ctx.graph_sum else d_out      # every node gets its graph's gradient
-        bag = Fn._Bag()
+        from . import aggregate
+        bag = aggregate._Bag()
         bag.g, bag.use_cnt, bag.with_rest, bag.row_ids, bag.reduce_cr = blocks.csr(), False, False, None, 0
-        bag.s_total, bag.total_rows, bag.total_group = None, None, Fn.NOT_SHARED
-        dS, dlut = Fn._aggregate_backward(bag, S, lut[0].contiguous(), dY.contiguous(), need_f, need_r)
+        bag.s_total, bag.total_rows, bag.total_group = None, None, aggregate.NOT_SHARED
+        dS, dlut = aggregate._aggregate_backward(bag, S, lut[0].contiguous(), dY.contiguous(), need_f, need_r)
         pg_f = pg_r = [None] * 6
         if need_f:
             _, pg_f = Fn._shape_function_grads(x, params[:6], ctx.present[:6], None, dS, True, Lf, Hf, Cf, F, dests=ctx.dests[:6])

@@ -70,7 +70,8 @@ class VertexPartition:
 
 
 def _hip_compute() -> Dict[str, Callable]:
-    from .functional import add_rest_total_term, column_sums, feature_mlps, rest_total_term, rho_aggregate
+    from .aggregate import add_rest_total_term, rest_total_term, rho_aggregate
+    from .functional import column_sums, feature_mlps
     return {"feature_mlps": feature_mlps, "column_sums": column_sums, "aggregate": rho_aggregate,
             "rest_total_term": rest_total_term, "add_rest_total_term": add_rest_total_term}
 

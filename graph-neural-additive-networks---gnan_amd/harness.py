@@ -19,7 +19,7 @@ is copied into them and replayed (``SlottedGraphStep``).  ``GNAN_GRAPHED_STEPS=0
 without a capturable mode, a loader that uploads fresh tensors per epoch) silently keeps the eager loop.
 
 The loss step itself — rows of the task mask, ``nn.BCEWithLogitsLoss()`` / ``nn.CrossEntropyLoss()`` at their default options,
-the gradient w.r.t. the logits, the hit count and the epoch's running totals — is one launch (``functional.loss_step`` ->
+the gradient w.r.t. the logits, the hit count and the epoch's running totals — is one launch (``losses.loss_step`` ->
 ``gnan_loss_step``) in the eager loop and in the captured steps alike; any other loss callable runs as given
 (``GNAN_FUSED_LOSS=0``: always).
 """
@@ -151,7 +151,7 @@ def _fused_kind(loss_fn, outputs, labels=None):
     if not torch.is_tensor(outputs) or not outputs.is_cuda:
         return None
     from . import _lib
-    from .functional import loss_kind
+    from .losses import loss_kind
     kind = loss_kind(loss_fn, outputs)
     if kind == _lib.LOSS_CROSS_ENTROPY and labels is not None and labels.numel():
         global _LABEL_RANGE
@@ -270,7 +270,7 @@ def _graphed_epoch(model, data, loss_fn, optimizer, classify, label_index, compu
         def loss_of(outputs):
             kind = _fused_kind(loss_fn, outputs, data.y)
             if kind is not None:                     # selection, loss, its gradient and the hit count in one launch
-                from .functional import loss_step
+                from .losses import loss_step
                 rec["fused"] = True
                 loss, hits = loss_step(outputs, labels_m, kind, index=idx, want_hits=True, unit_upstream=True,
                                        out_loss=rec["report"][2], out_hits=rec["report"][3])
@@ -371,7 +371,7 @@ class _GraphTaskSteps:
             def loss_of(outputs, label):
                 kind = _fused_kind(loss_fn, outputs)
                 if kind is not None and outputs.shape[0] == label.numel():
-                    from .functional import loss_step
+                    from .losses import loss_step
                     loss, _ = loss_step(outputs, label, kind, want_hits=False, loss_sum=self.total_loss,
                                         hits_sum=self.hits if classify else None, unit_upstream=True)
                     return loss, None
@@ -451,7 +451,7 @@ def _run(model, loader, loss_fn, device, optimizer, classify, label_index, compu
         kind = _fused_kind(loss_fn, outputs, data.y)     # (the caller's label tensor: a stable object to remember the range of)
         if kind is not None and (not is_graph_task or outputs.shape[0] == labels.numel()):
             # gnan_loss_step: the mask's rows, the loss, its gradient, the hit count and the running totals in one launch
-            from .functional import loss_step
+            from .losses import loss_step
             idx = None
             if not is_graph_task:
                 idx = getattr(data, mask_name).nonzero().flatten()

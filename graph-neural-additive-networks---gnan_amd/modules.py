@@ -23,7 +23,8 @@ from torch import nn
 
 from . import _lib
 from ._cache import TensorKeyedCache
-from .functional import StackedMLP, feature_mlps, graph_readout, rho_aggregate
+from .aggregate import rho_aggregate
+from .functional import StackedMLP, feature_mlps, graph_readout
 from .graph import HopGraph, hop_inputs
 
 
@@ -381,7 +382,7 @@ class StandaloneTensorGNAN(_PathBase):
         if self.normalize_rho:
             # GNAN.py:65-67: rho(node_distances / normalization_matrix) — rho's exact table, D look-ups per row, in the
             # order the aggregation walks the rows (functional.pre_rho_aggregate)
-            from .functional import pre_rho_aggregate
+            from .aggregate import pre_rho_aggregate
             Y = pre_rho_aggregate(g, S, self._stacked("rho", [self.rho]), hop_inputs(g.n_codes, g.device), s_total=total)
         else:
             Y = rho_aggregate(g, S, lut, use_cnt=False, s_total=total)                # [N, C]
@@ -550,7 +551,7 @@ class TensorGNAN(_PathBase):
             # over features.  Same function, F times the aggregation traffic; kept because the intermediate
             # is the per-feature contribution tensor mf[c, i, k] and because BASELINE's workload is stated
             # in this order.
-            from .functional import reference_order_applies, reference_order_forward
+            from .aggregate import reference_order_applies, reference_order_forward
             stacked = None if self._dropout_active() or self.operand_dtype != torch.float32 else self._stacked("fs", self.fs)
             if stacked is not None and reference_order_applies(x, stacked, lut, g):
                 # training at scale: one node whose backward pass is the sum-first order's (the read-out makes every

@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from . import aggregate
 from . import functional as Fn
 from .functional import StackedMLP
 from .graph import HopGraph, hop_inputs
@@ -130,10 +131,10 @@ class _SmallGraph(torch.autograd.Function):
             raise RuntimeError("the one-launch small-graph forward with pre-rho normalisation was taken where its backward "
                                "does not apply (float32 parameters and output gradient expected)")
         dY = d_out.reshape(1, Cf).expand(n, Cf).contiguous() if ctx.graph_sum else d_out.contiguous()
-        bag = Fn._Bag()
+        bag = aggregate._Bag()
         bag.g, bag.use_cnt, bag.with_rest, bag.row_ids, bag.reduce_cr = ctx.g, ctx.use_cnt, False, None, 0
-        bag.s_total, bag.total_rows, bag.total_group = None, None, Fn.NOT_SHARED
-        dS, dlut = Fn._aggregate_backward(bag, S, lut, dY, need_f, need_r)
+        bag.s_total, bag.total_rows, bag.total_group = None, None, aggregate.NOT_SHARED
+        dS, dlut = aggregate._aggregate_backward(bag, S, lut, dY, need_f, need_r)
         pg_f = pg_r = [None] * 6
         if need_f:
             _, pg_f = Fn._shape_function_grads(x, fp, ctx.present[:6], None, dS, True, Lf, Hf, Cf, F, dests=ctx.dests[:6])

@@ -1,10 +1,10 @@
 """Plain-torch stand-ins for the ``gnan_spmm_*`` launchers — TEST INFRASTRUCTURE ONLY.
 
-They let the CPU suite drive the product's host logic around the kernels (``functional._RhoAggregate``: which
+They let the CPU suite drive the product's host logic around the kernels (``aggregate._RhoAggregate``: which
 launches a backward pass makes, with which operands, and what it adds on top — the rest-bucket terms, the
 collectives of the multi-rank variants) without a GPU: ``install()`` swaps them in for
-``functional.spmm_launch`` / ``shell_sums_launch`` / ``lut_grad_launch`` / ``column_sums`` inside the calling (test)
-process.  Each restates the documented semantics of its launcher (functional.py, include/gnan_hip.h) with index
+``aggregate.spmm_launch`` / ``shell_sums_launch`` / ``lut_grad_launch`` / ``functional.column_sums`` inside the calling (test)
+process.  Each restates the documented semantics of its launcher (aggregate.py, include/gnan_hip.h) with index
 arithmetic in float64; the GPU suite checks the real kernels against the oracle, this file is checked against the
 oracle in tests/test_host_logic.py.  CSR graphs only.
 """
@@ -119,18 +119,20 @@ def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None, ds_add=None):
 
 def install():
     """Swap the stand-ins in (call inside the test process / spawned worker; undo with the returned function)."""
-    from gnan_amd import _lib, functional
-    saved = {name: getattr(functional, name) for name in ("spmm_launch", "shell_sums_launch", "lut_grad_launch", "column_sums",
-                                                          "bwd_narrow_launch", "pack_bwd_rows")}
-    saved_req = _lib.require_device
-    functional.spmm_launch, functional.shell_sums_launch = spmm_launch, shell_sums_launch
-    functional.lut_grad_launch, functional.column_sums = lut_grad_launch, column_sums
-    functional.bwd_narrow_launch, functional.pack_bwd_rows = bwd_narrow_launch, pack_bwd_rows
+    from gnan_amd import _lib, aggregate, functional
+    mine = {"spmm_launch": spmm_launch, "shell_sums_launch": shell_sums_launch, "lut_grad_launch": lut_grad_launch,
+            "bwd_narrow_launch": bwd_narrow_launch, "pack_bwd_rows": pack_bwd_rows}
+    saved = {name: getattr(aggregate, name) for name in mine}
+    saved_sums, saved_req = functional.column_sums, _lib.require_device
+    for name, fn in mine.items():
+        setattr(aggregate, name, fn)
+    functional.column_sums = column_sums                       # (aggregate reads it through the functional module)
     _lib.require_device = lambda *a, **k: None
 
     def undo():
         for name, fn in saved.items():
-            setattr(functional, name, fn)
+            setattr(aggregate, name, fn)
+        functional.column_sums = saved_sums
         _lib.require_device = saved_req
     return undo
 

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import gnan_oracle as O
+from gnan_amd import aggregate  # noqa: E402  (the aggregation's switches are patched below)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -165,7 +166,7 @@ def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
     sliced = spmm_launch(g, S, lut, True, with_rest=False, reduce_cr=reduce_cr)
     sliced_sub = spmm_launch(g, S, lut, True, with_rest=False, row_ids=ids, reduce_cr=reduce_cr)
     sliced_t = spmm_launch(g.transposed(), S, lut, True, False, None, weight_by_col=True)
-    monkeypatch.setattr(functional, "DENSE_SLICE_MAX_ROWS", 0)             # row blocks only
+    monkeypatch.setattr(aggregate, "DENSE_SLICE_MAX_ROWS", 0)             # row blocks only
     plain = spmm_launch(g, S, lut, True, with_rest=False, reduce_cr=reduce_cr)
     plain_t = spmm_launch(g.transposed(), S, lut, True, False, None, weight_by_col=True)
     assert float((sliced - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
@@ -180,7 +181,7 @@ def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
     monkeypatch.undo()
     Sg, lg = S.clone().requires_grad_(True), lut.clone().requires_grad_(True)
     rho_aggregate(g, Sg, lg, True).pow(2).sum().backward()
-    monkeypatch.setattr(functional, "DENSE_SLICE_MAX_ROWS", 0)
+    monkeypatch.setattr(aggregate, "DENSE_SLICE_MAX_ROWS", 0)
     Sp, lp = S.clone().requires_grad_(True), lut.clone().requires_grad_(True)
     rho_aggregate(g, Sp, lp, True).pow(2).sum().backward()
     assert float((Sg.grad - Sp.grad).abs().max()) <= 2e-5 * float(Sp.grad.abs().max())
@@ -982,8 +983,8 @@ def test_dense_table_gradient_in_one_pass(n, D, W, dyc, use_cnt, monkeypatch):
     up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     got = {}
     for tag, fused in (("one_pass", True), ("shell_sums", False)):
-        monkeypatch.setattr(functional, "DENSE_LUT_GRAD", fused)
-        monkeypatch.setattr(functional, "SMALL_DENSE_ROWS", 1024 if fused else 0)
+        monkeypatch.setattr(aggregate, "DENSE_LUT_GRAD", fused)
+        monkeypatch.setattr(aggregate, "SMALL_DENSE_ROWS", 1024 if fused else 0)
         Sx, lut = S.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
         got[tag] = torch.autograd.grad(rho_aggregate(g, Sx, lut, use_cnt, with_rest=False), [Sx, lut], up)
     S64, lut64 = S.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
@@ -1018,7 +1019,7 @@ def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, m
     up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     got = {}
     for tag, on in (("fused", True), ("two_pass", False), ("fused2", True)):
-        monkeypatch.setattr(functional, "NARROW_FUSED_BACKWARD", on)
+        monkeypatch.setattr(aggregate, "NARROW_FUSED_BACKWARD", on)
         S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
         Y = rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest)
         got[tag] = torch.autograd.grad(Y, [S, lut], up)
@@ -1075,10 +1076,10 @@ def test_fused_narrow_backward_walks_sorted_copy_with_hot_columns(W, K, with_res
     up = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     monkeypatch.setattr(G, "HOT_COLUMNS", 64)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
-    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    monkeypatch.setattr(aggregate, "NARROW_SORTED_MIN_NNZ", 0)
     got = {}
     for tag, min_rows in (("natural", 1 << 30), ("sorted_hot", 1)):
-        monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
+        monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
         S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
         Y = rho_aggregate(g, S, lut, True, with_rest=with_rest)
         got[tag] = torch.autograd.grad(Y, [S, lut], up)
@@ -1091,12 +1092,12 @@ def test_fused_narrow_backward_walks_sorted_copy_with_hot_columns(W, K, with_res
         assert int(hub.sum()) >= 1
         assert torch.equal(got["natural"][0][~hub], got["sorted_hot"][0][~hub])
         assert O.rel_err(got["sorted_hot"][0].cpu(), got["natural"][0].cpu().double()) <= 2e-6
-        monkeypatch.setattr(functional, "NARROW_BWD_PERSISTENT", False)     # the generic kernel on the same copy
+        monkeypatch.setattr(aggregate, "NARROW_BWD_PERSISTENT", False)     # the generic kernel on the same copy
         S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
         plain = torch.autograd.grad(rho_aggregate(g, S, lut, True, with_rest=with_rest), [S, lut], up)
         assert torch.equal(plain[0], got["natural"][0])
-        monkeypatch.setattr(functional, "HOT_ROWS_IN_LDS", False)           # persistent, every packed row from memory
-        monkeypatch.setattr(functional, "NARROW_BWD_PERSISTENT", True)
+        monkeypatch.setattr(aggregate, "HOT_ROWS_IN_LDS", False)           # persistent, every packed row from memory
+        monkeypatch.setattr(aggregate, "NARROW_BWD_PERSISTENT", True)
         S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
         cold = torch.autograd.grad(rho_aggregate(g, S, lut, True, with_rest=with_rest), [S, lut], up)
         assert torch.equal(cold[0], got["sorted_hot"][0]) and torch.equal(cold[1], got["sorted_hot"][1])
@@ -1120,8 +1121,8 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
     from gnan_amd.functional import spmm_launch
     monkeypatch.setattr(G, "HOT_COLUMNS", 64)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
-    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
-    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
+    monkeypatch.setattr(aggregate, "NARROW_SORTED_MIN_NNZ", 0)
     rng = np.random.default_rng(W + 40)
     n, K = 5000, 2
     D = K + 2
@@ -1133,8 +1134,8 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
     lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
     out = {}
     for tag, walk, hot_rows in (("natural", False, False), ("sorted", True, False), ("hot", True, True)):
-        monkeypatch.setattr(functional, "NARROW_SORTED_WALK", walk)
-        monkeypatch.setattr(functional, "HOT_COLUMN_ROWS", hot_rows)
+        monkeypatch.setattr(aggregate, "NARROW_SORTED_WALK", walk)
+        monkeypatch.setattr(aggregate, "HOT_COLUMN_ROWS", hot_rows)
         out[tag] = spmm_launch(g, S, lut, not s_by_code, not s_by_code, s_by_code=s_by_code)
     assert g._sorted_copy_hot is not None and g._sorted_copy_hot.n_cols == n + 64
     assert int((g._sorted_copy_hot.col >= n).sum()) >= int(hot.sum())
@@ -1145,7 +1146,7 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
     assert torch.equal(out["natural"][~hub], out["hot"][~hub])
     assert O.rel_err(out["hot"].cpu(), out["natural"].cpu().double()) <= 2e-6
     if W in (1, 2, 4) and not s_by_code:
-        monkeypatch.setattr(functional, "HOT_ROWS_IN_LDS", False)
+        monkeypatch.setattr(aggregate, "HOT_ROWS_IN_LDS", False)
         assert torch.equal(spmm_launch(g, S, lut, True, True), out["natural"])            # the plain kernel on the same copy
     if not s_by_code:
         wt = lut.cpu().double().unsqueeze(0) / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
@@ -1160,8 +1161,8 @@ def test_packed_index_entries_give_the_same_bits(W, K, bf16, monkeypatch):
     itself is checked against its definition, and shapes it cannot carry keep the two arrays."""
     from gnan_amd import functional, graph as G
     from gnan_amd.functional import spmm_launch
-    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
-    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
+    monkeypatch.setattr(aggregate, "NARROW_SORTED_MIN_NNZ", 0)
     rng = np.random.default_rng(W + K)
     n, D = 6000, K + 2
     rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 5000), (5999, 2100)])
@@ -1172,7 +1173,7 @@ def test_packed_index_entries_give_the_same_bits(W, K, bf16, monkeypatch):
     lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
     out = {}
     for packed in (False, True):
-        monkeypatch.setattr(functional, "PACKED_INDEX", packed)
+        monkeypatch.setattr(aggregate, "PACKED_INDEX", packed)
         out[packed] = spmm_launch(g, S, lut, True, True, reduce_cr=1 if W == 64 else 0)
     copy = g.degree_sorted_copy()[0]
     assert copy.colp is not None
@@ -1208,16 +1209,16 @@ def test_aggregation_paths_agree_on_random_shapes(seed, monkeypatch):
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN", 1)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_SHARE", 0.0)
-    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    monkeypatch.setattr(aggregate, "NARROW_SORTED_MIN_NNZ", 0)
     out = []
     for min_rows, walk, hot_rows, packed, wide in ((1 << 30, False, False, False, False), (1, True, False, False, True),
                                                    (1, True, True, True, True), (1, True, True, False, False),
                                                    (1 << 30, False, False, False, True)):
-        monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
-        monkeypatch.setattr(functional, "NARROW_SORTED_WALK", walk)
-        monkeypatch.setattr(functional, "HOT_COLUMN_ROWS", hot_rows)
-        monkeypatch.setattr(functional, "PACKED_INDEX", packed)
-        monkeypatch.setattr(functional, "WIDE_INDEX_LOADS", wide)
+        monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
+        monkeypatch.setattr(aggregate, "NARROW_SORTED_WALK", walk)
+        monkeypatch.setattr(aggregate, "HOT_COLUMN_ROWS", hot_rows)
+        monkeypatch.setattr(aggregate, "PACKED_INDEX", packed)
+        monkeypatch.setattr(aggregate, "WIDE_INDEX_LOADS", wide)
         out.append(spmm_launch(g, S, lut, use_cnt, with_rest))
     sliced = torch.from_numpy(np.diff(rowptr) > 64).to(DEV)     # rows some plan may slice (narrow rows: from 64 pairs)
     for k, y in enumerate(out[1:]):
@@ -1260,10 +1261,10 @@ def test_aggregation_gradients_agree_on_random_shapes(seed, monkeypatch):
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN", 1)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_SHARE", 0.0)
-    monkeypatch.setattr(functional, "NARROW_SORTED_MIN_NNZ", 0)
+    monkeypatch.setattr(aggregate, "NARROW_SORTED_MIN_NNZ", 0)
     got = []
     for min_rows in (1 << 30, 1):
-        monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
+        monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", min_rows)
         S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
         got.append(torch.autograd.grad(rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest), [S, lut], up))
     assert torch.equal(got[0][0], got[1][0])
@@ -1289,8 +1290,8 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     g = _graph(rowptr, col, code, n, K + 2)
     S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).to(DEV)
     lut = torch.tensor([[1.0], [0.5], [0.01]], device=DEV)
-    assert functional.DEGREE_SORTED_COPY
-    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY_MIN_ROWS", 2)
+    assert aggregate.DEGREE_SORTED_COPY
+    monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", 2)
     y_copy = spmm_launch(g, S, lut, True, True)                  # degree-sorted copy of the CSR (scatter_out = 2)
     r_copy = spmm_launch(g, S, lut, True, True, reduce_cr=1)
     gs, order, _ = g.degree_sorted_copy()
@@ -1302,10 +1303,10 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
         a, b = rowptr[o[q]], rowptr[o[q] + 1]
         assert np.array_equal(col_s[rp_s[q]:rp_s[q + 1]], col[a:b]) and np.array_equal(code_s[rp_s[q]:rp_s[q + 1]], code[a:b])
     assert torch.equal(gs.cnt, g.cnt[order.long()])
-    monkeypatch.setattr(functional, "DEGREE_SORTED_COPY", False)  # degree order through an index (scatter_out = 1)
+    monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY", False)  # degree order through an index (scatter_out = 1)
     assert torch.equal(y_copy, spmm_launch(g, S, lut, True, True))
     assert torch.equal(r_copy, spmm_launch(g, S, lut, True, True, reduce_cr=1))
-    monkeypatch.setattr(functional, "DEGREE_SCHEDULE_MIN_WIDTH", 1 << 30)   # natural order
+    monkeypatch.setattr(aggregate, "DEGREE_SCHEDULE_MIN_WIDTH", 1 << 30)   # natural order
     assert torch.equal(y_copy, spmm_launch(g, S, lut, True, True))
     assert torch.equal(r_copy, spmm_launch(g, S, lut, True, True, reduce_cr=1))
 

@@ -11,6 +11,7 @@ import torch
 from conftest import Golden, golden_names
 from helpers import inputs_from, params_from, tolerance_ok
 from oracle import gnan_oracle as O
+from gnan_amd import aggregate  # noqa: E402  (the aggregation's switches are patched below)
 
 pytestmark = pytest.mark.gpu
 
@@ -433,12 +434,12 @@ def test_reference_order_training_uses_the_sum_first_backward(gpu, C, rho_per_fe
     from gnan_amd import HopGraph, _lib, functional, models
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
     used = {"n": 0}
-    real = functional._ReferenceOrderAggregate.forward
+    real = aggregate._ReferenceOrderAggregate.forward
 
     def counting(ctx, *a):
         used["n"] += 1
         return real(ctx, *a)
-    monkeypatch.setattr(functional._ReferenceOrderAggregate, "forward", staticmethod(counting))
+    monkeypatch.setattr(aggregate._ReferenceOrderAggregate, "forward", staticmethod(counting))
     rng = np.random.default_rng(C)
     n, F = 3000, 9
     ei = rng.integers(0, n, (2, 4 * n))

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import gnan_amd  # noqa: F401
-from gnan_amd import HopGraph, functional, pwl
+from gnan_amd import HopGraph, aggregate, functional, pwl
 from gnan_amd.functional import StackedMLP
 from oracle import gnan_oracle as O
 
@@ -183,7 +183,7 @@ def cpu_kernels():
     (2, 1, 1, True, False, 0, True),
 ])
 def test_aggregation_backward_host_logic_vs_oracle_autograd(cpu_kernels, W, Cw, K, use_cnt, per_row, cr, subset):
-    """functional._RhoAggregate on stand-in launchers (tests/cpu_kernels.py) == autograd through the oracle: checks which
+    """aggregate._RhoAggregate on stand-in launchers (tests/cpu_kernels.py) == autograd through the oracle: checks which
     launches the backward pass makes and what it adds around them (rest-bucket terms, fused-sum broadcast, row subsets)."""
     rng = np.random.default_rng(W * 7 + Cw + K)
     n, D = 40, K + 2
@@ -192,7 +192,7 @@ def test_aggregation_backward_host_logic_vs_oracle_autograd(cpu_kernels, W, Cw, 
     S = torch.from_numpy(rng.standard_normal((n, W)).astype(np.float32)).requires_grad_(True)
     lut = torch.from_numpy(rng.standard_normal((n, D, Cw) if per_row else (D, Cw)).astype(np.float32)).requires_grad_(True)
     rows = torch.from_numpy(rng.permutation(n)[:11].astype(np.int32)) if subset else None
-    Y = functional.rho_aggregate(g, S, lut, use_cnt, row_ids=rows, reduce_channels=cr)
+    Y = aggregate.rho_aggregate(g, S, lut, use_cnt, row_ids=rows, reduce_channels=cr)
     up = torch.from_numpy(rng.standard_normal(tuple(Y.shape)).astype(np.float32))
     dS, dlut = torch.autograd.grad(Y, [S, lut], up)
     S64, lut64 = S.detach().double().requires_grad_(True), lut.detach().double().requires_grad_(True)
@@ -219,7 +219,7 @@ def test_rest_bucket_total_over_the_first_rows_only(cpu_kernels):
     S = torch.from_numpy(rng.standard_normal((n_cols, W)).astype(np.float32)).requires_grad_(True)
     lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).requires_grad_(True)
     total = S[:n_own].sum(0).detach()
-    Y = functional.rho_aggregate(g, S, lut, True, s_total=total, total_rows=n_own)
+    Y = aggregate.rho_aggregate(g, S, lut, True, s_total=total, total_rows=n_own)
     up = torch.from_numpy(rng.standard_normal(tuple(Y.shape)).astype(np.float32))
     dS, dlut = torch.autograd.grad(Y, [S, lut], up)
     S64, lut64 = S.detach().double().requires_grad_(True), lut.detach().double().requires_grad_(True)

@@ -19,7 +19,7 @@ from gnan_amd import HopGraph, synthetic as syn
 from gnan_amd import functional
 from gnan_amd.functional import column_sums, spmm_launch
 
-functional.DEGREE_SCHEDULE_MIN_WIDTH = int(os.environ.get("MIN_WIDTH", "8"))
+aggregate.DEGREE_SCHEDULE_MIN_WIDTH = int(os.environ.get("MIN_WIDTH", "8"))
 
 dev = torch.device("cuda")
 N, E = 10_000_000, 100_000_000

@@ -1,5 +1,5 @@
 """EXPERIMENT: narrow operand rows (W = 1..4) walked in degree order through the degree-sorted copy of the CSR
-(functional.NARROW_SORTED_WALK), with and without the hot rows appended (functional.HOT_COLUMN_ROWS), against natural order.     python tools/experiments/narrow_sorted.py [W ...]"""
+(aggregate.NARROW_SORTED_WALK), with and without the hot rows appended (aggregate.HOT_COLUMN_ROWS), against natural order.     python tools/experiments/narrow_sorted.py [W ...]"""
 import os
 import sys
 
@@ -38,6 +38,6 @@ for W in [int(w) for w in sys.argv[1:]] or [1, 2, 4]:
     ys = []
     for label, walk, hot in (("natural order", False, False), ("degree-sorted copy", True, False),
                              ("degree-sorted copy + hot rows appended", True, True)):
-        functional.NARROW_SORTED_WALK, functional.HOT_COLUMN_ROWS = walk, hot
+        aggregate.NARROW_SORTED_WALK, aggregate.HOT_COLUMN_ROWS = walk, hot
         ys.append(bench(S, total, f"W = {W}: {label}"))
     print("    identical:", all(bool(torch.equal(ys[0], y)) for y in ys[1:]))
