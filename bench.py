@@ -769,18 +769,33 @@ def main():
                                               operand_dtype=op_dtype, tables=tables, marks=marks)
             return partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
                                        operand_dtype=op_dtype, tables=tables, marks=marks)
+        def all_ranks(ok: bool) -> bool:             # every rank replays, or none does (the collectives must pair up)
+            if world == 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag))
+        want = None
         try:
             with torch.no_grad():
                 want = share_forward(prefetch.launch()).clone()
             share = SharePipeline(share_forward, stacked, x=x, fork_at=args.share_fork)
-            got = [share.step().clone() for _ in range(2)]          # both graphs once
+        except (CaptureFailed, RuntimeError) as e:
+            share, share_note = None, f"not capturable ({type(e).__name__}: {str(e)[:200]}): eager loop"
+        if not all_ranks(share is not None):
+            if share is not None:
+                share_note = "another rank could not capture its share: eager loop on every rank"
+            share = None
+        if share is not None:                        # (same number of replays — of captured collectives — on every rank)
+            got = [share.step().clone() for _ in range(4)]          # both graphs twice: a node that replays correctly only once shows
             torch.cuda.synchronize()
             scale = float(want.abs().max())
             worst = max(float((o - want).abs().max()) for o in got)
-            if share.tripped() or not worst <= 1e-6 * scale:
-                share, share_note = None, f"first replays off by {worst / max(scale, 1e-30):.2e} (or guard tripped): eager loop"
-        except (CaptureFailed, RuntimeError) as e:
-            share, share_note = None, f"not capturable ({type(e).__name__}: {str(e)[:200]}): eager loop"
+            good = not share.tripped() and worst <= 1e-6 * scale
+            if not all_ranks(good):
+                share = None
+                share_note = (f"first replays off by {worst / max(scale, 1e-30):.2e} (or guard tripped): eager loop" if not good
+                              else "another rank's replays did not reproduce its eager forward: eager loop on every rank")
 
     def step(record):
         marks = {}

@@ -509,6 +509,11 @@ __device__ __forceinline__ unsigned long long fixed_bits(float v, double s) {
   return static_cast<unsigned long long>(__double_as_longlong(d)) - 0x4338000000000000ull;
 }
 
+__device__ __forceinline__ unsigned long long fixed_bits_d(double v, double s) {
+  const double d = fma(v, s, 6755399441055744.0);
+  return static_cast<unsigned long long>(__double_as_longlong(d)) - 0x4338000000000000ull;
+}
+
 template <int FG, int BS, bool FIXED>
 __global__ __launch_bounds__(BS) void fpwl_moments_kernel(const MomentParams mp) {
   using bin_t = std::conditional_t<FIXED, unsigned long long, float>;
@@ -772,6 +777,61 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
     a0[f] = live[f] ? p.anchor[base + s_off[q * FPT + f]] : 0.f;
   }
   const double s0 = mp.scales[0], s1 = mp.scales[1];
+  if constexpr (!RAGGED) {
+    if (saved && (SUMF || mp.vec_g)) {
+      // The forward kept the pieces: no search.  Binned here are sum g and sum g * x (the product exact in float64) — two LDS
+      // atomics per look-up and NOTHING the wave has to wait for (reading the piece's anchor first put an LDS round trip in
+      // front of every pair of atomics: the LDS pipe sat idle 40 % of the time, profiles/r04_sq_train.txt); the anchor enters
+      // once per piece and workgroup, when the bins are flushed: M1 = sum g (x - a) = sum g x - a sum g.  The NEXT round's
+      // x / gradient / pieces are requested before this round's atomics (unconditional loads from a clamped address — a
+      // guarded load hides the loads in flight from the compiler, which then waits for all of them).
+      int64_t n = n_lo + nl;
+      if (n < n_hi) {
+        const int64_t last = n_hi - 1;
+        const uint8_t* pin = p.piece_in + static_cast<int64_t>(grp) * p.n * FG + q * FPT;
+        const float* xin = p.x + k0 + q * FPT;
+        const float* gin = SUMF ? mp.g : mp.g + k0 + q * FPT;
+        float4 cx = *reinterpret_cast<const float4*>(xin + n * p.x_stride);
+        unsigned cp = *reinterpret_cast<const unsigned*>(pin + n * FG);
+        float4 cg;
+        if constexpr (SUMF) { cg.x = gin[n * mp.g_stride]; cg.y = cg.z = cg.w = cg.x; }
+        else cg = *reinterpret_cast<const float4*>(gin + n * mp.g_stride);
+        for (; n < n_hi; n += NODES) {
+          const int64_t nn = n + NODES < n_hi ? n + NODES : last;
+          const float4 nx = *reinterpret_cast<const float4*>(xin + nn * p.x_stride);
+          const unsigned np = *reinterpret_cast<const unsigned*>(pin + nn * FG);
+          float4 ng;
+          if constexpr (SUMF) { ng.x = gin[nn * mp.g_stride]; ng.y = ng.z = ng.w = ng.x; }
+          else ng = *reinterpret_cast<const float4*>(gin + nn * mp.g_stride);
+          const float xv[FPT] = {cx.x, cx.y, cx.z, cx.w};
+          const float gv[FPT] = {cg.x, cg.y, cg.z, cg.w};
+          unsigned long long t0 = 0ull;
+          if constexpr (SUMF) t0 = fixed_bits(gv[0], s0);
+#pragma unroll
+          for (int f = 0; f < FPT; ++f) {
+            const int idx = binoff[f] + P2 + static_cast<int>((cp >> (8 * f)) & 0xffu);
+            if constexpr (!SUMF) t0 = fixed_bits(gv[f], s0);
+            atomicAdd(bins + idx, t0);
+            atomicAdd(bins + tot + idx, fixed_bits_d(static_cast<double>(gv[f]) * static_cast<double>(xv[f]), s1));
+          }
+          cx = nx; cp = np; cg = ng;
+        }
+      }
+      __syncthreads();
+      unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2;      // [T][2]
+      const double ratio = s1 / s0;
+      for (int i = tid; i < tot; i += BS) {
+        const long long m0 = static_cast<long long>(bins[i]), m1x = static_cast<long long>(bins[tot + i]);
+        if (m0 != 0 || m1x != 0) {
+          // (float64: relative error 2^-53 of |a sum g| per workgroup and piece — the same in every run: the node blocks are fixed)
+          const long long m1 = m1x - __double2ll_rn(static_cast<double>(smem[i]) * static_cast<double>(m0) * ratio);
+          if (m0 != 0) atomicAdd(out + 2 * i, static_cast<unsigned long long>(m0));
+          if (m1 != 0) atomicAdd(out + 2 * i + 1, static_cast<unsigned long long>(m1));
+        }
+      }
+      return;
+    }
+  }
   for (int64_t n = n_lo + nl; n < n_hi; n += NODES) {
     float xv[FPT];
     if constexpr (RAGGED) {
