@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -180,7 +180,7 @@ class SmallGraphBwdArgs(C.Structure):
         ("x", C.c_void_p), ("x_stride", C.c_int64), ("n", C.c_int32), ("F", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp),
         ("code", C.c_void_p), ("D", C.c_int32), ("pre_rho", C.c_int32), ("cnt", C.c_void_p), ("cnt_stride", C.c_int64),
         ("S", C.c_void_p), ("lut", C.c_void_p), ("dY", C.c_void_p), ("dYsum", C.c_void_p), ("df", SmallMlpGrads),
-        ("drho", SmallMlpGrads),
+        ("drho", SmallMlpGrads), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -283,6 +283,7 @@ SYMBOLS = {
     "gnan_small_graph_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "gnan_small_graph_fwd": (C.c_int, [C.POINTER(SmallGraphArgs), C.c_void_p]),
     "gnan_small_graph_bwd": (C.c_int, [C.POINTER(SmallGraphBwdArgs), C.c_void_p]),
+    "gnan_small_graph_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gnan_small_graph_nam_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gnan_small_graph_nam_fwd": (C.c_int, [C.POINTER(SmallGraphNamArgs), C.c_void_p]),
     "gnan_small_graph_nam_bwd": (C.c_int, [C.POINTER(SmallGraphNamBwdArgs), C.c_void_p]),

@@ -302,9 +302,16 @@ struct SmallBwdParams {
   const float* dY;
   const float* dYsum;
   int pre_rho;               // lut is the rows' table [n, D] = rho(u_d / max(cnt[i, d], 1)) (GNAN.py:65-67)
+  // pre-rho: rho's n * D arguments are split by rows over rho_groups workgroups (blockIdx F .. F + rho_groups - 1), rows_per rows
+  // each; with more than one group every group leaves its gradients in its slot of part (kRhoSlot floats: W2's 64 x 64, then
+  // five vectors of 64) and the last to arrive adds them in group order
+  int rho_groups, rows_per;
+  float* part;
+  unsigned* counter;
 };
 
 constexpr int kBinStride = kWave + 1;
+constexpr int kRhoSlot = kMaxH * kMaxH + 5 * kMaxH, kRhoGroupsMax = 12;       // 12 slots = 207 KB: inside a captured step's 256-KB scratch
 
 // NB as in small_graph_kernel (2: n <= 128 — hop codes and the row-weight / bin area take 50 KB: dynamic LDS).
 template <int C, int NB>
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   __shared__ double s_part[kWaves][kWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int k = blockIdx.x, n = p.n;
-  const bool is_rho = k == p.F;
+  const bool is_rho = k >= p.F;
   // ---- everything from memory in one batch ----------------------------------------------------------------------------------
   {
     constexpr int kWordsPer = kNodes * kNodes / 4 / 256;
@@ -408,9 +415,11 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   while (nw < 4 && 2 * nw * p.D * stride <= kUFloats) nw *= 2;
   float* bins = s_u + wave * p.D * stride;
   double acc = 0.0;                                        // lane d: dlut[d] over this wave's rows
-  for (int r = 0; nw * r < n; ++r) {
-    const int i = nw * r + wave;
-    const bool live = wave < nw && i < n;
+  const int i_lo = p.pre_rho ? (k - p.F) * p.rows_per : 0;         // this workgroup's rows (all of them unless pre-rho splits)
+  const int i_hi = p.pre_rho ? (i_lo + p.rows_per < n ? i_lo + p.rows_per : n) : n;
+  for (int r = 0; i_lo + nw * r < i_hi; ++r) {
+    const int i = i_lo + nw * r + wave;
+    const bool live = wave < nw && i < i_hi;
     if (live) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
       float sum = 0.f;
       for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];
       if (p.pre_rho) {
-        s_dl[i * p.D + lane] = sum;                        // every (row, shell) is an argument of rho of its own
+        s_dl[(i - i_lo) * p.D + lane] = sum;               // every (row, shell) is an argument of rho of its own
       } else {
         if (p.cnt) {
           const int c = p.cnt[i * p.cnt_stride + lane];
@@ -443,18 +452,66 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     __syncthreads();
   }
   if (p.pre_rho) {
-    // rho's parameter gradients over its n * D arguments u_d / max(cnt[i, d], 1) (the bins are dead: the arguments take their place)
-    for (int e = threadIdx.x; e < n * p.D; e += 256) {
+    // rho's parameter gradients over this workgroup's arguments u_d / max(cnt[i, d], 1) (the bins are dead: the arguments take
+    // their place)
+    const int count = (i_hi - i_lo) * p.D;
+    for (int e = threadIdx.x; e < count; e += 256) {
       const int d = e % p.D;
-      const int c = p.cnt[(e / p.D) * p.cnt_stride + d];
+      const int c = p.cnt[(i_lo + e / p.D) * p.cnt_stride + d];
       const float ud = d < p.D - 1 ? 1.0f / (static_cast<float>(d) + 1.0f) : 0.f;
       s_u[e] = ud / static_cast<float>(c > 1 ? c : 1);
     }
     __syncthreads();
     auto ua_of = [&](int64_t e) { return s_u[e]; };
     auto ga_of = [&](int64_t e, int) { return s_dl[e]; };
-    if (p.r_mid) gnan_bwd::feature_grads<1, true>(p.r, 0, 0, n * p.D, 0, nodrop, ua_of, ga_of, red);
-    else gnan_bwd::feature_grads<1, false>(p.r, 0, 0, n * p.D, 0, nodrop, ua_of, ga_of, red);
+    gnan_bwd::Weights w = p.r;
+    if (p.rho_groups > 1) {                                // partial gradients into this group's slot
+      float* slot = p.part + static_cast<int64_t>(k - p.F) * kRhoSlot;
+      w.d_w_mid = slot;
+      w.d_w_first = slot + kMaxH * kMaxH; w.d_b_first = p.r.d_b_first ? slot + kMaxH * kMaxH + kMaxH : nullptr;
+      w.d_b_mid = p.r.d_b_mid ? slot + kMaxH * kMaxH + 2 * kMaxH : nullptr; w.d_w_last = slot + kMaxH * kMaxH + 3 * kMaxH;
+      w.d_b_last = p.r.d_b_last ? slot + kMaxH * kMaxH + 4 * kMaxH : nullptr;
+    }
+    if (p.r_mid) gnan_bwd::feature_grads<1, true>(w, 0, 0, count, 0, nodrop, ua_of, ga_of, red);
+    else gnan_bwd::feature_grads<1, false>(w, 0, 0, count, 0, nodrop, ua_of, ga_of, red);
+    if (p.rho_groups == 1) return;
+    // ---- join of the rho groups: the last to arrive adds the partial gradients in group order ------------------------------------
+    __shared__ unsigned s_last_rho;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last_rho = atomicAdd(p.counter, 1u);
+    __syncthreads();
+    if (s_last_rho != static_cast<unsigned>(p.rho_groups) - 1) return;
+    __threadfence();
+    // (a thread's loads of all groups' terms are issued together, 16 bytes each: a load -> add loop over the groups would
+    //  wait for every load in turn — 160 cold round trips per thread, longer than the whole rest of the launch)
+    const int H = p.r.H;
+    float* const vec[5] = {p.r.d_w_first, p.r.d_b_first, p.r_mid ? p.r.d_b_mid : nullptr, p.r.d_w_last, p.r.d_b_last};
+    float* const dW2 = p.r_mid ? p.r.d_w_mid : nullptr;
+    for (int e4 = threadIdx.x; e4 < kRhoSlot / 4; e4 += 256) {
+      float4 v[kRhoGroupsMax];
+#pragma unroll
+      for (int g = 0; g < kRhoGroupsMax; ++g) {
+        const int gg = g < p.rho_groups ? g : 0;
+        v[g] = *reinterpret_cast<const float4*>(p.part + static_cast<int64_t>(gg) * kRhoSlot + 4 * e4);
+      }
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < kRhoGroupsMax; ++g) {
+        if (g < p.rho_groups) { sum[0] += v[g].x; sum[1] += v[g].y; sum[2] += v[g].z; sum[3] += v[g].w; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * e4 + u;
+        if (idx < kMaxH * kMaxH) {
+          if (dW2 && idx < H * H) dW2[idx] = sum[u];
+        } else {
+          const int t = (idx - kMaxH * kMaxH) / kMaxH, e = (idx - kMaxH * kMaxH) % kMaxH;
+          if (vec[t] && e < (t == 4 ? 1 : H)) vec[t][e] = sum[u];
+        }
+      }
+    }
+    if (threadIdx.x == 0) *p.counter = 0u;
     return;
   }
   s_part[wave][lane] = wave < nw ? acc : 0.0;
@@ -478,14 +535,14 @@ constexpr size_t small_bwd_dyn_bytes(bool pre_rho) {
 template <int C>
 int launch_small_bwd(const SmallBwdParams& p, hipStream_t st) {
   if (p.n <= 64) {
-    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 1>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256),
+    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 1>), dim3(static_cast<unsigned>(p.F + p.rho_groups)), dim3(256),
                        small_bwd_dyn_bytes<1>(p.pre_rho != 0), st, p);
   } else {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_bwd_kernel<C, 2>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        static_cast<int>(small_bwd_dyn_bytes<2>(true)));
     if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_graph_bwd: hipFuncSetAttribute: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 2>), dim3(static_cast<unsigned>(p.F) + 1), dim3(256),
+    hipLaunchKernelGGL((small_graph_bwd_kernel<C, 2>), dim3(static_cast<unsigned>(p.F + p.rho_groups)), dim3(256),
                        small_bwd_dyn_bytes<2>(p.pre_rho != 0), st, p);
   }
   return gnan::check_launch("small_graph_bwd_kernel");
@@ -536,6 +593,11 @@ extern "C" int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_
   return gnan::check_launch("small_graph_kernel");
 }
 
+extern "C" size_t gnan_small_graph_bwd_workspace_bytes(int32_t n, int32_t D) {
+  (void)n; (void)D;
+  return 16 + static_cast<size_t>(kRhoGroupsMax) * kRhoSlot * sizeof(float);   // counter (own 16 bytes) | part [<= 12][kRhoSlot]
+}
+
 extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "small_graph_bwd: null args");
   GNAN_REQUIRE(a->n >= 1 && a->F >= 1 && a->D >= 1, "small_graph_bwd: bad sizes n=%d F=%d D=%d", a->n, a->F, a->D);
@@ -554,6 +616,20 @@ extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_str
   p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
   p.S = a->S; p.lut = a->lut; p.dY = a->dY; p.dYsum = a->dYsum; p.pre_rho = a->pre_rho != 0;
   GNAN_REQUIRE(!p.pre_rho || a->cnt != nullptr, "small_graph_bwd: pre-rho normalisation needs the shell sizes");
+  p.rho_groups = 1; p.rows_per = a->n; p.part = nullptr; p.counter = nullptr;
+  if (p.pre_rho) {
+    // rho's n * D arguments by rows over up to 12 workgroups — about as many arguments each as a feature workgroup has nodes —
+    // when the caller lent the room for their partial gradients
+    int groups = a->D < kRhoGroupsMax ? a->D : kRhoGroupsMax;
+    groups = groups < a->n ? groups : a->n;
+    const size_t need = gnan_small_graph_bwd_workspace_bytes(a->n, a->D);
+    if (groups > 1 && a->workspace != nullptr && a->workspace_bytes >= need) {
+      p.rows_per = (a->n + groups - 1) / groups;
+      p.rho_groups = (a->n + p.rows_per - 1) / p.rows_per;
+      p.counter = static_cast<unsigned*>(a->workspace);
+      p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 16);
+    }
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a->f.C) {
     case 1: return launch_small_bwd<1>(p, st);

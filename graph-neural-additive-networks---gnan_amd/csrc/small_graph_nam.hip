@@ -163,11 +163,21 @@ __global__ __launch_bounds__(256) void small_graph_nam_kernel(const NamParams p)
   __syncthreads();
   if (s_last != gridDim.x - 1) return;
   __threadfence();
-  if (static_cast<int>(threadIdx.x) < C) {
-    float s = 0.f;
-    for (int kk = 0; kk < p.F; ++kk) s += p.part[kk * C + threadIdx.x];
-    p.out[threadIdx.x] = s;
+  // (every term fetched by a thread of its own — all loads in flight together — then added in feature order from LDS)
+  const int chunk = kWeightFloats / C * C;           // whole features per pass through the (now free) weight image
+  for (int e0 = 0; e0 < p.F * C; e0 += chunk) {
+    const int en = p.F * C - e0 < chunk ? p.F * C - e0 : chunk;
+    __syncthreads();
+    for (int e = threadIdx.x; e < en; e += 256) weights[e] = p.part[e0 + e];
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < C) {
+      float s = e0 == 0 ? 0.f : s_colw[threadIdx.x];
+      for (int e = threadIdx.x; e < en; e += C) s += weights[e];
+      s_colw[threadIdx.x] = s;
+    }
   }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < C) p.out[threadIdx.x] = s_colw[threadIdx.x];
   if (threadIdx.x == 0) *p.counter = 0u;
 }
 
@@ -294,7 +304,13 @@ __global__ __launch_bounds__(256) void small_graph_nam_bwd_kernel(const NamBwdPa
     const int kn = p.F - k0 < kMaxH ? p.F - k0 : kMaxH;
     for (int j = threadIdx.x; j < n; j += 256) {
       float t = s_g[j];
-      for (int kk = 0; kk < kn; ++kk) t = fmaf(s_dh[kk], p.fx[static_cast<int64_t>(k0 + kk) * n + j], t);
+      for (int kk = 0; kk < kn; kk += 8) {            // eight features' terms requested together (a load -> fma loop waits for each)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = kk + u < kn ? p.fx[static_cast<int64_t>(k0 + kk + u) * n + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t = fmaf(kk + u < kn ? s_dh[kk + u] : 0.f, v[u], t);
+      }
       s_g[j] = t;
     }
   }

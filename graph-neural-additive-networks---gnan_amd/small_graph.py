@@ -115,12 +115,14 @@ class _SmallGraph(torch.autograd.Function):
                                           b_mid=None if o[3] is None else _lib.ptr(o[3][0]), w_last=_lib.ptr(o[4]), b_last=_lib.ptr(o[5]))
             g_out = d_out.detach().contiguous()
             cnt = ctx.g.cnt if ctx.use_cnt else None
+            ws = _workspace(x.device, _lib.lib().gnan_small_graph_bwd_workspace_bytes(n, ctx.g.n_codes)) if pre_rho else None
             a = _lib.SmallGraphBwdArgs(x=_lib.ptr(x), x_stride=x.stride(0), n=n, F=F, f=_small_mlp(keep[:6], Lf, Hf, Cf),
                                        rho=_small_mlp(keep[6:], Lr, Hr, Cr), code=_lib.ptr(ctx.g.code), D=ctx.g.n_codes,
                                        pre_rho=int(pre_rho), cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0),
                                        S=_lib.ptr(S),
                                        lut=_lib.ptr(lut), dY=None if ctx.graph_sum else _lib.ptr(g_out),
-                                       dYsum=_lib.ptr(g_out) if ctx.graph_sum else None, df=grads(outs_f), drho=grads(outs_r))
+                                       dYsum=_lib.ptr(g_out) if ctx.graph_sum else None, df=grads(outs_f), drho=grads(outs_r),
+                                       workspace=_lib.ptr(ws), workspace_bytes=0 if ws is None else ws.numel() * 4)
             _lib.check(_lib.lib().gnan_small_graph_bwd(a, _lib.stream_of(x)), "gnan_small_graph_bwd")
             if not need_f:
                 outs_f = [None] * 6

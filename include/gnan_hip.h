@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 39
+#define GNAN_ABI_VERSION 40
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -632,7 +632,8 @@ int gnan_dense_blocks_to_code(const float* dist, int64_t stride, int64_t n, cons
  * dS[j, :] = sum_i lut[code[i, j]] / max(cnt[i, code[i, j]], 1) * dY[i, :] itself and runs gnan_fmlp_bwd's body on feature k;
  * workgroup F forms dlut[d] = sum_i 1 / max(cnt[i, d], 1) * sum_{j : code[i, j] == d} <dY[i, :], S[j, :]> and runs it on rho.
  * Covers n <= 128, D <= 64, a one-channel rho, L in {2, 3}, H <= 64, C <= 8; GNAN_ERR_UNSUPPORTED otherwise (the general
- * kernels then: gnan_spmm_fwd on the transposed codes, gnan_spmm_lut_grad, gnan_fmlp_bwd twice).  No workspace, no atomics. */
+ * kernels then: gnan_spmm_fwd on the transposed codes, gnan_spmm_lut_grad, gnan_fmlp_bwd twice).  No atomics on data; a workspace
+ * only to split the pre-rho variant's rho work (below). */
 typedef struct gnan_small_mlp_grads {
   float* w_first;
   float* b_first;            /* NULL exactly where the MLP has no such bias */
@@ -658,7 +659,12 @@ typedef struct gnan_small_graph_bwd_args {
   const float* dYsum;        /* [f.C] or NULL (used when dY is NULL) */
   gnan_small_mlp_grads df;
   gnan_small_mlp_grads drho;
+  void* workspace;           /* optional (pre_rho): gnan_small_graph_bwd_workspace_bytes(n, D) bytes whose first 16 are ZERO before the
+                                first launch (the kernel leaves them zero) — rho's n * D arguments are then split over up to 12
+                                workgroups whose partial gradients the last one adds in order; without it one workgroup walks them all */
+  size_t workspace_bytes;
 } gnan_small_graph_bwd_args;
+size_t gnan_small_graph_bwd_workspace_bytes(int32_t n, int32_t D);
 int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_stream_t stream);
 
 /* The same small graph-level task with a NAM read-out over the per-feature aggregates (models.py:358-384 with is_graph_task
