@@ -341,6 +341,35 @@ def run_c3(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fb_ms, fb_min = _event_ms(fwd_bwd, args.steps, 0)
+    # ... and the same step replayed from ONE hipGraph launch (what gnan_amd.harness does with a full-batch epoch from its
+    # third pass on): the eager step above is bound by the host issuing ~60 launches, not by the device
+    replay = {"replayed_fwd_bwd_ms": None, "replayed_fwd_bwd_ms_min": None, "replay_note": None}
+    try:
+        from gnan_amd.graphed import CaptureFailed, GraphedCallable
+        eager_grads = [p.grad.detach().clone() for p in model.parameters()]
+
+        def clear():
+            for p in model.parameters():
+                p.grad = None
+
+        def static_step():
+            out = model.forward(data)
+            ((out - target) ** 2).mean().backward()
+            return out
+        captured = GraphedCallable(static_step, warmup=2, before_capture=clear)
+        captured.replay()
+        captured.replay()
+        torch.cuda.synchronize()
+        scale = max(float(g0.abs().max()) for g0 in eager_grads)
+        worst = max(float((p.grad - g0).abs().max()) for p, g0 in zip(model.parameters(), eager_grads))
+        if not worst <= 1e-5 * scale:
+            replay["replay_note"] = f"replayed gradients off by {worst / max(scale, 1e-30):.2e} of the largest: not reported"
+        else:
+            replay["replayed_fwd_bwd_ms"], replay["replayed_fwd_bwd_ms_min"] = _event_ms(captured.replay, args.steps, 0)
+            replay["replay_note"] = (f"{captured.kernel_nodes} kernels per replay; gradients within {worst / max(scale, 1e-30):.1e} "
+                                     "of the eager step's")
+    except (CaptureFailed, RuntimeError) as e:
+        replay["replay_note"] = f"not capturable ({type(e).__name__}: {str(e)[:160]})"
 
     stage_names = ["lut", "fmlp", "spmm"]
     stages = {n: 0.0 for n in stage_names}
@@ -374,8 +403,9 @@ def run_c3(args):
                           "frac": b_spmm / (stages["spmm"] / 1e3) / 1e9 / HBM_PEAK_GBPS if stages["spmm"] > 0 else 0.0},
         "stages_ms": stages, "seeds": {"graph": 0, "features": 1, "weights": 0, "target": 2}, "git_sha": git_sha(),
         "timed_call": "gnan_amd.models.TensorGNAN.forward(data) + loss.backward()", "setup_s": t_setup,
-        "checksum": float(out.double().sum()), "backward": True,
+        "checksum": float(out.detach().double().sum()), "backward": True,
     }
+    result.update(replay)
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_c3(args, model, g, x, fwd())
     print(json.dumps(result), flush=True)
