@@ -279,6 +279,19 @@ def _event_ms(fn, steps, warmup):
     return ts[len(ts) // 2], ts[0]
 
 
+def apply_sets(args):
+    """--set MODULE.NAME=VALUE: module-level constants of the package, before the run (A/B aid)."""
+    import ast
+    import importlib
+    for item in args.set:
+        target, value = item.split("=", 1)
+        mod_name, attr = target.rsplit(".", 1)
+        mod = importlib.import_module("gnan_amd." + mod_name)
+        if not hasattr(mod, attr):
+            raise SystemExit(f"--set: gnan_amd.{mod_name} has no {attr}")
+        setattr(mod, attr, ast.literal_eval(value))
+
+
 def run_c3(args):
     """BASELINE config 3: ogbn-arxiv-shaped TensorGNAN forward + backward on one GPU (SURVEY.md section 8d C3;
     /root/reference datasets.py:273-291: N = 169 343, E = 1 166 243, 128 features + the ones column, num_classes = 1 as the
@@ -288,6 +301,7 @@ def run_c3(args):
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
     from gnan_amd.models import TensorGNAN
+    apply_sets(args)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
@@ -699,15 +713,7 @@ def main():
     from gnan_amd.graph import hop_inputs
     if args.index_buckets:
         functional.INDEX_BUCKETS = args.index_buckets
-    for item in args.set:
-        import ast
-        import importlib
-        target, value = item.split("=", 1)
-        mod_name, attr = target.rsplit(".", 1)
-        mod = importlib.import_module("gnan_amd." + mod_name)
-        if not hasattr(mod, attr):
-            raise SystemExit(f"--set: gnan_amd.{mod_name} has no {attr}")
-        setattr(mod, attr, ast.literal_eval(value))
+    apply_sets(args)
     functional.FMLP_ALGO = {"auto": _lib.FMLP_AUTO, "lane": _lib.FMLP_LANE, "mfma": _lib.FMLP_MFMA,
                             "pwl": _lib.FMLP_PWL}[args.fmlp_algo]
     from gnan_amd.models import TensorGNAN
@@ -946,7 +952,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_source, "traffic_over_algorithmic": traffic / b_alg if traffic else None,
-                         "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"]},
+                         "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": stages["spmm"],
+                         # narrow operand rows (sum-first: W * 4 < 128 B): every stored pair is one sub-line gather; bytes are
+                         # the wrong yardstick there (the kernel is bound by gather requests: L2 hits, LDS-resident hub rows
+                         # and misses at ~55 G/s), so the gather rate is stated next to the byte fraction
+                         "gathers_per_launch": int(g.nnz) if W * (2 if args.operand == "bf16" else 4) < 128 else None,
+                         "gathers_G_per_s": (g.nnz / spmm_s / 1e9) if (W * (2 if args.operand == "bf16" else 4) < 128 and spmm_s > 0) else None},
             "stages_ms": stages,
             "step_ms_device": {"min": per_step[0], "median": per_step[len(per_step) // 2]} if per_step else None,
             "seeds": {"graph": 0, "features": 1, "weights": 0}, "git_sha": git_sha(),

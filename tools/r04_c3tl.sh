@@ -1,0 +1,25 @@
+#!/bin/bash
+# kernel timeline of one replayed forward + backward step of config 3 (bench.py --config c3)
+OUT=gpurun_out/r04c3; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+rocprofv3 --kernel-trace -f csv -d $OUT/t -o k -- python3 bench.py --config c3 --no-cpu-baseline --steps 5 --warmup 2 "$@" > $OUT/log.txt 2>&1
+python3 - <<'PY'
+import csv, glob
+for f in glob.glob('gpurun_out/r04c3/t/**/*kernel_trace.csv', recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    n = 36 if 'c3' else 36
+    import re
+    note = open('gpurun_out/r04c3/log.txt').read()
+    m = re.search(r'(\d+) kernels per replay', note)
+    n = int(m.group(1)) if m else 36
+    last = rows[-n:]
+    t0 = int(last[0]['Start_Timestamp'])
+    prev_end = t0
+    for r in last:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  {name[:90]}")
+        prev_end = e
+    print('total', (int(last[-1]['End_Timestamp']) - t0) / 1e3)
+PY
+rm -rf $OUT/t
