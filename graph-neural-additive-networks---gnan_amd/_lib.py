@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -249,6 +249,16 @@ class SmallBatchArgs(C.Structure):
     ]
 
 
+class SmallBatchBwdArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_stride", C.c_int64), ("total_nodes", C.c_int64), ("F", C.c_int32), ("n_graphs", C.c_int32),
+        ("max_nodes", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp), ("code", C.c_void_p), ("node_off", C.c_void_p),
+        ("code_off", C.c_void_p), ("D", C.c_int32), ("rho_raw_hops", C.c_int32), ("rest_zero", C.c_int32),
+        ("S", C.c_void_p), ("lut", C.c_void_p), ("dY", C.c_void_p), ("dYsum", C.c_void_p), ("df", SmallMlpGrads),
+        ("drho", SmallMlpGrads), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/gnan_hip.h declares: (name, restype, argtypes)
@@ -289,6 +299,8 @@ SYMBOLS = {
     "gnan_small_graph_nam_bwd": (C.c_int, [C.POINTER(SmallGraphNamBwdArgs), C.c_void_p]),
     "gnan_small_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
     "gnan_small_batch_fwd": (C.c_int, [C.POINTER(SmallBatchArgs), C.c_void_p]),
+    "gnan_small_batch_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SmallBatchBwdArgs)]),
+    "gnan_small_batch_bwd": (C.c_int, [C.POINTER(SmallBatchBwdArgs), C.c_void_p]),
     "gnan_hops_to_code": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnan_dense_blocks_to_code": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),

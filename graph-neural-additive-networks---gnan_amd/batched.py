@@ -195,9 +195,14 @@ def hop_graph_from_counts(dist: torch.Tensor) -> HopGraph:
     return HopGraph.from_csr(rowptr, cols.to(torch.int32), codes.to(torch.uint8), n_cols=n, n_codes=max_hop + 2)
 
 
+BATCH_BACKWARD_KERNEL = True             # the backward of a small batch in two launches (gnan_small_batch_bwd)
+BATCH_BACKWARD_MAX_WORKSPACE = 256 << 20   # ... while the graphs' gradient slabs stay below 256 MiB
+
+
 class _BatchedGraphs(torch.autograd.Function):
-    """``[G, C]`` per-graph read-outs (or ``[N, C]`` node outputs) of a batch by ONE launch; backward: the general kernels
-    on the blocks' CSR from the saved node sums and rho table."""
+    """``[G, C]`` per-graph read-outs (or ``[N, C]`` node outputs) of a batch by ONE launch; backward: two launches
+    (``gnan_small_batch_bwd``: every graph's share of the gradients, then their sum in graph order) for at most 64 hop codes,
+    else the general kernels on the blocks' CSR from the saved node sums and rho table."""
 
     @staticmethod
     def forward(ctx, x, blocks: HopBlocks, graph_sum, fm, rm, *params):
@@ -240,6 +245,32 @@ class _BatchedGraphs(torch.autograd.Function):
         Lr, Hr, Cr = ctx.rm
         need_f, need_r = any(ctx.needs_input_grad[5:11]), any(ctx.needs_input_grad[11:])
         blocks = ctx.blocks
+        if (BATCH_BACKWARD_KERNEL and Cr in (1, Cf) and blocks.n_codes <= 64 and d_out.dtype == torch.float32
+                and all(t is None or t.dtype == torch.float32 for t in params)):
+            # two launches: every graph's workgroups leave its share of the gradients in a slab, the slabs are added in order
+            keep = [None if t is None else Fn._c(t.detach()) for t in params]
+            outs_f, outs_r = Fn._grad_outputs(keep[:6], ctx.dests[:6]), Fn._grad_outputs(keep[6:], ctx.dests[6:])
+
+            def grads(o):
+                return _lib.SmallMlpGrads(w_first=_lib.ptr(o[0]), b_first=_lib.ptr(o[1]),
+                                          w_mid=None if o[2] is None else _lib.ptr(o[2][0]),
+                                          b_mid=None if o[3] is None else _lib.ptr(o[3][0]), w_last=_lib.ptr(o[4]), b_last=_lib.ptr(o[5]))
+            g_out = d_out.detach().contiguous()
+            a = _lib.SmallBatchBwdArgs(x=_lib.ptr(x), x_stride=x.stride(0), total_nodes=blocks.total_nodes, F=F,
+                                       n_graphs=blocks.n_graphs, max_nodes=blocks.max_nodes, f=_small_mlp(keep[:6], Lf, Hf, Cf),
+                                       rho=_small_mlp(keep[6:], Lr, Hr, Cr), code=_lib.ptr(blocks.code),
+                                       node_off=_lib.ptr(blocks.node_off), code_off=_lib.ptr(blocks.code_off), D=blocks.n_codes,
+                                       rho_raw_hops=1, rest_zero=1, S=_lib.ptr(S), lut=_lib.ptr(lut),
+                                       dY=None if ctx.graph_sum else _lib.ptr(g_out),
+                                       dYsum=_lib.ptr(g_out) if ctx.graph_sum else None, df=grads(outs_f), drho=grads(outs_r),
+                                       workspace=None, workspace_bytes=0)
+            need = _lib.lib().gnan_small_batch_bwd_workspace_bytes(a)
+            if need <= BATCH_BACKWARD_MAX_WORKSPACE:
+                ws = torch.empty(need // 4 + 1, dtype=torch.float32, device=x.device)
+                a.workspace, a.workspace_bytes = _lib.ptr(ws), ws.numel() * 4
+                _lib.check(_lib.lib().gnan_small_batch_bwd(a, _lib.stream_of(x)), "gnan_small_batch_bwd")
+                return (None, None, None, None, None, *[o if need_f else None for o in outs_f],
+                        *[o if need_r else None for o in outs_r])
         dY = d_out.index_select(0, blocks.batch_vector()) if ctx.graph_sum else d_out      # every node gets its graph's gradient
         from . import aggregate
         bag = aggregate._Bag()
@@ -327,3 +358,70 @@ class TensorGNAN(_PathBase):
         bv = batch_vector.to(Y.device).long()               # a batch that is not block-diagonal: the reference's own scatter
         out = torch.zeros(int(bv.max()) + 1, Y.shape[1], device=Y.device, dtype=Y.dtype)
         return out.index_add(0, bv, Y)
+
+
+class GraphedBatchStep:
+    """A captured step for batches of graphs (batched_pyg_main.py:205-226: forward, loss, backward, optimizer step), replayed
+    from ONE hipGraph launch per batch.
+
+    Every batch has another shape, so the step is captured over SLOTS: feature rows ``[node_capacity, F]``, packed hop codes,
+    the two offset arrays and the labels.  The kernels of a small batch read every graph's size from the offset arrays on the
+    device (``gnan_small_batch_fwd`` / ``_bwd``: blockIdx.y = graph), so one capture serves any batch of ``n_graphs`` graphs
+    that fits the slots; ``n_codes`` is captured at a capacity too (hop codes beyond a batch's own largest hop are the rest
+    code's business: weight 0, no gradient).  :meth:`run` copies a batch into the slots (one launch) and replays; it returns
+    None for a batch that does not fit (another number of graphs, more nodes, a longer hop): the caller steps eagerly.
+
+    ``loss_of(outputs, labels) -> loss``; ``optimizer=None`` captures the evaluation pass.  Construction runs the FIRST
+    batch's step eagerly (a real step: the parameters are updated) and captures after it.
+    """
+
+    def __init__(self, model: "TensorGNAN", optimizer, loss_of, x, blocks: HopBlocks, labels, node_capacity: Optional[int] = None,
+                 n_codes: Optional[int] = None):
+        from .graphed import GraphedStep
+        _lib.require_device(x, labels)
+        dev = x.device
+        self.n_graphs, self.F = blocks.n_graphs, int(x.shape[1])
+        self.node_capacity = int(node_capacity or BATCH_KERNEL_MAX_TOTAL_NODES)
+        self.n_codes = int(n_codes or min(64, max(16, blocks.n_codes + 8)))
+        self.code_capacity = self.n_graphs * BATCH_KERNEL_MAX_NODES * BATCH_KERNEL_MAX_NODES
+        if not self.fits(x, blocks, labels):
+            raise ValueError("the first batch does not fit the slots it defines")
+        self.x = torch.zeros((self.node_capacity, self.F), dtype=torch.float32, device=dev)
+        self.code = torch.full((self.code_capacity,), 255, dtype=torch.uint8, device=dev)
+        self.node_off = torch.zeros(self.n_graphs + 1, dtype=torch.int32, device=dev)
+        self.code_off = torch.zeros(self.n_graphs + 1, dtype=torch.int64, device=dev)
+        self.labels = torch.empty_like(labels)
+        self.blocks = HopBlocks(self.code, self.node_off, self.code_off, [0] * self.n_graphs, self.n_codes - 2)
+        self.blocks.total_nodes, self.blocks.max_nodes = self.node_capacity, BATCH_KERNEL_MAX_NODES
+        self._labels_shape = tuple(labels.shape)
+        self.load(x, blocks, labels)
+        self.step = GraphedStep(model, None, lambda out: (loss_of(out, self.labels), None), optimizer,
+                                forward=lambda: model(self.x, self.blocks, None), warmup=1)
+
+    def fits(self, x, blocks: HopBlocks, labels) -> bool:
+        return bool(blocks.n_graphs == self.n_graphs and x.shape[1] == self.F and blocks.total_nodes <= self.node_capacity
+                    and blocks.n_codes <= self.n_codes and blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
+                    and int(blocks.code.numel()) <= self.code_capacity and x.dtype == torch.float32 and x.is_cuda
+                    and (not hasattr(self, "_labels_shape") or tuple(labels.shape) == self._labels_shape))
+
+    def load(self, x, blocks: HopBlocks, labels) -> None:
+        n, m = int(x.shape[0]), int(blocks.code.numel())
+        pairs = [(self.x[:n], x), (self.code[:m], blocks.code), (self.node_off, blocks.node_off), (self.code_off, blocks.code_off),
+                 (self.labels, labels)]
+        if all(s.is_contiguous() and d.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape and s.is_cuda for d, s in pairs):
+            _lib.multi_copy(pairs)                    # one launch
+            return
+        for d, s in pairs:
+            d.copy_(s)
+
+    def run(self, x, blocks: HopBlocks, labels):
+        """``(outputs [G, C], loss, None)`` of the replayed step on this batch (static tensors, overwritten by the next replay),
+        or None if the batch does not fit the slots or the capture has gone stale."""
+        if not self.fits(x, blocks, labels) or self.step.graph is None or self.step.stale():
+            return None
+        self.load(x, blocks, labels)
+        return self.step.replay()
+
+    @property
+    def kernel_nodes(self) -> int:
+        return int(self.step.graph.kernel_nodes)

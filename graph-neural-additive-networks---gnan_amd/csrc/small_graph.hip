@@ -308,6 +308,21 @@ struct SmallBwdParams {
   int rho_groups, rows_per;
   float* part;
   unsigned* counter;
+  int rho_raw;               // batched variant: rho's inputs are the raw hop counts (batched_pyg_main.py:151)
+  int rest_zero;             // ... and pairs beyond the last listed hop carry weight 0: no gradient through lut[D - 1]
+  int rho_c;                 // rho's channels: 1, or f.C (one per output channel: the batched variant's rho, batched_pyg_main.py:
+                             // 125-131; lut is [D, C] then; no shell normalisation, not with pre_rho)
+};
+
+// Many small graphs in one launch (the backward of small_graph_batch_kernel): blockIdx.y = graph.  Graph g's workgroups leave the
+// gradients of f and rho that ITS nodes contribute in slab g of `grads` (the twelve tensors back to back, f's then rho's);
+// batch_grad_reduce_kernel adds the slabs in graph order.
+struct BatchBwdParams {
+  SmallBwdParams base;           // pointers of graph 0; n unused; gradient pointers = slab 0
+  const int32_t* node_off;
+  const int64_t* code_off;
+  int64_t slab;                  // floats per graph
+  int dy_per_graph;              // dYsum is [G, C] (graph read-out) rather than dY [N, C]
 };
 
 constexpr int kBinStride = kWave + 1;
@@ -315,11 +330,10 @@ constexpr int kRhoSlot = kMaxH * kMaxH + 5 * kMaxH, kRhoGroupsMax = 12;       //
 
 // NB as in small_graph_kernel (2: n <= 128 — hop codes and the row-weight / bin area take 50 KB: dynamic LDS).
 template <int C, int NB>
-__global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdParams p) {
+__device__ __forceinline__ void small_graph_bwd_body(const SmallBwdParams& p, float* dyn) {
   constexpr int kNodes = 64 * NB;
   constexpr int kUFloats = kNodes * kWave > 2 * kWave * kBinStride ? kNodes * kWave : 2 * kWave * kBinStride;
-  __shared__ gnan_bwd::RedBuffer red;
-  extern __shared__ __attribute__((aligned(16))) float dyn[];                   // s_u | s_code
+  __shared__ gnan_bwd::RedBuffer red;                                           // dyn: s_u | s_code
   float* s_u = dyn;                                   // row weights [n][64] (features) | bins [waves][D][n | 1] (rho)
   uint8_t* s_code = reinterpret_cast<uint8_t*>(dyn + kUFloats);                 // [n][n]
   float* s_dl = dyn + kUFloats + kNodes * kNodes / 4;                           // pre-rho only: table gradient [n][D]
@@ -373,7 +387,10 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     __syncthreads();                                       // (s_g doubles as dS / dlut below: nobody reads it yet)
     if (wave == 0 && lane < p.D) s_g[lane] = l;            // the rho table, for a moment
     __syncthreads();
-    if (!is_rho) {
+    if (p.rho_c > 1) {                                     // (uniform) one table column per channel: [D][C] in place of the rows' weights
+      if (!is_rho)
+        for (int e = threadIdx.x; e < p.D * C; e += 256) s_u[e] = p.lut[e];
+    } else if (!is_rho) {
 #pragma unroll
       for (int t = 0; t < kCntPer; ++t) {
         const int e = threadIdx.x + t * 256;
@@ -392,11 +409,20 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     for (int e = threadIdx.x; e < n * C; e += 256) {
       const int j = e / C, c = e % C;
       float acc = 0.f;
+      if (p.rho_c > 1) {
 #pragma unroll 8
-      for (int i = 0; i < n; ++i) {
-        int d = s_code[i * n + j];
-        d = d < p.D - 1 ? d : p.D - 1;
-        acc = fmaf(s_u[i * kWave + d], s_dY[i * C + c], acc);
+        for (int i = 0; i < n; ++i) {
+          int d = s_code[i * n + j];
+          d = d < p.D - 1 ? d : p.D - 1;
+          acc = fmaf(s_u[d * C + c], s_dY[i * C + c], acc);
+        }
+      } else {
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) {
+          int d = s_code[i * n + j];
+          d = d < p.D - 1 ? d : p.D - 1;
+          acc = fmaf(s_u[i * kWave + d], s_dY[i * C + c], acc);
+        }
       }
       s_g[e] = acc;
     }
@@ -405,6 +431,64 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
     auto g_of = [&](int64_t node, int c) { return s_g[node * C + c]; };
     if (p.f_mid) gnan_bwd::feature_grads<C, true>(p.f, k, 0, n, 0, nodrop, x_of, g_of, red);
     else gnan_bwd::feature_grads<C, false>(p.f, k, 0, n, 0, nodrop, x_of, g_of, red);
+    return;
+  }
+  if (p.rho_c > 1) {
+    // ---- a rho of one channel per output channel (the batched variant): dlut[d, c] = sum over the pairs (i, j) of hop code d of
+    // dY[i, c] S[j, c].  A thread per (d, c, slice of the rows) walks the pairs in order — the code is one LDS broadcast per
+    // pair — and the slices are added in order: n^2 D C / 256 steps (900 pairs x 80 entries: 2 us; the binning of the one-channel
+    // path would need C passes of its two barriers per row).
+    const int DC = p.D * C;
+    const int slices = DC >= 256 ? 1 : 256 / DC;           // row slices per (d, c)
+    float* part = s_u;                                     // [slices][DC]
+    for (int e0 = 0; e0 < DC; e0 += 256) {
+      const int e = e0 + static_cast<int>(threadIdx.x) % (DC < 256 ? DC : 256);
+      const int sl = DC >= 256 ? 0 : static_cast<int>(threadIdx.x) / DC;
+      if (e < DC && sl < slices) {
+        const int d = e / C, c = e % C;
+        const int rows = (n + slices - 1) / slices;
+        const int r_lo = sl * rows, r_hi = r_lo + rows < n ? r_lo + rows : n;
+        float acc = 0.f;
+        for (int i = r_lo; i < r_hi; ++i) {
+          const float gy = s_dY[i * C + c];
+          const uint8_t* codes = s_code + i * n;
+          // (eight pairs' code and node sum requested together: one pair at a time the loop waits for two LDS round trips per
+          //  pair — 0.33 ms for a batch whose largest graph has 100 nodes)
+          int j = 0;
+          for (; j + 8 <= n; j += 8) {
+            int dd[8];
+            float sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { dd[u] = codes[j + u]; sv[u] = s_S[(j + u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int du = dd[u] < p.D - 1 ? dd[u] : p.D - 1;
+              acc += du == d ? gy * sv[u] : 0.f;
+            }
+          }
+          for (; j < n; ++j) {
+            int du = codes[j];
+            du = du < p.D - 1 ? du : p.D - 1;
+            acc += du == d ? gy * s_S[j * C + c] : 0.f;
+          }
+        }
+        part[sl * DC + e] = acc;
+      }
+      __syncthreads();
+      if (static_cast<int>(threadIdx.x) < (DC - e0 < 256 ? DC - e0 : 256) && (DC >= 256 || static_cast<int>(threadIdx.x) < DC)) {
+        const int ee = e0 + threadIdx.x;
+        float sum = 0.f;
+        for (int q2 = 0; q2 < slices; ++q2) sum += part[q2 * DC + ee];
+        s_g[ee] = (p.rest_zero && ee / C == p.D - 1) ? 0.f : sum;
+      }
+      __syncthreads();
+    }
+    auto uc_of = [&](int64_t node) {
+      return node < p.D - 1 ? (p.rho_raw ? static_cast<float>(node) : 1.0f / (static_cast<float>(node) + 1.0f)) : 0.f;
+    };
+    auto gc_of = [&](int64_t node, int c) { return s_g[node * C + c]; };
+    if (p.r_mid) gnan_bwd::feature_grads<C, true>(p.r, 0, 0, p.D, 0, nodrop, uc_of, gc_of, red);
+    else gnan_bwd::feature_grads<C, false>(p.r, 0, 0, p.D, 0, nodrop, uc_of, gc_of, red);
     return;
   }
   // ---- table gradient, then rho's parameter gradients ---------------------------------------------------------------------------
@@ -516,12 +600,71 @@ __global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdPara
   }
   s_part[wave][lane] = wave < nw ? acc : 0.0;
   __syncthreads();
-  if (wave == 0 && lane < p.D) s_g[lane] = static_cast<float>(((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]);
+  if (wave == 0 && lane < p.D)
+    s_g[lane] = (p.rest_zero && lane == p.D - 1) ? 0.f
+                : static_cast<float>(((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]);
   __syncthreads();
-  auto u_of = [&](int64_t node) { return node < p.D - 1 ? 1.0f / (static_cast<float>(node) + 1.0f) : 0.f; };
+  auto u_of = [&](int64_t node) {
+    return node < p.D - 1 ? (p.rho_raw ? static_cast<float>(node) : 1.0f / (static_cast<float>(node) + 1.0f)) : 0.f;
+  };
   auto gl_of = [&](int64_t node, int) { return s_g[node]; };
   if (p.r_mid) gnan_bwd::feature_grads<1, true>(p.r, 0, 0, p.D, 0, nodrop, u_of, gl_of, red);
   else gnan_bwd::feature_grads<1, false>(p.r, 0, 0, p.D, 0, nodrop, u_of, gl_of, red);
+}
+
+template <int C, int NB>
+__global__ __launch_bounds__(256) void small_graph_bwd_kernel(const SmallBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  small_graph_bwd_body<C, NB>(p, dyn);
+}
+
+template <int C, int NB>
+__global__ __launch_bounds__(256) void small_graph_batch_bwd_kernel(const BatchBwdParams bp) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  const int g = blockIdx.y;
+  SmallBwdParams p = bp.base;
+  const int64_t o = bp.node_off[g];
+  p.n = static_cast<int>(bp.node_off[g + 1] - o);
+  p.x += o * p.x_stride;
+  p.code += bp.code_off[g];
+  p.S += o * C;
+  p.lut += static_cast<int64_t>(g) * p.D * p.rho_c;
+  if (bp.dy_per_graph) p.dYsum += static_cast<int64_t>(g) * C;
+  else p.dY += o * C;
+  // graph g's slab of gradients: the same tensor layout, bp.slab floats further on
+  const int64_t by = static_cast<int64_t>(g) * bp.slab;
+  gnan_bwd::Weights* ws[2] = {&p.f, &p.r};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    gnan_bwd::Weights& w = *ws[t];
+    w.d_w_first += by; w.d_w_last += by;
+    if (w.d_b_first) w.d_b_first += by;
+    if (w.d_w_mid) w.d_w_mid += by;
+    if (w.d_b_mid) w.d_b_mid += by;
+    if (w.d_b_last) w.d_b_last += by;
+  }
+  small_graph_bwd_body<C, NB>(p, dyn);
+}
+
+// out[e] = sum_g slabs[g][e], graphs in order, eight graphs' terms requested together; the slab is the twelve gradient tensors
+// back to back and `dst` lists where each lives (offsets ascending, a NULL destination = a tensor that does not exist)
+struct ReduceSeg { int64_t at[13]; float* dst[12]; };
+__global__ __launch_bounds__(256) void batch_grad_reduce_kernel(const float* __restrict__ slabs, int64_t slab, int n_graphs,
+                                                              const ReduceSeg seg) {
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < slab; e += static_cast<int64_t>(gridDim.x) * 256) {
+    float sum = 0.f;
+    for (int g0 = 0; g0 < n_graphs; g0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = g0 + u < n_graphs ? slabs[static_cast<int64_t>(g0 + u) * slab + e] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    int t = 0;
+#pragma unroll
+    for (int u = 1; u < 12; ++u) t += e >= seg.at[u] ? 1 : 0;
+    if (seg.dst[t]) seg.dst[t][e - seg.at[t]] = sum;
+  }
 }
 
 template <int NB>
@@ -616,7 +759,7 @@ extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_str
   p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
   p.S = a->S; p.lut = a->lut; p.dY = a->dY; p.dYsum = a->dYsum; p.pre_rho = a->pre_rho != 0;
   GNAN_REQUIRE(!p.pre_rho || a->cnt != nullptr, "small_graph_bwd: pre-rho normalisation needs the shell sizes");
-  p.rho_groups = 1; p.rows_per = a->n; p.part = nullptr; p.counter = nullptr;
+  p.rho_groups = 1; p.rows_per = a->n; p.part = nullptr; p.counter = nullptr; p.rho_raw = 0; p.rest_zero = 0; p.rho_c = 1;
   if (p.pre_rho) {
     // rho's n * D arguments by rows over up to 12 workgroups — about as many arguments each as a feature workgroup has nodes —
     // when the caller lent the room for their partial gradients
@@ -686,6 +829,116 @@ extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_
     hipLaunchKernelGGL(small_graph_batch_kernel<2>, grid, dim3(kWaves * kWave), lds, st, bp);
   }
   return gnan::check_launch("small_graph_batch_kernel");
+}
+
+namespace {
+// the twelve gradient tensors of (f, rho) back to back: offsets (floats) of each inside a slab, 0-sized where a tensor is absent
+int64_t slab_layout(const gnan_small_mlp* f, int F, const gnan_small_mlp* r, int64_t at[13]) {
+  int64_t o = 0;
+  const gnan_small_mlp* m[2] = {f, r};
+  const int Fs[2] = {F, 1};
+  for (int t = 0; t < 2; ++t) {
+    const int64_t H = m[t]->H, C = m[t]->C, Fk = Fs[t];            // (rho: C = its own channel count)
+    const bool mid = m[t]->L == 3;
+    const int64_t size[6] = {Fk * H, m[t]->b_first ? Fk * H : 0, mid ? Fk * H * H : 0, (mid && m[t]->b_mid) ? Fk * H : 0,
+                             Fk * C * H, m[t]->b_last ? Fk * C : 0};
+    for (int u = 0; u < 6; ++u) { at[6 * t + u] = o; o += size[u]; }
+  }
+  at[12] = o;
+  return o;
+}
+
+template <int C>
+int launch_small_batch_bwd(const BatchBwdParams& bp, int n_graphs, int max_nodes, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>(bp.base.F) + 1, static_cast<unsigned>(n_graphs));
+  if (max_nodes <= 64) {
+    hipLaunchKernelGGL((small_graph_batch_bwd_kernel<C, 1>), grid, dim3(256), small_bwd_dyn_bytes<1>(false), st, bp);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_batch_bwd_kernel<C, 2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       static_cast<int>(small_bwd_dyn_bytes<2>(false)));
+    if (attr != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_batch_bwd: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL((small_graph_batch_bwd_kernel<C, 2>), grid, dim3(256), small_bwd_dyn_bytes<2>(false), st, bp);
+  }
+  return gnan::check_launch("small_graph_batch_bwd_kernel");
+}
+}  // namespace
+
+extern "C" size_t gnan_small_batch_bwd_workspace_bytes(const gnan_small_batch_bwd_args* a) {
+  if (a == nullptr) return 0;
+  int64_t at[13];
+  return static_cast<size_t>(a->n_graphs) * static_cast<size_t>(slab_layout(&a->f, a->F, &a->rho, at)) * sizeof(float);
+}
+
+extern "C" int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr, "small_batch_bwd: null args");
+  GNAN_REQUIRE(a->n_graphs >= 0 && a->F >= 1 && a->D >= 1 && a->total_nodes >= 0, "small_batch_bwd: bad sizes");
+  GNAN_REQUIRE(grads_ok(&a->f, &a->df) && grads_ok(&a->rho, &a->drho),
+               "small_batch_bwd: a gradient pointer for every weight, and for a bias exactly where there is one");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t at[13];
+  const int64_t slab = slab_layout(&a->f, a->F, &a->rho, at);
+  float* const dst[12] = {a->df.w_first, a->df.b_first, a->f.L == 3 ? a->df.w_mid : nullptr, a->f.L == 3 ? a->df.b_mid : nullptr,
+                          a->df.w_last, a->df.b_last, a->drho.w_first, a->drho.b_first, a->rho.L == 3 ? a->drho.w_mid : nullptr,
+                          a->rho.L == 3 ? a->drho.b_mid : nullptr, a->drho.w_last, a->drho.b_last};
+  if (a->n_graphs == 0) {                              // nothing contributes: the gradients are zero
+    for (int t = 0; t < 12; ++t)
+      if (dst[t] && at[t + 1] > at[t]) {
+        hipError_t e = hipMemsetAsync(dst[t], 0, static_cast<size_t>(at[t + 1] - at[t]) * sizeof(float), st);
+        if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "small_batch_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+      }
+    return GNAN_OK;
+  }
+  if (a->max_nodes < 1 || a->max_nodes > kMaxNodes || a->D > kWave || !mlp_ok(&a->f, kMaxC) || !mlp_ok(&a->rho, kMaxC) ||
+      (a->rho.C != 1 && a->rho.C != a->f.C))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_batch_bwd: covers graphs of <= %d nodes, D <= %d shells, L in {2, 3}, H <= %d, C <= %d "
+                      "and a rho of one channel or one per output channel (got max n=%d D=%d L=%d/%d H=%d/%d C=%d/%d)", kMaxNodes,
+                      kWave, kMaxH, kMaxC, a->max_nodes, a->D, a->f.L, a->rho.L, a->f.H, a->rho.H, a->f.C, a->rho.C);
+  GNAN_REQUIRE(a->x && a->code && a->node_off && a->code_off && a->S && a->lut && (a->dY || a->dYsum),
+               "small_batch_bwd: null x / code / offsets / S / lut / output gradient");
+  GNAN_REQUIRE(a->x_stride >= a->F, "small_batch_bwd: row stride smaller than the width");
+  GNAN_REQUIRE(a->n_graphs <= 65535, "small_batch_bwd: at most 65535 graphs per launch");
+  const size_t need = static_cast<size_t>(a->n_graphs) * static_cast<size_t>(slab) * sizeof(float);
+  if (a->workspace == nullptr || a->workspace_bytes < need)
+    return gnan::fail(GNAN_ERR_WORKSPACE, "small_batch_bwd: workspace %zu B < required %zu B", a->workspace_bytes, need);
+  float* slabs = static_cast<float*>(a->workspace);
+  // graph 0's slab as the kernels' gradient tensors (the kernel shifts them by g * slab)
+  gnan_small_mlp_grads gf = {slabs + at[0], a->f.b_first ? slabs + at[1] : nullptr, slabs + at[2],
+                             (a->f.L == 3 && a->f.b_mid) ? slabs + at[3] : nullptr, slabs + at[4], a->f.b_last ? slabs + at[5] : nullptr};
+  gnan_small_mlp_grads gr = {slabs + at[6], a->rho.b_first ? slabs + at[7] : nullptr, slabs + at[8],
+                             (a->rho.L == 3 && a->rho.b_mid) ? slabs + at[9] : nullptr, slabs + at[10],
+                             a->rho.b_last ? slabs + at[11] : nullptr};
+  BatchBwdParams bp;
+  SmallBwdParams& p = bp.base;
+  p.x = a->x; p.x_stride = a->x_stride; p.n = 0; p.F = a->F;
+  p.f = to_weights(&a->f, &gf); p.r = to_weights(&a->rho, &gr);
+  if (a->f.L != 3) { p.f.d_w_mid = nullptr; p.f.d_b_mid = nullptr; }
+  if (a->rho.L != 3) { p.r.d_w_mid = nullptr; p.r.d_b_mid = nullptr; }
+  p.f_mid = a->f.L == 3; p.r_mid = a->rho.L == 3;
+  p.code = a->code; p.D = a->D; p.cnt = nullptr; p.cnt_stride = 0;
+  p.S = a->S; p.lut = a->lut; p.dY = a->dYsum ? nullptr : a->dY; p.dYsum = a->dYsum; p.pre_rho = 0;
+  p.rho_groups = 1; p.rows_per = 0; p.part = nullptr; p.counter = nullptr;
+  p.rho_raw = a->rho_raw_hops != 0; p.rest_zero = a->rest_zero != 0; p.rho_c = a->rho.C;
+  bp.node_off = a->node_off; bp.code_off = a->code_off; bp.slab = slab; bp.dy_per_graph = a->dYsum != nullptr;
+  int rc;
+  switch (a->f.C) {
+    case 1: rc = launch_small_batch_bwd<1>(bp, a->n_graphs, a->max_nodes, st); break;
+    case 2: rc = launch_small_batch_bwd<2>(bp, a->n_graphs, a->max_nodes, st); break;
+    case 3: rc = launch_small_batch_bwd<3>(bp, a->n_graphs, a->max_nodes, st); break;
+    case 4: rc = launch_small_batch_bwd<4>(bp, a->n_graphs, a->max_nodes, st); break;
+    case 5: rc = launch_small_batch_bwd<5>(bp, a->n_graphs, a->max_nodes, st); break;
+    case 6: rc = launch_small_batch_bwd<6>(bp, a->n_graphs, a->max_nodes, st); break;
+    case 7: rc = launch_small_batch_bwd<7>(bp, a->n_graphs, a->max_nodes, st); break;
+    default: rc = launch_small_batch_bwd<8>(bp, a->n_graphs, a->max_nodes, st); break;
+  }
+  if (rc != GNAN_OK) return rc;
+  ReduceSeg seg;
+  for (int t = 0; t < 13; ++t) seg.at[t] = at[t];
+  for (int t = 0; t < 12; ++t) seg.dst[t] = (at[t + 1] > at[t]) ? dst[t] : nullptr;
+  int64_t blocks = (slab + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(batch_grad_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, slabs, slab, a->n_graphs, seg);
+  return gnan::check_launch("batch_grad_reduce_kernel");
 }
 
 // Per-graph hop matrices (batched_pyg_main.py:19-48: float hop counts, -1 = unreachable) -> the packed uint8 codes the

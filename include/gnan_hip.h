@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 40
+#define GNAN_ABI_VERSION 41
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -666,6 +666,39 @@ typedef struct gnan_small_graph_bwd_args {
 } gnan_small_graph_bwd_args;
 size_t gnan_small_graph_bwd_workspace_bytes(int32_t n, int32_t D);
 int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_stream_t stream);
+
+/* The backward pass of gnan_small_batch_fwd: launch 1 — blockIdx.y = graph, the workgroups of gnan_small_graph_bwd per graph — leaves
+ * every graph's contribution to the gradients of f and rho in its slab of the workspace; launch 2 adds the slabs in graph
+ * order into df / drho.  dY [total_nodes, f.C], or dYsum [n_graphs, f.C] (the gradient of the per-graph read-out).  Covers
+ * graphs of <= 128 nodes, D <= 64, a rho of one channel or one per output channel (lut [n_graphs, D, rho.C]), L in {2, 3},
+ * H <= 64, C <= 8; GNAN_ERR_UNSUPPORTED otherwise (the
+ * general kernels on the blocks' CSR then).  workspace: gnan_small_batch_bwd_workspace_bytes(args) bytes, no initialisation. */
+typedef struct gnan_small_batch_bwd_args {
+  const float* x;
+  int64_t x_stride;
+  int64_t total_nodes;
+  int32_t F;
+  int32_t n_graphs;
+  int32_t max_nodes;
+  gnan_small_mlp f;
+  gnan_small_mlp rho;
+  const uint8_t* code;
+  const int32_t* node_off;
+  const int64_t* code_off;
+  int32_t D;
+  int32_t rho_raw_hops;
+  int32_t rest_zero;
+  const float* S;            /* [total_nodes, f.C] node sums of the forward */
+  const float* lut;          /* [n_graphs, D, rho.C] rho tables of the forward */
+  const float* dY;           /* [total_nodes, f.C] or NULL */
+  const float* dYsum;        /* [n_graphs, f.C] or NULL (used when not NULL) */
+  gnan_small_mlp_grads df;
+  gnan_small_mlp_grads drho;
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_small_batch_bwd_args;
+size_t gnan_small_batch_bwd_workspace_bytes(const gnan_small_batch_bwd_args* a);
+int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_stream_t stream);
 
 /* The same small graph-level task with a NAM read-out over the per-feature aggregates (models.py:358-384 with is_graph_task
  * and readout_n_layers > 0; models.py:259-300 for the read-out):

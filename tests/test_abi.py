@@ -79,7 +79,8 @@ def test_struct_layout_matches_header():
                         ("gnan_small_mlp_grads", _lib.SmallMlpGrads), ("gnan_small_graph_bwd_args", _lib.SmallGraphBwdArgs),
                         ("gnan_small_batch_args", _lib.SmallBatchArgs), ("gnan_fpwl_index_args", _lib.FpwlIndexArgs),
                         ("gnan_small_graph_nam_args", _lib.SmallGraphNamArgs),
-                        ("gnan_small_graph_nam_bwd_args", _lib.SmallGraphNamBwdArgs)):
+                        ("gnan_small_graph_nam_bwd_args", _lib.SmallGraphNamBwdArgs),
+                        ("gnan_small_batch_bwd_args", _lib.SmallBatchBwdArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

@@ -481,6 +481,124 @@ def test_reference_order_training_uses_the_sum_first_backward(gpu, C, rho_per_fe
         assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * scale, k
 
 
+@pytest.mark.parametrize("graph_task", [True, False])
+@pytest.mark.parametrize("bias", [True, False])
+def test_batched_backward_in_two_launches(gpu, monkeypatch, graph_task, bias):
+    """The backward of a small batch (one output channel, as the binary graph tasks have): gnan_small_batch_bwd — every graph's
+    share of the gradients of f and rho in one launch (blockIdx.y = graph), their sum in graph order in a second — == float64
+    autograd through the oracle of batched_pyg_main.py:133-184 == the general kernels on the blocks' CSR; bit-reproducible;
+    graphs of 1 to 128 nodes, per-graph read-out and node outputs."""
+    from gnan_amd import batched
+    rng = np.random.default_rng(7)
+    F, C, H = 5, 1, 16
+    sizes = [3, 64, 17, 100, 1, 30, 128, 45, 9, 65] + [int(v) for v in rng.integers(4, 60, 22)]
+    batch = []
+    for n in sizes:
+        hops = rng.integers(-1, 9, (n, n)).astype(np.float32)
+        hops[np.arange(n), np.arange(n)] = 0
+        batch.append((torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(gpu.DEV),
+                      torch.from_numpy(hops).to(gpu.DEV), torch.tensor([int(rng.integers(0, 2))], device=gpu.DEV)))
+    x, blocks, y, bv = batched.collate(batch)
+    N = sum(sizes)
+    dense = torch.full((N, N), -1.0, device=gpu.DEV)
+    o = 0
+    for _, d, _ in batch:
+        dense[o:o + d.shape[0], o:o + d.shape[0]] = d
+        o += d.shape[0]
+    torch.manual_seed(0)
+    mod = batched.TensorGNAN(F, C, 2, hidden_channels=H, device="cuda", bias=bias, is_graph_task=graph_task).to(gpu.DEV).eval()
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    up = torch.randn(len(sizes) if graph_task else N, C, generator=torch.Generator().manual_seed(1)).to(gpu.DEV)
+    monkeypatch.setattr(batched, "BATCH_KERNEL_MAX_TOTAL_NODES", 1 << 30)
+    calls = []
+    real = batched._lib.lib().gnan_small_batch_bwd
+    grads = {}
+    for tag, fused in (("two_launches", True), ("again", True), ("general", False)):
+        monkeypatch.setattr(batched, "BATCH_BACKWARD_KERNEL", fused)
+        mod.zero_grad(set_to_none=True)
+        out = mod(x, blocks, bv)
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            (out * up).sum().backward()
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages()]
+        assert any("small_graph_batch_bwd_kernel" in k for k in names) == fused, names
+        grads[tag] = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    p64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mod.state_dict().items()}
+    truth = O.batched_tensor_gnan_forward(x.cpu().double(), dense.cpu().double(), bv.cpu(), p64, graph_task)
+    (truth * up.cpu().double()).sum().backward()
+    gscale = max(float(v.grad.abs().max()) for v in p64.values())
+    for k, v in p64.items():
+        for tag in ("two_launches", "general"):
+            assert float((grads[tag][k].cpu().double() - v.grad).abs().max()) <= 2e-5 * gscale, (k, tag)
+        assert torch.equal(grads["two_launches"][k], grads["again"][k]), k
+
+
+def test_batched_training_step_replayed_over_slots(gpu):
+    """batched.GraphedBatchStep: the training step of batched_pyg_main.py:205-226 (forward, cross-entropy, backward, Adam)
+    captured ONCE over slots and replayed for batches of other shapes == the same steps issued eagerly on a twin model: losses
+    and parameters after eight batches; a batch that does not fit the slots is refused; the evaluation pass replays too."""
+    import copy
+    from gnan_amd import batched
+    rng = np.random.default_rng(11)
+    F, C, H, G = 6, 8, 16, 12
+    data = []
+    for _ in range(G * 9):
+        n = int(rng.integers(3, 70))
+        hops = rng.integers(-1, 8, (n, n)).astype(np.float32)
+        hops[np.arange(n), np.arange(n)] = 0
+        data.append((torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(gpu.DEV),
+                     torch.from_numpy(hops).to(gpu.DEV), torch.tensor([int(rng.integers(0, C))], device=gpu.DEV)))
+    batches = [batched.collate(data[i:i + G]) for i in range(0, len(data), G)]
+    torch.manual_seed(0)
+    a = batched.TensorGNAN(F, C, 2, hidden_channels=H, device="cuda").to(gpu.DEV)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    b = copy.deepcopy(a)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    opt_a, opt_b = torch.optim.Adam(a.parameters(), lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    eager = []
+    for x, blocks, y, bv in batches[:8]:
+        opt_a.zero_grad(set_to_none=True)
+        loss = loss_fn(a(x, blocks, bv), y)
+        loss.backward()
+        opt_a.step()
+        eager.append(float(loss))
+    x0, b0, y0, _ = batches[0]
+    gs = batched.GraphedBatchStep(b, opt_b, lambda out, lab: loss_fn(out, lab), x0, b0, y0)   # (runs the first batch's step)
+    replayed = []
+    for x, blocks, y, bv in batches[1:8]:
+        got = gs.run(x, blocks, y)
+        assert got is not None
+        replayed.append(float(got[1]))
+    assert gs.kernel_nodes <= 12, gs.kernel_nodes
+    for e, r in zip(eager[1:], replayed):
+        assert abs(e - r) <= 1e-4 * max(abs(e), 1.0), (eager, replayed)
+    scale = max(float(p.abs().max()) for p in a.parameters())
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) <= 1e-4 * scale
+    # a batch of another number of graphs, or with more nodes than the slots hold, is refused (the caller steps eagerly)
+    fewer = batched.collate(data[:G - 1])
+    assert gs.run(fewer[0], fewer[1], fewer[2]) is None
+    small = batched.GraphedBatchStep(b, None, lambda out, lab: loss_fn(out, lab), x0, b0, y0, node_capacity=int(x0.shape[0]))
+    big = max(batches, key=lambda t: t[0].shape[0])
+    if big[0].shape[0] > x0.shape[0]:
+        assert small.run(big[0], big[1], big[2]) is None
+    # evaluation pass replayed over the same kind of slots == the eager forward
+    ev = batched.GraphedBatchStep(b, None, lambda out, lab: loss_fn(out, lab), x0, b0, y0)
+    b.eval()
+    ev2 = batched.GraphedBatchStep(b, None, lambda out, lab: loss_fn(out, lab), x0, b0, y0)
+    x, blocks, y, bv = batches[8]
+    out, loss, _ = ev2.run(x, blocks, y)
+    with torch.no_grad():
+        want = b(x, blocks, bv)
+    assert float((out - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert abs(float(loss) - float(loss_fn(want, y))) <= 1e-6 * max(1.0, abs(float(loss)))
+    del ev
+
+
 def test_batched_graphs_in_one_launch(gpu, monkeypatch):
     """f-2 as a path: per-graph hop matrices -> packed code blocks on the device (no (sum N)^2 matrix), all graphs of a batch
     forwarded by ONE launch with the per-graph read-out in its epilogue; == the hop-coded CSR through the general kernels ==
