@@ -138,6 +138,8 @@ class HopBlocks:
         return blocks
 
     def batch_vector(self) -> torch.Tensor:
+        if getattr(self, "slots", False):
+            raise _lib.GnanHipError("these blocks are the slots of a captured step: their sizes live on the device only")
         if self._batch_vector is None:
             self._batch_vector = torch.repeat_interleave(torch.arange(self.n_graphs, device=self.code.device),
                                                          torch.tensor(self.sizes, device=self.code.device))
@@ -146,6 +148,8 @@ class HopBlocks:
     def csr(self) -> HopGraph:
         """The hop-coded CSR of the listed pairs (global node ids) — what the general kernels walk: index work on the
         ``sum n_g^2`` packed codes, never on ``(sum n_g)^2`` pairs."""
+        if getattr(self, "slots", False):
+            raise _lib.GnanHipError("these blocks are the slots of a captured step: their sizes live on the device only")
         if self._csr is None:
             dev = self.code.device
             sizes = torch.tensor(self.sizes, dtype=torch.int64, device=dev)
@@ -392,7 +396,7 @@ class GraphedBatchStep:
         self.code_off = torch.zeros(self.n_graphs + 1, dtype=torch.int64, device=dev)
         self.labels = torch.empty_like(labels)
         self.blocks = HopBlocks(self.code, self.node_off, self.code_off, [0] * self.n_graphs, self.n_codes - 2)
-        self.blocks.total_nodes, self.blocks.max_nodes = self.node_capacity, BATCH_KERNEL_MAX_NODES
+        self.blocks.total_nodes, self.blocks.max_nodes, self.blocks.slots = self.node_capacity, BATCH_KERNEL_MAX_NODES, True
         self._labels_shape = tuple(labels.shape)
         self.load(x, blocks, labels)
         self.step = GraphedStep(model, None, lambda out: (loss_of(out, self.labels), None), optimizer,
