@@ -522,7 +522,8 @@ __device__ __forceinline__ void small_graph_bwd_body(const SmallBwdParams& p, fl
     __syncthreads();
     if (live && lane < p.D) {
       float sum = 0.f;
-      for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];
+#pragma unroll 8
+      for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];        // (unrolled: eight reads in flight, not one)
       if (p.pre_rho) {
         s_dl[(i - i_lo) * p.D + lane] = sum;               // every (row, shell) is an argument of rho of its own
       } else {

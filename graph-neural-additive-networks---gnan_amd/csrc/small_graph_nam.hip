@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void small_graph_nam_bwd_kernel(const NamBwdPa
     __syncthreads();
     if (live && lane < D) {
       float sum = 0.f;
-      for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];
+#pragma unroll 8
+      for (int l = 0; l < n; ++l) sum += bins[lane * stride + l];        // (unrolled: eight reads in flight, not one)
       if (p.cnt) {
         const int c = p.cnt[i * p.cnt_stride + lane];
         sum *= 1.f / static_cast<float>(c > 1 ? c : 1);
