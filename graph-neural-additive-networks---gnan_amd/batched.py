@@ -224,7 +224,7 @@ class _BatchedGraphs(torch.autograd.Function):
         Ysum = torch.empty((G, Cf), dtype=torch.float32, device=dev) if graph_sum else None
         need = _lib.lib().gnan_small_batch_workspace_bytes(G, N, F, Cf)
         ws = torch.empty(need // 4 + 1, dtype=torch.int32, device=dev)
-        ws[: 4 * G].zero_()                                                  # the graphs' arrival counters
+        ws[: 32 * G].zero_()                                                 # the graphs' arrival counters (a 128-byte line each)
         a = _lib.SmallBatchArgs(x=_lib.ptr(xk), x_stride=xk.stride(0), total_nodes=N, F=F, n_graphs=G,
                                 max_nodes=blocks.max_nodes, f=_small_mlp(keep_f, Lf, Hf, Cf),
                                 rho=_small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(blocks.code),

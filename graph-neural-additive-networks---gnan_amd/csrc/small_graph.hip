@@ -130,12 +130,7 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
     }
   }
   // ---- join: the last workgroup to arrive finishes the graph --------------------------------------------------------------
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(p.counter, 1u);
-  __syncthreads();
-  if (s_last != gridDim.x - 1) return;
-  __threadfence();
+  if (!last_to_arrive(p.counter, gridDim.x, &s_last)) return;
   const int C = p.f.C, Cr = p.r.C, n = p.n;
   // (the fence above made the other workgroups' results visible to this one: plain loads from here on.  Every table the
   // aggregation reads — node sums, rho table, hop codes, the rows' weights — is staged in LDS; the per-row loop never waits
@@ -161,29 +156,35 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
   // walking its F terms itself left 30 of 256 threads with two rounds of loads: 2 us of a 20-us launch.)
   {
     const int nc = n * C;
-    const int per_chunk = kWeightFloats / nc;                     // features per pass (>= 9 at 64 nodes x 8 channels)
+    // staging: the part of the columns behind s_S / s_Y (the aggregation's tables move in there only after this phase): 7 168
+    // floats for one node block, 14 336 for two — 14 features per pass at 128 nodes x 8 channels (the weight image held 4)
+    float* stage = cols + 2 * kNodes * kMaxC;
+    constexpr int kStage = small_cols_floats(NB) - 2 * kNodes * kMaxC;
+    const int per_chunk = kStage / nc;
     for (int e = threadIdx.x; e < nc; e += blockDim.x) s_S[e] = 0.f;
     for (int k0 = 0; k0 < p.F; k0 += per_chunk) {
       const int kn = p.F - k0 < per_chunk ? p.F - k0 : per_chunk;
       __syncthreads();
-      for (int e0 = 0; e0 < kn * nc; e0 += 4 * 256) {
-        float v[4];
+      // (a 30-node, one-channel graph has 450 terms: two per thread.  A 100-node graph of the batched variant's 8 channels has
+      //  12 000: sixteen loads in flight per thread, not four — each batch of loads is one cold round trip)
+      for (int e0 = 0; e0 < kn * nc; e0 += 16 * 256) {
+        float v[16];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 16; ++t) {
           const int e = e0 + t * 256 + threadIdx.x;
           v[t] = e < kn * nc ? p.part[static_cast<int64_t>(k0) * nc + e] : 0.f;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 16; ++t) {
           const int e = e0 + t * 256 + threadIdx.x;
-          if (e < kn * nc) weights[e] = v[t];
+          if (e < kn * nc) stage[e] = v[t];
         }
       }
       __syncthreads();
       for (int e = threadIdx.x; e < nc; e += blockDim.x) {
         float sum = s_S[e];
 #pragma unroll 8
-        for (int kk = 0; kk < kn; ++kk) sum += weights[kk * nc + e];
+        for (int kk = 0; kk < kn; ++kk) sum += stage[kk * nc + e];
         s_S[e] = sum;
       }
     }
@@ -223,21 +224,31 @@ __device__ __forceinline__ void small_graph_body(const SmallParams& p, float* co
     const int cr = Cr == 1 ? 0 : c;
     const uint8_t* codes = s_code + i * n;
     float acc = 0.f;
+    // (three loops, not one with the case distinction inside: a branch per neighbour kept the compiler from overlapping the
+    //  neighbours' LDS reads — 40 of a 128-node, 8-channel graph's 59 us)
+    if (fast) {
+      const float* wrow = s_w + i * kWave;
 #pragma unroll 8
-    for (int j = 0; j < n; ++j) {                      // (unrolled: the code -> weight reads of eight neighbours overlap)
-      int d = codes[j];
-      d = d < p.D - 1 ? d : p.D - 1;
-      float w;
-      if (fast) {
-        w = s_w[i * kWave + d];
-      } else {
-        w = s_lut[d * Cr + cr];
-        if (p.cnt) {
-          const int q = p.cnt[i * p.cnt_stride + d];
-          w = w / static_cast<float>(q > 1 ? q : 1);
-        }
+      for (int j = 0; j < n; ++j) {                    // (unrolled: the code -> weight reads of eight neighbours overlap)
+        int d = codes[j];
+        d = d < p.D - 1 ? d : p.D - 1;
+        acc = fmaf(wrow[d], s_S[j * C + c], acc);
       }
-      acc = fmaf(w, s_S[j * C + c], acc);
+    } else if (p.cnt == nullptr) {
+      const float* lcol = s_lut + cr;
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) {
+        int d = codes[j];
+        d = d < p.D - 1 ? d : p.D - 1;
+        acc = fmaf(lcol[d * Cr], s_S[j * C + c], acc);
+      }
+    } else {
+      for (int j = 0; j < n; ++j) {
+        int d = codes[j];
+        d = d < p.D - 1 ? d : p.D - 1;
+        const int q = p.cnt[i * p.cnt_stride + d];
+        acc = fmaf(s_lut[d * Cr + cr] / static_cast<float>(q > 1 ? q : 1), s_S[j * C + c], acc);
+      }
     }
     s_Y[e] = acc;
     if (p.Y) p.Y[e] = acc;
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256) void small_graph_batch_kernel(const BatchParam
   if (p.Ysum) p.Ysum += static_cast<int64_t>(g) * p.f.C;
   p.lut += static_cast<int64_t>(g) * p.D * p.r.C;
   p.part += o * p.F * p.f.C;
-  p.counter += 4 * g;                                 // 16 bytes of its own per graph
+  p.counter += 32 * g;                                // a 128-byte line of its own per graph (arrivals of graphs sharing a line queue up behind each other)
   small_graph_body<NB>(p, cols);
 }
 
@@ -435,53 +446,88 @@ __device__ __forceinline__ void small_graph_bwd_body(const SmallBwdParams& p, fl
   }
   if (p.rho_c > 1) {
     // ---- a rho of one channel per output channel (the batched variant): dlut[d, c] = sum over the pairs (i, j) of hop code d of
-    // dY[i, c] S[j, c].  A thread per (d, c, slice of the rows) walks the pairs in order — the code is one LDS broadcast per
-    // pair — and the slices are added in order: n^2 D C / 256 steps (900 pairs x 80 entries: 2 us; the binning of the one-channel
-    // path would need C passes of its two barriers per row).
+    // dY[i, c] S[j, c]  (the binning of the one-channel path would need C passes of its two barriers per row).
+    // Rows in chunks of R: thread (row of the chunk, channel) bins the node sums of its row's neighbours by hop code into a
+    // column of its own (no other thread touches it), then thread (d, c) adds dY[i, c] * bin over the chunk's rows in order:
+    // n + R steps per thread and chunk.  (A thread per (d, c) walking ALL pairs was n^2 steps: 0.36 ms for one 128-node graph.)
     const int DC = p.D * C;
-    const int slices = DC >= 256 ? 1 : 256 / DC;           // row slices per (d, c)
-    float* part = s_u;                                     // [slices][DC]
-    for (int e0 = 0; e0 < DC; e0 += 256) {
-      const int e = e0 + static_cast<int>(threadIdx.x) % (DC < 256 ? DC : 256);
-      const int sl = DC >= 256 ? 0 : static_cast<int>(threadIdx.x) / DC;
-      if (e < DC && sl < slices) {
+    const int Dp = p.D | 1;                                // odd stride: the threads' columns start in different banks
+    if (p.dY == nullptr) {
+      // the graph read-out's gradient is the same for every row: dlut[d, c] = g[c] * sum_j S[j, c] * #{ i : code(i, j) == d }.
+      // A thread per column j counts its rows by hop code into a column of its own (n steps), a thread per (d, c) adds over j.
+      int* cc = reinterpret_cast<int*>(s_u);               // [n][Dp]
+      for (int j = threadIdx.x; j < n; j += 256) {
+        int* col = cc + j * Dp;
+        for (int d = 0; d < p.D; ++d) col[d] = 0;
+        for (int i = 0; i < n; ++i) {
+          int du = s_code[i * n + j];
+          du = du < p.D - 1 ? du : p.D - 1;
+          col[du] += 1;
+        }
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < DC; e += 256) {
         const int d = e / C, c = e % C;
-        const int rows = (n + slices - 1) / slices;
-        const int r_lo = sl * rows, r_hi = r_lo + rows < n ? r_lo + rows : n;
-        float acc = 0.f;
-        for (int i = r_lo; i < r_hi; ++i) {
-          const float gy = s_dY[i * C + c];
-          const uint8_t* codes = s_code + i * n;
-          // (eight pairs' code and node sum requested together: one pair at a time the loop waits for two LDS round trips per
-          //  pair — 0.33 ms for a batch whose largest graph has 100 nodes)
-          int j = 0;
-          for (; j + 8 <= n; j += 8) {
-            int dd[8];
-            float sv[8];
+        float a = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) a = fmaf(s_S[j * C + c], static_cast<float>(cc[j * Dp + d]), a);
+        s_g[e] = (p.rest_zero && d == p.D - 1) ? 0.f : a * s_dY[c];
+      }
+      __syncthreads();
+    } else {
+    int R = kUFloats / (C * Dp);
+    R = R < 256 / C ? R : 256 / C;
+    R = R < 1 ? 1 : R;
+    float* bins = s_u;                                     // [R * C][Dp]
+    const int tr = static_cast<int>(threadIdx.x) / C, tc = static_cast<int>(threadIdx.x) % C;
+    float acc[(kWave * kMaxC + 255) / 256];                // this thread's entries e = tid, tid + 256, ... of dlut [D][C]
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { dd[u] = codes[j + u]; sv[u] = s_S[(j + u) * C + c]; }
+    for (int u = 0; u < (kWave * kMaxC + 255) / 256; ++u) acc[u] = 0.f;
+    for (int i0 = 0; i0 < n; i0 += R) {
+      const int i = i0 + tr;
+      if (tr < R && i < n) {
+        float* col = bins + (tr * C + tc) * Dp;
+        for (int d = 0; d < p.D; ++d) col[d] = 0.f;
+        const uint8_t* codes = s_code + i * n;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+          int dd[8];
+          float sv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int du = dd[u] < p.D - 1 ? dd[u] : p.D - 1;
-              acc += du == d ? gy * sv[u] : 0.f;
-            }
-          }
-          for (; j < n; ++j) {
-            int du = codes[j];
-            du = du < p.D - 1 ? du : p.D - 1;
-            acc += du == d ? gy * s_S[j * C + c] : 0.f;
+          for (int u = 0; u < 8; ++u) { dd[u] = codes[j + u]; sv[u] = s_S[(j + u) * C + tc]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int du = dd[u] < p.D - 1 ? dd[u] : p.D - 1;
+            col[du] += sv[u];
           }
         }
-        part[sl * DC + e] = acc;
+        for (; j < n; ++j) {
+          int du = codes[j];
+          du = du < p.D - 1 ? du : p.D - 1;
+          col[du] += s_S[j * C + tc];
+        }
       }
       __syncthreads();
-      if (static_cast<int>(threadIdx.x) < (DC - e0 < 256 ? DC - e0 : 256) && (DC >= 256 || static_cast<int>(threadIdx.x) < DC)) {
-        const int ee = e0 + threadIdx.x;
-        float sum = 0.f;
-        for (int q2 = 0; q2 < slices; ++q2) sum += part[q2 * DC + ee];
-        s_g[ee] = (p.rest_zero && ee / C == p.D - 1) ? 0.f : sum;
+      const int rows = n - i0 < R ? n - i0 : R;
+#pragma unroll
+      for (int u = 0; u < (kWave * kMaxC + 255) / 256; ++u) {
+        const int e = static_cast<int>(threadIdx.x) + u * 256;
+        if (e < DC) {
+          const int d = e / C, c = e % C;
+          float a = acc[u];
+#pragma unroll 4
+          for (int r = 0; r < rows; ++r) a = fmaf(s_dY[(i0 + r) * C + c], bins[(r * C + c) * Dp + d], a);
+          acc[u] = a;
+        }
       }
       __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < (kWave * kMaxC + 255) / 256; ++u) {
+      const int e = static_cast<int>(threadIdx.x) + u * 256;
+      if (e < DC) s_g[e] = (p.rest_zero && e / C == p.D - 1) ? 0.f : acc[u];
+    }
+    __syncthreads();
     }
     auto uc_of = [&](int64_t node) {
       return node < p.D - 1 ? (p.rho_raw ? static_cast<float>(node) : 1.0f / (static_cast<float>(node) + 1.0f)) : 0.f;
@@ -562,12 +608,7 @@ __device__ __forceinline__ void small_graph_bwd_body(const SmallBwdParams& p, fl
     if (p.rho_groups == 1) return;
     // ---- join of the rho groups: the last to arrive adds the partial gradients in group order ------------------------------------
     __shared__ unsigned s_last_rho;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last_rho = atomicAdd(p.counter, 1u);
-    __syncthreads();
-    if (s_last_rho != static_cast<unsigned>(p.rho_groups) - 1) return;
-    __threadfence();
+    if (!last_to_arrive(p.counter, static_cast<unsigned>(p.rho_groups), &s_last_rho)) return;
     // (a thread's loads of all groups' terms are issued together, 16 bytes each: a load -> add loop over the groups would
     //  wait for every load in turn — 160 cold round trips per thread, longer than the whole rest of the launch)
     const int H = p.r.H;
@@ -789,7 +830,7 @@ extern "C" int gnan_small_graph_bwd(const gnan_small_graph_bwd_args* a, gnan_str
 
 
 extern "C" size_t gnan_small_batch_workspace_bytes(int32_t n_graphs, int64_t total_nodes, int32_t F, int32_t C) {
-  return static_cast<size_t>(n_graphs) * 16 + static_cast<size_t>(total_nodes) * F * C * sizeof(float);     // counters | part
+  return static_cast<size_t>(n_graphs) * 128 + static_cast<size_t>(total_nodes) * F * C * sizeof(float);    // counters (a line each) | part
 }
 
 extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_t stream) {
@@ -815,7 +856,7 @@ extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_
   p.code = a->code; p.D = a->D; p.cnt = nullptr; p.cnt_stride = 0;
   p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
   p.counter = static_cast<unsigned*>(a->workspace);
-  p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + static_cast<size_t>(a->n_graphs) * 16);
+  p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + static_cast<size_t>(a->n_graphs) * 128);
   p.rho_raw = a->rho_raw_hops != 0; p.rest_zero = a->rest_zero != 0; p.pre_rho = 0;
   bp.node_off = a->node_off; bp.code_off = a->code_off;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -144,6 +144,23 @@ constexpr int small_cols_floats(int nb) {
   return tables > 2 * kMaxH * kWave ? tables : 2 * kMaxH * kWave;
 }
 
+// Is this workgroup the last of `expected` to arrive at `counter`?  ONE thread releases the workgroup's results (the barrier before
+// it orders the other threads' stores before its fence) and, in the last workgroup, acquires the others'.  An agent-scope fence
+// is an L2 write-back / invalidate on this multi-die part: executed by every wave — 4 waves x 2 fences x the 512 workgroups of a
+// 32-graph batch — they queued up behind each other for 50 of the launch's 68 us.
+__device__ __forceinline__ bool last_to_arrive(unsigned* counter, unsigned expected, unsigned* s_slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    *s_slot = atomicAdd(counter, 1u);
+  }
+  __syncthreads();
+  if (*s_slot != expected - 1) return false;
+  if (threadIdx.x == 0) __threadfence();
+  __syncthreads();
+  return true;
+}
+
 inline gnan_bwd::Weights to_weights(const gnan_small_mlp* m, const gnan_small_mlp_grads* g) {
   gnan_bwd::Weights w;
   w.H = m->H;

@@ -157,12 +157,7 @@ __global__ __launch_bounds__(256) void small_graph_nam_kernel(const NamParams p)
       for (int c = 0; c < C; ++c) p.part[k * C + c] = out[c];
   }
   // ---- join: the last workgroup adds the features in order ------------------------------------------------------------------------
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(p.counter, 1u);
-  __syncthreads();
-  if (s_last != gridDim.x - 1) return;
-  __threadfence();
+  if (!last_to_arrive(p.counter, gridDim.x, &s_last)) return;
   // (every term fetched by a thread of its own — all loads in flight together — then added in feature order from LDS)
   const int chunk = kWeightFloats / C * C;           // whole features per pass through the (now free) weight image
   for (int e0 = 0; e0 < p.F * C; e0 += chunk) {
@@ -292,8 +287,8 @@ __global__ __launch_bounds__(256) void small_graph_nam_bwd_kernel(const NamBwdPa
     while (__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<unsigned>(p.F))
       __builtin_amdgcn_s_sleep(8);
   }
+  if (threadIdx.x == 0) __threadfence();               // (one acquire for the workgroup: see last_to_arrive)
   __syncthreads();
-  __threadfence();
   // T_j = sum_k d hidden_k fx[k, j]: chunks of 64 features through LDS
   for (int j = threadIdx.x; j < n; j += 256) s_g[j] = 0.f;
   for (int k0 = 0; k0 < p.F; k0 += kMaxH) {

@@ -594,7 +594,7 @@ int gnan_small_graph_fwd(const gnan_small_graph_args* a, gnan_stream_t stream);
  * per-graph read-out (the scatter_add_ of batched_pyg_main.py:173-181), lut [n_graphs, D, rho.C] a rho table per graph.
  * rho_raw_hops: rho is evaluated on the raw hop count d (batched_pyg_main.py:151) instead of 1 / (1 + d); rest_zero: codes
  * beyond D - 2 (the -1 mask of :155-156) carry weight 0.  No shell normalisation.  Covers graphs of <= 128 nodes (max_nodes).
- * workspace: gnan_small_batch_workspace_bytes(...) bytes whose first 16 * n_graphs are ZERO before the first launch (the
+ * workspace: gnan_small_batch_workspace_bytes(...) bytes whose first 128 * n_graphs are ZERO before the first launch (the
  * kernel leaves them zero).  gnan_hops_to_code / gnan_dense_blocks_to_code make the packed codes from the hop matrices:
  * status[0] |= 1 for an entry that is no integer in [0, 254] or negative, |= 2 for a listed pair outside the diagonal blocks
  * (dense form), status[1] = the largest hop (ZEROED by the caller). */
