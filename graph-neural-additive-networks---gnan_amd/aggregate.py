@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from . import functional as Fn
 from .functional import StackedMLP
-from .graph import HopGraph, hop_inputs
+from .graph import HopGraph
 
 DENSE_SLICE_MAX_ROWS = 16384  # dense layout: slice every row over workgroups while row blocks alone would not fill the GPU
 DENSE_SLICE_MIN_COLS = 512

@@ -15,13 +15,11 @@ from __future__ import annotations
 
 from typing import NamedTuple, Optional, Sequence
 
-import os
 
 import torch
 
 from . import _lib
 from ._cache import TensorKeyedCache
-from .graph import HopGraph, hop_inputs
 
 
 # =============================================================================

@@ -23,7 +23,6 @@ Dropout in training mode is stochastic per call and is never captured (``Graphed
 from __future__ import annotations
 
 import atexit
-import os
 import weakref
 from typing import Callable, List, Optional
 

@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Callable, Optional, Sequence
+from typing import Callable, Optional
 
 import numpy as np
 import torch
