@@ -375,14 +375,25 @@ class GraphedBatchStep:
     code's business: weight 0, no gradient).  :meth:`run` copies a batch into the slots (one launch) and replays; it returns
     None for a batch that does not fit (another number of graphs, more nodes, a longer hop): the caller steps eagerly.
 
-    ``loss_of(outputs, labels) -> loss``; ``optimizer=None`` captures the evaluation pass.  Construction runs the FIRST
-    batch's step eagerly (a real step: the parameters are updated) and captures after it.
+    ``loss_of(outputs, labels) -> loss`` — or a torch loss module: ``BCEWithLogitsLoss`` / ``CrossEntropyLoss`` with mean
+    reduction then run as ONE launch (``losses.loss_step``: loss and its gradient together) instead of torch's five;
+    ``optimizer=None`` captures the evaluation pass.  Construction runs the FIRST batch's step eagerly (a real step: the
+    parameters are updated) and captures after it.
     """
 
     def __init__(self, model: "TensorGNAN", optimizer, loss_of, x, blocks: HopBlocks, labels, node_capacity: Optional[int] = None,
                  n_codes: Optional[int] = None):
         from .graphed import GraphedStep
         _lib.require_device(x, labels)
+        if isinstance(loss_of, nn.Module):
+            from .losses import loss_kind, loss_step
+            loss_module = loss_of
+
+            def loss_of(out, lab):                   # noqa: F811  (the module's loss, fused where the kernel covers it)
+                kind = loss_kind(loss_module, out)
+                if kind is not None and out.shape[0] == lab.numel() and lab.dim() == 1:
+                    return loss_step(out, lab, kind, want_hits=False, unit_upstream=optimizer is not None)[0]
+                return loss_module(out, lab)
         dev = x.device
         self.n_graphs, self.F = blocks.n_graphs, int(x.shape[1])
         self.node_capacity = int(node_capacity or BATCH_KERNEL_MAX_TOTAL_NODES)

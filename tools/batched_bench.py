@@ -79,7 +79,7 @@ def main():
         if max(b[0].shape[0] for b in batches) <= cap or bs <= 32:
             x0, b0, y0, _ = batches[0]
             try:
-                gs = batched.GraphedBatchStep(mod, opt, lambda out, lab: loss_fn(out, lab), x0, b0, y0, node_capacity=cap)
+                gs = batched.GraphedBatchStep(mod, opt, loss_fn, x0, b0, y0, node_capacity=cap)
                 missed = [0]
 
                 def replayed():
