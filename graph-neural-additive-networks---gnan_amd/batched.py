@@ -378,11 +378,13 @@ class GraphedBatchStep:
     ``loss_of(outputs, labels) -> loss`` — or a torch loss module: ``BCEWithLogitsLoss`` / ``CrossEntropyLoss`` with mean
     reduction then run as ONE launch (``losses.loss_step``: loss and its gradient together) instead of torch's five;
     ``optimizer=None`` captures the evaluation pass.  Construction runs the FIRST batch's step eagerly (a real step: the
-    parameters are updated) and captures after it.
+    parameters are updated) and captures after it.  ``prepared``: the optimizer's capturable mode if another captured step of
+    the same optimizer switched it on already (``other.step.prepared``) — two steps that each prepare the optimizer
+    invalidate one another.
     """
 
     def __init__(self, model: "TensorGNAN", optimizer, loss_of, x, blocks: HopBlocks, labels, node_capacity: Optional[int] = None,
-                 n_codes: Optional[int] = None):
+                 n_codes: Optional[int] = None, prepared=None):
         from .graphed import GraphedStep
         _lib.require_device(x, labels)
         if isinstance(loss_of, nn.Module):
@@ -411,7 +413,7 @@ class GraphedBatchStep:
         self._labels_shape = tuple(labels.shape)
         self.load(x, blocks, labels)
         self.step = GraphedStep(model, None, lambda out: (loss_of(out, self.labels), None), optimizer,
-                                forward=lambda: model(self.x, self.blocks, None), warmup=1)
+                                forward=lambda: model(self.x, self.blocks, None), warmup=1, prepared=prepared)
 
     def fits(self, x, blocks: HopBlocks, labels) -> bool:
         return bool(blocks.n_graphs == self.n_graphs and x.shape[1] == self.F and blocks.total_nodes <= self.node_capacity
@@ -440,3 +442,48 @@ class GraphedBatchStep:
     @property
     def kernel_nodes(self) -> int:
         return int(self.step.graph.kernel_nodes)
+
+
+def train_epoch(model: "TensorGNAN", loader, loss_fn, optimizer, steps: Optional[dict] = None):
+    """One pass of the script's training loop (batched_pyg_main.py:205-226): per batch ``zero_grad``, forward, loss, accuracy
+    (``argmax == label``), ``backward``, ``optimizer.step()``; returns ``(mean loss, mean accuracy, steps)`` — the means over
+    the batches, as the script prints them.  ``loader`` yields ``(x_batch, dist_batch or HopBlocks, y_batch, batch_vector)``
+    (:func:`collate`'s tuples).  Batches that fit are replayed from a captured step (:class:`GraphedBatchStep`, one per number
+    of graphs, kept in ``steps`` — hand the returned dict to the next epoch); the others (a last, smaller batch; a batch with
+    more nodes than the slots hold) are stepped eagerly.  Loss and hit counts are added up on the device and read once."""
+    steps = {} if steps is None else steps
+    dev = next(model.parameters()).device
+    totals = torch.zeros(2, dtype=torch.float64, device=dev)            # sum of batch losses, sum of batch accuracies
+    n_batches = 0
+    for x, dist, y, bv in loader:
+        blocks = dist if isinstance(dist, HopBlocks) else model._blocks(dist, bv)
+        out = None
+        if blocks is not None and GRAPHED_BATCH_STEPS and not model._dropout_active():
+            gs = steps.get(blocks.n_graphs)
+            if gs is None and blocks.total_nodes <= BATCH_KERNEL_MAX_TOTAL_NODES and blocks.max_nodes <= BATCH_KERNEL_MAX_NODES:
+                try:
+                    gs = steps[blocks.n_graphs] = GraphedBatchStep(model, optimizer, loss_fn, x, blocks, y,
+                                                                   prepared=steps.get("prepared"))
+                    steps["prepared"] = gs.step.prepared
+                    out, loss = gs.step.warmup_result[0], gs.step.warmup_result[1]     # (construction ran this batch's step)
+                except Exception:                                        # noqa: BLE001  (not capturable here: eager from now on)
+                    steps[blocks.n_graphs] = gs = False
+            elif gs:
+                got = gs.run(x, blocks, y)
+                if got is not None:
+                    out, loss = got[0], got[1]
+        if out is None:
+            optimizer.zero_grad(set_to_none=True)
+            out = model(x, dist, bv)
+            loss = loss_fn(out, y)
+            loss.backward()
+            optimizer.step()
+        with torch.no_grad():
+            totals[0] += loss.detach().double()
+            totals[1] += (out.detach().argmax(dim=-1) == y).double().mean()
+        n_batches += 1
+    mean = (totals / max(n_batches, 1)).tolist()
+    return mean[0], mean[1], steps
+
+
+GRAPHED_BATCH_STEPS = True       # batched.train_epoch replays captured steps where a batch fits (off: the eager loop)

@@ -408,9 +408,10 @@ class GraphedStep:
         self.eager_step = eager_step
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        self.warmup_result = None                    # (outputs, loss, extras) of the LAST warm-up step: it was a real step
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                eager_step()
+                self.warmup_result = eager_step()
         torch.cuda.current_stream().wait_stream(side)
         # the update as one launch over the flat parameter buffers where that is the same computation (FlatAdamStep)
         if self.training:

@@ -576,7 +576,7 @@ def test_batched_training_step_replayed_over_slots(gpu):
     assert gs.kernel_nodes <= 8, gs.kernel_nodes
     for e, r in zip(eager[1:], replayed):
         assert abs(e - r) <= 1e-4 * max(abs(e), 1.0), (eager, replayed)
-    scale = max(float(p.abs().max()) for p in a.parameters())
+    scale = max(float(p.detach().abs().max()) for p in a.parameters())
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert float((pa - pb).abs().max()) <= 1e-4 * scale
     # a batch of another number of graphs, or with more nodes than the slots hold, is refused (the caller steps eagerly)
@@ -597,6 +597,52 @@ def test_batched_training_step_replayed_over_slots(gpu):
     assert float((out - want).abs().max()) <= 1e-6 * float(want.abs().max())
     assert abs(float(loss) - float(loss_fn(want, y))) <= 1e-6 * max(1.0, abs(float(loss)))
     del ev
+
+
+def test_batched_train_epoch_matches_the_scripts_loop(gpu, monkeypatch):
+    """batched.train_epoch == the loop of batched_pyg_main.py:205-226 written out (mean loss, mean accuracy, parameters after
+    the epoch), with batches that fit replayed from a captured step and a last, smaller batch stepped eagerly; a second epoch
+    reuses the captured steps."""
+    import copy
+    from gnan_amd import batched
+    rng = np.random.default_rng(5)
+    F, C, H, G = 6, 8, 16, 10
+    data = []
+    for _ in range(G * 5 + 3):                                            # a last batch of 3 graphs
+        n = int(rng.integers(3, 60))
+        hops = rng.integers(-1, 6, (n, n)).astype(np.float32)
+        hops[np.arange(n), np.arange(n)] = 0
+        data.append((torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(gpu.DEV),
+                     torch.from_numpy(hops).to(gpu.DEV), torch.tensor([int(rng.integers(0, C))], device=gpu.DEV)))
+    batches = [batched.collate(data[i:i + G]) for i in range(0, len(data), G)]
+    torch.manual_seed(0)
+    a = batched.TensorGNAN(F, C, 2, hidden_channels=H, device="cuda").to(gpu.DEV)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    b = copy.deepcopy(a)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    opt_a, opt_b = torch.optim.Adam(a.parameters(), lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    steps = None
+    for epoch in range(2):
+        tl = ta = 0.0
+        for x, blocks, y, bv in batches:                                  # the script's loop
+            opt_a.zero_grad(set_to_none=True)
+            out = a(x, blocks, bv)
+            loss = loss_fn(out, y)
+            acc = (out.argmax(dim=-1) == y).float().mean()
+            loss.backward()
+            opt_a.step()
+            tl += float(loss.detach())
+            ta += float(acc)
+        got_l, got_a, steps = batched.train_epoch(b, batches, loss_fn, opt_b, steps)
+        assert abs(got_l - tl / len(batches)) <= 1e-4 * max(1.0, abs(tl / len(batches))), (epoch, got_l, tl / len(batches))
+        assert abs(got_a - ta / len(batches)) <= 1e-6 + 1.0 / (G * len(batches)), (epoch, got_a, ta / len(batches))
+    assert isinstance(steps.get(G), batched.GraphedBatchStep) and steps[G].step.graph.replays >= 2 * 5 - 1
+    assert not isinstance(steps.get(3), bool) or steps.get(3) is not False      # (3 graphs: a step of its own, or eager)
+    scale = max(float(p.detach().abs().max()) for p in a.parameters())
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) <= 2e-4 * scale
 
 
 def test_batched_graphs_in_one_launch(gpu, monkeypatch):
