@@ -534,6 +534,25 @@ def run_c2(args, rank=0, world=1):
         replay_ms = (time.perf_counter() - t0) / len(graphs) * 1e3
     except Exception as e:                                   # the replayed pass is an extra figure, not the timed call
         replay_ms = f"failed: {type(e).__name__}: {e}"
+    # ... and a training epoch (trainer.py:23-86: batch_size 1, forward + loss + backward + Adam per graph) on a twin of the
+    # model: eager in its first passes, one captured step per graph shape from the third on
+    train_ms, train_kernels = None, None
+    try:
+        import copy
+        twin = copy.deepcopy(model).train()
+        opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+        labelled = graphs                            # (they carry their labels: y [1, 1])
+        for _ in range(3):
+            harness.train_epoch(twin, labelled, loss_fn, opt, dev, classify=True, is_graph_task=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        harness.train_epoch(twin, labelled, loss_fn, opt, dev, classify=True, is_graph_task=True)
+        torch.cuda.synchronize()
+        train_ms = (time.perf_counter() - t0) / len(labelled) * 1e3
+        recs = [r["step"] for r in harness._steps_of(twin).graph.buckets.values() if r["step"] is not None]
+        train_kernels = sorted({int(r.step.graph.kernel_nodes) for r in recs})
+    except Exception as e:
+        train_ms = f"failed: {type(e).__name__}: {e}"
     ms = elapsed / args.steps * 1e3
     # the forward of a 30-node graph is one launch (small_graph_kernel) of ~20 us: a chain of latencies.  Algorithmic bytes
     # per graph: N_g^2 hop codes (1 B) + N_g x D counts + x + the weights (F MLPs of 4.3k floats)
@@ -548,7 +567,8 @@ def run_c2(args, rank=0, world=1):
                    "graphs": args.graphs, "pairs": total_pairs, "partition": f"replicas x{world}", "exchange": "none",
                    "step": "one evaluation pass: models.TensorGNAN.forward(data) per graph, batch_size = 1"},
         "ms_per_graph": ms / max(1, len(graphs)), "graphs_per_s": args.graphs / (elapsed / args.steps),
-        "replayed_eval_ms_per_graph": replay_ms,
+        "replayed_eval_ms_per_graph": replay_ms, "replayed_train_ms_per_graph": train_ms,
+        "kernels_per_replayed_training_step": train_kernels,
         "roofline": {"bound": "hbm", "kernel": "small_graph_kernel (whole forward of a graph in one launch)",
                      "achieved": b_alg / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
