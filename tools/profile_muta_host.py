@@ -29,6 +29,6 @@ for name, fn, reps in (("forward", fwd, 4), ("forward+backward", fb, 2)):
     pr = cProfile.Profile(); pr.enable()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); pr.disable()
-    out = io.StringIO(); pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(22)
+    out = io.StringIO(); pstats.Stats(pr, stream=out).strip_dirs().sort_stats("tottime").print_stats(22)
     print("=====", name, "x", reps * len(graphs), "graphs")
     print("\n".join(l[:160] for l in out.getvalue().splitlines()[:36]))
