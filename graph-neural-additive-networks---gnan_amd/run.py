@@ -4,7 +4,7 @@
 
 * ``Adam(lr, weight_decay=wd)`` (main.py:141), ``ReduceLROnPlateau(factor 0.9, patience 100, min_lr 1e-8)`` stepped on the
   TRAINING loss after every epoch (main.py:148-154, 166);
-* ``EarlyStopping('Loss', patience, min_is_better=True)`` fed the validation loss (main.py:16-41, 142, 280), stopping only
+* a patience counter on the validation loss (:class:`PatienceCounter`; main.py:16-41, 142, 280), stopping only
   when ``early_stop_flag`` (main.py:284) — and the ``train_loss < loss_thresh`` stop (main.py:281);
 * one training pass, one validation pass and one test pass per epoch (main.py:156-164, 270-273) through
   ``gnan_amd.harness`` — plus a test pass whenever a checkpoint is written;
@@ -28,39 +28,58 @@ import math
 import os
 from typing import Callable, Optional
 
-import numpy as np
 import torch
 
 from . import harness
 
 
-class EarlyStopping:
-    """main.py:16-41 — counts the epochs in a row whose score was worse than the best one."""
+class PatienceCounter:
+    """Early-stop bookkeeping of the run loop (behaviour of main.py:16-41 as run_exp uses it: lower is better): how many
+    epochs in a row the watched value stayed strictly above the lowest value seen so far.  An equal value counts as an
+    improvement (it restarts the count); ``exhausted`` latches once ``patience`` such epochs have passed."""
 
-    def __init__(self, metric_name, patience=3, min_is_better=False):
-        self.metric_name = metric_name
-        self.patience = patience
-        self.min_is_better = min_is_better
-        self.counter = 0
-        self.best_score = None
-        self.early_stop = False
-        self.val_loss_min = np.inf
+    __slots__ = ("patience", "lowest", "bad_epochs", "exhausted")
 
-    def reset(self):
-        self.counter = 0
+    def __init__(self, patience: int):
+        self.patience = int(patience)
+        self.lowest = None
+        self.bad_epochs = 0
+        self.exhausted = False
 
-    def __call__(self, score):
-        if self.min_is_better:
-            score = -score
-        if self.best_score is None:
-            self.best_score = score
-        elif score < self.best_score:
-            self.counter += 1
-            if self.counter >= self.patience:
-                self.early_stop = True
+    def observe(self, value: float) -> bool:
+        if self.lowest is not None and value > self.lowest:
+            self.bad_epochs += 1
+            self.exhausted = self.exhausted or self.bad_epochs >= self.patience
         else:
-            self.best_score = score
-            self.counter = 0
+            self.lowest, self.bad_epochs = value, 0
+        return self.exhausted
+
+
+class CheckpointRules:
+    """When the run loop writes a checkpoint (main.py:167-171, 199-203, 229-235).  Each epoch at most one
+    validation-side rule fires (AUC when it is computed, accuracy otherwise) and then the training-loss rule.  The
+    accuracy rule's threshold is replaced by the validation LOSS when it fires (main.py:200 stores
+    ``val_loss``) — that decides at which epochs ``*_best_val_acc.pt`` is rewritten, so it is kept."""
+
+    def __init__(self, use_auc: bool):
+        self.use_auc = bool(use_auc)
+        self.val_bar = 0                      # the value the validation-side metric has to beat
+        self.lowest_train_loss = math.inf
+
+    def due(self, train_loss, val_loss, val_acc, val_auc):
+        """Tags of the checkpoints this epoch's numbers call for, in the order they are written."""
+        tags = []
+        if self.use_auc:
+            if val_auc > self.val_bar:
+                self.val_bar = val_auc
+                tags.append("best_val_auc")
+        elif val_acc > self.val_bar:
+            self.val_bar = val_loss
+            tags.append("best_val_acc")
+        if train_loss < self.lowest_train_loss:
+            self.lowest_train_loss = train_loss
+            tags.append("best_train_loss")
+        return tags
 
 
 def loss_and_out_dim(num_classes: int, is_regression: bool):
@@ -111,10 +130,8 @@ def run_exp(train_loader, val_loader, test_loader, num_features, seeds, n_layers
         net.to(device)
         optimizer = optimizer_type(params=net.parameters(), lr=lr, weight_decay=wd)          # main.py:141
         loss = loss_type()
-        early_stop = EarlyStopping(metric_name="Loss", patience=patience, min_is_better=True)
-        best_val_acc_model_val_acc = 0
-        best_val_acc_model_val_auc = 0
-        best_train_loss_model_train_loss = math.inf
+        patience_counter = PatienceCounter(patience)                                            # main.py:142
+        rules = CheckpointRules(compute_auc)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.9, patience=100, min_lr=1e-8)   # :148-154
         history, checkpoints, stopped = [], [], "num_epochs"
 
@@ -136,18 +153,8 @@ def run_exp(train_loader, val_loader, test_loader, num_features, seeds, n_layers
                                                             device=device, val_mask=True, compute_auc=compute_auc,
                                                             is_graph_task=is_graph_task)
             scheduler.step(train_loss)                                                          # main.py:166
-            if compute_auc:
-                if val_auc > best_val_acc_model_val_auc:                                        # main.py:167-171
-                    best_val_acc_model_val_auc = val_auc
-                    save("best_val_auc", epoch)
-                    test_pass()
-            elif val_acc > best_val_acc_model_val_acc:                                          # main.py:199-203
-                best_val_acc_model_val_acc = val_loss                                           # (sic, main.py:200)
-                save("best_val_acc", epoch)
-                test_pass()
-            if train_loss < best_train_loss_model_train_loss:                                   # main.py:229-235
-                best_train_loss_model_train_loss = train_loss
-                save("best_train_loss", epoch)
+            for tag in rules.due(train_loss, val_loss, val_acc, val_auc):                       # main.py:167-235
+                save(tag, epoch)
                 test_pass()
             test_loss, test_acc, test_auc = test_pass()                                         # main.py:270-273
             cur_lr = optimizer.param_groups[0]["lr"]
@@ -155,12 +162,12 @@ def run_exp(train_loader, val_loader, test_loader, num_features, seeds, n_layers
                             "test_loss": test_loss, "test_acc": test_acc, "lr": float(cur_lr)})
             log(f"Epoch: {epoch:03d}, Train Loss: {train_loss:.4f}, Train Acc: {train_acc:.4f}, Val Loss: {val_loss:.4f}, "
                 f"Val Acc: {val_acc:.4f} Test Loss: {test_loss:.4f}, Test Acc: {test_acc:.4f}")
-            early_stop(val_loss)                                                                # main.py:280
+            out_of_patience = patience_counter.observe(val_loss)                                # main.py:280
             if train_loss < loss_thresh:                                                        # main.py:281-283
                 stopped = f"loss under {loss_thresh} at epoch: {epoch}"
                 log(stopped)
                 break
-            if early_stop_flag and early_stop.early_stop:                                       # main.py:284-286
+            if early_stop_flag and out_of_patience:                                       # main.py:284-286
                 stopped = f"early stop at epoch: {epoch}"
                 log(stopped)
                 break

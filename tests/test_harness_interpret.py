@@ -68,11 +68,17 @@ def test_interpretability_exports_need_the_device():
 # ---------------------------------------------------------------------------------------------------------- run level
 def test_early_stopping_and_loss_rule():
     """main.py:16-41 and main.py:343-352."""
-    from gnan_amd.run import EarlyStopping, loss_and_out_dim
-    es = EarlyStopping("Loss", patience=3, min_is_better=True)
-    for v, stop in ((1.0, False), (0.9, False), (0.95, False), (0.91, False), (0.9, False), (1.2, False), (1.1, False), (1.3, True)):
-        es(v)
-        assert es.early_stop == stop, v          # 0.9 again is not worse (resets the count); three worse ones in a row stop
+    from gnan_amd.run import CheckpointRules, PatienceCounter, loss_and_out_dim
+    pc = PatienceCounter(3)
+    for v, stop in ((1.0, False), (0.9, False), (0.95, False), (0.91, False), (0.9, False), (1.2, False), (1.1, False), (1.3, True),
+                    (0.1, True)):
+        assert pc.observe(v) == stop, v          # 0.9 again is not worse (resets the count); three worse ones in a row stop; it latches
+    rules = CheckpointRules(use_auc=False)
+    assert rules.due(2.0, 0.7, 0.5, -1) == ["best_val_acc", "best_train_loss"]
+    assert rules.due(2.5, 0.6, 0.6, -1) == []                # the bar is now the validation LOSS 0.7 (main.py:200), 0.6 does not beat it
+    assert rules.due(1.5, 0.9, 0.8, -1) == ["best_val_acc", "best_train_loss"]
+    auc = CheckpointRules(use_auc=True)
+    assert auc.due(1.0, 0.5, 0.9, 0.6) == ["best_val_auc", "best_train_loss"] and auc.due(1.0, 0.5, 0.99, 0.6) == []
     assert loss_and_out_dim(2, False) == (torch.nn.BCEWithLogitsLoss, 1)
     assert loss_and_out_dim(40, False) == (torch.nn.CrossEntropyLoss, 40)
     assert loss_and_out_dim(1, True) == (torch.nn.MSELoss, 1)
