@@ -64,6 +64,9 @@ def parse():
                     help="torch.distributed backend (nccl = RCCL on ROCm); gloo + --same-device is a dry run of the "
                          "multi-rank code path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="development aid: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank: still create the process group on --backend and run the share's collectives over it "
+                         "(distributed.ALWAYS_COMMUNICATE) — RCCL on a 1-GPU box; combines with --emulate-world")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid on a 1-GPU box: run rank 0's share of a P-rank job WITHOUT the collectives "
                          "(stage times only; the printed value is not a result)")
@@ -247,7 +250,7 @@ def cpu_baseline(args, model, g, x, operand_full, out_gpu):
 def _redraw(model):
     """O(1)-scale weights (the upstream init, xavier with gain 0.01, gives ~1e-14 outputs)."""
     with torch.no_grad():
-        for p in model.parameters():
+        for _, p in model.named_parameters():
             if p.dim() == 2:
                 torch.nn.init.xavier_normal_(p, gain=1.0)
             else:
@@ -337,7 +340,7 @@ def run_c3(args):
         return out
 
     def fwd_bwd():
-        for p in model.parameters():
+        for _, p in model.named_parameters():
             p.grad = None
         out = model.forward(data)
         loss = ((out - target) ** 2).mean()
@@ -363,7 +366,7 @@ def run_c3(args):
         eager_grads = [p.grad.detach().clone() for p in model.parameters()]
 
         def clear():
-            for p in model.parameters():
+            for _, p in model.named_parameters():
                 p.grad = None
 
         def static_step():
@@ -715,7 +718,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    if args.force_dist and world == 1:                       # no launcher set the rendezvous up: a private one
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            free = s_.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+    if grouped:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -734,6 +747,9 @@ def main():
     if args.index_buckets:
         functional.INDEX_BUCKETS = args.index_buckets
     apply_sets(args)
+    if args.force_dist:
+        from gnan_amd import distributed as _dist_mod
+        _dist_mod.ALWAYS_COMMUNICATE = True
     functional.FMLP_ALGO = {"auto": _lib.FMLP_AUTO, "lane": _lib.FMLP_LANE, "mfma": _lib.FMLP_MFMA,
                             "pwl": _lib.FMLP_PWL}[args.fmlp_algo]
     from gnan_amd.models import TensorGNAN
@@ -741,8 +757,9 @@ def main():
     N, E, F, H, L, C = args.nodes, args.edges, args.feat, args.hidden, args.layers, args.out
     emulated = args.emulate_world > 1 and world == 1
     pworld = args.emulate_world if emulated else world       # how many shares the work is cut into
-    args.pipeline = args.pipeline == "on" or (args.pipeline == "auto" and pworld > 1)
-    partition = args.partition if args.partition != "auto" else choose_partition(N, F, C, pworld, args.order)
+    args.pipeline = args.pipeline == "on" or (args.pipeline == "auto" and (pworld > 1 or args.force_dist))
+    partition = args.partition if args.partition != "auto" else choose_partition(
+        N, F, C, max(pworld, 2) if args.force_dist else pworld, args.order)
     if emulated and partition in ("vertex", "exchange"):
         raise SystemExit("--emulate-world covers the halo and feature partitions (these shares need the other ranks' operand rows)")
     if partition == "feature" and args.order != "reference":
@@ -775,7 +792,7 @@ def main():
     torch.manual_seed(0)
     model = TensorGNAN(F, C, L, hidden_channels=H, normalize_rho=True, rho_per_feature=False, device="cuda")
     with torch.no_grad():                                    # O(1)-scale weights (the upstream init gives ~1e-14 outputs)
-        for p in model.parameters():
+        for _, p in model.named_parameters():
             if p.dim() == 2:
                 torch.nn.init.xavier_normal_(p, gain=1.0)
             else:
@@ -792,7 +809,7 @@ def main():
     # One GPU: the timed call is the drop-in itself, TensorGNAN.forward(data) (models.py:358-384) on a data object that
     # carries the hop-coded graph — graph lookup, weight views, rho on the D distinct distances, look-up, aggregation.
     # More than one rank: gnan_amd.distributed's forward of this rank's share (the reference has no multi-process path).
-    use_module = world == 1 and not emulated and partition == "vertex" and not args.pipeline
+    use_module = world == 1 and not emulated and partition == "vertex" and not args.pipeline and not args.force_dist
     if use_module:
         class Bag:
             pass
@@ -814,7 +831,7 @@ def main():
     pipe = {"next": prefetch.launch() if prefetch else None}
     # ... and the whole share as one graph launch per forward (halo / vertex partitions, inference)
     share, share_note = None, None
-    if world > 1 and args.backend != "nccl" and args.share_graph != "off":
+    if grouped and args.backend != "nccl" and args.share_graph != "off":
         share_note = f"{args.backend} collectives go through the host and cannot be captured: eager loop"
     elif args.share_graph != "off" and prefetch is not None and (args.share_graph == "on" or args.pipeline):
         from gnan_amd.graphed import CaptureFailed
@@ -826,7 +843,7 @@ def main():
             return partitioned_forward(x, g, stacked, lut, True, part, order=args.order, out_channels=C,
                                        operand_dtype=op_dtype, tables=tables, marks=marks)
         def all_ranks(ok: bool) -> bool:             # every rank replays, or none does (the collectives must pair up)
-            if world == 1:
+            if not grouped:
                 return ok
             flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -895,7 +912,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -908,13 +925,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    rank_ms = None
+    if grouped:                                      # every rank's own time (one all-gather); the line's time is the slowest
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        every = torch.empty(dist.get_world_size(), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, t)
+        every = (every / args.steps * 1e3).tolist()
+        rank_ms = {"min": min(every), "max": max(every), "per_rank": every}
+        elapsed = max(every) * args.steps / 1e3
 
     checksum = out.double().sum().reshape(1)
-    if world > 1 and partition != "feature":      # row-partitioned output: add the ranks' shares (feature: already whole)
+    if grouped and partition != "feature":      # row-partitioned output: add the ranks' shares (feature: already whole)
         dist.all_reduce(checksum, op=dist.ReduceOp.SUM)
     checksum = float(checksum)
 
@@ -955,17 +976,19 @@ def main():
         traffic, traffic_source = committed, "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of this command, not measured in this run)" % rec.get("source", "committed")
 
     result = None
-    if rank == 0:
+    if rank == 0 or emulated:                        # (an emulated share is its own one-process job whatever RANK selects)
         ms = elapsed / args.steps * 1e3
         result = {
             "metric": "edges aggregated/sec, TensorGNAN forward", "value": E / (elapsed / args.steps),
-            "unit": "edges/s", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "unit": "edges/s", "n_gpus": world, "ranks_seen": dist.get_world_size() if grouped else 1,
+            "process_group": dist.get_backend() if grouped else None, "collectives_forced": bool(args.force_dist) or None,
+            "rank_ms_per_step": rank_ms, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.operand == "f32" else "bf16 operand storage, f32 accumulate",
             "data": "synthetic",
             "config": {"workload": workload, "nodes": N, "edges": E, "stored_pairs_rank0": g.nnz,
                        "operand_width": W, "partition": f"{partition} x{world}", "exchange":
-                       "none" if world == 1 else ("all_reduce(column sums [W])" if partition == "halo" else
+                       "none" if not grouped else ("all_reduce(column sums [W])" if partition == "halo" else
                                                   "all_gather(operand [N,W])" if partition == "vertex" else
                                                   "all_to_all_v(listed remote operand rows [n_halo,W]) + all_reduce(column sums [W])"
                                                   if partition == "exchange" else "all_reduce(out [N,C])")},
@@ -1009,7 +1032,7 @@ def main():
             result["sustained_ms_per_step"] = (time.perf_counter() - t0) / n_sus * 1e3
             result["sustained_steps"] = n_sus
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -76,6 +76,7 @@ class HopBlocks:
         self.n_graphs = len(self.sizes)
         self.total_nodes = sum(self.sizes)
         self.max_nodes = max(self.sizes) if self.sizes else 0
+        self.min_nodes = min(self.sizes) if self.sizes else 0      # 0: a gap in the graph ids (an empty graph; the reference's scatter_add gives it zeros)
         self.n_codes = int(max_hop) + 2                      # hop counts 0 .. max_hop + the (weightless) rest code
         self._csr = None
         self._batch_vector = None
@@ -325,7 +326,9 @@ class TensorGNAN(_PathBase):
         _lib.require_device(x_batch)
         blocks = self._blocks(dist_batch, batch_vector)
         f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
-        if (BATCH_KERNEL and blocks is not None and not self._dropout_active() and 1 <= blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
+        # (a graph without nodes — a gap in batch_vector's ids — has no workgroup to write its row: the CSR route gives it zeros)
+        if (BATCH_KERNEL and blocks is not None and not self._dropout_active() and 1 <= blocks.min_nodes
+                and blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
                 and blocks.total_nodes <= BATCH_KERNEL_MAX_TOTAL_NODES and blocks.n_codes <= 256 and f.H <= 64 and f.C <= 8 and x_batch.dtype == torch.float32
                 and not x_batch.requires_grad and blocks.n_graphs <= 65535):
             fm, rm = (f.L, f.H, f.C, f.F), (rho.L, rho.H, rho.C)
@@ -346,6 +349,7 @@ class TensorGNAN(_PathBase):
             # weighted sum runs in torch on the device — the cold path, like the shape functions' (_check_dropout).
             deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
             row_of_pair = torch.repeat_interleave(torch.arange(g.n_rows, device=deg.device), deg)
+            self._stores["rho"].direct_use()                                                # (the module itself joins the autograd graph)
             w_pair = self.rho(hops[g.code.long()])                                          # [nnz, C], one mask per pair
             Y = torch.zeros_like(S).index_add(0, row_of_pair, w_pair * S[g.col.long()])
         else:
@@ -410,6 +414,7 @@ class GraphedBatchStep:
         self.labels = torch.empty_like(labels)
         self.blocks = HopBlocks(self.code, self.node_off, self.code_off, [0] * self.n_graphs, self.n_codes - 2)
         self.blocks.total_nodes, self.blocks.max_nodes, self.blocks.slots = self.node_capacity, BATCH_KERNEL_MAX_NODES, True
+        self.blocks.min_nodes = 1                            # (fits() admits batches of non-empty graphs only)
         self._labels_shape = tuple(labels.shape)
         self.load(x, blocks, labels)
         self.step = GraphedStep(model, None, lambda out: (loss_of(out, self.labels), None), optimizer,
@@ -417,6 +422,7 @@ class GraphedBatchStep:
 
     def fits(self, x, blocks: HopBlocks, labels) -> bool:
         return bool(blocks.n_graphs == self.n_graphs and x.shape[1] == self.F and blocks.total_nodes <= self.node_capacity
+                    and blocks.min_nodes >= 1
                     and blocks.n_codes <= self.n_codes and blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
                     and int(blocks.code.numel()) <= self.code_capacity and x.dtype == torch.float32 and x.is_cuda
                     and (not hasattr(self, "_labels_shape") or tuple(labels.shape) == self._labels_shape))
@@ -459,15 +465,35 @@ def train_epoch(model: "TensorGNAN", loader, loss_fn, optimizer, steps: Optional
         blocks = dist if isinstance(dist, HopBlocks) else model._blocks(dist, bv)
         out = None
         if blocks is not None and GRAPHED_BATCH_STEPS and not model._dropout_active():
+            # a captured step belongs to the (model, loss, optimizer) it was captured with: another loss callable or optimizer
+            # handed in with the same dict starts over
+            owner = (id(model), id(loss_fn), id(optimizer))
+            if steps.get("owner") != owner:
+                for k in [k for k in steps if k != "owner"]:
+                    old = steps.pop(k)
+                    if isinstance(old, GraphedBatchStep):
+                        old.step.release(restore_optimizer=True)
+                steps["owner"] = owner
             gs = steps.get(blocks.n_graphs)
-            if gs is None and blocks.total_nodes <= BATCH_KERNEL_MAX_TOTAL_NODES and blocks.max_nodes <= BATCH_KERNEL_MAX_NODES:
+            if (gs is None and blocks.total_nodes <= BATCH_KERNEL_MAX_TOTAL_NODES and blocks.max_nodes <= BATCH_KERNEL_MAX_NODES
+                    and blocks.min_nodes >= 1):
+                from .graphed import CaptureFailed
                 try:
                     gs = steps[blocks.n_graphs] = GraphedBatchStep(model, optimizer, loss_fn, x, blocks, y,
                                                                    prepared=steps.get("prepared"))
                     steps["prepared"] = gs.step.prepared
                     out, loss = gs.step.warmup_result[0], gs.step.warmup_result[1]     # (construction ran this batch's step)
-                except Exception:                                        # noqa: BLE001  (not capturable here: eager from now on)
+                except (CaptureFailed, ValueError) as e:
+                    # not capturable (a loss callable that synchronises, an optimizer without a capturable mode, a first batch
+                    # that does not fit its own slots): this number of graphs stays on the eager loop.  Anything else — out of
+                    # memory, an ABI mismatch — is the caller's to see.  If the construction already STEPPED this batch (its
+                    # warm-up step is a real one) that step is this batch's: stepping it again would update twice.
+                    import warnings
+                    warnings.warn(f"gnan_amd.batched: batches of {blocks.n_graphs} graphs stay on the eager loop ({e})")
                     steps[blocks.n_graphs] = gs = False
+                    done = getattr(e, "warmup_result", None)
+                    if done is not None:
+                        out, loss = done[0], done[1]
             elif gs:
                 got = gs.run(x, blocks, y)
                 if got is not None:

@@ -355,6 +355,8 @@ __global__ __launch_bounds__(256) void small_graph_nam_bwd_kernel(const NamBwdPa
   else gnan_bwd::feature_grads<1, false>(p.r, 0, 0, D, 0, nodrop, u_of, gl_of, red);
 }
 
+constexpr int kMaxBwdWorkgroups = 128;
+
 template <int CN>
 int launch_nam_bwd(const NamBwdParams& p, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_nam_bwd_kernel<CN>),
@@ -413,6 +415,13 @@ extern "C" int gnan_small_graph_nam_fwd(const gnan_small_graph_nam_args* a, gnan
 extern "C" int gnan_small_graph_nam_bwd(const gnan_small_graph_nam_bwd_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "small_graph_nam_bwd: null args");
   if (int rc = check_common("small_graph_nam_bwd", a->n, a->F, a->D, &a->f, &a->rho, &a->nam)) return rc;
+  // Workgroup F waits for the F producers of the same launch.  They wait for nobody, so the wait ends as soon as every one
+  // of them has been dispatched — whatever order the dispatcher picks — PROVIDED a producer can always find a free slot next
+  // to the waiting workgroup: the launch is kept small enough (at most one workgroup per compute unit of the smallest
+  // gfx950 part) that producers and the waiter are resident together even with other work on the device.
+  if (a->F + 1 > kMaxBwdWorkgroups)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_graph_nam_bwd: covers F <= %d features (one co-resident workgroup each; got F=%d)",
+                      kMaxBwdWorkgroups - 1, a->F);
   GNAN_REQUIRE(a->x && a->code && a->fx && a->lut && a->hidden && a->d_out, "small_graph_nam_bwd: null x / code / fx / lut / hidden / d_out");
   GNAN_REQUIRE(a->x_stride >= a->F && (a->cnt == nullptr || a->cnt_stride >= a->D), "small_graph_nam_bwd: row stride smaller than the width");
   GNAN_REQUIRE(grads_ok(&a->f, &a->df) && grads_ok(&a->rho, &a->drho),

@@ -50,6 +50,16 @@ import torch
 import torch.distributed as dist
 
 
+# A one-rank process group normally skips every collective.  With this switch on (``bench.py --force-dist``, the RCCL tests on a
+# one-GPU box) a rank talks to its group whatever its size: communicator creation, every collective's RCCL launch and the
+# all-reduce captured in :class:`SharePipeline`'s hipGraphs run on a world of one exactly as they would on eight.
+ALWAYS_COMMUNICATE = False
+
+
+def _communicates(world: int) -> bool:
+    return world > 1 or (ALWAYS_COMMUNICATE and dist.is_available() and dist.is_initialized())
+
+
 @dataclass
 class VertexPartition:
     n_nodes: int
@@ -124,7 +134,7 @@ class _SumOverRanks(torch.autograd.Function):
 def gather_operand(local: torch.Tensor, part: VertexPartition, group=None) -> torch.Tensor:
     """All-gather the per-node operand rows; returns the ``[n_nodes, W]`` prefix of the padded buffer.  Differentiable:
     the gradient of the gathered operand is reduce-scattered back to the owners of its rows."""
-    if part.world == 1:
+    if not _communicates(part.world):
         return local
     W = local.shape[1]
     if local.shape[0] != part.block:
@@ -157,7 +167,7 @@ def partitioned_forward(x_local: torch.Tensor, graph_local, stacked, lut: torch.
     operand_local, total = ops["feature_mlps"](x_local, stacked, order == "sum_first", return_total=True, **kw)
     mark("fmlp")
     operand = gather_operand(operand_local, part, group)
-    if part.world > 1:                       # one rank: no exchange, no event (every recorded event is a barrier packet)
+    if _communicates(part.world):            # one rank: no exchange, no event (every recorded event is a barrier packet)
         mark("gather")
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         mark("total")
@@ -241,7 +251,7 @@ def feature_parallel_forward(x_cols: torch.Tensor, graph_full, stacked_local, lu
         mark("fmlp")
         Y = x_cols.new_zeros((n, out_channels))
     mark("spmm")
-    if part.world > 1:
+    if _communicates(part.world):
         if torch.is_grad_enabled() and Y.requires_grad:
             Y = _SumOverRanks.apply(Y, group)
         else:
@@ -309,7 +319,7 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, total_rows=plan.n_own, **kw)
     mark("fmlp")
     rc = out_channels if order == "reference" else 0
-    if part.world > 1 and not torch.is_grad_enabled() and "rest_total_term" in ops:
+    if _communicates(part.world) and not torch.is_grad_enabled() and "rest_total_term" in ops:
         # inference: the aggregation does not wait for the all-reduce of the 256-byte column sums (tens of microseconds of
         # collective latency against ~0.6 ms of kernel on a 1/8 share) — it runs against zero sums, i.e. computes
         # sum_d (wt_d - wt_rest) * S, and the wt_rest * total term is added once the collective has landed
@@ -324,7 +334,7 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
         mark("spmm")
         return Y
     shared = {}
-    if part.world > 1:
+    if _communicates(part.world):
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         mark("total")
         shared = {"total_group": group}          # backward: the ranks add their rest-bucket vectors over the same group
@@ -383,7 +393,7 @@ def build_exchange_plan(graph_local, part: VertexPartition, group=None) -> Excha
     world, dev = part.world, plan.halo.device
     owner = torch.div(plan.halo, part.block, rounding_mode="floor")
     recv_counts = torch.bincount(owner, minlength=world).tolist()
-    if world == 1:
+    if not _communicates(world):
         return ExchangePlan(plan, [None], recv_counts)
     counts = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
     all_counts = [torch.empty_like(counts) for _ in range(world)]
@@ -439,7 +449,7 @@ def halo_exchange_forward(x_own: torch.Tensor, xplan: ExchangePlan, stacked, lut
     own, total = ops["feature_mlps"](x_own, stacked, order == "sum_first", return_total=True, **kw)
     mark("fmlp")
     shared = {}
-    if part.world > 1:
+    if _communicates(part.world):
         operand = torch.cat([own, _HaloExchange.apply(own, xplan, group)], dim=0)       # [own | halo]: the plan's column order
         mark("gather")
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)

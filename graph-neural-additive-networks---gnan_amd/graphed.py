@@ -241,6 +241,9 @@ class FlatAdamStep:
         names = [(st, name) for st in stores for name in st.buf]
         if not names or any(not st.consistent() or name not in st.grad for st, name in names):
             return None
+        flats = [st.flat[name] for st, name in names]
+        if {id(p) for p in group["params"]} == {id(p) for p in flats} and len(group["params"]) == len(flats):
+            return FlatAdamStep._over_flat_parameters(optimizer, names, flats)
         pairs = [st.views_like(name, st.buf[name]) for st, name in names]
         covered = {id(p) for pr in pairs for p, _ in pr}
         if covered != {id(p) for p in group["params"]} or len(covered) != sum(len(pr) for pr in pairs):
@@ -277,6 +280,46 @@ class FlatAdamStep:
             self.step_of.append(self.steps[at - 1])
         self.optimizer = optimizer
         self.whole = list(zip(self.P, self.G))                       # the stores' own tensors (valid() compares identities)
+        self._split()
+        return self
+
+    @staticmethod
+    def _over_flat_parameters(optimizer, names, flats) -> Optional["FlatAdamStep"]:
+        """The optimizer was built over ``model.parameters()`` — the flat Parameters themselves (``modules.FLAT_PARAMETERS``):
+        its own state tensors ARE flat already.  What this object adds to ``optimizer.step()`` is the skip flag of a guarded
+        replay and the cut into chunk-sized pieces (:meth:`_split`); state that does not exist yet is created as the optimizer
+        would create it (zeros, step 0)."""
+        group = optimizer.param_groups[0]
+        state = optimizer.state
+        if any(p.grad is not None and p.grad.is_sparse for p in flats):
+            return None
+        self = FlatAdamStep()
+        self.decoupled = bool(group.get("decoupled_weight_decay", False))
+        dev = flats[0].device
+        seen = [state[p]["step"] for p in flats if p in state and "step" in state[p]]
+        if seen and len(seen) != len(flats):
+            return None
+        if seen:
+            all_steps = torch.stack([s.detach().to(dev, torch.float32).reshape(()) for s in seen])
+            if bool((all_steps != all_steps[0]).any()):
+                return None
+            start = all_steps[0].clone()
+        else:
+            start = torch.zeros((), dtype=torch.float32, device=dev)
+        self.steps = start.repeat(len(flats)).contiguous()
+        for at, ((st, name), fp) in enumerate(zip(names, flats)):
+            old = state.get(fp)
+            if old and "exp_avg" in old:
+                M, V = old["exp_avg"], old["exp_avg_sq"]
+                if M.shape != fp.shape or not M.is_contiguous() or not V.is_contiguous() or M.device != fp.device:
+                    return None
+            else:
+                M, V = torch.zeros_like(fp.data), torch.zeros_like(fp.data)
+            state[fp] = {"step": self.steps[at], "exp_avg": M, "exp_avg_sq": V}
+            self.P.append(st.buf[name]); self.G.append(st.grad[name]); self.M.append(M); self.V.append(V)
+            self.step_of.append(self.steps[at])
+        self.optimizer = optimizer
+        self.whole = list(zip(self.P, self.G))
         self._split()
         return self
 
@@ -423,9 +466,10 @@ class GraphedStep:
             self.guard = None                     # the optimizer's own update cannot be skipped on the device: check before replaying
         try:
             self.graph = GraphedCallable(step, warmup=0, before_capture=clear, guard=self.guard)
-        except CaptureFailed:
+        except CaptureFailed as e:
             if self._own_prepared:
                 self.prepared.restore()
+            e.warmup_result = self.warmup_result      # warm-up steps were REAL steps: the caller must not step this input again
             raise
         self.outputs, self.loss, self.extras = self.graph.out
         self._probes = _probe_params(model)

@@ -57,6 +57,13 @@ def _tiny_init(module: nn.Module) -> None:
 
 GRAPH_CACHE_ENTRIES = 8192   # hop-coded graphs kept per model (graph tasks cycle through a few thousand small graphs per epoch)
 
+# ``model.parameters()`` hands out the flat buffers (a dozen Parameters) instead of the F x L per-layer tensors that are views of
+# them: what a stock optimizer built as main.py:141 builds it — ``Adam(model.parameters())`` — then zeroes and updates per step is
+# twelve tensors, not 8604 (Cora shape).  Every element-wise optimizer (Adam, AdamW, SGD, ...) computes the same numbers either
+# way; ``named_parameters()`` / ``state_dict()`` keep the reference's per-layer names and shapes (``sum(p.numel())``, main.py:92-97,
+# is the same).  False: ``parameters()`` is torch's own.
+FLAT_PARAMETERS = True
+
 
 class FlatMLPStore:
     """The F x L per-feature ``nn.Linear`` parameters of a ``ModuleList`` of identical MLPs, re-homed into six
@@ -71,6 +78,7 @@ class FlatMLPStore:
 
     def __init__(self, mlps):
         self.mlps = mlps
+        self.flat = {}                                 # name -> Parameter over buf[name] (same storage); identity survives rebuilds
         self.rebuild()
 
     def rebuild(self) -> None:
@@ -98,6 +106,22 @@ class FlatMLPStore:
                 if self.has_bias:
                     self.buf[part + "_b"] = home(layers, "bias")
         self.grad, self.grad_views, self.pending = {}, {}, {}
+        track = bool(lin[0][-1].weight.requires_grad)
+        for name, buf in self.buf.items():
+            fp = self.flat.get(name)
+            if fp is None:
+                self.flat[name] = nn.Parameter(buf, requires_grad=track)
+            else:                                     # moved (.to() / .float()): an optimizer built over the flat Parameters keeps them
+                fp.data = buf
+                fp.grad = None
+
+    def params(self):
+        """Every per-layer Parameter that is a view of this store's buffers."""
+        for layers in self.lin:
+            for m in layers:
+                yield m.weight
+                if m.bias is not None:
+                    yield m.bias
 
     def consistent(self) -> bool:
         """Cheap guard: the first and the last Parameter still live inside the buffers."""
@@ -146,13 +170,20 @@ class FlatMLPStore:
         return (p0.grad is not None and p1.grad is not None and p0.grad.data_ptr() == g[0, 0].data_ptr()
                 and p1.grad.data_ptr() == g[-1, -1].data_ptr())
 
+    def _occupied(self, name: str) -> bool:
+        """Does the flat gradient buffer hold gradients a new one must be ADDED to?  Not after either kind of caller zeroed
+        them: ``zero_grad()`` of an optimizer over ``model.parameters()`` drops the flat Parameter's ``.grad`` (the per-layer
+        views stay linked to the buffer — nothing of size F x L happens per step), one over the per-layer Parameters drops
+        theirs.  (``set_to_none=False`` zeroes the shared buffer in place, and adding to zeros is right.)"""
+        return self._linked(name) and self.flat[name].grad is not None
+
     def grad_dest(self, name: str, shape, device) -> Optional[torch.Tensor]:
         """Where a gradient kernel may write the stacked gradient of ``buf[name]`` directly — the flat gradient buffer, in the
         kernel's view of it — or None when the buffer holds gradients that must be added to (``.grad`` already linked: a
         second backward pass before ``zero_grad``) or has been handed out already.  The tensor comes back through autograd as
         the proxy leaf's gradient; :meth:`_on_grad` recognises it and only links the views (no copy: 5 us per buffer, twelve
         per step of a small graph)."""
-        if self.pending.get(name) or self._linked(name) or self.buf[name].dtype != torch.float32:
+        if self.pending.get(name) or self._occupied(name) or self.buf[name].dtype != torch.float32:
             return None
         if name not in self.grad:
             self.grad[name] = torch.empty_like(self.buf[name])
@@ -169,19 +200,36 @@ class FlatMLPStore:
         have = self.grad.get(name)
         if self.pending.get(name) and have is not None and g.data_ptr() == have.data_ptr() and g.numel() == have.numel():
             self.pending[name] = False                # written in place by the kernel (grad_dest)
+        else:
+            g = g.reshape(full.shape).to(full.dtype)
+            if self._occupied(name) or self.pending.get(name):
+                self.grad[name].add_(g)               # ordinary autograd accumulation, on the flat buffer (a pending direct
+            else:                                     # write already sits in it)
+                if name not in self.grad:
+                    self.grad[name] = torch.empty_like(full)
+                self.grad[name].copy_(g)              # the buffer (and the views cut from it) persists across steps
+        if not self._linked(name):
+            self._link_grads(name)
+        fp = self.flat[name]
+        if fp.grad is not self.grad[name]:
+            fp.grad = self.grad[name]
+
+    def direct_use(self) -> None:
+        """Call before the per-layer modules themselves (``self.mlps[k](x)``) take part in an autograd graph: autograd then
+        accumulates straight into the per-layer ``.grad`` tensors, so these must be views of the flat gradient buffers and the
+        flat Parameters must show those buffers — zeroed first if the last ``zero_grad`` dropped them."""
+        if not (torch.is_grad_enabled() and self.lin[0][-1].weight.requires_grad):
+            return
+        for name, buf in self.buf.items():
+            if name not in self.grad:
+                self.grad[name] = torch.zeros_like(buf)
+            elif not self._occupied(name):
+                self.grad[name].zero_()
+            self.pending[name] = False
             if not self._linked(name):
                 self._link_grads(name)
-            return
-        g = g.reshape(full.shape).to(full.dtype)
-        if self._linked(name) or self.pending.get(name):
-            self.grad[name].add_(g)                   # ordinary autograd accumulation, on the flat buffer (a pending direct
-            if not self._linked(name):                # write already sits in it)
-                self._link_grads(name)
-        else:
-            if name not in self.grad:
-                self.grad[name] = torch.empty_like(full)
-            self.grad[name].copy_(g)                  # the buffer (and the views cut from it) persists across steps
-            self._link_grads(name)
+            if self.flat[name].grad is not self.grad[name]:
+                self.flat[name].grad = self.grad[name]
 
     def stacked(self, track_grad: bool) -> StackedMLP:
         out = {}
@@ -206,6 +254,66 @@ class _PathBase(nn.Module):
         # hop-coded graphs derived from the inputs' tensors, found again by the identity of those tensor objects (not by
         # their addresses: the allocator recycles those between the graphs of a batch_size=1 loop, trainer.py:46)
         self._graph_cache = TensorKeyedCache(GRAPH_CACHE_ENTRIES)
+
+    def _mlp_groups(self):
+        """``(store name, MLPs)`` of the per-feature networks this module owns (what ``_stacked`` is called with)."""
+        groups = []
+        if isinstance(getattr(self, "fs", None), nn.ModuleList):
+            groups.append(("fs", self.fs))
+        if isinstance(getattr(self, "rho", None), nn.Sequential):
+            groups.append(("rho", [self.rho]))
+        return groups
+
+    def _ensure_stores(self) -> None:
+        for name, mlps in self._mlp_groups():
+            store = self._stores.get(name)
+            if store is None:
+                self._stores[name] = FlatMLPStore(mlps)
+            elif not store.consistent():
+                store.rebuild()
+
+    def parameters(self, recurse: bool = True):
+        """The flat buffers (see ``FLAT_PARAMETERS``) followed by whatever Parameter lies in none of them (``rhos[0 .. F-2]`` of
+        ``GNAN(rho_per_feature=True)``, GNAN.py:108-123: tensors no forward reads).  ``named_parameters()`` is torch's own."""
+        if not (FLAT_PARAMETERS and recurse and "_stores" in self.__dict__):
+            yield from super().parameters(recurse)
+            return
+        flats, managed = [], set()
+        for m in self.modules():
+            if isinstance(m, _PathBase) and "_stores" in m.__dict__:
+                m._ensure_stores()
+                for store in m._stores.values():
+                    flats.extend(store.flat[name] for name in store.buf)
+                    managed.update(id(p) for p in store.params())
+        yield from flats
+        for p in super().parameters(recurse=True):
+            if id(p) not in managed:
+                yield p
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """``Module.zero_grad`` for BOTH faces of the parameters: the flat Parameters (``parameters()``) and the per-layer views
+        whose ``.grad`` are views of the same gradient buffers.  (An optimizer's own ``zero_grad()`` only knows the Parameters
+        it was given: over ``model.parameters()`` it drops the flat gradients and leaves the per-layer ``.grad`` views standing
+        — stale until the next backward pass rewrites the buffer they look into; nothing of size F x L happens per step.)"""
+        super().zero_grad(set_to_none)
+        for m in self.modules():
+            for store in getattr(m, "_stores", {}).values():
+                store.pending.clear()
+                for name, g in store.grad.items():
+                    if not set_to_none:
+                        g.zero_()
+                    elif store._linked(name):
+                        for p, _ in store.grad_views.get(name, ()):
+                            p.grad = None
+
+    def requires_grad_(self, requires_grad: bool = True):
+        for _, p in self.named_parameters():
+            p.requires_grad_(requires_grad)
+        for m in self.modules():
+            for store in getattr(m, "_stores", {}).values():
+                for fp in store.flat.values():
+                    fp.requires_grad_(requires_grad)
+        return self
 
     def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): every Parameter moved on its own
         out = super()._apply(fn, *args, **kwargs)

@@ -184,12 +184,15 @@ def _nam_mlp(keep, L, H, C) -> "_lib.SmallMlp":
     return _small_mlp(keep, L, H, C)
 
 
+SMALL_GRAPH_NAM_MAX_FEATURES = 127   # the backward's workgroups (one per feature + rho's) must be resident together (csrc/small_graph_nam.hip)
+
+
 def small_graph_nam_applies(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: StackedMLP, nam: StackedMLP) -> bool:
     """Can ``gnan_small_graph_nam_fwd`` / ``_bwd`` take this graph-level forward with a NAM read-out?"""
     stacks = tuple(f[:6]) + tuple(rho[:6]) + tuple(nam[:6])
     return bool(SMALL_GRAPH_NAM and g.is_dense and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
                 and 1 <= x.shape[0] <= SMALL_GRAPH_MAX_NODES and g.n_rows == g.n_cols == x.shape[0] and g.n_codes <= 64
-                and x.shape[1] == f.F == nam.F and rho.F == 1 and f.C == 1 and rho.C == 1 and f.L in (2, 3) and rho.L in (2, 3)
+                and x.shape[1] == f.F == nam.F and f.F <= SMALL_GRAPH_NAM_MAX_FEATURES and rho.F == 1 and f.C == 1 and rho.C == 1 and f.L in (2, 3) and rho.L in (2, 3)
                 and nam.L in (1, 2, 3) and 1 <= f.H <= 64 and 1 <= rho.H <= 64 and (nam.L == 1 or 1 <= nam.H <= 64)
                 and 1 <= nam.C <= 8 and all(t is None or t.dtype == torch.float32 for t in stacks))
 

@@ -48,3 +48,56 @@ def tolerance_ok(y, ref32, truth64, floor=1e-5):
     e_build = O.rel_err(as_t(y), t)
     e_ref = O.rel_err(as_t(ref32), t)
     return e_build <= max(floor, e_ref), e_build, e_ref
+
+
+def _np64(v):
+    if v is None:
+        return None
+    if torch.is_tensor(v):
+        return v.detach().cpu().double().numpy()
+    return np.asarray(v, dtype=np.float64)
+
+
+def grad_rule(got, truth64, ref32=None, floor=1e-5):
+    """The tolerance rule of SURVEY section 8c applied to a set of parameter gradients as ONE vector: the largest deviation
+    from the float64 truth over all parameters, relative to the largest float64 gradient entry, must not exceed
+    ``max(floor, the same figure for the float32 reference)``.  ``got`` / ``truth64`` / ``ref32``: ``{name: array or tensor}``
+    (a missing or ``None`` entry counts as zeros; ``ref32=None``: no float32 reference, the bound is the floor).  ``ref32`` may
+    be a callable returning that dict: it is evaluated only when the build's error exceeds the floor (a float32 oracle pass
+    over a whole configuration costs minutes of host time and cannot change a verdict the floor already gives).
+    Returns ``(ok, e_build, e_ref, worst_name)``."""
+    if callable(ref32):
+        ok, e_build, _, worst = grad_rule(got, truth64, None, floor)
+        if ok:
+            return ok, e_build, float("nan"), worst
+        ref32 = ref32()
+    truth = {k: _np64(v) for k, v in truth64.items() if v is not None}
+    scale = max(float(np.abs(v).max()) for v in truth.values())
+    e_build, e_ref, worst = 0.0, 0.0, None
+    for k in set(truth) | {k for k, v in got.items() if v is not None}:
+        t = truth.get(k)
+        g = _np64(got.get(k))
+        if t is None:
+            t = np.zeros_like(g)
+        if g is None:
+            g = np.zeros_like(t)
+        e = float(np.abs(g.reshape(t.shape) - t).max()) / scale
+        if e > e_build:
+            e_build, worst = e, k
+        if ref32 is not None:
+            r = _np64(ref32.get(k))
+            r = np.zeros_like(t) if r is None else r
+            e_ref = max(e_ref, float(np.abs(r.reshape(t.shape) - t).max()) / scale)
+    return e_build <= max(floor, e_ref), e_build, e_ref, worst
+
+
+def module_grads(mod):
+    return {k: p.grad for k, p in mod.named_parameters()}
+
+
+def oracle_grads(loss_of_params, params, dtype):
+    """Gradients of ``loss_of_params(p)`` with the parameters cast to ``dtype`` (float32: the reference's own arithmetic
+    restated by the oracle; float64: the truth)."""
+    p = {k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+    loss_of_params(p).backward()
+    return {k: v.grad for k, v in p.items()}

@@ -20,9 +20,15 @@ def _make(kind):
     else:
         m = TensorGNAN(6, 1, 3, hidden_channels=8)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             p.normal_(0, 0.5)
     return m
+
+
+def _params(m, how):
+    """``flat``: ``model.parameters()`` — the flat buffers themselves (modules.FLAT_PARAMETERS; what main.py:141 hands its
+    optimizer); ``per_layer``: the F x L tensors of ``named_parameters()`` that are views of them."""
+    return list(m.parameters()) if how == "flat" else [p for _, p in m.named_parameters()]
 
 
 def _stores(m):
@@ -41,12 +47,13 @@ def _give_grads(m, seed):
             st._on_grad(name, torch.randn(buf.shape, generator=g))
 
 
+@pytest.mark.parametrize("how", ["flat", "per_layer"])
 @pytest.mark.parametrize("kind", ["readout", "plain"])
 @pytest.mark.parametrize("cls,kw", [(torch.optim.Adam, {"weight_decay": 1e-2}), (torch.optim.AdamW, {"weight_decay": 0.1}),
                                     (torch.optim.Adam, {})])
-def test_flat_update_equals_the_optimizer_step(kind, cls, kw):
+def test_flat_update_equals_the_optimizer_step(kind, cls, kw, how):
     a, b = _make(kind), _make(kind)
-    oa, ob = (cls(m.parameters(), lr=1e-2, fused=True, **kw) for m in (a, b))
+    oa, ob = (cls(_params(m, how), lr=1e-2, fused=True, **kw) for m in (a, b))
     flat = None
     for it in range(6):
         for m, o in ((a, oa), (b, ob)):
@@ -55,7 +62,7 @@ def test_flat_update_equals_the_optimizer_step(kind, cls, kw):
         oa.step()
         if it == 2:                                   # two ordinary steps first: their state is carried over
             flat = FlatAdamStep.build(b, ob)
-            assert flat is not None and flat.buffers < len(list(b.parameters()))
+            assert flat is not None and flat.buffers == len(list(b.parameters())) < len(list(b.named_parameters()))
         flat.step() if flat is not None else ob.step()
         if it == 4:                                   # the ordinary step keeps working on the views
             for m, o in ((a, oa), (b, ob)):
@@ -79,22 +86,69 @@ def test_flat_update_equals_the_optimizer_step(kind, cls, kw):
     assert not flat.intact(ob)
 
 
-def test_flat_update_declines_what_it_cannot_reproduce():
+@pytest.mark.parametrize("how", ["flat", "per_layer"])
+def test_flat_update_declines_what_it_cannot_reproduce(how):
     m = _make("plain")
     _give_grads(m, 0)
-    ok = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+    ok = torch.optim.Adam(_params(m, how), lr=1e-2, fused=True)
     assert FlatAdamStep.build(m, ok) is not None
-    assert FlatAdamStep.build(m, torch.optim.SGD(m.parameters(), lr=1e-2)) is None
-    assert FlatAdamStep.build(m, torch.optim.Adam(m.parameters(), lr=1e-2, fused=True, amsgrad=True)) is None
-    assert FlatAdamStep.build(m, torch.optim.Adam(m.parameters(), lr=1e-2)) is None                     # not the fused update
-    ps = list(m.parameters())
+    assert FlatAdamStep.build(m, torch.optim.SGD(_params(m, how), lr=1e-2)) is None
+    assert FlatAdamStep.build(m, torch.optim.Adam(_params(m, how), lr=1e-2, fused=True, amsgrad=True)) is None
+    assert FlatAdamStep.build(m, torch.optim.Adam(_params(m, how), lr=1e-2)) is None                     # not the fused update
+    ps = _params(m, how)
     assert FlatAdamStep.build(m, torch.optim.Adam([{"params": ps[:3]}, {"params": ps[3:], "lr": 1e-3}], fused=True)) is None
     assert FlatAdamStep.build(m, torch.optim.Adam(ps[:-1], lr=1e-2, fused=True)) is None                # a parameter left out
     extra = torch.nn.Parameter(torch.zeros(3))
     assert FlatAdamStep.build(m, torch.optim.Adam(ps + [extra], lr=1e-2, fused=True)) is None           # one from elsewhere
     fresh = _make("gnan")                              # no backward pass yet: no gradient buffers
     _stores(fresh)
-    assert FlatAdamStep.build(fresh, torch.optim.Adam(fresh.parameters(), lr=1e-2, fused=True)) is None
+    assert FlatAdamStep.build(fresh, torch.optim.Adam(_params(fresh, how), lr=1e-2, fused=True)) is None
     # rho_per_feature: rhos[0 .. F-2] are Parameters no forward ever reads (GNAN.py:108-123, 137) — they lie in no store
     _give_grads(fresh, 0)
-    assert FlatAdamStep.build(fresh, torch.optim.Adam(fresh.parameters(), lr=1e-2, fused=True)) is None
+    assert FlatAdamStep.build(fresh, torch.optim.Adam(_params(fresh, how), lr=1e-2, fused=True)) is None
+
+
+def test_parameters_are_the_flat_buffers_and_names_stay_the_references():
+    """``model.parameters()``: a dozen flat Parameters (+ the tensors no store holds) with the element count of
+    ``named_parameters()`` (main.py:92-97 sums ``numel``); names, shapes and ``state_dict`` keys are the per-layer ones;
+    an in-place update of a flat Parameter is an update of the per-layer views; a stock optimizer over ``parameters()``
+    steps to the same numbers as one over the per-layer tensors; ``zero_grad`` of either kind is honoured."""
+    from gnan_amd import modules
+    for kind in ("readout", "gnan", "plain"):
+        m, twin = _make(kind), _make(kind)
+        flat, named = list(m.parameters()), dict(m.named_parameters())
+        assert sum(p.numel() for p in flat) == sum(p.numel() for p in named.values())
+        assert len({id(p) for p in flat}) == len(flat) and len(flat) < len(named)
+        assert list(m.state_dict().keys()) == list(twin.state_dict().keys())
+        with torch.no_grad():
+            flat[0].mul_(2.0)
+        assert torch.equal(named["fs.0.0.weight"], 2.0 * dict(twin.named_parameters())["fs.0.0.weight"])
+        with torch.no_grad():
+            flat[0].mul_(0.5)
+        oa = torch.optim.Adam(m.parameters(), lr=1e-2, weight_decay=1e-3)                 # main.py:141
+        ob = torch.optim.Adam([p for _, p in twin.named_parameters()], lr=1e-2, weight_decay=1e-3)
+        for it in range(3):
+            oa.zero_grad()
+            ob.zero_grad()
+            _give_grads(m, it)
+            _give_grads(twin, it)
+            if it == 1:                                    # a second backward pass before the step: gradients add up, both ways
+                _give_grads(m, 50)
+                _give_grads(twin, 50)
+            for (k, p), (_, q) in zip(m.named_parameters(), twin.named_parameters()):
+                if k.startswith("rhos.") and not k.startswith(f"rhos.{len(m.fs) - 1}."):
+                    assert p.grad is None
+                else:
+                    assert torch.equal(p.grad, q.grad), k
+            oa.step()
+            ob.step()
+        for (k, p), (_, q) in zip(m.named_parameters(), twin.named_parameters()):
+            assert float((p - q).abs().max()) <= 1e-6 * float(q.abs().max()), k
+        m.requires_grad_(False)
+        assert not any(p.requires_grad for p in m.parameters()) and not any(p.requires_grad for _, p in m.named_parameters())
+    try:
+        modules.FLAT_PARAMETERS = False
+        m = _make("plain")
+        assert len(list(m.parameters())) == len(list(m.named_parameters()))
+    finally:
+        modules.FLAT_PARAMETERS = True

@@ -147,7 +147,7 @@ def test_full_size_pre_rho_normalisation(c4):
     for name, cls in (("pre", standalone.TensorGNAN), ("post", models.TensorGNAN)):
         m = cls(F, 1, 3, hidden_channels=64, device=DEV)
         with torch.no_grad():
-            for p in m.parameters():
+            for _, p in m.named_parameters():
                 p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
         mods[name] = m.to(DEV).eval()
 

@@ -48,7 +48,7 @@ def _model(F, C, seed=0):
     torch.manual_seed(seed)
     m = TensorGNAN(F, C, 3, hidden_channels=32, device=DEV)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             if p.dim() == 2:
                 torch.nn.init.xavier_normal_(p, gain=1.0)
             else:
@@ -113,7 +113,7 @@ def test_captured_steps_update_the_flat_buffers_bit_for_bit(n, F, C, dense, opt_
         assert rec["step"] is not None and rec["step"].graph.replays >= 9
         assert (rec["step"].flat is not None) == flat
         if flat:
-            assert rec["step"].flat.buffers <= 12 < len(list(m.parameters())) and len(rec["step"].flat.P) <= 36
+            assert rec["step"].flat.buffers <= 12 < len(list(m.named_parameters())) and len(rec["step"].flat.P) <= 36
         runs[flat] = ({k: v.detach().clone() for k, v in m.state_dict().items()}, copy.deepcopy(opt.state_dict()), m, opt, rec)
     for k, v in runs[False][0].items():
         assert torch.equal(v, runs[True][0][k]), k
@@ -242,7 +242,7 @@ def test_moved_parameters_invalidate_the_capture(monkeypatch):
     rec = [r.value for r in harness._steps_of(m).node.entries.values()][0]
     assert rec["step"] is not None and rec["step"].graph.replays == 2
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             p.mul_(1.5)                                   # in place: the graph reads the new values
     changed = harness.test_epoch(m, [data], loss_fn, DEV, classify=True, is_graph_task=False)
     assert rec["step"].graph.replays == 3 and abs(changed[0] - out[0]) > 1e-6
@@ -317,7 +317,7 @@ def test_graph_task_steps_replayed_per_shape_match_eager_steps(readout, monkeypa
         torch.manual_seed(0)
         m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, readout_n_layers=readout, device=DEV)
         with torch.no_grad():
-            for p in m.parameters():
+            for _, p in m.named_parameters():
                 p.copy_(torch.randn(p.shape) * 0.5)
         m = m.to(DEV).eval()
         return m, torch.optim.Adam(m.parameters(), lr=2e-3, capturable=True, fused=True)
@@ -364,11 +364,11 @@ def test_optimizers_the_flat_update_declines_are_replayed_with_their_own_step(ta
         torch.manual_seed(0)
         m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=(task == "graph"), readout_n_layers=0, device=DEV)
         with torch.no_grad():
-            for p in m.parameters():
+            for _, p in m.named_parameters():
                 p.copy_(torch.randn(p.shape) * 0.3)
         m = m.to(DEV).eval()
         if frozen:
-            for p in m.rho.parameters():
+            for _, p in m.rho.named_parameters():
                 p.requires_grad_(False)
             opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=True)
         else:
@@ -480,7 +480,7 @@ def test_graph_task_evaluation_passes_are_replayed_per_shape(readout, monkeypatc
     torch.manual_seed(0)
     m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, readout_n_layers=readout, device=DEV)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             p.copy_(torch.randn(p.shape) * 0.5)
     m = m.to(DEV).eval()
     monkeypatch.setattr(harness, "GRAPHED_STEPS", False)
@@ -493,7 +493,7 @@ def test_graph_task_evaluation_passes_are_replayed_per_shape(readout, monkeypatc
     replays = sum(r["step"].step.graph.replays for r in steps.buckets.values() if r["step"] is not None)
     assert replays >= 120, replays                             # 180 graphs, a handful of shapes, two eager sightings each
     with torch.no_grad():                                      # the weights move: the replay reads the new values
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             p.mul_(1.1)
     moved = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
     monkeypatch.setattr(harness, "GRAPHED_STEPS", False)

@@ -121,7 +121,7 @@ def test_interpretability_exports_come_from_the_kernels_tables():
     m = TensorGNAN(F, C, 3, hidden_channels=64, rho_per_feature=True, device=DEV)
     gen = torch.Generator().manual_seed(1)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
         m.fs[2][0].bias.zero_()                                     # a feature whose kinks all sit at 0 (the grid contains 0)
     m = m.to(DEV).eval()

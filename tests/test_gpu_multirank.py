@@ -12,6 +12,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from helpers import grad_rule, module_grads, oracle_grads
 from oracle import gnan_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -166,17 +167,23 @@ def test_ranks_with_the_hip_kernels_equal_single_process_and_oracle(world, varia
     err = O.rel_err(torch.from_numpy(got), truth.detach())
     assert err <= max(1e-5, e_ref), (err, e_ref, order)
     ((truth - _target(C).double()) ** 2).sum().backward()
-    scale = max(float(v.grad.abs().max()) for v in p64.values() if v.grad is not None)
-    single = dict(m.named_parameters())
-    for k, v in p64.items():
-        want = v.grad if v.grad is not None else torch.zeros_like(v)
-        summed = sum(p[k] for p in parts)                        # the data-parallel all-reduce of p.grad, done here
-        # feature partition: every rank back-propagates the SAME loss on the whole output into its own columns' shape
-        # functions; rho sees the whole loss on every rank (its gradient is the sum over the ranks' partial outputs)
-        err = float(np.abs(summed - want.numpy()).max()) / scale
-        assert err <= 2e-5, f"{k}: ranks vs oracle {err:.3e}"
-        e1 = float((single[k].grad.cpu().double() - want).abs().max()) / scale
-        assert e1 <= 2e-5, f"{k}: single process vs oracle {e1:.3e}"
+    # gradients by the same rule: max(1e-5, the float32 oracle's own gap to float64) — the sum-first chain in float32
+    cnt_np = g.cnt.cpu().long().numpy()
+    rp_np, col_np, code_np = g.rowptr.cpu().long().numpy(), g.col.cpu().numpy(), g.code.cpu().numpy()
+
+    def chain32(p):
+        S = O.feature_mlps(x.float(), p).sum(1)
+        wt = O.weight_table(O.rho_lut(p, 3), cnt_np).expand(N, -1, -1)
+        return ((O.spmm_csr(rp_np, col_np, code_np, S, wt) - _target(C)) ** 2).sum()
+    g32 = oracle_grads(chain32, m.state_dict(), torch.float32)
+    g64 = {k: v.grad for k, v in p64.items()}
+    # feature partition: every rank back-propagates the SAME loss on the whole output into its own columns' shape
+    # functions; rho sees the whole loss on every rank (its gradient is the sum over the ranks' partial outputs)
+    summed = {k: sum(p[k] for p in parts) for k in p64}          # the data-parallel all-reduce of p.grad, done here
+    ok, e_build, e_ref, where = grad_rule(summed, g64, g32)
+    assert ok, f"{where}: ranks vs oracle {e_build:.3e} (fp32 oracle {e_ref:.3e})"
+    ok, e_build, e_ref, where = grad_rule(module_grads(m), g64, g32)
+    assert ok, f"{where}: single process vs oracle {e_build:.3e} (fp32 oracle {e_ref:.3e})"
 
 
 def _bench_line(extra, timeout=1500):

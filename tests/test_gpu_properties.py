@@ -62,7 +62,7 @@ def test_dense_bfs_csr_and_oracle_agree(pr):
         ref = lambda xx, a, b, p: O.gnan_forward(xx, a, b, p, pr["normalize"])
     gen = torch.Generator().manual_seed(pr["seed"] % 1000)
     with torch.no_grad():
-        for p in mod.parameters():
+        for _, p in mod.named_parameters():
             p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
     p64 = {k: v.detach().double() for k, v in mod.state_dict().items()}
     truth = ref(x.double(), nd.double(), norm.double(), p64)

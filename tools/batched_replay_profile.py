@@ -13,7 +13,7 @@ def main():
     torch.manual_seed(0)
     mod = batched.TensorGNAN(15, 8, 2, hidden_channels=16, device="cuda").to("cuda")
     with torch.no_grad():
-        for p in mod.parameters():
+        for _, p in mod.named_parameters():
             p.copy_(torch.randn(p.shape) * 0.5)
     opt = torch.optim.Adam(mod.parameters(), lr=1e-3)
     loss_fn = torch.nn.CrossEntropyLoss()

@@ -11,7 +11,7 @@ dev = "cuda"
 torch.manual_seed(0)
 model = TensorGNAN(15, 1, 3, hidden_channels=64, is_graph_task=True, readout_n_layers=0, device="cuda")
 with torch.no_grad():
-    for p in model.parameters():
+    for _, p in model.named_parameters():
         if p.dim() == 2:
             torch.nn.init.xavier_normal_(p, gain=1.0)
         else:

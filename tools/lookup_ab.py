@@ -40,7 +40,7 @@ def main():
     torch.manual_seed(0)
     m = TensorGNAN(F, 1, 3, hidden_channels=64, device=DEV)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             if p.dim() == 2:
                 torch.nn.init.xavier_normal_(p, gain=1.0)
             else:

@@ -34,7 +34,7 @@ def timeit(fn, reps=10, warm=3):
 
 def redraw(m):
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             if p.dim() == 2:
                 torch.nn.init.xavier_normal_(p, gain=1.0)
             else:

@@ -53,7 +53,7 @@ def main():
     else:
         m = TensorGNAN(15, 1, 3, hidden_channels=64, is_graph_task=True, readout_n_layers=2 if variant == "nam" else 0, device=DEV)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             torch.nn.init.xavier_normal_(p, gain=1.0) if p.dim() == 2 else p.normal_(0.0, 0.5)
     m = m.to(DEV)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)

@@ -17,7 +17,7 @@ x = syn.block_features(N, F, 0, N, seed=1, device=dev)
 torch.manual_seed(0)
 model = TensorGNAN(F, 1, 3, hidden_channels=64, device="cuda")
 with torch.no_grad():
-    for p in model.parameters():
+    for _, p in model.named_parameters():
         if p.dim() == 2:
             torch.nn.init.xavier_normal_(p, gain=1.0)
         else:

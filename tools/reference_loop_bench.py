@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""The modules under the reference-SHAPED loop (tests/reference_loop.py: anomaly mode, zero_grad, forward, loss, backward,
+stock Adam over model.parameters(), loss.item() per step) on the three training shapes: Mutagenicity-shaped graphs
+(batch_size = 1), arxiv-shaped, Cora-shaped.  One JSON line per shape: ms per step with and without anomaly mode; with
+``--profile`` the host profile (cProfile, top 28 by own time) of the anomaly-mode loop goes to stderr."""
+import cProfile
+import io
+import json
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import graphed_step as gs  # noqa: E402
+import microbench as mb  # noqa: E402
+import reference_loop  # noqa: E402
+
+DEV = "cuda"
+PROFILE = "--profile" in sys.argv
+
+
+def model_for(F, C, graph_task):
+    torch.manual_seed(0)
+    m = mb.TensorGNAN(F, C, 3, hidden_channels=64, is_graph_task=graph_task, readout_n_layers=0, device=DEV)
+    mb.redraw(m)
+    return m.to(DEV).eval()
+
+
+def measure(name, batches, F, C, graph_task, epochs, extra):
+    loss_fn = torch.nn.BCEWithLogitsLoss() if C == 1 else torch.nn.CrossEntropyLoss()
+    out = {"what": name, "steps_per_epoch": len(batches), **extra}
+    for tag, anomaly in (("anomaly", True), ("plain", False)):
+        m = model_for(F, C, graph_task)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        out["optimizer_tensors"] = sum(len(g["params"]) for g in opt.param_groups)
+        ts = []
+        for e in range(epochs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret = reference_loop.train_epoch(m, batches, loss_fn, opt, DEV, classify=True, is_graph_task=graph_task,
+                                             detect_anomaly=anomaly)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / len(batches) * 1e3)
+        out[tag + "_ms_per_step_by_epoch"] = [round(t, 4) for t in ts]
+        out[tag + "_ms_per_step"] = round(min(ts[1:] or ts), 4)
+        out[tag + "_last"] = [float(v) for v in ret]
+        if anomaly and PROFILE:
+            pr = cProfile.Profile()
+            pr.enable()
+            reference_loop.train_epoch(m, batches, loss_fn, opt, DEV, classify=True, is_graph_task=graph_task)
+            torch.cuda.synchronize()
+            pr.disable()
+            buf = io.StringIO()
+            pstats.Stats(pr, stream=buf).strip_dirs().sort_stats("tottime").print_stats(28)
+            print("=====", name, "anomaly-mode epoch,", len(batches), "steps", file=sys.stderr)
+            print("\n".join(l[:170] for l in buf.getvalue().splitlines()[:44]), file=sys.stderr)
+    print(json.dumps(out), flush=True)
+
+
+def node_batches(make):
+    d, n, F, C = make()
+    g = torch.Generator().manual_seed(1)
+    d.y = torch.randint(0, max(C, 2), (n,), generator=g).to(DEV)
+    r = torch.rand(n, generator=g)
+    d.train_mask, d.val_mask, d.test_mask = (r < 0.6).to(DEV), ((r >= 0.6) & (r < 0.8)).to(DEV), (r >= 0.8).to(DEV)
+    return [d] * 20, F, C, n
+
+
+if __name__ == "__main__":
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["muta", "arxiv", "cora"]
+    if "muta" in which:
+        graphs = gs.muta_shaped()
+        measure("muta_shaped_600_graphs", graphs, 15, 1, True, 4, {"graphs": len(graphs)})
+    if "arxiv" in which:
+        b, F, C, n = node_batches(lambda: gs.arxiv_shaped(1))
+        measure("arxiv_shaped_C1", b, F, C, False, 3, {"nodes": n, "features": F})
+    if "arxiv40" in which:
+        b, F, C, n = node_batches(lambda: gs.arxiv_shaped(40))
+        measure("arxiv_shaped_C40", b, F, C, False, 3, {"nodes": n, "features": F})
+    if "cora" in which:
+        b, F, C, n = node_batches(gs.cora_shaped)
+        measure("cora_shaped", b, F, C, False, 3, {"nodes": n, "features": F})

@@ -32,7 +32,7 @@ def main():
     y = torch.randn(N, 1, device=DEV)
     m = TensorGNAN(F, 1, 3, hidden_channels=64, device=DEV)
     with torch.no_grad():
-        for p in m.parameters():
+        for _, p in m.named_parameters():
             torch.nn.init.xavier_normal_(p, gain=1.0) if p.dim() == 2 else p.normal_(0.0, 0.5)
     m = m.to(DEV).eval()                       # eval: the reference trains without Dropout after its first epoch
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)

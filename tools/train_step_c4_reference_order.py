@@ -14,7 +14,7 @@ x = syn.block_features(N, F, 0, N, seed=1, device=DEV)
 y = torch.randn(N, 1, device=DEV)
 m = TensorGNAN(F, 1, 3, hidden_channels=64, device=DEV)
 with torch.no_grad():
-    for p in m.parameters():
+    for _, p in m.named_parameters():
         torch.nn.init.xavier_normal_(p, gain=1.0) if p.dim() == 2 else p.normal_(0.0, 0.5)
 m = m.to(DEV).eval()
 m.aggregation_order = "reference"
