@@ -42,6 +42,10 @@ def parse():
                          "(default); c5 = papers100M-shaped, bf16 operand rows; c3 = ogbn-arxiv-shaped forward+backward; "
                          "c2 = Mutagenicity-shaped graph-level task (one small graph per forward)")
     ap.add_argument("--graphs", type=int, default=4337, help="c2: number of graphs (Mutagenicity has 4337)")
+    ap.add_argument("--loop", default="harness", choices=["harness", "reference"],
+                    help="c2 / c3: 'reference' adds the training step as the reference's UNCHANGED loop issues it (tests/reference_loop.py "
+                         "restates trainer.py:23-86: anomaly mode, zero_grad, forward, mask, loss, backward, stock Adam over "
+                         "model.parameters(), loss.item()): eager ms per step, with and without anomaly mode")
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--edges", type=int, default=100_000_000)
     ap.add_argument("--scale", type=int, default=24)
@@ -295,6 +299,33 @@ def apply_sets(args):
         setattr(mod, attr, ast.literal_eval(value))
 
 
+def reference_loop_leg(model, batches, n_out, graph_task, epochs=4):
+    """ms per step of the reference-shaped training loop over ``batches`` on a deep copy of ``model`` (stock Adam, eager)."""
+    import copy
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import reference_loop
+    loss_fn = torch.nn.BCEWithLogitsLoss() if n_out == 1 else torch.nn.CrossEntropyLoss()
+    out = {}
+    for tag, anomaly in (("anomaly_mode", True), ("plain", False)):
+        twin = copy.deepcopy(model).eval()
+        opt = torch.optim.Adam(twin.parameters(), lr=1e-3)                # main.py:141
+        best = None
+        for _ in range(epochs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret = reference_loop.train_epoch(twin, batches, loss_fn, opt, batches[0].x.device, classify=True,
+                                             is_graph_task=graph_task, detect_anomaly=anomaly)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / len(batches) * 1e3
+            best = t if best is None else min(best, t)
+        out[f"{tag}_ms_per_step"] = best
+        out[f"{tag}_last_loss"] = float(ret[0])
+        out["optimizer_tensors"] = sum(len(g["params"]) for g in opt.param_groups)
+    out["loop"] = ("tests/reference_loop.train_epoch (trainer.py:23-86 restated: set_detect_anomaly, zero_grad, forward, mask, loss, "
+                   "backward, torch.optim.Adam(model.parameters()).step(), loss.item() per step), best of %d epochs" % epochs)
+    return out
+
+
 def run_c3(args):
     """BASELINE config 3: ogbn-arxiv-shaped TensorGNAN forward + backward on one GPU (SURVEY.md section 8d C3;
     /root/reference datasets.py:273-291: N = 169 343, E = 1 166 243, 128 features + the ones column, num_classes = 1 as the
@@ -423,6 +454,11 @@ def run_c3(args):
         "checksum": float(out.detach().double().sum()), "backward": True,
     }
     result.update(replay)
+    if args.loop == "reference":
+        gen_c = torch.Generator().manual_seed(3)
+        labelled = _Bag(x=x, edge_index=None, gnan_graph=g, y=torch.randint(0, max(C, 2), (N,), generator=gen_c).to(dev),
+                        train_mask=(torch.rand(N, generator=gen_c) < 0.6).to(dev))
+        result["reference_loop"] = reference_loop_leg(model, [labelled] * 20, C, False, epochs=3)
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_c3(args, model, g, x, fwd())
     print(json.dumps(result), flush=True)
@@ -556,6 +592,7 @@ def run_c2(args, rank=0, world=1):
         train_kernels = sorted({int(r.step.graph.kernel_nodes) for r in recs})
     except Exception as e:
         train_ms = f"failed: {type(e).__name__}: {e}"
+    ref_loop = reference_loop_leg(model, graphs[:1000], 1, True, epochs=3) if args.loop == "reference" else None
     ms = elapsed / args.steps * 1e3
     # the forward of a 30-node graph is one launch (small_graph_kernel) of ~20 us: a chain of latencies.  Algorithmic bytes
     # per graph: N_g^2 hop codes (1 B) + N_g x D counts + x + the weights (F MLPs of 4.3k floats)
@@ -581,6 +618,8 @@ def run_c2(args, rank=0, world=1):
         "timed_call": "gnan_amd.models.TensorGNAN.forward(data), eager, per graph",
         "checksum": float(sum(float(o.double().sum()) for o in outs)),
     }
+    if ref_loop is not None:
+        result["reference_loop"] = ref_loop
     if world == 1 and not args.no_cpu_baseline:
         from oracle import gnan_oracle as O
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

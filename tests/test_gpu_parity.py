@@ -637,6 +637,36 @@ def test_batched_train_epoch_matches_the_scripts_loop(gpu, monkeypatch):
         assert float((pa - pb).abs().max()) <= 2e-4 * scale
 
 
+@pytest.mark.parametrize("name", ["case_002_standalone_tensor_node", "case_011_models_tensor_node", "case_026_models_gnan"])
+def test_integration_stub_f_sums_on_the_gpu(gpu, name):
+    """the ctypes stub a maintainer of the reference would paste into GNAN.py — its ``f_sums`` called
+    on the GPU with a PLAIN torch module list carrying a golden's weights (no gnan_amd class involved) == the oracle's
+    shape functions summed over the features (GNAN.py:57-62 + :157), float64 truth, 1e-5."""
+    from test_abi import integration_stub
+    g = Golden(name)
+    m = g.meta
+    ns = {}
+    exec(integration_stub(), ns)
+    F = g.inputs["x"].shape[1]
+
+    class Plain(torch.nn.Module):                        # what GNAN.py:24-34 builds
+        def __init__(self):
+            super().__init__()
+            self.out_channels, self.hidden_channels = m["C"], m["H"]
+            self.fs = torch.nn.ModuleList(torch.nn.Sequential(
+                torch.nn.Linear(1, m["H"]), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(m["H"], m["H"]), torch.nn.ReLU(),
+                torch.nn.Dropout(0.0), torch.nn.Linear(m["H"], m["C"])) for _ in range(F))
+    plain = Plain()
+    fs_sd = {k: torch.from_numpy(np.array(v)) for k, v in g.sd.items() if k.startswith("fs.")}
+    plain.load_state_dict(fs_sd, strict=True)
+    plain = plain.to(gpu.DEV)
+    x = torch.from_numpy(np.array(g.inputs["x"]))
+    with torch.no_grad():
+        got = ns["f_sums"](plain, x.to(gpu.DEV).contiguous())
+    want = O.feature_mlps(x.double(), {k: v.double() for k, v in fs_sd.items()}).sum(1)
+    assert got.shape == want.shape and O.rel_err(got.cpu(), want) <= 1e-5
+
+
 def test_batched_train_epoch_steps_an_uncapturable_batch_once(gpu):
     """A loss callable that reads the device (``.item()``) cannot be captured.  Constructing the captured step has by then
     already STEPPED the batch eagerly (its warm-up step is a real one): ``train_epoch`` must take that step as the batch's
