@@ -62,6 +62,37 @@ def measure(name, batches, F, C, graph_task, epochs, extra):
     print(json.dumps(out), flush=True)
 
 
+def phases(name, batches, F, C, graph_task):
+    """Host time per phase of the reference-shaped step (no anomaly mode): what the host spends ISSUING each phase (perf_counter
+    around it, no synchronisation added — the loop's own .item() calls are the only ones), summed over an epoch."""
+    import reference_loop as rl
+    loss_fn = torch.nn.BCEWithLogitsLoss() if C == 1 else torch.nn.CrossEntropyLoss()
+    m = model_for(F, C, graph_task)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for _ in range(2):
+        rl.train_epoch(m, batches, loss_fn, opt, DEV, classify=True, is_graph_task=graph_task, detect_anomaly=False)
+    acc = {k: 0.0 for k in ("labels", "zero_grad", "forward", "mask+loss", "backward", "optimizer.step", "loss.item", "hit_count")}
+    pc = time.perf_counter
+    torch.cuda.synchronize()
+    t_epoch = pc()
+    for data in batches:
+        t = pc(); labels = rl._labels(data, 0, loss_fn).to(DEV); acc["labels"] += pc() - t
+        t = pc(); opt.zero_grad(); acc["zero_grad"] += pc() - t
+        t = pc(); out = m.forward(data); acc["forward"] += pc() - t
+        t = pc()
+        if not graph_task:
+            labels, out = labels[data.train_mask], out[data.train_mask]
+        loss = rl._loss(loss_fn, out, labels); acc["mask+loss"] += pc() - t
+        t = pc(); loss.backward(); acc["backward"] += pc() - t
+        t = pc(); opt.step(); acc["optimizer.step"] += pc() - t
+        t = pc(); loss.item(); acc["loss.item"] += pc() - t
+        t = pc(); rl._hit_count(out, labels); acc["hit_count"] += pc() - t
+    torch.cuda.synchronize()
+    total = (pc() - t_epoch) / len(batches) * 1e3
+    print(json.dumps({"what": name + " host ms per step by phase", "total": round(total, 4),
+                      **{k: round(v / len(batches) * 1e3, 4) for k, v in acc.items()}}), flush=True)
+
+
 def node_batches(make):
     d, n, F, C = make()
     g = torch.Generator().manual_seed(1)
@@ -76,12 +107,15 @@ if __name__ == "__main__":
     if "muta" in which:
         graphs = gs.muta_shaped()
         measure("muta_shaped_600_graphs", graphs, 15, 1, True, 4, {"graphs": len(graphs)})
+        phases("muta_shaped_600_graphs", graphs, 15, 1, True)
     if "arxiv" in which:
         b, F, C, n = node_batches(lambda: gs.arxiv_shaped(1))
         measure("arxiv_shaped_C1", b, F, C, False, 3, {"nodes": n, "features": F})
+        phases("arxiv_shaped_C1", b, F, C, False)
     if "arxiv40" in which:
         b, F, C, n = node_batches(lambda: gs.arxiv_shaped(40))
         measure("arxiv_shaped_C40", b, F, C, False, 3, {"nodes": n, "features": F})
     if "cora" in which:
         b, F, C, n = node_batches(gs.cora_shaped)
         measure("cora_shaped", b, F, C, False, 3, {"nodes": n, "features": F})
+        phases("cora_shaped", b, F, C, False)
