@@ -579,7 +579,7 @@ def run_c2(args, rank=0, world=1):
         replay_ms = f"failed: {type(e).__name__}: {e}"
     # ... and a training epoch (trainer.py:23-86: batch_size 1, forward + loss + backward + Adam per graph) on a twin of the
     # model: eager in its first passes, one captured step per graph shape from the third on
-    train_ms, train_kernels = None, None
+    train_ms, train_kernels, captured_steps = None, None, None
     try:
         import copy
         twin = copy.deepcopy(model).train()
@@ -592,8 +592,10 @@ def run_c2(args, rank=0, world=1):
         harness.train_epoch(twin, labelled, loss_fn, opt, dev, classify=True, is_graph_task=True)
         torch.cuda.synchronize()
         train_ms = (time.perf_counter() - t0) / len(labelled) * 1e3
-        recs = [r["step"] for r in harness._steps_of(twin).graph.buckets.values() if r["step"] is not None]
+        st = harness._steps_of(twin).graph
+        recs = [r["step"] for r in st.buckets.values() if r["step"] is not None] + ([st.slot] if st.slot is not None else [])
         train_kernels = sorted({int(r.step.graph.kernel_nodes) for r in recs})
+        captured_steps = len(recs)
     except Exception as e:
         train_ms = f"failed: {type(e).__name__}: {e}"
     ref_loop = reference_loop_leg(model, graphs[:1000], 1, True, epochs=3) if args.loop == "reference" else None
@@ -612,7 +614,7 @@ def run_c2(args, rank=0, world=1):
                    "step": "one evaluation pass: models.TensorGNAN.forward(data) per graph, batch_size = 1"},
         "ms_per_graph": ms / max(1, len(graphs)), "graphs_per_s": args.graphs / (elapsed / args.steps),
         "replayed_eval_ms_per_graph": replay_ms, "replayed_train_ms_per_graph": train_ms,
-        "kernels_per_replayed_training_step": train_kernels,
+        "kernels_per_replayed_training_step": train_kernels, "captured_training_steps": captured_steps,
         "roofline": {"bound": "hbm", "kernel": "small_graph_kernel (whole forward of a graph in one launch)",
                      "achieved": b_alg / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -208,7 +208,7 @@ class LossArgs(C.Structure):
         ("logits", C.c_void_p), ("n_rows", C.c_int64), ("C", C.c_int32), ("kind", C.c_int32), ("stride", C.c_int64),
         ("index", C.c_void_p), ("n", C.c_int64), ("labels", C.c_void_p), ("loss", C.c_void_p), ("hits", C.c_void_p),
         ("grad", C.c_void_p), ("grad_stride", C.c_int64), ("loss_sum", C.c_void_p), ("hits_sum", C.c_void_p),
-        ("skip_sums", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("skip_sums", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("label_flag", C.c_void_p),
     ]
 
 
@@ -245,7 +245,7 @@ class SmallBatchArgs(C.Structure):
         ("max_nodes", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp), ("code", C.c_void_p), ("node_off", C.c_void_p),
         ("code_off", C.c_void_p), ("D", C.c_int32), ("rho_raw_hops", C.c_int32), ("rest_zero", C.c_int32),
         ("S", C.c_void_p), ("lut", C.c_void_p), ("Y", C.c_void_p), ("Ysum", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("cnt", C.c_void_p), ("cnt_stride", C.c_int64),
     ]
 
 
@@ -255,7 +255,8 @@ class SmallBatchBwdArgs(C.Structure):
         ("max_nodes", C.c_int32), ("f", SmallMlp), ("rho", SmallMlp), ("code", C.c_void_p), ("node_off", C.c_void_p),
         ("code_off", C.c_void_p), ("D", C.c_int32), ("rho_raw_hops", C.c_int32), ("rest_zero", C.c_int32),
         ("S", C.c_void_p), ("lut", C.c_void_p), ("dY", C.c_void_p), ("dYsum", C.c_void_p), ("df", SmallMlpGrads),
-        ("drho", SmallMlpGrads), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("drho", SmallMlpGrads), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("cnt", C.c_void_p),
+        ("cnt_stride", C.c_int64),
     ]
 
 

@@ -210,7 +210,10 @@ class _BatchedGraphs(torch.autograd.Function):
     else the general kernels on the blocks' CSR from the saved node sums and rho table."""
 
     @staticmethod
-    def forward(ctx, x, blocks: HopBlocks, graph_sum, fm, rm, *params):
+    def forward(ctx, x, blocks: HopBlocks, graph_sum, fm, rm, cnt, raw_hops, *params):
+        """``cnt`` (``[total_nodes, >= D]`` int32 shell sizes) and ``raw_hops=False``: the semantics of models.py:358-384 instead
+        of the batched script's — rho on ``1 / (1 + hop)``, rho(0) on the unlisted pairs, weights divided by the shell size
+        (``small_graph.SlotGraph``: a batch-size-1 loop through ONE captured step whatever the graphs' sizes)."""
         from . import functional as Fn
         Lf, Hf, Cf, F = fm
         Lr, Hr, Cr = rm
@@ -229,11 +232,13 @@ class _BatchedGraphs(torch.autograd.Function):
         a = _lib.SmallBatchArgs(x=_lib.ptr(xk), x_stride=xk.stride(0), total_nodes=N, F=F, n_graphs=G,
                                 max_nodes=blocks.max_nodes, f=_small_mlp(keep_f, Lf, Hf, Cf),
                                 rho=_small_mlp(keep_r, Lr, Hr, Cr), code=_lib.ptr(blocks.code),
-                                node_off=_lib.ptr(blocks.node_off), code_off=_lib.ptr(blocks.code_off), D=D, rho_raw_hops=1,
-                                rest_zero=1, S=_lib.ptr(S), lut=_lib.ptr(lut), Y=_lib.ptr(Y), Ysum=_lib.ptr(Ysum),
-                                workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4)
+                                node_off=_lib.ptr(blocks.node_off), code_off=_lib.ptr(blocks.code_off), D=D,
+                                rho_raw_hops=int(raw_hops), rest_zero=int(raw_hops), S=_lib.ptr(S), lut=_lib.ptr(lut),
+                                Y=_lib.ptr(Y), Ysum=_lib.ptr(Ysum), workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4,
+                                cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0))
         _lib.check(_lib.lib().gnan_small_batch_fwd(a, _lib.stream_of(xk)), "gnan_small_batch_fwd")
         ctx.blocks, ctx.graph_sum, ctx.fm, ctx.rm = blocks, graph_sum, fm, rm
+        ctx.cnt, ctx.raw_hops = cnt, bool(raw_hops)
         ctx.present = [t is not None for t in params]
         ctx.dests = Fn._grad_dests_of(params)
         ctx.save_for_backward(xk, S, lut, *[t for t in params if t is not None])
@@ -248,7 +253,7 @@ class _BatchedGraphs(torch.autograd.Function):
         params = [rest.pop(0) if pr else None for pr in ctx.present]
         Lf, Hf, Cf, F = ctx.fm
         Lr, Hr, Cr = ctx.rm
-        need_f, need_r = any(ctx.needs_input_grad[5:11]), any(ctx.needs_input_grad[11:])
+        need_f, need_r = any(ctx.needs_input_grad[7:13]), any(ctx.needs_input_grad[13:])
         blocks = ctx.blocks
         if (BATCH_BACKWARD_KERNEL and Cr in (1, Cf) and blocks.n_codes <= 64 and d_out.dtype == torch.float32
                 and all(t is None or t.dtype == torch.float32 for t in params)):
@@ -265,7 +270,8 @@ class _BatchedGraphs(torch.autograd.Function):
                                        n_graphs=blocks.n_graphs, max_nodes=blocks.max_nodes, f=_small_mlp(keep[:6], Lf, Hf, Cf),
                                        rho=_small_mlp(keep[6:], Lr, Hr, Cr), code=_lib.ptr(blocks.code),
                                        node_off=_lib.ptr(blocks.node_off), code_off=_lib.ptr(blocks.code_off), D=blocks.n_codes,
-                                       rho_raw_hops=1, rest_zero=1, S=_lib.ptr(S), lut=_lib.ptr(lut),
+                                       rho_raw_hops=int(ctx.raw_hops), rest_zero=int(ctx.raw_hops), S=_lib.ptr(S), lut=_lib.ptr(lut),
+                                       cnt=_lib.ptr(ctx.cnt), cnt_stride=0 if ctx.cnt is None else ctx.cnt.stride(0),
                                        dY=None if ctx.graph_sum else _lib.ptr(g_out),
                                        dYsum=_lib.ptr(g_out) if ctx.graph_sum else None, df=grads(outs_f), drho=grads(outs_r),
                                        workspace=None, workspace_bytes=0)
@@ -274,8 +280,11 @@ class _BatchedGraphs(torch.autograd.Function):
                 ws = torch.empty(need // 4 + 1, dtype=torch.float32, device=x.device)
                 a.workspace, a.workspace_bytes = _lib.ptr(ws), ws.numel() * 4
                 _lib.check(_lib.lib().gnan_small_batch_bwd(a, _lib.stream_of(x)), "gnan_small_batch_bwd")
-                return (None, None, None, None, None, *[o if need_f else None for o in outs_f],
+                return (None, None, None, None, None, None, None, *[o if need_f else None for o in outs_f],
                         *[o if need_r else None for o in outs_r])
+        if ctx.cnt is not None or not ctx.raw_hops:
+            raise _lib.GnanHipError("gnan_small_batch_bwd does not cover this slot step (more than 64 hop codes, a rho of several "
+                                    "channels or too large a workspace): no other route reads the slots' sizes from the device")
         dY = d_out.index_select(0, blocks.batch_vector()) if ctx.graph_sum else d_out      # every node gets its graph's gradient
         from . import aggregate
         bag = aggregate._Bag()
@@ -290,7 +299,7 @@ class _BatchedGraphs(torch.autograd.Function):
             hops = torch.arange(D - 1, dtype=torch.float32, device=x.device).view(-1, 1)     # rho's inputs: the raw hop counts
             _, pg_r = Fn._shape_function_grads(hops, params[6:], ctx.present[6:], None, dlut[: D - 1].reshape(-1, Cr), False,
                                                Lr, Hr, Cr, 1, dests=ctx.dests[6:])
-        return (None, None, None, None, None, *pg_f, *pg_r)
+        return (None, None, None, None, None, None, None, *pg_f, *pg_r)
 
 
 class TensorGNAN(_PathBase):
@@ -332,7 +341,7 @@ class TensorGNAN(_PathBase):
                 and blocks.total_nodes <= BATCH_KERNEL_MAX_TOTAL_NODES and blocks.n_codes <= 256 and f.H <= 64 and f.C <= 8 and x_batch.dtype == torch.float32
                 and not x_batch.requires_grad and blocks.n_graphs <= 65535):
             fm, rm = (f.L, f.H, f.C, f.F), (rho.L, rho.H, rho.C)
-            return _BatchedGraphs.apply(x_batch, blocks, bool(self.is_graph_task), fm, rm, *f[:6], *rho[:6])
+            return _BatchedGraphs.apply(x_batch, blocks, bool(self.is_graph_task), fm, rm, None, True, *f[:6], *rho[:6])
         if blocks is not None:
             g = blocks.csr()
         else:

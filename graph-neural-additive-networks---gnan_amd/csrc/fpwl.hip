@@ -1158,10 +1158,13 @@ int cu_count() {
 // flushed with one global atomic per touched bin at the end — worth ~600 rows — and x lines are shared between the
 // groups of a node block in L2, so blocks of 1024..8192 nodes in whole rounds of the resident workgroups.
 int tuned_moment_block(int64_t n, int n_groups, size_t lds, int bs) {
-  if (n < 262144) {
+  if (n < 16384) {
     const int64_t npb = (n / 1024 + 255) / 256 * 256;
     return static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
   }
+  // (round 5: the same model from 16k nodes on — the arxiv-shaped graph, 169k nodes x 9 groups, ran 5958 workgroups of 256
+  //  nodes, each paying the ~600 rows of image and flush: 70 % overhead and 25M global atomics onto 37k bins; one round of
+  //  ~750 workgroups of 2048 nodes instead)
   int per_cu = static_cast<int>((160 * 1024) / lds);
   if (per_cu > 2048 / bs) per_cu = 2048 / bs;
   if (per_cu < 1) per_cu = 1;
@@ -1169,7 +1172,7 @@ int tuned_moment_block(int64_t n, int n_groups, size_t lds, int bs) {
   const int unit = 128, overhead = 600;
   int64_t best_cost = -1;
   int best = 4096;
-  for (int npb = 1024; npb <= 8192; npb += unit) {
+  for (int npb = n < 262144 ? 256 : 1024; npb <= 8192; npb += unit) {
     const int64_t wgs = (n + npb - 1) / npb * n_groups;
     const int64_t rounds = (wgs + resident - 1) / resident;
     const int64_t cost = rounds * (npb + overhead);

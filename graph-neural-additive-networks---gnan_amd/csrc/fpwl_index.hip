@@ -17,6 +17,11 @@
 // the hinted range) — a plain binary search over the sorted anchors, rare.
 // Per look-up: 3 dependent LDS reads (entry, anchors, (val, slope)) and ~16 vector instructions; same formula
 // val + slope * (x - anchor) on the same piece as fpwl_fast_kernel, hence bit-identical results.
+// The kernel is bound by the LDS pipe (round 4 SQ counters: LDS busy 64 % of the CU cycles, 58 % of them bank conflicts —
+// three RANDOM gathers per look-up, and a random gather of 32 lanes over the banks costs ~3.5 cycles per lane group whatever
+// its width up to 8 bytes).  Round 5: the anchors sit in LDS as PAIRS (a_i, a_{i+1}) per piece, 8-byte aligned, so the two
+// anchors a look-up compares with are ONE ds_read_b64 (one gather: ~7 LDS cycles) instead of a ds_read2_b32 (two: ~14);
+// the code-1 path's next two anchors are the pair two pieces on.  28 -> 21 LDS cycles per wave look-up.
 //
 // Mapping: workgroup = (node block, group of FGX features), thread = (node, 4 features), one 16-B load of x and one 16-B
 // store per node and thread.  FGX = 32 where F allows: a node's 32 features are ONE full 128-byte line of x and of the
@@ -178,23 +183,24 @@ __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restr
 
 // ---------------------------------------------------------------------------------------------
 // the look-up
-// LDS image of a feature group: [FG][B] uint16 entries | anchors, feature f's run at s_off[f] + f * KF (KF NaNs behind
-// every feature: the correction reads never see the next feature's anchors) | [tot] (val, slope) pairs | s_off[FG + 1]
+// LDS image of a feature group: [FG][B] uint16 entries | anchor PAIRS (a_i, a_{i+1}), feature f's run at s_off[f] + f * KF
+// (KF NaN pairs behind every feature, and NaN as the last piece's "next": the comparisons never see the next feature's
+// anchors) | [tot] (val, slope) pairs | s_off[FG + 1]
 // ---------------------------------------------------------------------------------------------
 template <int FG, bool SUM, bool OUT16, int LOGB, int BS>
 __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
-  constexpr int KF = 3;                             // NaNs behind every feature's anchors: what the comparisons may read
+  constexpr int KF = 2;                             // NaN pairs behind every feature's run: what the comparisons may read
   static_assert(FG == 16 || FG == 32, "feature groups of 16 (half lines) or 32 (full lines)");
   constexpr int TPN = FG / FPT, B = 1 << LOGB, NODES = BS / TPN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)smem));
   constexpr int kTableBytes = FG * B * 2;
-  const int a_words = (p.tot_cap + FG * KF + 1) & ~1;            // even: the (val, slope) pairs stay 8-byte aligned
-  float* an_l = smem + kTableBytes / 4;
-  float2* vs_l = reinterpret_cast<float2*>(an_l + a_words);
+  const int a_pairs = p.tot_cap + FG * KF;                       // anchor pairs (a_i, a_{i+1}), 8 bytes each
+  float2* an_l = reinterpret_cast<float2*>(smem + kTableBytes / 4);
+  float2* vs_l = an_l + a_pairs;
   int* s_off = reinterpret_cast<int*>(vs_l + p.tot_cap);
   const int a_base = static_cast<int>(lds_base) + kTableBytes;
-  const int vs_base = a_base + 4 * a_words;
+  const int vs_base = a_base + 8 * a_pairs;
   const int tid = threadIdx.x;
   const int q = tid % TPN;
   const int nl = tid / TPN;
@@ -224,14 +230,18 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
       for (int i = tid; i < kTableBytes / 16; i += BS) dst[i] = src[i];
     }
     __syncthreads();
-    for (int i = tid; i < tot + FG * KF; i += BS) an_l[i] = __builtin_nanf("");    // x >= NaN is false for every x, +inf included
+    {                                               // x >= NaN is false for every x, +inf included
+      const float nanv = __builtin_nanf("");
+      for (int i = tid; i < tot + FG * KF; i += BS) an_l[i] = make_float2(nanv, nanv);
+    }
     __syncthreads();
     for (int i = tid; i < tot; i += BS) {
       // feature of global piece i: the largest f with s_off[f] <= i (a 4- or 5-step search on the LDS offsets)
       int f = 0;
 #pragma unroll
       for (int st = FG / 2; st > 0; st >>= 1) f += (s_off[f + st] <= i) ? st : 0;
-      an_l[i + f * KF] = p.anchor[base + i];
+      const float next = i + 1 < s_off[f + 1] ? p.anchor[base + i + 1] : __builtin_nanf("");   // the feature's last piece: no next anchor
+      an_l[i + f * KF] = make_float2(p.anchor[base + i], next);
       vs_l[i] = make_float2(p.val[base + i], p.slope[base + i]);
     }
     __syncthreads();
@@ -244,12 +254,12 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
       const int fg = q * FPT + f;
       ks[f] = p.key[2 * (k0 + fg)];
       ko[f] = p.key[2 * (k0 + fg) + 1];
-      a0[f] = a_base + 4 * (s_off[fg] + fg * KF);              // LDS byte address of the feature's anchor 0
-      cvs[f] = vs_base - 2 * a_base - 8 * fg * KF;             // (val, slope) address = 2 * anchor address + cvs
+      a0[f] = a_base + 8 * (s_off[fg] + fg * KF);              // LDS byte address of the feature's pair 0
+      cvs[f] = vs_base - a_base - 8 * fg * KF;                 // (val, slope) address = pair address + cvs
     }
 
     float ps[FPT] = {0.f, 0.f, 0.f, 0.f};           // column sums of the output (per-feature mode)
-    auto look_up = [&](const int64_t n, const float4 t) {
+    auto look_up = [&](const int64_t n, const float4 t, const float before) {
       const float xv[FPT] = {t.x, t.y, t.z, t.w};
       int e[FPT];
 #pragma unroll
@@ -261,19 +271,19 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
       float an[FPT];
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const int a = a0[f] + (e[f] & 0x3fff);
-        const float A0 = lds_f32(a), A1 = lds_f32(a + 4);
-        pa[f] = a + (xv[f] >= A1 ? 4 : 0);
-        an[f] = xv[f] >= A1 ? A1 : A0;
+        const int a = a0[f] + 2 * (e[f] & 0x3fff);             // (entries hold 4 * piece)
+        const float2 A01 = lds_f32x2(a);                       // (a_i, a_{i+1}): one 8-byte read
+        pa[f] = a + (xv[f] >= A01.y ? 8 : 0);
+        an[f] = xv[f] >= A01.y ? A01.y : A01.x;
       }
       if ((e[0] | e[1] | e[2] | e[3]) >> 14) {      // some bucket holds more than one breakpoint
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
           if (e[f] >> 14) {                         // two or three: compare with the next two anchors as well
-            const int a = a0[f] + (e[f] & 0x3fff);
-            const float A2 = lds_f32(a + 8), A3 = lds_f32(a + 12);
-            pa[f] += (xv[f] >= A2 ? 4 : 0) + (xv[f] >= A3 ? 4 : 0);
-            an[f] = xv[f] >= A3 ? A3 : (xv[f] >= A2 ? A2 : an[f]);
+            const int a = a0[f] + 2 * (e[f] & 0x3fff);
+            const float2 A23 = lds_f32x2(a + 16);              // pair i + 2 = (a_{i+2}, a_{i+3})
+            pa[f] += (xv[f] >= A23.x ? 8 : 0) + (xv[f] >= A23.y ? 8 : 0);
+            an[f] = xv[f] >= A23.y ? A23.y : (xv[f] >= A23.x ? A23.x : an[f]);
           }
         }
         if (((e[0] & e[0] >> 1) | (e[1] & e[1] >> 1) | (e[2] & e[2] >> 1) | (e[3] & e[3] >> 1)) >> 14) {   // code 3 somewhere
@@ -281,16 +291,16 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
           for (int f = 0; f < FPT; ++f) {
             if ((e[f] >> 14) == 3) {                // more: search the feature's sorted anchors
               const int fg = q * FPT + f;
-              const float* A = an_l + s_off[fg] + fg * KF;
+              const float2* A = an_l + s_off[fg] + fg * KF;
               const int pn = s_off[fg + 1] - s_off[fg] - 1;
               int idx = 0;
               for (int step = p.step0; step > 0; step >>= 1) {
                 const int j = idx + step;
                 const int jj = j <= pn ? j : 0;
-                idx = (j <= pn && A[jj] <= xv[f]) ? j : idx;
+                idx = (j <= pn && A[jj].x <= xv[f]) ? j : idx;
               }
-              pa[f] = a0[f] + 4 * idx;
-              an[f] = A[idx];
+              pa[f] = a0[f] + 8 * idx;
+              an[f] = A[idx].x;
             }
           }
         }
@@ -298,14 +308,14 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
       float y[FPT];
 #pragma unroll
       for (int f = 0; f < FPT; ++f) {
-        const float2 vs = lds_f32x2(2 * pa[f] + cvs[f]);
+        const float2 vs = lds_f32x2(pa[f] + cvs[f]);
         y[f] = fmaf(vs.y, xv[f] - an[f], vs.x);
       }
       if constexpr (SUM) {
         if (p.piece_out) {                          // (uniform) keep the pieces for the backward pass, group-major
           unsigned packed = 0u;
 #pragma unroll
-          for (int f = 0; f < FPT; ++f) packed |= static_cast<unsigned>((pa[f] - a0[f]) >> 2) << (8 * f);
+          for (int f = 0; f < FPT; ++f) packed |= static_cast<unsigned>((pa[f] - a0[f]) >> 3) << (8 * f);
           // (16-feature groups whatever FG is: the layout gnan_fpwl_moments_fixed reads)
           constexpr int G16 = FG / 16;
           *reinterpret_cast<unsigned*>(p.piece_out + (static_cast<int64_t>(g * G16 + q / 4) * p.n + n) * 16 + (q % 4) * FPT) = packed;
@@ -313,10 +323,7 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
         float acc = ((y[0] + y[1]) + y[2]) + y[3];          // fpwl_fast_kernel's association: bit-identical sums
 #pragma unroll
         for (int o = 1; o < TPN; o <<= 1) acc += __shfl_xor(acc, o);
-        if (q == 0) {
-          float* o = p.out + n * p.out_stride;
-          o[0] = g == 0 ? acc : o[0] + acc;
-        }
+        if (q == 0) p.out[n * p.out_stride] = before + acc;   // (`before`: the earlier groups' sum, 0 for the first group)
       } else {
         float4 r = make_float4(y[0], y[1], y[2], y[3]);
         if constexpr (OUT16) {
@@ -343,17 +350,29 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
     const float* xp = xq + (n_lo + nl) * p.x_stride;
     auto row = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr <= xlast ? ptr : xlast); };
     float4 cur[U], nxt[U];
+    // feature sum over several groups: the sum the EARLIER groups left in `out` travels with the x row — requested a round
+    // ahead like it.  (Read next to the store it feeds, every round waited for that load and, vmcnt being in order, for the
+    // prefetched x rows queued before it: the look-ups then ran with nothing in flight.)
+    float pre[U] = {}, pre_nxt[U] = {};
+    const bool add_before = SUM && g > g_lo;
+    auto before_of = [&](const int64_t n) { return p.out[(n < n_hi ? n : n_hi - 1) * p.out_stride]; };
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = row(xp + u * xstep);
+    for (int u = 0; u < U; ++u) {
+      cur[u] = row(xp + u * xstep);
+      if (add_before) pre[u] = before_of(n_lo + nl + u * NODES);
+    }
     for (int64_t n = n_lo + nl; n < n_hi; n += U * NODES) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) nxt[u] = row(xp + (U + u) * xstep);
+      for (int u = 0; u < U; ++u) {
+        nxt[u] = row(xp + (U + u) * xstep);
+        if (add_before) pre_nxt[u] = before_of(n + (U + u) * NODES);
+      }
       xp += U * xstep;
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (n + u * NODES < n_hi) look_up(n + u * NODES, cur[u]);
+        if (n + u * NODES < n_hi) look_up(n + u * NODES, cur[u], pre[u]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      for (int u = 0; u < U; ++u) { cur[u] = nxt[u]; pre[u] = pre_nxt[u]; }
     }
     if constexpr (!SUM) {
       if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64 (as fpwl_fast_kernel)
@@ -390,9 +409,9 @@ struct IndexPlan {
   size_t lds;
 };
 
-size_t image_bytes(int fg, int logb, int tot_cap) {
-  const size_t a_words = (static_cast<size_t>(tot_cap) + fg * 3 + 1) & ~static_cast<size_t>(1);
-  return (static_cast<size_t>(fg) << logb) * 2 + a_words * 4 + static_cast<size_t>(tot_cap) * 8 + (fg + 1) * 4;
+size_t image_bytes(int fg, int logb, int tot_cap) {          // bucket entries | anchor pairs (+ 2 NaN pairs per feature) | (val, slope) | offsets
+  const size_t a_pairs = static_cast<size_t>(tot_cap) + fg * 2;
+  return (static_cast<size_t>(fg) << logb) * 2 + a_pairs * 8 + static_cast<size_t>(tot_cap) * 8 + (fg + 1) * 4;
 }
 
 // Which instance serves these arguments, if any (one channel, whole feature groups, 16-byte aligned rows), and its node

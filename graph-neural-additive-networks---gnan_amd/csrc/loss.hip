@@ -6,7 +6,8 @@
 //   CE:   l_i = logsumexp(x_i) - x_i[t_i]              dl/dx_i = (softmax(x_i) - e_{t_i}) / n  hit: argmax x_i == t_i
 //   loss = mean_i l_i   (float32 terms as torch computes them, float64 across rows, fixed order: bit-reproducible)
 // The mean is over ALL n rows handed over (torch's default options): class labels outside [0, C) — ignore_index rows, which
-// torch leaves out of the mean — are not this kernel's business; gnan_amd/harness.py keeps the eager loss for such labels.
+// torch leaves out of the mean — are not this kernel's business; gnan_amd/harness.py keeps the eager loss for such labels, and
+// callers that cannot see the labels on the host (replayed steps) hand over `label_flag`, which such a row sets.
 #include "common.hpp"
 
 namespace {
@@ -26,6 +27,7 @@ struct LossParams {
   float* loss_sum;
   float* hits_sum;
   const float* skip_sums;   // optional flag: non-zero = leave the running totals alone (a replayed step whose guard tripped)
+  float* label_flag;        // optional flag: set to 1 by a cross-entropy row whose label lies outside [0, C)
   double* partial;   // [blocks, 2]
   int blocks;
 };
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams p) {
       for (int c = 0; c < p.C; ++c) z += expf(x[c] - m);
       const float lz = logf(z);
       const float xt = (t >= 0 && t < p.C) ? x[t] : 0.f;
+      if ((t < 0 || t >= p.C) && p.label_flag) *p.label_flag = 1.f;
       l_acc += static_cast<double>(-(xt - m - lz));
       h_acc += arg == t ? 1.0 : 0.0;
       if (p.grad) {
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) void loss_wide_ce_kernel(const LossParams p) {
     for (int off = 1; off < kWideLanes; off <<= 1) xt += __shfl_xor(xt, off);
     if (live && sub == 0) {
       const float target = (t_cls >= 0 && t_cls < p.C) ? xt : 0.f;
+      if ((t_cls < 0 || t_cls >= p.C) && p.label_flag) *p.label_flag = 1.f;
       l_acc += static_cast<double>(-(target - m - lz));
       h_acc += arg == t_cls ? 1.0 : 0.0;
     }
@@ -242,7 +246,7 @@ extern "C" int gnan_loss_step(const gnan_loss_args* a, gnan_stream_t stream) {
   p.t_f = a->kind == GNAN_LOSS_BCE_LOGITS ? static_cast<const float*>(a->labels) : nullptr;
   p.t_i = a->kind == GNAN_LOSS_CROSS_ENTROPY ? static_cast<const int64_t*>(a->labels) : nullptr;
   p.loss = a->loss; p.hits = a->hits; p.grad = a->grad; p.grad_stride = a->grad_stride;
-  p.loss_sum = a->loss_sum; p.hits_sum = a->hits_sum; p.skip_sums = a->skip_sums;
+  p.loss_sum = a->loss_sum; p.hits_sum = a->hits_sum; p.skip_sums = a->skip_sums; p.label_flag = a->label_flag;
   p.blocks = blocks_for(a->n);
   p.partial = static_cast<double*>(a->workspace);
   const size_t need = gnan_loss_workspace_bytes(a->n);

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void small_graph_batch_kernel(const BatchParam
   p.x += o * p.x_stride;
   p.code += bp.code_off[g];
   p.S += o * p.f.C;
+  if (p.cnt) p.cnt += o * p.cnt_stride;
   if (p.Y) p.Y += o * p.f.C;
   if (p.Ysum) p.Ysum += static_cast<int64_t>(g) * p.f.C;
   p.lut += static_cast<int64_t>(g) * p.D * p.r.C;
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(256) void small_graph_batch_bwd_kernel(const BatchB
   p.x += o * p.x_stride;
   p.code += bp.code_off[g];
   p.S += o * C;
+  if (p.cnt) p.cnt += o * p.cnt_stride;
   p.lut += static_cast<int64_t>(g) * p.D * p.rho_c;
   if (bp.dy_per_graph) p.dYsum += static_cast<int64_t>(g) * C;
   else p.dY += o * C;
@@ -846,6 +848,10 @@ extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_
                "small_batch: null x / code / offsets / S / lut / outputs");
   GNAN_REQUIRE(a->x_stride >= a->F, "small_batch: row stride smaller than the width");
   GNAN_REQUIRE(a->n_graphs <= 65535, "small_batch: at most 65535 graphs per launch");
+  GNAN_REQUIRE(a->cnt == nullptr || a->cnt_stride >= a->D, "small_batch: cnt row stride smaller than D");
+  if (a->cnt && (a->D > kWave || a->rho.C != 1))
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_batch: shell sizes need D <= %d and a one-channel rho (got D=%d rho.C=%d)", kWave,
+                      a->D, a->rho.C);
   const size_t need = gnan_small_batch_workspace_bytes(a->n_graphs, a->total_nodes, a->F, a->f.C);
   if (a->workspace == nullptr || a->workspace_bytes < need)
     return gnan::fail(GNAN_ERR_WORKSPACE, "small_batch: workspace %zu B < required %zu B", a->workspace_bytes, need);
@@ -853,7 +859,7 @@ extern "C" int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_
   SmallParams& p = bp.base;
   p.x = a->x; p.x_stride = a->x_stride; p.n = 0; p.F = a->F;
   p.f = to_mlp(&a->f); p.r = to_mlp(&a->rho);
-  p.code = a->code; p.D = a->D; p.cnt = nullptr; p.cnt_stride = 0;
+  p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
   p.S = a->S; p.lut = a->lut; p.Y = a->Y; p.Ysum = a->Ysum;
   p.counter = static_cast<unsigned*>(a->workspace);
   p.part = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + static_cast<size_t>(a->n_graphs) * 128);
@@ -940,6 +946,9 @@ extern "C" int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_str
                "small_batch_bwd: null x / code / offsets / S / lut / output gradient");
   GNAN_REQUIRE(a->x_stride >= a->F, "small_batch_bwd: row stride smaller than the width");
   GNAN_REQUIRE(a->n_graphs <= 65535, "small_batch_bwd: at most 65535 graphs per launch");
+  GNAN_REQUIRE(a->cnt == nullptr || a->cnt_stride >= a->D, "small_batch_bwd: cnt row stride smaller than D");
+  if (a->cnt && a->rho.C != 1)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_batch_bwd: shell sizes need a one-channel rho (got rho.C=%d)", a->rho.C);
   const size_t need = static_cast<size_t>(a->n_graphs) * static_cast<size_t>(slab) * sizeof(float);
   if (a->workspace == nullptr || a->workspace_bytes < need)
     return gnan::fail(GNAN_ERR_WORKSPACE, "small_batch_bwd: workspace %zu B < required %zu B", a->workspace_bytes, need);
@@ -957,7 +966,7 @@ extern "C" int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_str
   if (a->f.L != 3) { p.f.d_w_mid = nullptr; p.f.d_b_mid = nullptr; }
   if (a->rho.L != 3) { p.r.d_w_mid = nullptr; p.r.d_b_mid = nullptr; }
   p.f_mid = a->f.L == 3; p.r_mid = a->rho.L == 3;
-  p.code = a->code; p.D = a->D; p.cnt = nullptr; p.cnt_stride = 0;
+  p.code = a->code; p.D = a->D; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride;
   p.S = a->S; p.lut = a->lut; p.dY = a->dYsum ? nullptr : a->dY; p.dYsum = a->dYsum; p.pre_rho = 0;
   p.rho_groups = 1; p.rows_per = 0; p.part = nullptr; p.counter = nullptr;
   p.rho_raw = a->rho_raw_hops != 0; p.rest_zero = a->rest_zero != 0; p.rho_c = a->rho.C;

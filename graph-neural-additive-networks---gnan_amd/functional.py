@@ -923,6 +923,7 @@ def rho_row_lut(cnt: torch.Tensor, u: torch.Tensor, p: StackedMLP) -> torch.Tens
 PAD_FEATURES = 16            # the fast look-up / moment kernels and the 16-byte operand gathers want whole 16-feature groups
 PAD_MIN_WORK = 1 << 26       # n * F from which a ragged feature count is padded: the arxiv-shaped graph (n * F = 2^24.4) is
                              # bound by the host, the six concatenations (and their backward) cost it 0.1 / 1.5 ms
+PAD_MIN_WORK_STORE = 1 << 22  # ... when the parameter store already holds the padded stack (no concatenations): from 4M look-ups
 _X_PAD_CACHE = TensorKeyedCache(4)   # feature matrix (object identity + version), padded width -> zero-padded copy
 
 
@@ -994,14 +995,17 @@ def _feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_tot
         if total is None:
             total = column_sums(out if total_rows is None else out[:total_rows])
         return out, total
-    if PAD_FEATURES and p.F % PAD_FEATURES and p.C == 1 and p.L >= 2 and x.shape[0] * p.F >= PAD_MIN_WORK:
+    twin = getattr(p.w_last, "gnan_padded", None)           # modules.FlatMLPStore: the padded problem without the concatenations
+    if (PAD_FEATURES and p.F % PAD_FEATURES and p.C == 1 and p.L >= 2
+            and x.shape[0] * p.F >= (PAD_MIN_WORK_STORE if twin is not None else PAD_MIN_WORK)):
         # Real inputs have F = raw features + the ones column (129 for arxiv / papers100M): rows that are not 16-byte
         # aligned and a last feature group that is not whole, i.e. the general look-up kernel, scalar operand gathers
         # (F = 65 instead of 64 on the 10M-node graph: 22.4 instead of 5.7 ms per forward) and no bf16 rows.  The
         # problem is padded to a multiple of 16 features with all-zero shape functions instead: x once per (static)
         # feature matrix, the stacked weights per call (a few tiny concatenations autograd sees through).
         Fp = (p.F + PAD_FEATURES - 1) // PAD_FEATURES * PAD_FEATURES
-        res = _feature_mlps(_padded_x(x, Fp), _padded_stack(p, Fp), sum_features, return_total, out_dtype, total_rows)
+        padded = twin if (twin is not None and twin.F == Fp) else _padded_stack(p, Fp)
+        res = _feature_mlps(_padded_x(x, Fp), padded, sum_features, return_total, out_dtype, total_rows)
         if sum_features or pad_ok:              # [n, C] either way; or the caller takes the zero columns along
             return res
         if return_total:

@@ -35,6 +35,9 @@ import torch
 GRAPHED_STEPS = os.environ.get("GNAN_GRAPHED_STEPS", "1") != "0"
 GRAPH_AFTER = 2                      # eager epochs before a step is captured (they are the capture's warm-up)
 GRAPH_TASK_MAX_SHAPES = 4096         # captured steps a graph-level task may hold (each owns a private memory pool: >= 2 MB)
+SLOT_STEPS = True                    # graph-level tasks: ONE captured step over graph slots (graphed.SlotGraphStep) for every graph that
+                                     # fits them (<= 128 nodes, <= 63 hops); per-shape steps only for the others
+SLOT_AFTER = 2                       # eager steps of the loop before the slot step is captured (lazy initialisations, table sizes)
 
 
 class _StepStore:
@@ -89,6 +92,10 @@ def release_steps(model) -> None:
     if store is None:
         return
     recs = [e.value for e in store.node.entries.values()]
+    for steps in (store.graph, store.graph_eval):
+        if steps is not None and steps.slot is not None:
+            steps.slot.step.release(restore_optimizer=False)
+            steps.slot = None
     if store.graph is not None:
         recs += list(store.graph.buckets.values())
         store.graph.restore_optimizer()
@@ -325,6 +332,75 @@ class _GraphTaskSteps:
         self.total_loss = torch.zeros((), device=device)
         self.hits = torch.zeros((), device=device)
         self.labels = None
+        self.slot, self.slot_calls, self.slot_dead, self.slot_use_cnt = None, 0, False, None
+
+    def _loss_closure(self):
+        loss_fn, classify = self.loss_fn(), self.classify
+
+        def loss_of(outputs, label):
+            kind = _fused_kind(loss_fn, outputs)
+            if kind is not None and outputs.shape[0] == label.numel():
+                from .losses import loss_step
+                loss, _ = loss_step(outputs, label, kind, want_hits=False, loss_sum=self.total_loss,
+                                    hits_sum=self.hits if classify else None, unit_upstream=True)
+                return loss, None
+            loss = _loss_of(loss_fn, outputs, label)
+            self.total_loss.add_(loss.detach())
+            if classify:
+                self.hits.add_(_hits(outputs.detach(), label))
+            return loss, None
+        return loss_of
+
+    def _slot_mode(self, model):
+        """``use_cnt`` of the slot step this model can run (True / False), or None: the read-out of a graph-level task with
+        post-rho (or no) normalisation, a one-channel rho, features summed per node (small_graph.slot_graph_applies)."""
+        if self.slot_use_cnt is None:
+            from . import modules
+            from .small_graph import slot_graph_applies
+            mode = "no"
+            if (SLOT_STEPS and isinstance(model, (modules.TensorGNAN, modules.StandaloneTensorGNAN)) and model.is_graph_task
+                    and not (isinstance(model, modules.TensorGNAN) and (model.readout_n_layers > 0 or model.aggregation_order == "reference"))
+                    and not (isinstance(model, modules.StandaloneTensorGNAN) and model.normalize_rho)):
+                with torch.no_grad():
+                    f, rho = model._stacked("fs", model.fs), model._stacked("rho", [model.rho])
+                import types
+                if slot_graph_applies(types.SimpleNamespace(F=f.F), f, rho):
+                    mode = bool(model.normalize_rho)
+            self.slot_use_cnt = mode
+        return None if self.slot_use_cnt == "no" else self.slot_use_cnt
+
+    def _slot_step(self, model, graph, data, labels):
+        """True: the step ran from the slot capture.  False: this graph is for the other routes."""
+        from .graphed import CaptureFailed, SlotGraphStep
+        use_cnt = self._slot_mode(model)
+        if use_cnt is None or self.slot_dead:
+            return False
+        if self.slot is None:
+            if self.slot_calls < SLOT_AFTER:
+                self.slot_calls += 1
+                return False
+            from .small_graph import SLOT_CODES, SLOT_MAX_NODES
+            if not (graph.n_rows <= SLOT_MAX_NODES and graph.n_codes <= SLOT_CODES and data.x.dtype == torch.float32):
+                return False                           # (captured on the first graph that fits)
+            try:
+                if self.prepared is None and self.training:
+                    from .graphed import prepare_optimizer
+                    self.prepared = prepare_optimizer(self.optimizer())
+                self.slot = SlotGraphStep(model, self.optimizer(), self._loss_closure(), int(data.x.shape[1]), labels, use_cnt,
+                                          prepared=self.prepared, first=(graph, data.x, labels))
+                self.captured += 1
+            except CaptureFailed as e:
+                self.slot_dead = True
+                warnings.warn(f"gnan_amd: the graph-task slot step could not be captured into a hipGraph ({e}); per-shape steps instead")
+                return False
+        if not self.slot.fits(graph, data.x, labels):
+            return False
+        if self.slot.run(graph, data.x, labels) is None:     # stale (parameters moved, mode or hyper-parameters changed): capture anew
+            self.slot.step.release(restore_optimizer=False)
+            self.slot, self.slot_calls = None, SLOT_AFTER
+            self.captured -= 1
+            return False
+        return True
 
     def matches(self, model, optimizer, loss_fn, classify) -> bool:
         return (self.model() is model and self.optimizer() is optimizer and self.loss_fn() is loss_fn
@@ -356,6 +432,10 @@ class _GraphTaskSteps:
         graph = model.hop_graph(data)
         if not graph.is_dense:
             return False
+        if self._slot_step(model, graph, data, labels):
+            return True
+        if self.slot is not None and self.slot.fits(graph, data.x, labels):
+            return False                                # (the slot step just went stale: this graph steps eagerly, the next one re-captures)
         key = (graph.n_rows, graph.n_cols, graph.n_codes, tuple(data.x.shape), data.x.dtype, tuple(labels.shape), labels.dtype)
         rec = self.buckets.get(key)
         if rec is None:
@@ -366,20 +446,7 @@ class _GraphTaskSteps:
             if rec["calls"] < GRAPH_AFTER or self.captured >= GRAPH_TASK_MAX_SHAPES:
                 rec["calls"] += 1
                 return False
-            loss_fn, classify = self.loss_fn(), self.classify
-
-            def loss_of(outputs, label):
-                kind = _fused_kind(loss_fn, outputs)
-                if kind is not None and outputs.shape[0] == label.numel():
-                    from .losses import loss_step
-                    loss, _ = loss_step(outputs, label, kind, want_hits=False, loss_sum=self.total_loss,
-                                        hits_sum=self.hits if classify else None, unit_upstream=True)
-                    return loss, None
-                loss = _loss_of(loss_fn, outputs, label)
-                self.total_loss.add_(loss.detach())
-                if classify:
-                    self.hits.add_(_hits(outputs.detach(), label))
-                return loss, None
+            loss_of = self._loss_closure()
             try:
                 if self.prepared is None and self.training:
                     from .graphed import prepare_optimizer
@@ -405,6 +472,9 @@ def _graph_task_steps(model, optimizer, loss_fn, classify, device):
         if steps is not None:
             for rec in steps.buckets.values():
                 _drop_step(rec)
+            if steps.slot is not None:
+                steps.slot.step.release(restore_optimizer=False)
+                steps.slot = None
             steps.restore_optimizer()
         try:
             steps = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)

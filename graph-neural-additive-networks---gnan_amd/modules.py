@@ -63,6 +63,7 @@ GRAPH_CACHE_ENTRIES = 8192   # hop-coded graphs kept per model (graph tasks cycl
 # way; ``named_parameters()`` / ``state_dict()`` keep the reference's per-layer names and shapes (``sum(p.numel())``, main.py:92-97,
 # is the same).  False: ``parameters()`` is torch's own.
 FLAT_PARAMETERS = True
+PAD_STORE_FEATURES = True    # FlatMLPStore keeps room for F rounded up to 16 features (all-zero shape functions): see rebuild()
 
 
 class FlatMLPStore:
@@ -89,23 +90,39 @@ class FlatMLPStore:
         self.C = lin[0][-1].out_features
         self.H = lin[0][0].out_features if L >= 2 else 0
 
-        def home(layers, attr):                       # stack [len(layers), F, ...] and turn the Parameters into views
+        # A ragged feature count (F = raw features + the ones column: 129 on ogbn-arxiv / papers100M) keeps the fast look-up and
+        # moment kernels away (whole 16-feature groups, 16-byte rows).  The buffers are therefore allocated for Fp = F rounded
+        # up to 16 features, the extra ones all-zero shape functions that no Parameter, gradient view or optimizer ever sees:
+        # ``buf`` / ``grad`` / the flat Parameters are the first F features (contiguous: one layer per buffer), ``pbuf`` /
+        # ``pgrad`` the whole padded storage the kernels may take instead (``stacked(...).w_last.gnan_padded``) — what
+        # functional._padded_stack builds with six concatenations per forward, for free.
+        pad = PAD_STORE_FEATURES and self.F >= 16 and self.F % 16 and self.C == 1 and L in (2, 3)
+        self.Fp = (self.F + 15) // 16 * 16 if pad else self.F
+
+        def home(layers, attr):                       # stack [len(layers), Fp, ...] and turn the Parameters into views
             with torch.no_grad():
                 buf = torch.stack([torch.stack([getattr(lin[k][l], attr).data for k in range(self.F)], 0)
                                    for l in layers], 0).contiguous()
+                if self.Fp != self.F:
+                    whole = buf.new_zeros((buf.shape[0], self.Fp) + tuple(buf.shape[2:]))
+                    whole[:, :self.F] = buf
+                    buf = whole
                 for i, l in enumerate(layers):
-                    for k, view in enumerate(buf[i].unbind(0)):      # one C++ call for the F views
+                    for k, view in enumerate(buf[i].unbind(0)[:self.F]):      # one C++ call for the views
                         getattr(lin[k][l], attr).data = view
             return buf
         first, mid, last = ([0], list(range(1, L - 1)), [L - 1]) if L >= 2 else ([], [], [0])
         self.slots = {"first": first, "mid": mid, "last": last}
-        self.buf = {}
+        self.buf, self.pbuf = {}, {}
         for part, layers in self.slots.items():
             if layers:
-                self.buf[part + "_w"] = home(layers, "weight")
-                if self.has_bias:
-                    self.buf[part + "_b"] = home(layers, "bias")
-        self.grad, self.grad_views, self.pending = {}, {}, {}
+                for attr, tag in (("weight", "_w"), ("bias", "_b")):
+                    if tag == "_b" and not self.has_bias:
+                        continue
+                    whole = home(layers, attr)
+                    self.pbuf[part + tag] = whole
+                    self.buf[part + tag] = whole[:, :self.F] if self.Fp != self.F else whole
+        self.grad, self.pgrad, self.grad_views, self.pending = {}, {}, {}, {}
         track = bool(lin[0][-1].weight.requires_grad)
         for name, buf in self.buf.items():
             fp = self.flat.get(name)
@@ -183,31 +200,40 @@ class FlatMLPStore:
         second backward pass before ``zero_grad``) or has been handed out already.  The tensor comes back through autograd as
         the proxy leaf's gradient; :meth:`_on_grad` recognises it and only links the views (no copy: 5 us per buffer, twelve
         per step of a small graph)."""
-        if self.pending.get(name) or self._occupied(name) or self.buf[name].dtype != torch.float32:
+        if self.pending.get(name) is not None or self._occupied(name) or self.buf[name].dtype != torch.float32:
             return None
-        if name not in self.grad:
-            self.grad[name] = torch.empty_like(self.buf[name])
+        self._grad_buffer(name)
         view = self._kernel_view(name, self.grad[name])
-        if view is self.grad[name]:
+        if tuple(view.shape) != tuple(shape) and self.Fp != self.F:
+            view = self._kernel_view(name, self.pgrad[name])      # the padded twin's gradient: the whole padded buffer
+        if view is self.grad[name] or view is self.pgrad[name]:
             view = view.view(view.shape)              # a tensor object of its own: autograd keeps (not clones) a gradient nobody else holds
         if view.shape != shape or view.device != device or not view.is_contiguous():
             return None
-        self.pending[name] = True
+        self.pending[name] = view
         return view
 
+    def _grad_buffer(self, name: str) -> torch.Tensor:
+        """The persistent gradient buffer of ``buf[name]`` (first F features of ``pgrad[name]``, which mirrors ``pbuf[name]``)."""
+        if name not in self.grad:
+            whole = torch.zeros_like(self.pbuf[name])
+            self.pgrad[name] = whole
+            self.grad[name] = whole[:, :self.F] if self.Fp != self.F else whole
+        return self.grad[name]
+
     def _on_grad(self, name: str, g: torch.Tensor) -> None:
-        full = self.buf[name]
-        have = self.grad.get(name)
-        if self.pending.get(name) and have is not None and g.data_ptr() == have.data_ptr() and g.numel() == have.numel():
-            self.pending[name] = False                # written in place by the kernel (grad_dest)
+        handed = self.pending.get(name)
+        if handed is not None and g.data_ptr() == handed.data_ptr() and g.numel() == handed.numel():
+            self.pending[name] = None                 # written in place by the kernel (grad_dest)
         else:
-            g = g.reshape(full.shape).to(full.dtype)
-            if self._occupied(name) or self.pending.get(name):
-                self.grad[name].add_(g)               # ordinary autograd accumulation, on the flat buffer (a pending direct
+            self._grad_buffer(name)
+            # (a gradient of the padded twin has the padded buffer's size; its extra features' entries are nobody's gradient)
+            dest = self.pgrad[name] if (self.Fp != self.F and g.numel() == self.pgrad[name].numel()) else self.grad[name]
+            g = g.reshape(dest.shape).to(dest.dtype)
+            if self._occupied(name) or handed is not None:
+                dest.add_(g)                          # ordinary autograd accumulation, on the flat buffer (a pending direct
             else:                                     # write already sits in it)
-                if name not in self.grad:
-                    self.grad[name] = torch.empty_like(full)
-                self.grad[name].copy_(g)              # the buffer (and the views cut from it) persists across steps
+                dest.copy_(g)                         # the buffer (and the views cut from it) persists across steps
         if not self._linked(name):
             self._link_grads(name)
         fp = self.flat[name]
@@ -222,28 +248,36 @@ class FlatMLPStore:
             return
         for name, buf in self.buf.items():
             if name not in self.grad:
-                self.grad[name] = torch.zeros_like(buf)
+                self._grad_buffer(name)
             elif not self._occupied(name):
                 self.grad[name].zero_()
-            self.pending[name] = False
+            self.pending[name] = None
             if not self._linked(name):
                 self._link_grads(name)
             if self.flat[name].grad is not self.grad[name]:
                 self.flat[name].grad = self.grad[name]
 
     def stacked(self, track_grad: bool) -> StackedMLP:
-        out = {}
-        if track_grad and any(self.pending.values()):
+        if track_grad and any(v is not None for v in self.pending.values()):
             self.pending.clear()                      # a backward pass that claimed a destination never finished
-        for name, t in self.buf.items():
-            v = self._kernel_view(name, t)
-            if track_grad:
-                v = v.detach().requires_grad_(True)
-                v.register_hook(lambda g, name=name: self._on_grad(name, g))
-                v.gnan_grad_dest = lambda shape, device, name=name: self.grad_dest(name, shape, device)
-            out[name] = v
-        return StackedMLP(out.get("first_w"), out.get("first_b"), out.get("mid_w"), out.get("mid_b"),
-                          out["last_w"], out.get("last_b"), self.L, self.H, self.C, self.F)
+
+        def views(bufs, F):
+            out = {}
+            for name, t in bufs.items():
+                v = self._kernel_view(name, t)
+                if track_grad:
+                    v = v.detach().requires_grad_(True)
+                    v.register_hook(lambda g, name=name: self._on_grad(name, g))
+                    v.gnan_grad_dest = lambda shape, device, name=name: self.grad_dest(name, shape, device)
+                out[name] = v
+            return StackedMLP(out.get("first_w"), out.get("first_b"), out.get("mid_w"), out.get("mid_b"),
+                              out["last_w"], out.get("last_b"), self.L, self.H, self.C, F)
+        st = views(self.buf, self.F)
+        if self.Fp != self.F:
+            # the same shape functions followed by Fp - F all-zero ones, over the padded storage: what the fast kernels take for
+            # a ragged feature count (functional._feature_mlps); only ONE of the two sets of leaves receives a forward's gradient
+            st.w_last.gnan_padded = views(self.pbuf, self.Fp)
+        return st
 
 
 class _PathBase(nn.Module):
@@ -419,7 +453,15 @@ class _PathBase(nn.Module):
         """The whole forward by one launch where ``gnan_small_graph_fwd`` applies (a small dense-coded graph, features summed
         per node: what a graph-level task feeds per step; ``use_cnt``: False, True = post-rho normalisation, "pre" =
         GNAN.py:65-67), else None."""
-        from .small_graph import SMALL_GRAPH_MAX_NODES, small_graph_applies, small_graph_forward
+        from .small_graph import (SMALL_GRAPH_MAX_NODES, SlotGraph, slot_graph_applies, slot_graph_forward, small_graph_applies,
+                                  small_graph_forward)
+        if isinstance(g, SlotGraph):
+            # a captured step of a batch-size-1 loop: the graph sits in slots, its size is the device's to know
+            f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])
+            if use_cnt == "pre" or not graph_sum or not slot_graph_applies(g, f, rho):
+                raise _lib.GnanHipError("graph slots serve graph-level read-outs with post-rho (or no) normalisation, a one-channel "
+                                        "rho and at most 8 output channels")
+            return slot_graph_forward(g, f, rho, bool(use_cnt))
         if not g.is_dense or x.shape[0] > SMALL_GRAPH_MAX_NODES:
             return None
         f, rho = self._stacked("fs", self.fs), self._stacked("rho", [self.rho])

@@ -266,3 +266,86 @@ def small_graph_nam_forward(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: St
     _lib.require_device(x, f.w_last, rho.w_last, nam.w_last, g.code)
     return _SmallGraphNam.apply(x, g, bool(use_cnt), (f.L, f.H, f.F), (rho.L, rho.H), (nam.L, nam.H, nam.C),
                                 *f[:6], *rho[:6], *nam[:6])
+
+
+# =============================================================================
+# one graph in slots: a batch-size-1 loop through ONE captured step
+# =============================================================================
+SLOT_MAX_NODES = 128
+SLOT_CODES = 64              # hop codes the slots are laid out for (hops 0 .. 62 + the rest code); what gnan_small_batch_bwd covers
+_SLOT_CNT = None             # TensorKeyedCache: a graph's shell sizes (object identity + version) -> their [n, SLOT_CODES] layout
+
+
+class SlotGraph:
+    """ONE small dense-coded graph held in device slots whose SIZE only the device knows (``node_off = [0, n]``,
+    ``code_off = [0, n * n]``): what a captured step of a graph-level task reads (trainer.py:23-86 feeds one graph of another
+    size per step).  The batched kernels (``gnan_small_batch_fwd`` / ``_bwd``: blockIdx.y = graph, sizes from the offset
+    arrays) run it as a batch of one, with the shell sizes (``cnt``, ABI 42) and the reference's rho arguments — so ONE capture
+    serves every graph of up to 128 nodes and 63 hops, instead of one capture per (nodes, features, shells) shape.
+    ``cnt`` is laid out for ``SLOT_CODES`` codes whatever the graph's own largest hop: its listed hops keep their columns, its
+    rest bucket (unreachable pairs, code 255) moves to the last column, the columns between are hops no pair has."""
+    is_dense = True
+
+    def __init__(self, n_features: int, device, use_cnt: bool = True):
+        from .batched import HopBlocks
+        self.F, self.device, self.n_codes = int(n_features), torch.device(device), SLOT_CODES
+        self.x = torch.zeros((SLOT_MAX_NODES, self.F), dtype=torch.float32, device=device)
+        self.code = torch.full((SLOT_MAX_NODES * SLOT_MAX_NODES,), 255, dtype=torch.uint8, device=device)
+        self.cnt = torch.ones((SLOT_MAX_NODES, SLOT_CODES), dtype=torch.int32, device=device) if use_cnt else None
+        self.node_off = torch.zeros(2, dtype=torch.int32, device=device)
+        self.code_off = torch.zeros(2, dtype=torch.int64, device=device)
+        self.blocks = HopBlocks(self.code, self.node_off, self.code_off, [0], SLOT_CODES - 2)
+        self.blocks.total_nodes, self.blocks.max_nodes, self.blocks.min_nodes, self.blocks.slots = SLOT_MAX_NODES, SLOT_MAX_NODES, 1, True
+        self._offs = {}
+
+    def fits(self, graph: HopGraph, x: torch.Tensor) -> bool:
+        return bool(graph.is_dense and 1 <= graph.n_rows == graph.n_cols <= SLOT_MAX_NODES and graph.n_codes <= SLOT_CODES
+                    and x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (graph.n_rows, self.F)
+                    and (self.cnt is None or graph.cnt is not None))
+
+    def _cnt_layout(self, graph: HopGraph) -> torch.Tensor:
+        global _SLOT_CNT
+        if _SLOT_CNT is None:
+            from ._cache import TensorKeyedCache
+            _SLOT_CNT = TensorKeyedCache(1 << 16)
+        hit = _SLOT_CNT.get((graph.cnt,), SLOT_CODES)
+        if hit is None:
+            D = graph.n_codes
+            wide = torch.ones((graph.n_rows, SLOT_CODES), dtype=torch.int32, device=graph.cnt.device)
+            wide[:, : D - 1] = graph.cnt[:, : D - 1]
+            wide[:, SLOT_CODES - 1] = graph.cnt[:, D - 1]
+            hit = _SLOT_CNT.put((graph.cnt,), SLOT_CODES, wide)
+        return hit
+
+    def load(self, graph: HopGraph, x: torch.Tensor, extra=()) -> None:
+        """Copy a graph (that :meth:`fits`) into the slots — one launch (``gnan_multi_copy``); ``extra``: further (dst, src) pairs."""
+        n = graph.n_rows
+        offs = self._offs.get(n)
+        if offs is None:
+            offs = self._offs[n] = (torch.tensor([0, n], dtype=torch.int32, device=self.device),
+                                    torch.tensor([0, n * n], dtype=torch.int64, device=self.device))
+        pairs = [(self.x[:n], x), (self.code[: n * n], graph.code.reshape(-1)), (self.node_off, offs[0]), (self.code_off, offs[1])]
+        if self.cnt is not None:
+            pairs.append((self.cnt[:n], self._cnt_layout(graph)))
+        pairs += list(extra)
+        if all(sr.is_contiguous() and sr.dtype == d.dtype and sr.shape == d.shape and sr.is_cuda for d, sr in pairs) and len(pairs) <= 8:
+            _lib.multi_copy(pairs)
+            return
+        for d, sr in pairs:
+            d.copy_(sr)
+
+
+def slot_graph_applies(slot: SlotGraph, f: StackedMLP, rho: StackedMLP) -> bool:
+    return bool(f.F == slot.F and rho.F == 1 and f.L in (2, 3) and rho.L in (2, 3) and 1 <= f.H <= 64 and 1 <= rho.H <= 64
+                and f.C <= 8 and rho.C == 1 and all(t is None or t.dtype == torch.float32 for t in tuple(f[:6]) + tuple(rho[:6])))
+
+
+def slot_graph_forward(slot: SlotGraph, f: StackedMLP, rho: StackedMLP, use_cnt: bool) -> torch.Tensor:
+    """The graph read-out ``[C, 1]`` (GNAN.py:75-79 / models.py:383-384) of the graph in the slots: one launch forward, two
+    backward (``gnan_small_batch_bwd`` + the slab reduction)."""
+    from .batched import _BatchedGraphs
+    if use_cnt and slot.cnt is None:
+        raise _lib.GnanHipError("these slots were laid out without shell sizes")
+    fm, rm = (f.L, f.H, f.C, f.F), (rho.L, rho.H, rho.C)
+    out = _BatchedGraphs.apply(slot.x, slot.blocks, True, fm, rm, slot.cnt if use_cnt else None, False, *f[:6], *rho[:6])   # [1, C]
+    return out.reshape(-1, 1)

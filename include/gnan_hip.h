@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 41
+#define GNAN_ABI_VERSION 42
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -539,6 +539,9 @@ typedef struct gnan_loss_args {
                                 guard tripped is re-run eagerly and counted then) */
   void* workspace;           /* gnan_loss_workspace_bytes(n) */
   size_t workspace_bytes;
+  float* label_flag;         /* optional [1] device flag (ABI 42): set to 1 by a cross-entropy row whose class label lies
+                                outside [0, C) — torch leaves ignore_index rows out of the mean, this kernel averages over all n
+                                rows: a caller that cannot look at the labels on the host (a replayed step) reads the flag later */
 } gnan_loss_args;
 size_t gnan_loss_workspace_bytes(int64_t n);
 int gnan_loss_step(const gnan_loss_args* a, gnan_stream_t stream);
@@ -619,6 +622,11 @@ typedef struct gnan_small_batch_args {
   float* Ysum;               /* optional [n_graphs, f.C] */
   void* workspace;
   size_t workspace_bytes;
+  const int32_t* cnt;        /* optional [total_nodes, cnt_stride] shell sizes (ABI 42): pair (i, j) of a graph then weighs
+                                lut[d] / max(cnt[i, d], 1) as in gnan_small_graph_fwd — the post-rho normalisation of
+                                models.py:368-370 for a "batch" whose graphs (often just one: trainer.py's batch_size = 1) sit
+                                in slots whose sizes only the device knows; needs D <= 64 and a one-channel rho */
+  int64_t cnt_stride;        /* >= D */
 } gnan_small_batch_args;
 size_t gnan_small_batch_workspace_bytes(int32_t n_graphs, int64_t total_nodes, int32_t F, int32_t C);
 int gnan_small_batch_fwd(const gnan_small_batch_args* a, gnan_stream_t stream);
@@ -696,6 +704,8 @@ typedef struct gnan_small_batch_bwd_args {
   gnan_small_mlp_grads drho;
   void* workspace;
   size_t workspace_bytes;
+  const int32_t* cnt;        /* optional shell sizes, as in gnan_small_batch_args (ABI 42) */
+  int64_t cnt_stride;
 } gnan_small_batch_bwd_args;
 size_t gnan_small_batch_bwd_workspace_bytes(const gnan_small_batch_bwd_args* a);
 int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_stream_t stream);

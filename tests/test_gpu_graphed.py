@@ -309,6 +309,7 @@ def test_graph_task_steps_replayed_per_shape_match_eager_steps(readout, monkeypa
     _need_gpu()
     from gnan_amd import harness
     from gnan_amd.models import TensorGNAN
+    monkeypatch.setattr(harness, "SLOT_STEPS", False)          # (the per-shape steps: what graphs beyond the slots and the NAM read-out take)
     F = 15
     graphs = _graph_task(45, F, sizes=[12, 30, 12, 23, 30, 12, 41])
     loss_fn = torch.nn.BCEWithLogitsLoss()
@@ -352,6 +353,7 @@ def test_optimizers_the_flat_update_declines_are_replayed_with_their_own_step(ta
     _need_gpu()
     from gnan_amd import harness
     from gnan_amd.models import TensorGNAN
+    monkeypatch.setattr(harness, "SLOT_STEPS", False)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     if task == "graph":
         F = 15
@@ -474,6 +476,7 @@ def test_graph_task_evaluation_passes_are_replayed_per_shape(readout, monkeypatc
     _need_gpu()
     from gnan_amd import harness
     from gnan_amd.models import TensorGNAN
+    monkeypatch.setattr(harness, "SLOT_STEPS", False)
     F = 15
     graphs = _graph_task(60, F, sizes=[12, 30, 12, 23, 30, 12, 41])
     loss_fn = torch.nn.BCEWithLogitsLoss()
@@ -500,3 +503,94 @@ def test_graph_task_evaluation_passes_are_replayed_per_shape(readout, monkeypatc
     moved_eager = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
     assert abs(moved[0] - moved_eager[0]) <= 1e-6 * max(1.0, abs(moved_eager[0])) and abs(moved[0] - want[0]) > 1e-6
     harness.release_steps(m)
+
+
+# ---------------------------------------------------------------------------------------------------------- graph slots
+@pytest.mark.parametrize("normalize", [True, False])
+def test_slot_graph_forward_backward_equal_the_one_launch_path(normalize):
+    """small_graph.SlotGraph: one graph in device slots (its size known to the device only), forwarded and back-propagated by
+    the batched kernels with the shell sizes (ABI 42) == the per-graph one-launch kernels on the same graph: graphs of 1 to
+    128 nodes, with unreachable pairs, one and three output channels; and == the float64 oracle."""
+    _need_gpu()
+    from gnan_amd.models import TensorGNAN
+    from gnan_amd.small_graph import SlotGraph, slot_graph_applies, slot_graph_forward
+    from oracle import gnan_oracle as O
+    F = 7
+    graphs = _graph_task(12, F, sizes=[1, 5, 128, 64, 65, 30, 17, 100, 2, 41, 12, 90], seed=3)
+    for C in (1, 3):
+        torch.manual_seed(C)
+        m = TensorGNAN(F, C, 3, hidden_channels=16, is_graph_task=True, readout_n_layers=0, normalize_rho=normalize, device=DEV)
+        with torch.no_grad():
+            for _, p in m.named_parameters():
+                p.copy_(torch.randn(p.shape) * 0.5)
+        m = m.to(DEV).eval()
+        slot = SlotGraph(F, DEV, use_cnt=normalize)
+        for d in graphs:
+            g = m.hop_graph(d)
+            assert slot.fits(g, d.x)
+            m.zero_grad()
+            y0 = m.forward(d)
+            y0.pow(2).sum().backward()
+            g0 = {k: p.grad.clone() for k, p in m.named_parameters()}
+            slot.load(g, d.x)
+            m.zero_grad()
+            f, rho = m._stacked("fs", m.fs), m._stacked("rho", [m.rho])
+            assert slot_graph_applies(slot, f, rho)
+            y1 = slot_graph_forward(slot, f, rho, normalize)
+            y1.pow(2).sum().backward()
+            assert y1.shape == y0.shape == (C, 1)
+            scale = float(y0.abs().max()) + 1e-30
+            assert float((y1 - y0).abs().max()) <= 2e-6 * scale, (C, d.x.shape, float((y1 - y0).abs().max()) / scale)
+            gscale = max(float(v.abs().max()) for v in g0.values()) + 1e-30
+            for k, p in m.named_parameters():
+                assert float((p.grad - g0[k]).abs().max()) <= 2e-6 * gscale, (C, d.x.shape, k)
+            sd64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+            truth = O.tensor_gnan_forward_models(d.x.cpu().double(), d.node_distances.cpu().double(),
+                                                 d.normalization_matrix.cpu().double(), sd64, normalize, True, 0)
+            assert O.rel_err(y1.detach().cpu(), truth) <= 1e-5
+
+
+def test_graph_task_epochs_through_one_slot_step(monkeypatch):
+    """Graph-level task, batch_size = 1 (trainer.py:23-86): with graph slots the harness captures ONE training step (and one
+    evaluation step) per model, after two eager steps of the FIRST epoch, and replays it for every graph of up to 128 nodes
+    whatever its shape; larger graphs keep their own routes.  Epoch returns and parameters == the eager loop's."""
+    _need_gpu()
+    from gnan_amd import harness
+    from gnan_amd.models import TensorGNAN
+    F = 15
+    graphs = _graph_task(40, F, sizes=[12, 30, 9, 23, 130, 12, 41, 77, 5, 128])
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+
+    def make():
+        torch.manual_seed(0)
+        m = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, readout_n_layers=0, device=DEV)
+        with torch.no_grad():
+            for _, p in m.named_parameters():
+                p.copy_(torch.randn(p.shape) * 0.3)
+        m = m.to(DEV).eval()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3)
+    runs = {}
+    for on in (False, True):
+        monkeypatch.setattr(harness, "GRAPHED_STEPS", on)
+        m, opt = make()
+        hist = []
+        for epoch in range(3):
+            tr = harness.train_epoch(m, graphs, loss_fn, opt, DEV, classify=True, is_graph_task=True)
+            te = harness.test_epoch(m, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+            hist.append((tr[0], tr[1], te[0], te[1]))
+        runs[on] = (hist, {k: v.detach().clone() for k, v in m.state_dict().items()}, m)
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a[0] - b[0]) <= 1e-5 * max(1.0, abs(a[0])) and a[1] == b[1], (a, b)
+        assert abs(a[2] - b[2]) <= 1e-5 * max(1.0, abs(a[2])) and a[3] == b[3], (a, b)
+    scale = max(float(v.abs().max()) for v in runs[False][1].values())
+    for k, v in runs[False][1].items():
+        assert float((v - runs[True][1][k]).abs().max()) <= 1e-5 * scale, k
+    store = harness._steps_of(runs[True][2])
+    for steps, epochs in ((store.graph, 3), (store.graph_eval, 3)):
+        assert steps.slot is not None
+        n_fit = sum(d.x.shape[0] <= 128 for d in graphs)
+        assert steps.slot.step.graph.replays >= epochs * n_fit - 2          # from the third step of the first epoch on
+        assert steps.slot.step.graph.kernel_nodes <= 8
+        # the 130-node graphs: their own per-shape steps (or eager), never the slots
+        assert all(key[0] > 128 for key in steps.buckets)
+    harness.release_steps(runs[True][2])

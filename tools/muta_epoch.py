@@ -72,13 +72,19 @@ def main():
         torch.cuda.synchronize()
         eval_ms.append((time.perf_counter() - t0) / count * 1e3)
     st = harness._steps_of(m).graph
+    slot = st.slot
     replayed = six = 0
     eager_sizes, kernel_hist = [], {}
     for g in graphs:
         hop = m.hop_graph(g)
         key = (hop.n_rows, hop.n_cols, hop.n_codes, tuple(g.x.shape), g.x.dtype, (1,), torch.float32)
         rec = st.buckets.get(key)
-        if rec is not None and rec["step"] is not None:
+        if slot is not None and slot.fits(hop, g.x, slot.label):       # the one slot step (graphed.SlotGraphStep)
+            replayed += 1
+            kn = int(slot.step.graph.kernel_nodes)
+            kernel_hist[kn] = kernel_hist.get(kn, 0) + 1
+            six += kn <= 6
+        elif rec is not None and rec["step"] is not None:
             replayed += 1
             kn = int(rec["step"].step.graph.kernel_nodes)
             kernel_hist[kn] = kernel_hist.get(kn, 0) + 1
@@ -87,7 +93,8 @@ def main():
             eager_sizes.append(int(g.x.shape[0]))
     out.update(train_ms_per_graph_by_epoch=[round(t, 4) for t in train_ms], eval_ms_per_graph_by_epoch=[round(t, 4) for t in eval_ms],
                epoch_s=round(train_ms[-1] * count / 1e3, 3), last=[float(v) for v in ret[:2]], shapes=len(st.buckets),
-               captured_shapes=sum(r["step"] is not None for r in st.buckets.values()),
+               captured_shapes=sum(r["step"] is not None for r in st.buckets.values()) + (slot is not None),
+               slot_step=slot is not None, slot_replays=int(slot.step.graph.replays) if slot is not None else 0,
                steps_replayed_from_a_captured_step=replayed, share_replayed=round(replayed / count, 4),
                steps_of_at_most_six_kernels=six, share_at_most_six_kernels=round(six / count, 4),
                kernels_per_step_histogram={str(k): v for k, v in sorted(kernel_hist.items())},
