@@ -593,7 +593,7 @@ def run_c2(args, rank=0, world=1):
         torch.cuda.synchronize()
         train_ms = (time.perf_counter() - t0) / len(labelled) * 1e3
         st = harness._steps_of(twin).graph
-        recs = [r["step"] for r in st.buckets.values() if r["step"] is not None] + ([st.slot] if st.slot is not None else [])
+        recs = [r["step"] for r in st.buckets.values() if r["step"] is not None] + list(st.slots.values())
         train_kernels = sorted({int(r.step.graph.kernel_nodes) for r in recs})
         captured_steps = len(recs)
     except Exception as e:

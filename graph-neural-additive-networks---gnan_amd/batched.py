@@ -397,9 +397,13 @@ class GraphedBatchStep:
     """
 
     def __init__(self, model: "TensorGNAN", optimizer, loss_of, x, blocks: HopBlocks, labels, node_capacity: Optional[int] = None,
-                 n_codes: Optional[int] = None, prepared=None):
+                 n_codes: Optional[int] = None, prepared=None, label_flag: Optional[torch.Tensor] = None):
         from .graphed import GraphedStep
         _lib.require_device(x, labels)
+        # the labels change with every replayed batch and nobody looks at them on the host: the fused cross entropy raises this
+        # flag on the device for a class label outside [0, C) (torch would have left such a row out of the mean); whoever reads
+        # the epoch's totals reads it too (train_epoch below)
+        self.label_flag = label_flag if label_flag is not None else torch.zeros(1, dtype=torch.float32, device=x.device)
         if isinstance(loss_of, nn.Module):
             from .losses import loss_kind, loss_step
             loss_module = loss_of
@@ -407,7 +411,8 @@ class GraphedBatchStep:
             def loss_of(out, lab):                   # noqa: F811  (the module's loss, fused where the kernel covers it)
                 kind = loss_kind(loss_module, out)
                 if kind is not None and out.shape[0] == lab.numel() and lab.dim() == 1:
-                    return loss_step(out, lab, kind, want_hits=False, unit_upstream=optimizer is not None)[0]
+                    return loss_step(out, lab, kind, want_hits=False, unit_upstream=optimizer is not None,
+                                     label_flag=self.label_flag)[0]
                 return loss_module(out, lab)
         dev = x.device
         self.n_graphs, self.F = blocks.n_graphs, int(x.shape[1])
@@ -488,8 +493,10 @@ def train_epoch(model: "TensorGNAN", loader, loss_fn, optimizer, steps: Optional
                     and blocks.min_nodes >= 1):
                 from .graphed import CaptureFailed
                 try:
+                    if "label_flag" not in steps:
+                        steps["label_flag"] = torch.zeros(1, dtype=torch.float32, device=dev)
                     gs = steps[blocks.n_graphs] = GraphedBatchStep(model, optimizer, loss_fn, x, blocks, y,
-                                                                   prepared=steps.get("prepared"))
+                                                                   prepared=steps.get("prepared"), label_flag=steps["label_flag"])
                     steps["prepared"] = gs.step.prepared
                     out, loss = gs.step.warmup_result[0], gs.step.warmup_result[1]     # (construction ran this batch's step)
                 except (CaptureFailed, ValueError) as e:
@@ -517,7 +524,13 @@ def train_epoch(model: "TensorGNAN", loader, loss_fn, optimizer, steps: Optional
             totals[0] += loss.detach().double()
             totals[1] += (out.detach().argmax(dim=-1) == y).double().mean()
         n_batches += 1
-    mean = (totals / max(n_batches, 1)).tolist()
+    flag = steps.get("label_flag")
+    mean = (totals / max(n_batches, 1)).tolist() if flag is None else torch.cat([totals / max(n_batches, 1), flag.double()]).tolist()
+    if flag is not None and mean[2] != 0.0:
+        flag.zero_()
+        raise _lib.GnanHipError("a replayed batch held a class label outside [0, C): the fused cross entropy averages over such rows, "
+                                "torch's leaves them out (ignore_index) — this epoch's steps are not the script's; set "
+                                "gnan_amd.batched.GRAPHED_BATCH_STEPS = False for data with ignored labels")
     return mean[0], mean[1], steps
 
 

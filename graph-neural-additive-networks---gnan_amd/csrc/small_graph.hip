@@ -949,8 +949,11 @@ extern "C" int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_str
   GNAN_REQUIRE(a->cnt == nullptr || a->cnt_stride >= a->D, "small_batch_bwd: cnt row stride smaller than D");
   if (a->cnt && a->rho.C != 1)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "small_batch_bwd: shell sizes need a one-channel rho (got rho.C=%d)", a->rho.C);
-  const size_t need = static_cast<size_t>(a->n_graphs) * static_cast<size_t>(slab) * sizeof(float);
-  if (a->workspace == nullptr || a->workspace_bytes < need)
+  // ONE graph (a batch-size-1 step through graph slots): its share IS the gradient — the kernel writes the caller's tensors,
+  // no slab, no reduction launch (the kernel shifts graph g's pointers by g * slab = 0)
+  const bool direct = a->n_graphs == 1;
+  const size_t need = direct ? 0 : static_cast<size_t>(a->n_graphs) * static_cast<size_t>(slab) * sizeof(float);
+  if (!direct && (a->workspace == nullptr || a->workspace_bytes < need))
     return gnan::fail(GNAN_ERR_WORKSPACE, "small_batch_bwd: workspace %zu B < required %zu B", a->workspace_bytes, need);
   float* slabs = static_cast<float*>(a->workspace);
   // graph 0's slab as the kernels' gradient tensors (the kernel shifts them by g * slab)
@@ -959,6 +962,7 @@ extern "C" int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_str
   gnan_small_mlp_grads gr = {slabs + at[6], a->rho.b_first ? slabs + at[7] : nullptr, slabs + at[8],
                              (a->rho.L == 3 && a->rho.b_mid) ? slabs + at[9] : nullptr, slabs + at[10],
                              a->rho.b_last ? slabs + at[11] : nullptr};
+  if (direct) { gf = a->df; gr = a->drho; }
   BatchBwdParams bp;
   SmallBwdParams& p = bp.base;
   p.x = a->x; p.x_stride = a->x_stride; p.n = 0; p.F = a->F;
@@ -982,7 +986,7 @@ extern "C" int gnan_small_batch_bwd(const gnan_small_batch_bwd_args* a, gnan_str
     case 7: rc = launch_small_batch_bwd<7>(bp, a->n_graphs, a->max_nodes, st); break;
     default: rc = launch_small_batch_bwd<8>(bp, a->n_graphs, a->max_nodes, st); break;
   }
-  if (rc != GNAN_OK) return rc;
+  if (rc != GNAN_OK || direct) return rc;
   ReduceSeg seg;
   for (int t = 0; t < 13; ++t) seg.at[t] = at[t];
   for (int t = 0; t < 12; ++t) seg.dst[t] = (at[t + 1] > at[t]) ? dst[t] : nullptr;

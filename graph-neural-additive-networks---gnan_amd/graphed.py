@@ -577,10 +577,10 @@ class SlotGraphStep:
     (``SlottedGraphStep``: 451 captures / 2 GB on the Mutagenicity-shaped set)."""
 
     def __init__(self, model, optimizer, loss_of, n_features: int, label: torch.Tensor, use_cnt: bool,
-                 prepared: Optional[PreparedOptimizer] = None, first=None):
+                 prepared: Optional[PreparedOptimizer] = None, first=None, max_nodes: int = 128, n_codes: int = 64):
         from .small_graph import SlotGraph
         dev = label.device
-        self.slot = SlotGraph(n_features, dev, use_cnt=use_cnt)
+        self.slot = SlotGraph(n_features, dev, use_cnt=use_cnt, max_nodes=max_nodes, n_codes=n_codes)
         self.label = torch.empty_like(label)
         if first is not None:                         # (graph, x, label): what the capture's eager pass runs on
             self.load(*first)

@@ -93,9 +93,8 @@ def release_steps(model) -> None:
         return
     recs = [e.value for e in store.node.entries.values()]
     for steps in (store.graph, store.graph_eval):
-        if steps is not None and steps.slot is not None:
-            steps.slot.step.release(restore_optimizer=False)
-            steps.slot = None
+        if steps is not None:
+            steps.release_slots()
     if store.graph is not None:
         recs += list(store.graph.buckets.values())
         store.graph.restore_optimizer()
@@ -332,7 +331,8 @@ class _GraphTaskSteps:
         self.total_loss = torch.zeros((), device=device)
         self.hits = torch.zeros((), device=device)
         self.labels = None
-        self.slot, self.slot_calls, self.slot_dead, self.slot_use_cnt = None, 0, False, None
+        # graph slots: one captured step per (node tier, hop-code tier) — at most six whatever the graphs' shapes
+        self.slots, self.slot_calls, self.slot_dead, self.slot_use_cnt = {}, 0, False, None
 
     def _loss_closure(self):
         loss_fn, classify = self.loss_fn(), self.classify
@@ -372,35 +372,50 @@ class _GraphTaskSteps:
     def _slot_step(self, model, graph, data, labels):
         """True: the step ran from the slot capture.  False: this graph is for the other routes."""
         from .graphed import CaptureFailed, SlotGraphStep
+        from .small_graph import SLOT_CODE_TIERS, SLOT_CODES, SLOT_MAX_NODES
         use_cnt = self._slot_mode(model)
         if use_cnt is None or self.slot_dead:
             return False
-        if self.slot is None:
+        if not (graph.n_rows <= SLOT_MAX_NODES and graph.n_codes <= SLOT_CODES and data.x.dtype == torch.float32):
+            return False
+        # (nodes, hop codes) tier: the kernels' one- / two-block builds, and tables / bins no larger than the graphs need
+        tier = (64 if graph.n_rows <= 64 else 128, next(c for c in SLOT_CODE_TIERS if graph.n_codes <= c))
+        slot = self.slots.get(tier)
+        if slot is None:
             if self.slot_calls < SLOT_AFTER:
                 self.slot_calls += 1
                 return False
-            from .small_graph import SLOT_CODES, SLOT_MAX_NODES
-            if not (graph.n_rows <= SLOT_MAX_NODES and graph.n_codes <= SLOT_CODES and data.x.dtype == torch.float32):
-                return False                           # (captured on the first graph that fits)
             try:
                 if self.prepared is None and self.training:
                     from .graphed import prepare_optimizer
                     self.prepared = prepare_optimizer(self.optimizer())
-                self.slot = SlotGraphStep(model, self.optimizer(), self._loss_closure(), int(data.x.shape[1]), labels, use_cnt,
-                                          prepared=self.prepared, first=(graph, data.x, labels))
+                slot = self.slots[tier] = SlotGraphStep(model, self.optimizer(), self._loss_closure(), int(data.x.shape[1]), labels,
+                                                        use_cnt, prepared=self.prepared, first=(graph, data.x, labels),
+                                                        max_nodes=tier[0], n_codes=tier[1])
                 self.captured += 1
             except CaptureFailed as e:
                 self.slot_dead = True
                 warnings.warn(f"gnan_amd: the graph-task slot step could not be captured into a hipGraph ({e}); per-shape steps instead")
                 return False
-        if not self.slot.fits(graph, data.x, labels):
+        if not slot.fits(graph, data.x, labels):
             return False
-        if self.slot.run(graph, data.x, labels) is None:     # stale (parameters moved, mode or hyper-parameters changed): capture anew
-            self.slot.step.release(restore_optimizer=False)
-            self.slot, self.slot_calls = None, SLOT_AFTER
+        if slot.run(graph, data.x, labels) is None:          # stale (parameters moved, mode or hyper-parameters changed): capture anew
+            slot.step.release(restore_optimizer=False)
+            del self.slots[tier]
+            self.slot_calls = SLOT_AFTER
             self.captured -= 1
             return False
         return True
+
+    @property
+    def slot(self):
+        """The captured slot steps (tests / tools): the one of the smallest tier, or None."""
+        return self.slots[min(self.slots)] if self.slots else None
+
+    def release_slots(self) -> None:
+        for step in self.slots.values():
+            step.step.release(restore_optimizer=False)
+        self.slots = {}
 
     def matches(self, model, optimizer, loss_fn, classify) -> bool:
         return (self.model() is model and self.optimizer() is optimizer and self.loss_fn() is loss_fn
@@ -434,8 +449,8 @@ class _GraphTaskSteps:
             return False
         if self._slot_step(model, graph, data, labels):
             return True
-        if self.slot is not None and self.slot.fits(graph, data.x, labels):
-            return False                                # (the slot step just went stale: this graph steps eagerly, the next one re-captures)
+        if self._slot_mode(model) is not None and not self.slot_dead and graph.n_rows <= 128 and graph.n_codes <= 64:
+            return False                                # (a graph for the slots, not replayed this time: eager; no per-shape capture)
         key = (graph.n_rows, graph.n_cols, graph.n_codes, tuple(data.x.shape), data.x.dtype, tuple(labels.shape), labels.dtype)
         rec = self.buckets.get(key)
         if rec is None:
@@ -472,9 +487,7 @@ def _graph_task_steps(model, optimizer, loss_fn, classify, device):
         if steps is not None:
             for rec in steps.buckets.values():
                 _drop_step(rec)
-            if steps.slot is not None:
-                steps.slot.step.release(restore_optimizer=False)
-                steps.slot = None
+            steps.release_slots()
             steps.restore_optimizer()
         try:
             steps = _GraphTaskSteps(model, optimizer, loss_fn, classify, device)

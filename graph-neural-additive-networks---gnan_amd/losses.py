@@ -27,7 +27,8 @@ def loss_kind(loss_fn, outputs: torch.Tensor) -> Optional[int]:
 FUSED_LOSS = os.environ.get("GNAN_FUSED_LOSS", "1") != "0"
 
 
-def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, hits_sum, out_loss=None, out_hits=None):
+def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, hits_sum, out_loss=None, out_hits=None,
+                 label_flag=None):
     x = Fn._rows(outputs.detach())
     n_rows, C = x.shape
     n = int(labels.numel())
@@ -47,16 +48,16 @@ def _loss_launch(outputs, labels, kind, index, want_hits, want_grad, loss_sum, h
                       # a guarded captured step: a replay whose tables outgrew the capture is rolled back and re-run eagerly —
                       # its truncated look-up's loss must not reach the epoch's totals (it is counted by the re-run)
                       skip_sums=_lib.ptr(Fn.CAPTURE_GUARD) if (loss_sum is not None or hits_sum is not None) else None,
-                      workspace=_lib.ptr(ws), workspace_bytes=need)
+                      workspace=_lib.ptr(ws), workspace_bytes=need, label_flag=_lib.ptr(label_flag))
     _lib.check(_lib.lib().gnan_loss_step(a, _lib.stream_of(x)), "gnan_loss_step")
     return loss, hits, grad
 
 
 class _LossStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum, unit_upstream, out_loss, out_hits):
+    def forward(ctx, outputs, labels, kind, index, want_hits, loss_sum, hits_sum, unit_upstream, out_loss, out_hits, label_flag):
         loss, hits, grad = _loss_launch(outputs, labels, kind, index, want_hits, ctx.needs_input_grad[0], loss_sum, hits_sum,
-                                        out_loss, out_hits)
+                                        out_loss, out_hits, label_flag)
         ctx.grad, ctx.unit_upstream = grad, unit_upstream
         if hits is not None:
             ctx.mark_non_differentiable(hits)
@@ -65,19 +66,23 @@ class _LossStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         grad, ctx.grad = ctx.grad, None
-        return (grad if ctx.unit_upstream else grad * g_loss), None, None, None, None, None, None, None, None, None
+        return (grad if ctx.unit_upstream else grad * g_loss), None, None, None, None, None, None, None, None, None, None
 
 
 def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Optional[torch.Tensor] = None,
               want_hits: bool = True, loss_sum: Optional[torch.Tensor] = None, hits_sum: Optional[torch.Tensor] = None,
-              unit_upstream: bool = False, out_loss: Optional[torch.Tensor] = None, out_hits: Optional[torch.Tensor] = None):
+              unit_upstream: bool = False, out_loss: Optional[torch.Tensor] = None, out_hits: Optional[torch.Tensor] = None,
+              label_flag: Optional[torch.Tensor] = None):
     """``(loss, hits)`` of the rows ``index`` of ``outputs`` (all rows without it) by ``gnan_loss_step``: the mean loss as a
     0-d tensor that back-propagates into ``outputs`` (its gradient was formed in the same launch), the hit count as a 0-d
     int64 tensor (None unless ``want_hits``); ``loss_sum`` / ``hits_sum`` (0-d float32 device tensors) are added to in place.
     ``unit_upstream``: the caller promises to call ``backward()`` on this very loss (upstream gradient 1, as the epoch loops
     do, trainer.py:66) — the stored gradient is then handed down as it is instead of being multiplied by it (a launch).
     ``out_loss`` / ``out_hits``: one-element float32 / int64 device tensors to write the results into (a caller that wants to
-    read several results with ONE device-to-host copy lays them out next to each other)."""
+    read several results with ONE device-to-host copy lays them out next to each other).  ``label_flag``: a one-element
+    float32 device tensor a cross-entropy row with a class label outside ``[0, C)`` sets to 1 — such rows (torch's
+    ``ignore_index``) are averaged over like any other here, so a caller that cannot check the labels on the host (a replayed
+    step) reads the flag when it reads its totals."""
     _lib.require_device(outputs, labels)
     if labels.numel() == 0:
         raise ValueError("loss_step: no rows selected (the mean of an empty set)")
@@ -92,5 +97,8 @@ def loss_step(outputs: torch.Tensor, labels: torch.Tensor, kind: int, index: Opt
         raise ValueError("loss_step: out_loss is a one-element float32 device tensor")
     if out_hits is not None and (out_hits.dtype != torch.int64 or out_hits.numel() != 1 or not out_hits.is_cuda):
         raise ValueError("loss_step: out_hits is a one-element int64 device tensor")
-    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum, bool(unit_upstream), out_loss, out_hits)
+    if label_flag is not None and (label_flag.dtype != torch.float32 or label_flag.numel() != 1 or not label_flag.is_cuda):
+        raise ValueError("loss_step: label_flag is a one-element float32 device tensor")
+    got = _LossStep.apply(outputs, labels, kind, index, want_hits, loss_sum, hits_sum, bool(unit_upstream), out_loss, out_hits,
+                          label_flag)
     return got if want_hits else (got, None)

@@ -272,7 +272,8 @@ def small_graph_nam_forward(x: torch.Tensor, g: HopGraph, f: StackedMLP, rho: St
 # one graph in slots: a batch-size-1 loop through ONE captured step
 # =============================================================================
 SLOT_MAX_NODES = 128
-SLOT_CODES = 64              # hop codes the slots are laid out for (hops 0 .. 62 + the rest code); what gnan_small_batch_bwd covers
+SLOT_CODES = 64              # most hop codes slots are laid out for (hops 0 .. 62 + the rest code); what gnan_small_batch_bwd covers
+SLOT_CODE_TIERS = (16, 32, 64)   # ... and the capacities a loop picks from: the kernels' work on tables and bins grows with the capacity
 _SLOT_CNT = None             # TensorKeyedCache: a graph's shell sizes (object identity + version) -> their [n, SLOT_CODES] layout
 
 
@@ -282,24 +283,28 @@ class SlotGraph:
     size per step).  The batched kernels (``gnan_small_batch_fwd`` / ``_bwd``: blockIdx.y = graph, sizes from the offset
     arrays) run it as a batch of one, with the shell sizes (``cnt``, ABI 42) and the reference's rho arguments — so ONE capture
     serves every graph of up to 128 nodes and 63 hops, instead of one capture per (nodes, features, shells) shape.
-    ``cnt`` is laid out for ``SLOT_CODES`` codes whatever the graph's own largest hop: its listed hops keep their columns, its
+    ``cnt`` is laid out for the slots' ``n_codes`` codes whatever the graph's own largest hop: its listed hops keep their columns, its
     rest bucket (unreachable pairs, code 255) moves to the last column, the columns between are hops no pair has."""
     is_dense = True
 
-    def __init__(self, n_features: int, device, use_cnt: bool = True):
+    def __init__(self, n_features: int, device, use_cnt: bool = True, max_nodes: int = SLOT_MAX_NODES, n_codes: int = SLOT_CODES):
+        """``max_nodes``: 64 or 128 — the kernels come in a one-block (64 nodes, static LDS) and a two-block build; 97 % of
+        Mutagenicity-shaped graphs fit the first, which is the faster one."""
         from .batched import HopBlocks
-        self.F, self.device, self.n_codes = int(n_features), torch.device(device), SLOT_CODES
-        self.x = torch.zeros((SLOT_MAX_NODES, self.F), dtype=torch.float32, device=device)
-        self.code = torch.full((SLOT_MAX_NODES * SLOT_MAX_NODES,), 255, dtype=torch.uint8, device=device)
-        self.cnt = torch.ones((SLOT_MAX_NODES, SLOT_CODES), dtype=torch.int32, device=device) if use_cnt else None
+        if max_nodes not in (64, 128) or not 2 <= n_codes <= SLOT_CODES:
+            raise ValueError("graph slots hold 64 or 128 nodes and 2 to 64 hop codes")
+        self.F, self.device, self.n_codes, self.max_nodes = int(n_features), torch.device(device), int(n_codes), int(max_nodes)
+        self.x = torch.zeros((max_nodes, self.F), dtype=torch.float32, device=device)
+        self.code = torch.full((max_nodes * max_nodes,), 255, dtype=torch.uint8, device=device)
+        self.cnt = torch.ones((max_nodes, self.n_codes), dtype=torch.int32, device=device) if use_cnt else None
         self.node_off = torch.zeros(2, dtype=torch.int32, device=device)
         self.code_off = torch.zeros(2, dtype=torch.int64, device=device)
-        self.blocks = HopBlocks(self.code, self.node_off, self.code_off, [0], SLOT_CODES - 2)
-        self.blocks.total_nodes, self.blocks.max_nodes, self.blocks.min_nodes, self.blocks.slots = SLOT_MAX_NODES, SLOT_MAX_NODES, 1, True
+        self.blocks = HopBlocks(self.code, self.node_off, self.code_off, [0], self.n_codes - 2)
+        self.blocks.total_nodes, self.blocks.max_nodes, self.blocks.min_nodes, self.blocks.slots = max_nodes, max_nodes, 1, True
         self._offs = {}
 
     def fits(self, graph: HopGraph, x: torch.Tensor) -> bool:
-        return bool(graph.is_dense and 1 <= graph.n_rows == graph.n_cols <= SLOT_MAX_NODES and graph.n_codes <= SLOT_CODES
+        return bool(graph.is_dense and 1 <= graph.n_rows == graph.n_cols <= self.max_nodes and graph.n_codes <= self.n_codes
                     and x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (graph.n_rows, self.F)
                     and (self.cnt is None or graph.cnt is not None))
 
@@ -308,13 +313,13 @@ class SlotGraph:
         if _SLOT_CNT is None:
             from ._cache import TensorKeyedCache
             _SLOT_CNT = TensorKeyedCache(1 << 16)
-        hit = _SLOT_CNT.get((graph.cnt,), SLOT_CODES)
+        hit = _SLOT_CNT.get((graph.cnt,), self.n_codes)
         if hit is None:
             D = graph.n_codes
-            wide = torch.ones((graph.n_rows, SLOT_CODES), dtype=torch.int32, device=graph.cnt.device)
+            wide = torch.ones((graph.n_rows, self.n_codes), dtype=torch.int32, device=graph.cnt.device)
             wide[:, : D - 1] = graph.cnt[:, : D - 1]
-            wide[:, SLOT_CODES - 1] = graph.cnt[:, D - 1]
-            hit = _SLOT_CNT.put((graph.cnt,), SLOT_CODES, wide)
+            wide[:, self.n_codes - 1] = graph.cnt[:, D - 1]
+            hit = _SLOT_CNT.put((graph.cnt,), self.n_codes, wide)
         return hit
 
     def load(self, graph: HopGraph, x: torch.Tensor, extra=()) -> None:

@@ -587,10 +587,11 @@ def test_graph_task_epochs_through_one_slot_step(monkeypatch):
         assert float((v - runs[True][1][k]).abs().max()) <= 1e-5 * scale, k
     store = harness._steps_of(runs[True][2])
     for steps, epochs in ((store.graph, 3), (store.graph_eval, 3)):
-        assert steps.slot is not None
+        assert 2 <= len(steps.slots) <= 6 and {t[0] for t in steps.slots} == {64, 128}      # a step per (node, hop-code) tier, whatever the shapes
         n_fit = sum(d.x.shape[0] <= 128 for d in graphs)
-        assert steps.slot.step.graph.replays >= epochs * n_fit - 2          # from the third step of the first epoch on
-        assert steps.slot.step.graph.kernel_nodes <= 8
-        # the 130-node graphs: their own per-shape steps (or eager), never the slots
-        assert all(key[0] > 128 for key in steps.buckets)
+        replays = sum(s.step.graph.replays for s in steps.slots.values())
+        assert replays >= epochs * n_fit - 3, (replays, n_fit)         # from the third step of the first epoch on
+        assert all(s.step.graph.kernel_nodes <= 7 for s in steps.slots.values())
+        # the 130-node graphs: their own per-shape steps (or eager), never the slots; no per-shape capture for the others
+        assert all(key[0] > 128 for key, rec in steps.buckets.items() if rec["step"] is not None)
     harness.release_steps(runs[True][2])

@@ -102,8 +102,7 @@ def test_harness_epochs_on_gnan_modules_match_the_reference_trainer(name, graphe
         store = harness._steps_of(model)
         if meta["graph"]:
             replays = sum(r["step"].step.graph.replays for r in store.graph.buckets.values() if r["step"] is not None)
-            if store.graph.slot is not None:                       # one slot step for every graph that fits (graphed.SlotGraphStep)
-                replays += store.graph.slot.step.graph.replays
+            replays += sum(sl.step.graph.replays for sl in store.graph.slots.values())     # graph slots (graphed.SlotGraphStep)
         else:
             replays = sum(r.value["step"].graph.replays for r in store.node.entries.values() if r.value["step"] is not None)
         assert replays >= 3, "the captured step was never replayed"
@@ -241,8 +240,7 @@ def test_run_exp_reproduces_the_reference_run(name, tmp_path):
         steps = [id(e.value.get("step")) for e in store.node.entries.values() if e.value.get("step") is not None]
         if store.graph is not None:
             steps += [id(r["step"]) for r in store.graph.buckets.values() if r.get("step") is not None]
-            if store.graph.slot is not None:
-                steps.append(id(store.graph.slot))
+            steps += [id(sl) for sl in store.graph.slots.values()]
         opt = kw.get("optimizer")
         seen.append((sorted(steps), torch.is_tensor(opt.param_groups[0]["lr"])))
         return out

@@ -717,6 +717,33 @@ def test_batched_train_epoch_steps_an_uncapturable_batch_once(gpu):
         batched.train_epoch(b, batches, broken_loss, opt_b)
 
 
+def test_batched_replayed_steps_flag_labels_the_fused_loss_does_not_cover(gpu):
+    """A replayed batch's labels are never seen by the host.  A class label outside [0, C) — torch's ignore_index rows, left out
+    of its mean — is averaged over by the fused cross entropy: the kernel raises a device flag (gnan_loss_args.label_flag, ABI 42)
+    and the epoch that read it refuses its own numbers instead of returning another loss than the script's."""
+    from gnan_amd import _lib, batched
+    rng = np.random.default_rng(9)
+    F, C, H, G = 5, 4, 16, 6
+    data = []
+    for i in range(G * 4):
+        n = int(rng.integers(3, 40))
+        hops = rng.integers(-1, 5, (n, n)).astype(np.float32)
+        hops[np.arange(n), np.arange(n)] = 0
+        label = -100 if i == G * 2 + 1 else int(rng.integers(0, C))          # one ignored label, in the third batch
+        data.append((torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(gpu.DEV),
+                     torch.from_numpy(hops).to(gpu.DEV), torch.tensor([label], device=gpu.DEV)))
+    batches = [batched.collate(data[i:i + G]) for i in range(0, len(data), G)]
+    torch.manual_seed(0)
+    m = batched.TensorGNAN(F, C, 2, hidden_channels=H, device="cuda").to(gpu.DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    _, _, steps = batched.train_epoch(m, batches[:2], loss_fn, opt)          # clean batches: fine, and the step is captured
+    assert isinstance(steps.get(G), batched.GraphedBatchStep)
+    with pytest.raises(_lib.GnanHipError, match="outside"):
+        batched.train_epoch(m, batches, loss_fn, opt, steps)
+    _, _, steps = batched.train_epoch(m, batches[:2], loss_fn, opt, steps)   # the flag was reset: clean batches pass again
+
+
 def test_batched_batch_with_an_empty_graph_takes_the_csr_route(gpu):
     """A gap in ``batch_vector``'s graph ids is a graph without nodes: the reference's ``scatter_add`` gives it a zero row
     (batched_pyg_main.py:173-181).  The one-launch kernels have no workgroup that would write that row: such a batch must

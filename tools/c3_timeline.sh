@@ -1,15 +1,15 @@
 #!/bin/bash
 # kernel timeline of one replayed forward + backward step of config 3 (bench.py --config c3)
-OUT=gpurun_out/r04c3; mkdir -p $OUT
+OUT=gpurun_out/c3tl; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rocprofv3 --kernel-trace -f csv -d $OUT/t -o k -- python3 bench.py --config c3 --no-cpu-baseline --steps 5 --warmup 2 "$@" > $OUT/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob
-for f in glob.glob('gpurun_out/r04c3/t/**/*kernel_trace.csv', recursive=True):
+for f in glob.glob('gpurun_out/c3tl/t/**/*kernel_trace.csv', recursive=True):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
     n = 36 if 'c3' else 36
     import re
-    note = open('gpurun_out/r04c3/log.txt').read()
+    note = open('gpurun_out/c3tl/log.txt').read()
     m = re.search(r'(\d+) kernels per replay', note)
     n = int(m.group(1)) if m else 36
     last = rows[-n:]

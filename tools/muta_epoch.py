@@ -72,14 +72,16 @@ def main():
         torch.cuda.synchronize()
         eval_ms.append((time.perf_counter() - t0) / count * 1e3)
     st = harness._steps_of(m).graph
-    slot = st.slot
+    slots = st.slots
     replayed = six = 0
     eager_sizes, kernel_hist = [], {}
     for g in graphs:
         hop = m.hop_graph(g)
         key = (hop.n_rows, hop.n_cols, hop.n_codes, tuple(g.x.shape), g.x.dtype, (1,), torch.float32)
         rec = st.buckets.get(key)
-        if slot is not None and slot.fits(hop, g.x, slot.label):       # the one slot step (graphed.SlotGraphStep)
+        from gnan_amd.small_graph import SLOT_CODE_TIERS
+        slot = slots.get((64 if hop.n_rows <= 64 else 128, next((c for c in SLOT_CODE_TIERS if hop.n_codes <= c), 64)))
+        if slot is not None and slot.fits(hop, g.x, slot.label):       # the slot step of the graph's tier (graphed.SlotGraphStep)
             replayed += 1
             kn = int(slot.step.graph.kernel_nodes)
             kernel_hist[kn] = kernel_hist.get(kn, 0) + 1
@@ -93,8 +95,8 @@ def main():
             eager_sizes.append(int(g.x.shape[0]))
     out.update(train_ms_per_graph_by_epoch=[round(t, 4) for t in train_ms], eval_ms_per_graph_by_epoch=[round(t, 4) for t in eval_ms],
                epoch_s=round(train_ms[-1] * count / 1e3, 3), last=[float(v) for v in ret[:2]], shapes=len(st.buckets),
-               captured_shapes=sum(r["step"] is not None for r in st.buckets.values()) + (slot is not None),
-               slot_step=slot is not None, slot_replays=int(slot.step.graph.replays) if slot is not None else 0,
+               captured_shapes=sum(r["step"] is not None for r in st.buckets.values()) + len(slots),
+               slot_steps=[list(t) for t in sorted(slots)], slot_replays=sum(int(sl.step.graph.replays) for sl in slots.values()),
                steps_replayed_from_a_captured_step=replayed, share_replayed=round(replayed / count, 4),
                steps_of_at_most_six_kernels=six, share_at_most_six_kernels=round(six / count, 4),
                kernels_per_step_histogram={str(k): v for k, v in sorted(kernel_hist.items())},

@@ -1,7 +1,8 @@
 # Every measurement behind profiles/<tag>_* in one go, on the GPU box:   bash tools/profile_round.sh r04
 #   default bench (4 rocprofv3 passes), sum-first forward, training steps (sum-first and reference order), config 5 on one
 #   GPU (both orders), configs 2 and 3 (bench.py --config), emulated per-rank shares (replayed from hipGraphs and eager),
-#   look-up A/B + the access-pattern ceiling + SQ counters, batched graphs, harness epochs.
+#   look-up A/B + the access-pattern ceiling + SQ counters, batched graphs, harness epochs; round 5: config 3 timeline, the
+#   reference-shaped loop, RCCL on a one-rank group, all eight shares, the GPU suite's durations.
 #   Condense with  python profiles/summarize.py gpurun_out/<tag> profiles/<tag>
 TAG=${1:-r04}
 OUT=gpurun_out/$TAG
@@ -29,6 +30,15 @@ python3 tools/graphed_step.py arxiv cora muta arxiv40 > $OUT/graphed_steps.log 2
 python3 tools/small_graph_bench.py > $OUT/small_graph.log 2>&1
 python3 tools/muta_epoch.py > $OUT/muta_epoch.json 2> $OUT/muta_epoch.err                   # config 2 at its own size: 4337 graphs per epoch
 bash tools/graphed_timeline.sh $OUT/tl_muta muta > $OUT/timeline_muta.txt 2>&1                 # one replayed graph-task training step, kernel by kernel
+# ---- round 5 additions
+bash tools/c3_timeline.sh > $OUT/c3_timeline.txt 2>&1                                          # one replayed forward + backward step of config 3, kernel by kernel
+python3 tools/reference_loop_bench.py --profile > $OUT/reference_loop.jsonl 2> $OUT/reference_loop_host_profile.txt   # the reference-SHAPED loop (anomaly mode, stock Adam)
+python3 bench.py --config c3 --loop reference --no-cpu-baseline > $OUT/c3_loop_reference.log 2>&1
+python3 bench.py --config c2 --loop reference --no-cpu-baseline --steps 3 --warmup 1 > $OUT/c2_loop_reference.log 2>&1
+python3 bench.py --force-dist --traffic off --sustain-seconds 0 --no-cpu-baseline --steps 50 > $OUT/bench_force_dist_rccl.log 2>&1   # one rank, RCCL group, collectives on
+P=8 bash tools/emulate_shares_all.sh > $OUT/emulated_shares_all.txt 2>&1                      # every one of the 8 shares
+FORCE=1 P=8 bash tools/emulate_shares_all.sh > $OUT/emulated_shares_all_rccl.txt 2>&1         # ... each over a one-rank RCCL group (captured all-reduce)
+python3 -m pytest tests -q -m gpu --durations=15 > $OUT/gpu_suite_durations.txt 2>&1          # the whole GPU suite: total time and the slowest tests
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT
