@@ -1,0 +1,137 @@
+"""gnan_amd.replay: ``model.forward(data)`` and the backward pass behind it as two hipGraph replays under the reference's
+UNCHANGED loop shape (tests/reference_loop.py restates trainer.py:23-154: anomaly mode, zero_grad, forward, mask, loss,
+backward, a stock optimizer over ``model.parameters()``).  Same numbers as the eager launches, step for step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import reference_loop
+from test_gpu_graphed import DEV, _model, _need_gpu, _node_task
+
+pytestmark = pytest.mark.gpu
+
+
+def _plans(model):
+    cache = model.__dict__.get("_replays")
+    return [] if cache is None else [e.value["plan"] for e in cache.entries.values() if e.value["plan"] is not None]
+
+
+@pytest.mark.parametrize("n,F,C,dense,loss", [(3000, 129, 1, False, "BCEWithLogitsLoss"), (3000, 64, 1, False, "BCEWithLogitsLoss"),
+                                              (300, 9, 4, True, "CrossEntropyLoss"), (5000, 33, 3, False, "CrossEntropyLoss")])
+def test_reference_shaped_epochs_replayed_equal_the_eager_ones(n, F, C, dense, loss, monkeypatch):
+    """Two copies of a model walk the reference-shaped loop in lock-step, one with the replay switched off: after EVERY
+    epoch (training in anomaly mode + evaluation) losses, hit rates and parameters agree; the replaying copy has captured
+    one training plan (forward + backward) and one evaluation plan and replayed them from the third epoch on."""
+    _need_gpu()
+    from gnan_amd import replay
+    data = _node_task(n, F, C, dense)
+    loss_fn = getattr(torch.nn, loss)()
+    a = _model(F, C)
+    b = copy.deepcopy(a)
+    oa, ob = torch.optim.Adam(a.parameters(), lr=2e-3), torch.optim.Adam(b.parameters(), lr=2e-3)     # main.py:141
+    epochs = 7
+    for e in range(epochs):
+        monkeypatch.setattr(replay, "REPLAY_FORWARD", False)
+        ta = reference_loop.train_epoch(a, [data], loss_fn, oa, DEV, classify=True, is_graph_task=False)
+        ea = reference_loop.test_epoch(a, [data], loss_fn, DEV, classify=True, val_mask=True, is_graph_task=False)
+        monkeypatch.setattr(replay, "REPLAY_FORWARD", True)
+        tb = reference_loop.train_epoch(b, [data], loss_fn, ob, DEV, classify=True, is_graph_task=False)
+        eb = reference_loop.test_epoch(b, [data], loss_fn, DEV, classify=True, val_mask=True, is_graph_task=False)
+        assert abs(ta[0] - tb[0]) <= 1e-6 * max(1.0, abs(ta[0])) and ta[1] == tb[1], (e, ta, tb)
+        assert abs(ea[0] - eb[0]) <= 1e-6 * max(1.0, abs(ea[0])) and ea[1] == eb[1], (e, ea, eb)
+        scale = max(float(v.abs().max()) for v in a.state_dict().values())
+        for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert float((va - vb).abs().max()) <= 1e-6 * scale, (e, k)
+    plans = _plans(b)
+    assert sorted(p.grad for p in plans) == [False, True] and not _plans(a)
+    train = [p for p in plans if p.grad][0]
+    evalp = [p for p in plans if not p.grad][0]
+    assert train.fwd.replays == train.bwd.replays == epochs - 2 and evalp.fwd.replays == epochs - 2
+    # the per-layer gradients the reference's names expose are the flat buffers' views: alive after a replayed backward
+    named = dict(b.named_parameters())
+    assert named["fs.0.0.weight"].grad is not None and torch.isfinite(named["fs.0.0.weight"].grad).all()
+    replay.release(b)
+    assert not _plans(b)
+
+
+def test_replayed_forward_tells_stale_inputs_moved_parameters_and_double_forwards(monkeypatch):
+    _need_gpu()
+    from gnan_amd import replay
+    data = _node_task(3000, 64, 1, False)
+    m = _model(64, 1)
+    outs = [m.forward(data).detach().clone() for _ in range(4)]          # eager, eager, capture + replay, replay
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    plan = _plans(m)[0]
+    assert plan.grad and plan.fwd.replays == 2
+    # a backward pass after a SECOND forward on the same inputs: the first output's activations are gone — refused, loudly
+    y1 = m.forward(data)
+    y2 = m.forward(data)
+    with pytest.raises(RuntimeError, match="replayed again"):
+        y1.sum().backward()
+    y2.sum().backward()                                                    # the latest one is fine
+    g_replayed = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    monkeypatch.setattr(replay, "REPLAY_FORWARD", False)
+    m.forward(data).sum().backward()
+    monkeypatch.setattr(replay, "REPLAY_FORWARD", True)
+    scale = max(float(v.abs().max()) for v in g_replayed.values())
+    for k, p in m.named_parameters():
+        assert float((p.grad - g_replayed[k]).abs().max()) <= 1e-6 * scale, k
+    # gradients accumulate over two backward passes without zero_grad, as autograd's do
+    m.zero_grad()
+    m.forward(data).sum().backward()
+    m.forward(data).sum().backward()
+    for k, p in m.named_parameters():
+        assert float((p.grad - 2 * g_replayed[k]).abs().max()) <= 2e-6 * scale, k
+    # an in-place edit of the inputs: another version, another record — the old plan is not replayed
+    replays = plan.fwd.replays
+    data.x.mul_(1.0)
+    m.forward(data)
+    assert plan.fwd.replays == replays
+    # parameters moved to new storage: the plan is dropped and captured anew after its warm-up
+    data2 = _node_task(3000, 64, 1, False, seed=1)
+    m.zero_grad()                                                          # (standing gradients postpone a capture: it would freeze "assign")
+    for _ in range(3):
+        m.forward(data2)
+    assert any(p.fwd.replays >= 1 for p in _plans(m))
+    m.float()                                                              # (a no-op cast keeps storage) ...
+    m.to(DEV)
+    with torch.no_grad():
+        ev = [m.forward(data2).clone() for _ in range(4)]
+    assert all(torch.equal(o, ev[0]) for o in ev)
+
+
+def test_tables_that_outgrow_a_replayed_forward_fall_back_to_the_eager_launches(monkeypatch):
+    """The captured look-up is sized like the speculative one and checks the tables its own build produced on the device;
+    weights whose tables outgrow those sizes trip the plan's guard: that forward runs eagerly (right numbers), and a new
+    plan is captured with the larger tables."""
+    _need_gpu()
+    from gnan_amd import functional, replay
+    monkeypatch.setattr(functional, "PWL_MIN_WORK", 1 << 18)
+    monkeypatch.setattr(functional, "PWL_MIN_NODES", 1 << 12)
+    data = _node_task(5000, 64, 1, False)
+    m = _model(64, 1)
+    full = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():                                                  # three of four hidden units off: small tables
+        for k, p in m.named_parameters():
+            if k.startswith("fs") and (".0." in k or ".2." in k):
+                p[8:] = 0.0
+    with torch.no_grad():
+        for _ in range(4):
+            m.forward(data)
+    plan = _plans(m)[0]
+    assert plan.guarded and plan.fwd.replays == 2
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            p.copy_(full[k])
+        got = m.forward(data).clone()                                      # replay, guard trips, eager forward
+        assert plan.out is None                                            # (released)
+        monkeypatch.setattr(replay, "REPLAY_FORWARD", False)
+        want = m.forward(data)
+        monkeypatch.setattr(replay, "REPLAY_FORWARD", True)
+        assert torch.equal(got, want)
+        again = [m.forward(data).clone() for _ in range(3)]                # captured anew with the larger tables
+    assert all(torch.equal(o, want) for o in again)
+    assert any(p.fwd.replays >= 1 for p in _plans(m))
