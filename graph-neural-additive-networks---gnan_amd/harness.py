@@ -352,34 +352,20 @@ class _GraphTaskSteps:
         return loss_of
 
     def _slot_mode(self, model):
-        """``use_cnt`` of the slot step this model can run (True / False), or None: the read-out of a graph-level task with
-        post-rho (or no) normalisation, a one-channel rho, features summed per node (small_graph.slot_graph_applies)."""
-        if self.slot_use_cnt is None:
-            from . import modules
-            from .small_graph import slot_graph_applies
-            mode = "no"
-            if (SLOT_STEPS and isinstance(model, (modules.TensorGNAN, modules.StandaloneTensorGNAN)) and model.is_graph_task
-                    and not (isinstance(model, modules.TensorGNAN) and (model.readout_n_layers > 0 or model.aggregation_order == "reference"))
-                    and not (isinstance(model, modules.StandaloneTensorGNAN) and model.normalize_rho)):
-                with torch.no_grad():
-                    f, rho = model._stacked("fs", model.fs), model._stacked("rho", [model.rho])
-                import types
-                if slot_graph_applies(types.SimpleNamespace(F=f.F), f, rho):
-                    mode = bool(model.normalize_rho)
-            self.slot_use_cnt = mode
-        return None if self.slot_use_cnt == "no" else self.slot_use_cnt
+        from .small_graph import slot_mode
+        return slot_mode(model) if SLOT_STEPS else None
 
     def _slot_step(self, model, graph, data, labels):
         """True: the step ran from the slot capture.  False: this graph is for the other routes."""
         from .graphed import CaptureFailed, SlotGraphStep
-        from .small_graph import SLOT_CODE_TIERS, SLOT_CODES, SLOT_MAX_NODES
+        from .small_graph import slot_tier
         use_cnt = self._slot_mode(model)
         if use_cnt is None or self.slot_dead:
             return False
-        if not (graph.n_rows <= SLOT_MAX_NODES and graph.n_codes <= SLOT_CODES and data.x.dtype == torch.float32):
-            return False
         # (nodes, hop codes) tier: the kernels' one- / two-block builds, and tables / bins no larger than the graphs need
-        tier = (64 if graph.n_rows <= 64 else 128, next(c for c in SLOT_CODE_TIERS if graph.n_codes <= c))
+        tier = slot_tier(graph) if data.x.dtype == torch.float32 else None
+        if tier is None:
+            return False
         slot = self.slots.get(tier)
         if slot is None:
             if self.slot_calls < SLOT_AFTER:

@@ -19,9 +19,13 @@ modules' switches (key); the sizes of the shape-function tables — the captured
 produced (``gnan_pwl_check_fit`` -> the plan's guard flag), the flag is read right after the forward replay, and a tripped plan
 is dropped and the forward runs eagerly (the look-up then sizes itself); a second forward replay before the backward of the
 first would overwrite what that backward reads — refused loudly.  Not captured: training-mode Dropout, ``node_ids``,
-``x.requires_grad``, small graphs (one launch each way already, and a graph-level task feeds another object per step), anything
-while a capture is already running (``harness`` capturing a whole step).  Anomaly mode is switched off DURING the capture
+``x.requires_grad``, anything while a capture is already running (``harness`` capturing a whole step).  Anomaly mode is switched off DURING the capture
 (its NaN checks read the device) and nowhere else.
+
+Graph-level tasks hand over another small graph every step (batch_size = 1), so there is no input to key a plan on.  Those
+forwards go through GRAPH SLOTS instead (``small_graph.SlotGraph``: static buffers whose kernels read the graph's size from the
+device): one plan per (node tier, hop-code tier) is captured over the slots, and every graph that fits is copied in — one
+launch — and replayed, forward and backward one launch each (``_run_small``).
 """
 from __future__ import annotations
 
@@ -35,6 +39,7 @@ REPLAY_FORWARD = True        # off: every forward issues its launches eagerly
 REPLAY_AFTER = 2             # eager forwards on the same inputs before the capture (they are its warm-up: caches, table sizes)
 REPLAY_MIN_NODES = 256       # below: the small-graph paths (one launch each way) — and graph-level tasks hand over a new object per step
 REPLAY_PLANS = 4             # plans a model keeps (train / eval x a couple of inputs); the least recently used one is released
+REPLAY_SMALL_GRAPHS = True   # graph-level forwards of small dense graphs through graph slots (one plan per tier, any graph)
 
 
 def _stores_of(module):
@@ -186,13 +191,76 @@ def _key(module, inputs, grad: bool):
     return src, extra
 
 
+class _SlotInputs:
+    """Duck-typed ``Data`` over the slots of a :class:`small_graph.SlotGraph`."""
+
+    def __init__(self, slot):
+        self.x, self.edge_index, self.gnan_graph = slot.x, None, slot
+
+
+def _run_small(module, inputs):
+    """A graph-level forward of a SMALL dense graph (batch_size = 1: another graph object every step) through graph slots: the
+    graph is copied into the slots of its (node, hop-code) tier — one launch — and the tier's plan, captured over the slots, is
+    replayed: whatever graph comes, forward and backward are one graph launch each.  None: not for this route."""
+    from .small_graph import SlotGraph, slot_mode, slot_tier
+    use_cnt = slot_mode(module)
+    if use_cnt is None or inputs.x.dtype != torch.float32:
+        return None
+    g = module.hop_graph(inputs)
+    tier = slot_tier(g)
+    if tier is None or g.n_rows != inputs.x.shape[0]:
+        return None
+    stores = _stores_of(module)
+    grad = torch.is_grad_enabled() and any(st.flat[name].requires_grad for st in stores for name in st.buf)
+    book = module.__dict__.get("_replay_slots")
+    if book is None:
+        book = {"calls": 0, "plans": {}}
+        object.__setattr__(module, "_replay_slots", book)
+    key = (tier, grad, bool(module.training), tuple(bool(st.flat[name].requires_grad) for st in stores for name in st.buf))
+    rec = book["plans"].get(key)
+    if rec is None:
+        if book["calls"] < REPLAY_AFTER:
+            book["calls"] += 1
+            return None
+        rec = book["plans"][key] = {"plan": None, "slot": None, "dead": False}
+    if rec["dead"]:
+        return None
+    plan = rec["plan"]
+    if plan is not None and plan.stale(module):
+        plan.release()
+        plan = rec["plan"] = None
+    if plan is None:
+        from .graphed import CaptureFailed
+        try:
+            slot = SlotGraph(int(inputs.x.shape[1]), inputs.x.device, use_cnt=use_cnt, max_nodes=tier[0], n_codes=tier[1])
+            slot.load(g, inputs.x)
+            plan = _Plan(module, _SlotInputs(slot), grad)
+            rec["plan"], rec["slot"] = plan, slot
+        except _NotNow:
+            return None
+        except (CaptureFailed, _lib.GnanHipError, RuntimeError) as e:
+            rec["dead"] = True
+            import warnings
+            warnings.warn(f"gnan_amd.replay: small graphs of tier {tier} stay eager ({type(e).__name__}: {str(e)[:200]})")
+            return None
+    rec["slot"].load(g, inputs.x)
+    plan.gen += 1
+    plan.fwd.replay()
+    return _Replayed.apply(plan, plan.anchor) if plan.grad else plan.out
+
+
 def run(module, inputs, node_ids=None):
     """``module.forward``: a replay where a plan exists (or can be captured now), the eager forward otherwise."""
     x = getattr(inputs, "x", None)
     if (not REPLAY_FORWARD or node_ids is not None or not torch.is_tensor(x) or not x.is_cuda or x.requires_grad
-            or x.dim() != 2 or x.shape[0] < REPLAY_MIN_NODES or getattr(module, "stage_hook", None) is not None
+            or x.dim() != 2 or getattr(module, "stage_hook", None) is not None
             or module._dropout_active() or torch.cuda.is_current_stream_capturing()):
         return module._forward(inputs) if node_ids is None else module._forward(inputs, node_ids)
+    if x.shape[0] < REPLAY_MIN_NODES:
+        out = None
+        if REPLAY_SMALL_GRAPHS and x.shape[0] <= 128 and getattr(inputs, "gnan_graph", None) is None:
+            out = _run_small(module, inputs)
+        return module._forward(inputs) if out is None else out
     grad = torch.is_grad_enabled() and any(st.flat[name].requires_grad for st in _stores_of(module) for name in st.buf)
     cache = module.__dict__.get("_replays")
     if cache is None:
@@ -243,3 +311,7 @@ def release(module) -> None:
         for e in list(cache.entries.values()):
             _release_record(e.value)
         cache.clear()
+    book = module.__dict__.pop("_replay_slots", None)
+    if book is not None:
+        for rec in book["plans"].values():
+            _release_record(rec)

@@ -340,6 +340,33 @@ class SlotGraph:
             d.copy_(sr)
 
 
+def slot_mode(model):
+    """``use_cnt`` (True / False) of the slot forward this model can run, or None: the read-out of a graph-level task with
+    post-rho (or no) normalisation, a one-channel rho, features summed per node — ``models.TensorGNAN`` without a NAM read-out
+    in its default order, the stand-alone class without normalisation.  Decided once per model."""
+    mode = model.__dict__.get("_slot_mode", "?")
+    if mode == "?":
+        import types
+        from . import modules
+        mode = None
+        if (isinstance(model, (modules.TensorGNAN, modules.StandaloneTensorGNAN)) and model.is_graph_task
+                and not (isinstance(model, modules.TensorGNAN) and (model.readout_n_layers > 0 or model.aggregation_order == "reference"))
+                and not (isinstance(model, modules.StandaloneTensorGNAN) and model.normalize_rho)):
+            with torch.no_grad():
+                f, rho = model._stacked("fs", model.fs), model._stacked("rho", [model.rho])
+            if slot_graph_applies(types.SimpleNamespace(F=f.F), f, rho):
+                mode = bool(model.normalize_rho)
+        object.__setattr__(model, "_slot_mode", mode)
+    return mode
+
+
+def slot_tier(graph: HopGraph):
+    """(node tier, hop-code tier) of the slots a dense-coded graph fits, or None."""
+    if not graph.is_dense or graph.n_rows > SLOT_MAX_NODES or graph.n_codes > SLOT_CODES or graph.n_rows < 1:
+        return None
+    return (64 if graph.n_rows <= 64 else 128, next(c for c in SLOT_CODE_TIERS if graph.n_codes <= c))
+
+
 def slot_graph_applies(slot: SlotGraph, f: StackedMLP, rho: StackedMLP) -> bool:
     return bool(f.F == slot.F and rho.F == 1 and f.L in (2, 3) and rho.L in (2, 3) and 1 <= f.H <= 64 and 1 <= rho.H <= 64
                 and f.C <= 8 and rho.C == 1 and all(t is None or t.dtype == torch.float32 for t in tuple(f[:6]) + tuple(rho[:6])))

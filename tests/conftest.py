@@ -17,6 +17,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _host_threads():
+    """The oracle's passes are Python loops of small float64 matmuls: on a many-core GPU host torch's default — one intra-op
+    thread per hardware thread (256 on the MI355X boxes) — makes each of them slower, not faster (bench.py's CPU baseline
+    calibrates the same thing: 16 threads beat 256 by an order of magnitude on the shape-function loop).  The whole suite's
+    host side runs on at most 16 threads."""
+    import torch
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    yield
+    torch.set_num_threads(before)
+
+
 def golden_names(variant_prefix=None):
     with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
         names = json.load(f)

@@ -133,13 +133,14 @@ def test_full_size_training_step_gradients(c4, monkeypatch):
     assert abs(numeric - analytic) <= 2e-2 * max(abs(analytic), 1e-6), (numeric, analytic)
 
 
-def test_full_size_pre_rho_normalisation(c4):
+def test_full_size_pre_rho_normalisation(c4, monkeypatch):
     """The stand-alone TensorGNAN (GNAN.py:55-79: rho(node_distances / normalization_matrix)) at the full size: the per-row
     weight table comes from gnan_rho_row_lut (rho's exact table, 3 look-ups per row); sampled rows against a float64
     restatement; and the forward costs what the post-rho forward costs (the table replaces the count table one for one)."""
     import time
     from gnan_amd import GNAN as standalone
-    from gnan_amd import models
+    from gnan_amd import models, replay
+    monkeypatch.setattr(replay, "REPLAY_FORWARD", False)     # (the launches' cost is what is compared: a replayed forward skips their host side)
     g, x, st, sd, lut = c4
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(1)

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import reference_loop
-from test_gpu_graphed import DEV, _model, _need_gpu, _node_task
+from test_gpu_graphed import DEV, _graph_task, _model, _need_gpu, _node_task
 
 pytestmark = pytest.mark.gpu
 
@@ -135,3 +135,50 @@ def test_tables_that_outgrow_a_replayed_forward_fall_back_to_the_eager_launches(
         again = [m.forward(data).clone() for _ in range(3)]                # captured anew with the larger tables
     assert all(torch.equal(o, want) for o in again)
     assert any(p.fwd.replays >= 1 for p in _plans(m))
+
+
+@pytest.mark.parametrize("cls", ["models", "standalone_no_norm"])
+def test_graph_level_loop_replays_small_graphs_through_slots(cls, monkeypatch):
+    """trainer.py's graph-level loop (batch_size = 1: another graph object every step) in its own shape: from the third small
+    forward on, every graph of up to 128 nodes is copied into the slots of its tier and the tier's plan — captured over the
+    slots — is replayed, forward and backward one launch each; graphs beyond the slots run eagerly.  Epoch returns and
+    parameters == a twin with the replay switched off."""
+    _need_gpu()
+    from gnan_amd import GNAN as standalone
+    from gnan_amd import replay
+    from gnan_amd.models import TensorGNAN
+    F = 15
+    graphs = _graph_task(36, F, sizes=[12, 30, 9, 23, 130, 12, 41, 77, 5, 128])
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    torch.manual_seed(0)
+    if cls == "models":
+        a = TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, readout_n_layers=0, device=DEV)
+    else:
+        a = standalone.TensorGNAN(F, 1, 3, hidden_channels=32, is_graph_task=True, normalize_rho=False, device=DEV)
+    with torch.no_grad():
+        for _, p in a.named_parameters():
+            p.copy_(torch.randn(p.shape) * 0.3)
+    a = a.to(DEV).eval()
+    b = copy.deepcopy(a)
+    oa, ob = torch.optim.Adam(a.parameters(), lr=1e-3), torch.optim.Adam(b.parameters(), lr=1e-3)
+    for e in range(3):
+        monkeypatch.setattr(replay, "REPLAY_FORWARD", False)
+        ta = reference_loop.train_epoch(a, graphs, loss_fn, oa, DEV, classify=True, is_graph_task=True)
+        ea = reference_loop.test_epoch(a, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+        monkeypatch.setattr(replay, "REPLAY_FORWARD", True)
+        tb = reference_loop.train_epoch(b, graphs, loss_fn, ob, DEV, classify=True, is_graph_task=True)
+        eb = reference_loop.test_epoch(b, graphs, loss_fn, DEV, classify=True, val_mask=True, is_graph_task=True)
+        assert abs(ta[0] - tb[0]) <= 1e-5 * max(1.0, abs(ta[0])) and ta[1] == tb[1], (e, ta, tb)
+        assert abs(ea[0] - eb[0]) <= 1e-5 * max(1.0, abs(ea[0])) and ea[1] == eb[1], (e, ea, eb)
+        scale = max(float(v.abs().max()) for v in a.state_dict().values())
+        for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert float((va - vb).abs().max()) <= 1e-5 * scale, (e, k)
+    book = b.__dict__["_replay_slots"]
+    plans = [r["plan"] for r in book["plans"].values() if r["plan"] is not None]
+    train = [p for p in plans if p.grad]
+    assert train and all(p.bwd.replays == p.fwd.replays for p in train)
+    n_fit = sum(d.x.shape[0] <= 128 for d in graphs)
+    assert sum(p.fwd.replays for p in train) >= 3 * n_fit - 2 - len(train)      # all but the two warm-up forwards (and a capture each)
+    assert sum(p.fwd.replays for p in plans if not p.grad) >= 3 * n_fit - len(plans)
+    assert "_replay_slots" not in a.__dict__
+    replay.release(b)
