@@ -375,7 +375,7 @@ def run_c3(args):
         return out
 
     def fwd_bwd():
-        for _, p in model.named_parameters():
+        for p in model.parameters():             # what optimizer.zero_grad() of an optimizer over model.parameters() does (trainer.py:48)
             p.grad = None
         out = model.forward(data)
         loss = ((out - target) ** 2).mean()
@@ -401,8 +401,7 @@ def run_c3(args):
         eager_grads = [p.grad.detach().clone() for p in model.parameters()]
 
         def clear():
-            for _, p in model.named_parameters():
-                p.grad = None
+            model.zero_grad()
 
         def static_step():
             out = model.forward(data)
@@ -441,7 +440,9 @@ def run_c3(args):
         "n_gpus": 1, "ranks_seen": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"c3_arxiv_shaped_pa_{N}n_{E}e_F{F}_H{H}_L{L}_C{C}_sum_first_K1", "nodes": N, "edges": E,
-                   "stored_pairs": g.nnz, "step": "forward + MSE loss + backward of models.TensorGNAN (eager autograd)"},
+                   "stored_pairs": g.nnz, "step": "forward + MSE loss + backward of models.TensorGNAN as a caller's loop issues them "
+                                                  "(from its third step on the module replays its forward and backward from two hipGraphs: "
+                                                  "gnan_amd.replay)"},
         "fwd_ms": fwd_ms, "fwd_ms_min": fwd_min, "fwd_bwd_ms": fb_ms, "fwd_bwd_ms_min": fb_min,
         "fwd_edges_per_s": E / (fwd_ms / 1e3),
         "roofline": {"bound": "hbm", "kernel": "fpwl_fast_kernel (shape-function look-up, feature sum)",

@@ -47,6 +47,7 @@ class FpwlArgs(C.Structure):
         ("out_dtype", C.c_int32), ("total", C.c_void_p), ("total_workspace", C.c_void_p), ("total_workspace_bytes", C.c_size_t),
         ("total_rows", C.c_int64), ("piece_out", C.c_void_p), ("piece_in", C.c_void_p), ("flags", C.c_int32),
         ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32),
+        ("sum_workspace", C.c_void_p), ("sum_workspace_bytes", C.c_size_t),
     ]
 
 
@@ -276,6 +277,7 @@ SYMBOLS = {
     "gnan_pwl_check_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnan_rho_row_lut": (C.c_int, [C.POINTER(RhoLutArgs), C.c_void_p]),
     "gnan_fpwl_total_workspace_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),
+    "gnan_fpwl_sum_workspace_bytes": (C.c_size_t, [C.POINTER(FpwlArgs)]),
     "gnan_fpwl_fwd": (C.c_int, [C.POINTER(FpwlArgs), C.c_void_p]),
     "gnan_fpwl_index_build": (C.c_int, [C.POINTER(FpwlIndexArgs), C.c_void_p]),
     "gnan_feature_range": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

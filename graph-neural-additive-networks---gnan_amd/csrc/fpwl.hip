@@ -1433,6 +1433,7 @@ extern "C" int gnan_fpwl_moments_fixed(const gnan_fpwl_args* a, const float* gra
 bool gnan_index_applies(const gnan_fpwl_args* a);
 int gnan_index_nodes_per_block(const gnan_fpwl_args* a);
 int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st);
+size_t gnan_index_sum_workspace_bytes(const gnan_fpwl_args* a);
 
 extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
   if (int rc = common_checks(a)) return rc;
@@ -1497,6 +1498,11 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
     case 8: return launch<8, 512>(p, lds, st, a->total);
     default: return launch<16, 512>(p, lds, st, a->total);
   }
+}
+
+extern "C" size_t gnan_fpwl_sum_workspace_bytes(const gnan_fpwl_args* a) {
+  if (!a || a->n <= 0 || a->features_per_group != 16 || (a->total && a->sum_features)) return 0;
+  return gnan_index_sum_workspace_bytes(a);
 }
 
 extern "C" size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a) {

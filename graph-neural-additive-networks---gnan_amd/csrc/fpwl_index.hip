@@ -58,6 +58,7 @@ struct IndexParams {
   double* col_partial;
   int64_t total_rows;
   uint8_t* piece_out;
+  float* part;             // feature sum, split over the groups: [n_groups][n] partial sums (else NULL: the groups are walked inside the workgroup)
 };
 
 typedef __attribute__((address_space(3))) const float lds_cfloat;
@@ -206,7 +207,11 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
   const int nl = tid / TPN;
   int64_t nb = blockIdx.x;
   int g_first = 0;
-  if (!SUM) {                                       // (id % 8) = XCD, groups of a node block adjacent inside it (FG = 16: shared lines)
+  // feature sum on a medium batch: a workgroup per (node block, group) too — its partial sums go to p.part and are added in
+  // group order by sum_groups_kernel (walking the nine groups of a 144-feature model inside each of 662 small workgroups paid
+  // nine LDS images per 256 nodes and left most of the chip idle: 94 us for 24M look-ups)
+  const bool split = SUM && p.part != nullptr;
+  if (!SUM || split) {                              // (id % 8) = XCD, groups of a node block adjacent inside it (FG = 16: shared lines)
     const int64_t id = blockIdx.x;
     g_first = static_cast<int>((id >> 3) % p.n_groups);
     nb = ((id >> 3) / p.n_groups) * 8 + (id & 7);
@@ -214,8 +219,8 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
   const int64_t n_lo = nb * p.nodes_per_block;
   if (n_lo >= p.n) return;
   const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
-  const int g_lo = SUM ? 0 : g_first;
-  const int g_hi = SUM ? p.n_groups : g_lo + 1;
+  const int g_lo = (SUM && !split) ? 0 : g_first;
+  const int g_hi = (SUM && !split) ? p.n_groups : g_lo + 1;
   const float top = static_cast<float>(B - 1);
 
   for (int g = g_lo; g < g_hi; ++g) {
@@ -323,7 +328,10 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
         float acc = ((y[0] + y[1]) + y[2]) + y[3];          // fpwl_fast_kernel's association: bit-identical sums
 #pragma unroll
         for (int o = 1; o < TPN; o <<= 1) acc += __shfl_xor(acc, o);
-        if (q == 0) p.out[n * p.out_stride] = before + acc;   // (`before`: the earlier groups' sum, 0 for the first group)
+        if (q == 0) {
+          if (split) p.part[static_cast<int64_t>(g) * p.n + n] = acc;
+          else p.out[n * p.out_stride] = before + acc;       // (`before`: the earlier groups' sum, 0 for the first group)
+        }
       } else {
         float4 r = make_float4(y[0], y[1], y[2], y[3]);
         if constexpr (OUT16) {
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
     // ahead like it.  (Read next to the store it feeds, every round waited for that load and, vmcnt being in order, for the
     // prefetched x rows queued before it: the look-ups then ran with nothing in flight.)
     float pre[U] = {}, pre_nxt[U] = {};
-    const bool add_before = SUM && g > g_lo;
+    const bool add_before = SUM && !split && g > g_lo;
     auto before_of = [&](const int64_t n) { return p.out[(n < n_hi ? n : n_hi - 1) * p.out_stride]; };
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -392,6 +400,16 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
   }
 }
 
+// out[n] = ((part[0][n] + part[1][n]) + part[2][n]) + ... : the association of the in-workgroup walk (bit-identical sums)
+__global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict__ part, int n_groups, int64_t n,
+                                                         float* __restrict__ out, int64_t out_stride) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = part[i];
+  for (int g = 1; g < n_groups; ++g) s = s + part[static_cast<int64_t>(g) * n + i];
+  out[i * out_stride] = s;
+}
+
 int cu_count_() {
   static const int cus = [] {
     int dev = 0, n = 0;
@@ -405,9 +423,12 @@ int cu_count_() {
 
 struct IndexPlan {
   bool ok;
+  bool split;              // feature sum with a workgroup per (node block, group) + sum_groups_kernel
   int fg, logb, bs, tot_cap, npb;
   size_t lds;
 };
+
+constexpr int64_t kSplitSumMaxNodes = 1 << 19;     // beyond, node blocks alone fill the chip and the groups share a workgroup's x lines
 
 size_t image_bytes(int fg, int logb, int tot_cap) {          // bucket entries | anchor pairs (+ 2 NaN pairs per feature) | (val, slope) | offsets
   const size_t a_pairs = static_cast<size_t>(tot_cap) + fg * 2;
@@ -446,7 +467,26 @@ IndexPlan index_plan(const gnan_fpwl_args* a) {
   if (pl.fg == 32 && a->sum_features) pl.bs = 1024;
   if (pl.fg == 32 && (a->flags & GNAN_FPWL_INDEX_BS512)) pl.bs = 512;
   if (pl.fg == 32 && (a->flags & GNAN_FPWL_INDEX_BS1024)) pl.bs = 1024;
-  if (a->n < 262144) {
+  const int n_groups = a->F / pl.fg;
+  pl.split = a->sum_features && n_groups > 1 && a->n >= 16384 && a->n < kSplitSumMaxNodes && a->sum_workspace != nullptr &&
+             a->sum_workspace_bytes >= static_cast<size_t>(n_groups) * static_cast<size_t>(a->n) * sizeof(float);
+  if (pl.split) {
+    pl.bs = 512;
+    int per_cu = static_cast<int>((160 * 1024) / pl.lds);
+    if (per_cu > 2048 / pl.bs) per_cu = 2048 / pl.bs;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = static_cast<int64_t>(cu_count_()) * per_cu;
+    const int unit = 64, overhead = 500;
+    int64_t best_cost = -1;
+    int best = 2048;
+    for (int npb = 256; npb <= 16384; npb += unit) {
+      const int64_t wgs = ((a->n + npb - 1) / npb + 7) / 8 * 8 * n_groups;
+      const int64_t rounds = (wgs + resident - 1) / resident;
+      const int64_t cost = rounds * (npb + overhead);
+      if (best_cost < 0 || cost < best_cost || (cost == best_cost && npb > best)) { best_cost = cost; best = npb; }
+    }
+    pl.npb = best;
+  } else if (a->n < 262144) {
     const int64_t npb = (a->n / 1024 + 255) / 256 * 256;
     pl.npb = static_cast<int>(npb < 256 ? 256 : (npb > 4096 ? 4096 : npb));
   } else {
@@ -497,10 +537,11 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
   p.col_partial = col_partial;
   p.total_rows = (a->total_rows > 0 && a->total_rows < a->n) ? a->total_rows : a->n;
   p.piece_out = a->piece_out;
+  p.part = pl.split ? static_cast<float*>(a->sum_workspace) : nullptr;
   size_t lds = pl.lds;
   if (col_partial && lds < static_cast<size_t>(pl.bs) * 4 * sizeof(float)) lds = static_cast<size_t>(pl.bs) * 4 * sizeof(float);
   const int64_t bx = (p.n + p.nodes_per_block - 1) / p.nodes_per_block;
-  const int64_t wgs = a->sum_features ? bx : (bx + 7) / 8 * 8 * p.n_groups;
+  const int64_t wgs = (a->sum_features && !pl.split) ? bx : (bx + 7) / 8 * 8 * p.n_groups;
   if (wgs > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: too many nodes for one launch");
   auto go = [&](auto kernel) {
     if (lds > 64 * 1024) {
@@ -528,8 +569,25 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
   using I32 = std::integral_constant<int, 32>;
   using S512 = std::integral_constant<int, 512>;
   using S1024 = std::integral_constant<int, 1024>;
-  if (pl.fg == 32) return pl.bs == 1024 ? by_kf(I32{}, S1024{}) : by_kf(I32{}, S512{});
-  return by_kf(I16{}, S512{});
+  int rc;
+  if (pl.fg == 32) rc = pl.bs == 1024 ? by_kf(I32{}, S1024{}) : by_kf(I32{}, S512{});
+  else rc = by_kf(I16{}, S512{});
+  if (rc != GNAN_OK || !pl.split) return rc;
+  hipLaunchKernelGGL(sum_groups_kernel, dim3(static_cast<unsigned>((a->n + 255) / 256)), dim3(256), 0, st, p.part, p.n_groups, p.n,
+                     p.out, p.out_stride);
+  return gnan::check_launch("sum_groups_kernel");
+}
+
+// bytes of gnan_fpwl_args.sum_workspace this call would use (0: none): what index_plan's split needs
+size_t gnan_index_sum_workspace_bytes(const gnan_fpwl_args* a) {
+  if (!a || !a->sum_features || a->n < 16384 || a->n >= kSplitSumMaxNodes) return 0;
+  gnan_fpwl_args probe = *a;
+  probe.sum_workspace = nullptr;
+  probe.sum_workspace_bytes = 0;
+  const IndexPlan pl = index_plan(&probe);
+  if (!pl.ok) return 0;
+  const int n_groups = a->F / pl.fg;
+  return n_groups > 1 ? static_cast<size_t>(n_groups) * static_cast<size_t>(a->n) * sizeof(float) : 0;
 }
 
 extern "C" int gnan_feature_range(const float* x, int64_t n, int64_t x_stride, int32_t F, float* range, void* workspace,

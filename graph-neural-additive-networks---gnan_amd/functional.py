@@ -232,6 +232,13 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         a.index_table, a.index_key, a.index_buckets = _lib.ptr(index[0]), _lib.ptr(index[1]), int(index[0].shape[1])
     else:
         index_keep = _fpwl_index(a, x, t, x_range)      # noqa: F841  (alive until the look-up is queued)
+    sum_ws = None
+    if sum_features and a.index_table:
+        # a medium batch with several feature groups: a workgroup per (node block, group), partial sums added in group order
+        need = _lib.lib().gnan_fpwl_sum_workspace_bytes(a)
+        if need:
+            sum_ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)      # (alive until the look-up is queued)
+            a.sum_workspace, a.sum_workspace_bytes = _lib.ptr(sum_ws), need
     total = None
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0

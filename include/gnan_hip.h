@@ -177,6 +177,10 @@ typedef struct gnan_fpwl_args {
   const float* index_key;      /* ([F, buckets] entries and [F, 2] key coefficients).  With C == 1, whole 16-feature groups and   */
   int32_t index_buckets;       /* 16-byte aligned rows the look-up then finds a value's piece by arithmetic + one to three         */
                                /* comparisons instead of a search (csrc/fpwl_index.hip); same results bit for bit                  */
+  void* sum_workspace;         /* gnan_fpwl_fwd, optional (ABI 42): gnan_fpwl_sum_workspace_bytes() bytes.  With it a feature-sum     */
+  size_t sum_workspace_bytes;  /* look-up over several feature groups on a MEDIUM batch gives every (node block, group) a workgroup */
+                               /* of its own and adds the groups' partial sums in group order afterwards (same bits as the walk    */
+                               /* of all groups inside one workgroup, which leaves most of the chip idle below ~10^6 nodes)         */
 } gnan_fpwl_args;
 
 /* gnan_fpwl_args.flags (the library reads no environment variables: switches are the caller's, passed per call) */
@@ -189,6 +193,7 @@ enum gnan_fpwl_flags {
 };
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);
+size_t gnan_fpwl_sum_workspace_bytes(const gnan_fpwl_args* a);   /* 0: the call would not use one */
 int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream);
 
 /* Direct-index acceleration of the one-channel look-up (csrc/fpwl_index.hip; no counterpart in the reference, whose

@@ -1911,13 +1911,15 @@ def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets,
         assert same(got2, want), (lo, hi)
 
 
-def test_direct_index_keeps_the_pieces_for_the_backward_pass(monkeypatch):
+@pytest.mark.parametrize("F", [32, 48, 144])
+def test_direct_index_keeps_the_pieces_for_the_backward_pass(F, monkeypatch):
     """Training, one channel: the direct-index feature-sum kernel stores the same piece bytes as the tree-search kernel,
-    so the moment kernel bins the same terms — parameter gradients bit for bit."""
+    so the moment kernel bins the same terms — parameter gradients bit for bit.  F = 48 / 144: three / nine 16-feature groups
+    on a medium batch — a workgroup per (node block, group) and the groups' partial sums added in order (`sum_workspace`)."""
     from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
-    n, F, L, H = 80_000, 32, 3, 16
+    n, L, H = 80_000, 3, 16
     sd = _mlp_state(F, L, H, 1, True, seed=11)
     x = _index_inputs("uniform", n, F, seed=2)
     target = torch.randn(n, 1, generator=torch.Generator().manual_seed(1)).to(DEV)
