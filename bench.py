@@ -374,8 +374,10 @@ def run_c3(args):
             marks_all.append(marks)
         return out
 
+    params = list(model.parameters())            # (as an optimizer holds them: walking the module tree costs 0.7 ms per call)
+
     def fwd_bwd():
-        for p in model.parameters():             # what optimizer.zero_grad() of an optimizer over model.parameters() does (trainer.py:48)
+        for p in params:                         # what optimizer.zero_grad() of an optimizer over model.parameters() does (trainer.py:48)
             p.grad = None
         out = model.forward(data)
         loss = ((out - target) ** 2).mean()
@@ -398,7 +400,7 @@ def run_c3(args):
     replay = {"replayed_fwd_bwd_ms": None, "replayed_fwd_bwd_ms_min": None, "replay_note": None}
     try:
         from gnan_amd.graphed import CaptureFailed, GraphedCallable
-        eager_grads = [p.grad.detach().clone() for p in model.parameters()]
+        eager_grads = [p.grad.detach().clone() for p in params]
 
         def clear():
             model.zero_grad()
@@ -412,7 +414,7 @@ def run_c3(args):
         captured.replay()
         torch.cuda.synchronize()
         scale = max(float(g0.abs().max()) for g0 in eager_grads)
-        worst = max(float((p.grad - g0).abs().max()) for p, g0 in zip(model.parameters(), eager_grads))
+        worst = max(float((p.grad - g0).abs().max()) for p, g0 in zip(params, eager_grads))
         if not worst <= 1e-5 * scale:
             replay["replay_note"] = f"replayed gradients off by {worst / max(scale, 1e-30):.2e} of the largest: not reported"
         else:
