@@ -85,7 +85,7 @@ class TensorKeyedCache:
         self.entries.clear()
 
     def __deepcopy__(self, memo):                  # a copied / pickled model starts with an empty cache
-        return TensorKeyedCache(self.capacity)
+        return TensorKeyedCache(self.capacity, self.on_evict)
 
     def __reduce__(self):
         return (TensorKeyedCache, (self.capacity,))

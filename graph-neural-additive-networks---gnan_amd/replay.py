@@ -8,7 +8,7 @@ those run on the same tensors every epoch (main.py builds one ``Data`` object an
 
 So the modules capture themselves: the third ``forward`` on the same input tensors (object identity + version, as every
 cache here) captures the forward into one hipGraph and — with autograd on — the backward pass of the autograd graph that
-forward built into a second one.  From then on ``forward`` is one graph launch that returns a static output tensor behind a
+forward built into a second one.  From then on ``forward`` is one graph launch that returns (a copy of) its static output behind a
 single autograd node, and ``loss.backward()`` reaches that node, which copies the incoming gradient into a static buffer and
 launches the second graph; the parameter gradients land where they always land (the flat gradient buffers of
 ``modules.FlatMLPStore``), so ``optimizer.step()`` and ``named_parameters()`` see nothing new.  ~25 + ~45 launches and their
@@ -40,6 +40,9 @@ REPLAY_AFTER = 2             # eager forwards on the same inputs before the capt
 REPLAY_MIN_NODES = 256       # below: the small-graph paths (one launch each way) — and graph-level tasks hand over a new object per step
 REPLAY_PLANS = 4             # plans a model keeps (train / eval x a couple of inputs); the least recently used one is released
 REPLAY_SMALL_GRAPHS = True   # graph-level forwards of small dense graphs through graph slots (one plan per tier, any graph)
+REPLAY_COPY_MAX_BYTES = 256 << 20   # a replayed forward hands out a COPY of its static output up to this size (callers collect the
+                                    # outputs of an evaluation loop; the next replay must not rewrite what they hold); larger outputs
+                                    # are the static tensor itself, valid until the next forward on the same inputs
 
 
 def _stores_of(module):
@@ -140,13 +143,18 @@ class _NotNow(Exception):
     pass
 
 
+def _handed_out(plan: "_Plan") -> torch.Tensor:
+    out = plan.out.detach()
+    return out.clone() if out.numel() * out.element_size() <= REPLAY_COPY_MAX_BYTES else out
+
+
 class _Replayed(torch.autograd.Function):
     """The one autograd node of a replayed forward: its backward replays the captured backward pass."""
 
     @staticmethod
     def forward(ctx, plan: _Plan, anchor):
         ctx.plan, ctx.gen = plan, plan.gen
-        return plan.out.detach()
+        return _handed_out(plan)
 
     @staticmethod
     def backward(ctx, d_out):
@@ -191,6 +199,21 @@ def _key(module, inputs, grad: bool):
     return src, extra
 
 
+class _SlotBook:
+    """The slot plans of ONE model (``model.__dict__['_replay_slots']``).  A copied or pickled model starts without plans: a
+    hipGraph belongs to the tensors it was captured over (``copy.deepcopy(model)`` is what keeps a best-so-far checkpoint)."""
+
+    def __init__(self):
+        self.calls = 0
+        self.plans = {}
+
+    def __deepcopy__(self, memo):
+        return _SlotBook()
+
+    def __reduce__(self):
+        return (_SlotBook, ())
+
+
 class _SlotInputs:
     """Duck-typed ``Data`` over the slots of a :class:`small_graph.SlotGraph`."""
 
@@ -214,15 +237,15 @@ def _run_small(module, inputs):
     grad = torch.is_grad_enabled() and any(st.flat[name].requires_grad for st in stores for name in st.buf)
     book = module.__dict__.get("_replay_slots")
     if book is None:
-        book = {"calls": 0, "plans": {}}
+        book = _SlotBook()
         object.__setattr__(module, "_replay_slots", book)
     key = (tier, grad, bool(module.training), tuple(bool(st.flat[name].requires_grad) for st in stores for name in st.buf))
-    rec = book["plans"].get(key)
+    rec = book.plans.get(key)
     if rec is None:
-        if book["calls"] < REPLAY_AFTER:
-            book["calls"] += 1
+        if book.calls < REPLAY_AFTER:
+            book.calls += 1
             return None
-        rec = book["plans"][key] = {"plan": None, "slot": None, "dead": False}
+        rec = book.plans[key] = {"plan": None, "slot": None, "dead": False}
     if rec["dead"]:
         return None
     plan = rec["plan"]
@@ -246,7 +269,7 @@ def _run_small(module, inputs):
     rec["slot"].load(g, inputs.x)
     plan.gen += 1
     plan.fwd.replay()
-    return _Replayed.apply(plan, plan.anchor) if plan.grad else plan.out
+    return _Replayed.apply(plan, plan.anchor) if plan.grad else _handed_out(plan)
 
 
 def run(module, inputs, node_ids=None):
@@ -301,7 +324,7 @@ def run(module, inputs, node_ids=None):
         return module._forward(inputs)
     if plan.grad:
         return _Replayed.apply(plan, plan.anchor)
-    return plan.out
+    return _handed_out(plan)
 
 
 def release(module) -> None:
@@ -313,5 +336,5 @@ def release(module) -> None:
         cache.clear()
     book = module.__dict__.pop("_replay_slots", None)
     if book is not None:
-        for rec in book["plans"].values():
+        for rec in book.plans.values():
             _release_record(rec)

@@ -52,6 +52,10 @@ def test_reference_shaped_epochs_replayed_equal_the_eager_ones(n, F, C, dense, l
     # the per-layer gradients the reference's names expose are the flat buffers' views: alive after a replayed backward
     named = dict(b.named_parameters())
     assert named["fs.0.0.weight"].grad is not None and torch.isfinite(named["fs.0.0.weight"].grad).all()
+    c = copy.deepcopy(b)                                 # a model that holds plans can be copied: the copy starts without them
+    assert not _plans(c)
+    with torch.no_grad():
+        assert float((c.forward(data) - b.forward(data)).abs().max()) <= 1e-6 * float(b.forward(data).abs().max())
     replay.release(b)
     assert not _plans(b)
 
@@ -173,12 +177,24 @@ def test_graph_level_loop_replays_small_graphs_through_slots(cls, monkeypatch):
         scale = max(float(v.abs().max()) for v in a.state_dict().values())
         for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
             assert float((va - vb).abs().max()) <= 1e-5 * scale, (e, k)
+    # an evaluation loop may COLLECT its outputs: a replayed forward hands out copies, the next replay rewrites nothing of them
+    with torch.no_grad():
+        kept = [b.forward(d) for d in graphs[:12]]
+        again = [b.forward(d).clone() for d in graphs[:12]]
+    assert all(torch.equal(u, v) for u, v in zip(kept, again)) and len({float(u.sum()) for u in kept}) > 6
     book = b.__dict__["_replay_slots"]
-    plans = [r["plan"] for r in book["plans"].values() if r["plan"] is not None]
+    plans = [r["plan"] for r in book.plans.values() if r["plan"] is not None]
     train = [p for p in plans if p.grad]
     assert train and all(p.bwd.replays == p.fwd.replays for p in train)
     n_fit = sum(d.x.shape[0] <= 128 for d in graphs)
     assert sum(p.fwd.replays for p in train) >= 3 * n_fit - 2 - len(train)      # all but the two warm-up forwards (and a capture each)
     assert sum(p.fwd.replays for p in plans if not p.grad) >= 3 * n_fit - len(plans)
     assert "_replay_slots" not in a.__dict__
+    # a copy of a model that holds plans (main.py-style best-model snapshots: copy.deepcopy) starts without them and works
+    c = copy.deepcopy(b)
+    assert not c.__dict__["_replay_slots"].plans and not _plans(c)
+    with torch.no_grad():
+        assert torch.equal(c.forward(graphs[0]), b.forward(graphs[0]))
+    import pickle
+    assert pickle.loads(pickle.dumps(b.__dict__["_replay_slots"])).plans == {}
     replay.release(b)
