@@ -37,8 +37,11 @@ from . import _lib
 
 REPLAY_FORWARD = True        # off: every forward issues its launches eagerly
 REPLAY_AFTER = 2             # eager forwards on the same inputs before the capture (they are its warm-up: caches, table sizes)
-REPLAY_MIN_NODES = 256       # below: the small-graph paths (one launch each way) — and graph-level tasks hand over a new object per step
-REPLAY_PLANS = 4             # plans a model keeps (train / eval x a couple of inputs); the least recently used one is released
+REPLAY_MIN_NODES = 129       # below: the small-graph route (graph slots, `_run_small`)
+REPLAY_PLANS = 24            # plans a model keeps (train / eval x a few inputs; the graphs of a graph-level task that are too large for
+                             # the slots — 129 to 417 nodes on Mutagenicity — get one each).  A full book takes no new inputs (they stay
+                             # eager) rather than drop a live plan for them: a loop over more inputs than plans would otherwise capture,
+                             # evict and capture again for ever
 REPLAY_SMALL_GRAPHS = True   # graph-level forwards of small dense graphs through graph slots (one plan per tier, any graph)
 REPLAY_COPY_MAX_BYTES = 256 << 20   # a replayed forward hands out a COPY of its static output up to this size (callers collect the
                                     # outputs of an evaluation loop; the next replay must not rewrite what they hold); larger outputs
@@ -281,7 +284,7 @@ def run(module, inputs, node_ids=None):
         return module._forward(inputs) if node_ids is None else module._forward(inputs, node_ids)
     if x.shape[0] < REPLAY_MIN_NODES:
         out = None
-        if REPLAY_SMALL_GRAPHS and x.shape[0] <= 128 and getattr(inputs, "gnan_graph", None) is None:
+        if REPLAY_SMALL_GRAPHS and getattr(inputs, "gnan_graph", None) is None:
             out = _run_small(module, inputs)
         return module._forward(inputs) if out is None else out
     grad = torch.is_grad_enabled() and any(st.flat[name].requires_grad for st in _stores_of(module) for name in st.buf)
@@ -293,6 +296,12 @@ def run(module, inputs, node_ids=None):
     src, extra = _key(module, inputs, grad)
     rec = cache.get(src, extra)
     if rec is None:
+        if len(cache) >= cache.capacity:
+            # room only at the expense of an entry that holds no plan yet (the least recently used such one)
+            spare = next((k for k, e in cache.entries.items() if e.value["plan"] is None), None)
+            if spare is None:
+                return module._forward(inputs)
+            del cache.entries[spare]
         cache.put(src, extra, {"calls": 1, "plan": None, "dead": False, "graph": getattr(inputs, "gnan_graph", None)})
         return module._forward(inputs)
     if rec["dead"]:

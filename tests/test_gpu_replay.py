@@ -189,6 +189,9 @@ def test_graph_level_loop_replays_small_graphs_through_slots(cls, monkeypatch):
     n_fit = sum(d.x.shape[0] <= 128 for d in graphs)
     assert sum(p.fwd.replays for p in train) >= 3 * n_fit - 2 - len(train)      # all but the two warm-up forwards (and a capture each)
     assert sum(p.fwd.replays for p in plans if not p.grad) >= 3 * n_fit - len(plans)
+    # the 130-node graphs do not fit the slots: each is its own input (the same object every epoch) and gets a plan of its own
+    big = [p for p in _plans(b)]
+    assert len(big) >= 2 and all(p.fwd.replays >= 1 for p in big)
     assert "_replay_slots" not in a.__dict__
     # a copy of a model that holds plans (main.py-style best-model snapshots: copy.deepcopy) starts without them and works
     c = copy.deepcopy(b)
