@@ -349,7 +349,7 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
     // U nodes per thread and round, the x rows of the NEXT round requested before this round's look-ups start: a look-up
     // is ~16 vector instructions and 3 LDS round trips, so without loads in flight across rounds a wave would spend its
     // time waiting for one 16-byte load at a time (16 waves per CU x 1 KB = 4 MB in flight chip-wide: < 3 TB/s)
-    constexpr int U = 2;
+    constexpr int U = 2;                     // (three rows in flight in the feature-sum mode — 120 registers — measured the same: round 5)
     // (unconditional loads from a clamped address: a guarded load would hide the number of loads in flight from the
     //  compiler, which then waits for ALL of them — the prefetch included — before the first look-up)
     const float* xq = p.x + k0 + q * FPT;
@@ -358,29 +358,22 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
     const float* xp = xq + (n_lo + nl) * p.x_stride;
     auto row = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr <= xlast ? ptr : xlast); };
     float4 cur[U], nxt[U];
-    // feature sum over several groups: the sum the EARLIER groups left in `out` travels with the x row — requested a round
-    // ahead like it.  (Read next to the store it feeds, every round waited for that load and, vmcnt being in order, for the
-    // prefetched x rows queued before it: the look-ups then ran with nothing in flight.)
-    float pre[U] = {}, pre_nxt[U] = {};
-    const bool add_before = SUM && !split && g > g_lo;
-    auto before_of = [&](const int64_t n) { return p.out[(n < n_hi ? n : n_hi - 1) * p.out_stride]; };
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      cur[u] = row(xp + u * xstep);
-      if (add_before) pre[u] = before_of(n_lo + nl + u * NODES);
-    }
+    for (int u = 0; u < U; ++u) cur[u] = row(xp + u * xstep);
+    const bool add_before = SUM && !split && g > g_lo;   // feature sum over several groups inside the workgroup: read-modify-write of the output
     for (int64_t n = n_lo + nl; n < n_hi; n += U * NODES) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        nxt[u] = row(xp + (U + u) * xstep);
-        if (add_before) pre_nxt[u] = before_of(n + (U + u) * NODES);
-      }
+      for (int u = 0; u < U; ++u) nxt[u] = row(xp + (U + u) * xstep);
       xp += U * xstep;
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (n + u * NODES < n_hi) look_up(n + u * NODES, cur[u], pre[u]);
+        if (n + u * NODES < n_hi) {
+          // (requesting the earlier groups' sum a round ahead, next to the x row, was tried in round 5: 14 more registers, same time)
+          const float before = (add_before && q == 0) ? p.out[(n + u * NODES) * p.out_stride] : 0.f;
+          look_up(n + u * NODES, cur[u], before);
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) { cur[u] = nxt[u]; pre[u] = pre_nxt[u]; }
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
     if constexpr (!SUM) {
       if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64 (as fpwl_fast_kernel)
