@@ -705,7 +705,7 @@ class TensorGNAN(_PathBase):
             self._mark("lut")
             fx, total = self._operand(x, "fs", self.fs, False, rest, pad_ok=True)     # [N, F]   (f is 1-wide; + zero columns)
             self._mark("fmlp")
-            hidden = rho_aggregate(g, fx, lut, use_cnt, s_total=total).sum(dim=0).view(1, -1)[:, :x.shape[1]]   # [1, F]   models.py:379
+            hidden = graph_readout(rho_aggregate(g, fx, lut, use_cnt, s_total=total)).view(1, -1)[:, :x.shape[1]]   # [1, F]   models.py:379 (gnan_colsum)
             self._mark("spmm")
             return self.readout_nam(hidden).T                                         # [C, 1]   models.py:380-384
         lut = self._lut_global(g)

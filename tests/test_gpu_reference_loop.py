@@ -55,7 +55,8 @@ def test_modules_under_the_reference_shaped_loop_in_anomaly_mode(name):
             assert float(np.abs(v.cpu().numpy() - z["sd1/" + k]).max()) <= 2e-5 * scale, k
 
 
-@pytest.mark.parametrize("shape", ["node_csr", "node_csr_reference_order", "graph_dense_large", "graph_readout", "pre_rho"])
+@pytest.mark.parametrize("shape", ["node_csr", "node_csr_reference_order", "graph_dense_large", "graph_readout", "graph_readout_large",
+                                   "pre_rho"])
 def test_every_route_of_the_forward_survives_anomaly_mode(shape):
     """The routes the goldens do not reach (a CSR with a rest bucket and hub rows, the reference aggregation order, a dense
     graph too large for the one-launch kernel, the NAM read-out, the stand-alone file's pre-rho class): forward + backward
@@ -82,7 +83,7 @@ def test_every_route_of_the_forward_survives_anomaly_mode(shape):
         if shape.endswith("reference_order"):
             m.aggregation_order = "reference"
     else:
-        n = 300 if shape == "graph_dense_large" else 40
+        n = 300 if shape in ("graph_dense_large", "graph_readout_large") else 40
         F, C = 6, 2
         ei = np.stack([rng.integers(0, n, 3 * n), rng.integers(0, n, 3 * n)])
         ei = np.concatenate([ei, ei[::-1]], axis=1)
@@ -93,7 +94,7 @@ def test_every_route_of_the_forward_survives_anomaly_mode(shape):
             m = standalone.TensorGNAN(F, C, 3, hidden_channels=16, is_graph_task=True, device=DEV)
         else:
             m = models.TensorGNAN(F, C, 3, hidden_channels=16, is_graph_task=True, device=DEV,
-                                  readout_n_layers=2 if shape == "graph_readout" else 0)
+                                  readout_n_layers=2 if shape.startswith("graph_readout") else 0)
     gen = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for _, p in m.named_parameters():
@@ -107,6 +108,11 @@ def test_every_route_of_the_forward_survives_anomaly_mode(shape):
             y.pow(2).sum().backward()
         return y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
     y0, g0 = once(False)
+    if shape == "graph_readout_large":           # the general kernels + NAM read-out (models.py:379-381) against the float64 oracle
+        sd64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+        truth = O.tensor_gnan_forward_models(d.x.cpu().double(), d.node_distances.cpu().double(),
+                                             d.normalization_matrix.cpu().double(), sd64, True, True, 2)
+        assert O.rel_err(y0.cpu(), truth) <= 1e-5
     y1, g1 = once(True)
     y2, g2 = once(True)                                                # twice: nothing the first pass left behind trips the next
     assert sorted(g0) == sorted(g1) == sorted(g2) and len(g0) > 0
