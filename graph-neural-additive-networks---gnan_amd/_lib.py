@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -128,7 +128,11 @@ class MomentScalesArgs(C.Structure):
         ("grad", C.c_void_p), ("n", C.c_int64), ("width", C.c_int32), ("bits", C.c_int32), ("grad_stride", C.c_int64),
         ("anchor", C.c_void_p), ("T", C.c_int64), ("n_anchors", C.c_void_p), ("x_abs_max", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("scales", C.c_void_p),
+        ("zero", C.c_void_p), ("zero_bytes", C.c_size_t),
     ]
+
+
+MOMENT_SCALES_WORKSPACE_BYTES = 8192      # GNAN_MOMENT_SCALES_WORKSPACE_BYTES
 
 
 class SpmmLutGradArgs(C.Structure):
@@ -151,7 +155,8 @@ class SpmmBwdNarrowArgs(C.Structure):
         ("spmm", SpmmArgs), ("s_rows", C.c_void_p), ("s_rows_stride", C.c_int64), ("w_real", C.c_int32),
         ("with_rest", C.c_int32), ("dS", C.c_void_p), ("ds_stride", C.c_int64), ("dlut", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("ds_add", C.c_void_p),
-        ("hot_code_lo", C.c_int32), ("hot_codes", C.c_int32),
+        ("hot_code_lo", C.c_int32), ("hot_codes", C.c_int32), ("ds_add_scale", C.c_void_p), ("rest_total", C.c_void_p),
+        ("rest_q", C.c_void_p),
     ]
 
 

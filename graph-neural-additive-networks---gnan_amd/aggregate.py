@@ -266,10 +266,13 @@ def narrow_walk(g: HopGraph):
 
 
 def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool, W: int,
-                      walk=None, ds_add: Optional[torch.Tensor] = None):
+                      walk=None, ds_add: Optional[torch.Tensor] = None, rest_q: Optional[torch.Tensor] = None,
+                      rest_total: Optional[torch.Tensor] = None, add_to_rows: bool = False):
     """``gnan_spmm_bwd_narrow`` over the transposed adjacency ``gt``: returns ``(dS [n, W], dlut [D])`` — see the header for
     the layout of ``V [D * n_fwd_rows, 2 * half]`` (code-major).  ``walk = narrow_walk(gt)`` when the caller has already put the hot
-    rows behind ``V`` (``pack_bwd_rows(hot=...)``)."""
+    rows behind ``V`` (``pack_bwd_rows(hot=...)``).  The rest bucket's column-sum term ``wt(i, rest) * total``: ``rest_q [W]``
+    (the column sums of the packed rows' rest halves) and ``rest_total [W]`` add ``<rest_total, rest_q>`` to ``dlut[D - 1]``;
+    ``add_to_rows`` adds ``lut[D - 1] * rest_q`` to every row of ``dS`` (``ds_add``: a ready vector for the same place)."""
     _lib.require_device(V, S_rows, lut, gt.code)
     V = Fn._rows(V.detach().float())
     S_rows = Fn._rows(S_rows.detach().float())
@@ -296,6 +299,17 @@ def bwd_narrow_launch(gt: HopGraph, V: torch.Tensor, S_rows: torch.Tensor, lut: 
     na = _lib.SpmmBwdNarrowArgs(spmm=a, s_rows=_lib.ptr(S_rows), s_rows_stride=S_rows.stride(0), w_real=W,
                                 with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0), dlut=_lib.ptr(dlut),
                                 ds_add=None if ds_add is None else _lib.ptr(ds_add))
+    if rest_q is not None:
+        rest_q = rest_q.detach().float().contiguous()
+        if rest_total is not None:
+            rest_total = rest_total.detach().float().contiguous()
+            if rest_total.numel() != W or rest_q.numel() != W:
+                raise ValueError("bwd_narrow: rest_total / rest_q hold one value per operand column")
+            na.rest_total, na.rest_q = _lib.ptr(rest_total), _lib.ptr(rest_q)
+        if add_to_rows:
+            if ds_add is not None:
+                raise ValueError("bwd_narrow: either a ready ds_add or add_to_rows")
+            na.ds_add, na.ds_add_scale = _lib.ptr(rest_q), _lib.ptr(lut[D - 1:])
     if a.packed_index and hot is not None and HOT_ROWS_IN_LDS:
         # ... with the head of the appended hot rows in LDS.  Code 0 is the self pair of a hop-coded graph (one pair per
         # row, never a hot one): the LDS copy covers the other listed codes
@@ -384,17 +398,16 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         half = 1 << max(0, (W - 1).bit_length())
         walk = narrow_walk(g.transposed())
         V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
-        q_sum = ds_add = None
+        q_sum = total = None
+        add_to_rows = False
         if with_rest:
             q_sum = Fn.column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
-            if ctx.total_group is NOT_SHARED and ctx.total_rows is None:
-                # d/dS_j of  wt(i, rest) * total : the same vector rho(0) * q_sum for every j — added by the kernel's epilogue
-                ds_add = (lut[D - 1, 0].float() * q_sum).contiguous()
-                rest_added = True
-        dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk, ds_add=ds_add)
-        if with_rest:
-            total = ctx.s_total if ctx.s_total is not None else Fn.column_sums(S)
-            dl = torch.cat([dl[: D - 1], (dl[D - 1] + (total.float() * q_sum).sum()).reshape(1)])
+            # d/dS_j of  wt(i, rest) * total : the same vector rho(0) * q_sum for every j — added by the kernel's epilogue
+            add_to_rows = rest_added = ctx.total_group is NOT_SHARED and ctx.total_rows is None
+            # d/d lut[rest] of the same term: <total, q_sum> — added by the kernel's final pass
+            total = (ctx.s_total if ctx.s_total is not None else Fn.column_sums(S)).float().reshape(-1).contiguous()
+        dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk,
+                                   rest_q=q_sum, rest_total=total, add_to_rows=add_to_rows)
         dlut = dl.view(D, 1)
 
     if need_dS and not fused_bwd:

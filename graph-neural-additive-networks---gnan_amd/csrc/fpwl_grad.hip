@@ -80,12 +80,48 @@ __device__ __forceinline__ void piece_points(const float* A, int li, int P, doub
   else *xi = 0.5 * (*a + static_cast<double>(A[li + 1]));
 }
 
+// live[0 .. *n_live) = the pieces of [base, base + P) that hold at least one node (a non-zero moment), ascending: one parallel
+// pass over the moments and an ordered compaction by ballots (a single thread walking P flags in LDS cost ~5 us of the 64 the
+// arxiv shape's launch took).  Called by all kThreads threads of the workgroup; the caller's barrier publishes the list.
+template <int kThreads>
+__device__ __forceinline__ void list_live_pieces(const GradParams& p, int base, int P, double inv0, double inv1, int* live,
+                                                 int* wave_live, int* n_live) {
+  constexpr int kWaves = kThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, C = p.C;
+  int running = 0;
+  for (int l0 = 0; l0 < P; l0 += kThreads) {
+    const int li = l0 + tid;
+    bool nz = false;
+    if (li < P) {
+      double unused;
+      for (int c2 = 0; c2 < 2 * C; ++c2) nz |= piece_moment(p, base + li, c2, inv0, inv1, &unused);
+    }
+    const unsigned long long b = __ballot(nz);
+    if (lane == 0) wave_live[wave] = __popcll(b);
+    __syncthreads();
+    int before = running, all = running;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const int c = wave_live[w];
+      before += w < wave ? c : 0;
+      all += c;
+    }
+    if (nz) live[before + __popcll(b & ((1ull << lane) - 1ull))] = li;
+    running = all;
+    __syncthreads();                                // wave_live is rewritten by the next chunk
+  }
+  if (tid == 0) *n_live = running;
+}
+
 // ---- L == 3, H <= 64: NG groups of 256 threads walk the pieces NG at a time; in a group thread (j, ib) = (unit of
 // layer 2, quarter of the layer-1 units).  One group per workgroup needed 110 us on the arxiv shape (129 features x ~130
-// pieces, two barriers per piece, 129 workgroups on 256 CUs); four groups share the weights in LDS and a piece's
-// latency: 110 -> ~35 us.  The groups' accumulators meet in LDS in group order (fixed order: bit-reproducible).
+// pieces, two barriers per piece, 129 workgroups on 256 CUs); several groups share the weights in LDS and a piece's
+// latency, the live pieces are listed by ballots and a piece's moments, anchor and inner point are requested a round
+// ahead: 110 -> 64 -> 50 us (measured; two and four groups alike — what is left is the ~130 LDS reads and float64 fmas
+// per thread and piece).  The groups' accumulators meet in LDS in group order (fixed order: bit-reproducible).
 // CQ = ceil(C / 4) channel accumulators per thread: a template parameter so that the common one-channel case does not pay
-// 32 registers for them (1024 threads leave 128 VGPRs per lane; with CQ = 16 the kernel spilled 120 of them).
+// 32 registers for them.  1024 threads leave 128 VGPRs per lane: W2 is read from its padded LDS copy (conflict-free: row
+// stride H + 1) rather than kept in 16 registers, which spilled 86 at four groups; CQ = 16 spills 120 there and runs two.
 template <int kNG, int CQ>
 __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -104,9 +140,10 @@ __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams 
   double* e0 = h1p + H;
   double* e1 = e0 + H;
   double* Mv = e1 + H;
-  double* red = vec + kNG * (5 * H + 2 * C);      // [256]: one accumulator of every thread of a group at a time
-  int* live = reinterpret_cast<int*>(red + 256);  // [P]: the pieces that hold at least one node, ascending
+  double* red = vec + kNG * (5 * H + 2 * C);      // [kNG - 1][256]: one accumulator of every thread of groups 1.. at a time
+  int* live = reinterpret_cast<int*>(red + (kNG - 1) * 256);   // [P]: the pieces that hold at least one node, ascending
   __shared__ int n_live;
+  __shared__ int wave_live[4 * kNG];
   const int j = lt >> 2, ib = lt & 3;
   const int BI = (H + 3) >> 2;
   const int64_t kH = static_cast<int64_t>(k) * H;
@@ -118,12 +155,6 @@ __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams 
   }
   for (int i = tid; i < H * H; i += 256 * kNG) W2s[(i / H) * HS + i % H] = p.W2[kH * H + i];
   for (int i = tid; i < C * H; i += 256 * kNG) Wl[i] = p.Wl[kH * C + i];
-  float w2r[kBI];
-#pragma unroll
-  for (int r = 0; r < kBI; ++r) {
-    const int i = ib * BI + r;
-    w2r[r] = (j < H && r < BI && i < H) ? p.W2[(kH + j) * H + i] : 0.f;
-  }
   double dW2[kBI], dW3[CQ];
 #pragma unroll
   for (int r = 0; r < kBI; ++r) dW2[r] = 0.0;
@@ -134,35 +165,28 @@ __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams 
   const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
   // Most pieces hold no node (the kinks of a feature spread far beyond the range of its values): list the others first —
   // one parallel pass over the moments instead of a dependent global read and a barrier per piece (the kernel spent its
-  // time there: 110 us on the arxiv shape with ~130 pieces of which ~25 are live)
-  for (int li = tid; li < P; li += 256 * kNG) {
-    bool nz = false;
-    double unused;
-    for (int c2 = 0; c2 < 2 * C; ++c2) nz |= piece_moment(p, base + li, c2, inv0, inv1, &unused);
-    live[li] = nz ? 1 : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int n = 0;
-    for (int li = 0; li < P; ++li)
-      if (live[li]) live[n++] = li;                 // in place: n <= li
-    n_live = n;
-  }
+  // time there: 110 us on the arxiv shape with ~130 pieces of which ~25 are live).
+  list_live_pieces<256 * kNG>(p, base, P, inv0, inv1, live, wave_live, &n_live);
   __syncthreads();
   const int nl = n_live;
   double mval = 0.0;                                // this thread's moment of the group's NEXT piece, requested a round ahead
-  if (grp < nl && lt < 2 * C) piece_moment(p, base + live[grp], lt, inv0, inv1, &mval);
+  double a_next = 0.0, xi_next = 0.0;               // ... and its anchor and inner point (two dependent global reads otherwise)
+  if (grp < nl) {
+    if (lt < 2 * C) piece_moment(p, base + live[grp], lt, inv0, inv1, &mval);
+    piece_points(p.anchor + base, live[grp], P, &a_next, &xi_next);
+  }
 
   for (int l0 = 0; l0 < nl; l0 += kNG) {
     const int at = l0 + grp;                        // this group's piece of the round (a group beyond the list: zeros)
     const int li = at < nl ? live[at] : -1;
     __syncthreads();                                // the previous round's readers of the LDS vectors are done
-    double a = 0.0, xi = 0.0;
-    if (li >= 0) piece_points(p.anchor + base, li, P, &a, &xi);
-    if (lt < 2 * C) {
-      Mv[lt] = li >= 0 ? mval : 0.0;
-      mval = 0.0;
-      if (at + kNG < nl) piece_moment(p, base + live[at + kNG], lt, inv0, inv1, &mval);
+    const double a = a_next, xi = xi_next;          // (a group beyond the list: zero moments, any point)
+    if (lt < 2 * C) Mv[lt] = li >= 0 ? mval : 0.0;
+    mval = 0.0;
+    if (at + kNG < nl) {
+      const int ln = live[at + kNG];
+      if (lt < 2 * C) piece_moment(p, base + ln, lt, inv0, inv1, &mval);
+      piece_points(p.anchor + base, ln, P, &a_next, &xi_next);
     }
     if (lt < H) {
       const double wv = static_cast<double>(w1[lt]), bv = static_cast<double>(b1[lt]);
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams 
       for (int r = 0; r < kBI; ++r) {
         const int i = ib * BI + r;
         if (r < BI && i < H) {
-          const double w = static_cast<double>(w2r[r]);
+          const double w = static_cast<double>(W2s[j * HS + i]);
           si = fma(w, h1i[i], si);
           sa = fma(w, h1a[i], sa);
           sp = fma(w, h1p[i], sp);
@@ -236,13 +260,14 @@ __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams 
     // the next round's first barrier separates these reads of e0 / e1 from their next writes
   }
 
-  // groups 1 .. NG-1 hand their accumulators to group 0, one value per thread at a time, in group order
+  // groups 1 .. NG-1 hand their accumulators to group 0, one value per thread at a time; group 0 adds them in group order
   auto gather = [&](double& v) {
-    for (int g = 1; g < kNG; ++g) {
-      __syncthreads();
-      if (grp == g) red[lt] = v;
-      __syncthreads();
-      if (grp == 0) v += red[lt];
+    __syncthreads();
+    if (grp > 0) red[(grp - 1) * 256 + lt] = v;
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int g = 1; g < kNG; ++g) v += red[(g - 1) * 256 + lt];
     }
   };
 #pragma unroll
@@ -279,6 +304,7 @@ __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ double Mv[128];
   __shared__ int n_live;
+  __shared__ int wave_live[8];
   int* pieces = reinterpret_cast<int*>(smem_raw);   // [P]: the pieces that hold at least one node
   const int H = p.H, C = p.C;
   const int tid = threadIdx.x, k = blockIdx.x;
@@ -298,19 +324,7 @@ __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
   double dw1 = 0.0, db1 = 0.0, db3 = 0.0;
   const int base = p.off[k], P = p.off[k + 1] - base;
   const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
-  for (int li = tid; li < P; li += 512) {            // list the non-empty pieces first (see fpwl_grad3_kernel)
-    bool nz = false;
-    double unused;
-    for (int c2 = 0; c2 < 2 * C; ++c2) nz |= piece_moment(p, base + li, c2, inv0, inv1, &unused);
-    pieces[li] = nz ? 1 : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int n = 0;
-    for (int li = 0; li < P; ++li)
-      if (pieces[li]) pieces[n++] = li;
-    n_live = n;
-  }
+  list_live_pieces<512>(p, base, P, inv0, inv1, pieces, wave_live, &n_live);   // (see fpwl_grad3_kernel)
   __syncthreads();
   const int nl = n_live;
   double mval = 0.0;
@@ -360,12 +374,14 @@ __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
 }
 
 // ---- scales of the fixed-point moments --------------------------------------------------------------------------------
-// bits[0] = max |grad| over the [n, width] gradient, bits[1] = max |anchor| over the T anchors, as the bit patterns of
-// non-negative floats (their order is the order of the values; a NaN ends up on top and poisons the scales, as it would
-// poison the sums).
+// blk[2 b] = max |grad| over workgroup b's share of the [n, width] gradient, blk[2 b + 1] = max |anchor| over its share of
+// the T anchors, as the bit patterns of non-negative floats (their order is the order of the values; a NaN ends up on top
+// and poisons the scales, as it would poison the sums).  Every workgroup writes its own pair — no atomics, nothing to zero
+// first (a zeroing launch and its 8-byte target used to precede this one) — and, on the way, clears the moment accumulators
+// the next launch adds into (`zero`, int64 words: a framework fill launch otherwise).
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, int64_t n, int width, int64_t stride,
                                                      const float* __restrict__ anchor, int64_t T, const int32_t* off_end,
-                                                     unsigned* bits) {
+                                                     unsigned* blk, unsigned long long* zero, int64_t zero_words) {
   const int64_t total = n * width;
   if (off_end && *off_end < T) T = *off_end;       // tables held in a buffer of full capacity: only off[F] anchors are real
   float m = 0.f, ma = 0.f;
@@ -377,29 +393,47 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
     const float v = fabsf(anchor[e]);
     ma = (v > ma || v != v) ? v : ma;
   }
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < zero_words; e += static_cast<int64_t>(gridDim.x) * 256)
+    zero[e] = 0ull;
   unsigned u = __float_as_uint(m), ua = __float_as_uint(ma);
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned o = __shfl_xor(u, off), oa = __shfl_xor(ua, off);
     u = o > u ? o : u;
     ua = oa > ua ? oa : ua;
   }
-  // one pair of atomics per WORKGROUP: same-address atomics serialise (16k waves x 2 took 0.19 ms on a 10M-row gradient)
   __shared__ unsigned wmax[4][2];
   if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6][0] = u; wmax[threadIdx.x >> 6][1] = ua; }
   __syncthreads();
   if (threadIdx.x < 2) {
     unsigned m4 = wmax[0][threadIdx.x];
     for (int w = 1; w < 4; ++w) m4 = wmax[w][threadIdx.x] > m4 ? wmax[w][threadIdx.x] : m4;
-    if (m4) atomicMax(bits + threadIdx.x, m4);
+    blk[2 * blockIdx.x + threadIdx.x] = m4;
   }
 }
 
-// (a kernel, not hipMemsetAsync: inside a hipGraph capture the 8-byte memset was not replayed with the graph — measured:
-// the bits kept whatever a later tenant of the block had left there, the scales collapsed and every gradient came out 0)
-__global__ void zero_bits_kernel(unsigned* bits) { bits[0] = bits[1] = 0u; }
-
-__global__ void scales_kernel(const unsigned* bits, const double* x_abs_max, int nbits, double* scales) {
-  const float gf = __uint_as_float(bits[0]), af = __uint_as_float(bits[1]);
+// one workgroup: the maxima of the n_blk pairs, then the two scales
+__global__ __launch_bounds__(256) void scales_kernel(const unsigned* blk, int n_blk, const double* x_abs_max, int nbits,
+                                                     double* scales) {
+  unsigned u = 0u, ua = 0u;
+  for (int b = threadIdx.x; b < n_blk; b += 256) {
+    const unsigned v = blk[2 * b], va = blk[2 * b + 1];
+    u = v > u ? v : u;
+    ua = va > ua ? va : ua;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_xor(u, off), oa = __shfl_xor(ua, off);
+    u = o > u ? o : u;
+    ua = oa > ua ? oa : ua;
+  }
+  __shared__ unsigned wmax[4][2];
+  if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6][0] = u; wmax[threadIdx.x >> 6][1] = ua; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; ++w) {
+    u = wmax[w][0] > u ? wmax[w][0] : u;
+    ua = wmax[w][1] > ua ? wmax[w][1] : ua;
+  }
+  const float gf = __uint_as_float(u), af = __uint_as_float(ua);
   const double xm = *x_abs_max;
   if (gf != gf || af != af || xm != xm) {            // a NaN in the gradient poisons the sums, as it would in float
     scales[0] = scales[1] = static_cast<double>(NAN);
@@ -440,10 +474,13 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
   if (a->L == 3) {
     const size_t H = a->H, C = a->C;
     size_t lds = ((3 * H + H * (H + 1) + C * H) * sizeof(float) + 7) & ~size_t(7);
-    const int ng = 2;        // many channels: two groups (512 threads leave 256 registers per lane)
-    lds += (ng * (5 * H + 2 * C) + 256) * sizeof(double) + (static_cast<size_t>(a->max_pieces) + 8) * sizeof(int);   // + live pieces
+    // few channels: four groups (1024 threads, 128 registers per lane); many: two (256 registers — CQ = 16 spilled 120 at four)
+    // (measured on the arxiv shape, 128 features x ~130 pieces: 50 us with either group count — the pieces' LDS reads and
+    // float64 fmas bound it, not the barriers per round; four groups halve the rounds of features with few live pieces)
+    const int ng = C <= 4 ? 4 : 2;
+    lds += (ng * (5 * H + 2 * C) + (ng - 1) * 256) * sizeof(double) + (static_cast<size_t>(a->max_pieces) + 8) * sizeof(int);   // + live pieces
     const dim3 grid(a->F), block(256 * ng);
-    if (C <= 4) hipLaunchKernelGGL((fpwl_grad3_kernel<2, 1>), grid, block, lds, st, p);
+    if (C <= 4) hipLaunchKernelGGL((fpwl_grad3_kernel<4, 1>), grid, block, lds, st, p);
     else if (C <= 8) hipLaunchKernelGGL((fpwl_grad3_kernel<2, 2>), grid, block, lds, st, p);
     else if (C <= 16) hipLaunchKernelGGL((fpwl_grad3_kernel<2, 4>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((fpwl_grad3_kernel<2, 16>), grid, block, lds, st, p);
@@ -455,28 +492,25 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
 
 extern "C" int gnan_fpwl_moment_scales(const gnan_moment_scales_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "fpwl_moment_scales: null args");
-  const float* grad = a->grad;
-  const int64_t n = a->n, grad_stride = a->grad_stride, T = a->T;
-  const int32_t width = a->width, bits = a->bits;
-  const float* anchor = a->anchor;
-  const int32_t* n_anchors = a->n_anchors;
-  const double* x_abs_max = a->x_abs_max;
-  void* workspace = a->workspace;
-  const size_t workspace_bytes = a->workspace_bytes;
-  double* scales = a->scales;
-  GNAN_REQUIRE(n >= 0 && width >= 1 && grad_stride >= width && T >= 0, "fpwl_moment_scales: bad sizes");
-  GNAN_REQUIRE((grad || n == 0) && (anchor || T == 0) && x_abs_max && scales, "fpwl_moment_scales: null pointer");
-  GNAN_REQUIRE(workspace && workspace_bytes >= 2 * sizeof(unsigned), "fpwl_moment_scales: workspace of 8 bytes needed");
-  GNAN_REQUIRE(bits >= 1 && bits <= 62, "fpwl_moment_scales: bits must be in [1, 62]");
+  const int64_t n = a->n, T = a->T;
+  GNAN_REQUIRE(n >= 0 && a->width >= 1 && a->grad_stride >= a->width && T >= 0, "fpwl_moment_scales: bad sizes");
+  GNAN_REQUIRE((a->grad || n == 0) && (a->anchor || T == 0) && a->x_abs_max && a->scales, "fpwl_moment_scales: null pointer");
+  GNAN_REQUIRE(a->workspace && a->workspace_bytes >= GNAN_MOMENT_SCALES_WORKSPACE_BYTES,
+               "fpwl_moment_scales: workspace of GNAN_MOMENT_SCALES_WORKSPACE_BYTES bytes needed");
+  GNAN_REQUIRE(a->bits >= 1 && a->bits <= 62, "fpwl_moment_scales: bits must be in [1, 62]");
+  GNAN_REQUIRE(a->zero_bytes == 0 || (a->zero && a->zero_bytes % 8 == 0 && reinterpret_cast<uintptr_t>(a->zero) % 8 == 0),
+               "fpwl_moment_scales: zero must be 8-byte aligned, zero_bytes a multiple of 8");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  unsigned* b = static_cast<unsigned*>(workspace);
-  hipLaunchKernelGGL(zero_bits_kernel, dim3(1), dim3(1), 0, st, b);
-  if (int rc = gnan::check_launch("zero_bits_kernel")) return rc;
-  const int64_t work = n * width > T ? n * width : T;
+  unsigned* blk = static_cast<unsigned*>(a->workspace);
+  const int64_t zero_words = static_cast<int64_t>(a->zero_bytes / 8);
+  int64_t work = n * a->width > T ? n * a->width : T;
+  work = work > zero_words ? work : zero_words;
   int64_t blocks = (work + 256 * 8 - 1) / (256 * 8);
-  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-  hipLaunchKernelGGL(absmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad, n, width, grad_stride, anchor, T, n_anchors, b);
+  constexpr int64_t kMaxBlocks = GNAN_MOMENT_SCALES_WORKSPACE_BYTES / 8;
+  blocks = blocks < 1 ? 1 : (blocks > kMaxBlocks ? kMaxBlocks : blocks);
+  hipLaunchKernelGGL(absmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a->grad, n, a->width, a->grad_stride,
+                     a->anchor, T, a->n_anchors, blk, static_cast<unsigned long long*>(a->zero), zero_words);
   if (int rc = gnan::check_launch("absmax_kernel")) return rc;
-  hipLaunchKernelGGL(scales_kernel, dim3(1), dim3(1), 0, st, b, x_abs_max, bits, scales);
+  hipLaunchKernelGGL(scales_kernel, dim3(1), dim3(256), 0, st, blk, static_cast<int>(blocks), a->x_abs_max, a->bits, a->scales);
   return gnan::check_launch("scales_kernel");
 }

@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int kCap = 1024;        // breakpoints per feature this kernel can hold
+constexpr int kOverBit = 1 << 30; // on a feature's piece count: the feature ran out of room
 // nodes evaluated per pass (p.chunk): 64 while two [chunk, H] float64 tiles fit next to W2 (H <= 64: 64 x 64 / 4 = one
 // (two nodes, two units) item per thread), else 32; the root search overlaps consecutive passes by one node
 constexpr int kBT = 1024;         // threads of the build workgroup: one workgroup per feature means one wave per SIMD at
@@ -326,10 +327,9 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
       SL[i * C + c] = static_cast<float>(s);
     }
   }
-  if (tid == 0) {
-    p.pieces[k] = pieces;
-    if (over) atomicOr(p.overflow, 1);
-  }
+  // (the overflow flag rides on the feature's piece count and is gathered by pwl_compact_kernel: an atomicOr here needed the
+  // flag zeroed by a launch of its own before every build)
+  if (tid == 0) p.pieces[k] = pieces | (over ? kOverBit : 0);
 }
 
 // Pack the per-feature padded tables back to back: off[k] = pieces[0] + ... + pieces[k-1].
@@ -337,9 +337,10 @@ struct CompactParams {
   const float* anchor_p;   // padded [F, cap+1]
   const float* val_p;      // padded [F, cap+1, C]
   const float* slope_p;
-  const int32_t* pieces;
+  const int32_t* pieces;   // per feature, | kOverBit where the feature ran out of room
   int F, C, cap;
   int32_t* off;            // [F+1]
+  int32_t* overflow;       // [1]: 1 if any feature ran out of room, else 0 (written by the last feature's workgroup)
   float* anchor;           // compact [T], capacity F*(cap+1)
   float* val;
   float* slope;
@@ -348,8 +349,12 @@ struct CompactParams {
 __global__ __launch_bounds__(256) void pwl_compact_kernel(const CompactParams p) {
   __shared__ int red[256];
   const int k = blockIdx.x, tid = threadIdx.x;
-  int s = 0;
-  for (int j = tid; j < k; j += 256) s += p.pieces[j];
+  int s = 0, over = 0;
+  for (int j = tid; j < k; j += 256) {
+    const int v = p.pieces[j];
+    s += v & ~kOverBit;
+    over |= v & kOverBit;
+  }
   red[tid] = s;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
@@ -357,10 +362,15 @@ __global__ __launch_bounds__(256) void pwl_compact_kernel(const CompactParams p)
     __syncthreads();
   }
   const int base = red[0];
-  const int n = p.pieces[k];
+  const int own = p.pieces[k];
+  const int n = own & ~kOverBit;
+  const int any_over = __syncthreads_or(over | (own & kOverBit));
   if (tid == 0) {
     p.off[k] = base;
-    if (k == p.F - 1) p.off[p.F] = base + n;
+    if (k == p.F - 1) {
+      p.off[p.F] = base + n;
+      *p.overflow = any_over ? 1 : 0;
+    }
   }
   const float* a = p.anchor_p + static_cast<int64_t>(k) * (p.cap + 1);
   const float* v = p.val_p + static_cast<int64_t>(k) * (p.cap + 1) * p.C;
@@ -420,7 +430,7 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   CompactParams c;
   c.anchor_p = p.anchor; c.val_p = p.val; c.slope_p = p.slope; c.pieces = p.pieces;
   c.F = a->F; c.C = a->C; c.cap = a->cap;
-  c.off = a->off; c.anchor = a->anchor; c.val = a->val; c.slope = a->slope;
+  c.off = a->off; c.overflow = a->overflow; c.anchor = a->anchor; c.val = a->val; c.slope = a->slope;
   hipLaunchKernelGGL(pwl_compact_kernel, dim3(a->F), dim3(256), 0, st, c);
   return gnan::check_launch("pwl_compact_kernel");
 }

@@ -1141,7 +1141,10 @@ struct GradParams {
   float* dS;             // [n_rows, w_real]
   int64_t ds_stride;
   int with_rest;
-  const float* ds_add;   // optional [w_real]: added to every row of dS (the rest bucket's column-sum term)
+  const float* ds_add;   // optional [w_real]: added to every row of dS (the rest bucket's column-sum term) ...
+  const float* ds_scale; // ... times this device scalar when given (rho(0) = lut[rest]: the caller hands over the bare column sums)
+  const float* rest_total;   // optional [w_real], with rest_q [w_real]: dlut[D - 1] += <rest_total, rest_q> in the final pass
+  const float* rest_q;
   int hot_code_lo, hot_codes;   // spmm_bwd_hot_kernel: packed rows [hot_lo, hot_lo + hot_n) of these code blocks are served from LDS
 };
 
@@ -1178,7 +1181,7 @@ __device__ __forceinline__ void bwd_finish(const Params& p, const GradParams& gp
         ds = fmaf(-p.lut[rest], q, ds);
         pd[rest & 3] = fmaf(-sj, q, pd[rest & 3]);
       }
-      if (gp.ds_add) ds += gp.ds_add[w];
+      if (gp.ds_add) ds += gp.ds_scale ? __fmul_rn(*gp.ds_scale, gp.ds_add[w]) : gp.ds_add[w];
       gp.dS[oq * gp.ds_stride + w] = ds;
     }
   }
@@ -1451,7 +1454,7 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
           ds = fmaf(-p.lut[rest], qv, ds);
           pd[rest & 3] -= static_cast<double>(sj) * qv;
         }
-        if (gp.ds_add) ds += gp.ds_add[w];
+        if (gp.ds_add) ds += gp.ds_scale ? __fmul_rn(*gp.ds_scale, gp.ds_add[w]) : gp.ds_add[w];
         gp.dS[oq * gp.ds_stride + w] = ds;
       }
     } else if (k == 0 && w < p.W) {
@@ -1484,8 +1487,10 @@ __global__ __launch_bounds__(256) void spmm_lut_grad_fixup_kernel(const Params p
 }
 
 // dlut[d] = sum over the workgroup / hub-row partials, fixed order
+// (+ <tot, q> over w floats on entry D - 1 when tot is given: the rest bucket's column-sum term, gnan_spmm_bwd_narrow)
 __global__ __launch_bounds__(1024) void spmm_lut_grad_final_kernel(const double* __restrict__ blk, int64_t n, int D,
-                                                                   float* __restrict__ out) {
+                                                                   float* __restrict__ out, const float* __restrict__ tot = nullptr,
+                                                                   const float* __restrict__ q = nullptr, int w = 0) {
   // one 1024-thread workgroup: a thread adds whole [4] records (32 contiguous bytes), eight loads in flight; the partials
   // meet in a fixed tree.  (Four 256-thread workgroups walking 72k records of a 10M-node graph one by one took 95 us.)
   __shared__ double red[4][1024];
@@ -1517,7 +1522,12 @@ __global__ __launch_bounds__(1024) void spmm_lut_grad_final_kernel(const double*
       for (int d = 0; d < 4; ++d) red[d][threadIdx.x] += red[d][threadIdx.x + st];
     __syncthreads();
   }
-  if (static_cast<int>(threadIdx.x) < D && threadIdx.x < 4) out[threadIdx.x] = static_cast<float>(red[threadIdx.x][0]);
+  if (static_cast<int>(threadIdx.x) < D && threadIdx.x < 4) {
+    double v = red[threadIdx.x][0];
+    if (tot && static_cast<int>(threadIdx.x) == D - 1)
+      for (int c = 0; c < w; ++c) v = fma(static_cast<double>(tot[c]), static_cast<double>(q[c]), v);
+    out[threadIdx.x] = static_cast<float>(v);
+  }
 }
 
 template <int VEC, int LPR, bool BWD = false>
@@ -1534,7 +1544,8 @@ int launch_lut_grad(const Params& p, GradParams gp, hipStream_t st, float* dlut)
     if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
   }
   if (gp.reduce_rows) {
-    hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(1), dim3(1024), 0, st, gp.blk, row_blocks + p.n_long, p.D, dlut);
+    hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(1), dim3(1024), 0, st, gp.blk, row_blocks + p.n_long, p.D, dlut, gp.rest_total,
+                       gp.rest_q, gp.w_real);
     return gnan::check_launch("spmm_lut_grad_final_kernel");
   }
   return GNAN_OK;
@@ -1747,7 +1758,8 @@ int launch_bwd_hot(const Params& p, GradParams gp, hipStream_t st, float* dlut) 
     hipLaunchKernelGGL(spmm_lut_grad_fixup_kernel<true>, dim3(static_cast<unsigned>((p.n_long + 3) / 4)), dim3(256), 0, st, p, gp);
     if (int rc = gnan::check_launch("spmm_lut_grad_fixup_kernel")) return rc;
   }
-  hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(1), dim3(1024), 0, st, gp.blk, gp.n_row_blocks + p.n_long, p.D, dlut);
+  hipLaunchKernelGGL(spmm_lut_grad_final_kernel, dim3(1), dim3(1024), 0, st, gp.blk, gp.n_row_blocks + p.n_long, p.D, dlut,
+                     gp.rest_total, gp.rest_q, gp.w_real);
   return gnan::check_launch("spmm_lut_grad_final_kernel");
 }
 
@@ -1940,7 +1952,7 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* g, gnan_stream_
   pick_tiling(a, static_cast<const float*>(a->S), a->s_stride, &vec, &lpr);
   GradParams gp;
   gp.dY = dY; gp.dy_stride = dy_stride; gp.dy_channels = dy_channels; gp.dwt = dwt; gp.reduce_rows = reduce_rows;
-  gp.ds_add = nullptr;
+  gp.ds_add = nullptr; gp.ds_scale = nullptr; gp.rest_total = nullptr; gp.rest_q = nullptr; gp.w_real = 0;
   gp.slice_T = static_cast<float*>(workspace);
   size_t off = a->n_long > 0 ? static_cast<size_t>(a->n_slices) * 4 * static_cast<size_t>(a->W) * sizeof(float) : 0;
   off = (off + 15) / 16 * 16;   // the final reduction reads 16-byte halves of the [4] records
@@ -2038,6 +2050,8 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* g, gnan_str
   if (a->W < 2 || a->W > 64 || (a->W & (a->W - 1)) != 0 || w_real < 1 || w_real > half || a->s_stride != a->W)
     return gnan::fail(GNAN_ERR_UNSUPPORTED, "bwd_narrow: operand rows must be 2 * half floats, half a power of two in [w_real, 32] (got W=%d, w_real=%d)", a->W, w_real);
   GNAN_REQUIRE(s_rows_stride >= w_real && ds_stride >= w_real, "bwd_narrow: row stride smaller than the width");
+  GNAN_REQUIRE((g->rest_total == nullptr) == (g->rest_q == nullptr), "bwd_narrow: rest_total and rest_q come together");
+  GNAN_REQUIRE(g->rest_total == nullptr || with_rest, "bwd_narrow: rest_total without a rest bucket");
   if (a->n_rows == 0) {
     hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, st, dlut, a->D);
     return gnan::check_launch("zero_floats_kernel");
@@ -2058,6 +2072,8 @@ extern "C" int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* g, gnan_str
   gp.n_row_blocks = 0;
   gp.s_rows = s_rows; gp.s_rows_stride = s_rows_stride; gp.half = half; gp.w_real = w_real;
   gp.dS = dS; gp.ds_stride = ds_stride; gp.with_rest = with_rest; gp.ds_add = g->ds_add;
+  gp.ds_scale = g->ds_add ? g->ds_add_scale : nullptr;
+  gp.rest_total = g->rest_total; gp.rest_q = g->rest_q;
   gp.hot_code_lo = 0; gp.hot_codes = 0;
   if (bwd_hot_applies(a)) {
     // one-channel operands over a packed index stream: the persistent kernel, with the head of the appended hot rows in LDS

@@ -318,14 +318,16 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
             x_abs_max = x.abs().max().double()
         # scales[0] = 2^floor(bits - log2 max|grad|), scales[1] = 2^floor(bits - log2(max|grad| max|x - anchor|)):
         # one pass over the gradient on the device (gnan_fpwl_moment_scales), no host round trip
-        scales = torch.empty(3, dtype=torch.float64, device=x.device)        # [2] scales | 8 bytes of workspace
+        ws_words = _lib.MOMENT_SCALES_WORKSPACE_BYTES // 8
+        scales = torch.empty(2 + ws_words, dtype=torch.float64, device=x.device)        # [2] scales | the pass's workspace
+        Mi = torch.empty((T, 2, C), dtype=torch.int64, device=x.device)                  # (cleared by the same pass)
         # (tables captured into a hipGraph sit in a buffer of full capacity: only the first off[F] anchors are real)
         sa = _lib.MomentScalesArgs(grad=_lib.ptr(grad), n=n, width=grad.shape[1], bits=bits, grad_stride=grad.stride(0),
                                    anchor=_lib.ptr(t.anchor), T=T, n_anchors=_lib.ptr(t.off[F:]), x_abs_max=_lib.ptr(x_abs_max),
-                                   workspace=_lib.ptr(scales[2:]), workspace_bytes=8, scales=_lib.ptr(scales))
+                                   workspace=_lib.ptr(scales[2:]), workspace_bytes=_lib.MOMENT_SCALES_WORKSPACE_BYTES,
+                                   scales=_lib.ptr(scales), zero=_lib.ptr(Mi), zero_bytes=Mi.numel() * 8)
         _lib.check(_lib.lib().gnan_fpwl_moment_scales(sa, _lib.stream_of(x)), "gnan_fpwl_moment_scales")
         scales = scales[:2]
-        Mi = torch.zeros((T, 2, C), dtype=torch.int64, device=x.device)
         if located and len(located) == 1 and not rows:          # one channel: the forward's pieces, one byte per look-up
             a.piece_in = _lib.ptr(located[0])
         if rows:
@@ -752,6 +754,7 @@ class _FeatureMLPs(torch.autograd.Function):
         ctx.save_for_backward(x, *[t for t in params if t is not None])
         ctx.present = [t is not None for t in params]
         ctx.grad_dests = _grad_dests_of(params)
+        ctx.set_materialize_grads(False)      # (the non-differentiable column sums would get a zero-filled gradient: a launch)
         needs_grad = any(ctx.needs_input_grad[9:]) and not ctx.needs_input_grad[0]
         if needs_grad and out_dtype != torch.float32:
             raise _lib.GnanHipError("bf16 operand storage is an inference format: no backward pass")
@@ -780,6 +783,8 @@ class _FeatureMLPs(torch.autograd.Function):
         x = saved.pop(0)
         params = [saved.pop(0) if present else None for present in ctx.present]
         located, ctx.located = ctx.located, None
+        if grad_out is None:                  # nothing downstream used the values
+            return (None,) * (9 + len(params))
         gx, pg = _shape_function_grads(x, params, ctx.present, ctx.tables, grad_out, sum_features, L, H, C, F, ctx.x_abs_max,
                                        located, ctx.needs_input_grad[0], dests=ctx.grad_dests)
         return (gx, None, None, None, None, None, None, None, None, *pg)

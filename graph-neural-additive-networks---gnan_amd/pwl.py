@@ -288,7 +288,7 @@ def table_buffers(p):
     T = F * (cap + 1)
     need = _lib.lib().gnan_pwl_build_scratch_bytes(F, C, cap)
     return (torch.empty(T, dtype=torch.float32, device=dev), torch.empty((T, C), dtype=torch.float32, device=dev),
-            torch.empty((T, C), dtype=torch.float32, device=dev), torch.zeros(F + 2, dtype=torch.int32, device=dev),
+            torch.empty((T, C), dtype=torch.float32, device=dev), torch.empty(F + 2, dtype=torch.int32, device=dev),
             torch.empty(need // 8 + 1, dtype=torch.float64, device=dev))
 
 
@@ -301,9 +301,7 @@ def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0, buffers=None)
     F, C = p.F, p.C
     cap = min(1024, max(64, 4 * p.H) * (p.L - 1))
     if buffers is None:
-        buffers = table_buffers(p)
-    else:
-        buffers[3].zero_()                                            # off[F+1] | overflow start from zero
+        buffers = table_buffers(p)                                    # (off[F+1] | overflow: every entry is written by the build)
     anchor, val, slope, meta, scratch = buffers
     keepalive = [t if t is None else t.detach().float().contiguous() for t in p[:6]]
     w_mid = keepalive[2][0] if keepalive[2] is not None else None      # [1, F, H, H] -> [F, H, H]

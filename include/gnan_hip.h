@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 42
+#define GNAN_ABI_VERSION 43
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -264,7 +264,11 @@ int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32_t* piece, 
  * capacity) is not NULL —, x_abs_max one double in DEVICE memory (max |x| of the feature matrix) and
  * bits = 61 - ceil(log2 n), so that n terms cannot overflow 62 bits (values above 50 are treated as 50: the kernels
  * convert a term with one fused multiply-add onto 1.5 * 2^52, exact below 2^51).
- * workspace: 8 bytes.  One pass over grad + a single-thread kernel; no host round trip. */
+ * workspace: GNAN_MOMENT_SCALES_WORKSPACE_BYTES bytes (a pair of maxima per workgroup of the pass; nothing to initialise).
+ * zero / zero_bytes (optional): a buffer the same pass sets to zero — the int64 moment accumulators the following
+ * gnan_fpwl_moments_fixed adds into (a separate fill launch otherwise).  One pass over grad + a one-workgroup kernel; no
+ * host round trip. */
+#define GNAN_MOMENT_SCALES_WORKSPACE_BYTES 8192
 typedef struct gnan_moment_scales_args {
   const float* grad;         /* [n, width], row stride grad_stride */
   int64_t n;
@@ -275,9 +279,11 @@ typedef struct gnan_moment_scales_args {
   int64_t T;
   const int32_t* n_anchors;  /* optional device pointer: only the first *n_anchors anchors are real */
   const double* x_abs_max;   /* device scalar max |x| */
-  void* workspace;           /* >= 8 bytes */
+  void* workspace;           /* >= GNAN_MOMENT_SCALES_WORKSPACE_BYTES bytes, 4-byte aligned */
   size_t workspace_bytes;
   double* scales;            /* [2] out */
+  void* zero;                /* optional: zero_bytes bytes (8-byte aligned, a multiple of 8) set to zero by the same pass */
+  size_t zero_bytes;
 } gnan_moment_scales_args;
 int gnan_fpwl_moment_scales(const gnan_moment_scales_args* a, gnan_stream_t stream);
 
@@ -331,7 +337,7 @@ typedef struct gnan_pwl_build_args {
   float* val;             /* [F*(cap+1), C] */
   float* slope;           /* [F*(cap+1), C] */
   int32_t* off;           /* [F+1] */
-  int32_t* overflow;      /* [1], zeroed by the caller */
+  int32_t* overflow;      /* [1]: written 0 / 1 by every build (nothing to initialise) */
   void* scratch;          /* gnan_pwl_build_scratch_bytes(F, C, cap) */
   size_t scratch_bytes;
 } gnan_pwl_build_args;
@@ -878,6 +884,10 @@ typedef struct gnan_spmm_bwd_narrow_args {
                                 wt(i, rest) * total term is the same for every j (the caller forms it from the packed rows) */
   int32_t hot_code_lo;       /* with spmm.hot_rows > 0: first code block whose hot rows sit in LDS ... */
   int32_t hot_codes;         /* ... and how many blocks (>= 1) */
+  const float* ds_add_scale; /* optional device scalar: ds_add is multiplied by it on the way (rho(0) = lut[D - 1]: the caller then
+                                passes the bare column sums of the packed rows' rest halves — a framework launch less) */
+  const float* rest_total;   /* optional [w_real], with rest_q [w_real]: dlut[D - 1] += <rest_total, rest_q>, the table gradient */
+  const float* rest_q;       /*   of the same term (float64, in the final pass) — three framework launches less */
 } gnan_spmm_bwd_narrow_args;
 size_t gnan_spmm_bwd_narrow_workspace_bytes(const gnan_spmm_bwd_narrow_args* a);
 int gnan_spmm_bwd_narrow(const gnan_spmm_bwd_narrow_args* a, gnan_stream_t stream);

@@ -95,7 +95,7 @@ def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None):
     return V.permute(1, 0, 2).contiguous()                      # code-major [D, n, 2 * half]
 
 
-def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None, ds_add=None):
+def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None, ds_add=None, rest_q=None, rest_total=None, add_to_rows=False):
     D = lut.numel()
     half = V.shape[1] // 2
     row_of_pair, col, code = _pairs(gt)                     # rows of gt = nodes as neighbours; col = the forward row listing them
@@ -114,6 +114,10 @@ def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None, ds_add=None):
         dl[rest] = -(Sd * Q).sum()
     if ds_add is not None:
         ds += ds_add.detach().double().reshape(1, -1)
+    if rest_q is not None and add_to_rows:
+        ds += (l[rest].float() * rest_q.detach().float()).double().reshape(1, -1)
+    if rest_q is not None and rest_total is not None:
+        dl[rest] += (rest_total.detach().double().reshape(-1) * rest_q.detach().double().reshape(-1)).sum()
     return ds.float(), dl.float()
 
 

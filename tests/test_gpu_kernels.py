@@ -289,10 +289,11 @@ def test_table_lookup_matches_matrix_core_kernel_at_scale(monkeypatch):
     assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())
 
 
-@pytest.mark.parametrize("n,W", [(1, 1), (1000, 7), (4097, 64), (300_000, 64), (50_000, 3)])
+@pytest.mark.parametrize("n,W", [(1, 1), (1000, 7), (4097, 64), (300_000, 64), (50_000, 3), (169_343, 1), (8191, 4), (8193, 2),
+                                 (2_000_000, 1), (262_145, 4)])
 def test_column_sums(n, W):
     from gnan_amd.functional import column_sums
-    S = torch.randn(n, W, generator=torch.Generator().manual_seed(n)).to(DEV)
+    S = torch.randn(n, W + 1, generator=torch.Generator().manual_seed(n)).to(DEV)[:, :W]      # (strided rows)
     got = column_sums(S).cpu().double()
     want = S.cpu().double().sum(0)
     assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(S.abs().sum(0).max()))
@@ -709,13 +710,16 @@ def test_moment_scales_kernel(n, width, gscale):
     anchor = (torch.randn(300, generator=torch.Generator().manual_seed(1)) * 5).to(DEV)
     xmax = torch.tensor(3.25, dtype=torch.float64, device=DEV)
     bits = 61 - max(1, (max(n, 2) - 1).bit_length())
-    out = torch.empty(3, dtype=torch.float64, device=DEV)
+    ws = _lib.MOMENT_SCALES_WORKSPACE_BYTES
+    out = torch.empty(2 + ws // 8, dtype=torch.float64, device=DEV)
+    cleared = torch.full((1000,), 7, dtype=torch.int64, device=DEV)              # the moment accumulators: zeroed by the same pass
     padded = torch.cat([anchor, torch.full((50,), float("inf"), device=DEV)])     # a buffer of full capacity: the tail is not data
     n_real = torch.tensor([anchor.numel()], dtype=torch.int32, device=DEV)
     a = _lib.MomentScalesArgs(grad=_lib.ptr(g), n=n, width=width, bits=bits, grad_stride=g.stride(0), anchor=_lib.ptr(padded),
                               T=padded.numel(), n_anchors=_lib.ptr(n_real), x_abs_max=_lib.ptr(xmax), workspace=_lib.ptr(out[2:]),
-                              workspace_bytes=8, scales=_lib.ptr(out))
+                              workspace_bytes=ws, scales=_lib.ptr(out), zero=_lib.ptr(cleared), zero_bytes=999 * 8)
     _lib.check(_lib.lib().gnan_fpwl_moment_scales(a, _lib.stream_of(g)), "gnan_fpwl_moment_scales")
+    assert int(cleared[:999].abs().sum()) == 0 and int(cleared[999]) == 7
     tiny = torch.finfo(torch.float64).tiny
     g_max = g.abs().max().double().clamp_min(tiny)
     d_max = (xmax + anchor.abs().max().double()).clamp_min(tiny)
@@ -727,7 +731,12 @@ def test_moment_scales_kernel(n, width, gscale):
     gn[n // 2, 0] = float("nan")
     a = _lib.MomentScalesArgs(grad=_lib.ptr(gn), n=n, width=width, bits=bits, grad_stride=gn.stride(0), anchor=_lib.ptr(anchor),
                               T=anchor.numel(), n_anchors=None, x_abs_max=_lib.ptr(xmax), workspace=_lib.ptr(out[2:]),
-                              workspace_bytes=8, scales=_lib.ptr(out))
+                              workspace_bytes=ws, scales=_lib.ptr(out))
+    _lib.check(_lib.lib().gnan_fpwl_moment_scales(a, _lib.stream_of(g)), "gnan_fpwl_moment_scales")
+    assert bool(torch.isnan(out[:2]).all())
+    a.workspace_bytes = 8                                                        # too small a workspace is refused, not overrun
+    assert _lib.lib().gnan_fpwl_moment_scales(a, _lib.stream_of(g)) != 0
+    a.workspace_bytes = ws
     _lib.check(_lib.lib().gnan_fpwl_moment_scales(a, _lib.stream_of(g)), "gnan_fpwl_moment_scales")
     assert bool(torch.isnan(out[:2]).all())
 
