@@ -40,6 +40,7 @@ struct Params {
   int64_t total_rows;    // column sums cover nodes [0, total_rows) only
   int max_pieces;        // largest piece count of one feature
   int max_group_pieces;  // largest piece count of one feature group
+  int piece_stride;      // fpwl_moments_c1_kernel over kept pieces: bins of piece j of the group's feature f at [j * FG + f] (even, >= max_pieces)
   int soff_offset;       // fpwl_fast_kernel: float offset of its group-offset array in dynamic LDS
   int acc_offset;        // > 0 (sum over features, C > 1): float offset in dynamic LDS of the [C][NODES] accumulators;
                          // the workgroup then owns ONE pass of nodes and walks all feature groups for them
@@ -742,15 +743,19 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
   const int nf = RAGGED ? (p.F - k0 < FG ? p.F - k0 : FG) : FG;       // live features of the group (see fpwl_fast_kernel)
   const int base = p.off[k0];
   const int tot = p.off[k0 + nf] - base;
-  unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + kTreeWords);   // [2][tot]
+  const bool saved = p.piece_in != nullptr;          // (uniform) the forward pass kept the pieces: no trees, no search
+  const bool kept = !RAGGED && saved && (SUMF || mp.vec_g);   // ... and the loop below bins them piece-major, from offset 0
+  const int PM = p.piece_stride;
+  unsigned long long* bins = reinterpret_cast<unsigned long long*>(smem + (kept ? 0 : kTreeWords));   // [2][tot] | [2][PM][FG]
   int* s_off = reinterpret_cast<int*>(smem) + p.soff_offset;
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
   if (tid <= FG) s_off[tid] = p.off[k0 + (tid < nf ? tid : nf)] - base;
-  for (int i = tid; i < 2 * tot; i += BS) bins[i] = 0ull;
+  for (int i = tid; i < (kept ? 2 * FG * PM : 2 * tot); i += BS) bins[i] = 0ull;
   __syncthreads();
-  const bool saved = p.piece_in != nullptr;          // (uniform) the forward pass kept the pieces: no trees, no search
-  if (saved) {
+  if (kept) {
+    // nothing to stage: the anchors are read once per piece at the flush, from memory
+  } else if (saved) {
     for (int i = tid; i < tot; i += BS) smem[i] = p.anchor[base + i];       // anchors in piece order (tot <= FG * P2)
   } else {
     for (int i = tid; i < FG * P2; i += BS) {
@@ -786,45 +791,88 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
       // x / gradient / pieces are requested before this round's atomics (unconditional loads from a clamped address — a
       // guarded load hides the loads in flight from the compiler, which then waits for all of them).
       int64_t n = n_lo + nl;
+      const int rot = nl & 3;
       if (n < n_hi) {
         const int64_t last = n_hi - 1;
         const uint8_t* pin = p.piece_in + static_cast<int64_t>(grp) * p.n * FG + q * FPT;
         const float* xin = p.x + k0 + q * FPT;
         const float* gin = SUMF ? mp.g : mp.g + k0 + q * FPT;
-        float4 cx = *reinterpret_cast<const float4*>(xin + n * p.x_stride);
-        unsigned cp = *reinterpret_cast<const unsigned*>(pin + n * FG);
-        float4 cg;
-        if constexpr (SUMF) { cg.x = gin[n * mp.g_stride]; cg.y = cg.z = cg.w = cg.x; }
-        else cg = *reinterpret_cast<const float4*>(gin + n * mp.g_stride);
-        for (; n < n_hi; n += NODES) {
-          const int64_t nn = n + NODES < n_hi ? n + NODES : last;
-          const float4 nx = *reinterpret_cast<const float4*>(xin + nn * p.x_stride);
-          const unsigned np = *reinterpret_cast<const unsigned*>(pin + nn * FG);
-          float4 ng;
-          if constexpr (SUMF) { ng.x = gin[nn * mp.g_stride]; ng.y = ng.z = ng.w = ng.x; }
-          else ng = *reinterpret_cast<const float4*>(gin + nn * mp.g_stride);
+        struct Round { float4 x; unsigned pc; float4 g; };
+        // unconditional loads from a clamped node (see above); three rounds are in flight, each in registers of its own: a
+        // "next = far" hand-over at the end of the loop body made every iteration wait for the loads it had just issued
+        auto fetch = [&](int64_t m) {
+          m = m < n_hi ? m : last;
+          Round rd;
+          rd.x = *reinterpret_cast<const float4*>(xin + m * p.x_stride);
+          rd.pc = *reinterpret_cast<const unsigned*>(pin + m * FG);
+          if constexpr (SUMF) { rd.g.x = gin[m * mp.g_stride]; rd.g.y = rd.g.z = rd.g.w = rd.g.x; }
+          else rd.g = *reinterpret_cast<const float4*>(gin + m * mp.g_stride);
+          return rd;
+        };
+        auto bin = [&](const Round& rd) {
+          const float4 cx = rd.x, cg = rd.g;
+          const unsigned cp = rd.pc;
           const float xv[FPT] = {cx.x, cx.y, cx.z, cx.w};
           const float gv[FPT] = {cg.x, cg.y, cg.z, cg.w};
+          // Two things keep the lanes of one wave-wide atomic apart (72 % of the LDS-active cycles were bank conflicts,
+          // profiles/r04f_sq_train.txt; real data sits in a handful of pieces per feature, and atomics that meet in a bank pair —
+          // on one address or not — are served one after the other):
+          //  * issue slot s takes feature r = (s + node) % 4 of the thread's quad, so an instruction spreads over the bins of all
+          //    FG features, 64 / FG nodes each, instead of four features x sixteen nodes (4.36 -> 4.16 ms per C4 training step);
+          //  * the bins are piece-major, [piece][feature]: a feature owns the bank pairs f and f + 16 whatever pieces its nodes
+          //    fall into, so lanes of different features never meet (conflict cycles 1.7e8 -> 9e6 per launch).
+          // Integer adds: the sums are the same bit for bit.  With the conflicts gone the loop is bound by its vector
+          // instructions: the rotation selects x (32 bits) before the product, the piece by a variable bit-field extract,
+          // and g * 2^e1 is formed once per node (a power of two: the fused multiply-add rounds the same real number).
+          double gs1 = 0.0;
           unsigned long long t0 = 0ull;
-          if constexpr (SUMF) t0 = fixed_bits(gv[0], s0);
-#pragma unroll
-          for (int f = 0; f < FPT; ++f) {
-            const int idx = binoff[f] + P2 + static_cast<int>((cp >> (8 * f)) & 0xffu);
-            if constexpr (!SUMF) t0 = fixed_bits(gv[f], s0);
-            atomicAdd(bins + idx, t0);
-            atomicAdd(bins + tot + idx, fixed_bits_d(static_cast<double>(gv[f]) * static_cast<double>(xv[f]), s1));
+          if constexpr (SUMF) {
+            gs1 = static_cast<double>(gv[0]) * s1;
+            t0 = fixed_bits(gv[0], s0);
           }
-          cx = nx; cp = np; cg = ng;
+#pragma unroll
+          for (int s = 0; s < FPT; ++s) {
+            const int r = (s + rot) & 3;
+            const bool odd = (r & 1) != 0, up = (r & 2) != 0;      // (two selects by the bits of r: a chain of r == k tests
+            const float xlo = odd ? xv[1] : xv[0], xhi = odd ? xv[3] : xv[2];   //  is lowered to a switch with branches)
+            const float xr = up ? xhi : xlo;
+            const int ix = static_cast<int>(__builtin_amdgcn_ubfe(cp, 8u * static_cast<unsigned>(r), 8u)) * FG + (q * FPT + r);
+            unsigned long long v0 = t0;
+            double gr = gs1;
+            if constexpr (!SUMF) {
+              const float glo = odd ? gv[1] : gv[0], ghi = odd ? gv[3] : gv[2];
+              const float gsel = up ? ghi : glo;
+              v0 = fixed_bits(gsel, s0);
+              gr = static_cast<double>(gsel) * s1;
+            }
+            const double d = fma(gr, static_cast<double>(xr), 6755399441055744.0);
+            const unsigned long long v1 = static_cast<unsigned long long>(__double_as_longlong(d)) - 0x4338000000000000ull;
+            atomicAdd(bins + ix, v0);
+            atomicAdd(bins + FG * PM + ix, v1);
+          }
+        };
+        Round ra = fetch(n), rb = fetch(n + NODES), rc = fetch(n + 2 * NODES);
+        for (; n < n_hi; n += 3 * NODES) {
+          bin(ra);
+          ra = fetch(n + 3 * NODES);
+          if (n + NODES < n_hi) bin(rb);
+          rb = fetch(n + 4 * NODES);
+          if (n + 2 * NODES < n_hi) bin(rc);
+          rc = fetch(n + 5 * NODES);
         }
       }
       __syncthreads();
       unsigned long long* out = mp.Mi + static_cast<int64_t>(base) * 2;      // [T][2]
       const double ratio = s1 / s0;
       for (int i = tid; i < tot; i += BS) {
-        const long long m0 = static_cast<long long>(bins[i]), m1x = static_cast<long long>(bins[tot + i]);
+        int f = 0;
+#pragma unroll
+        for (int k = 1; k < FG; ++k) f += s_off[k] <= i ? 1 : 0;              // the feature of piece i (s_off ascending)
+        const int b = (i - s_off[f]) * FG + f;
+        const long long m0 = static_cast<long long>(bins[b]), m1x = static_cast<long long>(bins[FG * PM + b]);
         if (m0 != 0 || m1x != 0) {
           // (float64: relative error 2^-53 of |a sum g| per workgroup and piece — the same in every run: the node blocks are fixed)
-          const long long m1 = m1x - __double2ll_rn(static_cast<double>(smem[i]) * static_cast<double>(m0) * ratio);
+          const long long m1 = m1x - __double2ll_rn(static_cast<double>(p.anchor[base + i]) * static_cast<double>(m0) * ratio);
           if (m0 != 0) atomicAdd(out + 2 * i, static_cast<unsigned long long>(m0));
           if (m1 != 0) atomicAdd(out + 2 * i + 1, static_cast<unsigned long long>(m1));
         }
@@ -882,16 +930,24 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
         }
       }
     }
-    unsigned long long t0 = 0ull;
-    if constexpr (SUMF) t0 = fixed_bits(gv[0], s0);
+    int idx[FPT];
+    unsigned long long t0[FPT], t1[FPT];
 #pragma unroll
     for (int f = 0; f < FPT; ++f) {
-      const int piece = binoff[f] + ((a[f] - Q) >> 2);
-      if constexpr (!SUMF) t0 = fixed_bits(gv[f], s0);
-      const float m1 = gv[f] * (xv[f] - last[f]);
-      if (!RAGGED || live[f]) {
-        atomicAdd(bins + piece, t0);
-        atomicAdd(bins + tot + piece, fixed_bits(m1, s1));
+      idx[f] = (!RAGGED || live[f]) ? binoff[f] + ((a[f] - Q) >> 2) : -1;
+      t0[f] = fixed_bits(gv[SUMF ? 0 : f], s0);
+      t1[f] = fixed_bits(gv[f] * (xv[f] - last[f]), s1);
+    }
+    const int rot = nl & 3;                            // (issue slots rotated over the quad's features: see the kept-pieces loop)
+#pragma unroll
+    for (int s = 0; s < FPT; ++s) {
+      const int r = (s + rot) & 3;
+      const int ix = r == 0 ? idx[0] : (r == 1 ? idx[1] : (r == 2 ? idx[2] : idx[3]));
+      const unsigned long long v0 = SUMF ? t0[0] : (r == 0 ? t0[0] : (r == 1 ? t0[1] : (r == 2 ? t0[2] : t0[3])));
+      const unsigned long long v1 = r == 0 ? t1[0] : (r == 1 ? t1[1] : (r == 2 ? t1[2] : t1[3]));
+      if (!RAGGED || ix >= 0) {
+        atomicAdd(bins + ix, v0);
+        atomicAdd(bins + tot + ix, v1);
       }
     }
   }
@@ -909,6 +965,9 @@ int launch_moments_c1(MomentParams mp, hipStream_t st) {
   Params& p = mp.f;
   const size_t pieces = static_cast<size_t>(p.max_group_pieces);
   size_t lds = ((static_cast<size_t>(FG) << NSTEP) + (FG / 4) * kTreeSkew) * sizeof(float) + pieces * 2 * sizeof(unsigned long long);
+  p.piece_stride = (p.max_pieces + 1) & ~1;
+  if (!RAGGED && p.piece_in != nullptr && (p.sum_features || mp.vec_g))    // kept pieces: piece-major bins from offset 0, no trees
+    lds = static_cast<size_t>(2) * FG * p.piece_stride * sizeof(unsigned long long);
   p.soff_offset = static_cast<int>(lds / sizeof(float));
   lds += (FG + 1) * sizeof(int);
   if (lds > 150 * 1024) return -1;                       // caller falls back to the general kernels
