@@ -980,8 +980,14 @@ def main():
         if grouped:
             dist.barrier()
 
+    # The warm-up steps are the timed steps to the letter — events recorded, the previous step's output still held while the
+    # next one runs — so that the caching allocator has reached the timed loop's steady state before the clock starts: with
+    # `step(False)` and the result dropped, the first TIMED step could find its 2.56-GB operand block carved up for the kept
+    # output and ask the driver for a fresh one (hipMalloc of 2.56 GB: 0.4 s on a loaded host, i.e. +20 ms on each of 20 steps).
+    out = None
     for _ in range(args.warmup):
-        step(False)
+        out = step(True)
+    events.clear()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

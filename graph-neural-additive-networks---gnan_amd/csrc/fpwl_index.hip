@@ -357,23 +357,46 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
     const int64_t xstep = static_cast<int64_t>(NODES) * p.x_stride;
     const float* xp = xq + (n_lo + nl) * p.x_stride;
     auto row = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr <= xlast ? ptr : xlast); };
-    float4 cur[U], nxt[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = row(xp + u * xstep);
     const bool add_before = SUM && !split && g > g_lo;   // feature sum over several groups inside the workgroup: read-modify-write of the output
-    for (int64_t n = n_lo + nl; n < n_hi; n += U * NODES) {
+    // Two buffers of U rows take turns (A: even rounds, B: odd ones), each reloaded in place right after its look-ups: a
+    // "current = next" hand-over at the end of the loop body made every iteration wait for the rows it had just requested.
+    // The earlier groups' sums of a round's nodes are requested one half-iteration ahead, BEFORE the rows that follow, and
+    // unconditionally (from the row's own x when there is nothing to add): loads retire in order, so a look-up that waits for
+    // its sum waits for everything requested before it and for nothing requested after it — behind the next rows (or behind a
+    // guard the compiler cannot count through) the sums made the look-ups wait for the very prefetch they should overlap with.
+    float4 bufA[U], bufB[U];
+    float bvA[U], bvB[U];
+    auto rows = [&](float4 (&buf)[U], const float* from) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) nxt[u] = row(xp + (U + u) * xstep);
-      xp += U * xstep;
+      for (int u = 0; u < U; ++u) buf[u] = row(from + u * xstep);
+    };
+    auto befores = [&](float (&bv)[U], const int64_t nn) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bv[u] = 0.f;
+        if constexpr (SUM) {                         // (per-feature rows: nothing is ever added to)
+          const int64_t m = nn + u * NODES < n_hi ? nn + u * NODES : n_hi - 1;
+          bv[u] = *(add_before ? p.out + m * p.out_stride : xq + m * p.x_stride);
+        }
+      }
+    };
+    auto round = [&](const int64_t nn, const float4 (&buf)[U], const float (&bv)[U]) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (n + u * NODES < n_hi) {
-          // (requesting the earlier groups' sum a round ahead, next to the x row, was tried in round 5: 14 more registers, same time)
-          const float before = (add_before && q == 0) ? p.out[(n + u * NODES) * p.out_stride] : 0.f;
-          look_up(n + u * NODES, cur[u], before);
-        }
-#pragma unroll
-      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        if (nn + u * NODES < n_hi) look_up(nn + u * NODES, buf[u], add_before ? bv[u] : 0.f);
+    };
+    int64_t n = n_lo + nl;
+    rows(bufA, xp);
+    befores(bvA, n);
+    rows(bufB, xp + U * xstep);
+    for (; n < n_hi; n += 2 * U * NODES) {
+      befores(bvB, n + U * NODES);
+      round(n, bufA, bvA);
+      rows(bufA, xp + 2 * U * xstep);
+      befores(bvA, n + 2 * U * NODES);
+      round(n + U * NODES, bufB, bvB);
+      rows(bufB, xp + 3 * U * xstep);
+      xp += 2 * U * xstep;
     }
     if constexpr (!SUM) {
       if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64 (as fpwl_fast_kernel)
