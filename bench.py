@@ -448,7 +448,7 @@ def run_c3(args):
                                                   "gnan_amd.replay)"},
         "fwd_ms": fwd_ms, "fwd_ms_min": fwd_min, "fwd_bwd_ms": fb_ms, "fwd_bwd_ms_min": fb_min,
         "fwd_edges_per_s": E / (fwd_ms / 1e3),
-        "roofline": {"bound": "hbm", "kernel": "fpwl_fast_kernel (shape-function look-up, feature sum)",
+        "roofline": {"bound": "hbm", "kernel": "fpwl_index_kernel (shape-function look-up, feature sum; + sum_groups_kernel)",
                      "achieved": b_fmlp / (stages["fmlp"] / 1e3) / 1e9 if stages["fmlp"] > 0 else 0.0, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": b_fmlp / (stages["fmlp"] / 1e3) / 1e9 / HBM_PEAK_GBPS if stages["fmlp"] > 0 else 0.0,
                      "traffic": None, "algorithmic_bytes_per_launch": b_fmlp, "avg_launch_ms": stages["fmlp"],

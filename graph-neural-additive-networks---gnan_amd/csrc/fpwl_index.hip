@@ -364,39 +364,58 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
     // unconditionally (from the row's own x when there is nothing to add): loads retire in order, so a look-up that waits for
     // its sum waits for everything requested before it and for nothing requested after it — behind the next rows (or behind a
     // guard the compiler cannot count through) the sums made the look-ups wait for the very prefetch they should overlap with.
-    float4 bufA[U], bufB[U];
-    float bvA[U], bvB[U];
-    auto rows = [&](float4 (&buf)[U], const float* from) {
+    if constexpr (SUM) {
+      float4 bufA[U], bufB[U];
+      float bvA[U], bvB[U];
+      auto rows = [&](float4 (&buf)[U], const float* from) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) buf[u] = row(from + u * xstep);
-    };
-    auto befores = [&](float (&bv)[U], const int64_t nn) {
+        for (int u = 0; u < U; ++u) buf[u] = row(from + u * xstep);
+      };
+      auto befores = [&](float (&bv)[U], const int64_t nn) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        bv[u] = 0.f;
-        if constexpr (SUM) {                         // (per-feature rows: nothing is ever added to)
-          const int64_t m = nn + u * NODES < n_hi ? nn + u * NODES : n_hi - 1;
-          bv[u] = *(add_before ? p.out + m * p.out_stride : xq + m * p.x_stride);
+        for (int u = 0; u < U; ++u) {
+          bv[u] = 0.f;
+          if constexpr (SUM) {                         // (per-feature rows: nothing is ever added to)
+            const int64_t m = nn + u * NODES < n_hi ? nn + u * NODES : n_hi - 1;
+            bv[u] = *(add_before ? p.out + m * p.out_stride : xq + m * p.x_stride);
+          }
         }
-      }
-    };
-    auto round = [&](const int64_t nn, const float4 (&buf)[U], const float (&bv)[U]) {
+      };
+      auto round = [&](const int64_t nn, const float4 (&buf)[U], const float (&bv)[U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (nn + u * NODES < n_hi) look_up(nn + u * NODES, buf[u], add_before ? bv[u] : 0.f);
-    };
-    int64_t n = n_lo + nl;
-    rows(bufA, xp);
-    befores(bvA, n);
-    rows(bufB, xp + U * xstep);
-    for (; n < n_hi; n += 2 * U * NODES) {
-      befores(bvB, n + U * NODES);
-      round(n, bufA, bvA);
-      rows(bufA, xp + 2 * U * xstep);
-      befores(bvA, n + 2 * U * NODES);
-      round(n + U * NODES, bufB, bvB);
-      rows(bufB, xp + 3 * U * xstep);
-      xp += 2 * U * xstep;
+        for (int u = 0; u < U; ++u)
+          if (nn + u * NODES < n_hi) look_up(nn + u * NODES, buf[u], add_before ? bv[u] : 0.f);
+      };
+      int64_t n = n_lo + nl;
+      rows(bufA, xp);
+      befores(bvA, n);
+      rows(bufB, xp + U * xstep);
+      for (; n < n_hi; n += 2 * U * NODES) {
+        befores(bvB, n + U * NODES);
+        round(n, bufA, bvA);
+        rows(bufA, xp + 2 * U * xstep);
+        befores(bvA, n + 2 * U * NODES);
+        round(n + U * NODES, bufB, bvB);
+        rows(bufB, xp + 3 * U * xstep);
+        xp += 2 * U * xstep;
+      }
+    } else {
+      // per-feature rows: the plain hand-over loop.  This mode sits at its copy pattern's ceiling (0.97 ms on C4) and the
+      // two-buffer form measured SLOWER here (tools/lookup_ab.py: rows 1.03 -> 1.07 ms, bf16 rows 0.875 -> 0.95 — twice the
+      // code per iteration, nothing to gain from more loads in flight)
+      float4 cur[U], nxt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = row(xp + u * xstep);
+      for (int64_t n = n_lo + nl; n < n_hi; n += U * NODES) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = row(xp + (U + u) * xstep);
+        xp += U * xstep;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (n + u * NODES < n_hi) look_up(n + u * NODES, cur[u], 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      }
     }
     if constexpr (!SUM) {
       if (p.col_partial) {   // fixed-order workgroup reduction: NODES node slots per feature, float64 (as fpwl_fast_kernel)
