@@ -131,6 +131,46 @@ __global__ __launch_bounds__(256) void fmlp_lane_kernel(const Params p) {
     for (int c = 0; c < C; ++c) p.out[node * p.out_stride + c] = sacc[c * kWave];
 }
 
+// fmlp_point_kernel (2 <= L <= 3 with H <= 64; a handful of evaluations): ONE WAVE per (node, feature), lane = hidden unit.
+// The rho table of a truncated-hop graph is rho at three points, asked for on every training step: the matrix-core route
+// packs the weights first (two launches, 9 + 7 us) and the lane kernel walks the H x H layer in ONE lane (70 us).  Here the
+// wave holds a layer in its lanes: layer 1 is one fused multiply-add per lane, layer 2 a lane's own row of W2 (sixteen
+// 16-byte loads) against the layer-1 values handed round by v_readlane, the C outputs a fixed butterfly each.  Sums in
+// float32 like the other two kernels (another order: the three agree to a few ulp, tests/test_gpu_kernels.py).
+__global__ __launch_bounds__(64) void fmlp_point_kernel(const Params p) {
+  const int lane = threadIdx.x;
+  const int64_t node = blockIdx.x / p.F;
+  const int k = static_cast<int>(blockIdx.x - node * p.F);
+  const int H = p.H, C = p.C;
+  const float xv = p.x[node * p.x_stride + k];
+  const bool on = lane < H;
+  float h = 0.f;
+  if (on) h = fmaxf(fmaf(xv, p.w_first[k * H + lane], p.b_first ? p.b_first[k * H + lane] : 0.f), 0.f);
+  if (p.L == 3) {
+    const float* row = p.w_mid + (static_cast<int64_t>(k) * H + (on ? lane : 0)) * H;     // W2[k][lane][:]
+    float acc = (on && p.b_mid) ? p.b_mid[k * H + lane] : 0.f;
+    if ((H & 3) == 0 && (reinterpret_cast<uintptr_t>(p.w_mid) & 15) == 0) {
+      for (int i = 0; i < H; i += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(row + i);
+        acc = fmaf(w.x, __shfl(h, i), acc);
+        acc = fmaf(w.y, __shfl(h, i + 1), acc);
+        acc = fmaf(w.z, __shfl(h, i + 2), acc);
+        acc = fmaf(w.w, __shfl(h, i + 3), acc);
+      }
+    } else {
+      for (int i = 0; i < H; ++i) acc = fmaf(row[i], __shfl(h, i), acc);
+    }
+    h = on ? fmaxf(acc, 0.f) : 0.f;
+  }
+  float* out = p.out + node * p.out_stride + (p.sum_features ? 0 : static_cast<int64_t>(k) * C);
+  for (int c = 0; c < C; ++c) {
+    float v = on ? p.w_last[(static_cast<int64_t>(k) * C + c) * H + lane] * h : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) out[c] = v + (p.b_last ? p.b_last[k * C + c] : 0.f);
+  }
+}
+
 // =============================================================================================
 // MFMA path
 // =============================================================================================
@@ -459,8 +499,14 @@ Params make_params(const gnan_fmlp_args* a) {
 
 }  // namespace
 
+// a handful of evaluations under AUTO (no Dropout; with the feature sum only for a single feature): fmlp_point_kernel
+static bool point_route(const gnan_fmlp_args* a) {
+  return a->algo == GNAN_FMLP_AUTO && a->n * static_cast<int64_t>(a->F) <= 64 && (a->L == 2 || a->L == 3) && a->H >= 1 && a->H <= 64 &&
+         !(a->dropout_p > 0.f) && (!a->sum_features || a->F == 1);
+}
+
 extern "C" size_t gnan_fmlp_fwd_workspace_bytes(const gnan_fmlp_args* a) {
-  if (!a || a->algo == GNAN_FMLP_LANE) return 0;
+  if (!a || a->algo == GNAN_FMLP_LANE || point_route(a)) return 0;
   const Params p = make_params(a);
   MfmaShape s;
   if (!mfma_shape(p, &s) || p.drop_thresh != 0u) return 0;
@@ -487,6 +533,10 @@ extern "C" int gnan_fmlp_fwd(const gnan_fmlp_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "fmlp: dropout_p must be in [0, 1)");
   const Params p = make_params(a);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (point_route(a)) {
+    hipLaunchKernelGGL(fmlp_point_kernel, dim3(static_cast<unsigned>(a->n * a->F)), dim3(64), 0, st, p);
+    return gnan::check_launch("fmlp_point_kernel");
+  }
   MfmaShape shape;
   const bool can_mfma = mfma_shape(p, &shape) && p.drop_thresh == 0u;        // Dropout: lane kernel
   if (a->algo == GNAN_FMLP_MFMA && p.drop_thresh != 0u)

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(BS) void fpwl_moments_fast_kernel(const MomentParam
 // together), the anchor of the piece is the last tree entry the search stepped right at (one v_cndmask per step, no
 // anchor array in LDS: 50 KB per workgroup, three workgroups = 6 waves per SIMD), the bins are two arrays [2][tot]
 // (8-byte stride: the 64-bit atomics of a wave spread over all banks; interleaved (M0, M1) pairs used every other
-// bank pair), a conversion is fixed_bits() and the workgroup map is the forward's (the groups of a node block run back
+// bank pair; over the forward's kept pieces: piece-major, round 5), a conversion is fixed_bits() and the workgroup map is the forward's (the groups of a node block run back
 // to back on one XCD and share the 128-B lines of x in its L2).  SUMF: the gradient is [n, 1] (feature sum) and its M0
 // term is converted once per node; otherwise [n, F] and read as one 16-byte load next to x.
 template <int FG, int NSTEP, int BS, bool SUMF, bool RAGGED = false>
@@ -787,9 +787,10 @@ __global__ __launch_bounds__(BS) void fpwl_moments_c1_kernel(const MomentParams 
       // The forward kept the pieces: no search.  Binned here are sum g and sum g * x (the product exact in float64) — two LDS
       // atomics per look-up and NOTHING the wave has to wait for (reading the piece's anchor first put an LDS round trip in
       // front of every pair of atomics: the LDS pipe sat idle 40 % of the time, profiles/r04_sq_train.txt); the anchor enters
-      // once per piece and workgroup, when the bins are flushed: M1 = sum g (x - a) = sum g x - a sum g.  The NEXT round's
-      // x / gradient / pieces are requested before this round's atomics (unconditional loads from a clamped address — a
-      // guarded load hides the loads in flight from the compiler, which then waits for all of them).
+      // once per piece and workgroup, when the bins are flushed: M1 = sum g (x - a) = sum g x - a sum g.  The x / gradient /
+      // pieces of the next TWO rounds are in flight while a round is binned (unconditional loads from a clamped address — a
+      // guarded load hides the loads in flight from the compiler, which then waits for all of them).  In this branch the bins
+      // are piece-major, [2][piece_stride][FG] from LDS offset 0 (no trees, no anchors in LDS): see the loop.
       int64_t n = n_lo + nl;
       const int rot = nl & 3;
       if (n < n_hi) {

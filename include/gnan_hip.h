@@ -76,7 +76,8 @@ typedef struct gnan_fmlp_args {
   int32_t sum_features;
   float* out;            /* [n, out_stride] */
   int64_t out_stride;
-  int32_t algo;          /* gnan_fmlp_algo; AUTO picks the matrix-core kernel when the shape allows */
+  int32_t algo;          /* gnan_fmlp_algo; AUTO picks the matrix-core kernel when the shape allows, and for n * F <= 64
+                            evaluations (L in {2, 3}, H <= 64, no Dropout) a wave per evaluation: no workspace then */
   void* workspace;       /* packed weights for the matrix-core kernel, 16-byte aligned */
   size_t workspace_bytes;
   float dropout_p;       /* > 0: training-mode Dropout behind every hidden ReLU (GNAN.py:28,32), kept units scaled by    */

@@ -76,6 +76,41 @@ def test_feature_mlps_vs_oracle(F, L, H, C, bias, sum_features, algo, monkeypatc
     assert e_build <= max(1e-5, e_ref), (e_build, e_ref)
 
 
+@pytest.mark.parametrize("n,F,L,H,C,bias,sum_features", [
+    (3, 1, 3, 64, 1, True, False), (3, 1, 3, 64, 1, False, True), (64, 1, 3, 64, 7, True, False), (5, 1, 2, 64, 3, True, False),
+    (4, 1, 3, 33, 2, True, False), (2, 16, 3, 16, 4, False, False), (1, 64, 3, 64, 1, True, False), (7, 1, 3, 8, 40, True, True),
+])
+def test_a_handful_of_evaluations_take_the_point_kernel(n, F, L, H, C, bias, sum_features):
+    """n * F <= 64 evaluations under AUTO (rho on the D hop codes of a truncated graph, on every training step): one wave per
+    (node, feature), lane = hidden unit (fmlp_point_kernel) — against the float64 oracle and against the lane kernel, with
+    gradients through the same route (gnan_fmlp_bwd)."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    sd = _mlp_state(F, L, H, C, bias, seed=n * 10 + F)
+    x = (torch.rand(n, F, generator=torch.Generator().manual_seed(n)) * 2 - 0.5)
+    truth = O.feature_mlps(x.double(), {k: v.double() for k, v in sd.items()})
+    ref32 = O.feature_mlps(x, sd)
+    truth, ref32 = (truth.sum(1), ref32.sum(1)) if sum_features else (truth.reshape(n, -1), ref32.reshape(n, -1))
+    st = _stack(sd, F, L, H, C, bias)
+    assert _lib.lib().gnan_fmlp_fwd_workspace_bytes is not None
+    leaves = [None if t is None else t.to(DEV).requires_grad_(True) for t in st[:6]]
+    y = feature_mlps(x.to(DEV), functional.StackedMLP(*leaves, *st[6:]), sum_features)
+    e_build, e_ref = O.rel_err(y.detach().cpu(), truth), O.rel_err(ref32, truth)
+    assert e_build <= max(1e-5, e_ref), (e_build, e_ref)
+    y.square().sum().backward()
+    functional.FMLP_ALGO = _lib.FMLP_LANE
+    try:
+        leaves2 = [None if t is None else t.detach().clone().requires_grad_(True) for t in leaves]
+        y2 = feature_mlps(x.to(DEV), functional.StackedMLP(*leaves2, *st[6:]), sum_features)
+        y2.square().sum().backward()
+    finally:
+        functional.FMLP_ALGO = _lib.FMLP_AUTO
+    assert float((y - y2).abs().max()) <= 1e-5 * max(1e-30, float(y2.abs().max()))
+    for a, b in zip(leaves, leaves2):
+        if a is not None:
+            assert float((a.grad - b.grad).abs().max()) <= 2e-5 * max(1e-30, float(b.grad.abs().max()))
+
+
 def _random_csr(n_rows, n_cols, K, rng, hubs=()):
     deg = rng.poisson(6, n_rows)
     deg[rng.random(n_rows) < 0.1] = 0                    # empty rows
