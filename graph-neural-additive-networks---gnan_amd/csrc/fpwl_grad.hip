@@ -385,16 +385,26 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
   const int64_t total = n * width;
   if (off_end && *off_end < T) T = *off_end;       // tables held in a buffer of full capacity: only off[F] anchors are real
   float m = 0.f, ma = 0.f;
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+  const int64_t step = static_cast<int64_t>(gridDim.x) * 256;
+  int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (width == stride) {                         // dense rows: eight loads in flight per thread (one at a time: 22 us for 40 MB)
+    for (; e + 7 * step < total; e += 8 * step) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = fabsf(g[e + u * step]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = (t[u] > m || t[u] != t[u]) ? t[u] : m;
+    }
+  }
+  for (; e < total; e += step) {
     const float v = fabsf(width == stride ? g[e] : g[(e / width) * stride + e % width]);
     m = (v > m || v != v) ? v : m;
   }
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < T; e += static_cast<int64_t>(gridDim.x) * 256) {
-    const float v = fabsf(anchor[e]);
+  for (int64_t a = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; a < T; a += step) {
+    const float v = fabsf(anchor[a]);
     ma = (v > ma || v != v) ? v : ma;
   }
-  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < zero_words; e += static_cast<int64_t>(gridDim.x) * 256)
-    zero[e] = 0ull;
+  for (int64_t z = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; z < zero_words; z += step) zero[z] = 0ull;
   unsigned u = __float_as_uint(m), ua = __float_as_uint(ma);
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned o = __shfl_xor(u, off), oa = __shfl_xor(ua, off);

@@ -1967,8 +1967,8 @@ namespace {
 __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restrict__ dY, int64_t dy_stride, int W,
                                                             const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
                                                             int64_t n, int with_rest, float* __restrict__ V, int half,
-                                                            const int64_t* __restrict__ hot, int64_t n_hot) {
-  for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < n + n_hot; o += static_cast<int64_t>(gridDim.x) * 256) {
+                                                            const int64_t* __restrict__ hot, int64_t n_hot, int64_t o_begin) {
+  for (int64_t o = o_begin + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < n + n_hot; o += static_cast<int64_t>(gridDim.x) * 256) {
     const int64_t i = o < n ? o : hot[o - n];         // packed rows [n, n + n_hot): second copies of the nodes hot[]
     float r_rest = 1.f;
     if (cnt) {
@@ -1993,6 +1993,53 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
     }
   }
 }
+
+// One-channel gradients (half == 1: packed rows of two floats) with shell counts and at most four codes — the shape of every
+// sum-first training step: thread = TWO consecutive nodes, so that a node pair's counts are three 8-byte loads, its gradients
+// one, and its packed rows of a code ONE 16-byte store (the one-node form above moves the 10M-node graph's 400 MB at 2.9 TB/s:
+// 4- and 8-byte accesses).  Covers the nodes [0, n_pairs * 2); the tail and the hot copies go through the kernel above.
+template <int D>
+__global__ __launch_bounds__(256) void pack_bwd_pairs_kernel(const float* __restrict__ dY, const int32_t* __restrict__ cnt,
+                                                             int64_t n, int64_t n_pairs, int with_rest, float* __restrict__ V,
+                                                             const int64_t* __restrict__ hot, int64_t n_hot, int pair_blocks) {
+  const int64_t rows_per_code = n + n_hot;
+  if (static_cast<int>(blockIdx.x) >= pair_blocks) {
+    // the odd last node and the second copies of the nodes hot[] — in the SAME launch, next to the streaming part (a launch of
+    // their own: 35 us behind the pairs' 61 on the 10M-node graph)
+    const int64_t o = 2 * n_pairs + (static_cast<int64_t>(blockIdx.x) - pair_blocks) * 256 + threadIdx.x;
+    if (o >= rows_per_code) return;
+    const int64_t i = o < n ? o : hot[o - n];
+    const float g = dY[i];
+    int k[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) k[d] = cnt[i * D + d];
+    const float q = with_rest ? g / static_cast<float>(k[D - 1] > 1 ? k[D - 1] : 1) : 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      *reinterpret_cast<float2*>(V + (static_cast<int64_t>(d) * rows_per_code + o) * 2) =
+          make_float2(g / static_cast<float>(k[d] > 1 ? k[d] : 1), q);
+    return;
+  }
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_pairs; t += static_cast<int64_t>(pair_blocks) * 256) {
+    const float2 g = *reinterpret_cast<const float2*>(dY + 2 * t);
+    int k[2 * D];                                         // (the pair's 2 D counts start 8-byte aligned whatever D is)
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int2 c = *reinterpret_cast<const int2*>(cnt + 2 * D * t + 2 * u);
+      k[2 * u] = c.x; k[2 * u + 1] = c.y;
+    }
+    float r[2][D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      r[0][d] = static_cast<float>(k[d] > 1 ? k[d] : 1);
+      r[1][d] = static_cast<float>(k[D + d] > 1 ? k[D + d] : 1);
+    }
+    const float q0 = with_rest ? g.x / r[0][D - 1] : 0.f, q1 = with_rest ? g.y / r[1][D - 1] : 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      *reinterpret_cast<float4*>(V + (static_cast<int64_t>(d) * rows_per_code + 2 * t) * 2) = make_float4(g.x / r[0][d], q0, g.y / r[1][d], q1);
+  }
+}
 }  // namespace
 
 extern "C" int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_stream_t stream) {
@@ -2008,10 +2055,29 @@ extern "C" int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_st
   GNAN_REQUIRE(dy_stride >= W && (cnt == nullptr || cnt_stride >= D), "pack_bwd_rows: row stride smaller than the width");
   GNAN_REQUIRE(n_hot >= 0 && (n_hot == 0 || hot != nullptr), "pack_bwd_rows: n_hot without hot");
   if (n == 0) return GNAN_OK;
-  int64_t blocks = (n + n_hot + 255) / 256;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t o_begin = 0;
+  // node pairs (large graphs): needs the packed rows of every code to start 16-byte aligned ((n + n_hot) even) and dense inputs
+  if (half == 1 && W == 1 && cnt != nullptr && cnt_stride == D && dy_stride == 1 && D >= 2 && D <= 4 && n >= (int64_t(1) << 20) && (n + n_hot) % 2 == 0 &&
+      reinterpret_cast<uintptr_t>(dY) % 8 == 0 && reinterpret_cast<uintptr_t>(cnt) % 8 == 0 && reinterpret_cast<uintptr_t>(V) % 16 == 0) {
+    const int64_t n_pairs = n / 2;
+    int64_t pb = (n_pairs + 255) / 256;
+    pb = pb > 65536 ? 65536 : pb;
+    const int64_t tail = n + n_hot - 2 * n_pairs;
+    const int64_t tb = (tail + 255) / 256;
+    if (tb < (int64_t(1) << 20)) {
+      const dim3 grid(static_cast<unsigned>(pb + tb)), block(256);
+      const int pbi = static_cast<int>(pb);
+      if (D == 2) hipLaunchKernelGGL(pack_bwd_pairs_kernel<2>, grid, block, 0, st, dY, cnt, n, n_pairs, with_rest, V, hot, n_hot, pbi);
+      else if (D == 3) hipLaunchKernelGGL(pack_bwd_pairs_kernel<3>, grid, block, 0, st, dY, cnt, n, n_pairs, with_rest, V, hot, n_hot, pbi);
+      else hipLaunchKernelGGL(pack_bwd_pairs_kernel<4>, grid, block, 0, st, dY, cnt, n, n_pairs, with_rest, V, hot, n_hot, pbi);
+      return gnan::check_launch("pack_bwd_pairs_kernel");
+    }
+  }
+  int64_t blocks = (n + n_hot - o_begin + 255) / 256;
   blocks = blocks > 65536 ? 65536 : blocks;
-  hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot);
+  hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
+                     dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot, o_begin);
   return gnan::check_launch("pack_bwd_rows_kernel");
 }
 

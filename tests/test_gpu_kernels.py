@@ -325,14 +325,15 @@ def test_table_lookup_matches_matrix_core_kernel_at_scale(monkeypatch):
 
 
 @pytest.mark.parametrize("n,W", [(1, 1), (1000, 7), (4097, 64), (300_000, 64), (50_000, 3), (169_343, 1), (8191, 4), (8193, 2),
-                                 (2_000_000, 1), (262_145, 4)])
+                                 (2_000_000, 1), (262_145, 4), (65_539, 1), (1_000_001, 1)])
 def test_column_sums(n, W):
     from gnan_amd.functional import column_sums
     S = torch.randn(n, W + 1, generator=torch.Generator().manual_seed(n)).to(DEV)[:, :W]      # (strided rows)
-    got = column_sums(S).cpu().double()
-    want = S.cpu().double().sum(0)
-    assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(S.abs().sum(0).max()))
-    assert torch.equal(column_sums(S), column_sums(S))          # fixed reduction order
+    for S in (S, S.contiguous()):
+        got = column_sums(S).cpu().double()
+        want = S.cpu().double().sum(0)
+        assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(S.abs().sum(0).max()))
+        assert torch.equal(column_sums(S), column_sums(S))          # fixed reduction order
 
 
 @pytest.mark.parametrize("W,cr", [(1, 0), (1, 1), (8, 0), (8, 2), (24, 0), (24, 4), (64, 0), (64, 1), (320, 0), (320, 4)])
@@ -1106,6 +1107,26 @@ def test_packed_backward_rows_kernel(W, D, use_cnt, with_rest):
     ids = torch.from_numpy(rng.integers(0, n, 37)).to(DEV)                 # second copies of 37 nodes behind the n real rows
     Vh = pack_bwd_rows(dY, cnt, D, with_rest, half, hot=ids)
     assert Vh.shape == (D, n + 37, 2 * half) and torch.equal(Vh[:, :n], V) and torch.equal(Vh[:, n:], V[:, ids])
+
+
+@pytest.mark.parametrize("n,D,with_rest,n_hot", [(1 << 20, 3, True, 0), ((1 << 20) + 2, 3, True, 38), ((1 << 20) + 1, 3, True, 37),
+                                                   (1 << 20, 2, False, 16), (1 << 20, 4, True, 0), ((1 << 20) + 1, 3, True, 0)])
+def test_packed_backward_rows_of_large_one_channel_graphs(n, D, with_rest, n_hot):
+    """From 2^20 nodes on, one-channel gradients with shell counts are packed two nodes per thread (pack_bwd_pairs_kernel: 8-byte
+    count loads, 16-byte stores) when every code's block starts 16-byte aligned, the odd tail and the hot copies by the one-node
+    kernel: same bits as the slicing restatement either way (odd n + n_hot: the one-node kernel alone)."""
+    from gnan_amd.functional import pack_bwd_rows
+    import cpu_kernels
+    rng = np.random.default_rng(n % 1000 + D)
+    dY = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
+    cnt = torch.from_numpy(rng.integers(0, 50, (n, D)).astype(np.int32)).to(DEV)
+    ids = torch.from_numpy(rng.integers(0, n, n_hot)).to(DEV) if n_hot else None
+    V = pack_bwd_rows(dY, cnt, D, with_rest, 1, hot=ids)
+    want = cpu_kernels.pack_bwd_rows(dY.cpu(), cnt.cpu(), D, with_rest, 1)
+    assert V.shape == (D, n + n_hot, 2)
+    assert torch.equal(V[:, :n].cpu(), want)
+    if n_hot:
+        assert torch.equal(V[:, n:], V[:, ids])
 
 
 @pytest.mark.parametrize("W,K,with_rest", [(1, 1, True), (2, 2, True), (4, 1, False)])
