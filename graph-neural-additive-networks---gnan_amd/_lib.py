@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -48,6 +48,7 @@ class FpwlArgs(C.Structure):
         ("total_rows", C.c_int64), ("piece_out", C.c_void_p), ("piece_in", C.c_void_p), ("flags", C.c_int32),
         ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32),
         ("sum_workspace", C.c_void_p), ("sum_workspace_bytes", C.c_size_t),
+        ("sum_total", C.c_void_p), ("sum_total_workspace", C.c_void_p), ("sum_total_workspace_bytes", C.c_size_t),
     ]
 
 
@@ -146,7 +147,8 @@ class PackBwdRowsArgs(C.Structure):
     _fields_ = [
         ("dY", C.c_void_p), ("dy_stride", C.c_int64), ("W", C.c_int32), ("D", C.c_int32), ("cnt", C.c_void_p),
         ("cnt_stride", C.c_int64), ("n", C.c_int64), ("with_rest", C.c_int32), ("half", C.c_int32), ("V", C.c_void_p),
-        ("hot", C.c_void_p), ("n_hot", C.c_int64),
+        ("hot", C.c_void_p), ("n_hot", C.c_int64), ("q_sum", C.c_void_p), ("q_workspace", C.c_void_p),
+        ("q_workspace_bytes", C.c_size_t),
     ]
 
 
@@ -321,6 +323,7 @@ SYMBOLS = {
     "gnan_spmm_lut_grad_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmLutGradArgs)]),
     "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmLutGradArgs), C.c_void_p]),
     "gnan_spmm_pack_bwd_rows": (C.c_int, [C.POINTER(PackBwdRowsArgs), C.c_void_p]),
+    "gnan_spmm_pack_bwd_rows_workspace_bytes": (C.c_size_t, [C.POINTER(PackBwdRowsArgs)]),
     "gnan_spmm_bwd_narrow_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmBwdNarrowArgs)]),
     "gnan_spmm_bwd_narrow": (C.c_int, [C.POINTER(SpmmBwdNarrowArgs), C.c_void_p]),
     "gnan_colsum_workspace_bytes": (C.c_size_t, [C.c_int32]),

@@ -237,10 +237,11 @@ NARROW_BWD_PERSISTENT = True   # ... one channel: packed index, persistent workg
 
 
 def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_rest: bool, half: int,
-                  hot: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  hot: Optional[torch.Tensor] = None, want_q_sum: bool = False):
     """``V[d, i] = [dY_i / cnt(i, d) | dY_i / cnt(i, D-1)]`` (code-major ``[D, n (+ hot), 2 * half]``), halves zero padded to
     ``half`` floats (``gnan_spmm_pack_bwd_rows``); with ``hot`` (node ids) the rows of those nodes are repeated behind the n
-    real ones of every code block: ``V[d, n + k] = V[d, hot[k]]``."""
+    real ones of every code block: ``V[d, n + k] = V[d, hot[k]]``.  ``want_q_sum`` (one channel, rest bucket): returns
+    ``(V, q_sum [1])`` with ``q_sum = sum_i dY_i / cnt(i, D-1)`` over the n real nodes, out of the same pass."""
     _lib.require_device(dY)
     dY = Fn._rows(dY.detach().float())
     n, W = dY.shape
@@ -251,8 +252,17 @@ def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_re
     pa = _lib.PackBwdRowsArgs(dY=_lib.ptr(dY), dy_stride=dY.stride(0), W=W, D=D, cnt=_lib.ptr(c),
                               cnt_stride=0 if c is None else c.stride(0), n=n, with_rest=int(with_rest), half=half,
                               V=_lib.ptr(V), hot=_lib.ptr(h), n_hot=k)
+    q_sum = None
+    if want_q_sum:
+        if W != 1 or not with_rest:
+            raise ValueError("pack_bwd_rows: q_sum is the one-channel rest-bucket sum")
+        q_sum = torch.empty(1, dtype=torch.float32, device=dY.device)
+        pa.q_sum = _lib.ptr(q_sum)
+        need = _lib.lib().gnan_spmm_pack_bwd_rows_workspace_bytes(pa)
+        ws = torch.empty(max(1, need // 8), dtype=torch.float64, device=dY.device)      # (alive until the launch is queued)
+        pa.q_workspace, pa.q_workspace_bytes = _lib.ptr(ws), ws.numel() * 8
     _lib.check(_lib.lib().gnan_spmm_pack_bwd_rows(pa, _lib.stream_of(dY)), "gnan_spmm_pack_bwd_rows")
-    return V
+    return (V, q_sum) if want_q_sum else V
 
 
 def narrow_walk(g: HopGraph):
@@ -397,11 +407,15 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
         half = 1 << max(0, (W - 1).bit_length())
         walk = narrow_walk(g.transposed())
-        V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
         q_sum = total = None
+        if with_rest and W == 1:                            # ... and their rest halves' column sum out of the same pass
+            V, q_sum = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2], want_q_sum=True)
+        else:
+            V = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2])  # [D, n (+ hot), 2 * half]
         add_to_rows = False
         if with_rest:
-            q_sum = Fn.column_sums(V[0, :g.n_rows, half:half + W])                            # sum_i dY_i / cnt(i, rest)
+            if q_sum is None:
+                q_sum = Fn.column_sums(V[0, :g.n_rows, half:half + W])                        # sum_i dY_i / cnt(i, rest)
             # d/dS_j of  wt(i, rest) * total : the same vector rho(0) * q_sum for every j — added by the kernel's epilogue
             add_to_rows = rest_added = ctx.total_group is NOT_SHARED and ctx.total_rows is None
             # d/d lut[rest] of the same term: <total, q_sum> — added by the kernel's final pass

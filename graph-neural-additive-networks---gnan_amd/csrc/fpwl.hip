@@ -1520,6 +1520,8 @@ extern "C" int gnan_fpwl_fwd(const gnan_fpwl_args* a, gnan_stream_t stream) {
     }
     return GNAN_OK;
   }
+  if (a->sum_total)
+    return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl: sum_total is written by the group-split direct-index feature sum only");
   const size_t lds = static_cast<size_t>(a->max_group_pieces) * (1 + 2 * static_cast<size_t>(table_stride(a->C))) * sizeof(float);
   Params p = base_params(a);
   auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };

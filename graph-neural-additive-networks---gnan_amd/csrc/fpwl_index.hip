@@ -436,13 +436,40 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
 }
 
 // out[n] = ((part[0][n] + part[1][n]) + part[2][n]) + ... : the association of the in-workgroup walk (bit-identical sums)
+// `col_partial` (optional): col_partial[blockIdx.x] = the workgroup's sum of out over the rows below total_rows (float64, fixed
+// tree) — the rest bucket's column sum out of this pass instead of a gnan_colsum over the result (gnan_fpwl_args.sum_total).
 __global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict__ part, int n_groups, int64_t n,
-                                                         float* __restrict__ out, int64_t out_stride) {
+                                                         float* __restrict__ out, int64_t out_stride,
+                                                         double* __restrict__ col_partial, int64_t total_rows) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = part[i];
-  for (int g = 1; g < n_groups; ++g) s = s + part[static_cast<int64_t>(g) * n + i];
-  out[i * out_stride] = s;
+  float s = 0.f;
+  if (i < n) {
+    s = part[i];
+    for (int g = 1; g < n_groups; ++g) s = s + part[static_cast<int64_t>(g) * n + i];
+    out[i * out_stride] = s;
+  }
+  if (col_partial == nullptr) return;
+  __shared__ double red[256];
+  red[threadIdx.x] = i < total_rows ? static_cast<double>(s) : 0.0;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) col_partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sum_total_final_kernel(const double* __restrict__ partial, int64_t n_partial, float* __restrict__ total) {
+  double s = 0.0;
+  for (int64_t b = threadIdx.x; b < n_partial; b += 256) s += partial[b];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = static_cast<float>(red[0]);
 }
 
 int cu_count_() {
@@ -607,10 +634,28 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
   int rc;
   if (pl.fg == 32) rc = pl.bs == 1024 ? by_kf(I32{}, S1024{}) : by_kf(I32{}, S512{});
   else rc = by_kf(I16{}, S512{});
-  if (rc != GNAN_OK || !pl.split) return rc;
-  hipLaunchKernelGGL(sum_groups_kernel, dim3(static_cast<unsigned>((a->n + 255) / 256)), dim3(256), 0, st, p.part, p.n_groups, p.n,
-                     p.out, p.out_stride);
-  return gnan::check_launch("sum_groups_kernel");
+  if (rc != GNAN_OK) return rc;
+  if (!pl.split) {
+    if (a->sum_total) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_index: sum_total is written by the group-split feature sum only (sum_workspace)");
+    return rc;
+  }
+  const int64_t sb = (a->n + 255) / 256;
+  double* tot_partial = nullptr;
+  if (a->sum_total) {
+    if (a->sum_total_workspace == nullptr || a->sum_total_workspace_bytes < static_cast<size_t>(sb) * sizeof(double) ||
+        reinterpret_cast<uintptr_t>(a->sum_total_workspace) % 8 != 0)
+      return gnan::fail(GNAN_ERR_WORKSPACE, "fpwl_index: sum_total workspace %zu B < required %zu B (8-byte aligned)",
+                        a->sum_total_workspace_bytes, static_cast<size_t>(sb) * sizeof(double));
+    tot_partial = static_cast<double*>(a->sum_total_workspace);
+  }
+  hipLaunchKernelGGL(sum_groups_kernel, dim3(static_cast<unsigned>(sb)), dim3(256), 0, st, p.part, p.n_groups, p.n,
+                     p.out, p.out_stride, tot_partial, p.total_rows);
+  if (int rc2 = gnan::check_launch("sum_groups_kernel")) return rc2;
+  if (tot_partial) {
+    hipLaunchKernelGGL(sum_total_final_kernel, dim3(1), dim3(256), 0, st, tot_partial, sb, a->sum_total);
+    return gnan::check_launch("sum_total_final_kernel");
+  }
+  return GNAN_OK;
 }
 
 // bytes of gnan_fpwl_args.sum_workspace this call would use (0: none): what index_plan's split needs

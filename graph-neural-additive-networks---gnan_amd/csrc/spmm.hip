@@ -1962,12 +1962,41 @@ extern "C" int gnan_spmm_lut_grad(const gnan_spmm_lut_grad_args* g, gnan_stream_
 }
 
 namespace {
+// partial[blockIdx.x] = the sum of `v` over the 256 threads of the workgroup (fixed tree, float64) — EVERY thread calls it.
+__device__ __forceinline__ void block_sum_to(double v, double* __restrict__ partial) {
+  __shared__ double red[256];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// q_sum[0] = sum of the workgroups' partials (one workgroup, fixed order): sum_i dY_i / cnt(i, rest), what gnan_colsum over the
+// packed rows' second halves returned — two launches and a strided 40-MB read on the 10M-node graph
+__global__ __launch_bounds__(256) void pack_q_final_kernel(const double* __restrict__ partial, int64_t n_partial, float* __restrict__ q_sum) {
+  double s = 0.0;
+  for (int64_t b = threadIdx.x; b < n_partial; b += 256) s += partial[b];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) q_sum[0] = static_cast<float>(red[0]);
+}
+
 // V[d * n + i, :] = [ dY_i / cnt(i, d) | dY_i / cnt(i, D-1) ]  (the packed operand of gnan_spmm_bwd_narrow), zero padded.
 // Thread = node: its gradient row and counts are read once, its D packed rows are one contiguous run of the output.
 __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restrict__ dY, int64_t dy_stride, int W,
                                                             const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
                                                             int64_t n, int with_rest, float* __restrict__ V, int half,
-                                                            const int64_t* __restrict__ hot, int64_t n_hot, int64_t o_begin) {
+                                                            const int64_t* __restrict__ hot, int64_t n_hot, int64_t o_begin,
+                                                            double* __restrict__ q_partial) {
+  double qs = 0.0;                                    // q_partial (W == 1): this thread's sum of dY_i / cnt(i, rest) over REAL nodes
   for (int64_t o = o_begin + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < n + n_hot; o += static_cast<int64_t>(gridDim.x) * 256) {
     const int64_t i = o < n ? o : hot[o - n];         // packed rows [n, n + n_hot): second copies of the nodes hot[]
     float r_rest = 1.f;
@@ -1991,7 +2020,9 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
         out[half + w] = with_rest ? g / r_rest : 0.f;
       }
     }
+    if (q_partial && with_rest && o < n) qs += static_cast<double>(dY[i * dy_stride] / r_rest);
   }
+  if (q_partial) block_sum_to(qs, q_partial);
 }
 
 // One-channel gradients (half == 1: packed rows of two floats) with shell counts and at most four codes — the shape of every
@@ -2001,23 +2032,28 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
 template <int D>
 __global__ __launch_bounds__(256) void pack_bwd_pairs_kernel(const float* __restrict__ dY, const int32_t* __restrict__ cnt,
                                                              int64_t n, int64_t n_pairs, int with_rest, float* __restrict__ V,
-                                                             const int64_t* __restrict__ hot, int64_t n_hot, int pair_blocks) {
+                                                             const int64_t* __restrict__ hot, int64_t n_hot, int pair_blocks,
+                                                             double* __restrict__ q_partial) {
   const int64_t rows_per_code = n + n_hot;
+  double qs = 0.0;
   if (static_cast<int>(blockIdx.x) >= pair_blocks) {
     // the odd last node and the second copies of the nodes hot[] — in the SAME launch, next to the streaming part (a launch of
     // their own: 35 us behind the pairs' 61 on the 10M-node graph)
     const int64_t o = 2 * n_pairs + (static_cast<int64_t>(blockIdx.x) - pair_blocks) * 256 + threadIdx.x;
-    if (o >= rows_per_code) return;
-    const int64_t i = o < n ? o : hot[o - n];
-    const float g = dY[i];
-    int k[D];
+    if (o < rows_per_code) {
+      const int64_t i = o < n ? o : hot[o - n];
+      const float g = dY[i];
+      int k[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) k[d] = cnt[i * D + d];
-    const float q = with_rest ? g / static_cast<float>(k[D - 1] > 1 ? k[D - 1] : 1) : 0.f;
+      for (int d = 0; d < D; ++d) k[d] = cnt[i * D + d];
+      const float q = with_rest ? g / static_cast<float>(k[D - 1] > 1 ? k[D - 1] : 1) : 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-      *reinterpret_cast<float2*>(V + (static_cast<int64_t>(d) * rows_per_code + o) * 2) =
-          make_float2(g / static_cast<float>(k[d] > 1 ? k[d] : 1), q);
+      for (int d = 0; d < D; ++d)
+        *reinterpret_cast<float2*>(V + (static_cast<int64_t>(d) * rows_per_code + o) * 2) =
+            make_float2(g / static_cast<float>(k[d] > 1 ? k[d] : 1), q);
+      if (o < n) qs = static_cast<double>(q);
+    }
+    if (q_partial) block_sum_to(qs, q_partial);
     return;
   }
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_pairs; t += static_cast<int64_t>(pair_blocks) * 256) {
@@ -2038,9 +2074,45 @@ __global__ __launch_bounds__(256) void pack_bwd_pairs_kernel(const float* __rest
 #pragma unroll
     for (int d = 0; d < D; ++d)
       *reinterpret_cast<float4*>(V + (static_cast<int64_t>(d) * rows_per_code + 2 * t) * 2) = make_float4(g.x / r[0][d], q0, g.y / r[1][d], q1);
+    qs += static_cast<double>(q0) + static_cast<double>(q1);
   }
+  if (q_partial) block_sum_to(qs, q_partial);
 }
 }  // namespace
+
+// the launch gnan_spmm_pack_bwd_rows makes for these arguments: node pairs (pair_blocks > 0) or one node per thread
+namespace {
+struct PackGrid {
+  bool pairs;
+  int64_t n_pairs, pair_blocks, blocks;    // blocks: the whole grid
+};
+PackGrid pack_grid(const gnan_pack_bwd_rows_args* a) {
+  PackGrid g{false, 0, 0, 0};
+  const int64_t n = a->n, n_hot = a->n_hot;
+  // node pairs (large graphs): needs the packed rows of every code to start 16-byte aligned ((n + n_hot) even) and dense inputs
+  if (a->half == 1 && a->W == 1 && a->cnt != nullptr && a->cnt_stride == a->D && a->dy_stride == 1 && a->D >= 2 && a->D <= 4 &&
+      n >= (int64_t(1) << 20) && (n + n_hot) % 2 == 0 && reinterpret_cast<uintptr_t>(a->dY) % 8 == 0 &&
+      reinterpret_cast<uintptr_t>(a->cnt) % 8 == 0 && reinterpret_cast<uintptr_t>(a->V) % 16 == 0) {
+    g.n_pairs = n / 2;
+    g.pair_blocks = (g.n_pairs + 255) / 256;
+    g.pair_blocks = g.pair_blocks > 65536 ? 65536 : g.pair_blocks;
+    const int64_t tb = (n + n_hot - 2 * g.n_pairs + 255) / 256;
+    if (tb < (int64_t(1) << 20)) {
+      g.pairs = true;
+      g.blocks = g.pair_blocks + tb;
+      return g;
+    }
+  }
+  g.blocks = (n + n_hot + 255) / 256;
+  g.blocks = g.blocks > 65536 ? 65536 : g.blocks;
+  return g;
+}
+}  // namespace
+
+extern "C" size_t gnan_spmm_pack_bwd_rows_workspace_bytes(const gnan_pack_bwd_rows_args* a) {
+  if (!a || a->q_sum == nullptr || a->n <= 0) return 0;
+  return static_cast<size_t>(pack_grid(a).blocks) * sizeof(double);
+}
 
 extern "C" int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_stream_t stream) {
   GNAN_REQUIRE(a != nullptr, "pack_bwd_rows: null args");
@@ -2054,31 +2126,41 @@ extern "C" int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_st
   GNAN_REQUIRE((dY && V) || n == 0, "pack_bwd_rows: null pointer");
   GNAN_REQUIRE(dy_stride >= W && (cnt == nullptr || cnt_stride >= D), "pack_bwd_rows: row stride smaller than the width");
   GNAN_REQUIRE(n_hot >= 0 && (n_hot == 0 || hot != nullptr), "pack_bwd_rows: n_hot without hot");
-  if (n == 0) return GNAN_OK;
+  GNAN_REQUIRE(a->q_sum == nullptr || (W == 1 && with_rest), "pack_bwd_rows: q_sum is the one-channel rest-bucket sum (W == 1, with_rest)");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int64_t o_begin = 0;
-  // node pairs (large graphs): needs the packed rows of every code to start 16-byte aligned ((n + n_hot) even) and dense inputs
-  if (half == 1 && W == 1 && cnt != nullptr && cnt_stride == D && dy_stride == 1 && D >= 2 && D <= 4 && n >= (int64_t(1) << 20) && (n + n_hot) % 2 == 0 &&
-      reinterpret_cast<uintptr_t>(dY) % 8 == 0 && reinterpret_cast<uintptr_t>(cnt) % 8 == 0 && reinterpret_cast<uintptr_t>(V) % 16 == 0) {
-    const int64_t n_pairs = n / 2;
-    int64_t pb = (n_pairs + 255) / 256;
-    pb = pb > 65536 ? 65536 : pb;
-    const int64_t tail = n + n_hot - 2 * n_pairs;
-    const int64_t tb = (tail + 255) / 256;
-    if (tb < (int64_t(1) << 20)) {
-      const dim3 grid(static_cast<unsigned>(pb + tb)), block(256);
-      const int pbi = static_cast<int>(pb);
-      if (D == 2) hipLaunchKernelGGL(pack_bwd_pairs_kernel<2>, grid, block, 0, st, dY, cnt, n, n_pairs, with_rest, V, hot, n_hot, pbi);
-      else if (D == 3) hipLaunchKernelGGL(pack_bwd_pairs_kernel<3>, grid, block, 0, st, dY, cnt, n, n_pairs, with_rest, V, hot, n_hot, pbi);
-      else hipLaunchKernelGGL(pack_bwd_pairs_kernel<4>, grid, block, 0, st, dY, cnt, n, n_pairs, with_rest, V, hot, n_hot, pbi);
-      return gnan::check_launch("pack_bwd_pairs_kernel");
+  if (n == 0) {
+    if (a->q_sum) {
+      hipLaunchKernelGGL(pack_q_final_kernel, dim3(1), dim3(256), 0, st, static_cast<const double*>(nullptr), static_cast<int64_t>(0), a->q_sum);
+      return gnan::check_launch("pack_q_final_kernel");
     }
+    return GNAN_OK;
   }
-  int64_t blocks = (n + n_hot - o_begin + 255) / 256;
-  blocks = blocks > 65536 ? 65536 : blocks;
-  hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
-                     dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot, o_begin);
-  return gnan::check_launch("pack_bwd_rows_kernel");
+  const PackGrid pg = pack_grid(a);
+  double* q_partial = nullptr;
+  if (a->q_sum) {
+    const size_t need = static_cast<size_t>(pg.blocks) * sizeof(double);
+    if (a->q_workspace == nullptr || a->q_workspace_bytes < need)
+      return gnan::fail(GNAN_ERR_WORKSPACE, "pack_bwd_rows: q workspace %zu B < required %zu B", a->q_workspace_bytes, need);
+    GNAN_REQUIRE(reinterpret_cast<uintptr_t>(a->q_workspace) % 8 == 0, "pack_bwd_rows: q workspace must be 8-byte aligned");
+    q_partial = static_cast<double*>(a->q_workspace);
+  }
+  if (pg.pairs) {
+    const dim3 grid(static_cast<unsigned>(pg.blocks)), block(256);
+    const int pbi = static_cast<int>(pg.pair_blocks);
+    if (D == 2) hipLaunchKernelGGL(pack_bwd_pairs_kernel<2>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial);
+    else if (D == 3) hipLaunchKernelGGL(pack_bwd_pairs_kernel<3>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial);
+    else hipLaunchKernelGGL(pack_bwd_pairs_kernel<4>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial);
+    if (int rc = gnan::check_launch("pack_bwd_pairs_kernel")) return rc;
+  } else {
+    hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(pg.blocks)), dim3(256), 0, st,
+                       dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot, static_cast<int64_t>(0), q_partial);
+    if (int rc = gnan::check_launch("pack_bwd_rows_kernel")) return rc;
+  }
+  if (q_partial) {
+    hipLaunchKernelGGL(pack_q_final_kernel, dim3(1), dim3(256), 0, st, q_partial, pg.blocks, a->q_sum);
+    return gnan::check_launch("pack_q_final_kernel");
+  }
+  return GNAN_OK;
 }
 
 static size_t bwd_narrow_workspace_bytes(const gnan_spmm_args* a) {

@@ -240,6 +240,13 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
             sum_ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)      # (alive until the look-up is queued)
             a.sum_workspace, a.sum_workspace_bytes = _lib.ptr(sum_ws), need
     total = None
+    if sum_ws is not None and want_total and C == 1 and n > 0:
+        # ... and the pass that adds the groups' partial sums hands back the column sum of the result (the rest bucket's operand):
+        # a gnan_colsum over the result otherwise (two more launches of a replayed step)
+        total = torch.empty(1, dtype=torch.float32, device=x.device)
+        tot_ws = torch.empty((n + 255) // 256, dtype=torch.float64, device=x.device)     # (alive until the look-up is queued)
+        a.sum_total, a.sum_total_workspace, a.sum_total_workspace_bytes = _lib.ptr(total), _lib.ptr(tot_ws), tot_ws.numel() * 8
+        a.total_rows = n if total_rows is None else int(total_rows)
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0 and n > 0):

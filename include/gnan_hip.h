@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 43
+#define GNAN_ABI_VERSION 44
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -182,6 +182,10 @@ typedef struct gnan_fpwl_args {
   size_t sum_workspace_bytes;  /* look-up over several feature groups on a MEDIUM batch gives every (node block, group) a workgroup */
                                /* of its own and adds the groups' partial sums in group order afterwards (same bits as the walk    */
                                /* of all groups inside one workgroup, which leaves most of the chip idle below ~10^6 nodes)         */
+  float* sum_total;            /* gnan_fpwl_fwd, optional (ABI 44), ONLY with sum_workspace in use (gnan_fpwl_sum_workspace_bytes() > 0, */
+  void* sum_total_workspace;   /* C == 1): sum_total[0] = sum of out over rows [0, total_rows) out of the group-sum pass (float64 per  */
+  size_t sum_total_workspace_bytes; /* workgroup, fixed order) — the rest bucket's operand without a gnan_colsum over the result;   */
+                               /* workspace: ceil(n / 256) * 8 bytes, 8-byte aligned                                              */
 } gnan_fpwl_args;
 
 /* gnan_fpwl_args.flags (the library reads no environment variables: switches are the caller's, passed per call) */
@@ -867,7 +871,13 @@ typedef struct gnan_pack_bwd_rows_args {
   float* V;                  /* [D, n + n_hot, 2 * half] */
   const int64_t* hot;        /* optional [n_hot] node ids (device memory) */
   int64_t n_hot;
+  float* q_sum;              /* optional [1] (W == 1, with_rest): sum_i dY_i / max(cnt[i, D-1], 1) over the n real nodes — the column
+                                sum of the packed rows' second halves that gnan_spmm_bwd_narrow's rest terms need (rest_q), out of the
+                                same pass (float64 per workgroup, fixed order) instead of a gnan_colsum over the strided halves */
+  void* q_workspace;         /* with q_sum: gnan_spmm_pack_bwd_rows_workspace_bytes(a) bytes, 8-byte aligned */
+  size_t q_workspace_bytes;
 } gnan_pack_bwd_rows_args;
+size_t gnan_spmm_pack_bwd_rows_workspace_bytes(const gnan_pack_bwd_rows_args* a);
 int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_stream_t stream);
 
 typedef struct gnan_spmm_bwd_narrow_args {

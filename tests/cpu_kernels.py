@@ -83,7 +83,7 @@ def lut_grad_launch(g, S, dY, D, use_cnt, with_rest, row_ids, s_total, reduce_ro
     return out.float().unsqueeze(-1)
 
 
-def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None):
+def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None, want_q_sum=False):
     assert hot is None
     dY = dY.detach().float()
     n, W = dY.shape
@@ -92,7 +92,10 @@ def pack_bwd_rows(dY, cnt, D, with_rest, half, hot=None):
     V[:, :, :W] = dY.unsqueeze(1) / den.unsqueeze(-1)
     if with_rest:
         V[:, :, half:half + W] = (dY / den[:, D - 1:D]).unsqueeze(1)
-    return V.permute(1, 0, 2).contiguous()                      # code-major [D, n, 2 * half]
+    V = V.permute(1, 0, 2).contiguous()                         # code-major [D, n, 2 * half]
+    if want_q_sum:
+        return V, V[0, :, half:half + 1].double().sum(0).float()
+    return V
 
 
 def bwd_narrow_launch(gt, V, S_rows, lut, with_rest, W, walk=None, ds_add=None, rest_q=None, rest_total=None, add_to_rows=False):

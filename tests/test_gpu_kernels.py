@@ -1107,6 +1107,12 @@ def test_packed_backward_rows_kernel(W, D, use_cnt, with_rest):
     ids = torch.from_numpy(rng.integers(0, n, 37)).to(DEV)                 # second copies of 37 nodes behind the n real rows
     Vh = pack_bwd_rows(dY, cnt, D, with_rest, half, hot=ids)
     assert Vh.shape == (D, n + 37, 2 * half) and torch.equal(Vh[:, :n], V) and torch.equal(Vh[:, n:], V[:, ids])
+    if W == 1 and with_rest:            # the rest halves' column sum out of the same pass (real nodes only: not the hot copies)
+        Vq, q = pack_bwd_rows(dY, cnt, D, with_rest, half, hot=ids, want_q_sum=True)
+        assert torch.equal(Vq, Vh)
+        ref = V[0, :, half].double().sum()
+        assert abs(float(q[0]) - float(ref)) <= 1e-6 * float(V[0, :, half].abs().double().sum())
+        assert torch.equal(q, pack_bwd_rows(dY, cnt, D, with_rest, half, hot=ids, want_q_sum=True)[1])      # fixed order
 
 
 @pytest.mark.parametrize("n,D,with_rest,n_hot", [(1 << 20, 3, True, 0), ((1 << 20) + 2, 3, True, 38), ((1 << 20) + 1, 3, True, 37),
@@ -1127,6 +1133,11 @@ def test_packed_backward_rows_of_large_one_channel_graphs(n, D, with_rest, n_hot
     assert torch.equal(V[:, :n].cpu(), want)
     if n_hot:
         assert torch.equal(V[:, n:], V[:, ids])
+    if with_rest:
+        Vq, q = pack_bwd_rows(dY, cnt, D, with_rest, 1, hot=ids, want_q_sum=True)
+        assert torch.equal(Vq, V)
+        ref = want[0, :, 1].double().sum()
+        assert abs(float(q[0]) - float(ref)) <= 1e-6 * float(want[0, :, 1].abs().double().sum())
 
 
 @pytest.mark.parametrize("W,K,with_rest", [(1, 1, True), (2, 2, True), (4, 1, False)])
@@ -1999,6 +2010,34 @@ def test_direct_index_keeps_the_pieces_for_the_backward_pass(F, monkeypatch):
         grads[on] = [S.detach()] + [t.grad for t in leaves]
     for a, b in zip(grads[False], grads[True]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("F,total_rows", [(48, None), (144, 50_001), (64, 1)])
+def test_group_split_feature_sum_hands_back_its_column_sum(F, total_rows, monkeypatch):
+    """A medium batch with several feature groups (a workgroup per (node block, group), `sum_workspace`): the pass that adds the
+    groups' partial sums also returns the column sum of the result over the first `total_rows` rows (`sum_total`) — what a
+    gnan_colsum over the result gave, without its two launches."""
+    from gnan_amd import _lib, functional
+    from gnan_amd.functional import feature_mlps
+    monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
+    n, L, H = 80_000, 3, 16
+    sd = _mlp_state(F, L, H, 1, True, seed=5)
+    x = _index_inputs("uniform", n, F, seed=3)
+    functional._RANGE_CHURN.clear()
+    st = _stack(sd, F, L, H, 1, True)
+    with torch.no_grad():
+        S, total = feature_mlps(x, st, True, return_total=True, total_rows=total_rows)
+        plain = feature_mlps(x, st, True)
+    assert torch.equal(S, plain)
+    rows = n if total_rows is None else total_rows
+    ref = S[:rows].double().sum(0)
+    assert total.shape == (1,) and abs(float(total[0]) - float(ref[0])) <= 1e-6 * float(S[:rows].abs().double().sum())
+    calls = []
+    real = functional.column_sums
+    monkeypatch.setattr(functional, "column_sums", lambda t: calls.append(1) or real(t))
+    with torch.no_grad():
+        _, again = feature_mlps(x, st, True, return_total=True, total_rows=total_rows)
+    assert torch.equal(again, total) and not calls           # fixed order; no separate column-sum pass
 
 
 def test_feature_range_kernel():
