@@ -64,6 +64,14 @@ def parse():
                          "the [N, C] partial outputs; halo = vertex blocks, the halo's shape functions recomputed (nothing of "
                          "size N on the wire); exchange = vertex blocks, only the listed remote operand rows travel "
                          "(x stays sharded); auto = fewer bytes over xGMI")
+    ap.add_argument("--cut", default="cost", choices=["cost", "rows"],
+                    help="halo / exchange partitions: node blocks of equal cost (look-up rows + stored pairs, "
+                         "distributed.balanced_bounds) or of equal row count")
+    ap.add_argument("--alt-partitions", default="auto", choices=["auto", "off"],
+                    help="more than one rank, halo partition: after the timed loop, also time a few steps of the partitions that DO "
+                         "move operand rows over xGMI (all-gather of the [N, W] operand; all-to-all-v of the listed halo rows) and "
+                         "print them as alt_partitions")
+    ap.add_argument("--alt-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL on ROCm); gloo + --same-device is a dry run of the "
                          "multi-rank code path on a 1-GPU box")
@@ -715,6 +723,73 @@ def measure_traffic(kernel_prefix="spmm_kernel<"):
                    f"--pmc WRITE_SIZE ({found['WRITE_SIZE']:.6g} KiB) per launch of {kernel_prefix}...>, separate child passes")
 
 
+def time_alt_partition(name, args, c):
+    """``--alt-steps`` forwards of the ``vertex`` (all-gather of the whole ``[N, W]`` operand) or ``exchange`` (all-to-all-v of
+    the listed halo rows) partition of the same workload, eager, stage by stage with HIP events; time = max over ranks."""
+    import torch.distributed as dist
+    from gnan_amd import synthetic as syn
+    from gnan_amd.distributed import (VertexPartition, build_exchange_plan, halo_exchange_forward, partitioned_forward)
+    N, F, C, dev, rank, world = c["N"], c["F"], c["C"], c["dev"], c["rank"], c["world"]
+    if name == "vertex":                         # equal blocks: the all-gather needs equally sized shards
+        part = VertexPartition(N, world, rank)
+        g = syn.hop1_csr(c["src"], c["dst"], N, part.lo, part.hi)
+        names = ["fmlp", "gather", "total", "spmm"]
+    else:
+        part = VertexPartition(N, world, rank, c["bounds"])
+        xplan = build_exchange_plan(syn.hop1_csr(c["src"], c["dst"], N, part.lo, part.hi), part)
+        g = xplan.halo.graph
+        names = ["fmlp", "gather", "total", "spmm"]
+    x = syn.block_features(N, F, part.lo, part.hi, seed=1, device=dev)
+    g.long_row_plan()
+    if g.n_rows >= 65536 and not g.is_dense:
+        g.degree_sorted_copy()
+    events = []
+
+    def one(record):
+        marks = {}
+
+        def mark(n):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks[n] = ev
+        with torch.no_grad():
+            if name == "vertex":
+                out = partitioned_forward(x, g, c["stacked"], c["lut"], True, part, order=args.order, out_channels=C,
+                                          marks=mark, operand_dtype=c["op_dtype"])
+            else:
+                out = halo_exchange_forward(x, xplan, c["stacked"], c["lut"], True, order=args.order, out_channels=C,
+                                            marks=mark, operand_dtype=c["op_dtype"])
+        if record:
+            events.append(marks)
+        return out
+    for _ in range(2):
+        out = one(False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.alt_steps):
+        out = one(True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    checksum = out.double().sum().reshape(1)
+    dist.all_reduce(checksum, op=dist.ReduceOp.SUM)
+    stages = {n: 0.0 for n in names}
+    for m in events:
+        prev = m["start"]
+        for n in names:
+            if n in m:
+                stages[n] += prev.elapsed_time(m[n]) / len(events)
+                prev = m[n]
+    ms = float(t) / args.alt_steps * 1e3
+    W = F * C if args.order == "reference" else C
+    moved = (N - (part.hi - part.lo)) * W * 4 if name == "vertex" else int(xplan.halo.halo.numel()) * W * 4
+    return {"ms_per_step": ms, "edges_per_s": c["E"] / (ms / 1e3), "steps": args.alt_steps, "loop": "eager",
+            "exchange": "all_gather(operand [N,W])" if name == "vertex" else "all_to_all_v(listed remote operand rows [n_halo,W])",
+            "bytes_received_rank0": moved, "stages_ms_rank0": stages, "checksum": float(checksum)}
+
+
 def launch_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher around it: start the N ranks ourselves.
 
@@ -788,7 +863,8 @@ def main():
     import gnan_amd  # noqa: F401
     from gnan_amd import synthetic as syn
     from gnan_amd.distributed import (FeaturePartition, VertexPartition, build_exchange_plan, build_halo_plan,
-                                      SharePipeline, choose_partition, feature_parallel_forward, halo_exchange_forward,
+                                      SharePipeline, balanced_bounds, choose_partition, feature_parallel_forward,
+                                      halo_exchange_forward,
                                       halo_recompute_forward, partitioned_forward, slice_features)
     from gnan_amd import _lib, functional
     from gnan_amd.functional import stack_mlps
@@ -813,14 +889,19 @@ def main():
         raise SystemExit("--emulate-world covers the halo and feature partitions (these shares need the other ranks' operand rows)")
     if partition == "feature" and args.order != "reference":
         raise SystemExit("--partition feature needs --order reference (sum-first exchanges the narrow operand)")
-    part = VertexPartition(N, pworld, rank)
+    t_setup = time.perf_counter()
+    src, dst = syn.rmat_edges(args.scale, N, E, seed=0, device=dev)
+    bounds = None
+    if pworld > 1 and partition in ("halo", "exchange") and args.cut == "cost":
+        # every rank draws the same edges, hence the same degrees and the same cut
+        bounds = balanced_bounds(torch.bincount(src, minlength=N) + 1, pworld)
+    part = VertexPartition(N, pworld, rank, bounds)
     fpart = FeaturePartition(F, pworld, rank)
     if emulated:                                             # same shares, no process group: collectives are skipped
         part.world = fpart.world = 1
-        part.__class__ = type("EmuV", (VertexPartition,), {"block": property(lambda self: -(-N // pworld))})
+        if bounds is None:
+            part.__class__ = type("EmuV", (VertexPartition,), {"block": property(lambda self: -(-N // pworld))})
         fpart.__class__ = type("EmuF", (FeaturePartition,), {"block": property(lambda self: -(-F // pworld))})
-    t_setup = time.perf_counter()
-    src, dst = syn.rmat_edges(args.scale, N, E, seed=0, device=dev)
     plan = None
     if partition == "halo":                      # owned rows; x rows of the owned nodes AND of the remote nodes they list
         plan = build_halo_plan(syn.hop1_csr(src, dst, N, part.lo, part.hi), part)
@@ -836,7 +917,9 @@ def main():
     else:                                        # whole graph, this rank's feature columns
         g = syn.hop1_csr(src, dst, N)
         x = syn.block_features(N, F, 0, N, seed=1, device=dev)[:, fpart.lo:fpart.hi].contiguous()
-    del src, dst
+    want_alt = grouped and not emulated and args.alt_partitions != "off" and partition == "halo" and args.order == "reference"
+    if not want_alt:
+        del src, dst
     torch.manual_seed(0)
     model = TensorGNAN(F, C, L, hidden_channels=H, normalize_rho=True, rho_per_feature=False, device="cuda")
     with torch.no_grad():                                    # O(1)-scale weights (the upstream init gives ~1e-14 outputs)
@@ -1046,6 +1129,19 @@ def main():
         # PMC counters need rocprofv3 around the process: the figure is the committed one of the same command, not of this run
         traffic, traffic_source = committed, "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of this command, not measured in this run)" % rec.get("source", "committed")
 
+    # ---- the partitions that move operand rows between the ranks, a few steps each (north_star's halo all-gather over xGMI
+    #      measured next to the halo-recompute line; every rank takes part, rank 0 prints) ----------------------------------
+    alt = None
+    if want_alt:
+        alt = {}
+        for name in ("vertex", "exchange"):
+            try:
+                alt[name] = time_alt_partition(name, args, dict(N=N, E=E, F=F, C=C, dev=dev, rank=rank, world=world, src=src, dst=dst,
+                                                                stacked=stacked, lut=lut, op_dtype=op_dtype, bounds=bounds))
+            except Exception as e:                   # (every rank fails alike or the next collective hangs: shapes are the same on all)
+                alt[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        del src, dst
+
     result = None
     if rank == 0 or emulated:                        # (an emulated share is its own one-process job whatever RANK selects)
         ms = elapsed / args.steps * 1e3
@@ -1084,6 +1180,9 @@ def main():
             "emulated_share_of": pworld if emulated else None, "setup_s": t_setup, "checksum": checksum,
             "amortised_setup_ms": amortised,
             "operand_rows_rank0": int(x.shape[0]),
+            "cut": None if pworld == 1 else ("cost" if bounds is not None else "rows"),
+            "owned_rows_rank0": [part.lo, part.hi] if partition != "feature" else None,
+            "alt_partitions": alt,
             # bf16 operand rows are an inference format: the library has no backward through them
             "backward": False if args.operand == "bf16" else None,
         }

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GNAN_HIP_LIB: development aid for same-box A/B runs of two builds of the library (tools/ab_lib.sh)
 LIB_PATH = os.environ.get("GNAN_HIP_LIB") or os.path.join(_HERE, "libgnan_hip.so")
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 GNAN_F32, GNAN_BF16 = 0, 1
 FMLP_AUTO, FMLP_LANE, FMLP_MFMA, FMLP_PWL = 0, 1, 2, 3   # PWL is host-side only (gnan_fpwl_fwd)
@@ -121,6 +121,18 @@ class SpmmArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("s_by_code", C.c_int32), ("nnz", C.c_int64), ("packed_index", C.c_int32),
         ("hot_lo", C.c_int64), ("hot_rows", C.c_int32),
+    ]
+
+
+class SpmmPbArgs(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("S", C.c_void_p), ("s_stride", C.c_int64), ("W", C.c_int32),
+        ("D", C.c_int32), ("lut", C.c_void_p), ("cnt", C.c_void_p), ("cnt_stride", C.c_int64), ("s_total", C.c_void_p),
+        ("Y", C.c_void_p), ("y_stride", C.c_int64), ("n_entries", C.c_int64), ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("cb_width", C.c_int32), ("n_cblocks", C.c_int32), ("chunk_q", C.c_void_p), ("cb_chunk_ptr", C.c_void_p),
+        ("n_bins", C.c_int32), ("acc_per_bin", C.c_int32), ("bin_order", C.c_void_p), ("bin_entry_ptr", C.c_void_p),
+        ("bin_row_ptr", C.c_void_p), ("slot_ptr", C.c_void_p), ("n_acc", C.c_int32), ("code_base", C.c_int32),
+        ("self_col", C.c_void_p), ("headroom_bits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -319,6 +331,8 @@ SYMBOLS = {
     "gnan_loss_step": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
+    "gnan_spmm_pb_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbArgs)]),
+    "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_lut_grad_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmLutGradArgs)]),
     "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmLutGradArgs), C.c_void_p]),

@@ -1,0 +1,313 @@
+// Narrow rho-weighted neighbourhood sum (sum-first order, GNAN.py:157-170: S = f_sums is [N, C], C small) without a single
+// per-pair memory request: "propagation blocking" through LDS on both sides (gfx950).
+//
+// The row-parallel kernels (spmm.hip: spmm_kernel<1,...>, spmm_hot_kernel) issue one 4-byte gather per listed pair.  On the
+// 10M-node / 110M-pair R-MAT graph 30 % of those gathers miss the XCD's L2 and each miss drags a 128-byte line over the
+// fabric (profiles/r06_pmc_spmm_hot.csv: 3.4e7 fabric requests, 4.3 GB fetched for 0.13 GB of useful operand bytes); the kernel
+// sits on that request wall at 0.87 ms = 0.17 of the HBM roofline.  Even if every gather hit L2 the 1.1e8 L2 requests would
+// cost ~0.4 ms.  Here NO pair touches L2 at random:
+//
+//   the pairs of the graph are bucketed ONCE per graph (HopGraph.pb_plan, static index work) into tiles
+//   (row bin b, column block cb): a column block is as many operand rows as fit 64 KB of LDS, a row bin as many output
+//   accumulators as fit 64 KB of LDS; entries are stored bin-major, 2 + 2 bytes per pair (column inside its block,
+//   accumulator inside its bin).
+//
+//   phase 1  pb_expand_kernel:  a workgroup loads ONE column block of the operand into LDS (coalesced) and writes
+//            E[q] = S[col(q)] for the entries of its tiles: 2 B read + 4 W B written per pair, all of it streamed.
+//   phase 2  pb_reduce_kernel:  a workgroup owns ONE row bin: its entries are one contiguous range; every entry is added to
+//            its row's accumulator in LDS with a 64-bit INTEGER atomic (fixed point scaled from max |S|: order-independent,
+//            hence bit-reproducible, and exact to 2^-40 of max |S| — closer to the float64 sum than a float32 chain is);
+//            the epilogue applies the row's weights  sum_d (wt(i,d) - wt(i,rest)) * T[i,d] + wt(i,rest) * total  and stores
+//            the output row: 2 + 4 W B read per pair.
+//
+// Hub rows own several accumulators (one per 512 pairs, entries dealt round-robin) so that no LDS address is hit by more
+// than a few lanes of an instruction; the epilogue adds them.  The self pair of every row (hop code 0: exactly one pair per
+// row in a hop-coded graph) never enters the tiles: the epilogue reads S[self] directly.
+// Algorithmic bytes per pair (SURVEY section 8d, W = 1): 4 (index) + 4 (operand) = 8; this scheme moves 2 + 4 + 2 + 4 = 12 B
+// per pair, streamed, against ~39 B of fabric traffic per pair for the gathers.
+#include "common.hpp"
+
+#include <cstdint>
+
+namespace {
+
+using gnan::kWave;
+
+constexpr int kChunk = 16;          // entries per chunk: tiles are padded to whole chunks (pads add to a dummy accumulator)
+constexpr int kThreads = 1024;
+
+struct PbParams {
+  int64_t n_rows, n_cols;
+  const float* S;
+  int W;
+  const float* lut;
+  int D;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  const float* s_total;
+  float* Y;
+  int64_t y_stride;
+  int64_t n_entries;
+  const uint16_t* src;
+  const uint16_t* dst;
+  int cb_width, n_cblocks, n_split;
+  const int32_t* chunk_q;
+  const int32_t* cb_chunk_ptr;
+  int n_bins;
+  const int32_t* bin_order;
+  const int32_t* bin_entry_ptr;
+  const int32_t* bin_row_ptr;
+  const int32_t* slot_ptr;
+  int n_acc, code_base;
+  const int32_t* self_col;
+  int acc_per_bin, headroom_bits;
+  float* E;
+  unsigned* absmax;     // bits of max |S| (non-negative floats order like their bit patterns; NaN sorts above +inf)
+};
+
+__global__ void pb_prep_kernel(unsigned* absmax) {
+  if (threadIdx.x == 0) *absmax = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 1: E[q, :] = S[block start + src[q], :]
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(kThreads) void pb_expand_kernel(const PbParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sblk[];          // [cb_width * W]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int cb = static_cast<int>(blockIdx.x) / p.n_split, part = static_cast<int>(blockIdx.x) % p.n_split;
+  const int64_t c0 = static_cast<int64_t>(cb) * p.cb_width;
+  const int ncol = static_cast<int>(p.n_cols - c0 < p.cb_width ? p.n_cols - c0 : p.cb_width);
+  {
+    const float* src = p.S + c0 * W;
+    float m = 0.f;
+    for (int i = tid; i < ncol * W; i += kThreads) {
+      const float v = src[i];
+      sblk[i] = v;
+      const float a = fabsf(v);
+      m = (a > m || v != v) ? a : m;                 // a NaN sticks (nothing compares greater than it afterwards)
+    }
+    if (part == 0) {                                 // every column block is seen by exactly one `part == 0` workgroup
+      unsigned bits = __float_as_uint(m);
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned o = __shfl_xor(bits, off);
+        bits = o > bits ? o : bits;
+      }
+      if (lane == 0 && bits) atomicMax(p.absmax, bits);
+    }
+  }
+  __syncthreads();
+  const int k_lo = p.cb_chunk_ptr[cb], k_hi = p.cb_chunk_ptr[cb + 1];
+  int per = (k_hi - k_lo + p.n_split - 1) / p.n_split;
+  per = (per + 3) & ~3;                               // whole wave-iterations (four chunks of 16 entries)
+  const int lo = k_lo + part * per;
+  const int hi = lo + per < k_hi ? lo + per : k_hi;
+  const int g = lane >> 4, l16 = lane & 15;
+  constexpr int U = 4;                                // wave-iterations in flight
+  for (int kw = lo + wave * 4; kw < hi; kw += (kThreads / kWave) * 4 * U) {
+    int q[U];
+    unsigned s[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kw + u * (kThreads / kWave) * 4 + g;
+      ok[u] = k < hi;
+      q[u] = p.chunk_q[ok[u] ? k : lo] + l16;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = p.src[q[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (W == 1) {
+        const float v = sblk[s[u]];
+        if (ok[u]) p.E[q[u]] = v;
+      } else if constexpr (W == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(sblk + 2 * s[u]);
+        if (ok[u]) *reinterpret_cast<float2*>(p.E + 2 * static_cast<int64_t>(q[u])) = v;
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(sblk + 4 * s[u]);
+        if (ok[u]) *reinterpret_cast<float4*>(p.E + 4 * static_cast<int64_t>(q[u])) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 2: one row bin per workgroup; 64-bit fixed-point accumulators in LDS
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_add(long long* acc, int idx, float v, double scale) {
+  const long long x = __double2ll_rn(static_cast<double>(v) * scale);
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc + idx), static_cast<unsigned long long>(x));
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
+  extern __shared__ __attribute__((aligned(16))) long long acc[];     // [acc_per_bin * W]
+  const int tid = threadIdx.x;
+  const int b = p.bin_order[blockIdx.x];
+  for (int i = tid; i < p.acc_per_bin * W; i += kThreads) acc[i] = 0;
+  // fixed point: |v| <= mx < 2^e; at most 2^headroom terms per output row => |sum * 2^shift| < 2^62
+  const float mx = __uint_as_float(*p.absmax);
+  const bool bad = !(mx <= 3.0e38f);                                    // inf or NaN somewhere in the operand
+  int e = 0;
+  if (!bad && mx > 0.f) (void)frexpf(mx, &e);
+  const int shift = 62 - p.headroom_bits - e;
+  const double scale = bad ? 0.0 : ldexp(1.0, shift), inv_scale = bad ? 0.0 : ldexp(1.0, -shift);
+  __syncthreads();
+  const int q_lo = p.bin_entry_ptr[b], q_hi = p.bin_entry_ptr[b + 1];   // multiples of kChunk
+  constexpr int U = 2;
+  for (int base = q_lo + tid * 4; base < q_hi; base += kThreads * 4 * U) {
+    uint2 d[U];
+    float4 v[U][W];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = base + u * kThreads * 4;
+      ok[u] = q < q_hi;
+      const int qs = ok[u] ? q : q_lo;
+      d[u] = *reinterpret_cast<const uint2*>(p.dst + qs);
+#pragma unroll
+      for (int w = 0; w < W; ++w) v[u][w] = *reinterpret_cast<const float4*>(p.E + static_cast<int64_t>(qs) * W + 4 * w);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      const int i0 = static_cast<int>(d[u].x & 0xffffu), i1 = static_cast<int>(d[u].x >> 16);
+      const int i2 = static_cast<int>(d[u].y & 0xffffu), i3 = static_cast<int>(d[u].y >> 16);
+      if constexpr (W == 1) {
+        lds_add(acc, i0, v[u][0].x, scale);
+        lds_add(acc, i1, v[u][0].y, scale);
+        lds_add(acc, i2, v[u][0].z, scale);
+        lds_add(acc, i3, v[u][0].w, scale);
+      } else if constexpr (W == 2) {
+        lds_add(acc, 2 * i0, v[u][0].x, scale); lds_add(acc, 2 * i0 + 1, v[u][0].y, scale);
+        lds_add(acc, 2 * i1, v[u][0].z, scale); lds_add(acc, 2 * i1 + 1, v[u][0].w, scale);
+        lds_add(acc, 2 * i2, v[u][1].x, scale); lds_add(acc, 2 * i2 + 1, v[u][1].y, scale);
+        lds_add(acc, 2 * i3, v[u][1].z, scale); lds_add(acc, 2 * i3 + 1, v[u][1].w, scale);
+      } else {
+        const int idx[4] = {i0, i1, i2, i3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lds_add(acc, 4 * idx[j], v[u][j].x, scale); lds_add(acc, 4 * idx[j] + 1, v[u][j].y, scale);
+          lds_add(acc, 4 * idx[j] + 2, v[u][j].z, scale); lds_add(acc, 4 * idx[j] + 3, v[u][j].w, scale);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue: the rows of the bin ---------------------------------------------------------
+  const int r_lo = p.bin_row_ptr[b], r_hi = p.bin_row_ptr[b + 1];
+  const int slot0 = p.slot_ptr[r_lo];
+  const int rest = p.D - 1;
+  for (int i = r_lo + tid; i < r_hi; i += kThreads) {
+    const int s_lo = p.slot_ptr[i] - slot0, s_hi = p.slot_ptr[i + 1] - slot0;
+    float wt[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float v = 0.f;
+      if (d < p.D) {
+        v = p.lut[d];
+        if (p.cnt) {
+          const int c = p.cnt[static_cast<int64_t>(i) * p.cnt_stride + d];
+          v = v / static_cast<float>(c > 1 ? c : 1);                   // IEEE division, as torch.div (spmm.hip: small_weights)
+        }
+      }
+      wt[d] = v;
+    }
+    const float w_rest = p.s_total ? wt[rest] : 0.f;
+    const int sc = p.self_col ? p.self_col[i] : -1;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      float out = 0.f;
+      if (sc >= 0) out = fmaf(wt[0] - w_rest, p.S[static_cast<int64_t>(sc) * W + w], out);
+      for (int a = 0; a < p.n_acc; ++a) {
+        long long t = 0;
+        for (int s = s_lo; s < s_hi; ++s) t += acc[(s * p.n_acc + a) * W + w];
+        const float tf = static_cast<float>(static_cast<double>(t) * inv_scale);
+        const int d = p.code_base + a;
+        const float wd = d == 0 ? wt[0] : (d == 1 ? wt[1] : (d == 2 ? wt[2] : wt[3]));
+        out = fmaf(wd - w_rest, tf, out);
+      }
+      if (p.s_total) out = fmaf(w_rest, p.s_total[w], out);
+      if (bad) out = __uint_as_float(0x7fc00000u);
+      p.Y[static_cast<int64_t>(i) * p.y_stride + w] = out;
+    }
+  }
+}
+
+int validate(const gnan_spmm_pb_args* a) {
+  GNAN_REQUIRE(a != nullptr, "gnan_spmm_pb_fwd: null arguments");
+  GNAN_REQUIRE(a->W == 1 || a->W == 2 || a->W == 4, "gnan_spmm_pb_fwd: W must be 1, 2 or 4 (got %d)", a->W);
+  GNAN_REQUIRE(a->n_rows >= 0 && a->n_cols > 0, "gnan_spmm_pb_fwd: bad sizes");
+  GNAN_REQUIRE(a->D >= 2 && a->D <= 4, "gnan_spmm_pb_fwd: D must be in [2, 4] (got %d)", a->D);
+  GNAN_REQUIRE(a->n_acc >= 1 && a->code_base >= 0 && a->code_base + a->n_acc <= a->D - 1,
+               "gnan_spmm_pb_fwd: the accumulators cover hop codes [%d, %d) of %d listed ones", a->code_base,
+               a->code_base + a->n_acc, a->D - 1);
+  GNAN_REQUIRE(a->s_stride == a->W, "gnan_spmm_pb_fwd: operand rows must be contiguous (s_stride == W)");
+  GNAN_REQUIRE(a->S && a->lut && a->Y && a->src && a->dst && a->chunk_q && a->cb_chunk_ptr && a->bin_order && a->bin_entry_ptr &&
+                   a->bin_row_ptr && a->slot_ptr,
+               "gnan_spmm_pb_fwd: null pointer");
+  GNAN_REQUIRE(a->n_entries >= 0 && a->n_entries % kChunk == 0 && a->n_entries < (int64_t{1} << 31),
+               "gnan_spmm_pb_fwd: n_entries must be a multiple of %d below 2^31", kChunk);
+  GNAN_REQUIRE(a->cb_width > 0 && static_cast<int64_t>(a->cb_width) * a->W * 4 <= 65536 && a->cb_width <= 65536,
+               "gnan_spmm_pb_fwd: a column block must fit 64 KB of LDS");
+  GNAN_REQUIRE(static_cast<int64_t>(a->n_cblocks) * a->cb_width >= a->n_cols && a->n_cblocks > 0, "gnan_spmm_pb_fwd: column blocks do not cover n_cols");
+  GNAN_REQUIRE(a->acc_per_bin > 0 && static_cast<int64_t>(a->acc_per_bin) * a->W * 8 <= 65536 && a->acc_per_bin <= 65536,
+               "gnan_spmm_pb_fwd: a bin's accumulators must fit 64 KB of LDS");
+  GNAN_REQUIRE(a->n_bins > 0 && a->headroom_bits >= 0 && a->headroom_bits <= 40, "gnan_spmm_pb_fwd: bad plan");
+  GNAN_REQUIRE(a->y_stride >= a->W, "gnan_spmm_pb_fwd: y_stride < W");
+  GNAN_REQUIRE((reinterpret_cast<uintptr_t>(a->dst) % 8) == 0 && (reinterpret_cast<uintptr_t>(a->src) % 2) == 0,
+               "gnan_spmm_pb_fwd: dst must be 8-byte aligned");
+  return GNAN_OK;
+}
+
+size_t pb_bytes(const gnan_spmm_pb_args* a) {
+  return 256 + static_cast<size_t>(a->n_entries) * static_cast<size_t>(a->W) * sizeof(float);
+}
+
+template <int W>
+int launch(const PbParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(pb_prep_kernel, dim3(1), dim3(64), 0, st, p.absmax);
+  if (int rc = gnan::check_launch("pb_prep_kernel")) return rc;
+  const size_t lds1 = static_cast<size_t>(p.cb_width) * W * sizeof(float);
+  hipLaunchKernelGGL((pb_expand_kernel<W>), dim3(static_cast<unsigned>(p.n_cblocks) * p.n_split), dim3(kThreads), lds1, st, p);
+  if (int rc = gnan::check_launch("pb_expand_kernel")) return rc;
+  const size_t lds2 = static_cast<size_t>(p.acc_per_bin) * W * sizeof(long long);
+  hipLaunchKernelGGL((pb_reduce_kernel<W>), dim3(static_cast<unsigned>(p.n_bins)), dim3(kThreads), lds2, st, p);
+  return gnan::check_launch("pb_reduce_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t gnan_spmm_pb_workspace_bytes(const gnan_spmm_pb_args* a) {
+  if (!a || a->n_entries < 0 || a->W <= 0) return 0;
+  return pb_bytes(a);
+}
+
+extern "C" int gnan_spmm_pb_fwd(const gnan_spmm_pb_args* a, gnan_stream_t stream) {
+  if (int rc = validate(a)) return rc;
+  GNAN_REQUIRE(a->workspace && a->workspace_bytes >= pb_bytes(a), "gnan_spmm_pb_fwd: workspace too small (%zu < %zu)",
+               a->workspace_bytes, pb_bytes(a));
+  GNAN_REQUIRE((reinterpret_cast<uintptr_t>(a->workspace) % 16) == 0, "gnan_spmm_pb_fwd: workspace must be 16-byte aligned");
+  if (a->n_rows == 0) return GNAN_OK;
+  PbParams p{};
+  p.n_rows = a->n_rows; p.n_cols = a->n_cols; p.S = a->S; p.W = a->W; p.lut = a->lut; p.D = a->D;
+  p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total; p.Y = a->Y; p.y_stride = a->y_stride;
+  p.n_entries = a->n_entries; p.src = a->src; p.dst = a->dst; p.cb_width = a->cb_width; p.n_cblocks = a->n_cblocks;
+  p.chunk_q = a->chunk_q; p.cb_chunk_ptr = a->cb_chunk_ptr; p.n_bins = a->n_bins; p.bin_order = a->bin_order;
+  p.bin_entry_ptr = a->bin_entry_ptr; p.bin_row_ptr = a->bin_row_ptr; p.slot_ptr = a->slot_ptr; p.n_acc = a->n_acc;
+  p.code_base = a->code_base; p.self_col = a->self_col; p.acc_per_bin = a->acc_per_bin; p.headroom_bits = a->headroom_bits;
+  p.absmax = static_cast<unsigned*>(a->workspace);
+  p.E = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 256);
+  // enough workgroups per column block that the launch is >> the resident ones (two per CU) whatever the block count
+  int split = (4096 + a->n_cblocks - 1) / a->n_cblocks;
+  p.n_split = split < 1 ? 1 : (split > 16 ? 16 : split);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a->W) {
+    case 1: return launch<1>(p, st);
+    case 2: return launch<2>(p, st);
+    default: return launch<4>(p, st);
+  }
+}

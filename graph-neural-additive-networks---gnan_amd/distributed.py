@@ -54,6 +54,8 @@ import torch.distributed as dist
 # one-GPU box) a rank talks to its group whatever its size: communicator creation, every collective's RCCL launch and the
 # all-reduce captured in :class:`SharePipeline`'s hipGraphs run on a world of one exactly as they would on eight.
 ALWAYS_COMMUNICATE = False
+# halo recompute, inference: look the owned rows up first and all-reduce their column sums under the halo rows' look-up
+SPLIT_HALO_LOOKUP = True
 
 
 def _communicates(world: int) -> bool:
@@ -62,21 +64,78 @@ def _communicates(world: int) -> bool:
 
 @dataclass
 class VertexPartition:
+    """Contiguous node blocks, one per rank.  ``bounds`` (``world + 1`` ascending node ids, ``bounds[0] = 0``,
+    ``bounds[-1] = n_nodes``) cuts them anywhere — :func:`balanced_bounds` cuts by cost; without it the blocks have
+    ``ceil(n_nodes / world)`` rows each (what the all-gather of :func:`gather_operand` needs: equally sized shards)."""
     n_nodes: int
     world: int
     rank: int
+    bounds: Optional[tuple] = None
+
+    def __post_init__(self):
+        if self.bounds is not None:
+            b = tuple(int(v) for v in self.bounds)
+            if len(b) != self.world + 1 or b[0] != 0 or b[-1] != self.n_nodes or any(x > y for x, y in zip(b, b[1:])):
+                raise ValueError(f"bounds must be {self.world + 1} ascending node ids from 0 to {self.n_nodes}, got {b}")
+            self.bounds = b
+
+    @property
+    def uniform(self) -> bool:
+        return self.bounds is None
 
     @property
     def block(self) -> int:                      # rows per rank, padded so every shard has the same size
+        if self.bounds is not None:
+            raise ValueError("a partition cut by cost has no common block size (the all-gather variant needs equal blocks)")
         return -(-self.n_nodes // self.world)
 
     @property
     def lo(self) -> int:
+        if self.bounds is not None:
+            return self.bounds[self.rank]
         return min(self.rank * self.block, self.n_nodes)
 
     @property
     def hi(self) -> int:
+        if self.bounds is not None:
+            return self.bounds[self.rank + 1]
         return min(self.lo + self.block, self.n_nodes)
+
+    def owner_of(self, nodes: torch.Tensor) -> torch.Tensor:
+        """Rank that owns each of ``nodes`` (int64 global ids)."""
+        if self.bounds is None:
+            return torch.div(nodes, self.block, rounding_mode="floor")
+        edges = torch.tensor(self.bounds[1:-1], dtype=nodes.dtype, device=nodes.device)
+        return torch.bucketize(nodes, edges, right=True)
+
+    def lo_of(self, ranks: torch.Tensor) -> torch.Tensor:
+        """First node of each of ``ranks``' blocks."""
+        if self.bounds is None:
+            return ranks * self.block
+        return torch.tensor(self.bounds[:-1], dtype=ranks.dtype, device=ranks.device)[ranks]
+
+
+# What a row of a share costs next to one stored pair (halo-recompute / exchange shares, reference order): the look-up of the
+# row's F features against the aggregation of one pair's F-float operand row — 93 ps per 64-feature row against 40 ps per pair on
+# an MI355X (DESIGN.md section 4.1 / 4.2) — and every stored pair of an R-MAT share brings ~0.11 halo rows to look up as well.
+ROW_COST_IN_PAIRS = 2.3
+HALO_ROWS_PER_PAIR = 0.11
+
+
+def balanced_bounds(degree: torch.Tensor, world: int, row_cost: float = ROW_COST_IN_PAIRS,
+                    halo_rows_per_pair: float = HALO_ROWS_PER_PAIR) -> tuple:
+    """Cut ``[0, n)`` into ``world`` contiguous blocks of equal COST rather than equal row count: ``degree[i]`` stored pairs of
+    row ``i`` (self pair included) at one unit each, plus ``row_cost`` per owned row and per halo row the pairs drag in.
+    Equal row counts leave the slowest of eight R-MAT shares 2.4 % above the mean; this cut is within a few 1e-4 of it.
+    Index arithmetic in float64 on whatever device ``degree`` lives; every rank computes the same cut from the same degrees."""
+    n = int(degree.numel())
+    if world <= 1 or n == 0:
+        return (0, n) if world <= 1 else tuple([0] + [n] * world)
+    cost = degree.to(torch.float64) * (1.0 + row_cost * halo_rows_per_pair) + row_cost
+    cum = torch.cumsum(cost, 0)
+    targets = cum[-1] * torch.arange(1, world, dtype=torch.float64, device=degree.device) / world
+    cuts = (torch.searchsorted(cum, targets, right=False) + 1).clamp_(max=n).tolist()
+    return tuple([0] + [int(c) for c in cuts] + [n])
 
 
 def _hip_compute() -> Dict[str, Callable]:
@@ -314,11 +373,36 @@ def halo_recompute_forward(x_compact: torch.Tensor, plan: HaloPlan, stacked, lut
     if tables is not None:
         kw["tables"] = tables      # built ahead of time on a side stream (functional.TablePrefetch; inference loops)
     sum_first = order == "sum_first"
+    rc = out_channels if order == "reference" else 0
+    if (SPLIT_HALO_LOOKUP and compute is None and _communicates(part.world) and not torch.is_grad_enabled() and stacked is not None
+            and stacked.F % 16 == 0 and 0 < plan.n_own < plan.n_needed):
+        # inference: the OWNED rows' look-up first — the column sums are theirs alone — then the all-reduce of those 4*W bytes
+        # runs under the halo rows' look-up (more than half of a share's look-up work on an R-MAT graph) and has landed when the
+        # aggregation starts: it takes the real sums, one launch, no rest-term pass behind it.  Both look-ups write into one
+        # operand; the row views are kept per input matrix (the look-up's range hint is remembered per tensor object).
+        views = getattr(plan, "_row_views", None)
+        if views is None or views[0] is not x_compact:
+            views = plan._row_views = (x_compact, x_compact[: plan.n_own], x_compact[plan.n_own:])
+        width = stacked.C if sum_first else stacked.F * stacked.C
+        operand = torch.empty((plan.n_needed, width), dtype=operand_dtype, device=x_compact.device)
+        rows_own, rows_halo = operand[: plan.n_own], operand[plan.n_own:]
+        own, total = ops["feature_mlps"](views[1], stacked, sum_first, return_total=True, out=rows_own, **kw)
+        if own is not rows_own:                               # (a look-up that could not take the caller's rows)
+            rows_own.copy_(own)
+        work = dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        halo = ops["feature_mlps"](views[2], stacked, sum_first, out=rows_halo, **kw)
+        if halo is not rows_halo:
+            rows_halo.copy_(halo)
+        mark("fmlp")
+        work.wait()
+        mark("total")
+        Y = ops["aggregate"](plan.graph, operand, lut, use_cnt, s_total=total, reduce_channels=rc, total_rows=plan.n_own)
+        mark("spmm")
+        return Y
     # the column sums ride in the shape-function pass, restricted to the owned rows: they partition the nodes, so the
     # ranks' sums add up to the whole graph's without double counting
     operand, total = ops["feature_mlps"](x_compact, stacked, sum_first, return_total=True, total_rows=plan.n_own, **kw)
     mark("fmlp")
-    rc = out_channels if order == "reference" else 0
     if _communicates(part.world) and not torch.is_grad_enabled() and "rest_total_term" in ops:
         # inference: the aggregation does not wait for the all-reduce of the 256-byte column sums (tens of microseconds of
         # collective latency against ~0.6 ms of kernel on a 1/8 share) — it runs against zero sums, i.e. computes
@@ -391,14 +475,14 @@ def build_exchange_plan(graph_local, part: VertexPartition, group=None) -> Excha
     needs (one exchange of counts, one of index lists — once per graph).  Index work only, bit-exact."""
     plan = build_halo_plan(graph_local, part)
     world, dev = part.world, plan.halo.device
-    owner = torch.div(plan.halo, part.block, rounding_mode="floor")
+    owner = part.owner_of(plan.halo)
     recv_counts = torch.bincount(owner, minlength=world).tolist()
     if not _communicates(world):
         return ExchangePlan(plan, [None], recv_counts)
     counts = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
     all_counts = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts, group=group)              # all_counts[q][r]: rows rank q needs from rank r
-    want = list(torch.split(plan.halo - owner * part.block, recv_counts))    # per owner: ITS local indices, in my halo order
+    want = list(torch.split(plan.halo - part.lo_of(owner), recv_counts))     # per owner: ITS local indices, in my halo order
     asked = [torch.empty(int(all_counts[q][part.rank]), dtype=torch.int64, device=dev) for q in range(world)]
     _peer_exchange([w.contiguous() for w in want], asked, group)
     return ExchangePlan(plan, asked, recv_counts)
@@ -507,13 +591,17 @@ class SharePipeline:
         main.wait_stream(self.prefetch.side)
         with torch.no_grad():
             forward(first, None)                            # eager: table sizes become known (the speculative plan)
-        self.pending = [first, None]
+        # every build the captured look-ups consume is checked against the captured sizes on the SIDE stream, by the replay
+        # that made it (launch(..., guard)); the eager builds of the warm-ups likewise, so that no check is captured on the
+        # main stream between look-up and aggregation (7 us of a 0.9-ms share)
+        self.pending = [launch(0, self.guard), None]
+        main.wait_stream(self.prefetch.side)
         self.graphs = []
         for p in (0, 1):
             if p == 1:
                 # graph 1 looks up from set 1: an eager build of it for the warm-up forwards (what graph 0's CAPTURE left
                 # in pending[1] describes a build that has not run)
-                self.pending[1] = launch(1)
+                self.pending[1] = launch(1, self.guard)
                 main.wait_stream(self.prefetch.side)
 
             def fn(p=p):

@@ -206,7 +206,11 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         out = per.view(n, F, C).sum(dim=1)
         return (out, None) if want_total else out
     global _ROOM_RESULT
-    if sum_features and _ROOM_REQUEST and out_dtype == torch.float32:
+    width = C if sum_features else F * C
+    if (_OUT_BUFFER is not None and tuple(_OUT_BUFFER.shape) == (n, width) and _OUT_BUFFER.dtype == out_dtype
+            and _OUT_BUFFER.stride(1) == 1 and _OUT_BUFFER.device == x.device):
+        out = _OUT_BUFFER                          # the caller's rows (feature_mlps(out=...): one operand filled by several look-ups)
+    elif sum_features and _ROOM_REQUEST and out_dtype == torch.float32:
         # room behind the rows for the compact copy of the most listed nodes' rows (append_hot_rows): the aggregation then
         # gathers the copy into place instead of copying the whole operand into a larger buffer first (40 MB at 10M nodes)
         room = torch.empty((n + _ROOM_REQUEST, C), dtype=out_dtype, device=x.device)
@@ -269,6 +273,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
     return (out, total) if want_total else out
 
 
+_OUT_BUFFER = None            # feature_mlps(out=...): where the table look-up stores its result instead of a fresh tensor
 _ROOM_REQUEST = 0             # rows of room feature_mlps(room_rows=...) asks the table look-up to leave behind its [n, C] result
 _ROOM_RESULT = None           # (data_ptr of the result, the larger buffer it heads) of the last look-up that did
 CAPTURED_BUILDS = []          # (sizes a look-up was captured with, the stacked weights it tabulates) of the capture in progress
@@ -969,11 +974,19 @@ def _padded_stack(p: StackedMLP, Fp: int) -> StackedMLP:
 
 def feature_mlps(x: torch.Tensor, p: StackedMLP, sum_features: bool, return_total: bool = False,
                  out_dtype=torch.float32, total_rows: Optional[int] = None, pad_ok: bool = False, tables=None,
-                 room_rows: int = 0):
+                 room_rows: int = 0, out: Optional[torch.Tensor] = None):
     """See :func:`_feature_mlps`.  ``room_rows`` (with ``sum_features``): the ``[n, C]`` result may head a buffer with that
     many more rows — marked by its ``gnan_room`` attribute — which :func:`rho_aggregate` fills with the compact copy of the
-    most listed nodes' rows instead of copying the operand (``append_hot_rows``)."""
-    global _ROOM_REQUEST, _ROOM_RESULT
+    most listed nodes' rows instead of copying the operand (``append_hot_rows``).  ``out`` (inference, table path): rows of a
+    caller-owned operand the look-up writes into — the result IS ``out`` when the look-up could use it (same shape and dtype),
+    a fresh tensor otherwise (the caller checks ``res is out``)."""
+    global _ROOM_REQUEST, _ROOM_RESULT, _OUT_BUFFER
+    if out is not None:
+        _OUT_BUFFER = out
+        try:
+            return _feature_mlps(x, p, sum_features, return_total, out_dtype, total_rows, pad_ok, tables)
+        finally:
+            _OUT_BUFFER = None
     if not (room_rows and sum_features):
         return _feature_mlps(x, p, sum_features, return_total, out_dtype, total_rows, pad_ok, tables)
     _ROOM_REQUEST, _ROOM_RESULT = int(room_rows), None
@@ -1083,21 +1096,3 @@ class _GraphReadout(torch.autograd.Function):
 def graph_readout(Y: torch.Tensor) -> torch.Tensor:
     """``[N, C] -> [C, 1]`` (what ``forward`` of a graph task returns, GNAN.py:79)."""
     return _GraphReadout.apply(Y).view(-1, 1)
-
-
-# =============================================================================
-# moved: the aggregation lives in ``aggregate``, the loss step in ``losses``.  Reads of the old names still resolve (scripts
-# written against earlier rounds); their switches are module constants of the NEW modules — set them there.
-# =============================================================================
-_MOVED_TO_AGGREGATE = frozenset(['_Bag', '_NotShared', '_PreRhoAggregate', '_ReferenceOrderAggregate', '_RhoAggregate', '_aggregate_backward', '_spmm_args', 'add_rest_total_term', 'append_hot_rows', 'bwd_narrow_launch', 'lut_grad_launch', 'narrow_walk', 'pack_bwd_rows', 'pre_rho_aggregate', 'reference_order_applies', 'reference_order_forward', 'rest_total_term', 'rho_aggregate', 'shell_sums_launch', 'spmm_launch'])
-_MOVED_TO_LOSSES = frozenset(['_LossStep', '_loss_launch', 'loss_kind', 'loss_step'])
-
-
-def __getattr__(name):
-    if name in _MOVED_TO_AGGREGATE:
-        from . import aggregate
-        return getattr(aggregate, name)
-    if name in _MOVED_TO_LOSSES:
-        from . import losses
-        return getattr(losses, name)
-    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

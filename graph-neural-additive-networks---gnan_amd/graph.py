@@ -35,6 +35,36 @@ HOT_COLUMNS_MIN_NNZ = 1 << 24    # below this the two extra launches that fill t
 HOT_COLUMNS_MIN_SHARE = 0.15     # ... and so does a graph whose K most listed neighbours receive less than this share of the pairs
 
 
+PB_LDS_BYTES = 65536        # propagation-blocked narrow aggregation (csrc/spmm_pb.hip): LDS of a column block / of a bin's accumulators
+PB_SLOT_PAIRS = 512         # ... entries per accumulator slot: a row with more owns several (no LDS address is hit by a whole wavefront)
+PB_CHUNK = 16               # ... tiles are padded to whole chunks of this many entries
+
+
+@dataclass
+class PbPlan:
+    """The listed pairs of a CSR graph bucketed into (row bin, column block) tiles for ``gnan_spmm_pb_fwd`` (see
+    ``include/gnan_hip.h``): static index work, built once per graph and operand width."""
+    W: int
+    n_entries: int
+    src: torch.Tensor             # int16 [n_entries]
+    dst: torch.Tensor             # int16 [n_entries]
+    cb_width: int
+    n_cblocks: int
+    chunk_q: torch.Tensor         # int32 [n_chunks], column-block-major
+    cb_chunk_ptr: torch.Tensor    # int32 [n_cblocks + 1]
+    n_bins: int
+    acc_per_bin: int
+    bin_order: torch.Tensor       # int32 [n_bins], largest first
+    bin_entry_ptr: torch.Tensor   # int32 [n_bins + 1]
+    bin_row_ptr: torch.Tensor     # int32 [n_bins + 1]
+    slot_ptr: torch.Tensor        # int32 [n_rows + 1]
+    n_acc: int
+    code_base: int
+    self_col: Optional[torch.Tensor]   # int32 [n_rows] or None
+    headroom_bits: int
+    n_pairs: int                  # real entries (without pads and without the pairs self_col serves)
+
+
 @dataclass
 class LongRowPlan:
     """Hub rows of a CSR graph, cut into fixed-size slices (deterministic reduction order)."""
@@ -67,6 +97,7 @@ class HopGraph:
     _sorted_copy_hot: Optional["HopGraph"] = field(default=None, repr=False)
     _hot_head_share: Optional[dict] = field(default=None, repr=False)   # share of the pairs listing the first K hot neighbours
     _inv_rest: Optional[torch.Tensor] = field(default=None, repr=False)
+    _pb_plans: dict = field(default_factory=dict, repr=False)       # pb_plan(): operand width -> PbPlan or None
     _cnt_by_col: bool = field(default=False, repr=False)     # transposed graphs: ``cnt`` rows belong to the neighbours
 
     @property
@@ -256,6 +287,109 @@ class HopGraph:
             hit = self._dense_plans[key] = LongRowPlan(rows, ptr, n_out, n_out * spr, threshold=0)
         return hit
 
+    def pb_plan(self, W: int = 1) -> Optional["PbPlan"]:
+        """Bucketed copy of the adjacency for the propagation-blocked narrow aggregation (``gnan_spmm_pb_fwd``), or None where
+        it does not apply (dense layout, no listed code besides the self pair's, 2^31 entries or more, a row too long for a bin).
+
+        Index work only, bit-exact, on whatever device the graph lives (the CPU suite checks it against the oracle).  A row
+        with more than ``PB_SLOT_PAIRS`` entries owns ``ceil(deg / PB_SLOT_PAIRS)`` accumulator slots and its entries are dealt
+        over them round-robin; rows go to bins in order, a bin holding as many slots as fit its LDS; within a bin the entries
+        are grouped by column block (as many operand rows as fit the expand kernel's LDS), every group padded to whole chunks.
+        The pair with hop code 0 of every row (its self pair; at most one per row) is left out and served from ``self_col``."""
+        if W in self._pb_plans:
+            return self._pb_plans[W]
+        plan = None if self.is_dense else self._build_pb_plan(int(W))
+        self._pb_plans[W] = plan
+        return plan
+
+    def _build_pb_plan(self, W: int) -> Optional["PbPlan"]:
+        dev, n, D = self.device, self.n_rows, self.n_codes
+        nnz = self.nnz
+        if W not in (1, 2, 4) or D < 2 or D > 4 or n == 0 or nnz == 0 or nnz + PB_CHUNK * 64 >= 2 ** 31:
+            return None
+        R = PB_LDS_BYTES // (8 * W)                 # accumulators (W-vectors of int64) per bin; the last one is the pads' dummy
+        cbw = PB_LDS_BYTES // (4 * W)               # operand rows per column block
+        i64 = dict(dtype=torch.int64, device=dev)
+        rowptr = self.rowptr.to(torch.int64)
+        deg = rowptr[1:] - rowptr[:-1]
+        row = torch.repeat_interleave(torch.arange(n, **i64), deg)
+        col = self.col.to(torch.int64)
+        code = self.code.to(torch.int64)
+        self_col, code_base, n_acc = None, 0, D - 1
+        if D >= 3:
+            is0 = code == 0
+            rows0 = row[is0]
+            if rows0.numel() == 0 or int(torch.bincount(rows0, minlength=n).max()) <= 1:
+                self_col = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                self_col[rows0] = col[is0].to(torch.int32)
+                keep = ~is0
+                row, col, code = row[keep], col[keep], code[keep]
+                code_base, n_acc = 1, D - 2
+                del keep
+            del is0, rows0
+        m = int(row.numel())
+        if m == 0:
+            return None
+        a = code - code_base
+        del code
+        deg2 = torch.bincount(row, minlength=n)
+        nslot = ((deg2 + PB_SLOT_PAIRS - 1) // PB_SLOT_PAIRS).clamp_(min=1)
+        slot_ptr = torch.zeros(n + 1, **i64)
+        slot_ptr[1:] = torch.cumsum(nslot, 0)
+        slots_per_bin = (R - 1) // n_acc
+        eff = slots_per_bin - int(nslot.max())     # a row's slots never straddle two bins: rows are assigned by their FIRST slot
+        if eff < slots_per_bin // 2:
+            return None
+        bin_of_row = slot_ptr[:-1] // eff
+        n_bins = int(bin_of_row[-1]) + 1
+        bin_row_ptr = torch.searchsorted(bin_of_row, torch.arange(n_bins + 1, **i64))
+        bin_slot0 = slot_ptr[bin_row_ptr[:-1]]
+        rowptr2 = torch.zeros(n + 1, **i64)
+        rowptr2[1:] = torch.cumsum(deg2, 0)
+        k = torch.arange(m, **i64) - rowptr2[row]
+        b = bin_of_row[row]
+        dst = (slot_ptr[row] + k % nslot[row] - bin_slot0[b]) * n_acc + a
+        del k, a, rowptr2
+        n_cb = -(-self.n_cols // cbw)
+        cb = torch.div(col, cbw, rounding_mode="floor")
+        srcl = col - cb * cbw
+        tile = b * n_cb + cb
+        del b, cb, col, row
+        tile_s, order = torch.sort(tile, stable=True)
+        del tile
+        n_tiles = n_bins * n_cb
+        tile_cnt = torch.bincount(tile_s, minlength=n_tiles)
+        padded = (tile_cnt + PB_CHUNK - 1) // PB_CHUNK * PB_CHUNK
+        tile_ptr = torch.zeros(n_tiles + 1, **i64)
+        tile_ptr[1:] = torch.cumsum(padded, 0)
+        n_entries = int(tile_ptr[-1])
+        if n_entries >= 2 ** 31:
+            return None
+        start = torch.zeros(n_tiles + 1, **i64)
+        start[1:] = torch.cumsum(tile_cnt, 0)
+        pos = tile_ptr[tile_s] + (torch.arange(m, **i64) - start[tile_s])
+        del tile_s, start
+        src16 = torch.zeros(n_entries, dtype=torch.int16, device=dev)
+        dst16 = torch.full((n_entries,), R - 1, dtype=torch.int16, device=dev)
+        src16[pos] = srcl[order].to(torch.int16)
+        dst16[pos] = dst[order].to(torch.int16)
+        del pos, order, srcl, dst
+        bin_entry_ptr = tile_ptr[torch.arange(n_bins + 1, **i64) * n_cb]
+        chunks = (padded // PB_CHUNK).view(n_bins, n_cb).t().contiguous().view(-1)        # column-block-major
+        starts = tile_ptr[:-1].view(n_bins, n_cb).t().contiguous().view(-1)
+        first = torch.zeros(chunks.numel() + 1, **i64)
+        first[1:] = torch.cumsum(chunks, 0)
+        n_chunks = int(first[-1])
+        chunk_q = torch.repeat_interleave(starts - first[:-1] * PB_CHUNK, chunks) + torch.arange(n_chunks, **i64) * PB_CHUNK
+        cb_chunk_ptr = first[torch.arange(n_cb + 1, **i64) * n_bins]
+        bin_order = torch.argsort(bin_entry_ptr[1:] - bin_entry_ptr[:-1], descending=True, stable=True)
+        headroom = max(1, int(deg2.max()) - 1).bit_length()
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        return PbPlan(W=W, n_entries=n_entries, src=src16, dst=dst16, cb_width=cbw, n_cblocks=n_cb, chunk_q=i32(chunk_q),
+                      cb_chunk_ptr=i32(cb_chunk_ptr), n_bins=n_bins, acc_per_bin=R, bin_order=i32(bin_order),
+                      bin_entry_ptr=i32(bin_entry_ptr), bin_row_ptr=i32(bin_row_ptr), slot_ptr=i32(slot_ptr), n_acc=n_acc,
+                      code_base=code_base, self_col=self_col, headroom_bits=headroom, n_pairs=m)
+
     def inv_rest_count(self) -> torch.Tensor:
         """``1 / max(cnt[:, D-1], 1)`` as float32 ``[n_rows, 1]`` (graph data, cached): the normalisation of the rest bucket."""
         if self._inv_rest is None:
@@ -377,9 +511,12 @@ class HopGraph:
         return self._sorted_copy_hot, order, hot
 
     def degree_schedule(self):
-        """Rows sorted by number of listed pairs (stable) and the hub-row plan in that order — the processing
+        """Rows sorted by number of listed pairs (stable, shortest first) and the hub-row plan in that order — the processing
         schedule of the aggregation kernel: the 4..32 rows that share a wavefront then have (almost) equal
-        lengths, so no lane group idles while a neighbour finishes a longer row.  Cached per graph."""
+        lengths, so no lane group idles while a neighbour finishes a longer row.  (Longest first — so that the workgroups
+        dispatched last hold the shortest rows — was measured in round 6 and LOSES: whole graph W = 64 4.45 -> 4.55 ms,
+        W = 1 0.89 -> 1.07 ms, a 1/8 share 0.911 -> 0.916 ms: the hub-row slices of the same launch already start first, and
+        the short rows' scattered stores then land in a burst at the end.)  Cached per graph."""
         if self._degree_order is None:
             deg = (self.rowptr[1:] - self.rowptr[:-1])
             self._degree_order = torch.argsort(deg, stable=True).to(torch.int32)

@@ -537,7 +537,7 @@ class StandaloneTensorGNAN(_PathBase):
         self._mark("fmlp")
         if self.normalize_rho:
             # GNAN.py:65-67: rho(node_distances / normalization_matrix) — rho's exact table, D look-ups per row, in the
-            # order the aggregation walks the rows (functional.pre_rho_aggregate)
+            # order the aggregation walks the rows (aggregate.pre_rho_aggregate)
             from .aggregate import pre_rho_aggregate
             Y = pre_rho_aggregate(g, S, self._stacked("rho", [self.rho]), hop_inputs(g.n_codes, g.device), s_total=total)
         else:

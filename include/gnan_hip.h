@@ -26,7 +26,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the functions declared in this header are exported */
 #pragma GCC visibility push(default)
 
-#define GNAN_ABI_VERSION 44
+#define GNAN_ABI_VERSION 45
 
 typedef void* gnan_stream_t; /* hipStream_t */
 
@@ -475,6 +475,69 @@ typedef struct gnan_spmm_args {
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
 int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream);
+
+/* -------------------------------------------------------------------------------------------
+ * gnan_spmm_pb_fwd — the same neighbourhood sum as gnan_spmm_fwd for NARROW fp32 operand rows (W in {1, 2, 4}: the
+ * sum-first order of GNAN.py:157-170, S = f_sums), global weight table (Cw == 1, D <= 4), CSR layout, every output row, from
+ * a bucketed copy of the adjacency the caller builds once per graph (gnan_amd.graph.HopGraph.pb_plan — index work only):
+ *
+ *   entries      the listed pairs that carry hop codes [code_base, code_base + n_acc), grouped into tiles
+ *                (row bin, column block), bin-major, every tile padded to whole chunks of 16 entries;
+ *                src[q] = operand row inside its column block (cb_width rows per block, cb_width * W * 4 <= 65536),
+ *                dst[q] = accumulator inside its bin = (slot of the row inside the bin) * n_acc + (code - code_base);
+ *                pad entries: src 0, dst acc_per_bin - 1 (a dummy the plan never assigns)
+ *   chunk_q      entry offset of every chunk, COLUMN-BLOCK-major (cb_chunk_ptr [n_cblocks + 1] delimits the blocks)
+ *   bins         bin b owns entries [bin_entry_ptr[b], bin_entry_ptr[b + 1]) and rows [bin_row_ptr[b], bin_row_ptr[b + 1]);
+ *                row i owns the accumulator slots [slot_ptr[i], slot_ptr[i + 1]) (a hub row several: its entries are dealt
+ *                over them), numbered from slot_ptr[first row of the bin]; at most (acc_per_bin - 1) / n_acc slots per
+ *                bin, acc_per_bin * W * 8 <= 65536; bin_order lists the bins in launch order (largest first)
+ *   self_col     optional [n_rows]: the operand row of the row's ONE pair with hop code 0 (-1: none) when those pairs are
+ *                left out of the entries (code_base = 1)
+ *   headroom_bits  ceil(log2(most entries any single output row receives)): sizes the 64-bit fixed point
+ *
+ * Y[i, :] = sum_d (wt(i,d) - wt(i,D-1)) * sum_{pairs of row i with code d} S[col, :]  +  wt(i,D-1) * s_total
+ * (wt(i,d) = lut[d] / max(cnt[i,d], 1); without s_total the rest weight is zero), i.e. gnan_spmm_fwd's result with the
+ * per-code sums exact to 2^-40 of max |S| (integer accumulation: order-independent, bit-reproducible) instead of a
+ * float32 chain.  No listed pair costs a memory request of its own: see csrc/spmm_pb.hip.
+ * workspace: gnan_spmm_pb_workspace_bytes(a) bytes, 16-byte aligned (the expanded operand, n_entries * W floats).
+ * A non-finite operand value yields NaN in every output row.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gnan_spmm_pb_args {
+  int64_t n_rows;
+  int64_t n_cols;
+  const float* S;            /* [n_cols, W] fp32, contiguous rows */
+  int64_t s_stride;          /* == W */
+  int32_t W;
+  int32_t D;                 /* hop codes incl. the rest bucket */
+  const float* lut;          /* [D] */
+  const int32_t* cnt;        /* optional [n_rows, cnt_stride] */
+  int64_t cnt_stride;
+  const float* s_total;      /* optional [W] */
+  float* Y;                  /* [n_rows, y_stride] */
+  int64_t y_stride;
+  int64_t n_entries;
+  const uint16_t* src;       /* [n_entries] */
+  const uint16_t* dst;       /* [n_entries], 8-byte aligned */
+  int32_t cb_width;
+  int32_t n_cblocks;
+  const int32_t* chunk_q;
+  const int32_t* cb_chunk_ptr;
+  int32_t n_bins;
+  int32_t acc_per_bin;
+  const int32_t* bin_order;
+  const int32_t* bin_entry_ptr;
+  const int32_t* bin_row_ptr;
+  const int32_t* slot_ptr;   /* [n_rows + 1] */
+  int32_t n_acc;
+  int32_t code_base;
+  const int32_t* self_col;
+  int32_t headroom_bits;
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_spmm_pb_args;
+
+size_t gnan_spmm_pb_workspace_bytes(const gnan_spmm_pb_args* a);
+int gnan_spmm_pb_fwd(const gnan_spmm_pb_args* a, gnan_stream_t stream);
 
 /* Shell sums for the backward pass (autograd through GNAN.py:67-70 w.r.t. rho's parameters):
  *   T[q, d, w] = sum_{e in row, code_e == d} S[col_e, w]            d < D-1

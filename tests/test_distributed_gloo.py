@@ -137,13 +137,19 @@ def _halo_compute(sd, C):
     return {**base, "aggregate": aggregate}
 
 
-def _halo_worker(rank, world, port, n, F, C, order, out_dir, overlap=False):
+def _cut(n, world, rank, src, cut):
+    """Equal row counts, or blocks of equal cost (what bench.py cuts the halo / exchange partitions by)."""
+    from gnan_amd.distributed import balanced_bounds
+    return VertexPartition(n, world, rank, balanced_bounds(torch.bincount(src, minlength=n) + 1, world) if cut == "cost" else None)
+
+
+def _halo_worker(rank, world, port, n, F, C, order, out_dir, overlap=False, cut="rows"):
     from gnan_amd.distributed import build_halo_plan, halo_recompute_forward
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         src, dst, x, sd = _problem(n, F, C)
-        part = VertexPartition(n, world, rank)
+        part = _cut(n, world, rank, src, cut)
         g = syn.hop1_csr(src, dst, n, part.lo, part.hi)
         plan = build_halo_plan(g, part)
         ids = plan.node_ids()
@@ -165,14 +171,15 @@ def _halo_worker(rank, world, port, n, F, C, order, out_dir, overlap=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,order,overlap", [(2, 300, "reference", False), (3, 301, "reference", False),
-                                                   (2, 300, "sum_first", False), (2, 300, "reference", True),
-                                                   (3, 301, "sum_first", True)])
-def test_halo_recompute_forward_equals_single_process(world, n, order, overlap, tmp_path):
+@pytest.mark.parametrize("world,n,order,overlap,cut", [(2, 300, "reference", False, "rows"), (3, 301, "reference", False, "rows"),
+                                                       (2, 300, "sum_first", False, "rows"), (2, 300, "reference", True, "rows"),
+                                                       (3, 301, "sum_first", True, "rows"), (3, 301, "reference", False, "cost"),
+                                                       (2, 300, "reference", True, "cost")])
+def test_halo_recompute_forward_equals_single_process(world, n, order, overlap, cut, tmp_path):
     F, C = 5, 1
     port = _free_port()
-    mp.spawn(_halo_worker, args=(world, port, n, F, C, order, str(tmp_path), overlap), nprocs=world, join=True)
-    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    mp.spawn(_halo_worker, args=(world, port, n, F, C, order, str(tmp_path), overlap, cut), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])   # blocks in rank order, whatever their sizes
     src, dst, x, sd = _problem(n, F, C)
     g = syn.hop1_csr(src, dst, n)
     S = O.feature_mlps(x, sd).sum(1)
@@ -194,7 +201,7 @@ def _grad_worker(rank, world, port, n, F, partition, order, out_dir):
     import cpu_kernels
     from gnan_amd.distributed import (FeaturePartition, build_halo_plan, feature_parallel_forward, halo_recompute_forward,
                                       slice_features)
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cpu_kernels.install()
@@ -266,10 +273,10 @@ def test_multi_rank_backward_adds_up_to_the_single_process_gradient(world, n, pa
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
-def _exchange_worker(rank, world, port, n, F, order, out_dir, with_grad):
+def _exchange_worker(rank, world, port, n, F, order, out_dir, with_grad, cut="rows"):
     import cpu_kernels
     from gnan_amd.distributed import build_exchange_plan, halo_exchange_forward
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cpu_kernels.install()
@@ -277,7 +284,7 @@ def _exchange_worker(rank, world, port, n, F, order, out_dir, with_grad):
         src, dst, x, sd = _grad_problem(n, F)
         leaves = {k: v.clone().requires_grad_(with_grad) for k, v in sd.items()}
         lut = O.rho_lut(leaves, 3, dtype=torch.float64).float()
-        part = VertexPartition(n, world, rank)
+        part = _cut(n, world, rank, src, cut)
         g = syn.hop1_csr(src, dst, n, part.lo, part.hi)
         xplan = build_exchange_plan(g, part)
         # index work is bit-exact: what a rank is asked to send is what the asker's halo lists, in the asker's order
@@ -304,13 +311,14 @@ def _exchange_worker(rank, world, port, n, F, order, out_dir, with_grad):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,order", [(2, 120, "sum_first"), (3, 121, "reference"), (4, 90, "sum_first")])
-def test_halo_exchange_forward_and_backward_equal_single_process(world, n, order, tmp_path):
+@pytest.mark.parametrize("world,n,order,cut", [(2, 120, "sum_first", "rows"), (3, 121, "reference", "rows"), (4, 90, "sum_first", "rows"),
+                                               (3, 121, "reference", "cost"), (4, 90, "sum_first", "cost")])
+def test_halo_exchange_forward_and_backward_equal_single_process(world, n, order, cut, tmp_path):
     """Only the listed remote operand rows travel (point-to-point all-to-all-v); forward == single process, and the sum
     over the ranks of the parameter gradients == the single-process gradient (the exchange runs in reverse in backward)."""
     F = 4
     port = _free_port()
-    mp.spawn(_exchange_worker, args=(world, port, n, F, order, str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_exchange_worker, args=(world, port, n, F, order, str(tmp_path), True, cut), nprocs=world, join=True)
     src, dst, x, sd = _grad_problem(n, F)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     g = syn.hop1_csr(src, dst, n)
@@ -343,3 +351,35 @@ def test_partition_arithmetic():
         assert parts[0].lo == 0 and parts[-1].hi == n
         assert all(a.hi == b.lo for a, b in zip(parts, parts[1:]))
         assert all(p.hi - p.lo <= p.block for p in parts)
+
+
+def test_blocks_of_equal_cost():
+    """distributed.balanced_bounds: contiguous blocks, every node in exactly one, costs within a row of the mean; the partition
+    answers ownership queries from the same bounds; the all-gather variant refuses an unequal cut."""
+    from gnan_amd.distributed import ROW_COST_IN_PAIRS, HALO_ROWS_PER_PAIR, balanced_bounds
+    gen = torch.Generator().manual_seed(0)
+    n, world = 5000, 8
+    deg = (torch.rand(n, generator=gen) ** -1.2).long().clamp_(max=900) + 1            # heavy-tailed
+    bounds = balanced_bounds(deg, world)
+    assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == n and all(a < b for a, b in zip(bounds, bounds[1:]))
+    cost = deg.double() * (1 + ROW_COST_IN_PAIRS * HALO_ROWS_PER_PAIR) + ROW_COST_IN_PAIRS
+    shares = [float(cost[a:b].sum()) for a, b in zip(bounds, bounds[1:])]
+    mean = sum(shares) / world
+    assert max(abs(s_ - mean) for s_ in shares) <= float(cost.max()) + 1e-9          # off by at most one row's cost
+    rows = [b - a for a, b in zip(bounds, bounds[1:])]
+    assert max(rows) > min(rows)                                                      # ... which equal row counts are not
+    parts = [VertexPartition(n, world, r, bounds) for r in range(world)]
+    assert [(p.lo, p.hi) for p in parts] == list(zip(bounds, bounds[1:])) and not parts[0].uniform
+    nodes = torch.arange(n)
+    owner = parts[0].owner_of(nodes)
+    for r, p in enumerate(parts):
+        assert bool((owner[p.lo:p.hi] == r).all())
+    assert torch.equal(nodes - parts[0].lo_of(owner), torch.cat([torch.arange(b - a) for a, b in zip(bounds, bounds[1:])]))
+    with pytest.raises(ValueError):
+        parts[0].block
+    with pytest.raises(ValueError):
+        VertexPartition(n, world, 0, (0, 10, 5) + bounds[3:])
+    assert balanced_bounds(deg, 1) == (0, n)
+    assert balanced_bounds(torch.ones(3, dtype=torch.int64), 8)[-1] == 3            # more ranks than nodes: empty blocks allowed
+    uni = VertexPartition(10, 3, 1)
+    assert uni.uniform and torch.equal(uni.owner_of(torch.arange(10)), torch.arange(10) // 4)

@@ -204,7 +204,8 @@ def c5():
 
 
 def test_c5_papers100m_shaped_bf16(c5):
-    from gnan_amd.functional import feature_mlps, rho_aggregate, spmm_launch
+    from gnan_amd.functional import feature_mlps
+    from gnan_amd.aggregate import rho_aggregate, spmm_launch
     N, g, x, st, lut = c5
     assert g.nnz == 111_059_956 + 1_615_685_872 and g.nnz * 4 > 2 ** 32      # byte offsets of the index arrays exceed 32 bits
     with torch.no_grad():
@@ -240,7 +241,8 @@ def test_more_than_2_31_listed_pairs(monkeypatch):
     whose slices start beyond pair 2^31."""
     import gnan_amd  # noqa: F401
     from gnan_amd import HopGraph, functional
-    from gnan_amd.functional import column_sums, spmm_launch
+    from gnan_amd.functional import column_sums
+    from gnan_amd.aggregate import spmm_launch
     N = 30_000_000
     ar = torch.arange(N, device=DEV)
     deg = 50 + (ar % 51)

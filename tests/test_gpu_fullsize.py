@@ -36,7 +36,8 @@ def c4():
 
 
 def test_full_size_sampled_rows_against_the_oracle(c4):
-    from gnan_amd.functional import feature_mlps, rho_aggregate
+    from gnan_amd.functional import feature_mlps
+    from gnan_amd.aggregate import rho_aggregate
     g, x, st, sd, lut = c4
     with torch.no_grad():
         S, total = feature_mlps(x, st, False, return_total=True)             # [N, 64]
@@ -64,7 +65,8 @@ def test_full_size_sampled_rows_against_the_oracle(c4):
 
 
 def test_full_size_reference_order_equals_sum_first(c4):
-    from gnan_amd.functional import feature_mlps, rho_aggregate
+    from gnan_amd.functional import feature_mlps
+    from gnan_amd.aggregate import rho_aggregate
     g, x, st, sd, lut = c4
     with torch.no_grad():
         S, total = feature_mlps(x, st, False, return_total=True)
@@ -76,7 +78,7 @@ def test_full_size_reference_order_equals_sum_first(c4):
 
 
 def test_full_size_adjoint_linearity_and_row_subsets(c4):
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     g, x, st, sd, lut = c4
     gen = torch.Generator(device=DEV).manual_seed(3)
     W = 8
@@ -102,7 +104,8 @@ def test_full_size_training_step_gradients(c4, monkeypatch):
     gnan_fpwl_param_grads == the torch route's (probe points, float64); (ii) a directional derivative of the loss along a
     random parameter direction, by central differences of two more forwards, matches <grad, direction>."""
     from gnan_amd import functional
-    from gnan_amd.functional import feature_mlps, rho_aggregate
+    from gnan_amd.functional import feature_mlps
+    from gnan_amd.aggregate import rho_aggregate
     g, x, st, sd, lut = c4
     target = torch.randn(N, 1, generator=torch.Generator(device=DEV).manual_seed(9), device=DEV)
 

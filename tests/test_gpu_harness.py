@@ -152,7 +152,7 @@ def test_fused_loss_step_matches_torch(kind, n_rows, C, masked):
     same rows; strided logits, float64 truth for the loss."""
     _need_gpu()
     from gnan_amd import _lib
-    from gnan_amd.functional import loss_kind, loss_step
+    from gnan_amd.losses import loss_kind, loss_step
     g = torch.Generator().manual_seed(n_rows + C)
     wide = (torch.randn(n_rows, C + 2, generator=g) * 3).to(DEV)
     logits = wide[:, 1:1 + C].clone().requires_grad_(True)                      # contiguous leaf ...
@@ -194,7 +194,7 @@ def test_fused_loss_step_matches_torch(kind, n_rows, C, masked):
 
 def test_fused_loss_step_declines_other_losses():
     _need_gpu()
-    from gnan_amd.functional import loss_kind
+    from gnan_amd.losses import loss_kind
     x1, x4 = torch.zeros(3, 1, device=DEV), torch.zeros(3, 4, device=DEV)
     assert loss_kind(torch.nn.MSELoss(), x1) is None
     assert loss_kind(torch.nn.BCEWithLogitsLoss(pos_weight=torch.ones(1, device=DEV)), x1) is None

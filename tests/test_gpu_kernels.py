@@ -143,7 +143,7 @@ def _cnt_np(rowptr, code, n_cols, D):
 @pytest.mark.parametrize("W,Cw", [(1, 1), (3, 1), (3, 3), (7, 7), (8, 1), (40, 40), (40, 8), (64, 1), (100, 1), (300, 1)])
 @pytest.mark.parametrize("K,use_cnt,per_row", [(1, True, False), (2, False, False), (5, True, False), (1, False, True)])
 def test_spmm_csr_vs_oracle(W, Cw, K, use_cnt, per_row):
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(W * 10 + K)
     n_rows, n_cols, D = 301, 257, K + 2
     rowptr, col, code = _random_csr(n_rows, n_cols, K, rng, hubs=[(5, 700), (17, 2500)])
@@ -161,7 +161,7 @@ def test_spmm_csr_vs_oracle(W, Cw, K, use_cnt, per_row):
 
 def test_spmm_row_subset_and_dense_equals_csr():
     from gnan_amd import HopGraph
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(7)
     n, D, W = 90, 6, 5
     hops = rng.integers(-1, D - 1, (n, n)).astype(np.int32)          # -1 = unreachable
@@ -188,7 +188,7 @@ def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
     """Cora-sized dense inputs: every row cut into column slices (dense_slice_plan) == one lane group per row (the
     arithmetic differs only in summation order) == the oracle; row subsets, transposed use and gradients included."""
     from gnan_amd import HopGraph, functional
-    from gnan_amd.functional import rho_aggregate, spmm_launch
+    from gnan_amd.aggregate import rho_aggregate, spmm_launch
     rng = np.random.default_rng(n + W)
     D = 7
     hops = rng.integers(-1, D - 1, (n, n)).astype(np.int32)
@@ -225,7 +225,7 @@ def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
 
 def test_spmm_is_linear_in_the_operand_at_scale():
     """Size-independent property at a size the oracle cannot reach: A(aS1 + S2) == a A S1 + A S2."""
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(11)
     n, K, W = 200_000, 1, 64
     deg = np.minimum(rng.zipf(1.8, n), 50_000)
@@ -245,7 +245,7 @@ def test_spmm_is_linear_in_the_operand_at_scale():
 
 
 def test_empty_inputs():
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     g = _graph(np.zeros(1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0, np.uint8), 5, 3)
     y = spmm_launch(g, torch.randn(5, 4, device=DEV), torch.randn(3, 1, device=DEV), True, True)
     assert y.shape == (0, 4)
@@ -254,7 +254,7 @@ def test_empty_inputs():
 @pytest.mark.parametrize("per_row,use_cnt,Cw", [(False, True, 1), (False, False, 3), (True, False, 3)])
 def test_rho_aggregate_gradients_vs_autograd_oracle(per_row, use_cnt, Cw):
     """Backward kernels (transposed SpMM + shell sums) vs torch autograd through the oracle, in float64."""
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     rng = np.random.default_rng(5)
     n, K, W = 120, 2, 6
     D = K + 2
@@ -340,7 +340,7 @@ def test_column_sums(n, W):
 def test_hub_rows_with_many_slices(W, cr):
     """Hub rows of 20 and 41 slices: the fix-up kernel's eight-loads-at-a-time loop, its slice lanes for operands narrower
     than a wave (W = 1, 8, 24) and its column passes for wider ones (W = 320), with and without the fused feature sum."""
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(1000 + W * 3 + cr)
     n_rows, n_cols, K = 64, 5000, 1
     D = K + 2
@@ -364,7 +364,7 @@ def test_hub_rows_with_many_slices(W, cr):
 def test_rest_bucket_total_can_be_added_afterwards(W, Cw, cr, per_row, use_cnt):
     """aggregate(total) == aggregate(zero sums) + rest_total_term(total): what lets a multi-rank forward overlap the
     all-reduce of the column sums with the aggregation (rows, hub slices, fused read-out, per-row tables)."""
-    from gnan_amd.functional import rest_total_term, spmm_launch
+    from gnan_amd.aggregate import rest_total_term, spmm_launch
     rng = np.random.default_rng(500 + W + Cw + cr)
     n, K = 700, 1
     D = K + 2
@@ -384,7 +384,7 @@ def test_rest_bucket_total_can_be_added_afterwards(W, Cw, cr, per_row, use_cnt):
 def test_fused_feature_sum_equals_unfused(W, cr):
     """reduce_cr: per-channel sums over the operand columns in the kernel epilogue (rows, hub slices, dense)."""
     from gnan_amd import HopGraph
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(W * 7 + cr)
     n, K = 400, 2
     D = K + 2
@@ -408,7 +408,7 @@ def test_fused_feature_sum_equals_unfused(W, cr):
 
 
 def test_fused_feature_sum_gradients():
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     rng = np.random.default_rng(3)
     n, K, F, C = 150, 1, 5, 2
     rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(2, 700)])
@@ -971,7 +971,7 @@ def test_table_build_kernel_degenerate_weights():
 def test_fused_table_gradient_equals_shell_sums_route(W, dyc, use_cnt, with_rest):
     """gnan_spmm_lut_grad (one pass, no [n, D, W] tensor) == shell sums contracted with dY in float64, for rows, hub
     rows, row subsets, the broadcast gradient of the fused read-out (dy_channels < W) and both reduction modes."""
-    from gnan_amd.functional import lut_grad_launch, shell_sums_launch
+    from gnan_amd.aggregate import lut_grad_launch, shell_sums_launch
     rng = np.random.default_rng(W * 3 + dyc)
     n, K = 3000, 2
     D = K + 2
@@ -1005,7 +1005,7 @@ def test_dense_table_gradient_in_one_pass(n, D, W, dyc, use_cnt, monkeypatch):
     bit-reproducible — and rho_aggregate's backward through it == the shell-sum route == float64 oracle autograd, with the
     operand gradient of small dense graphs read from (lut, cnt) per pair instead of a per-node weight table."""
     from gnan_amd import HopGraph, functional
-    from gnan_amd.functional import lut_grad_launch, rho_aggregate, shell_sums_launch
+    from gnan_amd.aggregate import lut_grad_launch, rho_aggregate, shell_sums_launch
     rng = np.random.default_rng(n + D)
     hops = rng.integers(-1, D - 1, (n, n)).astype(np.int32)          # -1 = unreachable: the last code
     hops[np.arange(n), np.arange(n)] = 0
@@ -1057,7 +1057,7 @@ def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, m
     two-pass route (pre-weighted gather + gnan_spmm_lut_grad) == autograd through the float64 oracle; hub columns (sliced
     rows of the transposed graph), empty rows, padded widths; bit-reproducible."""
     from gnan_amd import functional
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     rng = np.random.default_rng(W * 11 + K)
     n, D = 3000, K + 2
     rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 2500)])
@@ -1091,7 +1091,7 @@ def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, m
 def test_packed_backward_rows_kernel(W, D, use_cnt, with_rest):
     """gnan_spmm_pack_bwd_rows == the slicing restatement (tests/cpu_kernels.py): [dY / cnt(i, d) | dY / cnt(i, rest)],
     zero padded halves, strided gradient rows, counts of 0 treated as 1; empty input."""
-    from gnan_amd.functional import pack_bwd_rows
+    from gnan_amd.aggregate import pack_bwd_rows
     import cpu_kernels
     rng = np.random.default_rng(W * 7 + D)
     n = 4097
@@ -1121,7 +1121,7 @@ def test_packed_backward_rows_of_large_one_channel_graphs(n, D, with_rest, n_hot
     """From 2^20 nodes on, one-channel gradients with shell counts are packed two nodes per thread (pack_bwd_pairs_kernel: 8-byte
     count loads, 16-byte stores) when every code's block starts 16-byte aligned, the odd tail and the hot copies by the one-node
     kernel: same bits as the slicing restatement either way (odd n + n_hot: the one-node kernel alone)."""
-    from gnan_amd.functional import pack_bwd_rows
+    from gnan_amd.aggregate import pack_bwd_rows
     import cpu_kernels
     rng = np.random.default_rng(n % 1000 + D)
     dY = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
@@ -1146,7 +1146,7 @@ def test_fused_narrow_backward_walks_sorted_copy_with_hot_columns(W, K, with_res
     the natural-order call: operand gradient bit for bit, table gradient to float64 round-off (its partials are added in
     processing order); both == float64 oracle autograd."""
     from gnan_amd import functional, graph as G
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     rng = np.random.default_rng(W * 13 + K)
     n, D = 4000, K + 2
     rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(7, 700), (100, 2500)])
@@ -1199,7 +1199,7 @@ def test_narrow_rows_walk_sorted_copy_with_hot_columns(W, s_by_code, monkeypatch
     most listed neighbours' rows behind the operand (HopGraph.hot_columns) == natural order, bit for bit; hub rows,
     empty rows, pre-weighted (node, hop code) rows (s_by_code)."""
     from gnan_amd import functional, graph as G
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     monkeypatch.setattr(G, "HOT_COLUMNS", 64)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
     monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
@@ -1241,7 +1241,7 @@ def test_packed_index_entries_give_the_same_bits(W, K, bf16, monkeypatch):
     read as separate col / code arrays, bit for bit: rows, hub-row slices, wide index runs, bf16 rows; the packed array
     itself is checked against its definition, and shapes it cannot carry keep the two arrays."""
     from gnan_amd import functional, graph as G
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     monkeypatch.setattr(aggregate, "DEGREE_SORTED_COPY_MIN_ROWS", 1)
     monkeypatch.setattr(aggregate, "NARROW_SORTED_MIN_NNZ", 0)
     rng = np.random.default_rng(W + K)
@@ -1271,7 +1271,7 @@ def test_aggregation_paths_agree_on_random_shapes(seed, monkeypatch):
     natural order, degree-sorted copy, hot rows appended, packed / wide index loads on and off: the same bits from all of
     them, and the float64 oracle within 1e-5."""
     from gnan_amd import functional, graph as G
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(300, 9000))
     K = int(rng.integers(1, 3))
@@ -1322,7 +1322,7 @@ def test_aggregation_gradients_agree_on_random_shapes(seed, monkeypatch):
     over the degree-sorted copy with hot packed rows, wide operands through the per-node weight table: operand gradients
     identical between the walks, everything within 2e-5 of float64 oracle autograd."""
     from gnan_amd import functional, graph as G
-    from gnan_amd.functional import rho_aggregate
+    from gnan_amd.aggregate import rho_aggregate
     rng = np.random.default_rng(2000 + seed)
     n = int(rng.integers(300, 6000))
     K = int(rng.integers(1, 3))
@@ -1364,7 +1364,7 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
     """Rows processed in degree order (through a degree-sorted copy of the CSR, or through an index) and stored in
     place == rows processed in natural order (same arithmetic per row)."""
     from gnan_amd import functional
-    from gnan_amd.functional import spmm_launch
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(21)
     n, K, W = 5000, 1, 16
     rowptr, col, code = _random_csr(n, n, K, rng, hubs=[(3, 900), (4000, 4000)])
@@ -1395,7 +1395,8 @@ def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
 @pytest.mark.parametrize("W,reduce_cr", [(64, 1), (64, 0), (8, 1), (16, 0), (128, 4)])
 def test_bf16_operand_storage(W, reduce_cr):
     """bf16 rows, fp32 accumulate: exact w.r.t. the oracle evaluated on the bf16-rounded operand."""
-    from gnan_amd.functional import column_sums, spmm_launch
+    from gnan_amd.functional import column_sums
+    from gnan_amd.aggregate import spmm_launch
     rng = np.random.default_rng(W + reduce_cr)
     n, K = 3000, 1
     D = K + 2

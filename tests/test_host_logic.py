@@ -252,7 +252,7 @@ def test_hot_columns_point_at_the_appended_rows(monkeypatch):
     ties by id; every pair that lists one of them points at n_cols + rank in the copy, all other ids are untouched;
     flat or small graphs get no hot set."""
     from gnan_amd import HopGraph, graph as G
-    from gnan_amd.functional import append_hot_rows
+    from gnan_amd.aggregate import append_hot_rows
     monkeypatch.setattr(G, "HOT_COLUMNS", 8)
     monkeypatch.setattr(G, "HOT_COLUMNS_MIN_NNZ", 0)
     rng = np.random.default_rng(3)

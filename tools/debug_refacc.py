@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gnan_amd
 from gnan_amd import synthetic as syn, functional
-from gnan_amd.functional import feature_mlps, rho_aggregate, column_sums
+from gnan_amd.functional import feature_mlps, column_sums
+from gnan_amd.aggregate import rho_aggregate
 from oracle import gnan_oracle as O
 import test_gpu_multirank as T
 dev = "cuda"

@@ -4,7 +4,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnan_amd
 from gnan_amd import synthetic as syn
-from gnan_amd.functional import spmm_launch, column_sums
+from gnan_amd.functional import column_sums
+from gnan_amd.aggregate import spmm_launch
 
 dev = "cuda"
 N, E = 10_000_000, 100_000_000

@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnan_amd  # noqa
 from gnan_amd import HopGraph, synthetic as syn
 from gnan_amd import functional
-from gnan_amd.functional import column_sums, spmm_launch
+from gnan_amd.functional import column_sums
+from gnan_amd.aggregate import spmm_launch
 
 aggregate.DEGREE_SCHEDULE_MIN_WIDTH = int(os.environ.get("MIN_WIDTH", "8"))
 

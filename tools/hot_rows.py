@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnan_amd  # noqa
 from gnan_amd import HopGraph, synthetic as syn
-from gnan_amd.functional import spmm_launch
+from gnan_amd.aggregate import spmm_launch
 
 dev = torch.device("cuda")
 N, E, W = 10_000_000, 100_000_000, 64

@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnan_amd  # noqa
 from gnan_amd import functional, synthetic as syn
-from gnan_amd.functional import column_sums, spmm_launch
+from gnan_amd.functional import column_sums
+from gnan_amd.aggregate import spmm_launch
 
 dev = torch.device("cuda")
 N, E = 10_000_000, 100_000_000

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gnan_amd  # noqa
 from gnan_amd import synthetic as syn
-from gnan_amd.functional import feature_mlps, rho_aggregate
+from gnan_amd.functional import feature_mlps
+from gnan_amd.aggregate import rho_aggregate
 from gnan_amd.models import TensorGNAN
 from gnan_amd.graph import hop_inputs
 from gnan_amd.functional import stack_mlps
