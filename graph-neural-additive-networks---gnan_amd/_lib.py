@@ -136,6 +136,14 @@ class SpmmPbArgs(C.Structure):
     ]
 
 
+class SpmmPbBwdArgs(C.Structure):
+    _fields_ = [
+        ("pb", SpmmPbArgs), ("v_self", C.c_void_p), ("s_rows", C.c_void_p), ("s_rows_stride", C.c_int64),
+        ("with_rest", C.c_int32), ("dS", C.c_void_p), ("ds_stride", C.c_int64), ("dlut", C.c_void_p), ("ds_add", C.c_void_p),
+        ("ds_add_scale", C.c_void_p), ("rest_total", C.c_void_p), ("rest_q", C.c_void_p),
+    ]
+
+
 class MomentScalesArgs(C.Structure):
     _fields_ = [
         ("grad", C.c_void_p), ("n", C.c_int64), ("width", C.c_int32), ("bits", C.c_int32), ("grad_stride", C.c_int64),
@@ -333,6 +341,8 @@ SYMBOLS = {
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_pb_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbArgs)]),
     "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
+    "gnan_spmm_pb_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbBwdArgs)]),
+    "gnan_spmm_pb_bwd": (C.c_int, [C.POINTER(SpmmPbBwdArgs), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_lut_grad_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmLutGradArgs)]),
     "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmLutGradArgs), C.c_void_p]),

@@ -133,6 +133,14 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
     scatter = False
     n_hot = 0
     narrow = S.shape[1] * S.element_size() <= 8        # one or two lanes per row: see LONG_ROW_THRESHOLD_NARROW
+    if (PB_NARROW and not g.is_dense and row_ids is None and S.dtype == torch.float32 and S.shape[1] in PB_WIDTHS and not per_row
+            and not from_counts and lut_shape[1] == 1 and lut_shape[0] <= 4 and not weight_by_col and not minus_rest
+            and not s_by_code and reduce_cr == 0 and g.nnz >= PB_MIN_NNZ and not g._cnt_by_col):
+        # narrow rows of a large graph: no per-pair gather at all — bucketed pairs, operand blocks and accumulators in LDS
+        # (csrc/spmm_pb.hip; 10M-node R-MAT, W = 1: 0.87 ms of spmm_hot_kernel -> see DESIGN.md section 4.1c)
+        pb = g.pb_plan(S.shape[1])
+        if pb is not None:
+            return pb_launch(g, pb, S, lut, use_cnt, s_total, out)
     if g.is_dense:
         # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
         plan = g.dense_slice_plan(n_out) if (n_out < DENSE_SLICE_MAX_ROWS and g.n_cols >= DENSE_SLICE_MIN_COLS) else None
@@ -171,6 +179,89 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
         a.workspace, a.workspace_bytes = _lib.ptr(ws), need
     _lib.check(_lib.lib().gnan_spmm_fwd(a, _lib.stream_of(S)), "gnan_spmm_fwd")
     return out
+
+
+PB_NARROW = True            # narrow fp32 rows of large CSR graphs go through the propagation-blocked kernels (gnan_spmm_pb_fwd)
+PB_WIDTHS = (1, 2, 4)
+PB_BACKWARD = True          # ... and so does the one-column backward (gnan_spmm_pb_bwd over the transposed graph's copy)
+PB_MIN_NNZ = 1 << 23        # below, the row-parallel kernel's gathers stay in L2 and three launches cost more than they save
+
+
+def pb_launch(g: HopGraph, pb, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, s_total: Optional[torch.Tensor],
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One ``gnan_spmm_pb_fwd`` call over the bucketed copy ``pb = g.pb_plan(W)``: ``[n_rows, W]``, every row, global table."""
+    _lib.require_device(S, lut, pb.src)
+    W = S.shape[1]
+    if S.stride(0) != W or S.stride(1) != 1:
+        S = S.contiguous()
+    lut = lut.detach().float().reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty((g.n_rows, W), dtype=torch.float32, device=S.device)
+    a = _lib.SpmmPbArgs(n_rows=g.n_rows, n_cols=g.n_cols, S=_lib.ptr(S), s_stride=W, W=W, D=int(lut.numel()), lut=_lib.ptr(lut),
+                        cnt=_lib.ptr(g.cnt) if use_cnt else None, cnt_stride=g.cnt.stride(0), s_total=_lib.ptr(s_total),
+                        Y=_lib.ptr(out), y_stride=out.stride(0), n_entries=pb.n_entries, src=_lib.ptr(pb.src), dst=_lib.ptr(pb.dst),
+                        cb_width=pb.cb_width, n_cblocks=pb.n_cblocks, chunk_q=_lib.ptr(pb.chunk_q),
+                        cb_chunk_ptr=_lib.ptr(pb.cb_chunk_ptr), n_bins=pb.n_bins, acc_per_bin=pb.acc_per_bin,
+                        bin_order=_lib.ptr(pb.bin_order), bin_entry_ptr=_lib.ptr(pb.bin_entry_ptr),
+                        bin_row_ptr=_lib.ptr(pb.bin_row_ptr), slot_ptr=_lib.ptr(pb.slot_ptr), n_acc=pb.n_acc,
+                        code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits)
+    need = _lib.lib().gnan_spmm_pb_workspace_bytes(a)
+    ws = torch.empty((need + 15) // 16 * 4, dtype=torch.float32, device=S.device)       # (the caching allocator aligns to 512 B)
+    a.workspace, a.workspace_bytes = _lib.ptr(ws), ws.numel() * 4
+    _lib.check(_lib.lib().gnan_spmm_pb_fwd(a, _lib.stream_of(S)), "gnan_spmm_pb_fwd")
+    return out
+
+
+def pb_bwd_applies(g: HopGraph, W: int, D: int):
+    """The transposed graph's bucketed copy when the ONE-column backward can take the propagation-blocked route, else None."""
+    if not (PB_NARROW and PB_BACKWARD and W == 1 and not g.is_dense and D <= 4 and g.nnz >= PB_MIN_NNZ):
+        return None
+    pb = g.transposed().pb_plan(2)
+    return pb if (pb is not None and pb.n_acc == 1) else None
+
+
+def pb_bwd_launch(gt: HopGraph, pb, V: torch.Tensor, S_rows: torch.Tensor, lut: torch.Tensor, with_rest: bool,
+                  rest_q: Optional[torch.Tensor] = None, rest_total: Optional[torch.Tensor] = None, add_to_rows: bool = False):
+    """``gnan_spmm_pb_bwd`` over the bucketed copy ``pb = gt.pb_plan(2)`` of the transposed adjacency: ``(dS [n, 1], dlut [D])``
+    from the packed rows ``V [D, n_fwd_rows, 2]`` of :func:`pack_bwd_rows` (``half = 1``, no hot rows) — the arguments of
+    :func:`bwd_narrow_launch`."""
+    _lib.require_device(V, S_rows, lut, pb.src)
+    D = int(lut.numel())
+    V = V.detach().float().contiguous().view(D, -1, 2)
+    if V.shape[1] != gt.n_cols:
+        raise ValueError(f"packed rows for {V.shape[1]} nodes, the transposed graph lists {gt.n_cols}")
+    S_rows = Fn._rows(S_rows.detach().float())
+    lut = lut.detach().float().reshape(-1).contiguous()
+    dS = torch.empty((gt.n_rows, 1), dtype=torch.float32, device=V.device)
+    dlut = torch.empty(D, dtype=torch.float32, device=V.device)
+    block = V[pb.code_base]
+    a = _lib.SpmmPbArgs(n_rows=gt.n_rows, n_cols=gt.n_cols, S=_lib.ptr(block), s_stride=2, W=2, D=D, lut=_lib.ptr(lut),
+                        cnt=None, cnt_stride=0, s_total=None, Y=None, y_stride=0, n_entries=pb.n_entries, src=_lib.ptr(pb.src),
+                        dst=_lib.ptr(pb.dst), cb_width=pb.cb_width, n_cblocks=pb.n_cblocks, chunk_q=_lib.ptr(pb.chunk_q),
+                        cb_chunk_ptr=_lib.ptr(pb.cb_chunk_ptr), n_bins=pb.n_bins, acc_per_bin=pb.acc_per_bin,
+                        bin_order=_lib.ptr(pb.bin_order), bin_entry_ptr=_lib.ptr(pb.bin_entry_ptr),
+                        bin_row_ptr=_lib.ptr(pb.bin_row_ptr), slot_ptr=_lib.ptr(pb.slot_ptr), n_acc=pb.n_acc,
+                        code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits)
+    ga = _lib.SpmmPbBwdArgs(pb=a, v_self=_lib.ptr(V[0]) if pb.code_base else None, s_rows=_lib.ptr(S_rows),
+                            s_rows_stride=S_rows.stride(0), with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0),
+                            dlut=_lib.ptr(dlut))
+    keep = []
+    if rest_q is not None:
+        rest_q = rest_q.detach().float().reshape(-1).contiguous()
+        keep.append(rest_q)
+        if rest_total is not None:
+            rest_total = rest_total.detach().float().reshape(-1).contiguous()
+            keep.append(rest_total)
+            ga.rest_total, ga.rest_q = _lib.ptr(rest_total), _lib.ptr(rest_q)
+        if add_to_rows:
+            scale = lut[D - 1:]
+            keep.append(scale)
+            ga.ds_add, ga.ds_add_scale = _lib.ptr(rest_q), _lib.ptr(scale)
+    need = _lib.lib().gnan_spmm_pb_bwd_workspace_bytes(ga)
+    ws = torch.empty((need + 15) // 16 * 4, dtype=torch.float32, device=V.device)
+    ga.pb.workspace, ga.pb.workspace_bytes = _lib.ptr(ws), ws.numel() * 4
+    _lib.check(_lib.lib().gnan_spmm_pb_bwd(ga, _lib.stream_of(V)), "gnan_spmm_pb_bwd")
+    return dS, dlut
 
 
 def shell_sums_launch(g: HopGraph, S: torch.Tensor, lut_like: torch.Tensor, with_rest: bool,
@@ -406,7 +497,8 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
         # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
         half = 1 << max(0, (W - 1).bit_length())
-        walk = narrow_walk(g.transposed())
+        pb_t = pb_bwd_applies(g, W, D)                      # one column, large graph: no per-pair gather (csrc/spmm_pb.hip)
+        walk = (None, None, None) if pb_t is not None else narrow_walk(g.transposed())
         q_sum = total = None
         if with_rest and W == 1:                            # ... and their rest halves' column sum out of the same pass
             V, q_sum = pack_bwd_rows(dY, g.cnt if use_cnt else None, D, with_rest, half, hot=walk[2], want_q_sum=True)
@@ -420,8 +512,12 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
             add_to_rows = rest_added = ctx.total_group is NOT_SHARED and ctx.total_rows is None
             # d/d lut[rest] of the same term: <total, q_sum> — added by the kernel's final pass
             total = (ctx.s_total if ctx.s_total is not None else Fn.column_sums(S)).float().reshape(-1).contiguous()
-        dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk,
-                                   rest_q=q_sum, rest_total=total, add_to_rows=add_to_rows)
+        if pb_t is not None:
+            dS, dl = pb_bwd_launch(g.transposed(), pb_t, V, S, lut[:, 0], with_rest, rest_q=q_sum, rest_total=total,
+                                   add_to_rows=add_to_rows)
+        else:
+            dS, dl = bwd_narrow_launch(g.transposed(), V.view(-1, 2 * half), S, lut[:, 0], with_rest, W, walk=walk,
+                                       rest_q=q_sum, rest_total=total, add_to_rows=add_to_rows)
         dlut = dl.view(D, 1)
 
     if need_dS and not fused_bwd:

@@ -63,6 +63,16 @@ struct PbParams {
   int acc_per_bin, headroom_bits;
   float* E;
   unsigned* absmax;     // bits of max |S| (non-negative floats order like their bit patterns; NaN sorts above +inf)
+  // backward (pb_reduce_kernel<2, true>): the operand is the packed rows V[code_base] = [dY_i / cnt(i, d) | dY_i / cnt(i, rest)]
+  const float* v_self;  // V[0]: the packed rows of hop code 0 (the self pairs self_col serves), or null
+  const float* s_rows;  // [n_rows] forward operand (for the table gradient)
+  int64_t s_rows_stride;
+  int with_rest;
+  float* dS;
+  int64_t ds_stride;
+  const float* ds_add;        // optional [1]: added to every dS row ...
+  const float* ds_add_scale;  // ... times this [1] (optional)
+  double* dlut_partial;       // [n_bins, 4]
 };
 
 __global__ void pb_prep_kernel(unsigned* absmax) {
@@ -142,7 +152,7 @@ __device__ __forceinline__ void lds_add(long long* acc, int idx, float v, double
   atomicAdd(reinterpret_cast<unsigned long long*>(acc + idx), static_cast<unsigned long long>(x));
 }
 
-template <int W>
+template <int W, bool BWD = false>
 __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];     // [acc_per_bin * W]
   const int tid = threadIdx.x;
@@ -201,38 +211,131 @@ __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
   const int r_lo = p.bin_row_ptr[b], r_hi = p.bin_row_ptr[b + 1];
   const int slot0 = p.slot_ptr[r_lo];
   const int rest = p.D - 1;
-  for (int i = r_lo + tid; i < r_hi; i += kThreads) {
-    const int s_lo = p.slot_ptr[i] - slot0, s_hi = p.slot_ptr[i + 1] - slot0;
-    float wt[4];
+  if constexpr (!BWD) {
+    for (int i = r_lo + tid; i < r_hi; i += kThreads) {
+      const int s_lo = p.slot_ptr[i] - slot0, s_hi = p.slot_ptr[i + 1] - slot0;
+      float wt[4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      float v = 0.f;
-      if (d < p.D) {
-        v = p.lut[d];
-        if (p.cnt) {
-          const int c = p.cnt[static_cast<int64_t>(i) * p.cnt_stride + d];
-          v = v / static_cast<float>(c > 1 ? c : 1);                   // IEEE division, as torch.div (spmm.hip: small_weights)
+      for (int d = 0; d < 4; ++d) {
+        float v = 0.f;
+        if (d < p.D) {
+          v = p.lut[d];
+          if (p.cnt) {
+            const int c = p.cnt[static_cast<int64_t>(i) * p.cnt_stride + d];
+            v = v / static_cast<float>(c > 1 ? c : 1);                   // IEEE division, as torch.div (spmm.hip: small_weights)
+          }
         }
+        wt[d] = v;
       }
-      wt[d] = v;
-    }
-    const float w_rest = p.s_total ? wt[rest] : 0.f;
-    const int sc = p.self_col ? p.self_col[i] : -1;
+      const float w_rest = p.s_total ? wt[rest] : 0.f;
+      const int sc = p.self_col ? p.self_col[i] : -1;
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-      float out = 0.f;
-      if (sc >= 0) out = fmaf(wt[0] - w_rest, p.S[static_cast<int64_t>(sc) * W + w], out);
-      for (int a = 0; a < p.n_acc; ++a) {
-        long long t = 0;
-        for (int s = s_lo; s < s_hi; ++s) t += acc[(s * p.n_acc + a) * W + w];
-        const float tf = static_cast<float>(static_cast<double>(t) * inv_scale);
-        const int d = p.code_base + a;
-        const float wd = d == 0 ? wt[0] : (d == 1 ? wt[1] : (d == 2 ? wt[2] : wt[3]));
-        out = fmaf(wd - w_rest, tf, out);
+      for (int w = 0; w < W; ++w) {
+        float out = 0.f;
+        if (sc >= 0) out = fmaf(wt[0] - w_rest, p.S[static_cast<int64_t>(sc) * W + w], out);
+        for (int a = 0; a < p.n_acc; ++a) {
+          long long t = 0;
+          for (int s = s_lo; s < s_hi; ++s) t += acc[(s * p.n_acc + a) * W + w];
+          const float tf = static_cast<float>(static_cast<double>(t) * inv_scale);
+          const int d = p.code_base + a;
+          const float wd = d == 0 ? wt[0] : (d == 1 ? wt[1] : (d == 2 ? wt[2] : wt[3]));
+          out = fmaf(wd - w_rest, tf, out);
+        }
+        if (p.s_total) out = fmaf(w_rest, p.s_total[w], out);
+        if (bad) out = __uint_as_float(0x7fc00000u);
+        p.Y[static_cast<int64_t>(i) * p.y_stride + w] = out;
       }
-      if (p.s_total) out = fmaf(w_rest, p.s_total[w], out);
-      if (bad) out = __uint_as_float(0x7fc00000u);
-      p.Y[static_cast<int64_t>(i) * p.y_stride + w] = out;
+    }
+  } else {
+    // Backward over the TRANSPOSED adjacency (W == 2, one accumulated code d1 = code_base): row j of the bin is operand node j,
+    //   t1 = sum_{i lists j with code d1} dY_i / cnt(i, d1),   tr = sum_{the same i} dY_i / cnt(i, rest),
+    //   (a0, b0) = the packed row of j's self pair (hop code 0), then
+    //   dS_j = l_0 a0 + l_d1 t1 - l_rest (tr + b0) [+ ds_add],     dlut_d += S_j * (a0 | t1),   dlut_rest -= S_j (tr + b0).
+    static_assert(!BWD || W == 2, "the backward's packed rows are two floats");
+    const int d1 = p.code_base;
+    const float l0 = p.lut[0], l1 = p.lut[d1], lr = p.with_rest ? p.lut[rest] : 0.f;
+    float add = 0.f;
+    if (p.ds_add) add = p.ds_add_scale ? p.ds_add[0] * p.ds_add_scale[0] : p.ds_add[0];
+    double g0 = 0.0, g1 = 0.0, gr = 0.0;
+    for (int i = r_lo + tid; i < r_hi; i += kThreads) {
+      const int s_lo = p.slot_ptr[i] - slot0, s_hi = p.slot_ptr[i + 1] - slot0;
+      long long t1i = 0, tri = 0;
+      for (int s = s_lo; s < s_hi; ++s) {
+        t1i += acc[2 * s];
+        tri += acc[2 * s + 1];
+      }
+      const float t1 = static_cast<float>(static_cast<double>(t1i) * inv_scale);
+      float tr = static_cast<float>(static_cast<double>(tri) * inv_scale);
+      const int sc = (p.self_col && p.v_self) ? p.self_col[i] : -1;
+      float a0 = 0.f;
+      if (sc >= 0) {
+        const float2 v0 = *reinterpret_cast<const float2*>(p.v_self + 2 * static_cast<int64_t>(sc));
+        a0 = v0.x;
+        tr += v0.y;
+      }
+      float ds = d1 == 0 ? 0.f : l0 * a0;
+      ds = fmaf(l1, t1, ds);
+      ds = fmaf(-lr, tr, ds);
+      ds += add;
+      if (bad) ds = __uint_as_float(0x7fc00000u);
+      p.dS[static_cast<int64_t>(i) * p.ds_stride] = ds;
+      const double sj = static_cast<double>(p.s_rows[static_cast<int64_t>(i) * p.s_rows_stride]);
+      g0 += sj * a0;
+      g1 += sj * t1;
+      gr += sj * tr;
+    }
+    // per-bin partials of the table gradient: lanes, then waves, in a fixed order; the bins are added by pb_dlut_final_kernel
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      g0 += __shfl_xor(g0, off);
+      g1 += __shfl_xor(g1, off);
+      gr += __shfl_xor(gr, off);
+    }
+    __syncthreads();                                   // every accumulator has been read: the LDS is free
+    double* red = reinterpret_cast<double*>(acc);
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    if (lane == 0) {
+      red[wave * 3] = g0;
+      red[wave * 3 + 1] = g1;
+      red[wave * 3 + 2] = gr;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      double t = 0.0;
+      for (int w = 0; w < kThreads / kWave; ++w) t += red[w * 3 + tid];
+      p.dlut_partial[static_cast<int64_t>(b) * 4 + tid] = bad ? __longlong_as_double(0x7ff8000000000000LL) : t;
+    }
+  }
+}
+
+// dlut[d] from the bins' partials, in bin order (one workgroup; n_bins ~ 10^3); <rest_total, rest_q> goes into dlut[rest]
+__global__ __launch_bounds__(256) void pb_dlut_final_kernel(const double* __restrict__ partial, int n_bins, int D, int d1, int with_rest,
+                                                            const float* rest_total, const float* rest_q, float* __restrict__ dlut) {
+  __shared__ double red[256][3];
+  const int tid = threadIdx.x;
+  double g[3] = {0.0, 0.0, 0.0};
+  for (int b = tid; b < n_bins; b += 256) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] += partial[static_cast<int64_t>(b) * 4 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[tid][k] = g[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) red[tid][k] += red[tid + off][k];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int d = 0; d < D; ++d) dlut[d] = 0.f;
+    if (d1 != 0) dlut[0] = static_cast<float>(red[0][0]);
+    dlut[d1] = static_cast<float>(red[0][1]);
+    if (with_rest) {
+      double r = -red[0][2];
+      if (rest_total && rest_q) r += static_cast<double>(rest_total[0]) * static_cast<double>(rest_q[0]);
+      dlut[D - 1] = static_cast<float>(r);
     }
   }
 }
@@ -267,7 +370,7 @@ size_t pb_bytes(const gnan_spmm_pb_args* a) {
   return 256 + static_cast<size_t>(a->n_entries) * static_cast<size_t>(a->W) * sizeof(float);
 }
 
-template <int W>
+template <int W, bool BWD = false>
 int launch(const PbParams& p, hipStream_t st) {
   hipLaunchKernelGGL(pb_prep_kernel, dim3(1), dim3(64), 0, st, p.absmax);
   if (int rc = gnan::check_launch("pb_prep_kernel")) return rc;
@@ -275,8 +378,28 @@ int launch(const PbParams& p, hipStream_t st) {
   hipLaunchKernelGGL((pb_expand_kernel<W>), dim3(static_cast<unsigned>(p.n_cblocks) * p.n_split), dim3(kThreads), lds1, st, p);
   if (int rc = gnan::check_launch("pb_expand_kernel")) return rc;
   const size_t lds2 = static_cast<size_t>(p.acc_per_bin) * W * sizeof(long long);
-  hipLaunchKernelGGL((pb_reduce_kernel<W>), dim3(static_cast<unsigned>(p.n_bins)), dim3(kThreads), lds2, st, p);
+  hipLaunchKernelGGL((pb_reduce_kernel<W, BWD>), dim3(static_cast<unsigned>(p.n_bins)), dim3(kThreads), lds2, st, p);
   return gnan::check_launch("pb_reduce_kernel");
+}
+
+PbParams make_params(const gnan_spmm_pb_args* a) {
+  PbParams p{};
+  p.n_rows = a->n_rows; p.n_cols = a->n_cols; p.S = a->S; p.W = a->W; p.lut = a->lut; p.D = a->D;
+  p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total; p.Y = a->Y; p.y_stride = a->y_stride;
+  p.n_entries = a->n_entries; p.src = a->src; p.dst = a->dst; p.cb_width = a->cb_width; p.n_cblocks = a->n_cblocks;
+  p.chunk_q = a->chunk_q; p.cb_chunk_ptr = a->cb_chunk_ptr; p.n_bins = a->n_bins; p.bin_order = a->bin_order;
+  p.bin_entry_ptr = a->bin_entry_ptr; p.bin_row_ptr = a->bin_row_ptr; p.slot_ptr = a->slot_ptr; p.n_acc = a->n_acc;
+  p.code_base = a->code_base; p.self_col = a->self_col; p.acc_per_bin = a->acc_per_bin; p.headroom_bits = a->headroom_bits;
+  p.absmax = static_cast<unsigned*>(a->workspace);
+  p.E = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 256);
+  // enough workgroups per column block that the launch is >> the resident ones (two per CU) whatever the block count
+  int split = (2048 + a->n_cblocks - 1) / a->n_cblocks;
+  p.n_split = split < 1 ? 1 : (split > 16 ? 16 : split);
+  return p;
+}
+
+size_t pb_bwd_bytes(const gnan_spmm_pb_bwd_args* g) {
+  return (pb_bytes(&g->pb) + 15) / 16 * 16 + static_cast<size_t>(g->pb.n_bins) * 4 * sizeof(double);
 }
 
 }  // namespace
@@ -292,22 +415,42 @@ extern "C" int gnan_spmm_pb_fwd(const gnan_spmm_pb_args* a, gnan_stream_t stream
                a->workspace_bytes, pb_bytes(a));
   GNAN_REQUIRE((reinterpret_cast<uintptr_t>(a->workspace) % 16) == 0, "gnan_spmm_pb_fwd: workspace must be 16-byte aligned");
   if (a->n_rows == 0) return GNAN_OK;
-  PbParams p{};
-  p.n_rows = a->n_rows; p.n_cols = a->n_cols; p.S = a->S; p.W = a->W; p.lut = a->lut; p.D = a->D;
-  p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.s_total = a->s_total; p.Y = a->Y; p.y_stride = a->y_stride;
-  p.n_entries = a->n_entries; p.src = a->src; p.dst = a->dst; p.cb_width = a->cb_width; p.n_cblocks = a->n_cblocks;
-  p.chunk_q = a->chunk_q; p.cb_chunk_ptr = a->cb_chunk_ptr; p.n_bins = a->n_bins; p.bin_order = a->bin_order;
-  p.bin_entry_ptr = a->bin_entry_ptr; p.bin_row_ptr = a->bin_row_ptr; p.slot_ptr = a->slot_ptr; p.n_acc = a->n_acc;
-  p.code_base = a->code_base; p.self_col = a->self_col; p.acc_per_bin = a->acc_per_bin; p.headroom_bits = a->headroom_bits;
-  p.absmax = static_cast<unsigned*>(a->workspace);
-  p.E = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 256);
-  // enough workgroups per column block that the launch is >> the resident ones (two per CU) whatever the block count
-  int split = (4096 + a->n_cblocks - 1) / a->n_cblocks;
-  p.n_split = split < 1 ? 1 : (split > 16 ? 16 : split);
+  const PbParams p = make_params(a);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a->W) {
     case 1: return launch<1>(p, st);
     case 2: return launch<2>(p, st);
     default: return launch<4>(p, st);
   }
+}
+
+extern "C" size_t gnan_spmm_pb_bwd_workspace_bytes(const gnan_spmm_pb_bwd_args* g) {
+  if (!g || g->pb.n_entries < 0 || g->pb.W != 2 || g->pb.n_bins <= 0) return 0;
+  return pb_bwd_bytes(g);
+}
+
+extern "C" int gnan_spmm_pb_bwd(const gnan_spmm_pb_bwd_args* g, gnan_stream_t stream) {
+  GNAN_REQUIRE(g != nullptr, "gnan_spmm_pb_bwd: null arguments");
+  gnan_spmm_pb_args a = g->pb;
+  a.Y = g->dS;                       // (validate() wants an output; the backward epilogue writes dS)
+  a.y_stride = g->ds_stride < 2 ? 2 : g->ds_stride;
+  if (int rc = validate(&a)) return rc;
+  GNAN_REQUIRE(a.W == 2 && a.n_acc == 1, "gnan_spmm_pb_bwd: packed rows of two floats, one accumulated hop code (W %d, n_acc %d)", a.W,
+               a.n_acc);
+  GNAN_REQUIRE(g->dS && g->dlut && g->s_rows && g->ds_stride >= 1, "gnan_spmm_pb_bwd: null pointer");
+  GNAN_REQUIRE(a.code_base == 0 || g->v_self || !a.self_col, "gnan_spmm_pb_bwd: self pairs are left out of the entries but v_self is null");
+  GNAN_REQUIRE(a.workspace && a.workspace_bytes >= pb_bwd_bytes(g), "gnan_spmm_pb_bwd: workspace too small (%zu < %zu)",
+               a.workspace_bytes, pb_bwd_bytes(g));
+  GNAN_REQUIRE((reinterpret_cast<uintptr_t>(a.workspace) % 16) == 0, "gnan_spmm_pb_bwd: workspace must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PbParams p = make_params(&a);
+  p.v_self = g->v_self; p.s_rows = g->s_rows; p.s_rows_stride = g->s_rows_stride; p.with_rest = g->with_rest;
+  p.dS = g->dS; p.ds_stride = g->ds_stride; p.ds_add = g->ds_add; p.ds_add_scale = g->ds_add_scale;
+  p.dlut_partial = reinterpret_cast<double*>(static_cast<char*>(a.workspace) + (pb_bytes(&a) + 15) / 16 * 16);
+  if (a.n_rows > 0) {
+    if (int rc = launch<2, true>(p, st)) return rc;
+  }
+  hipLaunchKernelGGL(pb_dlut_final_kernel, dim3(1), dim3(256), 0, st, p.dlut_partial, a.n_rows > 0 ? a.n_bins : 0, a.D, a.code_base,
+                     g->with_rest, g->rest_total, g->rest_q, g->dlut);
+  return gnan::check_launch("pb_dlut_final_kernel");
 }

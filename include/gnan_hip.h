@@ -539,6 +539,36 @@ typedef struct gnan_spmm_pb_args {
 size_t gnan_spmm_pb_workspace_bytes(const gnan_spmm_pb_args* a);
 int gnan_spmm_pb_fwd(const gnan_spmm_pb_args* a, gnan_stream_t stream);
 
+/* Backward of the ONE-column aggregation through the same machinery, over the bucketed copy of the TRANSPOSED adjacency
+ * (row j = operand node j, entries = the output rows i that list j): both gradients from one pass, like
+ * gnan_spmm_bwd_narrow.  `pb` describes the transposed graph's plan for W = 2 with ONE accumulated hop code d1 = code_base
+ * (n_acc == 1: the 1-hop-truncated graphs of configs 3-5); pb.S = V[d1], the packed rows [dY_i / cnt(i, d1) | dY_i / cnt(i, D-1)]
+ * of gnan_spmm_pack_bwd_rows (half = 1) — pb.cnt / pb.s_total / pb.Y are not read; v_self = V[0] (the rows of hop code 0) when
+ * the plan serves the self pairs from self_col.  With t1[j], tr[j] the sums of the two halves over j's entries (+ the self
+ * pair's rest half in tr):
+ *   dS[j]    = lut[0] * V[0][self].x + lut[d1] * t1 - lut[D-1] * tr  (+ ds_add[0] * ds_add_scale[0])
+ *   dlut[d1] = sum_j s_rows[j] * t1[j],  dlut[0] = sum_j s_rows[j] * V[0][self].x,
+ *   dlut[D-1] = - sum_j s_rows[j] * tr[j] + rest_total[0] * rest_q[0]        (with_rest; other entries 0)
+ * The sums over an operand node's entries are exact to 2^-40 of max |V| (integer accumulation); the table gradient adds
+ * float64 partials per bin in bin order: bit-reproducible.  workspace: gnan_spmm_pb_bwd_workspace_bytes(g), 16-byte aligned. */
+typedef struct gnan_spmm_pb_bwd_args {
+  gnan_spmm_pb_args pb;
+  const float* v_self;       /* optional [n_fwd_rows, 2] */
+  const float* s_rows;       /* [pb.n_rows] forward operand, one column */
+  int64_t s_rows_stride;
+  int32_t with_rest;
+  float* dS;                 /* [pb.n_rows] */
+  int64_t ds_stride;
+  float* dlut;               /* [pb.D] */
+  const float* ds_add;       /* optional [1] */
+  const float* ds_add_scale; /* optional [1] */
+  const float* rest_total;   /* optional [1] */
+  const float* rest_q;       /* optional [1] */
+} gnan_spmm_pb_bwd_args;
+
+size_t gnan_spmm_pb_bwd_workspace_bytes(const gnan_spmm_pb_bwd_args* g);
+int gnan_spmm_pb_bwd(const gnan_spmm_pb_bwd_args* g, gnan_stream_t stream);
+
 /* Shell sums for the backward pass (autograd through GNAN.py:67-70 w.r.t. rho's parameters):
  *   T[q, d, w] = sum_{e in row, code_e == d} S[col_e, w]            d < D-1
  *   T[q, D-1, w] (+)= s_total[w] - sum_{e in row} S[col_e, w]       (if s_total; dense layout

@@ -42,14 +42,20 @@ def test_full_size_sampled_rows_against_the_oracle(c4):
     with torch.no_grad():
         S, total = feature_mlps(x, st, False, return_total=True)             # [N, 64]
         out = rho_aggregate(g, S, lut, True, s_total=total, reduce_channels=1)   # [N, 1]
+        # the modules' default order (GNAN.py:157-170: feature sum first, then a ONE-column aggregation — the propagation-
+        # blocked kernels of csrc/spmm_pb.hip at this size) against the same float64 rows
+        s1, t1 = feature_mlps(x, st, True, return_total=True)                # [N, 1]
+        out_sf = rho_aggregate(g, s1, lut, True, s_total=t1)
+        del s1
     assert out.shape == (N, 1) and bool(torch.isfinite(out).all())
+    assert out_sf.shape == (N, 1) and bool(torch.isfinite(out_sf).all())
     deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
     rng = np.random.default_rng(0)
     mid = torch.nonzero((deg > 512) & (deg < 3000)).flatten()[:6].cpu().numpy()      # just over the hub-row threshold
     rows = np.unique(np.concatenate([rng.integers(0, N, 240), torch.topk(deg, 2).indices.cpu().numpy(), mid]))
     # shape functions at the sampled rows' neighbours: oracle restatement of GNAN.py:57-62 in float64
     scale = float(out.abs().max())
-    worst = 0.0
+    worst = worst_sf = 0.0
     tot64 = total.double().cpu()
     cnt = g.cnt.cpu().numpy()
     p64 = {k: v.double() for k, v in sd.items()}
@@ -61,7 +67,9 @@ def test_full_size_sampled_rows_against_the_oracle(c4):
         w = lut.double().cpu().reshape(-1) / torch.from_numpy(np.maximum(cnt[i], 1)).double()
         acc = (w[codes].unsqueeze(1) * fx).sum(0) + w[-1] * (tot64 - fx.sum(0))
         worst = max(worst, abs(float(acc.sum()) - float(out[i, 0])))
+        worst_sf = max(worst_sf, abs(float(acc.sum()) - float(out_sf[i, 0])))
     assert worst <= 1e-5 * scale, (worst, scale)
+    assert worst_sf <= 1e-5 * scale, (worst_sf, scale)
 
 
 def test_full_size_reference_order_equals_sum_first(c4):

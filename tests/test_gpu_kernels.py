@@ -2065,3 +2065,127 @@ def test_feature_range_kernel():
     seen = [functional._feature_range(torch.randn(70_000, 16, device=DEV)) is not None for _ in range(5)]
     assert seen == [True, True, True, False, False]
     functional._RANGE_CHURN.clear()
+
+
+# =============================================================================
+# propagation-blocked narrow aggregation (csrc/spmm_pb.hip)
+# =============================================================================
+def _pb_graph(rng, n_rows, n_cols, D, hubs=(), self_pairs=True):
+    from test_pb_plan import random_graph
+    g, rowptr, col, code = random_graph(rng, n_rows, n_cols, D, hubs=hubs, self_pairs=self_pairs)
+    from gnan_amd import HopGraph
+    gd = HopGraph.from_csr(g.rowptr.to(DEV), g.col.to(DEV), g.code.to(DEV), n_cols=n_cols, n_codes=D)
+    return gd, rowptr, col, code
+
+
+@pytest.mark.parametrize("D,W,self_pairs,use_cnt,with_rest,lds", [(3, 1, True, True, True, 1024), (3, 2, True, False, True, 2048),
+                                                                   (4, 1, True, True, False, 1024), (4, 4, False, True, True, 4096),
+                                                                   (3, 1, False, True, True, 65536), (2, 1, False, True, True, 1024),
+                                                                   (3, 1, True, True, True, 65536), (3, 2, True, True, True, 65536)])
+def test_propagation_blocked_aggregation_vs_oracle(D, W, self_pairs, use_cnt, with_rest, lds, monkeypatch):
+    """gnan_spmm_pb_fwd == the float64 oracle (integer accumulation: 1e-6 is float32 rounding of inputs and weights only) and
+    is bit-reproducible; small LDS budgets give many bins / column blocks and multi-slot hub rows on a small graph."""
+    from gnan_amd import graph as G
+    from gnan_amd.aggregate import pb_launch, spmm_launch
+    monkeypatch.setattr(G, "PB_LDS_BYTES", lds)
+    if lds < 65536:
+        monkeypatch.setattr(G, "PB_SLOT_PAIRS", 8)
+    rng = np.random.default_rng(D * 10 + W + lds)
+    n_rows, n_cols = (700, 900) if lds < 65536 else (40_000, 50_000)
+    hubs = [(5, 60), (333, 150)] if lds < 65536 else [(5, 3000), (333, 20_000), (39_999, 700)]
+    g, rowptr, col, code = _pb_graph(rng, n_rows, n_cols, D, hubs=hubs, self_pairs=self_pairs)
+    plan = g.pb_plan(W)
+    assert plan is not None
+    S = torch.from_numpy(rng.standard_normal((n_cols, W)).astype(np.float32) * 3.0)
+    lut = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32))
+    total = S.double().sum(0).float() if with_rest else None
+    got = pb_launch(g, plan, S.to(DEV), lut.to(DEV), use_cnt, None if total is None else total.to(DEV))
+    again = pb_launch(g, plan, S.to(DEV), lut.to(DEV), use_cnt, None if total is None else total.to(DEV))
+    assert torch.equal(got, again)
+    # float64 truth, vectorised: out[i] = sum_e w(i, code_e) S[col_e] (+ w(i, rest) (sum_j S[j] - sum_e S[col_e]))
+    row_of = torch.repeat_interleave(torch.arange(n_rows), torch.from_numpy(np.diff(rowptr)))
+    colt, codet, S64 = torch.from_numpy(col).long(), torch.from_numpy(code).long(), S.double()
+    c = g.cnt.cpu().double().clamp_min(1) if use_cnt else torch.ones(n_rows, D, dtype=torch.float64)
+    l64 = lut.double().reshape(-1)
+    want = torch.zeros(n_rows, W, dtype=torch.float64).index_add(0, row_of, (l64[codet] / c[row_of, codet]).unsqueeze(1) * S64[colt])
+    if with_rest:
+        listed = torch.zeros(n_rows, W, dtype=torch.float64).index_add(0, row_of, S64[colt])
+        want = want + (l64[-1] / c[:, -1]).unsqueeze(1) * (total.double().unsqueeze(0) - listed)
+    assert got.shape == want.shape
+    assert O.rel_err(got.cpu(), want) <= 1e-6
+    # ... and the route: spmm_launch sends a large-enough graph here by itself, with the row-parallel kernel's result
+    monkeypatch.setattr(aggregate, "PB_MIN_NNZ", 0)
+    routed = spmm_launch(g, S.to(DEV), lut.to(DEV), use_cnt, with_rest, s_total=None if total is None else total.to(DEV))
+    assert torch.equal(routed, again)
+    monkeypatch.setattr(aggregate, "PB_NARROW", False)
+    rows_kernel = spmm_launch(g, S.to(DEV), lut.to(DEV), use_cnt, with_rest, s_total=None if total is None else total.to(DEV))
+    assert float((rows_kernel - again).abs().max()) <= 2e-5 * float(again.abs().max())
+
+
+def test_propagation_blocked_aggregation_non_finite_operand():
+    """An infinite or NaN operand value cannot be put in fixed point: every output row is NaN (the float chain would
+    have produced inf / NaN in the rows that list it)."""
+    from gnan_amd.aggregate import pb_launch
+    rng = np.random.default_rng(4)
+    g, *_ = _pb_graph(rng, 300, 300, 3)
+    S = torch.randn(300, 1)
+    S[17] = float("inf")
+    out = pb_launch(g, g.pb_plan(1), S.to(DEV), torch.tensor([[1.0], [0.5], [0.1]], device=DEV), True, None)
+    assert bool(torch.isnan(out).all())
+    S[17] = 0.0
+    out = pb_launch(g, g.pb_plan(1), S.to(DEV), torch.tensor([[1.0], [0.5], [0.1]], device=DEV), True, None)
+    assert bool(torch.isfinite(out).all())
+    zero = pb_launch(g, g.pb_plan(1), torch.zeros(300, 1, device=DEV), torch.tensor([[1.0], [0.5], [0.1]], device=DEV), True, None)
+    assert float(zero.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("D,self_pairs,use_cnt,with_rest,lds", [(3, True, True, True, 2048), (3, True, False, False, 2048),
+                                                                 (2, False, True, True, 2048), (3, True, True, True, 65536),
+                                                                 (3, False, True, True, 2048), (4, True, True, True, 2048)])
+def test_propagation_blocked_backward_vs_oracle_autograd(D, self_pairs, use_cnt, with_rest, lds, monkeypatch):
+    """One-column aggregation, forward AND backward on the bucketed copies (gnan_spmm_pb_fwd / gnan_spmm_pb_bwd over the
+    transposed graph): operand and table gradients against float64 oracle autograd, bit-reproducible, and equal to the
+    row-parallel kernels' gradients to float32 rounding.  D = 4 lists two non-self codes: the backward stays row-parallel."""
+    from gnan_amd import graph as G
+    from gnan_amd.aggregate import pb_bwd_applies, rho_aggregate
+    monkeypatch.setattr(G, "PB_LDS_BYTES", lds)
+    if lds < 65536:
+        monkeypatch.setattr(G, "PB_SLOT_PAIRS", 8)
+    monkeypatch.setattr(aggregate, "PB_MIN_NNZ", 0)
+    rng = np.random.default_rng(D * 7 + lds + int(self_pairs))
+    n = 900 if lds < 65536 else 30_000
+    hubs = [(5, 60), (333, 150)] if lds < 65536 else [(5, 3000), (333, 12_000)]
+    g, rowptr, col, code = _pb_graph(rng, n, n, D, hubs=hubs, self_pairs=self_pairs)
+    if rng.random() < 0.9:                                    # a few very popular neighbours: hub rows of the TRANSPOSED graph
+        hot = torch.from_numpy(rng.random(col.shape[0]) < 0.2)
+        hot &= g.code.cpu() != 0
+        col = col.copy()
+        col[hot.numpy()] = rng.integers(0, 6, int(hot.sum())) * (n // 6)
+        from gnan_amd import HopGraph
+        g = HopGraph.from_csr(g.rowptr, torch.from_numpy(col).to(DEV), g.code, n_cols=n, n_codes=D)
+    assert (pb_bwd_applies(g, 1, D) is not None) == (D <= 3)
+    S0 = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
+    lut0 = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    up = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
+
+    def grads():
+        S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+        return torch.autograd.grad(rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest), [S, lut], up)
+    got, again = grads(), grads()
+    assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+    monkeypatch.setattr(aggregate, "PB_NARROW", False)
+    rows = grads()
+    S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    row_of = torch.repeat_interleave(torch.arange(n), torch.from_numpy(np.diff(rowptr)))
+    colt, codet = torch.from_numpy(col).long(), torch.from_numpy(code).long()
+    y64 = torch.zeros(n, 1, dtype=torch.float64).index_add(0, row_of, wt[row_of, codet] * S64[colt])
+    if with_rest:
+        y64 = y64 + wt[:, -1] * (S64.sum(0, keepdim=True) - torch.zeros(n, 1, dtype=torch.float64).index_add(0, row_of, S64[colt]))
+    ref = torch.autograd.grad(y64, [S64, lut64], up.cpu().double())
+    for k in range(2):
+        scale = float(ref[k].abs().max())
+        assert float((got[k].cpu().double() - ref[k]).abs().max()) <= 1e-5 * scale, (k, scale)
+        assert float((got[k] - rows[k]).abs().max()) <= 2e-5 * scale, (k, scale)

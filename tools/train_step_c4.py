@@ -14,6 +14,9 @@ from gnan_amd import synthetic as syn  # noqa: E402
 from gnan_amd.models import TensorGNAN  # noqa: E402
 
 DEV = "cuda"
+if "PB_OFF" in os.environ:                 # A/B: the row-parallel narrow aggregation instead of csrc/spmm_pb.hip
+    from gnan_amd import aggregate as _agg
+    _agg.PB_NARROW = False
 N, E, SCALE = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (10_000_000, 100_000_000, 24)))
 F = 64
 
