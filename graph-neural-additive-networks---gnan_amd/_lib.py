@@ -133,6 +133,7 @@ class SpmmPbArgs(C.Structure):
         ("n_bins", C.c_int32), ("acc_per_bin", C.c_int32), ("bin_order", C.c_void_p), ("bin_entry_ptr", C.c_void_p),
         ("bin_row_ptr", C.c_void_p), ("slot_ptr", C.c_void_p), ("n_acc", C.c_int32), ("code_base", C.c_int32),
         ("self_col", C.c_void_p), ("headroom_bits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("flags", C.c_int32), ("self_is_row", C.c_int32),
     ]
 
 

@@ -183,6 +183,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
 
 PB_NARROW = True            # narrow fp32 rows of large CSR graphs go through the propagation-blocked kernels (gnan_spmm_pb_fwd)
 PB_WIDTHS = (1, 2, 4)
+PB_FLAGS = 0                # gnan_spmm_pb_args.flags (A/B switches of the kernels)
 PB_BACKWARD = True          # ... and so does the one-column backward (gnan_spmm_pb_bwd over the transposed graph's copy)
 PB_MIN_NNZ = 1 << 23        # below, the row-parallel kernel's gathers stay in L2 and three launches cost more than they save
 
@@ -204,7 +205,7 @@ def pb_launch(g: HopGraph, pb, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
                         cb_chunk_ptr=_lib.ptr(pb.cb_chunk_ptr), n_bins=pb.n_bins, acc_per_bin=pb.acc_per_bin,
                         bin_order=_lib.ptr(pb.bin_order), bin_entry_ptr=_lib.ptr(pb.bin_entry_ptr),
                         bin_row_ptr=_lib.ptr(pb.bin_row_ptr), slot_ptr=_lib.ptr(pb.slot_ptr), n_acc=pb.n_acc,
-                        code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits)
+                        code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits, flags=PB_FLAGS, self_is_row=int(pb.self_is_row))
     need = _lib.lib().gnan_spmm_pb_workspace_bytes(a)
     ws = torch.empty((need + 15) // 16 * 4, dtype=torch.float32, device=S.device)       # (the caching allocator aligns to 512 B)
     a.workspace, a.workspace_bytes = _lib.ptr(ws), ws.numel() * 4
@@ -241,7 +242,7 @@ def pb_bwd_launch(gt: HopGraph, pb, V: torch.Tensor, S_rows: torch.Tensor, lut: 
                         cb_chunk_ptr=_lib.ptr(pb.cb_chunk_ptr), n_bins=pb.n_bins, acc_per_bin=pb.acc_per_bin,
                         bin_order=_lib.ptr(pb.bin_order), bin_entry_ptr=_lib.ptr(pb.bin_entry_ptr),
                         bin_row_ptr=_lib.ptr(pb.bin_row_ptr), slot_ptr=_lib.ptr(pb.slot_ptr), n_acc=pb.n_acc,
-                        code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits)
+                        code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits, flags=PB_FLAGS, self_is_row=int(pb.self_is_row))
     ga = _lib.SpmmPbBwdArgs(pb=a, v_self=_lib.ptr(V[0]) if pb.code_base else None, s_rows=_lib.ptr(S_rows),
                             s_rows_stride=S_rows.stride(0), with_rest=int(with_rest), dS=_lib.ptr(dS), ds_stride=dS.stride(0),
                             dlut=_lib.ptr(dlut))

@@ -60,7 +60,7 @@ struct PbParams {
   const int32_t* slot_ptr;
   int n_acc, code_base;
   const int32_t* self_col;
-  int acc_per_bin, headroom_bits;
+  int acc_per_bin, headroom_bits, self_is_row;
   float* E;
   unsigned* absmax;     // bits of max |S| (non-negative floats order like their bit patterns; NaN sorts above +inf)
   // backward (pb_reduce_kernel<2, true>): the operand is the packed rows V[code_base] = [dY_i / cnt(i, d) | dY_i / cnt(i, rest)]
@@ -83,6 +83,24 @@ __global__ void pb_prep_kernel(unsigned* absmax) {
 // phase 1: E[q, :] = S[block start + src[q], :]
 // ---------------------------------------------------------------------------------------------
 template <int W>
+__device__ __forceinline__ void expand_store(const PbParams& p, const float* sblk, unsigned s, int q, bool ok) {
+  if constexpr (W == 1) {
+    const float v = sblk[s];
+    if (ok) p.E[q] = v;
+  } else if constexpr (W == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(sblk + 2 * s);
+    if (ok) *reinterpret_cast<float2*>(p.E + 2 * static_cast<int64_t>(q)) = v;
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(sblk + 4 * s);
+    if (ok) *reinterpret_cast<float4*>(p.E + 4 * static_cast<int64_t>(q)) = v;
+  }
+}
+
+// BATCH: a wave takes 64 chunks at a time — lane l fetches chunk_q[k + l] with ONE coalesced load, the 16 wave-iterations of
+// the batch (four chunks of 16 entries each) read their offsets from it by ds_bpermute, so that every iteration is
+// "entry column -> LDS -> store" with nothing in front of it and the 16 column loads of a batch are in flight together.
+// (Reading chunk_q inside every iteration put a dependent global load in front of each: 293 us per launch.)
+template <int W, bool BATCH>
 __global__ __launch_bounds__(kThreads) void pb_expand_kernel(const PbParams p) {
   extern __shared__ __attribute__((aligned(16))) float sblk[];          // [cb_width * W]
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -90,13 +108,22 @@ __global__ __launch_bounds__(kThreads) void pb_expand_kernel(const PbParams p) {
   const int64_t c0 = static_cast<int64_t>(cb) * p.cb_width;
   const int ncol = static_cast<int>(p.n_cols - c0 < p.cb_width ? p.n_cols - c0 : p.cb_width);
   {
-    const float* src = p.S + c0 * W;
+    const float* src = p.S + c0 * W;                  // 16-byte aligned: c0 * W is a multiple of the block's floats
+    const int nf = ncol * W;
     float m = 0.f;
-    for (int i = tid; i < ncol * W; i += kThreads) {
+    auto seen = [&m](float v) {
+      const float a = fabsf(v);
+      m = (a > m || v != v) ? a : m;                  // a NaN sticks (nothing compares greater than it afterwards)
+    };
+    for (int i = tid * 4; i + 3 < nf; i += kThreads * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      *reinterpret_cast<float4*>(sblk + i) = v;
+      seen(v.x); seen(v.y); seen(v.z); seen(v.w);
+    }
+    for (int i = (nf & ~3) + tid; i < nf; i += kThreads) {
       const float v = src[i];
       sblk[i] = v;
-      const float a = fabsf(v);
-      m = (a > m || v != v) ? a : m;                 // a NaN sticks (nothing compares greater than it afterwards)
+      seen(v);
     }
     if (part == 0) {                                 // every column block is seen by exactly one `part == 0` workgroup
       unsigned bits = __float_as_uint(m);
@@ -110,36 +137,46 @@ __global__ __launch_bounds__(kThreads) void pb_expand_kernel(const PbParams p) {
   }
   __syncthreads();
   const int k_lo = p.cb_chunk_ptr[cb], k_hi = p.cb_chunk_ptr[cb + 1];
-  int per = (k_hi - k_lo + p.n_split - 1) / p.n_split;
-  per = (per + 3) & ~3;                               // whole wave-iterations (four chunks of 16 entries)
-  const int lo = k_lo + part * per;
-  const int hi = lo + per < k_hi ? lo + per : k_hi;
   const int g = lane >> 4, l16 = lane & 15;
-  constexpr int U = 4;                                // wave-iterations in flight
-  for (int kw = lo + wave * 4; kw < hi; kw += (kThreads / kWave) * 4 * U) {
-    int q[U];
-    unsigned s[U];
-    bool ok[U];
+  if constexpr (BATCH) {
+    int per = (k_hi - k_lo + p.n_split - 1) / p.n_split;
+    per = (per + 63) & ~63;                           // whole batches
+    const int lo = k_lo + part * per;
+    const int hi = lo + per < k_hi ? lo + per : k_hi;
+    for (int kb = lo + wave * kWave; kb < hi; kb += (kThreads / kWave) * kWave) {
+      const int cq = kb + lane < hi ? p.chunk_q[kb + lane] : -1;
+      int q[16];
+      unsigned s[16];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = kw + u * (kThreads / kWave) * 4 + g;
-      ok[u] = k < hi;
-      q[u] = p.chunk_q[ok[u] ? k : lo] + l16;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) s[u] = p.src[q[u]];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if constexpr (W == 1) {
-        const float v = sblk[s[u]];
-        if (ok[u]) p.E[q[u]] = v;
-      } else if constexpr (W == 2) {
-        const float2 v = *reinterpret_cast<const float2*>(sblk + 2 * s[u]);
-        if (ok[u]) *reinterpret_cast<float2*>(p.E + 2 * static_cast<int64_t>(q[u])) = v;
-      } else {
-        const float4 v = *reinterpret_cast<const float4*>(sblk + 4 * s[u]);
-        if (ok[u]) *reinterpret_cast<float4*>(p.E + 4 * static_cast<int64_t>(q[u])) = v;
+      for (int it = 0; it < 16; ++it) {
+        const int q0 = __shfl(cq, it * 4 + g);
+        q[it] = q0 < 0 ? -1 : q0 + l16;
       }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) s[it] = p.src[q[it] < 0 ? 0 : q[it]];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) expand_store<W>(p, sblk, s[it], q[it], q[it] >= 0);
+    }
+  } else {
+    int per = (k_hi - k_lo + p.n_split - 1) / p.n_split;
+    per = (per + 3) & ~3;                               // whole wave-iterations (four chunks of 16 entries)
+    const int lo = k_lo + part * per;
+    const int hi = lo + per < k_hi ? lo + per : k_hi;
+    constexpr int U = 4;                                // wave-iterations in flight
+    for (int kw = lo + wave * 4; kw < hi; kw += (kThreads / kWave) * 4 * U) {
+      int q[U];
+      unsigned s[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = kw + u * (kThreads / kWave) * 4 + g;
+        ok[u] = k < hi;
+        q[u] = p.chunk_q[ok[u] ? k : lo] + l16;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[u] = p.src[q[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) expand_store<W>(p, sblk, s[u], q[u], ok[u]);
     }
   }
 }
@@ -147,12 +184,170 @@ __global__ __launch_bounds__(kThreads) void pb_expand_kernel(const PbParams p) {
 // ---------------------------------------------------------------------------------------------
 // phase 2: one row bin per workgroup; 64-bit fixed-point accumulators in LDS
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_add(long long* acc, int idx, float v, double scale) {
-  const long long x = __double2ll_rn(static_cast<double>(v) * scale);
+// v * 2^shift as a 64-bit integer.  BITS: from the float's own mantissa and exponent (a 24-bit integer shifted into place:
+// ~10 integer instructions, truncation toward zero below 2^-shift); otherwise through float64 (convert, multiply, and the
+// compiler's multi-instruction double -> int64 sequence; round to nearest).
+template <bool BITS>
+__device__ __forceinline__ long long to_fixed(float v, double scale, int shift) {
+  if constexpr (BITS) {
+    const unsigned b = __float_as_uint(v);
+    const int ex = static_cast<int>((b >> 23) & 0xffu);
+    const long long m = static_cast<long long>((b & 0x7fffffu) | (ex ? 0x800000u : 0u));
+    const int sh = (ex ? ex : 1) - 150 + shift;                    // v = +-m * 2^(ex - 150)
+    // both shifts are always executed (one of the two amounts is zero): a `sh >= 0 ? << : >>` became a divergent branch per entry
+    const int up = sh > 0 ? (sh > 62 ? 62 : sh) : 0, down = sh < 0 ? (sh < -63 ? 63 : -sh) : 0;
+    const long long x = (m << up) >> down;
+    return (b >> 31) ? -x : x;
+  } else {
+    return __double2ll_rn(static_cast<double>(v) * scale);
+  }
+}
+
+template <bool BITS>
+__device__ __forceinline__ void lds_add(long long* acc, int idx, float v, double scale, int shift) {
+  const long long x = to_fixed<BITS>(v, scale, shift);
   atomicAdd(reinterpret_cast<unsigned long long*>(acc + idx), static_cast<unsigned long long>(x));
 }
 
-template <int W, bool BWD = false>
+// The forward epilogue over the rows [r_lo, r_hi) of a bin: RB rows per thread at a time, every load of the batch issued before the
+// first use (one row after the other — slot bounds -> accumulators, self column -> operand value — the epilogue took as long as
+// streaming the entries).  No load sits behind a condition: a guarded load ends in s_waitcnt vmcnt(0) and the batch would run one
+// load at a time; an absent count table / self column is read from some other valid array and the value dropped by a select.
+template <int W, bool SINGLE, bool SELFROW>
+__device__ __forceinline__ void fwd_rows(const PbParams& p, const long long* acc, int tid, int r_lo, int r_hi, int slot0,
+                                         double inv_scale, bool bad) {
+  constexpr int RB = 4;
+  const int rest = p.D - 1;
+  float l[4], tot[W];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) l[d] = d < p.D ? p.lut[d] : 0.f;
+#pragma unroll
+  for (int w = 0; w < W; ++w) tot[w] = p.s_total ? p.s_total[w] : 0.f;
+  const bool has_cnt = p.cnt != nullptr, has_self = SELFROW || p.self_col != nullptr;
+  const int32_t* cnt_base = has_cnt ? p.cnt : reinterpret_cast<const int32_t*>(p.lut);
+  const int64_t cnt_step = has_cnt ? p.cnt_stride : 0;
+  const int32_t* self_base = p.self_col ? p.self_col : p.slot_ptr;
+  for (int i0 = r_lo + tid; i0 < r_hi; i0 += kThreads * RB) {
+    int s_lo[RB], s_hi[RB], sc[RB], c[RB][4];
+    float sv[RB][W];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * kThreads < r_hi ? i0 + r * kThreads : r_lo;      // rows past the end re-read the first row
+      if constexpr (SINGLE) {
+        s_lo[r] = i - r_lo;
+        s_hi[r] = s_lo[r] + 1;
+      } else {
+        s_lo[r] = p.slot_ptr[i] - slot0;
+        s_hi[r] = p.slot_ptr[i + 1] - slot0;
+      }
+      if constexpr (SELFROW) sc[r] = i;
+      else sc[r] = self_base[i];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) c[r][d] = cnt_base[static_cast<int64_t>(i) * cnt_step + (d < p.D ? d : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      sc[r] = has_self ? sc[r] : -1;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) c[r][d] = has_cnt ? c[r][d] : 1;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) sv[r][w] = p.S[static_cast<int64_t>(sc[r] < 0 ? 0 : sc[r]) * W + w];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * kThreads;
+      if (i >= r_hi) break;
+      float wt[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) wt[d] = l[d] / static_cast<float>(c[r][d] > 1 ? c[r][d] : 1);   // IEEE division, as torch.div (l[d] = 0 for d >= D)
+      const float w_rest = p.s_total ? wt[rest] : 0.f;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        float out = 0.f;
+        if (sc[r] >= 0) out = fmaf(wt[0] - w_rest, sv[r][w], out);
+        for (int a = 0; a < p.n_acc; ++a) {
+          long long t = 0;
+          for (int sl = s_lo[r]; sl < s_hi[r]; ++sl) t += acc[(sl * p.n_acc + a) * W + w];
+          const float tf = static_cast<float>(static_cast<double>(t) * inv_scale);
+          const int d = p.code_base + a;
+          const float wd = d == 0 ? wt[0] : (d == 1 ? wt[1] : (d == 2 ? wt[2] : wt[3]));
+          out = fmaf(wd - w_rest, tf, out);
+        }
+        if (p.s_total) out = fmaf(w_rest, tot[w], out);
+        if (bad) out = __uint_as_float(0x7fc00000u);
+        p.Y[static_cast<int64_t>(i) * p.y_stride + w] = out;
+      }
+    }
+  }
+}
+
+// The backward epilogue over the rows of a bin (see pb_reduce_kernel<2, true>): same batching as fwd_rows.
+template <bool SINGLE, bool SELFROW>
+__device__ __forceinline__ void bwd_rows(const PbParams& p, const long long* acc, int tid, int r_lo, int r_hi, int slot0,
+                                         double inv_scale, bool bad, float l0, float l1, float lr, float add, double& g0, double& g1,
+                                         double& gr) {
+  constexpr int RB = 4;
+  const int d1 = p.code_base;
+  const bool selfs = SELFROW || (p.self_col && p.v_self);
+  const int32_t* self_base = (p.self_col && p.v_self) ? p.self_col : p.slot_ptr;         // (unconditional loads, see fwd_rows)
+  const float* vself_base = p.v_self ? p.v_self : p.S;
+  for (int i0 = r_lo + tid; i0 < r_hi; i0 += kThreads * RB) {
+    int s_lo[RB], s_hi[RB], sc[RB];
+    float sj[RB];
+    float2 v0[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * kThreads < r_hi ? i0 + r * kThreads : r_lo;
+      if constexpr (SINGLE) {
+        s_lo[r] = i - r_lo;
+        s_hi[r] = s_lo[r] + 1;
+      } else {
+        s_lo[r] = p.slot_ptr[i] - slot0;
+        s_hi[r] = p.slot_ptr[i + 1] - slot0;
+      }
+      if constexpr (SELFROW) sc[r] = i;
+      else sc[r] = self_base[i];
+      sj[r] = p.s_rows[static_cast<int64_t>(i) * p.s_rows_stride];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      sc[r] = selfs ? sc[r] : -1;
+      v0[r] = *reinterpret_cast<const float2*>(vself_base + 2 * static_cast<int64_t>(sc[r] < 0 ? 0 : sc[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * kThreads;
+      if (i >= r_hi) break;
+      long long t1i = 0, tri = 0;
+      for (int sl = s_lo[r]; sl < s_hi[r]; ++sl) {
+        t1i += acc[2 * sl];
+        tri += acc[2 * sl + 1];
+      }
+      const float t1 = static_cast<float>(static_cast<double>(t1i) * inv_scale);
+      float tr = static_cast<float>(static_cast<double>(tri) * inv_scale);
+      float a0 = 0.f;
+      if (sc[r] >= 0) {
+        a0 = v0[r].x;
+        tr += v0[r].y;
+      }
+      float ds = d1 == 0 ? 0.f : l0 * a0;
+      ds = fmaf(l1, t1, ds);
+      ds = fmaf(-lr, tr, ds);
+      ds += add;
+      if (bad) ds = __uint_as_float(0x7fc00000u);
+      p.dS[static_cast<int64_t>(i) * p.ds_stride] = ds;
+      const double s64 = static_cast<double>(sj[r]);
+      g0 += s64 * a0;
+      g1 += s64 * t1;
+      gr += s64 * tr;
+    }
+  }
+}
+
+template <int W, bool BWD = false, bool BITS = false, int U = 2>
 __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];     // [acc_per_bin * W]
   const int tid = threadIdx.x;
@@ -167,7 +362,6 @@ __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
   const double scale = bad ? 0.0 : ldexp(1.0, shift), inv_scale = bad ? 0.0 : ldexp(1.0, -shift);
   __syncthreads();
   const int q_lo = p.bin_entry_ptr[b], q_hi = p.bin_entry_ptr[b + 1];   // multiples of kChunk
-  constexpr int U = 2;
   for (int base = q_lo + tid * 4; base < q_hi; base += kThreads * 4 * U) {
     uint2 d[U];
     float4 v[U][W];
@@ -183,25 +377,27 @@ __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!ok[u]) continue;
-      const int i0 = static_cast<int>(d[u].x & 0xffffu), i1 = static_cast<int>(d[u].x >> 16);
-      const int i2 = static_cast<int>(d[u].y & 0xffffu), i3 = static_cast<int>(d[u].y >> 16);
+      // (no branch around the atomics — the compiler sinks the second round's loads behind it: rounds past the end re-read
+      //  the bin's first entries and add them to the pads' dummy accumulator)
+      const int dummy = p.acc_per_bin - 1;
+      const int i0 = ok[u] ? static_cast<int>(d[u].x & 0xffffu) : dummy, i1 = ok[u] ? static_cast<int>(d[u].x >> 16) : dummy;
+      const int i2 = ok[u] ? static_cast<int>(d[u].y & 0xffffu) : dummy, i3 = ok[u] ? static_cast<int>(d[u].y >> 16) : dummy;
       if constexpr (W == 1) {
-        lds_add(acc, i0, v[u][0].x, scale);
-        lds_add(acc, i1, v[u][0].y, scale);
-        lds_add(acc, i2, v[u][0].z, scale);
-        lds_add(acc, i3, v[u][0].w, scale);
+        lds_add<BITS>(acc, i0, v[u][0].x, scale, shift);
+        lds_add<BITS>(acc, i1, v[u][0].y, scale, shift);
+        lds_add<BITS>(acc, i2, v[u][0].z, scale, shift);
+        lds_add<BITS>(acc, i3, v[u][0].w, scale, shift);
       } else if constexpr (W == 2) {
-        lds_add(acc, 2 * i0, v[u][0].x, scale); lds_add(acc, 2 * i0 + 1, v[u][0].y, scale);
-        lds_add(acc, 2 * i1, v[u][0].z, scale); lds_add(acc, 2 * i1 + 1, v[u][0].w, scale);
-        lds_add(acc, 2 * i2, v[u][1].x, scale); lds_add(acc, 2 * i2 + 1, v[u][1].y, scale);
-        lds_add(acc, 2 * i3, v[u][1].z, scale); lds_add(acc, 2 * i3 + 1, v[u][1].w, scale);
+        lds_add<BITS>(acc, 2 * i0, v[u][0].x, scale, shift); lds_add<BITS>(acc, 2 * i0 + 1, v[u][0].y, scale, shift);
+        lds_add<BITS>(acc, 2 * i1, v[u][0].z, scale, shift); lds_add<BITS>(acc, 2 * i1 + 1, v[u][0].w, scale, shift);
+        lds_add<BITS>(acc, 2 * i2, v[u][1].x, scale, shift); lds_add<BITS>(acc, 2 * i2 + 1, v[u][1].y, scale, shift);
+        lds_add<BITS>(acc, 2 * i3, v[u][1].z, scale, shift); lds_add<BITS>(acc, 2 * i3 + 1, v[u][1].w, scale, shift);
       } else {
         const int idx[4] = {i0, i1, i2, i3};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          lds_add(acc, 4 * idx[j], v[u][j].x, scale); lds_add(acc, 4 * idx[j] + 1, v[u][j].y, scale);
-          lds_add(acc, 4 * idx[j] + 2, v[u][j].z, scale); lds_add(acc, 4 * idx[j] + 3, v[u][j].w, scale);
+          lds_add<BITS>(acc, 4 * idx[j], v[u][j].x, scale, shift); lds_add<BITS>(acc, 4 * idx[j] + 1, v[u][j].y, scale, shift);
+          lds_add<BITS>(acc, 4 * idx[j] + 2, v[u][j].z, scale, shift); lds_add<BITS>(acc, 4 * idx[j] + 3, v[u][j].w, scale, shift);
         }
       }
     }
@@ -212,40 +408,15 @@ __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
   const int slot0 = p.slot_ptr[r_lo];
   const int rest = p.D - 1;
   if constexpr (!BWD) {
-    for (int i = r_lo + tid; i < r_hi; i += kThreads) {
-      const int s_lo = p.slot_ptr[i] - slot0, s_hi = p.slot_ptr[i + 1] - slot0;
-      float wt[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        float v = 0.f;
-        if (d < p.D) {
-          v = p.lut[d];
-          if (p.cnt) {
-            const int c = p.cnt[static_cast<int64_t>(i) * p.cnt_stride + d];
-            v = v / static_cast<float>(c > 1 ? c : 1);                   // IEEE division, as torch.div (spmm.hip: small_weights)
-          }
-        }
-        wt[d] = v;
-      }
-      const float w_rest = p.s_total ? wt[rest] : 0.f;
-      const int sc = p.self_col ? p.self_col[i] : -1;
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        float out = 0.f;
-        if (sc >= 0) out = fmaf(wt[0] - w_rest, p.S[static_cast<int64_t>(sc) * W + w], out);
-        for (int a = 0; a < p.n_acc; ++a) {
-          long long t = 0;
-          for (int s = s_lo; s < s_hi; ++s) t += acc[(s * p.n_acc + a) * W + w];
-          const float tf = static_cast<float>(static_cast<double>(t) * inv_scale);
-          const int d = p.code_base + a;
-          const float wd = d == 0 ? wt[0] : (d == 1 ? wt[1] : (d == 2 ? wt[2] : wt[3]));
-          out = fmaf(wd - w_rest, tf, out);
-        }
-        if (p.s_total) out = fmaf(w_rest, p.s_total[w], out);
-        if (bad) out = __uint_as_float(0x7fc00000u);
-        p.Y[static_cast<int64_t>(i) * p.y_stride + w] = out;
-      }
-    }
+    // which of the per-row index arrays the bin needs at all (workgroup-uniform: whole-batch variants, no guarded loads):
+    //   single   every row of the bin owns exactly one accumulator slot (all but the bins that hold a hub row): slot = row - first row
+    //   selfrow  the self pair of row i lists operand row i (gnan_spmm_pb_args.self_is_row): no self_col read
+    const bool single = p.slot_ptr[r_hi] - slot0 == r_hi - r_lo;
+    const bool selfrow = p.self_is_row != 0;
+    if (single && selfrow) fwd_rows<W, true, true>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad);
+    else if (single) fwd_rows<W, true, false>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad);
+    else if (selfrow) fwd_rows<W, false, true>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad);
+    else fwd_rows<W, false, false>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad);
   } else {
     // Backward over the TRANSPOSED adjacency (W == 2, one accumulated code d1 = code_base): row j of the bin is operand node j,
     //   t1 = sum_{i lists j with code d1} dY_i / cnt(i, d1),   tr = sum_{the same i} dY_i / cnt(i, rest),
@@ -257,33 +428,12 @@ __global__ __launch_bounds__(kThreads) void pb_reduce_kernel(const PbParams p) {
     float add = 0.f;
     if (p.ds_add) add = p.ds_add_scale ? p.ds_add[0] * p.ds_add_scale[0] : p.ds_add[0];
     double g0 = 0.0, g1 = 0.0, gr = 0.0;
-    for (int i = r_lo + tid; i < r_hi; i += kThreads) {
-      const int s_lo = p.slot_ptr[i] - slot0, s_hi = p.slot_ptr[i + 1] - slot0;
-      long long t1i = 0, tri = 0;
-      for (int s = s_lo; s < s_hi; ++s) {
-        t1i += acc[2 * s];
-        tri += acc[2 * s + 1];
-      }
-      const float t1 = static_cast<float>(static_cast<double>(t1i) * inv_scale);
-      float tr = static_cast<float>(static_cast<double>(tri) * inv_scale);
-      const int sc = (p.self_col && p.v_self) ? p.self_col[i] : -1;
-      float a0 = 0.f;
-      if (sc >= 0) {
-        const float2 v0 = *reinterpret_cast<const float2*>(p.v_self + 2 * static_cast<int64_t>(sc));
-        a0 = v0.x;
-        tr += v0.y;
-      }
-      float ds = d1 == 0 ? 0.f : l0 * a0;
-      ds = fmaf(l1, t1, ds);
-      ds = fmaf(-lr, tr, ds);
-      ds += add;
-      if (bad) ds = __uint_as_float(0x7fc00000u);
-      p.dS[static_cast<int64_t>(i) * p.ds_stride] = ds;
-      const double sj = static_cast<double>(p.s_rows[static_cast<int64_t>(i) * p.s_rows_stride]);
-      g0 += sj * a0;
-      g1 += sj * t1;
-      gr += sj * tr;
-    }
+    const bool single = p.slot_ptr[r_hi] - slot0 == r_hi - r_lo;
+    const bool selfrow = p.self_is_row != 0 && p.v_self != nullptr;
+    if (single && selfrow) bwd_rows<true, true>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad, l0, l1, lr, add, g0, g1, gr);
+    else if (single) bwd_rows<true, false>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad, l0, l1, lr, add, g0, g1, gr);
+    else if (selfrow) bwd_rows<false, true>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad, l0, l1, lr, add, g0, g1, gr);
+    else bwd_rows<false, false>(p, acc, tid, r_lo, r_hi, slot0, inv_scale, bad, l0, l1, lr, add, g0, g1, gr);
     // per-bin partials of the table gradient: lanes, then waves, in a fixed order; the bins are added by pb_dlut_final_kernel
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -361,6 +511,7 @@ int validate(const gnan_spmm_pb_args* a) {
                "gnan_spmm_pb_fwd: a bin's accumulators must fit 64 KB of LDS");
   GNAN_REQUIRE(a->n_bins > 0 && a->headroom_bits >= 0 && a->headroom_bits <= 40, "gnan_spmm_pb_fwd: bad plan");
   GNAN_REQUIRE(a->y_stride >= a->W, "gnan_spmm_pb_fwd: y_stride < W");
+  GNAN_REQUIRE(!a->self_is_row || a->n_cols >= a->n_rows, "gnan_spmm_pb_fwd: self_is_row needs an operand row per output row");
   GNAN_REQUIRE((reinterpret_cast<uintptr_t>(a->dst) % 8) == 0 && (reinterpret_cast<uintptr_t>(a->src) % 2) == 0,
                "gnan_spmm_pb_fwd: dst must be 8-byte aligned");
   return GNAN_OK;
@@ -371,14 +522,23 @@ size_t pb_bytes(const gnan_spmm_pb_args* a) {
 }
 
 template <int W, bool BWD = false>
-int launch(const PbParams& p, hipStream_t st) {
+int launch(const PbParams& p, hipStream_t st, int flags) {
   hipLaunchKernelGGL(pb_prep_kernel, dim3(1), dim3(64), 0, st, p.absmax);
   if (int rc = gnan::check_launch("pb_prep_kernel")) return rc;
   const size_t lds1 = static_cast<size_t>(p.cb_width) * W * sizeof(float);
-  hipLaunchKernelGGL((pb_expand_kernel<W>), dim3(static_cast<unsigned>(p.n_cblocks) * p.n_split), dim3(kThreads), lds1, st, p);
+  const dim3 grid1(static_cast<unsigned>(p.n_cblocks) * p.n_split);
+  if (flags & GNAN_PB_EXPAND_PER_ITERATION)
+    hipLaunchKernelGGL((pb_expand_kernel<W, false>), grid1, dim3(kThreads), lds1, st, p);
+  else
+    hipLaunchKernelGGL((pb_expand_kernel<W, true>), grid1, dim3(kThreads), lds1, st, p);
   if (int rc = gnan::check_launch("pb_expand_kernel")) return rc;
   const size_t lds2 = static_cast<size_t>(p.acc_per_bin) * W * sizeof(long long);
-  hipLaunchKernelGGL((pb_reduce_kernel<W, BWD>), dim3(static_cast<unsigned>(p.n_bins)), dim3(kThreads), lds2, st, p);
+  const dim3 grid2(static_cast<unsigned>(p.n_bins));
+  const bool dbl = (flags & GNAN_PB_FIXED_VIA_DOUBLE) != 0, u4 = (flags & GNAN_PB_REDUCE_UNROLL4) != 0;
+  if (dbl && u4) hipLaunchKernelGGL((pb_reduce_kernel<W, BWD, false, 4>), grid2, dim3(kThreads), lds2, st, p);
+  else if (dbl) hipLaunchKernelGGL((pb_reduce_kernel<W, BWD, false, 2>), grid2, dim3(kThreads), lds2, st, p);
+  else if (u4) hipLaunchKernelGGL((pb_reduce_kernel<W, BWD, true, 4>), grid2, dim3(kThreads), lds2, st, p);
+  else hipLaunchKernelGGL((pb_reduce_kernel<W, BWD, true, 2>), grid2, dim3(kThreads), lds2, st, p);
   return gnan::check_launch("pb_reduce_kernel");
 }
 
@@ -390,11 +550,13 @@ PbParams make_params(const gnan_spmm_pb_args* a) {
   p.chunk_q = a->chunk_q; p.cb_chunk_ptr = a->cb_chunk_ptr; p.n_bins = a->n_bins; p.bin_order = a->bin_order;
   p.bin_entry_ptr = a->bin_entry_ptr; p.bin_row_ptr = a->bin_row_ptr; p.slot_ptr = a->slot_ptr; p.n_acc = a->n_acc;
   p.code_base = a->code_base; p.self_col = a->self_col; p.acc_per_bin = a->acc_per_bin; p.headroom_bits = a->headroom_bits;
+  p.self_is_row = a->self_is_row;
   p.absmax = static_cast<unsigned*>(a->workspace);
   p.E = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 256);
   // enough workgroups per column block that the launch is >> the resident ones (two per CU) whatever the block count
   int split = (2048 + a->n_cblocks - 1) / a->n_cblocks;
-  p.n_split = split < 1 ? 1 : (split > 16 ? 16 : split);
+  if ((a->flags >> 8) & 0xff) split = (a->flags >> 8) & 0xff;          // A/B: workgroups per column block
+  p.n_split = split < 1 ? 1 : (split > 64 ? 64 : split);
   return p;
 }
 
@@ -418,9 +580,9 @@ extern "C" int gnan_spmm_pb_fwd(const gnan_spmm_pb_args* a, gnan_stream_t stream
   const PbParams p = make_params(a);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a->W) {
-    case 1: return launch<1>(p, st);
-    case 2: return launch<2>(p, st);
-    default: return launch<4>(p, st);
+    case 1: return launch<1>(p, st, a->flags);
+    case 2: return launch<2>(p, st, a->flags);
+    default: return launch<4>(p, st, a->flags);
   }
 }
 
@@ -448,7 +610,7 @@ extern "C" int gnan_spmm_pb_bwd(const gnan_spmm_pb_bwd_args* g, gnan_stream_t st
   p.dS = g->dS; p.ds_stride = g->ds_stride; p.ds_add = g->ds_add; p.ds_add_scale = g->ds_add_scale;
   p.dlut_partial = reinterpret_cast<double*>(static_cast<char*>(a.workspace) + (pb_bytes(&a) + 15) / 16 * 16);
   if (a.n_rows > 0) {
-    if (int rc = launch<2, true>(p, st)) return rc;
+    if (int rc = launch<2, true>(p, st, a.flags)) return rc;
   }
   hipLaunchKernelGGL(pb_dlut_final_kernel, dim3(1), dim3(256), 0, st, p.dlut_partial, a.n_rows > 0 ? a.n_bins : 0, a.D, a.code_base,
                      g->with_rest, g->rest_total, g->rest_q, g->dlut);

@@ -63,6 +63,7 @@ class PbPlan:
     self_col: Optional[torch.Tensor]   # int32 [n_rows] or None
     headroom_bits: int
     n_pairs: int                  # real entries (without pads and without the pairs self_col serves)
+    self_is_row: bool = False     # every row's self_col entry is the row itself: the kernels need not read self_col
 
 
 @dataclass
@@ -388,7 +389,9 @@ class HopGraph:
         return PbPlan(W=W, n_entries=n_entries, src=src16, dst=dst16, cb_width=cbw, n_cblocks=n_cb, chunk_q=i32(chunk_q),
                       cb_chunk_ptr=i32(cb_chunk_ptr), n_bins=n_bins, acc_per_bin=R, bin_order=i32(bin_order),
                       bin_entry_ptr=i32(bin_entry_ptr), bin_row_ptr=i32(bin_row_ptr), slot_ptr=i32(slot_ptr), n_acc=n_acc,
-                      code_base=code_base, self_col=self_col, headroom_bits=headroom, n_pairs=m)
+                      code_base=code_base, self_col=self_col, headroom_bits=headroom, n_pairs=m,
+                      self_is_row=bool(self_col is not None and n <= self.n_cols
+                                       and torch.equal(self_col, torch.arange(n, dtype=torch.int32, device=dev))))
 
     def inv_rest_count(self) -> torch.Tensor:
         """``1 / max(cnt[:, D-1], 1)`` as float32 ``[n_rows, 1]`` (graph data, cached): the normalisation of the rest bucket."""

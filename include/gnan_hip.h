@@ -502,6 +502,11 @@ int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream);
  * workspace: gnan_spmm_pb_workspace_bytes(a) bytes, 16-byte aligned (the expanded operand, n_entries * W floats).
  * A non-finite operand value yields NaN in every output row.
  * ------------------------------------------------------------------------------------------- */
+enum gnan_pb_flags {
+  GNAN_PB_EXPAND_PER_ITERATION = 1,  /* phase 1 reads a chunk's offset inside every wave-iteration (default: 64 offsets per load) */
+  GNAN_PB_FIXED_VIA_DOUBLE = 2,      /* phase 2 converts v * 2^shift through float64 (default: from the float's mantissa / exponent) */
+  GNAN_PB_REDUCE_UNROLL4 = 4         /* phase 2 keeps four rounds of loads in flight per thread (default: two) */
+};
 typedef struct gnan_spmm_pb_args {
   int64_t n_rows;
   int64_t n_cols;
@@ -534,6 +539,9 @@ typedef struct gnan_spmm_pb_args {
   int32_t headroom_bits;
   void* workspace;
   size_t workspace_bytes;
+  int32_t flags;             /* A/B switches (enum gnan_pb_flags): 0 = the defaults; bits 8-15 = workgroups per column block */
+  int32_t self_is_row;       /* the hop-code-0 pair of EVERY row i lists operand row i (a hop-coded graph's self pairs, n_cols >=
+                                n_rows): self_col is not read and may be NULL */
 } gnan_spmm_pb_args;
 
 size_t gnan_spmm_pb_workspace_bytes(const gnan_spmm_pb_args* a);

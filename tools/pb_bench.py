@@ -43,11 +43,15 @@ for W in [int(w) for w in sys.argv[1:]] or [1, 2]:
     t_plan = (time.perf_counter() - t0) * 1e3
     out = {"W": W, "plan_ms": t_plan, "entries": plan.n_entries, "pairs": plan.n_pairs, "bins": plan.n_bins,
            "column_blocks": plan.n_cblocks, "chunks": int(plan.chunk_q.numel())}
+    flag_sets = [int(f, 0) for f in os.environ.get("PB_FLAG_SETS", "0").split(",")]
+    USE_CNT, WITH_REST = os.environ.get("PB_USE_CNT", "1") == "1", os.environ.get("PB_WITH_REST", "1") == "1"
     for rnd in range(2):
-        aggregate.PB_NARROW = True
-        ms_pb, y_pb = timed(lambda: spmm_launch(g, S, lut, True, True, s_total=total))
-        aggregate.PB_NARROW = False
-        ms_rows, y_rows = timed(lambda: spmm_launch(g, S, lut, True, True, s_total=total))
-        out[f"pb_ms_{rnd}"], out[f"rows_ms_{rnd}"] = ms_pb, ms_rows
+        for fl in flag_sets:
+            aggregate.PB_NARROW, aggregate.PB_FLAGS = True, fl
+            ms_pb, y_pb = timed(lambda: spmm_launch(g, S, lut, USE_CNT, WITH_REST, s_total=total if WITH_REST else None))
+            out[f"pb_ms_flags{fl:#x}_{rnd}"] = ms_pb
+        aggregate.PB_NARROW, aggregate.PB_FLAGS = False, 0
+        ms_rows, y_rows = timed(lambda: spmm_launch(g, S, lut, USE_CNT, WITH_REST, s_total=total if WITH_REST else None))
+        out[f"rows_ms_{rnd}"] = ms_rows
     out["max_rel_diff"] = float((y_pb - y_rows).abs().max() / y_rows.abs().max())
     print(json.dumps(out), flush=True)
