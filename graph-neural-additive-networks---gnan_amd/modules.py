@@ -57,12 +57,13 @@ def _tiny_init(module: nn.Module) -> None:
 
 GRAPH_CACHE_ENTRIES = 8192   # hop-coded graphs kept per model (graph tasks cycle through a few thousand small graphs per epoch)
 
-# ``model.parameters()`` hands out the flat buffers (a dozen Parameters) instead of the F x L per-layer tensors that are views of
-# them: what a stock optimizer built as main.py:141 builds it — ``Adam(model.parameters())`` — then zeroes and updates per step is
-# twelve tensors, not 8604 (Cora shape).  Every element-wise optimizer (Adam, AdamW, SGD, ...) computes the same numbers either
-# way; ``named_parameters()`` / ``state_dict()`` keep the reference's per-layer names and shapes (``sum(p.numel())``, main.py:92-97,
-# is the same).  False: ``parameters()`` is torch's own.
-FLAT_PARAMETERS = True
+# ``model.parameters()`` is torch's own: the F x L per-layer tensors, in ``named_parameters()`` order — the nn.Module contract
+# (DDP hooks, tooling that zips or counts the two, optimizer state_dicts).  The flat buffers those tensors are views of are handed
+# out by ``model.flat_parameters()`` (= ``gnan_amd.optim_params(model)``): an optimizer built over THEM zeroes and updates a dozen
+# tensors per step instead of 8604 (Cora shape) and computes the same numbers (every element-wise optimizer does); give an
+# optimizer one face or the other, never both.  True: ``parameters()`` itself yields the flat buffers, as in round 5 — an opt-in for
+# an unchanged ``Adam(model.parameters())`` (main.py:141) that wants the cheap step and knows what it gives up.
+FLAT_PARAMETERS = False
 PAD_STORE_FEATURES = True    # FlatMLPStore keeps room for F rounded up to 16 features (all-zero shape functions): see rebuild()
 
 
@@ -309,11 +310,17 @@ class _PathBase(nn.Module):
                 store.rebuild()
 
     def parameters(self, recurse: bool = True):
-        """The flat buffers (see ``FLAT_PARAMETERS``) followed by whatever Parameter lies in none of them (``rhos[0 .. F-2]`` of
-        ``GNAN(rho_per_feature=True)``, GNAN.py:108-123: tensors no forward reads).  ``named_parameters()`` is torch's own."""
-        if not (FLAT_PARAMETERS and recurse and "_stores" in self.__dict__):
+        """torch's own ``parameters()`` (the per-layer tensors) unless ``modules.FLAT_PARAMETERS`` is switched on."""
+        if FLAT_PARAMETERS and recurse and "_stores" in self.__dict__:
+            yield from self.flat_parameters()
+        else:
             yield from super().parameters(recurse)
-            return
+
+    def flat_parameters(self):
+        """The flat buffers every per-layer Parameter is a view of, followed by whatever Parameter lies in none of them
+        (``rhos[0 .. F-2]`` of ``GNAN(rho_per_feature=True)``, GNAN.py:108-123: tensors no forward reads): what to hand an
+        optimizer INSTEAD of ``parameters()`` — same elements (``sum(p.numel())`` agrees), a dozen tensors.  An optimizer state
+        saved over one face does not load into an optimizer over the other."""
         flats, managed = [], set()
         for m in self.modules():
             if isinstance(m, _PathBase) and "_stores" in m.__dict__:
@@ -322,7 +329,7 @@ class _PathBase(nn.Module):
                     flats.extend(store.flat[name] for name in store.buf)
                     managed.update(id(p) for p in store.params())
         yield from flats
-        for p in super().parameters(recurse=True):
+        for p in nn.Module.parameters(self, recurse=True):
             if id(p) not in managed:
                 yield p
 
@@ -518,7 +525,9 @@ class StandaloneTensorGNAN(_PathBase):
         self._init_caches()
 
     def forward(self, inputs):
-        from . import replay
+        from . import cpu_route, replay
+        if cpu_route.applies(self, inputs.x):         # a CPU module on CPU inputs (the reference's default device): plain torch
+            return cpu_route.forward_standalone_tensor(self, inputs)
         return replay.run(self, inputs)               # the launches below, or — third call on the same inputs — their hipGraphs
 
     def _forward(self, inputs):
@@ -577,7 +586,9 @@ class _GNANCore(_PathBase):
         self._init_caches()
 
     def forward(self, inputs, node_ids=None):
-        from . import replay
+        from . import cpu_route, replay
+        if cpu_route.applies(self, inputs.x):
+            return cpu_route.forward_gnan(self, inputs, node_ids)
         return replay.run(self, inputs, node_ids)
 
     def _forward(self, inputs, node_ids=None):
@@ -635,6 +646,9 @@ class NAM(_PathBase):
         self._init_caches()
 
     def forward(self, x):
+        from . import cpu_route
+        if cpu_route.applies(self, x):
+            return cpu_route.forward_nam(self, x)
         self._check_dropout()
         return self._features(x, "fs", self.fs, True)
 
@@ -674,7 +688,9 @@ class TensorGNAN(_PathBase):
         self._init_caches()
 
     def forward(self, inputs):
-        from . import replay
+        from . import cpu_route, replay
+        if cpu_route.applies(self, inputs.x):
+            return cpu_route.forward_models_tensor(self, inputs)
         return replay.run(self, inputs)
 
     def _forward(self, inputs):

@@ -118,8 +118,8 @@ def run_exp(train_loader, val_loader, test_loader, num_features, seeds, n_layers
         raise ValueError("only model_name='gnan' lives on this path (the baselines of models.py:8-256 are out of scope)")
     if wandb_flag:
         raise ValueError("wandb logging is not part of this harness")
-    if device is None:
-        device = torch.device("cuda")                     # main.py:49-52 picks cuda when there is one; there is no CPU path here
+    if device is None:                                    # main.py:49-52: cuda when there is one, else the CPU (gnan_amd.cpu_route)
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     if loss_type is None:
         loss_type, _ = loss_and_out_dim(num_classes, is_regression)
     classify = True                                       # main.py:159: `~is_regression` is -1 or -2, truthy either way
@@ -128,7 +128,8 @@ def run_exp(train_loader, val_loader, test_loader, num_features, seeds, n_layers
         net = model if model is not None else build_model(num_features, out_dim, n_layers, hidden_channels, dropout, device,
                                                           rho_per_feature, normalize_m, is_graph_task, readout_n_layers)
         net.to(device)
-        optimizer = optimizer_type(params=net.parameters(), lr=lr, weight_decay=wd)          # main.py:141
+        from . import optim_params
+        optimizer = optimizer_type(params=optim_params(net), lr=lr, weight_decay=wd)         # main.py:141, over the flat buffers
         loss = loss_type()
         patience_counter = PatienceCounter(patience)                                            # main.py:142
         rules = CheckpointRules(compute_auc)

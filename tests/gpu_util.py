@@ -1,4 +1,4 @@
-"""Helpers for the GPU parity tests: fixture -> gnan_amd module on cuda:0."""
+"""Helpers for the parity tests: fixture -> gnan_amd module on cuda:0 (or, for the CPU route's tests, on the CPU)."""
 import numpy as np
 import torch
 
@@ -16,10 +16,10 @@ class Bag:
         self.__dict__.update(kw)
 
 
-def build_module(g):
+def build_module(g, dev=DEV):
     m = g.meta
     F = g.inputs["x"].shape[1]
-    kw = dict(in_channels=F, out_channels=m["C"], hidden_channels=m["H"], bias=m["bias"], dropout=0.0, device=DEV)
+    kw = dict(in_channels=F, out_channels=m["C"], hidden_channels=m["H"], bias=m["bias"], dropout=0.0, device=dev)
     v = m["variant"]
     if v.startswith("standalone_tensor"):
         mod = amd_standalone.TensorGNAN(n_layers=m["L"], normalize_rho=m["normalize_rho"],
@@ -40,11 +40,11 @@ def build_module(g):
         raise ValueError(v)
     sd = {k: torch.from_numpy(np.array(a)) for k, a in g.sd.items()}
     mod.load_state_dict(sd, strict=True)          # key names and shapes are part of the drop-in contract
-    return mod.to(DEV).eval()
+    return mod.to(dev).eval()
 
 
-def device_inputs(g):
-    return Bag(**{k: torch.from_numpy(np.array(v)).to(DEV) for k, v in g.inputs.items()})
+def device_inputs(g, dev=DEV):
+    return Bag(**{k: torch.from_numpy(np.array(v)).to(dev) for k, v in g.inputs.items()})
 
 
 def call(mod, g, data):

@@ -26,9 +26,9 @@ def _make(kind):
 
 
 def _params(m, how):
-    """``flat``: ``model.parameters()`` — the flat buffers themselves (modules.FLAT_PARAMETERS; what main.py:141 hands its
-    optimizer); ``per_layer``: the F x L tensors of ``named_parameters()`` that are views of them."""
-    return list(m.parameters()) if how == "flat" else [p for _, p in m.named_parameters()]
+    """``flat``: ``model.flat_parameters()`` — the flat buffers themselves (``gnan_amd.optim_params``); ``per_layer``: the F x L
+    tensors of ``parameters()`` / ``named_parameters()`` that are views of them (what main.py:141 hands its optimizer)."""
+    return list(m.flat_parameters()) if how == "flat" else list(m.parameters())
 
 
 def _stores(m):
@@ -62,7 +62,7 @@ def test_flat_update_equals_the_optimizer_step(kind, cls, kw, how):
         oa.step()
         if it == 2:                                   # two ordinary steps first: their state is carried over
             flat = FlatAdamStep.build(b, ob)
-            assert flat is not None and flat.buffers == len(list(b.parameters())) < len(list(b.named_parameters()))
+            assert flat is not None and flat.buffers == len(list(b.flat_parameters())) < len(list(b.named_parameters()))
         flat.step() if flat is not None else ob.step()
         if it == 4:                                   # the ordinary step keeps working on the views
             for m, o in ((a, oa), (b, ob)):
@@ -108,15 +108,21 @@ def test_flat_update_declines_what_it_cannot_reproduce(how):
     assert FlatAdamStep.build(fresh, torch.optim.Adam(_params(fresh, how), lr=1e-2, fused=True)) is None
 
 
-def test_parameters_are_the_flat_buffers_and_names_stay_the_references():
-    """``model.parameters()``: a dozen flat Parameters (+ the tensors no store holds) with the element count of
-    ``named_parameters()`` (main.py:92-97 sums ``numel``); names, shapes and ``state_dict`` keys are the per-layer ones;
-    an in-place update of a flat Parameter is an update of the per-layer views; a stock optimizer over ``parameters()``
-    steps to the same numbers as one over the per-layer tensors; ``zero_grad`` of either kind is honoured."""
+def test_parameters_is_torchs_own_and_flat_parameters_are_the_buffers():
+    """``model.parameters()`` is the nn.Module contract (the tensors of ``named_parameters()``, same objects, same order);
+    ``model.flat_parameters()`` / ``gnan_amd.optim_params(model)``: a dozen flat Parameters (+ the tensors no store holds) with
+    the same element count (main.py:92-97 sums ``numel``); names, shapes and ``state_dict`` keys are the per-layer ones; an
+    in-place update of a flat Parameter is an update of the per-layer views; a stock optimizer over the flat face steps to the
+    same numbers as one over ``parameters()``; ``zero_grad`` of either kind is honoured; ``FLAT_PARAMETERS = True`` is the
+    round-5 behaviour (``parameters()`` yields the flat face)."""
+    import gnan_amd
     from gnan_amd import modules
     for kind in ("readout", "gnan", "plain"):
         m, twin = _make(kind), _make(kind)
-        flat, named = list(m.parameters()), dict(m.named_parameters())
+        named = dict(m.named_parameters())
+        assert [id(p) for p in m.parameters()] == [id(p) for p in named.values()]            # torch's own
+        flat = list(m.flat_parameters())
+        assert [id(p) for p in gnan_amd.optim_params(m)] == [id(p) for p in flat]
         assert sum(p.numel() for p in flat) == sum(p.numel() for p in named.values())
         assert len({id(p) for p in flat}) == len(flat) and len(flat) < len(named)
         assert list(m.state_dict().keys()) == list(twin.state_dict().keys())
@@ -125,8 +131,8 @@ def test_parameters_are_the_flat_buffers_and_names_stay_the_references():
         assert torch.equal(named["fs.0.0.weight"], 2.0 * dict(twin.named_parameters())["fs.0.0.weight"])
         with torch.no_grad():
             flat[0].mul_(0.5)
-        oa = torch.optim.Adam(m.parameters(), lr=1e-2, weight_decay=1e-3)                 # main.py:141
-        ob = torch.optim.Adam([p for _, p in twin.named_parameters()], lr=1e-2, weight_decay=1e-3)
+        oa = torch.optim.Adam(gnan_amd.optim_params(m), lr=1e-2, weight_decay=1e-3)
+        ob = torch.optim.Adam(twin.parameters(), lr=1e-2, weight_decay=1e-3)                  # main.py:141
         for it in range(3):
             oa.zero_grad()
             ob.zero_grad()
@@ -145,10 +151,11 @@ def test_parameters_are_the_flat_buffers_and_names_stay_the_references():
         for (k, p), (_, q) in zip(m.named_parameters(), twin.named_parameters()):
             assert float((p - q).abs().max()) <= 1e-6 * float(q.abs().max()), k
         m.requires_grad_(False)
-        assert not any(p.requires_grad for p in m.parameters()) and not any(p.requires_grad for _, p in m.named_parameters())
+        assert not any(p.requires_grad for p in m.flat_parameters()) and not any(p.requires_grad for p in m.parameters())
+    assert gnan_amd.optim_params(torch.nn.Linear(2, 2)).__len__() == 2                       # any other module: its parameters()
     try:
-        modules.FLAT_PARAMETERS = False
-        m = _make("plain")
-        assert len(list(m.parameters())) == len(list(m.named_parameters()))
-    finally:
         modules.FLAT_PARAMETERS = True
+        m = _make("plain")
+        assert [id(p) for p in m.parameters()] == [id(p) for p in m.flat_parameters()]
+    finally:
+        modules.FLAT_PARAMETERS = False
