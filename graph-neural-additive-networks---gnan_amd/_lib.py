@@ -420,5 +420,6 @@ def require_device(*tensors: Optional[torch.Tensor]) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise GnanHipError(
-                "gnan_amd runs on the MI355X only: got a CPU tensor. Move the module and its inputs to the GPU "
-                "(`model.to('cuda')`, `data.to('cuda')`); there is deliberately no CPU fallback.")
+                "gnan_amd's kernels run on the MI355X only: got a CPU tensor. Move the module and its inputs to the GPU "
+                "(`model.to('cuda')`, `data.to('cuda')`); there is deliberately no CPU fallback behind the HIP path "
+                "(a module that lives on the CPU is evaluated by gnan_amd.cpu_route when it is called with CPU inputs).")

@@ -95,19 +95,28 @@ def test_struct_layout_matches_header():
         assert fields == [f[0] for f in cls._fields_], struct
 
 
-def test_cpu_tensors_are_rejected_loudly():
+def test_the_hip_path_has_no_cpu_fallback():
+    """The kernels' launch wrappers reject CPU tensors loudly, and a module on one device called with inputs on another raises:
+    nothing silently moves work to the CPU.  (A module that LIVES on the CPU, called with CPU inputs, is the CPU route's —
+    tests/test_cpu_route.py.)"""
+    from gnan_amd import HopGraph
+    from gnan_amd.aggregate import rho_aggregate
+    from gnan_amd.functional import feature_mlps, stack_mlps
     from gnan_amd.models import TensorGNAN
+    m = TensorGNAN(3, 2, 3, hidden_channels=8).eval()
+    with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
+        feature_mlps(torch.rand(5, 3), stack_mlps(m.fs), True)
+    g = HopGraph.from_csr(torch.tensor([0, 1, 2]), torch.tensor([0, 1], dtype=torch.int32), torch.zeros(2, dtype=torch.uint8),
+                          n_cols=2, n_codes=2)
+    with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
+        rho_aggregate(g, torch.rand(2, 1), torch.rand(2, 1), True)
 
     class Bag:
         pass
 
     d = Bag()
-    d.x = torch.rand(5, 3)
-    d.edge_index = torch.zeros(2, 0, dtype=torch.long)
-    d.node_distances = torch.eye(5)
-    d.normalization_matrix = torch.ones(5, 5)
-    m = TensorGNAN(3, 2, 3, hidden_channels=8).eval()
-    with pytest.raises(_lib.GnanHipError, match="no CPU fallback"):
+    d.x = torch.rand(5, 3, device="meta")              # inputs on another device than the module
+    with pytest.raises(_lib.GnanHipError, match="ONE device"):
         m.forward(d)
 
 
