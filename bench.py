@@ -46,6 +46,9 @@ def parse():
                     help="c2 / c3: 'reference' adds the training step as the reference's UNCHANGED loop issues it (tests/reference_loop.py "
                          "restates trainer.py:23-86: anomaly mode, zero_grad, forward, mask, loss, backward, stock Adam over "
                          "model.parameters(), loss.item()): eager ms per step, with and without anomaly mode")
+    ap.add_argument("--fresh-inputs", action="store_true",
+                    help="--loop reference: a second leg whose batches live on the host — data.to(device) builds NEW device tensors "
+                         "every step (trainer.py:46), the upload timed on its own as well")
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--edges", type=int, default=100_000_000)
     ap.add_argument("--scale", type=int, default=24)
@@ -281,6 +284,32 @@ class _Bag:
         return self
 
 
+class _HostBag:
+    """A batch as the reference's loader holds it — on the HOST (pinned): ``to(device)`` builds NEW device tensors every call, what
+    trainer.py:46 does per step (datasets.py:339-349 collates, ``data.to(device)`` uploads).  Attributes that are not tensors (an
+    attached ``gnan_graph``) travel as they are."""
+
+    def __init__(self, **kw):
+        self.__dict__.update({k: (v.detach().cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in kw.items()})
+
+    def to(self, device):
+        return _Bag(**{k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in self.__dict__.items()})
+
+
+def _upload_ms(batches, device, reps=3):
+    """ms per batch of ``data.to(device)`` alone (the H2D copy the reference's loop pays every step)."""
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in batches:
+            b.to(device)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / len(batches) * 1e3
+        best = t if best is None else min(best, t)
+    return best
+
+
 def _event_ms(fn, steps, warmup):
     """Device time of ``fn`` per call: HIP events on torch's current stream (the stream every kernel of the library is
     launched on), median and min over ``steps`` calls after ``warmup``."""
@@ -311,13 +340,27 @@ def apply_sets(args):
         setattr(mod, attr, ast.literal_eval(value))
 
 
-def reference_loop_leg(model, batches, n_out, graph_task, epochs=4):
-    """ms per step of the reference-shaped training loop over ``batches`` on a deep copy of ``model`` (stock Adam, eager)."""
+def reference_loop_leg(model, batches, n_out, graph_task, epochs=4, fresh_inputs=False):
+    """ms per step of the reference-shaped training loop over ``batches`` on a deep copy of ``model`` (stock Adam, eager).
+    ``fresh_inputs``: the batches live on the host and ``data.to(device)`` builds new device tensors every step, exactly as
+    trainer.py:46 after datasets.py:339-349 — the figure then includes that upload, which is reported on its own as well."""
     import copy
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import reference_loop
     loss_fn = torch.nn.BCEWithLogitsLoss() if n_out == 1 else torch.nn.CrossEntropyLoss()
     out = {}
+    device = batches[0].x.device
+    if fresh_inputs:
+        # (the loop's label handling, trainer.py:32-40, now runs on host tensors: on a 256-thread host a 169k-element comparison costs
+        #  tens of ms of OpenMP start-up — the host side is limited as tests/conftest.py limits it)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        hosts = {}
+        for b in batches:                               # (a repeated batch: one host copy)
+            if id(b) not in hosts:
+                hosts[id(b)] = _HostBag(**b.__dict__)
+        batches = [hosts[id(b)] for b in batches]
+        out["upload_ms_per_step"] = _upload_ms(batches, device)
+        epochs = max(epochs, 4)                         # the inputs are adopted on the third step and captured three steps later
     for tag, anomaly in (("anomaly_mode", True), ("plain", False)):
         twin = copy.deepcopy(model).eval()
         opt = torch.optim.Adam(twin.parameters(), lr=1e-3)                # main.py:141
@@ -325,12 +368,14 @@ def reference_loop_leg(model, batches, n_out, graph_task, epochs=4):
         for _ in range(epochs):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ret = reference_loop.train_epoch(twin, batches, loss_fn, opt, batches[0].x.device, classify=True,
+            ret = reference_loop.train_epoch(twin, batches, loss_fn, opt, device, classify=True,
                                              is_graph_task=graph_task, detect_anomaly=anomaly)
             torch.cuda.synchronize()
             t = (time.perf_counter() - t0) / len(batches) * 1e3
             best = t if best is None else min(best, t)
         out[f"{tag}_ms_per_step"] = best
+        if fresh_inputs:
+            out[f"{tag}_ms_per_step_without_upload"] = best - out["upload_ms_per_step"]
         out[f"{tag}_last_loss"] = float(ret[0])
         out["optimizer_tensors"] = sum(len(g["params"]) for g in opt.param_groups)
     out["loop"] = ("tests/reference_loop.train_epoch (trainer.py:23-86 restated: set_detect_anomaly, zero_grad, forward, mask, loss, "
@@ -475,6 +520,8 @@ def run_c3(args):
         labelled = _Bag(x=x, edge_index=None, gnan_graph=g, y=torch.randint(0, max(C, 2), (N,), generator=gen_c).to(dev),
                         train_mask=(torch.rand(N, generator=gen_c) < 0.6).to(dev))
         result["reference_loop"] = reference_loop_leg(model, [labelled] * 20, C, False, epochs=3)
+        if args.fresh_inputs:
+            result["reference_loop_fresh_inputs"] = reference_loop_leg(model, [labelled] * 20, C, False, epochs=3, fresh_inputs=True)
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_c3(args, model, g, x, fwd())
     print(json.dumps(result), flush=True)
@@ -611,6 +658,8 @@ def run_c2(args, rank=0, world=1):
     except Exception as e:
         train_ms = f"failed: {type(e).__name__}: {e}"
     ref_loop = reference_loop_leg(model, graphs[:1000], 1, True, epochs=3) if args.loop == "reference" else None
+    ref_fresh = (reference_loop_leg(model, graphs[:1000], 1, True, epochs=3, fresh_inputs=True)
+                 if (args.loop == "reference" and args.fresh_inputs) else None)
     ms = elapsed / args.steps * 1e3
     # the forward of a 30-node graph is one launch (small_graph_kernel) of ~20 us: a chain of latencies.  Algorithmic bytes
     # per graph: N_g^2 hop codes (1 B) + N_g x D counts + x + the weights (F MLPs of 4.3k floats)
@@ -638,6 +687,8 @@ def run_c2(args, rank=0, world=1):
     }
     if ref_loop is not None:
         result["reference_loop"] = ref_loop
+    if ref_fresh is not None:
+        result["reference_loop_fresh_inputs"] = ref_fresh
     if world == 1 and not args.no_cpu_baseline:
         from oracle import gnan_oracle as O
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

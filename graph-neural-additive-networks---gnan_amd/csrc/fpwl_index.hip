@@ -584,6 +584,16 @@ int gnan_index_nodes_per_block(const gnan_fpwl_args* a) { return index_plan(a).n
 int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st) {
   const IndexPlan pl = index_plan(a);
   if (!pl.ok) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_index: arguments outside what the direct-index kernel serves");
+  // everything that can be refused is refused BEFORE the first launch (a caller that retries another kernel on an error code —
+  // or a capture — must not find a look-up already queued)
+  if (a->sum_total) {
+    if (!pl.split)
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_index: sum_total is written by the group-split feature sum only (sum_workspace)");
+    const size_t need = static_cast<size_t>((a->n + 255) / 256) * sizeof(double);
+    if (a->sum_total_workspace == nullptr || a->sum_total_workspace_bytes < need || reinterpret_cast<uintptr_t>(a->sum_total_workspace) % 8 != 0)
+      return gnan::fail(GNAN_ERR_WORKSPACE, "fpwl_index: sum_total workspace %zu B < required %zu B (8-byte aligned)",
+                        a->sum_total_workspace_bytes, need);
+  }
   IndexParams p;
   p.x = a->x; p.n = a->n; p.x_stride = a->x_stride; p.F = a->F;
   p.off = a->off; p.anchor = a->anchor; p.val = a->val; p.slope = a->slope;
@@ -635,19 +645,9 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
   if (pl.fg == 32) rc = pl.bs == 1024 ? by_kf(I32{}, S1024{}) : by_kf(I32{}, S512{});
   else rc = by_kf(I16{}, S512{});
   if (rc != GNAN_OK) return rc;
-  if (!pl.split) {
-    if (a->sum_total) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_index: sum_total is written by the group-split feature sum only (sum_workspace)");
-    return rc;
-  }
+  if (!pl.split) return rc;
   const int64_t sb = (a->n + 255) / 256;
-  double* tot_partial = nullptr;
-  if (a->sum_total) {
-    if (a->sum_total_workspace == nullptr || a->sum_total_workspace_bytes < static_cast<size_t>(sb) * sizeof(double) ||
-        reinterpret_cast<uintptr_t>(a->sum_total_workspace) % 8 != 0)
-      return gnan::fail(GNAN_ERR_WORKSPACE, "fpwl_index: sum_total workspace %zu B < required %zu B (8-byte aligned)",
-                        a->sum_total_workspace_bytes, static_cast<size_t>(sb) * sizeof(double));
-    tot_partial = static_cast<double*>(a->sum_total_workspace);
-  }
+  double* tot_partial = a->sum_total ? static_cast<double*>(a->sum_total_workspace) : nullptr;      // (checked above)
   hipLaunchKernelGGL(sum_groups_kernel, dim3(static_cast<unsigned>(sb)), dim3(256), 0, st, p.part, p.n_groups, p.n,
                      p.out, p.out_stride, tot_partial, p.total_rows);
   if (int rc2 = gnan::check_launch("sum_groups_kernel")) return rc2;

@@ -265,9 +265,12 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         # moment kernel of the backward pass skips its search (C4 training step: look-up 1.11 -> 1.22 ms, moments 1.25 -> 0.95 ms)
         piece8 = torch.empty(((F + fpg - 1) // fpg, n, fpg), dtype=torch.uint8, device=x.device)    # group-major
         a.piece_out = _lib.ptr(piece8)
-        if _lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)) == 0:
+        rc = _lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x))
+        if rc == 0:
             located[:] = [piece8]
             return (out, total) if want_total else out
+        if rc != _lib.ERR_UNSUPPORTED:                  # only "not this kernel's shape" is a reason to ask again: nothing was launched
+            _lib.check(rc, "gnan_fpwl_fwd")
         a.piece_out = None                              # another kernel serves this shape: plain look-up
     _lib.check(_lib.lib().gnan_fpwl_fwd(a, _lib.stream_of(x)), "gnan_fpwl_fwd")
     return (out, total) if want_total else out

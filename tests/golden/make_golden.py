@@ -340,8 +340,9 @@ def trainer_case(manifest, tid, variant, C, loss_name, n_batches, n, f_raw=4, H=
         arrays["train_hist"] = np.array(hist_tr, dtype=np.float64)
         arrays["test_hist"] = np.array(hist_te, dtype=np.float64)
     if with_f64:
-        real_bce = torch.nn.BCEWithLogitsLoss.forward
+        real_bce, real_mse = torch.nn.BCEWithLogitsLoss.forward, torch.nn.MSELoss.forward
         torch.nn.BCEWithLogitsLoss.forward = lambda self, inp, target: real_bce(self, inp, target.to(inp.dtype))   # trainer.py:62 hands float32 labels over
+        torch.nn.MSELoss.forward = lambda self, inp, target: real_mse(self, inp, target.to(inp.dtype))
         try:
             m64 = build()
             m64.load_state_dict(sd0)
@@ -358,6 +359,7 @@ def trainer_case(manifest, tid, variant, C, loss_name, n_batches, n, f_raw=4, H=
         finally:
             torch.set_default_dtype(torch.float32)
             torch.nn.BCEWithLogitsLoss.forward = real_bce
+            torch.nn.MSELoss.forward = real_mse
         arrays["train_hist64"] = np.array(h_tr, dtype=np.float64)
         arrays["test_hist64"] = np.array(h_te, dtype=np.float64)
         for k, v in m64.state_dict().items():

@@ -101,3 +101,41 @@ def oracle_grads(loss_of_params, params, dtype):
     p = {k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
     loss_of_params(p).backward()
     return {k: v.grad for k, v in p.items()}
+
+
+# Two results that each lie within the floor (1e-5 of the largest entry) of the same truth differ by at most twice the floor:
+# the bound of a comparison between two ROUTES of the build (two kernels, eager against replayed, sliced against unsliced)
+# where both are checked against the truth elsewhere, or no float64 truth exists at the size.
+TWO_FLOORS = 2e-5
+
+
+def rule(got, truth64, ref32=None, floor=1e-5):
+    """SURVEY 8c for one tensor: ``max|got - truth| / max|truth| <= max(floor, the same figure for the float32 reference)``.
+    ``ref32``: the float32 reference's result, a callable returning it (evaluated only when the floor does not already
+    decide), or None (the bound is the floor).  Returns ``(ok, e_build, e_ref)``."""
+    t = _np64(truth64)
+    scale = max(float(np.abs(t).max()), 1e-300)
+    e_build = float(np.abs(_np64(got).reshape(t.shape) - t).max()) / scale
+    if e_build <= floor or ref32 is None:
+        return e_build <= floor, e_build, float("nan")
+    r = _np64(ref32() if callable(ref32) else ref32)
+    e_ref = float(np.abs(r.reshape(t.shape) - t).max()) / scale
+    return e_build <= max(floor, e_ref), e_build, e_ref
+
+
+def assert_rule(got, truth64, ref32=None, what=None, floor=1e-5):
+    ok, e_build, e_ref = rule(got, truth64, ref32, floor)
+    assert ok, f"{what}: build {e_build:.3e} vs fp32 reference {e_ref:.3e} (floor {floor:g})"
+
+
+def assert_grads_rule(got, truth64, ref32=None, what=None, floor=1e-5):
+    """:func:`grad_rule` on sequences or dicts of gradients (one vector: relative to the largest float64 entry of all)."""
+    def as_dict(v):
+        if v is None or callable(v) or isinstance(v, dict):
+            return v
+        return {i: t for i, t in enumerate(v)}
+    r = ref32
+    if callable(ref32):
+        r = lambda: as_dict(ref32())          # noqa: E731
+    ok, e_build, e_ref, where = grad_rule(as_dict(got), as_dict(truth64), as_dict(r) if not callable(r) else r, floor)
+    assert ok, f"{what} [{where}]: build {e_build:.3e} vs fp32 reference {e_ref:.3e} (floor {floor:g})"

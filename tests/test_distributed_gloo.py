@@ -270,7 +270,7 @@ def test_multi_rank_backward_adds_up_to_the_single_process_gradient(world, n, pa
     for k, v in leaves.items():
         got = sum(p[k] for p in parts)
         err = float(np.abs(got - v.grad.numpy()).max()) / scale
-        assert err <= 2e-5, f"{k}: {err:.3e}"
+        assert err <= 1e-5, f"{k}: {err:.3e}"                     # float64 truth: the floor of SURVEY 8c
 
 
 def _exchange_worker(rank, world, port, n, F, order, out_dir, with_grad, cut="rows"):
@@ -333,7 +333,7 @@ def test_halo_exchange_forward_and_backward_equal_single_process(world, n, order
     parts = [np.load(tmp_path / f"g{r}.npz") for r in range(world)]
     for k, v in leaves.items():
         err = float(np.abs(sum(p[k] for p in parts) - v.grad.numpy()).max()) / scale
-        assert err <= 2e-5, f"{k}: {err:.3e}"
+        assert err <= 1e-5, f"{k}: {err:.3e}"                     # float64 truth: the floor of SURVEY 8c
 
 
 def test_choose_partition_by_exchanged_bytes():

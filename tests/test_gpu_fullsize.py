@@ -100,7 +100,9 @@ def test_full_size_adjoint_linearity_and_row_subsets(c4):
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), float((y.double().abs() * As.double().abs()).sum()))
     full = spmm_launch(g, 1.5 * s + s2, lut, True, True)
     parts = 1.5 * spmm_launch(g, s, lut, True, True) + spmm_launch(g, s2, lut, True, True)
-    assert float((full - parts).abs().max()) <= 2e-5 * float(parts.abs().max())
+    # three kernel results, each within the floor of its truth: |A(1.5 s + s2) - (1.5 A s + A s2)| <= 1e-5 (|.| + 1.5 |A s| + |A s2|)
+    a1, a2 = spmm_launch(g, s, lut, True, True), spmm_launch(g, s2, lut, True, True)
+    assert float((full - parts).abs().max()) <= 1e-5 * float(full.abs().max() + 1.5 * a1.abs().max() + a2.abs().max())
     ids = torch.randint(0, N, (50_000,), generator=gen, device=DEV).to(torch.int32)
     sub = spmm_launch(g, s, lut, True, True, row_ids=ids)
     ref = spmm_launch(g, s, lut, True, True)

@@ -86,10 +86,10 @@ def test_graphed_epochs_match_eager_epochs(n, F, C, dense, loss, monkeypatch):
             assert all(r.value["step"] is not None and r.value["step"].graph.replays >= 20 for r in recs), "nothing was replayed"
     a, b = runs["eager"], runs["graphed"]
     assert a[0].shape == b[0].shape
-    assert np.allclose(a[0], b[0], rtol=2e-4, atol=1e-6), np.abs(a[0] - b[0]).max()
+    assert np.allclose(a[0], b[0], rtol=2e-5, atol=1e-6), np.abs(a[0] - b[0]).max()       # two routes of the same 24 steps
     scale = max(float(v.abs().max()) for v in a[1].values())
     for k in a[1]:
-        assert float((a[1][k] - b[1][k]).abs().max()) <= 2e-4 * scale, k
+        assert float((a[1][k] - b[1][k]).abs().max()) <= 2e-5 * scale, k
 
 
 @pytest.mark.parametrize("n,F,C,dense,opt_cls", [(3000, 129, 1, False, "Adam"), (300, 9, 4, True, "AdamW")])

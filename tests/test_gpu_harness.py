@@ -76,28 +76,21 @@ def test_harness_epochs_on_gnan_modules_match_the_reference_trainer(name, graphe
                                  is_graph_task=meta["graph"])
         te = harness.test_epoch(model, batches, loss_fn, DEV, classify=meta["classify"], compute_auc=False, val_mask=True,
                                 is_graph_task=meta["graph"])
-        if "train_hist64" in z.files:
-            # the Adam runs carry the reference's float64 twin run: the rule of SURVEY section 8c on the trajectory —
-            # |loss - loss64| <= max(1e-5, the float32 reference's own gap) of the loss scale; accuracies are hit counts
-            for got, h32, h64 in ((tr, hist_tr, z["train_hist64"]), (te, hist_te, z["test_hist64"])):
-                scale64 = np.abs(h64[:, 0]).max()
-                ref_gap = np.abs(h32[:, 0] - h64[:, 0]).max() / scale64
-                err = abs(float(got[0]) - h64[e, 0]) / scale64
-                assert err <= max(1e-5, ref_gap), (e, err, ref_gap)
-                assert abs(float(got[1]) - h32[e, 1]) <= 1e-6, (e, got, h32[e])        # (a float32 quotient in the fixture)
-            continue
-        rtol = 2e-4                              # SGD steps: linear in the float32 round-off of the gradients
-        assert np.allclose(np.array(tr, dtype=np.float64), hist_tr[e], rtol=rtol, atol=1e-5), (e, tr, hist_tr[e])
-        assert np.allclose(np.array(te, dtype=np.float64), hist_te[e], rtol=rtol, atol=1e-5), (e, te, hist_te[e])
+        # every trainer fixture carries the reference's float64 twin run (tests/golden/make_golden_run.py): the rule of SURVEY
+        # section 8c on the trajectory — |loss - loss64| <= max(1e-5, the float32 reference's own gap) of the loss scale;
+        # accuracies are hit counts
+        for got, h32, h64 in ((tr, hist_tr, z["train_hist64"]), (te, hist_te, z["test_hist64"])):
+            scale64 = np.abs(h64[:, 0]).max()
+            ref_gap = np.abs(h32[:, 0] - h64[:, 0]).max() / scale64
+            err = abs(float(got[0]) - h64[e, 0]) / scale64
+            assert err <= max(1e-5, ref_gap), (e, err, ref_gap)
+            assert abs(float(got[1]) - h32[e, 1]) <= 1e-6, (e, got, h32[e])        # (a float32 quotient in the fixture)
     assert not model.training                                       # trainer.py:97 leaves eval mode on
     scale = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("sd1/"))
-    if "train_hist64" in z.files:                # parameters after the run: against the float64 run, bounded by the float32 run's own gap
-        gap = max(float(np.abs(z["sd1/" + k] - z["sd1_64/" + k]).max()) for k in model.state_dict()) / scale
-        for k, v in model.state_dict().items():
-            assert float(np.abs(v.cpu().numpy() - z["sd1_64/" + k]).max()) <= max(1e-5, gap) * scale, (k, gap)
-    else:
-        for k, v in model.state_dict().items():
-            assert float(np.abs(v.cpu().numpy() - z["sd1/" + k]).max()) <= 2e-5 * scale, k
+    # parameters after the run: against the float64 run, bounded by the float32 run's own gap
+    gap = max(float(np.abs(z["sd1/" + k] - z["sd1_64/" + k]).max()) for k in model.state_dict()) / scale
+    for k, v in model.state_dict().items():
+        assert float(np.abs(v.cpu().numpy() - z["sd1_64/" + k]).max()) <= max(1e-5, gap) * scale, (k, gap)
     if graphed:
         store = harness._steps_of(model)
         if meta["graph"]:
@@ -270,9 +263,13 @@ def test_run_exp_reproduces_the_reference_run(name, tmp_path):
     for col in (1, 3, 5):                                              # accuracies: hit counts over sample counts, identical
         assert np.allclose(got[:, col], h32[:n, col], rtol=1e-6, atol=0), col
     assert [(e, f) for e, f in r["checkpoints"]] == [tuple(c) for c in meta["checkpoints"]]
-    for k, v in r["model"].state_dict().items():                      # where the run ended (same keys as the reference's)
-        want = z["sd1/" + k]
-        assert np.abs(v.cpu().numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), k
+    # where the run ended (same keys as the reference's): against the float64 twin run's parameters, within max(1e-5, the
+    # float32 reference's own distance from them) of the largest parameter — the rule of SURVEY section 8c, hundreds of epochs in
+    sd = r["model"].state_dict()
+    scale = max(float(np.abs(z["sd1_64/" + k]).max()) for k in sd)
+    gap = max(float(np.abs(z["sd1/" + k] - z["sd1_64/" + k]).max()) for k in sd) / scale
+    for k, v in sd.items():
+        assert float(np.abs(v.cpu().numpy() - z["sd1_64/" + k]).max()) <= max(1e-5, gap) * scale, (k, gap)
     # captured steps: there from the third epoch on, and the SAME ones after the learning rate changed
     assert seen[-1][0] and all(lr_is_tensor for _, lr_is_tensor in seen[3:])
     changes = np.nonzero(np.diff(h32[:n, 6]))[0]

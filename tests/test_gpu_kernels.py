@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import gnan_oracle as O
+from helpers import TWO_FLOORS, assert_grads_rule, assert_rule
 from gnan_amd import aggregate  # noqa: E402  (the aggregation's switches are patched below)
 
 pytestmark = pytest.mark.gpu
@@ -108,7 +109,7 @@ def test_a_handful_of_evaluations_take_the_point_kernel(n, F, L, H, C, bias, sum
     assert float((y - y2).abs().max()) <= 1e-5 * max(1e-30, float(y2.abs().max()))
     for a, b in zip(leaves, leaves2):
         if a is not None:
-            assert float((a.grad - b.grad).abs().max()) <= 2e-5 * max(1e-30, float(b.grad.abs().max()))
+            assert float((a.grad - b.grad).abs().max()) <= TWO_FLOORS * max(1e-30, float(b.grad.abs().max()))      # two routes
 
 
 def _random_csr(n_rows, n_cols, K, rng, hubs=()):
@@ -204,8 +205,8 @@ def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
     monkeypatch.setattr(aggregate, "DENSE_SLICE_MAX_ROWS", 0)             # row blocks only
     plain = spmm_launch(g, S, lut, True, with_rest=False, reduce_cr=reduce_cr)
     plain_t = spmm_launch(g.transposed(), S, lut, True, False, None, weight_by_col=True)
-    assert float((sliced - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
-    assert float((sliced_t - plain_t).abs().max()) <= 2e-5 * float(plain_t.abs().max())
+    assert float((sliced - plain).abs().max()) <= TWO_FLOORS * float(plain.abs().max())              # two routes; the truth: below
+    assert float((sliced_t - plain_t).abs().max()) <= TWO_FLOORS * float(plain_t.abs().max())
     assert torch.equal(sliced_sub, sliced[ids.long()])
     rowptr, col, code = O.csr_from_hops(hops, D - 2)
     wt = O.weight_table(lut.cpu().double(), g.cnt.cpu().numpy())
@@ -219,8 +220,16 @@ def test_dense_rows_sliced_over_workgroups(n, W, reduce_cr, Cw, monkeypatch):
     monkeypatch.setattr(aggregate, "DENSE_SLICE_MAX_ROWS", 0)
     Sp, lp = S.clone().requires_grad_(True), lut.clone().requires_grad_(True)
     rho_aggregate(g, Sp, lp, True).pow(2).sum().backward()
-    assert float((Sg.grad - Sp.grad).abs().max()) <= 2e-5 * float(Sp.grad.abs().max())
-    assert float((lg.grad - lp.grad).abs().max()) <= 2e-5 * float(lp.grad.abs().max())
+    assert float((Sg.grad - Sp.grad).abs().max()) <= TWO_FLOORS * float(Sp.grad.abs().max())         # two routes ...
+    assert float((lg.grad - lp.grad).abs().max()) <= TWO_FLOORS * float(lp.grad.abs().max())
+    # ... and both against float64 autograd through the oracle, by the rule
+    def oracle_grads_at(dtype):
+        S_, l_ = S.cpu().to(dtype).requires_grad_(True), lut.cpu().to(dtype).requires_grad_(True)
+        O.spmm_csr(rowptr, col, code, S_, O.weight_table(l_, g.cnt.cpu().numpy())).pow(2).sum().backward()
+        return [S_.grad, l_.grad]
+    t64 = oracle_grads_at(torch.float64)
+    for grads in ([Sg.grad, lg.grad], [Sp.grad, lp.grad]):
+        assert_grads_rule(grads, t64, lambda: oracle_grads_at(torch.float32), "dense rows, sliced / unsliced")
 
 
 def test_spmm_is_linear_in_the_operand_at_scale():
@@ -238,8 +247,9 @@ def test_spmm_is_linear_in_the_operand_at_scale():
     lut = torch.tensor([[1.0], [0.5], [0.01]], device=DEV)
     y = spmm_launch(g, 2.0 * S1 + S2, lut, True, True)
     y12 = 2.0 * spmm_launch(g, S1, lut, True, True) + spmm_launch(g, S2, lut, True, True)
-    scale = float(y12.abs().max())
-    assert float((y - y12).abs().max()) <= 2e-5 * scale
+    # three results of the kernel, each within the floor of its truth: |A(2 S1 + S2) - (2 A S1 + A S2)| <= 1e-5 (|y| + 2 |A S1| + |A S2|)
+    a1, a2 = spmm_launch(g, S1, lut, True, True), spmm_launch(g, S2, lut, True, True)
+    assert float((y - y12).abs().max()) <= 1e-5 * float(y.abs().max() + 2 * a1.abs().max() + a2.abs().max())
     # deterministic: the hub-row slices are reduced in a fixed order
     assert torch.equal(y, spmm_launch(g, 2.0 * S1 + S2, lut, True, True))
 
@@ -269,8 +279,13 @@ def test_rho_aggregate_gradients_vs_autograd_oracle(per_row, use_cnt, Cw):
     Sd = S.float().to(DEV).requires_grad_(True)
     lutd = lut.float().to(DEV).requires_grad_(True)
     rho_aggregate(g, Sd, lutd, use_cnt).pow(2).sum().backward()
-    assert O.rel_err(Sd.grad.cpu(), S64.grad) <= 2e-5
-    assert O.rel_err(lutd.grad.cpu(), lut64.grad) <= 2e-5
+    def oracle32():
+        S32, l32 = S.float().requires_grad_(True), lut.float().requires_grad_(True)
+        w32 = l32 if per_row else O.weight_table(l32, cnt if use_cnt else None).expand(n, -1, -1)
+        O.spmm_csr(rowptr, col, code, S32, w32).pow(2).sum().backward()
+        return S32.grad, l32.grad
+    assert_rule(Sd.grad, S64.grad, lambda: oracle32()[0], "dS")                     # each gradient against its own largest entry
+    assert_rule(lutd.grad, lut64.grad, lambda: oracle32()[1], "dlut")
 
 
 def test_matrix_core_kernel_is_the_one_auto_picks_and_rejects_foreign_shapes(monkeypatch):
@@ -446,8 +461,8 @@ def test_pwl_moments_kernel_vs_reference(F, L, H, C, sum_features, fixed, monkey
     want = pwl.moments_reference(x, g, tc, sum_features)
     xd, gd = x.to(DEV), g.to(DEV)
     got = _fpwl_moments(xd, t, gd, sum_features).cpu().double()
+    assert_rule(got, want, None, "moments")                 # float64 reference of the same sums: the floor
     scale = float(want.abs().max())
-    assert float((got - want).abs().max()) <= 2e-5 * scale
     if fixed:                                   # integer accumulation: bit-reproducible, and exact to ~2^-40 of the largest term
         assert torch.equal(_fpwl_moments(xd, t, gd, sum_features), _fpwl_moments(xd, t, gd, sum_features))
         assert float((got - want).abs().max()) <= 1e-6 * scale
@@ -513,7 +528,7 @@ def test_small_batch_backward_kernel_vs_autograd(F, L, H, C, bias, n, sum_featur
     scale = max(float(v.grad.abs().max()) for v in sd64.values())
     for a, b, c in zip(got["hip"], got["torch"], got["hip2"]):
         assert a.shape == b.shape
-        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-30), (float((a - b).abs().max()), scale)
+        assert float((a - b).abs().max()) <= TWO_FLOORS * max(scale, 1e-30), (float((a - b).abs().max()), scale)      # two routes
         assert torch.equal(a, c)
     # against the oracle's autograd: first-layer weights of all features
     w1 = torch.stack([sd64[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)])
@@ -601,7 +616,7 @@ def test_table_path_parameter_gradients_edge_cases(fixed, monkeypatch):
             if gscale == 0.0:
                 assert float(a.abs().max()) == 0.0
             else:
-                assert float((a - b).abs().max()) <= 2e-5 * scale, (n, spread, float((a - b).abs().max()), scale)
+                assert float((a - b).abs().max()) <= TWO_FLOORS * scale, (n, spread, float((a - b).abs().max()), scale)   # two routes
 
 
 @pytest.mark.parametrize("F,L,H,C,sum_features", [(129, 3, 32, 40, True), (20, 3, 16, 7, True), (9, 2, 24, 2, True),
@@ -687,7 +702,7 @@ def test_tables_too_large_for_lds_use_the_two_phase_kernels(sum_features):
 def test_table_path_agrees_with_oracle_on_random_shapes(seed, monkeypatch):
     """Seeded random models (features, depth, width, channels, batch size, gradient layout) through the table path's
     dispatcher — fast / ragged / general / two-phase kernels, kept pieces, chunked parameter gradients — against float64
-    oracle autograd: outputs within 1e-5, parameter gradients within 2e-5 of the largest.
+    oracle autograd: outputs and parameter gradients by the rule (1e-5 of the largest, or the float32 oracle's own error).
     (Fixed seeds: a wider sweep — 60 seeds — fails once, seed 19, identically on EVERY kernel route including round 1's: a
     node whose x lies within an ulp of a kink of its shape function falls on the other side of the float32-rounded
     breakpoint, and the ReLU subgradient there is a choice — 6e-4 of the largest gradient, the same ambiguity the float32
@@ -733,9 +748,21 @@ def test_table_path_agrees_with_oracle_on_random_shapes(seed, monkeypatch):
         if bias:
             want["b_mid"] = torch.stack([sd64[f"fs.{k}.3.bias"].grad for k in range(F)]).unsqueeze(0)
     names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
-    scale = max(float(v.abs().max()) for v in want.values())
-    for nm, gr in zip(names, got):
-        assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, (nm, F, L, H, C, n, sum_features)
+    def oracle32():
+        sd32 = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+        r = O.feature_mlps(x, sd32)
+        (r.sum(1) if sum_features else r.reshape(n, -1)).backward(gup)
+        w = {"w_first": torch.stack([sd32[f"fs.{k}.0.weight"].grad[:, 0] for k in range(F)]),
+             "w_last": torch.stack([sd32[f"fs.{k}.{last}.weight"].grad for k in range(F)])}
+        if bias:
+            w["b_first"] = torch.stack([sd32[f"fs.{k}.0.bias"].grad for k in range(F)])
+            w["b_last"] = torch.stack([sd32[f"fs.{k}.{last}.bias"].grad for k in range(F)])
+        if L == 3:
+            w["w_mid"] = torch.stack([sd32[f"fs.{k}.3.weight"].grad for k in range(F)]).unsqueeze(0)
+            if bias:
+                w["b_mid"] = torch.stack([sd32[f"fs.{k}.3.bias"].grad for k in range(F)]).unsqueeze(0)
+        return w
+    assert_grads_rule(dict(zip(names, got)), want, oracle32, (F, L, H, C, n, sum_features))
 
 
 @pytest.mark.parametrize("n,width,gscale", [(1000, 3, 1.0), (70000, 1, 1e-12), (5, 64, 1e20), (100, 2, 0.0)])
@@ -989,11 +1016,10 @@ def test_fused_table_gradient_equals_shell_sums_route(W, dyc, use_cnt, with_rest
             want = want / cnt.clamp_min(1).double()
         rows = lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, False)
         assert rows.shape == (n_out, D, 1)
-        scale = float(want.abs().max())
-        assert float((rows[..., 0].double() - want).abs().max()) <= 2e-5 * scale
+        assert_rule(rows[..., 0], want, None, "per-row table gradient")          # float64 contraction of the same shell sums: the floor
         total = lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, True)
         assert total.shape == (D, 1)
-        assert float((total[:, 0].double() - want.sum(0)).abs().max()) <= 2e-5 * float(want.abs().sum(0).max())
+        assert float((total[:, 0].double() - want.sum(0)).abs().max()) <= 1e-5 * float(want.abs().sum(0).max())   # (against the sum of magnitudes: the terms cancel)
         assert torch.equal(total, lut_grad_launch(g, S, dY, D, use_cnt, with_rest, ids, None, True))   # fixed order
 
 
@@ -1025,7 +1051,7 @@ def test_dense_table_gradient_in_one_pass(n, D, W, dyc, use_cnt, monkeypatch):
             want = want / cnt.clamp_min(1).double()
         total = lut_grad_launch(g, S, dY, Dg, use_cnt, False, ids, None, True)
         assert total.shape == (Dg, 1)
-        assert float((total[:, 0].double() - want.sum(0)).abs().max()) <= 2e-5 * float(want.abs().sum(0).max())
+        assert float((total[:, 0].double() - want.sum(0)).abs().max()) <= 1e-5 * float(want.abs().sum(0).max())
         assert torch.equal(total, lut_grad_launch(g, S, dY, Dg, use_cnt, False, ids, None, True))
     if dyc != W:
         return
@@ -1044,10 +1070,15 @@ def test_dense_table_gradient_in_one_pass(n, D, W, dyc, use_cnt, monkeypatch):
     codes = torch.from_numpy(np.where(hops >= 0, hops, Dg - 1)).long()
     A = wt[torch.arange(n).unsqueeze(1), codes, 0]                         # [n, n] pair weights
     ref = torch.autograd.grad(A @ S64, [S64, lut64], up.cpu().double())
-    for k in range(2):
-        scale = float(ref[k].abs().max())
+    def ref32():
+        S32, l32 = S.cpu().requires_grad_(True), lut0.cpu().requires_grad_(True)
+        w32 = l32.unsqueeze(0).expand(n, -1, -1)
+        if use_cnt:
+            w32 = w32 / g.cnt.cpu().clamp_min(1).float().unsqueeze(-1)
+        return torch.autograd.grad(w32[torch.arange(n).unsqueeze(1), codes, 0] @ S32, [S32, l32], up.cpu())
+    for k in range(2):                                          # each gradient against its own largest entry
         for tag in got:
-            assert float((got[tag][k].cpu().double() - ref[k]).abs().max()) <= 2e-5 * scale, (tag, k)
+            assert_rule(got[tag][k], ref[k], lambda k=k: ref32()[k], (tag, k))
 
 
 @pytest.mark.parametrize("W,K,use_cnt,with_rest", [(1, 1, True, True), (1, 2, True, True), (2, 1, False, True), (3, 2, True, True),
@@ -1079,10 +1110,15 @@ def test_fused_narrow_backward_equals_two_pass_route(W, K, use_cnt, with_rest, m
         wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
     want = O.spmm_csr(rowptr, col, code, S64, wt, with_rest=with_rest)
     dS64, dlut64 = torch.autograd.grad(want, [S64, lut64], up.cpu().double())
+    def ref32():
+        S32, l32 = S0.cpu().requires_grad_(True), lut0.cpu().requires_grad_(True)
+        w32 = l32.unsqueeze(0).expand(n, -1, -1)
+        if use_cnt:
+            w32 = w32 / g.cnt.cpu().clamp_min(1).float().unsqueeze(-1)
+        return torch.autograd.grad(O.spmm_csr(rowptr, col, code, S32, w32, with_rest=with_rest), [S32, l32], up.cpu())
     for k, ref in ((0, dS64), (1, dlut64)):
-        scale = float(ref.abs().max())
-        assert float((got["fused"][k].cpu().double() - ref).abs().max()) <= 2e-5 * scale, (k, scale)
-        assert float((got["two_pass"][k].cpu().double() - ref).abs().max()) <= 2e-5 * scale
+        assert_rule(got["fused"][k], ref, lambda k=k: ref32()[k], ("fused", k))
+        assert_rule(got["two_pass"][k], ref, lambda k=k: ref32()[k], ("two_pass", k))
         assert torch.equal(got["fused"][k], got["fused2"][k])
 
 
@@ -1189,8 +1225,12 @@ def test_fused_narrow_backward_walks_sorted_copy_with_hot_columns(W, K, with_res
     S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
     wt = lut64.unsqueeze(0).expand(n, -1, -1) / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
     want = O.spmm_csr(rowptr, col, code, S64, wt, with_rest=with_rest)
+    def ref32():
+        S32, l32 = S0.cpu().requires_grad_(True), lut0.cpu().requires_grad_(True)
+        w32 = l32.unsqueeze(0).expand(n, -1, -1) / g.cnt.cpu().clamp_min(1).float().unsqueeze(-1)
+        return torch.autograd.grad(O.spmm_csr(rowptr, col, code, S32, w32, with_rest=with_rest), [S32, l32], up.cpu())
     for k, ref in enumerate(torch.autograd.grad(want, [S64, lut64], up.cpu().double())):
-        assert float((got["sorted_hot"][k].cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert_rule(got["sorted_hot"][k], ref, lambda k=k: ref32()[k], k)
 
 
 @pytest.mark.parametrize("W,s_by_code", [(1, False), (2, False), (3, False), (4, False), (2, True)])
@@ -1320,7 +1360,7 @@ def test_aggregation_paths_agree_on_random_shapes(seed, monkeypatch):
 def test_aggregation_gradients_agree_on_random_shapes(seed, monkeypatch):
     """Seeded random shapes through the aggregation's autograd function — one-pass narrow backward over natural order and
     over the degree-sorted copy with hot packed rows, wide operands through the per-node weight table: operand gradients
-    identical between the walks, everything within 2e-5 of float64 oracle autograd."""
+    identical between the walks, everything by the rule against float64 oracle autograd."""
     from gnan_amd import functional, graph as G
     from gnan_amd.aggregate import rho_aggregate
     rng = np.random.default_rng(2000 + seed)
@@ -1354,10 +1394,15 @@ def test_aggregation_gradients_agree_on_random_shapes(seed, monkeypatch):
     if use_cnt:
         wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
     ref = torch.autograd.grad(O.spmm_csr(rowptr, col, code, S64, wt, with_rest=with_rest), [S64, lut64], up.cpu().double())
+    def ref32():
+        S32, l32 = S0.cpu().requires_grad_(True), lut0.cpu().requires_grad_(True)
+        w32 = l32.unsqueeze(0).expand(n, -1, -1)
+        if use_cnt:
+            w32 = w32 / g.cnt.cpu().clamp_min(1).float().unsqueeze(-1)
+        return torch.autograd.grad(O.spmm_csr(rowptr, col, code, S32, w32, with_rest=with_rest), [S32, l32], up.cpu())
     for k in range(2):
-        scale = float(ref[k].abs().max())
         for run in got:
-            assert float((run[k].cpu().double() - ref[k]).abs().max()) <= 2e-5 * scale, (k, scale)
+            assert_rule(run[k], ref[k], lambda k=k: ref32()[k], (k, seed))
 
 
 def test_degree_schedule_is_bit_identical_to_natural_order(monkeypatch):
@@ -1497,7 +1542,7 @@ def test_table_path_gradients_with_inputs_on_kinks(route, F, L, H, C, sum_featur
     """x EXACTLY on a ReLU kink — zero biases (the reference's own initial state, GNAN.py:49-53) with one-hot style
     features, or kinks placed on float32 numbers the inputs take.  torch differentiates relu at 0 as 0; every table route
     (fast / ragged / general / two-phase look-up, kept pieces, fixed-point and float moments, kernel and torch parameter
-    gradients) must hand the bias gradients to the same units: within 2e-5 of the largest gradient of float64 oracle autograd."""
+    gradients) must hand the bias gradients to the same units: within the floor (1e-5 of the largest gradient) of float64 oracle autograd."""
     from gnan_amd import _lib, functional
     from gnan_amd.functional import feature_mlps
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
@@ -1531,9 +1576,7 @@ def test_table_path_gradients_with_inputs_on_kinks(route, F, L, H, C, sum_featur
         want["w_mid"] = torch.stack([sd64[f"fs.{k}.3.weight"].grad for k in range(F)]).unsqueeze(0)
         want["b_mid"] = torch.stack([sd64[f"fs.{k}.3.bias"].grad for k in range(F)]).unsqueeze(0)
     names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
-    scale = max(float(v.abs().max()) for v in want.values())
-    for nm, gr in zip(names, got):
-        assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, (nm, route, mode)
+    assert_grads_rule(dict(zip(names, got)), want, None, (route, mode))
 
 
 def _rho_state(L, H, C, bias, seed, zero_bias=False):
@@ -1605,9 +1648,7 @@ def test_pre_rho_row_table_vs_oracle(L, H, C, bias, D, zero_bias, route, monkeyp
         ref["w_mid"] = torch.stack([p64[f"rho.{2 * li}.weight"].grad for li in range(1, L - 1)])
         if bias:
             ref["b_mid"] = torch.stack([p64[f"rho.{2 * li}.bias"].grad for li in range(1, L - 1)])
-    scale = max(float(v.abs().max()) for v in ref.values())
-    for nm, gr in zip(names, got):
-        assert float((gr.cpu().double().reshape(ref[nm].shape) - ref[nm]).abs().max()) <= 2e-5 * scale, (nm, route)
+    assert_grads_rule(dict(zip(names, got)), ref, None, route)
 
 
 @pytest.mark.parametrize("F,L,H,C,bias", [(5, 3, 16, 1, True), (4, 2, 8, 3, True), (6, 3, 64, 7, False), (3, 4, 8, 2, True),
@@ -1656,9 +1697,7 @@ def test_training_mode_dropout_in_the_kernels(F, L, H, C, bias, sum_features):
         if bias:
             want["b_mid"] = torch.stack([torch.stack([sd64[f"fs.{k}.{3 * li}.bias"].grad for k in range(F)]) for li in range(1, L - 1)])
     names = [nm for nm, t in zip(("w_first", "b_first", "w_mid", "b_mid", "w_last", "b_last"), st[:6]) if t is not None]
-    scale = max(float(v.abs().max()) for v in want.values())
-    for nm, gr in zip(names, got):
-        assert float((gr.cpu().double() - want[nm]).abs().max()) <= 2e-5 * scale, nm
+    assert_grads_rule(dict(zip(names, got)), want, None, (F, L, H, C))
     if L > 1:
         with torch.no_grad():
             again = feature_mlps_dropout(x.to(DEV), st, sum_features, drop_p, seed=seed)
@@ -1728,8 +1767,9 @@ def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt
     want, want_g = run(torch.float64, "cpu", False)
     assert got.shape == ((C, 1) if graph_sum else (n, C))
     assert O.rel_err(got.cpu(), want) <= 1e-5
-    for a, b in zip(got_g, want_g):
-        assert float((a.cpu().double() - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
+    ref32 = lambda: run(torch.float32, "cpu", False)[1]            # noqa: E731  (the float32 chain: the rule's bound, if needed)
+    for i, (a, b) in enumerate(zip(got_g, want_g)):
+        assert_rule(a, b, lambda i=i: ref32()[i], (a.shape,))
     again, again_g = run(torch.float32, DEV, True)
     assert torch.equal(got, again) and all(torch.equal(a, b) for a, b in zip(got_g, again_g))
     # the backward pass is ONE launch too where rho has one channel and there are at most 64 shells (gnan_small_graph_bwd);
@@ -1742,7 +1782,7 @@ def test_small_graph_forward_in_one_launch(n, F, C, L, H, rho_c, D_hops, use_cnt
     finally:
         small_graph.SMALL_GRAPH_BACKWARD = old_flag
     for a, b, w in zip(got_g, general_g, want_g):
-        assert float((a - b).abs().max()) <= (2e-5 if one_launch else 0.0) * float(w.abs().max())
+        assert float((a - b).abs().max()) <= (TWO_FLOORS if one_launch else 0.0) * float(w.abs().max())      # two routes
     # refused shapes: more nodes than the kernel holds, a CSR graph, inputs that want a gradient
     f, r = StackedMLP(*[None if t is None else t.to(DEV) for t in fp], L, H, C, F), StackedMLP(*[None if t is None else t.to(DEV) for t in rp], L, H, rho_c, 1)
     assert not small_graph_applies(x.to(DEV).requires_grad_(True), g, f, r)
@@ -1807,8 +1847,9 @@ def test_small_graph_pre_rho_in_one_launch(n, F, L, H, D_hops, graph_sum, bias_r
     want, want_g = run(torch.float64, "cpu", False)
     assert got.shape == ((1, 1) if graph_sum else (n, 1))
     assert O.rel_err(got.cpu(), want) <= 1e-5
-    for a, b in zip(got_g, want_g):
-        assert float((a.cpu().double() - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
+    ref32 = lambda: run(torch.float32, "cpu", False)[1]            # noqa: E731  (the float32 chain: the rule's bound, if needed)
+    for i, (a, b) in enumerate(zip(got_g, want_g)):
+        assert_rule(a, b, lambda i=i: ref32()[i], (a.shape,))
     again, again_g = run(torch.float32, DEV, True)
     assert torch.equal(got, again) and all(torch.equal(a, b) for a, b in zip(got_g, again_g))
     f = StackedMLP(*[None if t is None else t.to(DEV) for t in fp], L, H, 1, F)
@@ -1886,8 +1927,9 @@ def test_small_graph_nam_readout_in_one_launch(n, F, L, H, Ln, Hn, Cn, D_hops, u
     want, want_g = run(torch.float64, "cpu", False)
     assert got.shape == (Cn, 1)
     assert O.rel_err(got.cpu(), want) <= 1e-5
-    for a, b in zip(got_g, want_g):
-        assert float((a.cpu().double() - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-30), (a.shape,)
+    ref32 = lambda: run(torch.float32, "cpu", False)[1]            # noqa: E731
+    for i, (a, b) in enumerate(zip(got_g, want_g)):
+        assert_rule(a, b, lambda i=i: ref32()[i], (a.shape,))
     again, again_g = run(torch.float32, DEV, True)
     assert torch.equal(got, again) and all(torch.equal(a, b) for a, b in zip(got_g, again_g))
     dev_stack = lambda q, *dims: StackedMLP(*[None if t is None else t.to(DEV) for t in q], *dims)
@@ -2119,7 +2161,7 @@ def test_propagation_blocked_aggregation_vs_oracle(D, W, self_pairs, use_cnt, wi
     assert torch.equal(routed, again)
     monkeypatch.setattr(aggregate, "PB_NARROW", False)
     rows_kernel = spmm_launch(g, S.to(DEV), lut.to(DEV), use_cnt, with_rest, s_total=None if total is None else total.to(DEV))
-    assert float((rows_kernel - again).abs().max()) <= 2e-5 * float(again.abs().max())
+    assert float((rows_kernel - again).abs().max()) <= TWO_FLOORS * float(again.abs().max())            # two routes
 
 
 def test_propagation_blocked_aggregation_non_finite_operand():
@@ -2188,4 +2230,4 @@ def test_propagation_blocked_backward_vs_oracle_autograd(D, self_pairs, use_cnt,
     for k in range(2):
         scale = float(ref[k].abs().max())
         assert float((got[k].cpu().double() - ref[k]).abs().max()) <= 1e-5 * scale, (k, scale)
-        assert float((got[k] - rows[k]).abs().max()) <= 2e-5 * scale, (k, scale)
+        assert float((got[k] - rows[k]).abs().max()) <= TWO_FLOORS * scale, (k, scale)                  # two routes

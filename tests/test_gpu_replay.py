@@ -8,7 +8,8 @@ import pytest
 import torch
 
 import reference_loop
-from test_gpu_graphed import DEV, _graph_task, _model, _need_gpu, _node_task
+from oracle import gnan_oracle as O
+from test_gpu_graphed import DEV, Bag, _graph_task, _model, _need_gpu, _node_task
 
 pytestmark = pytest.mark.gpu
 
@@ -201,3 +202,62 @@ def test_graph_level_loop_replays_small_graphs_through_slots(cls, monkeypatch):
     import pickle
     assert pickle.loads(pickle.dumps(b.__dict__["_replay_slots"])).plans == {}
     replay.release(b)
+
+
+@pytest.mark.parametrize("shape", ["dense", "csr_attached"])
+def test_fresh_input_tensors_every_step_are_adopted_and_replayed(shape):
+    """The reference's real cadence (trainer.py:46: ``data.to(device)`` per step — NEW tensor objects with the same contents):
+    after a few steps the module adopts the inputs (private copies), captures over them and replays whenever the fresh tensors
+    compare equal — outputs and parameters step for step those of the loop over persistent tensors; a step whose contents
+    differ runs eagerly on the caller's tensors and is right too."""
+    _need_gpu()
+    from gnan_amd import replay
+    from gnan_amd.models import TensorGNAN
+    rng = np.random.default_rng(5)
+    n, F, C = 400, 9, 3
+    host = {"x": torch.from_numpy(rng.random((n, F), dtype=np.float32))}
+    if shape == "dense":
+        ei = np.stack([rng.integers(0, n, 1500), rng.integers(0, n, 1500)])
+        nd, norm = O.pre_process_dense(np.concatenate([ei, ei[::-1]], axis=1), n)
+        host.update(node_distances=nd, normalization_matrix=norm)
+        attached = {}
+    else:
+        src, dst = torch.from_numpy(rng.integers(0, n, 3000)), torch.from_numpy(rng.integers(0, n, 3000))
+        from gnan_amd import synthetic as syn
+        g = syn.hop1_csr(src.to(DEV), dst.to(DEV), n)
+        attached = {"gnan_graph": g}
+    y = torch.from_numpy(rng.integers(0, C, n)).to(DEV)
+
+    def fresh(scale=1.0):
+        return Bag(edge_index=None, **{k: (v * scale if k == "x" else v).to(DEV) for k, v in host.items()}, **attached)
+    torch.manual_seed(0)
+    a = TensorGNAN(F, C, 3, hidden_channels=16, device=DEV)
+    with torch.no_grad():
+        for _, p in a.named_parameters():
+            p.copy_(torch.randn(p.shape) * 0.4)
+    a = a.to(DEV).eval()
+    b = copy.deepcopy(a)
+    oa, ob = torch.optim.Adam(a.parameters(), lr=2e-3), torch.optim.Adam(b.parameters(), lr=2e-3)
+    persistent = fresh()
+    loss_fn = torch.nn.CrossEntropyLoss()
+    for step in range(12):
+        scale = 1.5 if step == 9 else 1.0                 # one step with other contents: eager, and right
+        data_b = fresh(scale)
+        data_a = persistent if scale == 1.0 else fresh(scale)
+        outs = []
+        for m, o, d in ((a, oa, data_a), (b, ob, data_b)):
+            o.zero_grad()
+            out = m.forward(d)
+            loss_fn(out, y).backward()
+            o.step()
+            outs.append(out.detach())
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max()), step
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((p - q).abs().max()) <= 1e-5 * max(1e-3, float(p.abs().max())), k
+    book = b.__dict__.get("_replay_adopted")
+    assert book is not None and any(e["static"] is not None for e in book.entries.values())
+    plans = [e.value["plan"] for e in b.__dict__["_replays"].entries.values() if e.value.get("plan") is not None]
+    assert plans and max(p.fwd.replays for p in plans) >= 3, "the adopted inputs were never replayed"
+    assert sum(e["changes"] for e in book.entries.values()) == 1
+    replay.release(b)
+    assert "_replay_adopted" not in b.__dict__
