@@ -361,9 +361,13 @@ def reference_loop_leg(model, batches, n_out, graph_task, epochs=4, fresh_inputs
         batches = [hosts[id(b)] for b in batches]
         out["upload_ms_per_step"] = _upload_ms(batches, device)
         epochs = max(epochs, 4)                         # the inputs are adopted on the third step and captured three steps later
-    for tag, anomaly in (("anomaly_mode", True), ("plain", False)):
+    import gnan_amd
+    # the optimizer as main.py:141 builds it — torch.optim.Adam(model.parameters()): the F x L per-layer tensors, torch's own
+    # per-tensor bookkeeping included — with and without anomaly mode; and over gnan_amd.optim_params(model), the flat buffers those
+    # tensors are views of (a one-line change in main.py; same numbers, a dozen tensors)
+    for tag, anomaly, flat in (("anomaly_mode", True, False), ("plain", False, False), ("optim_params_plain", False, True)):
         twin = copy.deepcopy(model).eval()
-        opt = torch.optim.Adam(twin.parameters(), lr=1e-3)                # main.py:141
+        opt = torch.optim.Adam(gnan_amd.optim_params(twin) if flat else twin.parameters(), lr=1e-3)
         best = None
         for _ in range(epochs):
             torch.cuda.synchronize()
@@ -377,7 +381,7 @@ def reference_loop_leg(model, batches, n_out, graph_task, epochs=4, fresh_inputs
         if fresh_inputs:
             out[f"{tag}_ms_per_step_without_upload"] = best - out["upload_ms_per_step"]
         out[f"{tag}_last_loss"] = float(ret[0])
-        out["optimizer_tensors"] = sum(len(g["params"]) for g in opt.param_groups)
+        out["optimizer_tensors_flat" if flat else "optimizer_tensors"] = sum(len(g["params"]) for g in opt.param_groups)
     out["loop"] = ("tests/reference_loop.train_epoch (trainer.py:23-86 restated: set_detect_anomaly, zero_grad, forward, mask, loss, "
                    "backward, torch.optim.Adam(model.parameters()).step(), loss.item() per step), best of %d epochs" % epochs)
     return out

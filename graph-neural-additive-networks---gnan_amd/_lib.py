@@ -125,6 +125,15 @@ class SpmmArgs(C.Structure):
     ]
 
 
+class SortedCsrArgs(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("rowptr_is64", C.c_int32), ("col", C.c_void_p),
+        ("code", C.c_void_p), ("cnt", C.c_void_p), ("D", C.c_int32), ("pack_shift", C.c_int32), ("order", C.c_void_p),
+        ("rowptr_s", C.c_void_p), ("col_s", C.c_void_p), ("code_s", C.c_void_p), ("colp_s", C.c_void_p), ("cnt_s", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class SpmmPbArgs(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("S", C.c_void_p), ("s_stride", C.c_int64), ("W", C.c_int32),
@@ -341,6 +350,8 @@ SYMBOLS = {
     "gnan_loss_step": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "gnan_spmm_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmArgs)]),
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
+    "gnan_degree_sorted_csr_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnan_degree_sorted_csr": (C.c_int, [C.POINTER(SortedCsrArgs), C.c_void_p]),
     "gnan_spmm_pb_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbArgs)]),
     "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
     "gnan_spmm_pb_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbBwdArgs)]),

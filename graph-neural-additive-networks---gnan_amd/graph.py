@@ -35,6 +35,7 @@ HOT_COLUMNS_MIN_NNZ = 1 << 24    # below this the two extra launches that fill t
 HOT_COLUMNS_MIN_SHARE = 0.15     # ... and so does a graph whose K most listed neighbours receive less than this share of the pairs
 
 
+SORTED_COPY_IN_HIP = True   # the degree-sorted copy by gnan_degree_sorted_csr (False: the framework ops below; CPU tensors always)
 PB_LDS_BYTES = 65536        # propagation-blocked narrow aggregation (csrc/spmm_pb.hip): LDS of a column block / of a bin's accumulators
 PB_SLOT_PAIRS = 512         # ... entries per accumulator slot: a row with more owns several (no LDS address is hit by a whole wavefront)
 PB_CHUNK = 16               # ... tiles are padded to whole chunks of this many entries
@@ -356,9 +357,13 @@ class HopGraph:
         srcl = col - cb * cbw
         tile = b * n_cb + cb
         del b, cb, col, row
-        tile_s, order = torch.sort(tile, stable=True)
-        del tile
         n_tiles = n_bins * n_cb
+        if n_tiles < 2 ** 31:                          # (a radix sort of 4-byte keys: half the passes of the 8-byte one)
+            tile_s, order = torch.sort(tile.to(torch.int32), stable=True)
+            tile_s = tile_s.to(torch.int64)
+        else:
+            tile_s, order = torch.sort(tile, stable=True)
+        del tile
         tile_cnt = torch.bincount(tile_s, minlength=n_tiles)
         padded = (tile_cnt + PB_CHUNK - 1) // PB_CHUNK * PB_CHUNK
         tile_ptr = torch.zeros(n_tiles + 1, **i64)
@@ -406,6 +411,8 @@ class HopGraph:
         ``Y[order[q]]`` (``scatter_out = 2``): same arithmetic per row, hence bit-identical output, but ``rowptr``, ``cnt``
         and the index pairs of the lane groups sharing a wavefront are adjacent in memory instead of scattered — fewer L2
         requests, which is what bounds the kernel.  Costs a second copy of (col, code) in HBM; cached per graph."""
+        if self._sorted_copy is None and SORTED_COPY_IN_HIP and self.rowptr.is_cuda and self.n_rows < 2 ** 31:
+            self._sorted_copy = self._degree_sorted_copy_hip()
         if self._sorted_copy is None:
             order, _ = self.degree_schedule()
             o = order.long()
@@ -442,6 +449,34 @@ class HopGraph:
             g.long_row_plan()
             self._sorted_copy = g
         return self._sorted_copy, self._degree_order, self._sorted_copy._plan
+
+    def _degree_sorted_copy_hip(self) -> "HopGraph":
+        """:meth:`degree_sorted_copy` by ``gnan_degree_sorted_csr`` (csrc/graph_build.hip): a stable radix sort of the rows by
+        length, a scan, one copy pass — the same arrays as the framework route below, bit for bit."""
+        dev, n, nnz = self.device, self.n_rows, self.nnz
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        rowptr_s = torch.empty_like(self.rowptr)
+        col_s, code_s = torch.empty_like(self.col), torch.empty_like(self.code)
+        pack = not (self.n_cols > (1 << PACK_SHIFT) or self.n_codes > 4)
+        colp = torch.empty_like(self.col) if pack else None
+        permute_cnt = self.cnt.shape[0] == n and not self._cnt_by_col
+        cnt = self.cnt.contiguous() if permute_cnt else None
+        cnt_s = torch.empty_like(cnt) if permute_cnt else self.cnt
+        need = _lib.lib().gnan_degree_sorted_csr_workspace_bytes(n)
+        ws = torch.empty((need + 255) // 256 * 64, dtype=torch.int32, device=dev)            # (the caching allocator aligns to 512 B)
+        a = _lib.SortedCsrArgs(n_rows=n, nnz=nnz, rowptr=_lib.ptr(self.rowptr), rowptr_is64=int(self.rowptr.dtype == torch.int64),
+                               col=_lib.ptr(self.col), code=_lib.ptr(self.code), cnt=_lib.ptr(cnt),
+                               D=int(self.cnt.shape[1]), pack_shift=PACK_SHIFT if pack else 0, order=_lib.ptr(order),
+                               rowptr_s=_lib.ptr(rowptr_s), col_s=_lib.ptr(col_s), code_s=_lib.ptr(code_s), colp_s=_lib.ptr(colp),
+                               cnt_s=_lib.ptr(cnt_s) if permute_cnt else None, workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4)
+        _lib.check(_lib.lib().gnan_degree_sorted_csr(a, _lib.stream_of(self.rowptr)), "gnan_degree_sorted_csr")
+        if self._degree_order is None:
+            self._degree_order = order
+            self._degree_plan = None                                   # (the index schedule's plan: built on demand, degree_schedule)
+        g = HopGraph(n_rows=n, n_cols=self.n_cols, n_codes=self.n_codes, code=code_s, cnt=cnt_s, rowptr=rowptr_s, col=col_s)
+        g.colp = colp
+        g.long_row_plan()
+        return g
 
     def hot_columns(self) -> Optional[torch.Tensor]:
         """The ``HOT_COLUMNS`` most listed neighbours (int64 node ids, most listed first; ties by id), or ``None`` when
@@ -523,6 +558,7 @@ class HopGraph:
         if self._degree_order is None:
             deg = (self.rowptr[1:] - self.rowptr[:-1])
             self._degree_order = torch.argsort(deg, stable=True).to(torch.int32)
+        if self._degree_plan is None:
             self._degree_plan = self.long_row_plan(self._degree_order)
         return self._degree_order, self._degree_plan
 

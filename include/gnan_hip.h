@@ -476,6 +476,34 @@ typedef struct gnan_spmm_args {
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
 int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream);
 
+/* The degree-sorted copy of a hop-coded CSR, the layout gnan_spmm_fwd walks with scatter_out = 2 (gnan_amd.graph.
+ * HopGraph.degree_sorted_copy): order = the rows sorted by their number of listed pairs, ascending, ties by row id (a STABLE
+ * radix sort); rowptr_s / col_s / code_s = the CSR with its rows in that order (pairs of a row in their original order);
+ * cnt_s[q, :] = cnt[order[q], :] (optional: [n_rows, D] contiguous); colp_s = col_s | code_s << pack_shift (optional).  Index
+ * work only, bit-exact.  workspace: gnan_degree_sorted_csr_workspace_bytes(n_rows), 256-byte aligned. */
+typedef struct gnan_sorted_csr_args {
+  int64_t n_rows;
+  int64_t nnz;
+  const void* rowptr;
+  int32_t rowptr_is64;
+  const int32_t* col;
+  const uint8_t* code;
+  const int32_t* cnt;        /* optional */
+  int32_t D;
+  int32_t pack_shift;        /* with colp_s */
+  int32_t* order;            /* out [n_rows] */
+  void* rowptr_s;            /* out [n_rows + 1], the width of rowptr */
+  int32_t* col_s;            /* out [nnz] */
+  uint8_t* code_s;           /* out [nnz] */
+  int32_t* colp_s;           /* out [nnz], optional */
+  int32_t* cnt_s;            /* out [n_rows, D], optional */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_sorted_csr_args;
+
+size_t gnan_degree_sorted_csr_workspace_bytes(int64_t n_rows);
+int gnan_degree_sorted_csr(const gnan_sorted_csr_args* a, gnan_stream_t stream);
+
 /* -------------------------------------------------------------------------------------------
  * gnan_spmm_pb_fwd — the same neighbourhood sum as gnan_spmm_fwd for NARROW fp32 operand rows (W in {1, 2, 4}: the
  * sum-first order of GNAN.py:157-170, S = f_sums), global weight table (Cw == 1, D <= 4), CSR layout, every output row, from

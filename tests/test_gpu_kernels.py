@@ -2231,3 +2231,29 @@ def test_propagation_blocked_backward_vs_oracle_autograd(D, self_pairs, use_cnt,
         scale = float(ref[k].abs().max())
         assert float((got[k].cpu().double() - ref[k]).abs().max()) <= 1e-5 * scale, (k, scale)
         assert float((got[k] - rows[k]).abs().max()) <= TWO_FLOORS * scale, (k, scale)                  # two routes
+
+
+@pytest.mark.parametrize("idx_dtype,n,hubs", [(torch.int64, 5000, [(3, 900), (4000, 4000)]), (torch.int32, 70_000, [(5, 200_000), (69_999, 129)]),
+                                              (torch.int32, 300, [])])
+def test_degree_sorted_copy_by_the_library_equals_the_framework_route(idx_dtype, n, hubs, monkeypatch):
+    """gnan_degree_sorted_csr (stable radix sort of the rows by length, scan, copy pass) == the torch route, array by array, bit
+    for bit: processing order, row pointers, column ids, hop codes, the packed index stream, the permuted shell sizes — for a
+    graph and for its transpose (whose count table belongs to the neighbours and is not permuted)."""
+    from gnan_amd import graph as G
+    rng = np.random.default_rng(n)
+    rowptr, col, code = _random_csr(n, n + 17, 2, rng, hubs=hubs)
+    for transposed in (False, True):
+        made = []
+        for hip in (True, False):
+            monkeypatch.setattr(G, "SORTED_COPY_IN_HIP", hip)
+            g = _graph(rowptr, col, code, n + 17, 4, idx_dtype=idx_dtype)
+            g = g.transposed() if transposed else g
+            made.append(g.degree_sorted_copy())
+        (a, oa, pa), (b, ob, pb) = made
+        assert torch.equal(oa, ob)
+        assert a.rowptr.dtype == b.rowptr.dtype and torch.equal(a.rowptr, b.rowptr)
+        assert torch.equal(a.col, b.col) and torch.equal(a.code, b.code) and torch.equal(a.cnt, b.cnt)
+        assert (a.colp is None) == (b.colp is None) and (a.colp is None or torch.equal(a.colp, b.colp))
+        assert pa.n_long == pb.n_long and pa.n_slices == pb.n_slices
+        if pa.n_long:
+            assert torch.equal(pa.rows, pb.rows) and torch.equal(pa.slice_ptr, pb.slice_ptr)
