@@ -95,9 +95,9 @@ def parse():
                          "graph launch per forward, the next forward's table build on a forked branch, the all-reduce of the "
                          "column sums captured with RCCL).  auto: on where --pipeline is on (a multi-rank share), falling back "
                          "to the eager loop if the step cannot be captured or its first replay disagrees with the eager forward")
-    ap.add_argument("--share-fork", default="start", choices=["start", "fmlp"],
+    ap.add_argument("--share-fork", default="fmlp", choices=["start", "fmlp"],
                     help="where the next forward's table build branches off inside a replayed share: under the look-up or "
-                         "under the aggregation")
+                         "under the aggregation (default: measured 0.919 against 0.944 ms on the slowest 1/8 share)")
     ap.add_argument("--index-buckets", type=int, default=0, help="cells per feature of the direct-index look-up (0: the library's default)")
     ap.add_argument("--sustain-seconds", type=float, default=10.0,
                     help="one GPU: after the timed region (and the CPU baseline) keep issuing the same step for this long, so "

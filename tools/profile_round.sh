@@ -18,7 +18,7 @@ python3 bench.py --config c5 --operand f32 --order sum_first --traffic off --sus
 python3 bench.py --config c3 --steps 20 --warmup 5 > $OUT/c3_bench.log 2>&1
 python3 bench.py --config c3 --out 40 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/c3_c40_bench.log 2>&1
 python3 bench.py --config c2 --steps 3 --warmup 1 > $OUT/c2_bench.log 2>&1
-bash tools/emulate_shares.sh --share-fork fmlp > $OUT/emulated_shares.txt 2>&1
+bash tools/emulate_shares.sh > $OUT/emulated_shares.txt 2>&1
 SHARE_GRAPH=off bash tools/emulate_shares.sh > $OUT/emulated_shares_eager.txt 2>&1
 python3 bench.py > $OUT/bench_full.log 2>&1                                                   # the driver's command: traffic measured, CPU baseline, sustained leg
 python3 tools/lookup_ab.py > $OUT/lookup_ab.jsonl 2> $OUT/lookup_ab.err
@@ -39,6 +39,15 @@ python3 bench.py --force-dist --traffic off --sustain-seconds 0 --no-cpu-baselin
 P=8 bash tools/emulate_shares_all.sh > $OUT/emulated_shares_all.txt 2>&1                      # every one of the 8 shares
 FORCE=1 P=8 bash tools/emulate_shares_all.sh > $OUT/emulated_shares_all_rccl.txt 2>&1         # ... each over a one-rank RCCL group (captured all-reduce)
 python3 -m pytest tests -q -m gpu --durations=15 > $OUT/gpu_suite_durations.txt 2>&1          # the whole GPU suite: total time and the slowest tests
+# ---- round 6 additions
+RANK=2 bash tools/step_timeline.sh $OUT/share_tl --emulate-world 8 --partition halo --force-dist > $OUT/share_timeline.txt 2>&1   # the slowest 1/8 share, kernel by kernel
+P=8 bash tools/emulate_shares_all.sh --cut rows > $OUT/emulated_shares_all_cut_rows.txt 2>&1                                   # ... with blocks of equal row count, for comparison
+python3 tools/pb_bench.py 1 2 > $OUT/pb_bench.jsonl 2> $OUT/pb_bench.err                                                       # propagation-blocked narrow aggregation against the row-parallel kernels
+bash tools/pmc_narrow.sh $OUT > $OUT/pmc_narrow.log 2>&1                                                                       # L2 hit / miss / fabric requests of the narrow kernels, old and new
+for f in "" "--flat"; do python3 tools/reference_loop_bench.py arxiv cora muta $f 2>/dev/null | grep -v "by phase"; python3 tools/reference_loop_bench.py arxiv cora muta --fresh-inputs $f 2>/dev/null; done > $OUT/reference_loop_faces.jsonl
+python3 bench.py --config c3 --loop reference --fresh-inputs --no-cpu-baseline > $OUT/c3_loop_reference_fresh.log 2>&1
+python3 bench.py --force-dist --traffic off --sustain-seconds 0 --no-cpu-baseline --steps 20 --partition halo > $OUT/bench_force_dist_alt_partitions.log 2>&1   # one rank, RCCL group: alt_partitions code path
+python3 tools/c1_cpu.py 3 > $OUT/c1_cpu.json 2> $OUT/c1_cpu.err                                                                # config 1 on the box's host cores
 find $OUT -name "*_kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT
