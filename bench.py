@@ -1002,7 +1002,7 @@ def main():
         # the narrow aggregation walks a bucketed copy of the pairs (HopGraph.pb_plan -> gnan_spmm_pb_fwd): one sort of the pairs
         from gnan_amd import aggregate as _agg
         t0 = time.perf_counter()
-        if _agg.PB_NARROW and g.nnz >= _agg.PB_MIN_NNZ:
+        if _agg.PB_NARROW and _agg.PB_MIN_NNZ <= g.nnz <= _agg.PB_MAX_NNZ:
             g.pb_plan(C)
         torch.cuda.synchronize()
         amortised["bucketed_pairs_plan_ms"] = (time.perf_counter() - t0) * 1e3
@@ -1192,19 +1192,6 @@ def main():
         # PMC counters need rocprofv3 around the process: the figure is the committed one of the same command, not of this run
         traffic, traffic_source = committed, "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of this command, not measured in this run)" % rec.get("source", "committed")
 
-    # ---- the partitions that move operand rows between the ranks, a few steps each (north_star's halo all-gather over xGMI
-    #      measured next to the halo-recompute line; every rank takes part, rank 0 prints) ----------------------------------
-    alt = None
-    if want_alt:
-        alt = {}
-        for name in ("vertex", "exchange"):
-            try:
-                alt[name] = time_alt_partition(name, args, dict(N=N, E=E, F=F, C=C, dev=dev, rank=rank, world=world, src=src, dst=dst,
-                                                                stacked=stacked, lut=lut, op_dtype=op_dtype, bounds=bounds))
-            except Exception as e:                   # (every rank fails alike or the next collective hangs: shapes are the same on all)
-                alt[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
-        del src, dst
-
     result = None
     if rank == 0 or emulated:                        # (an emulated share is its own one-process job whatever RANK selects)
         ms = elapsed / args.steps * 1e3
@@ -1246,7 +1233,7 @@ def main():
             "operand_rows_rank0": int(x.shape[0]),
             "cut": None if pworld == 1 else ("cost" if bounds is not None else "rows"),
             "owned_rows_rank0": [part.lo, part.hi] if partition != "feature" else None,
-            "alt_partitions": alt,
+            "alt_partitions": None,
             # bf16 operand rows are an inference format: the library has no backward through them
             "backward": False if args.operand == "bf16" else None,
         }
@@ -1266,6 +1253,22 @@ def main():
                 torch.cuda.synchronize()
             result["sustained_ms_per_step"] = (time.perf_counter() - t0) / n_sus * 1e3
             result["sustained_steps"] = n_sus
+    # ---- the partitions that move operand rows between the ranks, a few steps each (north_star's halo all-gather over xGMI
+    #      measured next to the halo-recompute line; every rank takes part, rank 0 prints) ----------------------------------
+    if want_alt:
+        if result is not None:           # should a collective of the extra partitions hang, the measured line is at least in the log
+            print("bench.py: the line so far (alt_partitions follow): " + json.dumps(result), file=sys.stderr, flush=True)
+        alt = {}
+        for name in ("vertex", "exchange"):
+            try:
+                alt[name] = time_alt_partition(name, args, dict(N=N, E=E, F=F, C=C, dev=dev, rank=rank, world=world, src=src, dst=dst,
+                                                                stacked=stacked, lut=lut, op_dtype=op_dtype, bounds=bounds))
+            except Exception as e:                   # (every rank fails alike or the next collective hangs: shapes are the same on all)
+                alt[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        del src, dst
+        if result is not None:
+            result["alt_partitions"] = alt
+    if result is not None:
         print(json.dumps(result), flush=True)
     if grouped:
         dist.barrier()

@@ -135,7 +135,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
     narrow = S.shape[1] * S.element_size() <= 8        # one or two lanes per row: see LONG_ROW_THRESHOLD_NARROW
     if (PB_NARROW and not g.is_dense and row_ids is None and S.dtype == torch.float32 and S.shape[1] in PB_WIDTHS and not per_row
             and not from_counts and lut_shape[1] == 1 and lut_shape[0] <= 4 and not weight_by_col and not minus_rest
-            and not s_by_code and reduce_cr == 0 and g.nnz >= PB_MIN_NNZ and not g._cnt_by_col):
+            and not s_by_code and reduce_cr == 0 and PB_MIN_NNZ <= g.nnz <= PB_MAX_NNZ and not g._cnt_by_col):
         # narrow rows of a large graph: no per-pair gather at all — bucketed pairs, operand blocks and accumulators in LDS
         # (csrc/spmm_pb.hip; 10M-node R-MAT, W = 1: 0.87 ms of spmm_hot_kernel -> see DESIGN.md section 4.1c)
         pb = g.pb_plan(S.shape[1])
@@ -186,6 +186,7 @@ PB_WIDTHS = (1, 2, 4)
 PB_FLAGS = 0                # gnan_spmm_pb_args.flags (A/B switches of the kernels)
 PB_BACKWARD = True          # ... and so does the one-column backward (gnan_spmm_pb_bwd over the transposed graph's copy)
 PB_MIN_NNZ = 1 << 23        # below, the row-parallel kernel's gathers stay in L2 and three launches cost more than they save
+PB_MAX_NNZ = 1 << 29        # above, building the bucketed copy (a sort of the pairs, ~80 B of temporaries per pair) is not attempted
 
 
 def pb_launch(g: HopGraph, pb, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, s_total: Optional[torch.Tensor],
@@ -215,7 +216,7 @@ def pb_launch(g: HopGraph, pb, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
 
 def pb_bwd_applies(g: HopGraph, W: int, D: int):
     """The transposed graph's bucketed copy when the ONE-column backward can take the propagation-blocked route, else None."""
-    if not (PB_NARROW and PB_BACKWARD and W == 1 and not g.is_dense and D <= 4 and g.nnz >= PB_MIN_NNZ):
+    if not (PB_NARROW and PB_BACKWARD and W == 1 and not g.is_dense and D <= 4 and PB_MIN_NNZ <= g.nnz <= PB_MAX_NNZ):
         return None
     pb = g.transposed().pb_plan(2)
     return pb if (pb is not None and pb.n_acc == 1) else None
