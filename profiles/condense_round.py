@@ -65,7 +65,9 @@ for log, out in (("bench_full.log", "_bench_full.json"), ("sum_first_bench.log",
                  ("c5_sum_first_bench.log", "_c5_sum_first_bench.json"), ("c3_bench.log", "_c3_bench.json"),
                  ("c3_c40_bench.log", "_c3_c40_bench.json"), ("c2_bench.log", "_c2_bench.json"),
                  ("c3_loop_reference.log", "_c3_loop_reference.json"), ("c2_loop_reference.log", "_c2_loop_reference.json"),
-                 ("bench_force_dist_rccl.log", "_bench_force_dist_rccl.json"), ("muta_epoch.json", "_muta_epoch.json")):
+                 ("bench_force_dist_rccl.log", "_bench_force_dist_rccl.json"), ("muta_epoch.json", "_muta_epoch.json"),
+                 ("c3_loop_reference_fresh.log", "_c3_loop_reference_fresh.json"),
+                 ("bench_force_dist_alt_partitions.log", "_bench_force_dist_alt_partitions.json"), ("c1_cpu.json", "_c1_cpu_on_the_box.json")):
     json_of(log, out)
 stats_of("sum_first", "_sum_first_kernel_stats.csv")
 stats_of("train", "_train_step_c4_kernel_stats.csv")
@@ -73,7 +75,10 @@ for name, out in (("emulated_shares.txt", "_emulated_shares.txt"), ("emulated_sh
                   ("emulated_shares_all_rccl.txt", "_emulated_shares_all_rccl.txt"), ("lookup_ab.jsonl", "_lookup_ab.jsonl"),
                   ("sq_fwd.txt", "_sq_fwd.txt"), ("sq_train.txt", "_sq_train.txt"), ("batched_bench.jsonl", "_batched_bench.jsonl"),
                   ("timeline_muta.txt", "_timeline_muta.txt"), ("c3_timeline.txt", "_c3_timeline.txt"),
-                  ("reference_loop.jsonl", "_reference_loop.jsonl"), ("reference_loop_host_profile.txt", "_reference_loop_host_profile.txt")):
+                  ("reference_loop.jsonl", "_reference_loop.jsonl"), ("reference_loop_host_profile.txt", "_reference_loop_host_profile.txt"),
+                  ("share_timeline.txt", "_share_timeline.txt"), ("emulated_shares_all_cut_rows.txt", "_emulated_shares_all_cut_rows.txt"),
+                  ("pb_bench.jsonl", "_pb_bench.jsonl"), ("pmc_narrow.csv", "_pmc_narrow.csv"),
+                  ("reference_loop_faces.jsonl", "_reference_loop_faces.jsonl")):
     text_of(name, out)
 p = os.path.join(src, "graphed_steps.log")
 if os.path.exists(p):
