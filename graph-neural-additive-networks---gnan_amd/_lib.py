@@ -134,6 +134,33 @@ class SortedCsrArgs(C.Structure):
     ]
 
 
+class CsrTransposeArgs(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("rowptr_is64", C.c_int32),
+        ("col", C.c_void_p), ("code", C.c_void_p), ("long_rows", C.c_void_p), ("n_long", C.c_int32), ("rowptr_t", C.c_void_p),
+        ("col_t", C.c_void_p), ("code_t", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class PbKeysArgs(C.Structure):
+    _fields_ = [
+        ("rowptr", C.c_void_p), ("rowptr_is64", C.c_int32), ("col", C.c_void_p), ("code", C.c_void_p), ("n_rows", C.c_int64),
+        ("self_pos", C.c_void_p), ("code_base", C.c_int32), ("n_acc", C.c_int32), ("slot_ptr", C.c_void_p), ("bin_of_row", C.c_void_p),
+        ("bin_slot0", C.c_void_p), ("n_cb", C.c_int32), ("cb_width", C.c_int32), ("n_tiles", C.c_uint32), ("key", C.c_void_p),
+        ("val", C.c_void_p), ("tmp_src", C.c_void_p), ("tmp_dst", C.c_void_p), ("tile_cnt", C.c_void_p), ("long_rows", C.c_void_p),
+        ("n_long", C.c_int32),
+    ]
+
+
+class PbFillArgs(C.Structure):
+    _fields_ = [
+        ("nnz", C.c_int64), ("n_kept", C.c_int64), ("n_tiles", C.c_uint32), ("n_bins", C.c_int32), ("n_cb", C.c_int32),
+        ("dummy", C.c_int32), ("key", C.c_void_p), ("val", C.c_void_p), ("tmp_src", C.c_void_p), ("tmp_dst", C.c_void_p),
+        ("tile_ptr", C.c_void_p), ("tile_start", C.c_void_p), ("tile_cnt", C.c_void_p), ("chunk_first", C.c_void_p),
+        ("src16", C.c_void_p), ("dst16", C.c_void_p), ("chunk_q", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class SpmmPbArgs(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("S", C.c_void_p), ("s_stride", C.c_int64), ("W", C.c_int32),
@@ -352,6 +379,14 @@ SYMBOLS = {
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_degree_sorted_csr_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_degree_sorted_csr": (C.c_int, [C.POINTER(SortedCsrArgs), C.c_void_p]),
+    "gnan_csr_transpose_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gnan_csr_transpose": (C.c_int, [C.POINTER(CsrTransposeArgs), C.c_void_p]),
+    "gnan_pb_plan_long_row_threshold": (C.c_int32, []),
+    "gnan_pb_plan_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "gnan_pb_plan_keys": (C.c_int, [C.POINTER(PbKeysArgs), C.c_void_p]),
+    "gnan_pb_plan_fill_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_uint32]),
+    "gnan_pb_plan_fill": (C.c_int, [C.POINTER(PbFillArgs), C.c_void_p]),
     "gnan_spmm_pb_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbArgs)]),
     "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
     "gnan_spmm_pb_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbBwdArgs)]),

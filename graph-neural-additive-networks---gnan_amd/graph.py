@@ -35,6 +35,8 @@ HOT_COLUMNS_MIN_NNZ = 1 << 24    # below this the two extra launches that fill t
 HOT_COLUMNS_MIN_SHARE = 0.15     # ... and so does a graph whose K most listed neighbours receive less than this share of the pairs
 
 
+TRANSPOSE_IN_HIP = True     # HopGraph.transposed() by gnan_csr_transpose
+PB_PLAN_IN_HIP = True       # the pair-level work of HopGraph.pb_plan by gnan_pb_plan_* (False: framework ops; CPU tensors always)
 SORTED_COPY_IN_HIP = True   # the degree-sorted copy by gnan_degree_sorted_csr (False: the framework ops below; CPU tensors always)
 PB_LDS_BYTES = 65536        # propagation-blocked narrow aggregation (csrc/spmm_pb.hip): LDS of a column block / of a bin's accumulators
 PB_SLOT_PAIRS = 512         # ... entries per accumulator slot: a row with more owns several (no LDS address is hit by a whole wavefront)
@@ -300,9 +302,105 @@ class HopGraph:
         The pair with hop code 0 of every row (its self pair; at most one per row) is left out and served from ``self_col``."""
         if W in self._pb_plans:
             return self._pb_plans[W]
-        plan = None if self.is_dense else self._build_pb_plan(int(W))
+        if self.is_dense:
+            plan = None
+        elif PB_PLAN_IN_HIP and self.rowptr.is_cuda:
+            plan = self._build_pb_plan_hip(int(W))
+        else:
+            plan = self._build_pb_plan(int(W))
         self._pb_plans[W] = plan
         return plan
+
+    def _build_pb_plan_hip(self, W: int) -> Optional["PbPlan"]:
+        """:meth:`_build_pb_plan` with everything that touches every listed pair done by the library (``gnan_pb_plan_rows / _keys /
+        _fill``: one pass per row, one per pair, a stable radix sort of 4-byte keys, one scatter) and only the n_rows- and
+        tile-sized scans left to the framework — the same arrays, bit for bit (``tests/test_gpu_kernels.py``)."""
+        dev, n, D, nnz = self.device, self.n_rows, self.n_codes, self.nnz
+        if W not in (1, 2, 4) or D < 2 or D > 4 or n == 0 or nnz == 0 or nnz + PB_CHUNK * 64 >= 2 ** 31:
+            return None
+        L = _lib.lib()
+        st = _lib.stream_of(self.rowptr)
+        R = PB_LDS_BYTES // (8 * W)
+        cbw = PB_LDS_BYTES // (4 * W)
+        i32 = dict(dtype=torch.int32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        is64 = int(self.rowptr.dtype == torch.int64)
+        c0, self_col, self_pos = (torch.empty(n, **i32) for _ in range(3))
+        deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        long_rows = torch.nonzero(deg > int(L.gnan_pb_plan_long_row_threshold())).flatten().to(torch.int32)     # walked by a workgroup each
+        n_long = int(long_rows.numel())
+        _lib.check(L.gnan_pb_plan_rows(_lib.ptr(self.rowptr), is64, _lib.ptr(self.col), _lib.ptr(self.code), n, _lib.ptr(long_rows), n_long,
+                                       _lib.ptr(c0), _lib.ptr(self_col), _lib.ptr(self_pos), st), "gnan_pb_plan_rows")
+        code_base, n_acc = 0, D - 1
+        if D >= 3 and int(c0.max()) <= 1:
+            deg2, code_base, n_acc = deg - c0, 1, D - 2
+        else:
+            deg2, self_col, self_pos = deg, None, None
+        del c0
+        m = int(deg2.sum())
+        if m == 0:
+            return None
+        nslot = ((deg2 + PB_SLOT_PAIRS - 1) // PB_SLOT_PAIRS).clamp_(min=1)
+        slot_ptr = torch.zeros(n + 1, **i64)
+        slot_ptr[1:] = torch.cumsum(nslot, 0)
+        slots_per_bin = (R - 1) // n_acc
+        eff = slots_per_bin - int(nslot.max())
+        if eff < slots_per_bin // 2:
+            return None
+        bin_of_row = slot_ptr[:-1] // eff
+        n_bins = int(bin_of_row[-1]) + 1
+        bin_row_ptr = torch.searchsorted(bin_of_row, torch.arange(n_bins + 1, **i64))
+        bin_slot0 = slot_ptr[bin_row_ptr[:-1]]
+        n_cb = -(-self.n_cols // cbw)
+        n_tiles = n_bins * n_cb
+        if n_tiles >= 2 ** 31 - 1:
+            return None
+        slot_ptr32, bin_of_row32, bin_slot032 = slot_ptr.to(torch.int32), bin_of_row.to(torch.int32), bin_slot0.to(torch.int32)
+        key, val = torch.empty(nnz, **i32), torch.empty(nnz, **i32)
+        tmp_src, tmp_dst = torch.empty(nnz, dtype=torch.int16, device=dev), torch.empty(nnz, dtype=torch.int16, device=dev)
+        tile_cnt = torch.zeros(n_tiles + 1, **i32)
+        ka = _lib.PbKeysArgs(rowptr=_lib.ptr(self.rowptr), rowptr_is64=is64, col=_lib.ptr(self.col), code=_lib.ptr(self.code), n_rows=n,
+                             self_pos=_lib.ptr(self_pos), code_base=code_base, n_acc=n_acc, slot_ptr=_lib.ptr(slot_ptr32),
+                             bin_of_row=_lib.ptr(bin_of_row32), bin_slot0=_lib.ptr(bin_slot032), n_cb=n_cb, cb_width=cbw, n_tiles=n_tiles,
+                             key=_lib.ptr(key), val=_lib.ptr(val), tmp_src=_lib.ptr(tmp_src), tmp_dst=_lib.ptr(tmp_dst),
+                             tile_cnt=_lib.ptr(tile_cnt), long_rows=_lib.ptr(long_rows), n_long=n_long)
+        _lib.check(L.gnan_pb_plan_keys(ka, st), "gnan_pb_plan_keys")
+        cnt = tile_cnt[:n_tiles].to(torch.int64)
+        padded = (cnt + PB_CHUNK - 1) // PB_CHUNK * PB_CHUNK
+        tile_ptr = torch.zeros(n_tiles + 1, **i64)
+        tile_ptr[1:] = torch.cumsum(padded, 0)
+        n_entries = int(tile_ptr[-1])
+        if n_entries >= 2 ** 31:
+            return None
+        tile_start = torch.zeros(n_tiles + 1, **i64)
+        tile_start[1:] = torch.cumsum(cnt, 0)
+        chunks = (padded // PB_CHUNK).view(n_bins, n_cb).t().contiguous().view(-1)        # column-block-major
+        first = torch.zeros(n_tiles + 1, **i64)
+        first[1:] = torch.cumsum(chunks, 0)
+        n_chunks = int(first[-1])
+        src16 = torch.empty(n_entries, dtype=torch.int16, device=dev)
+        dst16 = torch.empty(n_entries, dtype=torch.int16, device=dev)
+        chunk_q = torch.empty(n_chunks, **i32)
+        tile_ptr32, tile_start32, first32 = tile_ptr.to(torch.int32), tile_start.to(torch.int32), first.to(torch.int32)
+        need = L.gnan_pb_plan_fill_workspace_bytes(nnz, n_tiles)
+        ws = torch.empty((need + 255) // 256 * 64, **i32)
+        fa = _lib.PbFillArgs(nnz=nnz, n_kept=m, n_tiles=n_tiles, n_bins=n_bins, n_cb=n_cb, dummy=R - 1, key=_lib.ptr(key), val=_lib.ptr(val),
+                             tmp_src=_lib.ptr(tmp_src), tmp_dst=_lib.ptr(tmp_dst), tile_ptr=_lib.ptr(tile_ptr32),
+                             tile_start=_lib.ptr(tile_start32), tile_cnt=_lib.ptr(tile_cnt), chunk_first=_lib.ptr(first32),
+                             src16=_lib.ptr(src16), dst16=_lib.ptr(dst16), chunk_q=_lib.ptr(chunk_q), workspace=_lib.ptr(ws),
+                             workspace_bytes=ws.numel() * 4)
+        _lib.check(L.gnan_pb_plan_fill(fa, st), "gnan_pb_plan_fill")
+        bin_entry_ptr = tile_ptr[torch.arange(n_bins + 1, **i64) * n_cb]
+        cb_chunk_ptr = first[torch.arange(n_cb + 1, **i64) * n_bins]
+        bin_order = torch.argsort(bin_entry_ptr[1:] - bin_entry_ptr[:-1], descending=True, stable=True)
+        headroom = max(1, int(deg2.max()) - 1).bit_length()
+        c32 = lambda t: t.to(torch.int32).contiguous()
+        return PbPlan(W=W, n_entries=n_entries, src=src16, dst=dst16, cb_width=cbw, n_cblocks=n_cb, chunk_q=chunk_q,
+                      cb_chunk_ptr=c32(cb_chunk_ptr), n_bins=n_bins, acc_per_bin=R, bin_order=c32(bin_order),
+                      bin_entry_ptr=c32(bin_entry_ptr), bin_row_ptr=c32(bin_row_ptr), slot_ptr=slot_ptr32, n_acc=n_acc,
+                      code_base=code_base, self_col=self_col, headroom_bits=headroom, n_pairs=m,
+                      self_is_row=bool(self_col is not None and n <= self.n_cols
+                                       and torch.equal(self_col, torch.arange(n, dtype=torch.int32, device=dev))))
 
     def _build_pb_plan(self, W: int) -> Optional["PbPlan"]:
         dev, n, D = self.device, self.n_rows, self.n_codes
@@ -573,6 +671,22 @@ class HopGraph:
         if self.is_dense:
             t = HopGraph(n_rows=self.n_cols, n_cols=self.n_rows, n_codes=self.n_codes,
                          code=self.code.t().contiguous(), cnt=self.cnt)
+        elif (TRANSPOSE_IN_HIP and self.rowptr.is_cuda and 0 < self.nnz < 2 ** 32 and self.n_rows < 2 ** 31 and self.n_cols < 2 ** 31):
+            # gnan_csr_transpose (csrc/graph_build.hip): a stable radix sort of the pairs by column id + one gather — the same arrays
+            # as the framework route below, bit for bit
+            L, dev = _lib.lib(), self.device
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            long_rows = torch.nonzero(deg > int(L.gnan_pb_plan_long_row_threshold())).flatten().to(torch.int32)
+            rowptr_t = torch.empty(self.n_cols + 1, dtype=self.rowptr.dtype, device=dev)
+            col_t, code_t = torch.empty_like(self.col), torch.empty_like(self.code)
+            need = L.gnan_csr_transpose_workspace_bytes(self.nnz, self.n_cols)
+            ws = torch.empty((need + 255) // 256 * 64, dtype=torch.int32, device=dev)
+            a = _lib.CsrTransposeArgs(n_rows=self.n_rows, n_cols=self.n_cols, nnz=self.nnz, rowptr=_lib.ptr(self.rowptr),
+                                      rowptr_is64=int(self.rowptr.dtype == torch.int64), col=_lib.ptr(self.col), code=_lib.ptr(self.code),
+                                      long_rows=_lib.ptr(long_rows), n_long=int(long_rows.numel()), rowptr_t=_lib.ptr(rowptr_t),
+                                      col_t=_lib.ptr(col_t), code_t=_lib.ptr(code_t), workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 4)
+            _lib.check(L.gnan_csr_transpose(a, _lib.stream_of(self.rowptr)), "gnan_csr_transpose")
+            t = HopGraph(n_rows=self.n_cols, n_cols=self.n_rows, n_codes=self.n_codes, code=code_t, cnt=self.cnt, rowptr=rowptr_t, col=col_t)
         else:
             deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
             row_of_edge = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), deg)

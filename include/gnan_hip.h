@@ -504,6 +504,95 @@ typedef struct gnan_sorted_csr_args {
 size_t gnan_degree_sorted_csr_workspace_bytes(int64_t n_rows);
 int gnan_degree_sorted_csr(const gnan_sorted_csr_args* a, gnan_stream_t stream);
 
+/* The transposed adjacency of a hop-coded CSR (gnan_amd.graph.HopGraph.transposed: what the backward walks): row j of the result
+ * lists the rows i that list neighbour j, in ascending i (a stable sort of the pairs by column id), with the pairs' hop codes;
+ * rowptr_t has the width of rowptr.  long_rows: the rows with more than gnan_pb_plan_long_row_threshold() pairs.  Bit-exact.
+ * workspace: gnan_csr_transpose_workspace_bytes(nnz, n_cols), 256-byte aligned. */
+typedef struct gnan_csr_transpose_args {
+  int64_t n_rows;
+  int64_t n_cols;
+  int64_t nnz;
+  const void* rowptr;
+  int32_t rowptr_is64;
+  const int32_t* col;
+  const uint8_t* code;
+  const int32_t* long_rows;
+  int32_t n_long;
+  void* rowptr_t;            /* out [n_cols + 1] */
+  int32_t* col_t;            /* out [nnz] */
+  uint8_t* code_t;           /* out [nnz] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_csr_transpose_args;
+
+size_t gnan_csr_transpose_workspace_bytes(int64_t nnz, int64_t n_cols);
+int gnan_csr_transpose(const gnan_csr_transpose_args* a, gnan_stream_t stream);
+
+/* The pair-level work of building the bucketed copy gnan_spmm_pb_fwd walks (gnan_amd.graph.HopGraph.pb_plan; the row-level
+ * arrays — slots, bins — are n_rows-sized scans the caller makes).  Index work only, bit-exact:
+ *   gnan_pb_plan_rows   c0[i] = pairs of row i with hop code 0; self_col[i] / self_pos[i] = column / position inside the row of the
+ *                       last such pair (-1: none)
+ *   gnan_pb_plan_keys   per listed pair e (rows in CSR order): key[e] = bin_of_row[i] * n_cb + col / cb_width (n_tiles for the pair
+ *                       at self_pos[i], which is left out), val[e] = e, tmp_src[e] = col % cb_width, tmp_dst[e] = (slot of the pair
+ *                       inside its bin) * n_acc + (code - code_base), the row's slots dealt round-robin over its kept pairs;
+ *                       tile_cnt[key] += 1 (tile_cnt [n_tiles + 1] zeroed by the caller)
+ *   gnan_pb_plan_fill   stable radix sort of (key, val); entry s of the sorted list goes to tile_ptr[key] + (s - tile_start[key])
+ *                       of src16 / dst16 (tile_ptr: prefix of the tiles' sizes padded to 16, tile_start: of their real sizes);
+ *                       pads get src 0 / dst `dummy`; chunk_q[chunk_first[cb * n_bins + b] + k] = tile_ptr[b * n_cb + cb] + 16 k.
+ * workspace of the fill: gnan_pb_plan_fill_workspace_bytes(nnz, n_tiles), 256-byte aligned. */
+typedef struct gnan_pb_keys_args {
+  const void* rowptr;
+  int32_t rowptr_is64;
+  const int32_t* col;
+  const uint8_t* code;
+  int64_t n_rows;
+  const int32_t* self_pos;   /* optional [n_rows] */
+  int32_t code_base;
+  int32_t n_acc;
+  const int32_t* slot_ptr;   /* [n_rows + 1] */
+  const int32_t* bin_of_row; /* [n_rows] */
+  const int32_t* bin_slot0;  /* [n_bins] */
+  int32_t n_cb;
+  int32_t cb_width;
+  uint32_t n_tiles;
+  uint32_t* key;             /* out [nnz] */
+  uint32_t* val;             /* out [nnz] */
+  uint16_t* tmp_src;         /* out [nnz] */
+  uint16_t* tmp_dst;         /* out [nnz] */
+  uint32_t* tile_cnt;        /* in/out [n_tiles + 1] */
+  const int32_t* long_rows;  /* [n_long]: every row with more than gnan_pb_plan_long_row_threshold() pairs (walked by a workgroup) */
+  int32_t n_long;
+} gnan_pb_keys_args;
+
+typedef struct gnan_pb_fill_args {
+  int64_t nnz;
+  int64_t n_kept;            /* pairs that enter the tiles (nnz - those left out) */
+  uint32_t n_tiles;
+  int32_t n_bins;
+  int32_t n_cb;
+  int32_t dummy;             /* dst of pad entries */
+  const uint32_t* key;
+  const uint32_t* val;
+  const uint16_t* tmp_src;
+  const uint16_t* tmp_dst;
+  const int32_t* tile_ptr;   /* [n_tiles + 1] */
+  const int32_t* tile_start; /* [n_tiles + 1] */
+  const uint32_t* tile_cnt;  /* [n_tiles + 1] */
+  const int32_t* chunk_first;/* [n_tiles + 1], column-block-major */
+  uint16_t* src16;           /* out [n_entries] */
+  uint16_t* dst16;           /* out [n_entries] */
+  int32_t* chunk_q;          /* out [n_chunks] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_pb_fill_args;
+
+int32_t gnan_pb_plan_long_row_threshold(void);
+int gnan_pb_plan_rows(const void* rowptr, int32_t rowptr_is64, const int32_t* col, const uint8_t* code, int64_t n_rows,
+                      const int32_t* long_rows, int32_t n_long, int32_t* c0, int32_t* self_col, int32_t* self_pos, gnan_stream_t stream);
+int gnan_pb_plan_keys(const gnan_pb_keys_args* a, gnan_stream_t stream);
+size_t gnan_pb_plan_fill_workspace_bytes(int64_t nnz, uint32_t n_tiles);
+int gnan_pb_plan_fill(const gnan_pb_fill_args* a, gnan_stream_t stream);
+
 /* -------------------------------------------------------------------------------------------
  * gnan_spmm_pb_fwd — the same neighbourhood sum as gnan_spmm_fwd for NARROW fp32 operand rows (W in {1, 2, 4}: the
  * sum-first order of GNAN.py:157-170, S = f_sums), global weight table (Cw == 1, D <= 4), CSR layout, every output row, from

@@ -61,7 +61,7 @@ def text_of(name, out):
 
 subprocess.check_call([sys.executable, os.path.join(here, "summarize.py"), src, pre])
 for log, out in (("bench_full.log", "_bench_full.json"), ("sum_first_bench.log", "_sum_first_bench.json"),
-                 ("train_step_noprof.log", "_train_step_c4.json"), ("c5_bench.log", "_c5_bench.json"),
+                 ("train_step_noprof.log", "_train_step_c4.json"), ("train_step_per_layer.log", "_train_step_c4_per_layer_optimizer.json"), ("c5_bench.log", "_c5_bench.json"),
                  ("c5_sum_first_bench.log", "_c5_sum_first_bench.json"), ("c3_bench.log", "_c3_bench.json"),
                  ("c3_c40_bench.log", "_c3_c40_bench.json"), ("c2_bench.log", "_c2_bench.json"),
                  ("c3_loop_reference.log", "_c3_loop_reference.json"), ("c2_loop_reference.log", "_c2_loop_reference.json"),

@@ -2257,3 +2257,51 @@ def test_degree_sorted_copy_by_the_library_equals_the_framework_route(idx_dtype,
         assert pa.n_long == pb.n_long and pa.n_slices == pb.n_slices
         if pa.n_long:
             assert torch.equal(pa.rows, pb.rows) and torch.equal(pa.slice_ptr, pb.slice_ptr)
+
+
+@pytest.mark.parametrize("D,W,self_pairs,lds,idx_dtype", [(3, 1, True, 1024, torch.int64), (3, 2, True, 2048, torch.int32), (4, 1, True, 1024, torch.int32),
+                                                          (4, 4, False, 4096, torch.int64), (3, 1, False, 65536, torch.int32), (2, 1, False, 1024, torch.int32),
+                                                          (3, 1, True, 65536, torch.int32)])
+def test_bucketed_pairs_by_the_library_equal_the_framework_route(D, W, self_pairs, lds, idx_dtype, monkeypatch):
+    """HopGraph.pb_plan built by gnan_pb_plan_rows / _keys / _fill == the framework route (which the CPU suite pins against the
+    oracle, tests/test_pb_plan.py), array by array, bit for bit."""
+    import dataclasses
+    from gnan_amd import HopGraph, graph as G
+    monkeypatch.setattr(G, "PB_LDS_BYTES", lds)
+    if lds < 65536:
+        monkeypatch.setattr(G, "PB_SLOT_PAIRS", 8)
+    rng = np.random.default_rng(D * 100 + W + lds)
+    n_rows, n_cols = (700, 900) if lds < 65536 else (40_000, 50_000)
+    hubs = [(5, 60), (333, 150)] if lds < 65536 else [(5, 3000), (333, 20_000), (39_999, 700)]
+    g0, rowptr, col, code = _pb_graph(rng, n_rows, n_cols, D, hubs=hubs, self_pairs=self_pairs)
+    plans = []
+    for hip in (True, False):
+        monkeypatch.setattr(G, "PB_PLAN_IN_HIP", hip)
+        g = HopGraph.from_csr(g0.rowptr.to(idx_dtype), g0.col, g0.code, n_cols=n_cols, n_codes=D)
+        plans.append(g.pb_plan(W))
+    a, b = plans
+    assert a is not None and b is not None
+    for f in dataclasses.fields(a):
+        x, y = getattr(a, f.name), getattr(b, f.name)
+        if torch.is_tensor(x) or torch.is_tensor(y):
+            assert torch.is_tensor(x) and torch.is_tensor(y) and x.dtype == y.dtype and torch.equal(x, y), f.name
+        else:
+            assert x == y, (f.name, x, y)
+
+
+@pytest.mark.parametrize("idx_dtype,n,hubs", [(torch.int64, 5000, [(3, 900), (4000, 4000)]), (torch.int32, 70_000, [(5, 200_000), (69_999, 300)])])
+def test_transposed_adjacency_by_the_library_equals_the_framework_route(idx_dtype, n, hubs, monkeypatch):
+    """gnan_csr_transpose == the torch route (stable argsort by column id), array by array, bit for bit — rectangular graph,
+    hub rows, a very popular neighbour."""
+    from gnan_amd import graph as G
+    rng = np.random.default_rng(n + 1)
+    rowptr, col, code = _random_csr(n, n + 9, 2, rng, hubs=hubs)
+    col[rng.random(col.shape[0]) < 0.2] = 7
+    made = []
+    for hip in (True, False):
+        monkeypatch.setattr(G, "TRANSPOSE_IN_HIP", hip)
+        made.append(_graph(rowptr, col, code, n + 9, 4, idx_dtype=idx_dtype).transposed())
+    a, b = made
+    assert (a.n_rows, a.n_cols) == (b.n_rows, b.n_cols) == (n + 9, n)
+    assert a.rowptr.dtype == b.rowptr.dtype and torch.equal(a.rowptr, b.rowptr)
+    assert torch.equal(a.col, b.col) and torch.equal(a.code, b.code) and a._cnt_by_col and b._cnt_by_col

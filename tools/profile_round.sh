@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT/sum_first -o sf -- python3 bench
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/train -o tr -- python3 tools/train_step_c4.py > $OUT/train_step.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/train_ref -o trr -- python3 tools/train_step_c4_reference_order.py > $OUT/train_step_reference.log 2>&1
 python3 tools/train_step_c4.py > $OUT/train_step_noprof.log 2>&1
+PER_LAYER=1 python3 tools/train_step_c4.py > $OUT/train_step_per_layer.log 2>&1              # the optimizer over model.parameters() (torch's per-tensor overhead on top)
 python3 bench.py --config c5 --traffic off --sustain-seconds 0 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_bench.log 2>&1
 python3 bench.py --config c5 --operand f32 --order sum_first --traffic off --sustain-seconds 0 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/c5_sum_first_bench.log 2>&1
 python3 bench.py --config c3 --steps 20 --warmup 5 > $OUT/c3_bench.log 2>&1

@@ -38,9 +38,13 @@ def main():
         for _, p in m.named_parameters():
             torch.nn.init.xavier_normal_(p, gain=1.0) if p.dim() == 2 else p.normal_(0.0, 0.5)
     m = m.to(DEV).eval()                       # eval: the reference trains without Dropout after its first epoch
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    # the optimizer over the flat parameter buffers (gnan_amd.optim_params: a dozen tensors) — what DESIGN.md quotes, the kernels'
+    # step; PER_LAYER=1: over model.parameters() as main.py:141 writes it (torch's per-tensor bookkeeping on ~390 tensors on top)
+    per_layer = bool(os.environ.get("PER_LAYER"))
+    opt = torch.optim.Adam(m.parameters() if per_layer else gnan_amd.optim_params(m), lr=1e-3)
     d = Bag(x=x, edge_index=None, gnan_graph=g)
-    out = {"what": f"train_step_rmat_{N}n_{E}e_F{F}"}
+    out = {"what": f"train_step_rmat_{N}n_{E}e_F{F}", "optimizer_over": "model.parameters()" if per_layer else "gnan_amd.optim_params(model)",
+           "optimizer_tensors": sum(len(gr["params"]) for gr in opt.param_groups)}
 
     def fwd():
         with torch.no_grad():
