@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--cut", default="cost", choices=["cost", "rows"],
                     help="halo / exchange partitions: node blocks of equal cost (look-up rows + stored pairs, "
                          "distributed.balanced_bounds) or of equal row count")
+    ap.add_argument("--alt-timeout", type=float, default=300.0,
+                    help="seconds the extra partitions may take before the measured line is printed without them")
     ap.add_argument("--alt-partitions", default="auto", choices=["auto", "off"],
                     help="more than one rank, halo partition: after the timed loop, also time a few steps of the partitions that DO "
                          "move operand rows over xGMI (all-gather of the [N, W] operand; all-to-all-v of the listed halo rows) and "
@@ -1259,12 +1261,28 @@ def main():
         if result is not None:           # should a collective of the extra partitions hang, the measured line is at least in the log
             print("bench.py: the line so far (alt_partitions follow): " + json.dumps(result), file=sys.stderr, flush=True)
         alt = {}
+
+        def bail():
+            # a collective of the extra partitions that never returns must not cost the measured line: every rank runs this
+            # timer (started behind the same barrier), rank 0 prints the line with what was finished, all leave with 0
+            if result is not None:
+                for name in ("vertex", "exchange"):
+                    alt.setdefault(name, {"error": f"not finished within --alt-timeout {args.alt_timeout} s"})
+                result["alt_partitions"] = alt
+                print(json.dumps(result), flush=True)
+            sys.stderr.flush()
+            os._exit(0)
+        import threading
+        timer = threading.Timer(args.alt_timeout, bail)
+        timer.daemon = True
+        timer.start()
         for name in ("vertex", "exchange"):
             try:
                 alt[name] = time_alt_partition(name, args, dict(N=N, E=E, F=F, C=C, dev=dev, rank=rank, world=world, src=src, dst=dst,
                                                                 stacked=stacked, lut=lut, op_dtype=op_dtype, bounds=bounds))
             except Exception as e:                   # (every rank fails alike or the next collective hangs: shapes are the same on all)
                 alt[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        timer.cancel()
         del src, dst
         if result is not None:
             result["alt_partitions"] = alt

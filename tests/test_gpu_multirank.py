@@ -217,3 +217,22 @@ def test_bench_starts_its_own_ranks(partition):
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["config"]["partition"] == f"{partition} x2"
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
     assert abs(two["checksum"] - one["checksum"]) <= 1e-5 * abs(one["checksum"]), (two["checksum"], one["checksum"])
+
+
+def test_bench_line_survives_extra_partitions_that_do_not_finish():
+    """A collective of the ``alt_partitions`` legs that never returns (first contact with a real 8-GPU node) must not cost the
+    measured line: behind ``--alt-timeout`` every rank leaves with 0 and rank 0 prints the line, the legs marked unfinished."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    env_had = os.environ.pop("WORLD_SIZE", None)
+    try:
+        cut = _bench_line(["--gpus", "2", "--same-device", "--backend", "gloo", "--partition", "halo", "--alt-timeout", "0.001"])
+        full = _bench_line(["--gpus", "2", "--same-device", "--backend", "gloo", "--partition", "halo"])
+    finally:
+        if env_had is not None:
+            os.environ["WORLD_SIZE"] = env_had
+    assert cut["value"] > 0 and set(cut["alt_partitions"]) == {"vertex", "exchange"}
+    assert any("not finished" in str(v.get("error", "")) for v in cut["alt_partitions"].values()), cut["alt_partitions"]
+    for name, leg in full["alt_partitions"].items():
+        assert "error" not in leg, (name, leg)
+        assert abs(leg["checksum"] - full["checksum"]) <= 1e-5 * abs(full["checksum"]), (name, leg["checksum"], full["checksum"])
