@@ -10,6 +10,14 @@
 //      into (anchor, value, slope) per piece.
 // It replaces ~150 tiny framework launches of the torch restatement of the same procedure
 // (gnan_amd/pwl.py:_build_padded, which remains the reference implementation and the L >= 4 path).
+//
+// L = 3, H <= 64 ("affine" route): between two consecutive FIRST-layer kinks every second-layer pre-activation is affine in x,
+// z_j(x) = A[s][j] x + B[s][j], and crossing the kink of unit k changes (A, B) by W2[j, k] (w1_k, b1_k).  The (H + 1) x H forms
+// are built incrementally — one direct sum for the leftmost interval, two fmas per unit and kink after it — and BOTH the root
+// search of step 2 and the table evaluation of step 3 read z_j(x) off them: O(H) per node instead of the O(H^2) dot products
+// that were 37 of the kernel's 50 us on the arxiv shape (LDS-issue bound; profiles/r06 notes in DESIGN_HISTORY R6.6).
+// Sorting is by ranking (every element counts the elements before it: broadcast LDS reads, one barrier) instead of a bitonic
+// network (21-55 barrier rounds).
 #include "common.hpp"
 
 #include <cmath>
@@ -40,21 +48,34 @@ struct BuildParams {
   double* scratch;       // [F, cap + 2, C] network values at the table nodes
   int hid_offset;        // byte offset of the two [chunk, H] float64 tiles in dynamic LDS (8-byte aligned)
   int chunk;             // nodes per pass
+  int affine;            // L == 3 by the interval forms: the tile region holds A | B [(H + 1), H] | zt [chunk, H] | k1 [H] | unit_at [H]
 };
 
-__device__ __forceinline__ void bitonic_sort(double* a, int n_pow2, int tid) {
-  for (int k = 2; k <= n_pow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n_pow2; i += kBT) {
-        const int l = i ^ j;
-        if (l > i) {
-          const double x = a[i], y = a[l];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { a[i] = y; a[l] = x; }
-        }
+// Stable merge by ranking of a SORTED run a[0, na) and an unsorted one b[0, nb) into out (a before b on ties, ties inside b by
+// index): an element of a keeps its index and adds the elements of b below it, an element of b adds its place in a (binary
+// search) to the elements of b before it.  All lanes read the same element of b at the same time (LDS broadcast); out must
+// not alias a or b.
+__device__ __forceinline__ void rank_merge(const double* a, int na, const double* b, int nb, double* out, int tid) {
+  for (int e = tid; e < na + nb; e += kBT) {
+    const bool from_a = e < na;
+    const int ie = from_a ? e : e - na;
+    const double v = from_a ? a[ie] : b[ie];
+    int r = ie;
+    if (!from_a) {
+      int lo = 0, hi = na;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
       }
-      __syncthreads();
+      r = lo;
     }
+    const int tie = from_a ? 0 : ie;                        // elements of b equal to v count if their index is below this
+#pragma unroll 16
+    for (int i = 0; i < nb; ++i) {
+      const double x = b[i];
+      r += (x < v || (x == v && i < tie)) ? 1 : 0;
+    }
+    out[r] = v;
   }
 }
 
@@ -121,14 +142,24 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* bp = reinterpret_cast<double*>(smem_raw);        // [kCap]
   double* cand = bp + kCap;                                 // [kCap]
-  float* w1 = reinterpret_cast<float*>(cand + kCap);        // [H]
+  double* tmp = cand + kCap;                                // [kCap] where the rank sorts put their result
+  float* w1 = reinterpret_cast<float*>(tmp + kCap);         // [H]
   float* b1 = w1 + p.H;                                     // [H]
   float* b2 = b1 + p.H;                                     // [H]
-  float* W2 = b2 + p.H;                                     // [H*H] (L == 3)
+  float* wl = b2 + p.H;                                     // [4 * H + 4] last layer's rows and biases of up to four channels
+  float* W2 = wl + 4 * p.H + 4;                             // [H*H] (L == 3), transposed: W2[k * H + j]
   double* h1 = reinterpret_cast<double*>(smem_raw + p.hid_offset);    // [chunk, H] relu(layer 1)
   double* zt = h1 + p.chunk * p.H;                                     // [chunk, H] layer-2 pre-activations
+  // the affine route's use of the same region
+  const int HS = p.H + 1;                                              // row stride of the forms: lanes = nodes read rows of
+  double* A = h1;                                                      // different intervals at the same unit, conflict-free
+  double* B = A + (p.H + 1) * HS;                                      // [(H + 1), HS] each
+  double* k1 = B + (p.H + 1) * HS + p.chunk * p.H;                     // [H] first-layer kinks, sorted
+  int* unit_at = reinterpret_cast<int*>(k1 + p.H);                     // [H] the unit whose kink is the r-th
+  if (p.affine) zt = B + (p.H + 1) * HS;
   __shared__ int n_cand, n_bp, over;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x;
   const int H = p.H, C = p.C;
   const double INF = INFINITY;
@@ -138,30 +169,57 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
     b1[i] = p.b_first ? p.b_first[k * H + i] : 0.f;
     b2[i] = (p.L == 3 && p.b_mid) ? p.b_mid[k * H + i] : 0.f;
   }
-  if (p.L == 3)
+  if (C <= 4) {                                             // (a global read inside the output sums is a microsecond each)
+    for (int i = tid; i < C * H; i += kBT) wl[i] = p.w_last[static_cast<int64_t>(k) * C * H + i];
+    if (tid < C) wl[4 * H + tid] = p.b_last ? p.b_last[k * C + tid] : 0.f;
+  }
+  // W2 (16 KB at H = 64, one cold read per workgroup) is requested now and stored behind step 1, which needs only w1 and b1
+  const bool w2_ahead = p.L == 3 && H * H <= 4 * kBT;
+  float w2r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (w2_ahead) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tid + q * kBT < H * H) w2r[q] = p.w_mid[static_cast<int64_t>(k) * H * H + tid + q * kBT];
+  } else if (p.L == 3) {
     for (int i = tid; i < H * H; i += kBT)       // coalesced read of W[j][kk], transposed write
       W2[(i % H) * H + i / H] = p.w_mid[static_cast<int64_t>(k) * H * H + i];
-  for (int i = tid; i < kCap; i += kBT) bp[i] = INF;
-  if (tid == 0) { n_cand = 0; over = 0; }
+  }
+  if (tid == 0) { n_cand = 0; over = 0; n_bp = 0; }
   __syncthreads();
 
-  // ---- 1. first-layer kinks -------------------------------------------------------------------
+  // ---- 1. first-layer kinks, sorted by ranking (ties by unit) -----------------------------------
   for (int j = tid; j < H; j += kBT) {
     const double t = w1[j] != 0.f ? -static_cast<double>(b1[j]) / static_cast<double>(w1[j]) : INF;
-    bp[j] = isfinite(t) ? t : INF;
+    cand[j] = isfinite(t) ? t : INF;
   }
   __syncthreads();
-  int pow2 = 1;
-  while (pow2 < H) pow2 <<= 1;
-  bitonic_sort(bp, pow2, tid);
-  if (tid == 0) n_bp = 0;
+  for (int j = tid; j < H; j += kBT) {
+    const double t = cand[j];
+    if (t < INF) {
+      int r = 0;
+#pragma unroll 16
+      for (int i = 0; i < H; ++i) {
+        const double x = cand[i];
+        r += (x < t || (x == t && i < j)) ? 1 : 0;
+      }
+      bp[r] = t;
+      if (p.affine) unit_at[r] = j;
+      atomicAdd(&n_bp, 1);
+    }
+  }
+  if (w2_ahead) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + q * kBT;
+      if (i < H * H) W2[(i % H) * H + i / H] = w2r[q];
+    }
+  }
   __syncthreads();
-  if (tid < H && isfinite(bp[tid]) && (tid == H - 1 || !isfinite(bp[tid + 1]))) n_bp = tid + 1;   // sorted: infinities last
-  __syncthreads();
+  const int P1 = n_bp;                                       // first-layer kinks (finite ones)
 
   // ---- 2. second-layer kinks ------------------------------------------------------------------
   if (p.L == 3) {
-    const int P = n_bp;
+    const int P = P1;
     const double t_first = P ? bp[0] : 0.0, t_last = P ? bp[P - 1] : 0.0;
     const int n_nodes = P + 4;
     auto node = [&](int i) -> double {
@@ -170,42 +228,122 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
       if (i < P + 2) return bp[i - 2];
       return i == P + 2 ? t_last + 1.0 : t_last + 2.0;
     };
-    // passes of chunk - 1 intervals (chunk nodes, one node of overlap); thread = (interval, unit)
     auto push = [&](double r) {
       if (isfinite(r)) {
         const int at = atomicAdd(&n_cand, 1);
         if (at < kCap) cand[at] = r; else over = 1;
       }
     };
-    for (int c0 = 0; c0 < n_nodes - 1; c0 += p.chunk - 1) {
-      const int nn = n_nodes - c0 < p.chunk ? n_nodes - c0 : p.chunk;                    // nodes of this pass
-      eval_nodes(node, c0, nn, H, true, w1, b1, b2, W2, h1, zt, tid);
-      for (int it = tid; it < (nn - 1) * H; it += kBT) {
-        const int li = it / H + 1, j = it % H, i = c0 + li;                              // interval (i - 1, i)
-        const double e_prev = node(i - 1), e = node(i);
-        const double z_prev = zt[(li - 1) * H + j], z = zt[li * H + j];
-        if (z_prev * z < 0.0) push(e_prev + (e - e_prev) * (z_prev / (z_prev - z)));
-        if (i == n_nodes - 1) {                             // right ray: extrapolate the outermost affine piece
-          const double dr = z - z_prev;
-          if (dr != 0.0 && z / dr < 0.0) push(e - z / dr * (e - e_prev));
+    // interval (i - 1, i) of the nodes, unit j, with the pre-activations at its two ends
+    auto roots = [&](int i, double e_prev, double e, double z_prev, double z) {
+      if (z_prev * z < 0.0) push(e_prev + (e - e_prev) * (z_prev / (z_prev - z)));
+      if (i == n_nodes - 1) {                               // right ray: extrapolate the outermost affine piece
+        const double dr = z - z_prev;
+        if (dr != 0.0 && z / dr < 0.0) push(e - z / dr * (e - e_prev));
+      }
+      if (i == 1) {                                         // left ray
+        const double dl = z - z_prev;
+        if (dl != 0.0 && z_prev / dl > 0.0) push(e_prev - z_prev / dl * (e - e_prev));
+      }
+    };
+    if (p.affine) {
+      // the interval forms: z_j(x) = A[s][j] x + B[s][j] for x between first-layer kinks s - 1 and s.  Left of all kinks the
+      // units with w1 < 0 are active (and the constant ones with b1 > 0); crossing the kink of unit k switches it on (w1 > 0)
+      // or off.  float x float products are exact in float64: every step is one rounding per form.
+      // Two levels over the 16 waves (a chain of 2 H dependent LDS round trips on one wave was 11 of the kernel's 33 us): wave w
+      // sums units 4w .. 4w+3 of the leftmost form and the steps of kinks 4w .. 4w+3; the partial sums meet in the tile region
+      // and every wave adds what lies before its own steps, in wave order (fixed order: bit-reproducible).
+      for (int i = tid; i < P; i += kBT) k1[i] = bp[i];
+      double* pa = zt;                                      // [16][H] partial sums of the leftmost form
+      double* pb = pa + 16 * H;
+      double* sa = pb + 16 * H;                             // [16][H] sums of a wave's steps
+      double* sb = sa + 16 * H;
+      double la[4] = {0.0, 0.0, 0.0, 0.0}, lb[4] = {0.0, 0.0, 0.0, 0.0};      // running sums of this wave's steps
+      if (lane < H) {
+        const int j = lane;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = 4 * wave + u;
+          if (kk < H) {
+            const float w = w1[kk], bb = b1[kk];
+            const double w2 = (w < 0.f || (w == 0.f && bb > 0.f)) ? static_cast<double>(W2[kk * H + j]) : 0.0;
+            a = fma(w2, static_cast<double>(w), a);
+            b = fma(w2, static_cast<double>(bb), b);
+          }
         }
-        if (i == 1) {                                       // left ray
-          const double dl = z - z_prev;
-          if (dl != 0.0 && z_prev / dl > 0.0) push(e_prev - z_prev / dl * (e - e_prev));
+        pa[wave * H + j] = a;
+        pb[wave * H + j] = b;
+        a = 0.0;
+        b = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sk = 4 * wave + u;
+          if (sk < P) {
+            const int kk = unit_at[sk];
+            const double w2 = w1[kk] > 0.f ? static_cast<double>(W2[kk * H + j]) : -static_cast<double>(W2[kk * H + j]);
+            a += w2 * static_cast<double>(w1[kk]);          // (exact products: two float32 factors)
+            b += w2 * static_cast<double>(b1[kk]);
+          }
+          la[u] = a;
+          lb[u] = b;
+        }
+        sa[wave * H + j] = a;
+        sb[wave * H + j] = b;
+      }
+      __syncthreads();
+      if (lane < H) {
+        const int j = lane;
+        double a = 0.0, b = b2[j];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          a += pa[w * H + j];
+          b += pb[w * H + j];
+        }
+        if (wave == 0) {
+          A[j] = a;
+          B[j] = b;
+        }
+        for (int w = 0; w < wave; ++w) {
+          a += sa[w * H + j];
+          b += sb[w * H + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sk = 4 * wave + u;
+          if (sk < P) {
+            A[(sk + 1) * HS + j] = a + la[u];
+            B[(sk + 1) * HS + j] = b + lb[u];
+          }
         }
       }
-      __syncthreads();                                      // the tiles are rewritten by the next chunk
+      __syncthreads();                                      // (cand is free again: its kinks were read before the forms)
+      for (int i = 1 + wave; i < n_nodes; i += kBT / 64) {    // wave = interval (i - 1, i), lane = unit
+        const int s = i - 2 < 0 ? 0 : (i - 2 > P ? P : i - 2);
+        const double e_prev = node(i - 1), e = node(i);
+        if (lane < H) {
+          const double a = A[s * HS + lane], b = B[s * HS + lane];
+          roots(i, e_prev, e, fma(a, e_prev, b), fma(a, e, b));
+        }
+      }
+    } else {
+      // passes of chunk - 1 intervals (chunk nodes, one node of overlap); thread = (interval, unit)
+      for (int c0 = 0; c0 < n_nodes - 1; c0 += p.chunk - 1) {
+        const int nn = n_nodes - c0 < p.chunk ? n_nodes - c0 : p.chunk;                    // nodes of this pass
+        eval_nodes(node, c0, nn, H, true, w1, b1, b2, W2, h1, zt, tid);
+        for (int it = tid; it < (nn - 1) * H; it += kBT) {
+          const int li = it / H + 1, j = it % H, i = c0 + li;                              // interval (i - 1, i)
+          roots(i, node(i - 1), node(i), zt[(li - 1) * H + j], zt[li * H + j]);
+        }
+        __syncthreads();                                      // the tiles are rewritten by the next chunk
+      }
     }
     __syncthreads();
     const int nc = n_cand < kCap ? n_cand : kCap;
     if (P + nc > p.cap) { if (tid == 0) over = 1; }
     const int total = P + nc < kCap ? P + nc : kCap;
-    for (int i = tid; i < nc; i += kBT)
-      if (P + i < kCap) bp[P + i] = cand[i];
-    __syncthreads();
-    pow2 = 1;
-    while (pow2 < total) pow2 <<= 1;
-    bitonic_sort(bp, pow2 > 1 ? pow2 : 2, tid);
+    rank_merge(bp, P, cand, total - P, tmp, tid);
+    { double* t = bp; bp = tmp; tmp = t; }                  // (nothing reads bp beyond its n_bp entries from here on)
     if (tid == 0) n_bp = total < p.cap ? total : p.cap;
     __syncthreads();
   }
@@ -246,25 +384,95 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
       return t_last + 1.0;
     };
     const int Pn = P ? P : 1;                               // table nodes between the two outer ones
-    // the network at the table nodes, p.chunk nodes at a time: the last hidden layer into LDS (eval_nodes), then
-    // (node, channel) pairs take the output dot products
-    for (int n0 = 0; n0 < Pn + 2; n0 += p.chunk) {
-      const int nn = Pn + 2 - n0 < p.chunk ? Pn + 2 - n0 : p.chunk;
-      eval_nodes(tnode, n0, nn, H, p.L == 3, w1, b1, b2, W2, h1, zt, tid);
-      if (mark) {
-        for (int it = tid; it < nn * H; it += kBT) {
-          const int g = n0 + it / H, j = it % H;            // table node g is anchor g - 1
-          if (g < 1 || g > P) continue;
-          bool zero = w1[j] != 0.f && fma(static_cast<double>(w1[j]), bp[g - 1], static_cast<double>(b1[j])) == 0.0;
-          if (p.L == 3) zero |= zt[it] == 0.0;
-          if (zero) on_kink[g - 1] = 1;
+    // the network at the table nodes, p.chunk nodes at a time: the last hidden layer into LDS, then (node, channel) pairs
+    // take the output dot products
+    // affine route, C <= 4: one pass, a thread per node keeps the output sums in registers; more channels: relu(z) goes to the
+    // tile chunk by chunk and (node, channel) pairs take the dot products as below
+    const bool inline_out = p.affine && C <= 4;
+    const int step = inline_out ? Pn + 2 : p.chunk;
+    for (int n0 = 0; n0 < Pn + 2; n0 += step) {
+      const int nn = Pn + 2 - n0 < step ? Pn + 2 - n0 : step;
+      if (inline_out) {
+        // eight lanes = one table node, each takes every eighth unit in order and the eight partial sums meet by lane exchange
+        // (fixed order).  The loop is bound by float64 issue, not by LDS: a thread per node left 14 of the 16 waves idle for 7 us.
+        // The forms' rows are padded, so lanes in different intervals read different banks.
+        const int q = tid & 7;
+        for (int g0 = 0; g0 < nn; g0 += kBT / 8) {          // (n0 == 0: all nodes; node g is anchor g - 1)
+          const int g = g0 + (tid >> 3);
+          const bool live = g < nn;
+          const double x = tnode(live ? g : 0);
+          int s = 0;
+          for (int i = q; i < P1; i += 8) s += k1[i] <= x ? 1 : 0;            // its interval: first-layer kinks <= x
+          s += __shfl_xor(s, 1);
+          s += __shfl_xor(s, 2);
+          s += __shfl_xor(s, 4);
+          const bool check = mark && g >= 1 && g <= P;
+          int zero = 0;
+          double acc[4] = {0.0, 0.0, 0.0, 0.0};
+          const double* Ar = A + s * HS;
+          const double* Br = B + s * HS;
+#pragma unroll 4
+          for (int j = q; j < H; j += 8) {
+            double z = fma(Ar[j], x, Br[j]);
+            const float wj = w1[j];                         // (no branch in here: the loads of the next units go out early)
+            const double h = fma(static_cast<double>(wj), x, static_cast<double>(b1[j]));
+            zero |= ((z == 0.0) | ((wj != 0.f) & (h == 0.0))) ? 1 : 0;
+            z = z > 0.0 ? z : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < C) acc[c] = fma(static_cast<double>(wl[c * H + j]), z, acc[c]);
+          }
+#pragma unroll
+          for (int m = 1; m < 8; m <<= 1) {
+            zero |= __shfl_xor(zero, m);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < C) acc[c] += __shfl_xor(acc[c], m);
+          }
+          if (live && q == 0) {
+            if (zero && check) on_kink[g - 1] = 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < C) V[static_cast<int64_t>(g) * C + c] = acc[c] + static_cast<double>(wl[4 * H + c]);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
+      if (p.affine) {
+        for (int ni = wave; ni < nn; ni += kBT / 64) {      // wave = node, lane = unit: relu(z) into the tile
+          const int g = n0 + ni;
+          const double x = tnode(g);
+          const int s = __popcll(__ballot(lane < P1 && k1[lane] <= x));
+          bool zero = false;
+          if (lane < H) {
+            double z = fma(A[s * HS + lane], x, B[s * HS + lane]);
+            if (mark && g >= 1 && g <= P)
+              zero = z == 0.0 || (w1[lane] != 0.f && fma(static_cast<double>(w1[lane]), x, static_cast<double>(b1[lane])) == 0.0);
+            zt[ni * H + lane] = z > 0.0 ? z : 0.0;
+          }
+          if (mark && __ballot(zero) != 0 && lane == 0) on_kink[g - 1] = 1;
+        }
+        __syncthreads();
+      } else {
+        eval_nodes(tnode, n0, nn, H, p.L == 3, w1, b1, b2, W2, h1, zt, tid);
+        if (mark) {
+          for (int it = tid; it < nn * H; it += kBT) {
+            const int g = n0 + it / H, j = it % H;
+            if (g < 1 || g > P) continue;
+            bool zero = w1[j] != 0.f && fma(static_cast<double>(w1[j]), bp[g - 1], static_cast<double>(b1[j])) == 0.0;
+            if (p.L == 3) zero |= zt[it] == 0.0;
+            if (zero) on_kink[g - 1] = 1;
+          }
         }
       }
       const double* hid = h1;                               // L == 2: relu(layer 1) is the last hidden layer
       if (p.L == 3) {
-        if (mark) __syncthreads();
-        for (int it = tid; it < nn * H; it += kBT) zt[it] = zt[it] > 0.0 ? zt[it] : 0.0;
-        __syncthreads();
+        if (!p.affine) {
+          if (mark) __syncthreads();
+          for (int it = tid; it < nn * H; it += kBT) zt[it] = zt[it] > 0.0 ? zt[it] : 0.0;
+          __syncthreads();
+        }
         hid = zt;
       }
       for (int it = tid; it < nn * C; it += kBT) {
@@ -290,11 +498,10 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
       if (tid == 0) over = 1;
       break;
     }
-    for (int i = tid; i < nf; i += kBT) bp[P + i] = static_cast<double>(extra[i]);     // bp[P ..] held +inf
+    for (int i = tid; i < nf; i += kBT) bp[P + i] = static_cast<double>(extra[i]);     // (P + nf <= cap <= kCap)
     __syncthreads();
-    pow2 = 2;
-    while (pow2 < P + nf) pow2 <<= 1;
-    bitonic_sort(bp, pow2, tid);
+    rank_merge(bp, P, bp + P, nf, tmp, tid);
+    { double* t = bp; bp = tmp; tmp = t; }
     if (tid == 0) n_bp = P + nf;
   }
   __syncthreads();
@@ -308,13 +515,13 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   __threadfence_block();
   __syncthreads();
   const int pieces = P + 1;
-  float* A = p.anchor + static_cast<int64_t>(k) * (p.cap + 1);
+  float* A_out = p.anchor + static_cast<int64_t>(k) * (p.cap + 1);
   float* VL = p.val + static_cast<int64_t>(k) * (p.cap + 1) * C;
   float* SL = p.slope + static_cast<int64_t>(k) * (p.cap + 1) * C;
   for (int i = tid; i < pieces; i += kBT) {
     // piece i lies between table nodes i and i+1; it is anchored at its left kink, piece 0 at the first kink
     const int an = i == 0 ? 1 : i;
-    A[i] = static_cast<float>(tnode(an));
+    A_out[i] = static_cast<float>(tnode(an));
     const double width = tnode(i + 1) - tnode(i);
     for (int c = 0; c < C; ++c) {
       VL[i * C + c] = static_cast<float>(V[static_cast<int64_t>(an) * C + c]);
@@ -414,11 +621,14 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   p.val = p.anchor + static_cast<size_t>(a->F) * (a->cap + 1);
   p.slope = p.val + static_cast<size_t>(a->F) * (a->cap + 1) * a->C;
   p.pieces = reinterpret_cast<int32_t*>(p.slope + static_cast<size_t>(a->F) * (a->cap + 1) * a->C);
-  size_t lds = 2 * kCap * sizeof(double) + (3 * static_cast<size_t>(a->H) + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
+  size_t lds = 3 * kCap * sizeof(double) + (7 * static_cast<size_t>(a->H) + 4 + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
   lds = (lds + 7) & ~static_cast<size_t>(7);
   p.hid_offset = static_cast<int>(lds);
   p.chunk = a->H <= 64 ? 64 : 32;
-  lds += 2 * static_cast<size_t>(p.chunk) * a->H * sizeof(double);
+  p.affine = (a->L == 3 && a->H <= 64) ? 1 : 0;           // (H + 1) x H interval forms of 16 bytes: 67 KB at H = 64
+  const size_t H_ = static_cast<size_t>(a->H);
+  if (p.affine) lds += (2 * (H_ + 1) * (H_ + 1) + p.chunk * H_ + H_) * sizeof(double) + H_ * sizeof(int);
+  else lds += 2 * static_cast<size_t>(p.chunk) * a->H * sizeof(double);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwl_build_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
