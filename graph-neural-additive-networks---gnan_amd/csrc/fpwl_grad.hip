@@ -299,6 +299,244 @@ __global__ __launch_bounds__(256 * kNG) void fpwl_grad3_kernel(const GradParams 
   if (lt < C && p.d_bl) p.d_bl[static_cast<int64_t>(k) * C + lt] = static_cast<float>(db3);
 }
 
+// ---- L == 3, H <= 64, C <= 4, at most 1024 pieces per feature: the same sums in O(live pieces x H + H^2) ------------------
+// Along the pieces of a feature (ascending x) every first-layer unit switches ONCE: its mask at a piece's inner point,
+// fma(w1_i, xi, b1_i) > 0, is monotone in xi.  So
+//   * the second layer's pre-activation at piece n is an affine form  z_j(x) = Aj x + Bj  that changes by W2[j, i] (w1_i, b1_i)
+//     when unit i switches — one wave (lane = unit j of layer 2) sweeps the live pieces in order, keeping (Aj, Bj) and the
+//     masks D2, e0, e1, h2a, h2' of the derivation above without a single dot product over the first layer;
+//   * the sums over pieces that carry a first-layer mask,  SG[j][i] = sum_n D1_n[i] (e0_n[j] a_n + e1_n[j])  and
+//     SE[j][i] = sum_n D1_n[i] e0_n[j],  are prefix sums of the sweep taken when unit i switches (or the total minus them), and
+//         dW2[j][i] = w1_i SG[j][i] + b1_i SE[j][i]      dw1[i] = sum_j W2[j, i] SG[j][i]      db1[i] = sum_j W2[j, i] SE[j][i]
+//     come out of them once per feature.
+// fpwl_grad3_kernel spends three mat-vecs and a rank-2 update of H x H per live piece (7 us per round of four pieces on the arxiv
+// shape, LDS-issue bound: 50 us); this one ~0.1 us per piece and ~5 us per feature.  Fixed orders: bit-reproducible.
+constexpr int kSweepPieces = 1024;     // live pieces whose points fit LDS
+constexpr int kSweepChunk = 128;       // live pieces whose moments are staged at a time
+
+__global__ __launch_bounds__(256) void fpwl_grad3_sweep_kernel(const GradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int H = p.H, C = p.C, HS = H + 1;
+  double* xi_s = reinterpret_cast<double*>(smem_raw);          // [kSweepPieces] inner point of live piece n
+  double* an_s = xi_s + kSweepPieces;                           // [kSweepPieces] its anchor
+  double* mom = an_s + kSweepPieces;                            // [kSweepChunk][8]: M0[0..4) | M1[0..4) of a chunk's pieces
+  double* PG = mom + kSweepChunk * 8;                           // [H][HS] prefix of G at unit i's switch, per unit j
+  double* PE = PG + H * HS;                                     // [H][HS]
+  double* TG = PE + H * HS;                                     // [H] totals
+  double* TE = TG + H;                                          // [H]
+  float* w1 = reinterpret_cast<float*>(TE + H);
+  float* b1 = w1 + H;
+  float* b2 = b1 + H;
+  float* Wl = b2 + H;                  // [4][H]
+  float* W2s = Wl + 4 * H;             // [H][HS]: W2[j][i], padded rows
+  int* bnd = reinterpret_cast<int*>(W2s + H * HS);              // [H] live pieces before unit i's switch
+  int* order = bnd + H;                                         // [H] units by (bnd, index)
+  int* sw_bnd = order + H;                                      // [H + 1] bnd of the r-th switch (sentinel behind the last)
+  float* sw_w = reinterpret_cast<float*>(sw_bnd + H + 1);       // [H] signed factors of the r-th switch
+  float* sw_b = sw_w + H;                                       // [H]
+  int* live = reinterpret_cast<int*>(sw_b + H);                 // [P]
+  __shared__ int n_live;
+  __shared__ int wave_live[4];
+  const int tid = threadIdx.x, k = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t kH = static_cast<int64_t>(k) * H;
+
+  for (int i = tid; i < H; i += 256) {
+    w1[i] = p.w1[kH + i];
+    b1[i] = p.b1 ? p.b1[kH + i] : 0.f;
+    b2[i] = p.b2 ? p.b2[kH + i] : 0.f;
+  }
+  for (int i = tid; i < H * H; i += 256) W2s[(i / H) * HS + i % H] = p.W2[kH * H + i];
+  for (int i = tid; i < C * H; i += 256) Wl[i] = p.Wl[kH * C + i];
+  const int base = p.off[k], P = p.off[k + 1] - base;
+  const double inv0 = p.Mi ? 1.0 / p.scales[0] : 1.0, inv1 = p.Mi ? 1.0 / p.scales[1] : 1.0;
+  list_live_pieces<256>(p, base, P, inv0, inv1, live, wave_live, &n_live);
+  __syncthreads();
+  const int nl = n_live;
+  for (int n = tid; n < nl; n += 256) piece_points(p.anchor + base, live[n], P, &an_s[n], &xi_s[n]);
+  __syncthreads();
+  // where each first-layer unit switches: units with w1 < 0 (and the constant ones with b1 > 0) are on for the first bnd
+  // live pieces, the others off for the first bnd
+  if (tid < H) {
+    const double w = static_cast<double>(w1[tid]), b = static_cast<double>(b1[tid]);
+    int on = 0;
+#pragma unroll 8
+    for (int n = 0; n < nl; ++n) on += fma(w, xi_s[n], b) > 0.0 ? 1 : 0;
+    const bool starts_on = w1[tid] < 0.f || (w1[tid] == 0.f && b1[tid] > 0.f);
+    bnd[tid] = starts_on ? on : nl - on;
+  }
+  __syncthreads();
+  if (tid < H) {
+    const int mine = bnd[tid];
+    int r = 0;
+#pragma unroll 8
+    for (int i = 0; i < H; ++i) {
+      const int o = bnd[i];
+      r += (o < mine || (o == mine && i < tid)) ? 1 : 0;
+    }
+    order[r] = tid;
+  }
+  __syncthreads();
+
+  // ---- the sweep: wave 0, lane = unit j of layer 2; all waves stage the moments of a chunk --------------------------------
+  // the form left of all switches: quad = unit j, its four lanes split the first-layer units (fixed butterfly); handed to wave 0
+  // through TG / TE, which hold nothing yet
+  {
+    const int jq = tid >> 2, ibq = tid & 3, BIq = (H + 3) >> 2;
+    double a0 = 0.0, b0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < kBI; ++r) {
+      const int i = ibq * BIq + r;
+      const int ic = (r < BIq && i < H) ? i : 0;
+      const float w = w1[ic], b = b1[ic];
+      const bool use = r < BIq && i < H && jq < H && (w < 0.f || (w == 0.f && b > 0.f));
+      const double w2v = static_cast<double>(W2s[(jq < H ? jq : 0) * HS + ic]);
+      const double w2 = use ? w2v : 0.0;
+      a0 = fma(w2, static_cast<double>(w), a0);
+      b0 = fma(w2, static_cast<double>(b), b0);
+    }
+    a0 = quad_sum(a0);
+    b0 = quad_sum(b0);
+    if (ibq == 0 && jq < H) {
+      TG[jq] = a0;
+      TE[jq] = b0 + static_cast<double>(b2[jq]);
+    }
+  }
+  // the switches in sweep order with what they add to the form's coefficients' factors: one level of LDS reads in the sweep
+  if (tid < H) {
+    const int i = order[tid];
+    sw_bnd[tid] = bnd[i];
+    sw_w[tid] = w1[i] > 0.f ? w1[i] : -w1[i];             // |w1|: switching on adds W2 w1 (w1 > 0), switching off subtracts W2 w1 (w1 < 0)
+    sw_b[tid] = w1[i] > 0.f ? b1[i] : -b1[i];
+  }
+  __syncthreads();
+  const int j = lane;
+  const bool jl = wave == 0 && j < H;
+  double Aj = jl ? TG[j] : 0.0, Bj = jl ? TE[j] : 0.0;
+  double RG = 0.0, RE = 0.0, db2 = 0.0;
+  double dW3[4] = {0.0, 0.0, 0.0, 0.0}, db3[4] = {0.0, 0.0, 0.0, 0.0};
+  float wl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) wl[c] = (jl && c < C) ? Wl[c * H + j] : 0.f;
+  int cursor = 0;
+  // the next switch, requested one ahead: its position, unit and this lane's W2 entry
+  int nx_bnd = sw_bnd[0], nx_i = order[0];
+  double nx_w2 = jl ? static_cast<double>(W2s[j * HS + nx_i]) : 0.0;
+  double nx_w = static_cast<double>(sw_w[0]), nx_b = static_cast<double>(sw_b[0]);
+  for (int c0 = 0; c0 < nl; c0 += kSweepChunk) {
+    const int cn = nl - c0 < kSweepChunk ? nl - c0 : kSweepChunk;
+    __syncthreads();                                  // the previous chunk's moments have been read
+    for (int it = tid; it < cn * 8; it += 256) {
+      const int n = it >> 3, c2 = it & 7;
+      const int c = c2 & 3;
+      double v = 0.0;
+      if (c < C) piece_moment(p, base + live[c0 + n], (c2 >> 2) * C + c, inv0, inv1, &v);
+      mom[it] = v;
+    }
+    __syncthreads();
+    if (jl) {
+      for (int n = 0; n < cn; ++n) {
+        const int g = c0 + n;
+        const double x = xi_s[g], a = an_s[g];
+        double m0[4], m1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          m0[c] = mom[n * 8 + c];                     // (zero beyond C)
+          m1[c] = mom[n * 8 + 4 + c];
+        }
+        while (cursor < H && nx_bnd == g) {           // units that switch between live pieces g - 1 and g
+          PG[j * HS + nx_i] = RG;
+          PE[j * HS + nx_i] = RE;
+          Aj += nx_w2 * nx_w;                         // (exact products of two float32 factors)
+          Bj += nx_w2 * nx_b;
+          ++cursor;
+          const int cc = cursor < H ? cursor : H - 1;
+          nx_bnd = cursor < H ? sw_bnd[cc] : -1;
+          nx_i = order[cc];
+          nx_w2 = static_cast<double>(W2s[j * HS + nx_i]);
+          nx_w = static_cast<double>(sw_w[cc]);
+          nx_b = static_cast<double>(sw_b[cc]);
+        }
+        const bool on2 = fma(Aj, x, Bj) > 0.0;
+        const double h2a = on2 ? fma(Aj, a, Bj) : 0.0, h2p = on2 ? Aj : 0.0;
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          p0 = fma(static_cast<double>(wl[c]), m0[c], p0);
+          p1 = fma(static_cast<double>(wl[c]), m1[c], p1);
+          dW3[c] = fma(m0[c], h2a, fma(m1[c], h2p, dW3[c]));
+          db3[c] += m0[c];
+        }
+        const double e0 = on2 ? p0 : 0.0, e1 = on2 ? p1 : 0.0;
+        db2 += e0;
+        RG += fma(e0, a, e1);
+        RE += e0;
+      }
+    }
+  }
+  if (jl) {
+    for (; cursor < H; ++cursor) {                    // units that never switch within the live pieces
+      const int i = order[cursor];
+      PG[j * HS + i] = RG;
+      PE[j * HS + i] = RE;
+    }
+    TG[j] = RG;
+    TE[j] = RE;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) p.d_Wl[(static_cast<int64_t>(k) * C + c) * H + j] = static_cast<float>(dW3[c]);
+    if (p.d_b2) p.d_b2[kH + j] = static_cast<float>(db2);
+    if (j == 0 && p.d_bl) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) p.d_bl[static_cast<int64_t>(k) * C + c] = static_cast<float>(db3[c]);
+    }
+  }
+  __syncthreads();
+
+  // ---- once per feature: the H x H outputs from the prefix sums ------------------------------------------------------------
+  // a unit that starts on carries the pieces BEFORE its switch (the prefix), the others the pieces after it (total - prefix)
+  const int u = tid >> 2, ib = tid & 3;               // quad = one unit; its four lanes split the other index
+  const int BI = (H + 3) >> 2;
+  if (u < H) {
+    // row j = u of dW2 (loads unconditional at clamped indices: a guarded load waits for everything before it)
+    const double tg = TG[u], te = TE[u];
+#pragma unroll 4
+    for (int r = 0; r < kBI; ++r) {
+      const int i = ib * BI + r;
+      const bool ok = r < BI && i < H;
+      const int ic = ok ? i : 0;
+      const float w = w1[ic], b = b1[ic];
+      const double pg = PG[u * HS + ic], pe = PE[u * HS + ic];
+      const bool starts_on = w < 0.f || (w == 0.f && b > 0.f);
+      const double sg = starts_on ? pg : tg - pg;
+      const double se = starts_on ? pe : te - pe;
+      if (ok) p.d_W2[(kH + u) * H + i] = static_cast<float>(fma(static_cast<double>(w), sg, static_cast<double>(b) * se));
+    }
+    // column i = u: dw1, db1
+    const bool starts_on = w1[u] < 0.f || (w1[u] == 0.f && b1[u] > 0.f);
+    double q0 = 0.0, q1 = 0.0;
+#pragma unroll 4
+    for (int r = 0; r < kBI; ++r) {
+      const int jj = ib * BI + r;
+      const bool ok = r < BI && jj < H;
+      const int jc = ok ? jj : 0;
+      const double wv = static_cast<double>(W2s[jc * HS + u]);
+      const double w = ok ? wv : 0.0;
+      const double pg = PG[jc * HS + u], pe = PE[jc * HS + u];
+      const double sg = starts_on ? pg : TG[jc] - pg;
+      const double se = starts_on ? pe : TE[jc] - pe;
+      q1 = fma(w, sg, q1);
+      q0 = fma(w, se, q0);
+    }
+    q0 = quad_sum(q0);
+    q1 = quad_sum(q1);
+    if (ib == 0) {
+      p.d_w1[kH + u] = static_cast<float>(q1);
+      if (p.d_b1) p.d_b1[kH + u] = static_cast<float>(q0);
+    }
+  }
+}
+
 // ---- L == 2, H <= 128: thread (i, cb) = (hidden unit, quarter of the output channels) --------------------------------
 __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -487,6 +725,18 @@ extern "C" int gnan_fpwl_param_grads(const gnan_fpwl_grad_args* a, gnan_stream_t
     // few channels: four groups (1024 threads, 128 registers per lane); many: two (256 registers — CQ = 16 spilled 120 at four)
     // (measured on the arxiv shape, 128 features x ~130 pieces: 50 us with either group count — the pieces' LDS reads and
     // float64 fmas bound it, not the barriers per round; four groups halve the rounds of features with few live pieces)
+    if (C <= 4 && a->max_pieces <= kSweepPieces) {
+      const size_t HS = H + 1;
+      const size_t sweep = (2 * kSweepPieces + kSweepChunk * 8 + 2 * H * HS + 2 * H) * sizeof(double) +
+                           (3 * H + 4 * H + H * HS) * sizeof(float) + (5 * H + 1 + static_cast<size_t>(a->max_pieces) + 8) * sizeof(int);
+      if (sweep > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fpwl_grad3_sweep_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sweep));
+        if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl_param_grads: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      }
+      hipLaunchKernelGGL(fpwl_grad3_sweep_kernel, dim3(a->F), dim3(256), sweep, st, p);
+      return gnan::check_launch("fpwl_grad3_sweep_kernel");
+    }
     const int ng = C <= 4 ? 4 : 2;
     lds += (ng * (5 * H + 2 * C) + (ng - 1) * 256) * sizeof(double) + (static_cast<size_t>(a->max_pieces) + 8) * sizeof(int);   // + live pieces
     const dim3 grid(a->F), block(256 * ng);
