@@ -50,6 +50,7 @@ class FpwlArgs(C.Structure):
         ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32),
         ("sum_workspace", C.c_void_p), ("sum_workspace_bytes", C.c_size_t),
         ("sum_total", C.c_void_p), ("sum_total_workspace", C.c_void_p), ("sum_total_workspace_bytes", C.c_size_t),
+        ("sum_total_arrive", C.c_void_p),
     ]
 
 
@@ -70,6 +71,7 @@ class PwlBuildArgs(C.Structure):
         ("F", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32),
         ("anchor", C.c_void_p), ("val", C.c_void_p), ("slope", C.c_void_p), ("off", C.c_void_p),
         ("overflow", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+        ("index_range", C.c_void_p), ("index_table", C.c_void_p), ("index_key", C.c_void_p), ("index_buckets", C.c_int32),
     ]
 
 
@@ -187,7 +189,7 @@ class MomentScalesArgs(C.Structure):
         ("grad", C.c_void_p), ("n", C.c_int64), ("width", C.c_int32), ("bits", C.c_int32), ("grad_stride", C.c_int64),
         ("anchor", C.c_void_p), ("T", C.c_int64), ("n_anchors", C.c_void_p), ("x_abs_max", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("scales", C.c_void_p),
-        ("zero", C.c_void_p), ("zero_bytes", C.c_size_t),
+        ("zero", C.c_void_p), ("zero_bytes", C.c_size_t), ("arrive_counter", C.c_void_p),
     ]
 
 
@@ -206,7 +208,7 @@ class PackBwdRowsArgs(C.Structure):
         ("dY", C.c_void_p), ("dy_stride", C.c_int64), ("W", C.c_int32), ("D", C.c_int32), ("cnt", C.c_void_p),
         ("cnt_stride", C.c_int64), ("n", C.c_int64), ("with_rest", C.c_int32), ("half", C.c_int32), ("V", C.c_void_p),
         ("hot", C.c_void_p), ("n_hot", C.c_int64), ("q_sum", C.c_void_p), ("q_workspace", C.c_void_p),
-        ("q_workspace_bytes", C.c_size_t),
+        ("q_workspace_bytes", C.c_size_t), ("q_arrive", C.c_void_p),
     ]
 
 

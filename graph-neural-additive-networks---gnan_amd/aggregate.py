@@ -351,6 +351,7 @@ def pack_bwd_rows(dY: torch.Tensor, cnt: Optional[torch.Tensor], D: int, with_re
             raise ValueError("pack_bwd_rows: q_sum is the one-channel rest-bucket sum")
         q_sum = torch.empty(1, dtype=torch.float32, device=dY.device)
         pa.q_sum = _lib.ptr(q_sum)
+        pa.q_arrive = _lib.ptr(Fn.arrive_counter(dY.device, 2))
         need = _lib.lib().gnan_spmm_pack_bwd_rows_workspace_bytes(pa)
         ws = torch.empty(max(1, need // 8), dtype=torch.float64, device=dY.device)      # (alive until the launch is queued)
         pa.q_workspace, pa.q_workspace_bytes = _lib.ptr(ws), ws.numel() * 8

@@ -617,9 +617,12 @@ __global__ __launch_bounds__(512) void fpwl_grad2_kernel(const GradParams p) {
 // and poisons the scales, as it would poison the sums).  Every workgroup writes its own pair — no atomics, nothing to zero
 // first (a zeroing launch and its 8-byte target used to precede this one) — and, on the way, clears the moment accumulators
 // the next launch adds into (`zero`, int64 words: a framework fill launch otherwise).
+__device__ __forceinline__ void finish_scales(const unsigned* blk, int n_blk, const double* x_abs_max, int nbits, double* scales);
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, int64_t n, int width, int64_t stride,
                                                      const float* __restrict__ anchor, int64_t T, const int32_t* off_end,
-                                                     unsigned* blk, unsigned long long* zero, int64_t zero_words) {
+                                                     unsigned* blk, unsigned long long* zero, int64_t zero_words,
+                                                     unsigned* arrive, const double* x_abs_max, int nbits, double* scales) {
   const int64_t total = n * width;
   if (off_end && *off_end < T) T = *off_end;       // tables held in a buffer of full capacity: only off[F] anchors are real
   float m = 0.f, ma = 0.f;
@@ -657,11 +660,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
     for (int w = 1; w < 4; ++w) m4 = wmax[w][threadIdx.x] > m4 ? wmax[w][threadIdx.x] : m4;
     blk[2 * blockIdx.x + threadIdx.x] = m4;
   }
+  // with an arrival counter the last workgroup of the pass takes the scales itself (scales_kernel otherwise: a launch of 5 us)
+  if (arrive != nullptr && gnan::last_block(arrive)) finish_scales(blk, static_cast<int>(gridDim.x), x_abs_max, nbits, scales);
 }
 
 // one workgroup: the maxima of the n_blk pairs, then the two scales
-__global__ __launch_bounds__(256) void scales_kernel(const unsigned* blk, int n_blk, const double* x_abs_max, int nbits,
-                                                     double* scales) {
+__device__ __forceinline__ void finish_scales(const unsigned* blk, int n_blk, const double* x_abs_max, int nbits, double* scales) {
   unsigned u = 0u, ua = 0u;
   for (int b = threadIdx.x; b < n_blk; b += 256) {
     const unsigned v = blk[2 * b], va = blk[2 * b + 1];
@@ -673,13 +677,13 @@ __global__ __launch_bounds__(256) void scales_kernel(const unsigned* blk, int n_
     u = o > u ? o : u;
     ua = oa > ua ? oa : ua;
   }
-  __shared__ unsigned wmax[4][2];
-  if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6][0] = u; wmax[threadIdx.x >> 6][1] = ua; }
+  __shared__ unsigned wmax2[4][2];
+  if ((threadIdx.x & 63) == 0) { wmax2[threadIdx.x >> 6][0] = u; wmax2[threadIdx.x >> 6][1] = ua; }
   __syncthreads();
   if (threadIdx.x != 0) return;
   for (int w = 1; w < 4; ++w) {
-    u = wmax[w][0] > u ? wmax[w][0] : u;
-    ua = wmax[w][1] > ua ? wmax[w][1] : ua;
+    u = wmax2[w][0] > u ? wmax2[w][0] : u;
+    ua = wmax2[w][1] > ua ? wmax2[w][1] : ua;
   }
   const float gf = __uint_as_float(u), af = __uint_as_float(ua);
   const double xm = *x_abs_max;
@@ -694,6 +698,12 @@ __global__ __launch_bounds__(256) void scales_kernel(const unsigned* blk, int n_
   const double e1 = fmin(fmax(floor(nbits - log2(g * d)), -1000.0), 1000.0);
   scales[0] = ldexp(1.0, static_cast<int>(e0));
   scales[1] = ldexp(1.0, static_cast<int>(e1));
+}
+
+
+__global__ __launch_bounds__(256) void scales_kernel(const unsigned* blk, int n_blk, const double* x_abs_max, int nbits,
+                                                     double* scales) {
+  finish_scales(blk, n_blk, x_abs_max, nbits, scales);
 }
 
 }  // namespace
@@ -769,8 +779,10 @@ extern "C" int gnan_fpwl_moment_scales(const gnan_moment_scales_args* a, gnan_st
   constexpr int64_t kMaxBlocks = GNAN_MOMENT_SCALES_WORKSPACE_BYTES / 8;
   blocks = blocks < 1 ? 1 : (blocks > kMaxBlocks ? kMaxBlocks : blocks);
   hipLaunchKernelGGL(absmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, a->grad, n, a->width, a->grad_stride,
-                     a->anchor, T, a->n_anchors, blk, static_cast<unsigned long long*>(a->zero), zero_words);
+                     a->anchor, T, a->n_anchors, blk, static_cast<unsigned long long*>(a->zero), zero_words,
+                     reinterpret_cast<unsigned*>(a->arrive_counter), a->x_abs_max, a->bits, a->scales);
   if (int rc = gnan::check_launch("absmax_kernel")) return rc;
+  if (a->arrive_counter != nullptr) return GNAN_OK;
   hipLaunchKernelGGL(scales_kernel, dim3(1), dim3(256), 0, st, blk, static_cast<int>(blocks), a->x_abs_max, a->bits, a->scales);
   return gnan::check_launch("scales_kernel");
 }

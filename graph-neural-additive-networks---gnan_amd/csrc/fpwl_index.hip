@@ -31,6 +31,7 @@
 // 10M x 64 matrix (a framework element-wise kernel: 0.86).  The x rows of the next round are requested before the
 // current round's look-ups.  Column sums / feature sum / kept pieces in the epilogue as in fpwl_fast_kernel.
 #include "common.hpp"
+#include "fpwl_bucket.hpp"
 
 #include <cstdint>
 #include <type_traits>
@@ -77,10 +78,7 @@ __device__ __forceinline__ unsigned bf16_bits(float f) {      // round-to-neares
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-// The bucket of x: ONE definition for the look-up and for the builder (which buckets the anchors with it).
-__device__ __forceinline__ int bucket_of(float x, float ks, float ko, float top) {
-  return static_cast<int>(__builtin_amdgcn_fmed3f(__fmaf_rn(x, ks, ko), 0.0f, top));   // NaN -> 0 (med3 = min3 on NaN)
-}
+using gnan_index::bucket_of;      // (csrc/fpwl_bucket.hpp: ONE definition for the look-up and for the builders)
 
 // ---------------------------------------------------------------------------------------------
 // column minima / maxima of the feature matrix: the range hint.  Order-preserving integer images of the floats and
@@ -127,59 +125,8 @@ __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restr
                                                           const float* __restrict__ range,
                                                           uint16_t* __restrict__ table, float* __restrict__ key,
                                                           int32_t* __restrict__ stats) {
-  constexpr int B = 1 << LOGB;
-  __shared__ int cnt[B];
-  __shared__ int part[256];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  float lo = range[2 * f], hi = range[2 * f + 1];
-  if (!(lo <= hi) || !(fabsf(lo) < 3.0e38f) || !(fabsf(hi) < 3.0e38f)) { lo = 0.f; hi = 0.f; }     // empty / non-finite hint
-  // buckets 1 .. B-2 span [lo, hi]: key(lo) = 1.5, key(hi) = B - 1.5.  The span is at least 2^-10 of the larger magnitude:
-  // |lo * ks| then stays below 2^20 * B / 1024, so ko's rounding moves a key by < 0.1 bucket — x = lo never slips into
-  // the end bucket — and a constant column (the ones column of pre_process_datasets.py:127) still gets a bucket of its own
-  const float span = fmaxf(hi - lo, fmaxf(fmaxf(fabsf(lo), fabsf(hi)) * 0.0009765625f, 1e-30f));
-  const float ks = static_cast<float>(B - 3) / span;
-  const float ko = __fmaf_rn(-lo, ks, 1.5f);
-  const float top = static_cast<float>(B - 1);
-  for (int i = tid; i < B; i += 256) cnt[i] = 0;
-  __syncthreads();
-  const int base = off[f], pn = off[f + 1] - base - 1;          // breakpoints are entries 1 .. pn (entry 0: anchor of piece 0)
-  for (int j = 1 + tid; j <= pn; j += 256) atomicAdd(&cnt[bucket_of(anchor[base + j], ks, ko, top)], 1);
-  __syncthreads();
-  // exclusive prefix over the B buckets: thread t owns buckets [t * B / 256, (t + 1) * B / 256)
-  constexpr int PER = B / 256 > 0 ? B / 256 : 1;
-  int s = 0;
-  if (tid * PER < B)
-    for (int i = 0; i < PER; ++i) s += cnt[tid * PER + i];
-  part[tid] = s;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int flagged = 0;
-  if (tid * PER < B) {
-    int run = part[tid] - s;
-    for (int i = 0; i < PER; ++i) {
-      const int k = tid * PER + i, c = cnt[k];
-      const int code = c <= 1 ? 0 : (c <= 3 ? 1 : 3);
-      table[static_cast<int64_t>(f) * B + k] = static_cast<uint16_t>(run * 4 | code << 14);
-      if (code == 3 && k > 0 && k < B - 1) ++flagged;
-      run += c;
-    }
-  }
-  if (tid == 0) { key[2 * f] = ks; key[2 * f + 1] = ko; }
-  if (stats) {                                  // searched buckets inside the hinted range: the fast path's health
-    __syncthreads();
-    part[tid] = flagged;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if (tid < st) part[tid] += part[tid + st];
-      __syncthreads();
-    }
-    if (tid == 0) stats[f] = part[0];
-  }
+  const int f = blockIdx.x, base = off[f];
+  gnan_index::build_bucket_index<LOGB>(f, anchor + base, off[f + 1] - base - 1, range, table, key, stats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,7 +387,7 @@ __global__ __launch_bounds__(BS) void fpwl_index_kernel(const IndexParams p) {
 // tree) — the rest bucket's column sum out of this pass instead of a gnan_colsum over the result (gnan_fpwl_args.sum_total).
 __global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict__ part, int n_groups, int64_t n,
                                                          float* __restrict__ out, int64_t out_stride,
-                                                         double* __restrict__ col_partial, int64_t total_rows) {
+                                                         double* col_partial, int64_t total_rows, unsigned* arrive, float* total) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   float s = 0.f;
   if (i < n) {
@@ -457,6 +404,10 @@ __global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict
     __syncthreads();
   }
   if (threadIdx.x == 0) col_partial[blockIdx.x] = red[0];
+  if (arrive != nullptr && gnan::last_block(arrive)) {      // (sum_total_final_kernel's sum, by the last workgroup of this pass)
+    const double s_all = gnan::sum_partials_256(col_partial, static_cast<int64_t>(gridDim.x));
+    if (threadIdx.x == 0) total[0] = static_cast<float>(s_all);
+  }
 }
 
 __global__ __launch_bounds__(256) void sum_total_final_kernel(const double* __restrict__ partial, int64_t n_partial, float* __restrict__ total) {
@@ -648,10 +599,11 @@ int gnan_index_fwd(const gnan_fpwl_args* a, double* col_partial, hipStream_t st)
   if (!pl.split) return rc;
   const int64_t sb = (a->n + 255) / 256;
   double* tot_partial = a->sum_total ? static_cast<double*>(a->sum_total_workspace) : nullptr;      // (checked above)
+  unsigned* arrive = (tot_partial && sb <= gnan::kMaxArriveBlocks) ? reinterpret_cast<unsigned*>(a->sum_total_arrive) : nullptr;
   hipLaunchKernelGGL(sum_groups_kernel, dim3(static_cast<unsigned>(sb)), dim3(256), 0, st, p.part, p.n_groups, p.n,
-                     p.out, p.out_stride, tot_partial, p.total_rows);
+                     p.out, p.out_stride, tot_partial, p.total_rows, arrive, a->sum_total);
   if (int rc2 = gnan::check_launch("sum_groups_kernel")) return rc2;
-  if (tot_partial) {
+  if (tot_partial && arrive == nullptr) {
     hipLaunchKernelGGL(sum_total_final_kernel, dim3(1), dim3(256), 0, st, tot_partial, sb, a->sum_total);
     return gnan::check_launch("sum_total_final_kernel");
   }

@@ -19,6 +19,7 @@
 // Sorting is by ranking (every element counts the elements before it: broadcast LDS reads, one barrier) instead of a bitonic
 // network (21-55 barrier rounds).
 #include "common.hpp"
+#include "fpwl_bucket.hpp"
 
 #include <cmath>
 
@@ -551,8 +552,12 @@ struct CompactParams {
   float* anchor;           // compact [T], capacity F*(cap+1)
   float* val;
   float* slope;
+  const float* index_range;   // optional: the look-up's bucket tables out of this pass (csrc/fpwl_bucket.hpp)
+  uint16_t* index_table;
+  float* index_key;
 };
 
+template <int LOGB>
 __global__ __launch_bounds__(256) void pwl_compact_kernel(const CompactParams p) {
   __shared__ int red[256];
   const int k = blockIdx.x, tid = threadIdx.x;
@@ -587,6 +592,10 @@ __global__ __launch_bounds__(256) void pwl_compact_kernel(const CompactParams p)
     p.val[static_cast<int64_t>(base) * p.C + i] = v[i];
     p.slope[static_cast<int64_t>(base) * p.C + i] = sl[i];
   }
+  if constexpr (LOGB > 0) {            // the feature's bucket table, from its anchors where they lie (index_build_kernel otherwise)
+    __syncthreads();
+    gnan_index::build_bucket_index<LOGB>(k, a, n - 1, p.index_range, p.index_table, p.index_key, nullptr);
+  }
 }
 
 size_t padded_floats(int F, int C, int cap) { return static_cast<size_t>(F) * (cap + 1) * (1 + 2 * static_cast<size_t>(C)); }
@@ -608,6 +617,10 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   GNAN_REQUIRE(a->w_first && a->w_last && a->anchor && a->val && a->slope && a->off && a->overflow && a->scratch,
                "pwl_build: null pointer");
   if (a->L == 3) GNAN_REQUIRE(a->w_mid != nullptr, "pwl_build: L == 3 needs w_mid");
+  GNAN_REQUIRE((a->index_table == nullptr && a->index_key == nullptr && a->index_range == nullptr) ||
+                   (a->index_table && a->index_key && a->index_range &&
+                    (a->index_buckets == 256 || a->index_buckets == 512 || a->index_buckets == 1024 || a->index_buckets == 2048)),
+               "pwl_build: index_range / index_table / index_key go together, index_buckets in {256, 512, 1024, 2048}");
   if (a->scratch_bytes < gnan_pwl_build_scratch_bytes(a->F, a->C, a->cap))
     return gnan::fail(GNAN_ERR_WORKSPACE, "pwl_build: scratch too small");
   BuildParams p;
@@ -641,7 +654,13 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   c.anchor_p = p.anchor; c.val_p = p.val; c.slope_p = p.slope; c.pieces = p.pieces;
   c.F = a->F; c.C = a->C; c.cap = a->cap;
   c.off = a->off; c.overflow = a->overflow; c.anchor = a->anchor; c.val = a->val; c.slope = a->slope;
-  hipLaunchKernelGGL(pwl_compact_kernel, dim3(a->F), dim3(256), 0, st, c);
+  c.index_range = a->index_range; c.index_table = a->index_table; c.index_key = a->index_key;
+  const dim3 grid(a->F), block(256);
+  if (a->index_table == nullptr) hipLaunchKernelGGL(pwl_compact_kernel<0>, grid, block, 0, st, c);
+  else if (a->index_buckets == 256) hipLaunchKernelGGL(pwl_compact_kernel<8>, grid, block, 0, st, c);
+  else if (a->index_buckets == 512) hipLaunchKernelGGL(pwl_compact_kernel<9>, grid, block, 0, st, c);
+  else if (a->index_buckets == 1024) hipLaunchKernelGGL(pwl_compact_kernel<10>, grid, block, 0, st, c);
+  else hipLaunchKernelGGL(pwl_compact_kernel<11>, grid, block, 0, st, c);
   return gnan::check_launch("pwl_compact_kernel");
 }
 

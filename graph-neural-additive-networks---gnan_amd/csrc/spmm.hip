@@ -1974,6 +1974,15 @@ __device__ __forceinline__ void block_sum_to(double v, double* __restrict__ part
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// ... and, with an arrival counter, the last workgroup of the pass adds the partials (pack_q_final_kernel's sum, same order)
+__device__ __forceinline__ void block_sum_finish(double v, double* partial, unsigned* arrive, float* out) {
+  block_sum_to(v, partial);
+  if (arrive != nullptr && gnan::last_block(arrive)) {
+    const double s_all = gnan::sum_partials_256(partial, static_cast<int64_t>(gridDim.x));
+    if (threadIdx.x == 0) out[0] = static_cast<float>(s_all);
+  }
+}
+
 // q_sum[0] = sum of the workgroups' partials (one workgroup, fixed order): sum_i dY_i / cnt(i, rest), what gnan_colsum over the
 // packed rows' second halves returned — two launches and a strided 40-MB read on the 10M-node graph
 __global__ __launch_bounds__(256) void pack_q_final_kernel(const double* __restrict__ partial, int64_t n_partial, float* __restrict__ q_sum) {
@@ -1995,7 +2004,7 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
                                                             const int32_t* __restrict__ cnt, int64_t cnt_stride, int D,
                                                             int64_t n, int with_rest, float* __restrict__ V, int half,
                                                             const int64_t* __restrict__ hot, int64_t n_hot, int64_t o_begin,
-                                                            double* __restrict__ q_partial) {
+                                                            double* q_partial, unsigned* q_arrive, float* q_sum) {
   double qs = 0.0;                                    // q_partial (W == 1): this thread's sum of dY_i / cnt(i, rest) over REAL nodes
   for (int64_t o = o_begin + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < n + n_hot; o += static_cast<int64_t>(gridDim.x) * 256) {
     const int64_t i = o < n ? o : hot[o - n];         // packed rows [n, n + n_hot): second copies of the nodes hot[]
@@ -2022,7 +2031,7 @@ __global__ __launch_bounds__(256) void pack_bwd_rows_kernel(const float* __restr
     }
     if (q_partial && with_rest && o < n) qs += static_cast<double>(dY[i * dy_stride] / r_rest);
   }
-  if (q_partial) block_sum_to(qs, q_partial);
+  if (q_partial) block_sum_finish(qs, q_partial, q_arrive, q_sum);
 }
 
 // One-channel gradients (half == 1: packed rows of two floats) with shell counts and at most four codes — the shape of every
@@ -2033,7 +2042,7 @@ template <int D>
 __global__ __launch_bounds__(256) void pack_bwd_pairs_kernel(const float* __restrict__ dY, const int32_t* __restrict__ cnt,
                                                              int64_t n, int64_t n_pairs, int with_rest, float* __restrict__ V,
                                                              const int64_t* __restrict__ hot, int64_t n_hot, int pair_blocks,
-                                                             double* __restrict__ q_partial) {
+                                                             double* q_partial, unsigned* q_arrive, float* q_sum) {
   const int64_t rows_per_code = n + n_hot;
   double qs = 0.0;
   if (static_cast<int>(blockIdx.x) >= pair_blocks) {
@@ -2053,7 +2062,7 @@ __global__ __launch_bounds__(256) void pack_bwd_pairs_kernel(const float* __rest
             make_float2(g / static_cast<float>(k[d] > 1 ? k[d] : 1), q);
       if (o < n) qs = static_cast<double>(q);
     }
-    if (q_partial) block_sum_to(qs, q_partial);
+    if (q_partial) block_sum_finish(qs, q_partial, q_arrive, q_sum);
     return;
   }
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; t < n_pairs; t += static_cast<int64_t>(pair_blocks) * 256) {
@@ -2076,7 +2085,7 @@ __global__ __launch_bounds__(256) void pack_bwd_pairs_kernel(const float* __rest
       *reinterpret_cast<float4*>(V + (static_cast<int64_t>(d) * rows_per_code + 2 * t) * 2) = make_float4(g.x / r[0][d], q0, g.y / r[1][d], q1);
     qs += static_cast<double>(q0) + static_cast<double>(q1);
   }
-  if (q_partial) block_sum_to(qs, q_partial);
+  if (q_partial) block_sum_finish(qs, q_partial, q_arrive, q_sum);
 }
 }  // namespace
 
@@ -2144,19 +2153,22 @@ extern "C" int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_st
     GNAN_REQUIRE(reinterpret_cast<uintptr_t>(a->q_workspace) % 8 == 0, "pack_bwd_rows: q workspace must be 8-byte aligned");
     q_partial = static_cast<double*>(a->q_workspace);
   }
+  // q_sum by the last workgroup of the packing launch where the caller lends an arrival counter (a fence per workgroup: small grids)
+  unsigned* q_arrive = (q_partial && pg.blocks <= gnan::kMaxArriveBlocks) ? reinterpret_cast<unsigned*>(a->q_arrive) : nullptr;
   if (pg.pairs) {
     const dim3 grid(static_cast<unsigned>(pg.blocks)), block(256);
     const int pbi = static_cast<int>(pg.pair_blocks);
-    if (D == 2) hipLaunchKernelGGL(pack_bwd_pairs_kernel<2>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial);
-    else if (D == 3) hipLaunchKernelGGL(pack_bwd_pairs_kernel<3>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial);
-    else hipLaunchKernelGGL(pack_bwd_pairs_kernel<4>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial);
+    if (D == 2) hipLaunchKernelGGL(pack_bwd_pairs_kernel<2>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial, q_arrive, a->q_sum);
+    else if (D == 3) hipLaunchKernelGGL(pack_bwd_pairs_kernel<3>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial, q_arrive, a->q_sum);
+    else hipLaunchKernelGGL(pack_bwd_pairs_kernel<4>, grid, block, 0, st, dY, cnt, n, pg.n_pairs, with_rest, V, hot, n_hot, pbi, q_partial, q_arrive, a->q_sum);
     if (int rc = gnan::check_launch("pack_bwd_pairs_kernel")) return rc;
   } else {
     hipLaunchKernelGGL(pack_bwd_rows_kernel, dim3(static_cast<unsigned>(pg.blocks)), dim3(256), 0, st,
-                       dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot, static_cast<int64_t>(0), q_partial);
+                       dY, dy_stride, W, cnt, cnt_stride, D, n, with_rest, V, half, hot, n_hot, static_cast<int64_t>(0), q_partial,
+                       q_arrive, a->q_sum);
     if (int rc = gnan::check_launch("pack_bwd_rows_kernel")) return rc;
   }
-  if (q_partial) {
+  if (q_partial && q_arrive == nullptr) {
     hipLaunchKernelGGL(pack_q_final_kernel, dim3(1), dim3(256), 0, st, q_partial, pg.blocks, a->q_sum);
     return gnan::check_launch("pack_q_final_kernel");
   }

@@ -231,7 +231,8 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
                       max_group_pieces=t.max_group_pieces, sum_features=int(sum_features),
                       out=_lib.ptr(out), out_stride=out.stride(0),
                       out_dtype=_lib.GNAN_BF16 if out_dtype == torch.bfloat16 else _lib.GNAN_F32, flags=_fpwl_flags())
-    if index is not None and a.C == 1 and t.features_per_group == 16 and F % 16 == 0:
+    if (index is not None and a.C == 1 and t.features_per_group == 16 and F % 16 == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and t.max_pieces <= 4096):
         # direct-index tables built ahead of time for THESE tables (TablePrefetch(x_range=...): on the side stream)
         a.index_table, a.index_key, a.index_buckets = _lib.ptr(index[0]), _lib.ptr(index[1]), int(index[0].shape[1])
     else:
@@ -250,6 +251,7 @@ def _fpwl_launch(x: torch.Tensor, t, sum_features: bool, want_total: bool = Fals
         total = torch.empty(1, dtype=torch.float32, device=x.device)
         tot_ws = torch.empty((n + 255) // 256, dtype=torch.float64, device=x.device)     # (alive until the look-up is queued)
         a.sum_total, a.sum_total_workspace, a.sum_total_workspace_bytes = _lib.ptr(total), _lib.ptr(tot_ws), tot_ws.numel() * 8
+        a.sum_total_arrive = _lib.ptr(arrive_counter(x.device, 1))
         a.total_rows = n if total_rows is None else int(total_rows)
     fpg = t.features_per_group
     if (want_total and not sum_features and C == 1 and fpg % 4 == 0 and F % fpg == 0 and x.stride(0) % 4 == 0
@@ -284,6 +286,29 @@ CAPTURE_PINS = None           # list while graphed.GraphedCallable captures: cac
 CAPTURE_GUARD = None          # float32 [1] while a guarded step is captured: set to 1 by a look-up whose tables outgrew its sizes
 CAPTURE_SCRATCH = None        # int32 [64K], ZEROED EAGERLY by graphed.GraphedCallable before its capture and owned by that step:
                               # workspaces whose invariant is "zero between launches" (the small-graph kernel's arrival counter)
+
+
+ARRIVE_COUNTERS = True        # lend the passes that end in a sum over their workgroups an arrival counter (include/gnan_hip.h):
+                              # the last workgroup takes the sum, one launch less per pass
+ARRIVE_SLOTS = 64             # counters at the END of the zeroed scratch: slot 0 moment scales, 1 group-sum total, 2 packed rows' q
+_ARRIVE_POOL = {}             # (device index, stream handle) -> zeroed int32 [ARRIVE_SLOTS]: eager launches of one stream take turns
+
+
+def arrive_counter(dev, slot: int):
+    """Four bytes that are zero between launches (``gnan::last_block`` leaves them zero), or None where nobody guarantees that:
+    a capture that is not the framework's own (``graphed.GraphedCallable`` zeroes its scratch eagerly and owns it)."""
+    if not ARRIVE_COUNTERS:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        ws = CAPTURE_SCRATCH
+        if ws is None or ws.device != dev:
+            return None
+        return ws[ws.numel() - ARRIVE_SLOTS + slot:]
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ARRIVE_POOL.get(key)
+    if buf is None:
+        buf = _ARRIVE_POOL[key] = torch.zeros(ARRIVE_SLOTS, dtype=torch.int32, device=dev)
+    return buf[slot:]
 
 
 def _pin_for_capture(obj):
@@ -340,7 +365,8 @@ def _fpwl_moments(x: torch.Tensor, t, grad: torch.Tensor, sum_features: bool,
         sa = _lib.MomentScalesArgs(grad=_lib.ptr(grad), n=n, width=grad.shape[1], bits=bits, grad_stride=grad.stride(0),
                                    anchor=_lib.ptr(t.anchor), T=T, n_anchors=_lib.ptr(t.off[F:]), x_abs_max=_lib.ptr(x_abs_max),
                                    workspace=_lib.ptr(scales[2:]), workspace_bytes=_lib.MOMENT_SCALES_WORKSPACE_BYTES,
-                                   scales=_lib.ptr(scales), zero=_lib.ptr(Mi), zero_bytes=Mi.numel() * 8)
+                                   scales=_lib.ptr(scales), zero=_lib.ptr(Mi), zero_bytes=Mi.numel() * 8,
+                                   arrive_counter=_lib.ptr(arrive_counter(x.device, 0)))
         _lib.check(_lib.lib().gnan_fpwl_moment_scales(sa, _lib.stream_of(x)), "gnan_fpwl_moment_scales")
         scales = scales[:2]
         if located and len(located) == 1 and not rows:          # one channel: the forward's pieces, one byte per look-up
@@ -377,13 +403,14 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
         stacked = StackedMLP(*[_c(t) for t in p[:6]], *p[6:])
 
         x_range = _feature_range(x) if p.C == 1 else None
-        index = getattr(prebuilt, "index", None) if prebuilt is not None else None
+        built = [getattr(prebuilt, "index", None) if prebuilt is not None else None]      # direct-index tables made with the tables
+        request = None if x_range is None else (x_range, INDEX_BUCKETS)
 
         def look_up(t):
             return _fpwl_launch(x, t, sum_features, want_total=True, out_dtype=out_dtype, total_rows=total_rows,
-                                located=located, x_range=x_range, index=index) \
+                                located=located, x_range=x_range, index=built[0]) \
                 if want_total else (_fpwl_launch(x, t, sum_features, out_dtype=out_dtype, located=located,
-                                                 x_range=x_range, index=index), None)
+                                                 x_range=x_range, index=built[0]), None)
 
         if prebuilt is not None and torch.cuda.is_current_stream_capturing():
             # a captured inference step (distributed.SharePipeline): the tables sit in caller-owned buffers the PREVIOUS
@@ -422,7 +449,8 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
             # hipGraph capture (gnan_amd/graphed.py): no device->host copy may happen here, so the look-up is sized like
             # the speculative one — from the piece counts of the LAST eager forward, with room — and whoever replays the
             # graph checks before every replay that the tables of the current weights still fit (CAPTURED_BUILDS)
-            pending = build_tables_lazy(stacked)
+            pending = build_tables_lazy(stacked, index_request=request)
+            built[0] = pending.index
             guess = pending.speculative()
             if guess is None:
                 raise _lib.GnanHipError("graph capture needs one eager forward of this model first (table sizes unknown)")
@@ -440,7 +468,8 @@ def _fmlp_forward(x: torch.Tensor, p: "StackedMLP", sum_features: bool, want_tot
             # look-up during which the GPU idles (60-70 us: 1 % of the C4 forward, 6 % of a 1/8 share).  The look-up is
             # queued right behind the build with the sizes of the LAST forward plus some room; the counts are read
             # afterwards (they arrived long before) and the look-up is queued again in the rare case they outgrew the guess.
-            pending = build_tables_lazy(stacked)
+            pending = build_tables_lazy(stacked, index_request=request)
+            built[0] = pending.index
             guess = pending.speculative()
             res = None
             if guess is not None:
@@ -511,10 +540,13 @@ class TablePrefetch:
         self.side.wait_stream(main)               # the weights (and the allocator's reuse of freed blocks) are ordered
         self.slot = 1 + (getattr(self, "slot", 1) % 2)          # two builds can be in flight: alternate read-back buffers
         with torch.cuda.stream(self.side):
-            pending = build_tables_lazy(self.stacked, pinned_slot=self.slot, buffers=buffers)
+            request = None
+            if x_range is not None and index_buffers is not None:
+                request = (x_range, int(index_buffers[0].shape[1]), index_buffers)
+            pending = build_tables_lazy(self.stacked, pinned_slot=self.slot, buffers=buffers, index_request=request)
             F = self.stacked.F
-            if x_range is not None and index_buffers is not None and self.stacked.C == 1 and F % 16 == 0:
-                table, key = index_buffers
+            if request is not None and pending.index is None and self.stacked.C == 1 and F % 16 == 0:
+                table, key = index_buffers                   # (pwl.INDEX_IN_BUILD off: the builder's own launch)
                 ia = _lib.FpwlIndexArgs(off=_lib.ptr(pending.meta), anchor=_lib.ptr(pending.anchor), F=F,
                                         buckets=int(table.shape[1]), range=_lib.ptr(x_range), table=_lib.ptr(table),
                                         key=_lib.ptr(key), stats=None)

@@ -292,7 +292,10 @@ def table_buffers(p):
             torch.empty(need // 8 + 1, dtype=torch.float64, device=dev))
 
 
-def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0, buffers=None):
+INDEX_IN_BUILD = True        # the look-up's direct-index tables out of the build's compaction pass (gnan_pwl_build_args.index_*)
+
+
+def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0, buffers=None, index_request=None):
     """Tables by TWO kernel launches (``gnan_pwl_build``: a workgroup per feature finds the kinks and tabulates the
     network in float64, LDS-resident; a second tiny kernel packs the features back to back) and one
     device->host copy of the F+1 offsets.  Covers L in {2, 3}, H <= 128; same result as :func:`_build_padded`."""
@@ -311,17 +314,30 @@ def _build_tables_hip(p, lazy: bool = False, pinned_slot: int = 0, buffers=None)
                           F=F, L=p.L, H=p.H, C=C, cap=cap, anchor=_lib.ptr(anchor), val=_lib.ptr(val),
                           slope=_lib.ptr(slope), off=_lib.ptr(meta), overflow=meta[F + 1:].data_ptr(),
                           scratch=_lib.ptr(scratch), scratch_bytes=scratch.numel() * 8)
+    index = None
+    if index_request is not None and INDEX_IN_BUILD:
+        # (x_range [F, 2], buckets[, (table, key) caller-owned]): one launch less than gnan_fpwl_index_build behind the build
+        x_range, buckets = index_request[0], int(index_request[1])
+        if x_range is not None and C == 1 and F % 16 == 0 and tuple(x_range.shape) == (F, 2) and x_range.dtype == torch.float32 and x_range.is_contiguous():
+            index = index_request[2] if len(index_request) > 2 and index_request[2] is not None else (
+                torch.empty((F, buckets), dtype=torch.int16, device=dev), torch.empty((F, 2), dtype=torch.float32, device=dev))
+            a.index_range, a.index_table, a.index_key, a.index_buckets = (_lib.ptr(x_range), _lib.ptr(index[0]), _lib.ptr(index[1]),
+                                                                          buckets)
+            keepalive.append(x_range)
     _lib.check(_lib.lib().gnan_pwl_build(a, _lib.stream_of(anchor)), "gnan_pwl_build")
     if torch.cuda.is_current_stream_capturing():
         # inside a hipGraph capture nothing may wait for the device: no read-back.  Whoever replays the graph checks
         # BEFORE each replay (an eager build of the same weights) that the tables still fit the captured look-up
-        return _PendingTables(meta, None, None, anchor, val, slope, F, C, (dev, F, p.L, p.H, C), keepalive + [scratch])
+        pending = _PendingTables(meta, None, None, anchor, val, slope, F, C, (dev, F, p.L, p.H, C), keepalive + [scratch])
+        pending.index = index
+        return pending
     # the ONE device->host copy of the build: into a cached pinned buffer, asynchronously; an event marks its arrival
     pinned = _pinned_meta(dev, F + 2, pinned_slot)      # builds in flight at the same time (TablePrefetch) use their own slots
     pinned.copy_(meta, non_blocking=True)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(dev))
     pending = _PendingTables(meta, pinned, done, anchor, val, slope, F, C, (dev, F, p.L, p.H, C), keepalive + [scratch])
+    pending.index = index
     return pending if lazy else pending.resolve()
 
 
@@ -400,9 +416,11 @@ def hip_build_applies(p) -> bool:
 
 
 @torch.no_grad()
-def build_tables_lazy(p, pinned_slot: int = 0, buffers=None):
-    """Queue the table build and return a :class:`_PendingTables` (kernel route only; check :func:`hip_build_applies`)."""
-    return _build_tables_hip(p, lazy=True, pinned_slot=pinned_slot, buffers=buffers)
+def build_tables_lazy(p, pinned_slot: int = 0, buffers=None, index_request=None):
+    """Queue the table build and return a :class:`_PendingTables` (kernel route only; check :func:`hip_build_applies`).
+    ``index_request = (x_range [F, 2], buckets[, (table, key)])``: the look-up's direct-index tables come out of the same launches
+    (``pending.index``; None where they do not apply)."""
+    return _build_tables_hip(p, lazy=True, pinned_slot=pinned_slot, buffers=buffers, index_request=index_request)
 
 
 @torch.no_grad()

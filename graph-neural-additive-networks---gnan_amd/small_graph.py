@@ -71,7 +71,7 @@ class _SmallGraph(torch.autograd.Function):
             # runs on the framework's one capture stream, so a buffer keyed by stream would be shared by all captured steps,
             # and one allocated inside a capture would have its zero fill recorded, never run
             ws = Fn.CAPTURE_SCRATCH
-            if ws is None or ws.numel() * 4 < need:
+            if ws is None or (ws.numel() - Fn.ARRIVE_SLOTS) * 4 < need:      # (its last words are arrival counters)
                 ws = torch.zeros(need // 4 + 1, dtype=torch.int32, device=dev)     # (recorded fill: runs at every replay)
         else:
             key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
@@ -167,7 +167,7 @@ def _workspace(dev, need: int) -> torch.Tensor:
     step's own (see ``_SmallGraph.forward``)."""
     if torch.cuda.is_current_stream_capturing():
         ws = Fn.CAPTURE_SCRATCH
-        if ws is None or ws.numel() * 4 < need:
+        if ws is None or (ws.numel() - Fn.ARRIVE_SLOTS) * 4 < need:      # (its last words are arrival counters)
             ws = torch.zeros(need // 4 + 1, dtype=torch.int32, device=dev)
         return ws
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)

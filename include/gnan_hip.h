@@ -186,6 +186,7 @@ typedef struct gnan_fpwl_args {
   void* sum_total_workspace;   /* C == 1): sum_total[0] = sum of out over rows [0, total_rows) out of the group-sum pass (float64 per  */
   size_t sum_total_workspace_bytes; /* workgroup, fixed order) — the rest bucket's operand without a gnan_colsum over the result;   */
                                /* workspace: ceil(n / 256) * 8 bytes, 8-byte aligned                                              */
+  uint32_t* sum_total_arrive;  /* optional arrival counter (see gnan_moment_scales_args): sum_total out of the group-sum launch      */
 } gnan_fpwl_args;
 
 /* gnan_fpwl_args.flags (the library reads no environment variables: switches are the caller's, passed per call) */
@@ -274,6 +275,10 @@ int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32_t* piece, 
  * gnan_fpwl_moments_fixed adds into (a separate fill launch otherwise).  One pass over grad + a one-workgroup kernel; no
  * host round trip. */
 #define GNAN_MOMENT_SCALES_WORKSPACE_BYTES 8192
+/* Arrival counters (ABI 45): several passes end in a sum over their workgroups' partial results.  With an `*_arrive` counter — 4 bytes
+ * of device memory that are ZERO before the first launch that uses them; the pass leaves them zero — the last workgroup to finish
+ * takes that sum itself, bit-identical to the second launch it saves (5 us of a 0.24-ms step); NULL keeps the two launches.  A
+ * counter serves one pass at a time (launches on one stream may share it).  Passes of more than a few thousand workgroups ignore it. */
 typedef struct gnan_moment_scales_args {
   const float* grad;         /* [n, width], row stride grad_stride */
   int64_t n;
@@ -289,6 +294,7 @@ typedef struct gnan_moment_scales_args {
   double* scales;            /* [2] out */
   void* zero;                /* optional: zero_bytes bytes (8-byte aligned, a multiple of 8) set to zero by the same pass */
   size_t zero_bytes;
+  uint32_t* arrive_counter;  /* optional arrival counter (see above): the scales out of the one launch */
 } gnan_moment_scales_args;
 int gnan_fpwl_moment_scales(const gnan_moment_scales_args* a, gnan_stream_t stream);
 
@@ -345,6 +351,12 @@ typedef struct gnan_pwl_build_args {
   int32_t* overflow;      /* [1]: written 0 / 1 by every build (nothing to initialise) */
   void* scratch;          /* gnan_pwl_build_scratch_bytes(F, C, cap) */
   size_t scratch_bytes;
+  /* optional (ABI 45), all four or none: the direct-index tables of the look-up (gnan_fpwl_index_build) out of the build's own
+   * compaction pass — one launch less per forward.  Same tables, bit for bit. */
+  const float* index_range;  /* [F, 2] value range of every feature (gnan_feature_range) */
+  uint16_t* index_table;     /* out [F, index_buckets] */
+  float* index_key;          /* out [F, 2] */
+  int32_t index_buckets;     /* 256, 512, 1024 or 2048 */
 } gnan_pwl_build_args;
 
 size_t gnan_pwl_build_scratch_bytes(int32_t F, int32_t C, int32_t cap);
@@ -1094,6 +1106,7 @@ typedef struct gnan_pack_bwd_rows_args {
                                 same pass (float64 per workgroup, fixed order) instead of a gnan_colsum over the strided halves */
   void* q_workspace;         /* with q_sum: gnan_spmm_pack_bwd_rows_workspace_bytes(a) bytes, 8-byte aligned */
   size_t q_workspace_bytes;
+  uint32_t* q_arrive;        /* optional arrival counter (see gnan_moment_scales_args): q_sum out of the packing launch */
 } gnan_pack_bwd_rows_args;
 size_t gnan_spmm_pack_bwd_rows_workspace_bytes(const gnan_pack_bwd_rows_args* a);
 int gnan_spmm_pack_bwd_rows(const gnan_pack_bwd_rows_args* a, gnan_stream_t stream);

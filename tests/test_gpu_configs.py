@@ -282,3 +282,51 @@ def test_more_than_2_31_listed_pairs(monkeypatch):
         del S, out, sub
     del g, col, code
     torch.cuda.empty_cache()
+
+
+def test_c3_passes_that_finish_their_own_sums_equal_the_two_launch_routes(monkeypatch):
+    """Round 6: with an arrival counter the last workgroup of a pass takes the sum over the workgroups' partial results (moment
+    scales, the group-sum's column total, the packed rows' q), and the look-up's bucket tables come out of the table build's
+    compaction pass.  Same bits as the extra launches they replace — outputs and every gradient, eagerly and replayed from the
+    captured step (counters in the step's zeroed scratch)."""
+    import gnan_amd  # noqa: F401
+    from gnan_amd import functional as Fn, models, pwl
+    from gnan_amd import synthetic as syn
+    N, E, F, H, L = 169_343, 1_166_243, 129, 64, 3
+    src, dst = syn.preferential_attachment_edges(N, E, seed=0, device=DEV)
+    g = syn.hop1_csr(src, dst, N)
+    x = syn.block_features(N, F, 0, N, seed=1, device=DEV)
+    target = torch.randn(N, 1, generator=torch.Generator().manual_seed(2)).to(DEV)
+    data = Bag(x=x, edge_index=None, gnan_graph=g)
+
+    def run(fused, steps):
+        monkeypatch.setattr(Fn, "ARRIVE_COUNTERS", fused)
+        monkeypatch.setattr(pwl, "INDEX_IN_BUILD", fused)
+        torch.manual_seed(0)
+        mod = models.TensorGNAN(F, 1, L, hidden_channels=H, device=DEV)
+        gen = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for _, p in mod.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=gen) * (0.5 if p.dim() == 1 else (2.0 / sum(p.shape)) ** 0.5))
+        mod = mod.to(DEV).train()
+        outs, launches = [], []
+        for _ in range(steps):                                  # the third call on the same inputs is a replay (gnan_amd/replay.py)
+            mod.zero_grad(set_to_none=True)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                y = mod.forward(data)
+                ((y - target) ** 2).mean().backward()
+                torch.cuda.synchronize()
+            launches.append(sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name
+                                and "Memset" not in e.name))
+            outs.append((y.detach().clone(), {k: v.clone() for k, v in module_grads(mod).items()}))
+        return outs, launches
+
+    fused, n_fused = run(True, 4)
+    plain, n_plain = run(False, 4)
+    for (ya, ga), (yb, gb) in zip(fused, plain):
+        assert torch.equal(ya, yb)
+        assert ga.keys() == gb.keys() and all(torch.equal(ga[k], gb[k]) for k in ga), [k for k in ga if not torch.equal(ga[k], gb[k])]
+    # an eager step; a replayed one.  (At this size only the scales and the bucket tables lose their launch: a pass of 662
+    # workgroups keeps its second launch — an agent-scope fence per workgroup cost 13 us against the 5 it saves; the group-sum
+    # total and the packed rows' q use their counters below 128 workgroups, e.g. on Cora-sized graphs.)
+    assert n_plain[1] - n_fused[1] >= 2 and n_plain[3] - n_fused[3] >= 2, (n_plain, n_fused)

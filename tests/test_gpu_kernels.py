@@ -1982,11 +1982,16 @@ def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets,
     """csrc/fpwl_index.hip finds the piece of a value by arithmetic on a per-feature grid over the data's range plus
     comparisons inside the cell; it must give the bits of the tree-search kernel (same piece, same formula) for ANY
     input — on kinks, outside the hinted range, non-finite — and for a range hint that is wrong."""
-    from gnan_amd import _lib, functional
+    from gnan_amd import _lib, functional, pwl
     from gnan_amd.functional import feature_mlps
     monkeypatch.setattr(functional, "FMLP_ALGO", _lib.FMLP_PWL)
     monkeypatch.setattr(functional, "INDEX_BUCKETS", buckets)
     monkeypatch.setattr(functional, "INDEX_FLAGS", flags)       # 0: 32-feature groups (full lines); 8 / 16: 512 / 1024 threads; 4: 16-feature groups
+    # the bucket tables by their own launch where the test counts them (`built`); out of the table build's compaction pass (round 6,
+    # the default) for the 16-feature groups — same tables (test_bucket_tables_out_of_the_table_build_...), and the look-up must
+    # be handed them either way
+    in_build = flags == 4
+    monkeypatch.setattr(pwl, "INDEX_IN_BUILD", in_build)
     n, F, L, H = 70_001, 32, 3, 24
     sd = _on_kink_state(F, L, H, 1, "exact", seed=3) if kind in ("levels", "one_hot") else _mlp_state(F, L, H, 1, True, seed=3)
     st = _stack(sd, F, L, H, 1, True)
@@ -2009,8 +2014,15 @@ def test_direct_index_lookup_is_the_tree_search_bit_for_bit(kind, mode, buckets,
     want, want_total = run(False)
     assert built and all(b is None for b in built)
     del built[:]
+    handed = []
+    real_launch = functional._fpwl_launch
+    monkeypatch.setattr(functional, "_fpwl_launch", lambda *a, **k: handed.append(k.get("index")) or real_launch(*a, **k))
     got, got_total = run(True)
-    assert built and built[-1] is not None          # the direct-index tables were built and handed to the look-up
+    monkeypatch.setattr(functional, "_fpwl_launch", real_launch)
+    if in_build:
+        assert not built and handed and handed[-1] is not None      # made by the build, handed to the look-up
+    else:
+        assert built and built[-1] is not None      # the direct-index tables were built and handed to the look-up
     def same(a, b):         # bit for bit; a NaN matches a NaN (its sign follows the order of the operands of a sum)
         a, b = a.float(), b.float()
         na, nb_ = torch.isnan(a), torch.isnan(b)
@@ -2305,3 +2317,73 @@ def test_transposed_adjacency_by_the_library_equals_the_framework_route(idx_dtyp
     assert (a.n_rows, a.n_cols) == (b.n_rows, b.n_cols) == (n + 9, n)
     assert a.rowptr.dtype == b.rowptr.dtype and torch.equal(a.rowptr, b.rowptr)
     assert torch.equal(a.col, b.col) and torch.equal(a.code, b.code) and a._cnt_by_col and b._cnt_by_col
+
+
+@pytest.mark.parametrize("F,H,buckets", [(16, 8, 256), (64, 64, 512), (32, 33, 1024)])
+def test_bucket_tables_out_of_the_table_build_equal_the_builder_launch(F, H, buckets, monkeypatch):
+    """gnan_pwl_build with index_range / index_table / index_key == gnan_pwl_build + gnan_fpwl_index_build: tables, keys and the
+    look-up that reads them, bit for bit."""
+    from gnan_amd import _lib, functional as Fn, pwl
+    sd = _mlp_state(F, 3, H, 1, True, seed=F + H)
+    st = _stack(sd, F, 3, H, 1, True)
+    x = (torch.rand(4096, F, generator=torch.Generator().manual_seed(3)) * 4 - 2).to(DEV)
+    x_range = torch.stack([x.min(0).values, x.max(0).values], 1).contiguous()
+    monkeypatch.setattr(Fn, "INDEX_BUCKETS", buckets)
+    got = []
+    for fused in (True, False):
+        monkeypatch.setattr(pwl, "INDEX_IN_BUILD", fused)
+        pending = pwl.build_tables_lazy(st, index_request=(x_range, buckets))
+        assert (pending.index is not None) == fused
+        t = pending.resolve()
+        index = pending.index
+        if index is None:
+            a = _lib.FpwlArgs(C=1)
+            a_keep = Fn._fpwl_index(a, x, t, x_range)
+            assert a_keep is not None
+            index = tuple(a_keep)
+        out = Fn._fpwl_launch(x, t, True, x_range=x_range, index=index)
+        got.append((index[0].clone(), index[1].clone(), out.clone()))
+    for a, b in zip(*got):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [300, 20_000])
+def test_small_passes_take_their_sums_by_the_last_workgroup(n, monkeypatch):
+    """Below 128 workgroups the group-sum total and the packed rows' q come out of the pass's own launch (arrival counters,
+    include/gnan_hip.h): the same bits as the second launch, forward and backward, three steps in a row (the counters return to zero)."""
+    from gnan_amd import functional as Fn, models
+    F, H = 48, 16
+    rng = np.random.default_rng(n)
+    rowptr, col, code = _random_csr(n, n, 1, rng)
+    g = _graph(rowptr, col, code, n, 3)
+    x = torch.rand(n, F, generator=torch.Generator().manual_seed(1)).to(DEV)
+    target = torch.randn(n, 1, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    class Bag:
+        pass
+    data = Bag()
+    data.x, data.edge_index, data.gnan_graph = x, None, g
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(Fn, "ARRIVE_COUNTERS", fused)
+        monkeypatch.setattr(Fn, "FMLP_ALGO", _lib_mod().FMLP_PWL)
+        torch.manual_seed(0)
+        mod = models.TensorGNAN(F, 1, 3, hidden_channels=H, device=DEV)
+        with torch.no_grad():
+            for _, p in mod.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(3)) * 0.3)
+        mod = mod.to(DEV).train()
+        steps = []
+        for _ in range(3):
+            mod.zero_grad(set_to_none=True)
+            y = mod.forward(data)
+            ((y - target) ** 2).mean().backward()
+            steps.append((y.detach().clone(), [p.grad.clone() for p in mod.parameters() if p.grad is not None]))
+        res.append(steps)
+    for (ya, ga), (yb, gb) in zip(*res):
+        assert torch.equal(ya, yb) and len(ga) == len(gb) and all(torch.equal(a, b) for a, b in zip(ga, gb))
+
+
+def _lib_mod():
+    from gnan_amd import _lib
+    return _lib
