@@ -173,6 +173,16 @@ class SpmmPbArgs(C.Structure):
         ("bin_row_ptr", C.c_void_p), ("slot_ptr", C.c_void_p), ("n_acc", C.c_int32), ("code_base", C.c_int32),
         ("self_col", C.c_void_p), ("headroom_bits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("flags", C.c_int32), ("self_is_row", C.c_int32),
+        ("shell_out", C.c_void_p), ("S_self", C.c_void_p), ("out_add", C.c_void_p), ("out_add_scale", C.c_void_p),
+    ]
+
+
+class PbPack1Args(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("dY", C.c_void_p), ("dy_stride", C.c_int64), ("cnt", C.c_void_p), ("cnt_stride", C.c_int64),
+        ("D", C.c_int32), ("d1", C.c_int32), ("with_rest", C.c_int32), ("self_is_row", C.c_int32), ("self_col", C.c_void_p),
+        ("lut", C.c_void_p), ("S", C.c_void_p), ("shell", C.c_void_p), ("s_total", C.c_void_p), ("c", C.c_void_p), ("e", C.c_void_p),
+        ("q", C.c_void_p), ("dlut", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -393,6 +403,8 @@ SYMBOLS = {
     "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
     "gnan_spmm_pb_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbBwdArgs)]),
     "gnan_spmm_pb_bwd": (C.c_int, [C.POINTER(SpmmPbBwdArgs), C.c_void_p]),
+    "gnan_spmm_pb_pack1_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnan_spmm_pb_pack1": (C.c_int, [C.POINTER(PbPack1Args), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_spmm_lut_grad_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmLutGradArgs)]),
     "gnan_spmm_lut_grad": (C.c_int, [C.POINTER(SpmmLutGradArgs), C.c_void_p]),

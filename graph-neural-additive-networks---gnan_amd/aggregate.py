@@ -97,7 +97,8 @@ def append_hot_rows(S: torch.Tensor, hot: torch.Tensor, group: int = 1, room: Op
 def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_cnt: bool, with_rest: bool,
                 row_ids: Optional[torch.Tensor] = None, weight_by_col: bool = False,
                 minus_rest: bool = False, s_total: Optional[torch.Tensor] = None, reduce_cr: int = 0,
-                s_by_code: bool = False, lut_of_counts=None, lut_channels: int = 1, room=None) -> torch.Tensor:
+                s_by_code: bool = False, lut_of_counts=None, lut_channels: int = 1, room=None,
+                keep_shell: Optional[list] = None) -> torch.Tensor:
     """One ``gnan_spmm_fwd`` call (no autograd).  ``lut`` is ``[D, Cw]`` or ``[n_adj_rows, D, Cw]``.
     ``reduce_cr`` in FUSABLE_READOUT returns ``[n, reduce_cr]`` = per-channel sums over the operand columns.
     ``s_by_code``: ``S`` is ``[n_cols * D, W]`` and the pair with neighbour ``c`` and hop code ``d`` reads row ``c*D + d``.
@@ -140,7 +141,12 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
         # (csrc/spmm_pb.hip; 10M-node R-MAT, W = 1: 0.87 ms of spmm_hot_kernel -> see DESIGN.md section 4.1c)
         pb = g.pb_plan(S.shape[1])
         if pb is not None:
-            return pb_launch(g, pb, S, lut, use_cnt, s_total, out)
+            shell = None
+            if keep_shell is not None and S.shape[1] == 1 and pb.n_acc == 1:
+                # a training forward keeps the rows' raw shell sums (4 bytes per row): its backward then needs no second column
+                shell = torch.empty(g.n_rows, dtype=torch.float32, device=S.device)
+                keep_shell.append(shell)
+            return pb_launch(g, pb, S, lut, use_cnt, s_total, out, shell_out=shell)
     if g.is_dense:
         # one lane group per row fills the chip only with >~ 16k rows; below that every row is sliced over workgroups
         plan = g.dense_slice_plan(n_out) if (n_out < DENSE_SLICE_MAX_ROWS and g.n_cols >= DENSE_SLICE_MIN_COLS) else None
@@ -190,8 +196,11 @@ PB_MAX_NNZ = 1 << 29        # above, building the bucketed copy (a sort of the p
 
 
 def pb_launch(g: HopGraph, pb, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool, s_total: Optional[torch.Tensor],
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One ``gnan_spmm_pb_fwd`` call over the bucketed copy ``pb = g.pb_plan(W)``: ``[n_rows, W]``, every row, global table."""
+              out: Optional[torch.Tensor] = None, shell_out: Optional[torch.Tensor] = None, S_self: Optional[torch.Tensor] = None,
+              out_add=None) -> torch.Tensor:
+    """One ``gnan_spmm_pb_fwd`` call over the bucketed copy ``pb = g.pb_plan(W)``: ``[n_rows, W]``, every row, global table.
+    ``shell_out [n_rows]`` (W == 1): the rows' raw sums of the accumulated hop code, kept for the backward; ``S_self``: the self
+    pairs' operand where it is not ``S``; ``out_add = (value [1], scale [1])``: their product is added to every row."""
     _lib.require_device(S, lut, pb.src)
     W = S.shape[1]
     if S.stride(0) != W or S.stride(1) != 1:
@@ -207,11 +216,67 @@ def pb_launch(g: HopGraph, pb, S: torch.Tensor, lut: torch.Tensor, use_cnt: bool
                         bin_order=_lib.ptr(pb.bin_order), bin_entry_ptr=_lib.ptr(pb.bin_entry_ptr),
                         bin_row_ptr=_lib.ptr(pb.bin_row_ptr), slot_ptr=_lib.ptr(pb.slot_ptr), n_acc=pb.n_acc,
                         code_base=pb.code_base, self_col=_lib.ptr(pb.self_col), headroom_bits=pb.headroom_bits, flags=PB_FLAGS, self_is_row=int(pb.self_is_row))
+    if shell_out is not None:
+        a.shell_out = _lib.ptr(shell_out)
+    if S_self is not None:
+        a.S_self = _lib.ptr(S_self)
+    if out_add is not None:
+        a.out_add, a.out_add_scale = _lib.ptr(out_add[0]), _lib.ptr(out_add[1])
     need = _lib.lib().gnan_spmm_pb_workspace_bytes(a)
     ws = torch.empty((need + 15) // 16 * 4, dtype=torch.float32, device=S.device)       # (the caching allocator aligns to 512 B)
     a.workspace, a.workspace_bytes = _lib.ptr(ws), ws.numel() * 4
     _lib.check(_lib.lib().gnan_spmm_pb_fwd(a, _lib.stream_of(S)), "gnan_spmm_pb_fwd")
     return out
+
+
+PB_BACKWARD_ONE_COLUMN = True   # the one-column backward from the forward's kept shell sums: no second column through the buckets
+
+
+def pb_bwd1_applies(g: HopGraph, W: int, D: int, with_rest: bool, add_to_rows: bool, shell):
+    """``(forward plan, transposed W = 1 plan)`` when the one-column backward can run WITHOUT the packed second column
+    (``gnan_spmm_pb_pack1`` + ``gnan_spmm_pb_fwd`` over the transposed adjacency), else None."""
+    if not (PB_NARROW and PB_BACKWARD and PB_BACKWARD_ONE_COLUMN and shell is not None and W == 1 and not g.is_dense and D <= 4
+            and PB_MIN_NNZ <= g.nnz <= PB_MAX_NNZ and (add_to_rows or not with_rest)):
+        return None
+    fwd = g.pb_plan(1)
+    if fwd is None or fwd.n_acc != 1 or fwd.code_base < 1:
+        return None
+    pbt = g.transposed().pb_plan(1)
+    if pbt is None or pbt.n_acc != 1 or pbt.code_base != fwd.code_base:
+        return None
+    return fwd, pbt
+
+
+def pb_bwd1_launch(g: HopGraph, plans, dY: torch.Tensor, S: torch.Tensor, shell: torch.Tensor, lut: torch.Tensor, use_cnt: bool,
+                   with_rest: bool, s_total: Optional[torch.Tensor]):
+    """``(dS [n_cols, 1], dlut [D])`` of the one-column aggregation: one pass over the ROWS (``gnan_spmm_pb_pack1``: c, e, q and
+    the whole table gradient from the kept shell sums), then the forward's two phases over the transposed adjacency with ``c``
+    as the operand."""
+    fwd, pbt = plans
+    _lib.require_device(dY, S, shell, lut)
+    n, dev = g.n_rows, dY.device
+    D = int(lut.numel())
+    dY = Fn._rows(dY.detach().float())
+    S = S.detach().float().contiguous()
+    lut = lut.detach().float().reshape(-1).contiguous()
+    c = torch.empty(n, dtype=torch.float32, device=dev)
+    e = torch.empty(n, dtype=torch.float32, device=dev)
+    q = torch.empty(1, dtype=torch.float32, device=dev)
+    dlut = torch.empty(D, dtype=torch.float32, device=dev)
+    need = _lib.lib().gnan_spmm_pb_pack1_workspace_bytes(n)
+    ws = torch.empty((need + 15) // 16 * 2, dtype=torch.float64, device=dev)
+    cnt = g.cnt if use_cnt else None
+    tot = None if (s_total is None or not with_rest) else s_total.detach().float().reshape(-1).contiguous()
+    pa = _lib.PbPack1Args(n=n, dY=_lib.ptr(dY), dy_stride=dY.stride(0), cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0),
+                          D=D, d1=fwd.code_base, with_rest=int(with_rest), self_is_row=int(fwd.self_is_row),
+                          self_col=_lib.ptr(fwd.self_col), lut=_lib.ptr(lut), S=_lib.ptr(S), shell=_lib.ptr(shell),
+                          s_total=_lib.ptr(tot), c=_lib.ptr(c), e=_lib.ptr(e), q=_lib.ptr(q), dlut=_lib.ptr(dlut),
+                          workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 8)
+    _lib.check(_lib.lib().gnan_spmm_pb_pack1(pa, _lib.stream_of(dY)), "gnan_spmm_pb_pack1")
+    gt = g.transposed()
+    ones = torch.ones(D, dtype=torch.float32, device=dev)
+    dS = pb_launch(gt, pbt, c.view(n, 1), ones, False, None, S_self=e, out_add=(q, lut[D - 1:]) if with_rest else None)
+    return dS, dlut
 
 
 def pb_bwd_applies(g: HopGraph, W: int, D: int):
@@ -454,8 +519,11 @@ class _RhoAggregate(torch.autograd.Function):
         ctx.s_total = None if s_total is None else s_total.detach()
         ctx.total_rows, ctx.total_group = total_rows, total_group
         ctx.save_for_backward(S, lut)
-        return spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr,
-                           room=getattr(S, "gnan_room", None))
+        kept = [] if (PB_BACKWARD_ONE_COLUMN and S.shape[1] == 1 and any(ctx.needs_input_grad[:2])) else None
+        out = spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr,
+                          room=getattr(S, "gnan_room", None), keep_shell=kept)
+        ctx.shell = kept[0] if kept else None
+        return out
 
     @staticmethod
     def backward(ctx, dY):
@@ -500,6 +568,16 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         # [dY_i / cnt(i, d) | dY_i / cnt(i, rest)] and yields the operand gradient AND the table gradient (the two-pass
         # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
         half = 1 << max(0, (W - 1).bit_length())
+        shares_total = with_rest and not (ctx.total_group is NOT_SHARED and ctx.total_rows is None)
+        plans = pb_bwd1_applies(g, W, D, with_rest, not shares_total, getattr(ctx, "shell", None))
+        if plans is not None:
+            # one column, large graph, shell sums kept by the forward: a pass over the rows and ONE column through the buckets
+            total = None
+            if with_rest:
+                total = (ctx.s_total if ctx.s_total is not None else Fn.column_sums(S)).float().reshape(-1).contiguous()
+            dS, dl = pb_bwd1_launch(g, plans, dY, S, ctx.shell, lut[:, 0], use_cnt, with_rest, total)
+            rest_added = with_rest
+            return dS, dl.view(D, 1)
         pb_t = pb_bwd_applies(g, W, D)                      # one column, large graph: no per-pair gather (csrc/spmm_pb.hip)
         walk = (None, None, None) if pb_t is not None else narrow_walk(g.transposed())
         q_sum = total = None

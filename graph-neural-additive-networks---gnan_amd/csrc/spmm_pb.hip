@@ -73,6 +73,11 @@ struct PbParams {
   const float* ds_add;        // optional [1]: added to every dS row ...
   const float* ds_add_scale;  // ... times this [1] (optional)
   double* dlut_partial;       // [n_bins, 4]
+  // forward extras (W == 1): the rows' raw shell sums out, a separate operand for the self pairs, a constant added to every row
+  float* shell_out;
+  const float* S_self;
+  const float* out_add;
+  const float* out_add_scale;
 };
 
 __global__ void pb_prep_kernel(unsigned* absmax) {
@@ -227,6 +232,8 @@ __device__ __forceinline__ void fwd_rows(const PbParams& p, const long long* acc
   const int32_t* cnt_base = has_cnt ? p.cnt : reinterpret_cast<const int32_t*>(p.lut);
   const int64_t cnt_step = has_cnt ? p.cnt_stride : 0;
   const int32_t* self_base = p.self_col ? p.self_col : p.slot_ptr;
+  const float* s_self = p.S_self ? p.S_self : p.S;
+  const float add = p.out_add ? p.out_add[0] * p.out_add_scale[0] : 0.f;
   for (int i0 = r_lo + tid; i0 < r_hi; i0 += kThreads * RB) {
     int s_lo[RB], s_hi[RB], sc[RB], c[RB][4];
     float sv[RB][W];
@@ -254,7 +261,7 @@ __device__ __forceinline__ void fwd_rows(const PbParams& p, const long long* acc
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
 #pragma unroll
-      for (int w = 0; w < W; ++w) sv[r][w] = p.S[static_cast<int64_t>(sc[r] < 0 ? 0 : sc[r]) * W + w];
+      for (int w = 0; w < W; ++w) sv[r][w] = s_self[static_cast<int64_t>(sc[r] < 0 ? 0 : sc[r]) * W + w];
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -272,11 +279,15 @@ __device__ __forceinline__ void fwd_rows(const PbParams& p, const long long* acc
           long long t = 0;
           for (int sl = s_lo[r]; sl < s_hi[r]; ++sl) t += acc[(sl * p.n_acc + a) * W + w];
           const float tf = static_cast<float>(static_cast<double>(t) * inv_scale);
+          if constexpr (W == 1) {
+            if (p.shell_out) p.shell_out[i] = bad ? __uint_as_float(0x7fc00000u) : tf;      // (n_acc == 1 with shell_out: validated)
+          }
           const int d = p.code_base + a;
           const float wd = d == 0 ? wt[0] : (d == 1 ? wt[1] : (d == 2 ? wt[2] : wt[3]));
           out = fmaf(wd - w_rest, tf, out);
         }
         if (p.s_total) out = fmaf(w_rest, tot[w], out);
+        out += add;
         if (bad) out = __uint_as_float(0x7fc00000u);
         p.Y[static_cast<int64_t>(i) * p.y_stride + w] = out;
       }
@@ -490,6 +501,114 @@ __global__ __launch_bounds__(256) void pb_dlut_final_kernel(const double* __rest
   }
 }
 
+// ---- the one-column backward's row pass (gnan_spmm_pb_pack1): c, e, and float64 partials of (q, g0, g1, gr) per workgroup ----------
+struct Pack1Params {
+  int64_t n;
+  const float* dY;
+  int64_t dy_stride;
+  const int32_t* cnt;
+  int64_t cnt_stride;
+  int D, d1, with_rest, self_is_row;
+  const int32_t* self_col;
+  const float* lut;
+  const float* S;
+  const float* shell;
+  float* c;
+  float* e;
+  double* partial;      // [blocks, 4]
+};
+
+constexpr int kPackRows = 4;      // rows per thread
+
+__global__ __launch_bounds__(256) void pb_pack1_kernel(const Pack1Params p) {
+  const int rest = p.D - 1;
+  const float l0 = p.lut[0], l1 = p.lut[p.d1], lr = p.with_rest ? p.lut[rest] : 0.f;
+  const bool has_cnt = p.cnt != nullptr;
+  const int32_t* cnt_base = has_cnt ? p.cnt : reinterpret_cast<const int32_t*>(p.lut);       // (unconditional loads, see fwd_rows)
+  const int64_t cnt_step = has_cnt ? p.cnt_stride : 0;
+  const bool col_given = p.self_col != nullptr;
+  const int32_t* self_base = col_given ? p.self_col : reinterpret_cast<const int32_t*>(p.lut);
+  double q = 0.0, g0 = 0.0, g1 = 0.0, gr = 0.0;
+  const int64_t first = (static_cast<int64_t>(blockIdx.x) * kPackRows) * 256 + threadIdx.x;
+  float dy[kPackRows], sh[kPackRows], sv[kPackRows];
+  int c0[kPackRows], c1[kPackRows], cr[kPackRows], sc[kPackRows];
+#pragma unroll
+  for (int r = 0; r < kPackRows; ++r) {
+    const int64_t i = first + r * 256 < p.n ? first + r * 256 : 0;
+    dy[r] = p.dY[i * p.dy_stride];
+    sh[r] = p.shell[i];
+    c0[r] = cnt_base[i * cnt_step];
+    c1[r] = cnt_base[i * cnt_step + (has_cnt ? p.d1 : 0)];
+    cr[r] = cnt_base[i * cnt_step + (has_cnt ? rest : 0)];
+    sc[r] = self_base[col_given ? i : 0];
+  }
+#pragma unroll
+  for (int r = 0; r < kPackRows; ++r) {
+    const int64_t i = first + r * 256 < p.n ? first + r * 256 : 0;
+    sc[r] = p.self_is_row ? static_cast<int>(i) : (col_given ? sc[r] : -1);
+    sv[r] = p.S[sc[r] < 0 ? 0 : sc[r]];
+  }
+#pragma unroll
+  for (int r = 0; r < kPackRows; ++r) {
+    const int64_t i = first + r * 256;
+    if (i >= p.n) break;
+    const float d0 = has_cnt ? static_cast<float>(c0[r] > 1 ? c0[r] : 1) : 1.f;
+    const float d1f = has_cnt ? static_cast<float>(c1[r] > 1 ? c1[r] : 1) : 1.f;
+    const float drf = has_cnt ? static_cast<float>(cr[r] > 1 ? cr[r] : 1) : 1.f;
+    const float a0 = dy[r] / d0, a1 = dy[r] / d1f, ar = p.with_rest ? dy[r] / drf : 0.f;      // IEEE division, as the packed rows
+    const bool self = sc[r] >= 0;
+    const float sself = self ? sv[r] : 0.f;
+    p.c[i] = fmaf(l1, a1, -(lr * ar));
+    p.e[i] = self ? fmaf(l0, a0, -(lr * ar)) : 0.f;
+    q += static_cast<double>(ar);
+    g0 += static_cast<double>(sself) * static_cast<double>(a0);
+    g1 += static_cast<double>(sh[r]) * static_cast<double>(a1);
+    gr += (static_cast<double>(sself) + static_cast<double>(sh[r])) * static_cast<double>(ar);
+  }
+  __shared__ double red[256][4];
+  red[threadIdx.x][0] = q; red[threadIdx.x][1] = g0; red[threadIdx.x][2] = g1; red[threadIdx.x][3] = gr;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) p.partial[static_cast<int64_t>(blockIdx.x) * 4 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+// q and dlut from the workgroups' partials: one 1024-thread workgroup, records of 32 bytes, fixed order (~10^4 records on 10M rows)
+__global__ __launch_bounds__(1024) void pb_pack1_final_kernel(const double* __restrict__ partial, int64_t n_blocks, int D, int d1,
+                                                              int with_rest, const float* s_total, float* __restrict__ q_out,
+                                                              float* __restrict__ dlut) {
+  __shared__ double red[1024][4];
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
+  const double2* rec = reinterpret_cast<const double2*>(partial);
+  for (int64_t b = threadIdx.x; b < n_blocks; b += 1024) {
+    const double2 lo = rec[b * 2], hi = rec[b * 2 + 1];
+    g[0] += lo.x; g[1] += lo.y; g[2] += hi.x; g[3] += hi.y;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = g[k];
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + off][k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double q = red[0][0];
+    q_out[0] = static_cast<float>(q);
+    for (int d = 0; d < D; ++d) dlut[d] = 0.f;
+    dlut[0] = static_cast<float>(red[0][1]);
+    dlut[d1] = static_cast<float>(red[0][2]);
+    if (with_rest) dlut[D - 1] = static_cast<float>(-red[0][3] + (s_total ? static_cast<double>(s_total[0]) * static_cast<double>(q_out[0]) : 0.0));
+  }
+}
+
 int validate(const gnan_spmm_pb_args* a) {
   GNAN_REQUIRE(a != nullptr, "gnan_spmm_pb_fwd: null arguments");
   GNAN_REQUIRE(a->W == 1 || a->W == 2 || a->W == 4, "gnan_spmm_pb_fwd: W must be 1, 2 or 4 (got %d)", a->W);
@@ -514,6 +633,9 @@ int validate(const gnan_spmm_pb_args* a) {
   GNAN_REQUIRE(!a->self_is_row || a->n_cols >= a->n_rows, "gnan_spmm_pb_fwd: self_is_row needs an operand row per output row");
   GNAN_REQUIRE((reinterpret_cast<uintptr_t>(a->dst) % 8) == 0 && (reinterpret_cast<uintptr_t>(a->src) % 2) == 0,
                "gnan_spmm_pb_fwd: dst must be 8-byte aligned");
+  GNAN_REQUIRE((a->shell_out == nullptr && a->S_self == nullptr) || a->W == 1, "gnan_spmm_pb_fwd: shell_out / S_self serve W == 1");
+  GNAN_REQUIRE(a->shell_out == nullptr || a->n_acc == 1, "gnan_spmm_pb_fwd: shell_out is the sum of ONE accumulated hop code");
+  GNAN_REQUIRE((a->out_add == nullptr) == (a->out_add_scale == nullptr), "gnan_spmm_pb_fwd: out_add and out_add_scale go together");
   return GNAN_OK;
 }
 
@@ -551,6 +673,7 @@ PbParams make_params(const gnan_spmm_pb_args* a) {
   p.bin_entry_ptr = a->bin_entry_ptr; p.bin_row_ptr = a->bin_row_ptr; p.slot_ptr = a->slot_ptr; p.n_acc = a->n_acc;
   p.code_base = a->code_base; p.self_col = a->self_col; p.acc_per_bin = a->acc_per_bin; p.headroom_bits = a->headroom_bits;
   p.self_is_row = a->self_is_row;
+  p.shell_out = a->shell_out; p.S_self = a->S_self; p.out_add = a->out_add; p.out_add_scale = a->out_add_scale;
   p.absmax = static_cast<unsigned*>(a->workspace);
   p.E = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + 256);
   // enough workgroups per column block that the launch is >> the resident ones (two per CU) whatever the block count
@@ -594,6 +717,7 @@ extern "C" size_t gnan_spmm_pb_bwd_workspace_bytes(const gnan_spmm_pb_bwd_args* 
 extern "C" int gnan_spmm_pb_bwd(const gnan_spmm_pb_bwd_args* g, gnan_stream_t stream) {
   GNAN_REQUIRE(g != nullptr, "gnan_spmm_pb_bwd: null arguments");
   gnan_spmm_pb_args a = g->pb;
+  a.shell_out = nullptr; a.S_self = nullptr; a.out_add = nullptr; a.out_add_scale = nullptr;       // (forward-only fields)
   a.Y = g->dS;                       // (validate() wants an output; the backward epilogue writes dS)
   a.y_stride = g->ds_stride < 2 ? 2 : g->ds_stride;
   if (int rc = validate(&a)) return rc;
@@ -615,4 +739,34 @@ extern "C" int gnan_spmm_pb_bwd(const gnan_spmm_pb_bwd_args* g, gnan_stream_t st
   hipLaunchKernelGGL(pb_dlut_final_kernel, dim3(1), dim3(256), 0, st, p.dlut_partial, a.n_rows > 0 ? a.n_bins : 0, a.D, a.code_base,
                      g->with_rest, g->rest_total, g->rest_q, g->dlut);
   return gnan::check_launch("pb_dlut_final_kernel");
+}
+
+extern "C" size_t gnan_spmm_pb_pack1_workspace_bytes(int64_t n) {
+  if (n <= 0) return 32;
+  return static_cast<size_t>((n + 256 * kPackRows - 1) / (256 * kPackRows)) * 4 * sizeof(double);
+}
+
+extern "C" int gnan_spmm_pb_pack1(const gnan_pb_pack1_args* a, gnan_stream_t stream) {
+  GNAN_REQUIRE(a != nullptr && a->n >= 0 && a->D >= 2 && a->D <= 4, "gnan_spmm_pb_pack1: bad sizes");
+  GNAN_REQUIRE(a->d1 >= 1 && a->d1 < a->D - (a->with_rest ? 1 : 0), "gnan_spmm_pb_pack1: d1 = %d is not a listed hop code behind the self code", a->d1);
+  GNAN_REQUIRE(a->q && a->dlut && a->lut && (a->n == 0 || (a->dY && a->S && a->shell && a->c && a->e)), "gnan_spmm_pb_pack1: null pointer");
+  GNAN_REQUIRE(a->dy_stride >= 1 && (a->cnt == nullptr || a->cnt_stride >= a->D), "gnan_spmm_pb_pack1: row stride smaller than the width");
+  GNAN_REQUIRE(a->workspace && a->workspace_bytes >= gnan_spmm_pb_pack1_workspace_bytes(a->n) &&
+                   reinterpret_cast<uintptr_t>(a->workspace) % 16 == 0,
+               "gnan_spmm_pb_pack1: workspace of %zu bytes, 16-byte aligned", gnan_spmm_pb_pack1_workspace_bytes(a->n));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t blocks = a->n > 0 ? (a->n + 256 * kPackRows - 1) / (256 * kPackRows) : 0;
+  GNAN_REQUIRE(blocks < (int64_t{1} << 31), "gnan_spmm_pb_pack1: too many rows for one launch");
+  double* partial = static_cast<double*>(a->workspace);
+  if (blocks > 0) {
+    Pack1Params p;
+    p.n = a->n; p.dY = a->dY; p.dy_stride = a->dy_stride; p.cnt = a->cnt; p.cnt_stride = a->cnt_stride; p.D = a->D; p.d1 = a->d1;
+    p.with_rest = a->with_rest; p.self_is_row = a->self_is_row; p.self_col = a->self_col; p.lut = a->lut; p.S = a->S;
+    p.shell = a->shell; p.c = a->c; p.e = a->e; p.partial = partial;
+    hipLaunchKernelGGL(pb_pack1_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p);
+    if (int rc = gnan::check_launch("pb_pack1_kernel")) return rc;
+  }
+  hipLaunchKernelGGL(pb_pack1_final_kernel, dim3(1), dim3(1024), 0, st, partial, blocks, a->D, a->d1, a->with_rest, a->s_total, a->q,
+                     a->dlut);
+  return gnan::check_launch("pb_pack1_final_kernel");
 }

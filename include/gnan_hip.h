@@ -671,6 +671,13 @@ typedef struct gnan_spmm_pb_args {
   int32_t flags;             /* A/B switches (enum gnan_pb_flags): 0 = the defaults; bits 8-15 = workgroups per column block */
   int32_t self_is_row;       /* the hop-code-0 pair of EVERY row i lists operand row i (a hop-coded graph's self pairs, n_cols >=
                                 n_rows): self_col is not read and may be NULL */
+  /* optional, W == 1 (ABI 45) — what lets the SAME two phases serve the one-column backward without moving a second column
+   * (gnan_spmm_pb_pack1 below): */
+  float* shell_out;          /* [n_rows]: the row's raw sum over its listed pairs of the accumulated hop code (before any weight) —
+                                kept by a training forward: the table gradient is then a sum over ROWS, not over pairs */
+  const float* S_self;       /* [n_cols]: the operand of the hop-code-0 (self) pairs, when it is not S */
+  const float* out_add;      /* [1], with out_add_scale [1]: out_add[0] * out_add_scale[0] is added to every output row */
+  const float* out_add_scale;
 } gnan_spmm_pb_args;
 
 size_t gnan_spmm_pb_workspace_bytes(const gnan_spmm_pb_args* a);
@@ -705,6 +712,41 @@ typedef struct gnan_spmm_pb_bwd_args {
 
 size_t gnan_spmm_pb_bwd_workspace_bytes(const gnan_spmm_pb_bwd_args* g);
 int gnan_spmm_pb_bwd(const gnan_spmm_pb_bwd_args* g, gnan_stream_t stream);
+
+/* The one-column backward WITHOUT a second column (round 6; 0.74 -> 0.45 ms on the 10M-node graph).  With the forward's shell sums
+ * kept (gnan_spmm_pb_args.shell_out: shell[i] = sum of S over row i's listed pairs of hop code d1), every term of the table
+ * gradient is a sum over ROWS, and the operand gradient needs ONE number per row — the two per-pair factors of gnan_spmm_pb_bwd,
+ * dY_i / cnt(i, d1) and dY_i / cnt(i, D-1), enter dS only through  c_i = lut[d1] a1_i - lut[D-1] ar_i:
+ *   a0 = dY_i / max(cnt(i, 0), 1), a1 = dY_i / max(cnt(i, d1), 1), ar = with_rest ? dY_i / max(cnt(i, D-1), 1) : 0  (cnt NULL: 1)
+ *   c[i] = lut[d1] a1 - lut[D-1] ar          e[i] = lut[0] a0 - lut[D-1] ar  (the self pair's share; 0 for a row without one)
+ *   q    = sum_i ar                          dlut[0] = sum_i self_i a0,   dlut[d1] = sum_i shell[i] a1
+ *   dlut[D-1] = - sum_i (self_i + shell[i]) ar + s_total[0] q            (self_i = S[self column of row i], 0 without one)
+ * float64 per workgroup, fixed order.  Then  dS = gnan_spmm_pb_fwd over the TRANSPOSED adjacency's W = 1 plan with S = c, S_self = e,
+ * lut = ones, cnt = NULL, s_total = NULL, out_add = q, out_add_scale = &lut[D-1]:  dS[j] = sum_{i lists j} c_i + e_j + lut[D-1] q.
+ * workspace: gnan_spmm_pb_pack1_workspace_bytes(n) bytes, 8-byte aligned, nothing to initialise. */
+typedef struct gnan_pb_pack1_args {
+  int64_t n;                 /* rows of the forward */
+  const float* dY;           /* [n], stride dy_stride */
+  int64_t dy_stride;
+  const int32_t* cnt;        /* optional [n, cnt_stride] */
+  int64_t cnt_stride;
+  int32_t D, d1, with_rest;
+  int32_t self_is_row;       /* the forward plan's: row i's self pair lists operand row i */
+  const int32_t* self_col;   /* the forward plan's self column per row (-1: none), or NULL (no self pairs unless self_is_row) */
+  const float* lut;          /* [D] */
+  const float* S;            /* forward operand, one column, contiguous */
+  const float* shell;        /* [n] */
+  const float* s_total;      /* optional [1] (with_rest) */
+  float* c;                  /* out [n] */
+  float* e;                  /* out [n] */
+  float* q;                  /* out [1] */
+  float* dlut;               /* out [D] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_pb_pack1_args;
+
+size_t gnan_spmm_pb_pack1_workspace_bytes(int64_t n);
+int gnan_spmm_pb_pack1(const gnan_pb_pack1_args* a, gnan_stream_t stream);
 
 /* Shell sums for the backward pass (autograd through GNAN.py:67-70 w.r.t. rho's parameters):
  *   T[q, d, w] = sum_{e in row, code_e == d} S[col_e, w]            d < D-1

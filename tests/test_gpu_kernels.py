@@ -2196,12 +2196,19 @@ def test_propagation_blocked_aggregation_non_finite_operand():
 @pytest.mark.parametrize("D,self_pairs,use_cnt,with_rest,lds", [(3, True, True, True, 2048), (3, True, False, False, 2048),
                                                                  (2, False, True, True, 2048), (3, True, True, True, 65536),
                                                                  (3, False, True, True, 2048), (4, True, True, True, 2048)])
-def test_propagation_blocked_backward_vs_oracle_autograd(D, self_pairs, use_cnt, with_rest, lds, monkeypatch):
-    """One-column aggregation, forward AND backward on the bucketed copies (gnan_spmm_pb_fwd / gnan_spmm_pb_bwd over the
-    transposed graph): operand and table gradients against float64 oracle autograd, bit-reproducible, and equal to the
-    row-parallel kernels' gradients to float32 rounding.  D = 4 lists two non-self codes: the backward stays row-parallel."""
+@pytest.mark.parametrize("one_column", [True, False])
+def test_propagation_blocked_backward_vs_oracle_autograd(D, self_pairs, use_cnt, with_rest, lds, one_column, monkeypatch):
+    """One-column aggregation, forward AND backward on the bucketed copies: operand and table gradients against float64 oracle
+    autograd, bit-reproducible, and equal to the row-parallel kernels' gradients to float32 rounding.  `one_column`: the backward
+    from the forward's kept shell sums (gnan_spmm_pb_pack1 + gnan_spmm_pb_fwd over the transposed graph, W = 1; graphs whose self
+    pairs carry hop code 0) — else, and where that does not apply, the packed two-column rows (gnan_spmm_pb_bwd).  D = 4 lists
+    two non-self codes: the backward stays row-parallel."""
     from gnan_amd import graph as G
     from gnan_amd.aggregate import pb_bwd_applies, rho_aggregate
+    monkeypatch.setattr(aggregate, "PB_BACKWARD_ONE_COLUMN", one_column)
+    ran = []
+    real = aggregate.pb_bwd1_launch
+    monkeypatch.setattr(aggregate, "pb_bwd1_launch", lambda *a, **k: ran.append(1) or real(*a, **k))
     monkeypatch.setattr(G, "PB_LDS_BYTES", lds)
     if lds < 65536:
         monkeypatch.setattr(G, "PB_SLOT_PAIRS", 8)
@@ -2227,6 +2234,9 @@ def test_propagation_blocked_backward_vs_oracle_autograd(D, self_pairs, use_cnt,
         return torch.autograd.grad(rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest), [S, lut], up)
     got, again = grads(), grads()
     assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+    plan = g.pb_plan(1)
+    assert bool(ran) == (one_column and plan.n_acc == 1 and plan.code_base >= 1), (ran, D, self_pairs, plan.n_acc, plan.code_base)
+    assert not one_column or ran or D != 3 or self_pairs is False
     monkeypatch.setattr(aggregate, "PB_NARROW", False)
     rows = grads()
     S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
