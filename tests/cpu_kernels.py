@@ -23,7 +23,7 @@ def column_sums(S):
 
 
 def spmm_launch(g, S, lut, use_cnt, with_rest, row_ids=None, weight_by_col=False, minus_rest=False, s_total=None,
-                reduce_cr=0, s_by_code=False, lut_of_counts=None, lut_channels=1, room=None):
+                reduce_cr=0, s_by_code=False, lut_of_counts=None, lut_channels=1, room=None, keep_shell=None):
     assert not g.is_dense
     if lut is None:
         lut = lut_of_counts(g.cnt)
