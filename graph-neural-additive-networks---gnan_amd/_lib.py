@@ -123,7 +123,7 @@ class SpmmArgs(C.Structure):
         ("n_long", C.c_int32), ("n_slices", C.c_int32), ("slice_edges", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("s_by_code", C.c_int32), ("nnz", C.c_int64), ("packed_index", C.c_int32),
-        ("hot_lo", C.c_int64), ("hot_rows", C.c_int32),
+        ("hot_lo", C.c_int64), ("hot_rows", C.c_int32), ("shell_out", C.c_void_p),
     ]
 
 
@@ -174,6 +174,14 @@ class SpmmPbArgs(C.Structure):
         ("self_col", C.c_void_p), ("headroom_bits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("flags", C.c_int32), ("self_is_row", C.c_int32),
         ("shell_out", C.c_void_p), ("S_self", C.c_void_p), ("out_add", C.c_void_p), ("out_add_scale", C.c_void_p),
+    ]
+
+
+class PackZArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("dY", C.c_void_p), ("dy_stride", C.c_int64), ("cnt", C.c_void_p), ("cnt_stride", C.c_int64),
+        ("D", C.c_int32), ("with_rest", C.c_int32), ("lut", C.c_void_p), ("shell", C.c_void_p), ("s_total", C.c_void_p),
+        ("Z", C.c_void_p), ("q", C.c_void_p), ("dlut", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -403,6 +411,8 @@ SYMBOLS = {
     "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
     "gnan_spmm_pb_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbBwdArgs)]),
     "gnan_spmm_pb_bwd": (C.c_int, [C.POINTER(SpmmPbBwdArgs), C.c_void_p]),
+    "gnan_spmm_pack_z_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnan_spmm_pack_z": (C.c_int, [C.POINTER(PackZArgs), C.c_void_p]),
     "gnan_spmm_pb_pack1_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_spmm_pb_pack1": (C.c_int, [C.POINTER(PbPack1Args), C.c_void_p]),
     "gnan_spmm_shell_sums": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),

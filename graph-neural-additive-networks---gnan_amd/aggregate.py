@@ -106,6 +106,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
     graph from its shell counts (the pre-rho normalisation, :func:`pre_rho_aggregate`); it is called on the counts of the
     graph that is actually walked, so a degree-sorted copy gets its table in its own row order and nothing is permuted."""
     _lib.require_device(S, lut, g.code)
+    whole = row_ids is None                              # (the walks below may bring row_ids of their own)
     S = S.detach()
     if S.dtype != torch.bfloat16:                        # bf16 rows: storage format only, accumulation stays fp32
         S = S.float()
@@ -142,7 +143,7 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
         pb = g.pb_plan(S.shape[1])
         if pb is not None:
             shell = None
-            if keep_shell is not None and S.shape[1] == 1 and pb.n_acc == 1:
+            if keep_shell is not None and PB_BACKWARD_ONE_COLUMN and S.shape[1] == 1 and pb.n_acc == 1:
                 # a training forward keeps the rows' raw shell sums (4 bytes per row): its backward then needs no second column
                 shell = torch.empty(g.n_rows, dtype=torch.float32, device=S.device)
                 keep_shell.append(shell)
@@ -183,8 +184,59 @@ def spmm_launch(g: HopGraph, S: torch.Tensor, lut: Optional[torch.Tensor], use_c
     if need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=S.device)
         a.workspace, a.workspace_bytes = _lib.ptr(ws), need
+    if (keep_shell is not None and ROWS_BACKWARD_ONE_COLUMN and S.shape[1] == 1 and S.dtype == torch.float32 and not g.is_dense
+            and not per_row and lut_shape[1] == 1 and lut_shape[0] <= 4 and not weight_by_col and not minus_rest and not s_by_code
+            and reduce_cr == 0 and n_hot == 0 and a.n_slices == 0 and whole and not g._cnt_by_col):
+        # a training forward of a one-column operand keeps its rows' raw per-code sums ([n, D - 1]): the backward is then a pass
+        # over rows plus one gather of pre-weighted numbers (rows_bwd1_launch) instead of two numbers per row over the transposed pairs
+        shell = torch.empty((n_out, lut_shape[0] - 1), dtype=torch.float32, device=S.device)
+        a.shell_out = _lib.ptr(shell)
+        keep_shell.append(shell)
     _lib.check(_lib.lib().gnan_spmm_fwd(a, _lib.stream_of(S)), "gnan_spmm_fwd")
     return out
+
+
+_ONES = {}
+
+
+def _ones_table(dev, D: int) -> torch.Tensor:
+    """``[D, 1]`` ones on ``dev`` (a constant: made once, not by a fill launch per backward)."""
+    t = _ONES.get((dev, D))
+    if t is None:
+        t = torch.ones((D, 1), dtype=torch.float32, device=dev)
+        if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):      # (a capture's allocations are its own)
+            _ONES[(dev, D)] = t
+    return t
+
+
+ROWS_BACKWARD_ONE_COLUMN = True     # row-parallel route: keep the forward's per-code shell sums, backward by gnan_spmm_pack_z
+
+
+def rows_bwd1_launch(g: HopGraph, dY: torch.Tensor, shell: torch.Tensor, lut: torch.Tensor, use_cnt: bool, with_rest: bool,
+                     s_total: Optional[torch.Tensor]):
+    """``(dS [n_cols, 1], dlut [D])`` of the one-column aggregation on the row-parallel route from the forward's kept per-code shell
+    sums ``[n, D - 1]``: ``gnan_spmm_pack_z`` (a pass over the rows: Z, q, the table gradient), then the forward kernel over the
+    transposed adjacency with one pre-weighted operand row per (node, hop code)."""
+    _lib.require_device(dY, shell, lut)
+    n, dev = g.n_rows, dY.device
+    D = int(lut.numel())
+    dY = Fn._rows(dY.detach().float())
+    lut = lut.detach().float().reshape(-1).contiguous()
+    Z = torch.empty((n * D, 1), dtype=torch.float32, device=dev)
+    q = torch.empty(1, dtype=torch.float32, device=dev)
+    dlut = torch.empty(D, dtype=torch.float32, device=dev)
+    need = _lib.lib().gnan_spmm_pack_z_workspace_bytes(n)
+    ws = torch.empty((need + 15) // 16 * 2, dtype=torch.float64, device=dev)
+    cnt = g.cnt if use_cnt else None
+    tot = None if (s_total is None or not with_rest) else s_total.detach().float().reshape(-1).contiguous()
+    za = _lib.PackZArgs(n=n, dY=_lib.ptr(dY), dy_stride=dY.stride(0), cnt=_lib.ptr(cnt), cnt_stride=0 if cnt is None else cnt.stride(0),
+                        D=D, with_rest=int(with_rest), lut=_lib.ptr(lut), shell=_lib.ptr(shell), s_total=_lib.ptr(tot), Z=_lib.ptr(Z),
+                        q=_lib.ptr(q), dlut=_lib.ptr(dlut), workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 8)
+    _lib.check(_lib.lib().gnan_spmm_pack_z(za, _lib.stream_of(dY)), "gnan_spmm_pack_z")
+    dS = spmm_launch(g.transposed(), Z, _ones_table(dev, D), False, False, None, s_by_code=True)
+    if with_rest:
+        dS.addcmul_(lut[D - 1:], q)                          # d/dS_j of wt(i, rest) * total: rho(0) q on every row
+    return dS, dlut
 
 
 PB_NARROW = True            # narrow fp32 rows of large CSR graphs go through the propagation-blocked kernels (gnan_spmm_pb_fwd)
@@ -274,8 +326,7 @@ def pb_bwd1_launch(g: HopGraph, plans, dY: torch.Tensor, S: torch.Tensor, shell:
                           workspace=_lib.ptr(ws), workspace_bytes=ws.numel() * 8)
     _lib.check(_lib.lib().gnan_spmm_pb_pack1(pa, _lib.stream_of(dY)), "gnan_spmm_pb_pack1")
     gt = g.transposed()
-    ones = torch.ones(D, dtype=torch.float32, device=dev)
-    dS = pb_launch(gt, pbt, c.view(n, 1), ones, False, None, S_self=e, out_add=(q, lut[D - 1:]) if with_rest else None)
+    dS = pb_launch(gt, pbt, c.view(n, 1), _ones_table(dev, D), False, None, S_self=e, out_add=(q, lut[D - 1:]) if with_rest else None)
     return dS, dlut
 
 
@@ -519,7 +570,7 @@ class _RhoAggregate(torch.autograd.Function):
         ctx.s_total = None if s_total is None else s_total.detach()
         ctx.total_rows, ctx.total_group = total_rows, total_group
         ctx.save_for_backward(S, lut)
-        kept = [] if (PB_BACKWARD_ONE_COLUMN and S.shape[1] == 1 and any(ctx.needs_input_grad[:2])) else None
+        kept = [] if (S.shape[1] == 1 and all(ctx.needs_input_grad[:2]) and S.dtype == torch.float32) else None
         out = spmm_launch(g, S, lut, use_cnt, with_rest, row_ids, s_total=s_total, reduce_cr=reduce_cr,
                           room=getattr(S, "gnan_room", None), keep_shell=kept)
         ctx.shell = kept[0] if kept else None
@@ -569,7 +620,15 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
         # route below traverses the same pairs twice: 1.89 + 2.01 ms on the 10M-node graph)
         half = 1 << max(0, (W - 1).bit_length())
         shares_total = with_rest and not (ctx.total_group is NOT_SHARED and ctx.total_rows is None)
-        plans = pb_bwd1_applies(g, W, D, with_rest, not shares_total, getattr(ctx, "shell", None))
+        kept = getattr(ctx, "shell", None)
+        if kept is not None and kept.dim() == 2 and ROWS_BACKWARD_ONE_COLUMN and W == 1 and not shares_total:
+            # the row-parallel forward kept its per-code shell sums: a pass over the rows and one gather over the transposed pairs
+            total = None
+            if with_rest:
+                total = (ctx.s_total if ctx.s_total is not None else Fn.column_sums(S)).float().reshape(-1).contiguous()
+            dS, dl = rows_bwd1_launch(g, dY, kept, lut[:, 0], use_cnt, with_rest, total)
+            return dS, dl.view(D, 1)
+        plans = pb_bwd1_applies(g, W, D, with_rest, not shares_total, kept if (kept is not None and kept.dim() == 1) else None)
         if plans is not None:
             # one column, large graph, shell sums kept by the forward: a pass over the rows and ONE column through the buckets
             total = None

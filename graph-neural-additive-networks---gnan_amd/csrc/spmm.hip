@@ -53,6 +53,7 @@ struct Params {
   float* partial;  // [n_slices, 2, W]
   int64_t hot_lo;  // spmm_hot_kernel: operand rows [hot_lo, hot_lo + hot_n) are served from an LDS copy
   int hot_n;
+  float* shell_out;  // [n_rows, D - 1] raw per-code sums of the operand over the row's pairs (W == 1, small-D route, a lane per row)
 };
 
 __device__ __forceinline__ int64_t load_rowptr(const Params& p, int64_t i) {
@@ -321,6 +322,10 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
     }
   }
   float red[4] = {0.f, 0.f, 0.f, 0.f};  // fused feature sum (reduce_cr in {1, 2, 4}): channel partials of this lane
+  // a training forward of a one-column operand keeps the raw per-code sums of its rows (gnan_spmm_args.shell_out): a lane owns a
+  // row here, so three more accumulators and a select per pair
+  constexpr bool kShell = SMALLD && VEC == 1 && LPR == 1 && !BYCODE && !DENSE;
+  float sh[3] = {0.f, 0.f, 0.f};
   // (uniform) one weight per pair from a per-neighbour table, no counts, no rest subtraction: see the index loads below
   const bool pair_weights = !SMALLD && !DENSE && p.weight_by_col && p.Cw == 1 && p.cnt == nullptr && !p.minus_rest && p.lut_row_stride != 0;
 
@@ -407,6 +412,11 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
               const float w = sw.pick(d[u]);
 #pragma unroll
               for (int v = 0; v < VEC; ++v) acc.v[v] = fmaf(w, sv.v[v], acc.v[v]);
+              if constexpr (kShell) {
+                sh[0] += d[u] == 0 ? sv.v[0] : 0.f;
+                sh[1] += d[u] == 1 ? sv.v[0] : 0.f;
+                sh[2] += d[u] == 2 ? sv.v[0] : 0.f;
+              }
             } else {
               Vec<VEC> w;
               if (pair_weights) {
@@ -447,6 +457,12 @@ __device__ __forceinline__ void rows_body(const Params& p, const int64_t block_i
           for (int c = 0; c < 4; ++c) red[c] += ch == c ? acc.v[v] : 0.f;
         }
       }
+    }
+  }
+  if constexpr (kShell) {
+    if (p.shell_out) {
+      float* t = p.shell_out + out_row(p, q, i) * (p.D - 1);
+      for (int dd = 0; dd < p.D - 1; ++dd) t[dd] = dd == 0 ? sh[0] : (dd == 1 ? sh[1] : sh[2]);
     }
   }
   if (p.reduce_cr) {
@@ -1096,6 +1112,7 @@ Params make_params(const gnan_spmm_args* a) {
   p.slice_edges = a->slice_edges;
   p.partial = static_cast<float*>(a->workspace);
   p.hot_lo = a->hot_lo; p.hot_n = a->hot_rows;
+  p.shell_out = a->shell_out;
   return p;
 }
 
@@ -2294,6 +2311,13 @@ extern "C" int gnan_spmm_fwd(const gnan_spmm_args* a, gnan_stream_t stream) {
     lpr = 1;
     while (lpr * 8 < a->W && lpr < kWave) lpr <<= 1;
     return launch_lpr<8>(p, lpr, false, smalld, st);
+  }
+  if (a->shell_out != nullptr) {
+    const bool ok = smalld && a->W == 1 && a->n_slices == 0 && a->reduce_cr == 0 && !a->s_by_code && a->s_dtype == GNAN_F32 &&
+                    a->hot_rows == 0 && vec == 1 && lpr == 1;
+    if (!ok)
+      return gnan::fail(GNAN_ERR_UNSUPPORTED, "spmm: shell_out serves a one-column fp32 operand on the small-D CSR route without hub-row "
+                                              "slices, fused read-out or hot rows");
   }
   if (smalld && hot_kernel_applies(a))                // narrow rows, hottest operand rows in LDS (persistent workgroups)
     return a->W == 1 ? launch_hot<1>(p, st) : (a->W == 2 ? launch_hot<2>(p, st) : launch_hot<4>(p, st));

@@ -483,6 +483,10 @@ typedef struct gnan_spmm_args {
   int32_t hot_rows;              /* hot_rows) are the most listed neighbours' rows, most listed first, and the column ids of their
                                   * pairs point there (a compact copy behind the operand).  hot_rows > 0 lets the library serve them
                                   * from LDS (persistent workgroups, hot_rows * W <= 32768 floats); 0 = off.  Same output bits */
+  float* shell_out;              /* gnan_spmm_fwd, optional (ABI 45): [n_rows, D - 1] the row's RAW sums of S over its listed pairs, per
+                                  * hop code (before any weight) — what a training forward keeps so that its backward is a pass over
+                                  * rows (gnan_spmm_pack_z).  One-column operand (W == 1), global one-channel table with D <= 4, CSR,
+                                  * no hub-row slices (n_slices == 0), no fused read-out, no hot rows; GNAN_ERR_UNSUPPORTED otherwise */
 } gnan_spmm_args;
 
 size_t gnan_spmm_fwd_workspace_bytes(const gnan_spmm_args* a);
@@ -744,6 +748,32 @@ typedef struct gnan_pb_pack1_args {
   void* workspace;
   size_t workspace_bytes;
 } gnan_pb_pack1_args;
+
+/* The same row pass for the row-parallel kernels (graphs the bucketed route declines; any D <= 4): from the forward's per-code shell
+ * sums T [n, D - 1] (gnan_spmm_args.shell_out) and dY [n]:
+ *   a_d = dY_i / max(cnt(i, d), 1) (cnt NULL: dY_i),  ar = with_rest ? a_{D-1} : 0
+ *   Z[i, d] = lut[d] a_d - lut[D-1] ar  (d < D - 1),  Z[i, D-1] = 0         q = sum_i ar
+ *   dlut[d] = sum_i a_d T[i, d]  (d < D - 1),          dlut[D-1] = - sum_i ar sum_d T[i, d] + s_total[0] q   (with_rest, else 0)
+ * Then dS = gnan_spmm_fwd over the transposed adjacency with S = Z ([n * D] rows, s_by_code = 1), a table of ones, no counts, plus
+ * lut[D-1] q on every row.  float64 per workgroup, fixed order.  workspace: gnan_spmm_pack_z_workspace_bytes(n), 16-byte aligned. */
+typedef struct gnan_pack_z_args {
+  int64_t n;
+  const float* dY;           /* [n], stride dy_stride */
+  int64_t dy_stride;
+  const int32_t* cnt;        /* optional [n, cnt_stride] */
+  int64_t cnt_stride;
+  int32_t D, with_rest;
+  const float* lut;          /* [D] */
+  const float* shell;        /* [n, D - 1] */
+  const float* s_total;      /* optional [1] */
+  float* Z;                  /* out [n, D] */
+  float* q;                  /* out [1] */
+  float* dlut;               /* out [D] */
+  void* workspace;
+  size_t workspace_bytes;
+} gnan_pack_z_args;
+size_t gnan_spmm_pack_z_workspace_bytes(int64_t n);
+int gnan_spmm_pack_z(const gnan_pack_z_args* a, gnan_stream_t stream);
 
 size_t gnan_spmm_pb_pack1_workspace_bytes(int64_t n);
 int gnan_spmm_pb_pack1(const gnan_pb_pack1_args* a, gnan_stream_t stream);

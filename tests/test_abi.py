@@ -75,7 +75,7 @@ def test_struct_layout_matches_header():
                         ("gnan_spmm_lut_grad_args", _lib.SpmmLutGradArgs), ("gnan_pack_bwd_rows_args", _lib.PackBwdRowsArgs),
                         ("gnan_spmm_bwd_narrow_args", _lib.SpmmBwdNarrowArgs), ("gnan_bfs_dense_args", _lib.BfsDenseArgs),
                         ("gnan_spmm_pb_args", _lib.SpmmPbArgs), ("gnan_spmm_pb_bwd_args", _lib.SpmmPbBwdArgs),
-                        ("gnan_pb_pack1_args", _lib.PbPack1Args),
+                        ("gnan_pb_pack1_args", _lib.PbPack1Args), ("gnan_pack_z_args", _lib.PackZArgs),
                         ("gnan_sorted_csr_args", _lib.SortedCsrArgs), ("gnan_pb_keys_args", _lib.PbKeysArgs),
                         ("gnan_pb_fill_args", _lib.PbFillArgs), ("gnan_csr_transpose_args", _lib.CsrTransposeArgs),
                         ("gnan_bfs_khop_args", _lib.BfsKhopArgs), ("gnan_loss_args", _lib.LossArgs),

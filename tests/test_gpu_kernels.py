@@ -2397,3 +2397,54 @@ def test_small_passes_take_their_sums_by_the_last_workgroup(n, monkeypatch):
 def _lib_mod():
     from gnan_amd import _lib
     return _lib
+
+
+@pytest.mark.parametrize("D,use_cnt,with_rest,n", [(3, True, True, 5000), (3, False, False, 5000), (2, True, True, 700),
+                                                    (4, True, True, 5000), (4, False, True, 90_000), (3, True, True, 90_000)])
+def test_row_parallel_backward_from_kept_shell_sums_vs_oracle_autograd(D, use_cnt, with_rest, n, monkeypatch):
+    """One-column aggregation on the row-parallel route: a training forward keeps its rows' per-code shell sums
+    (gnan_spmm_args.shell_out) and the backward is gnan_spmm_pack_z (a pass over rows: Z, q, the table gradient) + one gather over
+    the transposed pairs.  Operand and table gradients against float64 oracle autograd, bit-reproducible, and equal to the packed
+    two-column route (gnan_spmm_pack_bwd_rows + gnan_spmm_bwd_narrow) to float32 rounding.  Very popular neighbours: hub rows
+    of the TRANSPOSED graph."""
+    from gnan_amd import HopGraph
+    from gnan_amd.aggregate import rho_aggregate
+    monkeypatch.setattr(aggregate, "PB_NARROW", False)
+    ran = []
+    real = aggregate.rows_bwd1_launch
+    monkeypatch.setattr(aggregate, "rows_bwd1_launch", lambda *a, **k: ran.append(1) or real(*a, **k))
+    rng = np.random.default_rng(D * 11 + n)
+    rowptr, col, code = _random_csr(n, n, D - 2, rng) if D > 2 else _random_csr(n, n, 0, rng)
+    hot = rng.random(col.shape[0]) < 0.15
+    hot &= code != 0
+    col = col.copy()
+    col[hot] = rng.integers(0, 5, int(hot.sum())) * (n // 5)
+    g = HopGraph.from_csr(torch.from_numpy(rowptr).to(DEV), torch.from_numpy(col).to(DEV), torch.from_numpy(code).to(DEV), n_cols=n,
+                          n_codes=D)
+    S0 = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
+    lut0 = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).to(DEV)
+    up = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
+
+    def grads():
+        S, lut = S0.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+        return torch.autograd.grad(rho_aggregate(g, S, lut, use_cnt, with_rest=with_rest), [S, lut], up)
+    got, again = grads(), grads()
+    assert ran and torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+    monkeypatch.setattr(aggregate, "ROWS_BACKWARD_ONE_COLUMN", False)
+    del ran[:]
+    packed = grads()
+    assert not ran
+    S64, lut64 = S0.cpu().double().requires_grad_(True), lut0.cpu().double().requires_grad_(True)
+    wt = lut64.unsqueeze(0).expand(n, -1, -1)
+    if use_cnt:
+        wt = wt / g.cnt.cpu().clamp_min(1).double().unsqueeze(-1)
+    row_of = torch.repeat_interleave(torch.arange(n), torch.from_numpy(np.diff(rowptr)))
+    colt, codet = torch.from_numpy(col).long(), torch.from_numpy(code).long()
+    y64 = torch.zeros(n, 1, dtype=torch.float64).index_add(0, row_of, wt[row_of, codet] * S64[colt])
+    if with_rest:
+        y64 = y64 + wt[:, -1] * (S64.sum(0, keepdim=True) - torch.zeros(n, 1, dtype=torch.float64).index_add(0, row_of, S64[colt]))
+    ref = torch.autograd.grad(y64, [S64, lut64], up.cpu().double())
+    for k in range(2):
+        scale = float(ref[k].abs().max())
+        assert float((got[k].cpu().double() - ref[k]).abs().max()) <= 1e-5 * scale, (k, scale)
+        assert float((got[k] - packed[k]).abs().max()) <= TWO_FLOORS * scale, (k, scale)                # two routes
