@@ -74,7 +74,7 @@ stats_of("train", "_train_step_c4_kernel_stats.csv")
 for name, out in (("emulated_shares.txt", "_emulated_shares.txt"), ("emulated_shares_all.txt", "_emulated_shares_all.txt"),
                   ("emulated_shares_all_rccl.txt", "_emulated_shares_all_rccl.txt"), ("lookup_ab.jsonl", "_lookup_ab.jsonl"),
                   ("sq_fwd.txt", "_sq_fwd.txt"), ("sq_train.txt", "_sq_train.txt"), ("batched_bench.jsonl", "_batched_bench.jsonl"),
-                  ("timeline_muta.txt", "_timeline_muta.txt"), ("c3_timeline.txt", "_c3_timeline.txt"),
+                  ("timeline_muta.txt", "_timeline_muta.txt"), ("c3_timeline.txt", "_c3_timeline.txt"), ("c3_c40_timeline.txt", "_c3_c40_timeline.txt"),
                   ("reference_loop.jsonl", "_reference_loop.jsonl"), ("reference_loop_host_profile.txt", "_reference_loop_host_profile.txt"),
                   ("share_timeline.txt", "_share_timeline.txt"), ("emulated_shares_all_cut_rows.txt", "_emulated_shares_all_cut_rows.txt"),
                   ("pb_bench.jsonl", "_pb_bench.jsonl"), ("pmc_narrow.csv", "_pmc_narrow.csv"),

@@ -33,6 +33,7 @@ python3 tools/muta_epoch.py > $OUT/muta_epoch.json 2> $OUT/muta_epoch.err       
 bash tools/graphed_timeline.sh $OUT/tl_muta muta > $OUT/timeline_muta.txt 2>&1                 # one replayed graph-task training step, kernel by kernel
 # ---- round 5 additions
 bash tools/c3_timeline.sh > $OUT/c3_timeline.txt 2>&1                                          # one replayed forward + backward step of config 3, kernel by kernel
+bash tools/c3_timeline.sh --out 40 > $OUT/c3_c40_timeline.txt 2>&1                              # ... with 40 output channels (the ogbn-arxiv task's width)
 python3 tools/reference_loop_bench.py --profile > $OUT/reference_loop.jsonl 2> $OUT/reference_loop_host_profile.txt   # the reference-SHAPED loop (anomaly mode, stock Adam)
 python3 bench.py --config c3 --loop reference --no-cpu-baseline > $OUT/c3_loop_reference.log 2>&1
 python3 bench.py --config c2 --loop reference --no-cpu-baseline --steps 3 --warmup 1 > $OUT/c2_loop_reference.log 2>&1
