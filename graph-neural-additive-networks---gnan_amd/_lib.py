@@ -62,6 +62,7 @@ class FpwlIndexArgs(C.Structure):
 
 
 FPWL_MOMENTS_GENERAL, FPWL_LOCATE_SORTED, FPWL_INDEX_HALF_LINES, FPWL_INDEX_BS512, FPWL_INDEX_BS1024 = 1, 2, 4, 8, 16   # gnan_fpwl_args.flags
+FPWL_ROWS_MOMENTS_LANE_PER_CHANNEL = 32
 
 
 class PwlBuildArgs(C.Structure):

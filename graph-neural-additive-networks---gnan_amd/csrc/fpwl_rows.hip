@@ -316,6 +316,92 @@ __global__ __launch_bounds__(1024) void fpwl_rows_moments_kernel(const RowsMomen
   }
 }
 
+// 34..42 channels (ogbn-arxiv: 40 classes): a lane per channel leaves 22-30 of a wavefront's 64 lanes idle in a kernel bound by
+// vector issue.  Here a lane takes a PAIR of channels and a wavefront three nodes per step (3 x ceil(C / 2) <= 63 lanes busy):
+// one 8-byte gradient load, four conversions, four LDS atomics per lane and step.  Same terms, same integer bins: the same bits
+// as fpwl_rows_moments_kernel<64>.
+__global__ __launch_bounds__(1024) void fpwl_rows_moments_pairs_kernel(const RowsMomentParams p) {
+  constexpr int NWAVES = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long bins[];   // [pieces of feature k][2 C + 1]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int GS = (p.cc + 1) / 2;                       // lanes per node
+  const int slot = lane / GS, c0 = (lane - slot * GS) * 2;
+  const bool lane_on = slot < 3;
+  const unsigned wpc = static_cast<unsigned>(p.wgs_per_chunk);
+  const unsigned chunk = __builtin_amdgcn_readfirstlane(blockIdx.x / wpc);
+  const unsigned id = __builtin_amdgcn_readfirstlane(blockIdx.x - chunk * wpc);
+  const int k = __builtin_amdgcn_readfirstlane(static_cast<int>((id >> 3) % static_cast<unsigned>(p.F)));
+  const int64_t nb = static_cast<int64_t>(__builtin_amdgcn_readfirstlane(((id >> 3) / static_cast<unsigned>(p.F)) * 8 + (id & 7)));
+  const int c_lo = static_cast<int>(chunk) * p.cc;
+  const int C = p.C - c_lo < p.cc ? p.C - c_lo : p.cc;
+  const int Rb = 2 * p.cc + 1;
+  const int base = p.off[k];
+  const int tot = p.off[k + 1] - base;
+  const int64_t n_lo = nb * p.nodes_per_block;
+  if (n_lo >= p.n) return;
+  for (int i = tid; i < tot * Rb; i += 1024) bins[i] = 0ull;
+  __syncthreads();
+  const double s0 = p.scales[0], s1 = p.scales[1];
+  const int64_t n_hi = n_lo + p.nodes_per_block < p.n ? n_lo + p.nodes_per_block : p.n;
+  const int64_t gbase = (p.sum_features ? 0 : static_cast<int64_t>(k) * p.C) + c_lo;
+  const bool has0 = lane_on && c0 < C, has1 = lane_on && c0 + 1 < C;
+  const int ca = has0 ? c0 : 0, cb = has1 ? c0 + 1 : ca;
+  // rows whose channel pairs are 8-byte aligned and whole (C even): float2 loads
+  const bool pair_load = (C & 1) == 0 && (p.g_stride & 1) == 0 && (gbase & 1) == 0 && (reinterpret_cast<uintptr_t>(p.g) & 7) == 0;
+  constexpr int U = 8;
+  for (int64_t n0 = n_lo + static_cast<int64_t>(wave) * kWave; n0 < n_hi; n0 += NWAVES * kWave) {
+    int pv = 0;
+    float dv = 0.f;
+    if (n0 + lane < n_hi) {
+      pv = p.piece[(n0 + lane) * p.F + k] - base;
+      dv = p.dx[(n0 + lane) * p.F + k];
+    }
+    const int m = static_cast<int>(n_hi - n0 < kWave ? n_hi - n0 : kWave);
+    for (int i0 = 0; i0 < m; i0 += U * 3) {
+      float ga[U], gb[U], dd[U];
+      int t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 3 + (lane_on ? slot : 0);
+        const int ic = i < m ? i : m - 1;              // (past the end: a valid node, its terms are dropped below)
+        t[u] = __shfl(pv, ic);
+        dd[u] = __shfl(dv, ic);
+        const float* row = p.g + (n0 + ic) * p.g_stride + gbase;
+        if (pair_load) {                                 // (uniform) one 8-byte load per lane and node
+          const float2 v = *reinterpret_cast<const float2*>(row + ca);
+          ga[u] = v.x;
+          gb[u] = v.y;
+        } else {
+          ga[u] = row[ca];
+          gb[u] = row[cb];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i0 + u * 3 + slot < m) {
+          unsigned long long* b = bins + static_cast<int64_t>(t[u]) * Rb + c0;
+          if (has0) {
+            atomicAdd(b, fixed_bits(ga[u], s0));
+            atomicAdd(b + p.cc, fixed_bits(ga[u] * dd[u], s1));
+          }
+          if (has1) {
+            atomicAdd(b + 1, fixed_bits(gb[u], s0));
+            atomicAdd(b + p.cc + 1, fixed_bits(gb[u] * dd[u], s1));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = p.Mi + static_cast<int64_t>(base) * 2 * p.C;
+  for (int i = tid; i < tot * 2 * C; i += 1024) {
+    const int t = i / (2 * C), r = i - t * 2 * C, m = r / C, c2 = r - m * C;
+    const unsigned long long v = bins[t * Rb + m * p.cc + c2];
+    if (v != 0ull) atomicAdd(out + static_cast<int64_t>(t) * 2 * p.C + m * p.C + c_lo + c2, v);
+  }
+}
+
 int cp2_of(int C) {
   int cp2 = 8;
   while (cp2 < C) cp2 <<= 1;
@@ -467,6 +553,16 @@ extern "C" int gnan_fpwl_rows_moments_fixed(const gnan_fpwl_args* a, const int32
   if (p.wgs_per_chunk * n_chunks > 0x7fffffffLL) return gnan::fail(GNAN_ERR_UNSUPPORTED, "fpwl_rows_moments: too many nodes for one launch");
   const dim3 grid(static_cast<unsigned>(p.wgs_per_chunk * n_chunks));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cc > 32 && 3 * ((cc + 1) / 2) <= kWave && !(a->flags & GNAN_FPWL_ROWS_MOMENTS_LANE_PER_CHANNEL)) {
+    // 33..42 channels: a pair of channels per lane, three nodes per step (see fpwl_rows_moments_pairs_kernel)
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fpwl_rows_moments_pairs_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "fpwl_rows_moments: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(fpwl_rows_moments_pairs_kernel, grid, dim3(1024), lds, st, p);
+    return gnan::check_launch("fpwl_rows_moments_pairs_kernel");
+  }
   switch (cp2_of(cc)) {
     case 8: return launch_rows_moments<8>(p, lds, grid, st);
     case 16: return launch_rows_moments<16>(p, lds, grid, st);

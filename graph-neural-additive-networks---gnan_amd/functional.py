@@ -92,9 +92,11 @@ INDEX_FLAGS = 0               # A/B aid: _lib.FPWL_INDEX_HALF_LINES / FPWL_INDEX
 
 def _fpwl_flags() -> int:
     """``gnan_fpwl_args.flags`` from this module's switches (the library itself reads no environment variables)."""
-    return (_lib.FPWL_MOMENTS_GENERAL if MOMENTS_GENERAL else 0) | (_lib.FPWL_LOCATE_SORTED if LOCATE_SORTED else 0) | INDEX_FLAGS
+    return ((_lib.FPWL_MOMENTS_GENERAL if MOMENTS_GENERAL else 0) | (_lib.FPWL_LOCATE_SORTED if LOCATE_SORTED else 0) | INDEX_FLAGS
+            | (_lib.FPWL_ROWS_MOMENTS_LANE_PER_CHANNEL if ROWS_MOMENTS_LANE_PER_CHANNEL else 0))
 
 
+ROWS_MOMENTS_LANE_PER_CHANNEL = False   # A/B: 33..42 channels with a lane per channel instead of a pair of channels per lane
 FPWL_ROWS = True   # several output channels: two-phase look-up (csrc/fpwl_rows.hip)
 FPWL_ROWS_MIN_NODES = 32768
 # fewer channels: locating the pieces separately costs more than it saves (GNAN_FPWL_ROWS_MIN_C: A/B aid).  10M nodes x 64

@@ -195,7 +195,9 @@ enum gnan_fpwl_flags {
   GNAN_FPWL_LOCATE_SORTED = 2,   /* gnan_fpwl_locate: the sorted-array search also where the tree search applies */
   GNAN_FPWL_INDEX_HALF_LINES = 4, /* direct-index look-up: 16-feature groups (half lines of x per workgroup) where 32 would fit */
   GNAN_FPWL_INDEX_BS512 = 8,     /* direct-index look-up with 32-feature groups: 512-thread workgroups whatever the mode */
-  GNAN_FPWL_INDEX_BS1024 = 16    /* ... 1024-thread workgroups whatever the mode */
+  GNAN_FPWL_INDEX_BS1024 = 16,   /* ... 1024-thread workgroups whatever the mode */
+  GNAN_FPWL_ROWS_MOMENTS_LANE_PER_CHANNEL = 32 /* gnan_fpwl_rows_moments_fixed, 33..42 channels: a lane per channel (one node per step)
+                                  * instead of a pair of channels per lane and three nodes per step (A/B; same bits) */
 };
 
 size_t gnan_fpwl_total_workspace_bytes(const gnan_fpwl_args* a);

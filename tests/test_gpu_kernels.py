@@ -622,7 +622,8 @@ def test_table_path_parameter_gradients_edge_cases(fixed, monkeypatch):
 @pytest.mark.parametrize("F,L,H,C,sum_features", [(129, 3, 32, 40, True), (20, 3, 16, 7, True), (9, 2, 24, 2, True),
                                                    (33, 3, 16, 64, True), (12, 3, 16, 5, False), (70, 3, 8, 17, False),
                                                    (20, 3, 16, 100, True), (6, 3, 8, 130, False),    # > 64 channels: chunks
-                                                   (32, 3, 16, 13, True)])
+                                                   (32, 3, 16, 13, True),
+                                                   (20, 3, 16, 34, True), (12, 3, 16, 41, False), (16, 3, 16, 42, True)])   # 33..42: a pair of channels per lane
 def test_two_phase_lookup_for_several_channels(F, L, H, C, sum_features, monkeypatch):
     """csrc/fpwl_rows.hip: piece / dx located once per (node, feature) (bit-exact index work against the reference search),
     forward rows == the thread-per-node kernel (same arithmetic per term; the feature sum in the same order when a thread
