@@ -49,6 +49,7 @@ struct BuildParams {
   double* scratch;       // [F, cap + 2, C] network values at the table nodes
   int hid_offset;        // byte offset of the two [chunk, H] float64 tiles in dynamic LDS (8-byte aligned)
   int chunk;             // nodes per pass
+  int wl_wide;           // 5..64 channels and room in LDS: the last layer's rows staged there for the output sums
   int affine;            // L == 3 by the interval forms: the tile region holds A | B [(H + 1), H] | zt [chunk, H] | k1 [H] | unit_at [H]
 };
 
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
   float* b2 = b1 + p.H;                                     // [H]
   float* wl = b2 + p.H;                                     // [4 * H + 4] last layer's rows and biases of up to four channels
   float* W2 = wl + 4 * p.H + 4;                             // [H*H] (L == 3), transposed: W2[k * H + j]
+  float* wl_wide = W2 + (p.L == 3 ? p.H * p.H : 0);        // [C][H + 1] + [C] (5..64 channels: p.wl_wide): rows padded against bank conflicts
   double* h1 = reinterpret_cast<double*>(smem_raw + p.hid_offset);    // [chunk, H] relu(layer 1)
   double* zt = h1 + p.chunk * p.H;                                     // [chunk, H] layer-2 pre-activations
   // the affine route's use of the same region
@@ -169,6 +171,10 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
     w1[i] = p.w_first[k * H + i];
     b1[i] = p.b_first ? p.b_first[k * H + i] : 0.f;
     b2[i] = (p.L == 3 && p.b_mid) ? p.b_mid[k * H + i] : 0.f;
+  }
+  if (p.wl_wide) {
+    for (int i = tid; i < C * H; i += kBT) wl_wide[(i / H) * (H + 1) + i % H] = p.w_last[static_cast<int64_t>(k) * C * H + i];
+    if (tid < C) wl_wide[C * (H + 1) + tid] = p.b_last ? p.b_last[k * C + tid] : 0.f;
   }
   if (C <= 4) {                                             // (a global read inside the output sums is a microsecond each)
     for (int i = tid; i < C * H; i += kBT) wl[i] = p.w_last[static_cast<int64_t>(k) * C * H + i];
@@ -476,12 +482,24 @@ __global__ __launch_bounds__(kBT) void pwl_build_kernel(const BuildParams p) {
         }
         hid = zt;
       }
-      for (int it = tid; it < nn * C; it += kBT) {
-        const int ni = it / C, c = it % C;
-        double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
+      if (p.wl_wide) {                                     // (uniform) the last layer's rows from LDS
+        for (int it = tid; it < nn * C; it += kBT) {
+          const int ni = it / C, c = it % C;
+          double acc = static_cast<double>(wl_wide[C * (H + 1) + c]);
+          const float* wr = wl_wide + c * (H + 1);
+          const double* hr = hid + ni * H;
 #pragma unroll 8
-        for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
-        V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
+          for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(wr[j]), hr[j], acc);
+          V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
+        }
+      } else {
+        for (int it = tid; it < nn * C; it += kBT) {
+          const int ni = it / C, c = it % C;
+          double acc = p.b_last ? static_cast<double>(p.b_last[k * C + c]) : 0.0;
+#pragma unroll 8
+          for (int j = 0; j < H; ++j) acc = fma(static_cast<double>(Wl[c * H + j]), hid[ni * H + j], acc);
+          V[static_cast<int64_t>(n0 + ni) * C + c] = acc;
+        }
       }
       __syncthreads();
     }
@@ -635,6 +653,13 @@ extern "C" int gnan_pwl_build(const gnan_pwl_build_args* a, gnan_stream_t stream
   p.slope = p.val + static_cast<size_t>(a->F) * (a->cap + 1) * a->C;
   p.pieces = reinterpret_cast<int32_t*>(p.slope + static_cast<size_t>(a->F) * (a->cap + 1) * a->C);
   size_t lds = 3 * kCap * sizeof(double) + (7 * static_cast<size_t>(a->H) + 4 + (a->L == 3 ? static_cast<size_t>(a->H) * a->H : 0)) * sizeof(float);
+  // 5..64 channels: the last layer's rows (padded) behind W2, if everything still fits 160 KB
+  const size_t wide_floats = static_cast<size_t>(a->C) * (a->H + 1) + a->C;
+  const size_t tiles_guess = (a->L == 3 && a->H <= 64)
+                                 ? (2 * static_cast<size_t>(a->H + 1) * (a->H + 1) + 64 * static_cast<size_t>(a->H) + a->H) * sizeof(double) + a->H * sizeof(int)
+                                 : 2 * static_cast<size_t>(a->H <= 64 ? 64 : 32) * a->H * sizeof(double);
+  p.wl_wide = (a->C > 4 && a->C <= 64 && lds + wide_floats * sizeof(float) + 8 + tiles_guess + 64 <= 160 * 1024) ? 1 : 0;
+  if (p.wl_wide) lds += wide_floats * sizeof(float);
   lds = (lds + 7) & ~static_cast<size_t>(7);
   p.hid_offset = static_cast<int>(lds);
   p.chunk = a->H <= 64 ? 64 : 32;
