@@ -412,6 +412,9 @@ SYMBOLS = {
     "gnan_spmm_pb_fwd": (C.c_int, [C.POINTER(SpmmPbArgs), C.c_void_p]),
     "gnan_spmm_pb_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(SpmmPbBwdArgs)]),
     "gnan_spmm_pb_bwd": (C.c_int, [C.POINTER(SpmmPbBwdArgs), C.c_void_p]),
+    "gnan_weight_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gnan_colsum_weighted": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnan_spmm_pack_z_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_spmm_pack_z": (C.c_int, [C.POINTER(PackZArgs), C.c_void_p]),
     "gnan_spmm_pb_pack1_workspace_bytes": (C.c_size_t, [C.c_int64]),

@@ -681,30 +681,38 @@ def _aggregate_backward(ctx, S, lut, dY, need_dS: bool, need_dlut: bool):
             # wide operand: the weight of a pair belongs to the NEIGHBOUR's row there.  Read from (lut, cnt) that is two
             # random count reads, two divisions and a subtraction per pair; a per-node table wt(i, d) - wt(i, rest)
             # built once per backward pass makes it one 4-byte read (arxiv-shaped W = 40: 0.55 -> 0.28 ms)
-            wt = (lut if per_row else lut.unsqueeze(0)).float()                               # [N or 1, D, Cw]
-            if use_cnt:
-                wt = wt / g.cnt.clamp_min(1).float().unsqueeze(-1)
-            if with_rest:
-                wt = wt - wt[:, D - 1:D]
-            dS = spmm_launch(g.transposed(), dY_full, wt.expand(g.n_rows, D, Cw).contiguous(), False, False, None,
-                             weight_by_col=True)
+            if not per_row and lut.is_cuda and g.cnt.dtype == torch.int32:
+                wt = Fn.weight_table(lut, g.cnt if use_cnt else None, g.n_rows, with_rest)    # one launch (four framework ones before)
+            else:
+                wt = (lut if per_row else lut.unsqueeze(0)).float()                           # [N or 1, D, Cw]
+                if use_cnt:
+                    wt = wt / g.cnt.clamp_min(1).float().unsqueeze(-1)
+                if with_rest:
+                    wt = wt - wt[:, D - 1:D]
+                wt = wt.expand(g.n_rows, D, Cw).contiguous()
+            dS = spmm_launch(g.transposed(), dY_full, wt, False, False, None, weight_by_col=True)
         else:
             dS = spmm_launch(g.transposed(), dY_full, lut, use_cnt, False, None,
                              weight_by_col=True, minus_rest=with_rest)
     if need_dS:
         if with_rest and not rest_added:
             # d/dS_j of  wt(i, rest) * total  : the same vector for every j
-            l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
-            w_rest = l_rest * inv_counts()[:, D - 1:D] if use_cnt else l_rest   # [n_out or 1, Cw]
-            w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
-            v = (w_rest * dY).sum(0, keepdim=True)
+            if (not per_row and rows is None and Cw == 1 and use_cnt and dY.is_cuda and g.cnt.dtype == torch.int32
+                    and dY.shape[0] == g.n_rows):
+                # rho(0) sum_i dY[i, :] / cnt(i, rest) in one weighted column sum (eight framework launches before)
+                v = Fn.column_sums_weighted(dY, g.cnt[:, D - 1], lut[D - 1]).view(1, W)
+            else:
+                l_rest = (lut[rows, D - 1] if rows is not None else lut[:, D - 1]) if per_row else lut[D - 1].unsqueeze(0)
+                w_rest = l_rest * inv_counts()[:, D - 1:D] if use_cnt else l_rest   # [n_out or 1, Cw]
+                w_rest = w_rest.expand(dY.shape[0], Cw).repeat(1, W // Cw)
+                v = (w_rest * dY).sum(0, keepdim=True)
             if ctx.total_group is not NOT_SHARED:
                 # the total was summed over the ranks of a group: every rank's output rows pull on every rank's
                 # summed operand rows, so the ranks add their vectors (W floats) before handing them down
                 import torch.distributed as dist
                 dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ctx.total_group)
             if ctx.total_rows is None:
-                dS = dS + v
+                dS.add_(v)
             else:                          # only the first rows of S went into the total (owned rows ahead of halo rows)
                 dS[: ctx.total_rows] += v
 

@@ -10,7 +10,9 @@ constexpr int kBlocks = 1024;
 // BF16: S holds bf16 rows (VEC must be 4: 8-B loads), widened to fp32 before summing.
 template <int VEC, bool BF16 = false>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ S, int64_t n, int W, int64_t stride,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, const int32_t* __restrict__ wcnt = nullptr,
+                                                             int64_t wstride = 0) {
+  // wcnt (gnan_colsum_weighted): row r counts with weight 1 / max(wcnt[r * wstride], 1)
   // thread (cx, ry): column chunk cx of VEC floats, rows ry, ry + RY, ... inside this workgroup's row range
   const int chunks = (W + VEC - 1) / VEC;
   const int cpb = chunks < 256 ? chunks : 256;     // column chunks handled per pass
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     if (c < chunks && ry < RY) {
       int64_t r = r0 + ry;
-      if constexpr (!BF16 && VEC == 1) {
+      if constexpr (!BF16 && VEC == 1) if (wcnt == nullptr) {
         // narrow operands (one float per thread and row): eight rows in flight per thread — with one, a 40-MB column of the
         // 10M-node graph took 27 us (1.5 TB/s: request latency, not bandwidth)
         for (; r + 7 * static_cast<int64_t>(RY) < r1; r += 8 * static_cast<int64_t>(RY)) {
@@ -47,9 +49,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
           acc[2] += __uint_as_float(t.y << 16); acc[3] += __uint_as_float(t.y & 0xffff0000u);
         } else if constexpr (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4*>(ptr);
-          acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+          if (wcnt) {
+            const int q = wcnt[r * wstride];
+            const float d = static_cast<float>(q > 1 ? q : 1);
+            acc[0] += t.x / d; acc[1] += t.y / d; acc[2] += t.z / d; acc[3] += t.w / d;
+          } else {
+            acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+          }
         } else {
-          acc[0] += ptr[0];
+          if (wcnt) {
+            const int q = wcnt[r * wstride];
+            acc[0] += ptr[0] / static_cast<float>(q > 1 ? q : 1);
+          } else {
+            acc[0] += ptr[0];
+          }
         }
       }
     }
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 // One workgroup per column: 256 threads stride over the per-workgroup partials, then a fixed-order tree.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int blocks, int W,
-                                                           float* __restrict__ total) {
+                                                           float* __restrict__ total, const float* __restrict__ scale = nullptr) {
   __shared__ double red[256];
   const int w = blockIdx.x;
   double s = 0.0;
@@ -81,10 +94,58 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
     if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) total[w] = static_cast<float>(red[0]);
+  if (threadIdx.x == 0) total[w] = static_cast<float>(scale ? red[0] * static_cast<double>(scale[0]) : red[0]);
+}
+
+// wt[i, d, c] = lut[d, c] / max(cnt[i, d], 1) - (with_rest ? lut[D - 1, c] / max(cnt[i, D - 1], 1) : 0): the per-node weight table of the
+// wide backward (gnan_spmm_fwd with weight_by_col), IEEE divisions and one subtraction as the framework expression it replaces
+__global__ __launch_bounds__(256) void weight_table_kernel(const float* __restrict__ lut, const int32_t* __restrict__ cnt, int64_t cnt_stride,
+                                                           int64_t n, int D, int Cw, int with_rest, float* __restrict__ wt) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= n * D * Cw) return;
+  const int c = static_cast<int>(idx % Cw);
+  const int d = static_cast<int>((idx / Cw) % D);
+  const int64_t i = idx / (static_cast<int64_t>(Cw) * D);
+  const int qd = cnt ? cnt[i * cnt_stride + d] : 1, qr = cnt ? cnt[i * cnt_stride + D - 1] : 1;
+  float w = lut[d * Cw + c] / static_cast<float>(qd > 1 ? qd : 1);
+  if (with_rest) w -= lut[(D - 1) * Cw + c] / static_cast<float>(qr > 1 ? qr : 1);
+  wt[idx] = w;
 }
 
 }  // namespace
+
+extern "C" int gnan_weight_table(const float* lut, const int32_t* cnt, int64_t cnt_stride, int64_t n, int32_t D, int32_t Cw,
+                                 int32_t with_rest, float* wt, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && D >= 1 && Cw >= 1, "weight_table: bad sizes");
+  GNAN_REQUIRE((lut && wt) || n == 0, "weight_table: null pointer");
+  GNAN_REQUIRE(cnt == nullptr || cnt_stride >= D, "weight_table: count rows shorter than D");
+  if (n == 0) return GNAN_OK;
+  const int64_t blocks = (n * D * Cw + 255) / 256;
+  GNAN_REQUIRE(blocks < (int64_t{1} << 31), "weight_table: too many entries for one launch");
+  hipLaunchKernelGGL(weight_table_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), lut, cnt,
+                     cnt_stride, n, D, Cw, with_rest, wt);
+  return gnan::check_launch("weight_table_kernel");
+}
+
+extern "C" int gnan_colsum_weighted(const float* S, int64_t n, int32_t W, int64_t stride, const int32_t* cnt, int64_t cnt_stride,
+                                    const float* scale, float* total, void* workspace, size_t workspace_bytes, gnan_stream_t stream) {
+  GNAN_REQUIRE(n >= 0 && W >= 1, "colsum_weighted: bad sizes");
+  GNAN_REQUIRE(S && total && workspace && cnt, "colsum_weighted: null pointer");
+  GNAN_REQUIRE(stride >= W && cnt_stride >= 1, "colsum_weighted: row stride smaller than the width");
+  if (workspace_bytes < static_cast<size_t>(kBlocks) * W * sizeof(double))
+    return gnan::fail(GNAN_ERR_WORKSPACE, "colsum_weighted: workspace too small");
+  GNAN_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 8 == 0, "colsum_weighted: workspace must be 8-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int blocks = static_cast<int>(n / 256 + 1);
+  blocks = blocks > kBlocks ? kBlocks : blocks;
+  double* partial = static_cast<double*>(workspace);
+  const bool vec = W % 4 == 0 && stride % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0;
+  if (vec) hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(blocks), dim3(256), 0, st, S, n, W, stride, partial, cnt, cnt_stride);
+  else hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(blocks), dim3(256), 0, st, S, n, W, stride, partial, cnt, cnt_stride);
+  if (int rc = gnan::check_launch("colsum_partial_kernel")) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(W), dim3(256), 0, st, partial, blocks, W, total, scale);
+  return gnan::check_launch("colsum_final_kernel");
+}
 
 extern "C" size_t gnan_colsum_workspace_bytes(int32_t W) { return static_cast<size_t>(kBlocks) * W * sizeof(double); }
 

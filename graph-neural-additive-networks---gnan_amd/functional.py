@@ -1105,6 +1105,35 @@ def column_sums(S: torch.Tensor) -> torch.Tensor:
     return total
 
 
+def column_sums_weighted(S: torch.Tensor, cnt_col: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``total[w] = scale * sum_r S[r, w] / max(cnt_col[r], 1)`` (``gnan_colsum_weighted``): ``cnt_col`` a column VIEW of the shell-count
+    table (int32, any row stride), ``scale`` a device scalar — the rest bucket's pull on every operand row in the wide backward."""
+    _lib.require_device(S, cnt_col)
+    S = _rows(S.detach().float())
+    n, W = S.shape
+    if cnt_col.dtype != torch.int32 or cnt_col.dim() != 1 or cnt_col.shape[0] != n:
+        raise ValueError("column_sums_weighted: one int32 count per row")
+    total = torch.empty(W, dtype=torch.float32, device=S.device)
+    need = _lib.lib().gnan_colsum_workspace_bytes(W)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=S.device)
+    _lib.check(_lib.lib().gnan_colsum_weighted(_lib.ptr(S), n, W, S.stride(0), _lib.ptr(cnt_col), cnt_col.stride(0),
+                                               _lib.ptr(scale), _lib.ptr(total), _lib.ptr(ws), need, _lib.stream_of(S)),
+               "gnan_colsum_weighted")
+    return total
+
+
+def weight_table(lut: torch.Tensor, cnt: Optional[torch.Tensor], n: int, with_rest: bool) -> torch.Tensor:
+    """``wt [n, D, Cw] = lut[d, c] / max(cnt[i, d], 1) - (with_rest ? lut[D-1, c] / max(cnt[i, D-1], 1) : 0)`` (``gnan_weight_table``):
+    the per-node weights the wide backward reads by neighbour."""
+    _lib.require_device(lut, cnt)
+    lut = lut.detach().float().contiguous()
+    D, Cw = lut.shape
+    wt = torch.empty((n, D, Cw), dtype=torch.float32, device=lut.device)
+    _lib.check(_lib.lib().gnan_weight_table(_lib.ptr(lut), _lib.ptr(cnt), 0 if cnt is None else cnt.stride(0), n, D, Cw, int(with_rest),
+                                            _lib.ptr(wt), _lib.stream_of(lut)), "gnan_weight_table")
+    return wt
+
+
 def feature_sum(fx: torch.Tensor, C: int) -> torch.Tensor:
     """``out[i, c] = sum_k fx[i, k * C + c]`` (``gnan_feature_sum``; C in {1, 2, 4}, whole 16-byte quads per row)."""
     _lib.require_device(fx)

@@ -1091,6 +1091,15 @@ int gnan_small_graph_nam_bwd(const gnan_small_graph_nam_bwd_args* a, gnan_stream
 int gnan_multi_copy(int32_t count, const void* const* src, void* const* dst, const int64_t* bytes, gnan_stream_t stream);
 
 /* same for bf16 operand rows (stride in elements, W % 4 == 0, 8-B aligned rows) */
+/* The wide backward's two per-row expressions as kernels (framework element-wise chains before; ABI 45):
+ *   gnan_weight_table:    wt[i, d, c] = lut[d, c] / max(cnt[i, d], 1) - (with_rest ? lut[D-1, c] / max(cnt[i, D-1], 1) : 0)   (cnt NULL: 1)
+ *   gnan_colsum_weighted: total[w] = scale[0] * sum_r S[r, w] / max(cnt[r * cnt_stride], 1)  (scale NULL: 1) — with cnt pointing at the
+ *                         rest column of the count table and scale at lut[D-1]: d/dS_j of the rest bucket's column-sum term.
+ * workspace of gnan_colsum_weighted: gnan_colsum_workspace_bytes(W). */
+int gnan_weight_table(const float* lut, const int32_t* cnt, int64_t cnt_stride, int64_t n, int32_t D, int32_t Cw, int32_t with_rest,
+                      float* wt, gnan_stream_t stream);
+int gnan_colsum_weighted(const float* S, int64_t n, int32_t W, int64_t stride, const int32_t* cnt, int64_t cnt_stride, const float* scale,
+                         float* total, void* workspace, size_t workspace_bytes, gnan_stream_t stream);
 int gnan_colsum_bf16(const void* S, int64_t n, int32_t W, int64_t stride, float* total, void* workspace,
                      size_t workspace_bytes, gnan_stream_t stream);
 
