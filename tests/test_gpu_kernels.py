@@ -2449,3 +2449,25 @@ def test_row_parallel_backward_from_kept_shell_sums_vs_oracle_autograd(D, use_cn
         scale = float(ref[k].abs().max())
         assert float((got[k].cpu().double() - ref[k]).abs().max()) <= 1e-5 * scale, (k, scale)
         assert float((got[k] - packed[k]).abs().max()) <= TWO_FLOORS * scale, (k, scale)                # two routes
+
+
+@pytest.mark.parametrize("n,D,Cw,W,use_cnt,with_rest", [(5000, 3, 1, 40, True, True), (777, 4, 1, 7, True, False), (3000, 3, 2, 8, False, True)])
+def test_wide_backward_row_expressions_as_kernels(n, D, Cw, W, use_cnt, with_rest):
+    """gnan_weight_table == the framework expression it replaced, bit for bit (IEEE divisions, one subtraction);
+    gnan_colsum_weighted == the float64 sum of dY / cnt * scale."""
+    from gnan_amd import functional as Fn
+    gen = torch.Generator().manual_seed(n + D)
+    lut = torch.randn(D, Cw, generator=gen).to(DEV)
+    cnt = torch.randint(0, 50, (n, D), generator=gen, dtype=torch.int32).to(DEV)
+    got = Fn.weight_table(lut, cnt if use_cnt else None, n, with_rest)
+    want = lut.unsqueeze(0).float()
+    if use_cnt:
+        want = want / cnt.clamp_min(1).float().unsqueeze(-1)
+    if with_rest:
+        want = want - want[:, D - 1:D]
+    assert torch.equal(got, want.expand(n, D, Cw).contiguous())
+    if Cw == 1:
+        dY = torch.randn(n, W, generator=gen).to(DEV)
+        v = Fn.column_sums_weighted(dY, cnt[:, D - 1], lut[D - 1])
+        ref = (dY.double() / cnt[:, D - 1:D].clamp_min(1).double()).sum(0) * lut[D - 1].double()
+        assert float((v.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + 1e-30)
