@@ -2471,3 +2471,22 @@ def test_wide_backward_row_expressions_as_kernels(n, D, Cw, W, use_cnt, with_res
         v = Fn.column_sums_weighted(dY, cnt[:, D - 1], lut[D - 1])
         ref = (dY.double() / cnt[:, D - 1:D].clamp_min(1).double()).sum(0) * lut[D - 1].double()
         assert float((v.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + 1e-30)
+
+
+@pytest.mark.parametrize("n", [5_000, 30_000])
+def test_arrival_counters_stress(n, monkeypatch):
+    """The last workgroup's sum against the two-launch route, 2000 launches in a row on fresh data (the packed rows' q, 20 / 118
+    workgroups: below the 128 above which a pass keeps its second launch) — the same bits, every time."""
+    from gnan_amd import functional as Fn
+    from gnan_amd.aggregate import pack_bwd_rows
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    cnt = torch.randint(0, 9, (n, 3), generator=gen, device=DEV, dtype=torch.int32)
+    bad = 0
+    for it in range(2000):
+        dY = torch.randn(n, 1, generator=gen, device=DEV)
+        monkeypatch.setattr(Fn, "ARRIVE_COUNTERS", True)
+        _, q1 = pack_bwd_rows(dY, cnt, 3, True, 1, want_q_sum=True)
+        monkeypatch.setattr(Fn, "ARRIVE_COUNTERS", False)
+        _, q0 = pack_bwd_rows(dY, cnt, 3, True, 1, want_q_sum=True)
+        bad += int(not torch.equal(q0, q1))
+    assert bad == 0, bad
