@@ -400,6 +400,10 @@ SYMBOLS = {
     "gnan_spmm_fwd": (C.c_int, [C.POINTER(SpmmArgs), C.c_void_p]),
     "gnan_degree_sorted_csr_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnan_degree_sorted_csr": (C.c_int, [C.POINTER(SortedCsrArgs), C.c_void_p]),
+    "gnan_long_row_plan_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gnan_long_row_plan_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "gnan_long_row_plan_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnan_csr_transpose_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnan_csr_transpose": (C.c_int, [C.POINTER(CsrTransposeArgs), C.c_void_p]),
     "gnan_pb_plan_long_row_threshold": (C.c_int32, []),

@@ -553,3 +553,100 @@ extern "C" int gnan_csr_transpose(const gnan_csr_transpose_args* a, gnan_stream_
                      a->col_t, a->code_t);
   return gnan::check_launch("tr_gather_kernel");
 }
+
+// =============================================================================================
+// The hub-row plan (HopGraph.long_row_plan): the rows with more than `threshold` pairs in ascending order and the prefix of their
+// slice counts ceil(pairs / slice_edges) — two passes over the row lengths (count per block of 256 rows, scan, ordered fill).  It
+// replaces ~10 framework launches whose first use in a process cost 20 ms of lazily loaded kernels (cold setup of the bench line).
+// =============================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void long_count_kernel(const void* rowptr, int is64, int64_t n, int64_t threshold, int* block_cnt) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const bool is_long = i < n && load_ptr(rowptr, is64, i + 1) - load_ptr(rowptr, is64, i) > threshold;
+  const int c = __syncthreads_count(is_long ? 1 : 0);
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(256) void long_fill_kernel(const void* rowptr, int is64, int64_t n, int64_t threshold, int64_t slice_edges,
+                                                        const int* block_off, int32_t* long_rows, int32_t* n_sl) {
+  __shared__ int wave_cnt[4];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  int64_t deg = 0;
+  if (i < n) deg = load_ptr(rowptr, is64, i + 1) - load_ptr(rowptr, is64, i);
+  const bool is_long = i < n && deg > threshold;
+  const unsigned long long b = __ballot(is_long);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = __popcll(b);
+  __syncthreads();
+  int before = block_off[blockIdx.x];
+  for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+  if (is_long) {
+    const int at = before + __popcll(b & ((1ull << lane) - 1ull));
+    long_rows[at] = static_cast<int32_t>(i);
+    n_sl[at] = static_cast<int32_t>((deg + slice_edges - 1) / slice_edges);
+  }
+}
+
+__global__ void long_ptr0_kernel(int32_t* slice_ptr) { slice_ptr[0] = 0; }
+
+}  // namespace
+
+extern "C" size_t gnan_long_row_plan_workspace_bytes(int64_t n_rows) {
+  const size_t nb = static_cast<size_t>((n_rows + 255) / 256);
+  size_t scan_bytes = 0;
+  int* in = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, scan_bytes, in, in, 0, nb + 1, rocprim::plus<int>());
+  size_t scan2 = 0;                                   // (phase 2 scans up to n_rows slice counts)
+  (void)rocprim::inclusive_scan(nullptr, scan2, in, in, static_cast<size_t>(n_rows > 0 ? n_rows : 1), rocprim::plus<int>());
+  scan_bytes = scan_bytes > scan2 ? scan_bytes : scan2;
+  return ((nb + 1) * 2 * sizeof(int) + 255) / 256 * 256 + (scan_bytes + 255) / 256 * 256 + 256;
+}
+
+// Phase 1: block counts and their exclusive scan; total[0] = number of hub rows (device; the caller reads it back to size phase 2).
+extern "C" int gnan_long_row_plan_count(const void* rowptr, int32_t rowptr_is64, int64_t n_rows, int64_t threshold, void* workspace,
+                                        size_t workspace_bytes, int32_t* total, gnan_stream_t stream) {
+  GNAN_REQUIRE(rowptr && workspace && total && n_rows > 0 && n_rows < (int64_t{1} << 31) && threshold >= 0, "long_row_plan_count: bad arguments");
+  GNAN_REQUIRE(workspace_bytes >= gnan_long_row_plan_workspace_bytes(n_rows) && reinterpret_cast<uintptr_t>(workspace) % 256 == 0,
+               "long_row_plan_count: workspace of %zu bytes, 256-byte aligned", gnan_long_row_plan_workspace_bytes(n_rows));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t nb = static_cast<size_t>((n_rows + 255) / 256);
+  int* cnt = static_cast<int*>(workspace);
+  int* off = cnt + (nb + 1);
+  char* tmp = static_cast<char*>(workspace) + ((nb + 1) * 2 * sizeof(int) + 255) / 256 * 256;
+  hipLaunchKernelGGL(long_count_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, rowptr, rowptr_is64, n_rows, threshold, cnt);
+  if (int rc = gnan::check_launch("long_count_kernel")) return rc;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<unsigned*>(cnt + nb), int64_t{1});     // the scan's extra slot
+  size_t scan_bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, scan_bytes, cnt, off, 0, nb + 1, rocprim::plus<int>());
+  hipError_t e = rocprim::exclusive_scan(tmp, scan_bytes, cnt, off, 0, nb + 1, rocprim::plus<int>(), st);
+  if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "long_row_plan_count: scan: %s", hipGetErrorString(e));
+  e = hipMemcpyAsync(total, off + nb, sizeof(int), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "long_row_plan_count: copy: %s", hipGetErrorString(e));
+  return GNAN_OK;
+}
+
+// Phase 2 (same workspace, untouched since phase 1): long_rows [n_long] ascending, slice_ptr [n_long + 1]; slice_ptr[n_long] = slices.
+extern "C" int gnan_long_row_plan_fill(const void* rowptr, int32_t rowptr_is64, int64_t n_rows, int64_t threshold, int64_t slice_edges,
+                                       int64_t n_long, void* workspace, size_t workspace_bytes, int32_t* long_rows, int32_t* slice_ptr,
+                                       gnan_stream_t stream) {
+  GNAN_REQUIRE(rowptr && workspace && long_rows && slice_ptr && n_rows > 0 && n_long > 0 && slice_edges > 0, "long_row_plan_fill: bad arguments");
+  GNAN_REQUIRE(workspace_bytes >= gnan_long_row_plan_workspace_bytes(n_rows), "long_row_plan_fill: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t nb = static_cast<size_t>((n_rows + 255) / 256);
+  int* cnt = static_cast<int*>(workspace);
+  int* off = cnt + (nb + 1);
+  char* tmp = static_cast<char*>(workspace) + ((nb + 1) * 2 * sizeof(int) + 255) / 256 * 256;
+  // the slice counts land in slice_ptr[1 ..] and are scanned in place
+  hipLaunchKernelGGL(long_fill_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, st, rowptr, rowptr_is64, n_rows, threshold, slice_edges,
+                     off, long_rows, slice_ptr + 1);
+  if (int rc = gnan::check_launch("long_fill_kernel")) return rc;
+  hipLaunchKernelGGL(long_ptr0_kernel, dim3(1), dim3(1), 0, st, slice_ptr);
+  size_t scan_bytes = 0;
+  (void)rocprim::inclusive_scan(nullptr, scan_bytes, slice_ptr + 1, slice_ptr + 1, static_cast<size_t>(n_long), rocprim::plus<int>());
+  if (scan_bytes > gnan_long_row_plan_workspace_bytes(n_rows) - ((nb + 1) * 2 * sizeof(int) + 255) / 256 * 256)
+    return gnan::fail(GNAN_ERR_WORKSPACE, "long_row_plan_fill: scan needs %zu bytes", scan_bytes);
+  hipError_t e = rocprim::inclusive_scan(tmp, scan_bytes, slice_ptr + 1, slice_ptr + 1, static_cast<size_t>(n_long), rocprim::plus<int>(), st);
+  if (e != hipSuccess) return gnan::fail(GNAN_ERR_HIP, "long_row_plan_fill: scan: %s", hipGetErrorString(e));
+  return GNAN_OK;
+}

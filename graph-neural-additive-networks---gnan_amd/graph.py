@@ -35,6 +35,7 @@ HOT_COLUMNS_MIN_NNZ = 1 << 24    # below this the two extra launches that fill t
 HOT_COLUMNS_MIN_SHARE = 0.15     # ... and so does a graph whose K most listed neighbours receive less than this share of the pairs
 
 
+LONG_PLAN_IN_HIP = True     # HopGraph.long_row_plan() by gnan_long_row_plan_count / _fill
 TRANSPOSE_IN_HIP = True     # HopGraph.transposed() by gnan_csr_transpose
 PB_PLAN_IN_HIP = True       # the pair-level work of HopGraph.pb_plan by gnan_pb_plan_* (False: framework ops; CPU tensors always)
 SORTED_COPY_IN_HIP = True   # the degree-sorted copy by gnan_degree_sorted_csr (False: the framework ops below; CPU tensors always)
@@ -251,6 +252,37 @@ class HopGraph:
                 return self._plan
             if threshold in self._plans:
                 return self._plans[threshold]
+        if row_ids is None and LONG_PLAN_IN_HIP and self.rowptr.is_cuda and 0 < self.n_rows < 2 ** 31:
+            plan = self._long_row_plan_hip(threshold)
+        else:
+            plan = self._long_row_plan_torch(row_ids, threshold)
+        if row_ids is None:
+            if threshold == LONG_ROW_THRESHOLD:
+                self._plan = plan
+            else:
+                self._plans[threshold] = plan
+        return plan
+
+    def _long_row_plan_hip(self, threshold: int) -> LongRowPlan:
+        """gnan_long_row_plan_count / _fill (csrc/graph_build.hip): the same arrays as the framework route below."""
+        L, dev = _lib.lib(), self.device
+        need = L.gnan_long_row_plan_workspace_bytes(self.n_rows)
+        ws = torch.empty((need + 255) // 256 * 64, dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        is64 = int(self.rowptr.dtype == torch.int64)
+        st = _lib.stream_of(self.rowptr)
+        _lib.check(L.gnan_long_row_plan_count(_lib.ptr(self.rowptr), is64, self.n_rows, threshold, _lib.ptr(ws), ws.numel() * 4,
+                                              _lib.ptr(total), st), "gnan_long_row_plan_count")
+        n_long = int(total.item())
+        if n_long == 0:
+            return LongRowPlan(None, None, threshold=threshold)
+        rows = torch.empty(n_long, dtype=torch.int32, device=dev)
+        ptr = torch.empty(n_long + 1, dtype=torch.int32, device=dev)
+        _lib.check(L.gnan_long_row_plan_fill(_lib.ptr(self.rowptr), is64, self.n_rows, threshold, SLICE_EDGES, n_long, _lib.ptr(ws),
+                                             ws.numel() * 4, _lib.ptr(rows), _lib.ptr(ptr), st), "gnan_long_row_plan_fill")
+        return LongRowPlan(rows, ptr, n_long, int(ptr[-1].item()), threshold=threshold)
+
+    def _long_row_plan_torch(self, row_ids, threshold: int) -> LongRowPlan:
         deg = (self.rowptr[1:] - self.rowptr[:-1])
         if row_ids is not None:
             deg = deg[row_ids.long()]
@@ -263,11 +295,6 @@ class HopGraph:
             ptr = torch.zeros(n_long + 1, dtype=torch.int64, device=self.device)
             ptr[1:] = torch.cumsum(n_sl, 0)
             plan = LongRowPlan(long_rows.to(torch.int32), ptr.to(torch.int32), n_long, int(ptr[-1]), threshold=threshold)
-        if row_ids is None:
-            if threshold == LONG_ROW_THRESHOLD:
-                self._plan = plan
-            else:
-                self._plans[threshold] = plan
         return plan
 
     def narrow_row_plan(self) -> LongRowPlan:

@@ -522,6 +522,17 @@ typedef struct gnan_sorted_csr_args {
 size_t gnan_degree_sorted_csr_workspace_bytes(int64_t n_rows);
 int gnan_degree_sorted_csr(const gnan_sorted_csr_args* a, gnan_stream_t stream);
 
+/* The hub-row plan of gnan_spmm_fwd (long_rows / long_slice_ptr of gnan_spmm_args; gnan_amd.graph.HopGraph.long_row_plan): the rows
+ * with more than `threshold` pairs in ascending order and the prefix sums of their slice counts ceil(pairs / slice_edges).  Two calls
+ * around ONE read-back: _count leaves the number of hub rows in total[0] (device memory), the caller sizes long_rows [n_long] and
+ * slice_ptr [n_long + 1] and calls _fill with the SAME workspace (gnan_long_row_plan_workspace_bytes(n_rows), 256-byte aligned).
+ * Index work only, bit-exact. */
+size_t gnan_long_row_plan_workspace_bytes(int64_t n_rows);
+int gnan_long_row_plan_count(const void* rowptr, int32_t rowptr_is64, int64_t n_rows, int64_t threshold, void* workspace,
+                             size_t workspace_bytes, int32_t* total, gnan_stream_t stream);
+int gnan_long_row_plan_fill(const void* rowptr, int32_t rowptr_is64, int64_t n_rows, int64_t threshold, int64_t slice_edges, int64_t n_long,
+                            void* workspace, size_t workspace_bytes, int32_t* long_rows, int32_t* slice_ptr, gnan_stream_t stream);
+
 /* The transposed adjacency of a hop-coded CSR (gnan_amd.graph.HopGraph.transposed: what the backward walks): row j of the result
  * lists the rows i that list neighbour j, in ascending i (a stable sort of the pairs by column id), with the pairs' hop codes;
  * rowptr_t has the width of rowptr.  long_rows: the rows with more than gnan_pb_plan_long_row_threshold() pairs.  Bit-exact.

@@ -182,9 +182,10 @@ def test_full_size_pre_rho_normalisation(c4, monkeypatch):
             times[name] = (time.perf_counter() - t0) / 10
             if name == "pre":
                 y = out
-    # measured: within 5 % of each other.  The assertion guards the route, not the last per cent (a torch MLP on N x D rows
-    # would be tens of milliseconds): generous enough for a noisy shared box
-    assert times["pre"] <= 1.25 * times["post"] + 5e-4, times
+    # The assertion guards the route, not the last per cent (a torch MLP on N x D rows would be tens of milliseconds).  Since round 6
+    # the post-rho forward takes the propagation-blocked aggregation (1.0 ms) and the per-row table of the pre-rho class keeps the
+    # row-parallel kernels (1.8-1.9 ms): generous enough for that and for a noisy shared box
+    assert times["pre"] <= 2.5 * times["post"] + 5e-4, times
     m = mods["pre"]
     p64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
     rng = np.random.default_rng(0)

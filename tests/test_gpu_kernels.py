@@ -2490,3 +2490,20 @@ def test_arrival_counters_stress(n, monkeypatch):
         _, q0 = pack_bwd_rows(dY, cnt, 3, True, 1, want_q_sum=True)
         bad += int(not torch.equal(q0, q1))
     assert bad == 0, bad
+
+
+@pytest.mark.parametrize("idx_dtype,n,hubs,thr", [(torch.int64, 5000, [(3, 900), (4000, 4000), (4999, 600)], 512),
+                                                   (torch.int32, 70_000, [(5, 200_000), (69_999, 129)], 64), (torch.int32, 300, [], 512)])
+def test_hub_row_plan_by_the_library_equals_the_framework_route(idx_dtype, n, hubs, thr, monkeypatch):
+    """gnan_long_row_plan_count / _fill == the torch route (nonzero + cumsum), array by array."""
+    from gnan_amd import graph as G
+    rng = np.random.default_rng(n + thr)
+    rowptr, col, code = _random_csr(n, n, 1, rng, hubs=hubs)
+    plans = []
+    for hip in (True, False):
+        monkeypatch.setattr(G, "LONG_PLAN_IN_HIP", hip)
+        plans.append(_graph(rowptr, col, code, n, 3, idx_dtype=idx_dtype).long_row_plan(None, thr))
+    a, b = plans
+    assert (a.n_long, a.n_slices, a.threshold) == (b.n_long, b.n_slices, b.threshold) and a.n_long == sum(1 for _, d in hubs if d > thr)
+    if a.n_long:
+        assert a.rows.dtype == b.rows.dtype == torch.int32 and torch.equal(a.rows, b.rows) and torch.equal(a.slice_ptr, b.slice_ptr)
